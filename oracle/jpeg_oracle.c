@@ -1,0 +1,692 @@
+/*
+ * jpeg_oracle.c -- plain-C restatement of the thorfdbg/libjpeg block-decode path
+ * (Huffman sequential scan -> dequant + 8x8 IDCT -> centred chroma upsampling -> YCbCr->RGB).
+ *
+ * TEST INFRASTRUCTURE ONLY (see jpeg_oracle.h).  Written to be read next to the reference:
+ * it favours literal emulation of the reference's buffer manipulations (including the in-place
+ * aliasing of the horizontal upsampling filter) over speed.  Scalar, single-threaded.
+ *
+ * Parity status: PINNED against the reference binary (tests/test_oracle.py, tests/golden/).
+ */
+#include "jpeg_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Zig-zag scan order: position k of the scan -> natural index x + 8y.
+ * Restates dct/dct.cpp:57-74 (DCT::ScanOrder), regenerated here by walking the diagonals.
+ * ---------------------------------------------------------------------------------------- */
+static int g_scan_order[64];
+static int g_scan_order_ready = 0;
+
+static void build_scan_order(void)
+{
+  int k = 0, d, i;
+  for (d = 0; d < 15; d++) {
+    /* diagonal d holds the positions with x + y == d; even diagonals run bottom-left -> top-right */
+    for (i = 0; i <= d; i++) {
+      int x = (d & 1) ? (d - i) : i;
+      int y = d - x;
+      if (x < 8 && y < 8) {
+        /* the walk direction alternates: odd diagonals go from (d,0) down-left, even ones up-right */
+        g_scan_order[k++] = x + (y << 3);
+      }
+    }
+  }
+  g_scan_order_ready = 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Header parsing (marker/frame.cpp:111-..., marker/scan.cpp:163-..., marker/quantization.cpp:474-537,
+ * coding/huffmantemplate.cpp:878-905, codestream/tables.cpp:1003-...).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int defined;
+  uint8_t counts[16];
+  uint8_t values[256];
+  int nvalues;
+  /* canonical decode tables, T.81 F.2.2.3 (equivalent to the two-level LUT the reference builds
+   * in coding/huffmantemplate.cpp:802-874) */
+  int32_t mincode[17], maxcode[18], valptr[17];
+} oj_huff;
+
+typedef struct {
+  const uint8_t *data;
+  size_t len;
+  oj_info *info;
+  oj_huff dc[4], ac[4];
+  int restart_interval;
+  int have_frame;
+} oj_parser;
+
+static int rd16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
+
+static void huff_build(oj_huff *h)
+{
+  int l, code = 0, k = 0;
+  for (l = 1; l <= 16; l++) {
+    h->valptr[l] = k;
+    h->mincode[l] = code;
+    code += h->counts[l - 1];
+    k += h->counts[l - 1];
+    h->maxcode[l] = h->counts[l - 1] ? code - 1 : -1;
+    code <<= 1;
+  }
+  h->maxcode[17] = 0x7fffffff;
+}
+
+static int parse_dqt(oj_parser *ps, const uint8_t *p, int n)
+{
+  /* marker/quantization.cpp:474-537: Pq/Tq byte, then 64 entries in zig-zag order, stored
+   * de-zigzagged (:502-527). */
+  while (n > 0) {
+    int pq = p[0] >> 4, tq = p[0] & 15, i;
+    if (tq > 3 || pq > 1) return OJ_ERR_MALFORMED;
+    if (n < 1 + 64 * (pq + 1)) return OJ_ERR_MALFORMED;
+    for (i = 0; i < 64; i++) {
+      int v = pq ? rd16(p + 1 + 2 * i) : p[1 + i];
+      ps->info->quant[tq][g_scan_order[i]] = (uint16_t)v;
+    }
+    ps->info->quant_defined[tq] = 1;
+    p += 1 + 64 * (pq + 1);
+    n -= 1 + 64 * (pq + 1);
+  }
+  return OJ_OK;
+}
+
+static int parse_dht(oj_parser *ps, const uint8_t *p, int n)
+{
+  while (n > 0) {
+    int tc = p[0] >> 4, th = p[0] & 15, i, total = 0;
+    oj_huff *h;
+    if (tc > 1 || th > 3 || n < 17) return OJ_ERR_MALFORMED;
+    h = tc ? &ps->ac[th] : &ps->dc[th];
+    for (i = 0; i < 16; i++) { h->counts[i] = p[1 + i]; total += p[1 + i]; }
+    if (total > 256 || n < 17 + total) return OJ_ERR_MALFORMED;
+    memcpy(h->values, p + 17, (size_t)total);
+    h->nvalues = total;
+    h->defined = 1;
+    huff_build(h);
+    p += 17 + total;
+    n -= 17 + total;
+  }
+  return OJ_OK;
+}
+
+static int parse_sof(oj_parser *ps, const uint8_t *p, int n)
+{
+  oj_info *f = ps->info;
+  int c;
+  if (n < 6) return OJ_ERR_MALFORMED;
+  f->precision = p[0];
+  f->height = rd16(p + 1);
+  f->width = rd16(p + 3);
+  f->ncomp = p[5];
+  if (f->precision != 8) return OJ_ERR_UNSUPPORTED;
+  if (f->ncomp < 1 || f->ncomp > OJ_MAX_COMP || n < 6 + 3 * f->ncomp) return OJ_ERR_MALFORMED;
+  if (f->width == 0 || f->height == 0) return OJ_ERR_UNSUPPORTED; /* DNL-defined height */
+  f->hmax = f->vmax = 1;
+  for (c = 0; c < f->ncomp; c++) {
+    f->comp_id[c] = p[6 + 3 * c];
+    f->hs[c] = p[7 + 3 * c] >> 4;
+    f->vs[c] = p[7 + 3 * c] & 15;
+    f->tq[c] = p[8 + 3 * c];
+    if (f->hs[c] < 1 || f->hs[c] > 4 || f->vs[c] < 1 || f->vs[c] > 4 || f->tq[c] > 3)
+      return OJ_ERR_MALFORMED;
+    if (f->hs[c] > f->hmax) f->hmax = f->hs[c];
+    if (f->vs[c] > f->vmax) f->vmax = f->vs[c];
+  }
+  f->mcus_x = (f->width + 8 * f->hmax - 1) / (8 * f->hmax);
+  f->mcus_y = (f->height + 8 * f->vmax - 1) / (8 * f->vmax);
+  for (c = 0; c < f->ncomp; c++) {
+    /* marker/component.cpp: subsampling = max / own; must divide evenly */
+    if (f->hmax % f->hs[c] || f->vmax % f->vs[c]) return OJ_ERR_UNSUPPORTED;
+    f->subx[c] = f->hmax / f->hs[c];
+    f->suby[c] = f->vmax / f->vs[c];
+    f->bw[c] = f->mcus_x * f->hs[c];
+    f->bh[c] = f->mcus_y * f->vs[c];
+    f->cw[c] = (f->width + f->subx[c] - 1) / f->subx[c];
+    f->ch[c] = (f->height + f->suby[c] - 1) / f->suby[c];
+  }
+  ps->have_frame = 1;
+  return OJ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Bit reader: io/bitstream.cpp:56-118 (byte-stuffing flavour) + io/bitstream.hpp:106-210.
+ * FF 00 -> FF; any other FF xx is a marker: the reader stays in front of it and hands out
+ * zero bits from then on.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t *p, *end;
+  uint32_t acc; /* MSB-first window */
+  int nbits;
+  int marker; /* sitting at a marker / end of data */
+} oj_bits;
+
+static void bits_init(oj_bits *b, const uint8_t *p, const uint8_t *end)
+{
+  b->p = p; b->end = end; b->acc = 0; b->nbits = 0; b->marker = 0;
+}
+
+static void bits_fill(oj_bits *b)
+{
+  while (b->nbits <= 24) {
+    uint32_t c = 0;
+    if (!b->marker) {
+      if (b->p >= b->end) {
+        b->marker = 1;
+      } else if (b->p[0] == 0xff) {
+        if (b->p + 1 < b->end && b->p[1] == 0x00) { c = 0xff; b->p += 2; }
+        else b->marker = 1;
+      } else {
+        c = *b->p++;
+      }
+    }
+    b->acc |= c << (24 - b->nbits);
+    b->nbits += 8;
+  }
+}
+
+static uint32_t bits_get(oj_bits *b, int n)
+{
+  uint32_t v;
+  if (n == 0) return 0;
+  if (b->nbits < n) bits_fill(b);
+  v = b->acc >> (32 - n);
+  b->acc <<= n;
+  b->nbits -= n;
+  return v;
+}
+
+/* coding/huffmandecoder.hpp:103-124 in its T.81 F.2.2.3 form. Returns -1 for an unassigned code. */
+static int huff_get(oj_bits *b, const oj_huff *h)
+{
+  int32_t code = 0;
+  int l;
+  for (l = 1; l <= 16; l++) {
+    code = (code << 1) | (int32_t)bits_get(b, 1);
+    if (h->maxcode[l] >= 0 && code <= h->maxcode[l] && code >= h->mincode[l])
+      return h->values[h->valptr[l] + (code - h->mincode[l])];
+  }
+  return -1;
+}
+
+/* codestream/sequentialscan.cpp:678-773 for ScanStart=0, ScanStop=63, lowbit=0, non-residual,
+ * non-progressive. */
+static int decode_block(oj_bits *b, const oj_huff *dc, const oj_huff *ac, int32_t *prevdc,
+                        int32_t *block)
+{
+  int s = huff_get(b, dc), k;
+  int32_t diff = 0;
+  if (s < 0) return OJ_ERR_MALFORMED;
+  if (s > 0) {
+    if (s > 15) return OJ_ERR_MALFORMED; /* :686-688 */
+    diff = (int32_t)bits_get(b, s);
+    if (diff < (1 << (s - 1))) diff += (int32_t)((-1L) * (1L << s)) + 1; /* :690-692 */
+  }
+  *prevdc += diff;
+  block[0] = *prevdc;
+  k = 1;
+  do {
+    int rs = huff_get(b, ac), r, ss;
+    if (rs < 0) return OJ_ERR_MALFORMED;
+    r = rs >> 4; ss = rs & 15;
+    if (ss == 0) {
+      if (r == 15) { k += 16; continue; } /* ZRL, :713-715 */
+      if (r == 0) break;                  /* EOB, :718-722 */
+      return OJ_ERR_MALFORMED;            /* :747-750 (EOB runs exist only in progressive mode) */
+    }
+    k += r;
+    diff = (int32_t)bits_get(b, ss);
+    if (diff < (1 << (ss - 1))) diff += (int32_t)((-1L) * (1L << ss)) + 1;
+    if (k >= 64) return OJ_ERR_MALFORMED; /* :763-765 */
+    block[g_scan_order[k]] = diff;
+    k++;
+  } while (k <= 63);
+  return OJ_OK;
+}
+
+/* One scan: codestream/sequentialscan.cpp:381-428 (ParseMCU) driven row by row, restart handling as
+ * in codestream/entropyparser.hpp:147-160 / entropyparser.cpp:117-135 (happy path only: a missing or
+ * wrong RSTn is reported as OJ_ERR_MALFORMED instead of being resynchronised). */
+static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *ecs,
+                       const uint8_t *end, int32_t *const planes[OJ_MAX_COMP],
+                       const uint8_t **next)
+{
+  const oj_info *f = ps->info;
+  int ns = sos[0], ci[OJ_MAX_COMP], td[OJ_MAX_COMP], ta[OJ_MAX_COMP], i, c;
+  int32_t pred[OJ_MAX_COMP] = {0, 0, 0, 0};
+  int mx, my, mcus_x, mcus_y, togo, rstn = 0;
+  oj_bits b;
+  if (ns < 1 || ns > f->ncomp || n < 1 + 2 * ns + 3) return OJ_ERR_MALFORMED;
+  for (i = 0; i < ns; i++) {
+    int id = sos[1 + 2 * i];
+    for (c = 0; c < f->ncomp; c++) if (f->comp_id[c] == id) break;
+    if (c == f->ncomp) return OJ_ERR_MALFORMED;
+    ci[i] = c; td[i] = sos[2 + 2 * i] >> 4; ta[i] = sos[2 + 2 * i] & 15;
+    if (td[i] > 3 || ta[i] > 3 || !ps->dc[td[i]].defined || !ps->ac[ta[i]].defined)
+      return OJ_ERR_MALFORMED;
+  }
+  if (sos[1 + 2 * ns] != 0 || sos[2 + 2 * ns] != 63 || sos[3 + 2 * ns] != 0)
+    return OJ_ERR_UNSUPPORTED; /* spectral selection / successive approximation */
+  if (ns > 1) { mcus_x = f->mcus_x; mcus_y = f->mcus_y; }
+  else {
+    /* single-component scan: 1x1 MCUs over ceil(cw/8) x ceil(ch/8) blocks
+     * (sequentialscan.cpp:396-397; marker/component.cpp) */
+    mcus_x = (f->cw[ci[0]] + 7) >> 3; mcus_y = (f->ch[ci[0]] + 7) >> 3;
+  }
+  bits_init(&b, ecs, end);
+  togo = ps->restart_interval;
+  for (my = 0; my < mcus_y; my++) {
+    for (mx = 0; mx < mcus_x; mx++) {
+      if (ps->restart_interval) {
+        if (togo == 0) {
+          /* entropyparser.cpp:117-135: skip FF fillers, require RSTn, reset predictors and the bit
+           * buffer (sequentialscan.cpp:266-274) */
+          const uint8_t *p = b.p;
+          while (p + 1 < end && p[0] == 0xff && p[1] == 0xff) p++;
+          if (p + 1 >= end || p[0] != 0xff || p[1] != 0xd0 + rstn) return OJ_ERR_MALFORMED;
+          rstn = (rstn + 1) & 7;
+          bits_init(&b, p + 2, end);
+          for (i = 0; i < OJ_MAX_COMP; i++) pred[i] = 0;
+          togo = ps->restart_interval;
+        }
+        togo--;
+      }
+      for (i = 0; i < ns; i++) {
+        int bx, by, w = (ns > 1) ? f->hs[ci[i]] : 1, h = (ns > 1) ? f->vs[ci[i]] : 1;
+        c = ci[i];
+        for (by = 0; by < h; by++)
+          for (bx = 0; bx < w; bx++) {
+            int32_t dummy[64];
+            int X = mx * w + bx, Y = my * h + by, rc;
+            int32_t *blk = (X < f->bw[c] && Y < f->bh[c]) ? planes[c] + ((size_t)Y * f->bw[c] + X) * 64
+                                                          : dummy;
+            rc = decode_block(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk);
+            if (rc) return rc;
+          }
+      }
+    }
+  }
+  /* advance to the next marker */
+  {
+    const uint8_t *p = b.p;
+    while (p + 1 < end && !(p[0] == 0xff && p[1] != 0x00 && p[1] != 0xff)) p++;
+    *next = p;
+  }
+  return OJ_OK;
+}
+
+static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
+{
+  const uint8_t *p = ps->data, *end = ps->data + ps->len;
+  oj_info *f = ps->info;
+  int rc;
+  if (!g_scan_order_ready) build_scan_order();
+  if (ps->len < 4 || p[0] != 0xff || p[1] != 0xd8) return OJ_ERR_MALFORMED;
+  p += 2;
+  f->adobe_transform = -1;
+  for (;;) {
+    int m, n;
+    if (p + 2 > end) return OJ_ERR_EOF;
+    if (p[0] != 0xff) return OJ_ERR_MALFORMED;
+    while (p + 1 < end && p[1] == 0xff) p++; /* fill bytes */
+    m = p[1];
+    p += 2;
+    if (m == 0xd9) break; /* EOI */
+    if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
+    if (p + 2 > end) return OJ_ERR_EOF;
+    n = rd16(p);
+    if (n < 2 || p + n > end) return OJ_ERR_EOF;
+    switch (m) {
+    case 0xdb: rc = parse_dqt(ps, p + 2, n - 2); if (rc) return rc; break;
+    case 0xc4: rc = parse_dht(ps, p + 2, n - 2); if (rc) return rc; break;
+    case 0xdd: if (n < 4) return OJ_ERR_MALFORMED; ps->restart_interval = rd16(p + 2); break;
+    case 0xc0: case 0xc1:
+      if (ps->have_frame) return OJ_ERR_MALFORMED;
+      rc = parse_sof(ps, p + 2, n - 2); if (rc) return rc; break;
+    case 0xc2: case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb:
+    case 0xcd: case 0xce: case 0xcf:
+      return OJ_ERR_UNSUPPORTED;
+    case 0xee: /* APP14 Adobe: marker/adobemarker.cpp; "Adobe" + version(2) flags0(2) flags1(2) transform(1) */
+      if (n >= 14 && memcmp(p + 2, "Adobe", 5) == 0) f->adobe_transform = p[13];
+      break;
+    case 0xda: {
+      const uint8_t *next = NULL;
+      if (!ps->have_frame) return OJ_ERR_MALFORMED;
+      f->restart_interval = ps->restart_interval;
+      if (!planes) goto done; /* header-only walk stops at the first scan */
+      rc = decode_scan(ps, p + 2, n - 2, p + n, end, planes, &next);
+      if (rc) return rc;
+      p = next;
+      continue;
+    }
+    default: break; /* APPn, COM, ...: skipped */
+    }
+    p += n;
+  }
+done:
+  if (!ps->have_frame) return OJ_ERR_MALFORMED;
+  /* codestream/tables.cpp:2021-2030: three components and no Adobe "None" -> YCbCr, else identity */
+  f->ycbcr = (f->ncomp == 3 && f->adobe_transform != 0) ? 1 : 0;
+  return OJ_OK;
+}
+
+int oj_read_info(const uint8_t *data, size_t len, oj_info *info)
+{
+  oj_parser ps;
+  memset(&ps, 0, sizeof(ps));
+  memset(info, 0, sizeof(*info));
+  ps.data = data; ps.len = len; ps.info = info;
+  return walk(&ps, NULL);
+}
+
+int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
+                           int32_t *const planes[OJ_MAX_COMP])
+{
+  oj_parser ps;
+  oj_info tmp;
+  int c;
+  memset(&ps, 0, sizeof(ps));
+  memset(&tmp, 0, sizeof(tmp));
+  ps.data = data; ps.len = len; ps.info = &tmp;
+  for (c = 0; c < info->ncomp; c++)
+    memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
+  return walk(&ps, planes);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Dequantisation + inverse DCT: dct/idct.cpp:226-339 (IDCT<4,LONG,false,false>), constants
+ * dct/idct.hpp:70-77 (FIX_BITS = 9, INTERMEDIATE_BITS = 0) and idct.cpp:65-78 (TO_FIX).
+ * All arithmetic wraps modulo 2^32 like the reference's LONG does on this platform; the
+ * rounding additions are carried out in 64 bits because the reference adds `1L << n` (a 64-bit
+ * long on LP64) before shifting.
+ * ---------------------------------------------------------------------------------------- */
+#define FIX9(x) ((int32_t)((x) * 512.0 + 0.5))
+static int32_t w32(int64_t v) { return (int32_t)(uint32_t)(uint64_t)v; }
+static int32_t mul32(int32_t a, int32_t b) { return w32((int64_t)a * (int64_t)b); }
+static int32_t add32(int32_t a, int32_t b) { return w32((int64_t)a + (int64_t)b); }
+static int32_t sub32(int32_t a, int32_t b) { return w32((int64_t)a - (int64_t)b); }
+static int32_t shl32(int32_t a, int n) { return w32((int64_t)((uint64_t)(int64_t)a << n)); }
+
+static void idct_1d(const int32_t s[8], int32_t o[8])
+{
+  /* even part */
+  int32_t z1 = mul32(add32(s[2], s[6]), FIX9(0.541196100));
+  int32_t tmp2 = add32(z1, mul32(s[6], -FIX9(1.847759065)));
+  int32_t tmp3 = add32(z1, mul32(s[2], FIX9(0.765366865)));
+  int32_t tmp0 = shl32(add32(s[0], s[4]), 9);
+  int32_t tmp1 = shl32(sub32(s[0], s[4]), 9);
+  int32_t tmp10 = add32(tmp0, tmp3), tmp13 = sub32(tmp0, tmp3);
+  int32_t tmp11 = add32(tmp1, tmp2), tmp12 = sub32(tmp1, tmp2);
+  /* odd part */
+  int32_t t0 = s[7], t1 = s[5], t2 = s[3], t3 = s[1];
+  int32_t tz1 = add32(t0, t3), tz2 = add32(t1, t2), tz3 = add32(t0, t2), tz4 = add32(t1, t3);
+  int32_t z5 = mul32(add32(tz3, tz4), FIX9(1.175875602));
+  int32_t z2, z3, z4;
+  tmp0 = mul32(t0, FIX9(0.298631336));
+  tmp1 = mul32(t1, FIX9(2.053119869));
+  tmp2 = mul32(t2, FIX9(3.072711026));
+  tmp3 = mul32(t3, FIX9(1.501321110));
+  z1 = mul32(tz1, -FIX9(0.899976223));
+  z2 = mul32(tz2, -FIX9(2.562915447));
+  z3 = add32(mul32(tz3, -FIX9(1.961570560)), z5);
+  z4 = add32(mul32(tz4, -FIX9(0.390180644)), z5);
+  tmp0 = add32(tmp0, add32(z1, z3));
+  tmp1 = add32(tmp1, add32(z2, z4));
+  tmp2 = add32(tmp2, add32(z2, z3));
+  tmp3 = add32(tmp3, add32(z1, z4));
+  o[0] = add32(tmp10, tmp3); o[7] = sub32(tmp10, tmp3);
+  o[1] = add32(tmp11, tmp2); o[6] = sub32(tmp11, tmp2);
+  o[2] = add32(tmp12, tmp1); o[5] = sub32(tmp12, tmp1);
+  o[3] = add32(tmp13, tmp0); o[4] = sub32(tmp13, tmp0);
+}
+
+void oj_idct_block(int32_t out[64], const int32_t coef[64], const uint16_t quant[64], int precision)
+{
+  int32_t tmp[64];
+  int r, c, k;
+  int32_t dcoffset;
+  if (!coef) { memset(out, 0, 64 * sizeof(int32_t)); return; }
+  /* caller passes dcoffset = 1 << (P-1) (blockbitmaprequester.cpp:1048); shifted by preshift + 3 */
+  dcoffset = (int32_t)(1L << (precision - 1)) << (4 + 3);
+  for (r = 0; r < 8; r++) {
+    int32_t s[8], o[8];
+    for (k = 0; k < 8; k++) s[k] = mul32(coef[r * 8 + k], (int32_t)quant[r * 8 + k] << 4);
+    if (r == 0) s[0] = add32(s[0], dcoffset);
+    idct_1d(s, o);
+    for (k = 0; k < 8; k++) tmp[r * 8 + k] = w32(((int64_t)o[k] + 256) >> 9);
+  }
+  for (c = 0; c < 8; c++) {
+    int32_t s[8], o[8];
+    for (k = 0; k < 8; k++) s[k] = tmp[k * 8 + c];
+    idct_1d(s, o);
+    for (k = 0; k < 8; k++) out[k * 8 + c] = w32(((int64_t)o[k] + 2048) >> 12);
+  }
+}
+
+void oj_idct_plane(int32_t *samples, const int32_t *coef, int bw, int bh, const uint16_t quant[64],
+                   int precision)
+{
+  int bx, by, y;
+  for (by = 0; by < bh; by++)
+    for (bx = 0; bx < bw; bx++) {
+      int32_t o[64];
+      oj_idct_block(o, coef + ((size_t)by * bw + bx) * 64, quant, precision);
+      for (y = 0; y < 8; y++)
+        memcpy(samples + ((size_t)(by * 8 + y) * bw + bx) * 8, o + y * 8, 8 * sizeof(int32_t));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Upsampling: upsampling/upsampler.cpp.  The 8x8 buffer is filled by the vertical core from
+ * three line pointers and then filtered IN PLACE by the horizontal core, exactly like the
+ * reference, so its aliasing behaviour (a freshly written output feeding a later one) is kept.
+ * ---------------------------------------------------------------------------------------- */
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* value at line `row`, line-buffer index `idx` (reference: line->m_pData[idx], data starts at +1,
+ * m_pData[0] = sample 0 and m_pData[cw+1] = sample cw-1: upsamplerbase.cpp:322-323) */
+static int32_t line_at(const int32_t *plane, int pitch, int cw, int row, int idx)
+{
+  return plane[(size_t)row * pitch + clampi(idx - 1, 0, cw - 1)];
+}
+
+void oj_upsample_block(int32_t out[64], const int32_t *plane, int pitch, int cw, int ch, int sx,
+                       int sy, int X0, int Y0)
+{
+  /* upsampler.cpp:83-117 */
+  int y = Y0 / sy, x = X0 / sx + 1, l, j;
+  int top = y > 0 ? y - 1 : 0, cur = y, bot;
+  int ymod = Y0 % sy, xmod = X0 % sx;
+  int32_t *target = out;
+  if (cur > ch - 1) cur = ch - 1; /* blocks entirely below the last stored line are never output */
+  if (top > ch - 1) top = ch - 1;
+  bot = cur + 1 < ch ? cur + 1 : cur;
+  if (sx > 1) x--;
+#define T(j) line_at(plane, pitch, cw, top, x + (j))
+#define C(j) line_at(plane, pitch, cw, cur, x + (j))
+#define B(j) line_at(plane, pitch, cw, bot, x + (j))
+#define ADVANCE() do { top = cur; cur = bot; if (bot + 1 < ch) bot++; } while (0)
+  for (l = 0; l < 8; l++, target += 8) {
+    switch (sy) {
+    case 1: /* :118-131 */
+      for (j = 0; j < 8; j++) target[j] = C(j);
+      if (cur + 1 < ch) cur++;
+      break;
+    case 2: /* :136-168 */
+      if (ymod == 0) {
+        for (j = 0; j < 8; j++) target[j] = w32((int64_t)T(j) + 3 * (int64_t)C(j) + ((j & 1) ? 1 : 2)) >> 2;
+        ymod = 1;
+      } else {
+        for (j = 0; j < 8; j++) target[j] = w32((int64_t)B(j) + 3 * (int64_t)C(j) + ((j & 1) ? 2 : 1)) >> 2;
+        ymod = 0; ADVANCE();
+      }
+      break;
+    case 3: /* :174-215 */
+      if (ymod == 0) {
+        for (j = 0; j < 8; j++) target[j] = w32((int64_t)T(j) + 3 * (int64_t)C(j) + ((j & 1) ? 1 : 2)) >> 2;
+        ymod = 1;
+      } else if (ymod == 1) {
+        for (j = 0; j < 8; j++) target[j] = C(j);
+        ymod = 2;
+      } else {
+        for (j = 0; j < 8; j++) target[j] = w32((int64_t)B(j) + 3 * (int64_t)C(j) + ((j & 1) ? 2 : 1)) >> 2;
+        ymod = 0; ADVANCE();
+      }
+      break;
+    case 4: /* :221-271 */
+      if (ymod == 0) {
+        for (j = 0; j < 8; j++) target[j] = w32(3 * (int64_t)T(j) + 5 * (int64_t)C(j) + ((j & 1) ? 3 : 4)) >> 3;
+        ymod = 1;
+      } else if (ymod == 1) {
+        for (j = 0; j < 8; j++) target[j] = w32((int64_t)T(j) + 7 * (int64_t)C(j) + ((j & 1) ? 4 : 3)) >> 3;
+        ymod = 2;
+      } else if (ymod == 2) {
+        for (j = 0; j < 8; j++) target[j] = w32((int64_t)B(j) + 7 * (int64_t)C(j) + ((j & 1) ? 3 : 4)) >> 3;
+        ymod = 3;
+      } else {
+        for (j = 0; j < 8; j++) target[j] = w32(3 * (int64_t)B(j) + 5 * (int64_t)C(j) + ((j & 1) ? 3 : 4)) >> 3;
+        ymod = 0; ADVANCE();
+      }
+      break;
+    }
+  }
+#undef T
+#undef C
+#undef B
+#undef ADVANCE
+  /* horizontal, in place on each buffer line; src = target + 1 */
+#define F2(a, b, r) (w32((int64_t)(a) + 3 * (int64_t)(b) + (r)) >> 2)
+#define F8(wa, a, wb, b, r) (w32((wa) * (int64_t)(a) + (wb) * (int64_t)(b) + (r)) >> 3)
+  for (l = 0, target = out; l < 8; l++, target += 8) {
+    int32_t *src = target + 1, *o = target, t;
+    switch (sx) {
+    case 1: break;
+    case 2: /* :283-307 */
+      o[7] = F2(src[4], src[3], 1);
+      o[6] = F2(src[2], src[3], 2);
+      o[5] = F2(src[3], src[2], 1);
+      o[4] = F2(src[1], src[2], 2);
+      o[3] = F2(src[2], src[1], 1);
+      o[2] = F2(src[0], src[1], 2); t = src[0];
+      o[1] = F2(src[1], t, 1); /* src[1] is o[2] by now */
+      o[0] = F2(src[-1], t, 2);
+      break;
+    case 3: /* :313-361 */
+      if (xmod == 0) {
+        o[7] = src[2];
+        o[6] = F2(src[1], src[2], 2);
+        o[5] = F2(src[2], src[1], 1);
+        o[4] = src[1];
+        o[3] = F2(src[0], src[1], 2);
+        o[2] = F2(src[1], src[0], 1);
+        o[0] = F2(src[-1], src[0], 2);
+        o[1] = src[0];
+      } else if (xmod == 1) {
+        o[7] = F2(src[3], src[2], 1);
+        o[6] = src[2];
+        o[5] = F2(src[1], src[2], 2);
+        o[4] = F2(src[2], src[1], 1);
+        o[3] = src[1]; t = src[0];
+        o[2] = F2(t, src[1], 2);
+        o[1] = F2(src[1], t, 1);
+        o[0] = t;
+      } else {
+        o[7] = F2(src[2], src[3], 2);
+        o[6] = F2(src[3], src[2], 1);
+        o[5] = src[2];
+        o[4] = F2(src[1], src[2], 2);
+        o[3] = F2(src[2], src[1], 1);
+        o[2] = src[1]; t = src[0];
+        o[1] = F2(t, src[1], 2);
+        o[0] = F2(src[1], t, 1);
+      }
+      break;
+    case 4: /* :367-387 */
+      o[7] = F8(3, src[2], 5, src[1], 1);
+      o[6] = F8(1, src[2], 7, src[1], 2);
+      o[5] = F8(1, src[0], 7, src[1], 1);
+      o[4] = F8(3, src[0], 5, src[1], 2); t = src[0];
+      o[3] = F8(3, src[1], 5, t, 1);
+      o[2] = F8(1, src[1], 7, t, 2);
+      o[1] = F8(1, src[-1], 7, t, 1);
+      o[0] = F8(3, src[-1], 5, t, 2);
+      break;
+    }
+  }
+#undef F2
+#undef F8
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Colour transformation + clamp + store: colortrafo/ycbcrtrafo.cpp:842-850 (YCbCr), :852-856
+ * (identity), :921-936 (clamp), tools/numerics.hpp:57-71 (FIX_BITS = 13, COLOR_BITS = 4),
+ * colortrafo/colortransformerfactory.cpp:136-138 (matrix).
+ * ---------------------------------------------------------------------------------------- */
+#define FIX13(x) ((int64_t)((x) * 8192.0 + 0.5))
+static uint8_t clamp8(int64_t v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+int oj_reconstruct(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint8_t *pixels, int use_ycbcr)
+{
+  int32_t *samp[OJ_MAX_COMP] = {0, 0, 0, 0};
+  int c, X0, Y0, x, y, rc = OJ_OK;
+  int ycc = use_ycbcr < 0 ? f->ycbcr : use_ycbcr;
+  const int64_t L[9] = {FIX13(1.0), FIX13(0.0), FIX13(1.40200),
+                        FIX13(1.0), -FIX13(0.3441362861), -FIX13(0.7141362859),
+                        FIX13(1.0), FIX13(1.772), FIX13(0.0)};
+  const int32_t dcshift = (int32_t)(1 << (f->precision - 1)) << 4;
+  for (c = 0; c < f->ncomp; c++) {
+    if (!f->quant_defined[f->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
+    samp[c] = (int32_t *)malloc((size_t)f->bw[c] * f->bh[c] * 64 * sizeof(int32_t));
+    if (!samp[c]) { rc = OJ_ERR_NOMEM; goto out; }
+    oj_idct_plane(samp[c], planes[c], f->bw[c], f->bh[c], f->quant[f->tq[c]], f->precision);
+  }
+  for (Y0 = 0; Y0 < f->height; Y0 += 8)
+    for (X0 = 0; X0 < f->width; X0 += 8) {
+      int32_t blk[OJ_MAX_COMP][64];
+      for (c = 0; c < f->ncomp; c++)
+        oj_upsample_block(blk[c], samp[c], f->bw[c] * 8, f->cw[c], f->ch[c], f->subx[c], f->suby[c], X0, Y0);
+      for (y = 0; y < 8 && Y0 + y < f->height; y++)
+        for (x = 0; x < 8 && X0 + x < f->width; x++) {
+          uint8_t *px = pixels + ((size_t)(Y0 + y) * f->width + (X0 + x)) * f->ncomp;
+          int k = y * 8 + x;
+          if (ycc && f->ncomp == 3) {
+            int64_t yy = blk[0][k], cb = (int64_t)blk[1][k] - dcshift, cr = (int64_t)blk[2][k] - dcshift;
+            px[0] = clamp8((yy * L[0] + cb * L[1] + cr * L[2] + 65536) >> 17);
+            px[1] = clamp8((yy * L[3] + cb * L[4] + cr * L[5] + 65536) >> 17);
+            px[2] = clamp8((yy * L[6] + cb * L[7] + cr * L[8] + 65536) >> 17);
+          } else {
+            for (c = 0; c < f->ncomp; c++) px[c] = clamp8(((int64_t)blk[c][k] + 8) >> 4);
+          }
+        }
+    }
+out:
+  for (c = 0; c < OJ_MAX_COMP; c++) free(samp[c]);
+  return rc;
+}
+
+int oj_decode(const uint8_t *data, size_t len, oj_info *info, uint8_t **pixels)
+{
+  int32_t *planes[OJ_MAX_COMP] = {0, 0, 0, 0};
+  int rc = oj_read_info(data, len, info), c;
+  *pixels = NULL;
+  if (rc) return rc;
+  for (c = 0; c < info->ncomp; c++) {
+    planes[c] = (int32_t *)malloc((size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
+    if (!planes[c]) { rc = OJ_ERR_NOMEM; goto out; }
+  }
+  rc = oj_decode_coefficients(data, len, info, planes);
+  if (rc) goto out;
+  *pixels = (uint8_t *)malloc((size_t)info->width * info->height * info->ncomp);
+  if (!*pixels) { rc = OJ_ERR_NOMEM; goto out; }
+  rc = oj_reconstruct(info, planes, *pixels, -1);
+  if (rc) { free(*pixels); *pixels = NULL; }
+out:
+  for (c = 0; c < OJ_MAX_COMP; c++) free(planes[c]);
+  return rc;
+}
+
+void oj_free(void *p) { free(p); }

@@ -1,0 +1,164 @@
+"""ctypes wrapper around oracle/liboracle.so (the plain-C restatement) and oracle/_ref/jpeg
+(the real reference binary, when built).  TEST INFRASTRUCTURE ONLY: importable from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from libjpeg_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+REF_BIN = os.path.join(HERE, "_ref", "jpeg")
+REF_SRC = os.environ.get("LIBJPEG_REFERENCE", "/root/reference")
+
+
+class OjInfo(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("precision", C.c_int), ("ncomp", C.c_int),
+        ("comp_id", C.c_int * 4), ("hs", C.c_int * 4), ("vs", C.c_int * 4), ("tq", C.c_int * 4),
+        ("subx", C.c_int * 4), ("suby", C.c_int * 4), ("hmax", C.c_int), ("vmax", C.c_int),
+        ("mcus_x", C.c_int), ("mcus_y", C.c_int), ("bw", C.c_int * 4), ("bh", C.c_int * 4),
+        ("cw", C.c_int * 4), ("ch", C.c_int * 4), ("restart_interval", C.c_int),
+        ("adobe_transform", C.c_int), ("ycbcr", C.c_int), ("quant", (C.c_uint16 * 64) * 4),
+        ("quant_defined", C.c_int * 4),
+    ]
+
+
+def build(ref: bool = True) -> None:
+    """Compile liboracle.so and, if the reference sources are present, oracle/_ref/jpeg."""
+    subprocess.run(["make", "-s", "-C", HERE], check=True)
+    if ref and os.path.isdir(REF_SRC) and not os.path.exists(REF_BIN):
+        subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref", f"REF={REF_SRC}"], check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build(ref=False)
+        L = C.CDLL(LIB)
+        L.oj_read_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo)]
+        L.oj_decode_coefficients.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
+        L.oj_idct_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.oj_idct_block.restype = None
+        L.oj_idct_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oj_idct_plane.restype = None
+        L.oj_upsample_block.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7
+        L.oj_upsample_block.restype = None
+        L.oj_reconstruct.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def read_info(data: bytes) -> OjInfo:
+    info = OjInfo()
+    rc = lib().oj_read_info(data, len(data), C.byref(info))
+    if rc:
+        raise ValueError(f"oracle: oj_read_info failed rc={rc}")
+    return info
+
+
+def decode_coefficients(data: bytes, info: OjInfo | None = None):
+    """-> (info, [int32 ndarray (bh, bw, 64) per component]) quantised, natural order."""
+    info = info or read_info(data)
+    planes = [np.zeros((info.bh[c], info.bw[c], 64), np.int32) for c in range(info.ncomp)]
+    ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - info.ncomp))
+    rc = lib().oj_decode_coefficients(data, len(data), C.byref(info), ptrs)
+    if rc:
+        raise ValueError(f"oracle: oj_decode_coefficients failed rc={rc}")
+    return info, planes
+
+
+def reconstruct(info: OjInfo, planes, use_ycbcr: int = -1) -> np.ndarray:
+    """Coefficient planes -> (H, W, ncomp) uint8."""
+    planes = [np.ascontiguousarray(p, np.int32) for p in planes]
+    ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - info.ncomp))
+    out = np.zeros((info.height, info.width, info.ncomp), np.uint8)
+    rc = lib().oj_reconstruct(C.byref(info), ptrs, out.ctypes.data, use_ycbcr)
+    if rc:
+        raise ValueError(f"oracle: oj_reconstruct failed rc={rc}")
+    return out
+
+
+def decode(data: bytes, use_ycbcr: int = -1) -> np.ndarray:
+    info, planes = decode_coefficients(data)
+    return reconstruct(info, planes, use_ycbcr)
+
+
+def idct_block(coef: np.ndarray, quant: np.ndarray, precision: int = 8) -> np.ndarray:
+    coef = np.ascontiguousarray(coef, np.int32).reshape(64)
+    quant = np.ascontiguousarray(quant, np.uint16).reshape(64)
+    out = np.zeros(64, np.int32)
+    lib().oj_idct_block(out.ctypes.data, coef.ctypes.data, quant.ctypes.data, precision)
+    return out.reshape(8, 8)
+
+
+def idct_plane(coef: np.ndarray, quant: np.ndarray, precision: int = 8) -> np.ndarray:
+    bh, bw, _ = coef.shape
+    coef = np.ascontiguousarray(coef, np.int32)
+    quant = np.ascontiguousarray(quant, np.uint16).reshape(64)
+    out = np.zeros((bh * 8, bw * 8), np.int32)
+    lib().oj_idct_plane(out.ctypes.data, coef.ctypes.data, bw, bh, quant.ctypes.data, precision)
+    return out
+
+
+def upsample_block(plane: np.ndarray, cw: int, ch: int, sx: int, sy: int, X0: int, Y0: int) -> np.ndarray:
+    plane = np.ascontiguousarray(plane, np.int32)
+    out = np.zeros(64, np.int32)
+    lib().oj_upsample_block(out.ctypes.data, plane.ctypes.data, plane.shape[1], cw, ch, sx, sy, X0, Y0)
+    return out.reshape(8, 8)
+
+
+# ---------------------------------------------------------------------------- real reference
+def have_reference() -> bool:
+    return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
+
+
+def read_pnm(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        d = f.read()
+    magic, rest = d.split(b"\n", 1)
+    dims, rest = rest.split(b"\n", 1)
+    maxv, rest = rest.split(b"\n", 1)
+    w, h = map(int, dims.split())
+    ch = 3 if magic == b"P6" else 1
+    return np.frombuffer(rest, np.uint8, w * h * ch).reshape(h, w, ch)
+
+
+def write_ppm(path: str, img: np.ndarray) -> None:
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    with open(path, "wb") as f:
+        f.write(b"P%d\n%d %d\n255\n" % (6 if ch == 3 else 5, w, h))
+        f.write(np.ascontiguousarray(img, np.uint8).tobytes())
+
+
+def reference_decode(data: bytes, extra_args=()) -> np.ndarray:
+    """Decode with the real reference CLI (cmd/main.cpp:746-747 -> cmd/reconstruct.cpp:68)."""
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        src, dst = os.path.join(d, "in.jpg"), os.path.join(d, "out.ppm")
+        with open(src, "wb") as f:
+            f.write(data)
+        subprocess.run([REF_BIN, *extra_args, src, dst], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        return read_pnm(dst).copy()
+
+
+def reference_encode(img: np.ndarray, args) -> bytes:
+    """Encode with the real reference CLI, e.g. args=['-bl','-q','85','-s','1x1,2x2,2x2','-z','8']."""
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        src, dst = os.path.join(d, "in.ppm"), os.path.join(d, "out.jpg")
+        write_ppm(src, img)
+        subprocess.run([REF_BIN, *args, src, dst], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        with open(dst, "rb") as f:
+            return f.read()

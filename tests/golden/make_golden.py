@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/: JPEG fixtures + the REAL reference's decode of each.
+
+Run in the build container (needs oracle/_ref/jpeg, i.e. `make -C oracle ref` with /root/reference
+present, and Pillow):   python tests/golden/make_golden.py
+
+For every case it stores  <name>.jpg  and records in manifest.json the sha256 of the pixel bytes
+the reference binary (cmd/reconstruct.cpp via `jpeg in.jpg out.ppm`) produced, the geometry, and
+-- for the small cases -- the raw pixels in <name>.bin so a failing test can show a diff.
+Large cases ("big") store no files: only sha256(jpeg bytes) + sha256(reference pixels); tests
+regenerate the stream with the same deterministic recipe and use the entry if the bytes agree.
+"""
+import hashlib
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from libjpeg_amd import synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha(b: bytes) -> str:
+    return hashlib.sha256(b).hexdigest()
+
+
+def insert_adobe(data: bytes, transform: int) -> bytes:
+    """Insert an APP14 'Adobe' segment right after SOI (marker/adobemarker.cpp layout)."""
+    seg = b"\xff\xee" + struct.pack(">H", 14) + b"Adobe" + struct.pack(">HHHB", 100, 0, 0, transform)
+    return data[:2] + seg + data[2:]
+
+
+def ref_sub(s):  # reference CLI takes SUBSAMPLING factors
+    return ["-s", s]
+
+
+CASES = []
+
+
+def case(name, w, h, seed, enc, **kw):
+    CASES.append(dict(name=name, w=w, h=h, seed=seed, enc=enc, **kw))
+
+
+# BASELINE.json config 1: 512x512 4:4:4 Q75 baseline, reference-encoded
+case("cfg1_512x512_444_q75_ref", 512, 512, 1234, "ref", args=["-bl", "-q", "75"])
+# small-size analogues of configs 2/3 (reference encoder: Tq=0 everywhere; Pillow: Tq=1 chroma)
+case("ref_80x48_420", 80, 48, 1, "ref", args=["-bl", "-q", "85", "-s", "1x1,2x2,2x2"])
+case("ref_75x45_420_dri2", 75, 45, 2, "ref", args=["-bl", "-q", "85", "-s", "1x1,2x2,2x2", "-z", "2"])
+case("ref_33x17_420_dri1", 33, 17, 3, "ref", args=["-bl", "-q", "60", "-s", "1x1,2x2,2x2", "-z", "1"])
+case("ref_16x16_420", 16, 16, 4, "ref", args=["-bl", "-q", "90", "-s", "1x1,2x2,2x2"])
+case("ref_100x9_422", 100, 9, 5, "ref", args=["-bl", "-q", "85", "-s", "1x1,2x1,2x1"])
+case("ref_97x61_440", 97, 61, 6, "ref", args=["-bl", "-q", "85", "-s", "1x1,1x2,1x2"])
+case("ref_97x61_411", 97, 61, 7, "ref", args=["-bl", "-q", "85", "-s", "1x1,4x1,4x1"])
+case("ref_97x61_3x3", 97, 61, 8, "ref", args=["-bl", "-q", "85", "-s", "1x1,3x3,3x3", "-z", "3"])
+case("ref_97x61_4x4", 97, 61, 9, "ref", args=["-bl", "-q", "85", "-s", "1x1,4x4,4x4"])
+case("ref_64x64_2x4", 64, 64, 10, "ref", args=["-bl", "-q", "85", "-s", "1x1,2x4,2x4"])
+case("ref_23x50_lumasub", 23, 50, 11, "ref", args=["-bl", "-q", "85", "-s", "2x2,1x1,1x1"])
+case("ref_97x61_mixed", 97, 61, 12, "ref", args=["-bl", "-q", "85", "-s", "1x1,2x1,1x2"])
+case("ref_120x88_sof1_420", 120, 88, 13, "ref", args=["-q", "85", "-s", "1x1,2x2,2x2", "-z", "4"])
+case("ref_64x40_q2", 64, 40, 14, "ref", args=["-bl", "-q", "2", "-s", "1x1,2x2,2x2"])
+case("ref_64x40_q100", 64, 40, 15, "ref", args=["-bl", "-q", "100"])
+case("pil_80x48_444", 80, 48, 20, "pil", quality=75, sub="444", dri=0)
+case("pil_75x45_420_dri2", 75, 45, 21, "pil", quality=85, sub="420", dri=2)
+case("pil_33x17_420_dri1", 33, 17, 22, "pil", quality=85, sub="420", dri=1)
+case("pil_200x120_420_dri8", 200, 120, 23, "pil", quality=85, sub="420", dri=8)
+case("pil_131x77_422", 131, 77, 24, "pil", quality=50, sub="422", dri=0)
+case("pil_70x40_gray", 70, 40, 25, "pil", quality=80, sub="gray", dri=3)
+case("pil_9x9_420", 9, 9, 26, "pil", quality=95, sub="420", dri=0)
+case("pil_1x1_444", 1, 1, 27, "pil", quality=95, sub="444", dri=0)
+case("pil_80x48_444_adobe0", 80, 48, 28, "pil", quality=75, sub="444", dri=0, adobe=0)
+case("pil_80x48_420_adobe1", 80, 48, 29, "pil", quality=75, sub="420", dri=0, adobe=1)
+# full-size configs 2 / 3 (hash-only)
+case("big_4k_420_q85", 3840, 2160, 1234, "pil", quality=85, sub="420", dri=0, big=True)
+case("big_4k_420_q85_dri8", 3840, 2160, 1234, "pil", quality=85, sub="420", dri=8, big=True)
+case("big_8k_420_q85_dri8", 7680, 4320, 1234, "pil", quality=85, sub="420", dri=8, big=True)
+
+
+def main():
+    O.build()
+    assert O.have_reference(), "oracle/_ref/jpeg missing: run `make -C oracle ref`"
+    manifest = {}
+    for c in CASES:
+        img = synth.synth_image(c["w"], c["h"], c["seed"])
+        if c["enc"] == "ref":
+            data = O.reference_encode(img, c["args"])
+        else:
+            if c["sub"] == "gray":
+                data = synth.encode_jpeg(img[..., 0], c["quality"], restart_mcus=c["dri"])
+            else:
+                data = synth.encode_jpeg(img, c["quality"], c["sub"], c["dri"])
+            if "adobe" in c:
+                data = insert_adobe(data, c["adobe"])
+        ref = O.reference_decode(data)
+        assert ref.shape[:2] == (c["h"], c["w"]), (c["name"], ref.shape)
+        ent = dict(width=c["w"], height=c["h"], channels=int(ref.shape[2]), seed=c["seed"],
+                   encoder=c["enc"], jpeg_sha256=sha(data), pixels_sha256=sha(ref.tobytes()),
+                   jpeg_bytes=len(data))
+        for k in ("args", "quality", "sub", "dri", "adobe"):
+            if k in c:
+                ent[k] = c[k]
+        if c.get("big"):
+            ent["big"] = True
+        else:
+            with open(os.path.join(OUT, c["name"] + ".jpg"), "wb") as f:
+                f.write(data)
+            if ref.size <= 120000:
+                with open(os.path.join(OUT, c["name"] + ".bin"), "wb") as f:
+                    f.write(ref.tobytes())
+                ent["pixels_file"] = c["name"] + ".bin"
+        manifest[c["name"]] = ent
+        print(c["name"], len(data), ent["pixels_sha256"][:12])
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""Pins the CPU restatement (oracle/jpeg_oracle.c) against the REAL reference.
+
+1. every committed fixture in tests/golden (pixels produced by the reference binary, see
+   tests/golden/make_golden.py) must be reproduced bit-exactly;
+2. when oracle/_ref/jpeg is available (build container), fresh random streams are decoded by both
+   and compared live.
+These run on CPU (-m "not gpu")."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import BIG_CASES, MANIFEST, SMALL_CASES, big_jpeg, golden_jpeg, golden_pixels
+from libjpeg_amd import synth
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_oracle_matches_reference_golden(oracle, name):
+    ent = MANIFEST[name]
+    out = oracle.decode(golden_jpeg(name))
+    assert out.shape == (ent["height"], ent["width"], ent["channels"])
+    exp = golden_pixels(name)
+    if exp is not None:
+        assert np.array_equal(out, exp), f"{(out != exp).sum()} differing samples"
+    assert hashlib.sha256(out.tobytes()).hexdigest() == ent["pixels_sha256"]
+
+
+@pytest.mark.parametrize("name", [n for n in BIG_CASES if "4k" in n])
+def test_oracle_matches_reference_4k(oracle, name):
+    data = big_jpeg(name)
+    if data is None:
+        pytest.skip("this box's Pillow produces different bytes than the manifest recipe")
+    out = oracle.decode(data)
+    assert hashlib.sha256(out.tobytes()).hexdigest() == MANIFEST[name]["pixels_sha256"]
+
+
+def test_scan_order_and_quant_natural_order(oracle):
+    # DQT values are stored de-zigzagged (marker/quantization.cpp:502-527): the first row of the
+    # natural-order table must be zig-zag positions 0,1,5,6,14,15,27,28
+    data = golden_jpeg("pil_80x48_444")
+    i = data.index(b"\xff\xdb")
+    zz = np.frombuffer(data[i + 5:i + 5 + 64], np.uint8)
+    info = oracle.read_info(data)
+    q0 = np.array(info.quant[0][:])
+    assert list(q0[:8]) == [int(zz[k]) for k in (0, 1, 5, 6, 14, 15, 27, 28)]
+
+
+def test_idct_dc_only_and_null(oracle):
+    # DC-only block: every sample equals ((dc*q*16 + 128*128) ... ) through both passes; check
+    # against the closed form of dct/idct.cpp with all AC = 0
+    q = np.full(64, 8, np.uint16)
+    c = np.zeros(64, np.int32)
+    c[0] = 5
+    out = oracle.idct_block(c, q)
+    s0 = 5 * (8 << 4) + (128 << 7)
+    row = ((s0 << 9) + 256) >> 9
+    val = ((row << 9) + 2048) >> 12
+    assert (out == val).all()
+
+
+@pytest.mark.parametrize("sx,sy", [(2, 2), (2, 1), (1, 2)])
+def test_upsample_inplace_alias_quirk(oracle, sx, sy):
+    # out[1] of every 8-wide group is computed from the already overwritten out[2]
+    # (upsampling/upsampler.cpp:301-302); a closed form WITHOUT the alias must differ somewhere.
+    rng = np.random.default_rng(0)
+    plane = rng.integers(0, 4096, size=(16, 16)).astype(np.int32)
+    blk = oracle.upsample_block(plane, 16, 16, sx, sy, 8, 8)
+    if sx == 2:
+        y = 8 // sy
+        x0 = 8 // 2
+        def V(j, l):
+            cc = np.clip(x0 - 1 + j, 0, 15)
+            if sy == 1:
+                return int(plane[min(y + l, 15), cc])
+            yy = y + l // 2
+            if l % 2 == 0:
+                return (int(plane[max(yy - 1, 0), cc]) + 3 * int(plane[yy, cc]) + (2 if j % 2 == 0 else 1)) >> 2
+            return (int(plane[min(yy + 1, 15), cc]) + 3 * int(plane[yy, cc]) + (1 if j % 2 == 0 else 2)) >> 2
+        for l in range(8):
+            s = [V(j + 1, l) for j in range(-1, 6)]  # s[k] = src[k-1+1] ... index shift: s[0]=src[-1]
+            src = lambda k: s[k + 1]
+            o2 = (src(0) + 3 * src(1) + 2) >> 2
+            assert blk[l, 2] == o2
+            assert blk[l, 1] == (o2 + 3 * src(0) + 1) >> 2
+            assert blk[l, 0] == (src(-1) + 3 * src(0) + 2) >> 2
+            assert blk[l, 7] == (src(4) + 3 * src(3) + 1) >> 2
+
+
+def _live_cases():
+    rng = np.random.default_rng(99)
+    for i in range(12):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+        yield w, h, int(rng.integers(30, 98)), ["444", "420", "422"][i % 3], int(rng.integers(0, 5)), 1000 + i
+
+
+@pytest.mark.parametrize("w,h,q,sub,dri,seed", list(_live_cases()))
+def test_oracle_vs_live_reference(oracle, w, h, q, sub, dri, seed):
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/jpeg not built (needs /root/reference)")
+    data = synth.encode_jpeg(synth.synth_image(w, h, seed), q, sub, dri)
+    assert np.array_equal(oracle.decode(data), oracle.reference_decode(data))
