@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X JPEG block-decode path (BASELINE.json metric).
+
+A "step" is one pass of the hot path (fused dequant + IDCT + chroma upsample + YCbCr->RGB kernel) over one
+batch of F synthetic 8K (7680x4320) 4:2:0 baseline frames whose int16 coefficient planes are already
+resident in HBM; pixels are written to HBM.  value = decoded Mpixels/s over all ranks.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--size 8k|4k]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL barrier only: frames
+are independent, nothing is exchanged).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from libjpeg_amd import api, synth  # noqa: E402
+
+SIZES = {"8k": (7680, 4320), "4k": (3840, 2160)}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_PIXEL_420 = 6.0  # int16 coefficients in (3 B/px) + interleaved RGB out (3 B/px)
+
+
+def cpu_baseline(jpeg_bytes, width, height):
+    """Reference CPU path timed on this box's host cores (rank 0, N=1 only).  Uses oracle/_ref/jpeg (the
+    real reference binary, kind 'reference') if it was built, else the oracle's C restatement ('port')."""
+    from oracle import oracle as O
+
+    mpix = width * height / 1e6
+    if O.have_reference():
+        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+            src, dst = os.path.join(d, "in.jpg"), os.path.join(d, "out.ppm")
+            with open(src, "wb") as f:
+                f.write(jpeg_bytes)
+            ts = []
+            for _ in range(5):
+                t = time.perf_counter()
+                subprocess.run([O.REF_BIN, src, dst], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                ts.append(time.perf_counter() - t)
+        best = sorted(ts)[len(ts) // 2]
+        return dict(value=round(mpix / best, 2), unit="Mpixels/s", cores=1, kind="reference",
+                    sample=f"5 whole-process decodes of one {width}x{height} 4:2:0 Q85 DRI=8 frame by oracle/_ref/jpeg "
+                           f"(file in /dev/shm -> PPM in /dev/shm), median {best * 1e3:.0f} ms")
+    ts = []
+    for _ in range(5):
+        t = time.perf_counter()
+        O.decode(jpeg_bytes)
+        ts.append(time.perf_counter() - t)
+    best = sorted(ts)[len(ts) // 2]
+    return dict(value=round(mpix / best, 2), unit="Mpixels/s", cores=1, kind="port",
+                sample=f"5 in-memory decodes of one {width}x{height} 4:2:0 frame by oracle/liboracle.so, median {best * 1e3:.0f} ms")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8, help="frames per step and rank (device resident)")
+    ap.add_argument("--size", default="8k", choices=sorted(SIZES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the reconstruction path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H = SIZES[args.size]
+    F = args.frames
+    # ---- workload: F frames per rank, two distinct pictures per rank, coefficient planes in HBM ----------
+    dec = api.Decoder(local_rank)
+    host_planes, jpegs = [], []
+    info = None
+    for i in range(2):
+        data = synth.synth_jpeg(W, H, seed=1234 + 17 * rank + i, quality=85, subsampling="420", restart_mcus=8)
+        jpegs.append(data)
+        info = dec.read(data)
+        host_planes.append(np.concatenate([dec.coefficients(c).reshape(-1) for c in range(info.components)]))
+    n = int(info.coef_count)
+    coef = torch.empty((F, n), dtype=torch.int16, device="cuda")
+    for f in range(F):
+        coef[f].copy_(torch.from_numpy(host_planes[f % 2]))
+    row = W * 3
+    out = torch.empty((F, H, row), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), F, row, H * row, n, stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: one kernel per step
+    if dist:
+        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(t[0]), float(t[1])
+
+    pixels_per_step = W * H * F * world
+    ms_per_step = wall * 1e3 / args.steps
+    value = pixels_per_step / (ms_per_step * 1e-3) / 1e6
+    alg_bytes = W * H * F * BYTES_PER_PIXEL_420  # per launch (one rank)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "decoded Mpixels/s, 8K 4:2:0 baseline (fused IDCT+upsample+YCbCr kernel, coefficients resident in HBM)",
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32 (int16 coefficients in, u8 pixels out)", "data": "synthetic",
+        "config": {"workload": f"{F} x {W}x{H} 4:2:0 Q85 DRI=8 baseline frames per GPU per step (BASELINE configs[2] frame shape, "
+                               f"device-resident coefficient planes)", "frames_per_gpu": F, "kernel": api.kernel_name(info),
+                   "fast_arith": int(info.fast_arith), "parallelism": f"image-sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)},
+    }
+
+    if rank == 0 and not args.no_end_to_end:
+        # whole decode of one frame through the decoder object: host Huffman (all cores) + streaming H2D +
+        # kernel + D2H into host memory.  PCIe/host inclusive -- reported beside, never as `value`.
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter()
+            dec.read(jpegs[0])
+            dec.reconstruct()
+            ts.append(time.perf_counter() - t)
+        tm = dec.timing()
+        best = min(ts)
+        result["end_to_end"] = {"value": round(W * H / best / 1e6, 1), "unit": "Mpixels/s", "ms": round(best * 1e3, 2),
+                                "host_threads": os.cpu_count(), "phases_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
+                                "note": "one frame: bytes -> host Huffman (restart-interval parallel) -> pinned H2D -> kernel -> D2H"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(jpegs[0], W, H)
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            result["cpu_baseline"] = {"value": None, "error": repr(e)}
+    dec.close()
+    if rank == 0:
+        print(json.dumps(result))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

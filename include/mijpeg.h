@@ -1,0 +1,166 @@
+/*
+ * mijpeg.h -- C ABI of the MI355X-native JPEG block-decode path (libjpeg_amd/libmijpeg.so).
+ *
+ * This is the drop-in boundary for the hot path of thorfdbg/libjpeg:
+ *
+ *      JPEG::Read            (interface/jpeg.cpp:205-354)   -> mijpeg_set_input + mijpeg_read_header
+ *                                                              + mijpeg_decode_coefficients (+ upload)
+ *      JPEG::GetInformation  (interface/jpeg.cpp:822-957)   -> mijpeg_info (filled by read_header)
+ *      JPEG::DisplayRectangle(interface/jpeg.cpp:694-722)   -> mijpeg_reconstruct_rect
+ *          = Image::ReconstructRegion (codestream/image.cpp:1087-1123)
+ *          = BlockBitmapRequester::ReconstructRegion (control/blockbitmaprequester.cpp:1249-1272)
+ *      JPEG::LastError       (interface/jpeg.cpp:959-968)   -> mijpeg_last_error
+ *
+ * The reference has no C ABI (it exports the C++ class JPEG); the source-compatible class JPEG in
+ * libjpeg_amd/csrc/interface/ is implemented on top of these entry points, see INTEGRATION.md.
+ *
+ * Conventions: extern "C", plain pointers and sizes, int return codes (0 = ok, negative = the
+ * reference's JPGERR_* value, interface/parameters.hpp:1156-1228), no exceptions cross the
+ * boundary, the library never takes ownership of pixel memory.  hipStream_t is passed as void*.
+ */
+#ifndef MIJPEG_H
+#define MIJPEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIJPEG_MAX_COMPONENTS 4
+
+/* Error codes: numeric values of the reference's JPGERR_* (interface/parameters.hpp:1156-1228). */
+#define MIJPEG_OK 0
+#define MIJPEG_ERR_INVALID_PARAMETER (-1024)
+#define MIJPEG_ERR_UNEXPECTED_EOF (-1025)
+#define MIJPEG_ERR_UNEXPECTED_EOB (-1026)
+#define MIJPEG_ERR_STREAM_EMPTY (-1027)
+#define MIJPEG_ERR_OVERFLOW_PARAMETER (-1028)
+#define MIJPEG_ERR_NOT_AVAILABLE (-1029)
+#define MIJPEG_ERR_OBJECT_EXISTS (-1030)
+#define MIJPEG_ERR_OBJECT_DOESNT_EXIST (-1031)
+#define MIJPEG_ERR_MISSING_PARAMETER (-1032)
+#define MIJPEG_ERR_BAD_STREAM (-1033)
+#define MIJPEG_ERR_OPERATION_UNIMPLEMENTED (-1034)
+#define MIJPEG_ERR_PHASE_ERROR (-1035)
+#define MIJPEG_ERR_NO_JPG (-1036)
+#define MIJPEG_ERR_DOUBLE_MARKER (-1037)
+#define MIJPEG_ERR_MALFORMED_STREAM (-1038)
+#define MIJPEG_ERR_NOT_IN_PROFILE (-1040)
+#define MIJPEG_ERR_THREAD_ABORTED (-1041)
+#define MIJPEG_ERR_INVALID_HUFFMAN (-1042)
+#define MIJPEG_ERR_OUT_OF_MEMORY (-2048)
+#define MIJPEG_ERR_DEVICE (-8191) /* HIP runtime failure (no reference equivalent) */
+
+/* flags for the reconstruct calls */
+#define MIJPEG_FLAG_NO_COLOR_TRANSFORM 1u /* JPGTAG_MATRIX_LTRAFO = JPGFLAG_MATRIX_COLORTRANSFORMATION_NONE (CLI -c) */
+#define MIJPEG_FLAG_FORCE_GENERIC 2u      /* use the unfused generic kernels even where a fused one exists (testing) */
+#define MIJPEG_FLAG_FORCE_SAFE 4u         /* use the 32/64-bit "safe" arithmetic flavour even if the range check passed */
+
+typedef struct mijpeg_decoder mijpeg_decoder;
+
+/* Frame geometry, as JPEG::GetInformation reports it plus the coefficient-plane layout. */
+typedef struct mijpeg_info {
+  int32_t width, height;     /* JPGTAG_IMAGE_WIDTH / HEIGHT                                     */
+  int32_t components;        /* JPGTAG_IMAGE_DEPTH                                              */
+  int32_t precision;         /* JPGTAG_IMAGE_PRECISION (8 on this path)                         */
+  int32_t hsamp[MIJPEG_MAX_COMPONENTS], vsamp[MIJPEG_MAX_COMPONENTS]; /* SOF Hi, Vi              */
+  int32_t subx[MIJPEG_MAX_COMPONENTS], suby[MIJPEG_MAX_COMPONENTS];   /* JPGTAG_IMAGE_SUBX/SUBY  */
+  int32_t quant_index[MIJPEG_MAX_COMPONENTS];                         /* SOF Tqi                 */
+  int32_t mcus_x, mcus_y;    /* interleaved MCU grid                                            */
+  int32_t blocks_w[MIJPEG_MAX_COMPONENTS], blocks_h[MIJPEG_MAX_COMPONENTS]; /* plane size, blocks */
+  int32_t restart_interval;  /* DRI                                                             */
+  int32_t ycbcr;             /* 1 = L-transformation is YCbCr->RGB (codestream/tables.cpp:2021-2030) */
+  int32_t fast_arith;        /* set by decode_coefficients: 1 = every block passed the range check */
+  int64_t coef_offset[MIJPEG_MAX_COMPONENTS]; /* start of each component plane, in int16 units   */
+  int64_t coef_count;        /* total int16 coefficients of one frame (all planes)              */
+  uint16_t quant[4][64];     /* DQT deltas in natural order, index = Tq                          */
+} mijpeg_info;
+
+/* ---- decoder object (one image at a time; one object = one host thread at a time) ---------- */
+
+/* device >= 0: HIP device ordinal, coefficient store is pinned host memory + a device mirror.
+ * device  < 0: host-only object (header parsing and entropy decoding, no GPU needed). */
+int mijpeg_create(mijpeg_decoder **out, int device);
+void mijpeg_destroy(mijpeg_decoder *d);
+
+/* The byte range is borrowed until the next set_input / destroy. */
+int mijpeg_set_input(mijpeg_decoder *d, const uint8_t *data, size_t size);
+
+/* SOI .. first SOS: tables, frame header.  Replaces Decoder::ParseHeaderIncremental +
+ * Image::StartParseFrame (codestream/decoder.cpp:77, codestream/image.cpp:660). */
+int mijpeg_read_header(mijpeg_decoder *d, mijpeg_info *info);
+
+/* Entropy-decode all scans into the planar int16 coefficient store (natural order, quantised):
+ * replaces the Scan::ParseMCU loop of JPEG::ReadInternal (interface/jpeg.cpp:300-340) =
+ * SequentialScan::ParseMCU/DecodeBlock (codestream/sequentialscan.cpp:381-428, 678-773).
+ * threads <= 0: one per host core.  Restart intervals decode in parallel.  With a device, MCU-row
+ * bands are hipMemcpyAsync'ed to the GPU while later bands are still being decoded. */
+int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads);
+
+/* Current frame information (after mijpeg_decode_coefficients it includes fast_arith). */
+int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info);
+
+/* Host view of a decoded component plane: blocks_h x blocks_w x 64 int16. */
+const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component);
+
+/* Device pointer of the uploaded frame (coef_count int16) or NULL. */
+const int16_t *mijpeg_device_coefficients(mijpeg_decoder *d);
+
+/* Reconstruct the whole frame on the GPU into DEVICE memory: interleaved 8-bit samples,
+ * `components` bytes per pixel, `row_stride` bytes per line.  Asynchronous on the decoder's stream
+ * unless `sync` is non-zero. */
+int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_stride, uint32_t flags,
+                              int sync);
+
+/* Reconstruct a rectangle into HOST memory described like the reference's ImageBitMap
+ * (interface/imagebitmap.hpp): for component c, dst[c] is the address of canvas pixel (0,0),
+ * bytes_per_pixel[c] / bytes_per_row[c] the strides.  Rectangle and component range are inclusive,
+ * as in JPGTAG_DECODER_MINX..MAXY / MINCOMPONENT..MAXCOMPONENT (codestream/rectanglerequest.cpp:92-152). */
+int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y,
+                            int32_t min_comp, int32_t max_comp, uint32_t flags,
+                            void *const dst[MIJPEG_MAX_COMPONENTS],
+                            const int32_t bytes_per_pixel[MIJPEG_MAX_COMPONENTS],
+                            const int32_t bytes_per_row[MIJPEG_MAX_COMPONENTS]);
+
+/* Error of the last failing call on this object (JPEG::LastError). Returns the code, 0 if none. */
+int mijpeg_last_error(mijpeg_decoder *d, const char **message);
+
+/* Seconds spent in the phases of the last decode (huffman, h2d, kernel, d2h) -- diagnostics. */
+int mijpeg_last_timing(mijpeg_decoder *d, double out_seconds[4]);
+
+/* ---- stateless device entry points (inputs and outputs resident in HBM) -------------------- */
+
+/* Describes a batch of equally shaped frames whose coefficient planes are already on the device. */
+typedef struct mijpeg_batch {
+  mijpeg_info info;            /* geometry + quantiser tables (shared by the batch unless quant_dev) */
+  const int16_t *coef_dev;     /* frame f starts at coef_dev + f * coef_frame_stride (int16 units) */
+  int64_t coef_frame_stride;
+  const uint16_t *quant_dev;   /* optional: per-frame tables [frames][4][64] u16 on the device      */
+  uint8_t *out_dev;            /* frame f pixels at out_dev + f * out_frame_stride (bytes)          */
+  int64_t out_frame_stride;
+  int64_t out_row_stride;      /* bytes per line                                                  */
+  int32_t frames;
+  uint32_t flags;
+  void *workspace;             /* device scratch for the unfused path, see mijpeg_workspace_bytes     */
+  size_t workspace_bytes;
+} mijpeg_batch;
+
+/* Device scratch the batch needs (0 for the fused kernels). */
+size_t mijpeg_workspace_bytes(const mijpeg_batch *batch);
+
+/* dequant + IDCT + upsample + colour transform + interleaved store for `frames` frames in one
+ * launch on `stream` (hipStream_t).  Asynchronous.  This is what bench.py times. */
+int mijpeg_launch_reconstruct(const mijpeg_batch *batch, void *stream);
+
+/* Name of the kernel the batch would run ("fused420", "generic", ...) -- for profiling scripts. */
+const char *mijpeg_kernel_name(const mijpeg_batch *batch);
+
+/* Library / build identification. */
+const char *mijpeg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,227 @@
+"""ctypes binding of libjpeg_amd/libmijpeg.so (include/mijpeg.h) for tests and bench.py.
+
+This is plumbing above the C ABI: it mirrors the decode half of the reference's `class JPEG`
+(interface/jpeg.hpp:185-252): Read -> `Decoder.read`, GetInformation -> `Decoder.info`,
+DisplayRectangle -> `Decoder.reconstruct` / `reconstruct_rect`, LastError -> `MijpegError`.
+The product path has no CPU fallback: if the shared library (HIP kernels inside) is missing, `lib()`
+fails loudly; if no GPU is present, every reconstruct call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmijpeg.so")
+
+FLAG_NO_COLOR_TRANSFORM = 1
+FLAG_FORCE_GENERIC = 2
+FLAG_FORCE_SAFE = 4
+
+ERR_DEVICE = -8191
+
+
+class MijpegInfo(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32), ("precision", C.c_int32),
+        ("hsamp", C.c_int32 * 4), ("vsamp", C.c_int32 * 4), ("subx", C.c_int32 * 4), ("suby", C.c_int32 * 4),
+        ("quant_index", C.c_int32 * 4), ("mcus_x", C.c_int32), ("mcus_y", C.c_int32),
+        ("blocks_w", C.c_int32 * 4), ("blocks_h", C.c_int32 * 4), ("restart_interval", C.c_int32),
+        ("ycbcr", C.c_int32), ("fast_arith", C.c_int32), ("coef_offset", C.c_int64 * 4),
+        ("coef_count", C.c_int64), ("quant", (C.c_uint16 * 64) * 4),
+    ]
+
+
+class MijpegBatch(C.Structure):
+    _fields_ = [
+        ("info", MijpegInfo), ("coef_dev", C.c_void_p), ("coef_frame_stride", C.c_int64),
+        ("quant_dev", C.c_void_p), ("out_dev", C.c_void_p), ("out_frame_stride", C.c_int64),
+        ("out_row_stride", C.c_int64), ("frames", C.c_int32), ("flags", C.c_uint32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class MijpegError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mijpeg error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def build(force: bool = False) -> str:
+    """Compile libmijpeg.so in-tree (hipcc --offload-arch=gfx950); cross-compiles without a GPU."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-s", "-j4", "-C", os.path.join(HERE, "csrc")], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the reconstruction path)")
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER
+        L.mijpeg_version.restype = C.c_char_p
+        L.mijpeg_create.argtypes = [P(C.c_void_p), C.c_int]
+        L.mijpeg_destroy.argtypes = [C.c_void_p]
+        L.mijpeg_destroy.restype = None
+        L.mijpeg_set_input.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.mijpeg_read_header.argtypes = [C.c_void_p, P(MijpegInfo)]
+        L.mijpeg_get_info.argtypes = [C.c_void_p, P(MijpegInfo)]
+        L.mijpeg_decode_coefficients.argtypes = [C.c_void_p, C.c_int]
+        L.mijpeg_coefficients.argtypes = [C.c_void_p, C.c_int]
+        L.mijpeg_coefficients.restype = C.c_void_p
+        L.mijpeg_device_coefficients.argtypes = [C.c_void_p]
+        L.mijpeg_device_coefficients.restype = C.c_void_p
+        L.mijpeg_reconstruct_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int]
+        L.mijpeg_reconstruct_rect.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_uint32, P(C.c_void_p), P(C.c_int32), P(C.c_int32)]
+        L.mijpeg_last_error.argtypes = [C.c_void_p, P(C.c_char_p)]
+        L.mijpeg_last_timing.argtypes = [C.c_void_p, P(C.c_double)]
+        L.mijpeg_launch_reconstruct.argtypes = [P(MijpegBatch), C.c_void_p]
+        L.mijpeg_kernel_name.argtypes = [P(MijpegBatch)]
+        L.mijpeg_kernel_name.restype = C.c_char_p
+        L.mijpeg_workspace_bytes.argtypes = [P(MijpegBatch)]
+        L.mijpeg_workspace_bytes.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+class Decoder:
+    """One image at a time.  device=None -> host-only object (parsing + Huffman decoding)."""
+
+    def __init__(self, device: int | None = 0):
+        self._h = C.c_void_p()
+        rc = lib().mijpeg_create(C.byref(self._h), -1 if device is None else int(device))
+        if rc:
+            raise MijpegError(rc, "mijpeg_create failed (no usable HIP device?)")
+        self._data = None
+        self.info: MijpegInfo | None = None
+
+    def close(self):
+        if self._h:
+            lib().mijpeg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            msg = C.c_char_p()
+            lib().mijpeg_last_error(self._h, C.byref(msg))
+            raise MijpegError(rc, (msg.value or b"").decode())
+
+    def read_header(self, data: bytes) -> MijpegInfo:
+        """Tables + frame header (JPEG::Read up to the first scan, then JPEG::GetInformation)."""
+        self._data = data  # keep alive: the library borrows the bytes
+        self._check(lib().mijpeg_set_input(self._h, data, len(data)))
+        info = MijpegInfo()
+        self._check(lib().mijpeg_read_header(self._h, C.byref(info)))
+        self.info = info
+        return info
+
+    def read(self, data: bytes, threads: int = 0) -> MijpegInfo:
+        """JPEG::Read: parse everything and entropy-decode all scans (uploads when a device is attached)."""
+        self._data = data
+        self._check(lib().mijpeg_set_input(self._h, data, len(data)))
+        self._check(lib().mijpeg_decode_coefficients(self._h, threads))
+        info = MijpegInfo()
+        self._check(lib().mijpeg_get_info(self._h, C.byref(info)))
+        self.info = info
+        return info
+
+    def coefficients(self, comp: int) -> np.ndarray:
+        f = self.info
+        p = lib().mijpeg_coefficients(self._h, comp)
+        if not p:
+            raise MijpegError(-1031, "no decoded coefficients")
+        n = f.blocks_w[comp] * f.blocks_h[comp] * 64
+        arr = np.ctypeslib.as_array((C.c_int16 * n).from_address(p))
+        return arr.reshape(f.blocks_h[comp], f.blocks_w[comp], 64).copy()
+
+    def device_coefficients(self) -> int:
+        return lib().mijpeg_device_coefficients(self._h) or 0
+
+    def reconstruct(self, flags: int = 0) -> np.ndarray:
+        """JPEG::DisplayRectangle over the whole canvas -> (H, W, C) uint8 in host memory."""
+        f = self.info
+        return self.reconstruct_rect(0, 0, f.width - 1, f.height - 1, flags=flags)
+
+    def reconstruct_rect(self, x0, y0, x1, y1, comp0=0, comp1=None, flags: int = 0,
+                         out: np.ndarray | None = None) -> np.ndarray:
+        f = self.info
+        nc = f.components
+        comp1 = nc - 1 if comp1 is None else comp1
+        if out is None:
+            out = np.zeros((f.height, f.width, nc), np.uint8)
+        base = out.ctypes.data
+        dst = (C.c_void_p * 4)(*[base + c if c < nc else None for c in range(4)])
+        bpp = (C.c_int32 * 4)(*([nc] * 4))
+        bpr = (C.c_int32 * 4)(*([out.strides[0]] * 4))
+        self._check(lib().mijpeg_reconstruct_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags, dst, bpp, bpr))
+        return out
+
+    def reconstruct_device(self, dst_ptr: int, row_stride: int, flags: int = 0, sync: bool = True):
+        self._check(lib().mijpeg_reconstruct_device(self._h, dst_ptr, row_stride, flags, 1 if sync else 0))
+
+    def timing(self):
+        t = (C.c_double * 4)()
+        lib().mijpeg_last_timing(self._h, t)
+        return dict(huffman=t[0], h2d_wait=t[1], kernel=t[2], d2h=t[3])
+
+
+def decode(data: bytes, device: int = 0, threads: int = 0, flags: int = 0) -> np.ndarray:
+    """`jpeg in.jpg out.ppm` in one call: bytes -> (H, W, C) uint8."""
+    d = Decoder(device)
+    try:
+        d.read(data, threads)
+        return d.reconstruct(flags)
+    finally:
+        d.close()
+
+
+def launch_reconstruct(info: MijpegInfo, coef_dev: int, out_dev: int, frames: int, out_row_stride: int,
+                       out_frame_stride: int, coef_frame_stride: int | None = None, flags: int = 0,
+                       workspace: int = 0, workspace_bytes: int = 0, stream: int = 0) -> None:
+    """Stateless batch launch (device-resident coefficients -> device pixels), asynchronous."""
+    b = MijpegBatch()
+    C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
+    b.coef_dev = coef_dev
+    b.coef_frame_stride = info.coef_count if coef_frame_stride is None else coef_frame_stride
+    b.out_dev = out_dev
+    b.out_frame_stride = out_frame_stride
+    b.out_row_stride = out_row_stride
+    b.frames = frames
+    b.flags = flags
+    b.workspace = workspace
+    b.workspace_bytes = workspace_bytes
+    rc = lib().mijpeg_launch_reconstruct(C.byref(b), stream)
+    if rc:
+        raise MijpegError(rc, "mijpeg_launch_reconstruct failed")
+
+
+def workspace_bytes(info: MijpegInfo, frames: int, flags: int = 0) -> int:
+    b = MijpegBatch()
+    C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
+    b.frames = frames
+    b.flags = flags
+    return int(lib().mijpeg_workspace_bytes(C.byref(b)))
+
+
+def kernel_name(info: MijpegInfo, flags: int = 0) -> str:
+    b = MijpegBatch()
+    C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
+    b.flags = flags
+    return lib().mijpeg_kernel_name(C.byref(b)).decode()

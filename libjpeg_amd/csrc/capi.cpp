@@ -1,0 +1,439 @@
+// capi.cpp -- the C ABI of include/mijpeg.h: decoder object (host entropy decoding + streaming upload +
+// GPU reconstruction + rectangle service) and the stateless batch launch.  Compiled with hipcc (host side
+// only uses the HIP runtime API).  There is NO CPU fallback for the reconstruction: without a device the
+// reconstruct calls fail with MIJPEG_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <new>
+#include <string>
+
+#include "../../include/mijpeg.h"
+#include "host_decoder.hpp"
+#include "kernels.hpp"
+
+using namespace mij;
+
+struct mijpeg_decoder {
+  int device = -1;
+  HostDecoder host;
+  const uint8_t *data = nullptr;
+  size_t size = 0;
+  bool parsed = false, decoded = false, uploaded = false;
+  // coefficient store: pinned when a device is attached
+  int16_t *coef_host = nullptr;
+  size_t coef_host_cap = 0; // int16 units
+  int16_t *coef_dev = nullptr;
+  size_t coef_dev_cap = 0;
+  // reconstruction cache for the rectangle service
+  uint8_t *img_dev = nullptr;
+  size_t img_dev_cap = 0;
+  uint8_t *img_host = nullptr; // pinned
+  size_t img_host_cap = 0;
+  bool img_valid = false;
+  uint32_t img_flags = 0;
+  int32_t *ws_dev = nullptr;
+  size_t ws_cap = 0; // bytes
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int err_code = 0;
+  std::string err_msg;
+  double timing[4] = {0, 0, 0, 0};
+};
+
+static int set_error(mijpeg_decoder *d, int code, const std::string &msg)
+{
+  d->err_code = code;
+  d->err_msg = msg;
+  return code;
+}
+
+static int hip_fail(mijpeg_decoder *d, hipError_t e, const char *what)
+{
+  return set_error(d, MIJPEG_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(d, call)                                  \
+  do {                                                    \
+    hipError_t e_ = (call);                               \
+    if (e_ != hipSuccess) return hip_fail(d, e_, #call);  \
+  } while (0)
+
+extern "C" {
+
+const char *mijpeg_version(void) { return "libjpeg_amd/mijpeg 0.1 (gfx950)"; }
+
+int mijpeg_create(mijpeg_decoder **out, int device)
+{
+  if (!out) return MIJPEG_ERR_INVALID_PARAMETER;
+  *out = nullptr;
+  mijpeg_decoder *d = new (std::nothrow) mijpeg_decoder();
+  if (!d) return MIJPEG_ERR_OUT_OF_MEMORY;
+  d->device = device;
+  if (device >= 0) {
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&d->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&d->ev1);
+    if (e != hipSuccess) {
+      delete d;
+      return MIJPEG_ERR_DEVICE;
+    }
+  }
+  *out = d;
+  return MIJPEG_OK;
+}
+
+void mijpeg_destroy(mijpeg_decoder *d)
+{
+  if (!d) return;
+  if (d->device >= 0) {
+    (void)hipSetDevice(d->device);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    if (d->coef_host) (void)hipHostFree(d->coef_host);
+    if (d->img_host) (void)hipHostFree(d->img_host);
+    if (d->coef_dev) (void)hipFree(d->coef_dev);
+    if (d->img_dev) (void)hipFree(d->img_dev);
+    if (d->ws_dev) (void)hipFree(d->ws_dev);
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+  } else {
+    free(d->coef_host);
+  }
+  delete d;
+}
+
+int mijpeg_set_input(mijpeg_decoder *d, const uint8_t *data, size_t size)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (!data || !size) return set_error(d, MIJPEG_ERR_STREAM_EMPTY, "empty input stream");
+  d->data = data;
+  d->size = size;
+  d->parsed = d->decoded = d->uploaded = d->img_valid = false;
+  return MIJPEG_OK;
+}
+
+int mijpeg_read_header(mijpeg_decoder *d, mijpeg_info *info)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
+  const int rc = d->host.parse(d->data, d->size, true);
+  if (rc) return set_error(d, rc, d->host.error.message);
+  if (info) *info = d->host.info;
+  return MIJPEG_OK;
+}
+
+static int ensure_coef_store(mijpeg_decoder *d, size_t count)
+{
+  if (d->coef_host_cap < count) {
+    if (d->device >= 0) {
+      if (d->coef_host) (void)hipHostFree(d->coef_host);
+      d->coef_host = nullptr;
+      d->coef_host_cap = 0;
+      HIP_TRY(d, hipHostMalloc((void **)&d->coef_host, count * sizeof(int16_t), hipHostMallocDefault));
+    } else {
+      free(d->coef_host);
+      d->coef_host = (int16_t *)malloc(count * sizeof(int16_t));
+      if (!d->coef_host) return set_error(d, MIJPEG_ERR_OUT_OF_MEMORY, "out of memory for the coefficient store");
+    }
+    d->coef_host_cap = count;
+  }
+  if (d->device >= 0 && d->coef_dev_cap < count) {
+    if (d->coef_dev) (void)hipFree(d->coef_dev);
+    d->coef_dev = nullptr;
+    d->coef_dev_cap = 0;
+    HIP_TRY(d, hipMalloc((void **)&d->coef_dev, count * sizeof(int16_t)));
+    d->coef_dev_cap = count;
+  }
+  return MIJPEG_OK;
+}
+
+int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
+  if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
+  int rc = d->host.parse(d->data, d->size, false);
+  if (rc) return set_error(d, rc, d->host.error.message);
+  d->parsed = true;
+  const mijpeg_info &f = d->host.info;
+  rc = ensure_coef_store(d, (size_t)f.coef_count);
+  if (rc) return rc;
+  d->img_valid = false;
+  d->uploaded = false;
+
+  hipError_t copy_err = hipSuccess;
+  std::function<void(int, int)> cb;
+  if (d->device >= 0) {
+    // stream finished MCU-row bands to the device while the workers decode the rest
+    (void)hipEventRecord(d->ev0, d->stream);
+    cb = [&](int r0, int r1) {
+      for (int c = 0; c < f.components; c++) {
+        const size_t row = (size_t)f.blocks_w[c] * 64 * f.vsamp[c]; // int16 per MCU row of this component
+        const size_t off = (size_t)f.coef_offset[c] + row * r0, cnt = row * (r1 - r0);
+        hipError_t e = hipMemcpyAsync(d->coef_dev + off, d->coef_host + off, cnt * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
+        if (e != hipSuccess) copy_err = e;
+      }
+    };
+  }
+  rc = d->host.decode(d->coef_host, threads, cb);
+  d->timing[0] = d->host.huffman_seconds;
+  if (rc) return set_error(d, rc, d->host.error.message);
+  if (copy_err != hipSuccess) return hip_fail(d, copy_err, "hipMemcpyAsync(coefficients)");
+  d->decoded = true;
+  if (d->device >= 0) {
+    (void)hipEventRecord(d->ev1, d->stream);
+    d->uploaded = true;
+  }
+  return MIJPEG_OK;
+}
+
+int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info)
+{
+  if (!d || !info) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
+  *info = d->host.info;
+  return MIJPEG_OK;
+}
+
+const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component)
+{
+  if (!d || !d->decoded || component < 0 || component >= d->host.info.components) return nullptr;
+  return d->coef_host + d->host.info.coef_offset[component];
+}
+
+const int16_t *mijpeg_device_coefficients(mijpeg_decoder *d) { return (d && d->uploaded) ? d->coef_dev : nullptr; }
+
+int mijpeg_last_error(mijpeg_decoder *d, const char **message)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (message) *message = d->err_code ? d->err_msg.c_str() : nullptr;
+  return d->err_code;
+}
+
+int mijpeg_last_timing(mijpeg_decoder *d, double out_seconds[4])
+{
+  if (!d || !out_seconds) return MIJPEG_ERR_INVALID_PARAMETER;
+  for (int i = 0; i < 4; i++) out_seconds[i] = d->timing[i];
+  return MIJPEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stateless batch launch
+// ------------------------------------------------------------------------------------------------
+static bool is_420(const mijpeg_info &f)
+{
+  return f.components == 3 && f.hsamp[0] == 2 && f.vsamp[0] == 2 && f.hsamp[1] == 1 && f.vsamp[1] == 1 &&
+         f.hsamp[2] == 1 && f.vsamp[2] == 1;
+}
+
+static bool use_fused420(const mijpeg_batch *b)
+{
+  return is_420(b->info) && b->info.ycbcr && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM));
+}
+
+const char *mijpeg_kernel_name(const mijpeg_batch *b)
+{
+  if (!b) return "";
+  return use_fused420(b) ? "fused420_kernel" : "idct_planes_kernel+upsample_color_kernel";
+}
+
+size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
+{
+  if (!b || use_fused420(b)) return 0;
+  return (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames;
+}
+
+int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
+{
+  if (!b || !b->coef_dev || !b->out_dev || b->frames < 1) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (b->quant_dev) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: not yet
+  const mijpeg_info &f = b->info;
+  if (f.precision != 8 || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
+  const bool fast = f.fast_arith && !(b->flags & MIJPEG_FLAG_FORCE_SAFE);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (use_fused420(b)) {
+    Fused420Args a;
+    memset(&a, 0, sizeof(a));
+    a.coef = b->coef_dev;
+    a.coef_frame_stride = b->coef_frame_stride;
+    a.off_y = f.coef_offset[0];
+    a.off_cb = f.coef_offset[1];
+    a.off_cr = f.coef_offset[2];
+    a.out = b->out_dev;
+    a.out_frame_stride = b->out_frame_stride;
+    a.row_stride = b->out_row_stride;
+    a.width = f.width;
+    a.height = f.height;
+    a.bw_y = f.blocks_w[0];
+    a.bh_y = f.blocks_h[0];
+    a.bw_c = f.blocks_w[1];
+    a.bh_c = f.blocks_h[1];
+    a.cw = (f.width + 1) / 2;
+    a.ch = (f.height + 1) / 2;
+    a.tiles_x = (f.width + 127) / 128;
+    a.tiles_y = (f.height + 127) / 128;
+    a.frames = b->frames;
+    a.aligned8 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 7) == 0;
+    for (int c = 0; c < 3; c++) memcpy(a.q[c], f.quant[f.quant_index[c]], 128);
+    rc = launch_fused420(a, fast, s);
+  } else {
+    if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
+    GenericArgs a;
+    memset(&a, 0, sizeof(a));
+    a.coef = b->coef_dev;
+    a.coef_frame_stride = b->coef_frame_stride;
+    a.samples = (int32_t *)b->workspace;
+    a.sample_frame_stride = f.coef_count;
+    a.out = b->out_dev;
+    a.out_frame_stride = b->out_frame_stride;
+    a.row_stride = b->out_row_stride;
+    a.width = f.width;
+    a.height = f.height;
+    a.ncomp = f.components;
+    a.ycbcr = (f.ycbcr && !(b->flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM)) ? 1 : 0;
+    a.frames = b->frames;
+    for (int c = 0; c < f.components; c++) {
+      a.coef_off[c] = f.coef_offset[c];
+      a.sample_off[c] = f.coef_offset[c];
+      a.bw[c] = f.blocks_w[c];
+      a.bh[c] = f.blocks_h[c];
+      a.subx[c] = f.subx[c];
+      a.suby[c] = f.suby[c];
+      a.cw[c] = (f.width + f.subx[c] - 1) / f.subx[c];
+      a.ch[c] = (f.height + f.suby[c] - 1) / f.suby[c];
+      memcpy(a.q[c], f.quant[f.quant_index[c]], 128);
+    }
+    rc = launch_generic(a, fast, s);
+  }
+  return rc ? MIJPEG_ERR_DEVICE : MIJPEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder-object reconstruction
+// ------------------------------------------------------------------------------------------------
+static int ensure_dev(mijpeg_decoder *d, void **ptr, size_t *cap, size_t bytes)
+{
+  if (*cap >= bytes) return MIJPEG_OK;
+  if (*ptr) (void)hipFree(*ptr);
+  *ptr = nullptr;
+  *cap = 0;
+  HIP_TRY(d, hipMalloc(ptr, bytes));
+  *cap = bytes;
+  return MIJPEG_OK;
+}
+
+int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_stride, uint32_t flags, int sync)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
+  if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
+  if (!dst_device) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "destination pointer is NULL");
+  HIP_TRY(d, hipSetDevice(d->device));
+  mijpeg_batch b;
+  memset(&b, 0, sizeof(b));
+  b.info = d->host.info;
+  b.coef_dev = d->coef_dev;
+  b.coef_frame_stride = b.info.coef_count;
+  b.out_dev = (uint8_t *)dst_device;
+  b.out_row_stride = row_stride;
+  b.out_frame_stride = row_stride * b.info.height;
+  b.frames = 1;
+  b.flags = flags;
+  const size_t ws = mijpeg_workspace_bytes(&b);
+  if (ws) {
+    int rc = ensure_dev(d, (void **)&d->ws_dev, &d->ws_cap, ws);
+    if (rc) return rc;
+    b.workspace = d->ws_dev;
+    b.workspace_bytes = d->ws_cap;
+  }
+  const int rc = mijpeg_launch_reconstruct(&b, d->stream);
+  if (rc) return set_error(d, rc, rc == MIJPEG_ERR_DEVICE ? std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError())
+                                                           : std::string("reconstruction not available for this stream"));
+  if (sync) HIP_TRY(d, hipStreamSynchronize(d->stream));
+  return MIJPEG_OK;
+}
+
+int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp,
+                            int32_t max_comp, uint32_t flags, void *const dst[MIJPEG_MAX_COMPONENTS],
+                            const int32_t bytes_per_pixel[MIJPEG_MAX_COMPONENTS],
+                            const int32_t bytes_per_row[MIJPEG_MAX_COMPONENTS])
+{
+  if (!d || !dst || !bytes_per_pixel || !bytes_per_row) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
+  if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
+  const mijpeg_info &f = d->host.info;
+  const int nc = f.components;
+  // the whole frame is reconstructed once per (stream, flags) and then served rectangle by rectangle,
+  // which is what the stripe loop of cmd/reconstruct.cpp:334-342 asks for
+  if (!d->img_valid || d->img_flags != flags) {
+    HIP_TRY(d, hipSetDevice(d->device));
+    const size_t bytes = (size_t)f.width * f.height * nc;
+    const size_t row = ((size_t)f.width * nc + 7) & ~(size_t)7;
+    const size_t padded = row * f.height;
+    int rc = ensure_dev(d, (void **)&d->img_dev, &d->img_dev_cap, padded);
+    if (rc) return rc;
+    if (d->img_host_cap < padded) {
+      if (d->img_host) (void)hipHostFree(d->img_host);
+      d->img_host = nullptr;
+      d->img_host_cap = 0;
+      HIP_TRY(d, hipHostMalloc((void **)&d->img_host, padded, hipHostMallocDefault));
+      d->img_host_cap = padded;
+    }
+    (void)bytes;
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    HIP_TRY(d, hipStreamSynchronize(d->stream)); // uploads complete
+    auto t1 = clk::now();
+    rc = mijpeg_reconstruct_device(d, d->img_dev, (int64_t)row, flags, 1);
+    if (rc) return rc;
+    auto t2 = clk::now();
+    HIP_TRY(d, hipMemcpyAsync(d->img_host, d->img_dev, padded, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    auto t3 = clk::now();
+    d->timing[1] = std::chrono::duration<double>(t1 - t0).count();
+    d->timing[2] = std::chrono::duration<double>(t2 - t1).count();
+    d->timing[3] = std::chrono::duration<double>(t3 - t2).count();
+    d->img_valid = true;
+    d->img_flags = flags;
+  }
+  if (min_x < 0) min_x = 0;
+  if (min_y < 0) min_y = 0;
+  if (max_x >= f.width) max_x = f.width - 1;
+  if (max_y >= f.height) max_y = f.height - 1;
+  if (min_comp < 0) min_comp = 0;
+  if (max_comp >= nc) max_comp = nc - 1;
+  const size_t row = ((size_t)f.width * nc + 7) & ~(size_t)7;
+  // interleaved destination (the layout cmd/bitmaphook.cpp hands out): whole lines at once
+  bool interleaved = min_comp == 0 && max_comp == nc - 1 && dst[0];
+  for (int c = 0; c < nc && interleaved; c++)
+    interleaved = dst[c] == (uint8_t *)dst[0] + c && bytes_per_pixel[c] == nc && bytes_per_row[c] == bytes_per_row[0];
+  if (interleaved) {
+    for (int y = min_y; y <= max_y; y++)
+      memcpy((uint8_t *)dst[0] + (ptrdiff_t)y * bytes_per_row[0] + (ptrdiff_t)min_x * nc,
+             d->img_host + (size_t)y * row + (size_t)min_x * nc, (size_t)(max_x - min_x + 1) * nc);
+    return MIJPEG_OK;
+  }
+  for (int c = min_comp; c <= max_comp; c++) {
+    if (!dst[c]) continue;
+    for (int y = min_y; y <= max_y; y++) {
+      const uint8_t *src = d->img_host + (size_t)y * row + (size_t)min_x * nc + c;
+      uint8_t *out = (uint8_t *)dst[c] + (ptrdiff_t)y * bytes_per_row[c] + (ptrdiff_t)min_x * bytes_per_pixel[c];
+      const int n = max_x - min_x + 1;
+      const int bpp = bytes_per_pixel[c];
+      if (nc == 1 && bpp == 1) {
+        memcpy(out, src, (size_t)n);
+      } else {
+        for (int x = 0; x < n; x++) out[(ptrdiff_t)x * bpp] = src[(size_t)x * nc];
+      }
+    }
+  }
+  return MIJPEG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,102 @@
+// host_decoder.hpp -- host side of the path: marker parsing and restart-interval-parallel Huffman
+// decoding into planar int16 coefficient planes.  No HIP in here: this part also runs (and is
+// tested) on a box without a GPU.
+//
+// Reference behaviour reproduced (happy path; corrupt streams are reported, not resynchronised):
+//   codestream/tables.cpp:1003-...      marker dispatch (DQT, DHT, DRI, APP14)
+//   marker/quantization.cpp:474-537     DQT, stored de-zigzagged
+//   coding/huffmantemplate.cpp:802-905  DHT -> decoder tables
+//   marker/frame.cpp:111-..             SOF0/SOF1
+//   marker/scan.cpp:163-..              SOS
+//   codestream/sequentialscan.cpp:381-428, 678-773   ParseMCU / DecodeBlock
+//   codestream/entropyparser.cpp:117-135             restart markers
+//   io/bitstream.cpp:56-118                          byte stuffing, zero bits at a marker
+#ifndef MIJ_HOST_DECODER_HPP
+#define MIJ_HOST_DECODER_HPP
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/mijpeg.h"
+
+namespace mij {
+
+struct HuffTable {
+  bool defined = false;
+  uint8_t counts[16] = {0};
+  uint8_t values[256] = {0};
+  // decoder: LOOKAHEAD-bit direct table, entry = (length << 8) | symbol, 0 = longer code
+  static constexpr int LOOKAHEAD = 10;
+  uint16_t fast[1 << LOOKAHEAD];
+  int32_t maxcode[18]; // maxcode[l] for codes of length l (left-aligned compare uses plain codes)
+  int32_t valoff[17];  // values index = code + valoff[l]
+  void build();
+};
+
+struct ScanComponent {
+  int comp = 0; // index into the frame's components
+  int td = 0, ta = 0;
+};
+
+struct Scan {
+  int ncomp = 0;
+  ScanComponent sc[MIJPEG_MAX_COMPONENTS];
+  HuffTable dc[MIJPEG_MAX_COMPONENTS], ac[MIJPEG_MAX_COMPONENTS]; // snapshot per scan component
+  int restart_interval = 0;
+  int mcus_x = 0, mcus_y = 0; // MCU grid of THIS scan
+  size_t ecs_begin = 0, ecs_end = 0; // entropy coded data [begin, end) in the input
+  std::vector<size_t> interval_begin; // byte offset of every restart interval (first = ecs_begin)
+};
+
+struct StreamError {
+  int code = 0;
+  std::string message;
+};
+
+class HostDecoder {
+public:
+  // Parse SOI .. EOI structure: fills info, scans (with their restart-interval offsets).
+  // header_only stops after the first SOS header has been seen.
+  int parse(const uint8_t *data, size_t size, bool header_only);
+
+  // Entropy-decode every scan into `coef` (info.coef_count int16, layout info.coef_offset).
+  // on_rows_done(first_mcu_row, end_mcu_row) is called from the calling thread, in order, as
+  // bands of frame MCU rows become final (while later bands are still being decoded when the
+  // last scan is interleaved; otherwise once at the end).  Used for streaming uploads; may be empty.
+  int decode(int16_t *coef, int threads, const std::function<void(int, int)> &on_rows_done);
+
+  mijpeg_info info{};
+  std::vector<Scan> scans;
+  StreamError error;
+  double huffman_seconds = 0;
+
+private:
+  const uint8_t *data_ = nullptr;
+  size_t size_ = 0;
+  HuffTable dc_[4], ac_[4];
+  uint16_t quant_[4][64];
+  bool quant_defined_[4] = {false, false, false, false};
+  int restart_interval_ = 0;
+  int adobe_transform_ = -1;
+  bool have_frame_ = false;
+  int comp_id_[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
+  // per scan: end offset of every restart interval and the RSTn code that terminated it
+  std::vector<size_t> interval_end_;
+  std::vector<uint8_t> rst_code_;
+  std::vector<std::vector<size_t>> scan_interval_end_;
+  std::vector<std::vector<uint8_t>> scan_rst_code_;
+  int fail(int code, const char *msg);
+  int parse_sof(const uint8_t *p, int n);
+  int parse_sos(const uint8_t *p, int n, size_t ecs_begin);
+  void find_intervals(Scan &s);
+};
+
+// zig-zag position -> natural index (dct/dct.cpp:57-74), generated at start-up
+extern const uint8_t *scan_order();
+
+} // namespace mij
+#endif

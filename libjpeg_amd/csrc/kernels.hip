@@ -1,0 +1,627 @@
+// kernels.hip -- CDNA4 (gfx950) kernels of the JPEG block-reconstruction path.
+//
+// What they replace in the reference (thorfdbg/libjpeg), all integer arithmetic, bit-exact:
+//   dequant + 8x8 inverse DCT   dct/idct.cpp:226-339            (IDCT<4,LONG,false,false>)
+//   centred chroma upsampling   upsampling/upsampler.cpp:83-117, 136-168, 283-307 (+ 3x/4x cores)
+//                               upsampling/upsamplerbase.cpp:300-327 (edge replication)
+//   YCbCr->RGB / identity       colortrafo/ycbcrtrafo.cpp:842-856, 921-936, 974-1006
+//   the block loop around them  control/blockbitmaprequester.cpp:1013-1224
+//
+// Two families:
+//   fused420_kernel   the hot path (4:2:0, three components): one launch turns int16 coefficient planes
+//                     into interleaved RGB; chroma never leaves the CU (LDS), luma never leaves registers.
+//   generic kernels   any sampling 1..4 x 1..4, 1..4 components: IDCT to int32 planes, then a per-line
+//                     upsample+colour kernel.  Correct everywhere, used for everything that is not 4:2:0.
+//
+// Mapping (MI355X-first): ONE LANE OWNS ONE 8x8 BLOCK.  Both IDCT passes run out of the
+// lane's registers (64 VGPRs), so there is no transposition and no cross-lane traffic in the transform;
+// the coefficient rows reach the owning lane through a 2 KB-per-wave LDS staging buffer that is fed by
+// fully coalesced 16-byte loads (64 lanes x 16 B = 1 KiB contiguous per instruction).
+//
+// Arithmetic flavours: FAST uses 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24, full rate) and 32-bit
+// colour accumulation; it is selected by the host only when every block of the frame satisfies
+// sum_k |c_k| * q_k < 16384, which bounds every intermediate below 2^31 and every multiplicand below 2^23
+// (DESIGN.md "range check"); every 8-bit image produced by a forward DCT satisfies it.  SAFE reproduces
+// the reference's wrap-around LONG arithmetic and its 64-bit colour accumulation for any input.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mij {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ----------------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ int mulc(int a, int c)
+{
+  if (FAST) return __mul24(a, c);
+  return (int)((unsigned)a * (unsigned)c);
+}
+__device__ __forceinline__ int addw(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int subw(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+__device__ __forceinline__ int shlw(int a, int n) { return (int)((unsigned)a << n); }
+
+// floor((x + 2^(n-1)) / 2^n) with the addition carried out beyond 32 bits, as the reference's
+// `(x + (1L << (n-1))) >> n` does on LP64 (dct/idct.cpp:70-78).
+template <bool FAST, int N>
+__device__ __forceinline__ int round_shift(int x)
+{
+  if (FAST) return (x + (1 << (N - 1))) >> N;
+  return (x >> N) + (((x & ((1 << N) - 1)) + (1 << (N - 1))) >> N);
+}
+
+// TO_FIX(x) = WORD(x * 512 + 0.5), dct/idct.cpp:65
+#define FIX9(x) ((int)((x) * 512.0 + 0.5))
+
+// One 8-point inverse transform (dct/idct.cpp:233-283 / :287-332), SHIFT = 9 (rows) or 12 (columns).
+template <bool FAST, int SHIFT>
+__device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int &s4, int &s5, int &s6, int &s7)
+{
+  // even part
+  int z1 = mulc<FAST>(addw(s2, s6), FIX9(0.541196100));
+  int tmp2 = addw(z1, mulc<FAST>(s6, -FIX9(1.847759065)));
+  int tmp3 = addw(z1, mulc<FAST>(s2, FIX9(0.765366865)));
+  int tmp0 = shlw(addw(s0, s4), 9);
+  int tmp1 = shlw(subw(s0, s4), 9);
+  if (FAST) { // fold the rounding constant into the even part: it reaches every output exactly once
+    tmp0 += 1 << (SHIFT - 1);
+    tmp1 += 1 << (SHIFT - 1);
+  }
+  int tmp10 = addw(tmp0, tmp3), tmp13 = subw(tmp0, tmp3);
+  int tmp11 = addw(tmp1, tmp2), tmp12 = subw(tmp1, tmp2);
+  // odd part
+  int tz1 = addw(s7, s1), tz2 = addw(s5, s3), tz3 = addw(s7, s3), tz4 = addw(s5, s1);
+  int z5 = mulc<FAST>(addw(tz3, tz4), FIX9(1.175875602));
+  int o0 = mulc<FAST>(s7, FIX9(0.298631336));
+  int o1 = mulc<FAST>(s5, FIX9(2.053119869));
+  int o2 = mulc<FAST>(s3, FIX9(3.072711026));
+  int o3 = mulc<FAST>(s1, FIX9(1.501321110));
+  int y1 = mulc<FAST>(tz1, -FIX9(0.899976223));
+  int y2 = mulc<FAST>(tz2, -FIX9(2.562915447));
+  int y3 = addw(mulc<FAST>(tz3, -FIX9(1.961570560)), z5);
+  int y4 = addw(mulc<FAST>(tz4, -FIX9(0.390180644)), z5);
+  o0 = addw(o0, addw(y1, y3));
+  o1 = addw(o1, addw(y2, y4));
+  o2 = addw(o2, addw(y2, y3));
+  o3 = addw(o3, addw(y1, y4));
+  if (FAST) {
+    s0 = (tmp10 + o3) >> SHIFT; s7 = (tmp10 - o3) >> SHIFT;
+    s1 = (tmp11 + o2) >> SHIFT; s6 = (tmp11 - o2) >> SHIFT;
+    s2 = (tmp12 + o1) >> SHIFT; s5 = (tmp12 - o1) >> SHIFT;
+    s3 = (tmp13 + o0) >> SHIFT; s4 = (tmp13 - o0) >> SHIFT;
+  } else {
+    s0 = round_shift<false, SHIFT>(addw(tmp10, o3)); s7 = round_shift<false, SHIFT>(subw(tmp10, o3));
+    s1 = round_shift<false, SHIFT>(addw(tmp11, o2)); s6 = round_shift<false, SHIFT>(subw(tmp11, o2));
+    s2 = round_shift<false, SHIFT>(addw(tmp12, o1)); s5 = round_shift<false, SHIFT>(subw(tmp12, o1));
+    s3 = round_shift<false, SHIFT>(addw(tmp13, o0)); s4 = round_shift<false, SHIFT>(subw(tmp13, o0));
+  }
+}
+
+// Dequantise the eight packed rows of a block and run both passes in registers.
+// rows[k] holds coefficient row k (8 x int16, natural order), q the component's 64 deltas.
+// Result v[y*8+x] = sample * 16 (COLOR_BITS = 4 fractional bits), not clamped.
+template <bool FAST>
+__device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const uint16_t *__restrict__ q, int (&v)[64])
+{
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const unsigned w[4] = {rows[k].x, rows[k].y, rows[k].z, rows[k].w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int lo = (int)(short)(w[i] & 0xffffu);
+      int hi = ((int)w[i]) >> 16;
+      v[k * 8 + 2 * i] = mulc<FAST>(lo, (int)q[k * 8 + 2 * i] << 4);
+      v[k * 8 + 2 * i + 1] = mulc<FAST>(hi, (int)q[k * 8 + 2 * i + 1] << 4);
+    }
+  }
+  v[0] = addw(v[0], 128 << 7); // dcoffset = 2^(P-1) << (preshift + 3), P = 8 (idct.cpp:231, :246)
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    idct_1d<FAST, 9>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5],
+                     v[r * 8 + 6], v[r * 8 + 7]);
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    idct_1d<FAST, 12>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Coalesced block fetch: the wave reads 64 blocks x 128 B with eight 1-KiB-per-instruction loads
+// (lane i takes the i-th 16-byte chunk), then hands every lane the eight rows of ITS block through a
+// 2 KB LDS staging buffer, 16 blocks at a time.  The chunk position inside a block is XOR-swizzled
+// with the block index so that both the 8-lane-group writes and the 16-lane-group reads are free of
+// bank conflicts (MI355X_MICROARCH.md, LDS: ds_write_b128 / ds_read_b128 lane groups).
+// blockptr(n) returns the address of local block n (0..63) or nullptr (-> zeros).
+// ----------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void fetch_blocks(u32x4 (&rows)[8], u32x4 *stage, int lane, F blockptr)
+{
+  u32x4 raw[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    const int16_t *p = blockptr((lane >> 3) + 8 * m);
+    raw[m] = p ? *(reinterpret_cast<const u32x4 *>(p) + (lane & 7)) : u32x4{0, 0, 0, 0};
+  }
+  const int k = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int nb = (lane >> 3) + 8 * t;
+      stage[nb * 8 + (k ^ (nb & 7))] = raw[2 * j + t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if ((lane >> 4) == j) {
+      const int nb = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 8; r++) rows[r] = stage[nb * 8 + (r ^ (nb & 7))];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// colour transform of one pixel (colortrafo/ycbcrtrafo.cpp:842-850 + clamp :921-936)
+// FIX_BITS = 13, matrix = TO_FIX of {1,0,1.402; 1,-0.3441362861,-0.7141362859; 1,1.772,0}
+// ----------------------------------------------------------------------------------------------
+#define L_CR_R 11485
+#define L_CB_G 2819
+#define L_CR_G 5850
+#define L_CB_B 14516
+
+__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
+
+template <bool FAST>
+__device__ __forceinline__ void ycc_to_rgb(int y, int cb, int cr, int &r, int &g, int &b)
+{
+  if (FAST) {
+    // dc shift (128 << 4 = 2048) and rounding folded into the constants
+    const int KR = 65536 - 2048 * L_CR_R;
+    const int KG = 65536 + 2048 * (L_CB_G + L_CR_G);
+    const int KB = 65536 - 2048 * L_CB_B;
+    const int y13 = y << 13;
+    r = clamp255((__mul24(cr, L_CR_R) + (y13 + KR)) >> 17);
+    g = clamp255((__mul24(cb, -L_CB_G) + __mul24(cr, -L_CR_G) + (y13 + KG)) >> 17);
+    b = clamp255((__mul24(cb, L_CB_B) + (y13 + KB)) >> 17);
+  } else {
+    const long long yy = (long long)y * 8192 + 65536;
+    const long long cbl = (long long)cb - 2048, crl = (long long)cr - 2048;
+    long long rr = (yy + crl * L_CR_R) >> 17;
+    long long gg = (yy - cbl * L_CB_G - crl * L_CR_G) >> 17;
+    long long bb = (yy + cbl * L_CB_B) >> 17;
+    r = (int)(rr < 0 ? 0 : (rr > 255 ? 255 : rr));
+    g = (int)(gg < 0 ? 0 : (gg > 255 ? 255 : gg));
+    b = (int)(bb < 0 ? 0 : (bb > 255 ? 255 : bb));
+  }
+}
+
+// COLOR_TO_INT + clamp (identity transformation, tools/numerics.hpp:69)
+template <bool FAST>
+__device__ __forceinline__ int color_to_int(int x)
+{
+  if (FAST) return clamp255((x + 8) >> 4);
+  long long v = ((long long)x + 8) >> 4;
+  return (int)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// (a + 3 b + r) >> 2 in wrapping 32-bit arithmetic (the reference's LONG), upsampler.cpp filter taps
+__device__ __forceinline__ int tap13(int a, int b, int r) { return (int)((unsigned)a + 3u * (unsigned)b + (unsigned)r) >> 2; }
+
+// ==============================================================================================
+// fused 4:2:0 kernel
+// ==============================================================================================
+// Work decomposition: one workgroup (256 threads = 4 waves) reconstructs a 128x128-pixel tile =
+// 8x8 MCUs = 16x16 luma blocks + (8+2)x(8+2) chroma blocks per chroma component (one block of halo
+// all around, recomputed from the coefficients instead of exchanged between workgroups).
+//   phase A  waves 0,1 transform the 100 Cb blocks, waves 2,3 the 100 Cr blocks, and store the
+//            66x66 samples the tile needs into LDS (int32, pitch 72 -> 16-byte aligned block rows)
+//   fix-up   (tiles on an image edge only) replicate the last valid chroma column/row outwards,
+//            upsamplerbase.cpp:322-323 and the top/bottom line duplication of upsampler.cpp:100-112
+//   phase B  every lane transforms one luma block, keeps it in registers, upsamples its 8x8 chroma
+//            neighbourhood from LDS (vertical then horizontal filter, including the in-place aliasing
+//            of output column 1), converts to RGB and stores 8 lines x 24 bytes.
+constexpr int F420_TILE_BLOCKS = 16;      // luma blocks per tile side
+constexpr int F420_CGRID = 10;            // chroma blocks per tile side incl. halo
+constexpr int F420_CROWS = 66;            // chroma lines kept in LDS (64 + 2 halo)
+constexpr int F420_CPITCH = 72;           // dwords per LDS chroma line; column pc <-> chroma x_rel = pc - 4
+constexpr int F420_THREADS = 256;
+
+template <bool FAST>
+__global__ __launch_bounds__(F420_THREADS) void fused420_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) int cplane[2][F420_CROWS * F420_CPITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give every XCD
+  // a contiguous run of logical tiles: neighbouring tiles (which re-read each other's chroma halo) then
+  // share an L2.
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  {
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  // ------------------------------------------------------------------ phase A: chroma -> LDS
+  {
+    const int comp = wave >> 1; // 0 = Cb, 1 = Cr (wave-uniform)
+    const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
+    const int gx0 = tx * 8 - 1, gy0 = ty * 8 - 1;
+    const int base = (wave & 1) * 64;
+    u32x4 rows[8];
+    fetch_blocks(rows, stage, lane, [&](int n) -> const int16_t * {
+      const int idx = base + n;
+      const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
+      const int gx = gx0 + cbx, gy = gy0 + cby;
+      if (idx >= F420_CGRID * F420_CGRID || gx < 0 || gy < 0 || gx >= a.bw_c || gy >= a.bh_c) return nullptr;
+      return plane + ((int64_t)gy * a.bw_c + gx) * 64;
+    });
+    const int idx = base + lane;
+    const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
+    const int gx = gx0 + cbx, gy = gy0 + cby;
+    if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
+      int v[64];
+      dequant_idct<FAST>(rows, a.q[1 + comp], v);
+      int *cp = cplane[comp];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int pr = 8 * cby + r - 7;
+        if (pr >= 0 && pr < F420_CROWS) {
+          if (cbx == 0) {
+            cp[pr * F420_CPITCH + 3] = v[r * 8 + 7];
+          } else if (cbx == F420_CGRID - 1) {
+            cp[pr * F420_CPITCH + 68] = v[r * 8 + 0];
+          } else {
+            i32x4 *dst = reinterpret_cast<i32x4 *>(cp + pr * F420_CPITCH + 8 * cbx - 4);
+            dst[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
+            dst[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ edge fix-up (uniform branch)
+  {
+    const int last_col = a.cw - 1 - tx * 64; // last valid chroma column, tile-relative
+    const int last_row = a.ch - 1 - ty * 64;
+    const bool edge = (tx == 0) | (ty == 0) | (last_col < 64) | (last_row < 64);
+    if (edge) {
+      if (tid < 2 * F420_CROWS) { // one thread per stored line: replicate columns
+        int *p = cplane[tid / F420_CROWS] + (tid % F420_CROWS) * F420_CPITCH;
+        if (tx == 0) p[3] = p[4];
+        if (last_col < 64) {
+          const int v = p[last_col + 4];
+          for (int pc = last_col + 5; pc <= 68; pc++) p[pc] = v;
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * F420_CROWS) { // one thread per stored column: replicate lines
+        int *p = cplane[tid / F420_CROWS] + 3 + (tid % F420_CROWS);
+        if (ty == 0) p[0] = p[F420_CPITCH];
+        if (last_row < 64) {
+          const int v = p[(last_row + 1) * F420_CPITCH];
+          for (int pr = last_row + 2; pr < F420_CROWS; pr++) p[pr * F420_CPITCH] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ phase B: luma + colour
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  const int y_plane_w = a.bw_y;
+  u32x4 rows[8];
+  {
+    const int16_t *__restrict__ plane = coef + a.off_y;
+    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+    fetch_blocks(rows, stage, lane, [&](int n) -> const int16_t * {
+      const int x = gbx0 + (n & 15), y = gby0 + (n >> 4);
+      if (x >= a.bw_y || y >= a.bh_y) return nullptr;
+      return plane + ((int64_t)y * y_plane_w + x) * 64;
+    });
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
+  int yv[64];
+  dequant_idct<FAST>(rows, a.q[0], yv);
+
+  uint8_t *__restrict__ out = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y0 * a.row_stride + (int64_t)X0 * 3;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = a.aligned8 && npx == 8;
+
+  // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns pc = 4 bx + 3 + j
+  const int *cb_base = cplane[0] + (4 * by) * F420_CPITCH + 4 * bx;
+  const int *cr_base = cplane[1] + (4 * by) * F420_CPITCH + 4 * bx;
+
+  auto load6 = [](const int *p, int (&d)[6]) {
+    // p is 16-byte aligned; wanted: p[3..8]
+    const i32x4 mid = *reinterpret_cast<const i32x4 *>(p + 4);
+    d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
+  };
+
+  int cbT[6], cbC[6], cbB[6], crT[6], crC[6], crB[6];
+  load6(cb_base, cbT); load6(cb_base + F420_CPITCH, cbC);
+  load6(cr_base, crT); load6(cr_base + F420_CPITCH, crC);
+
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    load6(cb_base + (m + 2) * F420_CPITCH, cbB);
+    load6(cr_base + (m + 2) * F420_CPITCH, crB);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int l = 2 * m + half;
+      // vertical filter (upsampler.cpp:149-165): even output lines look up, odd ones down; the
+      // rounding constant alternates with the buffer column parity
+      int vb[6], vr[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const int rnd = ((j & 1) ^ half) ? 1 : 2;
+        vb[j] = tap13(half ? cbB[j] : cbT[j], cbC[j], rnd);
+        vr[j] = tap13(half ? crB[j] : crT[j], crC[j], rnd);
+      }
+      // horizontal filter in place (upsampler.cpp:291-303); src[k] = v[k + 1]
+      int ub[8], ur[8];
+      auto hfilt = [](const int (&v)[6], int (&o)[8]) {
+        o[7] = tap13(v[5], v[4], 1);
+        o[6] = tap13(v[3], v[4], 2);
+        o[5] = tap13(v[4], v[3], 1);
+        o[4] = tap13(v[2], v[3], 2);
+        o[3] = tap13(v[3], v[2], 1);
+        o[2] = tap13(v[1], v[2], 2);
+        o[1] = tap13(o[2], v[1], 1); // src[1] has already been overwritten by out[2]
+        o[0] = tap13(v[0], v[1], 2);
+      };
+      hfilt(vb, ub);
+      hfilt(vr, ur);
+      if (l < nln) {
+        unsigned px[24];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          int r, g, b;
+          ycc_to_rgb<FAST>(yv[l * 8 + x], ub[x], ur[x], r, g, b);
+          px[3 * x] = r; px[3 * x + 1] = g; px[3 * x + 2] = b;
+        }
+        uint8_t *dst = out + (int64_t)l * a.row_stride;
+        if (fast_store) {
+          unsigned w[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) w[i] = px[4 * i] | (px[4 * i + 1] << 8) | (px[4 * i + 2] << 16) | (px[4 * i + 3] << 24);
+          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+          __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
+          __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
+          __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+        } else {
+#pragma unroll
+          for (int x = 0; x < 8; x++)
+            if (x < npx) {
+              dst[3 * x] = (uint8_t)px[3 * x]; dst[3 * x + 1] = (uint8_t)px[3 * x + 1]; dst[3 * x + 2] = (uint8_t)px[3 * x + 2];
+            }
+        }
+      }
+    }
+    // slide the three-line window
+#pragma unroll
+    for (int j = 0; j < 6; j++) { cbT[j] = cbC[j]; cbC[j] = cbB[j]; crT[j] = crC[j]; crC[j] = crB[j]; }
+  }
+}
+
+// ==============================================================================================
+// generic path, kernel 1: dequant + IDCT of every block of every component into int32 sample planes
+// ==============================================================================================
+template <bool FAST>
+__global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
+{
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // grid.x covers 64-block groups of one (frame, component): blockIdx.y = frame * ncomp + comp
+  const int comp = blockIdx.y % a.ncomp, frame = blockIdx.y / a.ncomp;
+  const int nblocks = a.bw[comp] * a.bh[comp];
+  const int first = (blockIdx.x * 4 + wave) * 64;
+  if (first >= nblocks) return;
+  const int16_t *__restrict__ plane = a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp];
+  u32x4 rows[8];
+  fetch_blocks(rows, stage_all[wave], lane, [&](int n) -> const int16_t * {
+    return (first + n < nblocks) ? plane + (int64_t)(first + n) * 64 : nullptr;
+  });
+  const int blk = first + lane;
+  if (blk >= nblocks) return;
+  int v[64];
+  dequant_idct<FAST>(rows, a.q[comp], v);
+  const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
+  const int pitch = a.bw[comp] * 8;
+  int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    i32x4 *d = reinterpret_cast<i32x4 *>(dst + (int64_t)r * pitch);
+    d[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
+    d[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
+  }
+}
+
+// ==============================================================================================
+// generic path, kernel 2: one thread = one line of one 8-pixel output group; upsample every
+// component (any factor 1..4) exactly like the reference's buffer code, transform, store.
+// ==============================================================================================
+// Line buffer of the reference for output line Y of the 8x8 block at X0 (upsampler.cpp:83-117):
+// vertical core output for buffer columns j = 0..7, then the in-place horizontal core.
+__device__ __forceinline__ int f8(int wa, int x, int wb, int y, int r)
+{
+  return (int)((unsigned)wa * (unsigned)x + (unsigned)wb * (unsigned)y + (unsigned)r) >> 3;
+}
+
+__device__ void upsample_line(const int *__restrict__ plane, int pitch, int cw, int ch, int sx, int sy, int X0, int Y,
+                              int (&o)[8])
+{
+  const int y = Y / sy, ymod = Y - y * sy;
+  const int cur = min(y, ch - 1), top = min(max(y - 1, 0), ch - 1), bot = min(cur + 1, ch - 1);
+  const int x = (sx > 1) ? X0 / sx - 1 : X0; // chroma column of buffer entry 0
+  const int *pc = plane + (int64_t)cur * pitch, *pt = plane + (int64_t)top * pitch, *pb = plane + (int64_t)bot * pitch;
+  int v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int col = min(max(x + j, 0), cw - 1);
+    const int c = pc[col];
+    const int odd = j & 1;
+    int val = c;
+    if (sy == 2) {
+      val = ymod == 0 ? tap13(pt[col], c, odd ? 1 : 2) : tap13(pb[col], c, odd ? 2 : 1);
+    } else if (sy == 3) {
+      if (ymod == 0) val = tap13(pt[col], c, odd ? 1 : 2);
+      else if (ymod == 2) val = tap13(pb[col], c, odd ? 2 : 1);
+    } else if (sy == 4) {
+      if (ymod == 0) val = f8(3, pt[col], 5, c, odd ? 3 : 4);
+      else if (ymod == 1) val = f8(1, pt[col], 7, c, odd ? 4 : 3);
+      else if (ymod == 2) val = f8(1, pb[col], 7, c, odd ? 3 : 4);
+      else val = f8(3, pb[col], 5, c, odd ? 3 : 4);
+    }
+    v[j] = val;
+  }
+  // horizontal core, literally in place like the reference (target == v, src == v + 1):
+  // the statement order below is the reference's, so an entry overwritten by an earlier output is
+  // seen by later ones exactly as there
+  if (sx == 2) { // upsampler.cpp:283-307
+    v[7] = tap13(v[5], v[4], 1);
+    v[6] = tap13(v[3], v[4], 2);
+    v[5] = tap13(v[4], v[3], 1);
+    v[4] = tap13(v[2], v[3], 2);
+    v[3] = tap13(v[3], v[2], 1);
+    const int s0 = v[1];
+    v[2] = tap13(s0, v[2], 2);
+    v[1] = tap13(v[2], s0, 1);
+    v[0] = tap13(v[0], s0, 2);
+  } else if (sx == 3) { // upsampler.cpp:313-361
+    const int xmod = X0 % 3;
+    if (xmod == 0) {
+      v[7] = v[3];
+      v[6] = tap13(v[2], v[3], 2);
+      v[5] = tap13(v[3], v[2], 1);
+      v[4] = v[2];
+      v[3] = tap13(v[1], v[2], 2);
+      v[2] = tap13(v[2], v[1], 1);
+      v[0] = tap13(v[0], v[1], 2);
+      // out[1] = src[0]: v[1] stays
+    } else if (xmod == 1) {
+      v[7] = tap13(v[4], v[3], 1);
+      v[6] = v[3];
+      v[5] = tap13(v[2], v[3], 2);
+      v[4] = tap13(v[3], v[2], 1);
+      v[3] = v[2];
+      const int s0 = v[1];
+      v[2] = tap13(s0, v[2], 2);
+      v[1] = tap13(v[2], s0, 1);
+      v[0] = s0;
+    } else {
+      v[7] = tap13(v[3], v[4], 2);
+      v[6] = tap13(v[4], v[3], 1);
+      v[5] = v[3];
+      v[4] = tap13(v[2], v[3], 2);
+      v[3] = tap13(v[3], v[2], 1);
+      const int s0 = v[1]; // out[2] = src[1]: v[2] stays
+      v[1] = tap13(s0, v[2], 2);
+      v[0] = tap13(v[2], s0, 1);
+    }
+  } else if (sx == 4) { // upsampler.cpp:367-387
+    v[7] = f8(3, v[3], 5, v[2], 1);
+    v[6] = f8(1, v[3], 7, v[2], 2);
+    v[5] = f8(1, v[1], 7, v[2], 1);
+    v[4] = f8(3, v[1], 5, v[2], 2);
+    const int s0 = v[1];
+    v[3] = f8(3, v[2], 5, s0, 1);
+    v[2] = f8(1, v[2], 7, s0, 2);
+    v[1] = f8(1, v[0], 7, s0, 1);
+    v[0] = f8(3, v[0], 5, s0, 2);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = v[j];
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a)
+{
+  const int groups = (a.width + 7) >> 3;
+  const int gxi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Y = blockIdx.y;
+  const int frame = blockIdx.z;
+  if (gxi >= groups) return;
+  const int X0 = gxi * 8;
+  int s[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    if (c < a.ncomp) {
+      const int *plane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[c];
+      upsample_line(plane, a.bw[c] * 8, a.cw[c], a.ch[c], a.subx[c], a.suby[c], X0, Y, s[c]);
+    }
+  }
+  uint8_t *dst = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride + (int64_t)X0 * a.ncomp;
+  const int npx = min(8, a.width - X0);
+#pragma unroll
+  for (int x = 0; x < 8; x++) {
+    if (x >= npx) break;
+    if (a.ycbcr && a.ncomp == 3) {
+      int r, g, b;
+      ycc_to_rgb<FAST>(s[0][x], s[1][x], s[2][x], r, g, b);
+      dst[3 * x] = (uint8_t)r; dst[3 * x + 1] = (uint8_t)g; dst[3 * x + 2] = (uint8_t)b;
+    } else {
+#pragma unroll
+      for (int c = 0; c < MAXC; c++)
+        if (c < a.ncomp) dst[a.ncomp * x + c] = (uint8_t)color_to_int<FAST>(s[c][x]);
+    }
+  }
+}
+
+// ==============================================================================================
+// launchers
+// ==============================================================================================
+int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  if (total == 0) return 0;
+  if (fast)
+    hipLaunchKernelGGL(fused420_kernel<true>, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else
+    hipLaunchKernelGGL(fused420_kernel<false>, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
+{
+  int maxblocks = 0;
+  for (int c = 0; c < a.ncomp; c++) maxblocks = max(maxblocks, a.bw[c] * a.bh[c]);
+  dim3 g1((maxblocks + 255) / 256, a.ncomp * a.frames);
+  if (fast)
+    hipLaunchKernelGGL(idct_planes_kernel<true>, g1, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(idct_planes_kernel<false>, g1, dim3(256), 0, stream, a);
+  const int groups = (a.width + 7) >> 3;
+  const int bs = groups >= 256 ? 256 : 64;
+  dim3 g2((groups + bs - 1) / bs, a.height, a.frames);
+  if (fast)
+    hipLaunchKernelGGL(upsample_color_kernel<true>, g2, dim3(bs), 0, stream, a);
+  else
+    hipLaunchKernelGGL(upsample_color_kernel<false>, g2, dim3(bs), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+} // namespace mij

@@ -1,0 +1,48 @@
+// kernels.hpp -- argument blocks and launch entry points of kernels.hip (internal to libmijpeg.so).
+#ifndef MIJ_KERNELS_HPP
+#define MIJ_KERNELS_HPP
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace mij {
+
+constexpr int MAXC = 4;
+
+// fused 4:2:0 (Y 1x1, Cb/Cr 2x2 subsampled).  Passed by value: the quantiser tables travel in the
+// kernarg segment and are read with scalar loads.
+struct Fused420Args {
+  const int16_t *coef;        // frame 0; planes at off_y / off_cb / off_cr (int16 units)
+  int64_t coef_frame_stride;  // int16 units
+  int64_t off_y, off_cb, off_cr;
+  uint8_t *out;               // interleaved RGB
+  int64_t out_frame_stride;   // bytes
+  int64_t row_stride;         // bytes
+  int32_t width, height;
+  int32_t bw_y, bh_y, bw_c, bh_c; // coefficient plane sizes in blocks (MCU padded)
+  int32_t cw, ch;                 // valid chroma samples: ceil(W/2), ceil(H/2)
+  int32_t tiles_x, tiles_y, frames;
+  int32_t aligned8;               // out, strides all multiples of 8 bytes -> 8-byte stores
+  uint16_t q[3][64];              // deltas per component (Y, Cb, Cr), natural order
+};
+
+// generic path: any sampling / component count, two kernels with int32 sample planes in between
+struct GenericArgs {
+  const int16_t *coef;
+  int64_t coef_frame_stride;
+  int64_t coef_off[MAXC];
+  int32_t *samples;            // workspace: per frame, per component (bw*8) x (bh*8) int32
+  int64_t sample_frame_stride; // int32 units
+  int64_t sample_off[MAXC];
+  uint8_t *out;
+  int64_t out_frame_stride, row_stride;
+  int32_t width, height, ncomp, ycbcr, frames;
+  int32_t bw[MAXC], bh[MAXC], cw[MAXC], ch[MAXC], subx[MAXC], suby[MAXC];
+  uint16_t q[MAXC][64];
+};
+
+int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
+int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream);
+
+} // namespace mij
+#endif
