@@ -68,6 +68,14 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the reconstruction path)")
+        # When PyTorch is used in the same process (tests and bench.py use it for device buffers, streams and
+        # torch.distributed) its bundled HIP runtime must be the one this library binds to: two HIP runtimes in
+        # one process do not see each other's device state.  Importing torch first makes the dynamic linker
+        # resolve libamdhip64 to the copy that is already loaded.  Without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing, not a dependency of the C ABI
+            pass
         L = C.CDLL(LIB_PATH)
         P = C.POINTER
         L.mijpeg_version.restype = C.c_char_p

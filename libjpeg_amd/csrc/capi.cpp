@@ -254,7 +254,11 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   if (b->quant_dev) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: not yet
   const mijpeg_info &f = b->info;
   if (f.precision != 8 || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
-  const bool fast = f.fast_arith && !(b->flags & MIJPEG_FLAG_FORCE_SAFE);
+  // fast arithmetic: range check passed (host decoder) and every delta << 4 fits a signed 16-bit operand
+  bool fast = f.fast_arith && !(b->flags & MIJPEG_FLAG_FORCE_SAFE);
+  for (int c = 0; c < f.components && fast; c++)
+    for (int i = 0; i < 64; i++)
+      if (f.quant[f.quant_index[c]][i] > 2047) fast = false;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (use_fused420(b)) {
@@ -280,7 +284,8 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.tiles_y = (f.height + 127) / 128;
     a.frames = b->frames;
     a.aligned8 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 7) == 0;
-    for (int c = 0; c < 3; c++) memcpy(a.q[c], f.quant[f.quant_index[c]], 128);
+    for (int c = 0; c < 3; c++)
+      for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
     rc = launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
@@ -307,7 +312,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
       a.suby[c] = f.suby[c];
       a.cw[c] = (f.width + f.subx[c] - 1) / f.subx[c];
       a.ch[c] = (f.height + f.suby[c] - 1) / f.suby[c];
-      memcpy(a.q[c], f.quant[f.quant_index[c]], 128);
+      for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
     }
     rc = launch_generic(a, fast, s);
   }

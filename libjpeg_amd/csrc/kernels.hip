@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.hpp"
 
@@ -47,6 +48,39 @@ __device__ __forceinline__ int mulc(int a, int c)
 __device__ __forceinline__ int addw(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 __device__ __forceinline__ int subw(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 __device__ __forceinline__ int shlw(int a, int n) { return (int)((unsigned)a << n); }
+
+// Hand-picked instructions (rates measured with tools/microbench/valu_rate.hip: every VOP3 integer op and
+// every multiply issues once per ~4 cycles per SIMD, so the instruction COUNT is what the kernel pays for):
+//   v_mad_i32_i24  d = a(24 bit) * k + c            multiply-accumulate in one issue slot
+//   v_mad_i32_i16  d = half(w) * q + 0              unpacks a 16-bit coefficient and dequantises it in one
+//   v_cvt_pk_i16_i32 + v_sat_pk_u8_i16              clamp to [0,255] and pack two samples per instruction
+__device__ __forceinline__ int mad24(int a, int k, int c)
+{
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int mul16_lo(unsigned w, int q)
+{
+  int d;
+  asm("v_mad_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(w), "s"(q));
+  return d;
+}
+__device__ __forceinline__ int mul16_hi(unsigned w, int q)
+{
+  int d;
+  asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "s"(q));
+  return d;
+}
+// two int32 -> two bytes (each clamped to [0,255]) in bits 0..15: lo = a, hi = b
+__device__ __forceinline__ unsigned sat_pack2(int a, int b)
+{
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 p = __builtin_amdgcn_cvt_pk_i16(a, b);
+  unsigned d;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(p));
+  return d;
+}
 
 // floor((x + 2^(n-1)) / 2^n) with the addition carried out beyond 32 bits, as the reference's
 // `(x + (1L << (n-1))) >> n` does on LP64 (dct/idct.cpp:70-78).
@@ -105,23 +139,29 @@ __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int 
 }
 
 // Dequantise the eight packed rows of a block and run both passes in registers.
-// rows[k] holds coefficient row k (8 x int16, natural order), q the component's 64 deltas.
+// rows[k] holds coefficient row k (8 x int16, natural order), q the component's 64 deltas << 4 (idct.cpp:98-109).
 // Result v[y*8+x] = sample * 16 (COLOR_BITS = 4 fractional bits), not clamped.
-template <bool FAST>
-__device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const uint16_t *__restrict__ q, int (&v)[64])
+// DCOFF = false leaves out the level shift dcoffset = 2^(P-1) << 7 (idct.cpp:231, :246).  That constant
+// passes through both rounding shifts exactly ((x + 2^14 * 2^9 + 2^8) >> 9 = ((x + 2^8) >> 9) + 2^14, and
+// (x + 2^14 * 2^9 + 2^11) >> 12 = ((x + 2^11) >> 12) + 2^11), so the result is exactly 2048 lower.
+template <bool FAST, bool DCOFF>
+__device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64])
 {
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const unsigned w[4] = {rows[k].x, rows[k].y, rows[k].z, rows[k].w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      int lo = (int)(short)(w[i] & 0xffffu);
-      int hi = ((int)w[i]) >> 16;
-      v[k * 8 + 2 * i] = mulc<FAST>(lo, (int)q[k * 8 + 2 * i] << 4);
-      v[k * 8 + 2 * i + 1] = mulc<FAST>(hi, (int)q[k * 8 + 2 * i + 1] << 4);
+      if (FAST) { // deltas <= 2047 (checked by the host): q fits a signed 16-bit operand
+        v[k * 8 + 2 * i] = mul16_lo(w[i], q[k * 8 + 2 * i]);
+        v[k * 8 + 2 * i + 1] = mul16_hi(w[i], q[k * 8 + 2 * i + 1]);
+      } else {
+        v[k * 8 + 2 * i] = mulc<false>((int)(short)(w[i] & 0xffffu), q[k * 8 + 2 * i]);
+        v[k * 8 + 2 * i + 1] = mulc<false>(((int)w[i]) >> 16, q[k * 8 + 2 * i + 1]);
+      }
     }
   }
-  v[0] = addw(v[0], 128 << 7); // dcoffset = 2^(P-1) << (preshift + 3), P = 8 (idct.cpp:231, :246)
+  if (DCOFF) v[0] = addw(v[0], 128 << 7);
 #pragma unroll
   for (int r = 0; r < 8; r++)
     idct_1d<FAST, 9>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5],
@@ -232,8 +272,8 @@ constexpr int F420_CROWS = 66;            // chroma lines kept in LDS (64 + 2 ha
 constexpr int F420_CPITCH = 72;           // dwords per LDS chroma line; column pc <-> chroma x_rel = pc - 4
 constexpr int F420_THREADS = 256;
 
-template <bool FAST>
-__global__ __launch_bounds__(F420_THREADS) void fused420_kernel(const Fused420Args a)
+template <bool FAST, int MINW>
+__global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) int cplane[2][F420_CROWS * F420_CPITCH];
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
@@ -278,7 +318,7 @@ __global__ __launch_bounds__(F420_THREADS) void fused420_kernel(const Fused420Ar
     const int gx = gx0 + cbx, gy = gy0 + cby;
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
       int v[64];
-      dequant_idct<FAST>(rows, a.q[1 + comp], v);
+      dequant_idct<FAST, !FAST>(rows, a.q[1 + comp], v);
       int *cp = cplane[comp];
 #pragma unroll
       for (int r = 0; r < 8; r++) {
@@ -343,7 +383,7 @@ __global__ __launch_bounds__(F420_THREADS) void fused420_kernel(const Fused420Ar
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct<FAST>(rows, a.q[0], yv);
+  dequant_idct<FAST, !FAST>(rows, a.q[0], yv);
 
   uint8_t *__restrict__ out = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y0 * a.row_stride + (int64_t)X0 * 3;
   const int npx = min(8, a.width - X0);
@@ -395,28 +435,66 @@ __global__ __launch_bounds__(F420_THREADS) void fused420_kernel(const Fused420Ar
       hfilt(vb, ub);
       hfilt(vr, ur);
       if (l < nln) {
-        unsigned px[24];
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-          int r, g, b;
-          ycc_to_rgb<FAST>(yv[l * 8 + x], ub[x], ur[x], r, g, b);
-          px[3 * x] = r; px[3 * x + 1] = g; px[3 * x + 2] = b;
-        }
         uint8_t *dst = out + (int64_t)l * a.row_stride;
-        if (fast_store) {
-          unsigned w[6];
+        if (FAST) {
+          // y, cb, cr arrive WITHOUT the level shift (DCOFF = false): with y = y' + 2048 and cb - 2048 = cb' the
+          // reference's (y * 8192 + (cb - 2048) * Lb + (cr - 2048) * Lr + 65536) >> 17 becomes
+          // (y' * 8192 + K + cb' * Lb + cr' * Lr) >> 17 with one constant K for all three channels
+          const int K = (2048 << 13) + 65536;
+          int rr[8], gg[8], bb[8];
 #pragma unroll
-          for (int i = 0; i < 6; i++) w[i] = px[4 * i] | (px[4 * i + 1] << 8) | (px[4 * i + 2] << 16) | (px[4 * i + 3] << 24);
-          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
-          __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
-          __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
-          __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
-        } else {
+          for (int x = 0; x < 8; x++) {
+            const int yk = (yv[l * 8 + x] << 13) + K;
+            rr[x] = mad24(ur[x], L_CR_R, yk) >> 17;
+            gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk)) >> 17;
+            bb[x] = mad24(ub[x], L_CB_B, yk) >> 17;
+          }
+          if (fast_store) {
+            // 24 bytes r0 g0 b0 r1 ... b7: clamp + pack two samples per instruction pair
+            unsigned h[12];
 #pragma unroll
-          for (int x = 0; x < 8; x++)
-            if (x < npx) {
-              dst[3 * x] = (uint8_t)px[3 * x]; dst[3 * x + 1] = (uint8_t)px[3 * x + 1]; dst[3 * x + 2] = (uint8_t)px[3 * x + 2];
+            for (int x = 0; x < 8; x += 2) {
+              h[3 * (x / 2) + 0] = sat_pack2(rr[x], gg[x]);
+              h[3 * (x / 2) + 1] = sat_pack2(bb[x], rr[x + 1]);
+              h[3 * (x / 2) + 2] = sat_pack2(gg[x + 1], bb[x + 1]);
             }
+            unsigned w[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+            u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+            __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
+            __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
+            __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+          } else {
+#pragma unroll
+            for (int x = 0; x < 8; x++)
+              if (x < npx) {
+                dst[3 * x] = (uint8_t)clamp255(rr[x]); dst[3 * x + 1] = (uint8_t)clamp255(gg[x]); dst[3 * x + 2] = (uint8_t)clamp255(bb[x]);
+              }
+          }
+        } else {
+          unsigned px[24];
+#pragma unroll
+          for (int x = 0; x < 8; x++) {
+            int r, g, b;
+            ycc_to_rgb<false>(yv[l * 8 + x], ub[x], ur[x], r, g, b);
+            px[3 * x] = r; px[3 * x + 1] = g; px[3 * x + 2] = b;
+          }
+          if (fast_store) {
+            unsigned w[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) w[i] = px[4 * i] | (px[4 * i + 1] << 8) | (px[4 * i + 2] << 16) | (px[4 * i + 3] << 24);
+            u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+            __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
+            __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
+            __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+          } else {
+#pragma unroll
+            for (int x = 0; x < 8; x++)
+              if (x < npx) {
+                dst[3 * x] = (uint8_t)px[3 * x]; dst[3 * x + 1] = (uint8_t)px[3 * x + 1]; dst[3 * x + 2] = (uint8_t)px[3 * x + 2];
+              }
+          }
         }
       }
     }
@@ -448,7 +526,7 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   const int blk = first + lane;
   if (blk >= nblocks) return;
   int v[64];
-  dequant_idct<FAST>(rows, a.q[comp], v);
+  dequant_idct<FAST, true>(rows, a.q[comp], v);
   const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
   const int pitch = a.bw[comp] * 8;
   int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
@@ -598,10 +676,15 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
   if (total == 0) return 0;
-  if (fast)
-    hipLaunchKernelGGL(fused420_kernel<true>, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  static const int variant = getenv("MIJPEG_F420_VARIANT") ? atoi(getenv("MIJPEG_F420_VARIANT")) : 0; // tuning aid
+  if (!fast)
+    hipLaunchKernelGGL((fused420_kernel<false, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else if (variant == 1)
+    hipLaunchKernelGGL((fused420_kernel<true, 3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else if (variant == 2)
+    hipLaunchKernelGGL((fused420_kernel<true, 4>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else
-    hipLaunchKernelGGL(fused420_kernel<false>, dim3(total), dim3(F420_THREADS), 0, stream, a);
+    hipLaunchKernelGGL((fused420_kernel<true, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -23,7 +23,7 @@ struct Fused420Args {
   int32_t cw, ch;                 // valid chroma samples: ceil(W/2), ceil(H/2)
   int32_t tiles_x, tiles_y, frames;
   int32_t aligned8;               // out, strides all multiples of 8 bytes -> 8-byte stores
-  uint16_t q[3][64];              // deltas per component (Y, Cb, Cr), natural order
+  int32_t q[3][64];               // deltas << 4 per component (Y, Cb, Cr), natural order (idct.cpp:98-109)
 };
 
 // generic path: any sampling / component count, two kernels with int32 sample planes in between
@@ -38,7 +38,7 @@ struct GenericArgs {
   int64_t out_frame_stride, row_stride;
   int32_t width, height, ncomp, ycbcr, frames;
   int32_t bw[MAXC], bh[MAXC], cw[MAXC], ch[MAXC], subx[MAXC], suby[MAXC];
-  uint16_t q[MAXC][64];
+  int32_t q[MAXC][64];         // deltas << 4
 };
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
