@@ -95,47 +95,65 @@ __device__ __forceinline__ int round_shift(int x)
 #define FIX9(x) ((int)((x) * 512.0 + 0.5))
 
 // One 8-point inverse transform (dct/idct.cpp:233-283 / :287-332), SHIFT = 9 (rows) or 12 (columns).
+// Before the final shift everything is exact integer arithmetic modulo 2^32, so any algebraically equal
+// arrangement gives the reference's bits.  The FAST flavour is arranged for the fewest issue slots
+// (44 per transform): products are folded into nested v_mad_i32_i24 chains, e.g. the reference's
+//   tmp0 = ttmp0 * c5 + z1 + z3  with  z1 = (ttmp0 + ttmp3) * -c9,  z3 = (ttmp0 + ttmp2) * -c11 + z5
+// becomes mad(tz1, -c9, mad(ttmp0, c5, z3)); the rounding constant is folded into the even part.
 template <bool FAST, int SHIFT>
 __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int &s4, int &s5, int &s6, int &s7)
 {
-  // even part
-  int z1 = mulc<FAST>(addw(s2, s6), FIX9(0.541196100));
-  int tmp2 = addw(z1, mulc<FAST>(s6, -FIX9(1.847759065)));
-  int tmp3 = addw(z1, mulc<FAST>(s2, FIX9(0.765366865)));
+  if (FAST) {
+    const int R = 1 << (SHIFT - 1);
+    // even part (12)
+    const int t0 = ((s0 + s4) << 9) + R;
+    const int t1 = ((s0 - s4) << 9) + R;
+    const int z1 = __mul24(s2 + s6, FIX9(0.541196100));
+    const int tmp2 = mad24(s6, -FIX9(1.847759065), z1);
+    const int tmp3 = mad24(s2, FIX9(0.765366865), z1);
+    const int t10 = t0 + tmp3, t13 = t0 - tmp3, t11 = t1 + tmp2, t12 = t1 - tmp2;
+    // odd part (16)
+    const int tz1 = s7 + s1, tz2 = s5 + s3, tz3 = s7 + s3, tz4 = s5 + s1;
+    const int z5 = __mul24(tz3 + tz4, FIX9(1.175875602));
+    const int z3 = mad24(tz3, -FIX9(1.961570560), z5);
+    const int z4 = mad24(tz4, -FIX9(0.390180644), z5);
+    const int o0 = mad24(tz1, -FIX9(0.899976223), mad24(s7, FIX9(0.298631336), z3));
+    const int o1 = mad24(tz2, -FIX9(2.562915447), mad24(s5, FIX9(2.053119869), z4));
+    const int o2 = mad24(tz2, -FIX9(2.562915447), mad24(s3, FIX9(3.072711026), z3));
+    const int o3 = mad24(tz1, -FIX9(0.899976223), mad24(s1, FIX9(1.501321110), z4));
+    // outputs (16)
+    s0 = (t10 + o3) >> SHIFT; s7 = (t10 - o3) >> SHIFT;
+    s1 = (t11 + o2) >> SHIFT; s6 = (t11 - o2) >> SHIFT;
+    s2 = (t12 + o1) >> SHIFT; s5 = (t12 - o1) >> SHIFT;
+    s3 = (t13 + o0) >> SHIFT; s4 = (t13 - o0) >> SHIFT;
+    return;
+  }
+  // SAFE: the reference's statement order in wrapping 32-bit arithmetic
+  int z1 = mulc<false>(addw(s2, s6), FIX9(0.541196100));
+  int tmp2 = addw(z1, mulc<false>(s6, -FIX9(1.847759065)));
+  int tmp3 = addw(z1, mulc<false>(s2, FIX9(0.765366865)));
   int tmp0 = shlw(addw(s0, s4), 9);
   int tmp1 = shlw(subw(s0, s4), 9);
-  if (FAST) { // fold the rounding constant into the even part: it reaches every output exactly once
-    tmp0 += 1 << (SHIFT - 1);
-    tmp1 += 1 << (SHIFT - 1);
-  }
   int tmp10 = addw(tmp0, tmp3), tmp13 = subw(tmp0, tmp3);
   int tmp11 = addw(tmp1, tmp2), tmp12 = subw(tmp1, tmp2);
-  // odd part
   int tz1 = addw(s7, s1), tz2 = addw(s5, s3), tz3 = addw(s7, s3), tz4 = addw(s5, s1);
-  int z5 = mulc<FAST>(addw(tz3, tz4), FIX9(1.175875602));
-  int o0 = mulc<FAST>(s7, FIX9(0.298631336));
-  int o1 = mulc<FAST>(s5, FIX9(2.053119869));
-  int o2 = mulc<FAST>(s3, FIX9(3.072711026));
-  int o3 = mulc<FAST>(s1, FIX9(1.501321110));
-  int y1 = mulc<FAST>(tz1, -FIX9(0.899976223));
-  int y2 = mulc<FAST>(tz2, -FIX9(2.562915447));
-  int y3 = addw(mulc<FAST>(tz3, -FIX9(1.961570560)), z5);
-  int y4 = addw(mulc<FAST>(tz4, -FIX9(0.390180644)), z5);
+  int z5 = mulc<false>(addw(tz3, tz4), FIX9(1.175875602));
+  int o0 = mulc<false>(s7, FIX9(0.298631336));
+  int o1 = mulc<false>(s5, FIX9(2.053119869));
+  int o2 = mulc<false>(s3, FIX9(3.072711026));
+  int o3 = mulc<false>(s1, FIX9(1.501321110));
+  int y1 = mulc<false>(tz1, -FIX9(0.899976223));
+  int y2 = mulc<false>(tz2, -FIX9(2.562915447));
+  int y3 = addw(mulc<false>(tz3, -FIX9(1.961570560)), z5);
+  int y4 = addw(mulc<false>(tz4, -FIX9(0.390180644)), z5);
   o0 = addw(o0, addw(y1, y3));
   o1 = addw(o1, addw(y2, y4));
   o2 = addw(o2, addw(y2, y3));
   o3 = addw(o3, addw(y1, y4));
-  if (FAST) {
-    s0 = (tmp10 + o3) >> SHIFT; s7 = (tmp10 - o3) >> SHIFT;
-    s1 = (tmp11 + o2) >> SHIFT; s6 = (tmp11 - o2) >> SHIFT;
-    s2 = (tmp12 + o1) >> SHIFT; s5 = (tmp12 - o1) >> SHIFT;
-    s3 = (tmp13 + o0) >> SHIFT; s4 = (tmp13 - o0) >> SHIFT;
-  } else {
-    s0 = round_shift<false, SHIFT>(addw(tmp10, o3)); s7 = round_shift<false, SHIFT>(subw(tmp10, o3));
-    s1 = round_shift<false, SHIFT>(addw(tmp11, o2)); s6 = round_shift<false, SHIFT>(subw(tmp11, o2));
-    s2 = round_shift<false, SHIFT>(addw(tmp12, o1)); s5 = round_shift<false, SHIFT>(subw(tmp12, o1));
-    s3 = round_shift<false, SHIFT>(addw(tmp13, o0)); s4 = round_shift<false, SHIFT>(subw(tmp13, o0));
-  }
+  s0 = round_shift<false, SHIFT>(addw(tmp10, o3)); s7 = round_shift<false, SHIFT>(subw(tmp10, o3));
+  s1 = round_shift<false, SHIFT>(addw(tmp11, o2)); s6 = round_shift<false, SHIFT>(subw(tmp11, o2));
+  s2 = round_shift<false, SHIFT>(addw(tmp12, o1)); s5 = round_shift<false, SHIFT>(subw(tmp12, o1));
+  s3 = round_shift<false, SHIFT>(addw(tmp13, o0)); s4 = round_shift<false, SHIFT>(subw(tmp13, o0));
 }
 
 // Dequantise the eight packed rows of a block and run both passes in registers.
