@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from libjpeg_amd import api, synth  # noqa: E402
+from libjpeg_amd import api, sharding, synth  # noqa: E402
 
 SIZES = {"8k": (7680, 4320), "4k": (3840, 2160)}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -111,26 +111,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+
+    def timed_steps():
+        ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        ev1.record(stream)
+        return W * H * F * args.steps
+
+    # barrier + torch.cuda.synchronize() on both sides, MAX over ranks of the elapsed time (libjpeg_amd/sharding.py)
+    wall, pixels = sharding.timed_region(timed_steps, dist)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: one kernel per step
+    total_pixels, wall = sharding.reduce_result(pixels, wall, dist)
     if dist:
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = float(t[0]), float(t[1])
+        kernel_ms = float(t[0])
+    assert total_pixels == W * H * F * args.steps * world
 
     pixels_per_step = W * H * F * world
     ms_per_step = wall * 1e3 / args.steps

@@ -1,0 +1,269 @@
+// jpeg.cpp -- class JPEG (decode half) on top of the C ABI.  What each member replaces in the reference:
+//   Read             interface/jpeg.cpp:205-354   (stream pulled through the I/O hook, io/iostream.cpp;
+//                                                  whole entropy decode happens here, as in the reference)
+//   GetInformation   interface/jpeg.cpp:822-957
+//   DisplayRectangle interface/jpeg.cpp:694-722 -> codestream/rectanglerequest.cpp:62-190 (tag parsing),
+//                    control/bitmapctrl.cpp:142-176 + interface/bitmaphook.cpp:130-248 (REQUEST / RELEASE
+//                    protocol per component), control/blockbitmaprequester.cpp:1229-1244 (the height the hook
+//                    reports bounds the block rows that are reconstructed)
+//   LastError        interface/jpeg.cpp:959-979
+// Error convention: every call returns JPG_TRUE / JPG_FALSE, nothing is thrown across the boundary.
+#include "jpeg.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../../include/mijpeg.h"
+#include "hooks.hpp"
+#include "parameters.hpp"
+
+struct JPEG::Impl {
+  mijpeg_decoder *dec = nullptr;
+  std::vector<uint8_t> stream; // the codestream, pulled through the I/O hook
+  mijpeg_info info;
+  bool loaded = false;
+  int err = 0;
+  std::string errmsg;
+  int fail(int code, const char *msg)
+  {
+    err = code;
+    errmsg = msg ? msg : "";
+    return JPG_FALSE;
+  }
+  int fail_from_decoder(int code)
+  {
+    const char *m = nullptr;
+    mijpeg_last_error(dec, &m);
+    return fail(code, m ? m : "decoder error");
+  }
+};
+
+JPEG::JPEG() : m_pImpl(nullptr) {}
+JPEG::~JPEG() {}
+
+class JPEG *JPEG::Construct(struct JPG_TagItem *tags)
+{
+  JPEG *o = new (std::nothrow) JPEG();
+  if (!o) return nullptr;
+  o->m_pImpl = new (std::nothrow) Impl();
+  if (!o->m_pImpl) {
+    delete o;
+    return nullptr;
+  }
+  memset(&o->m_pImpl->info, 0, sizeof(mijpeg_info));
+  int device = getenv("MIJPEG_DEVICE") ? atoi(getenv("MIJPEG_DEVICE")) : 0;
+  if (tags) device = tags->GetTagData(JPGTAG_MIJPEG_DEVICE, device);
+  if (mijpeg_create(&o->m_pImpl->dec, device) != MIJPEG_OK) {
+    delete o->m_pImpl;
+    delete o;
+    return nullptr;
+  }
+  return o;
+}
+
+void JPEG::Destruct(class JPEG *o)
+{
+  if (!o) return;
+  if (o->m_pImpl) {
+    mijpeg_destroy(o->m_pImpl->dec);
+    delete o->m_pImpl;
+  }
+  delete o;
+}
+
+JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
+{
+  Impl *p = m_pImpl;
+  p->err = 0;
+  if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::Read requires a tag list with an I/O hook");
+  if (tags->GetTagData(JPGTAG_DECODER_STOP, 0))
+    return p->fail(JPGERR_NOT_IMPLEMENTED, "incremental reading (JPGTAG_DECODER_STOP) is not available on the accelerated path");
+  struct JPG_Hook *io = (struct JPG_Hook *)tags->GetTagPtr(JPGTAG_HOOK_IOHOOK);
+  if (!io) return p->fail(JPGERR_MISSING_PARAMETER, "no I/O hook (JPGTAG_HOOK_IOHOOK) specified");
+  if (!p->loaded) {
+    // pull the whole codestream: the entropy decoder works on an in-memory stream
+    p->stream.clear();
+    const size_t chunk = 1 << 20;
+    for (;;) {
+      const size_t at = p->stream.size();
+      p->stream.resize(at + chunk);
+      struct JPG_TagItem iotags[] = {
+          JPG_PointerTag(JPGTAG_FIO_HANDLE, tags->GetTagPtr(JPGTAG_HOOK_IOSTREAM)),
+          JPG_PointerTag(JPGTAG_FIO_BUFFER, p->stream.data() + at),
+          JPG_ValueTag(JPGTAG_FIO_SIZE, (JPG_LONG)chunk),
+          JPG_ValueTag(JPGTAG_FIO_ACTION, JPGFLAG_ACTION_READ),
+          JPG_ValueTag(JPGTAG_FIO_SEEKMODE, JPGFLAG_OFFSET_CURRENT),
+          JPG_ValueTag(JPGTAG_FIO_OFFSET, 0),
+          JPG_PointerTag(JPGTAG_FIO_USERDATA, io->hk_pData),
+          JPG_EndTag};
+      const JPG_LONG got = io->CallLong(iotags);
+      if (got < 0) {
+        p->stream.clear();
+        return p->fail(got, "the I/O hook signalled an error");
+      }
+      p->stream.resize(at + (size_t)got);
+      if ((size_t)got < chunk) break;
+    }
+    if (p->stream.empty()) return p->fail(JPGERR_STREAM_EMPTY, "the I/O hook delivered no data");
+    int rc = mijpeg_set_input(p->dec, p->stream.data(), p->stream.size());
+    if (rc) return p->fail_from_decoder(rc);
+    const int threads = tags->GetTagData(JPGTAG_MIJPEG_THREADS, getenv("MIJPEG_THREADS") ? atoi(getenv("MIJPEG_THREADS")) : 0);
+    rc = mijpeg_decode_coefficients(p->dec, threads);
+    if (rc) return p->fail_from_decoder(rc);
+    mijpeg_get_info(p->dec, &p->info);
+    p->loaded = true;
+  }
+  return JPG_TRUE;
+}
+
+JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
+{
+  Impl *p = m_pImpl;
+  if (!p->loaded) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no image loaded to request information from");
+  if (!tags) return JPG_TRUE;
+  const mijpeg_info &f = p->info;
+  tags->SetTagData(JPGTAG_IMAGE_WIDTH, f.width);
+  tags->SetTagData(JPGTAG_IMAGE_HEIGHT, f.height);
+  tags->SetTagData(JPGTAG_IMAGE_DEPTH, f.components);
+  tags->SetTagData(JPGTAG_IMAGE_PRECISION, f.precision);
+  const JPG_LONG n = tags->GetTagData(JPGTAG_IMAGE_SUBLENGTH, 0);
+  if (n > 0) {
+    uint8_t *sx = (uint8_t *)tags->GetTagPtr(JPGTAG_IMAGE_SUBX), *sy = (uint8_t *)tags->GetTagPtr(JPGTAG_IMAGE_SUBY);
+    if (sx) memset(sx, 0, (size_t)n);
+    if (sy) memset(sy, 0, (size_t)n);
+    for (int c = 0; c < f.components && c < n; c++) {
+      if (sx) sx[c] = (uint8_t)f.subx[c];
+      if (sy) sy[c] = (uint8_t)f.suby[c];
+    }
+  }
+  // no merging specification box on this path: integer output, no output conversion (jpeg.cpp:836-862)
+  tags->SetTagData(JPGTAG_IMAGE_IS_FLOAT, 0);
+  tags->SetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION, 0);
+  // no alpha channel: the reference neutralises these two tags (jpeg.cpp:946-951)
+  if (struct JPG_TagItem *t = tags->FindTagItem(JPGTAG_ALPHA_MODE)) t->ti_Tag = JPGTAG_TAG_IGNORE;
+  if (struct JPG_TagItem *t = tags->FindTagItem(JPGTAG_ALPHA_TAGLIST)) t->ti_Tag = JPGTAG_TAG_IGNORE;
+  return JPG_TRUE;
+}
+
+JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
+{
+  Impl *p = m_pImpl;
+  p->err = 0;
+  if (!p->loaded) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no image loaded that could be reconstructed");
+  const mijpeg_info &f = p->info;
+  // codestream/rectanglerequest.cpp:62-190: defaults = whole canvas, requests are clipped, negatives are errors
+  JPG_LONG minx = 0, miny = 0, maxx = f.width - 1, maxy = f.height - 1, c0 = 0, c1 = f.components - 1;
+  bool upsample = true, ctrafo = true;
+  struct JPG_Hook *bmh = nullptr;
+  for (const struct JPG_TagItem *t = tags ? tags->FirstTagItem() : nullptr; t; t = t->NextTagItem()) {
+    const JPG_LONG v = t->ti_Data.ti_lData;
+    switch (t->ti_Tag) {
+    case JPGTAG_DECODER_MINX: if (v < 0) return p->fail(JPGERR_OVERFLOW_PARAMETER, "Rectangle MinX underflow, must be >= 0"); if (v > minx) minx = v; break;
+    case JPGTAG_DECODER_MINY: if (v < 0) return p->fail(JPGERR_OVERFLOW_PARAMETER, "Rectangle MinY underflow, must be >= 0"); if (v > miny) miny = v; break;
+    case JPGTAG_DECODER_MAXX: if (v < 0) return p->fail(JPGERR_OVERFLOW_PARAMETER, "Rectangle MaxX underflow, must be >= 0"); if (v < maxx) maxx = v; break;
+    case JPGTAG_DECODER_MAXY: if (v < 0) return p->fail(JPGERR_OVERFLOW_PARAMETER, "Rectangle MaxY underflow, must be >= 0"); if (v < maxy) maxy = v; break;
+    case JPGTAG_DECODER_MINCOMPONENT: if (v < 0 || v > 65535) return p->fail(JPGERR_OVERFLOW_PARAMETER, "MinComponent overflow, must be >= 0 && < 65536"); if (v > c0) c0 = v; break;
+    case JPGTAG_DECODER_MAXCOMPONENT: if (v < 0 || v > 65535) return p->fail(JPGERR_OVERFLOW_PARAMETER, "MaxComponent overflow, must be >= 0 && < 65536"); if (v < c1) c1 = v; break;
+    case JPGTAG_DECODER_UPSAMPLE: upsample = v != 0; break;
+    case JPGTAG_MATRIX_LTRAFO: ctrafo = v != JPGFLAG_MATRIX_COLORTRANSFORMATION_NONE; break;
+    case JPGTAG_BIH_HOOK: bmh = (struct JPG_Hook *)t->ti_Data.ti_pPtr; break;
+    default: break;
+    }
+  }
+  if (!upsample)
+    return p->fail(JPGERR_NOT_IMPLEMENTED, "reconstruction without upsampling (JPGTAG_DECODER_UPSAMPLE = false) is not on the accelerated path");
+  if (minx > maxx || miny > maxy || c0 > c1) return JPG_TRUE; // empty request: nothing to do
+  if (!bmh) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no bitmap hook (JPGTAG_BIH_HOOK) specified");
+
+  // REQUEST: one hook call per component with the tag layout of interface/bitmaphook.cpp:130-161
+  void *dst[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
+  int32_t bpp[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0}, bpr[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
+  struct Bitmap { void *mem; JPG_LONG width, height, bpr, bpp, type; void *user; } bm[MIJPEG_MAX_COMPONENTS];
+  auto call_hook = [&](int c, int action, Bitmap &b) -> JPG_LONG {
+    const int sx = f.subx[c], sy = f.suby[c];
+    struct JPG_TagItem ht[] = {
+        JPG_ValueTag(JPGTAG_BIO_ACTION, action),
+        JPG_PointerTag(JPGTAG_BIO_MEMORY, b.mem),
+        JPG_ValueTag(JPGTAG_BIO_WIDTH, b.width),
+        JPG_ValueTag(JPGTAG_BIO_HEIGHT, b.height),
+        JPG_ValueTag(JPGTAG_BIO_BYTESPERROW, b.bpr),
+        JPG_ValueTag(JPGTAG_BIO_BYTESPERPIXEL, b.bpp),
+        JPG_ValueTag(JPGTAG_BIO_PIXELTYPE, b.type),
+        JPG_ValueTag(JPGTAG_BIO_ROI, 0),
+        JPG_ValueTag(JPGTAG_BIO_COMPONENT, c),
+        JPG_PointerTag(JPGTAG_BIO_USERDATA, b.user),
+        JPG_ValueTag(JPGTAG_BIO_MINX, minx),
+        JPG_ValueTag(JPGTAG_BIO_MINY, miny),
+        JPG_ValueTag(JPGTAG_BIO_MAXX, maxx),
+        JPG_ValueTag(JPGTAG_BIO_MAXY, maxy),
+        JPG_ValueTag(JPGTAG_BIO_ALPHA, 0),
+        JPG_ValueTag(JPGTAG_BIO_PIXEL_MINX, (minx + sx - 1) / sx),
+        JPG_ValueTag(JPGTAG_BIO_PIXEL_MINY, (miny + sy - 1) / sy),
+        JPG_ValueTag(JPGTAG_BIO_PIXEL_MAXX, (maxx + sx) / sx - 1),
+        JPG_ValueTag(JPGTAG_BIO_PIXEL_MAXY, (maxy + sy) / sy - 1),
+        JPG_ValueTag(JPGTAG_BIO_PIXEL_XORG, 0),
+        JPG_ValueTag(JPGTAG_BIO_PIXEL_YORG, 0),
+        JPG_EndTag};
+    const JPG_LONG r = bmh->CallLong(ht);
+    if (action == JPGFLAG_BIO_REQUEST) {
+      b.mem = ht[1].ti_Data.ti_pPtr;
+      b.width = ht[2].ti_Data.ti_lData;
+      b.height = ht[3].ti_Data.ti_lData;
+      b.bpr = ht[4].ti_Data.ti_lData;
+      b.bpp = ht[5].ti_Data.ti_lData;
+      b.type = ht[6].ti_Data.ti_lData;
+      b.user = ht[9].ti_Data.ti_pPtr;
+    }
+    return r;
+  };
+  JPG_LONG maxmcu = 0x7fffffff;
+  for (int c = c0; c <= c1; c++) {
+    bm[c] = Bitmap{nullptr, 0, 0, 0, 0, CTYP_UBYTE, nullptr};
+    const JPG_LONG r = call_hook(c, JPGFLAG_BIO_REQUEST, bm[c]);
+    if (r < 0) return p->fail(r, "BitMapHook signalled an error");
+    if (bm[c].type != CTYP_UBYTE && bm[c].type != 0) // control/bitmapctrl.cpp:152-158: types must fit the data
+      return p->fail(JPGERR_INVALID_PARAMETER, "pixel type of the user bitmap must be CTYP_UBYTE for 8 bit images");
+    dst[c] = bm[c].type ? bm[c].mem : nullptr; // pixel type 0 = "no memory for this component"
+    bpp[c] = bm[c].bpp;
+    bpr[c] = bm[c].bpr;
+    // blockbitmaprequester.cpp:1229-1244: the reported height bounds the reconstructed block rows
+    const JPG_LONG m = (JPG_LONG)(((uint32_t)bm[c].height) >> 3) - 1;
+    if (m < maxmcu) maxmcu = m;
+  }
+  int rc = MIJPEG_OK;
+  const JPG_LONG ylimit = (maxmcu >= 0x0fffffff) ? maxy : (maxmcu + 1) * 8 - 1;
+  const JPG_LONG y1 = maxy < ylimit ? maxy : ylimit;
+  if (maxmcu >= 0 && y1 >= miny)
+    rc = mijpeg_reconstruct_rect(p->dec, minx, miny, maxx, y1, c0, c1, ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM, dst, bpp, bpr);
+  // RELEASE is always delivered, also after a failure, so the client can let go of its buffers
+  JPG_LONG hookerr = 0;
+  for (int c = c0; c <= c1; c++) {
+    const JPG_LONG r = call_hook(c, JPGFLAG_BIO_RELEASE, bm[c]);
+    if (r < 0 && !hookerr) hookerr = r;
+  }
+  if (rc) return p->fail_from_decoder(rc);
+  if (hookerr) return p->fail(hookerr, "BitMapHook signalled an error");
+  return JPG_TRUE;
+}
+
+JPG_LONG JPEG::LastError(const char *&error)
+{
+  error = m_pImpl->err ? m_pImpl->errmsg.c_str() : nullptr;
+  return m_pImpl->err;
+}
+
+JPG_LONG JPEG::LastWarning(const char *&warning)
+{
+  warning = nullptr;
+  return 0;
+}
+
+JPG_LONG JPEG::Write(struct JPG_TagItem *) { return m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "the encoder is not part of the accelerated path"); }
+JPG_LONG JPEG::ProvideImage(struct JPG_TagItem *) { return m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "the encoder is not part of the accelerated path"); }
+JPG_LONG JPEG::PeekMarker(struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }
+JPG_LONG JPEG::ReadMarker(void *, JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }
+JPG_LONG JPEG::SkipMarker(JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }
+JPG_LONG JPEG::WriteMarker(void *, JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "the encoder is not part of the accelerated path"); return -1; }

@@ -191,3 +191,47 @@ def test_round_trip_properties_8k(dec):
     for y in range(0, f.height, 8):
         dec.reconstruct_rect(0, y, f.width - 1, y + 7, out=stripes)
     assert band_hashes(stripes) == ha
+
+
+# ------------------------------------------------------------------------------------------------------
+# the drop-in surface: `class JPEG` (tag/hook API) driven by the cmd/reconstruct-compatible front end
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cfg1_512x512_444_q75_ref", "ref_75x45_420_dri2", "pil_200x120_420_dri8", "pil_70x40_gray",
+                                  "ref_97x61_3x3", "pil_33x17_420_dri1"])
+def test_cli_writes_the_references_pnm(tmp_path, name):
+    """`jpeg in.jpg out.ppm` (class JPEG: Read / GetInformation / DisplayRectangle per 8-line stripe with an I/O
+    hook and a bitmap hook) must write byte for byte the PNM the reference binary writes."""
+    import os
+    import subprocess
+
+    from conftest import GOLDEN_DIR, ROOT
+
+    exe = os.path.join(ROOT, "libjpeg_amd", "bin", "jpeg")
+    assert os.path.exists(exe), "libjpeg_amd/bin/jpeg not built (run __graft_entry__.build())"
+    ent = MANIFEST[name]
+    out = tmp_path / "out.pnm"
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".jpg"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    data = out.read_bytes()
+    header = b"P%d\n%d %d\n255\n" % (6 if ent["channels"] == 3 else 5, ent["width"], ent["height"])
+    assert data.startswith(header)
+    assert hashlib.sha256(data[len(header):]).hexdigest() == ent["pixels_sha256"]
+
+
+def test_cli_no_color_transform_and_errors(tmp_path, oracle):
+    import os
+    import subprocess
+
+    from conftest import GOLDEN_DIR, ROOT
+
+    exe = os.path.join(ROOT, "libjpeg_amd", "bin", "jpeg")
+    src = os.path.join(GOLDEN_DIR, "ref_80x48_420.jpg")
+    out = tmp_path / "o.ppm"
+    r = subprocess.run([exe, "-c", src, str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exp = oracle.decode(golden_jpeg("ref_80x48_420"), use_ycbcr=0)
+    assert out.read_bytes().split(b"255\n", 1)[1] == exp.tobytes()
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"\xff\xd8\xff\xc2garbage")
+    r = subprocess.run([exe, str(bad), str(out)], capture_output=True, text=True)
+    assert r.returncode != 0 and "reading a JPEG file failed - error" in r.stderr

@@ -1,0 +1,70 @@
+"""Multi-rank path on CPU: two processes over the gloo backend run the same image-sharding logic bench.py and
+the batch config use (independent frames per rank, barrier on both sides of the timed region, MAX over ranks of
+the elapsed time, SUM of the work) -- with the host entropy decoder as the per-rank work, since there is no GPU
+here.  There is no data-path collective to test: frames never move between ranks."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import os, sys, time, hashlib
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from libjpeg_amd import api, synth, sharding
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    frames = list(range(10))                       # global frame ids of the batch
+    mine = sharding.frames_of_rank(len(frames), rank, world)
+    assert sorted(sum((sharding.frames_of_rank(len(frames), r, world) for r in range(world)), [])) == frames
+    dec = api.Decoder(None)                        # host-only: parsing + Huffman decoding
+    digest = hashlib.sha256()
+    def work():
+        for i in mine:
+            dec.read(synth.synth_jpeg(160, 96, seed=1000 + i, quality=85, subsampling="420", restart_mcus=2), threads=1)
+            digest.update(dec.coefficients(0).tobytes())
+        return len(mine) * 160 * 96
+    elapsed, units = sharding.timed_region(work, dist)
+    total_units, max_elapsed = sharding.reduce_result(units, elapsed, dist)
+    assert total_units == 10 * 160 * 96, total_units
+    assert max_elapsed >= elapsed - 1e-9
+    print("RANK", rank, "frames", mine, "units", units, "total", total_units, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_sharding_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "frames [0, 2, 4, 6, 8]" in outs[0] and "frames [1, 3, 5, 7, 9]" in outs[1]
+
+
+def test_frames_of_rank_partitions():
+    from libjpeg_amd import sharding
+
+    for n in (0, 1, 7, 256):
+        for world in (1, 2, 4, 8):
+            parts = [sharding.frames_of_rank(n, r, world) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
