@@ -72,11 +72,15 @@ __device__ __forceinline__ int mul16_hi(unsigned w, int q)
   asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "s"(q));
   return d;
 }
-// two int32 -> two bytes (each clamped to [0,255]) in bits 0..15: lo = a, hi = b
-__device__ __forceinline__ unsigned sat_pack2(int a, int b)
+// (xa >> 17, xb >> 17), each clamped to [0,255], as two bytes in bits 0..15 (lo = a, hi = b):
+// v_perm_b32 gathers the two high halves (= x >> 16 as int16), one packed shift finishes the >> 17,
+// v_sat_pk_u8_i16 clamps and packs: 1.5 instructions per sample.
+__device__ __forceinline__ unsigned shift17_sat_pack2(int xa, int xb)
 {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const s16x2 p = __builtin_amdgcn_cvt_pk_i16(a, b);
+  const unsigned hi = __builtin_amdgcn_perm((unsigned)xb, (unsigned)xa, 0x07060302u);
+  s16x2 p = __builtin_bit_cast(s16x2, hi);
+  p = p >> (short)1;
   unsigned d;
   asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(p));
   return d;
@@ -195,17 +199,15 @@ __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *
 // 2 KB LDS staging buffer, 16 blocks at a time.  The chunk position inside a block is XOR-swizzled
 // with the block index so that both the 8-lane-group writes and the 16-lane-group reads are free of
 // bank conflicts (MI355X_MICROARCH.md, LDS: ds_write_b128 / ds_read_b128 lane groups).
-// blockptr(n) returns the address of local block n (0..63) or nullptr (-> zeros).
+// chunkptr(m) returns the address of the lane's m-th 16-byte chunk; blocks outside the plane are redirected to a
+// clamped (valid) block whose result is simply never used, so the loads need no predication.
 // ----------------------------------------------------------------------------------------------
 template <class F>
-__device__ __forceinline__ void fetch_blocks(u32x4 (&rows)[8], u32x4 *stage, int lane, F blockptr)
+__device__ __forceinline__ void fetch_blocks(u32x4 (&rows)[8], u32x4 *stage, int lane, F chunkptr)
 {
   u32x4 raw[8];
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    const int16_t *p = blockptr((lane >> 3) + 8 * m);
-    raw[m] = p ? *(reinterpret_cast<const u32x4 *>(p) + (lane & 7)) : u32x4{0, 0, 0, 0};
-  }
+  for (int m = 0; m < 8; m++) raw[m] = *chunkptr(m); // m-th load of this lane: chunk (lane & 7) of local block (lane >> 3) + 8 m
   const int k = lane & 7;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -324,12 +326,11 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
     const int gx0 = tx * 8 - 1, gy0 = ty * 8 - 1;
     const int base = (wave & 1) * 64;
     u32x4 rows[8];
-    fetch_blocks(rows, stage, lane, [&](int n) -> const int16_t * {
-      const int idx = base + n;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int idx = min(base + (lane >> 3) + 8 * m, F420_CGRID * F420_CGRID - 1);
       const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
-      const int gx = gx0 + cbx, gy = gy0 + cby;
-      if (idx >= F420_CGRID * F420_CGRID || gx < 0 || gy < 0 || gx >= a.bw_c || gy >= a.bh_c) return nullptr;
-      return plane + ((int64_t)gy * a.bw_c + gx) * 64;
+      const int gx = min(max(gx0 + cbx, 0), a.bw_c - 1), gy = min(max(gy0 + cby, 0), a.bh_c - 1);
+      return reinterpret_cast<const u32x4 *>(plane + ((int64_t)gy * a.bw_c + gx) * 64) + (lane & 7);
     });
     const int idx = base + lane;
     const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
@@ -392,10 +393,11 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   {
     const int16_t *__restrict__ plane = coef + a.off_y;
     const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
-    fetch_blocks(rows, stage, lane, [&](int n) -> const int16_t * {
-      const int x = gbx0 + (n & 15), y = gby0 + (n >> 4);
-      if (x >= a.bw_y || y >= a.bh_y) return nullptr;
-      return plane + ((int64_t)y * y_plane_w + x) * 64;
+    // local block n = (lane >> 3) + 8 m sits at column n & 15 = (lane >> 3) + 8 (m & 1), row n >> 4 = m >> 1 of the wave's 16 x 4 blocks
+    const int x0 = gbx0 + (lane >> 3);
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(plane + ((int64_t)y * y_plane_w + x) * 64) + (lane & 7);
     });
   }
   const int X0 = gbx * 8, Y0 = gby * 8;
@@ -463,18 +465,18 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 #pragma unroll
           for (int x = 0; x < 8; x++) {
             const int yk = (yv[l * 8 + x] << 13) + K;
-            rr[x] = mad24(ur[x], L_CR_R, yk) >> 17;
-            gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk)) >> 17;
-            bb[x] = mad24(ub[x], L_CB_B, yk) >> 17;
+            rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
+            gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
+            bb[x] = mad24(ub[x], L_CB_B, yk);
           }
           if (fast_store) {
             // 24 bytes r0 g0 b0 r1 ... b7: clamp + pack two samples per instruction pair
             unsigned h[12];
 #pragma unroll
             for (int x = 0; x < 8; x += 2) {
-              h[3 * (x / 2) + 0] = sat_pack2(rr[x], gg[x]);
-              h[3 * (x / 2) + 1] = sat_pack2(bb[x], rr[x + 1]);
-              h[3 * (x / 2) + 2] = sat_pack2(gg[x + 1], bb[x + 1]);
+              h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
+              h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
+              h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
             }
             unsigned w[6];
 #pragma unroll
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 #pragma unroll
             for (int x = 0; x < 8; x++)
               if (x < npx) {
-                dst[3 * x] = (uint8_t)clamp255(rr[x]); dst[3 * x + 1] = (uint8_t)clamp255(gg[x]); dst[3 * x + 2] = (uint8_t)clamp255(bb[x]);
+                dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
               }
           }
         } else {
@@ -538,8 +540,9 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   if (first >= nblocks) return;
   const int16_t *__restrict__ plane = a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp];
   u32x4 rows[8];
-  fetch_blocks(rows, stage_all[wave], lane, [&](int n) -> const int16_t * {
-    return (first + n < nblocks) ? plane + (int64_t)(first + n) * 64 : nullptr;
+  fetch_blocks(rows, stage_all[wave], lane, [&](int m) -> const u32x4 * {
+    const int n = min(first + (lane >> 3) + 8 * m, nblocks - 1);
+    return reinterpret_cast<const u32x4 *>(plane + (int64_t)n * 64) + (lane & 7);
   });
   const int blk = first + lane;
   if (blk >= nblocks) return;
