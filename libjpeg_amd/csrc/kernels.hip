@@ -325,13 +325,27 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
     const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
     const int gx0 = tx * 8 - 1, gy0 = ty * 8 - 1;
     const int base = (wave & 1) * 64;
+    // tiles whose whole 10 x 10 block window lies inside the plane need no clamping (wave-uniform)
+    const bool inside = gx0 >= 0 && gy0 >= 0 && gx0 + F420_CGRID <= a.bw_c && gy0 + F420_CGRID <= a.bh_c;
     u32x4 rows[8];
-    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
-      const int idx = min(base + (lane >> 3) + 8 * m, F420_CGRID * F420_CGRID - 1);
-      const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
-      const int gx = min(max(gx0 + cbx, 0), a.bw_c - 1), gy = min(max(gy0 + cby, 0), a.bh_c - 1);
-      return reinterpret_cast<const u32x4 *>(plane + ((int64_t)gy * a.bw_c + gx) * 64) + (lane & 7);
-    });
+    // local block n = (lane >> 3) + 8 m is grid index base + n (clamped to the grid: waves 1 and 3 only hold 36 blocks)
+    const int idx0 = base + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    if (inside) {
+      const unsigned off0 = (unsigned)((gy0 * a.bw_c + gx0) * 128), rowb = (unsigned)a.bw_c * 128u;
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const unsigned i = (unsigned)min(idx0 + 8 * m, F420_CGRID * F420_CGRID - 1);
+        const unsigned y = (i * 205u) >> 11, x = i - y * F420_CGRID; // i / 10, i % 10 for i < 1029
+        return reinterpret_cast<const u32x4 *>(pbase + (off0 + y * rowb + x * 128u));
+      });
+    } else {
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int i = min(idx0 + 8 * m, F420_CGRID * F420_CGRID - 1);
+        const int y = (i * 205) >> 11, x = i - y * F420_CGRID;
+        const int gx = min(max(gx0 + x, 0), a.bw_c - 1), gy = min(max(gy0 + y, 0), a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((gy * a.bw_c + gx) * 128));
+      });
+    }
     const int idx = base + lane;
     const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
     const int gx = gx0 + cbx, gy = gy0 + cby;
@@ -395,9 +409,10 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
     const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
     // local block n = (lane >> 3) + 8 m sits at column n & 15 = (lane >> 3) + 8 (m & 1), row n >> 4 = m >> 1 of the wave's 16 x 4 blocks
     const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
     fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
       const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
-      return reinterpret_cast<const u32x4 *>(plane + ((int64_t)y * y_plane_w + x) * 64) + (lane & 7);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * y_plane_w + x) * 128));
     });
   }
   const int X0 = gbx * 8, Y0 = gby * 8;
@@ -405,7 +420,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   int yv[64];
   dequant_idct<FAST, !FAST>(rows, a.q[0], yv);
 
-  uint8_t *__restrict__ out = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y0 * a.row_stride + (int64_t)X0 * 3;
+  // uniform frame base + 32-bit lane offsets (a frame of pixels is far below 4 GB)
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
   const bool fast_store = a.aligned8 && npx == 8;
@@ -455,7 +472,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
       hfilt(vb, ub);
       hfilt(vr, ur);
       if (l < nln) {
-        uint8_t *dst = out + (int64_t)l * a.row_stride;
+        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         if (FAST) {
           // y, cb, cr arrive WITHOUT the level shift (DCOFF = false): with y = y' + 2048 and cb - 2048 = cb' the
           // reference's (y * 8192 + (cb - 2048) * Lb + (cr - 2048) * Lr + 65536) >> 17 becomes
