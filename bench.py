@@ -152,17 +152,21 @@ def main():
     if rank == 0 and not args.no_end_to_end:
         # whole decode of one frame through the decoder object: host Huffman (all cores) + streaming H2D +
         # kernel + D2H into host memory.  PCIe/host inclusive -- reported beside, never as `value`.
+        user = np.empty((H, W, 3), np.uint8)
+        user[:] = 0  # touch the pages once: a real client reuses its frame buffer
         ts = []
-        for _ in range(3):
+        for _ in range(5):
             t = time.perf_counter()
             dec.read(jpegs[0])
-            dec.reconstruct()
+            dec.reconstruct(out=user)
             ts.append(time.perf_counter() - t)
         tm = dec.timing()
         best = min(ts)
         result["end_to_end"] = {"value": round(W * H / best / 1e6, 1), "unit": "Mpixels/s", "ms": round(best * 1e3, 2),
-                                "host_threads": os.cpu_count(), "phases_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
-                                "note": "one frame: bytes -> host Huffman (restart-interval parallel) -> pinned H2D -> kernel -> D2H"}
+                                "host_threads": api.default_threads(), "host_cores": os.cpu_count(),
+                                "phases_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
+                                "note": "one frame, PCIe and host inclusive: bytes -> host Huffman (restart-interval parallel) -> "
+                                        "pinned H2D (streamed) -> kernel -> D2H -> copy into the caller's interleaved bitmap"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(jpegs[0], W, H)

@@ -157,6 +157,9 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *batch, void *stream);
 /* Name of the kernel the batch would run ("fused420", "generic", ...) -- for profiling scripts. */
 const char *mijpeg_kernel_name(const mijpeg_batch *batch);
 
+/* Worker threads mijpeg_decode_coefficients uses for threads <= 0 (MIJPEG_THREADS overrides; default min(cores, 64)). */
+int mijpeg_default_threads(void);
+
 /* Library / build identification. */
 const char *mijpeg_version(void);
 

@@ -162,10 +162,10 @@ class Decoder:
     def device_coefficients(self) -> int:
         return lib().mijpeg_device_coefficients(self._h) or 0
 
-    def reconstruct(self, flags: int = 0) -> np.ndarray:
+    def reconstruct(self, flags: int = 0, out: np.ndarray | None = None) -> np.ndarray:
         """JPEG::DisplayRectangle over the whole canvas -> (H, W, C) uint8 in host memory."""
         f = self.info
-        return self.reconstruct_rect(0, 0, f.width - 1, f.height - 1, flags=flags)
+        return self.reconstruct_rect(0, 0, f.width - 1, f.height - 1, flags=flags, out=out)
 
     def reconstruct_rect(self, x0, y0, x1, y1, comp0=0, comp1=None, flags: int = 0,
                          out: np.ndarray | None = None) -> np.ndarray:
@@ -188,6 +188,12 @@ class Decoder:
         t = (C.c_double * 4)()
         lib().mijpeg_last_timing(self._h, t)
         return dict(huffman=t[0], h2d_wait=t[1], kernel=t[2], d2h=t[3])
+
+
+def default_threads() -> int:
+    L = lib()
+    L.mijpeg_default_threads.restype = C.c_int
+    return int(L.mijpeg_default_threads())
 
 
 def decode(data: bytes, device: int = 0, threads: int = 0, flags: int = 0) -> np.ndarray:

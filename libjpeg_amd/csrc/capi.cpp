@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <new>
 #include <string>
@@ -65,6 +66,8 @@ static int hip_fail(mijpeg_decoder *d, hipError_t e, const char *what)
 extern "C" {
 
 const char *mijpeg_version(void) { return "libjpeg_amd/mijpeg 0.1 (gfx950)"; }
+
+int mijpeg_default_threads(void) { return default_threads(); }
 
 int mijpeg_create(mijpeg_decoder **out, int device)
 {
@@ -419,9 +422,20 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
   for (int c = 0; c < nc && interleaved; c++)
     interleaved = dst[c] == (uint8_t *)dst[0] + c && bytes_per_pixel[c] == nc && bytes_per_row[c] == bytes_per_row[0];
   if (interleaved) {
-    for (int y = min_y; y <= max_y; y++)
-      memcpy((uint8_t *)dst[0] + (ptrdiff_t)y * bytes_per_row[0] + (ptrdiff_t)min_x * nc,
-             d->img_host + (size_t)y * row + (size_t)min_x * nc, (size_t)(max_x - min_x + 1) * nc);
+    const size_t line = (size_t)(max_x - min_x + 1) * nc;
+    const int lines = max_y - min_y + 1;
+    auto copy_lines = [&](int y0, int y1) {
+      for (int y = y0; y < y1; y++)
+        memcpy((uint8_t *)dst[0] + (ptrdiff_t)y * bytes_per_row[0] + (ptrdiff_t)min_x * nc,
+               d->img_host + (size_t)y * row + (size_t)min_x * nc, line);
+    };
+    // big rectangles (whole frames) are copied by the worker pool: one memcpy stream per worker
+    const int parts = (int)std::min<size_t>((size_t)std::min(default_threads(), 16), line * lines / (4u << 20));
+    if (parts > 1) {
+      parallel_for(parts, [&](int i) { copy_lines(min_y + (int)((int64_t)lines * i / parts), min_y + (int)((int64_t)lines * (i + 1) / parts)); });
+    } else {
+      copy_lines(min_y, max_y + 1);
+    }
     return MIJPEG_OK;
   }
   for (int c = min_comp; c <= max_comp; c++) {

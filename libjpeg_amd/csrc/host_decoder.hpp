@@ -95,6 +95,11 @@ private:
   void find_intervals(Scan &s);
 };
 
+int default_threads();
+
+// Run fn(i) for i in [0, n) on the entropy-decoder worker pool (used for large host-side pixel copies).
+void parallel_for(int n, const std::function<void(int)> &fn);
+
 // zig-zag position -> natural index (dct/dct.cpp:57-74), generated at start-up
 extern const uint8_t *scan_order();
 
