@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=8, help="frames per step and rank (device resident)")
     ap.add_argument("--size", default="8k", choices=sorted(SIZES))
+    ap.add_argument("--subsampling", default="420", choices=["420", "444"], help="420 = the BASELINE workload; 444 for side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
@@ -94,7 +95,7 @@ def main():
     host_planes, jpegs = [], []
     info = None
     for i in range(2):
-        data = synth.synth_jpeg(W, H, seed=1234 + 17 * rank + i, quality=85, subsampling="420", restart_mcus=8)
+        data = synth.synth_jpeg(W, H, seed=1234 + 17 * rank + i, quality=85, subsampling=args.subsampling, restart_mcus=8)
         jpegs.append(data)
         info = dec.read(data)
         host_planes.append(np.concatenate([dec.coefficients(c).reshape(-1) for c in range(info.components)]))
@@ -133,7 +134,8 @@ def main():
     pixels_per_step = W * H * F * world
     ms_per_step = wall * 1e3 / args.steps
     value = pixels_per_step / (ms_per_step * 1e-3) / 1e6
-    alg_bytes = W * H * F * BYTES_PER_PIXEL_420  # per launch (one rank)
+    bpp = BYTES_PER_PIXEL_420 if args.subsampling == "420" else 9.0  # 4:4:4: 3 x 2 B in + 3 B out
+    alg_bytes = W * H * F * bpp  # per launch (one rank)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
     result = {
@@ -141,7 +143,7 @@ def main():
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32 (int16 coefficients in, u8 pixels out)", "data": "synthetic",
-        "config": {"workload": f"{F} x {W}x{H} 4:2:0 Q85 DRI=8 baseline frames per GPU per step (BASELINE configs[2] frame shape, "
+        "config": {"workload": f"{F} x {W}x{H} {args.subsampling[0]}:{args.subsampling[1]}:{args.subsampling[2]} Q85 DRI=8 baseline frames per GPU per step (BASELINE configs[2] frame shape, "
                                f"device-resident coefficient planes)", "frames_per_gpu": F, "kernel": api.kernel_name(info),
                    "fast_arith": int(info.fast_arith), "parallelism": f"image-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

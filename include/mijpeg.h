@@ -76,6 +76,8 @@ typedef struct mijpeg_info {
   int64_t coef_offset[MIJPEG_MAX_COMPONENTS]; /* start of each component plane, in int16 units   */
   int64_t coef_count;        /* total int16 coefficients of one frame (all planes)              */
   uint16_t quant[4][64];     /* DQT deltas in natural order, index = Tq                          */
+  int32_t range_max[MIJPEG_MAX_COMPONENTS]; /* set by decode_coefficients: max over the component's blocks of
+                                sum_k |c_k| * q_k (bounds every IDCT output by 4 * range_max) */
 } mijpeg_info;
 
 /* ---- decoder object (one image at a time; one object = one host thread at a time) ---------- */

@@ -31,7 +31,7 @@ class MijpegInfo(C.Structure):
         ("quant_index", C.c_int32 * 4), ("mcus_x", C.c_int32), ("mcus_y", C.c_int32),
         ("blocks_w", C.c_int32 * 4), ("blocks_h", C.c_int32 * 4), ("restart_interval", C.c_int32),
         ("ycbcr", C.c_int32), ("fast_arith", C.c_int32), ("coef_offset", C.c_int64 * 4),
-        ("coef_count", C.c_int64), ("quant", (C.c_uint16 * 64) * 4),
+        ("coef_count", C.c_int64), ("quant", (C.c_uint16 * 64) * 4), ("range_max", C.c_int32 * 4),
     ]
 
 

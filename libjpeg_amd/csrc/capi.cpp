@@ -234,6 +234,31 @@ static bool is_420(const mijpeg_info &f)
          f.hsamp[2] == 1 && f.vsamp[2] == 1;
 }
 
+static bool is_444(const mijpeg_info &f)
+{
+  return f.components == 3 && f.hsamp[0] == 1 && f.vsamp[0] == 1 && f.hsamp[1] == 1 && f.vsamp[1] == 1 && f.hsamp[2] == 1 &&
+         f.vsamp[2] == 1;
+}
+
+static bool fast_ok(const mijpeg_batch *b)
+{
+  // fast arithmetic: range check passed (host decoder) and every delta << 4 fits a signed 16-bit operand
+  const mijpeg_info &f = b->info;
+  if (!f.fast_arith || (b->flags & MIJPEG_FLAG_FORCE_SAFE)) return false;
+  for (int c = 0; c < f.components; c++)
+    for (int i = 0; i < 64; i++)
+      if (f.quant[f.quant_index[c]][i] > 2047) return false;
+  return true;
+}
+
+// fused 4:4:4 keeps the chroma samples as packed int16: needs |sample| <= 4 * range_max < 32768
+static bool use_fused444(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  return is_444(f) && f.ycbcr && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
+         f.range_max[1] < 8190 && f.range_max[2] < 8190;
+}
+
 static bool use_fused420(const mijpeg_batch *b)
 {
   return is_420(b->info) && b->info.ycbcr && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM));
@@ -242,12 +267,12 @@ static bool use_fused420(const mijpeg_batch *b)
 const char *mijpeg_kernel_name(const mijpeg_batch *b)
 {
   if (!b) return "";
-  return use_fused420(b) ? "fused420_kernel" : "idct_planes_kernel+upsample_color_kernel";
+  return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : "idct_planes_kernel+upsample_color_kernel";
 }
 
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
 {
-  if (!b || use_fused420(b)) return 0;
+  if (!b || use_fused420(b) || use_fused444(b)) return 0;
   return (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames;
 }
 
@@ -257,14 +282,11 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   if (b->quant_dev) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: not yet
   const mijpeg_info &f = b->info;
   if (f.precision != 8 || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
-  // fast arithmetic: range check passed (host decoder) and every delta << 4 fits a signed 16-bit operand
-  bool fast = f.fast_arith && !(b->flags & MIJPEG_FLAG_FORCE_SAFE);
-  for (int c = 0; c < f.components && fast; c++)
-    for (int i = 0; i < 64; i++)
-      if (f.quant[f.quant_index[c]][i] > 2047) fast = false;
+  const bool fast = fast_ok(b);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (use_fused420(b)) {
+  const bool f444 = use_fused444(b);
+  if (use_fused420(b) || f444) {
     Fused420Args a;
     memset(&a, 0, sizeof(a));
     a.coef = b->coef_dev;
@@ -289,7 +311,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.aligned8 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 7) == 0;
     for (int c = 0; c < 3; c++)
       for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
-    rc = launch_fused420(a, fast, s);
+    rc = f444 ? launch_fused444(a, s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

@@ -72,6 +72,29 @@ __device__ __forceinline__ int mul16_hi(unsigned w, int q)
   asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "s"(q));
   return d;
 }
+// d = half(pk) * k + c with k an SGPR constant that fits 16 bits: consumes a packed int16 sample without unpacking
+__device__ __forceinline__ int mad16_lo(unsigned pk, int k, int c)
+{
+  int d;
+  asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(pk), "s"(k), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int mad16_hi(unsigned pk, int k, int c)
+{
+  int d;
+  asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(pk), "s"(k), "v"(c));
+  return d;
+}
+
+// {lo16(hi), lo16(lo)} -> one register.  volatile: the packing must happen where it is written (right after the
+// transform), otherwise the compiler keeps all 64 unpacked samples alive and packs lazily at the use.
+__device__ __forceinline__ unsigned pack_lo16_now(int hi, int lo)
+{
+  unsigned d;
+  asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi), "v"(lo), "s"(0x05040100u));
+  return d;
+}
+
 // (xa >> 17, xb >> 17), each clamped to [0,255], as two bytes in bits 0..15 (lo = a, hi = b):
 // v_perm_b32 gathers the two high halves (= x >> 16 as int16), one packed shift finishes the >> 17,
 // v_sat_pk_u8_i16 clamps and packs: 1.5 instructions per sample.
@@ -542,6 +565,127 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 }
 
 // ==============================================================================================
+// fused 4:4:4 kernel (three components, no subsampling, YCbCr): ReconstructUnsampled,
+// control/blockbitmaprequester.cpp:1013-1074
+// ==============================================================================================
+// One lane owns one block POSITION and transforms its Cb, Cr and Y blocks one after the other; the two
+// chroma results are kept as packed int16 pairs (32 + 32 VGPRs) that the colour multiply-adds read half by half
+// (v_mad_i32_i16 op_sel), the luma result stays in 64 VGPRs.  No barrier, no halo, LDS only for the coalesced
+// block fetch.  FAST arithmetic only, and only when the host's range check bounds every chroma sample by
+// 4 * range_max < 32768 (so the packing is exact); everything else takes the generic two-kernel path.
+// Algorithmic bytes: 3 x 2 B in + 3 B out = 9 B/pixel.
+template <int MINW>
+__global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  {
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+  const int x0 = gbx0 + (lane >> 3);
+
+  // all three planes have the same geometry (bw_y x bh_y blocks)
+  auto fetch = [&](u32x4 (&rows)[8], int64_t plane_off) {
+    const char *pbase = reinterpret_cast<const char *>(coef + plane_off) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  };
+
+  unsigned cbp[32], crp[32];
+  {
+    u32x4 rows[8];
+    int v[64];
+    fetch(rows, a.off_cb);
+    dequant_idct<true, false>(rows, a.q[1], v);
+#pragma unroll
+    for (int i = 0; i < 32; i++) cbp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
+    __builtin_amdgcn_sched_barrier(0); // keep the next component's loads from being hoisted above this transform (register pressure)
+    fetch(rows, a.off_cr);
+    dequant_idct<true, false>(rows, a.q[2], v);
+#pragma unroll
+    for (int i = 0; i < 32; i++) crp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int yv[64];
+  {
+    u32x4 rows[8];
+    fetch(rows, a.off_y);
+    const int X0 = gbx * 8, Y0 = gby * 8;
+    if (X0 >= a.width || Y0 >= a.height) return;
+    dequant_idct<true, false>(rows, a.q[0], yv);
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = a.aligned8 && npx == 8;
+  const int K = (2048 << 13) + 65536;
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    if (l < nln) {
+      int rr[8], gg[8], bb[8];
+#pragma unroll
+      for (int x = 0; x < 8; x++) {
+        const int yk = (yv[l * 8 + x] << 13) + K;
+        const unsigned cb2 = cbp[(l * 8 + x) >> 1], cr2 = crp[(l * 8 + x) >> 1];
+        if (x & 1) {
+          rr[x] = mad16_hi(cr2, L_CR_R, yk);
+          gg[x] = mad16_hi(cr2, -L_CR_G, mad16_hi(cb2, -L_CB_G, yk));
+          bb[x] = mad16_hi(cb2, L_CB_B, yk);
+        } else {
+          rr[x] = mad16_lo(cr2, L_CR_R, yk);
+          gg[x] = mad16_lo(cr2, -L_CR_G, mad16_lo(cb2, -L_CB_G, yk));
+          bb[x] = mad16_lo(cb2, L_CB_B, yk);
+        }
+      }
+      uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+      if (fast_store) {
+        unsigned h[12];
+#pragma unroll
+        for (int x = 0; x < 8; x += 2) {
+          h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
+          h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
+          h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
+        }
+        unsigned w[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+        u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+        __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
+        __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
+        __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+        __builtin_amdgcn_sched_barrier(0); // one line at a time: do not interleave the lines' temporaries
+      } else {
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+          if (x < npx) {
+            dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
+          }
+      }
+    }
+  }
+}
+
+// ==============================================================================================
 // generic path, kernel 1: dequant + IDCT of every block of every component into int32 sample planes
 // ==============================================================================================
 template <bool FAST>
@@ -723,6 +867,18 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
     hipLaunchKernelGGL((fused420_kernel<true, 4>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else
     hipLaunchKernelGGL((fused420_kernel<true, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused444(const Fused420Args &a, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  if (total == 0) return 0;
+  static const int variant = getenv("MIJPEG_F444_VARIANT") ? atoi(getenv("MIJPEG_F444_VARIANT")) : 0; // tuning aid
+  if (variant == 1)
+    hipLaunchKernelGGL((fused444_kernel<2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else // 168 VGPRs -> three waves per SIMD: 5 % faster than the unconstrained 171-register build
+    hipLaunchKernelGGL((fused444_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -56,6 +56,29 @@ def test_fused420_tile_edges_vs_oracle(dec, oracle, w, h, flags):
     assert bad == 0, f"{bad} differing samples, first at {np.argwhere(out != exp)[:4].tolist()}"
 
 
+@pytest.mark.parametrize("flags", [0, api.FLAG_FORCE_SAFE])
+@pytest.mark.parametrize("w,h", EDGE_SIZES + [(512, 512), (1920, 1080)])
+def test_fused444_vs_oracle(dec, oracle, w, h, flags):
+    data = synth.synth_jpeg(w, h, 300 + w + h, 88, "444", (w + h) % 5)
+    f = dec.read(data)
+    # the fused kernel only exists in the fast flavour; FORCE_SAFE must route to the generic kernels
+    assert api.kernel_name(f, flags) == ("fused444_kernel" if flags == 0 else "idct_planes_kernel+upsample_color_kernel")
+    out = dec.reconstruct(flags)
+    exp = oracle.decode(data)
+    bad = int((out != exp).sum())
+    assert bad == 0, f"{bad} differing samples, first at {np.argwhere(out != exp)[:4].tolist()}"
+
+
+def test_fused444_range_gate(dec, oracle):
+    """Chroma samples are kept as packed int16 in the fused 4:4:4 kernel: a frame whose range check does not bound
+    them below 2^15 must take the generic path (and still be exact)."""
+    data = synth.synth_jpeg(96, 64, 11, 1, "444", 0)  # quality 1: deltas of 255, huge dequantised sums
+    f = dec.read(data)
+    name = api.kernel_name(f)
+    assert (name == "fused444_kernel") == (f.fast_arith == 1 and f.range_max[1] < 8190 and f.range_max[2] < 8190)
+    assert np.array_equal(dec.reconstruct(), oracle.decode(data))
+
+
 @pytest.mark.parametrize("sub", ["444", "422", "420"])
 @pytest.mark.parametrize("w,h", [(640, 360), (333, 211)])
 def test_generic_path_vs_oracle(dec, oracle, w, h, sub):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_info_struct_layout_matches_header():
     # sizeof(mijpeg_info): 4*4 + 5*16 + 8 + 2*16 + 12 (+4 pad) + 32 + 8 + 512
-    assert ctypes.sizeof(api.MijpegInfo) == 16 + 80 + 8 + 32 + 16 + 32 + 8 + 512
+    assert ctypes.sizeof(api.MijpegInfo) == 16 + 80 + 8 + 32 + 16 + 32 + 8 + 512 + 16
 
 
 @pytest.mark.parametrize("name", SMALL_CASES)
@@ -114,4 +114,5 @@ def test_range_check_rejects_absurd_coefficients(oracle):
         q = np.array(f.quant[f.quant_index[c]][:], np.int64)
         worst = max(worst, int((np.abs(d.coefficients(c).astype(np.int64)) * q).sum(axis=2).max()))
     assert f.fast_arith == (1 if worst < 16384 else 0)
+    assert max(f.range_max[c] for c in range(f.components)) == worst
     d.close()
