@@ -151,6 +151,16 @@ def main():
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)},
     }
 
+    # HBM bytes per launch measured by the PMC passes (tools/gpu_profile.sh): counters cannot be read from inside this
+    # process, so the number measured for this exact workload is carried in profiles/ next to the CSVs it came from
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
+            t = json.load(f).get(api.kernel_name(info))
+        if t and (t["frames"], t["width"], t["height"]) == (F, W, H):
+            result["roofline"]["traffic"] = t["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0 and not args.no_end_to_end:
         # whole decode of one frame through the decoder object: host Huffman (all cores) + streaming H2D +
         # kernel + D2H into host memory.  PCIe/host inclusive -- reported beside, never as `value`.
