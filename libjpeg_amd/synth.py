@@ -50,3 +50,14 @@ def encode_jpeg(img: np.ndarray, quality: int = 85, subsampling: str = "420",
 def synth_jpeg(width: int, height: int, seed: int = 1234, quality: int = 85,
                subsampling: str = "420", restart_mcus: int = 0) -> bytes:
     return encode_jpeg(synth_image(width, height, seed), quality, subsampling, restart_mcus)
+
+
+def synth_hdr(width: int, height: int, seed: int = 99) -> np.ndarray:
+    """Synthetic HDR picture: base^2.2 * 2^(4 sin(x/400) + 2 cos(y/300)) * (1 + N(0, 0.01)),
+    floor 1e-4, float32 RGB."""
+    rng = np.random.default_rng(seed)
+    base = synth_image(width, height, seed).astype(np.float32) / 255.0
+    y, x = np.mgrid[0:height, 0:width].astype(np.float32)
+    gain = np.exp2(4.0 * np.sin(x / 400.0) + 2.0 * np.cos(y / 300.0))[..., None]
+    noise = 1.0 + rng.normal(0.0, 0.01, size=(height, width, 3)).astype(np.float32)
+    return np.maximum(base ** 2.2 * gain * noise, 1e-4).astype(np.float32)

@@ -10,6 +10,7 @@
  */
 #include "jpeg_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -51,6 +52,15 @@ typedef struct {
   int32_t mincode[17], maxcode[18], valptr[17];
 } oj_huff;
 
+/* One JPEG XT box, reassembled from its APP11 segments (boxes/box.cpp:88-200). */
+typedef struct {
+  uint32_t type;
+  uint16_t en;
+  uint8_t *data;
+  size_t len, cap;
+} oj_box;
+
+#define OJ_MAX_BOXES 32
 typedef struct {
   const uint8_t *data;
   size_t len;
@@ -58,6 +68,8 @@ typedef struct {
   oj_huff dc[4], ac[4];
   int restart_interval;
   int have_frame;
+  oj_box *boxes; /* optional: where APP11 boxes are collected (OJ_MAX_BOXES entries) */
+  int nboxes;
 } oj_parser;
 
 static int rd16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
@@ -123,7 +135,7 @@ static int parse_sof(oj_parser *ps, const uint8_t *p, int n)
   f->height = rd16(p + 1);
   f->width = rd16(p + 3);
   f->ncomp = p[5];
-  if (f->precision != 8) return OJ_ERR_UNSUPPORTED;
+  if (f->precision != 8 && f->precision != 12) return OJ_ERR_UNSUPPORTED;
   if (f->ncomp < 1 || f->ncomp > OJ_MAX_COMP || n < 6 + 3 * f->ncomp) return OJ_ERR_MALFORMED;
   if (f->width == 0 || f->height == 0) return OJ_ERR_UNSUPPORTED; /* DNL-defined height */
   f->hmax = f->vmax = 1;
@@ -350,6 +362,34 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
     case 0xc2: case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb:
     case 0xcd: case 0xce: case 0xcf:
       return OJ_ERR_UNSUPPORTED;
+    case 0xeb: /* APP11 "JP": one segment of a box: en(2) z(4) lbox(4) tbox(4) [xlbox(8)] payload; boxes/box.cpp:88-150 */
+      if (ps->boxes && n >= 2 + 2 + 2 + 4 + 4 + 4 && p[2] == 0x4a && p[3] == 0x50) {
+        const uint8_t *q = p + 4;
+        uint16_t en = (uint16_t)rd16(q);
+        uint32_t lbox = ((uint32_t)rd16(q + 6) << 16) | (uint32_t)rd16(q + 8);
+        uint32_t tbox = ((uint32_t)rd16(q + 10) << 16) | (uint32_t)rd16(q + 12);
+        const uint8_t *pay = q + 14;
+        int blen = n - 2 - 2 - 2 - 4 - 4 - 4, b;
+        if (lbox == 1) { pay += 8; blen -= 8; }
+        if (blen < 0) return OJ_ERR_MALFORMED;
+        for (b = 0; b < ps->nboxes; b++)
+          if (ps->boxes[b].type == tbox && ps->boxes[b].en == en) break;
+        if (b == ps->nboxes) {
+          if (ps->nboxes == OJ_MAX_BOXES) return OJ_ERR_UNSUPPORTED;
+          memset(&ps->boxes[b], 0, sizeof(oj_box));
+          ps->boxes[b].type = tbox; ps->boxes[b].en = en;
+          ps->nboxes++;
+        }
+        if (ps->boxes[b].len + (size_t)blen > ps->boxes[b].cap) {
+          size_t cap = (ps->boxes[b].len + (size_t)blen) * 2 + 64;
+          uint8_t *nd = (uint8_t *)realloc(ps->boxes[b].data, cap);
+          if (!nd) return OJ_ERR_NOMEM;
+          ps->boxes[b].data = nd; ps->boxes[b].cap = cap;
+        }
+        memcpy(ps->boxes[b].data + ps->boxes[b].len, pay, (size_t)blen); /* segments arrive in sequence order */
+        ps->boxes[b].len += (size_t)blen;
+      }
+      break;
     case 0xee: /* APP14 Adobe: marker/adobemarker.cpp; "Adobe" + version(2) flags0(2) flags1(2) transform(1) */
       if (n >= 14 && memcmp(p + 2, "Adobe", 5) == 0) f->adobe_transform = p[13];
       break;
@@ -357,7 +397,13 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
       const uint8_t *next = NULL;
       if (!ps->have_frame) return OJ_ERR_MALFORMED;
       f->restart_interval = ps->restart_interval;
-      if (!planes) goto done; /* header-only walk stops at the first scan */
+      if (!planes && !ps->boxes) goto done; /* header-only walk stops at the first scan (unless boxes are wanted) */
+      if (!planes) { /* skip the entropy coded data */
+        const uint8_t *q = p + n;
+        while (q + 1 < end && !(q[0] == 0xff && q[1] != 0x00 && q[1] != 0xff && !(q[1] >= 0xd0 && q[1] <= 0xd7))) q++;
+        p = q;
+        continue;
+      }
       rc = decode_scan(ps, p + 2, n - 2, p + n, end, planes, &next);
       if (rc) return rc;
       p = next;
@@ -627,45 +673,250 @@ void oj_upsample_block(int32_t out[64], const int32_t *plane, int pitch, int cw,
  * colortrafo/colortransformerfactory.cpp:136-138 (matrix).
  * ---------------------------------------------------------------------------------------- */
 #define FIX13(x) ((int64_t)((x) * 8192.0 + 0.5))
-static uint8_t clamp8(int64_t v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+static int64_t clampmax(int64_t v, int64_t max) { return v < 0 ? 0 : (v > max ? max : v); }
+/* INVERT_NEGS, colortrafo/ycbcrtrafo.cpp:66: two's complement -> sign-magnitude half-float bit pattern */
+static int16_t invert_negs(int16_t w) { return (int16_t)(((w >> 15) & 0x7fff) ^ w); }
 
-int oj_reconstruct(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint8_t *pixels, int use_ycbcr)
+/* XT profile C parameters (NULL for a plain JPEG): colortrafo/colortransformerfactory.cpp:206-594 */
+typedef struct {
+  const oj_info *rinfo;             /* residual frame geometry */
+  int32_t *const *rplanes;          /* residual coefficient planes */
+  const int32_t *ltable[3];         /* L lookup tables (2^8 entries) or NULL = none (identity) */
+  int ltrafo_ycbcr, rtrafo_ycbcr;   /* 1: YCbCr matrix, 0: identity */
+  int64_t outmax, outshift;         /* 2^(8 + extra bits) - 1 and its half */
+  int is_float, clamp;              /* OCON: cast to float (half codes), clamping */
+} oj_xt;
+
+/* Output: pixels8 (precision 8, no XT) or pixels16 (precision 12, or XT: 16 bit codes). */
+static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint8_t *pixels8, uint16_t *pixels16,
+                          int use_ycbcr, const oj_xt *xt)
 {
-  int32_t *samp[OJ_MAX_COMP] = {0, 0, 0, 0};
+  int32_t *samp[OJ_MAX_COMP] = {0, 0, 0, 0}, *rsamp[OJ_MAX_COMP] = {0, 0, 0, 0};
   int c, X0, Y0, x, y, rc = OJ_OK;
   int ycc = use_ycbcr < 0 ? f->ycbcr : use_ycbcr;
   const int64_t L[9] = {FIX13(1.0), FIX13(0.0), FIX13(1.40200),
                         FIX13(1.0), -FIX13(0.3441362861), -FIX13(0.7141362859),
                         FIX13(1.0), FIX13(1.772), FIX13(0.0)};
   const int32_t dcshift = (int32_t)(1 << (f->precision - 1)) << 4;
+  const int64_t maxval = ((int64_t)1 << f->precision) - 1;
   for (c = 0; c < f->ncomp; c++) {
     if (!f->quant_defined[f->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
     samp[c] = (int32_t *)malloc((size_t)f->bw[c] * f->bh[c] * 64 * sizeof(int32_t));
     if (!samp[c]) { rc = OJ_ERR_NOMEM; goto out; }
     oj_idct_plane(samp[c], planes[c], f->bw[c], f->bh[c], f->quant[f->tq[c]], f->precision);
+    if (xt) { /* residual: same transform, level shift 2^(Pr-1) (control/residualblockhelper.cpp:191-202) */
+      const oj_info *r = xt->rinfo;
+      if (!r->quant_defined[r->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
+      rsamp[c] = (int32_t *)malloc((size_t)r->bw[c] * r->bh[c] * 64 * sizeof(int32_t));
+      if (!rsamp[c]) { rc = OJ_ERR_NOMEM; goto out; }
+      oj_idct_plane(rsamp[c], xt->rplanes[c], r->bw[c], r->bh[c], r->quant[r->tq[c]], r->precision);
+    }
   }
   for (Y0 = 0; Y0 < f->height; Y0 += 8)
     for (X0 = 0; X0 < f->width; X0 += 8) {
-      int32_t blk[OJ_MAX_COMP][64];
-      for (c = 0; c < f->ncomp; c++)
+      int32_t blk[OJ_MAX_COMP][64], rblk[OJ_MAX_COMP][64];
+      for (c = 0; c < f->ncomp; c++) {
         oj_upsample_block(blk[c], samp[c], f->bw[c] * 8, f->cw[c], f->ch[c], f->subx[c], f->suby[c], X0, Y0);
+        if (xt) {
+          const oj_info *r = xt->rinfo;
+          oj_upsample_block(rblk[c], rsamp[c], r->bw[c] * 8, r->cw[c], r->ch[c], r->subx[c], r->suby[c], X0, Y0);
+        }
+      }
       for (y = 0; y < 8 && Y0 + y < f->height; y++)
         for (x = 0; x < 8 && X0 + x < f->width; x++) {
-          uint8_t *px = pixels + ((size_t)(Y0 + y) * f->width + (X0 + x)) * f->ncomp;
+          const size_t pix = ((size_t)(Y0 + y) * f->width + (X0 + x)) * f->ncomp;
           int k = y * 8 + x;
+          int64_t v[OJ_MAX_COMP];
           if (ycc && f->ncomp == 3) {
             int64_t yy = blk[0][k], cb = (int64_t)blk[1][k] - dcshift, cr = (int64_t)blk[2][k] - dcshift;
-            px[0] = clamp8((yy * L[0] + cb * L[1] + cr * L[2] + 65536) >> 17);
-            px[1] = clamp8((yy * L[3] + cb * L[4] + cr * L[5] + 65536) >> 17);
-            px[2] = clamp8((yy * L[6] + cb * L[7] + cr * L[8] + 65536) >> 17);
+            v[0] = (yy * L[0] + cb * L[1] + cr * L[2] + 65536) >> 17;
+            v[1] = (yy * L[3] + cb * L[4] + cr * L[5] + 65536) >> 17;
+            v[2] = (yy * L[6] + cb * L[7] + cr * L[8] + 65536) >> 17;
           } else {
-            for (c = 0; c < f->ncomp; c++) px[c] = clamp8(((int64_t)blk[c][k] + 8) >> 4);
+            for (c = 0; c < f->ncomp; c++) v[c] = ((int64_t)blk[c][k] + 8) >> 4;
+          }
+          if (xt) {
+            /* colortrafo/ycbcrtrafo.cpp:750-829 (residual), :861-878 (L-LUT, C = identity, merge), :897-955 (half clamp) */
+            const oj_info *r = xt->rinfo;
+            const int64_t rmax16 = ((((int64_t)1 << r->precision)) << 4) - 1; /* ((m_lRMax + 1) << COLOR_BITS) - 1 */
+            const int64_t omax16 = ((xt->outmax + 1) << 4) - 1;
+            int64_t rr[3];
+            /* Q tables: identity, 2^(Pr + 4) -> 2^(16 + 4): scales by 2^(16 - Pr)  (parametrictonemappingbox.cpp:387-430) */
+            int64_t ry = clampmax(rblk[0][k], rmax16) << (16 - r->precision);
+            int64_t rcb = clampmax(rblk[1][k], rmax16) << (16 - r->precision);
+            int64_t rcr = clampmax(rblk[2][k], rmax16) << (16 - r->precision);
+            if (xt->rtrafo_ycbcr) {
+              rcb -= xt->outshift << 4; rcr -= xt->outshift << 4;
+              rr[0] = (ry * L[0] + rcb * L[1] + rcr * L[2] + 4096) >> 13; /* FIX_COLOR_TO_INTCOLOR */
+              rr[1] = (ry * L[3] + rcb * L[4] + rcr * L[5] + 4096) >> 13;
+              rr[2] = (ry * L[6] + rcb * L[7] + rcr * L[8] + 4096) >> 13;
+            } else {
+              rr[0] = ry; rr[1] = rcb; rr[2] = rcr;
+            }
+            /* R2 tables: identity 2^(16 + 4) -> 2^16: floor(x / 16 + 0.5) */
+            for (c = 0; c < 3; c++) rr[c] = (clampmax(rr[c], omax16) + 8) >> 4;
+            for (c = 0; c < 3; c++) {
+              int64_t lv = xt->ltable[c] ? xt->ltable[c][clampmax(v[c], maxval)] : v[c];
+              v[c] = lv + rr[c] - xt->outshift; /* C transformation = identity: FIX_TO_INT(x * 8192) == x */
+            }
+            if (xt->is_float && xt->clamp) {
+              const int64_t pinf = (xt->outmax >> 1) - (xt->outmax >> 6) - 1;
+              const int64_t minf = invert_negs((int16_t)(uint16_t)(pinf | 0x8000));
+              for (c = 0; c < 3; c++) {
+                int64_t t = v[c] > pinf ? pinf : (v[c] < minf ? minf : v[c]);
+                pixels16[pix + c] = (uint16_t)invert_negs((int16_t)t);
+              }
+            } else {
+              for (c = 0; c < 3; c++) pixels16[pix + c] = (uint16_t)clampmax(v[c], xt->outmax);
+            }
+          } else if (pixels8) {
+            for (c = 0; c < f->ncomp; c++) pixels8[pix + c] = (uint8_t)clampmax(v[c], maxval);
+          } else {
+            for (c = 0; c < f->ncomp; c++) pixels16[pix + c] = (uint16_t)clampmax(v[c], maxval);
           }
         }
     }
 out:
-  for (c = 0; c < OJ_MAX_COMP; c++) free(samp[c]);
+  for (c = 0; c < OJ_MAX_COMP; c++) { free(samp[c]); free(rsamp[c]); }
   return rc;
+}
+
+int oj_reconstruct(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint8_t *pixels, int use_ycbcr)
+{
+  if (f->precision != 8) return OJ_ERR_UNSUPPORTED;
+  return reconstruct_ex(f, planes, pixels, NULL, use_ycbcr, NULL);
+}
+
+int oj_reconstruct16(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint16_t *pixels, int use_ycbcr)
+{
+  return reconstruct_ex(f, planes, NULL, pixels, use_ycbcr, NULL);
+}
+
+
+/* ------------------------------------------------------------------------------------------
+ * JPEG XT (ISO/IEC 18477) profile C, the subset the reference's encoder writes for
+ * `-r -h -profile c -r12`: legacy 8-bit codestream + APP11 boxes SPEC{LTRF,RTRF,LPTS,OCON}, TONE (explicit
+ * inverse tone mapping table) and RESI (a second, 12-bit Huffman sequential codestream).
+ * Box plumbing: codestream/tables.cpp:1172-1277, boxes/box.cpp:88-200, boxes/mergingspecbox.cpp.
+ * ---------------------------------------------------------------------------------------- */
+#define BOXID(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
+
+static void free_boxes(oj_box *boxes, int n) { int i; for (i = 0; i < n; i++) free(boxes[i].data); }
+
+int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float)
+{
+  oj_box boxes[OJ_MAX_BOXES];
+  oj_parser ps;
+  oj_info rinfo;
+  oj_xt xt;
+  int32_t *planes[OJ_MAX_COMP] = {0, 0, 0, 0}, *rplanes[OJ_MAX_COMP] = {0, 0, 0, 0};
+  int32_t *tables[16];
+  int32_t *identity = NULL;
+  const oj_box *spec = NULL, *resi = NULL;
+  int ltrafo = 255, rtrafo = 255, ctrafo = 255, lidx[4] = {255, 255, 255, 255}, have_lpts = 0;
+  int ocon = -1, b, c, rc;
+  size_t j;
+  *pixels = NULL;
+  memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(tables, 0, sizeof(tables));
+  ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes;
+  rc = walk(&ps, NULL);
+  if (rc) { free_boxes(boxes, ps.nboxes); return rc; }
+  for (b = 0; b < ps.nboxes; b++) {
+    if (boxes[b].type == BOXID('S', 'P', 'E', 'C')) spec = &boxes[b];
+    if (boxes[b].type == BOXID('R', 'E', 'S', 'I')) resi = &boxes[b];
+    if (boxes[b].type == BOXID('F', 'I', 'N', 'E') || boxes[b].type == BOXID('R', 'F', 'I', 'N')) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+    if (boxes[b].type == BOXID('T', 'O', 'N', 'E')) {
+      /* boxes/inversetonemappingbox.cpp: index/residual-bits byte, then 2^n 16-bit entries */
+      const oj_box *t = &boxes[b];
+      int idx, n, i;
+      if (t->len < 1 + 512 || !(t->len & 1)) { rc = OJ_ERR_MALFORMED; goto out; }
+      idx = t->data[0] >> 4; n = (int)((t->len - 1) >> 1);
+      if ((t->data[0] & 15) > 8 || n != 256) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+      tables[idx] = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+      if (!tables[idx]) { rc = OJ_ERR_NOMEM; goto out; }
+      for (i = 0; i < n; i++) tables[idx][i] = rd16(t->data + 1 + 2 * i);
+    }
+  }
+  if (!spec || !resi || info->ncomp != 3 || info->precision != 8) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  for (j = 0; j + 8 <= spec->len;) { /* superbox: LBox(4) TBox(4) payload (boxes/superbox.cpp) */
+    uint32_t l = ((uint32_t)rd16(spec->data + j) << 16) | (uint32_t)rd16(spec->data + j + 2);
+    uint32_t t = ((uint32_t)rd16(spec->data + j + 4) << 16) | (uint32_t)rd16(spec->data + j + 6);
+    const uint8_t *pl = spec->data + j + 8;
+    if (l < 8 || j + l > spec->len) { rc = OJ_ERR_MALFORMED; goto out; }
+    if (t == BOXID('L', 'T', 'R', 'F')) ltrafo = pl[0] >> 4;
+    else if (t == BOXID('R', 'T', 'R', 'F')) rtrafo = pl[0] >> 4;
+    else if (t == BOXID('C', 'T', 'R', 'F')) ctrafo = pl[0] >> 4;
+    else if (t == BOXID('L', 'P', 'T', 'S')) { have_lpts = 1; lidx[0] = pl[0] >> 4; lidx[1] = pl[0] & 15; lidx[2] = pl[1] >> 4; lidx[3] = pl[1] & 15; }
+    else if (t == BOXID('O', 'C', 'O', 'N')) ocon = pl[0];
+    else if (t == BOXID('R', 'S', 'P', 'C')) { if (pl[0]) { rc = OJ_ERR_UNSUPPORTED; goto out; } }
+    else if (t == BOXID('L', 'D', 'C', 'T') || t == BOXID('R', 'D', 'C', 'T')) { if ((pl[0] >> 4) != 0 && (pl[0] >> 4) != 2) { rc = OJ_ERR_UNSUPPORTED; goto out; } }
+    else { rc = OJ_ERR_UNSUPPORTED; goto out; } /* Q/R/R2/S tables, D/S transformations, ...: outside the subset */
+    j += l;
+  }
+  /* codestream/tables.cpp:1994-2031 and the R analogue: undefined -> YCbCr for three components */
+  if (ltrafo == 255) ltrafo = 2;
+  if (rtrafo == 255) rtrafo = 2;
+  if ((ltrafo != 1 && ltrafo != 2) || (rtrafo != 1 && rtrafo != 2) || (ctrafo != 255 && ctrafo != 1)) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  if (ocon < 0 || (ocon & 0x08) || (ocon & 0x01)) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* lossless / output lookup */
+  memset(&xt, 0, sizeof(xt));
+  xt.outmax = ((int64_t)1 << (8 + (ocon >> 4))) - 1;
+  xt.outshift = (xt.outmax + 1) >> 1;
+  xt.is_float = (ocon & 0x04) ? 1 : 0;
+  xt.clamp = (ocon & 0x02) ? 1 : 0;
+  if (!xt.clamp || xt.outmax != 65535) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  xt.ltrafo_ycbcr = ltrafo == 2; xt.rtrafo_ycbcr = rtrafo == 2;
+  for (c = 0; c < 3; c++) {
+    if (have_lpts) {
+      if (!tables[lidx[c]]) { rc = OJ_ERR_MALFORMED; goto out; } /* "the L lookup table specified in the codestream does not exist" */
+      xt.ltable[c] = tables[lidx[c]];
+    } else { /* identity, e = 1: floor((2^16 - 1) * (i / (2^8 - 1)) + 0.5) = 257 i */
+      if (!identity) {
+        int i;
+        identity = (int32_t *)malloc(256 * sizeof(int32_t));
+        if (!identity) { rc = OJ_ERR_NOMEM; goto out; }
+        for (i = 0; i < 256; i++) identity[i] = 257 * i;
+      }
+      xt.ltable[c] = identity;
+    }
+  }
+  /* the residual codestream is an ordinary codestream of its own (codestream/image.cpp:1264-1300) */
+  rc = oj_read_info(resi->data, resi->len, &rinfo);
+  if (rc) goto out;
+  if (rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp) { rc = OJ_ERR_MALFORMED; goto out; }
+  if (rinfo.precision + 4 > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  info->ycbcr = xt.ltrafo_ycbcr;
+  for (c = 0; c < 3; c++) {
+    planes[c] = (int32_t *)malloc((size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
+    rplanes[c] = (int32_t *)malloc((size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
+    if (!planes[c] || !rplanes[c]) { rc = OJ_ERR_NOMEM; goto out; }
+  }
+  rc = oj_decode_coefficients(data, len, info, planes);
+  if (rc) goto out;
+  rc = oj_decode_coefficients(resi->data, resi->len, &rinfo, rplanes);
+  if (rc) goto out;
+  xt.rinfo = &rinfo; xt.rplanes = rplanes;
+  *pixels = (uint16_t *)malloc((size_t)info->width * info->height * 3 * sizeof(uint16_t));
+  if (!*pixels) { rc = OJ_ERR_NOMEM; goto out; }
+  rc = reconstruct_ex(info, planes, NULL, *pixels, xt.ltrafo_ycbcr, &xt);
+  if (rc) { free(*pixels); *pixels = NULL; }
+  if (is_float) *is_float = xt.is_float;
+out:
+  for (c = 0; c < OJ_MAX_COMP; c++) { free(planes[c]); free(rplanes[c]); }
+  for (c = 0; c < 16; c++) free(tables[c]);
+  free(identity);
+  free_boxes(boxes, ps.nboxes);
+  return rc;
+}
+
+/* Exact half -> float expansion the reference CLI applies before writing PFM (cmd/iohelpers.hpp:60-77). */
+float oj_half_to_float(uint16_t h)
+{
+  const int sign = h >> 15, exp = (h >> 10) & 31, man = h & 1023;
+  double v;
+  if (exp == 0) v = ldexp((double)man, -14 - 10);
+  else if (exp == 31) v = HUGE_VAL;
+  else v = ldexp((double)(man | 1024), -15 - 10 + exp);
+  return (float)(sign ? -v : v);
 }
 
 int oj_decode(const uint8_t *data, size_t len, oj_info *info, uint8_t **pixels)

@@ -86,6 +86,14 @@ void oj_upsample_block(int32_t out[64], const int32_t *plane, int pitch, int cw,
 int oj_reconstruct(const oj_info *info, int32_t *const planes[OJ_MAX_COMP], uint8_t *pixels,
                    int use_ycbcr);
 
+/* Same for frames of precision 12 (and 8): 16-bit samples out. */
+int oj_reconstruct16(const oj_info *info, int32_t *const planes[OJ_MAX_COMP], uint16_t *pixels, int use_ycbcr);
+
+/* JPEG XT profile C (subset: explicit L table, identity Q/R2 tables, standard matrices, no refinement scans):
+ * 16-bit codes out (half-float bit patterns when *is_float). colortrafo/ycbcrtrafo.cpp:750-955. */
+int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float);
+float oj_half_to_float(uint16_t h);
+
 /* Convenience: whole decode.  *pixels is malloc'ed (free with oj_free). */
 int oj_decode(const uint8_t *data, size_t len, oj_info *info, uint8_t **pixels);
 void oj_free(void *p);

@@ -53,6 +53,10 @@ def lib():
         L.oj_upsample_block.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7
         L.oj_upsample_block.restype = None
         L.oj_reconstruct.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        L.oj_reconstruct16.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        L.oj_decode_xt.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L.oj_free.argtypes = [C.c_void_p]
+        L.oj_free.restype = None
         _lib = L
     return _lib
 
@@ -85,6 +89,41 @@ def reconstruct(info: OjInfo, planes, use_ycbcr: int = -1) -> np.ndarray:
     if rc:
         raise ValueError(f"oracle: oj_reconstruct failed rc={rc}")
     return out
+
+
+def reconstruct16(info: OjInfo, planes, use_ycbcr: int = -1) -> np.ndarray:
+    """Coefficient planes of a precision 8 or 12 frame -> (H, W, ncomp) uint16."""
+    planes = [np.ascontiguousarray(p, np.int32) for p in planes]
+    ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - info.ncomp))
+    out = np.zeros((info.height, info.width, info.ncomp), np.uint16)
+    rc = lib().oj_reconstruct16(C.byref(info), ptrs, out.ctypes.data, use_ycbcr)
+    if rc:
+        raise ValueError(f"oracle: oj_reconstruct16 failed rc={rc}")
+    return out
+
+
+def decode16(data: bytes, use_ycbcr: int = -1) -> np.ndarray:
+    info, planes = decode_coefficients(data)
+    return reconstruct16(info, planes, use_ycbcr)
+
+
+def decode_xt(data: bytes):
+    """JPEG XT profile C -> ((H, W, 3) uint16 codes, is_float).  With is_float the codes are half-float bit patterns."""
+    info = OjInfo()
+    px = C.c_void_p()
+    isf = C.c_int(0)
+    rc = lib().oj_decode_xt(data, len(data), C.byref(info), C.byref(px), C.byref(isf))
+    if rc:
+        raise ValueError(f"oracle: oj_decode_xt failed rc={rc}")
+    n = info.width * info.height * 3
+    out = np.ctypeslib.as_array((C.c_uint16 * n).from_address(px.value)).reshape(info.height, info.width, 3).copy()
+    lib().oj_free(px)
+    return out, bool(isf.value)
+
+
+def half_codes_to_float(codes: np.ndarray) -> np.ndarray:
+    """cmd/iohelpers.hpp:60-77 (HalfToDouble) for finite codes: exact, so numpy's float16 view does the same."""
+    return codes.view(np.float16).astype(np.float32)
 
 
 def decode(data: bytes, use_ycbcr: int = -1) -> np.ndarray:
@@ -138,6 +177,47 @@ def write_ppm(path: str, img: np.ndarray) -> None:
     with open(path, "wb") as f:
         f.write(b"P%d\n%d %d\n255\n" % (6 if ch == 3 else 5, w, h))
         f.write(np.ascontiguousarray(img, np.uint8).tobytes())
+
+
+def read_pfm_reference(path: str) -> np.ndarray:
+    """PFM as the reference CLI writes it (cmd/reconstruct.cpp:321-323, cmd/bitmaphook.cpp:282-305):
+    'PF' / 'Pf' header, scale line, then big-endian float32 samples, top line first."""
+    with open(path, "rb") as f:
+        d = f.read()
+    magic, rest = d.split(b"\n", 1)
+    dims, rest = rest.split(b"\n", 1)
+    scale, rest = rest.split(b"\n", 1)
+    w, h = map(int, dims.split())
+    ch = 3 if magic == b"PF" else 1
+    return np.frombuffer(rest, ">f4", w * h * ch).reshape(h, w, ch).astype(np.float32)
+
+
+def write_pfm(path: str, img: np.ndarray) -> None:
+    """Standard little-endian PFM (bottom line first) as the reference encoder reads it."""
+    h, w = img.shape[:2]
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        f.write(np.ascontiguousarray(img[::-1], "<f4").tobytes())
+
+
+def reference_decode_hdr(data: bytes) -> np.ndarray:
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        src, dst = os.path.join(d, "in.jpg"), os.path.join(d, "out.pfm")
+        with open(src, "wb") as f:
+            f.write(data)
+        subprocess.run([REF_BIN, src, dst], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return read_pfm_reference(dst)
+
+
+def reference_encode_hdr(img: np.ndarray, args) -> bytes:
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        src, dst = os.path.join(d, "in.pfm"), os.path.join(d, "out.jpg")
+        write_pfm(src, img)
+        subprocess.run([REF_BIN, *args, src, dst], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        with open(dst, "rb") as f:
+            return f.read()
 
 
 def reference_decode(data: bytes, extra_args=()) -> np.ndarray:

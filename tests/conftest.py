@@ -21,7 +21,9 @@ def load_manifest():
 
 
 MANIFEST = load_manifest()
-SMALL_CASES = sorted(k for k, v in MANIFEST.items() if not v.get("big"))
+SMALL_CASES = sorted(k for k, v in MANIFEST.items() if not v.get("big") and "kind" not in v)  # 8-bit integer output
+XT_CASES = sorted(k for k, v in MANIFEST.items() if v.get("kind") == "xt_float32")
+P12_CASES = sorted(k for k, v in MANIFEST.items() if v.get("kind") == "u16")
 BIG_CASES = sorted(k for k, v in MANIFEST.items() if v.get("big"))
 
 
@@ -37,8 +39,9 @@ def golden_pixels(name: str):
     fn = ent.get("pixels_file")
     if not fn:
         return None
+    dtype = {"xt_float32": "<f4", "u16": "<u2"}.get(ent.get("kind"), np.uint8)
     with open(os.path.join(GOLDEN_DIR, fn), "rb") as f:
-        return np.frombuffer(f.read(), np.uint8).reshape(ent["height"], ent["width"], ent["channels"])
+        return np.frombuffer(f.read(), dtype).reshape(ent["height"], ent["width"], ent["channels"])
 
 
 def big_jpeg(name: str):

@@ -75,10 +75,39 @@ case("pil_9x9_420", 9, 9, 26, "pil", quality=95, sub="420", dri=0)
 case("pil_1x1_444", 1, 1, 27, "pil", quality=95, sub="444", dri=0)
 case("pil_80x48_444_adobe0", 80, 48, 28, "pil", quality=75, sub="444", dri=0, adobe=0)
 case("pil_80x48_420_adobe1", 80, 48, 29, "pil", quality=75, sub="420", dri=0, adobe=1)
+# JPEG XT profile C (BASELINE config 5, small analogues): HDR float input, reference encoder, reference PFM output
+case("xt_64x48_444", 64, 48, 5, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12"])
+case("xt_75x45_444", 75, 45, 6, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12"])
+case("xt_129x71_420", 129, 71, 7, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-s", "1x1,2x2,2x2"])
+case("xt_200x120_420_q60", 200, 120, 8, "xt", args=["-r", "-q", "60", "-Q", "70", "-h", "-profile", "c", "-r12", "-s", "1x1,2x2,2x2"])
+case("xt_33x17_422", 33, 17, 9, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-s", "1x1,2x1,2x1"])
+# plain 12-bit extended sequential (SOF1, P = 12): what the residual codestream of profile C is made of
+case("p12_64x48_444", 64, 48, 30, "p12", args=["-q", "85"])
+case("p12_120x90_420_dri3", 120, 90, 31, "p12", args=["-q", "85", "-s", "1x1,2x2,2x2", "-z", "3"])
 # full-size configs 2 / 3 (hash-only)
 case("big_4k_420_q85", 3840, 2160, 1234, "pil", quality=85, sub="420", dri=0, big=True)
 case("big_4k_420_q85_dri8", 3840, 2160, 1234, "pil", quality=85, sub="420", dri=8, big=True)
 case("big_8k_420_q85_dri8", 7680, 4320, 1234, "pil", quality=85, sub="420", dri=8, big=True)
+
+
+def synth_p12(w, h, seed):
+    img = synth.synth_image(w, h, seed).astype(np.uint16) * 16
+    return (img + (np.arange(w, dtype=np.uint16) % 16)[None, :, None]).astype(np.uint16)
+
+
+def encode_p12(img, args):
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+        h, w = img.shape[:2]
+        with open(d + "/in.ppm", "wb") as f:
+            f.write(b"P6\n%d %d\n4095\n" % (w, h))
+            f.write(img.astype(">u2").tobytes())
+        subprocess.run([O.REF_BIN, *args, d + "/in.ppm", d + "/o.jpg"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        data = open(d + "/o.jpg", "rb").read()
+        subprocess.run([O.REF_BIN, d + "/o.jpg", d + "/o.ppm"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        raw = open(d + "/o.ppm", "rb").read().split(b"\n", 3)[3]
+        return data, np.frombuffer(raw, ">u2", w * h * 3).reshape(h, w, 3).astype(np.uint16)
 
 
 def main():
@@ -86,6 +115,29 @@ def main():
     assert O.have_reference(), "oracle/_ref/jpeg missing: run `make -C oracle ref`"
     manifest = {}
     for c in CASES:
+        if c["enc"] in ("xt", "p12"):
+            if c["enc"] == "xt":
+                hdr = synth.synth_hdr(c["w"], c["h"], c["seed"]) * 4.0
+                data = O.reference_encode_hdr(hdr, c["args"])
+                ref = O.reference_decode_hdr(data)  # float32, what the reference CLI wrote as PFM
+                assert ref.shape == (c["h"], c["w"], 3)
+                pixel_bytes = np.ascontiguousarray(ref, "<f4").tobytes()
+                kind = "xt_float32"
+            else:
+                data, ref = encode_p12(synth_p12(c["w"], c["h"], c["seed"]), c["args"])
+                pixel_bytes = np.ascontiguousarray(ref, "<u2").tobytes()
+                kind = "u16"
+            ent = dict(width=c["w"], height=c["h"], channels=3, seed=c["seed"], encoder=c["enc"], kind=kind, args=c["args"],
+                       jpeg_sha256=sha(data), pixels_sha256=sha(pixel_bytes), jpeg_bytes=len(data))
+            with open(os.path.join(OUT, c["name"] + ".jpg"), "wb") as f:
+                f.write(data)
+            if len(pixel_bytes) <= 120000:
+                with open(os.path.join(OUT, c["name"] + ".bin"), "wb") as f:
+                    f.write(pixel_bytes)
+                ent["pixels_file"] = c["name"] + ".bin"
+            manifest[c["name"]] = ent
+            print(c["name"], len(data), ent["pixels_sha256"][:12])
+            continue
         img = synth.synth_image(c["w"], c["h"], c["seed"])
         if c["enc"] == "ref":
             data = O.reference_encode(img, c["args"])

@@ -10,7 +10,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import BIG_CASES, MANIFEST, SMALL_CASES, big_jpeg, golden_jpeg, golden_pixels
+from conftest import BIG_CASES, MANIFEST, P12_CASES, SMALL_CASES, XT_CASES, big_jpeg, golden_jpeg, golden_pixels
 from libjpeg_amd import synth
 
 
@@ -32,6 +32,40 @@ def test_oracle_matches_reference_4k(oracle, name):
         pytest.skip("this box's Pillow produces different bytes than the manifest recipe")
     out = oracle.decode(data)
     assert hashlib.sha256(out.tobytes()).hexdigest() == MANIFEST[name]["pixels_sha256"]
+
+
+@pytest.mark.parametrize("name", XT_CASES)
+def test_oracle_xt_profile_c_matches_reference_golden(oracle, name):
+    """JPEG XT profile C: half-float codes, expanded exactly like cmd/bitmaphook.cpp:282-305 does, must equal the floats
+    the reference wrote into its PFM, bit for bit."""
+    ent = MANIFEST[name]
+    codes, is_float = oracle.decode_xt(golden_jpeg(name))
+    assert is_float and codes.shape == (ent["height"], ent["width"], 3)
+    out = oracle.half_codes_to_float(codes)
+    exp = golden_pixels(name)
+    if exp is not None:
+        assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
+    assert hashlib.sha256(np.ascontiguousarray(out, "<f4").tobytes()).hexdigest() == ent["pixels_sha256"]
+
+
+@pytest.mark.parametrize("name", P12_CASES)
+def test_oracle_12bit_matches_reference_golden(oracle, name):
+    ent = MANIFEST[name]
+    out = oracle.decode16(golden_jpeg(name))
+    exp = golden_pixels(name)
+    if exp is not None:
+        assert np.array_equal(out, exp)
+    assert hashlib.sha256(np.ascontiguousarray(out, "<u2").tobytes()).hexdigest() == ent["pixels_sha256"]
+
+
+def test_oracle_xt_vs_live_reference(oracle):
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/jpeg not built (needs /root/reference)")
+    for w, h, extra in [(97, 61, []), (160, 112, ["-s", "1x1,2x2,2x2"]), (48, 80, ["-q", "40", "-Q", "50"])]:
+        data = oracle.reference_encode_hdr(synth.synth_hdr(w, h, w) * 3.0, ["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12"] + extra)
+        codes, _ = oracle.decode_xt(data)
+        ref = oracle.reference_decode_hdr(data)
+        assert np.array_equal(oracle.half_codes_to_float(codes).view(np.uint32), ref.view(np.uint32))
 
 
 def test_scan_order_and_quant_natural_order(oracle):
