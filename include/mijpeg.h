@@ -78,7 +78,27 @@ typedef struct mijpeg_info {
   uint16_t quant[4][64];     /* DQT deltas in natural order, index = Tq                          */
   int32_t range_max[MIJPEG_MAX_COMPONENTS]; /* set by decode_coefficients: max over the component's blocks of
                                 sum_k |c_k| * q_k (bounds every IDCT output by 4 * range_max) */
+  int32_t sample_bytes;      /* bytes per output sample: 1 (precision 8), 2 (precision 12, JPEG XT)          */
+  int32_t xt;                /* 1 = JPEG XT profile C stream: output = 16-bit codes, see mijpeg_xt_params     */
+  int32_t is_float;          /* JPGTAG_IMAGE_IS_FLOAT: the 16-bit codes are half-float bit patterns          */
+  int32_t reserved;
 } mijpeg_info;
+
+/* JPEG XT (ISO/IEC 18477-7) profile C parameters of the loaded stream, valid when info.xt != 0:
+ * what ColorTransformerFactory::InstallIntegerParameters (colortrafo/colortransformerfactory.cpp:300-594)
+ * installs into YCbCrTrafo<UWORD,3,Residual|Extended|ClampFlag|Float,...>.  Supported subset: explicit (TONE box)
+ * or identity L tables, identity Q and R2 tables, standard YCbCr / identity L and R transformations, identity C
+ * transformation, residual codestream = Huffman sequential 12 bit, no refinement scans. */
+typedef struct mijpeg_xt_params {
+  mijpeg_info residual;      /* residual codestream: geometry and quantiser tables; its coef_offset[] are offsets
+                                into the SAME per-frame coefficient buffer, behind the legacy planes            */
+  int32_t ltable[3][256];    /* L lookup tables per component: 8 bit in, 16 bit out                             */
+  int32_t ltrafo_ycbcr;      /* L transformation: 1 = YCbCr -> RGB, 0 = identity                                */
+  int32_t rtrafo_ycbcr;      /* R transformation                                                                */
+  int32_t out_max;           /* 2^(8 + extra range bits) - 1 = 65535                                            */
+  int32_t out_shift;         /* (out_max + 1) / 2                                                               */
+  int32_t is_float, clamp;   /* output conversion box: cast to float, clamping                                  */
+} mijpeg_xt_params;
 
 /* ---- decoder object (one image at a time; one object = one host thread at a time) ---------- */
 
@@ -104,6 +124,9 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads);
 /* Current frame information (after mijpeg_decode_coefficients it includes fast_arith). */
 int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info);
 
+/* JPEG XT parameters of the loaded stream (MIJPEG_ERR_OBJECT_DOESNT_EXIST if it is a plain JPEG). */
+int mijpeg_get_xt_params(mijpeg_decoder *d, mijpeg_xt_params *xt);
+
 /* Host view of a decoded component plane: blocks_h x blocks_w x 64 int16. */
 const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component);
 
@@ -111,7 +134,7 @@ const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component);
 const int16_t *mijpeg_device_coefficients(mijpeg_decoder *d);
 
 /* Reconstruct the whole frame on the GPU into DEVICE memory: interleaved 8-bit samples,
- * `components` bytes per pixel, `row_stride` bytes per line.  Asynchronous on the decoder's stream
+ * `components * sample_bytes` bytes per pixel, `row_stride` bytes per line.  Asynchronous on the decoder's stream
  * unless `sync` is non-zero. */
 int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_stride, uint32_t flags,
                               int sync);
@@ -147,6 +170,7 @@ typedef struct mijpeg_batch {
   uint32_t flags;
   void *workspace;             /* device scratch for the unfused path, see mijpeg_workspace_bytes     */
   size_t workspace_bytes;
+  const mijpeg_xt_params *xt;  /* required when info.xt != 0 (host memory)                            */
 } mijpeg_batch;
 
 /* Device scratch the batch needs (0 for the fused kernels). */

@@ -32,6 +32,14 @@ class MijpegInfo(C.Structure):
         ("blocks_w", C.c_int32 * 4), ("blocks_h", C.c_int32 * 4), ("restart_interval", C.c_int32),
         ("ycbcr", C.c_int32), ("fast_arith", C.c_int32), ("coef_offset", C.c_int64 * 4),
         ("coef_count", C.c_int64), ("quant", (C.c_uint16 * 64) * 4), ("range_max", C.c_int32 * 4),
+        ("sample_bytes", C.c_int32), ("xt", C.c_int32), ("is_float", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class MijpegXtParams(C.Structure):
+    _fields_ = [
+        ("residual", MijpegInfo), ("ltable", (C.c_int32 * 256) * 3), ("ltrafo_ycbcr", C.c_int32), ("rtrafo_ycbcr", C.c_int32),
+        ("out_max", C.c_int32), ("out_shift", C.c_int32), ("is_float", C.c_int32), ("clamp", C.c_int32),
     ]
 
 
@@ -40,7 +48,7 @@ class MijpegBatch(C.Structure):
         ("info", MijpegInfo), ("coef_dev", C.c_void_p), ("coef_frame_stride", C.c_int64),
         ("quant_dev", C.c_void_p), ("out_dev", C.c_void_p), ("out_frame_stride", C.c_int64),
         ("out_row_stride", C.c_int64), ("frames", C.c_int32), ("flags", C.c_uint32),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("xt", C.POINTER(MijpegXtParams)),
     ]
 
 
@@ -85,6 +93,7 @@ def lib():
         L.mijpeg_set_input.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.mijpeg_read_header.argtypes = [C.c_void_p, P(MijpegInfo)]
         L.mijpeg_get_info.argtypes = [C.c_void_p, P(MijpegInfo)]
+        L.mijpeg_get_xt_params.argtypes = [C.c_void_p, P(MijpegXtParams)]
         L.mijpeg_decode_coefficients.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_coefficients.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_coefficients.restype = C.c_void_p
@@ -150,6 +159,11 @@ class Decoder:
         self.info = info
         return info
 
+    def xt_params(self) -> MijpegXtParams:
+        xt = MijpegXtParams()
+        self._check(lib().mijpeg_get_xt_params(self._h, C.byref(xt)))
+        return xt
+
     def coefficients(self, comp: int) -> np.ndarray:
         f = self.info
         p = lib().mijpeg_coefficients(self._h, comp)
@@ -171,12 +185,13 @@ class Decoder:
                          out: np.ndarray | None = None) -> np.ndarray:
         f = self.info
         nc = f.components
+        sb = max(1, f.sample_bytes)  # 2: precision 12 or JPEG XT (16-bit codes)
         comp1 = nc - 1 if comp1 is None else comp1
         if out is None:
-            out = np.zeros((f.height, f.width, nc), np.uint8)
+            out = np.zeros((f.height, f.width, nc), np.uint8 if sb == 1 else np.uint16)
         base = out.ctypes.data
-        dst = (C.c_void_p * 4)(*[base + c if c < nc else None for c in range(4)])
-        bpp = (C.c_int32 * 4)(*([nc] * 4))
+        dst = (C.c_void_p * 4)(*[base + c * sb if c < nc else None for c in range(4)])
+        bpp = (C.c_int32 * 4)(*([nc * sb] * 4))
         bpr = (C.c_int32 * 4)(*([out.strides[0]] * 4))
         self._check(lib().mijpeg_reconstruct_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags, dst, bpp, bpr))
         return out
@@ -208,7 +223,7 @@ def decode(data: bytes, device: int = 0, threads: int = 0, flags: int = 0) -> np
 
 def launch_reconstruct(info: MijpegInfo, coef_dev: int, out_dev: int, frames: int, out_row_stride: int,
                        out_frame_stride: int, coef_frame_stride: int | None = None, flags: int = 0,
-                       workspace: int = 0, workspace_bytes: int = 0, stream: int = 0) -> None:
+                       workspace: int = 0, workspace_bytes: int = 0, stream: int = 0, xt: MijpegXtParams | None = None) -> None:
     """Stateless batch launch (device-resident coefficients -> device pixels), asynchronous."""
     b = MijpegBatch()
     C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
@@ -221,6 +236,8 @@ def launch_reconstruct(info: MijpegInfo, coef_dev: int, out_dev: int, frames: in
     b.flags = flags
     b.workspace = workspace
     b.workspace_bytes = workspace_bytes
+    if xt is not None:
+        b.xt = C.pointer(xt)
     rc = lib().mijpeg_launch_reconstruct(C.byref(b), stream)
     if rc:
         raise MijpegError(rc, "mijpeg_launch_reconstruct failed")

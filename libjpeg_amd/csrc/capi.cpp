@@ -186,6 +186,11 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   rc = d->host.decode(d->coef_host, threads, cb);
   d->timing[0] = d->host.huffman_seconds;
   if (rc) return set_error(d, rc, d->host.error.message);
+  if (d->device >= 0 && d->host.is_xt() && copy_err == hipSuccess) {
+    // the residual codestream's planes sit behind the legacy planes in the same buffer
+    const size_t off = (size_t)d->host.xt.residual.coef_offset[0], cnt = (size_t)f.coef_count - off;
+    copy_err = hipMemcpyAsync(d->coef_dev + off, d->coef_host + off, cnt * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
+  }
   if (copy_err != hipSuccess) return hip_fail(d, copy_err, "hipMemcpyAsync(coefficients)");
   d->decoded = true;
   if (d->device >= 0) {
@@ -200,6 +205,14 @@ int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info)
   if (!d || !info) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
   *info = d->host.info;
+  return MIJPEG_OK;
+}
+
+int mijpeg_get_xt_params(mijpeg_decoder *d, mijpeg_xt_params *xt)
+{
+  if (!d || !xt) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (!d->data || !d->host.is_xt()) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "the loaded stream is not a JPEG XT stream");
+  *xt = d->host.xt;
   return MIJPEG_OK;
 }
 
@@ -255,25 +268,28 @@ static bool fast_ok(const mijpeg_batch *b)
 static bool use_fused444(const mijpeg_batch *b)
 {
   const mijpeg_info &f = b->info;
-  return is_444(f) && f.ycbcr && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
+  return is_444(f) && f.ycbcr && !f.xt && f.precision == 8 && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
          f.range_max[1] < 8190 && f.range_max[2] < 8190;
 }
 
 static bool use_fused420(const mijpeg_batch *b)
 {
-  return is_420(b->info) && b->info.ycbcr && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM));
+  return is_420(b->info) && b->info.ycbcr && !b->info.xt && b->info.precision == 8 &&
+         !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM));
 }
 
 const char *mijpeg_kernel_name(const mijpeg_batch *b)
 {
   if (!b) return "";
-  return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : "idct_planes_kernel+upsample_color_kernel";
+  return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : b->info.xt ? "idct_planes_kernel+xt_merge_kernel"
+                                                                                                 : "idct_planes_kernel+upsample_color_kernel";
 }
 
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
 {
   if (!b || use_fused420(b) || use_fused444(b)) return 0;
-  return (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames;
+  // [4 KB: L lookup tables (JPEG XT)] [per frame: int32 sample planes, same layout as the coefficient planes]
+  return 4096 + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames;
 }
 
 int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
@@ -281,7 +297,8 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   if (!b || !b->coef_dev || !b->out_dev || b->frames < 1) return MIJPEG_ERR_INVALID_PARAMETER;
   if (b->quant_dev) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: not yet
   const mijpeg_info &f = b->info;
-  if (f.precision != 8 || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
+  if ((f.precision != 8 && f.precision != 12) || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
+  if (f.xt && (!b->xt || f.components != 3)) return MIJPEG_ERR_MISSING_PARAMETER;
   const bool fast = fast_ok(b);
   hipStream_t s = (hipStream_t)stream;
   int rc;
@@ -318,7 +335,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     memset(&a, 0, sizeof(a));
     a.coef = b->coef_dev;
     a.coef_frame_stride = b->coef_frame_stride;
-    a.samples = (int32_t *)b->workspace;
+    a.samples = (int32_t *)((char *)b->workspace + 4096);
     a.sample_frame_stride = f.coef_count;
     a.out = b->out_dev;
     a.out_frame_stride = b->out_frame_stride;
@@ -328,16 +345,36 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.ncomp = f.components;
     a.ycbcr = (f.ycbcr && !(b->flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM)) ? 1 : 0;
     a.frames = b->frames;
-    for (int c = 0; c < f.components; c++) {
-      a.coef_off[c] = f.coef_offset[c];
-      a.sample_off[c] = f.coef_offset[c];
-      a.bw[c] = f.blocks_w[c];
-      a.bh[c] = f.blocks_h[c];
-      a.subx[c] = f.subx[c];
-      a.suby[c] = f.suby[c];
-      a.cw[c] = (f.width + f.subx[c] - 1) / f.subx[c];
-      a.ch[c] = (f.height + f.suby[c] - 1) / f.suby[c];
-      for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
+    a.nplanes = f.components;
+    a.sample_bytes = f.precision > 8 || f.xt ? 2 : 1;
+    a.maxval = (1 << f.precision) - 1;
+    a.dcshift = (1 << (f.precision - 1)) << 4;
+    auto plane = [&](int p, const mijpeg_info &g, int c) {
+      a.coef_off[p] = g.coef_offset[c];
+      a.sample_off[p] = g.coef_offset[c];
+      a.bw[p] = g.blocks_w[c];
+      a.bh[p] = g.blocks_h[c];
+      a.subx[p] = g.subx[c];
+      a.suby[p] = g.suby[c];
+      a.cw[p] = (g.width + g.subx[c] - 1) / g.subx[c];
+      a.ch[p] = (g.height + g.suby[c] - 1) / g.suby[c];
+      a.dcoff[p] = (1 << (g.precision - 1)) << 7;
+      for (int i = 0; i < 64; i++) a.q[p][i] = (int32_t)g.quant[g.quant_index[c]][i] << 4;
+    };
+    for (int c = 0; c < f.components; c++) plane(c, f, c);
+    if (f.xt) {
+      const mijpeg_xt_params &x = *b->xt;
+      for (int c = 0; c < 3; c++) plane(3 + c, x.residual, c);
+      a.nplanes = 6;
+      a.xt = 1;
+      a.ycbcr = x.ltrafo_ycbcr; // the L transformation of the merging specification (the -c switch does not apply to XT here)
+      a.rtrafo_ycbcr = x.rtrafo_ycbcr;
+      a.out_shift = x.out_shift;
+      a.out_max = x.out_max;
+      a.is_float = x.is_float;
+      a.rprecision = x.residual.precision;
+      a.ltable = (const int32_t *)b->workspace;
+      if (hipMemcpyAsync(b->workspace, x.ltable, sizeof(x.ltable), hipMemcpyHostToDevice, s) != hipSuccess) return MIJPEG_ERR_DEVICE;
     }
     rc = launch_generic(a, fast, s);
   }
@@ -375,6 +412,7 @@ int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_s
   b.out_frame_stride = row_stride * b.info.height;
   b.frames = 1;
   b.flags = flags;
+  b.xt = d->host.is_xt() ? &d->host.xt : nullptr;
   const size_t ws = mijpeg_workspace_bytes(&b);
   if (ws) {
     int rc = ensure_dev(d, (void **)&d->ws_dev, &d->ws_cap, ws);
@@ -398,13 +436,14 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
   if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
   if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
   const mijpeg_info &f = d->host.info;
+  const int sb = f.sample_bytes > 0 ? f.sample_bytes : 1; // bytes per sample
   const int nc = f.components;
   // the whole frame is reconstructed once per (stream, flags) and then served rectangle by rectangle,
   // which is what the stripe loop of cmd/reconstruct.cpp:334-342 asks for
   if (!d->img_valid || d->img_flags != flags) {
     HIP_TRY(d, hipSetDevice(d->device));
-    const size_t bytes = (size_t)f.width * f.height * nc;
-    const size_t row = ((size_t)f.width * nc + 7) & ~(size_t)7;
+    const size_t bytes = (size_t)f.width * f.height * nc * sb;
+    const size_t row = ((size_t)f.width * nc * sb + 7) & ~(size_t)7;
     const size_t padded = row * f.height;
     int rc = ensure_dev(d, (void **)&d->img_dev, &d->img_dev_cap, padded);
     if (rc) return rc;
@@ -438,18 +477,18 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
   if (max_y >= f.height) max_y = f.height - 1;
   if (min_comp < 0) min_comp = 0;
   if (max_comp >= nc) max_comp = nc - 1;
-  const size_t row = ((size_t)f.width * nc + 7) & ~(size_t)7;
+  const size_t row = ((size_t)f.width * nc * sb + 7) & ~(size_t)7;
   // interleaved destination (the layout cmd/bitmaphook.cpp hands out): whole lines at once
   bool interleaved = min_comp == 0 && max_comp == nc - 1 && dst[0];
   for (int c = 0; c < nc && interleaved; c++)
-    interleaved = dst[c] == (uint8_t *)dst[0] + c && bytes_per_pixel[c] == nc && bytes_per_row[c] == bytes_per_row[0];
+    interleaved = dst[c] == (uint8_t *)dst[0] + c * sb && bytes_per_pixel[c] == nc * sb && bytes_per_row[c] == bytes_per_row[0];
   if (interleaved) {
-    const size_t line = (size_t)(max_x - min_x + 1) * nc;
+    const size_t line = (size_t)(max_x - min_x + 1) * nc * sb;
     const int lines = max_y - min_y + 1;
     auto copy_lines = [&](int y0, int y1) {
       for (int y = y0; y < y1; y++)
-        memcpy((uint8_t *)dst[0] + (ptrdiff_t)y * bytes_per_row[0] + (ptrdiff_t)min_x * nc,
-               d->img_host + (size_t)y * row + (size_t)min_x * nc, line);
+        memcpy((uint8_t *)dst[0] + (ptrdiff_t)y * bytes_per_row[0] + (ptrdiff_t)min_x * nc * sb,
+               d->img_host + (size_t)y * row + (size_t)min_x * nc * sb, line);
     };
     // big rectangles (whole frames) are copied by the worker pool: one memcpy stream per worker
     const int parts = (int)std::min<size_t>((size_t)std::min(default_threads(), 16), line * lines / (4u << 20));
@@ -463,14 +502,16 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
   for (int c = min_comp; c <= max_comp; c++) {
     if (!dst[c]) continue;
     for (int y = min_y; y <= max_y; y++) {
-      const uint8_t *src = d->img_host + (size_t)y * row + (size_t)min_x * nc + c;
+      const uint8_t *src = d->img_host + (size_t)y * row + ((size_t)min_x * nc + c) * sb;
       uint8_t *out = (uint8_t *)dst[c] + (ptrdiff_t)y * bytes_per_row[c] + (ptrdiff_t)min_x * bytes_per_pixel[c];
       const int n = max_x - min_x + 1;
       const int bpp = bytes_per_pixel[c];
-      if (nc == 1 && bpp == 1) {
-        memcpy(out, src, (size_t)n);
+      if (sb == 1) {
+        if (nc == 1 && bpp == 1) memcpy(out, src, (size_t)n);
+        else
+          for (int x = 0; x < n; x++) out[(ptrdiff_t)x * bpp] = src[(size_t)x * nc];
       } else {
-        for (int x = 0; x < n; x++) out[(ptrdiff_t)x * bpp] = src[(size_t)x * nc];
+        for (int x = 0; x < n; x++) memcpy(out + (ptrdiff_t)x * bpp, src + (size_t)x * nc * 2, 2);
       }
     }
   }

@@ -57,8 +57,17 @@ struct StreamError {
   std::string message;
 };
 
+// One JPEG XT box reassembled from its APP11 segments (boxes/box.cpp:88-200)
+struct XtBox {
+  uint32_t type = 0;
+  uint16_t en = 0;
+  std::vector<uint8_t> data;
+};
+
 class HostDecoder {
 public:
+  HostDecoder();
+  ~HostDecoder();
   // Parse SOI .. EOI structure: fills info, scans (with their restart-interval offsets).
   // header_only stops after the first SOS header has been seen.
   int parse(const uint8_t *data, size_t size, bool header_only);
@@ -70,6 +79,9 @@ public:
   int decode(int16_t *coef, int threads, const std::function<void(int, int)> &on_rows_done);
 
   mijpeg_info info{};
+  // JPEG XT profile C: parameters and the decoder of the residual codestream (RESI box); null for plain JPEG
+  bool is_xt() const { return residual_ != nullptr; }
+  mijpeg_xt_params xt{};
   std::vector<Scan> scans;
   StreamError error;
   double huffman_seconds = 0;
@@ -89,6 +101,10 @@ private:
   std::vector<uint8_t> rst_code_;
   std::vector<std::vector<size_t>> scan_interval_end_;
   std::vector<std::vector<uint8_t>> scan_rst_code_;
+  std::vector<XtBox> boxes_;
+  HostDecoder *residual_ = nullptr;
+  bool nested_ = false; // this object decodes a residual codestream
+  int finish_xt(bool header_only);
   int fail(int code, const char *msg);
   int parse_sof(const uint8_t *p, int n);
   int parse_sos(const uint8_t *p, int n, size_t ecs_begin);

@@ -186,11 +186,11 @@ __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int 
 // Dequantise the eight packed rows of a block and run both passes in registers.
 // rows[k] holds coefficient row k (8 x int16, natural order), q the component's 64 deltas << 4 (idct.cpp:98-109).
 // Result v[y*8+x] = sample * 16 (COLOR_BITS = 4 fractional bits), not clamped.
-// DCOFF = false leaves out the level shift dcoffset = 2^(P-1) << 7 (idct.cpp:231, :246).  That constant
+// dcoff = 0 leaves out the level shift dcoffset = 2^(P-1) << 7 (idct.cpp:231, :246).  That constant
 // passes through both rounding shifts exactly ((x + 2^14 * 2^9 + 2^8) >> 9 = ((x + 2^8) >> 9) + 2^14, and
 // (x + 2^14 * 2^9 + 2^11) >> 12 = ((x + 2^11) >> 12) + 2^11), so the result is exactly 2048 lower.
-template <bool FAST, bool DCOFF>
-__device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64])
+template <bool FAST>
+__device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff)
 {
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -206,7 +206,7 @@ __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *
       }
     }
   }
-  if (DCOFF) v[0] = addw(v[0], 128 << 7);
+  v[0] = addw(v[0], dcoff); // level shift 2^(P-1) << (preshift + 3); the fused fast kernels pass 0
 #pragma unroll
   for (int r = 0; r < 8; r++)
     idct_1d<FAST, 9>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5],
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
     const int gx = gx0 + cbx, gy = gy0 + cby;
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
       int v[64];
-      dequant_idct<FAST, !FAST>(rows, a.q[1 + comp], v);
+      dequant_idct<FAST>(rows, a.q[1 + comp], v, FAST ? 0 : (128 << 7));
       int *cp = cplane[comp];
 #pragma unroll
       for (int r = 0; r < 8; r++) {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct<FAST, !FAST>(rows, a.q[0], yv);
+  dequant_idct<FAST>(rows, a.q[0], yv, FAST ? 0 : (128 << 7));
 
   // uniform frame base + 32-bit lane offsets (a frame of pixels is far below 4 GB)
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -614,12 +614,12 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     u32x4 rows[8];
     int v[64];
     fetch(rows, a.off_cb);
-    dequant_idct<true, false>(rows, a.q[1], v);
+    dequant_idct<true>(rows, a.q[1], v, 0);
 #pragma unroll
     for (int i = 0; i < 32; i++) cbp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
     __builtin_amdgcn_sched_barrier(0); // keep the next component's loads from being hoisted above this transform (register pressure)
     fetch(rows, a.off_cr);
-    dequant_idct<true, false>(rows, a.q[2], v);
+    dequant_idct<true>(rows, a.q[2], v, 0);
 #pragma unroll
     for (int i = 0; i < 32; i++) crp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
     __builtin_amdgcn_sched_barrier(0);
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     fetch(rows, a.off_y);
     const int X0 = gbx * 8, Y0 = gby * 8;
     if (X0 >= a.width || Y0 >= a.height) return;
-    dequant_idct<true, false>(rows, a.q[0], yv);
+    dequant_idct<true>(rows, a.q[0], yv, 0);
   }
   const int X0 = gbx * 8, Y0 = gby * 8;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -694,8 +694,8 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // grid.x covers 64-block groups of one (frame, component): blockIdx.y = frame * ncomp + comp
-  const int comp = blockIdx.y % a.ncomp, frame = blockIdx.y / a.ncomp;
+  // grid.x covers 64-block groups of one (frame, plane): blockIdx.y = frame * nplanes + plane
+  const int comp = blockIdx.y % a.nplanes, frame = blockIdx.y / a.nplanes;
   const int nblocks = a.bw[comp] * a.bh[comp];
   const int first = (blockIdx.x * 4 + wave) * 64;
   if (first >= nblocks) return;
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   const int blk = first + lane;
   if (blk >= nblocks) return;
   int v[64];
-  dequant_idct<FAST, true>(rows, a.q[comp], v);
+  dequant_idct<FAST>(rows, a.q[comp], v, a.dcoff[comp]);
   const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
   const int pitch = a.bw[comp] * 8;
   int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
@@ -817,6 +817,18 @@ __device__ void upsample_line(const int *__restrict__ plane, int pitch, int cw, 
   for (int j = 0; j < 8; j++) o[j] = v[j];
 }
 
+// Exact (reference LONG / QUAD) colour stage for any precision: L matrix at FIX_BITS = 13 on samples with
+// COLOR_BITS = 4 fractional bits, ycbcrtrafo.cpp:842-856; not clamped here.
+__device__ __forceinline__ void ycc_to_rgb_wide(int y, int cb, int cr, int dcshift, long long &r, long long &g, long long &b)
+{
+  const long long yy = (long long)y * 8192 + 65536;
+  const long long cbl = (long long)cb - dcshift, crl = (long long)cr - dcshift;
+  r = (yy + crl * L_CR_R) >> 17;
+  g = (yy - cbl * L_CB_G - crl * L_CR_G) >> 17;
+  b = (yy + cbl * L_CB_B) >> 17;
+}
+__device__ __forceinline__ long long clampll(long long v, long long hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
 template <bool FAST>
 __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a)
 {
@@ -834,19 +846,102 @@ __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a
       upsample_line(plane, a.bw[c] * 8, a.cw[c], a.ch[c], a.subx[c], a.suby[c], X0, Y, s[c]);
     }
   }
-  uint8_t *dst = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride + (int64_t)X0 * a.ncomp;
+  uint8_t *dst = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride + (int64_t)X0 * a.ncomp * a.sample_bytes;
   const int npx = min(8, a.width - X0);
 #pragma unroll
   for (int x = 0; x < 8; x++) {
     if (x >= npx) break;
-    if (a.ycbcr && a.ncomp == 3) {
-      int r, g, b;
-      ycc_to_rgb<FAST>(s[0][x], s[1][x], s[2][x], r, g, b);
-      dst[3 * x] = (uint8_t)r; dst[3 * x + 1] = (uint8_t)g; dst[3 * x + 2] = (uint8_t)b;
+    if (a.sample_bytes == 1) {
+      if (a.ycbcr && a.ncomp == 3) {
+        int r, g, b;
+        ycc_to_rgb<FAST>(s[0][x], s[1][x], s[2][x], r, g, b);
+        dst[3 * x] = (uint8_t)r; dst[3 * x + 1] = (uint8_t)g; dst[3 * x + 2] = (uint8_t)b;
+      } else {
+#pragma unroll
+        for (int c = 0; c < MAXC; c++)
+          if (c < a.ncomp) dst[a.ncomp * x + c] = (uint8_t)color_to_int<FAST>(s[c][x]);
+      }
+    } else { // precision 12: 16-bit samples, clamp to 2^P - 1 (ycbcrtrafo.cpp:921-936 with m_lOutMax = 4095)
+      uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
+      if (a.ycbcr && a.ncomp == 3) {
+        long long r, g, b;
+        ycc_to_rgb_wide(s[0][x], s[1][x], s[2][x], a.dcshift, r, g, b);
+        d16[3 * x] = (uint16_t)clampll(r, a.maxval); d16[3 * x + 1] = (uint16_t)clampll(g, a.maxval); d16[3 * x + 2] = (uint16_t)clampll(b, a.maxval);
+      } else {
+#pragma unroll
+        for (int c = 0; c < MAXC; c++)
+          if (c < a.ncomp) d16[a.ncomp * x + c] = (uint16_t)clampll(((long long)s[c][x] + 8) >> 4, a.maxval);
+      }
+    }
+  }
+}
+
+// ==============================================================================================
+// JPEG XT profile C: legacy samples (planes 0..2) + residual samples (planes 3..5) -> 16-bit codes.
+// colortrafo/ycbcrtrafo.cpp:750-829 (residual chain: Q table, R transformation, R2 table), :842-878 (legacy chain:
+// L transformation, L table, C transformation = identity, merge), :897-955 (half-float clamp, INVERT_NEGS).
+// The Q and R2 tables of the supported subset are identities whose scaling is a shift
+// (boxes/parametrictonemappingbox.cpp:387-430 with e = 0), so they are evaluated arithmetically.
+// ==============================================================================================
+__global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
+{
+  const int groups = (a.width + 7) >> 3;
+  const int gxi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Y = blockIdx.y;
+  const int frame = blockIdx.z;
+  if (gxi >= groups) return;
+  const int X0 = gxi * 8;
+  int s[3][8], rs[3][8];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int *plane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[c];
+    upsample_line(plane, a.bw[c] * 8, a.cw[c], a.ch[c], a.subx[c], a.suby[c], X0, Y, s[c]);
+    const int *rplane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[3 + c];
+    upsample_line(rplane, a.bw[3 + c] * 8, a.cw[3 + c], a.ch[3 + c], a.subx[3 + c], a.suby[3 + c], X0, Y, rs[c]);
+  }
+  uint16_t *dst = reinterpret_cast<uint16_t *>(a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride) + (int64_t)X0 * 3;
+  const int npx = min(8, a.width - X0);
+  const long long rmax16 = ((1ll << a.rprecision) << 4) - 1; // ((m_lRMax + 1) << COLOR_BITS) - 1
+  const long long omax16 = (((long long)a.out_max + 1) << 4) - 1;
+  const int qshift = 16 - a.rprecision;
+  const long long pinf = (a.out_max >> 1) - (a.out_max >> 6) - 1; // largest finite half: 0x7bff
+  const long long minf = -pinf - 1;                               // INVERT_NEGS(pinf | 0x8000) = -31744
+#pragma unroll
+  for (int x = 0; x < 8; x++) {
+    if (x >= npx) break;
+    // residual chain
+    long long ry = clampll(rs[0][x], rmax16) << qshift, rcb = clampll(rs[1][x], rmax16) << qshift, rcr = clampll(rs[2][x], rmax16) << qshift;
+    long long rr[3];
+    if (a.rtrafo_ycbcr) {
+      rcb -= (long long)a.out_shift << 4;
+      rcr -= (long long)a.out_shift << 4;
+      rr[0] = (ry * 8192 + rcr * L_CR_R + 4096) >> 13; // FIX_COLOR_TO_INTCOLOR
+      rr[1] = (ry * 8192 - rcb * L_CB_G - rcr * L_CR_G + 4096) >> 13;
+      rr[2] = (ry * 8192 + rcb * L_CB_B + 4096) >> 13;
+    } else {
+      rr[0] = ry; rr[1] = rcb; rr[2] = rcr;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) rr[c] = (clampll(rr[c], omax16) + 8) >> 4;
+    // legacy chain
+    long long v[3];
+    if (a.ycbcr) {
+      ycc_to_rgb_wide(s[0][x], s[1][x], s[2][x], a.dcshift, v[0], v[1], v[2]);
     } else {
 #pragma unroll
-      for (int c = 0; c < MAXC; c++)
-        if (c < a.ncomp) dst[a.ncomp * x + c] = (uint8_t)color_to_int<FAST>(s[c][x]);
+      for (int c = 0; c < 3; c++) v[c] = ((long long)s[c][x] + 8) >> 4;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const long long lv = a.ltable[c * 256 + (int)clampll(v[c], a.maxval)];
+      long long m = lv + rr[c] - a.out_shift;
+      if (a.is_float) {
+        m = m > pinf ? pinf : (m < minf ? minf : m);
+        const short w = (short)m;
+        dst[3 * x + c] = (uint16_t)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS
+      } else {
+        dst[3 * x + c] = (uint16_t)clampll(m, a.out_max);
+      }
     }
   }
 }
@@ -885,8 +980,8 @@ int launch_fused444(const Fused420Args &a, hipStream_t stream)
 int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
 {
   int maxblocks = 0;
-  for (int c = 0; c < a.ncomp; c++) maxblocks = max(maxblocks, a.bw[c] * a.bh[c]);
-  dim3 g1((maxblocks + 255) / 256, a.ncomp * a.frames);
+  for (int c = 0; c < a.nplanes; c++) maxblocks = max(maxblocks, a.bw[c] * a.bh[c]);
+  dim3 g1((maxblocks + 255) / 256, a.nplanes * a.frames);
   if (fast)
     hipLaunchKernelGGL(idct_planes_kernel<true>, g1, dim3(256), 0, stream, a);
   else
@@ -894,7 +989,9 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   const int groups = (a.width + 7) >> 3;
   const int bs = groups >= 256 ? 256 : 64;
   dim3 g2((groups + bs - 1) / bs, a.height, a.frames);
-  if (fast)
+  if (a.xt)
+    hipLaunchKernelGGL(xt_merge_kernel, g2, dim3(bs), 0, stream, a);
+  else if (fast)
     hipLaunchKernelGGL(upsample_color_kernel<true>, g2, dim3(bs), 0, stream, a);
   else
     hipLaunchKernelGGL(upsample_color_kernel<false>, g2, dim3(bs), 0, stream, a);

@@ -26,19 +26,30 @@ struct Fused420Args {
   int32_t q[3][64];               // deltas << 4 per component (Y, Cb, Cr), natural order (idct.cpp:98-109)
 };
 
-// generic path: any sampling / component count, two kernels with int32 sample planes in between
+// generic path: any sampling / component count / precision, two kernels with int32 sample planes in between.
+// "Planes" are the component planes of the legacy codestream, followed -- for JPEG XT -- by those of the
+// residual codestream (3 + 3).
+constexpr int MAXP = 6;
 struct GenericArgs {
   const int16_t *coef;
   int64_t coef_frame_stride;
-  int64_t coef_off[MAXC];
-  int32_t *samples;            // workspace: per frame, per component (bw*8) x (bh*8) int32
+  int64_t coef_off[MAXP];
+  int32_t *samples;            // workspace: per frame, per plane (bw*8) x (bh*8) int32
   int64_t sample_frame_stride; // int32 units
-  int64_t sample_off[MAXC];
+  int64_t sample_off[MAXP];
   uint8_t *out;
   int64_t out_frame_stride, row_stride;
-  int32_t width, height, ncomp, ycbcr, frames;
-  int32_t bw[MAXC], bh[MAXC], cw[MAXC], ch[MAXC], subx[MAXC], suby[MAXC];
-  int32_t q[MAXC][64];         // deltas << 4
+  int32_t width, height, ncomp, ycbcr, frames, nplanes;
+  int32_t bw[MAXP], bh[MAXP], cw[MAXP], ch[MAXP], subx[MAXP], suby[MAXP];
+  int32_t dcoff[MAXP];         // level shift of the plane's transform: 2^(P-1) << 7 (dct/idct.cpp:231)
+  int32_t q[MAXP][64];         // deltas << 4
+  // output stage
+  int32_t sample_bytes;        // 1: 8-bit samples, 2: 16-bit samples
+  int32_t maxval;              // 2^P - 1: clamp of the integer output
+  int32_t dcshift;             // 2^(P-1) << 4: chroma level shift seen by the colour transformation
+  // JPEG XT profile C merge (colortrafo/ycbcrtrafo.cpp:750-955)
+  int32_t xt, rtrafo_ycbcr, out_shift, out_max, is_float, rprecision;
+  const int32_t *ltable;       // device: L lookup tables [3][256]
 };
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);

@@ -8,7 +8,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import BIG_CASES, MANIFEST, SMALL_CASES, big_jpeg, golden_jpeg, golden_pixels
+from conftest import BIG_CASES, MANIFEST, P12_CASES, SMALL_CASES, XT_CASES, big_jpeg, golden_jpeg, golden_pixels
 from libjpeg_amd import api, synth
 
 pytestmark = pytest.mark.gpu
@@ -127,6 +127,51 @@ def test_full_size_frames(dec, oracle, name):
     assert np.array_equal(out, exp)
     # the safe flavour must agree too
     assert np.array_equal(dec.reconstruct(api.FLAG_FORCE_SAFE), exp)
+
+
+# ------------------------------------------------------------------------------------------------------
+# JPEG XT profile C (BASELINE config 5) and 12-bit frames
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", XT_CASES)
+def test_xt_profile_c_golden(dec, oracle, name):
+    """Half-float codes from the GPU, expanded exactly (cmd/iohelpers.hpp:60-77), must equal bit for bit the floats the
+    reference wrote into its PFM; tolerance 0."""
+    ent = MANIFEST[name]
+    f = dec.read(golden_jpeg(name))
+    assert f.xt == 1 and f.is_float == 1 and f.sample_bytes == 2
+    assert api.kernel_name(f) == "idct_planes_kernel+xt_merge_kernel"
+    codes = dec.reconstruct()
+    assert codes.dtype == np.uint16 and codes.shape == (ent["height"], ent["width"], 3)
+    exp_codes, _ = oracle.decode_xt(golden_jpeg(name))
+    bad = int((codes != exp_codes).sum())
+    assert bad == 0, f"{bad} differing half codes, first at {np.argwhere(codes != exp_codes)[:4].tolist()}"
+    out = oracle.half_codes_to_float(codes)
+    assert hashlib.sha256(np.ascontiguousarray(out, "<f4").tobytes()).hexdigest() == ent["pixels_sha256"]
+
+
+@pytest.mark.parametrize("name", P12_CASES)
+def test_12bit_golden(dec, oracle, name):
+    ent = MANIFEST[name]
+    f = dec.read(golden_jpeg(name))
+    assert f.precision == 12 and f.sample_bytes == 2 and f.xt == 0
+    out = dec.reconstruct()
+    assert out.dtype == np.uint16
+    exp = golden_pixels(name)
+    assert np.array_equal(out, exp if exp is not None else oracle.decode16(golden_jpeg(name)))
+    assert hashlib.sha256(np.ascontiguousarray(out, "<u2").tobytes()).hexdigest() == ent["pixels_sha256"]
+
+
+def test_xt_4k_vs_oracle(dec, oracle):
+    """BASELINE config 5 at its full 4K size (reference-encoded on the fly where the reference binary is available,
+    i.e. in the build container; on the GPU box the committed small vectors above stand in)."""
+    if not oracle.have_reference():
+        pytest.skip("needs oracle/_ref/jpeg to encode the HDR stream")
+    data = oracle.reference_encode_hdr(synth.synth_hdr(3840, 2160, 99),
+                                       ["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-s", "1x1,2x2,2x2"])
+    dec.read(data)
+    codes = dec.reconstruct()
+    exp, _ = oracle.decode_xt(data)
+    assert np.array_equal(codes, exp)
 
 
 def _torch():

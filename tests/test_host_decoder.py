@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_info_struct_layout_matches_header():
     # sizeof(mijpeg_info): 4*4 + 5*16 + 8 + 2*16 + 12 (+4 pad) + 32 + 8 + 512
-    assert ctypes.sizeof(api.MijpegInfo) == 16 + 80 + 8 + 32 + 16 + 32 + 8 + 512 + 16
+    assert ctypes.sizeof(api.MijpegInfo) == 16 + 80 + 8 + 32 + 16 + 32 + 8 + 512 + 16 + 16
 
 
 @pytest.mark.parametrize("name", SMALL_CASES)
