@@ -1,9 +1,10 @@
 // main.cpp -- `jpeg` command line front end of the MI355X path: the decode half of the reference CLI.
 //   jpeg [-c] [-t threads] [-d device] in.jpg out.ppm
 // reproduces cmd/main.cpp:746-747 -> cmd/reconstruct.cpp:68-376 for the streams this path handles: the
-// image is reconstructed stripe by stripe (eight lines per JPEG::DisplayRectangle call) through a file I/O
+// image (8 bit -> PNM, 12 bit -> 16-bit PNM, JPEG XT profile C -> PFM) is reconstructed stripe by stripe (eight lines per JPEG::DisplayRectangle call) through a file I/O
 // hook and a bitmap hook, and written as binary PNM (P6 for three components, P5 for one) -- byte for
 // byte what the reference binary writes.  -c disables the colour transformation (reference: -c).
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,12 +33,25 @@ static JPG_LONG FileHook(struct JPG_Hook *hook, struct JPG_TagItem *tags)
   return -1;
 }
 
-// Bitmap hook state: one interleaved stripe of eight lines (cmd/bitmaphook.cpp:102-260, 8-bit integer case)
+// Bitmap hook state: one interleaved stripe of eight lines (cmd/bitmaphook.cpp:102-340)
 struct StripeBuffer {
   unsigned char *mem;
   unsigned width, height, depth;
+  unsigned bytes; // per sample: 1 (8 bit) or 2 (12 bit, JPEG XT half-float codes)
+  bool halffloat; // 16-bit samples are half-float codes: expanded to big-endian float32 when written (PFM)
   FILE *target;
 };
+
+// cmd/iohelpers.hpp:60-77: exact expansion of a half-float bit pattern
+static float HalfToFloat(unsigned short h)
+{
+  const int exponent = (h >> 10) & 31, mantissa = h & 1023;
+  double v;
+  if (exponent == 0) v = ldexp((double)mantissa, -14 - 10);
+  else if (exponent == 31) v = HUGE_VAL;
+  else v = ldexp((double)(mantissa | 1024), -15 - 10 + exponent);
+  return (float)((h & 0x8000) ? -v : v);
+}
 
 static JPG_LONG BitmapHook(struct JPG_Hook *hook, struct JPG_TagItem *tags)
 {
@@ -48,17 +62,33 @@ static JPG_LONG BitmapHook(struct JPG_Hook *hook, struct JPG_TagItem *tags)
   switch (tags->GetTagData(JPGTAG_BIO_ACTION)) {
   case JPGFLAG_BIO_REQUEST:
     // address of canvas pixel (0,0) of this component: the stripe buffer starts at line miny
-    tags->SetTagPtr(JPGTAG_BIO_MEMORY, sb->mem + comp - (size_t)miny * sb->depth * width);
+    tags->SetTagPtr(JPGTAG_BIO_MEMORY, sb->mem + ((size_t)comp - (size_t)miny * sb->depth * width) * sb->bytes);
     tags->SetTagData(JPGTAG_BIO_WIDTH, width);
     tags->SetTagData(JPGTAG_BIO_HEIGHT, 8 + miny);
-    tags->SetTagData(JPGTAG_BIO_BYTESPERROW, sb->depth * width);
-    tags->SetTagData(JPGTAG_BIO_BYTESPERPIXEL, sb->depth);
-    tags->SetTagData(JPGTAG_BIO_PIXELTYPE, CTYP_UBYTE);
+    tags->SetTagData(JPGTAG_BIO_BYTESPERROW, sb->depth * width * sb->bytes);
+    tags->SetTagData(JPGTAG_BIO_BYTESPERPIXEL, sb->depth * sb->bytes);
+    tags->SetTagData(JPGTAG_BIO_PIXELTYPE, sb->bytes == 2 ? CTYP_UWORD : CTYP_UBYTE);
     break;
   case JPGFLAG_BIO_RELEASE:
     if (comp == sb->depth - 1) { // all components of the stripe are in: write it
       const size_t n = (size_t)width * (maxy + 1 - miny) * sb->depth;
-      if (fwrite(sb->mem, 1, n, sb->target) != n) return JPGERR_UNEXPECTED_EOF;
+      if (sb->bytes == 1) {
+        if (fwrite(sb->mem, 1, n, sb->target) != n) return JPGERR_UNEXPECTED_EOF;
+      } else {
+        const unsigned short *px = (const unsigned short *)sb->mem;
+        for (size_t i = 0; i < n; i++) {
+          if (sb->halffloat) { // cmd/bitmaphook.cpp:282-305: big-endian IEEE single
+            const float v = HalfToFloat(px[i]);
+            unsigned int bits;
+            memcpy(&bits, &v, 4);
+            const unsigned char be[4] = {(unsigned char)(bits >> 24), (unsigned char)(bits >> 16), (unsigned char)(bits >> 8), (unsigned char)bits};
+            if (fwrite(be, 1, 4, sb->target) != 4) return JPGERR_UNEXPECTED_EOF;
+          } else { // PNM is big-endian
+            const unsigned char be[2] = {(unsigned char)(px[i] >> 8), (unsigned char)px[i]};
+            if (fwrite(be, 1, 2, sb->target) != 2) return JPGERR_UNEXPECTED_EOF;
+          }
+        }
+      }
     }
     break;
   }
@@ -80,24 +110,30 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
   if (ok) {
     unsigned char subx[4], suby[4];
     struct JPG_TagItem itags[] = {JPG_ValueTag(JPGTAG_IMAGE_WIDTH, 0), JPG_ValueTag(JPGTAG_IMAGE_HEIGHT, 0), JPG_ValueTag(JPGTAG_IMAGE_DEPTH, 0),
-                                  JPG_ValueTag(JPGTAG_IMAGE_PRECISION, 0), JPG_PointerTag(JPGTAG_IMAGE_SUBX, subx),
+                                  JPG_ValueTag(JPGTAG_IMAGE_PRECISION, 0), JPG_ValueTag(JPGTAG_IMAGE_IS_FLOAT, 0),
+                                  JPG_ValueTag(JPGTAG_IMAGE_OUTPUT_CONVERSION, 0), JPG_PointerTag(JPGTAG_IMAGE_SUBX, subx),
                                   JPG_PointerTag(JPGTAG_IMAGE_SUBY, suby), JPG_ValueTag(JPGTAG_IMAGE_SUBLENGTH, 4), JPG_EndTag};
     ok = jpeg->GetInformation(itags);
     if (ok) {
       const unsigned width = itags->GetTagData(JPGTAG_IMAGE_WIDTH), height = itags->GetTagData(JPGTAG_IMAGE_HEIGHT);
       const unsigned depth = itags->GetTagData(JPGTAG_IMAGE_DEPTH), prec = itags->GetTagData(JPGTAG_IMAGE_PRECISION);
-      if ((depth != 1 && depth != 3) || prec != 8) {
-        fprintf(stderr, "only 8 bit images with one or three components can be written as PNM by this front end\n");
+      const bool pfm = itags->GetTagData(JPGTAG_IMAGE_IS_FLOAT) != 0, convert = itags->GetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION) != 0;
+      if ((depth != 1 && depth != 3) || prec > 16 || (pfm && !convert)) {
+        fprintf(stderr, "only images with one or three components of up to 16 bits can be written as PNM/PFM by this front end\n");
         ok = 0; rc = 5;
       } else {
         StripeBuffer sb;
-        sb.mem = (unsigned char *)malloc((size_t)width * 8 * depth);
+        sb.bytes = prec > 8 ? 2 : 1; // cmd/reconstruct.cpp:169-180
+        sb.halffloat = pfm;
+        sb.mem = (unsigned char *)malloc((size_t)width * 8 * depth * sb.bytes);
         sb.width = width; sb.height = height; sb.depth = depth;
         sb.target = fopen(outfile, "wb");
         if (!sb.mem || !sb.target) { perror("failed to open the output file"); ok = 0; rc = 10; }
         else {
           struct JPG_Hook bmhook(BitmapHook, &sb);
-          fprintf(sb.target, "P%c\n%u %u\n%u\n", depth > 1 ? '6' : '5', width, height, (1u << prec) - 1);
+          // cmd/reconstruct.cpp:321-323
+          fprintf(sb.target, "P%c\n%u %u\n%u\n", pfm ? (depth > 1 ? 'F' : 'f') : (depth > 1 ? '6' : '5'), width, height,
+                  pfm ? 1u : (1u << prec) - 1);
           for (unsigned y = 0; y < height && ok; y += 8) { // cmd/reconstruct.cpp:334-342
             const unsigned last = y + 8 < height ? y + 8 : height;
             struct JPG_TagItem dtags[] = {JPG_PointerTag(JPGTAG_BIH_HOOK, &bmhook), JPG_ValueTag(JPGTAG_DECODER_MINY, y),

@@ -128,7 +128,8 @@ JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
   tags->SetTagData(JPGTAG_IMAGE_WIDTH, f.width);
   tags->SetTagData(JPGTAG_IMAGE_HEIGHT, f.height);
   tags->SetTagData(JPGTAG_IMAGE_DEPTH, f.components);
-  tags->SetTagData(JPGTAG_IMAGE_PRECISION, f.precision);
+  // JPEG XT: the image precision includes the extra range bits of the output conversion (8 + 8)
+  tags->SetTagData(JPGTAG_IMAGE_PRECISION, f.xt ? 16 : f.precision);
   const JPG_LONG n = tags->GetTagData(JPGTAG_IMAGE_SUBLENGTH, 0);
   if (n > 0) {
     uint8_t *sx = (uint8_t *)tags->GetTagPtr(JPGTAG_IMAGE_SUBX), *sy = (uint8_t *)tags->GetTagPtr(JPGTAG_IMAGE_SUBY);
@@ -139,9 +140,10 @@ JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
       if (sy) sy[c] = (uint8_t)f.suby[c];
     }
   }
-  // no merging specification box on this path: integer output, no output conversion (jpeg.cpp:836-862)
-  tags->SetTagData(JPGTAG_IMAGE_IS_FLOAT, 0);
-  tags->SetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION, 0);
+  // jpeg.cpp:836-862: with a merging specification that casts to float the samples are half-float codes
+  // (IS_FLOAT) which the client expands itself (OUTPUT_CONVERSION); plain JPEG: integer output
+  tags->SetTagData(JPGTAG_IMAGE_IS_FLOAT, f.xt && f.is_float ? 1 : 0);
+  tags->SetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION, f.xt && f.is_float ? 1 : 0);
   // no alpha channel: the reference neutralises these two tags (jpeg.cpp:946-951)
   if (struct JPG_TagItem *t = tags->FindTagItem(JPGTAG_ALPHA_MODE)) t->ti_Tag = JPGTAG_TAG_IGNORE;
   if (struct JPG_TagItem *t = tags->FindTagItem(JPGTAG_ALPHA_TAGLIST)) t->ti_Tag = JPGTAG_TAG_IGNORE;
@@ -221,11 +223,12 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
   };
   JPG_LONG maxmcu = 0x7fffffff;
   for (int c = c0; c <= c1; c++) {
-    bm[c] = Bitmap{nullptr, 0, 0, 0, 0, CTYP_UBYTE, nullptr};
+    bm[c] = Bitmap{nullptr, 0, 0, 0, 0, f.sample_bytes == 2 ? CTYP_UWORD : CTYP_UBYTE, nullptr};
     const JPG_LONG r = call_hook(c, JPGFLAG_BIO_REQUEST, bm[c]);
     if (r < 0) return p->fail(r, "BitMapHook signalled an error");
-    if (bm[c].type != CTYP_UBYTE && bm[c].type != 0) // control/bitmapctrl.cpp:152-158: types must fit the data
-      return p->fail(JPGERR_INVALID_PARAMETER, "pixel type of the user bitmap must be CTYP_UBYTE for 8 bit images");
+    const JPG_LONG want = f.sample_bytes == 2 ? CTYP_UWORD : CTYP_UBYTE;
+    if (bm[c].type != want && bm[c].type != 0) // control/bitmapctrl.cpp:152-158: types must fit the data
+      return p->fail(JPGERR_INVALID_PARAMETER, "pixel type of the user bitmap does not fit the sample precision of the image");
     dst[c] = bm[c].type ? bm[c].mem : nullptr; // pixel type 0 = "no memory for this component"
     bpp[c] = bm[c].bpp;
     bpr[c] = bm[c].bpr;

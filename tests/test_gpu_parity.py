@@ -286,6 +286,31 @@ def test_cli_writes_the_references_pnm(tmp_path, name):
     assert hashlib.sha256(data[len(header):]).hexdigest() == ent["pixels_sha256"]
 
 
+@pytest.mark.parametrize("name", XT_CASES[:3] + P12_CASES)
+def test_cli_writes_the_references_pfm_and_16bit_pnm(tmp_path, name):
+    """JPEG XT -> 'PF' file with big-endian floats (cmd/reconstruct.cpp:321-323, cmd/bitmaphook.cpp:282-305),
+    12 bit -> P6 with maxval 4095 and big-endian samples: the bytes the reference CLI writes."""
+    import os
+    import subprocess
+
+    from conftest import GOLDEN_DIR, ROOT
+
+    exe = os.path.join(ROOT, "libjpeg_amd", "bin", "jpeg")
+    ent = MANIFEST[name]
+    out = tmp_path / "out.bin"
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".jpg"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    data = out.read_bytes()
+    if ent["kind"] == "xt_float32":
+        header = b"PF\n%d %d\n1\n" % (ent["width"], ent["height"])
+        body = np.frombuffer(data[len(header):], ">f4").astype("<f4")
+    else:
+        header = b"P6\n%d %d\n4095\n" % (ent["width"], ent["height"])
+        body = np.frombuffer(data[len(header):], ">u2").astype("<u2")
+    assert data.startswith(header)
+    assert hashlib.sha256(body.tobytes()).hexdigest() == ent["pixels_sha256"]
+
+
 def test_cli_no_color_transform_and_errors(tmp_path, oracle):
     import os
     import subprocess
