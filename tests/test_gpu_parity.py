@@ -203,6 +203,25 @@ def test_batch_launch_device_resident(oracle):
     d.close()
 
 
+@pytest.mark.parametrize("sub", ["420", "444"])
+def test_unaligned_output_stride(oracle, sub):
+    """Packed rows whose stride is not a multiple of 8 bytes (131 * 3 = 393) take the byte-store path of the fused
+    kernels; a padded destination must not be written outside the picture."""
+    torch = _torch()
+    d = api.Decoder(0)
+    data = synth.synth_jpeg(131, 77, 9, 85, sub, 0)
+    f = d.read(data)
+    coef = torch.from_numpy(np.concatenate([d.coefficients(c).reshape(-1) for c in range(3)])).cuda()
+    d.close()
+    for row in (393, 400):
+        out = torch.full((77, row), 0xAB, dtype=torch.uint8, device="cuda")
+        api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, row, 77 * row, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res = out.cpu().numpy()
+        assert np.array_equal(res[:, :393].reshape(77, 131, 3), oracle.decode(data)), f"row stride {row}"
+        assert (res[:, 393:] == 0xAB).all()
+
+
 @pytest.mark.parametrize("generic", [False, True])
 def test_adversarial_coefficients_safe_flavour(oracle, generic):
     """Coefficients no encoder would produce (|c| up to 32767, q up to 255): intermediates wrap around 2^32.
