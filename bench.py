@@ -179,6 +179,20 @@ def main():
                                 "phases_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
                                 "note": "one frame, PCIe and host inclusive: bytes -> host Huffman (restart-interval parallel) -> "
                                         "pinned H2D (streamed) -> kernel -> D2H -> copy into the caller's interleaved bitmap"}
+    if rank == 0 and not args.no_end_to_end:
+        # the same, pipelined over a batch of frames (config 4's end-to-end shape): two decoder objects / streams
+        from libjpeg_amd import pipeline
+
+        nb = 24
+        pipe = pipeline.FramePipeline(local_rank, depth=2)
+        pipe.run([jpegs[i % 2] for i in range(4)])  # warm: pinned buffers, worker threads
+        t = time.perf_counter()
+        pipe.run([jpegs[i % 2] for i in range(nb)])
+        dt = time.perf_counter() - t
+        pipe.close()
+        result["end_to_end"]["pipelined"] = {"value": round(W * H * nb / dt / 1e6, 1), "unit": "Mpixels/s", "frames": nb,
+                                             "ms_per_frame": round(dt / nb * 1e3, 2), "depth": 2,
+                                             "note": "two decoder objects / streams, D2H straight into pinned frames; bound by the ~200 MB per 8K frame that cross PCIe"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(jpegs[0], W, H)

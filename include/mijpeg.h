@@ -139,6 +139,15 @@ const int16_t *mijpeg_device_coefficients(mijpeg_decoder *d);
 int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_stride, uint32_t flags,
                               int sync);
 
+/* Reconstruct the whole frame into HOST memory (interleaved samples, `row_stride` bytes per line) with the
+ * device-to-host copy landing directly in `dst_host`: no staging copy when the memory is pinned
+ * (mijpeg_host_alloc, hipHostMalloc, hipHostRegister); pageable memory works too, only slower. Synchronous. */
+int mijpeg_reconstruct_host(mijpeg_decoder *d, void *dst_host, int64_t row_stride, uint32_t flags);
+
+/* Pinned host memory for frame buffers (hipHostMalloc / hipHostFree). */
+void *mijpeg_host_alloc(size_t bytes);
+void mijpeg_host_free(void *p);
+
 /* Reconstruct a rectangle into HOST memory described like the reference's ImageBitMap
  * (interface/imagebitmap.hpp): for component c, dst[c] is the address of canvas pixel (0,0),
  * bytes_per_pixel[c] / bytes_per_row[c] the strides.  Rectangle and component range are inclusive,

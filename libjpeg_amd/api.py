@@ -101,6 +101,11 @@ def lib():
         L.mijpeg_device_coefficients.restype = C.c_void_p
         L.mijpeg_reconstruct_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int]
         L.mijpeg_reconstruct_rect.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_uint32, P(C.c_void_p), P(C.c_int32), P(C.c_int32)]
+        L.mijpeg_reconstruct_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32]
+        L.mijpeg_host_alloc.argtypes = [C.c_size_t]
+        L.mijpeg_host_alloc.restype = C.c_void_p
+        L.mijpeg_host_free.argtypes = [C.c_void_p]
+        L.mijpeg_host_free.restype = None
         L.mijpeg_last_error.argtypes = [C.c_void_p, P(C.c_char_p)]
         L.mijpeg_last_timing.argtypes = [C.c_void_p, P(C.c_double)]
         L.mijpeg_launch_reconstruct.argtypes = [P(MijpegBatch), C.c_void_p]
@@ -196,6 +201,12 @@ class Decoder:
         self._check(lib().mijpeg_reconstruct_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags, dst, bpp, bpr))
         return out
 
+    def reconstruct_into(self, out: np.ndarray, flags: int = 0) -> np.ndarray:
+        """Whole frame with the device-to-host copy landing directly in `out` (fast when `out` is pinned, see
+        pinned_frame()); `out` is (H, W, C) with contiguous pixels, any row stride."""
+        self._check(lib().mijpeg_reconstruct_host(self._h, out.ctypes.data, out.strides[0], flags))
+        return out
+
     def reconstruct_device(self, dst_ptr: int, row_stride: int, flags: int = 0, sync: bool = True):
         self._check(lib().mijpeg_reconstruct_device(self._h, dst_ptr, row_stride, flags, 1 if sync else 0))
 
@@ -203,6 +214,31 @@ class Decoder:
         t = (C.c_double * 4)()
         lib().mijpeg_last_timing(self._h, t)
         return dict(huffman=t[0], h2d_wait=t[1], kernel=t[2], d2h=t[3])
+
+
+class PinnedFrame:
+    """(H, W, C) frame buffer in pinned host memory (mijpeg_host_alloc); .array is the numpy view."""
+
+    def __init__(self, height: int, width: int, channels: int, dtype=np.uint8):
+        line = (width * channels * np.dtype(dtype).itemsize + 7) & ~7
+        self._bytes = line * height
+        self._p = lib().mijpeg_host_alloc(self._bytes)
+        if not self._p:
+            raise MemoryError("mijpeg_host_alloc failed")
+        raw = np.ctypeslib.as_array((C.c_uint8 * self._bytes).from_address(self._p)).reshape(height, line)
+        self.array = raw[:, :width * channels * np.dtype(dtype).itemsize].view(dtype).reshape(height, width, channels)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().mijpeg_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def default_threads() -> int:

@@ -427,6 +427,46 @@ int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_s
   return MIJPEG_OK;
 }
 
+void *mijpeg_host_alloc(size_t bytes)
+{
+  void *p = nullptr;
+  return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void mijpeg_host_free(void *p)
+{
+  if (p) (void)hipHostFree(p);
+}
+
+int mijpeg_reconstruct_host(mijpeg_decoder *d, void *dst_host, int64_t row_stride, uint32_t flags)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
+  if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
+  if (!dst_host) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "destination pointer is NULL");
+  const mijpeg_info &f = d->host.info;
+  const size_t line = (size_t)f.width * f.components * (f.sample_bytes > 0 ? f.sample_bytes : 1);
+  if (row_stride < (int64_t)line) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "row stride is smaller than a line of samples");
+  HIP_TRY(d, hipSetDevice(d->device));
+  const size_t row = (line + 7) & ~(size_t)7; // device image: 8-byte aligned lines -> wide stores in the kernel
+  int rc = ensure_dev(d, (void **)&d->img_dev, &d->img_dev_cap, row * f.height);
+  if (rc) return rc;
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  rc = mijpeg_reconstruct_device(d, d->img_dev, (int64_t)row, flags, 0);
+  if (rc) return rc;
+  if ((size_t)row_stride == row)
+    HIP_TRY(d, hipMemcpyAsync(dst_host, d->img_dev, row * f.height, hipMemcpyDeviceToHost, d->stream));
+  else
+    HIP_TRY(d, hipMemcpy2DAsync(dst_host, (size_t)row_stride, d->img_dev, row, line, (size_t)f.height, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  d->timing[1] = 0;
+  d->timing[2] = 0;
+  d->timing[3] = std::chrono::duration<double>(clk::now() - t0).count(); // upload tail + kernel + D2H
+  d->img_valid = false;
+  return MIJPEG_OK;
+}
+
 int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp,
                             int32_t max_comp, uint32_t flags, void *const dst[MIJPEG_MAX_COMPONENTS],
                             const int32_t bytes_per_pixel[MIJPEG_MAX_COMPONENTS],

@@ -347,3 +347,15 @@ def test_cli_no_color_transform_and_errors(tmp_path, oracle):
     bad.write_bytes(b"\xff\xd8\xff\xc2garbage")
     r = subprocess.run([exe, str(bad), str(out)], capture_output=True, text=True)
     assert r.returncode != 0 and "reading a JPEG file failed - error" in r.stderr
+
+
+def test_frame_pipeline_batch(oracle):
+    """BASELINE config 4 in miniature: a batch of independent frames through the overlapped pipeline (several decoder
+    objects / streams per GPU), every frame bit-exact."""
+    from libjpeg_amd import pipeline
+
+    streams = [synth.synth_jpeg(320 + 16 * (i % 3), 208, 1000 + i, 85, "420", 4) for i in range(12)]
+    frames = list(pipeline.decode_batch(streams, device=0, depth=3))
+    assert len(frames) == len(streams)
+    for data, px in zip(streams, frames):
+        assert np.array_equal(px, oracle.decode(data))
