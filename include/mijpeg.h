@@ -81,7 +81,7 @@ typedef struct mijpeg_info {
   int32_t sample_bytes;      /* bytes per output sample: 1 (precision 8), 2 (precision 12, JPEG XT)          */
   int32_t xt;                /* 1 = JPEG XT profile C stream: output = 16-bit codes, see mijpeg_xt_params     */
   int32_t is_float;          /* JPGTAG_IMAGE_IS_FLOAT: the 16-bit codes are half-float bit patterns          */
-  int32_t reserved;
+  int32_t progressive;       /* 1 = progressive frame (SOF2): informational, the reconstruction is the same         */
 } mijpeg_info;
 
 /* JPEG XT (ISO/IEC 18477-7) profile C parameters of the loaded stream, valid when info.xt != 0:

@@ -32,7 +32,7 @@ class MijpegInfo(C.Structure):
         ("blocks_w", C.c_int32 * 4), ("blocks_h", C.c_int32 * 4), ("restart_interval", C.c_int32),
         ("ycbcr", C.c_int32), ("fast_arith", C.c_int32), ("coef_offset", C.c_int64 * 4),
         ("coef_count", C.c_int64), ("quant", (C.c_uint16 * 64) * 4), ("range_max", C.c_int32 * 4),
-        ("sample_bytes", C.c_int32), ("xt", C.c_int32), ("is_float", C.c_int32), ("reserved", C.c_int32),
+        ("sample_bytes", C.c_int32), ("xt", C.c_int32), ("is_float", C.c_int32), ("progressive", C.c_int32),
     ]
 
 

@@ -47,6 +47,7 @@ struct Scan {
   ScanComponent sc[MIJPEG_MAX_COMPONENTS];
   HuffTable dc[MIJPEG_MAX_COMPONENTS], ac[MIJPEG_MAX_COMPONENTS]; // snapshot per scan component
   int restart_interval = 0;
+  int ss = 0, se = 63, ah = 0, al = 0; // spectral selection and successive approximation (progressive frames)
   int mcus_x = 0, mcus_y = 0; // MCU grid of THIS scan
   size_t ecs_begin = 0, ecs_end = 0; // entropy coded data [begin, end) in the input
   std::vector<size_t> interval_begin; // byte offset of every restart interval (first = ecs_begin)
@@ -95,6 +96,7 @@ private:
   int restart_interval_ = 0;
   int adobe_transform_ = -1;
   bool have_frame_ = false;
+  bool progressive_ = false; // SOF2
   int comp_id_[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
   // per scan: end offset of every restart interval and the RSTn code that terminated it
   std::vector<size_t> interval_end_;

@@ -30,7 +30,7 @@ def synth_image(width: int, height: int, seed: int = 1234, channels: int = 3) ->
 
 
 def encode_jpeg(img: np.ndarray, quality: int = 85, subsampling: str = "420",
-                restart_mcus: int = 0, optimize: bool = False) -> bytes:
+                restart_mcus: int = 0, optimize: bool = False, progressive: bool = False) -> bytes:
     """Baseline (SOF0) Huffman JPEG via Pillow; restart_mcus = DRI value (0 = none)."""
     from PIL import Image
 
@@ -43,13 +43,15 @@ def encode_jpeg(img: np.ndarray, quality: int = 85, subsampling: str = "420",
         kw["subsampling"] = _SUBSAMPLING[subsampling]
     if restart_mcus:
         kw["restart_marker_blocks"] = restart_mcus
+    if progressive:
+        kw["progressive"] = True
     im.save(buf, **kw)
     return buf.getvalue()
 
 
 def synth_jpeg(width: int, height: int, seed: int = 1234, quality: int = 85,
-               subsampling: str = "420", restart_mcus: int = 0) -> bytes:
-    return encode_jpeg(synth_image(width, height, seed), quality, subsampling, restart_mcus)
+               subsampling: str = "420", restart_mcus: int = 0, progressive: bool = False) -> bytes:
+    return encode_jpeg(synth_image(width, height, seed), quality, subsampling, restart_mcus, progressive=progressive)
 
 
 def synth_hdr(width: int, height: int, seed: int = 99) -> np.ndarray:

@@ -68,6 +68,7 @@ typedef struct {
   oj_huff dc[4], ac[4];
   int restart_interval;
   int have_frame;
+  int progressive; /* SOF2 */
   oj_box *boxes; /* optional: where APP11 boxes are collected (OJ_MAX_BOXES entries) */
   int nboxes;
 } oj_parser;
@@ -260,6 +261,95 @@ static int decode_block(oj_bits *b, const oj_huff *dc, const oj_huff *ac, int32_
   return OJ_OK;
 }
 
+/* Progressive first passes: codestream/sequentialscan.cpp:678-773 with spectral selection [ss, se], point transform
+ * al and EOB runs (`skip`, :716-722). */
+static int decode_block_first(oj_bits *b, const oj_huff *dc, const oj_huff *ac, int32_t *prevdc, int32_t *block,
+                              int ss, int se, int al, int *skip)
+{
+  if (ss == 0) {
+    int s = huff_get(b, dc);
+    int32_t diff = 0;
+    if (s < 0 || s > 15) return OJ_ERR_MALFORMED;
+    if (s) { diff = (int32_t)bits_get(b, s); if (diff < (1 << (s - 1))) diff += (int32_t)((-1L) * (1L << s)) + 1; }
+    *prevdc += diff;
+    block[0] = (int32_t)((uint32_t)*prevdc << al);
+  }
+  if (se) {
+    if (*skip > 0) { (*skip)--; return OJ_OK; }
+    {
+      int k = ss ? ss : 1;
+      do {
+        int rs = huff_get(b, ac), r, s;
+        int32_t diff;
+        if (rs < 0) return OJ_ERR_MALFORMED;
+        r = rs >> 4; s = rs & 15;
+        if (s == 0) {
+          if (r == 15) { k += 16; continue; }
+          *skip = 1 << r;
+          if (r) *skip |= (int)bits_get(b, r);
+          (*skip)--;
+          break;
+        }
+        k += r;
+        diff = (int32_t)bits_get(b, s);
+        if (diff < (1 << (s - 1))) diff += (int32_t)((-1L) * (1L << s)) + 1;
+        if (k >= 64) return OJ_ERR_MALFORMED;
+        block[g_scan_order[k]] = (int32_t)((uint32_t)diff << al);
+        k++;
+      } while (k <= se);
+    }
+  }
+  return OJ_OK;
+}
+
+/* Successive approximation refinement: codestream/refinementscan.cpp:584-700 */
+static int decode_block_refine(oj_bits *b, const oj_huff *ac, int32_t *block, int ss, int se, int al, int *skip)
+{
+  if (ss == 0) block[0] |= (int32_t)(bits_get(b, 1) << al);
+  if (se) {
+    int k = ss, run = 0;
+    int32_t s = 0;
+    int enter_at_start = 0;
+    if (*skip > 0) { run = se - ss + 1; (*skip)--; }
+    else { k--; enter_at_start = 1; }
+    do {
+      int32_t data;
+      if (!enter_at_start) {
+        data = block[g_scan_order[k]];
+        if (data) {
+          if (bits_get(b, 1)) block[g_scan_order[k]] += data > 0 ? (1 << al) : -(1 << al);
+          continue;
+        } else if (run) {
+          run--;
+          continue;
+        }
+        block[g_scan_order[k]] = (int32_t)((uint32_t)s << al);
+        if (k == se) break;
+      }
+      enter_at_start = 0;
+      {
+        int rs = huff_get(b, ac), r;
+        if (rs < 0) return OJ_ERR_MALFORMED;
+        r = rs >> 4; s = rs & 15;
+        if (s == 0) {
+          if (r == 15) run = r;
+          else {
+            *skip = 1 << r;
+            if (r) *skip |= (int)bits_get(b, r);
+            (*skip)--;
+            run = se - k + 1;
+          }
+        } else {
+          if (s != 1) return OJ_ERR_MALFORMED; /* the reference warns and leaves the block unrefined */
+          if (bits_get(b, 1) == 0) s = -s;
+          run = r;
+        }
+      }
+    } while (++k <= se);
+  }
+  return OJ_OK;
+}
+
 /* One scan: codestream/sequentialscan.cpp:381-428 (ParseMCU) driven row by row, restart handling as
  * in codestream/entropyparser.hpp:147-160 / entropyparser.cpp:117-135 (happy path only: a missing or
  * wrong RSTn is reported as OJ_ERR_MALFORMED instead of being resynchronised). */
@@ -271,6 +361,7 @@ static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *
   int ns = sos[0], ci[OJ_MAX_COMP], td[OJ_MAX_COMP], ta[OJ_MAX_COMP], i, c;
   int32_t pred[OJ_MAX_COMP] = {0, 0, 0, 0};
   int mx, my, mcus_x, mcus_y, togo, rstn = 0;
+  int ss, se, ah, al, skip[OJ_MAX_COMP] = {0, 0, 0, 0};
   oj_bits b;
   if (ns < 1 || ns > f->ncomp || n < 1 + 2 * ns + 3) return OJ_ERR_MALFORMED;
   for (i = 0; i < ns; i++) {
@@ -278,11 +369,17 @@ static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *
     for (c = 0; c < f->ncomp; c++) if (f->comp_id[c] == id) break;
     if (c == f->ncomp) return OJ_ERR_MALFORMED;
     ci[i] = c; td[i] = sos[2 + 2 * i] >> 4; ta[i] = sos[2 + 2 * i] & 15;
-    if (td[i] > 3 || ta[i] > 3 || !ps->dc[td[i]].defined || !ps->ac[ta[i]].defined)
-      return OJ_ERR_MALFORMED;
+    if (td[i] > 3 || ta[i] > 3) return OJ_ERR_MALFORMED;
   }
-  if (sos[1 + 2 * ns] != 0 || sos[2 + 2 * ns] != 63 || sos[3 + 2 * ns] != 0)
-    return OJ_ERR_UNSUPPORTED; /* spectral selection / successive approximation */
+  ss = sos[1 + 2 * ns]; se = sos[2 + 2 * ns]; ah = sos[3 + 2 * ns] >> 4; al = sos[3 + 2 * ns] & 15;
+  if (!ps->progressive) {
+    if (ss != 0 || se != 63 || ah != 0 || al != 0) return OJ_ERR_MALFORMED;
+  } else if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) {
+    return OJ_ERR_MALFORMED; /* T.81 G.1.1.1.1 */
+  }
+  for (i = 0; i < ns; i++) {
+    if ((ss == 0 && ah == 0 && !ps->dc[td[i]].defined) || (se > 0 && !ps->ac[ta[i]].defined)) return OJ_ERR_MALFORMED;
+  }
   if (ns > 1) { mcus_x = f->mcus_x; mcus_y = f->mcus_y; }
   else {
     /* single-component scan: 1x1 MCUs over ceil(cw/8) x ceil(ch/8) blocks
@@ -302,7 +399,7 @@ static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *
           if (p + 1 >= end || p[0] != 0xff || p[1] != 0xd0 + rstn) return OJ_ERR_MALFORMED;
           rstn = (rstn + 1) & 7;
           bits_init(&b, p + 2, end);
-          for (i = 0; i < OJ_MAX_COMP; i++) pred[i] = 0;
+          for (i = 0; i < OJ_MAX_COMP; i++) { pred[i] = 0; skip[i] = 0; }
           togo = ps->restart_interval;
         }
         togo--;
@@ -316,7 +413,9 @@ static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *
             int X = mx * w + bx, Y = my * h + by, rc;
             int32_t *blk = (X < f->bw[c] && Y < f->bh[c]) ? planes[c] + ((size_t)Y * f->bw[c] + X) * 64
                                                           : dummy;
-            rc = decode_block(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk);
+            if (!ps->progressive) rc = decode_block(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk);
+            else if (ah == 0) rc = decode_block_first(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk, ss, se, al, &skip[i]);
+            else rc = decode_block_refine(&b, &ps->ac[ta[i]], blk, ss, se, al, &skip[i]);
             if (rc) return rc;
           }
       }
@@ -356,10 +455,11 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
     case 0xdb: rc = parse_dqt(ps, p + 2, n - 2); if (rc) return rc; break;
     case 0xc4: rc = parse_dht(ps, p + 2, n - 2); if (rc) return rc; break;
     case 0xdd: if (n < 4) return OJ_ERR_MALFORMED; ps->restart_interval = rd16(p + 2); break;
-    case 0xc0: case 0xc1:
+    case 0xc0: case 0xc1: case 0xc2: /* baseline, extended sequential, progressive (Huffman) */
       if (ps->have_frame) return OJ_ERR_MALFORMED;
+      ps->progressive = m == 0xc2;
       rc = parse_sof(ps, p + 2, n - 2); if (rc) return rc; break;
-    case 0xc2: case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb:
+    case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb:
     case 0xcd: case 0xce: case 0xcf:
       return OJ_ERR_UNSUPPORTED;
     case 0xeb: /* APP11 "JP": one segment of a box: en(2) z(4) lbox(4) tbox(4) [xlbox(8)] payload; boxes/box.cpp:88-150 */

@@ -75,6 +75,13 @@ case("pil_9x9_420", 9, 9, 26, "pil", quality=95, sub="420", dri=0)
 case("pil_1x1_444", 1, 1, 27, "pil", quality=95, sub="444", dri=0)
 case("pil_80x48_444_adobe0", 80, 48, 28, "pil", quality=75, sub="444", dri=0, adobe=0)
 case("pil_80x48_420_adobe1", 80, 48, 29, "pil", quality=75, sub="420", dri=0, adobe=1)
+# progressive Huffman (SOF2): spectral selection + successive approximation
+case("refprog_97x61_420", 97, 61, 40, "ref", args=["-v", "-q", "80", "-s", "1x1,2x2,2x2"])
+case("refprog_64x64_444_dri5", 64, 64, 41, "ref", args=["-v", "-q", "80", "-z", "5"])
+case("refprog_120x88_420_qv", 120, 88, 42, "ref", args=["-v", "-qv", "-q", "85", "-s", "1x1,2x2,2x2"])
+case("pilprog_200x130_422", 200, 130, 43, "pil", quality=90, sub="422", dri=0, progressive=True)
+case("pilprog_75x45_420", 75, 45, 44, "pil", quality=75, sub="420", dri=0, progressive=True)
+case("pilprog_70x40_gray", 70, 40, 45, "pil", quality=80, sub="gray", dri=0, progressive=True)
 # JPEG XT profile C (BASELINE config 5, small analogues): HDR float input, reference encoder, reference PFM output
 case("xt_64x48_444", 64, 48, 5, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12"])
 case("xt_75x45_444", 75, 45, 6, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12"])
@@ -143,9 +150,9 @@ def main():
             data = O.reference_encode(img, c["args"])
         else:
             if c["sub"] == "gray":
-                data = synth.encode_jpeg(img[..., 0], c["quality"], restart_mcus=c["dri"])
+                data = synth.encode_jpeg(img[..., 0], c["quality"], restart_mcus=c["dri"], progressive=c.get("progressive", False))
             else:
-                data = synth.encode_jpeg(img, c["quality"], c["sub"], c["dri"])
+                data = synth.encode_jpeg(img, c["quality"], c["sub"], c["dri"], progressive=c.get("progressive", False))
             if "adobe" in c:
                 data = insert_adobe(data, c["adobe"])
         ref = O.reference_decode(data)

@@ -84,11 +84,13 @@ def test_error_codes_are_the_references():
     with pytest.raises(api.MijpegError) as e:
         d.read(data[: len(data) // 2])
     assert e.value.code in (-1025, -1038)  # UNEXPECTED_EOF / MALFORMED_STREAM
-    # progressive frame -> NOT_IMPLEMENTED on this path
-    prog = data.replace(b"\xff\xc0", b"\xff\xc2", 1)
+    # lossless frame (SOF3) -> NOT_IMPLEMENTED on this path; sequential scan parameters in a progressive frame -> malformed
     with pytest.raises(api.MijpegError) as e:
-        d.read(prog)
+        d.read(data.replace(b"\xff\xc0", b"\xff\xc3", 1))
     assert e.value.code == -1034
+    with pytest.raises(api.MijpegError) as e:
+        d.read(data.replace(b"\xff\xc0", b"\xff\xc2", 1))
+    assert e.value.code == -1038
     d.close()
 
 
