@@ -34,7 +34,7 @@ struct HuffTable {
   uint16_t fast[1 << LOOKAHEAD];
   int32_t maxcode[18]; // maxcode[l] for codes of length l (left-aligned compare uses plain codes)
   int32_t valoff[17];  // values index = code + valoff[l]
-  void build();
+  bool build(); // false: the code lengths over-subscribe the code space
 };
 
 struct ScanComponent {

@@ -118,3 +118,39 @@ def test_range_check_rejects_absurd_coefficients(oracle):
     assert f.fast_arith == (1 if worst < 16384 else 0)
     assert max(f.range_max[c] for c in range(f.components)) == worst
     d.close()
+
+
+def test_mutated_streams_never_crash():
+    """Robustness of the host side: byte flips, truncations and insertions in valid streams (sequential, progressive,
+    12 bit, JPEG XT) must end in a decoded frame or a MijpegError -- never in a crash or a hang."""
+    from conftest import P12_CASES, XT_CASES
+
+    rng = np.random.default_rng(12345)
+    names = ["pil_200x120_420_dri8", "ref_75x45_420_dri2", "pilprog_75x45_420", "refprog_64x64_444_dri5", "pil_70x40_gray",
+             XT_CASES[0], P12_CASES[0]]
+    d = api.Decoder(None)
+    outcomes = {"ok": 0, "error": 0}
+    for name in names:
+        base = bytearray(golden_jpeg(name))
+        for trial in range(150):
+            data = bytearray(base)
+            kind = trial % 4
+            if kind == 0:  # flip a few bytes anywhere
+                for _ in range(int(rng.integers(1, 6))):
+                    data[int(rng.integers(2, len(data)))] = int(rng.integers(0, 256))
+            elif kind == 1:  # damage the headers specifically
+                for _ in range(int(rng.integers(1, 4))):
+                    data[int(rng.integers(2, min(len(data), 700)))] = int(rng.integers(0, 256))
+            elif kind == 2:  # truncate
+                data = data[: int(rng.integers(4, len(data)))]
+            else:  # insert garbage
+                at = int(rng.integers(2, len(data)))
+                data[at:at] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))
+            try:
+                d.read(bytes(data), 2)
+                outcomes["ok"] += 1
+            except api.MijpegError as e:
+                assert e.code < 0
+                outcomes["error"] += 1
+    d.close()
+    assert outcomes["error"] > 100 and outcomes["ok"] + outcomes["error"] == 150 * len(names)

@@ -1,0 +1,37 @@
+// fuzz_host.cpp -- mutation fuzzing of the host decoder under AddressSanitizer / UBSan.
+//   g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined tools/fuzz_host.cpp libjpeg_amd/csrc/host_decoder.cpp -o /tmp/fuzz_host
+//   /tmp/fuzz_host tests/golden/*.jpg
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <vector>
+
+#include "../libjpeg_amd/csrc/host_decoder.hpp"
+static uint64_t rng_state = 88172645463325252ull;
+static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+int main(int argc, char **argv)
+{
+  long ok = 0, bad = 0;
+  for (int a = 1; a < argc; a++) {
+    std::ifstream f(argv[a], std::ios::binary);
+    std::vector<uint8_t> base((std::istreambuf_iterator<char>(f)), {});
+    for (int t = 0; t < 400; t++) {
+      std::vector<uint8_t> d = base;
+      switch (t % 4) {
+      case 0: for (int i = 0, n = 1 + rnd() % 5; i < n; i++) d[2 + rnd() % (d.size() - 2)] = (uint8_t)rnd(); break;
+      case 1: for (int i = 0, n = 1 + rnd() % 3; i < n; i++) d[2 + rnd() % (std::min<size_t>(d.size(), 700) - 2)] = (uint8_t)rnd(); break;
+      case 2: d.resize(4 + rnd() % (d.size() - 4)); break;
+      default: { size_t at = 2 + rnd() % (d.size() - 2); std::vector<uint8_t> g(1 + rnd() % 40); for (auto &x : g) x = (uint8_t)rnd(); d.insert(d.begin() + at, g.begin(), g.end()); }
+      }
+      mij::HostDecoder h;
+      int rc = h.parse(d.data(), d.size(), false);
+      if (!rc) {
+        std::vector<int16_t> c((size_t)h.info.coef_count + 64);
+        rc = h.decode(c.data(), 2, nullptr);
+      }
+      (rc ? bad : ok)++;
+    }
+  }
+  printf("decoded %ld, rejected %ld\n", ok, bad);
+  return 0;
+}
