@@ -75,6 +75,8 @@ case("pil_9x9_420", 9, 9, 26, "pil", quality=95, sub="420", dri=0)
 case("pil_1x1_444", 1, 1, 27, "pil", quality=95, sub="444", dri=0)
 case("pil_80x48_444_adobe0", 80, 48, 28, "pil", quality=75, sub="444", dri=0, adobe=0)
 case("pil_80x48_420_adobe1", 80, 48, 29, "pil", quality=75, sub="420", dri=0, adobe=1)
+# four components (Adobe CMYK): identity transformation, the reference writes one PGX raw file per component
+case("pil_90x60_cmyk", 90, 60, 50, "cmyk", quality=85)
 # progressive Huffman (SOF2): spectral selection + successive approximation
 case("refprog_97x61_420", 97, 61, 40, "ref", args=["-v", "-q", "80", "-s", "1x1,2x2,2x2"])
 case("refprog_64x64_444_dri5", 64, 64, 41, "ref", args=["-v", "-q", "80", "-z", "5"])
@@ -122,6 +124,27 @@ def main():
     assert O.have_reference(), "oracle/_ref/jpeg missing: run `make -C oracle ref`"
     manifest = {}
     for c in CASES:
+        if c["enc"] == "cmyk":
+            import io
+            import subprocess
+            import tempfile
+
+            from PIL import Image
+            img4 = synth.synth_image(c["w"], c["h"], c["seed"], channels=4)
+            buf = io.BytesIO()
+            Image.fromarray(img4, "CMYK").save(buf, format="JPEG", quality=c["quality"])
+            data = buf.getvalue()
+            with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+                open(d + "/in.jpg", "wb").write(data)
+                subprocess.run([O.REF_BIN, d + "/in.jpg", d + "/out"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                ref = np.stack([np.fromfile(d + "/out_%d.raw" % k, np.uint8).reshape(c["h"], c["w"]) for k in range(4)], -1)
+            ent = dict(width=c["w"], height=c["h"], channels=4, seed=c["seed"], encoder="pil-cmyk", quality=c["quality"],
+                       jpeg_sha256=sha(data), pixels_sha256=sha(ref.tobytes()), jpeg_bytes=len(data), pixels_file=c["name"] + ".bin")
+            open(os.path.join(OUT, c["name"] + ".jpg"), "wb").write(data)
+            open(os.path.join(OUT, c["name"] + ".bin"), "wb").write(ref.tobytes())
+            manifest[c["name"]] = ent
+            print(c["name"], len(data), ent["pixels_sha256"][:12])
+            continue
         if c["enc"] in ("xt", "p12"):
             if c["enc"] == "xt":
                 hdr = synth.synth_hdr(c["w"], c["h"], c["seed"]) * 4.0
