@@ -373,6 +373,8 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
       a.out_max = x.out_max;
       a.is_float = x.is_float;
       a.rprecision = x.residual.precision;
+      a.legacy32 = f.precision == 8 && f.range_max[0] < 16384 && f.range_max[1] < 16384 && f.range_max[2] < 16384 &&
+                   !(b->flags & MIJPEG_FLAG_FORCE_SAFE);
       a.ltable = (const int32_t *)b->workspace;
       if (hipMemcpyAsync(b->workspace, x.ltable, sizeof(x.ltable), hipMemcpyHostToDevice, s) != hipSuccess) return MIJPEG_ERR_DEVICE;
     }

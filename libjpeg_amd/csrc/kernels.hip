@@ -731,8 +731,8 @@ __device__ __forceinline__ int f8(int wa, int x, int wb, int y, int r)
   return (int)((unsigned)wa * (unsigned)x + (unsigned)wb * (unsigned)y + (unsigned)r) >> 3;
 }
 
-__device__ void upsample_line(const int *__restrict__ plane, int pitch, int cw, int ch, int sx, int sy, int X0, int Y,
-                              int (&o)[8])
+__device__ __forceinline__ void upsample_line_any(const int *__restrict__ plane, int pitch, int cw, int ch, int sx, int sy, int X0, int Y,
+                                               int (&o)[8])
 {
   const int y = Y / sy, ymod = Y - y * sy;
   const int cur = min(y, ch - 1), top = min(max(y - 1, 0), ch - 1), bot = min(cur + 1, ch - 1);
@@ -817,6 +817,62 @@ __device__ void upsample_line(const int *__restrict__ plane, int pitch, int cw, 
   for (int j = 0; j < 8; j++) o[j] = v[j];
 }
 
+// Compile-time specialisations of the same arithmetic for the layouts that matter (1x1, 2x1, 1x2, 2x2); groups that lie
+// inside the plane skip the index clamps, and 1x1 lines are two 16-byte loads.
+template <int SX, int SY>
+__device__ __forceinline__ void upsample_line_t(const int *__restrict__ plane, int pitch, int cw, int ch, int X0, int Y, int (&o)[8])
+{
+  const int y = Y / SY, ymod = Y - y * SY;
+  const int cur = min(y, ch - 1), top = min(max(y - 1, 0), ch - 1), bot = min(cur + 1, ch - 1);
+  const int x = (SX > 1) ? X0 / SX - 1 : X0;
+  const int *pc = plane + (int64_t)cur * pitch, *pv = plane + (int64_t)(ymod == 0 ? top : bot) * pitch;
+  int v[8];
+  if (SX == 1 && SY == 1) {
+    if (x + 7 < cw) { // X0 is a multiple of 8 and the pitch a multiple of 8 samples: 32-byte aligned
+      const i32x4 a = *reinterpret_cast<const i32x4 *>(pc + x), b = *reinterpret_cast<const i32x4 *>(pc + x + 4);
+      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[j] = pc[min(x + j, cw - 1)];
+    }
+    return;
+  }
+  const bool inside = x >= 0 && x + 7 < cw;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int col = inside ? x + j : min(max(x + j, 0), cw - 1);
+    const int c = pc[col];
+    if (SY == 2) v[j] = tap13(pv[col], c, ((j & 1) != 0) == (ymod == 0) ? 1 : 2);
+    else v[j] = c;
+  }
+  if (SX == 2) {
+    o[7] = tap13(v[5], v[4], 1);
+    o[6] = tap13(v[3], v[4], 2);
+    o[5] = tap13(v[4], v[3], 1);
+    o[4] = tap13(v[2], v[3], 2);
+    o[3] = tap13(v[3], v[2], 1);
+    o[2] = tap13(v[1], v[2], 2);
+    o[1] = tap13(o[2], v[1], 1); // in-place aliasing: src[1] already holds out[2]
+    o[0] = tap13(v[0], v[1], 2);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = v[j];
+  }
+}
+
+// Layout of a three-component frame as a template parameter of the generic kernels: luma 1x1 and both chroma
+// components subsampled by (CSX, CSY) in {1,2} x {1,2}; LAYOUT_ANY = runtime factors (everything else).
+constexpr int LAYOUT_ANY = 0;
+constexpr int layout_id(int csx, int csy) { return csx * 4 + csy; }
+template <int LAYOUT>
+__device__ __forceinline__ void upsample_plane_line(const GenericArgs &a, int p, int comp, int frame, int X0, int Y, int (&o)[8])
+{
+  const int *plane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[p];
+  if (LAYOUT == LAYOUT_ANY) upsample_line_any(plane, a.bw[p] * 8, a.cw[p], a.ch[p], a.subx[p], a.suby[p], X0, Y, o);
+  else if (comp == 0) upsample_line_t<1, 1>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
+  else upsample_line_t<LAYOUT / 4, LAYOUT % 4>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
+}
+
 // Exact (reference LONG / QUAD) colour stage for any precision: L matrix at FIX_BITS = 13 on samples with
 // COLOR_BITS = 4 fractional bits, ycbcrtrafo.cpp:842-856; not clamped here.
 __device__ __forceinline__ void ycc_to_rgb_wide(int y, int cb, int cr, int dcshift, long long &r, long long &g, long long &b)
@@ -829,7 +885,7 @@ __device__ __forceinline__ void ycc_to_rgb_wide(int y, int cb, int cr, int dcshi
 }
 __device__ __forceinline__ long long clampll(long long v, long long hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
-template <bool FAST>
+template <bool FAST, int LAYOUT>
 __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a)
 {
   const int groups = (a.width + 7) >> 3;
@@ -841,10 +897,7 @@ __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a
   int s[MAXC][8];
 #pragma unroll
   for (int c = 0; c < MAXC; c++) {
-    if (c < a.ncomp) {
-      const int *plane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[c];
-      upsample_line(plane, a.bw[c] * 8, a.cw[c], a.ch[c], a.subx[c], a.suby[c], X0, Y, s[c]);
-    }
+    if (c < a.ncomp) upsample_plane_line<LAYOUT>(a, c, c, frame, X0, Y, s[c]);
   }
   uint8_t *dst = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride + (int64_t)X0 * a.ncomp * a.sample_bytes;
   const int npx = min(8, a.width - X0);
@@ -883,6 +936,7 @@ __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a
 // The Q and R2 tables of the supported subset are identities whose scaling is a shift
 // (boxes/parametrictonemappingbox.cpp:387-430 with e = 0), so they are evaluated arithmetically.
 // ==============================================================================================
+template <int LAYOUT, int RLAYOUT>
 __global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
 {
   const int groups = (a.width + 7) >> 3;
@@ -894,53 +948,66 @@ __global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
   int s[3][8], rs[3][8];
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    const int *plane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[c];
-    upsample_line(plane, a.bw[c] * 8, a.cw[c], a.ch[c], a.subx[c], a.suby[c], X0, Y, s[c]);
-    const int *rplane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[3 + c];
-    upsample_line(rplane, a.bw[3 + c] * 8, a.cw[3 + c], a.ch[3 + c], a.subx[3 + c], a.suby[3 + c], X0, Y, rs[c]);
+    upsample_plane_line<LAYOUT>(a, c, c, frame, X0, Y, s[c]);
+    upsample_plane_line<RLAYOUT>(a, 3 + c, c, frame, X0, Y, rs[c]);
   }
   uint16_t *dst = reinterpret_cast<uint16_t *>(a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride) + (int64_t)X0 * 3;
   const int npx = min(8, a.width - X0);
-  const long long rmax16 = ((1ll << a.rprecision) << 4) - 1; // ((m_lRMax + 1) << COLOR_BITS) - 1
-  const long long omax16 = (((long long)a.out_max + 1) << 4) - 1;
+  // All of this fits 32 bits for the subset (12-bit residual, 16-bit output), and is arranged to stay exact:
+  //   Q table: clamp to [0, 2^(Pr+4) - 1], scale by 2^(16-Pr)  ->  ry = 16 * qy with qy in [0, 65535]
+  //   R transformation: (ry * 8192 + rcb * Lb + rcr * Lr + 4096) >> 13 with rcb = 16 * db, db = qcb - 32768:
+  //     = ry + ((db * Lb + dr * Lr + 256) >> 9)   (ry * 8192 is a multiple of 8192, 16 d L + 4096 = 16 (d L + 256))
+  //   R2 table: clamp to [0, 2^20 - 1], (x + 8) >> 4
+  const int rmax16 = ((1 << a.rprecision) << 4) - 1; // ((m_lRMax + 1) << COLOR_BITS) - 1
+  const int omax16 = ((a.out_max + 1) << 4) - 1;
   const int qshift = 16 - a.rprecision;
-  const long long pinf = (a.out_max >> 1) - (a.out_max >> 6) - 1; // largest finite half: 0x7bff
-  const long long minf = -pinf - 1;                               // INVERT_NEGS(pinf | 0x8000) = -31744
+  const int pinf = (a.out_max >> 1) - (a.out_max >> 6) - 1; // largest finite half: 0x7bff
+  const int minf = -pinf - 1;                               // INVERT_NEGS(pinf | 0x8000) = -31744
+  const bool narrow = a.legacy32 != 0; // 8-bit legacy frame that passed the range check: the 32-bit colour stage is exact
 #pragma unroll
   for (int x = 0; x < 8; x++) {
     if (x >= npx) break;
     // residual chain
-    long long ry = clampll(rs[0][x], rmax16) << qshift, rcb = clampll(rs[1][x], rmax16) << qshift, rcr = clampll(rs[2][x], rmax16) << qshift;
-    long long rr[3];
+    const int qy = min(max(rs[0][x], 0), rmax16) << qshift, qb = min(max(rs[1][x], 0), rmax16) << qshift,
+              qr = min(max(rs[2][x], 0), rmax16) << qshift; // ry, rcb, rcr before the level shift (multiples of 16 when Pr = 12)
+    int rr[3];
     if (a.rtrafo_ycbcr) {
-      rcb -= (long long)a.out_shift << 4;
-      rcr -= (long long)a.out_shift << 4;
-      rr[0] = (ry * 8192 + rcr * L_CR_R + 4096) >> 13; // FIX_COLOR_TO_INTCOLOR
-      rr[1] = (ry * 8192 - rcb * L_CB_G - rcr * L_CR_G + 4096) >> 13;
-      rr[2] = (ry * 8192 + rcb * L_CB_B + 4096) >> 13;
+      const int db = (qb >> 4) - a.out_shift, dr = (qr >> 4) - a.out_shift; // exact: qshift >= 4
+      rr[0] = qy + ((dr * L_CR_R + 256) >> 9);
+      rr[1] = qy + ((-db * L_CB_G - dr * L_CR_G + 256) >> 9);
+      rr[2] = qy + ((db * L_CB_B + 256) >> 9);
     } else {
-      rr[0] = ry; rr[1] = rcb; rr[2] = rcr;
+      rr[0] = qy; rr[1] = qb; rr[2] = qr;
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) rr[c] = (clampll(rr[c], omax16) + 8) >> 4;
+    for (int c = 0; c < 3; c++) rr[c] = (min(max(rr[c], 0), omax16) + 8) >> 4;
     // legacy chain
-    long long v[3];
+    int v[3];
     if (a.ycbcr) {
-      ycc_to_rgb_wide(s[0][x], s[1][x], s[2][x], a.dcshift, v[0], v[1], v[2]);
+      if (narrow) {
+        const int cb = s[1][x] - a.dcshift, cr = s[2][x] - a.dcshift, y13 = (s[0][x] << 13) + 65536;
+        v[0] = (y13 + cr * L_CR_R) >> 17;
+        v[1] = (y13 - cb * L_CB_G - cr * L_CR_G) >> 17;
+        v[2] = (y13 + cb * L_CB_B) >> 17;
+      } else {
+        long long r, g, b;
+        ycc_to_rgb_wide(s[0][x], s[1][x], s[2][x], a.dcshift, r, g, b);
+        v[0] = (int)clampll(r, a.maxval); v[1] = (int)clampll(g, a.maxval); v[2] = (int)clampll(b, a.maxval);
+      }
     } else {
 #pragma unroll
-      for (int c = 0; c < 3; c++) v[c] = ((long long)s[c][x] + 8) >> 4;
+      for (int c = 0; c < 3; c++) v[c] = (int)((((long long)s[c][x]) + 8) >> 4);
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const long long lv = a.ltable[c * 256 + (int)clampll(v[c], a.maxval)];
-      long long m = lv + rr[c] - a.out_shift;
+      const int lv = a.ltable[c * 256 + min(max(v[c], 0), a.maxval)];
+      int m = lv + rr[c] - a.out_shift;
       if (a.is_float) {
-        m = m > pinf ? pinf : (m < minf ? minf : m);
+        m = min(max(m, minf), pinf);
         const short w = (short)m;
         dst[3 * x + c] = (uint16_t)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS
       } else {
-        dst[3 * x + c] = (uint16_t)clampll(m, a.out_max);
+        dst[3 * x + c] = (uint16_t)min(max(m, 0), a.out_max);
       }
     }
   }
@@ -989,12 +1056,37 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   const int groups = (a.width + 7) >> 3;
   const int bs = groups >= 256 ? 256 : 64;
   dim3 g2((groups + bs - 1) / bs, a.height, a.frames);
-  if (a.xt)
-    hipLaunchKernelGGL(xt_merge_kernel, g2, dim3(bs), 0, stream, a);
-  else if (fast)
-    hipLaunchKernelGGL(upsample_color_kernel<true>, g2, dim3(bs), 0, stream, a);
-  else
-    hipLaunchKernelGGL(upsample_color_kernel<false>, g2, dim3(bs), 0, stream, a);
+  // layout of planes [first, first + 3): luma 1x1 and equal chroma factors in {1,2}^2 get a specialised instance
+  auto layout_of = [&](int first, int n) {
+    if (n != 3 || a.subx[first] != 1 || a.suby[first] != 1 || a.subx[first + 1] != a.subx[first + 2] || a.suby[first + 1] != a.suby[first + 2] ||
+        a.subx[first + 1] > 2 || a.suby[first + 1] > 2)
+      return LAYOUT_ANY;
+    return layout_id(a.subx[first + 1], a.suby[first + 1]);
+  };
+  const int lay = layout_of(0, a.ncomp);
+#define LAUNCH_COLOR(F, L) hipLaunchKernelGGL((upsample_color_kernel<F, L>), g2, dim3(bs), 0, stream, a)
+#define LAUNCH_XT(L, R) hipLaunchKernelGGL((xt_merge_kernel<L, R>), g2, dim3(bs), 0, stream, a)
+  if (a.xt) {
+    const int rlay = layout_of(3, 3);
+    if (rlay == layout_id(1, 1) && lay == layout_id(2, 2)) LAUNCH_XT(layout_id(2, 2), layout_id(1, 1));
+    else if (rlay == layout_id(1, 1) && lay == layout_id(1, 1)) LAUNCH_XT(layout_id(1, 1), layout_id(1, 1));
+    else if (rlay == layout_id(1, 1) && lay == layout_id(2, 1)) LAUNCH_XT(layout_id(2, 1), layout_id(1, 1));
+    else if (rlay == layout_id(2, 2) && lay == layout_id(2, 2)) LAUNCH_XT(layout_id(2, 2), layout_id(2, 2));
+    else LAUNCH_XT(LAYOUT_ANY, LAYOUT_ANY);
+  } else if (fast) {
+    if (lay == layout_id(1, 1)) LAUNCH_COLOR(true, layout_id(1, 1));
+    else if (lay == layout_id(2, 2)) LAUNCH_COLOR(true, layout_id(2, 2));
+    else if (lay == layout_id(2, 1)) LAUNCH_COLOR(true, layout_id(2, 1));
+    else if (lay == layout_id(1, 2)) LAUNCH_COLOR(true, layout_id(1, 2));
+    else LAUNCH_COLOR(true, LAYOUT_ANY);
+  } else {
+    if (lay == layout_id(1, 1)) LAUNCH_COLOR(false, layout_id(1, 1));
+    else if (lay == layout_id(2, 2)) LAUNCH_COLOR(false, layout_id(2, 2));
+    else if (lay == layout_id(2, 1)) LAUNCH_COLOR(false, layout_id(2, 1));
+    else LAUNCH_COLOR(false, LAYOUT_ANY);
+  }
+#undef LAUNCH_COLOR
+#undef LAUNCH_XT
   return (int)hipGetLastError();
 }
 

@@ -49,6 +49,7 @@ struct GenericArgs {
   int32_t dcshift;             // 2^(P-1) << 4: chroma level shift seen by the colour transformation
   // JPEG XT profile C merge (colortrafo/ycbcrtrafo.cpp:750-955)
   int32_t xt, rtrafo_ycbcr, out_shift, out_max, is_float, rprecision;
+  int32_t legacy32;            // legacy colour stage may run in 32 bits (8-bit frame that passed the range check)
   const int32_t *ltable;       // device: L lookup tables [3][256]
 };
 
