@@ -121,6 +121,14 @@ int mijpeg_read_header(mijpeg_decoder *d, mijpeg_info *info);
  * bands are hipMemcpyAsync'ed to the GPU while later bands are still being decoded. */
 int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads);
 
+/* The same on the GPU: the host only parses the headers and locates the restart markers, the compressed
+ * bytes are uploaded (a few MB instead of ~100 MB of coefficients) and one device thread decodes one restart interval.
+ * Available for single-scan Huffman sequential 8-bit frames with a restart interval and at least min_intervals
+ * restart intervals (<= 0: library default, below which the host decoder is the faster one); otherwise returns
+ * MIJPEG_ERR_NOT_AVAILABLE without side effects and the caller uses mijpeg_decode_coefficients.
+ * After it, mijpeg_coefficients() downloads the planes on first use. */
+int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals);
+
 /* Current frame information (after mijpeg_decode_coefficients it includes fast_arith). */
 int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info);
 

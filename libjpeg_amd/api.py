@@ -22,6 +22,7 @@ FLAG_FORCE_GENERIC = 2
 FLAG_FORCE_SAFE = 4
 
 ERR_DEVICE = -8191
+ERR_NOT_AVAILABLE = -1029
 
 
 class MijpegInfo(C.Structure):
@@ -95,6 +96,7 @@ def lib():
         L.mijpeg_get_info.argtypes = [C.c_void_p, P(MijpegInfo)]
         L.mijpeg_get_xt_params.argtypes = [C.c_void_p, P(MijpegXtParams)]
         L.mijpeg_decode_coefficients.argtypes = [C.c_void_p, C.c_int]
+        L.mijpeg_decode_coefficients_device.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_coefficients.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_coefficients.restype = C.c_void_p
         L.mijpeg_device_coefficients.argtypes = [C.c_void_p]
@@ -154,11 +156,22 @@ class Decoder:
         self.info = info
         return info
 
-    def read(self, data: bytes, threads: int = 0) -> MijpegInfo:
-        """JPEG::Read: parse everything and entropy-decode all scans (uploads when a device is attached)."""
+    def read(self, data: bytes, threads: int = 0, entropy: str = "host") -> MijpegInfo:
+        """JPEG::Read: parse everything and entropy-decode all scans (uploads when a device is attached).
+        entropy = "host" (restart-interval parallel on the CPU), "gpu" (on the device, error if the stream does not
+        qualify) or "auto" (device when it qualifies)."""
         self._data = data
         self._check(lib().mijpeg_set_input(self._h, data, len(data)))
-        self._check(lib().mijpeg_decode_coefficients(self._h, threads))
+        self.entropy_used = "host"
+        if entropy in ("gpu", "auto"):
+            rc = lib().mijpeg_decode_coefficients_device(self._h, 1 if entropy == "gpu" else 0)
+            if rc == 0:
+                self.entropy_used = "gpu"
+            elif rc != ERR_NOT_AVAILABLE or entropy == "gpu":
+                self._check(rc)
+                raise MijpegError(rc, "stream does not qualify for on-device entropy decoding")
+        if self.entropy_used == "host":
+            self._check(lib().mijpeg_decode_coefficients(self._h, threads))
         info = MijpegInfo()
         self._check(lib().mijpeg_get_info(self._h, C.byref(info)))
         self.info = info

@@ -14,6 +14,7 @@
 
 #include "../../include/mijpeg.h"
 #include "host_decoder.hpp"
+#include "huffman_dev.hpp"
 #include "kernels.hpp"
 
 using namespace mij;
@@ -38,6 +39,12 @@ struct mijpeg_decoder {
   uint32_t img_flags = 0;
   int32_t *ws_dev = nullptr;
   size_t ws_cap = 0; // bytes
+  // on-device entropy decoding: stream bytes, interval offsets, tables, status word
+  uint8_t *ent_dev = nullptr;
+  size_t ent_cap = 0;
+  uint8_t *ent_host = nullptr; // pinned staging for offsets + tables + status
+  size_t ent_host_cap = 0;
+  bool host_planes_stale = false; // coefficients live on the device only
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int err_code = 0;
@@ -101,6 +108,8 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->coef_dev) (void)hipFree(d->coef_dev);
     if (d->img_dev) (void)hipFree(d->img_dev);
     if (d->ws_dev) (void)hipFree(d->ws_dev);
+    if (d->ent_dev) (void)hipFree(d->ent_dev);
+    if (d->ent_host) (void)hipHostFree(d->ent_host);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -130,9 +139,11 @@ int mijpeg_read_header(mijpeg_decoder *d, mijpeg_info *info)
   return MIJPEG_OK;
 }
 
-static int ensure_coef_store(mijpeg_decoder *d, size_t count)
+static int ensure_dev(mijpeg_decoder *d, void **ptr, size_t *cap, size_t bytes);
+
+static int ensure_coef_store(mijpeg_decoder *d, size_t count, bool need_host = true)
 {
-  if (d->coef_host_cap < count) {
+  if (need_host && d->coef_host_cap < count) {
     if (d->device >= 0) {
       if (d->coef_host) (void)hipHostFree(d->coef_host);
       d->coef_host = nullptr;
@@ -168,6 +179,7 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   if (rc) return rc;
   d->img_valid = false;
   d->uploaded = false;
+  d->host_planes_stale = false;
 
   hipError_t copy_err = hipSuccess;
   std::function<void(int, int)> cb;
@@ -219,7 +231,150 @@ int mijpeg_get_xt_params(mijpeg_decoder *d, mijpeg_xt_params *xt)
 const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component)
 {
   if (!d || !d->decoded || component < 0 || component >= d->host.info.components) return nullptr;
+  if (d->host_planes_stale) { // decoded on the device: fetch once
+    if (hipSetDevice(d->device) != hipSuccess) return nullptr;
+    if (ensure_coef_store(d, (size_t)d->host.info.coef_count, true)) return nullptr;
+    if (hipMemcpyAsync(d->coef_host, d->coef_dev, (size_t)d->host.info.coef_count * sizeof(int16_t), hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
+        hipStreamSynchronize(d->stream) != hipSuccess)
+      return nullptr;
+    d->host_planes_stale = false;
+  }
   return d->coef_host + d->host.info.coef_offset[component];
+}
+
+// ------------------------------------------------------------------------------------------------
+// on-device entropy decoding
+// ------------------------------------------------------------------------------------------------
+int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
+  if (d->device < 0) return MIJPEG_ERR_NOT_AVAILABLE;
+  HIP_TRY(d, hipSetDevice(d->device));
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  int rc = d->host.parse(d->data, d->size, false);
+  if (rc) return set_error(d, rc, d->host.error.message);
+  d->parsed = true;
+  const auto t_parsed = clk::now();
+  mijpeg_info &f = d->host.info;
+  // eligibility: one Huffman sequential scan over all components (or a single-component frame), 8 bit, restart markers
+  if (f.progressive || f.xt || f.precision != 8 || d->host.scans.size() != 1) return MIJPEG_ERR_NOT_AVAILABLE;
+  const Scan &s = d->host.scans[0];
+  if (s.restart_interval <= 0 || s.ncomp != f.components) return MIJPEG_ERR_NOT_AVAILABLE;
+  const int64_t total_mcus = (int64_t)s.mcus_x * s.mcus_y;
+  const int64_t nint = (total_mcus + s.restart_interval - 1) / s.restart_interval;
+  if (min_intervals <= 0) min_intervals = 2048; // below this the device runs mostly idle
+  if (nint < min_intervals || nint > 0x7fffffff || d->size > 0xffffffffull) return MIJPEG_ERR_NOT_AVAILABLE;
+  if ((int64_t)s.interval_begin.size() < nint)
+    return set_error(d, MIJPEG_ERR_UNEXPECTED_EOF, "entropy coded segment ends before all restart intervals were found");
+  const std::vector<uint8_t> &rst = d->host.restart_codes(0);
+  for (int64_t i = 0; i + 1 < nint; i++)
+    if (rst[(size_t)i] != 0xd0 + (i & 7)) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "restart markers are out of sequence");
+  rc = ensure_coef_store(d, (size_t)f.coef_count, false);
+  if (rc) return rc;
+  d->img_valid = false;
+  d->uploaded = false;
+  d->decoded = false;
+
+  // device buffer: [stream bytes | pad][ibegin u32 x nint][iend u32 x nint][tables][status u32 x 8]
+  const size_t stream_bytes = ((d->size + 15) & ~(size_t)15) + HUFF_STREAM_PAD;
+  const size_t off_ib = stream_bytes, off_ie = off_ib + (size_t)nint * 4, off_tab = (off_ie + (size_t)nint * 4 + 15) & ~(size_t)15;
+  const int ntab = 2 * s.ncomp;
+  const size_t off_status = off_tab + (size_t)ntab * sizeof(HuffDevTable) + sizeof(HuffDevAux), total = off_status + 32;
+  rc = ensure_dev(d, (void **)&d->ent_dev, &d->ent_cap, total);
+  if (rc) return rc;
+  const size_t host_part = total - stream_bytes; // everything but the stream goes through pinned staging
+  if (d->ent_host_cap < host_part + 32) {
+    if (d->ent_host) (void)hipHostFree(d->ent_host);
+    d->ent_host = nullptr;
+    d->ent_host_cap = 0;
+    HIP_TRY(d, hipHostMalloc((void **)&d->ent_host, host_part + 32, hipHostMallocDefault));
+    d->ent_host_cap = host_part + 32;
+  }
+  uint32_t *ib = (uint32_t *)d->ent_host, *ie = ib + nint;
+  const std::vector<size_t> &iend = d->host.interval_ends(0);
+  for (int64_t i = 0; i < nint; i++) { ib[i] = (uint32_t)s.interval_begin[(size_t)i]; ie[i] = (uint32_t)iend[(size_t)i]; }
+  HuffDevTable *tabs = (HuffDevTable *)(d->ent_host + (off_tab - stream_bytes));
+  HuffDevAux *aux = (HuffDevAux *)(tabs + ntab);
+  memset(aux, 0, sizeof(*aux));
+  HuffScanArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int k = 0; k < s.ncomp; k++) {
+    const HuffTable *src[2] = {&s.dc[k], &s.ac[k]};
+    for (int t = 0; t < 2; t++) {
+      HuffDevTable &dst = tabs[2 * k + t];
+      memset(&dst, 0, sizeof(dst));
+      memcpy(dst.fast, src[t]->fast, sizeof(dst.fast));
+      if (t == 1) // AC: flag the symbols that only exist in progressive scans (EOB runs)
+        for (auto &e : dst.fast)
+          if (e && (e & 15) == 0 && (e & 0xff) != 0 && (e & 0xff) != 0xf0) e |= HUFF_DEV_INVALID;
+      memcpy(dst.maxcode, src[t]->maxcode, sizeof(dst.maxcode));
+      memcpy(dst.valoff, src[t]->valoff, sizeof(dst.valoff));
+      memcpy(dst.values, src[t]->values, sizeof(dst.values));
+    }
+    const int c = s.sc[k].comp;
+    a.comp_of[k] = c;
+    a.hs[k] = s.ncomp > 1 ? f.hsamp[c] : 1;
+    a.vs[k] = s.ncomp > 1 ? f.vsamp[c] : 1;
+    a.bw[k] = f.blocks_w[c];
+    a.coef_off[k] = f.coef_offset[c];
+    a.dc_tab[k] = 2 * k;
+    a.ac_tab[k] = 2 * k + 1;
+    const uint16_t *delta = f.quant[f.quant_index[c]];
+    for (int i = 0; i < 80; i++) {
+      const uint32_t pos = scan_order()[i];
+      aux->zq[k][i] = ((uint32_t)delta[pos] << 16) | (pos * 2);
+    }
+  }
+  a.lanes = 64; // few intervals: spread them over more waves
+  while (a.lanes > 1 && nint / a.lanes < 8192) a.lanes >>= 1;
+  if (const char *e = getenv("MIJPEG_HUFF_DEBUG")) a.debug = atoi(e);
+  if (const char *e = getenv("MIJPEG_HUFF_LANES")) { // tuning
+    const int l = atoi(e);
+    if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) a.lanes = l;
+  }
+  uint32_t *status_host = (uint32_t *)(d->ent_host + host_part);
+  a.data = d->ent_dev;
+  a.ibegin = (const uint32_t *)(d->ent_dev + off_ib);
+  a.iend = (const uint32_t *)(d->ent_dev + off_ie);
+  a.n_intervals = (int32_t)nint;
+  a.restart_interval = s.restart_interval;
+  a.total_mcus = (int32_t)total_mcus;
+  a.mcus_x = s.mcus_x;
+  a.ncomp = s.ncomp;
+  a.ntables = ntab;
+  a.tables = (const HuffDevTable *)(d->ent_dev + off_tab);
+  a.coef = d->coef_dev;
+  a.status = (uint32_t *)(d->ent_dev + off_status);
+  const auto t_prepared = clk::now();
+  HIP_TRY(d, hipMemcpyAsync(d->ent_dev, d->data, d->size, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part - 32, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, 32, d->stream));
+  // an interleaved scan writes every block of every plane; a single-component scan of a frame whose only component
+  // has sampling factors > 1 leaves the MCU padding blocks untouched (they must read as zero)
+  if (s.ncomp == 1 && (s.mcus_x != f.blocks_w[s.sc[0].comp] || s.mcus_y != f.blocks_h[s.sc[0].comp]))
+    HIP_TRY(d, hipMemsetAsync(d->coef_dev, 0, (size_t)f.coef_count * sizeof(int16_t), d->stream));
+  if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
+  if (const char *e = getenv("MIJPEG_HUFF_REPEAT")) // experiments: steady-state kernel time
+    for (int i = atoi(e); i > 1; i--) (void)launch_huffman_scan(a, d->stream);
+  HIP_TRY(d, hipMemcpyAsync(status_host, d->ent_dev + off_status, 32, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  d->timing[0] = std::chrono::duration<double>(clk::now() - t0).count();
+  d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count();       // header parse + restart marker search
+  d->timing[2] = std::chrono::duration<double>(t_prepared - t_parsed).count(); // tables and interval offsets
+  d->timing[3] = 0;
+  if (status_host[0] == HUFF_ERR_OVERFLOW) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
+  if (status_host[0]) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "entropy coded data is malformed (Huffman decoder out of sync)");
+  f.fast_arith = 1;
+  for (int c = 0; c < f.components; c++) {
+    f.range_max[c] = (int32_t)std::min<uint32_t>(status_host[1 + c], 0x7fffffffu);
+    if (f.range_max[c] >= 16384) f.fast_arith = 0;
+  }
+  d->decoded = true;
+  d->uploaded = true;
+  d->host_planes_stale = true;
+  return MIJPEG_OK;
 }
 
 const int16_t *mijpeg_device_coefficients(mijpeg_decoder *d) { return (d && d->uploaded) ? d->coef_dev : nullptr; }

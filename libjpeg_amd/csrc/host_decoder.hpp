@@ -80,6 +80,9 @@ public:
   int decode(int16_t *coef, int threads, const std::function<void(int, int)> &on_rows_done);
 
   mijpeg_info info{};
+  // restart-interval byte ranges of scan i (valid after parse(..., false)): [interval_begin[k], interval_ends(i)[k])
+  const std::vector<size_t> &interval_ends(size_t scan) const { return scan_interval_end_[scan]; }
+  const std::vector<uint8_t> &restart_codes(size_t scan) const { return scan_rst_code_[scan]; }
   // JPEG XT profile C: parameters and the decoder of the residual codestream (RESI box); null for plain JPEG
   bool is_xt() const { return residual_ != nullptr; }
   mijpeg_xt_params xt{};

@@ -1,0 +1,319 @@
+// huffman.hip -- on-device entropy decoding of Huffman sequential scans with restart markers.
+//
+// One THREAD decodes one restart interval: the intervals are independent by construction (DC predictors and the bit
+// buffer are reset at every RSTn, codestream/sequentialscan.cpp:266-274), the host only pre-scans the entropy coded
+// segment for the marker positions (memchr, ~0.4 ms for an 8K frame) and uploads the compressed bytes (a few MB)
+// instead of ~100 MB of coefficients.  Semantics are those of the host decoder (host_decoder.cpp), i.e. of
+// SequentialScan::DecodeBlock (codestream/sequentialscan.cpp:678-773) and BitStream<false>::Fill
+// (io/bitstream.cpp:56-118): FF00 -> FF, zero bits once parked in front of a marker.
+//
+// This is latency-bound pointer chasing, not bandwidth-bound work, so everything is arranged to keep the serial
+// chain of one interval short and to run many chains side by side:
+//   * All lanes of a wave walk the same MCU / component / block structure and only diverge inside the per-block
+//     symbol loop, which is branch-free apart from its exit.
+//   * A frame rarely has enough restart intervals to fill 1024 SIMDs with full waves, so only the first `lanes`
+//     lanes of a wave decode: more waves in flight and less divergence for free.
+//   * The compressed bytes of a lane are staged through a 128-byte ring in LDS.  The ring is topped up at the block
+//     boundaries (a point all lanes pass together) from registers that were loaded one block earlier, so the
+//     global-memory latency hides behind the decoding of a whole block; the symbol loop only touches LDS.
+//   * Coefficients are collected in a 128-byte LDS slot per lane; after every block the whole wave writes the slots
+//     out as full 128-byte lines (16 bytes per lane), which also provides the zeros: no memset of the store and no
+//     partial-line writes.  They land de-zigzagged as int16 in the planar store the reconstruction kernels read.
+//   * Decoder tables (10-bit direct table + canonical fallback per table), deltas and zigzag order live in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "huffman_dev.hpp"
+
+namespace mij {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RING = 128;             // bytes of stream staged per lane
+constexpr int RING_PITCH = RING + 16; // + mirror of the first 16 bytes so that an 8-byte read never wraps
+constexpr int LANE_LDS = 128 + RING_PITCH + 16; // coefficient slot + ring + block index (padded: 16-byte granules)
+
+// Bit reader over the device copy of the stream, through the lane's LDS ring.
+// ring holds the stream bytes [fill - 128, fill) at offset (address & 127); fill is a multiple of 16.
+// A refill step takes the leading ordinary bytes (up to four, none 0xFF, all before the end of the interval) of the
+// dword at the read position at once; a leading 0xFF is the stuffed pair FF 00 -> FF, or a marker in front of which
+// the reader parks and supplies zero bits: the rules of BitStream<false>::Fill (io/bitstream.cpp:56-118).
+// Invariant after refill(): n >= 32, i.e. the high dword of acc is valid, which is enough for one Huffman code
+// (<= 16 bits) plus its value bits (<= 15).  The stream buffer is padded (HUFF_STREAM_PAD) so that topping up past
+// the end of the last interval stays inside the allocation.
+struct DevBits {
+  const uint8_t *base; // device copy of the stream (16-byte aligned)
+  uint8_t *ring;       // LDS
+  uint32_t pos, end;   // byte offsets into the stream
+  uint32_t fill;
+  uint32_t rx0, rx1;   // ring dwords at pos & ~3
+  uint64_t acc;
+  int n;
+  bool parked;
+
+  __device__ __forceinline__ u32x4 fetch(uint32_t at) const { return *reinterpret_cast<const u32x4 *>(base + at); }
+  __device__ __forceinline__ void commit(u32x4 v)
+  {
+    const uint32_t o = fill & (RING - 1);
+    *reinterpret_cast<u32x4 *>(ring + o) = v;
+    if (o == 0) *reinterpret_cast<u32x4 *>(ring + RING) = v;
+    fill += 16;
+  }
+  __device__ __forceinline__ bool room() const { return fill - pos <= RING - 16; }
+  __device__ __forceinline__ void open(const uint8_t *stream, uint8_t *lds_ring, uint32_t begin, uint32_t stop)
+  {
+    base = stream;
+    ring = lds_ring;
+    pos = begin;
+    end = stop;
+    fill = begin & ~15u;
+    acc = 0;
+    n = 0;
+    parked = false;
+    const u32x4 c0 = fetch(fill), c1 = fetch(fill + 16), c2 = fetch(fill + 32), c3 = fetch(fill + 48);
+    commit(c0);
+    commit(c1);
+    commit(c2);
+    commit(c3);
+    peek_ring();
+  }
+  // request the two ring dwords that hold the four bytes at pos (after topping the ring up if a long block outran it)
+  __device__ __forceinline__ void peek_ring()
+  {
+    while (__builtin_expect(pos + 4 > fill, 0)) commit(fetch(fill)); // a block that outran the prefetch (rare)
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(ring + (pos & (RING - 4)));
+    rx0 = r[0];
+    rx1 = r[1];
+  }
+  // Common step without any branch: a lane that is short of bits (n < 32) and looks at four ordinary bytes that lie
+  // inside the interval and whose successors are in the ring takes them; everything else (0xFF, end of the interval,
+  // ring outrun by a long block) goes through refill_slow(), which is rarely entered.
+  __device__ __forceinline__ void refill()
+  {
+    const uint32_t x = __builtin_amdgcn_alignbyte(rx1, rx0, pos & 3u); // the four bytes at pos, little endian
+    const uint32_t ff = (~x - 0x01010101u) & x & 0x80808080u;          // nonzero: one of them is 0xFF
+    const bool take = (n < 32) & !parked & (ff == 0) & (end - pos >= 4u) & (fill - pos >= 8u);
+    const uint32_t xs = take ? __builtin_bswap32(x) : 0u;
+    acc |= (uint64_t)xs << ((32 - n) & 63);
+    n += take ? 32 : 0;
+    pos += take ? 4u : 0u;
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(ring + (pos & (RING - 4)));
+    rx0 = r[0]; // consumed by the next step: the LDS round trip is off the symbol-to-symbol chain
+    rx1 = r[1];
+    if (__builtin_expect(n < 32, 0)) refill_slow();
+  }
+  __device__ __forceinline__ void refill_slow()
+  {
+    while (n < 32) {
+      const uint32_t avail = end - pos;
+      if (parked || avail == 0) { parked = true; n += 32; continue; }
+      const uint32_t x = __builtin_amdgcn_alignbyte(rx1, rx0, pos & 3u);
+      const uint32_t ff = (~x - 0x01010101u) & x & 0x80808080u;          // lowest set bit marks the first 0xFF
+      const uint32_t k = min(ff ? (uint32_t)__builtin_ctz(ff) >> 3 : 4u, avail); // leading ordinary bytes
+      if (k) {
+        const int drop = 32 - 8 * (int)k;
+        const uint32_t xs = (__builtin_bswap32(x) >> drop) << drop;
+        acc |= (uint64_t)xs << (32 - n);
+        n += 8 * (int)k;
+        pos += k;
+        peek_ring();
+      } else if (avail >= 2 && (x & 0xff00u) == 0) { // FF 00
+        acc |= (uint64_t)0xff << (56 - n);
+        n += 8;
+        pos += 2;
+        peek_ring();
+      } else parked = true;
+    }
+  }
+  __device__ __forceinline__ uint32_t window() const { return (uint32_t)(acc >> 32); }
+  __device__ __forceinline__ void skip(int k) { acc <<= k; n -= k; }
+};
+
+// Huffman code at the top of the 32-bit window -> (length << 8) | symbol, 0 if no code matches.  For AC tables bit 15
+// flags the symbols that do not exist in sequential scans (s == 0 with a run other than 0 and 15, :747-750); the host
+// sets it in the direct table, the fallback for long codes sets it here.
+template <bool AC> __device__ __forceinline__ uint32_t dev_lookup(uint32_t win, const HuffDevTable *h)
+{
+  uint32_t e = h->fast[win >> (32 - HUFF_DEV_LOOKAHEAD)];
+  if (__builtin_expect(e == 0, 0)) {
+    const int code16 = (int)(win >> 16);
+    for (int l = HUFF_DEV_LOOKAHEAD + 1; l <= 16; l++) {
+      const int code = code16 >> (16 - l);
+      if (code <= h->maxcode[l]) {
+        const uint32_t sym = h->values[(code + h->valoff[l]) & 0xff];
+        e = ((uint32_t)l << 8) | sym;
+        if (AC && (sym & 15) == 0 && sym != 0 && sym != 0xf0) e |= HUFF_DEV_INVALID;
+        break;
+      }
+    }
+  }
+  return e;
+}
+
+// The s value bits that end `tot` bits into the window (code + value), sign-extended the JPEG way (F.2.2.1 EXTEND).
+__device__ __forceinline__ int dev_value(uint32_t win, int tot, int s)
+{
+  const uint32_t v = __builtin_amdgcn_ubfe(win, (uint32_t)(32 - tot), (uint32_t)s); // s = 0 -> 0
+  const uint32_t full = (1u << s) - 1u;
+  return (int)v - (int)(v <= (full >> 1) ? full : 0u);
+}
+
+// One block (sequentialscan.cpp:678-773) into this lane's 128-byte LDS slot (16-byte chunks XOR-swizzled by the lane
+// so that lanes writing the same coefficient position hit different banks).  zq[i] = (delta << 16) | (2 * natural
+// position) of scan position i.  The symbol loop has no branch but its exit and two rarely taken ones (long codes,
+// awkward refills); it is rotated: the table lookup of the next symbol is issued before the coefficient of the
+// current one is stored (after the last symbol of a block that lookup is simply not used).  ZRL and EOB store a zero
+// at a position that still holds zero.  Returns 0 or HUFF_ERR_*.
+__device__ __forceinline__ int dev_block(DevBits &br, const HuffDevTable *dc, const HuffDevTable *ac, const uint32_t *zq,
+                                         uint8_t *slot, int swz16, int &pred, uint32_t &qmax)
+{
+  br.refill();
+  uint32_t win = br.window();
+  uint32_t e = dev_lookup<false>(win, dc);
+  int s = (int)(e & 0xff), tot = (int)(e >> 8) + s;
+  if (e == 0 || s > 15) return HUFF_ERR_MALFORMED; // ":686 DC coefficient decoding out of sync"
+  pred += dev_value(win, tot, s);
+  br.skip(tot);
+  if (pred != (int16_t)pred) return HUFF_ERR_OVERFLOW;
+  br.refill();
+  win = br.window();
+  e = dev_lookup<true>(win, ac);
+  *reinterpret_cast<int16_t *>(slot + swz16) = (int16_t)pred;
+  uint32_t qsum = (uint32_t)abs(pred) * (zq[0] >> 16);
+  int kk = 1;
+  bool bad = false;
+  for (;;) {
+    const int rs = (int)(e & 0xff);
+    s = rs & 15;
+    tot = (int)((e >> 8) & 31u) + s;
+    const int val = dev_value(win, tot, s);
+    br.skip(tot);
+    kk += rs >> 4;
+    // no code / a symbol of progressive scans only (:747-750) / ":763 AC coefficient decoding out of sync"
+    bad |= (e - 1u >= (uint32_t)HUFF_DEV_INVALID - 1u) | ((s != 0) & (kk > 63));
+    const bool last = (rs == 0) | bad | (kk >= 63); // EOB, error, or position 63 reached (by a coefficient or a ZRL)
+    br.refill();
+    win = br.window();
+    const uint32_t z = zq[kk]; // kk <= 63 + 15, the table is padded; in flight together with the lookup below
+    e = dev_lookup<true>(win, ac);
+    *reinterpret_cast<int16_t *>(slot + ((z & 0xffffu) ^ (uint32_t)swz16)) = (int16_t)val;
+    qsum = min(qsum + (uint32_t)abs(val) * (z >> 16), 0x7fffffffu); // saturating like the host decoder
+    if (last) break;
+    kk++;
+  }
+  qmax = max(qmax, qsum);
+  return bad ? HUFF_ERR_MALFORMED : 0;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS of a workgroup: [tables | aux][per wave: lanes x 128-byte block slot | lanes x ring | lanes x block number]
+__global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  const int table_bytes = a.ntables * (int)sizeof(HuffDevTable) + (int)sizeof(HuffDevAux);
+  const HuffDevTable *tabs = reinterpret_cast<const HuffDevTable *>(lds_raw);
+  const HuffDevAux *aux = reinterpret_cast<const HuffDevAux *>(lds_raw + a.ntables * sizeof(HuffDevTable));
+  const int L = a.lanes, nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint8_t *stage = lds_raw + table_bytes + wv * (L * LANE_LDS);                     // L x 128
+  uint8_t *rings = stage + L * 128;                                                 // L x RING_PITCH
+  uint32_t *blkno = reinterpret_cast<uint32_t *>(stage + L * (128 + RING_PITCH));   // L x 4 (of 16)
+  {
+    // cooperative copy of the tables this scan uses, the deltas and the zigzag order (dwords); clear the slots
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
+    const int words = table_bytes / 4, rest = nwaves * L * LANE_LDS / 4;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < rest; i += blockDim.x) dst[words + i] = 0;
+  }
+  __syncthreads();
+  const int interval = (blockIdx.x * nwaves + wv) * L + lane;
+  const bool decoding = lane < L && interval < a.n_intervals;
+  const int ln = lane & (L - 1);
+
+  DevBits br; // lanes that do not decode never touch a ring (theirs would alias a decoding lane's)
+  br.base = a.data;
+  br.ring = rings + ln * RING_PITCH;
+  br.pos = br.end = br.fill = 0;
+  br.rx0 = br.rx1 = 0;
+  br.acc = 0;
+  br.n = 0;
+  br.parked = true;
+  if (decoding) br.open(a.data, rings + ln * RING_PITCH, a.ibegin[interval], a.iend[interval]);
+  // the next 32 bytes of the stream travel in registers for the duration of one block
+  uint32_t pend_at = br.fill;
+  u32x4 pend0 = br.fetch(pend_at), pend1 = br.fetch(pend_at + 16);
+  int pred[4] = {0, 0, 0, 0};
+  uint32_t qmax[4] = {0, 0, 0, 0};
+  int err = 0;
+  const int m0 = interval * a.restart_interval;
+  uint8_t *slot = stage + ln * 128;
+  const int swz16 = (lane & 7) << 4;
+  for (int mi = 0; mi < a.restart_interval; mi++) {
+    const int m = m0 + mi;
+    const bool live = decoding && m < a.total_mcus;
+    if (__ballot(live && !err) == 0) break;
+    const int my = m / a.mcus_x, mx = m - my * a.mcus_x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (k >= a.ncomp) break;
+      const HuffDevTable *dc = tabs + a.dc_tab[k], *ac = tabs + a.ac_tab[k];
+      const int h = a.hs[k], v = a.vs[k];
+      const uint32_t comp_base = (uint32_t)(a.coef_off[k] >> 6); // in blocks
+      for (int by = 0; by < v; by++)
+        for (int bx = 0; bx < h; bx++) {
+          uint32_t blk = 0; // block number + 1
+          if (live && !err && !(a.debug & 8)) {
+            err = dev_block(br, dc, ac, aux->zq[k], slot, swz16, pred[k], qmax[k]);
+            if (!err) blk = comp_base + (uint32_t)(my * v + by) * (uint32_t)a.bw[k] + (uint32_t)(mx * h + bx) + 1u;
+          }
+          // top the ring up with what was requested a block ago
+          if (!(a.debug & 4)) {
+          if (decoding && pend_at == br.fill && br.room()) br.commit(pend0);
+          if (decoding && pend_at + 16 == br.fill && br.room()) br.commit(pend1);
+          }
+          if (!(a.debug & 2)) {
+          if (lane < L) blkno[lane] = blk;
+          wave_lds_sync();
+          // the wave writes the L blocks out in 16-byte chunks (full 128-byte lines) and clears the slots
+          for (int c = lane; c < L * 8; c += 64) {
+            const int sl = c >> 3, ch = c & 7;
+            const uint32_t b = blkno[sl];
+            u32x4 *src = reinterpret_cast<u32x4 *>(stage + sl * 128 + ((ch ^ (sl & 7)) << 4));
+            const u32x4 val = *src;
+            *src = u32x4{0, 0, 0, 0};
+            if (b && !(a.debug & 1)) *reinterpret_cast<u32x4 *>(a.coef + ((size_t)(b - 1) << 6) + ch * 8) = val;
+          }
+          wave_lds_sync();
+          }
+          // request the next 32 bytes; they are not looked at before the next block is done
+          if (!(a.debug & 4)) {
+          pend_at = br.fill;
+          pend0 = br.fetch(pend_at);
+          pend1 = br.fetch(pend_at + 16);
+          }
+        }
+    }
+  }
+  if (err) atomicMax(&a.status[0], (uint32_t)err);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (k < a.ncomp && qmax[k]) atomicMax(&a.status[1 + a.comp_of[k]], qmax[k]);
+}
+
+int launch_huffman_scan(const HuffScanArgs &a, hipStream_t stream)
+{
+  if (a.n_intervals <= 0) return 0;
+  const int waves = (a.n_intervals + a.lanes - 1) / a.lanes, wpg = a.lanes >= 32 ? 2 : 4;
+  const size_t lds = (size_t)a.ntables * sizeof(HuffDevTable) + sizeof(HuffDevAux) + (size_t)wpg * a.lanes * LANE_LDS;
+  hipLaunchKernelGGL(huffman_scan_kernel, dim3((waves + wpg - 1) / wpg), dim3(64 * wpg), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+} // namespace mij

@@ -359,3 +359,96 @@ def test_frame_pipeline_batch(oracle):
     assert len(frames) == len(streams)
     for data, px in zip(streams, frames):
         assert np.array_equal(px, oracle.decode(data))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# on-device entropy decoding (one thread per restart interval) against the host decoder and the oracle
+# ---------------------------------------------------------------------------------------------------------------
+def _same_coefficients(a, b, ncomp):
+    for c in range(ncomp):
+        assert np.array_equal(a.coefficients(c), b.coefficients(c)), f"component {c}"
+
+
+@pytest.mark.parametrize("w,h,sub,ri,q", [
+    (640, 480, "420", 1, 85), (641, 479, "420", 7, 95), (1000, 333, "444", 5, 75), (515, 260, "422", 3, 30),
+    (256, 256, "420", 16, 100), (2048, 1024, "420", 128, 90), (333, 777, "444", 1000, 50),
+])
+def test_device_entropy_decoder_matches_host(dec, oracle, w, h, sub, ri, q):
+    data = synth.encode_jpeg(synth.synth_image(w, h, seed=w + h), q, sub, restart_mcus=ri)
+    host = api.Decoder(0)
+    hi = host.read(data)
+    gi = dec.read(data, entropy="gpu")
+    assert dec.entropy_used == "gpu"
+    assert gi.fast_arith == hi.fast_arith and list(gi.range_max) == list(hi.range_max)
+    out = dec.reconstruct()  # before the planes are fetched: the device copy is what the kernels read
+    assert np.array_equal(out, oracle.decode(data))
+    _same_coefficients(dec, host, hi.components)
+    host.close()
+
+
+def test_device_entropy_decoder_grey_and_optimized_tables(dec, oracle):
+    grey = synth.encode_jpeg(synth.synth_image(500, 300, 5, channels=1), 90, restart_mcus=4, optimize=True)
+    dec.read(grey, entropy="gpu")
+    assert np.array_equal(dec.reconstruct(), oracle.decode(grey))
+    col = synth.encode_jpeg(synth.synth_image(500, 300, 6), 92, "420", restart_mcus=2, optimize=True)
+    dec.read(col, entropy="gpu")
+    assert np.array_equal(dec.reconstruct(), oracle.decode(col))
+
+
+def test_device_entropy_decoder_eligibility_and_errors(dec):
+    # no restart interval, progressive: not available on the device ("auto" falls back to the host silently)
+    for data in (synth.synth_jpeg(320, 240), synth.synth_jpeg(320, 240, restart_mcus=4, progressive=True)):
+        with pytest.raises(api.MijpegError) as e:
+            dec.read(data, entropy="gpu")
+        assert e.value.code == api.ERR_NOT_AVAILABLE
+        dec.read(data, entropy="auto")
+        assert dec.entropy_used == "host"
+    # few intervals: "auto" keeps it on the host, "gpu" forces it
+    data = synth.synth_jpeg(320, 240, restart_mcus=4)
+    dec.read(data, entropy="auto")
+    assert dec.entropy_used == "host"
+    # corrupted entropy coded data: same error class as the host decoder
+    good = bytearray(synth.synth_jpeg(640, 480, restart_mcus=2, quality=95))
+    sos = good.find(b"\xff\xda")
+    rng = np.random.default_rng(3)
+    host = api.Decoder(0)
+    seen = 0
+    for trial in range(40):
+        bad = bytearray(good)
+        for pos in rng.integers(sos + 20, len(bad) - 2, size=8):
+            if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:
+                bad[pos] = int(rng.integers(0, 255))
+        codes = []
+        for d, mode in ((host, "host"), (dec, "gpu")):
+            try:
+                d.read(bytes(bad), entropy=mode)
+                codes.append(0)
+            except api.MijpegError as e:
+                codes.append(e.code)
+        assert codes[0] == codes[1], (trial, codes)
+        if codes[0] == 0:
+            _same_coefficients(dec, host, 3)
+        else:
+            seen += 1
+    assert seen > 0
+    host.close()
+
+
+def test_device_entropy_decoder_8k(dec):
+    """BASELINE config 3 (8K 4:2:0, DRI 8: 32 400 restart intervals) entropy-decoded on the device."""
+    ent = MANIFEST["big_8k_420_q85_dri8"]
+    data = big_jpeg("big_8k_420_q85_dri8")
+    pinned_by_reference = data is not None
+    if data is None:
+        data = synth.synth_jpeg(ent["width"], ent["height"], ent["seed"], ent["quality"], ent["sub"], ent["dri"])
+    host = api.Decoder(0)
+    hi = host.read(data)
+    gi = dec.read(data, entropy="auto")
+    assert dec.entropy_used == "gpu"
+    assert gi.fast_arith == hi.fast_arith == 1 and list(gi.range_max) == list(hi.range_max)
+    out = dec.reconstruct()
+    if pinned_by_reference:
+        assert _sha(out) == ent["pixels_sha256"]
+    assert np.array_equal(out, host.reconstruct())
+    _same_coefficients(dec, host, 3)
+    host.close()

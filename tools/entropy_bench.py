@@ -1,0 +1,32 @@
+"""Host vs on-device entropy decoding of one 8K 4:2:0 frame (wall clock of Decoder.read, coefficients end up in HBM)."""
+import sys
+import time
+
+import numpy as np
+
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from libjpeg_amd import api, synth
+
+W, H = 7680, 4320
+img = synth.synth_image(W, H, 1234)
+import os
+for ri in [int(x) for x in os.environ.get('RI', '1,2,4,8,32').split(',')]:
+    data = synth.encode_jpeg(img, 85, "420", restart_mcus=ri)
+    d = api.Decoder(0)
+    res = {}
+    for mode in ("host", "gpu"):
+        ts = []
+        for it in range(6):
+            t0 = time.perf_counter()
+            d.read(data, entropy=mode)
+            ts.append(time.perf_counter() - t0)
+        res[mode] = min(ts) * 1e3
+        res[mode + "_t"] = {k: round(v * 1e3, 3) for k, v in d.timing().items()}
+        t0 = time.perf_counter()
+        out = d.reconstruct()
+        res[mode + "_rec"] = (time.perf_counter() - t0) * 1e3
+        res[mode + "_sum"] = int(out.astype(np.uint64).sum())
+    assert res["host_sum"] == res["gpu_sum"] or os.environ.get("MIJPEG_HUFF_DEBUG")
+    print(f"dri={ri:4d} bytes={len(data)/1e6:.2f}MB host read {res['host']:.2f} ms  gpu read {res['gpu']:.2f} ms  {res['gpu_t']}", flush=True)
+    d.close()

@@ -27,7 +27,7 @@ for sub in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
                 acc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print(f"== counters ({sub}): per-dispatch mean")
         for k, ctrs in acc.items():
-            if not any(t in k for t in ("fused420", "fused444", "idct_planes", "upsample_color")):
+            if not any(t in k for t in ("fused420", "fused444", "idct_planes", "upsample_color", "huffman", "xt_merge")):
                 continue
             print("  kernel", k)
             for c, v in sorted(ctrs.items()):
