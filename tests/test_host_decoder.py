@@ -66,6 +66,19 @@ def test_coefficients_larger_streams(oracle, w, h, sub, dri):
     d.close()
 
 
+@pytest.mark.parametrize("dri,progressive", [(1, False), (8, False), (0, False), (8, True)])
+def test_parallel_marker_search_on_a_stream_of_several_chunks(oracle, dri, progressive):
+    """Streams beyond 1 MiB have their restart markers located by parallel chunks (HostDecoder::find_intervals)."""
+    data = synth.encode_jpeg(synth.synth_image(2560, 1440, 5), 95, "444", restart_mcus=dri, progressive=progressive)
+    assert len(data) > (1 << 20)
+    d = api.Decoder(None)
+    f = d.read(data, 4)
+    _, planes = oracle.decode_coefficients(data)
+    for c in range(f.components):
+        assert np.array_equal(d.coefficients(c), planes[c].astype(np.int16))
+    d.close()
+
+
 def test_reconstruct_without_device_fails_loudly():
     d = api.Decoder(None)
     d.read(golden_jpeg("ref_80x48_420"))
