@@ -111,7 +111,11 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
     int rc = mijpeg_set_input(p->dec, p->stream.data(), p->stream.size());
     if (rc) return p->fail_from_decoder(rc);
     const int threads = tags->GetTagData(JPGTAG_MIJPEG_THREADS, getenv("MIJPEG_THREADS") ? atoi(getenv("MIJPEG_THREADS")) : 0);
-    rc = mijpeg_decode_coefficients(p->dec, threads);
+    // streams with enough restart intervals are entropy-decoded on the device (JPGTAG_MIJPEG_ENTROPY /
+    // MIJPEG_ENTROPY: 0 = automatic, 1 = always on the host)
+    const int entropy = tags->GetTagData(JPGTAG_MIJPEG_ENTROPY, getenv("MIJPEG_ENTROPY") ? atoi(getenv("MIJPEG_ENTROPY")) : 0);
+    rc = entropy == 1 ? MIJPEG_ERR_NOT_AVAILABLE : mijpeg_decode_coefficients_device(p->dec, 0);
+    if (rc == MIJPEG_ERR_NOT_AVAILABLE) rc = mijpeg_decode_coefficients(p->dec, threads);
     if (rc) return p->fail_from_decoder(rc);
     mijpeg_get_info(p->dec, &p->info);
     p->loaded = true;

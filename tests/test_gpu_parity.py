@@ -305,6 +305,34 @@ def test_cli_writes_the_references_pnm(tmp_path, name):
     assert hashlib.sha256(data[len(header):]).hexdigest() == ent["pixels_sha256"]
 
 
+@pytest.mark.parametrize("entropy", ["0", "1"])
+def test_cli_4k_with_restart_markers_device_and_host_entropy(tmp_path, oracle, entropy):
+    """A 4K frame with 16 200 restart intervals goes through the on-device entropy decoder inside JPEG::Read
+    (MIJPEG_ENTROPY=0, the default) and through the host decoder (=1): the same PNM as the reference's."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    ent = MANIFEST["big_4k_420_q85_dri8"]
+    data = big_jpeg("big_4k_420_q85_dri8")
+    pinned_by_reference = data is not None
+    if data is None:
+        data = synth.synth_jpeg(ent["width"], ent["height"], ent["seed"], ent["quality"], ent["sub"], ent["dri"])
+    src, out = tmp_path / "in.jpg", tmp_path / "out.ppm"
+    src.write_bytes(data)
+    exe = os.path.join(ROOT, "libjpeg_amd", "bin", "jpeg")
+    r = subprocess.run([exe, str(src), str(out)], capture_output=True, text=True, env=dict(os.environ, MIJPEG_ENTROPY=entropy))
+    assert r.returncode == 0, r.stderr
+    got = out.read_bytes()
+    header = b"P6\n%d %d\n255\n" % (ent["width"], ent["height"])
+    assert got.startswith(header)
+    if pinned_by_reference:
+        assert hashlib.sha256(got[len(header):]).hexdigest() == ent["pixels_sha256"]
+    else:
+        assert got[len(header):] == oracle.decode(data).tobytes()
+
+
 @pytest.mark.parametrize("name", XT_CASES[:3] + P12_CASES)
 def test_cli_writes_the_references_pfm_and_16bit_pnm(tmp_path, name):
     """JPEG XT -> 'PF' file with big-endian floats (cmd/reconstruct.cpp:321-323, cmd/bitmaphook.cpp:282-305),
