@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(HERE, "libmijpeg.so")
 FLAG_NO_COLOR_TRANSFORM = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_FORCE_SAFE = 4
+FLAG_DEVICE_OUTPUT = 8
 
 ERR_DEVICE = -8191
 ERR_NOT_AVAILABLE = -1029
@@ -213,6 +214,19 @@ class Decoder:
         bpr = (C.c_int32 * 4)(*([out.strides[0]] * 4))
         self._check(lib().mijpeg_reconstruct_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags, dst, bpp, bpr))
         return out
+
+    def reconstruct_rect_device(self, x0, y0, x1, y1, ptrs, bytes_per_pixel, bytes_per_row, comp0=0, comp1=None,
+                                flags: int = 0):
+        """mijpeg_reconstruct_rect with MIJPEG_FLAG_DEVICE_OUTPUT: `ptrs[c]` is the device address of canvas pixel
+        (0,0) of component c (0/None = component not wanted), strides in bytes as in the reference's ImageBitMap."""
+        nc = self.info.components
+        comp1 = nc - 1 if comp1 is None else comp1
+        ptrs = list(ptrs) + [None] * (4 - len(ptrs))
+        dst = (C.c_void_p * 4)(*[p or None for p in ptrs])
+        bpp = (C.c_int32 * 4)(*(list(bytes_per_pixel) + [0] * (4 - len(bytes_per_pixel))))
+        bpr = (C.c_int32 * 4)(*(list(bytes_per_row) + [0] * (4 - len(bytes_per_row))))
+        self._check(lib().mijpeg_reconstruct_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags | FLAG_DEVICE_OUTPUT,
+                                                  dst, bpp, bpr))
 
     def reconstruct_into(self, out: np.ndarray, flags: int = 0) -> np.ndarray:
         """Whole frame with the device-to-host copy landing directly in `out` (fast when `out` is pinned, see

@@ -35,7 +35,8 @@ struct mijpeg_decoder {
   size_t img_dev_cap = 0;
   uint8_t *img_host = nullptr; // pinned
   size_t img_host_cap = 0;
-  bool img_valid = false;
+  bool img_valid = false;      // img_dev holds the reconstructed frame for img_flags
+  bool img_host_valid = false; // ... and img_host its copy
   uint32_t img_flags = 0;
   int32_t *ws_dev = nullptr;
   size_t ws_cap = 0; // bytes
@@ -640,13 +641,29 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
   const int nc = f.components;
   // the whole frame is reconstructed once per (stream, flags) and then served rectangle by rectangle,
   // which is what the stripe loop of cmd/reconstruct.cpp:334-342 asks for
+  const bool to_device = (flags & MIJPEG_FLAG_DEVICE_OUTPUT) != 0;
+  flags &= ~MIJPEG_FLAG_DEVICE_OUTPUT;
+  const size_t row = ((size_t)f.width * nc * sb + 7) & ~(size_t)7;
+  const size_t padded = row * f.height;
+  using clk = std::chrono::steady_clock;
   if (!d->img_valid || d->img_flags != flags) {
     HIP_TRY(d, hipSetDevice(d->device));
-    const size_t bytes = (size_t)f.width * f.height * nc * sb;
-    const size_t row = ((size_t)f.width * nc * sb + 7) & ~(size_t)7;
-    const size_t padded = row * f.height;
     int rc = ensure_dev(d, (void **)&d->img_dev, &d->img_dev_cap, padded);
     if (rc) return rc;
+    auto t0 = clk::now();
+    HIP_TRY(d, hipStreamSynchronize(d->stream)); // uploads complete
+    auto t1 = clk::now();
+    rc = mijpeg_reconstruct_device(d, d->img_dev, (int64_t)row, flags, 1);
+    if (rc) return rc;
+    d->timing[1] = std::chrono::duration<double>(t1 - t0).count();
+    d->timing[2] = std::chrono::duration<double>(clk::now() - t1).count();
+    d->timing[3] = 0;
+    d->img_valid = true;
+    d->img_host_valid = false;
+    d->img_flags = flags;
+  }
+  if (!to_device && !d->img_host_valid) {
+    HIP_TRY(d, hipSetDevice(d->device));
     if (d->img_host_cap < padded) {
       if (d->img_host) (void)hipHostFree(d->img_host);
       d->img_host = nullptr;
@@ -654,22 +671,11 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
       HIP_TRY(d, hipHostMalloc((void **)&d->img_host, padded, hipHostMallocDefault));
       d->img_host_cap = padded;
     }
-    (void)bytes;
-    using clk = std::chrono::steady_clock;
-    auto t0 = clk::now();
-    HIP_TRY(d, hipStreamSynchronize(d->stream)); // uploads complete
-    auto t1 = clk::now();
-    rc = mijpeg_reconstruct_device(d, d->img_dev, (int64_t)row, flags, 1);
-    if (rc) return rc;
     auto t2 = clk::now();
     HIP_TRY(d, hipMemcpyAsync(d->img_host, d->img_dev, padded, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(d, hipStreamSynchronize(d->stream));
-    auto t3 = clk::now();
-    d->timing[1] = std::chrono::duration<double>(t1 - t0).count();
-    d->timing[2] = std::chrono::duration<double>(t2 - t1).count();
-    d->timing[3] = std::chrono::duration<double>(t3 - t2).count();
-    d->img_valid = true;
-    d->img_flags = flags;
+    d->timing[3] = std::chrono::duration<double>(clk::now() - t2).count();
+    d->img_host_valid = true;
   }
   if (min_x < 0) min_x = 0;
   if (min_y < 0) min_y = 0;
@@ -677,7 +683,29 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
   if (max_y >= f.height) max_y = f.height - 1;
   if (min_comp < 0) min_comp = 0;
   if (max_comp >= nc) max_comp = nc - 1;
-  const size_t row = ((size_t)f.width * nc * sb + 7) & ~(size_t)7;
+  if (to_device) {
+    ScatterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = d->img_dev;
+    a.src_row = (int64_t)row;
+    a.ncomp = nc;
+    a.sample_bytes = sb;
+    a.x0 = min_x;
+    a.y0 = min_y;
+    a.w = max_x - min_x + 1;
+    a.h = max_y - min_y + 1;
+    a.c0 = min_comp;
+    a.c1 = max_comp;
+    for (int c = 0; c < nc; c++) {
+      a.dst[c] = (uint8_t *)dst[c];
+      a.bytes_per_pixel[c] = bytes_per_pixel[c];
+      a.bytes_per_row[c] = bytes_per_row[c];
+    }
+    HIP_TRY(d, hipSetDevice(d->device));
+    if (launch_scatter_rect(a, d->stream)) return hip_fail(d, hipGetLastError(), "scatter_rect_kernel launch");
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    return MIJPEG_OK;
+  }
   // interleaved destination (the layout cmd/bitmaphook.cpp hands out): whole lines at once
   bool interleaved = min_comp == 0 && max_comp == nc - 1 && dst[0];
   for (int c = 0; c < nc && interleaved; c++)

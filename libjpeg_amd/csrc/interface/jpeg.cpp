@@ -162,7 +162,7 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
   const mijpeg_info &f = p->info;
   // codestream/rectanglerequest.cpp:62-190: defaults = whole canvas, requests are clipped, negatives are errors
   JPG_LONG minx = 0, miny = 0, maxx = f.width - 1, maxy = f.height - 1, c0 = 0, c1 = f.components - 1;
-  bool upsample = true, ctrafo = true;
+  bool upsample = true, ctrafo = true, device_bitmaps = false;
   struct JPG_Hook *bmh = nullptr;
   for (const struct JPG_TagItem *t = tags ? tags->FirstTagItem() : nullptr; t; t = t->NextTagItem()) {
     const JPG_LONG v = t->ti_Data.ti_lData;
@@ -176,6 +176,7 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
     case JPGTAG_DECODER_UPSAMPLE: upsample = v != 0; break;
     case JPGTAG_MATRIX_LTRAFO: ctrafo = v != JPGFLAG_MATRIX_COLORTRANSFORMATION_NONE; break;
     case JPGTAG_BIH_HOOK: bmh = (struct JPG_Hook *)t->ti_Data.ti_pPtr; break;
+    case JPGTAG_MIJPEG_DEVICE_BITMAPS: device_bitmaps = v != 0; break;
     default: break;
     }
   }
@@ -244,7 +245,8 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
   const JPG_LONG ylimit = (maxmcu >= 0x0fffffff) ? maxy : (maxmcu + 1) * 8 - 1;
   const JPG_LONG y1 = maxy < ylimit ? maxy : ylimit;
   if (maxmcu >= 0 && y1 >= miny)
-    rc = mijpeg_reconstruct_rect(p->dec, minx, miny, maxx, y1, c0, c1, ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM, dst, bpp, bpr);
+    rc = mijpeg_reconstruct_rect(p->dec, minx, miny, maxx, y1, c0, c1,
+                                 (ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM) | (device_bitmaps ? MIJPEG_FLAG_DEVICE_OUTPUT : 0), dst, bpp, bpr);
   // RELEASE is always delivered, also after a failure, so the client can let go of its buffers
   JPG_LONG hookerr = 0;
   for (int c = c0; c <= c1; c++) {

@@ -1090,4 +1090,32 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// device-side bitmap hand-off: what PushReconstructedData's stores through ImageBitMap{ptr, BytesPerPixel,
+// BytesPerRow} do in the reference (colortrafo/ycbcrtrafo.cpp:974-1006), for bitmaps that live in HBM
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_rect_kernel(const ScatterArgs a)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= a.w) return;
+  const uint8_t *src = a.src + (int64_t)(a.y0 + y) * a.src_row + (int64_t)(a.x0 + x) * a.ncomp * a.sample_bytes;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    if (c < a.c0 || c > a.c1 || !a.dst[c]) continue;
+    uint8_t *out = a.dst[c] + (int64_t)(a.y0 + y) * a.bytes_per_row[c] + (int64_t)(a.x0 + x) * a.bytes_per_pixel[c];
+    if (a.sample_bytes == 1) out[0] = src[c];
+    else {
+      out[0] = src[2 * c];
+      out[1] = src[2 * c + 1];
+    }
+  }
+}
+
+int launch_scatter_rect(const ScatterArgs &a, hipStream_t stream)
+{
+  if (a.w <= 0 || a.h <= 0) return 0;
+  hipLaunchKernelGGL(scatter_rect_kernel, dim3((a.w + 255) / 256, a.h), dim3(256), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
 } // namespace mij

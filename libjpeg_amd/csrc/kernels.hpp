@@ -57,5 +57,19 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
 int launch_fused444(const Fused420Args &a, hipStream_t stream); // same argument block; all planes bw_y x bh_y
 int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream);
 
+// Rectangle of the reconstructed interleaved frame -> bitmaps in DEVICE memory described like the reference's
+// ImageBitMap (interface/imagebitmap.hpp): per component the address of canvas pixel (0,0) and the two strides.
+struct ScatterArgs {
+  const uint8_t *src;         // interleaved frame, ncomp * sample_bytes bytes per pixel
+  int64_t src_row;            // bytes per line of src
+  int32_t ncomp, sample_bytes;
+  int32_t x0, y0, w, h;       // rectangle (already clipped to the frame)
+  int32_t c0, c1;             // component range, inclusive
+  uint8_t *dst[4];
+  int32_t bytes_per_pixel[4];
+  int64_t bytes_per_row[4];
+};
+int launch_scatter_rect(const ScatterArgs &a, hipStream_t stream);
+
 } // namespace mij
 #endif

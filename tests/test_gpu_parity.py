@@ -480,3 +480,51 @@ def test_device_entropy_decoder_8k(dec):
     assert np.array_equal(out, host.reconstruct())
     _same_coefficients(dec, host, 3)
     host.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device-side bitmap hand-off (MIJPEG_FLAG_DEVICE_OUTPUT / JPGTAG_MIJPEG_DEVICE_BITMAPS)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["pil_200x120_420_dri8", "ref_97x61_3x3", "pil_70x40_gray"])
+def test_rectangles_into_device_bitmaps(dec, name):
+    import torch
+
+    data = golden_jpeg(name)
+    exp = golden_pixels(name)
+    f = dec.read(data)
+    H, W, C_ = exp.shape
+    # interleaved device bitmap with a padded row stride, served in 8-line stripes like cmd/reconstruct
+    stride = W * C_ + 13
+    buf = torch.zeros((H, stride), dtype=torch.uint8, device="cuda")
+    for y in range(0, H, 8):
+        dec.reconstruct_rect_device(0, y, W - 1, min(H, y + 8) - 1, [buf.data_ptr() + c for c in range(C_)], [C_] * C_, [stride] * C_)
+    got = buf.cpu().numpy()[:, : W * C_].reshape(H, W, C_)
+    assert np.array_equal(got, exp)
+    assert int(buf[:, W * C_:].sum()) == 0  # nothing beyond the lines
+    # planar device bitmaps, inner rectangle, one component left out
+    planes = torch.zeros((C_, H, W), dtype=torch.uint8, device="cuda")
+    x0, y0, x1, y1 = 3, 5, W - 7, H - 4
+    ptrs = [planes[c].data_ptr() for c in range(C_)]
+    if C_ == 3:
+        ptrs[1] = None
+    dec.reconstruct_rect_device(x0, y0, x1, y1, ptrs, [1] * C_, [W] * C_)
+    got = planes.cpu().numpy()
+    for c in range(C_):
+        want = np.zeros((H, W), np.uint8)
+        if not (C_ == 3 and c == 1):
+            want[y0:y1 + 1, x0:x1 + 1] = exp[y0:y1 + 1, x0:x1 + 1, c]
+        assert np.array_equal(got[c], want), c
+    # host rectangles still work afterwards (the device frame is reused, the host copy is made on demand)
+    assert np.array_equal(dec.reconstruct(), exp)
+
+
+def test_device_bitmaps_16bit_samples(dec):
+    import torch
+
+    name = P12_CASES[0]
+    exp = golden_pixels(name)
+    dec.read(golden_jpeg(name))
+    H, W, C_ = exp.shape
+    buf = torch.zeros((H, W, C_), dtype=torch.int16, device="cuda")
+    dec.reconstruct_rect_device(0, 0, W - 1, H - 1, [buf.data_ptr() + 2 * c for c in range(C_)], [2 * C_] * C_, [2 * W * C_] * C_)
+    assert np.array_equal(buf.cpu().numpy().view(np.uint16), exp)
