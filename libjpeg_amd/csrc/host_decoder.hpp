@@ -99,6 +99,7 @@ private:
   int restart_interval_ = 0;
   int adobe_transform_ = -1;
   bool have_frame_ = false;
+  bool need_dnl_ = false; // SOF carried zero lines
   bool progressive_ = false; // SOF2
   int comp_id_[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
   // per scan: end offset of every restart interval and the RSTn code that terminated it
@@ -112,6 +113,7 @@ private:
   int finish_xt(bool header_only);
   int fail(int code, const char *msg);
   int parse_sof(const uint8_t *p, int n);
+  int frame_geometry();
   int parse_sos(const uint8_t *p, int n, size_t ecs_begin);
   void find_intervals(Scan &s);
 };

@@ -68,6 +68,7 @@ typedef struct {
   oj_huff dc[4], ac[4];
   int restart_interval;
   int have_frame;
+  int need_dnl; /* SOF carried zero lines */
   int progressive; /* SOF2 */
   oj_box *boxes; /* optional: where APP11 boxes are collected (OJ_MAX_BOXES entries) */
   int nboxes;
@@ -127,6 +128,21 @@ static int parse_dht(oj_parser *ps, const uint8_t *p, int n)
   return OJ_OK;
 }
 
+static void frame_geometry(oj_info *f)
+{
+  int c;
+  f->mcus_x = (f->width + 8 * f->hmax - 1) / (8 * f->hmax);
+  f->mcus_y = (f->height + 8 * f->vmax - 1) / (8 * f->vmax);
+  for (c = 0; c < f->ncomp; c++) {
+    f->subx[c] = f->hmax / f->hs[c];
+    f->suby[c] = f->vmax / f->vs[c];
+    f->bw[c] = f->mcus_x * f->hs[c];
+    f->bh[c] = f->mcus_y * f->vs[c];
+    f->cw[c] = (f->width + f->subx[c] - 1) / f->subx[c];
+    f->ch[c] = (f->height + f->suby[c] - 1) / f->suby[c];
+  }
+}
+
 static int parse_sof(oj_parser *ps, const uint8_t *p, int n)
 {
   oj_info *f = ps->info;
@@ -138,7 +154,8 @@ static int parse_sof(oj_parser *ps, const uint8_t *p, int n)
   f->ncomp = p[5];
   if (f->precision != 8 && f->precision != 12) return OJ_ERR_UNSUPPORTED;
   if (f->ncomp < 1 || f->ncomp > OJ_MAX_COMP || n < 6 + 3 * f->ncomp) return OJ_ERR_MALFORMED;
-  if (f->width == 0 || f->height == 0) return OJ_ERR_UNSUPPORTED; /* DNL-defined height */
+  if (f->width == 0) return OJ_ERR_MALFORMED;
+  ps->need_dnl = f->height == 0; /* height arrives in a DNL marker behind the first scan (entropyparser.cpp:204-249) */
   f->hmax = f->vmax = 1;
   for (c = 0; c < f->ncomp; c++) {
     f->comp_id[c] = p[6 + 3 * c];
@@ -150,19 +167,27 @@ static int parse_sof(oj_parser *ps, const uint8_t *p, int n)
     if (f->hs[c] > f->hmax) f->hmax = f->hs[c];
     if (f->vs[c] > f->vmax) f->vmax = f->vs[c];
   }
-  f->mcus_x = (f->width + 8 * f->hmax - 1) / (8 * f->hmax);
-  f->mcus_y = (f->height + 8 * f->vmax - 1) / (8 * f->vmax);
-  for (c = 0; c < f->ncomp; c++) {
-    /* marker/component.cpp: subsampling = max / own; must divide evenly */
+  for (c = 0; c < f->ncomp; c++) /* marker/component.cpp: subsampling = max / own; must divide evenly */
     if (f->hmax % f->hs[c] || f->vmax % f->vs[c]) return OJ_ERR_UNSUPPORTED;
-    f->subx[c] = f->hmax / f->hs[c];
-    f->suby[c] = f->vmax / f->vs[c];
-    f->bw[c] = f->mcus_x * f->hs[c];
-    f->bh[c] = f->mcus_y * f->vs[c];
-    f->cw[c] = (f->width + f->subx[c] - 1) / f->subx[c];
-    f->ch[c] = (f->height + f->suby[c] - 1) / f->suby[c];
-  }
+  frame_geometry(f);
   ps->have_frame = 1;
+  return OJ_OK;
+}
+
+/* Height from the DNL marker that must follow the entropy coded data of the first scan
+ * (EntropyParser::ParseDNLMarker, codestream/entropyparser.cpp:204-249): FFDC, length 4, number of lines > 0. */
+static int resolve_dnl(oj_parser *ps, const uint8_t *ecs, const uint8_t *end)
+{
+  const uint8_t *q = ecs;
+  int h;
+  while (q + 1 < end && !(q[0] == 0xff && q[1] != 0x00 && q[1] != 0xff && !(q[1] >= 0xd0 && q[1] <= 0xd7))) q++;
+  if (q + 6 > end || q[1] != 0xdc) return OJ_ERR_MALFORMED; /* the reference then fails on the frame height as well */
+  if (rd16(q + 2) != 4) return OJ_ERR_MALFORMED;
+  h = rd16(q + 4);
+  if (h == 0) return OJ_ERR_MALFORMED;
+  ps->info->height = h;
+  frame_geometry(ps->info);
+  ps->need_dnl = 0;
   return OJ_OK;
 }
 
@@ -497,6 +522,7 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
       const uint8_t *next = NULL;
       if (!ps->have_frame) return OJ_ERR_MALFORMED;
       f->restart_interval = ps->restart_interval;
+      if (ps->need_dnl) { rc = resolve_dnl(ps, p + n, end); if (rc) return rc; }
       if (!planes && !ps->boxes) goto done; /* header-only walk stops at the first scan (unless boxes are wanted) */
       if (!planes) { /* skip the entropy coded data */
         const uint8_t *q = p + n;

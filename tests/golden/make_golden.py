@@ -65,6 +65,9 @@ case("ref_97x61_mixed", 97, 61, 12, "ref", args=["-bl", "-q", "85", "-s", "1x1,2
 case("ref_120x88_sof1_420", 120, 88, 13, "ref", args=["-q", "85", "-s", "1x1,2x2,2x2", "-z", "4"])
 case("ref_64x40_q2", 64, 40, 14, "ref", args=["-bl", "-q", "2", "-s", "1x1,2x2,2x2"])
 case("ref_64x40_q100", 64, 40, 15, "ref", args=["-bl", "-q", "100"])
+# number of lines in a DNL marker behind the first scan (SOF carries 0; codestream/entropyparser.cpp:204-249)
+case("ref_97x61_420_dnl", 97, 61, 60, "ref", args=["-bl", "-n", "-q", "80", "-s", "1x1,2x2,2x2"])
+case("ref_50x70_444_dnl_dri2", 50, 70, 61, "ref", args=["-bl", "-n", "-q", "80", "-z", "2"])
 case("pil_80x48_444", 80, 48, 20, "pil", quality=75, sub="444", dri=0)
 case("pil_75x45_420_dri2", 75, 45, 21, "pil", quality=85, sub="420", dri=2)
 case("pil_33x17_420_dri1", 33, 17, 22, "pil", quality=85, sub="420", dri=1)
@@ -81,6 +84,7 @@ case("pil_90x60_cmyk", 90, 60, 50, "cmyk", quality=85)
 case("refprog_97x61_420", 97, 61, 40, "ref", args=["-v", "-q", "80", "-s", "1x1,2x2,2x2"])
 case("refprog_64x64_444_dri5", 64, 64, 41, "ref", args=["-v", "-q", "80", "-z", "5"])
 case("refprog_120x88_420_qv", 120, 88, 42, "ref", args=["-v", "-qv", "-q", "85", "-s", "1x1,2x2,2x2"])
+case("refprog_75x45_420_dnl", 75, 45, 46, "ref", args=["-v", "-n", "-q", "80", "-s", "1x1,2x2,2x2"])
 case("pilprog_200x130_422", 200, 130, 43, "pil", quality=90, sub="422", dri=0, progressive=True)
 case("pilprog_75x45_420", 75, 45, 44, "pil", quality=75, sub="420", dri=0, progressive=True)
 case("pilprog_70x40_gray", 70, 40, 45, "pil", quality=80, sub="gray", dri=0, progressive=True)
