@@ -57,6 +57,7 @@ extern "C" {
 #define MIJPEG_FLAG_NO_COLOR_TRANSFORM 1u /* JPGTAG_MATRIX_LTRAFO = JPGFLAG_MATRIX_COLORTRANSFORMATION_NONE (CLI -c) */
 #define MIJPEG_FLAG_FORCE_GENERIC 2u      /* use the unfused generic kernels even where a fused one exists (testing) */
 #define MIJPEG_FLAG_FORCE_SAFE 4u         /* use the 32/64-bit "safe" arithmetic flavour even if the range check passed */
+#define MIJPEG_FLAG_NO_UPSAMPLING 16u      /* mijpeg_reconstruct_rect: JPGTAG_DECODER_UPSAMPLE = false -- one component on its own sample grid */
 #define MIJPEG_FLAG_DEVICE_OUTPUT 8u      /* mijpeg_reconstruct_rect: dst[] are DEVICE pointers; nothing crosses PCIe */
 
 typedef struct mijpeg_decoder mijpeg_decoder;
@@ -161,6 +162,9 @@ void mijpeg_host_free(void *p);
  * (interface/imagebitmap.hpp): for component c, dst[c] is the address of canvas pixel (0,0),
  * bytes_per_pixel[c] / bytes_per_row[c] the strides.  Rectangle and component range are inclusive,
  * as in JPGTAG_DECODER_MINX..MAXY / MINCOMPONENT..MAXCOMPONENT (codestream/rectanglerequest.cpp:92-152).
+ * With MIJPEG_FLAG_NO_UPSAMPLING (min_comp == max_comp required) the component is delivered at its own resolution
+ * without colour transformation; the rectangle is still given on the canvas and shrinks by the subsampling factors
+ * (control/bitmapctrl.cpp:273-294), dst[c] addresses the component's sample (0,0).
  * With MIJPEG_FLAG_DEVICE_OUTPUT the bitmaps live in device memory of the decoder's GPU and the pixels never leave
  * HBM ("device-side output"); the call returns when they are written. */
 int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y,

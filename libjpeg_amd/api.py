@@ -21,6 +21,7 @@ FLAG_NO_COLOR_TRANSFORM = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_FORCE_SAFE = 4
 FLAG_DEVICE_OUTPUT = 8
+FLAG_NO_UPSAMPLING = 16
 
 ERR_DEVICE = -8191
 ERR_NOT_AVAILABLE = -1029
@@ -213,6 +214,20 @@ class Decoder:
         bpp = (C.c_int32 * 4)(*([nc * sb] * 4))
         bpr = (C.c_int32 * 4)(*([out.strides[0]] * 4))
         self._check(lib().mijpeg_reconstruct_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags, dst, bpp, bpr))
+        return out
+
+    def reconstruct_unsampled(self, comp: int, flags: int = 0) -> np.ndarray:
+        """JPGTAG_DECODER_UPSAMPLE = false: component `comp` on its own sample grid, no colour transformation
+        (what the reference CLI's -U writes into out_<comp>.raw)."""
+        f = self.info
+        sb = max(1, f.sample_bytes)
+        w, h = -(-f.width // f.subx[comp]), -(-f.height // f.suby[comp])
+        out = np.zeros((h, w), np.uint8 if sb == 1 else np.uint16)
+        dst = (C.c_void_p * 4)(*[out.ctypes.data if c == comp else None for c in range(4)])
+        bpp = (C.c_int32 * 4)(*([sb] * 4))
+        bpr = (C.c_int32 * 4)(*([out.strides[0]] * 4))
+        self._check(lib().mijpeg_reconstruct_rect(self._h, 0, 0, f.width - 1, f.height - 1, comp, comp,
+                                                  flags | FLAG_NO_UPSAMPLING, dst, bpp, bpr))
         return out
 
     def reconstruct_rect_device(self, x0, y0, x1, y1, ptrs, bytes_per_pixel, bytes_per_row, comp0=0, comp1=None,

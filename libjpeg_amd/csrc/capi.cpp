@@ -38,6 +38,7 @@ struct mijpeg_decoder {
   bool img_valid = false;      // img_dev holds the reconstructed frame for img_flags
   bool img_host_valid = false; // ... and img_host its copy
   uint32_t img_flags = 0;
+  int img_view = -1;           // component of a non-upsampled reconstruction, -1: the whole picture
   int32_t *ws_dev = nullptr;
   size_t ws_cap = 0; // bytes
   // on-device entropy decoding: stream bytes, interval offsets, tables, status word
@@ -556,17 +557,37 @@ static int ensure_dev(mijpeg_decoder *d, void **ptr, size_t *cap, size_t bytes)
   return MIJPEG_OK;
 }
 
-int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_stride, uint32_t flags, int sync)
+// The frame as the reconstruction sees it: the whole picture, or -- without upsampling -- one component at its own
+// resolution, which is a single-component identity-transformed frame over that component's coefficient plane
+// (BlockBitmapRequester::ReconstructUnsampled with rr_bUpsampling = false: control/blockbitmaprequester.cpp:1013-1074,
+// control/bitmapctrl.cpp:273-294; the colour transformation is off then, codestream/rectanglerequest.cpp:157-159).
+static mijpeg_info view_of(const mijpeg_info &f, int comp)
 {
-  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
-  if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
-  if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
-  if (!dst_device) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "destination pointer is NULL");
+  if (comp < 0) return f;
+  mijpeg_info v = f;
+  v.components = 1;
+  v.width = (f.width + f.subx[comp] - 1) / f.subx[comp];
+  v.height = (f.height + f.suby[comp] - 1) / f.suby[comp];
+  v.hsamp[0] = v.vsamp[0] = v.subx[0] = v.suby[0] = 1;
+  v.quant_index[0] = f.quant_index[comp];
+  v.blocks_w[0] = f.blocks_w[comp];
+  v.blocks_h[0] = f.blocks_h[comp];
+  v.mcus_x = v.blocks_w[0];
+  v.mcus_y = v.blocks_h[0];
+  v.coef_offset[0] = 0;
+  v.coef_count = (int64_t)v.blocks_w[0] * v.blocks_h[0] * 64;
+  v.range_max[0] = f.range_max[comp];
+  v.ycbcr = 0;
+  return v;
+}
+
+static int reconstruct_view(mijpeg_decoder *d, int comp, void *dst_device, int64_t row_stride, uint32_t flags, int sync)
+{
   HIP_TRY(d, hipSetDevice(d->device));
   mijpeg_batch b;
   memset(&b, 0, sizeof(b));
-  b.info = d->host.info;
-  b.coef_dev = d->coef_dev;
+  b.info = view_of(d->host.info, comp);
+  b.coef_dev = d->coef_dev + (comp < 0 ? 0 : d->host.info.coef_offset[comp]);
   b.coef_frame_stride = b.info.coef_count;
   b.out_dev = (uint8_t *)dst_device;
   b.out_row_stride = row_stride;
@@ -586,6 +607,15 @@ int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_s
                                                            : std::string("reconstruction not available for this stream"));
   if (sync) HIP_TRY(d, hipStreamSynchronize(d->stream));
   return MIJPEG_OK;
+}
+
+int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_stride, uint32_t flags, int sync)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
+  if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
+  if (!dst_device) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "destination pointer is NULL");
+  return reconstruct_view(d, -1, dst_device, row_stride, flags & ~(MIJPEG_FLAG_DEVICE_OUTPUT | MIJPEG_FLAG_NO_UPSAMPLING), sync);
 }
 
 void *mijpeg_host_alloc(size_t bytes)
@@ -636,24 +666,55 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
   if (!d || !dst || !bytes_per_pixel || !bytes_per_row) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
   if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
-  const mijpeg_info &f = d->host.info;
+  const bool to_device = (flags & MIJPEG_FLAG_DEVICE_OUTPUT) != 0;
+  const bool unsampled = (flags & MIJPEG_FLAG_NO_UPSAMPLING) != 0;
+  flags &= ~(MIJPEG_FLAG_DEVICE_OUTPUT | MIJPEG_FLAG_NO_UPSAMPLING);
+  int view = -1; // component whose own sample grid is reconstructed, -1: the upsampled picture
+  if (unsampled) {
+    // control/bitmapctrl.cpp:273-294: one component at a time, no colour transformation, and the rectangle (given
+    // on the canvas) shrinks to the component's grid
+    if (min_comp < 0) min_comp = 0;
+    if (max_comp >= d->host.info.components) max_comp = d->host.info.components - 1;
+    if (min_comp != max_comp)
+      return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "if upsampling is disabled, components can only be reconstructed one by one");
+    if (d->host.is_xt())
+      return set_error(d, MIJPEG_ERR_OPERATION_UNIMPLEMENTED, "JPEG XT streams are not reconstructed without upsampling on this path");
+    view = min_comp;
+    flags |= MIJPEG_FLAG_NO_COLOR_TRANSFORM;
+    const int sx = d->host.info.subx[view], sy = d->host.info.suby[view];
+    min_x = (std::max(min_x, 0) + sx - 1) / sx;
+    max_x = (max_x + sx) / sx - 1;
+    min_y = (std::max(min_y, 0) + sy - 1) / sy;
+    max_y = (max_y + sy) / sy - 1;
+  }
+  const mijpeg_info f = view_of(d->host.info, view);
   const int sb = f.sample_bytes > 0 ? f.sample_bytes : 1; // bytes per sample
   const int nc = f.components;
-  // the whole frame is reconstructed once per (stream, flags) and then served rectangle by rectangle,
+  void *vdst[MIJPEG_MAX_COMPONENTS] = {dst[0], dst[1], dst[2], dst[3]};
+  int32_t vbpp[MIJPEG_MAX_COMPONENTS] = {bytes_per_pixel[0], bytes_per_pixel[1], bytes_per_pixel[2], bytes_per_pixel[3]};
+  int32_t vbpr[MIJPEG_MAX_COMPONENTS] = {bytes_per_row[0], bytes_per_row[1], bytes_per_row[2], bytes_per_row[3]};
+  if (view >= 0) { // the view has one component, number 0
+    vdst[0] = dst[view];
+    vbpp[0] = bytes_per_pixel[view];
+    vbpr[0] = bytes_per_row[view];
+    min_comp = max_comp = 0;
+  }
+  dst = vdst;
+  bytes_per_pixel = vbpp;
+  bytes_per_row = vbpr;
+  // the whole frame is reconstructed once per (stream, flags, view) and then served rectangle by rectangle,
   // which is what the stripe loop of cmd/reconstruct.cpp:334-342 asks for
-  const bool to_device = (flags & MIJPEG_FLAG_DEVICE_OUTPUT) != 0;
-  flags &= ~MIJPEG_FLAG_DEVICE_OUTPUT;
   const size_t row = ((size_t)f.width * nc * sb + 7) & ~(size_t)7;
   const size_t padded = row * f.height;
   using clk = std::chrono::steady_clock;
-  if (!d->img_valid || d->img_flags != flags) {
+  if (!d->img_valid || d->img_flags != flags || d->img_view != view) {
     HIP_TRY(d, hipSetDevice(d->device));
     int rc = ensure_dev(d, (void **)&d->img_dev, &d->img_dev_cap, padded);
     if (rc) return rc;
     auto t0 = clk::now();
     HIP_TRY(d, hipStreamSynchronize(d->stream)); // uploads complete
     auto t1 = clk::now();
-    rc = mijpeg_reconstruct_device(d, d->img_dev, (int64_t)row, flags, 1);
+    rc = reconstruct_view(d, view, d->img_dev, (int64_t)row, flags, 1);
     if (rc) return rc;
     d->timing[1] = std::chrono::duration<double>(t1 - t0).count();
     d->timing[2] = std::chrono::duration<double>(clk::now() - t1).count();
@@ -661,6 +722,7 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
     d->img_valid = true;
     d->img_host_valid = false;
     d->img_flags = flags;
+    d->img_view = view;
   }
   if (!to_device && !d->img_host_valid) {
     HIP_TRY(d, hipSetDevice(d->device));

@@ -1,9 +1,11 @@
 // main.cpp -- `jpeg` command line front end of the MI355X path: the decode half of the reference CLI.
-//   jpeg [-c] [-t threads] [-d device] in.jpg out.ppm
+//   jpeg [-c] [-U] [-t threads] [-d device] in.jpg out.ppm
 // reproduces cmd/main.cpp:746-747 -> cmd/reconstruct.cpp:68-376 for the streams this path handles: the
 // image (8 bit -> PNM, 12 bit -> 16-bit PNM, JPEG XT profile C -> PFM) is reconstructed stripe by stripe (eight lines per JPEG::DisplayRectangle call) through a file I/O
 // hook and a bitmap hook, and written as binary PNM (P6 for three components, P5 for one) -- byte for
-// byte what the reference binary writes.  -c disables the colour transformation (reference: -c).
+// byte what the reference binary writes.  -c disables the colour transformation (reference: -c); -U disables the
+// upsampling (reference: -U): like images with neither one nor three components, the components then go one by one
+// into PGX files (out_N.h + out_N.raw, listed in `out`), cmd/reconstruct.cpp:208-306.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -39,7 +41,10 @@ struct StripeBuffer {
   unsigned width, height, depth;
   unsigned bytes; // per sample: 1 (8 bit) or 2 (12 bit, JPEG XT half-float codes)
   bool halffloat; // 16-bit samples are half-float codes: expanded to big-endian float32 when written (PFM)
+  bool upsampling; // false: the hook works on the component's own sample grid (JPGTAG_BIO_PIXEL_*)
+  bool pgx;        // plane by plane into pgxfiles[] instead of stripe by stripe into target
   FILE *target;
+  FILE *pgxfiles[4];
 };
 
 // cmd/iohelpers.hpp:60-77: exact expansion of a half-float bit pattern
@@ -57,8 +62,10 @@ static JPG_LONG BitmapHook(struct JPG_Hook *hook, struct JPG_TagItem *tags)
 {
   StripeBuffer *sb = (StripeBuffer *)hook->hk_pData;
   const unsigned comp = (unsigned)tags->GetTagData(JPGTAG_BIO_COMPONENT);
-  const unsigned miny = (unsigned)tags->GetTagData(JPGTAG_BIO_MINY), maxy = (unsigned)tags->GetTagData(JPGTAG_BIO_MAXY);
-  const unsigned width = 1 + (unsigned)tags->GetTagData(JPGTAG_BIO_MAXX);
+  // cmd/bitmaphook.cpp:106-108
+  const unsigned miny = (unsigned)tags->GetTagData(sb->upsampling ? JPGTAG_BIO_MINY : JPGTAG_BIO_PIXEL_MINY);
+  const unsigned maxy = (unsigned)tags->GetTagData(sb->upsampling ? JPGTAG_BIO_MAXY : JPGTAG_BIO_PIXEL_MAXY);
+  const unsigned width = 1 + (unsigned)tags->GetTagData(sb->upsampling ? JPGTAG_BIO_MAXX : JPGTAG_BIO_PIXEL_MAXX);
   switch (tags->GetTagData(JPGTAG_BIO_ACTION)) {
   case JPGFLAG_BIO_REQUEST:
     // address of canvas pixel (0,0) of this component: the stripe buffer starts at line miny
@@ -70,7 +77,18 @@ static JPG_LONG BitmapHook(struct JPG_Hook *hook, struct JPG_TagItem *tags)
     tags->SetTagData(JPGTAG_BIO_PIXELTYPE, sb->bytes == 2 ? CTYP_UWORD : CTYP_UBYTE);
     break;
   case JPGFLAG_BIO_RELEASE:
-    if (comp == sb->depth - 1) { // all components of the stripe are in: write it
+    if (sb->pgx) { // cmd/bitmaphook.cpp:254, 308-326: PGX is plane-interleaved, samples big-endian
+      const size_t n = (size_t)width * (maxy + 1 - miny);
+      FILE *out = sb->pgxfiles[comp];
+      for (size_t i = 0; i < n; i++) {
+        const unsigned char *px = sb->mem + (i * sb->depth + comp) * sb->bytes;
+        if (sb->bytes == 2) {
+          unsigned short v;
+          memcpy(&v, px, 2);
+          if (fputc(v >> 8, out) == EOF || fputc(v & 0xff, out) == EOF) return JPGERR_UNEXPECTED_EOF;
+        } else if (fputc(px[0], out) == EOF) return JPGERR_UNEXPECTED_EOF;
+      }
+    } else if (comp == sb->depth - 1) { // all components of the stripe are in: write it
       const size_t n = (size_t)width * (maxy + 1 - miny) * sb->depth;
       if (sb->bytes == 1) {
         if (fwrite(sb->mem, 1, n, sb->target) != n) return JPGERR_UNEXPECTED_EOF;
@@ -95,7 +113,7 @@ static JPG_LONG BitmapHook(struct JPG_Hook *hook, struct JPG_TagItem *tags)
   return 0;
 }
 
-static int Reconstruct(const char *infile, const char *outfile, bool colortrafo, int threads, int device)
+static int Reconstruct(const char *infile, const char *outfile, bool colortrafo, bool upsample, int threads, int device)
 {
   FILE *in = fopen(infile, "rb");
   if (!in) { perror("failed to open the input file"); return 10; }
@@ -118,8 +136,9 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
       const unsigned width = itags->GetTagData(JPGTAG_IMAGE_WIDTH), height = itags->GetTagData(JPGTAG_IMAGE_HEIGHT);
       const unsigned depth = itags->GetTagData(JPGTAG_IMAGE_DEPTH), prec = itags->GetTagData(JPGTAG_IMAGE_PRECISION);
       const bool pfm = itags->GetTagData(JPGTAG_IMAGE_IS_FLOAT) != 0, convert = itags->GetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION) != 0;
-      if ((depth != 1 && depth != 3) || prec > 16 || (pfm && !convert)) {
-        fprintf(stderr, "only images with one or three components of up to 16 bits can be written as PNM/PFM by this front end\n");
+      const bool writepgx = (depth != 1 && depth != 3) || !upsample; // cmd/reconstruct.cpp:218-222
+      if (depth > 4 || prec > 16 || (pfm && (!convert || writepgx))) {
+        fprintf(stderr, "only images of up to four components of up to 16 bits (PNM/PGX), or JPEG XT profile C with output conversion (PFM), are written by this front end\n");
         ok = 0; rc = 5;
       } else {
         StripeBuffer sb;
@@ -127,9 +146,46 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
         sb.halffloat = pfm;
         sb.mem = (unsigned char *)malloc((size_t)width * 8 * depth * sb.bytes);
         sb.width = width; sb.height = height; sb.depth = depth;
+        sb.upsampling = upsample;
+        sb.pgx = writepgx;
+        memset(sb.pgxfiles, 0, sizeof(sb.pgxfiles));
         sb.target = fopen(outfile, "wb");
+        if (upsample) { // cmd/reconstruct.cpp:227-232: the subsampling factors are all implicitly 1 then
+          memset(subx, 1, sizeof(subx));
+          memset(suby, 1, sizeof(suby));
+        }
         if (!sb.mem || !sb.target) { perror("failed to open the output file"); ok = 0; rc = 10; }
-        else {
+        else if (writepgx) { // cmd/reconstruct.cpp:236-306
+          for (unsigned i = 0; i < depth && ok; i++) {
+            char headername[512], rawname[512];
+            snprintf(headername, sizeof(headername), "%s_%u.h", outfile, i);
+            snprintf(rawname, sizeof(rawname), "%s_%u.raw", outfile, i);
+            fprintf(sb.target, "%s\n", rawname);
+            FILE *hdr = fopen(headername, "wb");
+            if (hdr) {
+              fprintf(hdr, "PG ML +%u %u %u\n", prec, (width + subx[i] - 1) / subx[i], (height + suby[i] - 1) / suby[i]);
+              fclose(hdr);
+            }
+            sb.pgxfiles[i] = fopen(rawname, "wb");
+            if (!hdr || !sb.pgxfiles[i]) { perror("cannot create output file"); ok = 0; rc = 10; }
+          }
+          struct JPG_Hook bmhook(BitmapHook, &sb);
+          for (unsigned comp = 0; comp < depth && ok; comp++) {
+            const unsigned step = (unsigned)suby[comp] << 3;
+            for (unsigned y = 0; y < height && ok; y += step) {
+              const unsigned last = y + step < height ? y + step : height;
+              struct JPG_TagItem dtags[] = {JPG_PointerTag(JPGTAG_BIH_HOOK, &bmhook), JPG_ValueTag(JPGTAG_DECODER_MINY, y),
+                                            JPG_ValueTag(JPGTAG_DECODER_MAXY, last - 1), JPG_ValueTag(JPGTAG_DECODER_UPSAMPLE, upsample),
+                                            JPG_ValueTag(JPGTAG_MATRIX_LTRAFO, colortrafo ? JPGFLAG_MATRIX_COLORTRANSFORMATION_YCBCR
+                                                                                           : JPGFLAG_MATRIX_COLORTRANSFORMATION_NONE),
+                                            JPG_ValueTag(JPGTAG_DECODER_MINCOMPONENT, comp), JPG_ValueTag(JPGTAG_DECODER_MAXCOMPONENT, comp),
+                                            JPG_EndTag};
+              ok = jpeg->DisplayRectangle(dtags);
+            }
+          }
+          for (unsigned i = 0; i < depth; i++)
+            if (sb.pgxfiles[i]) fclose(sb.pgxfiles[i]);
+        } else {
           struct JPG_Hook bmhook(BitmapHook, &sb);
           // cmd/reconstruct.cpp:321-323
           fprintf(sb.target, "P%c\n%u %u\n%u\n", pfm ? (depth > 1 ? 'F' : 'f') : (depth > 1 ? '6' : '5'), width, height,
@@ -162,19 +218,20 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
 
 int main(int argc, char **argv)
 {
-  bool colortrafo = true;
+  bool colortrafo = true, upsample = true;
   int threads = 0, device = -1;
   while (argc > 3) {
     if (!strcmp(argv[1], "-c")) { colortrafo = false; argv++; argc--; }
+    else if (!strcmp(argv[1], "-U")) { upsample = false; argv++; argc--; }
     else if (!strcmp(argv[1], "-t") && argc > 4) { threads = atoi(argv[2]); argv += 2; argc -= 2; }
     else if (!strcmp(argv[1], "-d") && argc > 4) { device = atoi(argv[2]); argv += 2; argc -= 2; }
     else break;
   }
   if (argc != 3) {
-    fprintf(stderr, "usage: %s [-c] [-t threads] [-d device] source.jpg target.ppm\n"
+    fprintf(stderr, "usage: %s [-c] [-U] [-t threads] [-d device] source.jpg target.ppm\n"
                     "  reconstructs a Huffman sequential JPEG on an MI355X and writes a binary PNM,\n"
                     "  byte-identical to the output of the reference `jpeg source.jpg target.ppm`\n", argv[0]);
     return 5;
   }
-  return Reconstruct(argv[1], argv[2], colortrafo, threads, device);
+  return Reconstruct(argv[1], argv[2], colortrafo, upsample, threads, device);
 }

@@ -180,9 +180,13 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
     default: break;
     }
   }
-  if (!upsample)
-    return p->fail(JPGERR_NOT_IMPLEMENTED, "reconstruction without upsampling (JPGTAG_DECODER_UPSAMPLE = false) is not on the accelerated path");
   if (minx > maxx || miny > maxy || c0 > c1) return JPG_TRUE; // empty request: nothing to do
+  if (!upsample) {
+    // codestream/rectanglerequest.cpp:157-159, control/bitmapctrl.cpp:273-294
+    ctrafo = false;
+    if (c0 != c1)
+      return p->fail(JPGERR_INVALID_PARAMETER, "if upsampling is disabled, components can only be reconstructed one by one");
+  }
   if (!bmh) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no bitmap hook (JPGTAG_BIH_HOOK) specified");
 
   // REQUEST: one hook call per component with the tag layout of interface/bitmaphook.cpp:130-161
@@ -242,11 +246,15 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
     if (m < maxmcu) maxmcu = m;
   }
   int rc = MIJPEG_OK;
-  const JPG_LONG ylimit = (maxmcu >= 0x0fffffff) ? maxy : (maxmcu + 1) * 8 - 1;
+  // the block rows the bitmap covers are counted on the grid that is reconstructed: the canvas, or the component's own
+  const JPG_LONG lines_per_row = upsample ? 1 : f.suby[c0];
+  const JPG_LONG ylimit = (maxmcu >= 0x0fffffff / lines_per_row) ? maxy : (maxmcu + 1) * 8 * lines_per_row - 1;
   const JPG_LONG y1 = maxy < ylimit ? maxy : ylimit;
   if (maxmcu >= 0 && y1 >= miny)
     rc = mijpeg_reconstruct_rect(p->dec, minx, miny, maxx, y1, c0, c1,
-                                 (ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM) | (device_bitmaps ? MIJPEG_FLAG_DEVICE_OUTPUT : 0), dst, bpp, bpr);
+                                 (ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM) | (device_bitmaps ? MIJPEG_FLAG_DEVICE_OUTPUT : 0) |
+                                     (upsample ? 0 : MIJPEG_FLAG_NO_UPSAMPLING),
+                                 dst, bpp, bpr);
   // RELEASE is always delivered, also after a failure, so the client can let go of its buffers
   JPG_LONG hookerr = 0;
   for (int c = c0; c <= c1; c++) {

@@ -103,6 +103,10 @@ case("big_4k_420_q85_dri8", 3840, 2160, 1234, "pil", quality=85, sub="420", dri=
 case("big_8k_420_q85_dri8", 7680, 4320, 1234, "pil", quality=85, sub="420", dri=8, big=True)
 
 
+UNSAMPLED = ["ref_80x48_420", "ref_97x61_3x3", "ref_23x50_lumasub", "ref_97x61_mixed", "pil_131x77_422", "pil_70x40_gray",
+             "p12_120x90_420_dri3", "refprog_97x61_420"]
+
+
 def synth_p12(w, h, seed):
     img = synth.synth_image(w, h, seed).astype(np.uint16) * 16
     return (img + (np.arange(w, dtype=np.uint16) % 16)[None, :, None]).astype(np.uint16)
@@ -201,6 +205,18 @@ def main():
                 ent["pixels_file"] = c["name"] + ".bin"
         manifest[c["name"]] = ent
         print(c["name"], len(data), ent["pixels_sha256"][:12])
+    # reference `jpeg -U` (no upsampling: every component on its own grid, PGX raw files; cmd/reconstruct.cpp:208-306)
+    import subprocess
+    import tempfile
+    for name in UNSAMPLED:
+        with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+            with open(os.path.join(OUT, name + ".jpg"), "rb") as f:
+                open(d + "/in.jpg", "wb").write(f.read())
+            subprocess.run([O.REF_BIN, "-U", d + "/in.jpg", d + "/out"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            n = manifest[name]["channels"]
+            manifest[name]["unsampled"] = [dict(header=open(d + "/out_%d.h" % k).read(), sha256=sha(open(d + "/out_%d.raw" % k, "rb").read()))
+                                           for k in range(n)]
+        print(name, "-U", [u["header"].strip() for u in manifest[name]["unsampled"]])
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

@@ -528,3 +528,63 @@ def test_device_bitmaps_16bit_samples(dec):
     buf = torch.zeros((H, W, C_), dtype=torch.int16, device="cuda")
     dec.reconstruct_rect_device(0, 0, W - 1, H - 1, [buf.data_ptr() + 2 * c for c in range(C_)], [2 * C_] * C_, [2 * W * C_] * C_)
     assert np.array_equal(buf.cpu().numpy().view(np.uint16), exp)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# JPGTAG_DECODER_UPSAMPLE = false / CLI -U, and PGX output for images with neither one nor three components
+# ---------------------------------------------------------------------------------------------------------------
+UNSAMPLED_CASES = sorted(k for k, v in MANIFEST.items() if "unsampled" in v)
+
+
+@pytest.mark.parametrize("name", UNSAMPLED_CASES)
+def test_cli_without_upsampling_writes_the_references_pgx(tmp_path, name):
+    import os
+    import subprocess
+
+    from conftest import GOLDEN_DIR, ROOT
+
+    exe = os.path.join(ROOT, "libjpeg_amd", "bin", "jpeg")
+    out = tmp_path / "out"
+    r = subprocess.run([exe, "-U", os.path.join(GOLDEN_DIR, name + ".jpg"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = MANIFEST[name]["unsampled"]
+    assert out.read_text().split() == ["%s_%d.raw" % (out, k) for k in range(len(want))]
+    for k, u in enumerate(want):
+        assert (tmp_path / ("out_%d.h" % k)).read_text() == u["header"]
+        assert hashlib.sha256((tmp_path / ("out_%d.raw" % k)).read_bytes()).hexdigest() == u["sha256"], (name, k)
+
+
+@pytest.mark.parametrize("w,h,sub", [(333, 111, "420"), (64, 64, "444"), (129, 257, "422")])
+def test_unsampled_components_vs_oracle(dec, oracle, w, h, sub):
+    """Without upsampling a component is its IDCT output, rounded and clamped: (s + 8) >> 4 (identity transformation)."""
+    data = synth.synth_jpeg(w, h, 7, 80, sub, 3)
+    f = dec.read(data)
+    info, planes = oracle.decode_coefficients(data)
+    for c in range(3):
+        samples = oracle.idct_plane(planes[c].reshape(info.bh[c], info.bw[c], 64), np.array(info.quant[info.tq[c]]), 8)
+        exp = np.clip((samples + 8) >> 4, 0, 255).astype(np.uint8)[: info.ch[c], : info.cw[c]]
+        assert np.array_equal(dec.reconstruct_unsampled(c), exp), c
+    # a host rectangle of the upsampled picture afterwards: the cached frame is replaced, not mixed up
+    assert np.array_equal(dec.reconstruct(), oracle.decode(data))
+    with pytest.raises(api.MijpegError):  # components only one by one
+        dst = (api.C.c_void_p * 4)()
+        z = (api.C.c_int32 * 4)()
+        dec._check(api.lib().mijpeg_reconstruct_rect(dec._h, 0, 0, w - 1, h - 1, 0, 2, api.FLAG_NO_UPSAMPLING, dst, z, z))
+
+
+def test_cli_cmyk_writes_pgx_planes(tmp_path):
+    import os
+    import subprocess
+
+    from conftest import GOLDEN_DIR, ROOT
+
+    name = "pil_90x60_cmyk"
+    exp = golden_pixels(name)
+    exe = os.path.join(ROOT, "libjpeg_amd", "bin", "jpeg")
+    out = tmp_path / "out"
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".jpg"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for k in range(4):
+        assert (tmp_path / ("out_%d.h" % k)).read_text() == "PG ML +8 90 60\n"
+        got = np.frombuffer((tmp_path / ("out_%d.raw" % k)).read_bytes(), np.uint8).reshape(60, 90)
+        assert np.array_equal(got, exp[..., k]), k
