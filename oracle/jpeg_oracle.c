@@ -60,7 +60,7 @@ typedef struct {
   size_t len, cap;
 } oj_box;
 
-#define OJ_MAX_BOXES 32
+#define OJ_MAX_BOXES 64
 typedef struct {
   const uint8_t *data;
   size_t len;
@@ -70,6 +70,7 @@ typedef struct {
   int have_frame;
   int need_dnl; /* SOF carried zero lines */
   int progressive; /* SOF2 */
+  int hidden;      /* JPEG XT: bits of every coefficient that travel in hidden refinement scans (RSPC box) */
   oj_box *boxes; /* optional: where APP11 boxes are collected (OJ_MAX_BOXES entries) */
   int nboxes;
 } oj_parser;
@@ -378,10 +379,25 @@ static int decode_block_refine(oj_bits *b, const oj_huff *ac, int32_t *block, in
 /* One scan: codestream/sequentialscan.cpp:381-428 (ParseMCU) driven row by row, restart handling as
  * in codestream/entropyparser.hpp:147-160 / entropyparser.cpp:117-135 (happy path only: a missing or
  * wrong RSTn is reported as OJ_ERR_MALFORMED instead of being resynchronised). */
+static int decode_scan_ex(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *ecs,
+                          const uint8_t *end, int32_t *const planes[OJ_MAX_COMP],
+                          const uint8_t **next, int hidden_scan);
+
 static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *ecs,
                        const uint8_t *end, int32_t *const planes[OJ_MAX_COMP],
                        const uint8_t **next)
 {
+  return decode_scan_ex(ps, sos, n, ecs, end, planes, next, 0);
+}
+
+/* hidden_scan: the scan comes from a FINE / RFIN box (marker/scan.cpp:899-980): always a successive approximation
+ * refinement of one bit, its Al counts from the true LSB.  Visible scans of a frame with hidden bits address the bits
+ * above them: Al + hidden (marker/scan.cpp:353-437). */
+static int decode_scan_ex(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *ecs,
+                          const uint8_t *end, int32_t *const planes[OJ_MAX_COMP],
+                          const uint8_t **next, int hidden_scan)
+{
+  const int progressive = ps->progressive || hidden_scan || ps->hidden > 0;
   const oj_info *f = ps->info;
   int ns = sos[0], ci[OJ_MAX_COMP], td[OJ_MAX_COMP], ta[OJ_MAX_COMP], i, c;
   int32_t pred[OJ_MAX_COMP] = {0, 0, 0, 0};
@@ -397,11 +413,13 @@ static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *
     if (td[i] > 3 || ta[i] > 3) return OJ_ERR_MALFORMED;
   }
   ss = sos[1 + 2 * ns]; se = sos[2 + 2 * ns]; ah = sos[3 + 2 * ns] >> 4; al = sos[3 + 2 * ns] & 15;
-  if (!ps->progressive) {
+  if (!ps->progressive && !hidden_scan) {
     if (ss != 0 || se != 63 || ah != 0 || al != 0) return OJ_ERR_MALFORMED;
   } else if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) {
     return OJ_ERR_MALFORMED; /* T.81 G.1.1.1.1 */
   }
+  if (hidden_scan) { if (ah != al + 1) return OJ_ERR_MALFORMED; } /* "hidden refinement must refine by one bit per scan" */
+  else al += ps->hidden;
   for (i = 0; i < ns; i++) {
     if ((ss == 0 && ah == 0 && !ps->dc[td[i]].defined) || (se > 0 && !ps->ac[ta[i]].defined)) return OJ_ERR_MALFORMED;
   }
@@ -438,7 +456,7 @@ static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *
             int X = mx * w + bx, Y = my * h + by, rc;
             int32_t *blk = (X < f->bw[c] && Y < f->bh[c]) ? planes[c] + ((size_t)Y * f->bw[c] + X) * 64
                                                           : dummy;
-            if (!ps->progressive) rc = decode_block(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk);
+            if (!progressive) rc = decode_block(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk);
             else if (ah == 0) rc = decode_block_first(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk, ss, se, al, &skip[i]);
             else rc = decode_block_refine(&b, &ps->ac[ta[i]], blk, ss, se, al, &skip[i]);
             if (rc) return rc;
@@ -616,12 +634,60 @@ static void idct_1d(const int32_t s[8], int32_t o[8])
   o[3] = add32(tmp13, tmp0); o[4] = sub32(tmp13, tmp0);
 }
 
+/* The same butterfly for IDCT<4,QUAD>: T = 64 bits (dct/idct.cpp with FIXED = QUAD).  Nothing wraps, with one
+ * exception: the second pass forms `(dptr[0 << 3] + dptr[4 << 3]) << FIX_BITS` (idct.cpp:297-298) from LONG operands,
+ * so this sum and shift are 32-bit before they are widened (second_pass). */
+static void idct_1d_quad(const int64_t s[8], int64_t o[8], int second_pass)
+{
+  int64_t z1 = (s[2] + s[6]) * FIX9(0.541196100);
+  int64_t tmp2 = z1 + s[6] * -FIX9(1.847759065);
+  int64_t tmp3 = z1 + s[2] * FIX9(0.765366865);
+  int64_t tmp0 = second_pass ? (int64_t)shl32(add32((int32_t)s[0], (int32_t)s[4]), 9) : (s[0] + s[4]) * 512;
+  int64_t tmp1 = second_pass ? (int64_t)shl32(sub32((int32_t)s[0], (int32_t)s[4]), 9) : (s[0] - s[4]) * 512;
+  int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  int64_t t0 = s[7], t1 = s[5], t2 = s[3], t3 = s[1];
+  int64_t tz1 = t0 + t3, tz2 = t1 + t2, tz3 = t0 + t2, tz4 = t1 + t3;
+  int64_t z5 = (tz3 + tz4) * FIX9(1.175875602), z2, z3, z4;
+  tmp0 = t0 * FIX9(0.298631336);
+  tmp1 = t1 * FIX9(2.053119869);
+  tmp2 = t2 * FIX9(3.072711026);
+  tmp3 = t3 * FIX9(1.501321110);
+  z1 = tz1 * -FIX9(0.899976223);
+  z2 = tz2 * -FIX9(2.562915447);
+  z3 = tz3 * -FIX9(1.961570560) + z5;
+  z4 = tz4 * -FIX9(0.390180644) + z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  o[0] = tmp10 + tmp3; o[7] = tmp10 - tmp3;
+  o[1] = tmp11 + tmp2; o[6] = tmp11 - tmp2;
+  o[2] = tmp12 + tmp1; o[5] = tmp12 - tmp1;
+  o[3] = tmp13 + tmp0; o[4] = tmp13 - tmp0;
+}
+
 void oj_idct_block(int32_t out[64], const int32_t coef[64], const uint16_t quant[64], int precision)
 {
   int32_t tmp[64];
   int r, c, k;
   int32_t dcoffset;
   if (!coef) { memset(out, 0, 64 * sizeof(int32_t)); return; }
+  if (precision > 12) {
+    /* codestream/tables.cpp:1876-1891: IDCT<4,QUAD>.  The dequantising products and the DC offset are still LONG
+     * expressions (`source[k] * qnt[k] + dcoffset`, idct.cpp:238-259) and the pass results are stored as LONG. */
+    dcoffset = (int32_t)(1L << (precision - 1)) << (4 + 3);
+    for (r = 0; r < 8; r++) {
+      int64_t s[8], o[8];
+      for (k = 0; k < 8; k++) s[k] = mul32(coef[r * 8 + k], (int32_t)quant[r * 8 + k] << 4);
+      if (r == 0) s[0] = add32((int32_t)s[0], dcoffset);
+      idct_1d_quad(s, o, 0);
+      for (k = 0; k < 8; k++) tmp[r * 8 + k] = w32((o[k] + 256) >> 9);
+    }
+    for (c = 0; c < 8; c++) {
+      int64_t s[8], o[8];
+      for (k = 0; k < 8; k++) s[k] = tmp[k * 8 + c];
+      idct_1d_quad(s, o, 1);
+      for (k = 0; k < 8; k++) out[k * 8 + c] = w32((o[k] + 2048) >> 12);
+    }
+    return;
+  }
   /* caller passes dcoffset = 1 << (P-1) (blockbitmaprequester.cpp:1048); shifted by preshift + 3 */
   dcoffset = (int32_t)(1L << (precision - 1)) << (4 + 3);
   for (r = 0; r < 8; r++) {
@@ -929,6 +995,40 @@ int oj_reconstruct16(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint1
 
 static void free_boxes(oj_box *boxes, int n) { int i; for (i = 0; i < n; i++) free(boxes[i].data); }
 
+/* Hidden refinement scans: box number `en` = 0, 1, ... of `type` (FINE for the legacy frame, RFIN for the residual
+ * one) holds tables and one scan; they are read in this order once the visible scans are through
+ * (marker/frame.cpp:805-818, 1063-1071). */
+static int decode_hidden_scans(oj_parser *ps, const oj_box *boxes, int nboxes, uint32_t type, int32_t *const planes[OJ_MAX_COMP])
+{
+  int en;
+  for (en = 0;; en++) {
+    const oj_box *bx = NULL;
+    const uint8_t *p, *end, *next;
+    int b, rc, done = 0;
+    for (b = 0; b < nboxes; b++) if (boxes[b].type == type && boxes[b].en == en) bx = &boxes[b];
+    if (!bx) return OJ_OK;
+    p = bx->data; end = bx->data + bx->len;
+    while (!done) {
+      int m, n;
+      if (p + 4 > end || p[0] != 0xff) return OJ_ERR_MALFORMED;
+      m = p[1]; n = rd16(p + 2);
+      if (n < 2 || p + 2 + n > end) return OJ_ERR_MALFORMED;
+      switch (m) {
+      case 0xc4: rc = parse_dht(ps, p + 4, n - 2); if (rc) return rc; break;
+      case 0xdb: rc = parse_dqt(ps, p + 4, n - 2); if (rc) return rc; break;
+      case 0xdd: if (n < 4) return OJ_ERR_MALFORMED; ps->restart_interval = rd16(p + 4); break;
+      case 0xda:
+        rc = decode_scan_ex(ps, p + 4, n - 2, p + 2 + n, end, planes, &next, 1);
+        if (rc) return rc;
+        done = 1;
+        break;
+      default: break;
+      }
+      p += 2 + n;
+    }
+  }
+}
+
 int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float)
 {
   oj_box boxes[OJ_MAX_BOXES];
@@ -937,6 +1037,8 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   oj_xt xt;
   int32_t *planes[OJ_MAX_COMP] = {0, 0, 0, 0}, *rplanes[OJ_MAX_COMP] = {0, 0, 0, 0};
   int32_t *tables[16];
+  int tabsize[16] = {0};
+  int hidden_l = 0, hidden_r = 0; /* RSPC: bits of the legacy / residual coefficients in hidden refinement scans */
   int32_t *identity = NULL;
   const oj_box *spec = NULL, *resi = NULL;
   int ltrafo = 255, rtrafo = 255, ctrafo = 255, lidx[4] = {255, 255, 255, 255}, have_lpts = 0;
@@ -950,14 +1052,14 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   for (b = 0; b < ps.nboxes; b++) {
     if (boxes[b].type == BOXID('S', 'P', 'E', 'C')) spec = &boxes[b];
     if (boxes[b].type == BOXID('R', 'E', 'S', 'I')) resi = &boxes[b];
-    if (boxes[b].type == BOXID('F', 'I', 'N', 'E') || boxes[b].type == BOXID('R', 'F', 'I', 'N')) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     if (boxes[b].type == BOXID('T', 'O', 'N', 'E')) {
-      /* boxes/inversetonemappingbox.cpp: index/residual-bits byte, then 2^n 16-bit entries */
+      /* boxes/inversetonemappingbox.cpp: index/residual-bits byte, then 2^n 16-bit entries (n = 8 + hidden bits) */
       const oj_box *t = &boxes[b];
       int idx, n, i;
       if (t->len < 1 + 512 || !(t->len & 1)) { rc = OJ_ERR_MALFORMED; goto out; }
       idx = t->data[0] >> 4; n = (int)((t->len - 1) >> 1);
-      if ((t->data[0] & 15) > 8 || n != 256) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+      if ((t->data[0] & 15) > 8 || n < 256 || n > 4096 || (n & (n - 1))) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+      tabsize[idx] = n;
       tables[idx] = (int32_t *)malloc((size_t)n * sizeof(int32_t));
       if (!tables[idx]) { rc = OJ_ERR_NOMEM; goto out; }
       for (i = 0; i < n; i++) tables[idx][i] = rd16(t->data + 1 + 2 * i);
@@ -974,7 +1076,10 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
     else if (t == BOXID('C', 'T', 'R', 'F')) ctrafo = pl[0] >> 4;
     else if (t == BOXID('L', 'P', 'T', 'S')) { have_lpts = 1; lidx[0] = pl[0] >> 4; lidx[1] = pl[0] & 15; lidx[2] = pl[1] >> 4; lidx[3] = pl[1] & 15; }
     else if (t == BOXID('O', 'C', 'O', 'N')) ocon = pl[0];
-    else if (t == BOXID('R', 'S', 'P', 'C')) { if (pl[0]) { rc = OJ_ERR_UNSUPPORTED; goto out; } }
+    else if (t == BOXID('R', 'S', 'P', 'C')) { /* boxes/refinementspecbox.cpp:57-83 */
+      hidden_l = pl[0] >> 4; hidden_r = pl[0] & 15;
+      if (hidden_l > 4 || hidden_r > 4) { rc = OJ_ERR_MALFORMED; goto out; }
+    }
     else if (t == BOXID('L', 'D', 'C', 'T') || t == BOXID('R', 'D', 'C', 'T')) { if ((pl[0] >> 4) != 0 && (pl[0] >> 4) != 2) { rc = OJ_ERR_UNSUPPORTED; goto out; } }
     else { rc = OJ_ERR_UNSUPPORTED; goto out; } /* Q/R/R2/S tables, D/S transformations, ...: outside the subset */
     j += l;
@@ -992,15 +1097,17 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   if (!xt.clamp || xt.outmax != 65535) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   xt.ltrafo_ycbcr = ltrafo == 2; xt.rtrafo_ycbcr = rtrafo == 2;
   for (c = 0; c < 3; c++) {
+    const int entries = 256 << hidden_l; /* the L table is indexed with 8 + hidden bits (codestream/tables.cpp:549) */
     if (have_lpts) {
       if (!tables[lidx[c]]) { rc = OJ_ERR_MALFORMED; goto out; } /* "the L lookup table specified in the codestream does not exist" */
+      if (tabsize[lidx[c]] != entries) { rc = OJ_ERR_MALFORMED; goto out; }
       xt.ltable[c] = tables[lidx[c]];
-    } else { /* identity, e = 1: floor((2^16 - 1) * (i / (2^8 - 1)) + 0.5) = 257 i */
+    } else { /* identity, e = 1: floor((2^16 - 1) * (i / (2^n - 1)) + 0.5), = 257 i for n = 8 */
       if (!identity) {
         int i;
-        identity = (int32_t *)malloc(256 * sizeof(int32_t));
+        identity = (int32_t *)malloc((size_t)entries * sizeof(int32_t));
         if (!identity) { rc = OJ_ERR_NOMEM; goto out; }
-        for (i = 0; i < 256; i++) identity[i] = 257 * i;
+        for (i = 0; i < entries; i++) identity[i] = (int32_t)floor(65535.0 * ((double)i / (double)(entries - 1)) + 0.5);
       }
       xt.ltable[c] = identity;
     }
@@ -1009,17 +1116,33 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   rc = oj_read_info(resi->data, resi->len, &rinfo);
   if (rc) goto out;
   if (rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp) { rc = OJ_ERR_MALFORMED; goto out; }
-  if (rinfo.precision + 4 > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  if (rinfo.precision + hidden_r > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   info->ycbcr = xt.ltrafo_ycbcr;
   for (c = 0; c < 3; c++) {
     planes[c] = (int32_t *)malloc((size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
     rplanes[c] = (int32_t *)malloc((size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
     if (!planes[c] || !rplanes[c]) { rc = OJ_ERR_NOMEM; goto out; }
   }
-  rc = oj_decode_coefficients(data, len, info, planes);
-  if (rc) goto out;
-  rc = oj_decode_coefficients(resi->data, resi->len, &rinfo, rplanes);
-  if (rc) goto out;
+  {
+    /* visible scans with their bits moved up by the hidden ones, then the hidden refinement scans; from here on both
+     * frames simply have precision + hidden bits (Frame::HiddenPrecisionOf, marker/frame.cpp:368-373) */
+    oj_parser ls, rs;
+    oj_info ltmp, rtmp;
+    memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
+    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
+    rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r;
+    for (c = 0; c < 3; c++) {
+      memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
+      memset(rplanes[c], 0, (size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
+    }
+    rc = walk(&ls, planes);
+    if (!rc) rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes);
+    if (!rc) rc = walk(&rs, rplanes);
+    if (!rc) rc = decode_hidden_scans(&rs, boxes, ps.nboxes, BOXID('R', 'F', 'I', 'N'), rplanes);
+    if (rc) goto out;
+    info->precision += hidden_l;
+    rinfo.precision += hidden_r;
+  }
   xt.rinfo = &rinfo; xt.rplanes = rplanes;
   *pixels = (uint16_t *)malloc((size_t)info->width * info->height * 3 * sizeof(uint16_t));
   if (!*pixels) { rc = OJ_ERR_NOMEM; goto out; }

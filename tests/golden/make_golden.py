@@ -94,6 +94,14 @@ case("xt_75x45_444", 75, 45, 6, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", 
 case("xt_129x71_420", 129, 71, 7, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-s", "1x1,2x2,2x2"])
 case("xt_200x120_420_q60", 200, 120, 8, "xt", args=["-r", "-q", "60", "-Q", "70", "-h", "-profile", "c", "-r12", "-s", "1x1,2x2,2x2"])
 case("xt_33x17_422", 33, 17, 9, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-s", "1x1,2x1,2x1"])
+# ... with hidden refinement scans: -R n = n low bits of the legacy coefficients in FINE boxes (L table of 2^(8+n) entries),
+# -rR n = n low bits of the residual coefficients in RFIN boxes (BASELINE config 5's "-rR 4" variant; 12 + 4 bits makes the
+# reference's IDCT<4,QUAD> wrap in its second pass, which is part of what is pinned here)
+case("xt_64x48_444_R4", 64, 48, 5, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-R", "4"])
+case("xt_75x45_444_rR4", 75, 45, 6, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-rR", "4"])
+case("xt_129x71_420_R2_rR3_dri3", 129, 71, 7, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-R", "2", "-rR", "3",
+                                                            "-s", "1x1,2x2,2x2", "-z", "3"])
+case("xt_64x48_444_R1_rR1", 64, 48, 8, "xt", args=["-r", "-q", "70", "-Q", "80", "-h", "-profile", "c", "-r12", "-R", "1", "-rR", "1"])
 # plain 12-bit extended sequential (SOF1, P = 12): what the residual codestream of profile C is made of
 case("p12_64x48_444", 64, 48, 30, "p12", args=["-q", "85"])
 case("p12_120x90_420_dri3", 120, 90, 31, "p12", args=["-q", "85", "-s", "1x1,2x2,2x2", "-z", "3"])
