@@ -90,11 +90,17 @@ typedef struct mijpeg_info {
  * what ColorTransformerFactory::InstallIntegerParameters (colortrafo/colortransformerfactory.cpp:300-594)
  * installs into YCbCrTrafo<UWORD,3,Residual|Extended|ClampFlag|Float,...>.  Supported subset: explicit (TONE box)
  * or identity L tables, identity Q and R2 tables, standard YCbCr / identity L and R transformations, identity C
- * transformation, residual codestream = Huffman sequential 12 bit, no refinement scans. */
+ * transformation, residual codestream = Huffman sequential 12 bit, hidden refinement scans (-R / -rR of the reference
+ * encoder: FINE / RFIN boxes, up to four bits each). */
 typedef struct mijpeg_xt_params {
   mijpeg_info residual;      /* residual codestream: geometry and quantiser tables; its coef_offset[] are offsets
                                 into the SAME per-frame coefficient buffer, behind the legacy planes            */
-  int32_t ltable[3][256];    /* L lookup tables per component: 8 bit in, 16 bit out                             */
+  int32_t ltable[3][4096];   /* L lookup tables per component: 8 + hidden_bits in, 16 bit out (ltable_entries used)  */
+  int32_t ltable_entries;    /* 256 << hidden_bits                                                               */
+  int32_t hidden_bits;       /* RSPC: low bits of the legacy coefficients that arrived in hidden refinement scans
+                                (FINE boxes); the legacy frame reconstructs at precision 8 + hidden_bits         */
+  int32_t residual_hidden_bits; /* ... of the residual coefficients (RFIN boxes): precision 12 + residual_hidden_bits */
+  int32_t residual_wide;     /* 1: the residual planes hold int32 coefficients (two int16 slots each)           */
   int32_t ltrafo_ycbcr;      /* L transformation: 1 = YCbCr -> RGB, 0 = identity                                */
   int32_t rtrafo_ycbcr;      /* R transformation                                                                */
   int32_t out_max;           /* 2^(8 + extra range bits) - 1 = 65535                                            */

@@ -41,7 +41,8 @@ class MijpegInfo(C.Structure):
 
 class MijpegXtParams(C.Structure):
     _fields_ = [
-        ("residual", MijpegInfo), ("ltable", (C.c_int32 * 256) * 3), ("ltrafo_ycbcr", C.c_int32), ("rtrafo_ycbcr", C.c_int32),
+        ("residual", MijpegInfo), ("ltable", (C.c_int32 * 4096) * 3), ("ltable_entries", C.c_int32), ("hidden_bits", C.c_int32),
+        ("residual_hidden_bits", C.c_int32), ("residual_wide", C.c_int32), ("ltrafo_ycbcr", C.c_int32), ("rtrafo_ycbcr", C.c_int32),
         ("out_max", C.c_int32), ("out_shift", C.c_int32), ("is_float", C.c_int32), ("clamp", C.c_int32),
     ]
 

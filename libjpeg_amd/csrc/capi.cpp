@@ -445,11 +445,14 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
                                                                                                  : "idct_planes_kernel+upsample_color_kernel";
 }
 
+static const size_t LUT_BYTES = 3 * 4096 * sizeof(int32_t);
+
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
 {
   if (!b || use_fused420(b) || use_fused444(b)) return 0;
-  // [4 KB: L lookup tables (JPEG XT)] [per frame: int32 sample planes, same layout as the coefficient planes]
-  return 4096 + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames;
+  // [LUT_BYTES: L lookup tables (JPEG XT, up to 3 x 4096 entries)] [per frame: int32 sample planes, one sample per
+  // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients]
+  return LUT_BYTES + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames;
 }
 
 int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
@@ -495,7 +498,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     memset(&a, 0, sizeof(a));
     a.coef = b->coef_dev;
     a.coef_frame_stride = b->coef_frame_stride;
-    a.samples = (int32_t *)((char *)b->workspace + 4096);
+    a.samples = (int32_t *)((char *)b->workspace + LUT_BYTES);
     a.sample_frame_stride = f.coef_count;
     a.out = b->out_dev;
     a.out_frame_stride = b->out_frame_stride;
@@ -509,22 +512,35 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.sample_bytes = f.precision > 8 || f.xt ? 2 : 1;
     a.maxval = (1 << f.precision) - 1;
     a.dcshift = (1 << (f.precision - 1)) << 4;
-    auto plane = [&](int p, const mijpeg_info &g, int c) {
+    int64_t sample_off = 0;
+    auto plane = [&](int p, const mijpeg_info &g, int c, int precision) {
       a.coef_off[p] = g.coef_offset[c];
-      a.sample_off[p] = g.coef_offset[c];
+      a.sample_off[p] = sample_off;
+      sample_off += (int64_t)g.blocks_w[c] * g.blocks_h[c] * 64;
       a.bw[p] = g.blocks_w[c];
       a.bh[p] = g.blocks_h[c];
       a.subx[p] = g.subx[c];
       a.suby[p] = g.suby[c];
       a.cw[p] = (g.width + g.subx[c] - 1) / g.subx[c];
       a.ch[p] = (g.height + g.suby[c] - 1) / g.suby[c];
-      a.dcoff[p] = (1 << (g.precision - 1)) << 7;
+      a.dcoff[p] = (1 << (precision - 1)) << 7;
       for (int i = 0; i < 64; i++) a.q[p][i] = (int32_t)g.quant[g.quant_index[c]][i] << 4;
     };
-    for (int c = 0; c < f.components; c++) plane(c, f, c);
+    // JPEG XT frames reconstruct at their precision plus the bits that travelled in hidden refinement scans
+    // (Frame::HiddenPrecisionOf, marker/frame.cpp:368-373)
+    const int lprec = f.precision + (f.xt ? b->xt->hidden_bits : 0);
+    for (int c = 0; c < f.components; c++) plane(c, f, c, lprec);
+    a.maxval = (1 << lprec) - 1;
+    a.dcshift = (1 << (lprec - 1)) << 4;
     if (f.xt) {
       const mijpeg_xt_params &x = *b->xt;
-      for (int c = 0; c < 3; c++) plane(3 + c, x.residual, c);
+      const int rprec = x.residual.precision + x.residual_hidden_bits;
+      if (x.hidden_bits < 0 || x.hidden_bits > 4 || x.residual_hidden_bits < 0 || x.residual_hidden_bits > 4 || rprec > 16 ||
+          x.ltable_entries != (256 << x.hidden_bits) || (x.residual_wide != 0) != (x.residual_hidden_bits > 0))
+        return MIJPEG_ERR_INVALID_PARAMETER;
+      for (int c = 0; c < 3; c++) plane(3 + c, x.residual, c, rprec);
+      if (x.residual_wide) { a.wide_first = 3; a.wide_count = 3; }
+      a.ltable_entries = x.ltable_entries;
       a.nplanes = 6;
       a.xt = 1;
       a.ycbcr = x.ltrafo_ycbcr; // the L transformation of the merging specification (the -c switch does not apply to XT here)
@@ -532,11 +548,14 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
       a.out_shift = x.out_shift;
       a.out_max = x.out_max;
       a.is_float = x.is_float;
-      a.rprecision = x.residual.precision;
-      a.legacy32 = f.precision == 8 && f.range_max[0] < 16384 && f.range_max[1] < 16384 && f.range_max[2] < 16384 &&
+      a.rprecision = rprec;
+      a.legacy32 = lprec == 8 && f.range_max[0] < 16384 && f.range_max[1] < 16384 && f.range_max[2] < 16384 &&
                    !(b->flags & MIJPEG_FLAG_FORCE_SAFE);
       a.ltable = (const int32_t *)b->workspace;
-      if (hipMemcpyAsync(b->workspace, x.ltable, sizeof(x.ltable), hipMemcpyHostToDevice, s) != hipSuccess) return MIJPEG_ERR_DEVICE;
+      for (int c = 0; c < 3; c++)
+        if (hipMemcpyAsync((int32_t *)b->workspace + (size_t)c * x.ltable_entries, x.ltable[c], (size_t)x.ltable_entries * sizeof(int32_t),
+                           hipMemcpyHostToDevice, s) != hipSuccess)
+          return MIJPEG_ERR_DEVICE;
     }
     rc = launch_generic(a, fast, s);
   }

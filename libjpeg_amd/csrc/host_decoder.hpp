@@ -51,6 +51,7 @@ struct Scan {
   int mcus_x = 0, mcus_y = 0; // MCU grid of THIS scan
   size_t ecs_begin = 0, ecs_end = 0; // entropy coded data [begin, end) in the input
   std::vector<size_t> interval_begin; // byte offset of every restart interval (first = ecs_begin)
+  const uint8_t *base = nullptr;      // stream the offsets refer to; null = the decoder's input (hidden scans live in boxes)
 };
 
 struct StreamError {
@@ -110,7 +111,13 @@ private:
   std::vector<XtBox> boxes_;
   HostDecoder *residual_ = nullptr;
   bool nested_ = false; // this object decodes a residual codestream
+  int hidden_ = 0;      // JPEG XT: low bits of every coefficient that arrive in hidden refinement scans
+  bool parsing_hidden_ = false;
+  int64_t plane_offset_[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0}; // component planes inside this frame's own store
   int finish_xt(bool header_only);
+  int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
+  int parse_dht(const uint8_t *q, int len);
+  template <class T> int decode_t(T *coef, int threads, const std::function<void(int, int)> &on_rows_done);
   int fail(int code, const char *msg);
   int parse_sof(const uint8_t *p, int n);
   int frame_geometry();

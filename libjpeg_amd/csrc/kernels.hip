@@ -699,6 +699,7 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   const int nblocks = a.bw[comp] * a.bh[comp];
   const int first = (blockIdx.x * 4 + wave) * 64;
   if (first >= nblocks) return;
+  if (comp >= a.wide_first && comp < a.wide_first + a.wide_count) return; // idct_planes_wide_kernel's
   const int16_t *__restrict__ plane = a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp];
   u32x4 rows[8];
   fetch_blocks(rows, stage_all[wave], lane, [&](int m) -> const u32x4 * {
@@ -717,6 +718,71 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
     i32x4 *d = reinterpret_cast<i32x4 *>(dst + (int64_t)r * pitch);
     d[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
     d[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
+  }
+}
+
+// ==============================================================================================
+// generic path, kernel 1w: planes of frames whose precision (with hidden bits) exceeds 12 -- the residual frame of
+// JPEG XT streams written with -rR n.  The reference transforms them with IDCT<4,QUAD> (codestream/tables.cpp:1876-
+// 1891): 64-bit butterflies, while the dequantising products, the DC offset and the stored pass results stay LONG
+// (dct/idct.cpp:238-259) -- and so does `(dptr[0 << 3] + dptr[4 << 3]) << FIX_BITS` in the second pass (:297-298),
+// which wraps at 12 + 4 bits.  Coefficients are int32 (12 + 4 bits do not fit the 16-bit store).  One lane per block;
+// this path is about correctness, not speed.
+// ==============================================================================================
+__device__ __forceinline__ void idct_1d_quad(const long long (&s)[8], long long (&o)[8], bool second_pass)
+{
+  const long long z1 = (s[2] + s[6]) * FIX9(0.541196100);
+  const long long tmp2 = z1 + s[6] * -FIX9(1.847759065);
+  const long long tmp3 = z1 + s[2] * FIX9(0.765366865);
+  const long long tmp0 = second_pass ? (long long)shlw(addw((int)s[0], (int)s[4]), 9) : (s[0] + s[4]) * 512;
+  const long long tmp1 = second_pass ? (long long)shlw(subw((int)s[0], (int)s[4]), 9) : (s[0] - s[4]) * 512;
+  const long long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  const long long tz1 = s[7] + s[1], tz2 = s[5] + s[3], tz3 = s[7] + s[3], tz4 = s[5] + s[1];
+  const long long z5 = (tz3 + tz4) * FIX9(1.175875602);
+  const long long y1 = tz1 * -FIX9(0.899976223), y2 = tz2 * -FIX9(2.562915447);
+  const long long y3 = tz3 * -FIX9(1.961570560) + z5, y4 = tz4 * -FIX9(0.390180644) + z5;
+  const long long o0 = s[7] * FIX9(0.298631336) + y1 + y3;
+  const long long o1 = s[5] * FIX9(2.053119869) + y2 + y4;
+  const long long o2 = s[3] * FIX9(3.072711026) + y2 + y3;
+  const long long o3 = s[1] * FIX9(1.501321110) + y1 + y4;
+  o[0] = tmp10 + o3; o[7] = tmp10 - o3;
+  o[1] = tmp11 + o2; o[6] = tmp11 - o2;
+  o[2] = tmp12 + o1; o[5] = tmp12 - o1;
+  o[3] = tmp13 + o0; o[4] = tmp13 - o0;
+}
+
+__global__ __launch_bounds__(64) void idct_planes_wide_kernel(const GenericArgs a)
+{
+  const int comp = a.wide_first + blockIdx.y % a.wide_count, frame = blockIdx.y / a.wide_count;
+  const int nblocks = a.bw[comp] * a.bh[comp];
+  const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk >= nblocks) return;
+  const int32_t *__restrict__ src =
+      reinterpret_cast<const int32_t *>(a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp]) + (int64_t)blk * 64;
+  int tmp[64];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const i32x4 c0 = reinterpret_cast<const i32x4 *>(src + r * 8)[0], c1 = reinterpret_cast<const i32x4 *>(src + r * 8)[1];
+    const int c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    long long s[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = (long long)(int)((unsigned)c[k] * (unsigned)a.q[comp][r * 8 + k]); // LONG product
+    if (r == 0) s[0] = (long long)addw((int)s[0], a.dcoff[comp]);
+    idct_1d_quad(s, o, false);
+#pragma unroll
+    for (int k = 0; k < 8; k++) tmp[r * 8 + k] = (int)((o[k] + 256) >> 9);
+  }
+  const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
+  const int pitch = a.bw[comp] * 8;
+  int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
+#pragma unroll
+  for (int x = 0; x < 8; x++) {
+    long long s[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = tmp[k * 8 + x];
+    idct_1d_quad(s, o, true);
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[(int64_t)k * pitch + x] = (int)((o[k] + 2048) >> 12);
   }
 }
 
@@ -971,11 +1037,17 @@ __global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
     const int qy = min(max(rs[0][x], 0), rmax16) << qshift, qb = min(max(rs[1][x], 0), rmax16) << qshift,
               qr = min(max(rs[2][x], 0), rmax16) << qshift; // ry, rcb, rcr before the level shift (multiples of 16 when Pr = 12)
     int rr[3];
-    if (a.rtrafo_ycbcr) {
+    if (a.rtrafo_ycbcr && qshift >= 4) {
       const int db = (qb >> 4) - a.out_shift, dr = (qr >> 4) - a.out_shift; // exact: qshift >= 4
       rr[0] = qy + ((dr * L_CR_R + 256) >> 9);
       rr[1] = qy + ((-db * L_CB_G - dr * L_CR_G + 256) >> 9);
       rr[2] = qy + ((db * L_CB_B + 256) >> 9);
+    } else if (a.rtrafo_ycbcr) {
+      // hidden residual bits: the inputs are no multiples of 16 any more -- FIX_COLOR_TO_INTCOLOR of the 64-bit sums
+      const long long y13 = ((long long)qy << 13) + 4096, cb = qb - (a.out_shift << 4), cr = qr - (a.out_shift << 4);
+      rr[0] = (int)((y13 + cr * L_CR_R) >> 13);
+      rr[1] = (int)((y13 - cb * L_CB_G - cr * L_CR_G) >> 13);
+      rr[2] = (int)((y13 + cb * L_CB_B) >> 13);
     } else {
       rr[0] = qy; rr[1] = qb; rr[2] = qr;
     }
@@ -1000,7 +1072,7 @@ __global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const int lv = a.ltable[c * 256 + min(max(v[c], 0), a.maxval)];
+      const int lv = a.ltable[c * a.ltable_entries + min(max(v[c], 0), a.maxval)];
       int m = lv + rr[c] - a.out_shift;
       if (a.is_float) {
         m = min(max(m, minf), pinf);
@@ -1053,6 +1125,11 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
     hipLaunchKernelGGL(idct_planes_kernel<true>, g1, dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL(idct_planes_kernel<false>, g1, dim3(256), 0, stream, a);
+  if (a.wide_count > 0) {
+    int wb = 0;
+    for (int c = a.wide_first; c < a.wide_first + a.wide_count; c++) wb = max(wb, a.bw[c] * a.bh[c]);
+    hipLaunchKernelGGL(idct_planes_wide_kernel, dim3((wb + 63) / 64, a.wide_count * a.frames), dim3(64), 0, stream, a);
+  }
   const int groups = (a.width + 7) >> 3;
   const int bs = groups >= 256 ? 256 : 64;
   dim3 g2((groups + bs - 1) / bs, a.height, a.frames);

@@ -50,7 +50,10 @@ struct GenericArgs {
   // JPEG XT profile C merge (colortrafo/ycbcrtrafo.cpp:750-955)
   int32_t xt, rtrafo_ycbcr, out_shift, out_max, is_float, rprecision;
   int32_t legacy32;            // legacy colour stage may run in 32 bits (8-bit frame that passed the range check)
-  const int32_t *ltable;       // device: L lookup tables [3][256]
+  int32_t ltable_entries;      // entries per L table: 256 << hidden bits of the legacy frame
+  int32_t wide_first, wide_count; // planes [wide_first, wide_first + wide_count) hold int32 coefficients at coef_off (in
+                                  // int16 units) and are transformed by idct_planes_wide_kernel (IDCT<4,QUAD>)
+  const int32_t *ltable;       // device: L lookup tables [3][ltable_entries]
 };
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);

@@ -102,6 +102,8 @@ case("xt_75x45_444_rR4", 75, 45, 6, "xt", args=["-r", "-q", "85", "-Q", "90", "-
 case("xt_129x71_420_R2_rR3_dri3", 129, 71, 7, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-R", "2", "-rR", "3",
                                                             "-s", "1x1,2x2,2x2", "-z", "3"])
 case("xt_64x48_444_R1_rR1", 64, 48, 8, "xt", args=["-r", "-q", "70", "-Q", "80", "-h", "-profile", "c", "-r12", "-R", "1", "-rR", "1"])
+case("xt_200x120_420_R3_rR4", 200, 120, 9, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-R", "3", "-rR", "4",
+                                                        "-s", "1x1,2x2,2x2"])
 # plain 12-bit extended sequential (SOF1, P = 12): what the residual codestream of profile C is made of
 case("p12_64x48_444", 64, 48, 30, "p12", args=["-q", "85"])
 case("p12_120x90_420_dri3", 120, 90, 31, "p12", args=["-q", "85", "-s", "1x1,2x2,2x2", "-z", "3"])
