@@ -438,9 +438,19 @@ static bool use_fused420(const mijpeg_batch *b)
          !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM));
 }
 
+// the packed flavour filters (Cb, Cr) pairs in 16 bits: every chroma sample * 16 is bounded by 4 * range_max, and the
+// filter sums a + 3 b + r by four times that
+static bool use_fused420p(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  static const bool off = getenv("MIJPEG_NO_F420P") != nullptr; // tuning / A-B comparisons
+  return !off && use_fused420(b) && fast_ok(b) && f.range_max[1] < 2047 && f.range_max[2] < 2047;
+}
+
 const char *mijpeg_kernel_name(const mijpeg_batch *b)
 {
   if (!b) return "";
+  if (use_fused420p(b)) return "fused420p_kernel";
   return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : b->info.xt ? "idct_planes_kernel+xt_merge_kernel"
                                                                                                  : "idct_planes_kernel+upsample_color_kernel";
 }
@@ -491,7 +501,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.aligned8 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 7) == 0;
     for (int c = 0; c < 3; c++)
       for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
-    rc = f444 ? launch_fused444(a, s) : launch_fused420(a, fast, s);
+    rc = f444 ? launch_fused444(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

@@ -565,6 +565,223 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 }
 
 // ==============================================================================================
+// fused 4:2:0 kernel, packed chroma flavour
+// ==============================================================================================
+// Same decomposition as fused420_kernel<true>, for frames whose chroma samples are small enough for 16-bit filter
+// arithmetic: 4 * range_max < 8190 bounds every chroma sample (times 16), so the filter sums a + 3 b + r of
+// upsampler.cpp stay inside int16 and (Cb, Cr) of one position travel as ONE register (Cb low, Cr high half):
+//   * phase A is unchanged (waves 0, 1: Cb, waves 2, 3: Cr -- every wave, i.e. every SIMD, carries the same load)
+//     except that a sample is stored as the 16-bit half of its position's dword: one LDS plane instead of two;
+//   * both filter passes run as v_pk_mad_i16 / v_pk_add_i16 / v_pk_ashrrev_i16 on the pairs: half the instructions
+//     and half the LDS reads of the 32-bit flavour; the colour multiply-adds read the halves in place
+//     (v_mad_i32_i16 op_sel).
+// Everything else (tile shape, halo, edge replication, in-place aliasing of output column 1, store path) is
+// identical, and so are the results: wherever nothing overflows, int16 and int32 arithmetic agree.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned tap13_pk(unsigned a, unsigned b, short r)
+{
+  const s16x2 va = __builtin_bit_cast(s16x2, a), vb = __builtin_bit_cast(s16x2, b);
+  const s16x2 t = (va + vb * (short)3 + r) >> (short)2;
+  return __builtin_bit_cast(unsigned, t);
+}
+
+template <int MINW>
+__global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420_CPITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  { // XCD-aware tile order (see fused420_kernel)
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  // ------------------------------------------------------------------ phase A: chroma -> LDS halves
+  {
+    const int comp = wave >> 1; // 0 = Cb (low halves), 1 = Cr (high halves); wave-uniform
+    const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
+    const int gx0 = tx * 8 - 1, gy0 = ty * 8 - 1;
+    const int base = (wave & 1) * 64;
+    const bool inside = gx0 >= 0 && gy0 >= 0 && gx0 + F420_CGRID <= a.bw_c && gy0 + F420_CGRID <= a.bh_c;
+    u32x4 rows[8];
+    const int idx0 = base + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    if (inside) {
+      const unsigned off0 = (unsigned)((gy0 * a.bw_c + gx0) * 128), rowb = (unsigned)a.bw_c * 128u;
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const unsigned i = (unsigned)min(idx0 + 8 * m, F420_CGRID * F420_CGRID - 1);
+        const unsigned y = (i * 205u) >> 11, x = i - y * F420_CGRID; // i / 10, i % 10 for i < 1029
+        return reinterpret_cast<const u32x4 *>(pbase + (off0 + y * rowb + x * 128u));
+      });
+    } else {
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int i = min(idx0 + 8 * m, F420_CGRID * F420_CGRID - 1);
+        const int y = (i * 205) >> 11, x = i - y * F420_CGRID;
+        const int gx = min(max(gx0 + x, 0), a.bw_c - 1), gy = min(max(gy0 + y, 0), a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((gy * a.bw_c + gx) * 128));
+      });
+    }
+    const int idx = base + lane;
+    const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
+    const int gx = gx0 + cbx, gy = gy0 + cby;
+    if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
+      int v[64];
+      dequant_idct<true>(rows, a.q[1 + comp], v, 0);
+      short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int pr = 8 * cby + r - 7;
+        if (pr >= 0 && pr < F420_CROWS) {
+          if (cbx == 0) {
+            cp[2 * (pr * F420_CPITCH + 3)] = (short)v[r * 8 + 7];
+          } else if (cbx == F420_CGRID - 1) {
+            cp[2 * (pr * F420_CPITCH + 68)] = (short)v[r * 8 + 0];
+          } else {
+            short *dst = cp + 2 * (pr * F420_CPITCH + 8 * cbx - 4);
+#pragma unroll
+            for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ edge fix-up (uniform branch)
+  {
+    const int last_col = a.cw - 1 - tx * 64; // last valid chroma column, tile-relative
+    const int last_row = a.ch - 1 - ty * 64;
+    const bool edge = (tx == 0) | (ty == 0) | (last_col < 64) | (last_row < 64);
+    if (edge) {
+      if (tid < F420_CROWS) { // one thread per stored line: replicate columns
+        unsigned *p = cpair + tid * F420_CPITCH;
+        if (tx == 0) p[3] = p[4];
+        if (last_col < 64) {
+          const unsigned v = p[last_col + 4];
+          for (int pc = last_col + 5; pc <= 68; pc++) p[pc] = v;
+        }
+      }
+      __syncthreads();
+      if (tid < F420_CROWS) { // one thread per stored column: replicate lines
+        unsigned *p = cpair + 3 + tid;
+        if (ty == 0) p[0] = p[F420_CPITCH];
+        if (last_row < 64) {
+          const unsigned v = p[(last_row + 1) * F420_CPITCH];
+          for (int pr = last_row + 2; pr < F420_CROWS; pr++) p[pr * F420_CPITCH] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ phase B: luma, upsampling, colour
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  u32x4 rows[8];
+  {
+    const int16_t *__restrict__ plane = coef + a.off_y;
+    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
+  int yv[64];
+  dequant_idct<true>(rows, a.q[0], yv, 0);
+
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = a.aligned8 && npx == 8;
+  // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns pc = 4 bx + 3 + j
+  const unsigned *c_base = cpair + (4 * by) * F420_CPITCH + 4 * bx;
+  auto load6 = [](const unsigned *p, unsigned (&d)[6]) { // p is 16-byte aligned; wanted: p[3..8]
+    const u32x4 mid = *reinterpret_cast<const u32x4 *>(p + 4);
+    d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
+  };
+  unsigned cT[6], cC[6], cB[6];
+  load6(c_base, cT);
+  load6(c_base + F420_CPITCH, cC);
+  const int K = (2048 << 13) + 65536;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    load6(c_base + (m + 2) * F420_CPITCH, cB);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int l = 2 * m + half;
+      // vertical filter (upsampler.cpp:149-165), both components at once
+      unsigned v[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) v[j] = tap13_pk(half ? cB[j] : cT[j], cC[j], (short)(((j & 1) ^ half) ? 1 : 2));
+      // horizontal filter in place (upsampler.cpp:291-303); src[k] = v[k + 1]
+      unsigned u[8];
+      u[7] = tap13_pk(v[5], v[4], 1);
+      u[6] = tap13_pk(v[3], v[4], 2);
+      u[5] = tap13_pk(v[4], v[3], 1);
+      u[4] = tap13_pk(v[2], v[3], 2);
+      u[3] = tap13_pk(v[3], v[2], 1);
+      u[2] = tap13_pk(v[1], v[2], 2);
+      u[1] = tap13_pk(u[2], v[1], 1); // src[1] has already been overwritten by out[2]
+      u[0] = tap13_pk(v[0], v[1], 2);
+      if (l < nln) {
+        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+        int rr[8], gg[8], bb[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          const int yk = (yv[l * 8 + x] << 13) + K;
+          rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
+          gg[x] = mad16_hi(u[x], -L_CR_G, mad16_lo(u[x], -L_CB_G, yk));
+          bb[x] = mad16_lo(u[x], L_CB_B, yk);
+        }
+        if (fast_store) {
+          unsigned h[12];
+#pragma unroll
+          for (int x = 0; x < 8; x += 2) {
+            h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
+            h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
+            h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
+          }
+          unsigned w[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+          __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
+          __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
+          __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+        } else {
+#pragma unroll
+          for (int x = 0; x < 8; x++)
+            if (x < npx) {
+              dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
+            }
+        }
+      }
+    }
+    // slide the three-line window
+#pragma unroll
+    for (int j = 0; j < 6; j++) { cT[j] = cC[j]; cC[j] = cB[j]; }
+  }
+}
+
+// ==============================================================================================
 // fused 4:4:4 kernel (three components, no subsampling, YCbCr): ReconstructUnsampled,
 // control/blockbitmaprequester.cpp:1013-1074
 // ==============================================================================================
@@ -1101,6 +1318,20 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
     hipLaunchKernelGGL((fused420_kernel<true, 4>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else
     hipLaunchKernelGGL((fused420_kernel<true, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused420p(const Fused420Args &a, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  if (total == 0) return 0;
+  static const int variant = getenv("MIJPEG_F420P_VARIANT") ? atoi(getenv("MIJPEG_F420P_VARIANT")) : 0; // tuning aid
+  if (variant == 1)
+    hipLaunchKernelGGL((fused420p_kernel<4>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else if (variant == 2)
+    hipLaunchKernelGGL((fused420p_kernel<2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else
+    hipLaunchKernelGGL((fused420p_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

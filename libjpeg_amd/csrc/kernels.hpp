@@ -57,6 +57,7 @@ struct GenericArgs {
 };
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
+int launch_fused420p(const Fused420Args &a, hipStream_t stream); // FAST only, chroma samples within int16 filter range
 int launch_fused444(const Fused420Args &a, hipStream_t stream); // same argument block; all planes bw_y x bh_y
 int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream);
 

@@ -49,7 +49,7 @@ EDGE_SIZES = [(127, 127), (128, 128), (129, 129), (255, 130), (257, 127), (130, 
 def test_fused420_tile_edges_vs_oracle(dec, oracle, w, h, flags):
     data = synth.synth_jpeg(w, h, 100 + w + h, 90, "420", (w * h) % 4)
     f = dec.read(data)
-    assert api.kernel_name(f, flags) == "fused420_kernel"
+    assert api.kernel_name(f, flags) == ("fused420_kernel" if flags else "fused420p_kernel")  # packed chroma flavour when the range allows
     out = dec.reconstruct(flags)
     exp = oracle.decode(data)
     bad = int((out != exp).sum())
@@ -77,6 +77,33 @@ def test_fused444_range_gate(dec, oracle):
     name = api.kernel_name(f)
     assert (name == "fused444_kernel") == (f.fast_arith == 1 and f.range_max[1] < 8190 and f.range_max[2] < 8190)
     assert np.array_equal(dec.reconstruct(), oracle.decode(data))
+
+
+def test_fused420_packed_chroma_gate(dec, oracle):
+    """The packed flavour of the fused 4:2:0 kernel filters (Cb, Cr) pairs in 16 bits; frames whose range check does not
+    keep 4 * (a + 3 b + r) inside int16 take the 32-bit flavour: saturated graphics right at and beyond the gate."""
+    img = np.zeros((272, 400, 3), np.uint8)
+    img[:, :130] = (255, 0, 0)
+    img[:, 130:260] = (0, 0, 255)
+    img[:, 260:] = (0, 255, 0)
+    img[100:150] = (255, 255, 0)
+    seen = set()
+    for q in (50, 75, 90, 100):
+        data = synth.encode_jpeg(img, q, "420", restart_mcus=3)
+        f = dec.read(data)
+        name = api.kernel_name(f)
+        packed = f.fast_arith == 1 and f.range_max[1] < 2047 and f.range_max[2] < 2047
+        assert name == ("fused420p_kernel" if packed else "fused420_kernel")
+        seen.add(name)
+        assert np.array_equal(dec.reconstruct(), oracle.decode(data)), q
+    assert "fused420_kernel" in seen  # the gate was exercised
+    # moderately coloured content right below the gate stays exact in 16 bits
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (144, 208, 3)).astype(np.uint8)
+    for q in (60, 95):
+        data = synth.encode_jpeg(img, q, "420")
+        dec.read(data)
+        assert np.array_equal(dec.reconstruct(), oracle.decode(data))
 
 
 @pytest.mark.parametrize("sub", ["444", "422", "420"])
@@ -257,6 +284,59 @@ def test_adversarial_coefficients_safe_flavour(oracle, generic):
     res = out.cpu().numpy().reshape(144, 272, 3)
     bad = int((res != exp).sum())
     assert bad == 0, f"{bad} differing samples"
+
+
+def test_extreme_coefficients_at_the_packed_chroma_gate(oracle):
+    """The packed 4:2:0 flavour is admitted by sum |c| q < 2047 per chroma block.  Blocks that sit right at that bound
+    with every sign pattern (DC-only, single AC, dense) drive the 16-bit filter sums to their limits; the result must
+    still be the reference's."""
+    torch = _torch()
+    d = api.Decoder(0)
+    data = synth.synth_jpeg(272, 144, 5, 85, "420", 0)
+    f = d.read(data)
+    d.close()
+    rng = np.random.default_rng(77)
+    info, _ = oracle.decode_coefficients(data)
+    for t in range(4):
+        for i in range(64):
+            info.quant[t][i] = 1 if i else 2
+            f.quant[t][i] = info.quant[t][i]
+    planes = []
+    for c in range(3):
+        shape = (info.bh[c], info.bw[c], 64)
+        p = np.zeros(shape, np.int32)
+        kind = rng.integers(0, 4, size=shape[:2])
+        sign = rng.choice([-1, 1], size=shape[:2])
+        budget = 2046 if c else 8000
+        p[..., 0] = np.where(kind == 0, sign * (budget // 2), 0)  # DC alone: q[0] = 2
+        k = rng.integers(1, 64, size=shape[:2])
+        for by in range(shape[0]):
+            for bx in range(shape[1]):
+                if kind[by, bx] == 1:
+                    p[by, bx, k[by, bx]] = sign[by, bx] * budget  # one AC coefficient carries everything
+                elif kind[by, bx] >= 2:
+                    v = rng.integers(-40, 41, size=64)
+                    v[0] = 0
+                    scale = budget / max(1, int(np.abs(v).sum()))
+                    v = (v * scale).astype(np.int64)
+                    v[1] += np.sign(v[1] or 1) * (budget - int(np.abs(v).sum()))  # spend the rest: the sum is exactly the budget
+                    p[by, bx] = v
+        planes.append(p)
+    for c in range(3):
+        q = np.array(info.quant[info.tq[c]], np.int64)
+        f.range_max[c] = int((np.abs(planes[c]).astype(np.int64) * q).sum(axis=2).max())
+    assert f.range_max[1] <= 2046 and f.range_max[2] <= 2046
+    f.fast_arith = 1
+    assert api.kernel_name(f) == "fused420p_kernel"
+    exp = oracle.reconstruct(info, planes)
+    coef = torch.from_numpy(np.concatenate([p.astype(np.int16).reshape(-1) for p in planes])).cuda()
+    row = 272 * 3
+    out = torch.zeros((144, row), dtype=torch.uint8, device="cuda")
+    api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, row, 144 * row, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy().reshape(144, 272, 3)
+    bad = int((res != exp).sum())
+    assert bad == 0, f"{bad} differing samples, first at {np.argwhere(res != exp)[:4].tolist()}"
 
 
 def test_round_trip_properties_8k(dec):
