@@ -127,9 +127,32 @@ __device__ __forceinline__ int round_shift(int x)
 // (44 per transform): products are folded into nested v_mad_i32_i24 chains, e.g. the reference's
 //   tmp0 = ttmp0 * c5 + z1 + z3  with  z1 = (ttmp0 + ttmp3) * -c9,  z3 = (ttmp0 + ttmp2) * -c11 + z5
 // becomes mad(tz1, -c9, mad(ttmp0, c5, z3)); the rounding constant is folded into the even part.
-template <bool FAST, int SHIFT>
+// NZ = 4 (FAST only): s4..s7 are known to be zero and are not read; every term they feed is dropped and constants that
+// multiply the same input are added up (still exact: the ring Z / 2^32 is distributive), 31 slots instead of 44.
+template <bool FAST, int SHIFT, int NZ = 8>
 __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int &s4, int &s5, int &s6, int &s7)
 {
+  if (FAST && NZ == 4) {
+    const int R = 1 << (SHIFT - 1);
+    // even part (7): tmp2 = z1, tmp3 = s2 * (c0.541 + c0.765)
+    const int t0 = (s0 << 9) + R;
+    const int tmp2 = __mul24(s2, FIX9(0.541196100));
+    const int tmp3 = __mul24(s2, FIX9(0.541196100) + FIX9(0.765366865));
+    const int t10 = t0 + tmp3, t13 = t0 - tmp3, t11 = t0 + tmp2, t12 = t0 - tmp2;
+    // odd part (8): tz1 = tz4 = s1, tz2 = tz3 = s3
+    const int z5 = __mul24(s3 + s1, FIX9(1.175875602));
+    const int z3 = mad24(s3, -FIX9(1.961570560), z5);
+    const int z4 = mad24(s1, -FIX9(0.390180644), z5);
+    const int o0 = mad24(s1, -FIX9(0.899976223), z3);
+    const int o1 = mad24(s3, -FIX9(2.562915447), z4);
+    const int o2 = mad24(s3, FIX9(3.072711026) - FIX9(2.562915447), z3);
+    const int o3 = mad24(s1, FIX9(1.501321110) - FIX9(0.899976223), z4);
+    s0 = (t10 + o3) >> SHIFT; s7 = (t10 - o3) >> SHIFT;
+    s1 = (t11 + o2) >> SHIFT; s6 = (t11 - o2) >> SHIFT;
+    s2 = (t12 + o1) >> SHIFT; s5 = (t12 - o1) >> SHIFT;
+    s3 = (t13 + o0) >> SHIFT; s4 = (t13 - o0) >> SHIFT;
+    return;
+  }
   if (FAST) {
     const int R = 1 << (SHIFT - 1);
     // even part (12)
@@ -189,14 +212,17 @@ __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int 
 // dcoff = 0 leaves out the level shift dcoffset = 2^(P-1) << 7 (idct.cpp:231, :246).  That constant
 // passes through both rounding shifts exactly ((x + 2^14 * 2^9 + 2^8) >> 9 = ((x + 2^8) >> 9) + 2^14, and
 // (x + 2^14 * 2^9 + 2^11) >> 12 = ((x + 2^11) >> 12) + 2^11), so the result is exactly 2048 lower.
-template <bool FAST>
+// NR = 4 (FAST only): coefficient rows 4..7 are known to be zero (see rows_4_to_7_zero): they are neither dequantised nor
+// transformed, and the second pass runs the pruned butterfly.
+// NC = 4 (with NR = 4): coefficient columns 4..7 are zero too; the first pass is pruned the same way.
+template <bool FAST, int NR = 8, int NC = 8>
 __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff)
 {
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < NR; k++) {
     const unsigned w[4] = {rows[k].x, rows[k].y, rows[k].z, rows[k].w};
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NC / 2; i++) {
       if (FAST) { // deltas <= 2047 (checked by the host): q fits a signed 16-bit operand
         v[k * 8 + 2 * i] = mul16_lo(w[i], q[k * 8 + 2 * i]);
         v[k * 8 + 2 * i + 1] = mul16_hi(w[i], q[k * 8 + 2 * i + 1]);
@@ -208,12 +234,40 @@ __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *
   }
   v[0] = addw(v[0], dcoff); // level shift 2^(P-1) << (preshift + 3); the fused fast kernels pass 0
 #pragma unroll
-  for (int r = 0; r < 8; r++)
-    idct_1d<FAST, 9>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5],
-                     v[r * 8 + 6], v[r * 8 + 7]);
+  for (int r = 0; r < NR; r++)
+    idct_1d<FAST, 9, NC>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5],
+                         v[r * 8 + 6], v[r * 8 + 7]);
 #pragma unroll
   for (int c = 0; c < 8; c++)
-    idct_1d<FAST, 12>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+    idct_1d<FAST, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+}
+
+// True if coefficient rows 4..7 (the upper half of the vertical frequencies) are zero in every block the wave holds:
+// the usual case for chroma and for smooth luma.  Wave-uniform, so the caller branches without divergence.
+__device__ __forceinline__ bool rows_4_to_7_zero(const u32x4 (&rows)[8])
+{
+  unsigned o = 0;
+#pragma unroll
+  for (int r = 4; r < 8; r++) o |= rows[r].x | rows[r].y | rows[r].z | rows[r].w;
+  return __builtin_amdgcn_ballot_w64(o != 0) == 0;
+}
+
+// ... and the horizontal frequencies 4..7 of the remaining rows (dwords z, w of rows 0..3)
+__device__ __forceinline__ bool cols_4_to_7_zero(const u32x4 (&rows)[8])
+{
+  unsigned o = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) o |= rows[r].z | rows[r].w;
+  return __builtin_amdgcn_ballot_w64(o != 0) == 0;
+}
+
+// dequant_idct<true> with the pruned paths where the data allow it
+__device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff = 0)
+{
+  if (rows_4_to_7_zero(rows)) {
+    if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff);
+    else dequant_idct<true, 4, 8>(rows, q, v, dcoff);
+  } else dequant_idct<true, 8, 8>(rows, q, v, dcoff);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -374,7 +428,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
     const int gx = gx0 + cbx, gy = gy0 + cby;
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
       int v[64];
-      dequant_idct<FAST>(rows, a.q[1 + comp], v, FAST ? 0 : (128 << 7));
+      if (FAST) dequant_idct_sparse(rows, a.q[1 + comp], v);
+      else dequant_idct<false>(rows, a.q[1 + comp], v, 128 << 7);
       int *cp = cplane[comp];
 #pragma unroll
       for (int r = 0; r < 8; r++) {
@@ -441,7 +496,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct<FAST>(rows, a.q[0], yv, FAST ? 0 : (128 << 7));
+  if (FAST) dequant_idct_sparse(rows, a.q[0], yv);
+  else dequant_idct<false>(rows, a.q[0], yv, 128 << 7);
 
   // uniform frame base + 32-bit lane offsets (a frame of pixels is far below 4 GB)
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -639,7 +695,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     const int gx = gx0 + cbx, gy = gy0 + cby;
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
       int v[64];
-      dequant_idct<true>(rows, a.q[1 + comp], v, 0);
+      dequant_idct_sparse(rows, a.q[1 + comp], v);
       short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
 #pragma unroll
       for (int r = 0; r < 8; r++) {
@@ -704,7 +760,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct<true>(rows, a.q[0], yv, 0);
+  dequant_idct_sparse(rows, a.q[0], yv);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -831,12 +887,12 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     u32x4 rows[8];
     int v[64];
     fetch(rows, a.off_cb);
-    dequant_idct<true>(rows, a.q[1], v, 0);
+    dequant_idct_sparse(rows, a.q[1], v);
 #pragma unroll
     for (int i = 0; i < 32; i++) cbp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
     __builtin_amdgcn_sched_barrier(0); // keep the next component's loads from being hoisted above this transform (register pressure)
     fetch(rows, a.off_cr);
-    dequant_idct<true>(rows, a.q[2], v, 0);
+    dequant_idct_sparse(rows, a.q[2], v);
 #pragma unroll
     for (int i = 0; i < 32; i++) crp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
     __builtin_amdgcn_sched_barrier(0);
@@ -847,7 +903,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     fetch(rows, a.off_y);
     const int X0 = gbx * 8, Y0 = gby * 8;
     if (X0 >= a.width || Y0 >= a.height) return;
-    dequant_idct<true>(rows, a.q[0], yv, 0);
+    dequant_idct_sparse(rows, a.q[0], yv);
   }
   const int X0 = gbx * 8, Y0 = gby * 8;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -926,7 +982,8 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   const int blk = first + lane;
   if (blk >= nblocks) return;
   int v[64];
-  dequant_idct<FAST>(rows, a.q[comp], v, a.dcoff[comp]);
+  if (FAST) dequant_idct_sparse(rows, a.q[comp], v, a.dcoff[comp]);
+  else dequant_idct<false>(rows, a.q[comp], v, a.dcoff[comp]);
   const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
   const int pitch = a.bw[comp] * 8;
   int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;

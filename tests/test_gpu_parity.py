@@ -339,6 +339,51 @@ def test_extreme_coefficients_at_the_packed_chroma_gate(oracle):
     assert bad == 0, f"{bad} differing samples, first at {np.argwhere(res != exp)[:4].tolist()}"
 
 
+@pytest.mark.parametrize("sub", ["420", "444", "422"])
+@pytest.mark.parametrize("shape", ["rows03", "corner4x4", "corner_plus_one_dense_block"])
+def test_pruned_idct_paths(oracle, sub, shape):
+    """The fast kernels skip the transform work of coefficient rows / columns 4..7 when they are zero in all 64 blocks a
+    wave holds.  Planes built to take each path (only rows 0..3; only the 4 x 4 low-frequency corner; the same with
+    one dense block somewhere, which must switch its whole wave back to the full transform)."""
+    torch = _torch()
+    W, H = 400, 272
+    d = api.Decoder(0)
+    data = synth.synth_jpeg(W, H, 5, 85, sub, 0)
+    f = d.read(data)
+    d.close()
+    rng = np.random.default_rng(hash((sub, shape)) % 2**32)
+    info, _ = oracle.decode_coefficients(data)
+    planes = []
+    for c in range(3):
+        bh, bw = info.bh[c], info.bw[c]
+        p = rng.integers(-3, 4, size=(bh, bw, 8, 8)).astype(np.int32)
+        p[rng.random(p.shape) < 0.4] = 0
+        p[:, :, 4:, :] = 0
+        if shape != "rows03":
+            p[:, :, :, 4:] = 0
+        if shape == "corner_plus_one_dense_block":
+            p[bh // 2, bw // 3] = rng.integers(-1, 2, size=(8, 8))
+        p[..., 0, 0] = rng.integers(-40, 41, size=(bh, bw))
+        planes.append(p.reshape(bh, bw, 64))
+    for c in range(3):
+        q = np.array(info.quant[info.tq[c]], np.int64)
+        f.range_max[c] = int((np.abs(planes[c]).astype(np.int64) * q).sum(axis=2).max())
+    f.fast_arith = 1
+    assert max(f.range_max[:3]) < 2047, list(f.range_max)
+    exp = oracle.reconstruct(info, planes)
+    coef = torch.from_numpy(np.concatenate([p.astype(np.int16).reshape(-1) for p in planes])).cuda()
+    row = W * 3
+    out = torch.zeros((H, row), dtype=torch.uint8, device="cuda")
+    ws_bytes = api.workspace_bytes(f, 1)
+    ws = torch.zeros(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
+    api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, row, H * row, workspace=ws.data_ptr(), workspace_bytes=ws_bytes,
+                           stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy().reshape(H, W, 3)
+    bad = int((res != exp).sum())
+    assert bad == 0, f"{api.kernel_name(f)}: {bad} differing samples, first at {np.argwhere(res != exp)[:4].tolist()}"
+
+
 def test_round_trip_properties_8k(dec):
     """Size-independent properties at BASELINE's full 8K size: the three code paths (fast fused, safe fused,
     generic two-kernel) agree line band by line band (checksum of checksums), reconstruction is idempotent,
