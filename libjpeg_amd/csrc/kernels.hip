@@ -642,7 +642,7 @@ __device__ __forceinline__ unsigned tap13_pk(unsigned a, unsigned b, short r)
   return __builtin_bit_cast(unsigned, t);
 }
 
-template <int MINW>
+template <int MINW, int DBG = 0>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420_CPITCH];
@@ -707,6 +707,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
             cp[2 * (pr * F420_CPITCH + 68)] = (short)v[r * 8 + 0];
           } else {
             short *dst = cp + 2 * (pr * F420_CPITCH + 8 * cbx - 4);
+            if (DBG == 1) { dst[0] = (short)(v[r * 8] + v[r * 8 + 1] + v[r * 8 + 2] + v[r * 8 + 3] + v[r * 8 + 4] + v[r * 8 + 5] + v[r * 8 + 6] + v[r * 8 + 7]); continue; }
 #pragma unroll
             for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
           }
@@ -1387,6 +1388,8 @@ int launch_fused420p(const Fused420Args &a, hipStream_t stream)
     hipLaunchKernelGGL((fused420p_kernel<4>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else if (variant == 2)
     hipLaunchKernelGGL((fused420p_kernel<2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else if (variant == 9) // experiment: one LDS store per chroma line instead of eight (wrong pixels)
+    hipLaunchKernelGGL((fused420p_kernel<3, 1>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else
     hipLaunchKernelGGL((fused420p_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
