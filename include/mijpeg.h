@@ -182,6 +182,10 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
 /* Error of the last failing call on this object (JPEG::LastError). Returns the code, 0 if none. */
 int mijpeg_last_error(mijpeg_decoder *d, const char **message);
 
+/* Diagnostics: number of scans without restart markers that the host decoder decoded in parallel (self-synchronising
+ * speculative decoding) since the library was loaded; *pieces (may be NULL) = ranges they were stitched from. */
+int64_t mijpeg_speculative_scans(int64_t *pieces);
+
 /* Seconds spent in the phases of the last decode (huffman, h2d, kernel, d2h) -- diagnostics. */
 int mijpeg_last_timing(mijpeg_decoder *d, double out_seconds[4]);
 

@@ -100,6 +100,8 @@ def lib():
         L.mijpeg_get_xt_params.argtypes = [C.c_void_p, P(MijpegXtParams)]
         L.mijpeg_decode_coefficients.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_decode_coefficients_device.argtypes = [C.c_void_p, C.c_int]
+        L.mijpeg_speculative_scans.argtypes = [C.POINTER(C.c_int64)]
+        L.mijpeg_speculative_scans.restype = C.c_int64
         L.mijpeg_coefficients.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_coefficients.restype = C.c_void_p
         L.mijpeg_device_coefficients.argtypes = [C.c_void_p]
@@ -282,6 +284,13 @@ class PinnedFrame:
             self.close()
         except Exception:
             pass
+
+
+def speculative_scans():
+    """(scans, pieces) decoded by the host's self-synchronising parallel path since the library was loaded."""
+    p = C.c_int64(0)
+    n = lib().mijpeg_speculative_scans(C.byref(p))
+    return int(n), int(p.value)
 
 
 def default_threads() -> int:

@@ -214,6 +214,12 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   return MIJPEG_OK;
 }
 
+int64_t mijpeg_speculative_scans(int64_t *pieces)
+{
+  if (pieces) *pieces = g_speculative_pieces.load();
+  return g_speculative_scans.load();
+}
+
 int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info)
 {
   if (!d || !info) return MIJPEG_ERR_INVALID_PARAMETER;

@@ -17,6 +17,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <functional>
 #include <string>
 #include <vector>
@@ -118,6 +119,7 @@ private:
   int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
   int parse_dht(const uint8_t *q, int len);
   template <class T> int decode_t(T *coef, int threads, const std::function<void(int, int)> &on_rows_done);
+  template <class T> int decode_scan_speculative(T *coef, const Scan &s, int threads, uint32_t (&qmax_out)[MIJPEG_MAX_COMPONENTS]);
   int fail(int code, const char *msg);
   int parse_sof(const uint8_t *p, int n);
   int frame_geometry();
@@ -126,6 +128,9 @@ private:
 };
 
 int default_threads();
+
+// diagnostics: scans decoded by the self-synchronising parallel path since the library was loaded, and their pieces
+extern std::atomic<int64_t> g_speculative_scans, g_speculative_pieces;
 
 // Run fn(i) for i in [0, n) on the entropy-decoder worker pool (used for large host-side pixel copies).
 void parallel_for(int n, const std::function<void(int)> &fn);

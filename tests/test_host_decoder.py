@@ -79,6 +79,65 @@ def test_parallel_marker_search_on_a_stream_of_several_chunks(oracle, dri, progr
     d.close()
 
 
+@pytest.mark.parametrize("w,h,sub,q", [(2560, 1440, "444", 95), (3840, 2160, "420", 85), (1600, 1200, "422", 90), (2048, 2048, "gray", 92)])
+def test_streams_without_restart_markers_decode_in_parallel(oracle, w, h, sub, q):
+    """No DRI: the entropy coded segment is cut into ranges that are decoded speculatively and stitched where they
+    synchronise (HostDecoder::decode_scan_speculative); the coefficients must be the sequential decoder's."""
+    img = synth.synth_image(w, h, 9, channels=1 if sub == "gray" else 3)
+    data = synth.encode_jpeg(img, q, sub if sub != "gray" else "444")
+    d = api.Decoder(None)
+    before = api.speculative_scans()[0]
+    f = d.read(data, 8)
+    assert api.speculative_scans()[0] == before + 1  # really taken, not the fallback
+    one = api.Decoder(None)
+    one.read(data, 1)  # one thread: the plain sequential path
+    assert api.speculative_scans()[0] == before + 1
+    for c in range(f.components):
+        assert np.array_equal(d.coefficients(c), one.coefficients(c)), c
+    assert list(d.info.range_max) == list(one.info.range_max)
+    if w * h <= 2560 * 1440:
+        _, planes = oracle.decode_coefficients(data)
+        for c in range(f.components):
+            assert np.array_equal(d.coefficients(c), planes[c].astype(np.int16))
+    d.close()
+    one.close()
+
+
+def test_speculative_decoder_with_tiny_ranges():
+    """Ranges of a few dozen bytes (hundreds of synchronisation points, ranges that never synchronise, ranges cut at
+    stuffed bytes) on every small sequential stream without restart markers -- in a subprocess because the range
+    size is an environment setting."""
+    import subprocess
+    import sys
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests.conftest import SMALL_CASES, MANIFEST, golden_jpeg
+from libjpeg_amd import api, synth
+n = 0
+streams = [golden_jpeg(k) for k in SMALL_CASES if not MANIFEST[k].get("dri") and "-z" not in (MANIFEST[k].get("args") or []) and "prog" not in k]
+rng = np.random.default_rng(1)
+for q in (30, 75, 98):
+    streams.append(synth.encode_jpeg(rng.integers(0, 256, (96, 160, 3)).astype(np.uint8), q, "420"))  # noise: many 0xFF bytes
+for data in streams:
+    a, b = api.Decoder(None), api.Decoder(None)
+    fa = a.read(data, 7)
+    fb = b.read(data, 1)
+    for c in range(fa.components):
+        assert np.array_equal(a.coefficients(c), b.coefficients(c))
+    assert list(fa.range_max) == list(fb.range_max)
+    n += 1
+scans, pieces = api.speculative_scans()
+assert scans >= 1 and pieces >= 4 * scans, (scans, pieces, n)  # (streams shorter than four ranges take the sequential path)
+print("checked", n)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    for seg in ("64", "333", "4096"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MIJPEG_SPEC_SEGMENT_BYTES=seg))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "checked" in r.stdout
+
+
 def test_reconstruct_without_device_fails_loudly():
     d = api.Decoder(None)
     d.read(golden_jpeg("ref_80x48_420"))

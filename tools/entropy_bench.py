@@ -33,3 +33,16 @@ for ri in [int(x) for x in os.environ.get('RI', '1,2,4,8,32').split(',')]:
     assert res["host_sum"] == res["gpu_sum"] or os.environ.get("MIJPEG_HUFF_DEBUG")
     print(f"dri={ri:4d} bytes={len(data)/1e6:.2f}MB host read {res['host']:.2f} ms  gpu read {res['gpu']:.2f} ms  {res['gpu_t']}", flush=True)
     d.close()
+
+
+# streams without restart markers: sequential (1 thread) vs the self-synchronising parallel host decoder
+data = synth.encode_jpeg(img, 85, "420", restart_mcus=0)
+for th in (1, 4, 16, 64):
+    d = api.Decoder(None)
+    ts = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        d.read(data, threads=th)
+        ts.append(time.perf_counter() - t0)
+    print(f"threads_sweep no-DRI 8K: threads={th:3d} read {min(ts)*1e3:.2f} ms  speculative scans/pieces so far {api.speculative_scans()}", flush=True)
+    d.close()
