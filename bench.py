@@ -238,7 +238,22 @@ def main():
             if best_dt is None or dt < best_dt:
                 best_dt, best_depth = dt, depth
         dt = best_dt
+        # batch of frames: one Huffman launch + one reconstruction launch, pixels left in HBM (mijpeg_decode_batch_device)
+        nbatch = 32
+        bdec = api.Decoder(local_rank)
+        bout = torch.empty((nbatch, H, row), dtype=torch.uint8, device="cuda")
+        tb = []
+        for _ in range(4):
+            t = time.perf_counter()
+            bdec.decode_batch_device([jpegs[i % 2] for i in range(nbatch)])
+            bdec.reconstruct_batch_device(bout.data_ptr(), H * row, row)
+            tb.append(time.perf_counter() - t)
+        bdec.close()
+        del bout
         result["end_to_end"]["device_entropy"] = {
+            "batch": {"frames": nbatch, "ms_per_frame": round(min(tb) / nbatch * 1e3, 3), "value": round(W * H * nbatch / min(tb) / 1e6, 1),
+                      "unit": "Mpixels/s", "note": "32 streams in host memory -> parallel header parse -> H2D of the compressed bytes -> one "
+                                                   "huffman_scan_kernel launch -> one fused kernel launch, pixels left in HBM"},
             "value": round(W * H / min(ts) / 1e6, 1), "unit": "Mpixels/s", "ms": round(min(ts) * 1e3, 2),
             "read_ms": round(min(tr) * 1e3, 2), "pixels_left_in_hbm_ms": round(min(th) * 1e3, 2),
             "pipelined_ms_per_frame": round(dt / nb * 1e3, 2), "pipelined_value": round(W * H * nb / dt / 1e6, 1),

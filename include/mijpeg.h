@@ -137,6 +137,17 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads);
  * After it, mijpeg_coefficients() downloads the planes on first use. */
 int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals);
 
+/* Batches (SURVEY config 4: many frames of one shape).  n codestreams of identical width, height, sampling and
+ * quantisation tables, each qualifying for mijpeg_decode_coefficients_device, are parsed on the host in parallel, uploaded
+ * and entropy-decoded by ONE kernel launch (every workgroup works on one image; the restart intervals of all images fill
+ * the device, which a single image rarely does), into n coefficient stores that mijpeg_reconstruct_batch_device turns
+ * into n frames (`frame_stride` bytes apart, interleaved samples, `row_stride` bytes per line) with ONE launch of the
+ * reconstruction kernel.  Nothing but the compressed bytes crosses PCIe.  MIJPEG_ERR_NOT_AVAILABLE when the streams do
+ * not form such a batch.  The stream bytes are only read during the call. */
+int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals);
+int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags,
+                                    int sync);
+
 /* Current frame information (after mijpeg_decode_coefficients it includes fast_arith). */
 int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info);
 

@@ -100,6 +100,8 @@ def lib():
         L.mijpeg_get_xt_params.argtypes = [C.c_void_p, P(MijpegXtParams)]
         L.mijpeg_decode_coefficients.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_decode_coefficients_device.argtypes = [C.c_void_p, C.c_int]
+        L.mijpeg_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]
+        L.mijpeg_reconstruct_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_int]
         L.mijpeg_speculative_scans.argtypes = [C.POINTER(C.c_int64)]
         L.mijpeg_speculative_scans.restype = C.c_int64
         L.mijpeg_coefficients.argtypes = [C.c_void_p, C.c_int]
@@ -218,6 +220,22 @@ class Decoder:
         bpr = (C.c_int32 * 4)(*([out.strides[0]] * 4))
         self._check(lib().mijpeg_reconstruct_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags, dst, bpp, bpr))
         return out
+
+    def decode_batch_device(self, streams, min_intervals: int = 0) -> MijpegInfo:
+        """mijpeg_decode_batch_device: n streams of one shape -> n coefficient stores in HBM with one Huffman kernel launch."""
+        n = len(streams)
+        self._batch = list(streams)  # keep the bytes alive during the call
+        arr = (C.c_char_p * n)(*self._batch)
+        sizes = (C.c_size_t * n)(*[len(s) for s in self._batch])
+        self._check(lib().mijpeg_decode_batch_device(self._h, arr, sizes, n, min_intervals))
+        info = MijpegInfo()
+        self._check(lib().mijpeg_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.batch_frames = n
+        return info
+
+    def reconstruct_batch_device(self, dst_ptr: int, frame_stride: int, row_stride: int, flags: int = 0, sync: bool = True):
+        self._check(lib().mijpeg_reconstruct_batch_device(self._h, dst_ptr, frame_stride, row_stride, flags, 1 if sync else 0))
 
     def reconstruct_unsampled(self, comp: int, flags: int = 0) -> np.ndarray:
         """JPGTAG_DECODER_UPSAMPLE = false: component `comp` on its own sample grid, no colour transformation

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <new>
+#include <memory>
 #include <string>
 
 #include "../../include/mijpeg.h"
@@ -47,6 +48,10 @@ struct mijpeg_decoder {
   uint8_t *ent_host = nullptr; // pinned staging for offsets + tables + status
   size_t ent_host_cap = 0;
   bool host_planes_stale = false; // coefficients live on the device only
+  // batches (mijpeg_decode_batch_device): one parsed decoder per stream, frame 0's info with the batch's worst range
+  std::vector<std::unique_ptr<HostDecoder>> batch_hosts;
+  mijpeg_info batch_info{};
+  int batch_frames = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int err_code = 0;
@@ -182,6 +187,7 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   d->img_valid = false;
   d->uploaded = false;
   d->host_planes_stale = false;
+  d->batch_frames = 0;
 
   hipError_t copy_err = hipSuccess;
   std::function<void(int, int)> cb;
@@ -223,6 +229,10 @@ int64_t mijpeg_speculative_scans(int64_t *pieces)
 int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info)
 {
   if (!d || !info) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->batch_frames > 0) { // frame shape of the batch, range check of its most demanding image
+    *info = d->batch_info;
+    return MIJPEG_OK;
+  }
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
   *info = d->host.info;
   return MIJPEG_OK;
@@ -253,6 +263,195 @@ const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component)
 // ------------------------------------------------------------------------------------------------
 // on-device entropy decoding
 // ------------------------------------------------------------------------------------------------
+// Why a parsed stream cannot be entropy-decoded on the device (nullptr: it can).
+static const char *device_entropy_obstacle(const HostDecoder &h, size_t size)
+{
+  const mijpeg_info &f = h.info;
+  // one Huffman sequential scan over all components (or a single-component frame), 8 bit, restart markers
+  if (f.progressive || f.xt || f.precision != 8 || h.scans.size() != 1)
+    return "on-device entropy decoding needs a single-scan 8-bit Huffman sequential frame with enough restart intervals";
+  const Scan &s = h.scans[0];
+  if (s.restart_interval <= 0 || s.ncomp != f.components || size > 0xfffffff0ull)
+    return "on-device entropy decoding needs a single-scan 8-bit Huffman sequential frame with enough restart intervals";
+  return nullptr;
+}
+
+// Entropy-decode n parsed images of identical frame geometry on the device, image i into coef_dev + i * frame_stride.
+// infos[i] receives fast_arith / range_max.  Returns MIJPEG_OK, MIJPEG_ERR_NOT_AVAILABLE (nothing touched) or an error.
+static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, const uint8_t *const *datas, const size_t *sizes, int n,
+                                int min_intervals, int16_t *coef_dev, int64_t frame_stride)
+{
+  const mijpeg_info &f0 = hosts[0]->info;
+  const Scan &s0 = hosts[0]->scans[0];
+  int64_t total_intervals = 0;
+  std::vector<int64_t> nints((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const char *why = device_entropy_obstacle(*hosts[i], sizes[i]);
+    if (why) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+    const mijpeg_info &f = hosts[i]->info;
+    const Scan &s = hosts[i]->scans[0];
+    if (f.width != f0.width || f.height != f0.height || f.components != f0.components || memcmp(f.hsamp, f0.hsamp, sizeof(f.hsamp)) ||
+        memcmp(f.vsamp, f0.vsamp, sizeof(f.vsamp)))
+      return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the images of a batch must share width, height and sampling factors");
+    for (int k = 0; k < s.ncomp; k++)
+      if (s.sc[k].comp != s0.sc[k].comp) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the images of a batch must share the component order of their scan");
+    const int64_t total_mcus = (int64_t)s.mcus_x * s.mcus_y;
+    const int64_t nint = (total_mcus + s.restart_interval - 1) / s.restart_interval;
+    if (nint > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many restart intervals");
+    if ((int64_t)s.interval_begin.size() < nint)
+      return set_error(d, MIJPEG_ERR_UNEXPECTED_EOF, "entropy coded segment ends before all restart intervals were found");
+    const std::vector<uint8_t> &rst = hosts[i]->restart_codes(0);
+    for (int64_t k = 0; k + 1 < nint; k++)
+      if (rst[(size_t)k] != 0xd0 + (k & 7)) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "restart markers are out of sequence");
+    nints[(size_t)i] = nint;
+    total_intervals += nint;
+  }
+  if (min_intervals <= 0) min_intervals = 2048; // below this the device runs mostly idle
+  if (total_intervals < min_intervals || total_intervals > 0x7fffffff)
+    return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too few restart intervals to occupy the device");
+
+  HuffScanArgs a;
+  memset(&a, 0, sizeof(a));
+  // decoding lanes per wave: ~2048 waves keep the 1024 SIMDs busy; beyond that, fuller waves amortise the VALU
+  // (measured on 8K 4:2:0: 259200 intervals -> 64, 64800 -> 16, 32400 -> 8, 8100 -> 2..4)
+  a.lanes = 64;
+  while (a.lanes > 1 && total_intervals / a.lanes < 2048) a.lanes >>= 1;
+  if (const char *e = getenv("MIJPEG_HUFF_DEBUG")) a.debug = atoi(e);
+  if (const char *e = getenv("MIJPEG_HUFF_LANES")) { // tuning
+    const int l = atoi(e);
+    if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) a.lanes = l;
+  }
+  a.waves_per_group = a.lanes >= 32 ? 2 : 4;
+  const int per_group = a.lanes * a.waves_per_group; // intervals of one workgroup
+  const int ntab = 2 * s0.ncomp;
+  const size_t table_blob = (size_t)ntab * sizeof(HuffDevTable) + sizeof(HuffDevAux);
+
+  // device buffer: [streams, each padded][ibegin][iend][tables of every image][images][groups][status]
+  std::vector<size_t> stream_off((size_t)n);
+  size_t off = 0;
+  int64_t n_groups = 0;
+  for (int i = 0; i < n; i++) {
+    stream_off[(size_t)i] = off;
+    off += ((sizes[i] + 15) & ~(size_t)15) + HUFF_STREAM_PAD;
+    n_groups += (nints[(size_t)i] + per_group - 1) / per_group;
+  }
+  if (off > 0xfffffff0ull || n_groups > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "batch too large for one launch");
+  const size_t stream_bytes = off;
+  auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t off_ib = stream_bytes, off_ie = off_ib + (size_t)total_intervals * 4, off_tab = align16(off_ie + (size_t)total_intervals * 4);
+  const size_t off_img = align16(off_tab + (size_t)n * table_blob), off_grp = align16(off_img + (size_t)n * sizeof(HuffImage));
+  const size_t off_status = align16(off_grp + (size_t)n_groups * sizeof(HuffGroup)), status_bytes = (size_t)n * 32, total = off_status + status_bytes;
+  int rc = ensure_dev(d, (void **)&d->ent_dev, &d->ent_cap, total);
+  if (rc) return rc;
+  const size_t host_part = off_status - stream_bytes; // everything between the streams and the status words goes through pinned staging
+  if (d->ent_host_cap < host_part + status_bytes) {
+    if (d->ent_host) (void)hipHostFree(d->ent_host);
+    d->ent_host = nullptr;
+    d->ent_host_cap = 0;
+    HIP_TRY(d, hipHostMalloc((void **)&d->ent_host, host_part + status_bytes, hipHostMallocDefault));
+    d->ent_host_cap = host_part + status_bytes;
+  }
+  uint8_t *hp = d->ent_host - stream_bytes; // hp + device offset = staging address
+  uint32_t *ib = (uint32_t *)(hp + off_ib), *ie = (uint32_t *)(hp + off_ie);
+  HuffImage *images = (HuffImage *)(hp + off_img);
+  HuffGroup *groups = (HuffGroup *)(hp + off_grp);
+  int64_t first = 0, g = 0;
+  bool needs_clear = false;
+  for (int i = 0; i < n; i++) {
+    const mijpeg_info &f = hosts[i]->info;
+    const Scan &s = hosts[i]->scans[0];
+    const int64_t nint = nints[(size_t)i];
+    const std::vector<size_t> &iend = hosts[i]->interval_ends(0);
+    for (int64_t k = 0; k < nint; k++) { ib[first + k] = (uint32_t)s.interval_begin[(size_t)k]; ie[first + k] = (uint32_t)iend[(size_t)k]; }
+    HuffDevTable *tabs = (HuffDevTable *)(hp + off_tab + (size_t)i * table_blob);
+    HuffDevAux *aux = (HuffDevAux *)(tabs + ntab);
+    memset(aux, 0, sizeof(*aux));
+    for (int k = 0; k < s.ncomp; k++) {
+      const HuffTable *src[2] = {&s.dc[k], &s.ac[k]};
+      for (int t = 0; t < 2; t++) {
+        HuffDevTable &dst = tabs[2 * k + t];
+        memset(&dst, 0, sizeof(dst));
+        memcpy(dst.fast, src[t]->fast, sizeof(dst.fast));
+        if (t == 1) // AC: flag the symbols that only exist in progressive scans (EOB runs)
+          for (auto &e : dst.fast)
+            if (e && (e & 15) == 0 && (e & 0xff) != 0 && (e & 0xff) != 0xf0) e |= HUFF_DEV_INVALID;
+        memcpy(dst.maxcode, src[t]->maxcode, sizeof(dst.maxcode));
+        memcpy(dst.valoff, src[t]->valoff, sizeof(dst.valoff));
+        memcpy(dst.values, src[t]->values, sizeof(dst.values));
+      }
+      const int c = s.sc[k].comp;
+      const uint16_t *delta = f.quant[f.quant_index[c]];
+      for (int z = 0; z < 80; z++) {
+        const uint32_t pos = scan_order()[z];
+        aux->zq[k][z] = ((uint32_t)delta[pos] << 16) | (pos * 2);
+      }
+    }
+    HuffImage &im = images[i];
+    im.stream_off = (uint32_t)stream_off[(size_t)i];
+    im.first_interval = (uint32_t)first;
+    im.n_intervals = (int32_t)nint;
+    im.restart_interval = s.restart_interval;
+    im.total_mcus = s.mcus_x * s.mcus_y;
+    im.mcus_x = s.mcus_x;
+    im.coef_base = (int64_t)i * frame_stride;
+    im.table_off = (uint32_t)((size_t)i * table_blob);
+    im.status_off = (uint32_t)(i * 8);
+    for (int64_t k = 0; k < nint; k += per_group) {
+      groups[g].image = (uint32_t)i;
+      groups[g].first_interval = (uint32_t)k;
+      g++;
+    }
+    first += nint;
+    // an interleaved scan writes every block of every plane; a single-component scan of a frame whose only component
+    // has sampling factors > 1 leaves the MCU padding blocks untouched (they must read as zero)
+    if (s.ncomp == 1 && (s.mcus_x != f.blocks_w[s.sc[0].comp] || s.mcus_y != f.blocks_h[s.sc[0].comp])) needs_clear = true;
+  }
+  for (int k = 0; k < s0.ncomp; k++) {
+    const int c = s0.sc[k].comp;
+    a.comp_of[k] = c;
+    a.hs[k] = s0.ncomp > 1 ? f0.hsamp[c] : 1;
+    a.vs[k] = s0.ncomp > 1 ? f0.vsamp[c] : 1;
+    a.bw[k] = f0.blocks_w[c];
+    a.coef_off[k] = f0.coef_offset[c];
+    a.dc_tab[k] = 2 * k;
+    a.ac_tab[k] = 2 * k + 1;
+  }
+  a.data = d->ent_dev;
+  a.ibegin = (const uint32_t *)(d->ent_dev + off_ib);
+  a.iend = (const uint32_t *)(d->ent_dev + off_ie);
+  a.images = (const HuffImage *)(d->ent_dev + off_img);
+  a.groups = (const HuffGroup *)(d->ent_dev + off_grp);
+  a.n_groups = (int32_t)n_groups;
+  a.ncomp = s0.ncomp;
+  a.ntables = ntab;
+  a.tables = d->ent_dev + off_tab;
+  a.coef = coef_dev;
+  a.status = (uint32_t *)(d->ent_dev + off_status);
+  for (int i = 0; i < n; i++)
+    HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
+  if (needs_clear) HIP_TRY(d, hipMemsetAsync(coef_dev, 0, (size_t)n * (size_t)frame_stride * sizeof(int16_t), d->stream));
+  if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
+  if (const char *e = getenv("MIJPEG_HUFF_REPEAT")) // experiments: steady-state kernel time
+    for (int i = atoi(e); i > 1; i--) (void)launch_huffman_scan(a, d->stream);
+  uint32_t *status_host = (uint32_t *)(d->ent_host + host_part);
+  HIP_TRY(d, hipMemcpyAsync(status_host, d->ent_dev + off_status, status_bytes, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  for (int i = 0; i < n; i++) {
+    const uint32_t *st = status_host + 8 * i;
+    if (st[0] == HUFF_ERR_OVERFLOW) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
+    if (st[0]) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "entropy coded data is malformed (Huffman decoder out of sync)");
+    mijpeg_info &f = hosts[i]->info;
+    f.fast_arith = 1;
+    for (int c = 0; c < f.components; c++) {
+      f.range_max[c] = (int32_t)std::min<uint32_t>(st[1 + c], 0x7fffffffu);
+      if (f.range_max[c] >= 16384) f.fast_arith = 0;
+    }
+  }
+  return MIJPEG_OK;
+}
+
 int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
 {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
@@ -264,127 +463,106 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
   int rc = d->host.parse(d->data, d->size, false);
   if (rc) return set_error(d, rc, d->host.error.message);
   d->parsed = true;
+  d->batch_frames = 0;
   const auto t_parsed = clk::now();
-  mijpeg_info &f = d->host.info;
-  // eligibility: one Huffman sequential scan over all components (or a single-component frame), 8 bit, restart markers
-  const char *not_for_device = "on-device entropy decoding needs a single-scan 8-bit Huffman sequential frame with enough restart intervals";
-  if (f.progressive || f.xt || f.precision != 8 || d->host.scans.size() != 1) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, not_for_device);
-  const Scan &s = d->host.scans[0];
-  if (s.restart_interval <= 0 || s.ncomp != f.components) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, not_for_device);
-  const int64_t total_mcus = (int64_t)s.mcus_x * s.mcus_y;
-  const int64_t nint = (total_mcus + s.restart_interval - 1) / s.restart_interval;
-  if (min_intervals <= 0) min_intervals = 2048; // below this the device runs mostly idle
-  if (nint < min_intervals || nint > 0x7fffffff || d->size > 0xffffffffull) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, not_for_device);
-  if ((int64_t)s.interval_begin.size() < nint)
-    return set_error(d, MIJPEG_ERR_UNEXPECTED_EOF, "entropy coded segment ends before all restart intervals were found");
-  const std::vector<uint8_t> &rst = d->host.restart_codes(0);
-  for (int64_t i = 0; i + 1 < nint; i++)
-    if (rst[(size_t)i] != 0xd0 + (i & 7)) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "restart markers are out of sequence");
-  rc = ensure_coef_store(d, (size_t)f.coef_count, false);
+  if (const char *why = device_entropy_obstacle(d->host, d->size)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+  rc = ensure_coef_store(d, (size_t)d->host.info.coef_count, false);
   if (rc) return rc;
   d->img_valid = false;
   d->uploaded = false;
   d->decoded = false;
-
-  // device buffer: [stream bytes | pad][ibegin u32 x nint][iend u32 x nint][tables][status u32 x 8]
-  const size_t stream_bytes = ((d->size + 15) & ~(size_t)15) + HUFF_STREAM_PAD;
-  const size_t off_ib = stream_bytes, off_ie = off_ib + (size_t)nint * 4, off_tab = (off_ie + (size_t)nint * 4 + 15) & ~(size_t)15;
-  const int ntab = 2 * s.ncomp;
-  const size_t off_status = off_tab + (size_t)ntab * sizeof(HuffDevTable) + sizeof(HuffDevAux), total = off_status + 32;
-  rc = ensure_dev(d, (void **)&d->ent_dev, &d->ent_cap, total);
-  if (rc) return rc;
-  const size_t host_part = total - stream_bytes; // everything but the stream goes through pinned staging
-  if (d->ent_host_cap < host_part + 32) {
-    if (d->ent_host) (void)hipHostFree(d->ent_host);
-    d->ent_host = nullptr;
-    d->ent_host_cap = 0;
-    HIP_TRY(d, hipHostMalloc((void **)&d->ent_host, host_part + 32, hipHostMallocDefault));
-    d->ent_host_cap = host_part + 32;
-  }
-  uint32_t *ib = (uint32_t *)d->ent_host, *ie = ib + nint;
-  const std::vector<size_t> &iend = d->host.interval_ends(0);
-  for (int64_t i = 0; i < nint; i++) { ib[i] = (uint32_t)s.interval_begin[(size_t)i]; ie[i] = (uint32_t)iend[(size_t)i]; }
-  HuffDevTable *tabs = (HuffDevTable *)(d->ent_host + (off_tab - stream_bytes));
-  HuffDevAux *aux = (HuffDevAux *)(tabs + ntab);
-  memset(aux, 0, sizeof(*aux));
-  HuffScanArgs a;
-  memset(&a, 0, sizeof(a));
-  for (int k = 0; k < s.ncomp; k++) {
-    const HuffTable *src[2] = {&s.dc[k], &s.ac[k]};
-    for (int t = 0; t < 2; t++) {
-      HuffDevTable &dst = tabs[2 * k + t];
-      memset(&dst, 0, sizeof(dst));
-      memcpy(dst.fast, src[t]->fast, sizeof(dst.fast));
-      if (t == 1) // AC: flag the symbols that only exist in progressive scans (EOB runs)
-        for (auto &e : dst.fast)
-          if (e && (e & 15) == 0 && (e & 0xff) != 0 && (e & 0xff) != 0xf0) e |= HUFF_DEV_INVALID;
-      memcpy(dst.maxcode, src[t]->maxcode, sizeof(dst.maxcode));
-      memcpy(dst.valoff, src[t]->valoff, sizeof(dst.valoff));
-      memcpy(dst.values, src[t]->values, sizeof(dst.values));
-    }
-    const int c = s.sc[k].comp;
-    a.comp_of[k] = c;
-    a.hs[k] = s.ncomp > 1 ? f.hsamp[c] : 1;
-    a.vs[k] = s.ncomp > 1 ? f.vsamp[c] : 1;
-    a.bw[k] = f.blocks_w[c];
-    a.coef_off[k] = f.coef_offset[c];
-    a.dc_tab[k] = 2 * k;
-    a.ac_tab[k] = 2 * k + 1;
-    const uint16_t *delta = f.quant[f.quant_index[c]];
-    for (int i = 0; i < 80; i++) {
-      const uint32_t pos = scan_order()[i];
-      aux->zq[k][i] = ((uint32_t)delta[pos] << 16) | (pos * 2);
-    }
-  }
-  // decoding lanes per wave: ~2048 waves keep the 1024 SIMDs busy; beyond that, fuller waves amortise the VALU
-  // (measured on 8K 4:2:0: 259200 intervals -> 64, 64800 -> 16, 32400 -> 8, 8100 -> 2..4)
-  a.lanes = 64;
-  while (a.lanes > 1 && nint / a.lanes < 2048) a.lanes >>= 1;
-  if (const char *e = getenv("MIJPEG_HUFF_DEBUG")) a.debug = atoi(e);
-  if (const char *e = getenv("MIJPEG_HUFF_LANES")) { // tuning
-    const int l = atoi(e);
-    if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) a.lanes = l;
-  }
-  uint32_t *status_host = (uint32_t *)(d->ent_host + host_part);
-  a.data = d->ent_dev;
-  a.ibegin = (const uint32_t *)(d->ent_dev + off_ib);
-  a.iend = (const uint32_t *)(d->ent_dev + off_ie);
-  a.n_intervals = (int32_t)nint;
-  a.restart_interval = s.restart_interval;
-  a.total_mcus = (int32_t)total_mcus;
-  a.mcus_x = s.mcus_x;
-  a.ncomp = s.ncomp;
-  a.ntables = ntab;
-  a.tables = (const HuffDevTable *)(d->ent_dev + off_tab);
-  a.coef = d->coef_dev;
-  a.status = (uint32_t *)(d->ent_dev + off_status);
-  const auto t_prepared = clk::now();
-  HIP_TRY(d, hipMemcpyAsync(d->ent_dev, d->data, d->size, hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part - 32, hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, 32, d->stream));
-  // an interleaved scan writes every block of every plane; a single-component scan of a frame whose only component
-  // has sampling factors > 1 leaves the MCU padding blocks untouched (they must read as zero)
-  if (s.ncomp == 1 && (s.mcus_x != f.blocks_w[s.sc[0].comp] || s.mcus_y != f.blocks_h[s.sc[0].comp]))
-    HIP_TRY(d, hipMemsetAsync(d->coef_dev, 0, (size_t)f.coef_count * sizeof(int16_t), d->stream));
-  if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
-  if (const char *e = getenv("MIJPEG_HUFF_REPEAT")) // experiments: steady-state kernel time
-    for (int i = atoi(e); i > 1; i--) (void)launch_huffman_scan(a, d->stream);
-  HIP_TRY(d, hipMemcpyAsync(status_host, d->ent_dev + off_status, 32, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  HostDecoder *h = &d->host;
+  rc = device_entropy_batch(d, &h, &d->data, &d->size, 1, min_intervals, d->coef_dev, d->host.info.coef_count);
   d->timing[0] = std::chrono::duration<double>(clk::now() - t0).count();
-  d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count();       // header parse + restart marker search
-  d->timing[2] = std::chrono::duration<double>(t_prepared - t_parsed).count(); // tables and interval offsets
-  d->timing[3] = 0;
-  if (status_host[0] == HUFF_ERR_OVERFLOW) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
-  if (status_host[0]) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "entropy coded data is malformed (Huffman decoder out of sync)");
-  f.fast_arith = 1;
-  for (int c = 0; c < f.components; c++) {
-    f.range_max[c] = (int32_t)std::min<uint32_t>(status_host[1 + c], 0x7fffffffu);
-    if (f.range_max[c] >= 16384) f.fast_arith = 0;
-  }
+  d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count(); // header parse + restart marker search
+  d->timing[2] = d->timing[3] = 0;
+  if (rc) return rc;
   d->decoded = true;
   d->uploaded = true;
   d->host_planes_stale = true;
+  return MIJPEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batches: n streams of one geometry -> n coefficient stores -> n frames, two kernel launches in all
+// ------------------------------------------------------------------------------------------------
+int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)
+{
+  if (!d || !streams || !sizes || n < 1) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "decoder was created without a device");
+  HIP_TRY(d, hipSetDevice(d->device));
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  d->batch_frames = 0;
+  d->batch_hosts.resize((size_t)n);
+  for (auto &h : d->batch_hosts)
+    if (!h) h.reset(new HostDecoder());
+  // headers and restart markers of all streams, one stream per worker
+  std::vector<int> rcs((size_t)n, 0);
+  parallel_for(std::min(n, default_threads()), [&](int w) {
+    for (int i = w; i < n; i += std::min(n, default_threads())) rcs[(size_t)i] = d->batch_hosts[(size_t)i]->parse(streams[i], sizes[i], false);
+  });
+  for (int i = 0; i < n; i++)
+    if (rcs[(size_t)i]) return set_error(d, rcs[(size_t)i], d->batch_hosts[(size_t)i]->error.message);
+  const auto t_parsed = clk::now();
+  std::vector<HostDecoder *> hosts((size_t)n);
+  for (int i = 0; i < n; i++) hosts[(size_t)i] = d->batch_hosts[(size_t)i].get();
+  for (int i = 0; i < n; i++)
+    if (const char *why = device_entropy_obstacle(*hosts[(size_t)i], sizes[i])) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+  const mijpeg_info &f0 = hosts[0]->info;
+  for (int i = 1; i < n; i++) { // one reconstruction launch serves the batch: the deltas must agree too
+    const mijpeg_info &f = hosts[(size_t)i]->info;
+    for (int c = 0; c < f.components; c++)
+      if (memcmp(f.quant[f.quant_index[c]], f0.quant[f0.quant_index[c]], sizeof(f.quant[0])))
+        return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the images of a batch must share their quantisation tables");
+  }
+  int rc = ensure_coef_store(d, (size_t)f0.coef_count * (size_t)n, false);
+  if (rc) return rc;
+  d->img_valid = false;
+  d->uploaded = false;
+  d->decoded = false;
+  rc = device_entropy_batch(d, hosts.data(), streams, sizes, n, min_intervals, d->coef_dev, f0.coef_count);
+  d->timing[0] = std::chrono::duration<double>(clk::now() - t0).count();
+  d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count();
+  d->timing[2] = d->timing[3] = 0;
+  if (rc) return rc;
+  d->batch_info = f0;
+  d->batch_info.fast_arith = 1;
+  for (int i = 0; i < n; i++) { // the batch is as fast as its most demanding image
+    const mijpeg_info &f = hosts[(size_t)i]->info;
+    if (!f.fast_arith) d->batch_info.fast_arith = 0;
+    for (int c = 0; c < f.components; c++) d->batch_info.range_max[c] = std::max(d->batch_info.range_max[c], f.range_max[c]);
+  }
+  d->batch_frames = n;
+  return MIJPEG_OK;
+}
+
+int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags, int sync)
+{
+  if (!d || !dst_device) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->batch_frames < 1) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded batch: call mijpeg_decode_batch_device first");
+  HIP_TRY(d, hipSetDevice(d->device));
+  mijpeg_batch b;
+  memset(&b, 0, sizeof(b));
+  b.info = d->batch_info;
+  b.coef_dev = d->coef_dev;
+  b.coef_frame_stride = b.info.coef_count;
+  b.out_dev = (uint8_t *)dst_device;
+  b.out_row_stride = row_stride;
+  b.out_frame_stride = frame_stride;
+  b.frames = d->batch_frames;
+  b.flags = flags & ~(MIJPEG_FLAG_DEVICE_OUTPUT | MIJPEG_FLAG_NO_UPSAMPLING);
+  const size_t ws = mijpeg_workspace_bytes(&b);
+  if (ws) {
+    const int rc = ensure_dev(d, (void **)&d->ws_dev, &d->ws_cap, ws);
+    if (rc) return rc;
+    b.workspace = d->ws_dev;
+    b.workspace_bytes = d->ws_cap;
+  }
+  const int rc = mijpeg_launch_reconstruct(&b, d->stream);
+  if (rc) return set_error(d, rc, rc == MIJPEG_ERR_DEVICE ? std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError())
+                                                           : std::string("reconstruction not available for this batch"));
+  if (sync) HIP_TRY(d, hipStreamSynchronize(d->stream));
   return MIJPEG_OK;
 }
 

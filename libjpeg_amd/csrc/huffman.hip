@@ -221,45 +221,50 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
   const HuffDevAux *aux = reinterpret_cast<const HuffDevAux *>(lds_raw + a.ntables * sizeof(HuffDevTable));
   const int L = a.lanes, nwaves = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const HuffGroup grp = a.groups[blockIdx.x];
+  const HuffImage img = a.images[grp.image]; // uniform: scalar loads
   uint8_t *stage = lds_raw + table_bytes + wv * (L * LANE_LDS);                     // L x 128
   uint8_t *rings = stage + L * 128;                                                 // L x RING_PITCH
   uint32_t *blkno = reinterpret_cast<uint32_t *>(stage + L * (128 + RING_PITCH));   // L x 4 (of 16)
   {
-    // cooperative copy of the tables this scan uses, the deltas and the zigzag order (dwords); clear the slots
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables);
+    // cooperative copy of the image's tables, deltas and zigzag order (dwords); clear the slots
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables + img.table_off);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
     const int words = table_bytes / 4, rest = nwaves * L * LANE_LDS / 4;
     for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     for (int i = threadIdx.x; i < rest; i += blockDim.x) dst[words + i] = 0;
   }
   __syncthreads();
-  const int interval = (blockIdx.x * nwaves + wv) * L + lane;
-  const bool decoding = lane < L && interval < a.n_intervals;
+  const int interval = (int)grp.first_interval + wv * L + lane; // inside the image
+  const bool decoding = lane < L && interval < img.n_intervals;
   const int ln = lane & (L - 1);
+  const uint8_t *stream = a.data + img.stream_off;
+  int16_t *coef = a.coef + img.coef_base;
+  uint32_t *status = a.status + img.status_off;
 
   DevBits br; // lanes that do not decode never touch a ring (theirs would alias a decoding lane's)
-  br.base = a.data;
+  br.base = stream;
   br.ring = rings + ln * RING_PITCH;
   br.pos = br.end = br.fill = 0;
   br.rx0 = br.rx1 = 0;
   br.acc = 0;
   br.n = 0;
   br.parked = true;
-  if (decoding) br.open(a.data, rings + ln * RING_PITCH, a.ibegin[interval], a.iend[interval]);
+  if (decoding) br.open(stream, rings + ln * RING_PITCH, a.ibegin[img.first_interval + interval], a.iend[img.first_interval + interval]);
   // the next 32 bytes of the stream travel in registers for the duration of one block
   uint32_t pend_at = br.fill;
   u32x4 pend0 = br.fetch(pend_at), pend1 = br.fetch(pend_at + 16);
   int pred[4] = {0, 0, 0, 0};
   uint32_t qmax[4] = {0, 0, 0, 0};
   int err = 0;
-  const int m0 = interval * a.restart_interval;
+  const int m0 = interval * img.restart_interval;
   uint8_t *slot = stage + ln * 128;
   const int swz16 = (lane & 7) << 4;
-  for (int mi = 0; mi < a.restart_interval; mi++) {
+  for (int mi = 0; mi < img.restart_interval; mi++) {
     const int m = m0 + mi;
-    const bool live = decoding && m < a.total_mcus;
+    const bool live = decoding && m < img.total_mcus;
     if (__ballot(live && !err) == 0) break;
-    const int my = m / a.mcus_x, mx = m - my * a.mcus_x;
+    const int my = m / img.mcus_x, mx = m - my * img.mcus_x;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (k >= a.ncomp) break;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
             u32x4 *src = reinterpret_cast<u32x4 *>(stage + sl * 128 + ((ch ^ (sl & 7)) << 4));
             const u32x4 val = *src;
             *src = u32x4{0, 0, 0, 0};
-            if (b && !(a.debug & 1)) *reinterpret_cast<u32x4 *>(a.coef + ((size_t)(b - 1) << 6) + ch * 8) = val;
+            if (b && !(a.debug & 1)) *reinterpret_cast<u32x4 *>(coef + ((size_t)(b - 1) << 6) + ch * 8) = val;
           }
           wave_lds_sync();
           }
@@ -301,18 +306,17 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
         }
     }
   }
-  if (err) atomicMax(&a.status[0], (uint32_t)err);
+  if (err) atomicMax(&status[0], (uint32_t)err);
 #pragma unroll
   for (int k = 0; k < 4; k++)
-    if (k < a.ncomp && qmax[k]) atomicMax(&a.status[1 + a.comp_of[k]], qmax[k]);
+    if (k < a.ncomp && qmax[k]) atomicMax(&status[1 + a.comp_of[k]], qmax[k]);
 }
 
 int launch_huffman_scan(const HuffScanArgs &a, hipStream_t stream)
 {
-  if (a.n_intervals <= 0) return 0;
-  const int waves = (a.n_intervals + a.lanes - 1) / a.lanes, wpg = a.lanes >= 32 ? 2 : 4;
-  const size_t lds = (size_t)a.ntables * sizeof(HuffDevTable) + sizeof(HuffDevAux) + (size_t)wpg * a.lanes * LANE_LDS;
-  hipLaunchKernelGGL(huffman_scan_kernel, dim3((waves + wpg - 1) / wpg), dim3(64 * wpg), lds, stream, a);
+  if (a.n_groups <= 0) return 0;
+  const size_t lds = (size_t)a.ntables * sizeof(HuffDevTable) + sizeof(HuffDevAux) + (size_t)a.waves_per_group * a.lanes * LANE_LDS;
+  hipLaunchKernelGGL(huffman_scan_kernel, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -31,21 +31,40 @@ struct HuffDevAux {
 };
 static_assert(sizeof(HuffDevAux) % 16 == 0, "copied in dwords");
 
-struct HuffScanArgs {
-  const uint8_t *data;           // device copy of the codestream
-  const uint32_t *ibegin, *iend; // device: byte range of every restart interval
+// One image of a batch (device memory).  All images of a launch share the frame geometry (components, sampling, plane
+// sizes); stream bytes, restart interval, Huffman tables and deltas are per image.
+struct HuffImage {
+  uint32_t stream_off;       // byte offset of the image's codestream in `data` (16-byte aligned)
+  uint32_t first_interval;   // its first entry in ibegin / iend (whose offsets are relative to stream_off)
   int32_t n_intervals, restart_interval, total_mcus, mcus_x;
+  int64_t coef_base;         // int16 index of the image's coefficient store in `coef`
+  uint32_t table_off;        // byte offset (from `tables`) of its ntables HuffDevTable + one HuffDevAux
+  uint32_t status_off;       // dword index of its 8-dword status block in `status`
+};
+
+// A workgroup works on ONE image (the tables in its LDS are that image's): first interval of the group inside the image.
+struct HuffGroup {
+  uint32_t image, first_interval;
+};
+
+struct HuffScanArgs {
+  const uint8_t *data;           // device: codestreams of all images, each padded by HUFF_STREAM_PAD
+  const uint32_t *ibegin, *iend; // device: byte range of every restart interval, relative to the image's stream_off
+  const HuffImage *images;       // device
+  const HuffGroup *groups;       // device: one per workgroup
+  int32_t n_groups;
   int32_t ncomp;                 // components in the scan
   int32_t comp_of[4];            // frame component of scan component k
   int32_t hs[4], vs[4], bw[4];   // blocks per MCU and plane width in blocks, per scan component
-  int64_t coef_off[4];
-  int32_t dc_tab[4], ac_tab[4];  // indices into tables[]
+  int64_t coef_off[4];           // plane offsets inside an image's coefficient store
+  int32_t dc_tab[4], ac_tab[4];  // indices into the image's tables
   int32_t ntables;
   int32_t debug;                 // experiments only (MIJPEG_HUFF_DEBUG)
   int32_t lanes;                 // active lanes per wave (power of two, 1..64): fewer lanes = more waves, less divergence
-  const HuffDevTable *tables;    // device: ntables tables followed by one HuffDevAux
-  int16_t *coef;                 // frame base of the coefficient store (zeroed beforehand)
-  uint32_t *status;              // device: [0] error (0 = ok), [1 + c] max over blocks of sum |c| q for frame component c
+  int32_t waves_per_group;
+  const uint8_t *tables;         // device: per image ntables tables followed by one HuffDevAux
+  int16_t *coef;                 // coefficient stores
+  uint32_t *status;              // device: per image [0] error (0 = ok), [1 + c] max over blocks of sum |c| q for frame component c
 };
 
 int launch_huffman_scan(const HuffScanArgs &a, hipStream_t stream);

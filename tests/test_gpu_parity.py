@@ -713,3 +713,46 @@ def test_cli_cmyk_writes_pgx_planes(tmp_path):
         assert (tmp_path / ("out_%d.h" % k)).read_text() == "PG ML +8 90 60\n"
         got = np.frombuffer((tmp_path / ("out_%d.raw" % k)).read_bytes(), np.uint8).reshape(60, 90)
         assert np.array_equal(got, exp[..., k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batches: n streams -> one Huffman kernel launch -> one reconstruction launch (mijpeg_decode_batch_device)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,sub,ri,n", [(640, 480, "420", 2, 7), (333, 211, "444", 1, 5), (512, 256, "422", 4, 3), (1920, 1080, "420", 8, 16)])
+def test_batch_decode_on_the_device(oracle, w, h, sub, ri, n):
+    torch = _torch()
+    imgs = [synth.synth_image(w, h, 300 + i) for i in range(n)]
+    # optimised Huffman tables differ from image to image; the quantisation tables (same quality) do not
+    streams = [synth.encode_jpeg(im, 88, sub, restart_mcus=ri, optimize=(i % 2 == 1)) for i, im in enumerate(imgs)]
+    d = api.Decoder(0)
+    info = d.decode_batch_device(streams, min_intervals=1)
+    row = w * 3
+    out = torch.zeros((n, h, row), dtype=torch.uint8, device="cuda")
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row)
+    res = out.cpu().numpy().reshape(n, h, w, 3)
+    for i in range(n):
+        assert np.array_equal(res[i], oracle.decode(streams[i])), i
+    # the decoder object goes back to single images afterwards
+    one = d.read(streams[0])
+    assert np.array_equal(d.reconstruct(), res[0])
+    d.close()
+
+
+def test_batch_decode_rejects_what_is_not_a_batch():
+    d = api.Decoder(0)
+    a = synth.synth_jpeg(320, 240, 1, 85, "420", 2)
+    for other in (synth.synth_jpeg(336, 240, 1, 85, "420", 2),   # another width
+                  synth.synth_jpeg(320, 240, 1, 60, "420", 2),   # other quantisation tables
+                  synth.synth_jpeg(320, 240, 1, 85, "444", 2),   # another sampling
+                  synth.synth_jpeg(320, 240, 1, 85, "420", 0)):  # no restart markers
+        with pytest.raises(api.MijpegError) as e:
+            d.decode_batch_device([a, other], min_intervals=1)
+        assert e.value.code == api.ERR_NOT_AVAILABLE
+    bad = bytearray(a)
+    bad[len(bad) // 2] ^= 0x5A
+    bad[len(bad) // 2 + 1] = 0xFF
+    bad[len(bad) // 2 + 2] = 0xD9  # an EOI in the middle of the data: restart intervals go missing
+    with pytest.raises(api.MijpegError) as e:
+        d.decode_batch_device([a, bytes(bad)], min_intervals=1)
+    assert e.value.code != api.ERR_NOT_AVAILABLE
+    d.close()

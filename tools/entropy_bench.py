@@ -46,3 +46,22 @@ for th in (1, 4, 16, 64):
         ts.append(time.perf_counter() - t0)
     print(f"threads_sweep no-DRI 8K: threads={th:3d} read {min(ts)*1e3:.2f} ms  speculative scans/pieces so far {api.speculative_scans()}", flush=True)
     d.close()
+
+
+# batches of frames on the device: one Huffman launch + one reconstruction launch for n frames, pixels left in HBM
+import torch
+frames = [synth.encode_jpeg(synth.synth_image(W, H, 2000 + i), 85, "420", restart_mcus=8) for i in range(4)]
+for n in (1, 4, 16, 32):
+    batch = [frames[i % 4] for i in range(n)]
+    d = api.Decoder(0)
+    out = torch.empty((n, H, W * 3), dtype=torch.uint8, device="cuda")
+    ts, tp = [], []
+    for it in range(4):
+        t0 = time.perf_counter()
+        d.decode_batch_device(batch)
+        t1 = time.perf_counter()
+        d.reconstruct_batch_device(out.data_ptr(), H * W * 3, W * 3)
+        ts.append(time.perf_counter() - t0)
+        tp.append(d.timing()["h2d_wait"])
+    print(f"batch of {n:2d} 8K frames (DRI 8): {min(ts)*1e3:7.2f} ms = {min(ts)*1e3/n:.3f} ms per frame, {W*H*n/min(ts)/1e6:8.0f} Mpixel/s (host parse {min(tp)*1e3:.2f} ms)", flush=True)
+    d.close()
