@@ -48,6 +48,11 @@ struct mijpeg_decoder {
   uint8_t *ent_host = nullptr; // pinned staging for offsets + tables + status
   size_t ent_host_cap = 0;
   bool host_planes_stale = false; // coefficients live on the device only
+  double phase_prepare = 0, phase_device = 0; // last device entropy decode: host tables / upload + kernel
+  hipStream_t copy_stream = nullptr;          // uploads of a batch's streams, ahead of the kernels that decode them
+  std::vector<hipEvent_t> copy_events;
+  uint8_t *stage_host = nullptr;  // pinned gathering area for the streams of a batch
+  size_t stage_cap = 0;
   // batches (mijpeg_decode_batch_device): one parsed decoder per stream, frame 0's info with the batch's worst range
   std::vector<std::unique_ptr<HostDecoder>> batch_hosts;
   mijpeg_info batch_info{};
@@ -117,6 +122,9 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->ws_dev) (void)hipFree(d->ws_dev);
     if (d->ent_dev) (void)hipFree(d->ent_dev);
     if (d->ent_host) (void)hipHostFree(d->ent_host);
+    if (d->stage_host) (void)hipHostFree(d->stage_host);
+    for (hipEvent_t e : d->copy_events) (void)hipEventDestroy(e);
+    if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -285,6 +293,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   const Scan &s0 = hosts[0]->scans[0];
   int64_t total_intervals = 0;
   std::vector<int64_t> nints((size_t)n);
+  const auto tb0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n; i++) {
     const char *why = device_entropy_obstacle(*hosts[i], sizes[i]);
     if (why) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
@@ -427,17 +436,70 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   a.tables = d->ent_dev + off_tab;
   a.coef = coef_dev;
   a.status = (uint32_t *)(d->ent_dev + off_status);
-  for (int i = 0; i < n; i++)
-    HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
+  const auto tb1 = std::chrono::steady_clock::now();
   HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part, hipMemcpyHostToDevice, d->stream));
   HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
   if (needs_clear) HIP_TRY(d, hipMemsetAsync(coef_dev, 0, (size_t)n * (size_t)frame_stride * sizeof(int16_t), d->stream));
-  if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
-  if (const char *e = getenv("MIJPEG_HUFF_REPEAT")) // experiments: steady-state kernel time
-    for (int i = atoi(e); i > 1; i--) (void)launch_huffman_scan(a, d->stream);
+  const int repeat = getenv("MIJPEG_HUFF_REPEAT") ? atoi(getenv("MIJPEG_HUFF_REPEAT")) : 1; // experiments: steady-state kernel time
+  if (n == 1 || stream_bytes < ((size_t)8 << 20)) {
+    for (int i = 0; i < n; i++)
+      HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
+    for (int r = 0; r < std::max(1, repeat); r++)
+      if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
+  } else {
+    // large batches, in up to eight groups of images: the pool threads gather a group's streams into pinned memory, its
+    // DMA runs on a copy stream while the next group is gathered and while the kernel decodes the previous one
+    if (d->stage_cap < stream_bytes) {
+      if (d->stage_host) (void)hipHostFree(d->stage_host);
+      d->stage_host = nullptr;
+      d->stage_cap = 0;
+      HIP_TRY(d, hipHostMalloc((void **)&d->stage_host, stream_bytes, hipHostMallocDefault));
+      d->stage_cap = stream_bytes;
+    }
+    if (!d->copy_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    const int groups_of = std::max(4, (n + 7) / 8); // at least four images per launch keep the waves full
+    const int ngroups = (n + groups_of - 1) / groups_of;
+    while ((int)d->copy_events.size() < ngroups) {
+      hipEvent_t e;
+      HIP_TRY(d, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      d->copy_events.push_back(e);
+    }
+    // the copy stream must not overtake work that still reads the buffer from an earlier call
+    HIP_TRY(d, hipEventRecord(d->ev0, d->stream));
+    HIP_TRY(d, hipStreamWaitEvent(d->copy_stream, d->ev0, 0));
+    int64_t wg0 = 0;
+    for (int gi = 0, g0 = 0; g0 < n; g0 += groups_of, gi++) {
+      const int g1 = std::min(n, g0 + groups_of);
+      std::vector<std::pair<int, size_t>> pieces; // image, offset: 1 MiB pieces spread over the workers
+      for (int i = g0; i < g1; i++)
+        for (size_t o = 0; o < sizes[i]; o += (size_t)1 << 20) pieces.emplace_back(i, o);
+      const int workers = std::min<int>((int)pieces.size(), std::min(default_threads(), 16));
+      parallel_for(workers, [&](int w) {
+        for (size_t k = (size_t)w; k < pieces.size(); k += (size_t)workers) {
+          const int i = pieces[k].first;
+          const size_t o = pieces[k].second, len = std::min<size_t>((size_t)1 << 20, sizes[i] - o);
+          memcpy(d->stage_host + stream_off[(size_t)i] + o, datas[i] + o, len);
+        }
+      });
+      const size_t b0 = stream_off[(size_t)g0], b1 = g1 < n ? stream_off[(size_t)g1] : stream_bytes;
+      HIP_TRY(d, hipMemcpyAsync(d->ent_dev + b0, d->stage_host + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
+      HIP_TRY(d, hipEventRecord(d->copy_events[(size_t)gi], d->copy_stream));
+      HIP_TRY(d, hipStreamWaitEvent(d->stream, d->copy_events[(size_t)gi], 0));
+      int64_t wg1 = wg0;
+      for (int i = g0; i < g1; i++) wg1 += (nints[(size_t)i] + per_group - 1) / per_group;
+      HuffScanArgs part = a; // the workgroups of this group's images
+      part.groups = a.groups + wg0;
+      part.n_groups = (int32_t)(wg1 - wg0);
+      for (int r = 0; r < std::max(1, repeat); r++)
+        if (launch_huffman_scan(part, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
+      wg0 = wg1;
+    }
+  }
   uint32_t *status_host = (uint32_t *)(d->ent_host + host_part);
   HIP_TRY(d, hipMemcpyAsync(status_host, d->ent_dev + off_status, status_bytes, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(d, hipStreamSynchronize(d->stream));
+  d->phase_prepare = std::chrono::duration<double>(tb1 - tb0).count();                              // interval tables, Huffman tables
+  d->phase_device = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb1).count();  // upload + kernel + status
   for (int i = 0; i < n; i++) {
     const uint32_t *st = status_host + 8 * i;
     if (st[0] == HUFF_ERR_OVERFLOW) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
@@ -524,7 +586,8 @@ int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams,
   rc = device_entropy_batch(d, hosts.data(), streams, sizes, n, min_intervals, d->coef_dev, f0.coef_count);
   d->timing[0] = std::chrono::duration<double>(clk::now() - t0).count();
   d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count();
-  d->timing[2] = d->timing[3] = 0;
+  d->timing[2] = d->phase_prepare;
+  d->timing[3] = d->phase_device;
   if (rc) return rc;
   d->batch_info = f0;
   d->batch_info.fast_arith = 1;
