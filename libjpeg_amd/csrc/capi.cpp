@@ -279,7 +279,7 @@ static const char *device_entropy_obstacle(const HostDecoder &h, size_t size)
   if (f.progressive || f.xt || f.precision != 8 || h.scans.size() != 1)
     return "on-device entropy decoding needs a single-scan 8-bit Huffman sequential frame with enough restart intervals";
   const Scan &s = h.scans[0];
-  if (s.restart_interval <= 0 || s.ncomp != f.components || size > 0xfffffff0ull)
+  if (s.ncomp != f.components || size > 0xfffffff0ull)
     return "on-device entropy decoding needs a single-scan 8-bit Huffman sequential frame with enough restart intervals";
   return nullptr;
 }
@@ -293,6 +293,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   const Scan &s0 = hosts[0]->scans[0];
   int64_t total_intervals = 0;
   std::vector<int64_t> nints((size_t)n);
+  std::vector<std::unique_ptr<VirtualIntervals>> virt((size_t)n);
   const auto tb0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n; i++) {
     const char *why = device_entropy_obstacle(*hosts[i], sizes[i]);
@@ -305,13 +306,24 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     for (int k = 0; k < s.ncomp; k++)
       if (s.sc[k].comp != s0.sc[k].comp) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the images of a batch must share the component order of their scan");
     const int64_t total_mcus = (int64_t)s.mcus_x * s.mcus_y;
-    const int64_t nint = (total_mcus + s.restart_interval - 1) / s.restart_interval;
-    if (nint > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many restart intervals");
-    if ((int64_t)s.interval_begin.size() < nint)
-      return set_error(d, MIJPEG_ERR_UNEXPECTED_EOF, "entropy coded segment ends before all restart intervals were found");
-    const std::vector<uint8_t> &rst = hosts[i]->restart_codes(0);
-    for (int64_t k = 0; k + 1 < nint; k++)
-      if (rst[(size_t)k] != 0xd0 + (k & 7)) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "restart markers are out of sequence");
+    int64_t nint;
+    if (s.restart_interval > 0) {
+      nint = (total_mcus + s.restart_interval - 1) / s.restart_interval;
+      if (nint > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many restart intervals");
+      if ((int64_t)s.interval_begin.size() < nint)
+        return set_error(d, MIJPEG_ERR_UNEXPECTED_EOF, "entropy coded segment ends before all restart intervals were found");
+      const std::vector<uint8_t> &rst = hosts[i]->restart_codes(0);
+      for (int64_t k = 0; k + 1 < nint; k++)
+        if (rst[(size_t)k] != 0xd0 + (k & 7)) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "restart markers are out of sequence");
+    } else {
+      // no restart markers: the host's self-synchronising walk finds exact restart points ("virtual intervals"),
+      // about 16 K of them, and the device decodes from there
+      virt[(size_t)i].reset(new VirtualIntervals());
+      const int per = (int)std::min<int64_t>(64, std::max<int64_t>(1, total_mcus / 16384));
+      if (total_mcus < 256 || hosts[i]->plan_virtual_intervals(0, per, 0, *virt[(size_t)i]))
+        return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "stream without restart markers did not lend itself to speculative decoding");
+      nint = (int64_t)virt[(size_t)i]->byte_off.size();
+    }
     nints[(size_t)i] = nint;
     total_intervals += nint;
   }
@@ -347,7 +359,11 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   if (off > 0xfffffff0ull || n_groups > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "batch too large for one launch");
   const size_t stream_bytes = off;
   auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-  const size_t off_ib = stream_bytes, off_ie = off_ib + (size_t)total_intervals * 4, off_tab = align16(off_ie + (size_t)total_intervals * 4);
+  bool any_virtual = false;
+  for (int i = 0; i < n; i++) any_virtual |= virt[(size_t)i] != nullptr;
+  const size_t off_ib = stream_bytes, off_ie = off_ib + (size_t)total_intervals * 4;
+  const size_t off_isk = off_ie + (size_t)total_intervals * 4, off_ipr = align16(off_isk + (any_virtual ? (size_t)total_intervals : 0));
+  const size_t off_tab = align16(off_ipr + (any_virtual ? (size_t)total_intervals * 8 : 0));
   const size_t off_img = align16(off_tab + (size_t)n * table_blob), off_grp = align16(off_img + (size_t)n * sizeof(HuffImage));
   const size_t off_status = align16(off_grp + (size_t)n_groups * sizeof(HuffGroup)), status_bytes = (size_t)n * 32, total = off_status + status_bytes;
   int rc = ensure_dev(d, (void **)&d->ent_dev, &d->ent_cap, total);
@@ -371,7 +387,20 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     const Scan &s = hosts[i]->scans[0];
     const int64_t nint = nints[(size_t)i];
     const std::vector<size_t> &iend = hosts[i]->interval_ends(0);
-    for (int64_t k = 0; k < nint; k++) { ib[first + k] = (uint32_t)s.interval_begin[(size_t)k]; ie[first + k] = (uint32_t)iend[(size_t)k]; }
+    if (virt[(size_t)i]) {
+      const VirtualIntervals &vi = *virt[(size_t)i];
+      uint8_t *isk = hp + off_isk;
+      int16_t *ipr = (int16_t *)(hp + off_ipr);
+      for (int64_t k = 0; k < nint; k++) {
+        ib[first + k] = vi.byte_off[(size_t)k];
+        ie[first + k] = (uint32_t)s.ecs_end;
+        isk[first + k] = vi.bit_skip[(size_t)k];
+        memcpy(ipr + (first + k) * 4, &vi.pred[(size_t)k * 4], 8);
+      }
+    } else {
+      for (int64_t k = 0; k < nint; k++) { ib[first + k] = (uint32_t)s.interval_begin[(size_t)k]; ie[first + k] = (uint32_t)iend[(size_t)k]; }
+      if (any_virtual) memset(hp + off_isk + first, 0, (size_t)nint);
+    }
     HuffDevTable *tabs = (HuffDevTable *)(hp + off_tab + (size_t)i * table_blob);
     HuffDevAux *aux = (HuffDevAux *)(tabs + ntab);
     memset(aux, 0, sizeof(*aux));
@@ -399,7 +428,9 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     im.stream_off = (uint32_t)stream_off[(size_t)i];
     im.first_interval = (uint32_t)first;
     im.n_intervals = (int32_t)nint;
-    im.restart_interval = s.restart_interval;
+    im.restart_interval = virt[(size_t)i] ? virt[(size_t)i]->mcus_per_interval : s.restart_interval;
+    im.virt = virt[(size_t)i] ? 1u : 0u;
+    im.reserved = 0;
     im.total_mcus = s.mcus_x * s.mcus_y;
     im.mcus_x = s.mcus_x;
     im.coef_base = (int64_t)i * frame_stride;
@@ -428,6 +459,8 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   a.data = d->ent_dev;
   a.ibegin = (const uint32_t *)(d->ent_dev + off_ib);
   a.iend = (const uint32_t *)(d->ent_dev + off_ie);
+  a.iskip = d->ent_dev + off_isk;
+  a.ipred = (const int16_t *)(d->ent_dev + off_ipr);
   a.images = (const HuffImage *)(d->ent_dev + off_img);
   a.groups = (const HuffGroup *)(d->ent_dev + off_grp);
   a.n_groups = (int32_t)n_groups;

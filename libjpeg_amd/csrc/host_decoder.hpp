@@ -67,6 +67,16 @@ struct XtBox {
   std::vector<uint8_t> data;
 };
 
+// "Virtual restart intervals" of a scan without restart markers: exact restart points (byte, bits to skip, DC
+// predictors) every mcus_per_interval MCUs, found by the self-synchronising walk of the host decoder; the device
+// kernel then decodes the scan as if it had restart markers there.
+struct VirtualIntervals {
+  int mcus_per_interval = 0;
+  std::vector<uint32_t> byte_off; // offset into the stream of the first byte to load
+  std::vector<uint8_t> bit_skip;  // bits of that byte that belong to the previous block (0..7)
+  std::vector<int16_t> pred;      // 4 per interval: DC predictors of the scan components
+};
+
 class HostDecoder {
 public:
   HostDecoder();
@@ -80,6 +90,10 @@ public:
   // bands of frame MCU rows become final (while later bands are still being decoded when the
   // last scan is interleaved; otherwise once at the end).  Used for streaming uploads; may be empty.
   int decode(int16_t *coef, int threads, const std::function<void(int, int)> &on_rows_done);
+
+  // Walk scan `scan` (Huffman sequential, no restart markers needed) speculatively in parallel and return its virtual
+  // restart intervals; nonzero if the scan does not lend itself to it (the caller then decodes on the host).
+  int plan_virtual_intervals(size_t scan, int mcus_per_interval, int threads, VirtualIntervals &out);
 
   mijpeg_info info{};
   // restart-interval byte ranges of scan i (valid after parse(..., false)): [interval_begin[k], interval_ends(i)[k])
@@ -119,7 +133,8 @@ private:
   int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
   int parse_dht(const uint8_t *q, int len);
   template <class T> int decode_t(T *coef, int threads, const std::function<void(int, int)> &on_rows_done);
-  template <class T> int decode_scan_speculative(T *coef, const Scan &s, int threads, uint32_t (&qmax_out)[MIJPEG_MAX_COMPONENTS]);
+  template <class T> int decode_scan_speculative(T *coef, const Scan &s, int threads, uint32_t (&qmax_out)[MIJPEG_MAX_COMPONENTS],
+                                                 VirtualIntervals *plan_only = nullptr);
   int fail(int code, const char *msg);
   int parse_sof(const uint8_t *p, int n);
   int frame_geometry();

@@ -251,10 +251,17 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
   br.n = 0;
   br.parked = true;
   if (decoding) br.open(stream, rings + ln * RING_PITCH, a.ibegin[img.first_interval + interval], a.iend[img.first_interval + interval]);
+  int pred[4] = {0, 0, 0, 0};
+  if (img.virt && decoding) { // a restart point found by the host's walk: mid-byte, with the predictors accumulated so far
+    const uint32_t idx = img.first_interval + (uint32_t)interval;
+    br.refill();
+    br.skip(a.iskip[idx]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) pred[k] = a.ipred[idx * 4 + k];
+  }
   // the next 32 bytes of the stream travel in registers for the duration of one block
   uint32_t pend_at = br.fill;
   u32x4 pend0 = br.fetch(pend_at), pend1 = br.fetch(pend_at + 16);
-  int pred[4] = {0, 0, 0, 0};
   uint32_t qmax[4] = {0, 0, 0, 0};
   int err = 0;
   const int m0 = interval * img.restart_interval;

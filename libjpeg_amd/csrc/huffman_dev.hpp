@@ -40,6 +40,8 @@ struct HuffImage {
   int64_t coef_base;         // int16 index of the image's coefficient store in `coef`
   uint32_t table_off;        // byte offset (from `tables`) of its ntables HuffDevTable + one HuffDevAux
   uint32_t status_off;       // dword index of its 8-dword status block in `status`
+  uint32_t virt;             // 1: the intervals are virtual (no markers): start `iskip` bits into the byte, predictors from `ipred`
+  uint32_t reserved;
 };
 
 // A workgroup works on ONE image (the tables in its LDS are that image's): first interval of the group inside the image.
@@ -50,6 +52,8 @@ struct HuffGroup {
 struct HuffScanArgs {
   const uint8_t *data;           // device: codestreams of all images, each padded by HUFF_STREAM_PAD
   const uint32_t *ibegin, *iend; // device: byte range of every restart interval, relative to the image's stream_off
+  const uint8_t *iskip;          // device, virtual intervals: bits to drop in front of the first block
+  const int16_t *ipred;          // device, virtual intervals: DC predictors, four per interval
   const HuffImage *images;       // device
   const HuffGroup *groups;       // device: one per workgroup
   int32_t n_groups;

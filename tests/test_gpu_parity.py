@@ -756,3 +756,19 @@ def test_batch_decode_rejects_what_is_not_a_batch():
         d.decode_batch_device([a, bytes(bad)], min_intervals=1)
     assert e.value.code != api.ERR_NOT_AVAILABLE
     d.close()
+
+
+@pytest.mark.parametrize("w,h,sub,q", [(3840, 2160, "420", 85), (2560, 1440, "444", 95), (2048, 2048, "gray", 90)])
+def test_device_entropy_decoder_without_restart_markers(dec, w, h, sub, q):
+    """No DRI: the host's self-synchronising walk supplies exact restart points (bit offset + DC predictors) and the
+    device kernel decodes from them; coefficients and pixels must equal the host decoder's."""
+    img = synth.synth_image(w, h, 12, channels=1 if sub == "gray" else 3)
+    data = synth.encode_jpeg(img, q, sub if sub != "gray" else "444")
+    host = api.Decoder(0)
+    hi = host.read(data)
+    gi = dec.read(data, entropy="gpu")
+    assert dec.entropy_used == "gpu"
+    assert gi.fast_arith == hi.fast_arith and list(gi.range_max) == list(hi.range_max)
+    assert np.array_equal(dec.reconstruct(), host.reconstruct())
+    _same_coefficients(dec, host, hi.components)
+    host.close()

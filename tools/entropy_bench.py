@@ -48,6 +48,16 @@ for th in (1, 4, 16, 64):
     d.close()
 
 
+d = api.Decoder(0)
+for mode in ("host", "gpu"):
+    ts = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        d.read(data, entropy=mode)
+        ts.append(time.perf_counter() - t0)
+    print(f"no-DRI 8K to coefficients in HBM, entropy={mode}: {min(ts)*1e3:.2f} ms", flush=True)
+d.close()
+
 # batches of frames on the device: one Huffman launch + one reconstruction launch for n frames, pixels left in HBM
 import torch
 frames = [synth.encode_jpeg(synth.synth_image(W, H, 2000 + i), 85, "420", restart_mcus=8) for i in range(4)]
