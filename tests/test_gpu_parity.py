@@ -772,3 +772,30 @@ def test_device_entropy_decoder_without_restart_markers(dec, w, h, sub, q):
     assert np.array_equal(dec.reconstruct(), host.reconstruct())
     _same_coefficients(dec, host, hi.components)
     host.close()
+
+
+def test_randomised_streams_through_every_entry_path(oracle):
+    """60 seeded random streams (size, sampling, quality, restart interval, optimised tables, progressive, grey) through the
+    decoder object with entropy = host / auto, against the oracle; sizes small enough for the oracle to stay fast."""
+    rng = np.random.default_rng(20260925)
+    d = api.Decoder(0)
+    for t in range(60):
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        sub = ["444", "422", "420", "gray"][int(rng.integers(0, 4))]
+        q = int(rng.choice([5, 30, 50, 75, 90, 98]))
+        dri = int(rng.choice([0, 0, 1, 2, 5, 16]))
+        prog = bool(rng.integers(0, 5) == 0)
+        opt = bool(rng.integers(0, 2))
+        img = synth.synth_image(w, h, 1000 + t, channels=1 if sub == "gray" else 3)
+        if rng.integers(0, 3) == 0:  # noise: dense coefficients, many 0xFF bytes in the stream
+            img = rng.integers(0, 256, img.shape).astype(np.uint8)
+        try:
+            data = synth.encode_jpeg(img, q, sub if sub != "gray" else "444", restart_mcus=dri, optimize=opt, progressive=prog)
+        except OSError:  # Pillow refuses a few combinations (tiny images with restart markers)
+            continue
+        exp = oracle.decode(data)
+        for mode in ("host", "auto"):
+            d.read(data, threads=int(rng.integers(1, 9)), entropy=mode)
+            got = d.reconstruct()
+            assert got.shape == exp.shape and np.array_equal(got, exp), (t, w, h, sub, q, dri, prog, opt, mode, d.entropy_used)
+    d.close()
