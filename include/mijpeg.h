@@ -197,6 +197,10 @@ int mijpeg_last_error(mijpeg_decoder *d, const char **message);
  * speculative decoding) since the library was loaded; *pieces (may be NULL) = ranges they were stitched from. */
 int64_t mijpeg_speculative_scans(int64_t *pieces);
 
+/* Diagnostics: rounds the on-device self-synchronising walk needed in the last device entropy decode of streams
+ * without restart markers (0: no such walk took place, e.g. the streams had restart markers). */
+int mijpeg_device_walk_rounds(mijpeg_decoder *d);
+
 /* Seconds spent in the phases of the last decode (huffman, h2d, kernel, d2h) -- diagnostics. */
 int mijpeg_last_timing(mijpeg_decoder *d, double out_seconds[4]);
 

@@ -102,6 +102,8 @@ def lib():
         L.mijpeg_decode_coefficients_device.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]
         L.mijpeg_reconstruct_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_int]
+        L.mijpeg_device_walk_rounds.argtypes = [C.c_void_p]
+        L.mijpeg_device_walk_rounds.restype = C.c_int
         L.mijpeg_speculative_scans.argtypes = [C.POINTER(C.c_int64)]
         L.mijpeg_speculative_scans.restype = C.c_int64
         L.mijpeg_coefficients.argtypes = [C.c_void_p, C.c_int]
@@ -183,6 +185,10 @@ class Decoder:
         self._check(lib().mijpeg_get_info(self._h, C.byref(info)))
         self.info = info
         return info
+
+    def device_walk_rounds(self) -> int:
+        """Rounds the on-device self-synchronising walk took in the last device entropy decode (0 = none needed)."""
+        return int(lib().mijpeg_device_walk_rounds(self._h))
 
     def xt_params(self) -> MijpegXtParams:
         xt = MijpegXtParams()

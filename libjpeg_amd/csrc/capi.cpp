@@ -49,6 +49,10 @@ struct mijpeg_decoder {
   size_t ent_host_cap = 0;
   bool host_planes_stale = false; // coefficients live on the device only
   double phase_prepare = 0, phase_device = 0; // last device entropy decode: host tables / upload + kernel
+  uint8_t *walk_dev = nullptr, *walk_host = nullptr; // state of the device walk over streams without restart markers
+  size_t walk_cap = 0, walk_host_cap = 0;
+  int walk_rounds = 0;
+  uint32_t *walk_status_dev = nullptr;
   hipStream_t copy_stream = nullptr;          // uploads of a batch's streams, ahead of the kernels that decode them
   std::vector<hipEvent_t> copy_events;
   uint8_t *stage_host = nullptr;  // pinned gathering area for the streams of a batch
@@ -123,6 +127,8 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->ent_dev) (void)hipFree(d->ent_dev);
     if (d->ent_host) (void)hipHostFree(d->ent_host);
     if (d->stage_host) (void)hipHostFree(d->stage_host);
+    if (d->walk_dev) (void)hipFree(d->walk_dev);
+    if (d->walk_host) (void)hipHostFree(d->walk_host);
     for (hipEvent_t e : d->copy_events) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -234,6 +240,8 @@ int64_t mijpeg_speculative_scans(int64_t *pieces)
   return g_speculative_scans.load();
 }
 
+int mijpeg_device_walk_rounds(mijpeg_decoder *d) { return d ? d->walk_rounds : 0; }
+
 int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info)
 {
   if (!d || !info) return MIJPEG_ERR_INVALID_PARAMETER;
@@ -284,6 +292,179 @@ static const char *device_entropy_obstacle(const HostDecoder &h, size_t size)
   return nullptr;
 }
 
+// Streams without restart markers: find their virtual restart intervals on the device.  Rounds of huffman_walk_kernel
+// until the hand-over states between neighbouring subsequences stop changing, prefix sums over the subsequences
+// (block numbers, DC predictors: huffman_walk_scan_kernel), and one EMIT walk that writes the interval tables the
+// decode kernel reads.  The host only looks at the per-round "something changed" flags.
+// `images_host` is the staging copy of the HuffImage array (first_interval = start of the image's interval entries).
+static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int n, const std::vector<int> &dwalk, const HuffScanArgs &scan,
+                              const HuffImage *images_dev, uint32_t *ibegin_dev, uint8_t *iskip_dev, int16_t *ipred_dev,
+                              const HuffImage *images_host)
+{
+  const mijpeg_info &f0 = hosts[0]->info;
+  const Scan &s0 = hosts[0]->scans[0];
+  HuffWalkArgs w;
+  memset(&w, 0, sizeof(w));
+  w.ncomp = s0.ncomp;
+  int B = 0;
+  for (int k = 0; k < s0.ncomp; k++) {
+    const int c = s0.sc[k].comp;
+    w.hs[k] = s0.ncomp > 1 ? f0.hsamp[c] : 1;
+    w.vs[k] = s0.ncomp > 1 ? f0.vsamp[c] : 1;
+    B += w.hs[k] * w.vs[k];
+  }
+  if (B > 64) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many blocks per MCU for the device walk");
+  w.nblk_mcu = B;
+  w.ntables = scan.ntables;
+  // subsequence size: the serial part of the walk is (distance the decoder needs to synchronise + two subsequences),
+  // so small ones; larger only to bound the state arrays of very long streams
+  size_t longest = 0;
+  for (int i = 0; i < n; i++)
+    if (dwalk[(size_t)i]) longest = std::max(longest, hosts[i]->scans[0].ecs_end - hosts[i]->scans[0].ecs_begin);
+  uint32_t sub_bytes = 128;
+  while (sub_bytes < 1024 && longest / sub_bytes > ((size_t)1 << 20)) sub_bytes <<= 1;
+  if (const char *e = getenv("MIJPEG_WALK_SUB")) sub_bytes = (uint32_t)std::max(32, std::min(4096, atoi(e))); // experiments
+  w.sub_bytes = sub_bytes;
+  // per image: its subsequences; per workgroup: image and first subsequence
+  std::vector<uint32_t> img_sub0((size_t)n, 0), img_nsub((size_t)n, 0), img_e0((size_t)n, 0), img_e1((size_t)n, 0), img_int0((size_t)n, 0);
+  uint32_t nsub_total = 0;
+  for (int i = 0; i < n; i++) {
+    const Scan &s = hosts[i]->scans[0];
+    img_e0[(size_t)i] = (uint32_t)s.ecs_begin;
+    img_e1[(size_t)i] = (uint32_t)s.ecs_end;
+    img_int0[(size_t)i] = images_host[i].first_interval;
+    img_sub0[(size_t)i] = nsub_total;
+    if (dwalk[(size_t)i]) {
+      img_nsub[(size_t)i] = (uint32_t)((s.ecs_end - s.ecs_begin + sub_bytes - 1) / sub_bytes);
+      nsub_total += img_nsub[(size_t)i];
+    }
+  }
+  w.lanes = 64;
+  while (w.lanes > 1 && nsub_total / (uint32_t)w.lanes < 2048) w.lanes >>= 1;
+  if (const char *e = getenv("MIJPEG_WALK_LANES")) w.lanes = std::max(1, std::min(64, atoi(e))); // experiments (power of two)
+  w.waves_per_group = 4;
+  const uint32_t per_group = (uint32_t)(w.lanes * w.waves_per_group);
+  std::vector<uint32_t> sub_image, sub_first;
+  for (int i = 0; i < n; i++)
+    for (uint32_t k = 0; k < img_nsub[(size_t)i]; k += per_group) { sub_image.push_back((uint32_t)i); sub_first.push_back(k); }
+  w.n_groups = (int32_t)sub_image.size();
+  // one device buffer: [per group: image, first][per image: sub0, nsub, e0, e1, int0][per subsequence: state, stamp,
+  // nblocks, dcsum, first_block, first_pred][changed flag per round][status per image]
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  constexpr int MAX_ROUNDS = 48;
+  const size_t G = sub_image.size(), S = nsub_total;
+  size_t o = 0;
+  const size_t o_simg = o; o = al(o + G * 4);
+  const size_t o_sfirst = o; o = al(o + G * 4);
+  const size_t o_isub0 = o; o = al(o + (size_t)n * 4);
+  const size_t o_insub = o; o = al(o + (size_t)n * 4);
+  const size_t o_e0 = o; o = al(o + (size_t)n * 4);
+  const size_t o_e1 = o; o = al(o + (size_t)n * 4);
+  const size_t o_int0 = o; o = al(o + (size_t)n * 4);
+  const size_t o_state = o; o = al(o + S * 8);
+  const size_t o_up_end = o; // up to here the host fills the buffer
+  const size_t o_flags = o; o = al(o + (size_t)(MAX_ROUNDS + 1) * 4 + (size_t)n * 4); // changed[], walk_status[]
+  const size_t o_stamp = o; o = al(o + S * 4);
+  const size_t o_zero_end = o; // flags and stamps start out as zero
+  const size_t o_nblk = o; o = al(o + S * 4);
+  const size_t o_dcsum = o; o = al(o + S * 16);
+  const size_t o_fblk = o; o = al(o + S * 4);
+  const size_t o_fpred = o; o = al(o + S * 16);
+  uint32_t most = 0;
+  for (int i = 0; i < n; i++) most = std::max(most, img_nsub[(size_t)i]);
+  const int tiles = (int)((most + HUFF_WALK_TILE - 1) / HUFF_WALK_TILE);
+  if (tiles > HUFF_WALK_TILE) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "stream too long for the device walk");
+  const size_t o_tiles = o; o = al(o + (size_t)n * tiles * HUFF_WALK_SUMS_BYTES);
+  const size_t total = o;
+  int rc = ensure_dev(d, (void **)&d->walk_dev, &d->walk_cap, total);
+  if (rc) return rc;
+  const size_t host_bytes = o_up_end + (o_stamp - o_flags);
+  if (d->walk_host_cap < host_bytes) {
+    if (d->walk_host) (void)hipHostFree(d->walk_host);
+    d->walk_host = nullptr;
+    d->walk_host_cap = 0;
+    HIP_TRY(d, hipHostMalloc((void **)&d->walk_host, host_bytes, hipHostMallocDefault));
+    d->walk_host_cap = host_bytes;
+  }
+  uint8_t *wh = d->walk_host, *wd = d->walk_dev;
+  memcpy(wh + o_simg, sub_image.data(), G * 4);
+  memcpy(wh + o_sfirst, sub_first.data(), G * 4);
+  memcpy(wh + o_isub0, img_sub0.data(), (size_t)n * 4);
+  memcpy(wh + o_insub, img_nsub.data(), (size_t)n * 4);
+  memcpy(wh + o_e0, img_e0.data(), (size_t)n * 4);
+  memcpy(wh + o_e1, img_e1.data(), (size_t)n * 4);
+  memcpy(wh + o_int0, img_int0.data(), (size_t)n * 4);
+  // the initial guess: every subsequence starts at its boundary (behind a stuffed zero if it falls on one) with the
+  // first block of an MCU; for the first subsequence of an image that is no guess
+  {
+    uint64_t *st = (uint64_t *)(wh + o_state);
+    for (int i = 0; i < n; i++) {
+      const Scan &s = hosts[i]->scans[0];
+      const uint8_t *base = hosts[i]->stream_base();
+      for (uint32_t k = 0; k < img_nsub[(size_t)i]; k++) {
+        size_t q = s.ecs_begin + (size_t)k * sub_bytes;
+        if (k > 0 && base[q] == 0x00 && base[q - 1] == 0xff) q++;
+        st[img_sub0[(size_t)i] + k] = (uint64_t)q;
+      }
+    }
+  }
+  HIP_TRY(d, hipMemcpyAsync(wd, wh, o_up_end, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(d, hipMemsetAsync(wd + o_flags, 0, o_zero_end - o_flags, d->stream));
+  w.data = scan.data;
+  w.images = images_dev;
+  w.tables = scan.tables;
+  w.sub_image = (const uint32_t *)(wd + o_simg);
+  w.sub_first = (const uint32_t *)(wd + o_sfirst);
+  w.img_sub0 = (const uint32_t *)(wd + o_isub0);
+  w.img_nsub = (const uint32_t *)(wd + o_insub);
+  w.img_e0 = (const uint32_t *)(wd + o_e0);
+  w.img_e1 = (const uint32_t *)(wd + o_e1);
+  w.img_int0 = (const uint32_t *)(wd + o_int0);
+  w.state = (uint64_t *)(wd + o_state);
+  w.stamp = (uint32_t *)(wd + o_stamp);
+  w.changed = (uint32_t *)(wd + o_flags);
+  w.walk_status = w.changed + MAX_ROUNDS + 1;
+  w.nblocks = (uint32_t *)(wd + o_nblk);
+  w.dcsum = (int32_t *)(wd + o_dcsum);
+  w.first_block = (uint32_t *)(wd + o_fblk);
+  w.first_pred = (int32_t *)(wd + o_fpred);
+  w.tile_sums = (WalkSums *)(wd + o_tiles);
+  w.tiles_per_image = tiles;
+  w.ibegin = ibegin_dev;
+  w.iskip = iskip_dev;
+  w.ipred = ipred_dev;
+  const int64_t total_blocks = (int64_t)s0.mcus_x * s0.mcus_y * B;
+  w.total_blocks = (uint32_t)total_blocks;
+  // rounds, launched back to back in bunches; between bunches the host looks at the flags: a round that changed no
+  // hand-over state means the states are the fixed point (and the counts of the lanes' last walks belong to it)
+  uint32_t *flags_host = (uint32_t *)(wh + o_up_end);
+  static const int first_bunch = getenv("MIJPEG_WALK_ROUNDS") ? std::max(1, std::min(MAX_ROUNDS, atoi(getenv("MIJPEG_WALK_ROUNDS")))) : 8;
+  int round = 0;
+  for (;;) {
+    const int upto = round == 0 ? first_bunch : std::min(MAX_ROUNDS, round + 4);
+    while (round < upto) {
+      w.round = (uint32_t)++round;
+      if (launch_huffman_walk(w, false, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_walk_kernel launch");
+    }
+    HIP_TRY(d, hipMemcpyAsync(flags_host, wd + o_flags, (size_t)(MAX_ROUNDS + 1) * 4, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    if (!flags_host[round]) break;
+    if (round == MAX_ROUNDS) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "speculative decoding did not settle");
+  }
+  d->walk_rounds = 1;
+  for (int r = 1; r <= round; r++)
+    if (flags_host[r]) d->walk_rounds = r + 1; // rounds that were needed: the last one that changed something, and one to see it
+  if (launch_huffman_walk_scan(w, n, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_walk_scan_kernel launch");
+  // one interval size for the launch: the images share their geometry, hence their MCUs per virtual interval
+  int per = 0;
+  for (int i = 0; i < n; i++)
+    if (dwalk[(size_t)i]) per = dwalk[(size_t)i];
+  w.emit_every = (uint32_t)(per * B);
+  if (launch_huffman_walk(w, true, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_walk_kernel launch");
+  d->walk_status_dev = w.walk_status;
+  return MIJPEG_OK;
+}
+
 // Entropy-decode n parsed images of identical frame geometry on the device, image i into coef_dev + i * frame_stride.
 // infos[i] receives fast_arith / range_max.  Returns MIJPEG_OK, MIJPEG_ERR_NOT_AVAILABLE (nothing touched) or an error.
 static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, const uint8_t *const *datas, const size_t *sizes, int n,
@@ -293,7 +474,10 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   const Scan &s0 = hosts[0]->scans[0];
   int64_t total_intervals = 0;
   std::vector<int64_t> nints((size_t)n);
-  std::vector<std::unique_ptr<VirtualIntervals>> virt((size_t)n);
+  std::vector<std::unique_ptr<VirtualIntervals>> virt((size_t)n); // restart points planned by the host's walk ...
+  std::vector<int> dwalk((size_t)n, 0);                           // ... or MCUs per virtual interval when the device walks
+  d->walk_rounds = 0;
+  const bool device_walk = !(getenv("MIJPEG_DEVICE_WALK") && atoi(getenv("MIJPEG_DEVICE_WALK")) == 0);
   const auto tb0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n; i++) {
     const char *why = device_entropy_obstacle(*hosts[i], sizes[i]);
@@ -318,11 +502,18 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     } else {
       // no restart markers: the host's self-synchronising walk finds exact restart points ("virtual intervals"),
       // about 16 K of them, and the device decodes from there
-      virt[(size_t)i].reset(new VirtualIntervals());
       const int per = (int)std::min<int64_t>(64, std::max<int64_t>(1, total_mcus / 16384));
-      if (total_mcus < 256 || hosts[i]->plan_virtual_intervals(0, per, 0, *virt[(size_t)i]))
-        return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "stream without restart markers did not lend itself to speculative decoding");
-      nint = (int64_t)virt[(size_t)i]->byte_off.size();
+      if (total_mcus < 256 || s.ecs_end - s.ecs_begin < 4096)
+        return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "stream without restart markers is too small for speculative decoding");
+      if (device_walk) { // the restart points are found on the device (huffman_walk_kernel); their number is known already
+        dwalk[(size_t)i] = per;
+        nint = (total_mcus + per - 1) / per;
+      } else {
+        virt[(size_t)i].reset(new VirtualIntervals());
+        if (hosts[i]->plan_virtual_intervals(0, per, 0, *virt[(size_t)i]))
+          return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "stream without restart markers did not lend itself to speculative decoding");
+        nint = (int64_t)virt[(size_t)i]->byte_off.size();
+      }
     }
     nints[(size_t)i] = nint;
     total_intervals += nint;
@@ -359,8 +550,11 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   if (off > 0xfffffff0ull || n_groups > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "batch too large for one launch");
   const size_t stream_bytes = off;
   auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-  bool any_virtual = false;
-  for (int i = 0; i < n; i++) any_virtual |= virt[(size_t)i] != nullptr;
+  bool any_virtual = false, any_dwalk = false;
+  for (int i = 0; i < n; i++) {
+    any_virtual |= virt[(size_t)i] != nullptr || dwalk[(size_t)i] > 0;
+    any_dwalk |= dwalk[(size_t)i] > 0;
+  }
   const size_t off_ib = stream_bytes, off_ie = off_ib + (size_t)total_intervals * 4;
   const size_t off_isk = off_ie + (size_t)total_intervals * 4, off_ipr = align16(off_isk + (any_virtual ? (size_t)total_intervals : 0));
   const size_t off_tab = align16(off_ipr + (any_virtual ? (size_t)total_intervals * 8 : 0));
@@ -387,7 +581,11 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     const Scan &s = hosts[i]->scans[0];
     const int64_t nint = nints[(size_t)i];
     const std::vector<size_t> &iend = hosts[i]->interval_ends(0);
-    if (virt[(size_t)i]) {
+    if (dwalk[(size_t)i]) { // filled in by the EMIT walk on the device
+      for (int64_t k = 0; k < nint; k++) { ib[first + k] = (uint32_t)s.ecs_begin; ie[first + k] = (uint32_t)s.ecs_end; }
+      memset(hp + off_isk + first, 0, (size_t)nint);
+      memset(hp + off_ipr + (size_t)first * 8, 0, (size_t)nint * 8);
+    } else if (virt[(size_t)i]) {
       const VirtualIntervals &vi = *virt[(size_t)i];
       uint8_t *isk = hp + off_isk;
       int16_t *ipr = (int16_t *)(hp + off_ipr);
@@ -428,8 +626,8 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     im.stream_off = (uint32_t)stream_off[(size_t)i];
     im.first_interval = (uint32_t)first;
     im.n_intervals = (int32_t)nint;
-    im.restart_interval = virt[(size_t)i] ? virt[(size_t)i]->mcus_per_interval : s.restart_interval;
-    im.virt = virt[(size_t)i] ? 1u : 0u;
+    im.restart_interval = dwalk[(size_t)i] ? dwalk[(size_t)i] : virt[(size_t)i] ? virt[(size_t)i]->mcus_per_interval : s.restart_interval;
+    im.virt = (virt[(size_t)i] || dwalk[(size_t)i]) ? 1u : 0u;
     im.reserved = 0;
     im.total_mcus = s.mcus_x * s.mcus_y;
     im.mcus_x = s.mcus_x;
@@ -474,7 +672,15 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
   if (needs_clear) HIP_TRY(d, hipMemsetAsync(coef_dev, 0, (size_t)n * (size_t)frame_stride * sizeof(int16_t), d->stream));
   const int repeat = getenv("MIJPEG_HUFF_REPEAT") ? atoi(getenv("MIJPEG_HUFF_REPEAT")) : 1; // experiments: steady-state kernel time
-  if (n == 1 || stream_bytes < ((size_t)8 << 20)) {
+  if (any_dwalk) {
+    // the walk needs the streams first: everything goes up at once, then the rounds, then the decode launch
+    for (int i = 0; i < n; i++)
+      HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
+    const int wrc = device_walk_images(d, hosts, n, dwalk, a, (const HuffImage *)(d->ent_dev + off_img), (uint32_t *)(d->ent_dev + off_ib), d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images);
+    if (wrc) return wrc;
+    for (int r = 0; r < std::max(1, repeat); r++)
+      if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
+  } else if (n == 1 || stream_bytes < ((size_t)8 << 20)) {
     for (int i = 0; i < n; i++)
       HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
     for (int r = 0; r < std::max(1, repeat); r++)
@@ -530,7 +736,14 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   }
   uint32_t *status_host = (uint32_t *)(d->ent_host + host_part);
   HIP_TRY(d, hipMemcpyAsync(status_host, d->ent_dev + off_status, status_bytes, hipMemcpyDeviceToHost, d->stream));
+  uint32_t *walk_status_host = (uint32_t *)d->walk_host; // the walk's staging buffer is free again
+  if (any_dwalk) HIP_TRY(d, hipMemcpyAsync(walk_status_host, d->walk_status_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(d, hipStreamSynchronize(d->stream));
+  if (any_dwalk)
+    for (int i = 0; i < n; i++) {
+      if (walk_status_host[i] & 2) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
+      if (walk_status_host[i]) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "speculative decoding settled on something that is not a decode of the image");
+    }
   d->phase_prepare = std::chrono::duration<double>(tb1 - tb0).count();                              // interval tables, Huffman tables
   d->phase_device = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb1).count();  // upload + kernel + status
   for (int i = 0; i < n; i++) {

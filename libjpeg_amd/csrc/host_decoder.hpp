@@ -95,6 +95,8 @@ public:
   // restart intervals; nonzero if the scan does not lend itself to it (the caller then decodes on the host).
   int plan_virtual_intervals(size_t scan, int mcus_per_interval, int threads, VirtualIntervals &out);
 
+  const uint8_t *stream_base() const { return data_; } // the parsed input
+
   mijpeg_info info{};
   // restart-interval byte ranges of scan i (valid after parse(..., false)): [interval_begin[k], interval_ends(i)[k])
   const std::vector<size_t> &interval_ends(size_t scan) const { return scan_interval_end_[scan]; }

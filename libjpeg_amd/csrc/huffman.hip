@@ -49,6 +49,8 @@ struct DevBits {
   uint32_t rx0, rx1;   // ring dwords at pos & ~3
   uint64_t acc;
   int n;
+  int phantom; // zero bits supplied since the reader parked (the walk kernels need to know where the data really ends)
+  uint32_t hist; // bit i: the (i + 1)-th last byte taken was the FF of a stuffed pair, i.e. two stream bytes (walk kernels)
   bool parked;
 
   __device__ __forceinline__ u32x4 fetch(uint32_t at) const { return *reinterpret_cast<const u32x4 *>(base + at); }
@@ -69,6 +71,8 @@ struct DevBits {
     fill = begin & ~15u;
     acc = 0;
     n = 0;
+    phantom = 0;
+    hist = 0;
     parked = false;
     const u32x4 c0 = fetch(fill), c1 = fetch(fill + 16), c2 = fetch(fill + 32), c3 = fetch(fill + 48);
     commit(c0);
@@ -97,6 +101,7 @@ struct DevBits {
     acc |= (uint64_t)xs << ((32 - n) & 63);
     n += take ? 32 : 0;
     pos += take ? 4u : 0u;
+    hist <<= take ? 4 : 0;
     const uint32_t *r = reinterpret_cast<const uint32_t *>(ring + (pos & (RING - 4)));
     rx0 = r[0]; // consumed by the next step: the LDS round trip is off the symbol-to-symbol chain
     rx1 = r[1];
@@ -106,7 +111,7 @@ struct DevBits {
   {
     while (n < 32) {
       const uint32_t avail = end - pos;
-      if (parked || avail == 0) { parked = true; n += 32; continue; }
+      if (parked || avail == 0) { parked = true; n += 32; phantom += 32; continue; }
       const uint32_t x = __builtin_amdgcn_alignbyte(rx1, rx0, pos & 3u);
       const uint32_t ff = (~x - 0x01010101u) & x & 0x80808080u;          // lowest set bit marks the first 0xFF
       const uint32_t k = min(ff ? (uint32_t)__builtin_ctz(ff) >> 3 : 4u, avail); // leading ordinary bytes
@@ -116,11 +121,13 @@ struct DevBits {
         acc |= (uint64_t)xs << (32 - n);
         n += 8 * (int)k;
         pos += k;
+        hist <<= k;
         peek_ring();
       } else if (avail >= 2 && (x & 0xff00u) == 0) { // FF 00
         acc |= (uint64_t)0xff << (56 - n);
         n += 8;
         pos += 2;
+        hist = (hist << 1) | 1u;
         peek_ring();
       } else parked = true;
     }
@@ -249,6 +256,7 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
   br.rx0 = br.rx1 = 0;
   br.acc = 0;
   br.n = 0;
+  br.phantom = 0;
   br.parked = true;
   if (decoding) br.open(stream, rings + ln * RING_PITCH, a.ibegin[img.first_interval + interval], a.iend[img.first_interval + interval]);
   int pred[4] = {0, 0, 0, 0};
@@ -317,6 +325,299 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
 #pragma unroll
   for (int k = 0; k < 4; k++)
     if (k < a.ncomp && qmax[k]) atomicMax(&status[1 + a.comp_of[k]], qmax[k]);
+}
+
+// ==============================================================================================
+// Streams WITHOUT restart markers, entirely on the device: self-synchronising walk
+// ==============================================================================================
+// The entropy coded segment of an image is cut into subsequences of `sub_bytes` bytes and one lane walks one
+// subsequence (no coefficient stores): from a start state (byte, bits to skip, index of the block inside the MCU) to
+// the first block start at or behind the end of its subsequence, which it hands to its successor as THAT lane's start
+// state for the next round.  Round 0 starts every lane at its boundary with a guessed phase; since Huffman-coded JPEG
+// data re-synchronises, the hand-over states stop changing after a few rounds (Weissenberger & Schmidt, "Accelerating
+// JPEG Decompression on GPUs", 2021: the same fixed point), and what is then known per subsequence -- number of blocks,
+// sum of the DC differences per component -- gives, by prefix sums on the host, the block number and the DC predictors
+// at every subsequence start.  A last walk (EMIT) writes the "virtual restart intervals" huffman_scan_kernel decodes
+// from: byte, bit offset and predictors at every block whose number is a multiple of `emit_every`.
+// Start state of a subsequence in one 64-bit word (read and written as a unit): byte, bits to skip, block in the MCU.
+__device__ __forceinline__ uint64_t walk_state(uint32_t byte, uint32_t skip, uint32_t phase) { return (uint64_t)byte | ((uint64_t)skip << 32) | ((uint64_t)phase << 40); }
+__device__ __forceinline__ uint32_t walk_state_byte(uint64_t s) { return (uint32_t)s; }
+__device__ __forceinline__ uint32_t walk_state_skip(uint64_t s) { return (uint32_t)(s >> 32) & 7u; }
+__device__ __forceinline__ uint32_t walk_state_phase(uint64_t s) { return (uint32_t)(s >> 40) & 0xffu; }
+
+// One block without stores.  0 = fine, 1 = cannot be a block.
+__device__ __forceinline__ int dev_walk_block(DevBits &br, const HuffDevTable *dc, const HuffDevTable *ac, int &dcdiff)
+{
+  br.refill();
+  uint32_t win = br.window();
+  uint32_t e = dev_lookup<false>(win, dc);
+  int s = (int)(e & 0xff), tot = (int)(e >> 8) + s;
+  if (e == 0 || s > 15) return 1;
+  dcdiff = dev_value(win, tot, s);
+  br.skip(tot);
+  int kk = 1;
+  bool bad = false;
+  for (;;) {
+    br.refill();
+    win = br.window();
+    e = dev_lookup<true>(win, ac);
+    const int rs = (int)(e & 0xff);
+    s = rs & 15;
+    tot = (int)((e >> 8) & 31u) + s;
+    br.skip(tot);
+    kk += rs >> 4;
+    bad |= (e - 1u >= (uint32_t)HUFF_DEV_INVALID - 1u) | ((s != 0) & (kk > 63));
+    if ((rs == 0) | bad | (kk >= 63)) break;
+    kk++;
+  }
+  return bad ? 1 : 0;
+}
+
+// Where the reader stands, as (byte that holds the next unread bit, bits of it already used): step back over the
+// bytes whose bits are still buffered; `hist` knows which of them took two stream bytes.
+__device__ __forceinline__ void dev_exact_position(const DevBits &br, uint32_t &byte, uint32_t &skip)
+{
+  const int real = br.n - br.phantom;
+  if (real <= 0) { byte = br.end; skip = 0; return; }
+  const int back = (real + 7) >> 3; // <= 8
+  byte = br.pos - (uint32_t)back - (uint32_t)__builtin_popcount(br.hist & ((1u << back) - 1u));
+  skip = (uint32_t)(8 * back - real);
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void huffman_walk_kernel(const HuffWalkArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  const int table_bytes = a.ntables * (int)sizeof(HuffDevTable) + (int)sizeof(HuffDevAux);
+  const HuffDevTable *tabs = reinterpret_cast<const HuffDevTable *>(lds_raw);
+  uint8_t *blk_comp = lds_raw + table_bytes; // 64 bytes: scan component of block j of an MCU
+  const int L = a.lanes;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t img_i = a.sub_image[blockIdx.x];
+  const HuffImage img = a.images[img_i];
+  uint8_t *rings = lds_raw + table_bytes + 64 + wv * (L * RING_PITCH);
+  const uint32_t nsub = a.img_nsub[img_i], sub = a.sub_first[blockIdx.x] + (uint32_t)(wv * L + lane);
+  const uint32_t si = a.img_sub0[img_i] + sub;
+  // a lane walks (again) when its start state was written in the previous round -- or in this one already: the
+  // states are updated in place, a round may see some of its own hand-overs, which only gets it to the fixed point sooner
+  bool go = lane < L && sub < nsub;
+  if (!EMIT) go = go && a.stamp[si] + 1u >= a.round;
+  if (!__syncthreads_or(go)) return; // late rounds: hardly any workgroup has work left
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables + img.table_off);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
+    for (int i = threadIdx.x; i < table_bytes / 4; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x == 0) {
+      int j = 0;
+      for (int k = 0; k < a.ncomp; k++)
+        for (int i = 0; i < a.hs[k] * a.vs[k]; i++) blk_comp[j++] = (uint8_t)k;
+    }
+  }
+  __syncthreads();
+  if (!go) return;
+  const uint32_t e0 = a.img_e0[img_i], e1 = a.img_e1[img_i];
+  const uint32_t limit = sub + 1 < nsub ? e0 + (sub + 1) * a.sub_bytes : e1; // first byte of the successor's range
+  const uint8_t *stream = a.data + img.stream_off;
+  const uint64_t st = a.state[si];
+
+  DevBits br;
+  br.open(stream, rings + lane * RING_PITCH, walk_state_byte(st), e1);
+  br.refill();
+  br.skip((int)walk_state_skip(st));
+  int j = (int)walk_state_phase(st);
+  uint32_t pend_at = br.fill;
+  u32x4 pend0 = br.fetch(pend_at), pend1 = br.fetch(pend_at + 16);
+  uint32_t nb = 0;
+  int dcs[4] = {0, 0, 0, 0};
+  // EMIT: running block number and predictors
+  uint32_t g = EMIT ? a.first_block[si] : 0;
+  const uint32_t my_blocks = EMIT ? a.nblocks[si] : 0xffffffffu;
+  int pred[4] = {0, 0, 0, 0};
+  if (EMIT) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) pred[k] = a.first_pred[si * 4 + k];
+  }
+  uint32_t end_byte = e1, end_skip = 0;
+  for (;;) {
+    br.refill();
+    if (EMIT) {
+      if (nb >= my_blocks || g >= a.total_blocks) break;
+      if (g % a.emit_every == 0) {
+        uint32_t q, sk;
+        dev_exact_position(br, q, sk);
+        const uint32_t idx = a.img_int0[img_i] + g / a.emit_every;
+        a.ibegin[idx] = q;
+        a.iskip[idx] = (uint8_t)sk;
+#pragma unroll
+        for (int k = 0; k < 4; k++) a.ipred[idx * 4 + k] = (int16_t)pred[k];
+      }
+    } else {
+      if (br.parked && br.n - br.phantom <= 0) break; // the data end here
+      if (br.pos >= limit) { // possibly in the successor's range already (pos runs ahead by the buffered bits)
+        uint32_t q, sk;
+        dev_exact_position(br, q, sk);
+        if (q >= limit) { end_byte = q; end_skip = sk; break; }
+      }
+    }
+    const int k = blk_comp[j];
+    int dcdiff = 0;
+    const int bad = dev_walk_block(br, tabs + 2 * k, tabs + 2 * k + 1, dcdiff);
+    if (br.parked && br.n - br.phantom < 0) break; // ran over the end of the data inside a block
+    if (bad) {
+      if (EMIT) break; // cannot happen on the path the rounds agreed on
+      br.refill();
+      br.skip(1); // not a block: move on by one bit and guess again
+      j = 0;
+    } else {
+      nb++;
+      if (EMIT) { g++; pred[k] += dcdiff; }
+      else dcs[k] += dcdiff;
+      j = j + 1 == a.nblk_mcu ? 0 : j + 1;
+    }
+    // top the ring up with what was requested a block ago, request the next 32 bytes
+    if (pend_at == br.fill && br.room()) br.commit(pend0);
+    if (pend_at + 16 == br.fill && br.room()) br.commit(pend1);
+    pend_at = br.fill;
+    pend0 = br.fetch(pend_at);
+    pend1 = br.fetch(pend_at + 16);
+  }
+  if (!EMIT) {
+    a.nblocks[si] = nb;
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.dcsum[si * 4 + k] = dcs[k];
+    if (sub + 1 < nsub) {
+      const uint32_t t = si + 1;
+      const uint64_t handed = walk_state(end_byte, end_skip, (uint32_t)j);
+      if (a.state[t] != handed) {
+        a.state[t] = handed;
+        a.stamp[t] = a.round;
+        a.changed[a.round] = 1;
+      }
+    }
+  }
+}
+
+// Between the rounds and the EMIT walk: exclusive prefix sums of the block counts and DC sums over the subsequences of
+// every image, and the checks that tell a fixed point that is a decode of the image from one that is not: the phase
+// every subsequence starts in must be its block number modulo the blocks per MCU, the DC predictors must fit the
+// coefficient store, and the blocks must add up to the frame.  Three small kernels: sums per tile of 1024
+// subsequences, scan of the tile sums (one workgroup per image), scan inside the tiles + checks.
+constexpr int WALK_TILE = 1024;
+struct WalkSums {
+  long long v[5]; // blocks, DC sums
+};
+__device__ __forceinline__ WalkSums walk_sums_add(const WalkSums &x, const WalkSums &y)
+{
+  WalkSums r;
+#pragma unroll
+  for (int c = 0; c < 5; c++) r.v[c] = x.v[c] + y.v[c];
+  return r;
+}
+// inclusive scan over the workgroup's threads (WALK_TILE of them); `wave_tot` = 16 WalkSums of LDS
+__device__ __forceinline__ WalkSums walk_block_scan(WalkSums mine, WalkSums *wave_tot, WalkSums &block_total)
+{
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    WalkSums o;
+#pragma unroll
+    for (int c = 0; c < 5; c++) o.v[c] = __shfl_up(mine.v[c], d, 64);
+    if (lane >= d) mine = walk_sums_add(mine, o);
+  }
+  if (lane == 63) wave_tot[wv] = mine;
+  __syncthreads();
+  WalkSums before{{0, 0, 0, 0, 0}}, all{{0, 0, 0, 0, 0}};
+  for (int k = 0; k < WALK_TILE / 64; k++) {
+    const WalkSums t = wave_tot[k];
+    if (k < wv) before = walk_sums_add(before, t);
+    all = walk_sums_add(all, t);
+  }
+  __syncthreads();
+  block_total = all;
+  return walk_sums_add(mine, before);
+}
+__device__ __forceinline__ WalkSums walk_load(const HuffWalkArgs &a, uint32_t s0, uint32_t i, uint32_t nsub)
+{
+  WalkSums m{{0, 0, 0, 0, 0}};
+  if (i < nsub) {
+    m.v[0] = a.nblocks[s0 + i];
+    const int4 dc = *reinterpret_cast<const int4 *>(a.dcsum + (size_t)(s0 + i) * 4);
+    m.v[1] = dc.x; m.v[2] = dc.y; m.v[3] = dc.z; m.v[4] = dc.w;
+  }
+  return m;
+}
+// grid (tiles, images)
+__global__ __launch_bounds__(WALK_TILE) void huffman_walk_tile_sums_kernel(const HuffWalkArgs a)
+{
+  __shared__ WalkSums wave_tot[WALK_TILE / 64];
+  const uint32_t img_i = blockIdx.y, nsub = a.img_nsub[img_i], s0 = a.img_sub0[img_i];
+  if (blockIdx.x * WALK_TILE >= nsub) return;
+  WalkSums total;
+  (void)walk_block_scan(walk_load(a, s0, blockIdx.x * WALK_TILE + threadIdx.x, nsub), wave_tot, total);
+  if (threadIdx.x == 0) a.tile_sums[(size_t)img_i * a.tiles_per_image + blockIdx.x] = total;
+}
+// grid (images): exclusive scan of an image's tile sums, in place (at most WALK_TILE tiles per image)
+__global__ __launch_bounds__(WALK_TILE) void huffman_walk_tile_scan_kernel(const HuffWalkArgs a)
+{
+  __shared__ WalkSums wave_tot[WALK_TILE / 64];
+  const uint32_t img_i = blockIdx.x, nsub = a.img_nsub[img_i];
+  if (nsub == 0) return;
+  const uint32_t tiles = (nsub + WALK_TILE - 1) / WALK_TILE;
+  WalkSums *ts = a.tile_sums + (size_t)img_i * a.tiles_per_image;
+  WalkSums mine{{0, 0, 0, 0, 0}}, total;
+  if (threadIdx.x < tiles) mine = ts[threadIdx.x];
+  const WalkSums incl = walk_block_scan(mine, wave_tot, total);
+  if (threadIdx.x < tiles) {
+#pragma unroll
+    for (int c = 0; c < 5; c++) ts[threadIdx.x].v[c] = incl.v[c] - mine.v[c];
+  }
+  if (threadIdx.x == 0 && total.v[0] < (long long)a.total_blocks) atomicOr(&a.walk_status[img_i], 4u);
+}
+// grid (tiles, images)
+__global__ __launch_bounds__(WALK_TILE) void huffman_walk_prefix_kernel(const HuffWalkArgs a)
+{
+  __shared__ WalkSums wave_tot[WALK_TILE / 64];
+  const uint32_t img_i = blockIdx.y, nsub = a.img_nsub[img_i], s0 = a.img_sub0[img_i];
+  if (blockIdx.x * WALK_TILE >= nsub) return;
+  const uint32_t i = blockIdx.x * WALK_TILE + threadIdx.x;
+  const WalkSums mine = walk_load(a, s0, i, nsub);
+  WalkSums total;
+  WalkSums run = walk_block_scan(mine, wave_tot, total);
+  const WalkSums off = a.tile_sums[(size_t)img_i * a.tiles_per_image + blockIdx.x];
+#pragma unroll
+  for (int c = 0; c < 5; c++) run.v[c] += off.v[c] - mine.v[c]; // exclusive
+  if (i >= nsub) return;
+  const long long total_blocks = a.total_blocks;
+  const bool live = run.v[0] < total_blocks; // the subsequence starts inside the image, not in the padding behind it
+  uint32_t bad = 0;
+  if (live && mine.v[0] && walk_state_phase(a.state[s0 + i]) != (uint32_t)(run.v[0] % a.nblk_mcu)) bad |= 1;
+  a.first_block[s0 + i] = (uint32_t)(live ? run.v[0] : total_blocks);
+  int4 fp;
+  fp.x = (int)run.v[1]; fp.y = (int)run.v[2]; fp.z = (int)run.v[3]; fp.w = (int)run.v[4];
+#pragma unroll
+  for (int c = 1; c < 5; c++)
+    if (live && run.v[c] != (long long)(short)run.v[c]) bad |= 2;
+  *reinterpret_cast<int4 *>(a.first_pred + (size_t)(s0 + i) * 4) = fp;
+  if (bad) atomicOr(&a.walk_status[img_i], bad);
+}
+
+int launch_huffman_walk_scan(const HuffWalkArgs &a, int n_images, hipStream_t stream)
+{
+  static_assert(sizeof(WalkSums) == HUFF_WALK_SUMS_BYTES, "host sizes the tile sums");
+  if (a.tiles_per_image <= 0 || a.tiles_per_image > WALK_TILE) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(huffman_walk_tile_sums_kernel, dim3(a.tiles_per_image, n_images), dim3(WALK_TILE), 0, stream, a);
+  hipLaunchKernelGGL(huffman_walk_tile_scan_kernel, dim3(n_images), dim3(WALK_TILE), 0, stream, a);
+  hipLaunchKernelGGL(huffman_walk_prefix_kernel, dim3(a.tiles_per_image, n_images), dim3(WALK_TILE), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_huffman_walk(const HuffWalkArgs &a, bool emit, hipStream_t stream)
+{
+  if (a.n_groups <= 0) return 0;
+  const size_t lds = (size_t)a.ntables * sizeof(HuffDevTable) + sizeof(HuffDevAux) + 64 + (size_t)a.waves_per_group * a.lanes * RING_PITCH;
+  if (emit) hipLaunchKernelGGL(huffman_walk_kernel<true>, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
+  else hipLaunchKernelGGL(huffman_walk_kernel<false>, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
+  return (int)hipGetLastError();
 }
 
 int launch_huffman_scan(const HuffScanArgs &a, hipStream_t stream)

@@ -71,7 +71,47 @@ struct HuffScanArgs {
   uint32_t *status;              // device: per image [0] error (0 = ok), [1 + c] max over blocks of sum |c| q for frame component c
 };
 
+constexpr int HUFF_WALK_SUMS_BYTES = 40;
+constexpr int HUFF_WALK_TILE = 1024;
+// Self-synchronising walk of streams without restart markers (huffman_walk_kernel, see huffman.hip).
+struct HuffWalkArgs {
+  const uint8_t *data;           // device: the streams (as for HuffScanArgs)
+  const HuffImage *images;       // device: stream_off, table_off of every image (n_intervals etc. unused here)
+  const uint8_t *tables;
+  const uint32_t *sub_image;     // device, per workgroup: image of the workgroup's subsequences ...
+  const uint32_t *sub_first;     // ... and index of its first subsequence inside the image
+  const uint32_t *img_sub0;      // device, per image: index of its first subsequence in the state arrays
+  const uint32_t *img_nsub;      // per image: number of subsequences
+  const uint32_t *img_e0, *img_e1; // per image: entropy coded segment [e0, e1) relative to stream_off
+  // start state of every subsequence (byte | bits to skip << 32 | block inside the MCU << 40), updated in place: a
+  // lane writes its successor's, stamps it with the round, and sets changed[round]
+  uint64_t *state;
+  uint32_t *stamp;               // round that last wrote the state (0 = the initial guess)
+  uint32_t round;                // 1, 2, ...
+  uint32_t *changed;             // one flag per round
+  uint32_t *nblocks;             // out: blocks that start inside the subsequence
+  int32_t *dcsum;                // out: four per subsequence
+  uint32_t *walk_status;         // per image, from the prefix sums: 1 phase mismatch | 2 DC out of range | 4 too few blocks
+  struct WalkSums *tile_sums;    // scratch of the prefix sums: tiles_per_image entries of HUFF_WALK_SUMS_BYTES per image
+  int32_t tiles_per_image;       // ceil(max subsequences per image / 1024), at most 1024
+  // EMIT only
+  uint32_t *first_block;         // per subsequence: number of its first block in the image (huffman_walk_scan_kernel)
+  int32_t *first_pred;           // four per subsequence
+  const uint32_t *img_int0;      // per image: index of its first virtual interval
+  uint32_t *ibegin;
+  uint8_t *iskip;
+  int16_t *ipred;
+  uint32_t emit_every;           // blocks per virtual interval
+  uint32_t total_blocks;         // per image (the images of a launch share their geometry)
+  int32_t ncomp, nblk_mcu;       // scan components, blocks per MCU
+  int32_t hs[4], vs[4];
+  int32_t ntables, lanes, waves_per_group, n_groups;
+  uint32_t sub_bytes;
+};
+
 int launch_huffman_scan(const HuffScanArgs &a, hipStream_t stream);
+int launch_huffman_walk(const HuffWalkArgs &a, bool emit, hipStream_t stream);
+int launch_huffman_walk_scan(const HuffWalkArgs &a, int n_images, hipStream_t stream);
 
 } // namespace mij
 #endif

@@ -743,8 +743,7 @@ def test_batch_decode_rejects_what_is_not_a_batch():
     a = synth.synth_jpeg(320, 240, 1, 85, "420", 2)
     for other in (synth.synth_jpeg(336, 240, 1, 85, "420", 2),   # another width
                   synth.synth_jpeg(320, 240, 1, 60, "420", 2),   # other quantisation tables
-                  synth.synth_jpeg(320, 240, 1, 85, "444", 2),   # another sampling
-                  synth.synth_jpeg(320, 240, 1, 85, "420", 0)):  # no restart markers
+                  synth.synth_jpeg(320, 240, 1, 85, "444", 2)):  # another sampling
         with pytest.raises(api.MijpegError) as e:
             d.decode_batch_device([a, other], min_intervals=1)
         assert e.value.code == api.ERR_NOT_AVAILABLE
@@ -758,19 +757,71 @@ def test_batch_decode_rejects_what_is_not_a_batch():
     d.close()
 
 
-@pytest.mark.parametrize("w,h,sub,q", [(3840, 2160, "420", 85), (2560, 1440, "444", 95), (2048, 2048, "gray", 90)])
-def test_device_entropy_decoder_without_restart_markers(dec, w, h, sub, q):
-    """No DRI: the host's self-synchronising walk supplies exact restart points (bit offset + DC predictors) and the
-    device kernel decodes from them; coefficients and pixels must equal the host decoder's."""
+@pytest.mark.parametrize("walk", ["device", "host"])
+@pytest.mark.parametrize("w,h,sub,q", [(3840, 2160, "420", 85), (2560, 1440, "444", 95), (2048, 2048, "gray", 90),
+                                       (1000, 700, "422", 50), (7680, 4320, "420", 92), (640, 480, "420", 99)])
+def test_device_entropy_decoder_without_restart_markers(dec, monkeypatch, walk, w, h, sub, q):
+    """No DRI: a self-synchronising walk -- on the device (rounds of huffman_walk_kernel until the hand-over states
+    are a fixed point) or, MIJPEG_DEVICE_WALK=0, on the host -- supplies exact restart points (bit offset + DC
+    predictors) and the device kernel decodes from them; coefficients and pixels must equal the host decoder's."""
+    monkeypatch.setenv("MIJPEG_DEVICE_WALK", "1" if walk == "device" else "0")
     img = synth.synth_image(w, h, 12, channels=1 if sub == "gray" else 3)
     data = synth.encode_jpeg(img, q, sub if sub != "gray" else "444")
     host = api.Decoder(0)
     hi = host.read(data)
-    gi = dec.read(data, entropy="gpu")
+    try:
+        gi = dec.read(data, entropy="gpu")
+    except api.MijpegError as e:
+        # the host's planner wants longer streams (four of its 32 KiB segments) than the device walk (4 KiB)
+        assert walk == "host" and e.code == api.ERR_NOT_AVAILABLE and len(data) < 200_000
+        host.close()
+        return
     assert dec.entropy_used == "gpu"
+    assert (dec.device_walk_rounds() > 0) == (walk == "device")
     assert gi.fast_arith == hi.fast_arith and list(gi.range_max) == list(hi.range_max)
     assert np.array_equal(dec.reconstruct(), host.reconstruct())
     _same_coefficients(dec, host, hi.components)
+    host.close()
+
+
+@pytest.mark.parametrize("w,h,sub,n,mixed", [(1280, 720, "420", 6, False), (800, 608, "444", 4, True), (1920, 1080, "420", 9, True)])
+def test_batch_without_restart_markers(oracle, w, h, sub, n, mixed):
+    """Batches whose streams carry no restart markers (or only some do): one walk over all of them, one decode launch."""
+    torch = _torch()
+    streams = [synth.encode_jpeg(synth.synth_image(w, h, 500 + i), 85, sub, restart_mcus=(4 if mixed and i % 2 else 0),
+                                 optimize=(i % 3 == 1)) for i in range(n)]
+    d = api.Decoder(0)
+    d.decode_batch_device(streams, min_intervals=1)
+    assert d.device_walk_rounds() > 0
+    row = w * 3
+    out = torch.zeros((n, h, row), dtype=torch.uint8, device="cuda")
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row)
+    res = out.cpu().numpy().reshape(n, h, w, 3)
+    for i in range(n):
+        assert np.array_equal(res[i], oracle.decode(streams[i])), i
+    d.close()
+
+
+def test_device_walk_on_damaged_stream_reports_instead_of_hanging(dec):
+    """Corrupt entropy data without restart markers: the walk either settles and the decode kernel reports the damage,
+    or the stream is refused; nothing hangs and the host path sees the same stream as damaged or decodes it."""
+    data = bytearray(synth.synth_jpeg(1024, 768, 3, 85, "420", 0))
+    mid = len(data) // 2
+    for k in range(0, 64, 3):
+        data[mid + k] ^= 0xA5 if data[mid + k] not in (0xFF,) else 0
+    data = bytes(b if not (i > 700 and i < len(data) - 2 and data[i - 1] == 0xFF and b != 0) else 0 for i, b in enumerate(data))
+    try:
+        dec.read(data, entropy="auto")
+    except api.MijpegError:
+        return
+    host = api.Decoder(0)
+    try:
+        host.read(data)
+    except api.MijpegError:
+        host.close()
+        return
+    if dec.entropy_used == "gpu":
+        _same_coefficients(dec, host, host.info.components)
     host.close()
 
 

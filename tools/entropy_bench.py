@@ -49,30 +49,40 @@ for th in (1, 4, 16, 64):
 
 
 d = api.Decoder(0)
-for mode in ("host", "gpu"):
+for mode, walk in (("host", "1"), ("gpu", "0"), ("gpu", "1")):
+    os.environ["MIJPEG_DEVICE_WALK"] = walk
     ts = []
-    for it in range(4):
+    for it in range(6):
         t0 = time.perf_counter()
         d.read(data, entropy=mode)
         ts.append(time.perf_counter() - t0)
-    print(f"no-DRI 8K to coefficients in HBM, entropy={mode}: {min(ts)*1e3:.2f} ms", flush=True)
+    where = "" if mode == "host" else (" (walk on the device, %d rounds)" % d.device_walk_rounds() if walk == "1" else " (walk on the host)")
+    print(f"no-DRI 8K to coefficients in HBM, entropy={mode}{where}: {min(ts)*1e3:.2f} ms  { {k: round(v * 1e3, 3) for k, v in d.timing().items()} }", flush=True)
+os.environ["MIJPEG_DEVICE_WALK"] = "1"
 d.close()
 
 # batches of frames on the device: one Huffman launch + one reconstruction launch for n frames, pixels left in HBM
 import torch
-frames = [synth.encode_jpeg(synth.synth_image(W, H, 2000 + i), 85, "420", restart_mcus=8) for i in range(4)]
-for n in (1, 4, 16, 32):
-    batch = [frames[i % 4] for i in range(n)]
-    d = api.Decoder(0)
-    out = torch.empty((n, H, W * 3), dtype=torch.uint8, device="cuda")
-    ts, tp = [], []
-    for it in range(4):
-        t0 = time.perf_counter()
-        d.decode_batch_device(batch)
-        t1 = time.perf_counter()
-        d.reconstruct_batch_device(out.data_ptr(), H * W * 3, W * 3)
-        ts.append(time.perf_counter() - t0)
-        tm = d.timing()
-        tp.append((round(tm["h2d_wait"] * 1e3, 2), round(tm["kernel"] * 1e3, 2), round(tm["d2h"] * 1e3, 2), round((time.perf_counter() - t1) * 1e3, 2)))
-    print(f"batch of {n:2d} 8K frames (DRI 8): {min(ts)*1e3:7.2f} ms = {min(ts)*1e3/n:.3f} ms per frame, {W*H*n/min(ts)/1e6:8.0f} Mpixel/s (parse, prepare, upload+huffman, reconstruct ms: {tp[-1]})", flush=True)
-    d.close()
+for dri, walk, sizes in ((8, "1", (1, 4, 16, 32)), (0, "1", (1, 4, 16)), (0, "0", (4, 16))):
+    if os.environ.get("BATCH_ONLY_NODRI") and dri:
+        continue
+    os.environ["MIJPEG_DEVICE_WALK"] = walk
+    frames = [synth.encode_jpeg(synth.synth_image(W, H, 2000 + i), 85, "420", restart_mcus=dri) for i in range(4)]
+    what = f"DRI {dri}" if dri else ("no DRI, walk on the device" if walk == "1" else "no DRI, walk on the host")
+    for n in sizes:
+        batch = [frames[i % 4] for i in range(n)]
+        d = api.Decoder(0)
+        out = torch.empty((n, H, W * 3), dtype=torch.uint8, device="cuda")
+        ts, tp = [], []
+        for it in range(4):
+            t0 = time.perf_counter()
+            d.decode_batch_device(batch)
+            t1 = time.perf_counter()
+            d.reconstruct_batch_device(out.data_ptr(), H * W * 3, W * 3)
+            ts.append(time.perf_counter() - t0)
+            tm = d.timing()
+            tp.append((round(tm["h2d_wait"] * 1e3, 2), round(tm["kernel"] * 1e3, 2), round(tm["d2h"] * 1e3, 2), round((time.perf_counter() - t1) * 1e3, 2)))
+        rounds = f", {d.device_walk_rounds()} rounds" if d.device_walk_rounds() else ""
+        print(f"batch of {n:2d} 8K frames ({what}{rounds}): {min(ts)*1e3:7.2f} ms = {min(ts)*1e3/n:.3f} ms per frame, {W*H*n/min(ts)/1e6:8.0f} Mpixel/s (parse, prepare, upload+huffman, reconstruct ms: {tp[-1]})", flush=True)
+        d.close()
+os.environ["MIJPEG_DEVICE_WALK"] = "1"
