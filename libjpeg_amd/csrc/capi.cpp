@@ -316,13 +316,18 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
   if (B > 64) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many blocks per MCU for the device walk");
   w.nblk_mcu = B;
   w.ntables = scan.ntables;
-  // subsequence size: the serial part of the walk is (distance the decoder needs to synchronise + two subsequences),
-  // so small ones; larger only to bound the state arrays of very long streams
-  size_t longest = 0;
+  // subsequence size.  One image: the launch is latency-bound, its serial part is (distance the decoder needs to
+  // synchronise + two subsequences), so small ones.  Batches are throughput-bound and every round re-walks whole
+  // subsequences, so fewer rounds over larger ones (measured on 1, 4 and 16 8K frames: 128, 256, 512 bytes win).
+  size_t longest = 0, all_bytes = 0;
   for (int i = 0; i < n; i++)
-    if (dwalk[(size_t)i]) longest = std::max(longest, hosts[i]->scans[0].ecs_end - hosts[i]->scans[0].ecs_begin);
-  uint32_t sub_bytes = 128;
-  while (sub_bytes < 1024 && longest / sub_bytes > ((size_t)1 << 20)) sub_bytes <<= 1;
+    if (dwalk[(size_t)i]) {
+      const size_t len = hosts[i]->scans[0].ecs_end - hosts[i]->scans[0].ecs_begin;
+      longest = std::max(longest, len);
+      all_bytes += len;
+    }
+  uint32_t sub_bytes = all_bytes <= ((size_t)8 << 20) ? 128 : all_bytes <= ((size_t)32 << 20) ? 256 : 512;
+  while (sub_bytes < 1024 && longest / sub_bytes > ((size_t)1 << 20)) sub_bytes <<= 1; // bounds the prefix-sum tiles
   if (const char *e = getenv("MIJPEG_WALK_SUB")) sub_bytes = (uint32_t)std::max(32, std::min(4096, atoi(e))); // experiments
   w.sub_bytes = sub_bytes;
   // per image: its subsequences; per workgroup: image and first subsequence
@@ -672,17 +677,15 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
   if (needs_clear) HIP_TRY(d, hipMemsetAsync(coef_dev, 0, (size_t)n * (size_t)frame_stride * sizeof(int16_t), d->stream));
   const int repeat = getenv("MIJPEG_HUFF_REPEAT") ? atoi(getenv("MIJPEG_HUFF_REPEAT")) : 1; // experiments: steady-state kernel time
-  if (any_dwalk) {
-    // the walk needs the streams first: everything goes up at once, then the rounds, then the decode launch
+  const bool small = n == 1 || stream_bytes < ((size_t)8 << 20);
+  if (small) {
     for (int i = 0; i < n; i++)
       HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
-    const int wrc = device_walk_images(d, hosts, n, dwalk, a, (const HuffImage *)(d->ent_dev + off_img), (uint32_t *)(d->ent_dev + off_ib), d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images);
-    if (wrc) return wrc;
-    for (int r = 0; r < std::max(1, repeat); r++)
-      if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
-  } else if (n == 1 || stream_bytes < ((size_t)8 << 20)) {
-    for (int i = 0; i < n; i++)
-      HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
+    if (any_dwalk) {
+      const int wrc = device_walk_images(d, hosts, n, dwalk, a, (const HuffImage *)(d->ent_dev + off_img), (uint32_t *)(d->ent_dev + off_ib),
+                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images);
+      if (wrc) return wrc;
+    }
     for (int r = 0; r < std::max(1, repeat); r++)
       if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
   } else {
@@ -724,6 +727,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
       HIP_TRY(d, hipMemcpyAsync(d->ent_dev + b0, d->stage_host + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
       HIP_TRY(d, hipEventRecord(d->copy_events[(size_t)gi], d->copy_stream));
       HIP_TRY(d, hipStreamWaitEvent(d->stream, d->copy_events[(size_t)gi], 0));
+      if (any_dwalk) continue; // the walk below covers all images at once
       int64_t wg1 = wg0;
       for (int i = g0; i < g1; i++) wg1 += (nints[(size_t)i] + per_group - 1) / per_group;
       HuffScanArgs part = a; // the workgroups of this group's images
@@ -732,6 +736,13 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
       for (int r = 0; r < std::max(1, repeat); r++)
         if (launch_huffman_scan(part, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
       wg0 = wg1;
+    }
+    if (any_dwalk) {
+      const int wrc = device_walk_images(d, hosts, n, dwalk, a, (const HuffImage *)(d->ent_dev + off_img), (uint32_t *)(d->ent_dev + off_ib),
+                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images);
+      if (wrc) return wrc;
+      for (int r = 0; r < std::max(1, repeat); r++)
+        if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
     }
   }
   uint32_t *status_host = (uint32_t *)(d->ent_host + host_part);

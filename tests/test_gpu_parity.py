@@ -784,7 +784,8 @@ def test_device_entropy_decoder_without_restart_markers(dec, monkeypatch, walk, 
     host.close()
 
 
-@pytest.mark.parametrize("w,h,sub,n,mixed", [(1280, 720, "420", 6, False), (800, 608, "444", 4, True), (1920, 1080, "420", 9, True)])
+@pytest.mark.parametrize("w,h,sub,n,mixed", [(1280, 720, "420", 6, False), (800, 608, "444", 4, True), (1920, 1080, "420", 9, True),
+                                             (3840, 2160, "420", 10, False)])  # the last one: pipelined uploads
 def test_batch_without_restart_markers(oracle, w, h, sub, n, mixed):
     """Batches whose streams carry no restart markers (or only some do): one walk over all of them, one decode launch."""
     torch = _torch()
