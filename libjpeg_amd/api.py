@@ -363,8 +363,10 @@ def workspace_bytes(info: MijpegInfo, frames: int, flags: int = 0) -> int:
     return int(lib().mijpeg_workspace_bytes(C.byref(b)))
 
 
-def kernel_name(info: MijpegInfo, flags: int = 0) -> str:
+def kernel_name(info: MijpegInfo, flags: int = 0, xt: "MijpegXtParams | None" = None) -> str:
     b = MijpegBatch()
     C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
     b.flags = flags
+    if xt is not None:
+        b.xt = C.pointer(xt)
     return lib().mijpeg_kernel_name(C.byref(b)).decode()

@@ -951,9 +951,37 @@ static bool use_fused420p(const mijpeg_batch *b)
   return !off && use_fused420(b) && fast_ok(b) && f.range_max[1] < 2047 && f.range_max[2] < 2047;
 }
 
+// JPEG XT profile C in the shape the fused kernel covers: 8-bit 4:2:0 legacy frame and 12-bit 4:4:4 residual frame without
+// hidden bits, L transformation on, both frames within the range the fast transforms are exact for
+static bool use_fusedxt(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  if (!f.xt || !b->xt || !is_420(f) || f.precision != 8 || (b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_FORCE_SAFE))) return false;
+  // the legacy frame's range check (fast_arith itself is never set for XT frames: the generic kernels run SAFE on them)
+  for (int c = 0; c < 3; c++) {
+    if (f.range_max[c] >= 16384) return false;
+    for (int i = 0; i < 64; i++)
+      if (f.quant[f.quant_index[c]][i] > 2047) return false;
+  }
+  static const bool off = getenv("MIJPEG_NO_FUSEDXT") != nullptr; // A-B comparisons
+  if (off) return false;
+  const mijpeg_xt_params &x = *b->xt;
+  const mijpeg_info &r = x.residual;
+  if (x.hidden_bits || x.residual_hidden_bits || x.residual_wide || x.ltable_entries != 256 || !x.ltrafo_ycbcr || r.precision != 12 || r.components != 3 ||
+      x.out_max != 65535 || x.out_shift != 32768)
+    return false;
+  for (int c = 0; c < 3; c++) {
+    if (r.subx[c] != 1 || r.suby[c] != 1 || r.blocks_w[c] != r.blocks_w[0] || r.blocks_h[c] != r.blocks_h[0] || r.range_max[c] >= 65536) return false;
+    for (int i = 0; i < 64; i++)
+      if (r.quant[r.quant_index[c]][i] > 2047) return false;
+  }
+  return r.width == f.width && r.height == f.height;
+}
+
 const char *mijpeg_kernel_name(const mijpeg_batch *b)
 {
   if (!b) return "";
+  if (use_fusedxt(b)) return "fusedxt420_kernel";
   if (use_fused420p(b)) return "fused420p_kernel";
   return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : b->info.xt ? "idct_planes_kernel+xt_merge_kernel"
                                                                                                  : "idct_planes_kernel+upsample_color_kernel";
@@ -964,6 +992,7 @@ static const size_t LUT_BYTES = 3 * 4096 * sizeof(int32_t);
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
 {
   if (!b || use_fused420(b) || use_fused444(b)) return 0;
+  if (use_fusedxt(b)) return LUT_BYTES;
   // [LUT_BYTES: L lookup tables (JPEG XT, up to 3 x 4096 entries)] [per frame: int32 sample planes, one sample per
   // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients]
   return LUT_BYTES + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames;
@@ -979,10 +1008,12 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   const bool fast = fast_ok(b);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  const bool f444 = use_fused444(b);
-  if (use_fused420(b) || f444) {
-    Fused420Args a;
-    memset(&a, 0, sizeof(a));
+  const bool f444 = use_fused444(b), fxt = use_fusedxt(b);
+  if (fxt && (!b->workspace || b->workspace_bytes < LUT_BYTES)) return MIJPEG_ERR_MISSING_PARAMETER;
+  if (use_fused420(b) || f444 || fxt) {
+    FusedXtArgs xa;
+    memset(&xa, 0, sizeof(xa));
+    Fused420Args &a = xa.base;
     a.coef = b->coef_dev;
     a.coef_frame_stride = b->coef_frame_stride;
     a.off_y = f.coef_offset[0];
@@ -1005,7 +1036,26 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.aligned8 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 7) == 0;
     for (int c = 0; c < 3; c++)
       for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
-    rc = f444 ? launch_fused444(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
+    if (fxt) {
+      const mijpeg_xt_params &x = *b->xt;
+      const mijpeg_info &r = x.residual;
+      for (int c = 0; c < 3; c++) {
+        xa.ext.off_r[c] = r.coef_offset[c];
+        for (int i = 0; i < 64; i++) xa.ext.rq[c][i] = (int32_t)r.quant[r.quant_index[c]][i] << 4;
+        if (hipMemcpyAsync((int32_t *)b->workspace + (size_t)c * 256, x.ltable[c], 256 * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess)
+          return MIJPEG_ERR_DEVICE;
+      }
+      xa.ext.bw_r = r.blocks_w[0];
+      xa.ext.bh_r = r.blocks_h[0];
+      xa.ext.ltable = (const int32_t *)b->workspace;
+      xa.ext.rtrafo_ycbcr = x.rtrafo_ycbcr;
+      xa.ext.is_float = x.is_float;
+      xa.ext.out_max = x.out_max;
+      xa.ext.out_shift = x.out_shift;
+      xa.ext.aligned16 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 15) == 0;
+      rc = launch_fusedxt420(xa, s);
+    } else
+      rc = f444 ? launch_fused444(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

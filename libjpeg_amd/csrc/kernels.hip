@@ -369,6 +369,90 @@ constexpr int F420_CROWS = 66;            // chroma lines kept in LDS (64 + 2 ha
 constexpr int F420_CPITCH = 72;           // dwords per LDS chroma line; column pc <-> chroma x_rel = pc - 4
 constexpr int F420_THREADS = 256;
 
+// phase A of the 4:2:0 kernels with 32-bit chroma samples: the (8+2) x (8+2) chroma blocks of tile (tx, ty) -> LDS
+template <bool FAST>
+__device__ __forceinline__ void f420_chroma_to_lds(const Fused420Args &a, const int16_t *__restrict__ coef, int (*cplane)[F420_CROWS * F420_CPITCH],
+                                                   u32x4 *stage, int lane, int wave, int tx, int ty)
+{
+  const int comp = wave >> 1; // 0 = Cb, 1 = Cr (wave-uniform)
+  const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
+  const int gx0 = tx * 8 - 1, gy0 = ty * 8 - 1;
+  const int base = (wave & 1) * 64;
+  // tiles whose whole 10 x 10 block window lies inside the plane need no clamping (wave-uniform)
+  const bool inside = gx0 >= 0 && gy0 >= 0 && gx0 + F420_CGRID <= a.bw_c && gy0 + F420_CGRID <= a.bh_c;
+  u32x4 rows[8];
+  // local block n = (lane >> 3) + 8 m is grid index base + n (clamped to the grid: waves 1 and 3 only hold 36 blocks)
+  const int idx0 = base + (lane >> 3);
+  const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+  if (inside) {
+    const unsigned off0 = (unsigned)((gy0 * a.bw_c + gx0) * 128), rowb = (unsigned)a.bw_c * 128u;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const unsigned i = (unsigned)min(idx0 + 8 * m, F420_CGRID * F420_CGRID - 1);
+      const unsigned y = (i * 205u) >> 11, x = i - y * F420_CGRID; // i / 10, i % 10 for i < 1029
+      return reinterpret_cast<const u32x4 *>(pbase + (off0 + y * rowb + x * 128u));
+    });
+  } else {
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int i = min(idx0 + 8 * m, F420_CGRID * F420_CGRID - 1);
+      const int y = (i * 205) >> 11, x = i - y * F420_CGRID;
+      const int gx = min(max(gx0 + x, 0), a.bw_c - 1), gy = min(max(gy0 + y, 0), a.bh_c - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((gy * a.bw_c + gx) * 128));
+    });
+  }
+  const int idx = base + lane;
+  const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
+  const int gx = gx0 + cbx, gy = gy0 + cby;
+  if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
+    int v[64];
+    if (FAST) dequant_idct_sparse(rows, a.q[1 + comp], v);
+    else dequant_idct<false>(rows, a.q[1 + comp], v, 128 << 7);
+    int *cp = cplane[comp];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int pr = 8 * cby + r - 7;
+      if (pr >= 0 && pr < F420_CROWS) {
+        if (cbx == 0) {
+          cp[pr * F420_CPITCH + 3] = v[r * 8 + 7];
+        } else if (cbx == F420_CGRID - 1) {
+          cp[pr * F420_CPITCH + 68] = v[r * 8 + 0];
+        } else {
+          i32x4 *dst = reinterpret_cast<i32x4 *>(cp + pr * F420_CPITCH + 8 * cbx - 4);
+          dst[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
+          dst[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
+        }
+      }
+    }
+  }
+}
+
+// image-edge tiles: replicate the last valid chroma column / line outwards (upsamplerbase.cpp:322-323, upsampler.cpp:100-112)
+__device__ __forceinline__ void f420_chroma_edges(const Fused420Args &a, int (*cplane)[F420_CROWS * F420_CPITCH], int tid, int tx, int ty)
+{
+  const int last_col = a.cw - 1 - tx * 64; // last valid chroma column, tile-relative
+  const int last_row = a.ch - 1 - ty * 64;
+  const bool edge = (tx == 0) | (ty == 0) | (last_col < 64) | (last_row < 64);
+  if (edge) {
+    if (tid < 2 * F420_CROWS) { // one thread per stored line: replicate columns
+      int *p = cplane[tid / F420_CROWS] + (tid % F420_CROWS) * F420_CPITCH;
+      if (tx == 0) p[3] = p[4];
+      if (last_col < 64) {
+        const int v = p[last_col + 4];
+        for (int pc = last_col + 5; pc <= 68; pc++) p[pc] = v;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * F420_CROWS) { // one thread per stored column: replicate lines
+      int *p = cplane[tid / F420_CROWS] + 3 + (tid % F420_CROWS);
+      if (ty == 0) p[0] = p[F420_CPITCH];
+      if (last_row < 64) {
+        const int v = p[(last_row + 1) * F420_CPITCH];
+        for (int pr = last_row + 2; pr < F420_CROWS; pr++) p[pr * F420_CPITCH] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <bool FAST, int MINW>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fused420Args a)
 {
@@ -396,86 +480,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
-  // ------------------------------------------------------------------ phase A: chroma -> LDS
-  {
-    const int comp = wave >> 1; // 0 = Cb, 1 = Cr (wave-uniform)
-    const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
-    const int gx0 = tx * 8 - 1, gy0 = ty * 8 - 1;
-    const int base = (wave & 1) * 64;
-    // tiles whose whole 10 x 10 block window lies inside the plane need no clamping (wave-uniform)
-    const bool inside = gx0 >= 0 && gy0 >= 0 && gx0 + F420_CGRID <= a.bw_c && gy0 + F420_CGRID <= a.bh_c;
-    u32x4 rows[8];
-    // local block n = (lane >> 3) + 8 m is grid index base + n (clamped to the grid: waves 1 and 3 only hold 36 blocks)
-    const int idx0 = base + (lane >> 3);
-    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
-    if (inside) {
-      const unsigned off0 = (unsigned)((gy0 * a.bw_c + gx0) * 128), rowb = (unsigned)a.bw_c * 128u;
-      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
-        const unsigned i = (unsigned)min(idx0 + 8 * m, F420_CGRID * F420_CGRID - 1);
-        const unsigned y = (i * 205u) >> 11, x = i - y * F420_CGRID; // i / 10, i % 10 for i < 1029
-        return reinterpret_cast<const u32x4 *>(pbase + (off0 + y * rowb + x * 128u));
-      });
-    } else {
-      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
-        const int i = min(idx0 + 8 * m, F420_CGRID * F420_CGRID - 1);
-        const int y = (i * 205) >> 11, x = i - y * F420_CGRID;
-        const int gx = min(max(gx0 + x, 0), a.bw_c - 1), gy = min(max(gy0 + y, 0), a.bh_c - 1);
-        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((gy * a.bw_c + gx) * 128));
-      });
-    }
-    const int idx = base + lane;
-    const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
-    const int gx = gx0 + cbx, gy = gy0 + cby;
-    if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
-      int v[64];
-      if (FAST) dequant_idct_sparse(rows, a.q[1 + comp], v);
-      else dequant_idct<false>(rows, a.q[1 + comp], v, 128 << 7);
-      int *cp = cplane[comp];
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const int pr = 8 * cby + r - 7;
-        if (pr >= 0 && pr < F420_CROWS) {
-          if (cbx == 0) {
-            cp[pr * F420_CPITCH + 3] = v[r * 8 + 7];
-          } else if (cbx == F420_CGRID - 1) {
-            cp[pr * F420_CPITCH + 68] = v[r * 8 + 0];
-          } else {
-            i32x4 *dst = reinterpret_cast<i32x4 *>(cp + pr * F420_CPITCH + 8 * cbx - 4);
-            dst[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
-            dst[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
-          }
-        }
-      }
-    }
-  }
+  f420_chroma_to_lds<FAST>(a, coef, cplane, stage, lane, wave, tx, ty);
   __syncthreads();
-
-  // ------------------------------------------------------------------ edge fix-up (uniform branch)
-  {
-    const int last_col = a.cw - 1 - tx * 64; // last valid chroma column, tile-relative
-    const int last_row = a.ch - 1 - ty * 64;
-    const bool edge = (tx == 0) | (ty == 0) | (last_col < 64) | (last_row < 64);
-    if (edge) {
-      if (tid < 2 * F420_CROWS) { // one thread per stored line: replicate columns
-        int *p = cplane[tid / F420_CROWS] + (tid % F420_CROWS) * F420_CPITCH;
-        if (tx == 0) p[3] = p[4];
-        if (last_col < 64) {
-          const int v = p[last_col + 4];
-          for (int pc = last_col + 5; pc <= 68; pc++) p[pc] = v;
-        }
-      }
-      __syncthreads();
-      if (tid < 2 * F420_CROWS) { // one thread per stored column: replicate lines
-        int *p = cplane[tid / F420_CROWS] + 3 + (tid % F420_CROWS);
-        if (ty == 0) p[0] = p[F420_CPITCH];
-        if (last_row < 64) {
-          const int v = p[(last_row + 1) * F420_CPITCH];
-          for (int pr = last_row + 2; pr < F420_CROWS; pr++) p[pr * F420_CPITCH] = v;
-        }
-      }
-      __syncthreads();
-    }
-  }
+  f420_chroma_edges(a, cplane, tid, tx, ty);
 
   // ------------------------------------------------------------------ phase B: luma + colour
   const int bx = lane & 15, by = wave * 4 + (lane >> 4);
@@ -835,6 +842,194 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     // slide the three-line window
 #pragma unroll
     for (int j = 0; j < 6; j++) { cT[j] = cC[j]; cC[j] = cB[j]; }
+  }
+}
+
+// ==============================================================================================
+// fused JPEG XT profile C kernel: 8-bit 4:2:0 legacy frame + 12-bit 4:4:4 residual frame -> 16-bit codes
+// ==============================================================================================
+// The shape BASELINE config 5 names.  Decomposition of fused420_kernel<true>: phase A puts the tile's chroma samples of
+// the legacy frame into LDS; in phase B every lane owns one 8x8 pixel block and transforms FOUR coefficient blocks for
+// it: the three residual blocks first -- their samples are clamped to [0, 2^16) right away, which is the first thing
+// the merge does with them (Q table of the subset: clamp, scale by 16), so two of them share a register: 96 registers
+// for the block's residual -- then the legacy luma block.  Per line it upsamples chroma from LDS exactly as
+// fused420_kernel does, runs the legacy colour stage, looks the three 8-bit results up in the L tables (LDS), runs
+// the residual chain of xt_merge_kernel on the packed samples and stores eight pixels = 48 bytes.
+// All transforms are the FAST flavour without level shift; for the residual frame that is exact when
+// max_block sum |c| q < 2^16: the multiplier inputs then stay below 2^23 and the sums in front of the rounding shifts
+// below 2^31 (|row output| <= 16 M_r 725 / 512 with M_r the row's share of the sum, 725 = largest entry of the scaled
+// transform matrix; the column pass sees 22.7 M in total), so wrapping 32-bit and 24-bit-operand arithmetic agree.
+// The level shift 2^11 << 7 passes through both rounding shifts exactly and comes out as 2^15 (see dequant_idct).
+constexpr int FXT_MINW = 2;
+__global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(const Fused420Args a, const FusedXtExtra x)
+{
+  __shared__ __attribute__((aligned(16))) int cplane[2][F420_CROWS * F420_CPITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+  __shared__ int ltab[3 * 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  {
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, xc = b & 7, i = b >> 3;
+    logical = xc * q + min(xc, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i];
+  f420_chroma_to_lds<true>(a, coef, cplane, stage, lane, wave, tx, ty);
+  __syncthreads();
+  f420_chroma_edges(a, cplane, tid, tx, ty);
+
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+  const int X0 = (gbx0 + bx) * 8, Y0 = (ty * F420_TILE_BLOCKS + by) * 8;
+  u32x4 rows[8];
+  // the wave's 16 x 4 blocks of a plane of bw x bh blocks: local block n = (lane >> 3) + 8 m sits at column
+  // (lane >> 3) + 8 (m & 1), row m >> 1; blocks outside the plane are redirected to a valid one and never used
+  auto fetch_plane = [&](const int16_t *__restrict__ plane, int bw, int bh) {
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int xx = min(x0 + 8 * (m & 1), bw - 1), yy = min(gby0 + (m >> 1), bh - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * bw + xx) * 128));
+    });
+  };
+
+  // ------------------------------------------------------------------ residual blocks -> packed, clamped samples
+  unsigned rp0[32], rp1[32], rp2[32];
+  auto residual_block = [&](int64_t off, const int *__restrict__ q, unsigned (&rp)[32]) {
+    fetch_plane(coef + off, x.bw_r, x.bh_r);
+    int v[64];
+    dequant_idct_sparse(rows, q, v);
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int lo = min(max(v[2 * i] + 32768, 0), 65535), hi = min(max(v[2 * i + 1] + 32768, 0), 65535);
+      unsigned d;
+      asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(d) : "v"(hi), "v"(lo)); // volatile: pack here, see pack_lo16_now
+      rp[i] = d;
+    }
+  };
+  residual_block(x.off_r[0], x.rq[0], rp0);
+  residual_block(x.off_r[1], x.rq[1], rp1);
+  residual_block(x.off_r[2], x.rq[2], rp2);
+
+  // ------------------------------------------------------------------ legacy luma
+  fetch_plane(coef + a.off_y, a.bw_y, a.bh_y);
+  int yv[64];
+  dequant_idct_sparse(rows, a.q[0], yv);
+
+  const bool active = X0 < a.width && Y0 < a.height;
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 6u;
+  const int npx = min(8, a.width - X0);
+  const int nln = active ? min(8, a.height - Y0) : 0;
+  const bool fast_store = x.aligned16 && npx == 8;
+
+  const int *cb_base = cplane[0] + (4 * by) * F420_CPITCH + 4 * bx;
+  const int *cr_base = cplane[1] + (4 * by) * F420_CPITCH + 4 * bx;
+  auto load6 = [](const int *p, int (&d)[6]) {
+    const i32x4 mid = *reinterpret_cast<const i32x4 *>(p + 4);
+    d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
+  };
+  // constants of the merge (see xt_merge_kernel)
+  const int omax16 = ((x.out_max + 1) << 4) - 1;
+  const int pinf = (x.out_max >> 1) - (x.out_max >> 6) - 1, minf = -pinf - 1;
+
+  int cbT[6], cbC[6], cbB[6], crT[6], crC[6], crB[6];
+  load6(cb_base, cbT); load6(cb_base + F420_CPITCH, cbC);
+  load6(cr_base, crT); load6(cr_base + F420_CPITCH, crC);
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    load6(cb_base + (m + 2) * F420_CPITCH, cbB);
+    load6(cr_base + (m + 2) * F420_CPITCH, crB);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int l = 2 * m + half;
+      int vb[6], vr[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const int rnd = ((j & 1) ^ half) ? 1 : 2;
+        vb[j] = tap13(half ? cbB[j] : cbT[j], cbC[j], rnd);
+        vr[j] = tap13(half ? crB[j] : crT[j], crC[j], rnd);
+      }
+      int ub[8], ur[8];
+      auto hfilt = [](const int (&v)[6], int (&o)[8]) {
+        o[7] = tap13(v[5], v[4], 1);
+        o[6] = tap13(v[3], v[4], 2);
+        o[5] = tap13(v[4], v[3], 1);
+        o[4] = tap13(v[2], v[3], 2);
+        o[3] = tap13(v[3], v[2], 1);
+        o[2] = tap13(v[1], v[2], 2);
+        o[1] = tap13(o[2], v[1], 1); // src[1] has already been overwritten by out[2]
+        o[0] = tap13(v[0], v[1], 2);
+      };
+      hfilt(vb, ub);
+      hfilt(vr, ur);
+      unsigned px[24];
+      const int K = (2048 << 13) + 65536; // level shifts of the FAST transforms + rounding, see fused420_kernel
+#pragma unroll
+      for (int xx = 0; xx < 8; xx++) {
+        // legacy chain: L transformation, clamp to 8 bits, L table
+        const int yk = (yv[l * 8 + xx] << 13) + K;
+        const int lr = clamp255(mad24(ur[xx], L_CR_R, yk) >> 17);
+        const int lg = clamp255(mad24(ur[xx], -L_CR_G, mad24(ub[xx], -L_CB_G, yk)) >> 17);
+        const int lb = clamp255(mad24(ub[xx], L_CB_B, yk) >> 17);
+        const int lv[3] = {ltab[lr], ltab[256 + lg], ltab[512 + lb]};
+        // residual chain: (Q table done above) R transformation, R2 table
+        const int i = (l * 8 + xx) >> 1;
+        const unsigned sh = (xx & 1) ? 16u : 0u;
+        const int qy = (int)((rp0[i] >> sh) & 0xffffu), qb = (int)((rp1[i] >> sh) & 0xffffu), qr = (int)((rp2[i] >> sh) & 0xffffu);
+        int rr[3];
+        if (x.rtrafo_ycbcr) {
+          const int db = qb - x.out_shift, dr = qr - x.out_shift, y16 = qy << 4;
+          rr[0] = y16 + ((dr * L_CR_R + 256) >> 9);
+          rr[1] = y16 + ((-db * L_CB_G - dr * L_CR_G + 256) >> 9);
+          rr[2] = y16 + ((db * L_CB_B + 256) >> 9);
+        } else {
+          rr[0] = qy << 4; rr[1] = qb << 4; rr[2] = qr << 4;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const int r2 = (min(max(rr[c], 0), omax16) + 8) >> 4;
+          int mrg = lv[c] + r2 - x.out_shift;
+          if (x.is_float) {
+            mrg = min(max(mrg, minf), pinf);
+            const short w = (short)mrg;
+            px[3 * xx + c] = (unsigned)(unsigned short)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS
+          } else {
+            px[3 * xx + c] = (unsigned)min(max(mrg, 0), x.out_max);
+          }
+        }
+      }
+      if (l < nln) {
+        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+        if (fast_store) {
+          unsigned w[12];
+#pragma unroll
+          for (int i = 0; i < 12; i++) w[i] = px[2 * i] | (px[2 * i + 1] << 16);
+          u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+          __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
+          __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
+          __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+        } else {
+          unsigned short *d16 = reinterpret_cast<unsigned short *>(dst);
+#pragma unroll
+          for (int xx = 0; xx < 8; xx++)
+            if (xx < npx) { d16[3 * xx] = (unsigned short)px[3 * xx]; d16[3 * xx + 1] = (unsigned short)px[3 * xx + 1]; d16[3 * xx + 2] = (unsigned short)px[3 * xx + 2]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) { cbT[j] = cbC[j]; cbC[j] = cbB[j]; crT[j] = crC[j]; crC[j] = crB[j]; }
   }
 }
 
@@ -1392,6 +1587,13 @@ int launch_fused420p(const Fused420Args &a, hipStream_t stream)
     hipLaunchKernelGGL((fused420p_kernel<3, 1>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else
     hipLaunchKernelGGL((fused420p_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
+{
+  const unsigned total = (unsigned)x.base.tiles_x * x.base.tiles_y * x.base.frames;
+  hipLaunchKernelGGL(fusedxt420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   return (int)hipGetLastError();
 }
 

@@ -26,6 +26,20 @@ struct Fused420Args {
   int32_t q[3][64];               // deltas << 4 per component (Y, Cb, Cr), natural order (idct.cpp:98-109)
 };
 
+// fused JPEG XT profile C (8-bit 4:2:0 legacy frame + 12-bit 4:4:4 residual frame, see fusedxt420_kernel)
+struct FusedXtExtra {
+  int64_t off_r[3];           // residual planes (int16 units from the frame's coefficient base)
+  int32_t bw_r, bh_r;         // residual planes in blocks (4:4:4, padded to 8 only: may be narrower than the luma plane)
+  int32_t rq[3][64];          // residual deltas << 4
+  const int32_t *ltable;      // device: [3][256]
+  int32_t rtrafo_ycbcr, is_float, out_max, out_shift;
+  int32_t aligned16;          // out, strides multiples of 16 bytes
+};
+struct FusedXtArgs {
+  Fused420Args base;          // legacy frame, geometry; out = 16-bit samples, strides in bytes
+  FusedXtExtra ext;
+};
+
 // generic path: any sampling / component count / precision, two kernels with int32 sample planes in between.
 // "Planes" are the component planes of the legacy codestream, followed -- for JPEG XT -- by those of the
 // residual codestream (3 + 3).
@@ -59,6 +73,7 @@ struct GenericArgs {
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
 int launch_fused420p(const Fused420Args &a, hipStream_t stream); // FAST only, chroma samples within int16 filter range
 int launch_fused444(const Fused420Args &a, hipStream_t stream); // same argument block; all planes bw_y x bh_y
+int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream);
 int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream);
 
 // Rectangle of the reconstructed interleaved frame -> bitmaps in DEVICE memory described like the reference's

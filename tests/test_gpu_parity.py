@@ -166,9 +166,13 @@ def test_xt_profile_c_golden(dec, oracle, name):
     ent = MANIFEST[name]
     f = dec.read(golden_jpeg(name))
     assert f.xt == 1 and f.is_float == 1 and f.sample_bytes == 2
-    assert api.kernel_name(f) == "idct_planes_kernel+xt_merge_kernel"
+    # 8-bit 4:2:0 legacy + 12-bit 4:4:4 residual without hidden bits has a fused kernel; everything else takes three
+    fused = "_420" in name and "_R" not in name and "_rR" not in name
+    assert api.kernel_name(f, xt=dec.xt_params()) == ("fusedxt420_kernel" if fused else "idct_planes_kernel+xt_merge_kernel")
     codes = dec.reconstruct()
     assert codes.dtype == np.uint16 and codes.shape == (ent["height"], ent["width"], 3)
+    if fused:
+        assert np.array_equal(codes, dec.reconstruct(api.FLAG_FORCE_GENERIC))
     exp_codes, _ = oracle.decode_xt(golden_jpeg(name))
     bad = int((codes != exp_codes).sum())
     assert bad == 0, f"{bad} differing half codes, first at {np.argwhere(codes != exp_codes)[:4].tolist()}"
@@ -195,10 +199,25 @@ def test_xt_4k_vs_oracle(dec, oracle):
         pytest.skip("needs oracle/_ref/jpeg to encode the HDR stream")
     data = oracle.reference_encode_hdr(synth.synth_hdr(3840, 2160, 99),
                                        ["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-s", "1x1,2x2,2x2"])
-    dec.read(data)
+    f = dec.read(data)
+    assert api.kernel_name(f, xt=dec.xt_params()) == "fusedxt420_kernel"
     codes = dec.reconstruct()
     exp, _ = oracle.decode_xt(data)
     assert np.array_equal(codes, exp)
+    assert np.array_equal(dec.reconstruct(api.FLAG_FORCE_GENERIC), exp)
+
+
+@pytest.mark.parametrize("w,h", [(136, 72), (250, 130), (1023, 517), (128, 128)])
+def test_fused_xt_kernel_tile_edges(dec, oracle, w, h):
+    """Fused profile C kernel at sizes that leave partial tiles / blocks and a residual plane narrower than the luma plane."""
+    if not oracle.have_reference():
+        pytest.skip("needs oracle/_ref/jpeg to encode the HDR stream")
+    for q, rq in ((85, 90), (30, 60)):
+        data = oracle.reference_encode_hdr(synth.synth_hdr(w, h, 5 + w), ["-r", "-q", str(q), "-Q", str(rq), "-h", "-profile", "c", "-r12", "-s", "1x1,2x2,2x2"])
+        f = dec.read(data)
+        assert api.kernel_name(f, xt=dec.xt_params()) == "fusedxt420_kernel"
+        exp, _ = oracle.decode_xt(data)
+        assert np.array_equal(dec.reconstruct(), exp)
 
 
 def _torch():
