@@ -884,7 +884,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
-  for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i];
+  for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift; // the merge subtracts it anyway
   f420_chroma_to_lds<true>(a, coef, cplane, stage, lane, wave, tx, ty);
   __syncthreads();
   f420_chroma_edges(a, cplane, tid, tx, ty);
@@ -912,9 +912,9 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
     dequant_idct_sparse(rows, q, v);
 #pragma unroll
     for (int i = 0; i < 32; i++) {
-      const int lo = min(max(v[2 * i] + 32768, 0), 65535), hi = min(max(v[2 * i + 1] + 32768, 0), 65535);
+      // clamp(v + 2^15, 0, 2^16 - 1) - 2^15 as int16: the saturating conversion does clamp and pack for two samples
       unsigned d;
-      asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(d) : "v"(hi), "v"(lo)); // volatile: pack here, see pack_lo16_now
+      asm volatile("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(d) : "v"(v[2 * i]), "v"(v[2 * i + 1])); // volatile: pack here, see pack_lo16_now
       rp[i] = d;
     }
   };
@@ -941,8 +941,8 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
     d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
   };
   // constants of the merge (see xt_merge_kernel)
-  const int omax16 = ((x.out_max + 1) << 4) - 1;
-  const int pinf = (x.out_max >> 1) - (x.out_max >> 6) - 1, minf = -pinf - 1;
+  const int pinf = (x.out_max >> 1) - (x.out_max >> 6) - 1, minf = -pinf - 1; // largest finite half 0x7bff, and its mirror
+  const unsigned pinf2 = (unsigned)pinf * 0x10001u, minf2 = ((unsigned)minf & 0xffffu) * 0x10001u;
 
   int cbT[6], cbC[6], cbB[6], crT[6], crC[6], crB[6];
   load6(cb_base, cbT); load6(cb_base + F420_CPITCH, cbC);
@@ -974,48 +974,61 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
       };
       hfilt(vb, ub);
       hfilt(vr, ur);
-      unsigned px[24];
+      int mm[24]; // legacy + residual - output shift, R G B of the eight pixels
       const int K = (2048 << 13) + 65536; // level shifts of the FAST transforms + rounding, see fused420_kernel
 #pragma unroll
       for (int xx = 0; xx < 8; xx++) {
-        // legacy chain: L transformation, clamp to 8 bits, L table
+        // legacy chain: L transformation, clamp to 8 bits, L table (output shift already subtracted)
         const int yk = (yv[l * 8 + xx] << 13) + K;
         const int lr = clamp255(mad24(ur[xx], L_CR_R, yk) >> 17);
         const int lg = clamp255(mad24(ur[xx], -L_CR_G, mad24(ub[xx], -L_CB_G, yk)) >> 17);
         const int lb = clamp255(mad24(ub[xx], L_CB_B, yk) >> 17);
         const int lv[3] = {ltab[lr], ltab[256 + lg], ltab[512 + lb]};
-        // residual chain: (Q table done above) R transformation, R2 table
+        // residual chain on the packed samples s = q - 2^15 (q = Q table output / 16): R transformation
+        //   rr = 16 q_y + ((d L + 256) >> 9), R2 table r2 = (clamp(rr, 0, 16 (out_max + 1) - 1) + 8) >> 4
+        // = clamp((rr + 8) >> 4, 0, out_max + 1); with 16 q_y = 16 s_y + 2^19 and 2^19 = 2^28 >> 9, 8 = 4096 >> 9 the
+        // constants move into the multiply-add: all exact (|d L| < 2^29, so nothing wraps)
         const int i = (l * 8 + xx) >> 1;
-        const unsigned sh = (xx & 1) ? 16u : 0u;
-        const int qy = (int)((rp0[i] >> sh) & 0xffffu), qb = (int)((rp1[i] >> sh) & 0xffffu), qr = (int)((rp2[i] >> sh) & 0xffffu);
-        int rr[3];
+        const bool hi = (xx & 1) != 0;
+        int r2[3];
         if (x.rtrafo_ycbcr) {
-          const int db = qb - x.out_shift, dr = qr - x.out_shift, y16 = qy << 4;
-          rr[0] = y16 + ((dr * L_CR_R + 256) >> 9);
-          rr[1] = y16 + ((-db * L_CB_G - dr * L_CR_G + 256) >> 9);
-          rr[2] = y16 + ((db * L_CB_B + 256) >> 9);
-        } else {
-          rr[0] = qy << 4; rr[1] = qb << 4; rr[2] = qr << 4;
+          const int C = 256 + (1 << 28) + 4096;
+          const int t0 = hi ? mad16_hi(rp2[i], L_CR_R, C) : mad16_lo(rp2[i], L_CR_R, C);
+          const int t1 = hi ? mad16_hi(rp1[i], -L_CB_G, mad16_hi(rp2[i], -L_CR_G, C)) : mad16_lo(rp1[i], -L_CB_G, mad16_lo(rp2[i], -L_CR_G, C));
+          const int t2 = hi ? mad16_hi(rp1[i], L_CB_B, C) : mad16_lo(rp1[i], L_CB_B, C);
+          const int u0 = hi ? mad16_hi(rp0[i], 16, t0 >> 9) : mad16_lo(rp0[i], 16, t0 >> 9);
+          const int u1 = hi ? mad16_hi(rp0[i], 16, t1 >> 9) : mad16_lo(rp0[i], 16, t1 >> 9);
+          const int u2 = hi ? mad16_hi(rp0[i], 16, t2 >> 9) : mad16_lo(rp0[i], 16, t2 >> 9);
+          r2[0] = min(max(u0 >> 4, 0), x.out_max + 1);
+          r2[1] = min(max(u1 >> 4, 0), x.out_max + 1);
+          r2[2] = min(max(u2 >> 4, 0), x.out_max + 1);
+        } else { // identity: (16 q + 8) >> 4 = q
+          r2[0] = (hi ? (int)rp0[i] >> 16 : (int)(short)rp0[i]) + 32768;
+          r2[1] = (hi ? (int)rp1[i] >> 16 : (int)(short)rp1[i]) + 32768;
+          r2[2] = (hi ? (int)rp2[i] >> 16 : (int)(short)rp2[i]) + 32768;
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const int r2 = (min(max(rr[c], 0), omax16) + 8) >> 4;
-          int mrg = lv[c] + r2 - x.out_shift;
-          if (x.is_float) {
-            mrg = min(max(mrg, minf), pinf);
-            const short w = (short)mrg;
-            px[3 * xx + c] = (unsigned)(unsigned short)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS
-          } else {
-            px[3 * xx + c] = (unsigned)min(max(mrg, 0), x.out_max);
-          }
+        for (int c = 0; c < 3; c++) mm[3 * xx + c] = lv[c] + r2[c];
+      }
+      // clamp and, for float output, INVERT_NEGS (ycbcrtrafo.cpp:66) -- two samples per instruction: the saturating
+      // conversion to int16 cannot cut into the half-float range [minf, pinf], which lies inside int16
+      unsigned w[12];
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        if (x.is_float) {
+          unsigned pk, sg;
+          asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(pk) : "v"(mm[2 * i]), "v"(mm[2 * i + 1]));
+          asm("v_pk_max_i16 %0, %1, %2" : "=v"(pk) : "v"(pk), "v"(minf2));
+          asm("v_pk_min_i16 %0, %1, %2" : "=v"(pk) : "v"(pk), "v"(pinf2));
+          asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(sg) : "v"(pk)); // the constant has no high half of its own
+          w[i] = pk ^ (sg & 0x7fff7fffu);
+        } else {
+          w[i] = (unsigned)min(max(mm[2 * i], 0), x.out_max) | ((unsigned)min(max(mm[2 * i + 1], 0), x.out_max) << 16);
         }
       }
       if (l < nln) {
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         if (fast_store) {
-          unsigned w[12];
-#pragma unroll
-          for (int i = 0; i < 12; i++) w[i] = px[2 * i] | (px[2 * i + 1] << 16);
           u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
           __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
           __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
@@ -1023,8 +1036,8 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
         } else {
           unsigned short *d16 = reinterpret_cast<unsigned short *>(dst);
 #pragma unroll
-          for (int xx = 0; xx < 8; xx++)
-            if (xx < npx) { d16[3 * xx] = (unsigned short)px[3 * xx]; d16[3 * xx + 1] = (unsigned short)px[3 * xx + 1]; d16[3 * xx + 2] = (unsigned short)px[3 * xx + 2]; }
+          for (int k = 0; k < 24; k++)
+            if (k < 3 * npx) d16[k] = (unsigned short)(w[k >> 1] >> ((k & 1) * 16));
         }
       }
     }
