@@ -279,16 +279,19 @@ const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component)
 // ------------------------------------------------------------------------------------------------
 // on-device entropy decoding
 // ------------------------------------------------------------------------------------------------
-// Why a parsed stream cannot be entropy-decoded on the device (nullptr: it can).
-static const char *device_entropy_obstacle(const HostDecoder &h, size_t size)
+// Why a parsed stream cannot be entropy-decoded on the device (nullptr: it can).  `xt_part`: the stream is one of the
+// two codestreams of a JPEG XT profile C file (8-bit legacy or 12-bit residual frame without hidden refinement scans).
+static const char *device_entropy_obstacle(const HostDecoder &h, size_t size, bool xt_part = false)
 {
   const mijpeg_info &f = h.info;
-  // one Huffman sequential scan over all components (or a single-component frame), 8 bit, restart markers
-  if (f.progressive || f.xt || f.precision != 8 || h.scans.size() != 1)
-    return "on-device entropy decoding needs a single-scan 8-bit Huffman sequential frame with enough restart intervals";
+  // one Huffman sequential scan over all components (or a single-component frame)
+  if (f.progressive) return "on-device entropy decoding: progressive frames are decoded on the host";
+  if (f.xt && !xt_part) return "on-device entropy decoding: not for this JPEG XT stream";
+  if (f.precision != 8 && !(xt_part && f.precision == 12)) return "on-device entropy decoding: 8-bit frames (12-bit residual frames of JPEG XT) only";
+  if (h.scans.size() != 1 || h.hidden_bits()) return "on-device entropy decoding: the frame has more than one scan";
   const Scan &s = h.scans[0];
-  if (s.ncomp != f.components || size > 0xfffffff0ull)
-    return "on-device entropy decoding needs a single-scan 8-bit Huffman sequential frame with enough restart intervals";
+  if (s.ncomp != f.components) return "on-device entropy decoding: the scan does not cover all components";
+  if (size > 0xfffffff0ull) return "on-device entropy decoding: stream too long";
   return nullptr;
 }
 
@@ -473,7 +476,7 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
 // Entropy-decode n parsed images of identical frame geometry on the device, image i into coef_dev + i * frame_stride.
 // infos[i] receives fast_arith / range_max.  Returns MIJPEG_OK, MIJPEG_ERR_NOT_AVAILABLE (nothing touched) or an error.
 static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, const uint8_t *const *datas, const size_t *sizes, int n,
-                                int min_intervals, int16_t *coef_dev, int64_t frame_stride)
+                                int min_intervals, int16_t *coef_dev, int64_t frame_stride, bool xt_part = false)
 {
   const mijpeg_info &f0 = hosts[0]->info;
   const Scan &s0 = hosts[0]->scans[0];
@@ -485,7 +488,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   const bool device_walk = !(getenv("MIJPEG_DEVICE_WALK") && atoi(getenv("MIJPEG_DEVICE_WALK")) == 0);
   const auto tb0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n; i++) {
-    const char *why = device_entropy_obstacle(*hosts[i], sizes[i]);
+    const char *why = device_entropy_obstacle(*hosts[i], sizes[i], xt_part);
     if (why) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
     const mijpeg_info &f = hosts[i]->info;
     const Scan &s = hosts[i]->scans[0];
@@ -784,14 +787,30 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
   d->parsed = true;
   d->batch_frames = 0;
   const auto t_parsed = clk::now();
-  if (const char *why = device_entropy_obstacle(d->host, d->size)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+  HostDecoder *h = &d->host, *res = d->host.residual();
+  if (const char *why = device_entropy_obstacle(d->host, d->size, res != nullptr)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+  if (res) {
+    if (const char *why = device_entropy_obstacle(*res, res->stream_size(), true)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+    if (d->host.xt.residual_wide) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "32-bit residual coefficients are decoded on the host");
+  }
   rc = ensure_coef_store(d, (size_t)d->host.info.coef_count, false);
   if (rc) return rc;
   d->img_valid = false;
   d->uploaded = false;
   d->decoded = false;
-  HostDecoder *h = &d->host;
-  rc = device_entropy_batch(d, &h, &d->data, &d->size, 1, min_intervals, d->coef_dev, d->host.info.coef_count);
+  // JPEG XT: the planes of the residual frame follow those of the legacy frame in the same store
+  int64_t own_count = 0;
+  for (int c = 0; c < d->host.info.components; c++) own_count += (int64_t)d->host.info.blocks_w[c] * d->host.info.blocks_h[c] * 64;
+  rc = device_entropy_batch(d, &h, &d->data, &d->size, 1, min_intervals, d->coef_dev, own_count, res != nullptr);
+  if (!rc && res) {
+    const uint8_t *rdata = res->stream_base();
+    const size_t rsize = res->stream_size();
+    rc = device_entropy_batch(d, &res, &rdata, &rsize, 1, min_intervals, d->coef_dev + own_count, res->info.coef_count, true);
+    if (!rc) {
+      for (int c = 0; c < MIJPEG_MAX_COMPONENTS; c++) d->host.xt.residual.range_max[c] = res->info.range_max[c];
+      d->host.info.fast_arith = 0; // as HostDecoder::decode has it: the fast flavours are chosen per kernel for XT
+    }
+  }
   d->timing[0] = std::chrono::duration<double>(clk::now() - t0).count();
   d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count(); // header parse + restart marker search
   d->timing[2] = d->timing[3] = 0;

@@ -96,6 +96,9 @@ public:
   int plan_virtual_intervals(size_t scan, int mcus_per_interval, int threads, VirtualIntervals &out);
 
   const uint8_t *stream_base() const { return data_; } // the parsed input
+  size_t stream_size() const { return size_; }
+  HostDecoder *residual() const { return residual_; } // JPEG XT: decoder of the residual codestream
+  int hidden_bits() const { return hidden_; }
 
   mijpeg_info info{};
   // restart-interval byte ranges of scan i (valid after parse(..., false)): [interval_begin[k], interval_ends(i)[k])

@@ -205,6 +205,17 @@ def test_xt_4k_vs_oracle(dec, oracle):
     exp, _ = oracle.decode_xt(data)
     assert np.array_equal(codes, exp)
     assert np.array_equal(dec.reconstruct(api.FLAG_FORCE_GENERIC), exp)
+    # both codestreams (8-bit legacy, 12-bit residual; neither has restart markers) entropy-decoded on the device
+    host = api.Decoder(0)
+    host.read(data)
+    dec.read(data, entropy="gpu")
+    assert dec.entropy_used == "gpu" and dec.device_walk_rounds() > 0
+    assert np.array_equal(dec.reconstruct(), exp)
+    xg, xh = dec.xt_params(), host.xt_params()
+    assert list(xg.residual.range_max) == list(xh.residual.range_max) and list(dec.info.range_max) == list(host.info.range_max)
+    for c in range(3):
+        assert np.array_equal(dec.coefficients(c), host.coefficients(c))
+    host.close()
 
 
 @pytest.mark.parametrize("w,h", [(136, 72), (250, 130), (1023, 517), (128, 128)])
@@ -218,6 +229,9 @@ def test_fused_xt_kernel_tile_edges(dec, oracle, w, h):
         assert api.kernel_name(f, xt=dec.xt_params()) == "fusedxt420_kernel"
         exp, _ = oracle.decode_xt(data)
         assert np.array_equal(dec.reconstruct(), exp)
+        dec.read(data, entropy="auto")  # large enough: both codestreams on the device; otherwise the host decoder
+        assert np.array_equal(dec.reconstruct(), exp)
+        assert dec.entropy_used == ("gpu" if w * h > 200_000 else "host")
 
 
 def _torch():
