@@ -582,8 +582,9 @@ def test_device_entropy_decoder_grey_and_optimized_tables(dec, oracle):
 
 
 def test_device_entropy_decoder_eligibility_and_errors(dec):
-    # no restart interval, progressive: not available on the device ("auto" falls back to the host silently)
-    for data in (synth.synth_jpeg(320, 240), synth.synth_jpeg(320, 240, restart_mcus=4, progressive=True)):
+    # tiny without restart markers (the walk wants 256 MCUs), progressive: not available on the device ("auto" falls
+    # back to the host silently)
+    for data in (synth.synth_jpeg(160, 120), synth.synth_jpeg(320, 240, restart_mcus=4, progressive=True)):
         with pytest.raises(api.MijpegError) as e:
             dec.read(data, entropy="gpu")
         assert e.value.code == api.ERR_NOT_AVAILABLE
