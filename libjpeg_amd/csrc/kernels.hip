@@ -846,6 +846,182 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
 }
 
 // ==============================================================================================
+// fused 4:2:2 kernel (Y 1x1, Cb/Cr subsampled 2x1), packed chroma
+// ==============================================================================================
+// fused420p_kernel without the vertical direction: the chroma planes have the luma plane's height, so a 128x128 tile
+// needs (8 + 2) x 16 chroma blocks per component -- 1.25 rounds of transforms for the four waves where 4:2:0 needs
+// one -- and no halo lines; the samples of a line go through the horizontal filter only.  Same gate as the packed
+// 4:2:0 flavour (FAST arithmetic, chroma range_max < 2047), same store path.  Algorithmic bytes: 4 B in + 3 B out per pixel.
+constexpr int F422_CROWS = 128;
+
+template <int MINW>
+__global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) unsigned cpair[F422_CROWS * F420_CPITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  { // XCD-aware tile order (see fused420_kernel)
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  // ------------------------------------------------------------------ phase A: chroma -> LDS halves
+  // (8 + 2) x 16 blocks per component (one block of halo left and right, none above or below: no vertical filter);
+  // waves 0, 1 take Cb, waves 2, 3 Cr, 80 blocks each in two rounds of 64 + 16
+  {
+    const int comp = wave >> 1; // 0 = Cb (low halves), 1 = Cr (high halves); wave-uniform
+    const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
+    const int gx0 = tx * 8 - 1, gy0 = ty * 16;
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
+#pragma unroll 1
+    for (int rnd = 0; rnd < 2; rnd++) {
+      const int base = (wave & 1) * 80 + rnd * 64, count = rnd ? 16 : 64; // blocks of this round
+      u32x4 rows[8];
+      const int idx0 = base + (lane >> 3);
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int i = min(idx0 + 8 * m, base + count - 1);
+        const int y = (i * 205) >> 11, x = i - y * F420_CGRID; // i / 10, i % 10
+        const int gx = min(max(gx0 + x, 0), a.bw_c - 1), gy = min(gy0 + y, a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((gy * a.bw_c + gx) * 128));
+      });
+      const int idx = base + lane;
+      const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
+      const int gx = gx0 + cbx, gy = gy0 + cby;
+      if (lane < count && gx >= 0 && gx < a.bw_c && gy < a.bh_c) {
+        int v[64];
+        dequant_idct_sparse(rows, a.q[1 + comp], v);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const int pr = 8 * cby + r;
+          if (cbx == 0) {
+            cp[2 * (pr * F420_CPITCH + 3)] = (short)v[r * 8 + 7];
+          } else if (cbx == F420_CGRID - 1) {
+            cp[2 * (pr * F420_CPITCH + 68)] = (short)v[r * 8 + 0];
+          } else {
+            short *dst = cp + 2 * (pr * F420_CPITCH + 8 * cbx - 4);
+#pragma unroll
+            for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ edge fix-up (uniform branch): columns only
+  {
+    const int last_col = a.cw - 1 - tx * 64; // last valid chroma column, tile-relative
+    if ((tx == 0) | (last_col < 64)) {
+      if (tid < F422_CROWS) { // one thread per stored line
+        unsigned *p = cpair + tid * F420_CPITCH;
+        if (tx == 0) p[3] = p[4];
+        if (last_col < 64) {
+          const unsigned v = p[last_col + 4];
+          for (int pc = last_col + 5; pc <= 68; pc++) p[pc] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ phase B: luma, upsampling, colour
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  u32x4 rows[8];
+  {
+    const int16_t *__restrict__ plane = coef + a.off_y;
+    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
+  int yv[64];
+  dequant_idct_sparse(rows, a.q[0], yv);
+
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = a.aligned8 && npx == 8;
+  // chroma window of this block: lines pr = 8 by + l, columns pc = 4 bx + 3 + j
+  const unsigned *c_base = cpair + (8 * by) * F420_CPITCH + 4 * bx;
+  auto load6 = [](const unsigned *p, unsigned (&d)[6]) { // p is 16-byte aligned; wanted: p[3..8]
+    const u32x4 mid = *reinterpret_cast<const u32x4 *>(p + 4);
+    d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
+  };
+  const int K = (2048 << 13) + 65536;
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    {
+      // no vertical filter (VerticalFilterCore<1>, upsampler.cpp:118-131: a copy); horizontal filter in place
+      // (upsampler.cpp:291-303); src[k] = v[k + 1]
+      unsigned v[6];
+      load6(c_base + l * F420_CPITCH, v);
+      unsigned u[8];
+      u[7] = tap13_pk(v[5], v[4], 1);
+      u[6] = tap13_pk(v[3], v[4], 2);
+      u[5] = tap13_pk(v[4], v[3], 1);
+      u[4] = tap13_pk(v[2], v[3], 2);
+      u[3] = tap13_pk(v[3], v[2], 1);
+      u[2] = tap13_pk(v[1], v[2], 2);
+      u[1] = tap13_pk(u[2], v[1], 1); // src[1] has already been overwritten by out[2]
+      u[0] = tap13_pk(v[0], v[1], 2);
+      if (l < nln) {
+        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+        int rr[8], gg[8], bb[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          const int yk = (yv[l * 8 + x] << 13) + K;
+          rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
+          gg[x] = mad16_hi(u[x], -L_CR_G, mad16_lo(u[x], -L_CB_G, yk));
+          bb[x] = mad16_lo(u[x], L_CB_B, yk);
+        }
+        if (fast_store) {
+          unsigned h[12];
+#pragma unroll
+          for (int x = 0; x < 8; x += 2) {
+            h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
+            h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
+            h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
+          }
+          unsigned w[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+          __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
+          __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
+          __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+        } else {
+#pragma unroll
+          for (int x = 0; x < 8; x++)
+            if (x < npx) {
+              dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
+            }
+        }
+      }
+    }
+  }
+}
+
+// ==============================================================================================
 // fused JPEG XT profile C kernel: 8-bit 4:2:0 legacy frame + 12-bit 4:4:4 residual frame -> 16-bit codes
 // ==============================================================================================
 // The shape BASELINE config 5 names.  Decomposition of fused420_kernel<true>: phase A puts the tile's chroma samples of
@@ -1162,6 +1338,83 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
           if (x < npx) {
             dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
           }
+      }
+    }
+  }
+}
+
+// ==============================================================================================
+// single-component kernel (grey scale frames, and one component of any frame reconstructed without upsampling):
+// ReconstructUnsampled with the identity transformation, control/blockbitmaprequester.cpp:1013-1074
+// ==============================================================================================
+// One lane, one block: fetch, dequantise, transform, COLOR_TO_INT (x + 8) >> 4 with the level shift the fast transform
+// leaves out folded into the rounding constant, clamp, eight bytes per line.  Samples travel as packed int16 from the
+// addition on (range check: |sample * 16| <= 4 * range_max < 2^15).  Algorithmic bytes: 2 B in + 1 B out per pixel.
+__global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  {
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+  const int x0 = gbx0 + (lane >> 3);
+  u32x4 rows[8];
+  {
+    const char *pbase = reinterpret_cast<const char *>(coef + a.off_y) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  if (X0 >= a.width || Y0 >= a.height) return;
+  int v[64];
+  dequant_idct_sparse(rows, a.q[0], v);
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = a.aligned8 && npx == 8;
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    if (l < nln) {
+      unsigned b4[2]; // four clamped samples each
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        unsigned p[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          unsigned pk;
+          asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(pk) : "v"(v[l * 8 + 4 * h + 2 * i] + (2048 + 8)), "v"(v[l * 8 + 4 * h + 2 * i + 1] + (2048 + 8)));
+          s16x2 t = __builtin_bit_cast(s16x2, pk);
+          t = t >> (short)4;
+          asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p[i]) : "v"(t));
+        }
+        b4[h] = p[0] | (p[1] << 16);
+      }
+      uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+      if (fast_store) {
+        __builtin_nontemporal_store(u32x2{b4[0], b4[1]}, reinterpret_cast<u32x2 *>(dst));
+      } else {
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+          if (x < npx) dst[x] = (uint8_t)(b4[x >> 2] >> (8 * (x & 3)));
       }
     }
   }
@@ -1607,6 +1860,20 @@ int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
 {
   const unsigned total = (unsigned)x.base.tiles_x * x.base.tiles_y * x.base.frames;
   hipLaunchKernelGGL(fusedxt420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
+  return (int)hipGetLastError();
+}
+
+int launch_fused422(const Fused420Args &a, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  hipLaunchKernelGGL((fused422_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused1(const Fused420Args &a, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  hipLaunchKernelGGL(fused1_kernel, dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

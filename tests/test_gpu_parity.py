@@ -69,6 +69,59 @@ def test_fused444_vs_oracle(dec, oracle, w, h, flags):
     assert bad == 0, f"{bad} differing samples, first at {np.argwhere(out != exp)[:4].tolist()}"
 
 
+@pytest.mark.parametrize("flags", [0, api.FLAG_FORCE_SAFE])
+@pytest.mark.parametrize("w,h", EDGE_SIZES + [(512, 512), (1920, 1080), (1000, 999)])
+def test_fused422_vs_oracle(dec, oracle, w, h, flags):
+    data = synth.synth_jpeg(w, h, 500 + w + h, 87, "422", (w + 2 * h) % 5)
+    f = dec.read(data)
+    # the fused kernel only exists in the fast flavour; FORCE_SAFE must route to the generic kernels
+    assert api.kernel_name(f, flags) == ("fused422_kernel" if flags == 0 else "idct_planes_kernel+upsample_color_kernel")
+    out = dec.reconstruct(flags)
+    exp = oracle.decode(data)
+    bad = int((out != exp).sum())
+    assert bad == 0, f"{bad} differing samples, first at {np.argwhere(out != exp)[:4].tolist()}"
+
+
+@pytest.mark.parametrize("w,h", EDGE_SIZES + [(512, 512), (1920, 1080), (1001, 999)])
+def test_fused_single_component_vs_oracle(dec, oracle, w, h):
+    """Grey scale frames: one lane per block, identity transformation; FORCE_GENERIC and FORCE_SAFE take the two-kernel path."""
+    img = synth.synth_image(w, h, 900 + w, channels=1)
+    for q, ri in ((85, 0), (35, 3)):
+        data = synth.encode_jpeg(img, q, "444", restart_mcus=ri)
+        f = dec.read(data)
+        assert f.components == 1
+        assert api.kernel_name(f) == "fused1_kernel" and api.kernel_name(f, api.FLAG_FORCE_SAFE) == "idct_planes_kernel+upsample_color_kernel"
+        exp = oracle.decode(data)
+        out = dec.reconstruct()
+        assert np.array_equal(out.squeeze(), exp.squeeze())
+        assert np.array_equal(dec.reconstruct(api.FLAG_FORCE_GENERIC).squeeze(), exp.squeeze())
+
+
+def test_fused422_packed_chroma_gate(dec, oracle):
+    """Same 16-bit filter arithmetic, hence the same gate, as the packed 4:2:0 flavour; beyond it the generic kernels."""
+    img = np.zeros((272, 400, 3), np.uint8)
+    img[:, :130] = (255, 0, 0)
+    img[:, 130:260] = (0, 0, 255)
+    img[:, 260:] = (0, 255, 0)
+    img[100:150] = (255, 255, 0)
+    seen = set()
+    for q in (50, 75, 90, 100):
+        data = synth.encode_jpeg(img, q, "422", restart_mcus=3)
+        f = dec.read(data)
+        name = api.kernel_name(f)
+        packed = f.fast_arith == 1 and f.range_max[1] < 2047 and f.range_max[2] < 2047
+        assert name == ("fused422_kernel" if packed else "idct_planes_kernel+upsample_color_kernel")
+        seen.add(name)
+        assert np.array_equal(dec.reconstruct(), oracle.decode(data)), q
+    assert "idct_planes_kernel+upsample_color_kernel" in seen  # saturated graphics lie beyond the gate
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (144, 208, 3)).astype(np.uint8)
+    for q in (60, 95):
+        data = synth.encode_jpeg(img, q, "422")
+        dec.read(data)
+        assert np.array_equal(dec.reconstruct(), oracle.decode(data))
+
+
 def test_fused444_range_gate(dec, oracle):
     """Chroma samples are kept as packed int16 in the fused 4:4:4 kernel: a frame whose range check does not bound
     them below 2^15 must take the generic path (and still be exact)."""

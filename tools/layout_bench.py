@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Side measurement (not bench.py): reconstruction throughput per sampling layout, coefficients resident in HBM.
+8 frames of 8K per launch; prints kernel(s), ms per launch, Gpixel/s and algorithmic GB/s."""
+import os
+import sys
+import ctypes as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from libjpeg_amd import api, synth  # noqa: E402
+
+W, H, F = 7680, 4320, 8
+hip = C.cdll.LoadLibrary("libamdhip64.so")
+for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
+    img = synth.synth_image(W, H, 1234, channels=1 if sub == "gray" else 3)
+    data = synth.encode_jpeg(img, 85, "444" if sub == "gray" else sub, restart_mcus=8)
+    d = api.Decoder(0)
+    info = d.read(data)
+    n = int(info.coef_count)
+    nc = info.components
+    coef = torch.empty((F, n), dtype=torch.int16, device="cuda")
+    src = d.device_coefficients()
+    torch.cuda.synchronize()
+    for f in range(F):
+        hip.hipMemcpy(C.c_void_p(coef[f].data_ptr()), C.c_void_p(src), C.c_size_t(n * 2), 3)
+    row = W * nc
+    out = torch.empty((F, H, row), dtype=torch.uint8, device="cuda")
+    wsb = api.workspace_bytes(info, F)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), F, row, H * row, n, workspace=ws.data_ptr(), workspace_bytes=wsb, stream=stream.cuda_stream)
+
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(20):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    bpp = 2.0 * n / (W * H) + nc  # int16 coefficients in, bytes out
+    ok = bool(np.array_equal(out[0].cpu().numpy().reshape(H, W, nc).squeeze(), d.reconstruct().squeeze()))
+    print(f"{sub:>5}: {api.kernel_name(info):<44} {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px) same as decoder object: {ok}", flush=True)
+    d.close()
