@@ -222,7 +222,8 @@ typedef struct mijpeg_batch {
   const mijpeg_xt_params *xt;  /* required when info.xt != 0 (host memory)                            */
 } mijpeg_batch;
 
-/* Device scratch the batch needs (0 for the fused kernels). */
+/* Device scratch the batch needs (0 for the fused kernels of plain JPEG; the L tables for the fused JPEG XT kernel;
+ * tables + int32 sample planes for the generic kernels). */
 size_t mijpeg_workspace_bytes(const mijpeg_batch *batch);
 
 /* dequant + IDCT + upsample + colour transform + interleaved store for `frames` frames in one
