@@ -303,6 +303,53 @@ __device__ __forceinline__ void fetch_blocks(u32x4 (&rows)[8], u32x4 *stage, int
   }
 }
 
+// The same for 16 blocks (two loads per lane, lanes 0..15 receive their rows); chunkptr(m), m = 0, 1, as above.
+template <class F>
+__device__ __forceinline__ void fetch_blocks16(u32x4 (&rows)[8], u32x4 *stage, int lane, F chunkptr)
+{
+  const u32x4 raw0 = *chunkptr(0), raw1 = *chunkptr(1);
+  const int k = lane & 7, nb0 = lane >> 3, nb1 = nb0 + 8;
+  stage[nb0 * 8 + (k ^ (nb0 & 7))] = raw0;
+  stage[nb1 * 8 + (k ^ (nb1 & 7))] = raw1;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) rows[r] = stage[lane * 8 + (r ^ (lane & 7))];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// One column (x = 0 or x = 7) of a block's samples: the first pass only has to produce that one output per row, which
+// is the inner product of the row with the corresponding row of the transform's integer matrix -- written out of the
+// butterfly of idct_1d<true, 9>: out0/out7 = (t10 +- o3) with every product expanded (exact: the ring Z / 2^32 is
+// distributive) -- then the ordinary second pass on the eight results.  FAST arithmetic, no level shift.
+__device__ __forceinline__ void dequant_idct_column(const u32x4 (&rows)[8], const int *__restrict__ q, bool last, int (&col)[8])
+{
+  constexpr int E0 = 512, E2 = FIX9(0.541196100) + FIX9(0.765366865), E4 = 512, E6 = FIX9(0.541196100);
+  constexpr int O1 = FIX9(1.501321110) - FIX9(0.899976223) - FIX9(0.390180644) + FIX9(1.175875602), O3 = FIX9(1.175875602),
+                O5 = FIX9(1.175875602) - FIX9(0.390180644), O7 = FIX9(1.175875602) - FIX9(0.899976223);
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const unsigned w[4] = {rows[r].x, rows[r].y, rows[r].z, rows[r].w};
+    int s[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      s[2 * i] = mul16_lo(w[i], q[r * 8 + 2 * i]);
+      s[2 * i + 1] = mul16_hi(w[i], q[r * 8 + 2 * i + 1]);
+    }
+    int even = (s[0] << 9) + (1 << 8), odd = __mul24(s[1], O1);
+    even = mad24(s[2], E2, even);
+    odd = mad24(s[3], O3, odd);
+    even = mad24(s[4], E4, even);
+    odd = mad24(s[5], O5, odd);
+    even = mad24(s[6], E6, even);
+    odd = mad24(s[7], O7, odd);
+    const int acc = last ? even - odd : even + odd; // x = 7 : x = 0
+    col[r] = acc >> 9;
+  }
+  idct_1d<true, 12>(col[0], col[1], col[2], col[3], col[4], col[5], col[6], col[7]);
+}
+
 // ----------------------------------------------------------------------------------------------
 // colour transform of one pixel (colortrafo/ycbcrtrafo.cpp:842-850 + clamp :921-936)
 // FIX_BITS = 13, matrix = TO_FIX of {1,0,1.402; 1,-0.3441362861,-0.7141362859; 1,1.772,0}
@@ -878,44 +925,45 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   // ------------------------------------------------------------------ phase A: chroma -> LDS halves
-  // (8 + 2) x 16 blocks per component (one block of halo left and right, none above or below: no vertical filter);
-  // waves 0, 1 take Cb, waves 2, 3 Cr, 80 blocks each in two rounds of 64 + 16
+  // 8 x 16 blocks per component, 64 per wave (waves 0, 1: Cb, waves 2, 3: Cr; upper / lower half of the tile), plus one
+  // COLUMN of the 16 blocks left and right of them: the horizontal filter needs nothing else of the neighbours
   {
     const int comp = wave >> 1; // 0 = Cb (low halves), 1 = Cr (high halves); wave-uniform
     const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
-    const int gx0 = tx * 8 - 1, gy0 = ty * 16;
+    const int gx0 = tx * 8, gy0 = ty * 16 + (wave & 1) * 8;
     const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
     short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
-#pragma unroll 1
-    for (int rnd = 0; rnd < 2; rnd++) {
-      const int base = (wave & 1) * 80 + rnd * 64, count = rnd ? 16 : 64; // blocks of this round
-      u32x4 rows[8];
-      const int idx0 = base + (lane >> 3);
+    u32x4 rows[8];
+    { // the wave's 8 x 8 blocks: local block n = (lane >> 3) + 8 m is column n & 7 = lane >> 3, row n >> 3 = m
+      const int xx = min(gx0 + (lane >> 3), a.bw_c - 1);
       fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
-        const int i = min(idx0 + 8 * m, base + count - 1);
-        const int y = (i * 205) >> 11, x = i - y * F420_CGRID; // i / 10, i % 10
-        const int gx = min(max(gx0 + x, 0), a.bw_c - 1), gy = min(gy0 + y, a.bh_c - 1);
-        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((gy * a.bw_c + gx) * 128));
+        const int yy = min(gy0 + m, a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
       });
-      const int idx = base + lane;
-      const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
-      const int gx = gx0 + cbx, gy = gy0 + cby;
-      if (lane < count && gx >= 0 && gx < a.bw_c && gy < a.bh_c) {
+      const int cbx = lane & 7, cby = lane >> 3;
+      if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
         int v[64];
         dequant_idct_sparse(rows, a.q[1 + comp], v);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-          const int pr = 8 * cby + r;
-          if (cbx == 0) {
-            cp[2 * (pr * F420_CPITCH + 3)] = (short)v[r * 8 + 7];
-          } else if (cbx == F420_CGRID - 1) {
-            cp[2 * (pr * F420_CPITCH + 68)] = (short)v[r * 8 + 0];
-          } else {
-            short *dst = cp + 2 * (pr * F420_CPITCH + 8 * cbx - 4);
+          short *dst = cp + 2 * ((8 * ((wave & 1) * 8 + cby) + r) * F420_CPITCH + 8 * cbx + 4);
 #pragma unroll
-            for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
-          }
+          for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
         }
+      }
+    }
+    { // halo columns: local block n = lane >> 3 (+ 8) is side n & 1 (0: left neighbour, 1: right neighbour), row n >> 1
+      fetch_blocks16(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int n = (lane >> 3) + 8 * m;
+        const int xx = min(max((n & 1) ? gx0 + 8 : gx0 - 1, 0), a.bw_c - 1), yy = min(gy0 + (n >> 1), a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
+      });
+      const int side = lane & 1, cby = lane >> 1, gx = side ? gx0 + 8 : gx0 - 1;
+      if (lane < 16 && gx >= 0 && gx < a.bw_c && gy0 + cby < a.bh_c) {
+        int col[8];
+        dequant_idct_column(rows, a.q[1 + comp], side == 0, col); // left neighbour: its last column, right one: its first
+#pragma unroll
+        for (int r = 0; r < 8; r++) cp[2 * ((8 * ((wave & 1) * 8 + cby) + r) * F420_CPITCH + (side ? 68 : 3))] = (short)col[r];
       }
     }
   }
