@@ -516,6 +516,36 @@ def test_cli_writes_the_references_pnm(tmp_path, name):
     assert hashlib.sha256(data[len(header):]).hexdigest() == ent["pixels_sha256"]
 
 
+@pytest.mark.parametrize("name", ["cfg1_512x512_444_q75_ref", "ref_75x45_420_dri2", "pil_200x120_420_dri8", "pil_70x40_gray",
+                                  "ref_97x61_3x3", "pil_33x17_420_dri1", "xt_129x71_420", "xt_64x48_444"])
+def test_the_references_own_client_runs_on_this_library(tmp_path, name):
+    """oracle/_ref/jpeg_dropin is the reference's cmd/reconstruct.cpp with its bitmap and file hooks, compiled UNCHANGED
+    from the reference tree against libjpeg_amd's interface headers and linked with libmijpeg.so (oracle/Makefile,
+    target dropin; built where the reference sources are present).  It must write the bytes the reference binary writes."""
+    import os
+    import subprocess
+
+    from conftest import GOLDEN_DIR, ROOT
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "jpeg_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/jpeg_dropin is built from the reference sources (make -C oracle dropin)")
+    ent = MANIFEST[name]
+    out = tmp_path / "out.pnm"
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".jpg"), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+    data = out.read_bytes()
+    if ent.get("kind") == "xt_float32":  # 'PF' file with big-endian floats (cmd/reconstruct.cpp:321-323)
+        header = b"PF\n%d %d\n1\n" % (ent["width"], ent["height"])
+        assert data.startswith(header)
+        body = np.frombuffer(data[len(header):], ">f4").astype("<f4")
+        assert hashlib.sha256(body.tobytes()).hexdigest() == ent["pixels_sha256"]
+    else:
+        header = b"P%d\n%d %d\n255\n" % (6 if ent["channels"] == 3 else 5, ent["width"], ent["height"])
+        assert data.startswith(header)
+        assert hashlib.sha256(data[len(header):]).hexdigest() == ent["pixels_sha256"]
+
+
 @pytest.mark.parametrize("entropy", ["0", "1"])
 def test_cli_4k_with_restart_markers_device_and_host_entropy(tmp_path, oracle, entropy):
     """A 4K frame with 16 200 restart intervals goes through the on-device entropy decoder inside JPEG::Read
