@@ -1190,3 +1190,161 @@ out:
 }
 
 void oj_free(void *p) { free(p); }
+
+/* ==================================================================================================================
+ * Encoder direction: forward colour transformation, box downsampling, forward DCT + quantisation
+ * ================================================================================================================== */
+#define F9(x) ((int32_t)((x) * 512.0 + 0.5)) /* TO_FIX of dct/idct.cpp:65 */
+
+/* The quantiser multiplier LONG(FLOAT(1L << 30) / delta + 0.5) of dct/idct.cpp:106: a SINGLE precision quotient (FLOAT
+ * is float), widened for the addition.  For deltas that do not divide 2^30 it differs from the exactly rounded value
+ * by up to ~3e-8 relative, which flips about one coefficient in several thousand -- the reference binary this oracle
+ * is pinned to shows exactly these flips (tests/test_oracle.py::test_forward_matches_the_reference_encoder). */
+static int64_t inv_quant(uint16_t delta)
+{
+  volatile float q = (float)(1L << 30) / (float)delta; /* volatile: keep it a float whatever the FP unit */
+  return (int64_t)((double)q + 0.5);
+}
+
+/* Quantize of dct/idct.hpp:90-111 without dead zone: preshift 4, FIX_BITS 9, INTERMEDIATE_BITS 0, QUANTIZER_BITS 30 */
+static int32_t quantize(int32_t n, int64_t qnt)
+{
+  const int sh = 9 + 0 + 30 + 4 + 3;
+  return (int32_t)(((int64_t)n * qnt + (int64_t)(((uint32_t)(-n)) >> 31) + (((int64_t)1) << (sh - 1))) >> sh);
+}
+
+
+void oj_fdct_block(int32_t out[64], const int32_t in[64], const uint16_t quant[64], int precision)
+{
+  int32_t t[64];
+  int32_t dcoffset = w32((int64_t)(1 << (precision - 1)) << (4 + 3 + 3));
+  /* pass over columns (idct.cpp:125-170): t[k*8 + c] = frequency k of column c */
+  for (int c = 0; c < 8; c++) {
+    const int32_t *s = in + c;
+    int32_t tmp0 = w32((int64_t)s[0] + s[56]), tmp1 = w32((int64_t)s[8] + s[48]), tmp2 = w32((int64_t)s[16] + s[40]), tmp3 = w32((int64_t)s[24] + s[32]);
+    int32_t tmp10 = w32((int64_t)tmp0 + tmp3), tmp12 = w32((int64_t)tmp0 - tmp3), tmp11 = w32((int64_t)tmp1 + tmp2), tmp13 = w32((int64_t)tmp1 - tmp2);
+    tmp0 = w32((int64_t)s[0] - s[56]); tmp1 = w32((int64_t)s[8] - s[48]); tmp2 = w32((int64_t)s[16] - s[40]); tmp3 = w32((int64_t)s[24] - s[32]);
+    t[0 + c] = w32((int64_t)tmp10 + tmp11);
+    t[32 + c] = w32((int64_t)tmp10 - tmp11);
+    int32_t z1 = w32(((int64_t)tmp12 + tmp13) * F9(0.541196100));
+    t[16 + c] = w32(((int64_t)z1 + (int64_t)tmp12 * F9(0.765366865) + 256)) >> 9;
+    t[48 + c] = w32(((int64_t)z1 + (int64_t)tmp13 * -F9(1.847759065) + 256)) >> 9;
+    tmp10 = w32((int64_t)tmp0 + tmp3); tmp11 = w32((int64_t)tmp1 + tmp2); tmp12 = w32((int64_t)tmp0 + tmp2); tmp13 = w32((int64_t)tmp1 + tmp3);
+    z1 = w32(((int64_t)tmp12 + tmp13) * F9(1.175875602));
+    const int32_t tt0 = w32((int64_t)tmp0 * F9(1.501321110)), tt1 = w32((int64_t)tmp1 * F9(3.072711026)), tt2 = w32((int64_t)tmp2 * F9(2.053119869)),
+                  tt3 = w32((int64_t)tmp3 * F9(0.298631336)), tt10 = w32((int64_t)tmp10 * -F9(0.899976223)), tt11 = w32((int64_t)tmp11 * -F9(2.562915447)),
+                  tt12 = w32((int64_t)tmp12 * -F9(0.390180644) + z1), tt13 = w32((int64_t)tmp13 * -F9(1.961570560) + z1);
+    t[8 + c] = w32((int64_t)tt0 + tt10 + tt12 + 256) >> 9;
+    t[24 + c] = w32((int64_t)tt1 + tt11 + tt13 + 256) >> 9;
+    t[40 + c] = w32((int64_t)tt2 + tt11 + tt12 + 256) >> 9;
+    t[56 + c] = w32((int64_t)tt3 + tt10 + tt13 + 256) >> 9;
+  }
+  /* pass over rows and quantise (idct.cpp:174-218) */
+  for (int r = 0; r < 8; r++) {
+    const int32_t *d = t + r * 8;
+    int64_t q[8];
+    for (int k = 0; k < 8; k++) q[k] = inv_quant(quant[r * 8 + k]);
+    int32_t tmp0 = w32((int64_t)d[0] + d[7]), tmp1 = w32((int64_t)d[1] + d[6]), tmp2 = w32((int64_t)d[2] + d[5]), tmp3 = w32((int64_t)d[3] + d[4]);
+    int32_t tmp10 = w32((int64_t)tmp0 + tmp3), tmp12 = w32((int64_t)tmp0 - tmp3), tmp11 = w32((int64_t)tmp1 + tmp2), tmp13 = w32((int64_t)tmp1 - tmp2);
+    tmp0 = w32((int64_t)d[0] - d[7]); tmp1 = w32((int64_t)d[1] - d[6]); tmp2 = w32((int64_t)d[2] - d[5]); tmp3 = w32((int64_t)d[3] - d[4]);
+    out[r * 8 + 0] = quantize(w32(((int64_t)tmp10 + tmp11 - dcoffset) << 9), q[0]);
+    out[r * 8 + 4] = quantize(w32(((int64_t)tmp10 - tmp11) << 9), q[4]);
+    int32_t z1 = w32(((int64_t)tmp12 + tmp13) * F9(0.541196100));
+    out[r * 8 + 2] = quantize(w32((int64_t)z1 + (int64_t)tmp12 * F9(0.765366865)), q[2]);
+    out[r * 8 + 6] = quantize(w32((int64_t)z1 + (int64_t)tmp13 * -F9(1.847759065)), q[6]);
+    tmp10 = w32((int64_t)tmp0 + tmp3); tmp11 = w32((int64_t)tmp1 + tmp2); tmp12 = w32((int64_t)tmp0 + tmp2); tmp13 = w32((int64_t)tmp1 + tmp3);
+    z1 = w32(((int64_t)tmp12 + tmp13) * F9(1.175875602));
+    const int32_t tt0 = w32((int64_t)tmp0 * F9(1.501321110)), tt1 = w32((int64_t)tmp1 * F9(3.072711026)), tt2 = w32((int64_t)tmp2 * F9(2.053119869)),
+                  tt3 = w32((int64_t)tmp3 * F9(0.298631336)), tt10 = w32((int64_t)tmp10 * -F9(0.899976223)), tt11 = w32((int64_t)tmp11 * -F9(2.562915447)),
+                  tt12 = w32((int64_t)tmp12 * -F9(0.390180644) + z1), tt13 = w32((int64_t)tmp13 * -F9(1.961570560) + z1);
+    out[r * 8 + 1] = quantize(w32((int64_t)tt0 + tt10 + tt12), q[1]);
+    out[r * 8 + 3] = quantize(w32((int64_t)tt1 + tt11 + tt13), q[3]);
+    out[r * 8 + 5] = quantize(w32((int64_t)tt2 + tt11 + tt12), q[5]);
+    out[r * 8 + 7] = quantize(w32((int64_t)tt3 + tt10 + tt13), q[7]);
+    dcoffset = 0;
+  }
+}
+
+/* forward L transformation of one pixel, FIX_BITS 13 -> COLOR_BITS 4 (ycbcrtrafo.cpp:176-199; numerics.hpp:61) */
+static void rgb_to_ycc(int r, int g, int b, int32_t *y, int32_t *cb, int32_t *cr)
+{
+  const int64_t dc = ((int64_t)128) << 13, half = 256;
+  int64_t yy = ((int64_t)r * 2449 + (int64_t)g * 4809 + (int64_t)b * 934 + half) >> 9;
+  int64_t bb = ((int64_t)r * -1382 + (int64_t)g * -2714 + (int64_t)b * 4096 + dc + half) >> 9;
+  int64_t rr = ((int64_t)r * 4096 + (int64_t)g * -3430 + (int64_t)b * -666 + dc + half) >> 9;
+  const int64_t hi = (256 << 4) - 1;
+  *y = (int32_t)(yy < 0 ? 0 : yy > hi ? hi : yy);
+  *cb = (int32_t)(bb < 0 ? 0 : bb > hi ? hi : bb);
+  *cr = (int32_t)(rr < 0 ? 0 : rr > hi ? hi : rr);
+}
+
+int oj_forward(const oj_info *info, const uint8_t *rgb, int use_ycbcr, int32_t *const planes[OJ_MAX_COMP])
+{
+  const int W = info->width, H = info->height, nc = info->ncomp;
+  if ((nc != 1 && nc != 3) || info->precision != 8) return OJ_ERR_UNSUPPORTED;
+  /* colour-transformed samples of the whole image at COLOR_BITS precision, one plane per component; line buffers of
+   * subsampled components are width + 8 * subx long: beyond the image the last block column is mirrored
+   * (downsamplerbase.cpp:141-145), lines beyond the image do not exist */
+  int32_t *full[OJ_MAX_COMP] = {0, 0, 0, 0};
+  int pitch[OJ_MAX_COMP];
+  for (int c = 0; c < nc; c++) {
+    pitch[c] = W + 8 * info->subx[c] + 8;
+    full[c] = (int32_t *)calloc((size_t)pitch[c] * (size_t)(H + 8), sizeof(int32_t));
+    if (!full[c]) return OJ_ERR_NOMEM;
+  }
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      const uint8_t *p = rgb + ((size_t)y * W + x) * nc;
+      if (nc == 3 && use_ycbcr) rgb_to_ycc(p[0], p[1], p[2], &full[0][(size_t)y * pitch[0] + x], &full[1][(size_t)y * pitch[1] + x], &full[2][(size_t)y * pitch[2] + x]);
+      else
+        for (int c = 0; c < nc; c++) full[c][(size_t)y * pitch[c] + x] = (int32_t)p[c] << 4; /* INT_TO_COLOR; LUTs are identities */
+    }
+  for (int c = 0; c < nc; c++) {
+    const int sx = info->subx[c], sy = info->suby[c];
+    const int nbx = (info->cw[c] + 7) >> 3, nby = (info->ch[c] + 7) >> 3;
+    memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
+    if (sx == 1 && sy == 1) {
+      /* straight into the transform; partial blocks are pre-filled with the level shift (ycbcrtrafo.cpp:100-113) */
+      for (int by = 0; by < nby; by++)
+        for (int bx = 0; bx < nbx; bx++) {
+          int32_t blk[64];
+          for (int i = 0; i < 64; i++) {
+            const int x = bx * 8 + (i & 7), y = by * 8 + (i >> 3);
+            blk[i] = (x < W && y < H) ? full[c][(size_t)y * pitch[c] + x] : (128 << 4);
+          }
+          oj_fdct_block(planes[c] + ((size_t)by * info->bw[c] + bx) * 64, blk, info->quant[info->tq[c]], 8);
+        }
+      continue;
+    }
+    /* the line buffers: DefineRegion copies whole block rows (the pre-fill included), then mirrors the right edge */
+    const int ovl = (sx << 3) - 1;
+    for (int y = 0; y < H; y++) {
+      int32_t *line = full[c] + (size_t)y * pitch[c];
+      for (int x = W; x < ((W + 7) & ~7); x++) line[x] = 128 << 4;
+      for (int i = 0; i < ovl; i++) line[W + i] = line[W > i ? W - 1 - i : 0];
+    }
+    for (int by = 0; by < nby; by++)
+      for (int bx = 0; bx < nbx; bx++) {
+        int32_t blk[64];
+        const int ofs = (bx * sx) << 3;
+        int y = (by * sy) << 3;
+        for (int r = 0; r < 8; r++) {
+          int32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          int lines = 0;
+          while (lines < sy && y < H) {
+            const int32_t *src = full[c] + (size_t)y * pitch[c] + ofs;
+            for (int i = 0; i < 8; i++)
+              for (int k = 0; k < sx; k++) acc[i] += src[i * sx + k];
+            lines++;
+            y++;
+          }
+          const int norm = lines * sx;
+          for (int i = 0; i < 8; i++) blk[r * 8 + i] = norm > 1 ? acc[i] / norm : acc[i];
+        }
+        oj_fdct_block(planes[c] + ((size_t)by * info->bw[c] + bx) * 64, blk, info->quant[info->tq[c]], 8);
+      }
+  }
+  for (int c = 0; c < nc; c++) free(full[c]);
+  return OJ_OK;
+}
+

@@ -96,6 +96,19 @@ float oj_half_to_float(uint16_t h);
 
 /* Convenience: whole decode.  *pixels is malloc'ed (free with oj_free). */
 int oj_decode(const uint8_t *data, size_t len, oj_info *info, uint8_t **pixels);
+
+/* ---- encoder direction: the block pipeline in front of the entropy coder ------------------------
+ * Forward L transformation (colortrafo/ycbcrtrafo.cpp:85-242 with the matrix of colortransformerfactory.cpp:177-183),
+ * box downsampling (upsampling/downsampler.cpp:70-139, line buffers of downsamplerbase.cpp:124-155), forward DCT and
+ * quantisation (dct/idct.cpp:114-222, dct/idct.hpp:90-111, quantiser of idct.cpp:98-109) as
+ * BlockBitmapRequester::PullSourceData / AdvanceQRows drive them (control/blockbitmaprequester.cpp:505-576, 708-846).
+ * info supplies geometry, sampling factors and the quantiser deltas (ncomp 1 or 3, precision 8); rgb is interleaved
+ * 8-bit with `ncomp` samples per pixel; planes[c] receives bw[c]*bh[c]*64 int32 quantised coefficients, natural
+ * order -- the blocks that cover samples (block column < ceil(cw/8), block row < ceil(ch/8)); MCU padding blocks are
+ * left zero (what the entropy coder puts there is its business, codestream/sequentialscan.cpp). */
+int oj_forward(const oj_info *info, const uint8_t *rgb, int use_ycbcr, int32_t *const planes[OJ_MAX_COMP]);
+/* One block: samples * 16 (COLOR_BITS) -> quantised coefficients, dct/idct.cpp:114-222 with preshift 4. */
+void oj_fdct_block(int32_t out[64], const int32_t in[64], const uint16_t quant[64], int precision);
 void oj_free(void *p);
 
 #ifdef __cplusplus

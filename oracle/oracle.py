@@ -56,6 +56,8 @@ def lib():
         L.oj_reconstruct16.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
         L.oj_decode_xt.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.oj_free.argtypes = [C.c_void_p]
+        L.oj_forward.argtypes = [C.POINTER(OjInfo), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.oj_fdct_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.oj_free.restype = None
         _lib = L
     return _lib
@@ -67,6 +69,18 @@ def read_info(data: bytes) -> OjInfo:
     if rc:
         raise ValueError(f"oracle: oj_read_info failed rc={rc}")
     return info
+
+
+def forward(info: OjInfo, pixels: np.ndarray, use_ycbcr: int = 1):
+    """Encoder direction: interleaved 8-bit pixels (H, W, ncomp) -> [int32 ndarray (bh, bw, 64)] quantised coefficients for
+    the geometry, sampling factors and quantiser tables of `info` (e.g. read_info() of a file the reference wrote)."""
+    px = np.ascontiguousarray(pixels, np.uint8)
+    planes = [np.zeros((info.bh[c], info.bw[c], 64), np.int32) for c in range(info.ncomp)]
+    ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - info.ncomp))
+    rc = lib().oj_forward(C.byref(info), px.ctypes.data, use_ycbcr, ptrs)
+    if rc:
+        raise ValueError(f"oracle: oj_forward failed rc={rc}")
+    return planes
 
 
 def decode_coefficients(data: bytes, info: OjInfo | None = None):

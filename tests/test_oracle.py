@@ -133,3 +133,57 @@ def test_oracle_vs_live_reference(oracle, w, h, q, sub, dri, seed):
         pytest.skip("oracle/_ref/jpeg not built (needs /root/reference)")
     data = synth.encode_jpeg(synth.synth_image(w, h, seed), q, sub, dri)
     assert np.array_equal(oracle.decode(data), oracle.reference_decode(data))
+
+
+# ------------------------------------------------------------------------------------------------------
+# encoder direction: forward colour transformation + box downsampling + forward DCT + quantiser
+# ------------------------------------------------------------------------------------------------------
+def _covered(info, planes, c):
+    """The blocks that cover samples (the MCU padding blocks belong to the entropy coder)."""
+    return planes[c][:(info.ch[c] + 7) // 8, :(info.cw[c] + 7) // 8]
+
+
+FORWARD_GOLDEN = [n for n, e in MANIFEST.items() if e.get("encoder") == "ref" and e.get("channels") == 3 and "seed" in e
+                  and "-n" not in e["args"] and "sof1" not in n and not n.startswith("xt_") and "lumasub" not in n]
+
+
+@pytest.mark.parametrize("name", FORWARD_GOLDEN)
+def test_forward_matches_the_reference_encoders_golden_files(oracle, name):
+    """The committed golden files were written by the reference ENCODER from synth_image(w, h, seed): the coefficients in
+    them pin the forward restatement (colour transformation, downsampler edges, FDCT, the single-precision quantiser)."""
+    ent = MANIFEST[name]
+    img = synth.synth_image(ent["width"], ent["height"], ent["seed"])
+    info, ref = oracle.decode_coefficients(golden_jpeg(name))
+    mine = oracle.forward(info, img, 1)
+    for c in range(info.ncomp):
+        assert np.array_equal(_covered(info, mine, c), _covered(info, ref, c)), (name, c)
+
+
+@pytest.mark.parametrize("w,h,args,seed", [(512, 512, ["-bl", "-q", "75"], 1234), (640, 360, ["-bl", "-q", "97", "-s", "1x1,2x2,2x2"], 5),
+                                           (333, 211, ["-bl", "-q", "40", "-s", "1x1,2x1,2x1"], 6), (70, 40, ["-bl", "-q", "90"], 7)])
+def test_forward_matches_the_live_reference_encoder(oracle, w, h, args, seed):
+    if not oracle.have_reference():
+        pytest.skip("needs oracle/_ref/jpeg")
+    rng = np.random.default_rng(seed)
+    img = synth.synth_image(w, h, seed) if seed != 6 else rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    if seed == 7:
+        img = np.ascontiguousarray(img[..., :1])
+    info, ref = oracle.decode_coefficients(oracle.reference_encode(img.squeeze(), args))
+    mine = oracle.forward(info, img, 1)
+    for c in range(info.ncomp):
+        assert np.array_equal(_covered(info, mine, c), _covered(info, ref, c)), c
+
+
+def test_forward_then_inverse_is_close(oracle):
+    """Sanity of the pair: forward at a fine quantiser, then the (pinned) inverse path, reproduces the picture closely."""
+    img = synth.synth_image(96, 64, 9)
+    info, _ = oracle.decode_coefficients(golden_jpeg("ref_64x40_q100"))
+    info.width, info.height = 96, 64
+    for c in range(3):
+        info.cw[c], info.ch[c], info.bw[c], info.bh[c] = 96, 64, 12, 8
+    info.mcus_x, info.mcus_y = 12, 8
+    planes = oracle.forward(info, img, 1)
+    back = oracle.reconstruct(info, planes)
+    err = np.abs(back.astype(int) - img.astype(int))
+    assert err.max() <= 4 and err.mean() < 0.8, (err.max(), err.mean())
+
