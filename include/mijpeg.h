@@ -233,6 +233,32 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *batch, void *stream);
 /* Name of the kernel the batch would run ("fused420", "generic", ...) -- for profiling scripts. */
 const char *mijpeg_kernel_name(const mijpeg_batch *batch);
 
+/* ---- encoder direction of the block pipeline -----------------------------------------------------
+ * What BlockBitmapRequester::PullSourceData / AdvanceQRows (control/blockbitmaprequester.cpp:505-576, 708-846) do
+ * per block in front of the entropy coder: forward L transformation (colortrafo/ycbcrtrafo.cpp:85-242), box
+ * downsampling (upsampling/downsampler.cpp:70-139), forward DCT + quantisation (dct/idct.cpp:114-222), for frames
+ * resident in HBM.  Entropy coding and marker writing are not part of it. */
+
+/* Completes *info from width, height, components (1 or 3), precision (8), hsamp[], vsamp[], quant_index[] and quant[][]:
+ * MCU grid, subsampling factors, plane sizes, coef_offset[] and coef_count, as a frame header with these values
+ * would produce (marker/frame.cpp, marker/component.cpp).  Returns MIJPEG_OK or MIJPEG_ERR_INVALID_PARAMETER. */
+int mijpeg_frame_layout(mijpeg_info *info);
+
+typedef struct mijpeg_forward_batch {
+  mijpeg_info info;            /* completed by mijpeg_frame_layout; ycbcr = 1: RGB in, YCbCr coded; 0: identity   */
+  const uint8_t *pixels_dev;   /* interleaved 8-bit samples, `components` per pixel; frame f at + f * pixel_frame_stride */
+  int64_t pixel_frame_stride;  /* bytes                                                                            */
+  int64_t pixel_row_stride;    /* bytes per line                                                                   */
+  int16_t *coef_dev;           /* out: quantised coefficients in the layout the decoder reads (natural order inside a
+                                  block, blocks row-major, planes at info.coef_offset[]); MCU padding blocks are zero */
+  int64_t coef_frame_stride;   /* int16 units                                                                      */
+  int32_t frames;
+  uint32_t flags;              /* 0                                                                                */
+} mijpeg_forward_batch;
+
+/* One launch on `stream` (hipStream_t) for all frames of the batch.  Asynchronous. */
+int mijpeg_launch_forward(const mijpeg_forward_batch *batch, void *stream);
+
 /* Worker threads mijpeg_decode_coefficients uses for threads <= 0 (MIJPEG_THREADS overrides; default min(cores, 64)). */
 int mijpeg_default_threads(void);
 

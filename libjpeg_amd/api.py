@@ -56,6 +56,13 @@ class MijpegBatch(C.Structure):
     ]
 
 
+class MijpegForwardBatch(C.Structure):
+    _fields_ = [
+        ("info", MijpegInfo), ("pixels_dev", C.c_void_p), ("pixel_frame_stride", C.c_int64), ("pixel_row_stride", C.c_int64),
+        ("coef_dev", C.c_void_p), ("coef_frame_stride", C.c_int64), ("frames", C.c_int32), ("flags", C.c_uint32),
+    ]
+
+
 class MijpegError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"mijpeg error {code}: {message}")
@@ -353,6 +360,43 @@ def launch_reconstruct(info: MijpegInfo, coef_dev: int, out_dev: int, frames: in
     rc = lib().mijpeg_launch_reconstruct(C.byref(b), stream)
     if rc:
         raise MijpegError(rc, "mijpeg_launch_reconstruct failed")
+
+
+def frame_layout(width: int, height: int, components: int, hsamp, vsamp, quant, quant_index=None, ycbcr: int = 1) -> MijpegInfo:
+    """mijpeg_frame_layout: geometry of a frame to be coded (encoder direction).  quant: up to four tables of 64 deltas,
+    natural order; quant_index[c]: table of component c (default 0 for the first, 1 for the others)."""
+    f = MijpegInfo()
+    f.width, f.height, f.components, f.precision, f.ycbcr = width, height, components, 8, ycbcr
+    for c in range(components):
+        f.hsamp[c], f.vsamp[c] = hsamp[c], vsamp[c]
+        f.quant_index[c] = (0 if c == 0 else min(1, len(quant) - 1)) if quant_index is None else quant_index[c]
+    for t, tab in enumerate(quant):
+        for i in range(64):
+            f.quant[t][i] = int(tab[i])
+    L = lib()
+    L.mijpeg_frame_layout.argtypes = [C.POINTER(MijpegInfo)]
+    rc = L.mijpeg_frame_layout(C.byref(f))
+    if rc:
+        raise MijpegError(rc, "mijpeg_frame_layout failed")
+    return f
+
+
+def launch_forward(info: MijpegInfo, pixels_dev: int, coef_dev: int, frames: int, pixel_row_stride: int, pixel_frame_stride: int,
+                   coef_frame_stride: int | None = None, stream: int = 0) -> None:
+    """Encoder direction, stateless: device-resident interleaved pixels -> quantised coefficient planes in HBM (asynchronous)."""
+    b = MijpegForwardBatch()
+    C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
+    b.pixels_dev = pixels_dev
+    b.pixel_frame_stride = pixel_frame_stride
+    b.pixel_row_stride = pixel_row_stride
+    b.coef_dev = coef_dev
+    b.coef_frame_stride = info.coef_count if coef_frame_stride is None else coef_frame_stride
+    b.frames = frames
+    L = lib()
+    L.mijpeg_launch_forward.argtypes = [C.POINTER(MijpegForwardBatch), C.c_void_p]
+    rc = L.mijpeg_launch_forward(C.byref(b), stream)
+    if rc:
+        raise MijpegError(rc, "mijpeg_launch_forward failed")
 
 
 def workspace_bytes(info: MijpegInfo, frames: int, flags: int = 0) -> int:

@@ -16,6 +16,7 @@
 #include "../../include/mijpeg.h"
 #include "host_decoder.hpp"
 #include "huffman_dev.hpp"
+#include "forward.hpp"
 #include "kernels.hpp"
 
 using namespace mij;
@@ -1168,6 +1169,79 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     rc = launch_generic(a, fast, s);
   }
   return rc ? MIJPEG_ERR_DEVICE : MIJPEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder direction of the block pipeline
+// ------------------------------------------------------------------------------------------------
+int mijpeg_frame_layout(mijpeg_info *f)
+{
+  if (!f || f->width < 1 || f->height < 1 || f->width > 65535 || f->height > 65535 || f->components < 1 || f->components > MIJPEG_MAX_COMPONENTS)
+    return MIJPEG_ERR_INVALID_PARAMETER;
+  int hmax = 1, vmax = 1;
+  for (int c = 0; c < f->components; c++) {
+    if (f->hsamp[c] < 1 || f->hsamp[c] > 4 || f->vsamp[c] < 1 || f->vsamp[c] > 4 || f->quant_index[c] < 0 || f->quant_index[c] > 3)
+      return MIJPEG_ERR_INVALID_PARAMETER;
+    hmax = std::max(hmax, f->hsamp[c]);
+    vmax = std::max(vmax, f->vsamp[c]);
+  }
+  f->mcus_x = (f->width + 8 * hmax - 1) / (8 * hmax);
+  f->mcus_y = (f->height + 8 * vmax - 1) / (8 * vmax);
+  int64_t off = 0;
+  for (int c = 0; c < f->components; c++) {
+    if (hmax % f->hsamp[c] || vmax % f->vsamp[c]) return MIJPEG_ERR_INVALID_PARAMETER; // fractional subsampling factors
+    f->subx[c] = hmax / f->hsamp[c];
+    f->suby[c] = vmax / f->vsamp[c];
+    f->blocks_w[c] = f->mcus_x * f->hsamp[c];
+    f->blocks_h[c] = f->mcus_y * f->vsamp[c];
+    f->coef_offset[c] = off;
+    off += (int64_t)f->blocks_w[c] * f->blocks_h[c] * 64;
+  }
+  f->coef_count = off;
+  f->sample_bytes = 1;
+  return MIJPEG_OK;
+}
+
+int mijpeg_launch_forward(const mijpeg_forward_batch *b, void *stream)
+{
+  if (!b || !b->pixels_dev || !b->coef_dev || b->frames < 1) return MIJPEG_ERR_INVALID_PARAMETER;
+  const mijpeg_info &f = b->info;
+  if (f.precision != 8 || (f.components != 1 && f.components != 3) || f.xt) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
+  ForwardArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pixels = b->pixels_dev;
+  a.pixel_frame_stride = b->pixel_frame_stride;
+  a.pixel_row_stride = b->pixel_row_stride;
+  a.coef = b->coef_dev;
+  a.coef_frame_stride = b->coef_frame_stride;
+  a.width = f.width;
+  a.height = f.height;
+  a.ncomp = f.components;
+  a.ycbcr = f.ycbcr;
+  a.frames = b->frames;
+  uint64_t blocks = 0;
+  for (int c = 0; c < f.components; c++) {
+    if (f.subx[c] < 1 || f.suby[c] < 1 || f.blocks_w[c] < 1 || f.blocks_h[c] < 1) return MIJPEG_ERR_INVALID_PARAMETER;
+    a.subx[c] = f.subx[c];
+    a.suby[c] = f.suby[c];
+    a.bw[c] = f.blocks_w[c];
+    a.bh[c] = f.blocks_h[c];
+    a.nbx[c] = ((f.width + f.subx[c] - 1) / f.subx[c] + 7) >> 3;
+    a.nby[c] = ((f.height + f.suby[c] - 1) / f.suby[c] + 7) >> 3;
+    a.coef_off[c] = f.coef_offset[c];
+    a.first_block[c] = (uint32_t)blocks;
+    blocks += (uint64_t)f.blocks_w[c] * f.blocks_h[c];
+    for (int i = 0; i < 64; i++) {
+      const uint16_t delta = f.quant[f.quant_index[c]][i];
+      if (delta == 0) return MIJPEG_ERR_INVALID_PARAMETER;
+      // LONG(FLOAT(1L << QUANTIZER_BITS) / delta + 0.5), dct/idct.cpp:106: a single precision quotient
+      volatile float q = (float)(1L << 30) / (float)delta;
+      a.invq[c][i] = (int32_t)((double)q + 0.5);
+    }
+  }
+  if (blocks > 0xffffffffull) return MIJPEG_ERR_INVALID_PARAMETER;
+  a.first_block[f.components] = (uint32_t)blocks;
+  return launch_forward(a, (hipStream_t)stream) ? MIJPEG_ERR_DEVICE : MIJPEG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -984,3 +984,93 @@ def test_randomised_streams_through_every_entry_path(oracle):
             got = d.reconstruct()
             assert got.shape == exp.shape and np.array_equal(got, exp), (t, w, h, sub, q, dri, prog, opt, mode, d.entropy_used)
     d.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# encoder direction of the block pipeline: pixels in HBM -> quantised coefficient planes in HBM
+# ---------------------------------------------------------------------------------------------------------------
+def _forward_on_device(info, img, frames=1):
+    torch = _torch()
+    h, w = img.shape[:2]
+    nc = 1 if img.ndim == 2 else img.shape[2]
+    px = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+    if frames > 1:
+        px = px.unsqueeze(0).repeat(frames, *([1] * px.dim())).contiguous()
+    coef = torch.full((frames, int(info.coef_count)), 0x5A5A, dtype=torch.int16, device="cuda")
+    api.launch_forward(info, px.data_ptr(), coef.data_ptr(), frames, w * nc, h * w * nc, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = coef.cpu().numpy()
+    res = []
+    for f in range(frames):
+        res.append([out[f, info.coef_offset[c]:info.coef_offset[c] + info.blocks_w[c] * info.blocks_h[c] * 64]
+                    .reshape(info.blocks_h[c], info.blocks_w[c], 64) for c in range(info.components)])
+    return res
+
+
+FWD_LAYOUTS = {"444": ((1, 1, 1), (1, 1, 1)), "420": ((2, 1, 1), (2, 1, 1)), "422": ((2, 1, 1), (1, 1, 1)), "440": ((1, 1, 1), (2, 1, 1)),
+               "411": ((4, 1, 1), (1, 1, 1)), "3x3": ((3, 1, 1), (3, 1, 1)), "4x2": ((4, 1, 1), (2, 1, 1)), "mixed": ((2, 1, 2), (2, 2, 1))}
+
+
+@pytest.mark.parametrize("sub", list(FWD_LAYOUTS))
+@pytest.mark.parametrize("w,h", [(64, 48), (75, 45), (33, 17), (129, 71), (8, 8), (1, 1), (640, 360)])
+def test_forward_kernel_vs_oracle(oracle, w, h, sub):
+    """Forward L transformation + box downsampling + FDCT + quantiser on the device against the oracle's restatement
+    (which is pinned against the reference encoder): every layout, partial blocks, mirrored right edge, missing lines."""
+    hs, vs = FWD_LAYOUTS[sub]
+    rng = np.random.default_rng(w * 1000 + h)
+    img = synth.synth_image(w, h, 40 + w) if (w + h) % 2 else rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    quant = [rng.integers(1, 60, 64), rng.integers(1, 255, 64)]
+    info = api.frame_layout(w, h, 3, hs, vs, quant)
+    oi = oracle.OjInfo()
+    oi.width, oi.height, oi.precision, oi.ncomp = w, h, 8, 3
+    for c in range(3):
+        oi.hs[c], oi.vs[c], oi.tq[c] = hs[c], vs[c], info.quant_index[c]
+        oi.subx[c], oi.suby[c], oi.bw[c], oi.bh[c] = info.subx[c], info.suby[c], info.blocks_w[c], info.blocks_h[c]
+        oi.cw[c], oi.ch[c] = -(-w // info.subx[c]), -(-h // info.suby[c])
+    for t in range(2):
+        for i in range(64):
+            oi.quant[t][i] = int(quant[t][i])
+    exp = oracle.forward(oi, img, 1)
+    got = _forward_on_device(info, img)[0]
+    for c in range(3):
+        assert np.array_equal(got[c].astype(np.int32), exp[c]), (sub, c, np.argwhere(got[c] != exp[c])[:3].tolist())
+
+
+@pytest.mark.parametrize("name", ["ref_80x48_420", "ref_100x9_422", "ref_97x61_440", "ref_97x61_3x3", "ref_97x61_mixed", "ref_64x40_q2",
+                                  "ref_64x40_q100", "cfg1_512x512_444_q75_ref"])
+def test_forward_kernel_reproduces_the_reference_encoders_coefficients(dec, name):
+    """The golden files were written by the reference encoder from synth_image(w, h, seed): the device must arrive at the
+    coefficients that are in them (blocks that cover samples; the padding blocks belong to the entropy coder)."""
+    ent = MANIFEST[name]
+    if "seed" not in ent:
+        pytest.skip("no recipe for the source picture in the manifest")
+    img = synth.synth_image(ent["width"], ent["height"], ent["seed"])
+    f = dec.read(golden_jpeg(name))
+    info = api.frame_layout(f.width, f.height, 3, list(f.hsamp)[:3], list(f.vsamp)[:3], [list(f.quant[t]) for t in range(4)],
+                            quant_index=list(f.quant_index)[:3])
+    got = _forward_on_device(info, img, frames=2)
+    for c in range(3):
+        ref = dec.coefficients(c).reshape(f.blocks_h[c], f.blocks_w[c], 64)
+        nby, nbx = (-(-f.height // f.suby[c]) + 7) // 8, (-(-f.width // f.subx[c]) + 7) // 8
+        for fr in range(2):
+            assert np.array_equal(got[fr][c][:nby, :nbx], ref[:nby, :nbx]), (name, c, fr)
+            pad = got[fr][c].copy()
+            pad[:nby, :nbx] = 0
+            assert not pad.any()
+
+
+def test_forward_kernel_grey(oracle):
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (50, 70)).astype(np.uint8)
+    quant = [rng.integers(1, 40, 64)]
+    info = api.frame_layout(70, 50, 1, (1,), (1,), quant, ycbcr=0)
+    oi = oracle.OjInfo()
+    oi.width, oi.height, oi.precision, oi.ncomp = 70, 50, 8, 1
+    oi.hs[0] = oi.vs[0] = oi.subx[0] = oi.suby[0] = 1
+    oi.bw[0], oi.bh[0], oi.cw[0], oi.ch[0] = info.blocks_w[0], info.blocks_h[0], 70, 50
+    for i in range(64):
+        oi.quant[0][i] = int(quant[0][i])
+    exp = oracle.forward(oi, img[..., None], 0)
+    got = _forward_on_device(info, img)[0]
+    assert np.array_equal(got[0].astype(np.int32), exp[0])
+
