@@ -259,6 +259,29 @@ typedef struct mijpeg_forward_batch {
 /* One launch on `stream` (hipStream_t) for all frames of the batch.  Asynchronous. */
 int mijpeg_launch_forward(const mijpeg_forward_batch *batch, void *stream);
 
+/* Entropy coder + stream writer for what mijpeg_launch_forward produced (after a device-to-host copy): quantised
+ * coefficient planes in HOST memory, the layout of *info, -> a baseline (SOF0) JPEG stream with one interleaved
+ * Huffman-sequential scan (codestream/sequentialscan.cpp:430-676 WriteMCU / EncodeBlock; segment syntax: marker/ directory).
+ * restart_interval: MCUs per restart interval, 0 = none (the intervals are coded in parallel on `threads` threads,
+ * <= 0: default); optimize != 0: Huffman tables optimised for the picture (Annex K.2) instead of the Annex K.3 tables.
+ * MCU padding blocks are coded as "same DC, no AC".  *stream is malloc'ed: release it with mijpeg_free. */
+int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t *coef, int restart_interval, int optimize, int threads,
+                               uint8_t **stream, size_t *size);
+void mijpeg_free(void *p);
+
+/* The quantiser tables the reference encoder derives from `-q quality` with its default (Annex K) matrices:
+ * Quantization::InitDefaultTables, marker/quantization.cpp:275-466, for 8-bit frames -- natural order. */
+void mijpeg_quality_tables(int quality, uint16_t luma[64], uint16_t chroma[64]);
+
+/* Whole encoder-direction pipeline for one picture in HOST memory on the decoder object's device: upload, forward kernel,
+ * download of the coefficients, entropy coding (`jpeg -bl -q quality -s ... -z restart_interval [-h] in.ppm out.jpg` of the
+ * reference CLI, cmd/encodec.cpp; here: Annex K.3 or optimised Huffman tables, one interleaved baseline scan).
+ * pixels: interleaved 8-bit, `components` (1 or 3) per pixel, row_stride bytes per line; hsamp/vsamp: sampling factors
+ * per component (NULL: 1x1 everywhere); RGB input is coded as YCbCr.  *stream is malloc'ed (mijpeg_free). */
+int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
+                        int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize,
+                        uint8_t **stream, size_t *size);
+
 /* Worker threads mijpeg_decode_coefficients uses for threads <= 0 (MIJPEG_THREADS overrides; default min(cores, 64)). */
 int mijpeg_default_threads(void);
 

@@ -197,6 +197,25 @@ class Decoder:
         """Rounds the on-device self-synchronising walk took in the last device entropy decode (0 = none needed)."""
         return int(lib().mijpeg_device_walk_rounds(self._h))
 
+    def encode(self, img: np.ndarray, quality: int = 85, subsampling: str = "444", restart_mcus: int = 0, optimize: bool = False) -> bytes:
+        """mijpeg_encode_image: (H, W, 3) RGB or (H, W) grey uint8 picture -> baseline JPEG; forward transform on the device."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape[:2]
+        nc = 1 if img.ndim == 2 else img.shape[2]
+        hs, vs = {"444": ((1, 1, 1), (1, 1, 1)), "420": ((2, 1, 1), (2, 1, 1)), "422": ((2, 1, 1), (1, 1, 1)), "440": ((1, 1, 1), (2, 1, 1)),
+                  "411": ((4, 1, 1), (1, 1, 1))}[subsampling]
+        L = lib()
+        L.mijpeg_encode_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.mijpeg_free.argtypes = [C.c_void_p]
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(L.mijpeg_encode_image(self._h, img.ctypes.data, w, h, nc, w * nc, quality, (C.c_int32 * 4)(*hs, 1), (C.c_int32 * 4)(*vs, 1),
+                                          restart_mcus, 1 if optimize else 0, C.byref(p), C.byref(n)))
+        try:
+            return C.string_at(p, n.value)
+        finally:
+            L.mijpeg_free(p)
+
     def xt_params(self) -> MijpegXtParams:
         xt = MijpegXtParams()
         self._check(lib().mijpeg_get_xt_params(self._h, C.byref(xt)))
@@ -397,6 +416,23 @@ def launch_forward(info: MijpegInfo, pixels_dev: int, coef_dev: int, frames: int
     rc = L.mijpeg_launch_forward(C.byref(b), stream)
     if rc:
         raise MijpegError(rc, "mijpeg_launch_forward failed")
+
+
+def encode_coefficients(info: MijpegInfo, coef: np.ndarray, restart_interval: int = 0, optimize: bool = False, threads: int = 0) -> bytes:
+    """mijpeg_encode_coefficients: quantised coefficient planes (host int16, info.coef_count of them) -> baseline JPEG stream."""
+    coef = np.ascontiguousarray(coef, np.int16).reshape(-1)
+    assert coef.size == info.coef_count
+    L = lib()
+    L.mijpeg_encode_coefficients.argtypes = [C.POINTER(MijpegInfo), C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.mijpeg_free.argtypes = [C.c_void_p]
+    p, n = C.c_void_p(), C.c_size_t()
+    rc = L.mijpeg_encode_coefficients(C.byref(info), coef.ctypes.data, restart_interval, 1 if optimize else 0, threads, C.byref(p), C.byref(n))
+    if rc:
+        raise MijpegError(rc, "mijpeg_encode_coefficients failed")
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        L.mijpeg_free(p)
 
 
 def workspace_bytes(info: MijpegInfo, frames: int, flags: int = 0) -> int:

@@ -50,6 +50,8 @@ struct mijpeg_decoder {
   size_t ent_host_cap = 0;
   bool host_planes_stale = false; // coefficients live on the device only
   double phase_prepare = 0, phase_device = 0; // last device entropy decode: host tables / upload + kernel
+  uint8_t *enc_dev = nullptr; // encoder direction: pixels + coefficients of one picture
+  size_t enc_cap = 0;
   uint8_t *walk_dev = nullptr, *walk_host = nullptr; // state of the device walk over streams without restart markers
   size_t walk_cap = 0, walk_host_cap = 0;
   int walk_rounds = 0;
@@ -129,6 +131,7 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->ent_host) (void)hipHostFree(d->ent_host);
     if (d->stage_host) (void)hipHostFree(d->stage_host);
     if (d->walk_dev) (void)hipFree(d->walk_dev);
+    if (d->enc_dev) (void)hipFree(d->enc_dev);
     if (d->walk_host) (void)hipHostFree(d->walk_host);
     for (hipEvent_t e : d->copy_events) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
@@ -1242,6 +1245,69 @@ int mijpeg_launch_forward(const mijpeg_forward_batch *b, void *stream)
   if (blocks > 0xffffffffull) return MIJPEG_ERR_INVALID_PARAMETER;
   a.first_block[f.components] = (uint32_t)blocks;
   return launch_forward(a, (hipStream_t)stream) ? MIJPEG_ERR_DEVICE : MIJPEG_OK;
+}
+
+void mijpeg_quality_tables(int quality, uint16_t luma[64], uint16_t chroma[64])
+{
+  // ISO/IEC 10918-1 Annex K.1 / K.2 matrices, natural order
+  static const uint8_t K1[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,  69,  56,
+                                 14, 17, 22, 29, 51,  87,  80,  62,  18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                                 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+  static const uint8_t K2[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+  quality = std::min(100, std::max(1, quality));
+  const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2; // quantization.cpp:296-299
+  for (int j = 0; j < 64; j++) {
+    luma[j] = (uint16_t)std::min(255, std::max(1, (K1[j] * scale + 50) / 100)); // :411, :443-466
+    chroma[j] = (uint16_t)std::min(255, std::max(1, (K2[j] * scale + 50) / 100));
+  }
+}
+
+int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
+                        int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint8_t **stream, size_t *size)
+{
+  if (!d || !pixels || !stream || !size || (components != 1 && components != 3) || row_stride < (int64_t)width * components)
+    return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "decoder was created without a device");
+  HIP_TRY(d, hipSetDevice(d->device));
+  mijpeg_forward_batch b;
+  memset(&b, 0, sizeof(b));
+  mijpeg_info &f = b.info;
+  f.width = width;
+  f.height = height;
+  f.components = components;
+  f.precision = 8;
+  f.ycbcr = components == 3 ? 1 : 0;
+  for (int c = 0; c < components; c++) {
+    f.hsamp[c] = hsamp ? hsamp[c] : 1;
+    f.vsamp[c] = vsamp ? vsamp[c] : 1;
+    // the reference encoder defines a luma and a chroma table but its frame header selects table 0 for every component
+    // (what its own files show: tests/test_encoder.py::test_quality_tables_are_the_reference_encoders), so that is
+    // what reproduces its coefficients
+    f.quant_index[c] = 0;
+  }
+  mijpeg_quality_tables(quality, f.quant[0], f.quant[1]);
+  int rc = mijpeg_frame_layout(&f);
+  if (rc) return set_error(d, rc, "invalid frame layout for encoding");
+  const size_t px_bytes = (size_t)row_stride * (size_t)height, coef_bytes = (size_t)f.coef_count * sizeof(int16_t);
+  rc = ensure_dev(d, (void **)&d->enc_dev, &d->enc_cap, px_bytes + 256 + coef_bytes);
+  if (rc) return rc;
+  std::vector<int16_t> coef((size_t)f.coef_count);
+  int16_t *coef_dev = (int16_t *)(d->enc_dev + ((px_bytes + 255) & ~(size_t)255));
+  HIP_TRY(d, hipMemcpyAsync(d->enc_dev, pixels, px_bytes, hipMemcpyHostToDevice, d->stream));
+  b.pixels_dev = d->enc_dev;
+  b.pixel_row_stride = row_stride;
+  b.pixel_frame_stride = (int64_t)px_bytes;
+  b.coef_dev = coef_dev;
+  b.coef_frame_stride = f.coef_count;
+  b.frames = 1;
+  rc = mijpeg_launch_forward(&b, d->stream);
+  if (rc) return set_error(d, rc, "forward kernel launch failed");
+  HIP_TRY(d, hipMemcpyAsync(coef.data(), coef_dev, coef_bytes, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  rc = mijpeg_encode_coefficients(&f, coef.data(), restart_interval, optimize, 0, stream, size);
+  if (rc) return set_error(d, rc, "entropy coding failed");
+  return MIJPEG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

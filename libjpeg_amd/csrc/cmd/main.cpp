@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "../../../include/mijpeg.h"
 #include "../interface/hooks.hpp"
 #include "../interface/jpeg.hpp"
 #include "../interface/parameters.hpp"
@@ -216,11 +217,77 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
   return rc;
 }
 
+// Encoder direction (the reference CLI's `jpeg -bl -q n [-s HxV,HxV,HxV] [-z n] [-h] source.ppm target.jpg`, cmd/main.cpp ->
+// cmd/encodec.cpp): binary PNM (P5 / P6, maxval 255) in, baseline JPEG out, through the C ABI's mijpeg_encode_image.
+// -s takes the reference's SUBSAMPLING factors per component (1x1,2x2,2x2 = 4:2:0).
+static int Encode(const char *src, const char *dst, int quality, const char *sub, int restart, bool optimize, int device)
+{
+  FILE *in = fopen(src, "rb");
+  if (!in) { perror(src); return 10; }
+  int w = 0, h = 0, maxval = 0;
+  char magic[3] = {0, 0, 0};
+  if (fscanf(in, "%2s %d %d %d", magic, &w, &h, &maxval) != 4 || magic[0] != 'P' || (magic[1] != '5' && magic[1] != '6') || maxval != 255 || w < 1 || h < 1) {
+    fprintf(stderr, "%s: only binary PGM / PPM files with 8 bits per sample are supported as encoder input\n", src);
+    fclose(in);
+    return 10;
+  }
+  fgetc(in); // the single white space behind the header
+  const int nc = magic[1] == '6' ? 3 : 1;
+  const size_t bytes = (size_t)w * (size_t)h * (size_t)nc;
+  unsigned char *px = (unsigned char *)malloc(bytes);
+  if (!px || fread(px, 1, bytes, in) != bytes) {
+    fprintf(stderr, "%s: unexpected end of file\n", src);
+    fclose(in);
+    free(px);
+    return 10;
+  }
+  fclose(in);
+  int32_t hs[4] = {1, 1, 1, 1}, vs[4] = {1, 1, 1, 1};
+  if (sub && nc == 3) { // subsampling factors -> sampling factors
+    int sx[3], sy[3];
+    if (sscanf(sub, "%dx%d,%dx%d,%dx%d", &sx[0], &sy[0], &sx[1], &sy[1], &sx[2], &sy[2]) != 6) { fprintf(stderr, "-s expects e.g. 1x1,2x2,2x2\n"); free(px); return 5; }
+    int mx = 1, my = 1;
+    for (int c = 0; c < 3; c++) { if (sx[c] < 1 || sx[c] > 4 || sy[c] < 1 || sy[c] > 4) { fprintf(stderr, "subsampling factors must be 1..4\n"); free(px); return 5; } mx = sx[c] > mx ? sx[c] : mx; my = sy[c] > my ? sy[c] : my; }
+    for (int c = 0; c < 3; c++) {
+      if (mx % sx[c] || my % sy[c]) { fprintf(stderr, "unsupported combination of subsampling factors\n"); free(px); return 5; }
+      hs[c] = mx / sx[c];
+      vs[c] = my / sy[c];
+    }
+  }
+  mijpeg_decoder *d = NULL;
+  if (mijpeg_create(&d, device < 0 ? 0 : device) || !d) { fprintf(stderr, "no MI355X device available\n"); free(px); return 10; }
+  uint8_t *stream = NULL;
+  size_t size = 0;
+  int rc = mijpeg_encode_image(d, px, w, h, nc, (int64_t)w * nc, quality, hs, vs, restart, optimize ? 1 : 0, &stream, &size);
+  free(px);
+  if (rc) {
+    const char *msg = NULL;
+    mijpeg_last_error(d, &msg);
+    fprintf(stderr, "encoding failed: error %d %s\n", rc, msg ? msg : "");
+    mijpeg_destroy(d);
+    return 10;
+  }
+  mijpeg_destroy(d);
+  FILE *out = fopen(dst, "wb");
+  if (!out || fwrite(stream, 1, size, out) != size) { perror(dst); if (out) fclose(out); mijpeg_free(stream); return 10; }
+  fclose(out);
+  mijpeg_free(stream);
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   bool colortrafo = true, upsample = true;
   int threads = 0, device = -1;
+  int quality = -1, restart = 0;
+  const char *sub = NULL;
+  bool optimize = false;
   while (argc > 3) {
+    if (!strcmp(argv[1], "-q") && argc > 4) { quality = atoi(argv[2]); argv += 2; argc -= 2; continue; }
+    if (!strcmp(argv[1], "-s") && argc > 4) { sub = argv[2]; argv += 2; argc -= 2; continue; }
+    if (!strcmp(argv[1], "-z") && argc > 4) { restart = atoi(argv[2]); argv += 2; argc -= 2; continue; }
+    if (!strcmp(argv[1], "-h")) { optimize = true; argv++; argc--; continue; }
+    if (!strcmp(argv[1], "-bl")) { argv++; argc--; continue; } // baseline is what the encoder writes anyway
     if (!strcmp(argv[1], "-c")) { colortrafo = false; argv++; argc--; }
     else if (!strcmp(argv[1], "-U")) { upsample = false; argv++; argc--; }
     else if (!strcmp(argv[1], "-t") && argc > 4) { threads = atoi(argv[2]); argv += 2; argc -= 2; }
@@ -230,8 +297,11 @@ int main(int argc, char **argv)
   if (argc != 3) {
     fprintf(stderr, "usage: %s [-c] [-U] [-t threads] [-d device] source.jpg target.ppm\n"
                     "  reconstructs a Huffman sequential JPEG on an MI355X and writes a binary PNM,\n"
-                    "  byte-identical to the output of the reference `jpeg source.jpg target.ppm`\n", argv[0]);
+                    "  byte-identical to the output of the reference `jpeg source.jpg target.ppm`\n"
+                    "       %s -q quality [-bl] [-s 1x1,2x2,2x2] [-z restart-interval] [-h] [-d device] source.ppm target.jpg\n"
+                    "  encodes a binary PNM as baseline JPEG: the coefficients the reference encoder computes\n", argv[0], argv[0]);
     return 5;
   }
+  if (quality >= 0) return Encode(argv[1], argv[2], quality, sub, restart, optimize, device);
   return Reconstruct(argv[1], argv[2], colortrafo, upsample, threads, device);
 }

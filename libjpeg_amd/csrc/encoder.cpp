@@ -1,0 +1,343 @@
+// encoder.cpp -- entropy coder and stream writer behind the encoder-direction kernel: quantised coefficient planes
+// (host memory, the decoder's layout) -> baseline JPEG stream.
+//
+// What the reference's SequentialScan does when writing (codestream/sequentialscan.cpp:430-676: WriteMCU, EncodeBlock,
+// Restart / Flush; marker/*.cpp for the segment syntax): one interleaved Huffman-sequential scan over all components,
+// DC differences per component reset at every restart marker, AC run/size symbols with ZRL and EOB, byte stuffing,
+// one-bits as padding in front of a marker (io/bitstream.hpp).  Restart intervals are independent, so they are coded
+// in parallel into buffers of their own and concatenated with the RSTn markers in between.
+// Huffman tables: the general purpose tables of ISO/IEC 10918-1 Annex K.3, or tables optimised for the picture
+// (K.2: code lengths from the symbol statistics, limited to 16 bits).
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "host_decoder.hpp"
+
+namespace mij {
+namespace {
+
+struct EncTable {
+  uint8_t counts[16];
+  uint8_t values[256];
+  int nvalues;
+  uint16_t code[256];
+  uint8_t len[256];
+  void derive()
+  {
+    memset(code, 0, sizeof(code));
+    memset(len, 0, sizeof(len));
+    unsigned c = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; l++) {
+      for (int i = 0; i < counts[l - 1]; i++, k++) {
+        code[values[k]] = (uint16_t)c++;
+        len[values[k]] = (uint8_t)l;
+      }
+      c <<= 1;
+    }
+    nvalues = k;
+  }
+};
+
+// Annex K.3 general purpose tables
+const uint8_t K3_DC_L_COUNTS[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t K3_DC_C_COUNTS[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t K3_DC_VALUES[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t K3_AC_L_COUNTS[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t K3_AC_L_VALUES[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+    0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+    0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+    0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+    0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+    0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+const uint8_t K3_AC_C_COUNTS[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t K3_AC_C_VALUES[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+    0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+    0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+    0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+    0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+    0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+
+void set_table(EncTable &t, const uint8_t counts[16], const uint8_t *values, int n)
+{
+  memcpy(t.counts, counts, 16);
+  memset(t.values, 0, sizeof(t.values));
+  memcpy(t.values, values, (size_t)n);
+  t.derive();
+}
+
+// Annex K.2: optimal code lengths from frequencies, no code longer than 16 bits, no all-ones code
+void optimal_table(EncTable &t, const uint32_t freq_in[256])
+{
+  long freq[257];
+  int codesize[257], others[257];
+  for (int i = 0; i < 256; i++) freq[i] = freq_in[i];
+  freq[256] = 1; // reserves the all-ones code word
+  memset(codesize, 0, sizeof(codesize));
+  for (int i = 0; i < 257; i++) others[i] = -1;
+  for (;;) {
+    int c1 = -1, c2 = -1;
+    long v = 1000000000L;
+    for (int i = 0; i <= 256; i++)
+      if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
+    v = 1000000000L;
+    for (int i = 0; i <= 256; i++)
+      if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
+    if (c2 < 0) break;
+    freq[c1] += freq[c2];
+    freq[c2] = 0;
+    codesize[c1]++;
+    while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
+    others[c1] = c2;
+    codesize[c2]++;
+    while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
+  }
+  int bits[33];
+  memset(bits, 0, sizeof(bits));
+  for (int i = 0; i <= 256; i++)
+    if (codesize[i]) bits[std::min(codesize[i], 32)]++;
+  for (int i = 32; i > 16; i--)
+    while (bits[i] > 0) {
+      int j = i - 2;
+      while (bits[j] == 0) j--;
+      bits[i] -= 2;
+      bits[i - 1]++;
+      bits[j + 1] += 2;
+      bits[j]--;
+    }
+  int i = 16;
+  while (bits[i] == 0) i--;
+  bits[i]--; // the reserved code point
+  for (int l = 1; l <= 16; l++) t.counts[l - 1] = (uint8_t)bits[l];
+  int k = 0;
+  memset(t.values, 0, sizeof(t.values));
+  for (int l = 1; l <= 32; l++)
+    for (int s = 0; s < 256; s++)
+      if (codesize[s] == l) t.values[k++] = (uint8_t)s;
+  t.derive();
+}
+
+struct BitWriter {
+  std::vector<uint8_t> &out;
+  uint64_t acc = 0;
+  int n = 0;
+  explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+  void put(unsigned bits, int len)
+  {
+    acc = (acc << len) | (bits & ((1u << len) - 1u));
+    n += len;
+    while (n >= 8) {
+      const uint8_t b = (uint8_t)(acc >> (n - 8));
+      out.push_back(b);
+      if (b == 0xff) out.push_back(0); // byte stuffing
+      n -= 8;
+    }
+  }
+  void flush() // one-bits up to the byte boundary
+  {
+    if (n) put((1u << (8 - n)) - 1u, 8 - n);
+  }
+};
+
+inline int category(int v)
+{
+  unsigned a = (unsigned)(v < 0 ? -v : v);
+  int s = 0;
+  while (a) { s++; a >>= 1; }
+  return s;
+}
+
+// One block: sequentialscan.cpp EncodeBlock.  Either codes it (bw != null) or counts its symbols.
+inline void code_block(const int16_t *blk, int &pred, const EncTable &dc, const EncTable &ac, BitWriter *bw, uint32_t *dcfreq, uint32_t *acfreq,
+                       const uint8_t *zz)
+{
+  const int diff = (blk ? blk[0] : pred) - pred;
+  pred += diff;
+  int s = category(diff);
+  if (bw) {
+    bw->put(dc.code[s], dc.len[s]);
+    if (s) bw->put((unsigned)(diff < 0 ? diff - 1 : diff), s);
+  } else dcfreq[s]++;
+  int run = 0;
+  if (blk)
+    for (int k = 1; k < 64; k++) {
+      const int v = blk[zz[k]];
+      if (v == 0) { run++; continue; }
+      while (run > 15) {
+        if (bw) bw->put(ac.code[0xf0], ac.len[0xf0]);
+        else acfreq[0xf0]++;
+        run -= 16;
+      }
+      s = category(v);
+      const int sym = (run << 4) | s;
+      if (bw) {
+        bw->put(ac.code[sym], ac.len[sym]);
+        bw->put((unsigned)(v < 0 ? v - 1 : v), s);
+      } else acfreq[sym]++;
+      run = 0;
+    }
+  else run = 63;
+  if (run > 0) {
+    if (bw) bw->put(ac.code[0], ac.len[0]);
+    else acfreq[0]++;
+  }
+}
+
+void put16(std::vector<uint8_t> &o, unsigned v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
+
+void write_dht(std::vector<uint8_t> &o, int tc, int th, const EncTable &t)
+{
+  o.push_back(0xff); o.push_back(0xc4);
+  put16(o, (unsigned)(2 + 1 + 16 + t.nvalues));
+  o.push_back((uint8_t)((tc << 4) | th));
+  o.insert(o.end(), t.counts, t.counts + 16);
+  o.insert(o.end(), t.values, t.values + t.nvalues);
+}
+
+} // namespace
+} // namespace mij
+
+using namespace mij;
+
+extern "C" void mijpeg_free(void *p) { free(p); }
+
+extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t *coef, int restart_interval, int optimize, int threads,
+                                          uint8_t **stream, size_t *size)
+{
+  if (!info || !coef || !stream || !size || restart_interval < 0 || restart_interval > 65535) return MIJPEG_ERR_INVALID_PARAMETER;
+  const mijpeg_info &f = *info;
+  if (f.precision != 8 || (f.components != 1 && f.components != 3)) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
+  const int nc = f.components;
+  const uint8_t *zz = scan_order();
+  const int64_t total_mcus = (int64_t)f.mcus_x * f.mcus_y;
+  const int64_t ri = restart_interval ? restart_interval : total_mcus;
+  const int64_t nint = (total_mcus + ri - 1) / ri;
+  if (threads <= 0) threads = default_threads();
+  // the blocks that cover samples; the MCU padding blocks are coded as "same DC, no AC"
+  int nbx[4], nby[4], hs[4], vs[4];
+  for (int c = 0; c < nc; c++) {
+    nbx[c] = ((f.width + f.subx[c] - 1) / f.subx[c] + 7) >> 3;
+    nby[c] = ((f.height + f.suby[c] - 1) / f.suby[c] + 7) >> 3;
+    hs[c] = nc > 1 ? f.hsamp[c] : 1;
+    vs[c] = nc > 1 ? f.vsamp[c] : 1;
+  }
+  auto walk_interval = [&](int64_t i, const EncTable *dct, const EncTable *act, BitWriter *bw, uint32_t (*dcf)[256], uint32_t (*acf)[256]) {
+    int pred[4] = {0, 0, 0, 0};
+    const int64_t m0 = i * ri, m1 = std::min(total_mcus, m0 + ri);
+    for (int64_t m = m0; m < m1; m++) {
+      const int my = (int)(m / f.mcus_x), mx = (int)(m - (int64_t)my * f.mcus_x);
+      for (int c = 0; c < nc; c++) {
+        const int t = c ? 1 : 0;
+        for (int by = 0; by < vs[c]; by++)
+          for (int bx = 0; bx < hs[c]; bx++) {
+            const int gx = mx * hs[c] + bx, gy = my * vs[c] + by;
+            const int16_t *blk = (gx < nbx[c] && gy < nby[c]) ? coef + f.coef_offset[c] + ((int64_t)gy * f.blocks_w[c] + gx) * 64 : nullptr;
+            code_block(blk, pred[c], dct[t], act[t], bw, dcf ? dcf[t] : nullptr, acf ? acf[t] : nullptr, zz);
+          }
+      }
+    }
+  };
+  EncTable dct[2], act[2];
+  if (optimize) {
+    const int parts = (int)std::min<int64_t>(threads, nint);
+    std::vector<std::vector<uint32_t>> stats((size_t)parts, std::vector<uint32_t>(4 * 256, 0));
+    parallel_for(parts, [&](int p) {
+      uint32_t(*dcf)[256] = reinterpret_cast<uint32_t(*)[256]>(stats[(size_t)p].data());
+      uint32_t(*acf)[256] = dcf + 2;
+      for (int64_t i = nint * p / parts; i < nint * (p + 1) / parts; i++) walk_interval(i, dct, act, nullptr, dcf, acf);
+    });
+    uint32_t sum[4][256];
+    memset(sum, 0, sizeof(sum));
+    for (auto &s : stats)
+      for (int k = 0; k < 4 * 256; k++) (&sum[0][0])[k] += s[(size_t)k];
+    for (int t = 0; t < (nc > 1 ? 2 : 1); t++) {
+      optimal_table(dct[t], sum[t]);
+      optimal_table(act[t], sum[2 + t]);
+    }
+  } else {
+    set_table(dct[0], K3_DC_L_COUNTS, K3_DC_VALUES, 12);
+    set_table(dct[1], K3_DC_C_COUNTS, K3_DC_VALUES, 12);
+    set_table(act[0], K3_AC_L_COUNTS, K3_AC_L_VALUES, 162);
+    set_table(act[1], K3_AC_C_COUNTS, K3_AC_C_VALUES, 162);
+  }
+  // entropy coded segments, one buffer per restart interval
+  std::vector<std::vector<uint8_t>> seg((size_t)nint);
+  const int tasks = (int)std::min<int64_t>(nint, (int64_t)threads * 8);
+  parallel_for(std::min(threads, tasks), [&](int w) {
+    const int workers = std::min(threads, tasks);
+    for (int64_t i = w; i < nint; i += workers) {
+      seg[(size_t)i].reserve(1024);
+      BitWriter bw(seg[(size_t)i]);
+      walk_interval(i, dct, act, &bw, nullptr, nullptr);
+      bw.flush();
+    }
+  });
+  // the stream
+  std::vector<uint8_t> o;
+  size_t ecs = 0;
+  for (auto &s : seg) ecs += s.size() + 2;
+  o.reserve(ecs + 1024);
+  o.push_back(0xff); o.push_back(0xd8);
+  bool used[4] = {false, false, false, false};
+  for (int c = 0; c < nc; c++) used[f.quant_index[c]] = true;
+  for (int t = 0; t < 4; t++)
+    if (used[t]) {
+      bool wide = false;
+      for (int i = 0; i < 64; i++) wide |= f.quant[t][i] > 255;
+      o.push_back(0xff); o.push_back(0xdb);
+      put16(o, (unsigned)(2 + 1 + (wide ? 128 : 64)));
+      o.push_back((uint8_t)((wide ? 0x10 : 0) | t));
+      for (int k = 0; k < 64; k++) {
+        if (wide) o.push_back((uint8_t)(f.quant[t][zz[k]] >> 8));
+        o.push_back((uint8_t)f.quant[t][zz[k]]);
+      }
+    }
+  o.push_back(0xff); o.push_back(0xc0);
+  put16(o, (unsigned)(8 + 3 * nc));
+  o.push_back(8);
+  put16(o, (unsigned)f.height);
+  put16(o, (unsigned)f.width);
+  o.push_back((uint8_t)nc);
+  for (int c = 0; c < nc; c++) {
+    o.push_back((uint8_t)(c + 1));
+    o.push_back((uint8_t)((f.hsamp[c] << 4) | f.vsamp[c]));
+    o.push_back((uint8_t)f.quant_index[c]);
+  }
+  for (int t = 0; t < (nc > 1 ? 2 : 1); t++) {
+    write_dht(o, 0, t, dct[t]);
+    write_dht(o, 1, t, act[t]);
+  }
+  if (restart_interval) {
+    o.push_back(0xff); o.push_back(0xdd);
+    put16(o, 4);
+    put16(o, (unsigned)restart_interval);
+  }
+  o.push_back(0xff); o.push_back(0xda);
+  put16(o, (unsigned)(6 + 2 * nc));
+  o.push_back((uint8_t)nc);
+  for (int c = 0; c < nc; c++) {
+    o.push_back((uint8_t)(c + 1));
+    o.push_back((uint8_t)(c ? 0x11 : 0x00));
+  }
+  o.push_back(0); o.push_back(63); o.push_back(0);
+  for (int64_t i = 0; i < nint; i++) {
+    o.insert(o.end(), seg[(size_t)i].begin(), seg[(size_t)i].end());
+    if (i + 1 < nint) { o.push_back(0xff); o.push_back((uint8_t)(0xd0 + (i & 7))); }
+  }
+  o.push_back(0xff); o.push_back(0xd9);
+  uint8_t *p = (uint8_t *)malloc(o.size());
+  if (!p) return MIJPEG_ERR_OUT_OF_MEMORY;
+  memcpy(p, o.data(), o.size());
+  *stream = p;
+  *size = o.size();
+  return MIJPEG_OK;
+}

