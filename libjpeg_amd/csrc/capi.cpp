@@ -1222,6 +1222,7 @@ int mijpeg_launch_forward(const mijpeg_forward_batch *b, void *stream)
   a.ncomp = f.components;
   a.ycbcr = f.ycbcr;
   a.frames = b->frames;
+  const bool dword_lines = (((uintptr_t)b->pixels_dev | (uintptr_t)b->pixel_frame_stride | (uintptr_t)b->pixel_row_stride) & 3) == 0;
   uint64_t blocks = 0;
   for (int c = 0; c < f.components; c++) {
     if (f.subx[c] < 1 || f.suby[c] < 1 || f.blocks_w[c] < 1 || f.blocks_h[c] < 1) return MIJPEG_ERR_INVALID_PARAMETER;
@@ -1232,6 +1233,9 @@ int mijpeg_launch_forward(const mijpeg_forward_batch *b, void *stream)
     a.nbx[c] = ((f.width + f.subx[c] - 1) / f.subx[c] + 7) >> 3;
     a.nby[c] = ((f.height + f.suby[c] - 1) / f.suby[c] + 7) >> 3;
     a.coef_off[c] = f.coef_offset[c];
+    a.fast[c] = dword_lines && f.components == 3 && f.ycbcr && f.subx[c] <= 2 && f.suby[c] <= 2 && !getenv("MIJPEG_FORWARD_SLOW");
+    a.fast_nbx[c] = f.width / (8 * f.subx[c]);
+    a.fast_nby[c] = f.height / (8 * f.suby[c]);
     a.first_block[c] = (uint32_t)blocks;
     blocks += (uint64_t)f.blocks_w[c] * f.blocks_h[c];
     for (int i = 0; i < 64; i++) {

@@ -69,6 +69,82 @@ __device__ __forceinline__ int ycc_component(int c, int r, int g, int b)
   return min(max(v, 0), (256 << 4) - 1);
 }
 
+// forward transform of one block of samples, quantisation, 128-byte store (idct.cpp:125-170 columns, :174-218 rows)
+__device__ __forceinline__ void transform_and_store(const int (&blk)[64], const int *__restrict__ invq, int16_t *dst)
+{
+  // pass over columns (idct.cpp:125-170), then rows with quantisation (:174-218)
+  int t[64];
+#pragma unroll
+  for (int col = 0; col < 8; col++) {
+    const int s[8] = {blk[col], blk[8 + col], blk[16 + col], blk[24 + col], blk[32 + col], blk[40 + col], blk[48 + col], blk[56 + col]};
+    int o[8];
+    fdct_1d(s, o);
+    t[col] = o[0];
+    t[32 + col] = o[4];
+#pragma unroll
+    for (int k = 1; k < 8; k++)
+      if (k != 4) t[k * 8 + col] = wadd(o[k], 256) >> 9; // FIXED_TO_INTERMEDIATE
+  }
+  const int dcoffset = 128 << 10; // 2^(P-1) << (preshift + 3 + 3)
+  unsigned packed[32];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int s[8] = {t[r * 8], t[r * 8 + 1], t[r * 8 + 2], t[r * 8 + 3], t[r * 8 + 4], t[r * 8 + 5], t[r * 8 + 6], t[r * 8 + 7]};
+    int o[8];
+    fdct_1d(s, o);
+    o[0] = (int)((unsigned)wsub(o[0], r == 0 ? dcoffset : 0) << 9);
+    o[4] = (int)((unsigned)o[4] << 9);
+    int qv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) qv[k] = quantize(o[k], invq[r * 8 + k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) packed[r * 4 + k] = ((unsigned)qv[2 * k] & 0xffffu) | ((unsigned)qv[2 * k + 1] << 16);
+  }
+  u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+#pragma unroll
+  for (int i = 0; i < 8; i++) d4[i] = u32x4{packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]};
+}
+
+// Interior blocks of RGB -> YCbCr frames with subsampling factors 1 or 2: the block's SX*8 x SY*8 pixels are read as
+// dwords (rows of 24 * SX bytes; the host checks that lines start dword-aligned), the bytes picked apart in registers,
+// only the block's own component computed, the box filter's division a shift (the sums are not negative).
+template <int SX, int SY>
+__device__ __forceinline__ void gather_block_fast(const uint8_t *img, int64_t row_stride, int x0, int y0, int c, int (&blk)[64])
+{
+  constexpr int ND = 6 * SX;                 // dwords per line of the block
+  constexpr int RB = 8 / (SX * SY);          // output rows per batch: 48 dwords in flight at a time, one memory round trip each
+#pragma unroll
+  for (int r0 = 0; r0 < 8; r0 += RB) {
+    unsigned dw[RB * SY][ND];
+#pragma unroll
+    for (int l = 0; l < RB * SY; l++) {
+      const unsigned *line = reinterpret_cast<const unsigned *>(img + (int64_t)(y0 + r0 * SY + l) * row_stride + (int64_t)x0 * 3);
+#pragma unroll
+      for (int i = 0; i < ND; i++) dw[l][i] = line[i];
+    }
+    __builtin_amdgcn_sched_barrier(0); // the loads of one batch together, those of the next not before this one is used up
+#pragma unroll
+    for (int rr = 0; rr < RB; rr++) {
+      int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int ly = 0; ly < SY; ly++)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+          for (int k = 0; k < SX; k++) {
+            const int j = 3 * (i * SX + k); // byte of the pixel's R inside the line
+            const unsigned *d = dw[rr * SY + ly];
+            const int r8 = (int)((d[j >> 2] >> (8 * (j & 3))) & 0xffu), g8 = (int)((d[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xffu),
+                      b8 = (int)((d[(j + 2) >> 2] >> (8 * ((j + 2) & 3))) & 0xffu);
+            acc[i] += ycc_component(c, r8, g8, b8);
+          }
+#pragma unroll
+      for (int i = 0; i < 8; i++) blk[(r0 + rr) * 8 + i] = acc[i] >> (SX * SY == 4 ? 2 : SX * SY == 2 ? 1 : 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 __global__ __launch_bounds__(256) void fdct_blocks_kernel(const ForwardArgs a)
 {
   const unsigned per_frame = a.first_block[a.ncomp];
@@ -95,6 +171,8 @@ __global__ __launch_bounds__(256) void fdct_blocks_kernel(const ForwardArgs a)
     return (int)p[c] << 4;
   };
   int blk[64];
+  // interior blocks of frames the fast kernels cover are theirs
+  if (a.fast[c] && bx < a.fast_nbx[c] && by < a.fast_nby[c]) return;
   if (sx == 1 && sy == 1) {
     // partial blocks are pre-filled with the level shift (ycbcrtrafo.cpp:100-113)
 #pragma unroll
@@ -111,7 +189,8 @@ __global__ __launch_bounds__(256) void fdct_blocks_kernel(const ForwardArgs a)
     // (downsamplerbase.cpp:141-145), a row of the block without any line stays zero (downsampler.cpp:92-95)
     const int ofs = (bx * sx) << 3;
     int y = (by * sy) << 3;
-    for (int r = 0; r < 8; r++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) { // unrolled: blk stays in registers
       int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int lines = 0;
       while (lines < sy && y < H) {
@@ -129,43 +208,39 @@ __global__ __launch_bounds__(256) void fdct_blocks_kernel(const ForwardArgs a)
       for (int i = 0; i < 8; i++) blk[r * 8 + i] = norm > 1 ? acc[i] / norm : acc[i];
     }
   }
-  // pass over columns (idct.cpp:125-170), then rows with quantisation (:174-218)
-  int t[64];
-#pragma unroll
-  for (int col = 0; col < 8; col++) {
-    const int s[8] = {blk[col], blk[8 + col], blk[16 + col], blk[24 + col], blk[32 + col], blk[40 + col], blk[48 + col], blk[56 + col]};
-    int o[8];
-    fdct_1d(s, o);
-    t[col] = o[0];
-    t[32 + col] = o[4];
-#pragma unroll
-    for (int k = 1; k < 8; k++)
-      if (k != 4) t[k * 8 + col] = wadd(o[k], 256) >> 9; // FIXED_TO_INTERMEDIATE
-  }
-  const int dcoffset = 128 << 10; // 2^(P-1) << (preshift + 3 + 3)
-  unsigned packed[32];
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const int s[8] = {t[r * 8], t[r * 8 + 1], t[r * 8 + 2], t[r * 8 + 3], t[r * 8 + 4], t[r * 8 + 5], t[r * 8 + 6], t[r * 8 + 7]};
-    int o[8];
-    fdct_1d(s, o);
-    o[0] = (int)((unsigned)wsub(o[0], r == 0 ? dcoffset : 0) << 9);
-    o[4] = (int)((unsigned)o[4] << 9);
-    int qv[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) qv[k] = quantize(o[k], a.invq[c][r * 8 + k]);
-#pragma unroll
-    for (int k = 0; k < 4; k++) packed[r * 4 + k] = ((unsigned)qv[2 * k] & 0xffffu) | ((unsigned)qv[2 * k + 1] << 16);
-  }
-  u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
-#pragma unroll
-  for (int i = 0; i < 8; i++) d4[i] = u32x4{packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]};
+  transform_and_store(blk, a.invq[c], dst);
+}
+
+// the interior blocks of component c: grid (blocks of 256 lanes over fast_nbx * fast_nby, frames)
+template <int SX, int SY>
+__global__ __launch_bounds__(256, SX * SY == 4 ? 2 : 3) void fdct_interior_kernel(const ForwardArgs a, int c)
+{
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x, frame = blockIdx.y;
+  const unsigned n = (unsigned)a.fast_nbx[c] * (unsigned)a.fast_nby[c];
+  if (gid >= n) return;
+  const int by = (int)(gid / (unsigned)a.fast_nbx[c]), bx = (int)(gid - (unsigned)by * (unsigned)a.fast_nbx[c]);
+  int16_t *dst = a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[c] + ((int64_t)by * a.bw[c] + bx) * 64;
+  const uint8_t *img = a.pixels + (int64_t)frame * a.pixel_frame_stride;
+  int blk[64];
+  gather_block_fast<SX, SY>(img, a.pixel_row_stride, (bx * SX) << 3, (by * SY) << 3, c, blk);
+  transform_and_store(blk, a.invq[c], dst);
 }
 
 int launch_forward(const ForwardArgs &a, hipStream_t stream)
 {
   const unsigned per_frame = a.first_block[a.ncomp];
   if (per_frame == 0 || a.frames < 1) return 0;
+  for (int c = 0; c < a.ncomp; c++) {
+    if (!a.fast[c]) continue;
+    const unsigned n = (unsigned)a.fast_nbx[c] * (unsigned)a.fast_nby[c];
+    if (n == 0) continue;
+    const dim3 grid((n + 255) / 256, a.frames);
+    const int key = a.subx[c] * 4 + a.suby[c];
+    if (key == 5) hipLaunchKernelGGL((fdct_interior_kernel<1, 1>), grid, dim3(256), 0, stream, a, c);
+    else if (key == 10) hipLaunchKernelGGL((fdct_interior_kernel<2, 2>), grid, dim3(256), 0, stream, a, c);
+    else if (key == 9) hipLaunchKernelGGL((fdct_interior_kernel<2, 1>), grid, dim3(256), 0, stream, a, c);
+    else hipLaunchKernelGGL((fdct_interior_kernel<1, 2>), grid, dim3(256), 0, stream, a, c);
+  }
   hipLaunchKernelGGL(fdct_blocks_kernel, dim3((per_frame + 255) / 256, a.frames), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }

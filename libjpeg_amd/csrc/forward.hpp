@@ -13,6 +13,9 @@ struct ForwardArgs {
   int16_t *coef;                  // coefficient store, the decoder's layout
   int64_t coef_frame_stride;      // int16 units
   int32_t width, height, ncomp, ycbcr, frames;
+  // interior blocks -- whole blocks inside the picture: columns < fast_nbx, rows < fast_nby -- of components with subsampling
+  // factors 1 or 2 go through fdct_interior_kernel when the lines can be read as dwords (RGB -> YCbCr frames only)
+  int32_t fast[4], fast_nbx[4], fast_nby[4];
   int32_t subx[4], suby[4];       // subsampling factors per component
   int32_t bw[4], bh[4];           // plane size in blocks (MCU padded)
   int32_t nbx[4], nby[4];         // blocks that cover samples: ceil(ceil(W / subx) / 8), ...

@@ -42,6 +42,19 @@ for sub in os.environ.get("LAYOUTS", "420,422,444").split(","):
     api.launch_reconstruct(ref, coef.data_ptr(), out.data_ptr(), 1, W * 3, H * W * 3, n, stream=stream.cuda_stream)
     torch.cuda.synchronize()
     err = (out[0].cpu().numpy().reshape(H, W, 3).astype(np.int16) - img).astype(np.float64)
-    print(f"{sub}: fdct_blocks_kernel {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px); "
+    print(f"{sub}: fdct_interior_kernel x3 + fdct_blocks_kernel {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px); "
           f"round trip through the fused decoder: PSNR {10*np.log10(255**2/np.mean(err**2)):.1f} dB", flush=True)
+# whole pipeline for one 8K picture in host memory (upload, kernels, download of the coefficients, entropy coder on the host cores)
+import time
+for sub, ri, opt in (("420", 8, False), ("420", 8, True), ("420", 0, False)):
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter(); data = d.encode(img, 85, sub, ri, opt); ts.append(time.perf_counter() - t)
+    print(f"encode one 8K {sub} picture, restart interval {ri}, {'optimised' if opt else 'Annex K'} Huffman tables: {min(ts)*1e3:.1f} ms "
+          f"= {W*H/min(ts)/1e6:.0f} Mpixel/s, {len(data)/1e6:.2f} MB", flush=True)
 d.close()
+# the reference encoder on one host core, same picture and switches
+from oracle import oracle as O
+if O.have_reference():
+    t = time.perf_counter(); ref = O.reference_encode(img, ["-bl", "-q", "85", "-s", "1x1,2x2,2x2", "-z", "8"]); dt = time.perf_counter() - t
+    print(f"reference encoder (oracle/_ref/jpeg, one core, file in and out of /dev/shm): {dt*1e3:.0f} ms = {W*H/dt/1e6:.1f} Mpixel/s, {len(ref)/1e6:.2f} MB")
