@@ -130,17 +130,24 @@ struct BitWriter {
   std::vector<uint8_t> &out;
   uint64_t acc = 0;
   int n = 0;
-  explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+  bool stuff = true;    // false: plain bits, for pieces that are merged (and stuffed) later
+  uint64_t nbits = 0;   // bits written so far
+  explicit BitWriter(std::vector<uint8_t> &o, bool stuffing = true) : out(o), stuff(stuffing) {}
   void put(unsigned bits, int len)
   {
     acc = (acc << len) | (bits & ((1u << len) - 1u));
     n += len;
+    nbits += (uint64_t)len;
     while (n >= 8) {
       const uint8_t b = (uint8_t)(acc >> (n - 8));
       out.push_back(b);
-      if (b == 0xff) out.push_back(0); // byte stuffing
+      if (b == 0xff && stuff) out.push_back(0); // byte stuffing
       n -= 8;
     }
+  }
+  void flush_zero() // raw pieces: the rest of the last byte stays zero
+  {
+    if (n) { out.push_back((uint8_t)((acc << (8 - n)) & 0xff)); n = 0; }
   }
   void flush() // one-bits up to the byte boundary
   {
@@ -230,9 +237,8 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
     hs[c] = nc > 1 ? f.hsamp[c] : 1;
     vs[c] = nc > 1 ? f.vsamp[c] : 1;
   }
-  auto walk_interval = [&](int64_t i, const EncTable *dct, const EncTable *act, BitWriter *bw, uint32_t (*dcf)[256], uint32_t (*acf)[256]) {
-    int pred[4] = {0, 0, 0, 0};
-    const int64_t m0 = i * ri, m1 = std::min(total_mcus, m0 + ri);
+  auto walk_mcus = [&](int64_t m0, int64_t m1, int (&pred)[4], const EncTable *dct, const EncTable *act, BitWriter *bw, uint32_t (*dcf)[256],
+                       uint32_t (*acf)[256]) {
     for (int64_t m = m0; m < m1; m++) {
       const int my = (int)(m / f.mcus_x), mx = (int)(m - (int64_t)my * f.mcus_x);
       for (int c = 0; c < nc; c++) {
@@ -244,6 +250,90 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
             code_block(blk, pred[c], dct[t], act[t], bw, dcf ? dcf[t] : nullptr, acf ? acf[t] : nullptr, zz);
           }
       }
+    }
+  };
+  auto walk_interval = [&](int64_t i, const EncTable *dct, const EncTable *act, BitWriter *bw, uint32_t (*dcf)[256], uint32_t (*acf)[256]) {
+    int pred[4] = {0, 0, 0, 0};
+    walk_mcus(i * ri, std::min(total_mcus, i * ri + ri), pred, dct, act, bw, dcf, acf);
+  };
+  // DC predictor of component c in front of MCU m of an interval that starts at MCU m_first: the DC of the last block of c
+  // that covers samples and is coded before m (padding blocks repeat the predictor)
+  auto pred_before = [&](int64_t m, int64_t m_first, int c) -> int {
+    for (int64_t k = m - 1; k >= m_first; k--) {
+      const int my = (int)(k / f.mcus_x), mx = (int)(k - (int64_t)my * f.mcus_x);
+      for (int by = vs[c] - 1; by >= 0; by--)
+        for (int bx = hs[c] - 1; bx >= 0; bx--) {
+          const int gx = mx * hs[c] + bx, gy = my * vs[c] + by;
+          if (gx < nbx[c] && gy < nby[c]) return coef[f.coef_offset[c] + ((int64_t)gy * f.blocks_w[c] + gx) * 64];
+        }
+    }
+    return 0;
+  };
+  // A long interval on several threads: pieces of whole MCUs are coded as plain bit strings from their predictors, put
+  // together at their bit offsets (bytes that belong to one piece in parallel, the few bytes shared by two pieces
+  // afterwards), padded with one-bits and byte-stuffed.
+  auto code_interval_in_pieces = [&](int64_t i, int pieces, const EncTable *dct, const EncTable *act, std::vector<uint8_t> &out) {
+    const int64_t m_first = i * ri, m_last = std::min(total_mcus, m_first + ri), count = m_last - m_first;
+    pieces = (int)std::max<int64_t>(1, std::min<int64_t>(pieces, count / 64));
+    std::vector<std::vector<uint8_t>> raw((size_t)pieces);
+    std::vector<uint64_t> bits((size_t)pieces + 1, 0);
+    parallel_for(std::min(pieces, threads), [&](int w) {
+      for (int p = w; p < pieces; p += std::min(pieces, threads)) {
+        const int64_t a0 = m_first + count * p / pieces, a1 = m_first + count * (p + 1) / pieces;
+        int pred[4] = {0, 0, 0, 0};
+        for (int c = 0; c < nc; c++) pred[c] = pred_before(a0, m_first, c);
+        raw[(size_t)p].reserve((size_t)(a1 - a0) * 32);
+        BitWriter bw(raw[(size_t)p], false);
+        walk_mcus(a0, a1, pred, dct, act, &bw, nullptr, nullptr);
+        bw.flush_zero();
+        bits[(size_t)p + 1] = bw.nbits;
+        raw[(size_t)p].push_back(0); // one byte of slack for the shifted reads below
+        raw[(size_t)p].push_back(0);
+      }
+    });
+    for (int p = 0; p < pieces; p++) bits[(size_t)p + 1] += bits[(size_t)p];
+    const uint64_t total = bits[(size_t)pieces];
+    std::vector<uint8_t> plain((size_t)((total + 7) >> 3), 0);
+    parallel_for(std::min(pieces, threads), [&](int w) {
+      for (int p = w; p < pieces; p += std::min(pieces, threads)) {
+        const uint64_t b0 = bits[(size_t)p], b1 = bits[(size_t)p + 1];
+        const uint8_t *src = raw[(size_t)p].data();
+        const uint64_t j0 = (b0 + 7) >> 3, j1 = b1 >> 3; // output bytes made of this piece's bits only
+        if (j1 <= j0) continue;
+        const uint64_t q = 8 * j0 - b0; // piece-local bit position of output byte j0: 0..7
+        const unsigned sh = (unsigned)(q & 7);
+        const uint8_t *s0 = src + (q >> 3);
+        if (sh == 0) memcpy(plain.data() + j0, s0, (size_t)(j1 - j0));
+        else
+          for (uint64_t j = j0; j < j1; j++, s0++) plain[(size_t)j] = (uint8_t)((s0[0] << sh) | (s0[1] >> (8 - sh)));
+      }
+    });
+    auto bit_at = [&](uint64_t b) -> unsigned { // bit b of the merged string
+      const size_t p = (size_t)(std::upper_bound(bits.begin(), bits.end(), b) - bits.begin()) - 1;
+      const uint64_t l = b - bits[p];
+      return (raw[p][(size_t)(l >> 3)] >> (7 - (l & 7))) & 1u;
+    };
+    for (int p = 0; p <= pieces; p++) { // the bytes around the piece boundaries (and the last, partial one)
+      const uint64_t b = bits[(size_t)p];
+      for (uint64_t j = (b >> 3); j <= (b >> 3) + 1 && j < plain.size(); j++) {
+        if (p > 0 && p < pieces && (b & 7) == 0 && j != (b >> 3)) continue;
+        unsigned v = 0;
+        for (int k = 0; k < 8; k++) {
+          const uint64_t gb = 8 * j + (uint64_t)k;
+          v = (v << 1) | (gb < total ? bit_at(gb) : 1u); // one-bits pad the last byte
+        }
+        plain[(size_t)j] = (uint8_t)v;
+      }
+    }
+    out.clear();
+    out.reserve(plain.size() + plain.size() / 64 + 16);
+    const uint8_t *q = plain.data(), *end = q + plain.size();
+    while (q < end) { // byte stuffing: a zero byte behind every 0xFF
+      const uint8_t *ff = (const uint8_t *)memchr(q, 0xff, (size_t)(end - q));
+      if (!ff) { out.insert(out.end(), q, end); break; }
+      out.insert(out.end(), q, ff + 1);
+      out.push_back(0);
+      q = ff + 1;
     }
   };
   EncTable dct[2], act[2];
@@ -272,6 +362,10 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
   // entropy coded segments, one buffer per restart interval
   std::vector<std::vector<uint8_t>> seg((size_t)nint);
   const int tasks = (int)std::min<int64_t>(nint, (int64_t)threads * 8);
+  if (nint < threads && threads > 1 && ri >= 256) { // few, long intervals: parallelism inside them
+    const int pieces = (int)std::min<int64_t>(4096, ((int64_t)threads * 4 + nint - 1) / nint);
+    for (int64_t i = 0; i < nint; i++) code_interval_in_pieces(i, pieces, dct, act, seg[(size_t)i]);
+  } else
   parallel_for(std::min(threads, tasks), [&](int w) {
     const int workers = std::min(threads, tasks);
     for (int64_t i = w; i < nint; i += workers) {

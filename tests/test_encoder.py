@@ -58,6 +58,27 @@ def test_entropy_coder_round_trips_and_others_decode_it(oracle, w, h, hs, vs, ri
         assert np.array_equal(oracle.reference_decode(data), oracle.decode(data))
 
 
+@pytest.mark.parametrize("w,h,hs,vs,ri", [(640, 360, (2, 1, 1), (2, 1, 1), 0), (1000, 700, (1, 1, 1), (1, 1, 1), 0), (1023, 517, (2, 1, 1), (1, 1, 1), 600),
+                                         (2048, 1024, (2, 1, 1), (2, 1, 1), 0)])
+def test_long_intervals_coded_in_pieces_give_the_serial_stream(oracle, w, h, hs, vs, ri):
+    """Scans without (or with few) restart markers are coded in pieces of whole MCUs on several threads and merged at bit
+    granularity: the stream must be byte for byte what one thread writes."""
+    rng = np.random.default_rng(w + h)
+    img = synth.synth_image(w, h, 11) if w != 1000 else rng.integers(0, 256, (h, w, 3)).astype(np.uint8)  # noise: many 0xFF bytes
+    quant = [rng.integers(1, 12, 64), rng.integers(1, 20, 64)]
+    info = api.frame_layout(w, h, 3, hs, vs, quant)
+    planes = oracle.forward(_oj_info(oracle, info, w, h, quant), img, 1)
+    coef = np.concatenate([p.reshape(-1) for p in planes]).astype(np.int16)
+    for opt in (False, True):
+        serial = api.encode_coefficients(info, coef, ri, opt, threads=1)
+        for th in (2, 7, 16):
+            assert api.encode_coefficients(info, coef, ri, opt, threads=th) == serial, (opt, th)
+    _, back = oracle.decode_coefficients(serial)
+    for c in range(3):
+        nby, nbx = (-(-h // info.suby[c]) + 7) // 8, (-(-w // info.subx[c]) + 7) // 8
+        assert np.array_equal(back[c][:nby, :nbx], planes[c][:nby, :nbx])
+
+
 def test_grey_and_extreme_coefficients(oracle):
     rng = np.random.default_rng(2)
     img = rng.integers(0, 256, (40, 56)).astype(np.uint8)
