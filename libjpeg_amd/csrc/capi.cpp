@@ -540,7 +540,6 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   // (measured on 8K 4:2:0: 259200 intervals -> 64, 64800 -> 16, 32400 -> 8, 8100 -> 2..4)
   a.lanes = 64;
   while (a.lanes > 1 && total_intervals / a.lanes < 2048) a.lanes >>= 1;
-  if (const char *e = getenv("MIJPEG_HUFF_DEBUG")) a.debug = atoi(e);
   if (const char *e = getenv("MIJPEG_HUFF_LANES")) { // tuning
     const int l = atoi(e);
     if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) a.lanes = l;

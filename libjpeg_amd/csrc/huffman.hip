@@ -289,16 +289,13 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
       for (int by = 0; by < v; by++)
         for (int bx = 0; bx < h; bx++) {
           uint32_t blk = 0; // block number + 1
-          if (live && !err && !(a.debug & 8)) {
+          if (live && !err) {
             err = dev_block(br, dc, ac, aux->zq[k], slot, swz16, pred[k], qmax[k]);
             if (!err) blk = comp_base + (uint32_t)(my * v + by) * (uint32_t)a.bw[k] + (uint32_t)(mx * h + bx) + 1u;
           }
           // top the ring up with what was requested a block ago
-          if (!(a.debug & 4)) {
           if (decoding && pend_at == br.fill && br.room()) br.commit(pend0);
           if (decoding && pend_at + 16 == br.fill && br.room()) br.commit(pend1);
-          }
-          if (!(a.debug & 2)) {
           if (lane < L) blkno[lane] = blk;
           wave_lds_sync();
           // the wave writes the L blocks out in 16-byte chunks (full 128-byte lines) and clears the slots
@@ -308,16 +305,13 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
             u32x4 *src = reinterpret_cast<u32x4 *>(stage + sl * 128 + ((ch ^ (sl & 7)) << 4));
             const u32x4 val = *src;
             *src = u32x4{0, 0, 0, 0};
-            if (b && !(a.debug & 1)) *reinterpret_cast<u32x4 *>(coef + ((size_t)(b - 1) << 6) + ch * 8) = val;
+            if (b) *reinterpret_cast<u32x4 *>(coef + ((size_t)(b - 1) << 6) + ch * 8) = val;
           }
           wave_lds_sync();
-          }
           // request the next 32 bytes; they are not looked at before the next block is done
-          if (!(a.debug & 4)) {
           pend_at = br.fill;
           pend0 = br.fetch(pend_at);
           pend1 = br.fetch(pend_at + 16);
-          }
         }
     }
   }

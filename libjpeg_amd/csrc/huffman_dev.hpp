@@ -63,7 +63,7 @@ struct HuffScanArgs {
   int64_t coef_off[4];           // plane offsets inside an image's coefficient store
   int32_t dc_tab[4], ac_tab[4];  // indices into the image's tables
   int32_t ntables;
-  int32_t debug;                 // experiments only (MIJPEG_HUFF_DEBUG)
+  int32_t reserved;
   int32_t lanes;                 // active lanes per wave (power of two, 1..64): fewer lanes = more waves, less divergence
   int32_t waves_per_group;
   const uint8_t *tables;         // device: per image ntables tables followed by one HuffDevAux

@@ -325,7 +325,7 @@ __device__ __forceinline__ void fetch_blocks16(u32x4 (&rows)[8], u32x4 *stage, i
 // distributive) -- then the ordinary second pass on the eight results.  FAST arithmetic, no level shift.
 __device__ __forceinline__ void dequant_idct_column(const u32x4 (&rows)[8], const int *__restrict__ q, bool last, int (&col)[8])
 {
-  constexpr int E0 = 512, E2 = FIX9(0.541196100) + FIX9(0.765366865), E4 = 512, E6 = FIX9(0.541196100);
+  constexpr int E2 = FIX9(0.541196100) + FIX9(0.765366865), E4 = 512, E6 = FIX9(0.541196100); // (s0 enters shifted by 9)
   constexpr int O1 = FIX9(1.501321110) - FIX9(0.899976223) - FIX9(0.390180644) + FIX9(1.175875602), O3 = FIX9(1.175875602),
                 O5 = FIX9(1.175875602) - FIX9(0.390180644), O7 = FIX9(1.175875602) - FIX9(0.899976223);
 #pragma unroll
@@ -696,7 +696,7 @@ __device__ __forceinline__ unsigned tap13_pk(unsigned a, unsigned b, short r)
   return __builtin_bit_cast(unsigned, t);
 }
 
-template <int MINW, int DBG = 0>
+template <int MINW>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420_CPITCH];
@@ -761,7 +761,6 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
             cp[2 * (pr * F420_CPITCH + 68)] = (short)v[r * 8 + 0];
           } else {
             short *dst = cp + 2 * (pr * F420_CPITCH + 8 * cbx - 4);
-            if (DBG == 1) { dst[0] = (short)(v[r * 8] + v[r * 8 + 1] + v[r * 8 + 2] + v[r * 8 + 3] + v[r * 8 + 4] + v[r * 8 + 5] + v[r * 8 + 6] + v[r * 8 + 7]); continue; }
 #pragma unroll
             for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
           }
@@ -1718,9 +1717,11 @@ template <int LAYOUT>
 __device__ __forceinline__ void upsample_plane_line(const GenericArgs &a, int p, int comp, int frame, int X0, int Y, int (&o)[8])
 {
   const int *plane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[p];
-  if (LAYOUT == LAYOUT_ANY) upsample_line_any(plane, a.bw[p] * 8, a.cw[p], a.ch[p], a.subx[p], a.suby[p], X0, Y, o);
-  else if (comp == 0) upsample_line_t<1, 1>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
-  else upsample_line_t<LAYOUT / 4, LAYOUT % 4>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
+  if constexpr (LAYOUT == LAYOUT_ANY) upsample_line_any(plane, a.bw[p] * 8, a.cw[p], a.ch[p], a.subx[p], a.suby[p], X0, Y, o);
+  else {
+    if (comp == 0) upsample_line_t<1, 1>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
+    else upsample_line_t<LAYOUT / 4, LAYOUT % 4>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
+  }
 }
 
 // Exact (reference LONG / QUAD) colour stage for any precision: L matrix at FIX_BITS = 13 on samples with
@@ -1876,15 +1877,9 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
   if (total == 0) return 0;
-  static const int variant = getenv("MIJPEG_F420_VARIANT") ? atoi(getenv("MIJPEG_F420_VARIANT")) : 0; // tuning aid
-  if (!fast)
-    hipLaunchKernelGGL((fused420_kernel<false, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else if (variant == 1)
-    hipLaunchKernelGGL((fused420_kernel<true, 3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else if (variant == 2)
-    hipLaunchKernelGGL((fused420_kernel<true, 4>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else
-    hipLaunchKernelGGL((fused420_kernel<true, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  // two workgroups per CU for both flavours (132 / 194 VGPRs)
+  if (!fast) hipLaunchKernelGGL((fused420_kernel<false, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused420_kernel<true, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1892,15 +1887,8 @@ int launch_fused420p(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
   if (total == 0) return 0;
-  static const int variant = getenv("MIJPEG_F420P_VARIANT") ? atoi(getenv("MIJPEG_F420P_VARIANT")) : 0; // tuning aid
-  if (variant == 1)
-    hipLaunchKernelGGL((fused420p_kernel<4>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else if (variant == 2)
-    hipLaunchKernelGGL((fused420p_kernel<2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else if (variant == 9) // experiment: one LDS store per chroma line instead of eight (wrong pixels)
-    hipLaunchKernelGGL((fused420p_kernel<3, 1>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else
-    hipLaunchKernelGGL((fused420p_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  // three workgroups per CU (109 VGPRs, 27 KB LDS): two or four measured slower (profiles/r01/summary_fused420p.txt)
+  hipLaunchKernelGGL((fused420p_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
