@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "host_decoder.hpp"
@@ -164,12 +165,15 @@ inline int category(int v)
 }
 
 // One block: sequentialscan.cpp EncodeBlock.  Either codes it (bw != null) or counts its symbols.
-inline void code_block(const int16_t *blk, int &pred, const EncTable &dc, const EncTable &ac, BitWriter *bw, uint32_t *dcfreq, uint32_t *acfreq,
+// Returns false when a value does not fit the 8-bit processes (DC differences of more than 11, AC coefficients of more
+// than 10 bits: Tables F.1 / F.2), for which neither the Annex K tables nor SOF0 have room.
+inline bool code_block(const int16_t *blk, int &pred, const EncTable &dc, const EncTable &ac, BitWriter *bw, uint32_t *dcfreq, uint32_t *acfreq,
                        const uint8_t *zz)
 {
   const int diff = (blk ? blk[0] : pred) - pred;
   pred += diff;
   int s = category(diff);
+  if (s > 11) return false;
   if (bw) {
     bw->put(dc.code[s], dc.len[s]);
     if (s) bw->put((unsigned)(diff < 0 ? diff - 1 : diff), s);
@@ -185,6 +189,7 @@ inline void code_block(const int16_t *blk, int &pred, const EncTable &dc, const 
         run -= 16;
       }
       s = category(v);
+      if (s > 10) return false;
       const int sym = (run << 4) | s;
       if (bw) {
         bw->put(ac.code[sym], ac.len[sym]);
@@ -197,6 +202,7 @@ inline void code_block(const int16_t *blk, int &pred, const EncTable &dc, const 
     if (bw) bw->put(ac.code[0], ac.len[0]);
     else acfreq[0]++;
   }
+  return true;
 }
 
 void put16(std::vector<uint8_t> &o, unsigned v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
@@ -237,6 +243,7 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
     hs[c] = nc > 1 ? f.hsamp[c] : 1;
     vs[c] = nc > 1 ? f.vsamp[c] : 1;
   }
+  std::atomic<bool> out_of_range{false};
   auto walk_mcus = [&](int64_t m0, int64_t m1, int (&pred)[4], const EncTable *dct, const EncTable *act, BitWriter *bw, uint32_t (*dcf)[256],
                        uint32_t (*acf)[256]) {
     for (int64_t m = m0; m < m1; m++) {
@@ -247,7 +254,7 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
           for (int bx = 0; bx < hs[c]; bx++) {
             const int gx = mx * hs[c] + bx, gy = my * vs[c] + by;
             const int16_t *blk = (gx < nbx[c] && gy < nby[c]) ? coef + f.coef_offset[c] + ((int64_t)gy * f.blocks_w[c] + gx) * 64 : nullptr;
-            code_block(blk, pred[c], dct[t], act[t], bw, dcf ? dcf[t] : nullptr, acf ? acf[t] : nullptr, zz);
+            if (!code_block(blk, pred[c], dct[t], act[t], bw, dcf ? dcf[t] : nullptr, acf ? acf[t] : nullptr, zz)) out_of_range.store(true, std::memory_order_relaxed);
           }
       }
     }
@@ -375,6 +382,7 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
       bw.flush();
     }
   });
+  if (out_of_range.load()) return MIJPEG_ERR_OVERFLOW_PARAMETER; // coefficients outside what an 8-bit frame can hold
   // the stream
   std::vector<uint8_t> o;
   size_t ecs = 0;

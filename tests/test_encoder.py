@@ -118,3 +118,18 @@ def test_quality_tables_are_the_reference_encoders(oracle):
         assert list(info.tq)[:3] == [0, 0, 0]
         seen += 1
     assert seen >= 5
+
+
+def test_coefficients_outside_the_8_bit_range_are_refused():
+    info = api.frame_layout(16, 16, 1, (1,), (1,), [np.ones(64, int)], ycbcr=0)
+    coef = np.zeros(int(info.coef_count), np.int16)
+    coef[5] = 1024  # 11 bits: more than an AC coefficient of an 8-bit frame can have
+    with pytest.raises(api.MijpegError):
+        api.encode_coefficients(info, coef)
+    coef[5] = 1023
+    coef[0] = 2047
+    assert api.encode_coefficients(info, coef)[:2] == b"\xff\xd8"
+    coef[0] = 2048  # DC difference of 12 bits
+    with pytest.raises(api.MijpegError):
+        api.encode_coefficients(info, coef, optimize=True)
+
