@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""One-off differential campaign (longer than the test suite wants to be): N seeded random streams through the decoder object
+(host and device entropy decoding, every kernel family) against the oracle, and random pictures through the encoder pipeline
+against the oracle's forward restatement.  Prints a summary; exit code 1 on any difference."""
+import collections
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from libjpeg_amd import api, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+N = int(os.environ.get("N", "1200"))
+rng = np.random.default_rng(int(os.environ.get("SEED", "777")))
+d = api.Decoder(0)
+kernels, entropy, skipped, bad = collections.Counter(), collections.Counter(), 0, 0
+t0 = time.time()
+for t in range(N):
+    big = rng.integers(0, 12) == 0
+    w, h = (int(rng.integers(700, 2600)), int(rng.integers(500, 1600))) if big else (int(rng.integers(1, 700)), int(rng.integers(1, 500)))
+    sub = ["444", "422", "420", "gray"][int(rng.integers(0, 4))]
+    q = int(rng.choice([3, 20, 50, 75, 85, 95, 100]))
+    dri = int(rng.choice([0, 0, 1, 3, 8, 40]))
+    prog, opt = bool(rng.integers(0, 6) == 0), bool(rng.integers(0, 2))
+    img = synth.synth_image(w, h, 5000 + t, channels=1 if sub == "gray" else 3)
+    style = int(rng.integers(0, 4))
+    if style == 0:
+        img = rng.integers(0, 256, img.shape).astype(np.uint8)
+    elif style == 1:  # saturated graphics
+        img = (img > 128).astype(np.uint8) * 255
+    try:
+        data = synth.encode_jpeg(img, q, sub if sub != "gray" else "444", restart_mcus=dri, optimize=opt, progressive=prog)
+    except OSError:
+        skipped += 1
+        continue
+    exp = O.decode(data)
+    for mode in ("host", "auto"):
+        f = d.read(data, threads=int(rng.integers(1, 17)), entropy=mode)
+        got = d.reconstruct()
+        kernels[api.kernel_name(f)] += 1
+        entropy[d.entropy_used] += 1
+        if got.shape != exp.shape or not np.array_equal(got, exp):
+            bad += 1
+            print("DECODE DIFFERENCE", t, w, h, sub, q, dri, prog, opt, mode, flush=True)
+    # encoder direction on the same picture (colour pictures only, the layouts the CLI offers)
+    if sub != "gray" and t % 3 == 0:
+        esub = ["444", "420", "422", "440", "411"][int(rng.integers(0, 5))]
+        ri = int(rng.choice([0, 0, 2, 16]))
+        enc = d.encode(img, q, esub, ri, opt)
+        info, planes = O.decode_coefficients(enc)
+        fwd = O.forward(info, img, 1)
+        for c in range(3):
+            nby, nbx = (info.ch[c] + 7) // 8, (info.cw[c] + 7) // 8
+            if not np.array_equal(planes[c][:nby, :nbx], fwd[c][:nby, :nbx]):
+                bad += 1
+                print("ENCODE DIFFERENCE", t, w, h, esub, q, ri, opt, c, flush=True)
+        d.read(enc, entropy="auto")
+        if not np.array_equal(d.reconstruct(), O.decode(enc)):
+            bad += 1
+            print("ENCODE->DECODE DIFFERENCE", t, w, h, esub, q, ri, flush=True)
+        kernels["(encoded streams)"] += 1
+print(f"{N} random streams ({skipped} refused by the test encoder), {time.time() - t0:.0f} s: {bad} differences")
+print("reconstruction kernels:", dict(kernels))
+print("entropy decoder used:", dict(entropy))
+sys.exit(1 if bad else 0)
