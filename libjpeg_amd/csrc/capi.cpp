@@ -1269,6 +1269,8 @@ void mijpeg_quality_tables(int quality, uint16_t luma[64], uint16_t chroma[64])
 int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
                         int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint8_t **stream, size_t *size)
 {
+  using clk = std::chrono::steady_clock;
+  const auto t_begin = clk::now();
   if (!d || !pixels || !stream || !size || (components != 1 && components != 3) || row_stride < (int64_t)width * components)
     return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "decoder was created without a device");
@@ -1295,20 +1297,53 @@ int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width,
   const size_t px_bytes = (size_t)row_stride * (size_t)height, coef_bytes = (size_t)f.coef_count * sizeof(int16_t);
   rc = ensure_dev(d, (void **)&d->enc_dev, &d->enc_cap, px_bytes + 256 + coef_bytes);
   if (rc) return rc;
-  std::vector<int16_t> coef((size_t)f.coef_count);
   int16_t *coef_dev = (int16_t *)(d->enc_dev + ((px_bytes + 255) & ~(size_t)255));
-  HIP_TRY(d, hipMemcpyAsync(d->enc_dev, pixels, px_bytes, hipMemcpyHostToDevice, d->stream));
+  // pinned staging: [pixels][coefficients].  The picture goes up in bands, each gathered into pinned memory by the pool
+  // threads while the DMA of the previous band runs; the coefficients come down into pinned memory the coder reads.
+  const size_t stage_bytes = ((px_bytes + 255) & ~(size_t)255) + coef_bytes;
+  if (d->stage_cap < stage_bytes) {
+    if (d->stage_host) (void)hipHostFree(d->stage_host);
+    d->stage_host = nullptr;
+    d->stage_cap = 0;
+    HIP_TRY(d, hipHostMalloc((void **)&d->stage_host, stage_bytes, hipHostMallocDefault));
+    d->stage_cap = stage_bytes;
+  }
+  int16_t *coef_host = (int16_t *)(d->stage_host + ((px_bytes + 255) & ~(size_t)255));
+  {
+    const size_t band = std::max<size_t>((size_t)8 << 20, (px_bytes + 7) / 8) & ~(size_t)255;
+    for (size_t b0 = 0; b0 < px_bytes; b0 += band) {
+      const size_t len = std::min(band, px_bytes - b0);
+      const size_t pieces = (len + ((size_t)1 << 20) - 1) >> 20;
+      const int workers = (int)std::min<size_t>(pieces, (size_t)std::min(default_threads(), 16));
+      parallel_for(workers, [&](int w) {
+        for (size_t k = (size_t)w; k < pieces; k += (size_t)workers) {
+          const size_t o = b0 + (k << 20), n = std::min<size_t>((size_t)1 << 20, b0 + len - o);
+          memcpy(d->stage_host + o, pixels + o, n);
+        }
+      });
+      HIP_TRY(d, hipMemcpyAsync(d->enc_dev + b0, d->stage_host + b0, len, hipMemcpyHostToDevice, d->stream));
+    }
+  }
   b.pixels_dev = d->enc_dev;
   b.pixel_row_stride = row_stride;
   b.pixel_frame_stride = (int64_t)px_bytes;
   b.coef_dev = coef_dev;
   b.coef_frame_stride = f.coef_count;
   b.frames = 1;
+  const auto t_up = clk::now(); // uploads enqueued (the gathering is synchronous)
   rc = mijpeg_launch_forward(&b, d->stream);
   if (rc) return set_error(d, rc, "forward kernel launch failed");
-  HIP_TRY(d, hipMemcpyAsync(coef.data(), coef_dev, coef_bytes, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(d, hipStreamSynchronize(d->stream));
-  rc = mijpeg_encode_coefficients(&f, coef.data(), restart_interval, optimize, 0, stream, size);
+  const auto t_kernel = clk::now();
+  HIP_TRY(d, hipMemcpyAsync(coef_host, coef_dev, coef_bytes, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  const auto t_down = clk::now();
+  rc = mijpeg_encode_coefficients(&f, coef_host, restart_interval, optimize, 0, stream, size);
+  // mijpeg_last_timing: gather + upload, kernels (incl. the rest of the upload), download, entropy coder
+  d->timing[0] = std::chrono::duration<double>(t_up - t_begin).count();
+  d->timing[1] = std::chrono::duration<double>(t_kernel - t_up).count();
+  d->timing[2] = std::chrono::duration<double>(t_down - t_kernel).count();
+  d->timing[3] = std::chrono::duration<double>(clk::now() - t_down).count();
   if (rc) return set_error(d, rc, "entropy coding failed");
   return MIJPEG_OK;
 }

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <vector>
 
 #include "host_decoder.hpp"
@@ -127,41 +128,55 @@ void optimal_table(EncTable &t, const uint32_t freq_in[256])
   t.derive();
 }
 
+// Bit writer into a caller-provided buffer that is large enough for the worst case (see worst_case_bytes): 64-bit
+// accumulator, four bytes at a time; a word that holds an 0xFF byte goes byte by byte through the stuffing.
 struct BitWriter {
-  std::vector<uint8_t> &out;
+  uint8_t *p;           // next byte to write
+  uint8_t *const begin;
   uint64_t acc = 0;
   int n = 0;
-  bool stuff = true;    // false: plain bits, for pieces that are merged (and stuffed) later
+  const bool stuff;     // false: plain bits, for pieces that are merged (and stuffed) later
   uint64_t nbits = 0;   // bits written so far
-  explicit BitWriter(std::vector<uint8_t> &o, bool stuffing = true) : out(o), stuff(stuffing) {}
-  void put(unsigned bits, int len)
+  explicit BitWriter(uint8_t *buf, bool stuffing = true) : p(buf), begin(buf), stuff(stuffing) {}
+  inline void byte(uint8_t b)
+  {
+    *p++ = b;
+    if (b == 0xff && stuff) *p++ = 0; // byte stuffing
+  }
+  inline void put(unsigned bits, int len)
   {
     acc = (acc << len) | (bits & ((1u << len) - 1u));
     n += len;
     nbits += (uint64_t)len;
-    while (n >= 8) {
-      const uint8_t b = (uint8_t)(acc >> (n - 8));
-      out.push_back(b);
-      if (b == 0xff && stuff) out.push_back(0); // byte stuffing
-      n -= 8;
+    if (n >= 32) {
+      const uint32_t w = (uint32_t)(acc >> (n - 32));
+      n -= 32;
+      if (stuff && ((w & ~(w + 0x01010101u)) & 0x80808080u)) { // some byte is 0xFF
+        byte((uint8_t)(w >> 24)); byte((uint8_t)(w >> 16)); byte((uint8_t)(w >> 8)); byte((uint8_t)w);
+      } else {
+        p[0] = (uint8_t)(w >> 24); p[1] = (uint8_t)(w >> 16); p[2] = (uint8_t)(w >> 8); p[3] = (uint8_t)w;
+        p += 4;
+      }
     }
+  }
+  void drain() { while (n >= 8) { byte((uint8_t)(acc >> (n - 8))); n -= 8; } }
+  void flush() // one-bits up to the byte boundary
+  {
+    drain();
+    if (n) { byte((uint8_t)(((acc << (8 - n)) | ((1u << (8 - n)) - 1u)) & 0xff)); n = 0; }
   }
   void flush_zero() // raw pieces: the rest of the last byte stays zero
   {
-    if (n) { out.push_back((uint8_t)((acc << (8 - n)) & 0xff)); n = 0; }
+    drain();
+    if (n) { byte((uint8_t)((acc << (8 - n)) & 0xff)); n = 0; }
   }
-  void flush() // one-bits up to the byte boundary
-  {
-    if (n) put((1u << (8 - n)) - 1u, 8 - n);
-  }
+  size_t size() const { return (size_t)(p - begin); }
 };
 
 inline int category(int v)
 {
-  unsigned a = (unsigned)(v < 0 ? -v : v);
-  int s = 0;
-  while (a) { s++; a >>= 1; }
-  return s;
+  const unsigned a = (unsigned)(v < 0 ? -v : v);
+  return a ? 32 - __builtin_clz(a) : 0;
 }
 
 // One block: sequentialscan.cpp EncodeBlock.  Either codes it (bw != null) or counts its symbols.
@@ -259,6 +274,11 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
       }
     }
   };
+  int blocks_per_mcu = 0;
+  for (int c = 0; c < nc; c++) blocks_per_mcu += hs[c] * vs[c];
+  // bytes `mcus` MCUs can take at most: 63 AC coefficients of 16 + 10 bits and a DC difference of 16 + 11 bits per block,
+  // every byte stuffed, plus slack for the word-wise writer
+  auto worst_case_bytes = [&](int64_t mcus) -> size_t { return (size_t)mcus * (size_t)blocks_per_mcu * 420 + 64; };
   auto walk_interval = [&](int64_t i, const EncTable *dct, const EncTable *act, BitWriter *bw, uint32_t (*dcf)[256], uint32_t (*acf)[256]) {
     int pred[4] = {0, 0, 0, 0};
     walk_mcus(i * ri, std::min(total_mcus, i * ri + ri), pred, dct, act, bw, dcf, acf);
@@ -289,11 +309,12 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
         const int64_t a0 = m_first + count * p / pieces, a1 = m_first + count * (p + 1) / pieces;
         int pred[4] = {0, 0, 0, 0};
         for (int c = 0; c < nc; c++) pred[c] = pred_before(a0, m_first, c);
-        raw[(size_t)p].reserve((size_t)(a1 - a0) * 32);
-        BitWriter bw(raw[(size_t)p], false);
+        std::unique_ptr<uint8_t[]> scratch(new uint8_t[worst_case_bytes(a1 - a0)]); // not zeroed: only what is written gets touched
+        BitWriter bw(scratch.get(), false);
         walk_mcus(a0, a1, pred, dct, act, &bw, nullptr, nullptr);
         bw.flush_zero();
         bits[(size_t)p + 1] = bw.nbits;
+        raw[(size_t)p].assign(scratch.get(), scratch.get() + bw.size());
         raw[(size_t)p].push_back(0); // one byte of slack for the shifted reads below
         raw[(size_t)p].push_back(0);
       }
@@ -367,27 +388,45 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
     set_table(act[1], K3_AC_C_COUNTS, K3_AC_C_VALUES, 162);
   }
   // entropy coded segments, one buffer per restart interval
-  std::vector<std::vector<uint8_t>> seg((size_t)nint);
-  const int tasks = (int)std::min<int64_t>(nint, (int64_t)threads * 8);
+  // the entropy coded data: `parts` buffers that follow each other in the stream (RSTn markers included)
+  std::vector<std::unique_ptr<uint8_t[]>> part_mem;
+  std::vector<std::vector<uint8_t>> part_vec;
+  std::vector<const uint8_t *> part_ptr;
+  std::vector<size_t> part_len;
   if (nint < threads && threads > 1 && ri >= 256) { // few, long intervals: parallelism inside them
     const int pieces = (int)std::min<int64_t>(4096, ((int64_t)threads * 4 + nint - 1) / nint);
-    for (int64_t i = 0; i < nint; i++) code_interval_in_pieces(i, pieces, dct, act, seg[(size_t)i]);
-  } else
-  parallel_for(std::min(threads, tasks), [&](int w) {
-    const int workers = std::min(threads, tasks);
-    for (int64_t i = w; i < nint; i += workers) {
-      seg[(size_t)i].reserve(1024);
-      BitWriter bw(seg[(size_t)i]);
-      walk_interval(i, dct, act, &bw, nullptr, nullptr);
-      bw.flush();
+    part_vec.resize((size_t)nint);
+    for (int64_t i = 0; i < nint; i++) {
+      code_interval_in_pieces(i, pieces, dct, act, part_vec[(size_t)i]);
+      if (i + 1 < nint) { part_vec[(size_t)i].push_back(0xff); part_vec[(size_t)i].push_back((uint8_t)(0xd0 + (i & 7))); }
+      part_ptr.push_back(part_vec[(size_t)i].data());
+      part_len.push_back(part_vec[(size_t)i].size());
     }
-  });
+  } else { // every worker codes a run of whole intervals, one behind the other, into one buffer
+    const int workers = (int)std::max<int64_t>(1, std::min<int64_t>(threads, nint));
+    part_mem.resize((size_t)workers);
+    part_ptr.resize((size_t)workers);
+    part_len.resize((size_t)workers);
+    parallel_for(workers, [&](int w) {
+      const int64_t i0 = nint * w / workers, i1 = nint * (w + 1) / workers;
+      const int64_t mcus = std::min(total_mcus, i1 * ri) - i0 * ri;
+      part_mem[(size_t)w].reset(new uint8_t[worst_case_bytes(mcus) + (size_t)(i1 - i0) * 4]); // not zeroed: only what is written gets touched
+      uint8_t *q = part_mem[(size_t)w].get();
+      for (int64_t i = i0; i < i1; i++) {
+        BitWriter bw(q);
+        walk_interval(i, dct, act, &bw, nullptr, nullptr);
+        bw.flush();
+        q += bw.size();
+        if (i + 1 < nint) { *q++ = 0xff; *q++ = (uint8_t)(0xd0 + (i & 7)); }
+      }
+      part_ptr[(size_t)w] = part_mem[(size_t)w].get();
+      part_len[(size_t)w] = (size_t)(q - part_mem[(size_t)w].get());
+    });
+  }
   if (out_of_range.load()) return MIJPEG_ERR_OVERFLOW_PARAMETER; // coefficients outside what an 8-bit frame can hold
   // the stream
   std::vector<uint8_t> o;
-  size_t ecs = 0;
-  for (auto &s : seg) ecs += s.size() + 2;
-  o.reserve(ecs + 1024);
+  o.reserve(2048);
   o.push_back(0xff); o.push_back(0xd8);
   bool used[4] = {false, false, false, false};
   for (int c = 0; c < nc; c++) used[f.quant_index[c]] = true;
@@ -431,15 +470,22 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
     o.push_back((uint8_t)(c ? 0x11 : 0x00));
   }
   o.push_back(0); o.push_back(63); o.push_back(0);
-  for (int64_t i = 0; i < nint; i++) {
-    o.insert(o.end(), seg[(size_t)i].begin(), seg[(size_t)i].end());
-    if (i + 1 < nint) { o.push_back(0xff); o.push_back((uint8_t)(0xd0 + (i & 7))); }
-  }
-  o.push_back(0xff); o.push_back(0xd9);
-  uint8_t *p = (uint8_t *)malloc(o.size());
+  // header so far, then the parts at their offsets (copied in parallel), EOI
+  const size_t nparts = part_ptr.size();
+  std::vector<size_t> at(nparts + 1);
+  at[0] = o.size();
+  for (size_t k = 0; k < nparts; k++) at[k + 1] = at[k] + part_len[k];
+  const size_t total_size = at[nparts] + 2;
+  uint8_t *p = (uint8_t *)malloc(total_size);
   if (!p) return MIJPEG_ERR_OUT_OF_MEMORY;
   memcpy(p, o.data(), o.size());
+  parallel_for((int)std::min<size_t>((size_t)threads, nparts), [&](int w) {
+    const size_t workers = std::min<size_t>((size_t)threads, nparts);
+    for (size_t k = (size_t)w; k < nparts; k += workers) memcpy(p + at[k], part_ptr[k], part_len[k]);
+  });
+  p[total_size - 2] = 0xff;
+  p[total_size - 1] = 0xd9;
   *stream = p;
-  *size = o.size();
+  *size = total_size;
   return MIJPEG_OK;
 }
