@@ -283,6 +283,41 @@ def main():
             "restart_interval_mcus": 8, "stream_bytes": len(jpegs[0]),
             "note": "bytes -> header parse + restart marker search on the host -> H2D of the compressed stream -> "
                     "huffman_scan_kernel (one lane per restart interval) -> fused kernel -> D2H of the pixels"}
+    if rank == 0 and not args.no_end_to_end:
+        # encoder direction of the block pipeline: forward kernels on frames resident in HBM, and one picture
+        # from host memory to a baseline stream (upload, kernels, download of the coefficients, entropy coder on the host)
+        try:
+            img = synth.synth_image(W, H, 1234 + 17 * rank)
+            fi = api.frame_layout(W, H, 3, (2, 1, 1), (2, 1, 1), [list(info.quant[t]) for t in range(4)], quant_index=list(info.quant_index)[:3])
+            FE = 8
+            px = torch.from_numpy(img).cuda().unsqueeze(0).repeat(FE, 1, 1, 1).contiguous()
+            fcoef = torch.empty((FE, int(fi.coef_count)), dtype=torch.int16, device="cuda")
+            for _ in range(150):  # settles the clocks like the main measurement does
+                api.launch_forward(fi, px.data_ptr(), fcoef.data_ptr(), FE, W * 3, H * W * 3, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(20):
+                api.launch_forward(fi, px.data_ptr(), fcoef.data_ptr(), FE, W * 3, H * W * 3, stream=stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            fms = e0.elapsed_time(e1) / 20
+            del px, fcoef
+            dec.encode(img, 85, "420", 8, False)
+            te = []
+            for _ in range(4):
+                t = time.perf_counter()
+                stream_bytes = dec.encode(img, 85, "420", 8, False)
+                te.append(time.perf_counter() - t)
+            result["end_to_end"]["encoder_direction"] = {
+                "forward_kernels": {"value": round(W * H * FE / fms / 1e3, 1), "unit": "Mpixels/s", "ms": round(fms, 3), "frames": FE,
+                                    "algorithmic_GBps": round(W * H * FE * 6 / fms / 1e6, 1),
+                                    "note": "RGB in HBM -> YCbCr 4:2:0 -> FDCT -> quantiser -> int16 planes in HBM (fdct_interior_kernel x3 + fdct_blocks_kernel)"},
+                "encode_picture": {"value": round(W * H / min(te) / 1e6, 1), "unit": "Mpixels/s", "ms": round(min(te) * 1e3, 2), "stream_bytes": len(stream_bytes),
+                                   "note": "one 8K picture in host memory -> baseline JPEG, restart interval 8, Annex K tables: the reference "
+                                           "encoder's tables and coefficients (mijpeg_encode_image)"}}
+        except Exception as e:  # a side measurement never costs the headline number
+            result["end_to_end"]["encoder_direction"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(jpegs[0], W, H)
