@@ -16,33 +16,11 @@
 #include <memory>
 #include <vector>
 
+#include "encoder.hpp"
 #include "host_decoder.hpp"
 
 namespace mij {
 namespace {
-
-struct EncTable {
-  uint8_t counts[16];
-  uint8_t values[256];
-  int nvalues;
-  uint16_t code[256];
-  uint8_t len[256];
-  void derive()
-  {
-    memset(code, 0, sizeof(code));
-    memset(len, 0, sizeof(len));
-    unsigned c = 0;
-    int k = 0;
-    for (int l = 1; l <= 16; l++) {
-      for (int i = 0; i < counts[l - 1]; i++, k++) {
-        code[values[k]] = (uint16_t)c++;
-        len[values[k]] = (uint8_t)l;
-      }
-      c <<= 1;
-    }
-    nvalues = k;
-  }
-};
 
 // Annex K.3 general purpose tables
 const uint8_t K3_DC_L_COUNTS[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
@@ -232,6 +210,74 @@ void write_dht(std::vector<uint8_t> &o, int tc, int th, const EncTable &t)
 }
 
 } // namespace
+
+void enc_standard_tables(EncTables &t)
+{
+  set_table(t.dc[0], K3_DC_L_COUNTS, K3_DC_VALUES, 12);
+  set_table(t.dc[1], K3_DC_C_COUNTS, K3_DC_VALUES, 12);
+  set_table(t.ac[0], K3_AC_L_COUNTS, K3_AC_L_VALUES, 162);
+  set_table(t.ac[1], K3_AC_C_COUNTS, K3_AC_C_VALUES, 162);
+}
+
+void enc_optimal_tables(EncTables &t, const uint32_t dcfreq[2][256], const uint32_t acfreq[2][256], int ntables)
+{
+  for (int k = 0; k < ntables; k++) {
+    optimal_table(t.dc[k], dcfreq[k]);
+    optimal_table(t.ac[k], acfreq[k]);
+  }
+}
+
+// SOI, DQT, SOF0, DHT, DRI, SOS: everything in front of the entropy coded data
+void enc_write_headers(std::vector<uint8_t> &o, const mijpeg_info &f, const EncTables &tabs, int restart_interval)
+{
+  const int nc = f.components;
+  const uint8_t *zz = scan_order();
+  const EncTable *dct = tabs.dc, *act = tabs.ac;
+  o.reserve(2048);
+  o.push_back(0xff); o.push_back(0xd8);
+  bool used[4] = {false, false, false, false};
+  for (int c = 0; c < nc; c++) used[f.quant_index[c]] = true;
+  for (int t = 0; t < 4; t++)
+    if (used[t]) {
+      bool wide = false;
+      for (int i = 0; i < 64; i++) wide |= f.quant[t][i] > 255;
+      o.push_back(0xff); o.push_back(0xdb);
+      put16(o, (unsigned)(2 + 1 + (wide ? 128 : 64)));
+      o.push_back((uint8_t)((wide ? 0x10 : 0) | t));
+      for (int k = 0; k < 64; k++) {
+        if (wide) o.push_back((uint8_t)(f.quant[t][zz[k]] >> 8));
+        o.push_back((uint8_t)f.quant[t][zz[k]]);
+      }
+    }
+  o.push_back(0xff); o.push_back(0xc0);
+  put16(o, (unsigned)(8 + 3 * nc));
+  o.push_back(8);
+  put16(o, (unsigned)f.height);
+  put16(o, (unsigned)f.width);
+  o.push_back((uint8_t)nc);
+  for (int c = 0; c < nc; c++) {
+    o.push_back((uint8_t)(c + 1));
+    o.push_back((uint8_t)((f.hsamp[c] << 4) | f.vsamp[c]));
+    o.push_back((uint8_t)f.quant_index[c]);
+  }
+  for (int t = 0; t < (nc > 1 ? 2 : 1); t++) {
+    write_dht(o, 0, t, dct[t]);
+    write_dht(o, 1, t, act[t]);
+  }
+  if (restart_interval) {
+    o.push_back(0xff); o.push_back(0xdd);
+    put16(o, 4);
+    put16(o, (unsigned)restart_interval);
+  }
+  o.push_back(0xff); o.push_back(0xda);
+  put16(o, (unsigned)(6 + 2 * nc));
+  o.push_back((uint8_t)nc);
+  for (int c = 0; c < nc; c++) {
+    o.push_back((uint8_t)(c + 1));
+    o.push_back((uint8_t)(c ? 0x11 : 0x00));
+  }
+  o.push_back(0); o.push_back(63); o.push_back(0);
+}
 } // namespace mij
 
 using namespace mij;
@@ -377,15 +423,13 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
     memset(sum, 0, sizeof(sum));
     for (auto &s : stats)
       for (int k = 0; k < 4 * 256; k++) (&sum[0][0])[k] += s[(size_t)k];
-    for (int t = 0; t < (nc > 1 ? 2 : 1); t++) {
-      optimal_table(dct[t], sum[t]);
-      optimal_table(act[t], sum[2 + t]);
-    }
+    EncTables opt;
+    enc_optimal_tables(opt, sum, sum + 2, nc > 1 ? 2 : 1);
+    for (int t = 0; t < 2; t++) { dct[t] = opt.dc[t]; act[t] = opt.ac[t]; }
   } else {
-    set_table(dct[0], K3_DC_L_COUNTS, K3_DC_VALUES, 12);
-    set_table(dct[1], K3_DC_C_COUNTS, K3_DC_VALUES, 12);
-    set_table(act[0], K3_AC_L_COUNTS, K3_AC_L_VALUES, 162);
-    set_table(act[1], K3_AC_C_COUNTS, K3_AC_C_VALUES, 162);
+    EncTables std_tabs;
+    enc_standard_tables(std_tabs);
+    for (int t = 0; t < 2; t++) { dct[t] = std_tabs.dc[t]; act[t] = std_tabs.ac[t]; }
   }
   // entropy coded segments, one buffer per restart interval
   // the entropy coded data: `parts` buffers that follow each other in the stream (RSTn markers included)
@@ -426,50 +470,9 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
   if (out_of_range.load()) return MIJPEG_ERR_OVERFLOW_PARAMETER; // coefficients outside what an 8-bit frame can hold
   // the stream
   std::vector<uint8_t> o;
-  o.reserve(2048);
-  o.push_back(0xff); o.push_back(0xd8);
-  bool used[4] = {false, false, false, false};
-  for (int c = 0; c < nc; c++) used[f.quant_index[c]] = true;
-  for (int t = 0; t < 4; t++)
-    if (used[t]) {
-      bool wide = false;
-      for (int i = 0; i < 64; i++) wide |= f.quant[t][i] > 255;
-      o.push_back(0xff); o.push_back(0xdb);
-      put16(o, (unsigned)(2 + 1 + (wide ? 128 : 64)));
-      o.push_back((uint8_t)((wide ? 0x10 : 0) | t));
-      for (int k = 0; k < 64; k++) {
-        if (wide) o.push_back((uint8_t)(f.quant[t][zz[k]] >> 8));
-        o.push_back((uint8_t)f.quant[t][zz[k]]);
-      }
-    }
-  o.push_back(0xff); o.push_back(0xc0);
-  put16(o, (unsigned)(8 + 3 * nc));
-  o.push_back(8);
-  put16(o, (unsigned)f.height);
-  put16(o, (unsigned)f.width);
-  o.push_back((uint8_t)nc);
-  for (int c = 0; c < nc; c++) {
-    o.push_back((uint8_t)(c + 1));
-    o.push_back((uint8_t)((f.hsamp[c] << 4) | f.vsamp[c]));
-    o.push_back((uint8_t)f.quant_index[c]);
-  }
-  for (int t = 0; t < (nc > 1 ? 2 : 1); t++) {
-    write_dht(o, 0, t, dct[t]);
-    write_dht(o, 1, t, act[t]);
-  }
-  if (restart_interval) {
-    o.push_back(0xff); o.push_back(0xdd);
-    put16(o, 4);
-    put16(o, (unsigned)restart_interval);
-  }
-  o.push_back(0xff); o.push_back(0xda);
-  put16(o, (unsigned)(6 + 2 * nc));
-  o.push_back((uint8_t)nc);
-  for (int c = 0; c < nc; c++) {
-    o.push_back((uint8_t)(c + 1));
-    o.push_back((uint8_t)(c ? 0x11 : 0x00));
-  }
-  o.push_back(0); o.push_back(63); o.push_back(0);
+  EncTables tabs;
+  for (int t = 0; t < 2; t++) { tabs.dc[t] = dct[t]; tabs.ac[t] = act[t]; }
+  enc_write_headers(o, f, tabs, restart_interval);
   // header so far, then the parts at their offsets (copied in parallel), EOI
   const size_t nparts = part_ptr.size();
   std::vector<size_t> at(nparts + 1);
