@@ -281,6 +281,13 @@ void mijpeg_quality_tables(int quality, uint16_t luma[64], uint16_t chroma[64]);
 int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
                         int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize,
                         uint8_t **stream, size_t *size);
+/* The same with flags.  By default the entropy coder runs on the device too (hencode.hip: the coefficients never leave
+ * HBM, only the finished stream comes down); MIJPEG_ENCODE_HOST_CODER downloads the coefficients and codes them with
+ * mijpeg_encode_coefficients.  Both write the same bytes. */
+#define MIJPEG_ENCODE_HOST_CODER 1u
+int mijpeg_encode_image_ex(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
+                           int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint32_t flags,
+                           uint8_t **stream, size_t *size);
 
 /* Worker threads mijpeg_decode_coefficients uses for threads <= 0 (MIJPEG_THREADS overrides; default min(cores, 64)). */
 int mijpeg_default_threads(void);

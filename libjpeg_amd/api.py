@@ -197,20 +197,22 @@ class Decoder:
         """Rounds the on-device self-synchronising walk took in the last device entropy decode (0 = none needed)."""
         return int(lib().mijpeg_device_walk_rounds(self._h))
 
-    def encode(self, img: np.ndarray, quality: int = 85, subsampling: str = "444", restart_mcus: int = 0, optimize: bool = False) -> bytes:
-        """mijpeg_encode_image: (H, W, 3) RGB or (H, W) grey uint8 picture -> baseline JPEG; forward transform on the device."""
+    def encode(self, img: np.ndarray, quality: int = 85, subsampling: str = "444", restart_mcus: int = 0, optimize: bool = False,
+               coder: str = "gpu") -> bytes:
+        """mijpeg_encode_image_ex: (H, W, 3) RGB or (H, W) grey uint8 picture -> baseline JPEG; forward transform on the device,
+        entropy coder on the device (coder="gpu") or on the host cores (coder="host")."""
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape[:2]
         nc = 1 if img.ndim == 2 else img.shape[2]
         hs, vs = {"444": ((1, 1, 1), (1, 1, 1)), "420": ((2, 1, 1), (2, 1, 1)), "422": ((2, 1, 1), (1, 1, 1)), "440": ((1, 1, 1), (2, 1, 1)),
                   "411": ((4, 1, 1), (1, 1, 1))}[subsampling]
         L = lib()
-        L.mijpeg_encode_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.POINTER(C.c_int32),
-                                          C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.mijpeg_encode_image_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.mijpeg_free.argtypes = [C.c_void_p]
         p, n = C.c_void_p(), C.c_size_t()
-        self._check(L.mijpeg_encode_image(self._h, img.ctypes.data, w, h, nc, w * nc, quality, (C.c_int32 * 4)(*hs, 1), (C.c_int32 * 4)(*vs, 1),
-                                          restart_mcus, 1 if optimize else 0, C.byref(p), C.byref(n)))
+        self._check(L.mijpeg_encode_image_ex(self._h, img.ctypes.data, w, h, nc, w * nc, quality, (C.c_int32 * 4)(*hs, 1), (C.c_int32 * 4)(*vs, 1),
+                                             restart_mcus, 1 if optimize else 0, 1 if coder == "host" else 0, C.byref(p), C.byref(n)))
         try:
             return C.string_at(p, n.value)
         finally:

@@ -16,7 +16,9 @@
 #include "../../include/mijpeg.h"
 #include "host_decoder.hpp"
 #include "huffman_dev.hpp"
+#include "encoder.hpp"
 #include "forward.hpp"
+#include "hencode.hpp"
 #include "kernels.hpp"
 
 using namespace mij;
@@ -52,6 +54,8 @@ struct mijpeg_decoder {
   double phase_prepare = 0, phase_device = 0; // last device entropy decode: host tables / upload + kernel
   uint8_t *enc_dev = nullptr; // encoder direction: pixels + coefficients of one picture
   size_t enc_cap = 0;
+  uint8_t *henc_dev = nullptr, *henc_out_dev = nullptr; // device entropy coder: block / interval arrays; streams
+  size_t henc_cap = 0, henc_out_cap = 0;
   uint8_t *walk_dev = nullptr, *walk_host = nullptr; // state of the device walk over streams without restart markers
   size_t walk_cap = 0, walk_host_cap = 0;
   int walk_rounds = 0;
@@ -132,6 +136,8 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->stage_host) (void)hipHostFree(d->stage_host);
     if (d->walk_dev) (void)hipFree(d->walk_dev);
     if (d->enc_dev) (void)hipFree(d->enc_dev);
+    if (d->henc_dev) (void)hipFree(d->henc_dev);
+    if (d->henc_out_dev) (void)hipFree(d->henc_out_dev);
     if (d->walk_host) (void)hipHostFree(d->walk_host);
     for (hipEvent_t e : d->copy_events) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
@@ -1266,8 +1272,143 @@ void mijpeg_quality_tables(int quality, uint16_t luma[64], uint16_t chroma[64])
   }
 }
 
+// Entropy coding of one frame's coefficient planes on the device (hencode.hip) and download of the finished stream.
+static int device_entropy_code(mijpeg_decoder *d, const mijpeg_info &f, const int16_t *coef_dev, int restart_interval, int optimize,
+                               uint8_t **stream, size_t *size)
+{
+  const int nc = f.components;
+  HencArgs a;
+  memset(&a, 0, sizeof(a));
+  a.coef = coef_dev;
+  a.ncomp = nc;
+  a.mcus_x = f.mcus_x;
+  a.total_mcus = f.mcus_x * f.mcus_y;
+  a.ri = restart_interval ? restart_interval : a.total_mcus;
+  int B = 0;
+  for (int c = 0; c < nc; c++) {
+    a.hs[c] = nc > 1 ? f.hsamp[c] : 1;
+    a.vs[c] = nc > 1 ? f.vsamp[c] : 1;
+    a.bw[c] = f.blocks_w[c];
+    a.nbx[c] = ((f.width + f.subx[c] - 1) / f.subx[c] + 7) >> 3;
+    a.nby[c] = ((f.height + f.suby[c] - 1) / f.suby[c] + 7) >> 3;
+    a.coef_off[c] = f.coef_offset[c];
+    for (int by = 0; by < a.vs[c]; by++)
+      for (int bx = 0; bx < a.hs[c]; bx++) {
+        if (B >= 64) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many blocks per MCU for the device entropy coder");
+        a.blk_comp[B] = (uint8_t)c;
+        a.blk_bx[B] = (uint8_t)bx;
+        a.blk_by[B] = (uint8_t)by;
+        B++;
+      }
+  }
+  a.blocks_per_mcu = B;
+  const uint64_t nblocks = (uint64_t)a.total_mcus * (uint64_t)B;
+  if (nblocks >= ((uint64_t)1 << 30)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "frame too large for the device entropy coder");
+  a.total_blocks = (uint32_t)nblocks;
+  a.n_intervals = (uint32_t)((a.total_mcus + a.ri - 1) / a.ri);
+  const uint32_t N = a.total_blocks, I = a.n_intervals;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  // arena 1: tables, statistics, block and interval arrays, scan scratch
+  size_t o = 0;
+  const size_t o_tab = o; o = al(o + sizeof(HencTables));
+  const size_t o_hist = o; o = al(o + 4 * 256 * 4);
+  const size_t o_bits = o; o = al(o + (size_t)N * 4);
+  const size_t o_bitpos = o; o = al(o + ((size_t)N + 1) * 8);
+  const size_t o_ibytes = o; o = al(o + (size_t)I * 4);
+  const size_t o_istart = o; o = al(o + ((size_t)I + 1) * 8);
+  const size_t scratch_words = ((size_t)N / 1024 + 8) * 2 + 8192;
+  const size_t o_scratch = o; o = al(o + scratch_words * 8);
+  int rc = ensure_dev(d, (void **)&d->henc_dev, &d->henc_cap, o);
+  if (rc) return rc;
+  uint8_t *base = d->henc_dev;
+  a.tables = (const HencTables *)(base + o_tab);
+  a.hist = (uint32_t *)(base + o_hist);
+  a.bits = (uint32_t *)(base + o_bits);
+  a.bitpos = (const uint64_t *)(base + o_bitpos);
+  a.ibytes = (uint32_t *)(base + o_ibytes);
+  a.istart = (const uint64_t *)(base + o_istart);
+  uint64_t *scratch = (uint64_t *)(base + o_scratch);
+  EncTables tabs;
+  enc_standard_tables(tabs);
+  auto upload_tables = [&]() -> int {
+    HencTables h;
+    memset(&h, 0, sizeof(h));
+    for (int t = 0; t < 2; t++) {
+      for (int k = 0; k < 16; k++) { h.dc_code[t][k] = tabs.dc[t].code[k]; h.dc_len[t][k] = tabs.dc[t].len[k]; }
+      for (int k = 0; k < 256; k++) { h.ac_code[t][k] = tabs.ac[t].code[k]; h.ac_len[t][k] = tabs.ac[t].len[k]; }
+    }
+    HIP_TRY(d, hipMemcpyAsync(base + o_tab, &h, sizeof(h), hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream)); // h lives on this stack frame
+    return MIJPEG_OK;
+  };
+  rc = upload_tables();
+  if (rc) return rc;
+  if (optimize) { // symbol statistics first, tables from them (Annex K.2)
+    HIP_TRY(d, hipMemsetAsync(base + o_hist, 0, 4 * 256 * 4, d->stream));
+    if (henc_count(a, true, d->stream)) return hip_fail(d, hipGetLastError(), "henc_count_kernel launch");
+    uint32_t hist[4][256];
+    HIP_TRY(d, hipMemcpyAsync(hist, base + o_hist, sizeof(hist), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    enc_optimal_tables(tabs, hist, hist + 2, nc > 1 ? 2 : 1);
+    rc = upload_tables();
+    if (rc) return rc;
+  }
+  if (henc_count(a, false, d->stream)) return hip_fail(d, hipGetLastError(), "henc_count_kernel launch");
+  if (exclusive_scan_u32(a.bits, (uint64_t *)a.bitpos, N, scratch, d->stream)) return hip_fail(d, hipGetLastError(), "scan launch");
+  if (henc_interval_bytes(a, d->stream)) return hip_fail(d, hipGetLastError(), "henc_interval_bytes_kernel launch");
+  if (exclusive_scan_u32(a.ibytes, (uint64_t *)a.istart, I, scratch, d->stream)) return hip_fail(d, hipGetLastError(), "scan launch");
+  uint64_t plain_bytes = 0;
+  HIP_TRY(d, hipMemcpyAsync(&plain_bytes, a.istart + I, 8, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  // (coefficients the forward kernels make of 8-bit pixels always have a code: at most 11 / 10 bits, the host coder's check)
+  // arena 2: plain stream, 0xFF counts, stuffed stream
+  const uint32_t chunks = (uint32_t)((plain_bytes + 255) / 256);
+  size_t q = 0;
+  const size_t q_plain = q; q = al(q + (size_t)plain_bytes + 16);
+  const size_t q_ffc = q; q = al(q + (size_t)chunks * 4 + 4);
+  const size_t q_ffs = q; q = al(q + ((size_t)chunks + 1) * 8);
+  const size_t q_out = q; q = al(q + (size_t)plain_bytes * 2 + (size_t)I * 2 + 16);
+  rc = ensure_dev(d, (void **)&d->henc_out_dev, &d->henc_out_cap, q);
+  if (rc) return rc;
+  uint8_t *ob = d->henc_out_dev;
+  a.plain = (uint32_t *)(ob + q_plain);
+  a.plain_bytes = plain_bytes;
+  a.ffcount = (uint32_t *)(ob + q_ffc);
+  a.ffstart = (const uint64_t *)(ob + q_ffs);
+  a.out = ob + q_out;
+  HIP_TRY(d, hipMemsetAsync(ob + q_plain, 0, al((size_t)plain_bytes + 16), d->stream));
+  if (henc_emit(a, d->stream)) return hip_fail(d, hipGetLastError(), "henc_emit_kernel launch");
+  if (henc_count_ff(a, d->stream)) return hip_fail(d, hipGetLastError(), "henc_count_ff_kernel launch");
+  if (exclusive_scan_u32(a.ffcount, (uint64_t *)a.ffstart, chunks, scratch, d->stream)) return hip_fail(d, hipGetLastError(), "scan launch");
+  if (henc_stuff(a, d->stream)) return hip_fail(d, hipGetLastError(), "henc_stuff_kernel launch");
+  uint64_t ff_total = 0;
+  HIP_TRY(d, hipMemcpyAsync(&ff_total, a.ffstart + chunks, 8, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  const size_t ecs = (size_t)plain_bytes + (size_t)ff_total + (size_t)(I - 1) * 2;
+  std::vector<uint8_t> head;
+  enc_write_headers(head, f, tabs, restart_interval);
+  uint8_t *p = (uint8_t *)malloc(head.size() + ecs + 2);
+  if (!p) return set_error(d, MIJPEG_ERR_OUT_OF_MEMORY, "out of memory for the stream");
+  memcpy(p, head.data(), head.size());
+  hipError_t e = hipMemcpyAsync(p + head.size(), a.out, ecs, hipMemcpyDeviceToHost, d->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+  if (e != hipSuccess) { free(p); return hip_fail(d, e, "download of the stream"); }
+  p[head.size() + ecs] = 0xff;
+  p[head.size() + ecs + 1] = 0xd9;
+  *stream = p;
+  *size = head.size() + ecs + 2;
+  return MIJPEG_OK;
+}
+
 int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
                         int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint8_t **stream, size_t *size)
+{
+  return mijpeg_encode_image_ex(d, pixels, width, height, components, row_stride, quality, hsamp, vsamp, restart_interval, optimize, 0, stream, size);
+}
+
+int mijpeg_encode_image_ex(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
+                           int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint32_t flags,
+                           uint8_t **stream, size_t *size)
 {
   using clk = std::chrono::steady_clock;
   const auto t_begin = clk::now();
@@ -1333,6 +1474,15 @@ int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width,
   const auto t_up = clk::now(); // uploads enqueued (the gathering is synchronous)
   rc = mijpeg_launch_forward(&b, d->stream);
   if (rc) return set_error(d, rc, "forward kernel launch failed");
+  static const bool env_host_coder = getenv("MIJPEG_ENTROPY_CODER") && !strcmp(getenv("MIJPEG_ENTROPY_CODER"), "host");
+  if (!(flags & MIJPEG_ENCODE_HOST_CODER) && !env_host_coder) {
+    if (restart_interval < 0 || restart_interval > 65535) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "invalid restart interval");
+    rc = device_entropy_code(d, f, coef_dev, restart_interval, optimize, stream, size);
+    d->timing[0] = std::chrono::duration<double>(t_up - t_begin).count();
+    d->timing[1] = std::chrono::duration<double>(clk::now() - t_up).count(); // kernels, entropy coder and download of the stream
+    d->timing[2] = d->timing[3] = 0;
+    if (rc != MIJPEG_ERR_NOT_AVAILABLE) return rc;
+  }
   HIP_TRY(d, hipStreamSynchronize(d->stream));
   const auto t_kernel = clk::now();
   HIP_TRY(d, hipMemcpyAsync(coef_host, coef_dev, coef_bytes, hipMemcpyDeviceToHost, d->stream));

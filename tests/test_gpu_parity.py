@@ -1131,3 +1131,30 @@ def test_cli_encodes_like_the_reference_cli(tmp_path, oracle):
     assert r.returncode == 0, r.stderr
     assert oracle.decode(dst.read_bytes()).shape[:2] == (120, 200)
 
+
+@pytest.mark.parametrize("w,h,sub,q,ri,opt", [(64, 48, "444", 75, 0, False), (75, 45, "420", 85, 2, True), (129, 71, "422", 30, 5, False),
+                                              (33, 17, "411", 95, 1, True), (640, 360, "420", 85, 8, False), (1000, 700, "440", 99, 0, True),
+                                              (1920, 1080, "420", 85, 0, False), (8, 8, "444", 50, 0, False), (1, 1, "420", 90, 1, True)])
+def test_device_entropy_coder_writes_the_host_coders_stream(dec, oracle, w, h, sub, q, ri, opt):
+    """hencode.hip (count, prefix sums, emit with atomicOr, stuffing with RSTn markers) against encoder.cpp: the same bytes;
+    noise pictures at high quality make plenty of 0xFF bytes and long codes."""
+    rng = np.random.default_rng(w + h)
+    img = synth.synth_image(w, h, 90 + w) if w != 1000 else rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    on_device = dec.encode(img, q, sub, ri, opt, coder="gpu")
+    on_host = dec.encode(img, q, sub, ri, opt, coder="host")
+    assert on_device == on_host
+    info, planes = oracle.decode_coefficients(on_device)
+    exp = oracle.forward(info, img, 1)
+    for c in range(3):
+        nby, nbx = (info.ch[c] + 7) // 8, (info.cw[c] + 7) // 8
+        assert np.array_equal(planes[c][:nby, :nbx], exp[c][:nby, :nbx])
+
+
+def test_device_entropy_coder_grey(dec, oracle):
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (123, 77)).astype(np.uint8)
+    for ri, opt in ((0, False), (3, True)):
+        a = dec.encode(img, 92, "444", ri, opt, coder="gpu")
+        assert a == dec.encode(img, 92, "444", ri, opt, coder="host")
+        assert np.abs(oracle.decode(a).squeeze().astype(int) - img).max() < 40
+
