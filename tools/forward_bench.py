@@ -46,12 +46,13 @@ for sub in os.environ.get("LAYOUTS", "420,422,444").split(","):
           f"round trip through the fused decoder: PSNR {10*np.log10(255**2/np.mean(err**2)):.1f} dB", flush=True)
 # whole pipeline for one 8K picture in host memory (upload, kernels, download of the coefficients, entropy coder on the host cores)
 import time
-for sub, ri, opt in (("420", 8, False), ("420", 8, True), ("420", 0, False)):
+for sub, ri, opt, coder in (("420", 8, False, "gpu"), ("420", 8, True, "gpu"), ("420", 0, False, "gpu"), ("444", 0, True, "gpu"),
+                            ("420", 8, False, "host"), ("420", 8, True, "host"), ("420", 0, False, "host")):
     ts = []
-    d.encode(img, 85, sub, ri, opt)  # warm: pinned staging, worker threads
+    d.encode(img, 85, sub, ri, opt, coder=coder)  # warm: pinned staging, worker threads
     for _ in range(5):
-        t = time.perf_counter(); data = d.encode(img, 85, sub, ri, opt); ts.append(time.perf_counter() - t)
-    print(f"encode one 8K {sub} picture, restart interval {ri}, {'optimised' if opt else 'Annex K'} Huffman tables: {min(ts)*1e3:.1f} ms "
+        t = time.perf_counter(); data = d.encode(img, 85, sub, ri, opt, coder=coder); ts.append(time.perf_counter() - t)
+    print(f"encode one 8K {sub} picture, entropy coder on the {'device' if coder == 'gpu' else 'host'}, restart interval {ri}, {'optimised' if opt else 'Annex K'} Huffman tables: {min(ts)*1e3:.1f} ms "
           f"= {W*H/min(ts)/1e6:.0f} Mpixel/s, {len(data)/1e6:.2f} MB; gather+upload / kernels / download / coder ms: "
           f"{[round(v * 1e3, 2) for v in d.timing().values()]}", flush=True)
 d.close()
