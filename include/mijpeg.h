@@ -289,6 +289,12 @@ int mijpeg_encode_image_ex(mijpeg_decoder *d, const uint8_t *pixels, int32_t wid
                            int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint32_t flags,
                            uint8_t **stream, size_t *size);
 
+/* Frames that are already in device memory (a renderer's or a video pipeline's output): forward kernels for the whole batch in
+ * one launch, then the device entropy coder frame by frame; only the finished streams cross PCIe.  batch->coef_dev is
+ * scratch for the coefficient planes (frames * coef_frame_stride int16).  streams[f] is malloc'ed (mijpeg_free). */
+int mijpeg_encode_batch_device(mijpeg_decoder *d, const mijpeg_forward_batch *batch, int restart_interval, int optimize,
+                               uint8_t **streams, size_t *sizes);
+
 /* Worker threads mijpeg_decode_coefficients uses for threads <= 0 (MIJPEG_THREADS overrides; default min(cores, 64)). */
 int mijpeg_default_threads(void);
 

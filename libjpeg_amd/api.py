@@ -218,6 +218,24 @@ class Decoder:
         finally:
             L.mijpeg_free(p)
 
+    def encode_batch_device(self, info: MijpegInfo, pixels_dev: int, coef_dev: int, frames: int, pixel_row_stride: int, pixel_frame_stride: int,
+                            restart_mcus: int = 0, optimize: bool = False):
+        """mijpeg_encode_batch_device: frames resident in HBM -> list of baseline JPEG streams (forward kernels + device entropy coder)."""
+        b = MijpegForwardBatch()
+        C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
+        b.pixels_dev, b.pixel_frame_stride, b.pixel_row_stride = pixels_dev, pixel_frame_stride, pixel_row_stride
+        b.coef_dev, b.coef_frame_stride, b.frames = coef_dev, info.coef_count, frames
+        L = lib()
+        L.mijpeg_encode_batch_device.argtypes = [C.c_void_p, C.POINTER(MijpegForwardBatch), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.mijpeg_free.argtypes = [C.c_void_p]
+        ptrs, sizes = (C.c_void_p * frames)(), (C.c_size_t * frames)()
+        self._check(L.mijpeg_encode_batch_device(self._h, C.byref(b), restart_mcus, 1 if optimize else 0, ptrs, sizes))
+        out = []
+        for f in range(frames):
+            out.append(C.string_at(ptrs[f], sizes[f]))
+            L.mijpeg_free(ptrs[f])
+        return out
+
     def xt_params(self) -> MijpegXtParams:
         xt = MijpegXtParams()
         self._check(lib().mijpeg_get_xt_params(self._h, C.byref(xt)))

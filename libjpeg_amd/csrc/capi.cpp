@@ -1400,6 +1400,24 @@ static int device_entropy_code(mijpeg_decoder *d, const mijpeg_info &f, const in
   return MIJPEG_OK;
 }
 
+int mijpeg_encode_batch_device(mijpeg_decoder *d, const mijpeg_forward_batch *b, int restart_interval, int optimize, uint8_t **streams, size_t *sizes)
+{
+  if (!d || !b || !streams || !sizes || b->frames < 1 || restart_interval < 0 || restart_interval > 65535) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "decoder was created without a device");
+  HIP_TRY(d, hipSetDevice(d->device));
+  for (int f = 0; f < b->frames; f++) { streams[f] = nullptr; sizes[f] = 0; }
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = mijpeg_launch_forward(b, d->stream);
+  if (rc) return set_error(d, rc, "forward kernel launch failed");
+  for (int f = 0; f < b->frames && !rc; f++)
+    rc = device_entropy_code(d, b->info, b->coef_dev + (int64_t)f * b->coef_frame_stride, restart_interval, optimize, &streams[f], &sizes[f]);
+  if (rc)
+    for (int f = 0; f < b->frames; f++) { free(streams[f]); streams[f] = nullptr; sizes[f] = 0; }
+  d->timing[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); // mijpeg_last_timing: the whole call
+  d->timing[1] = d->timing[2] = d->timing[3] = 0;
+  return rc;
+}
+
 int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
                         int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint8_t **stream, size_t *size)
 {

@@ -1158,3 +1158,25 @@ def test_device_entropy_coder_grey(dec, oracle):
         assert a == dec.encode(img, 92, "444", ri, opt, coder="host")
         assert np.abs(oracle.decode(a).squeeze().astype(int) - img).max() < 40
 
+
+def test_encode_batch_of_frames_resident_in_hbm(dec, oracle):
+    """mijpeg_encode_batch_device: one forward launch for the batch, the device coder per frame; every stream equals the one
+    mijpeg_encode_image makes of the same picture and quantiser tables."""
+    import ctypes as C
+
+    torch = _torch()
+    w, h, n = 640, 360, 5
+    imgs = [synth.synth_image(w, h, 300 + i) for i in range(n)]
+    luma, chroma = np.zeros(64, np.uint16), np.zeros(64, np.uint16)
+    L = api.lib()
+    L.mijpeg_quality_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.mijpeg_quality_tables.restype = None
+    L.mijpeg_quality_tables(80, luma.ctypes.data, chroma.ctypes.data)
+    info = api.frame_layout(w, h, 3, (2, 1, 1), (2, 1, 1), [luma, chroma], quant_index=[0, 0, 0])
+    px = torch.from_numpy(np.stack(imgs)).cuda()
+    coef = torch.empty((n, int(info.coef_count)), dtype=torch.int16, device="cuda")
+    streams = dec.encode_batch_device(info, px.data_ptr(), coef.data_ptr(), n, w * 3, h * w * 3, restart_mcus=4, optimize=True)
+    for i in range(n):
+        assert streams[i] == dec.encode(imgs[i], 80, "420", 4, True), i
+        assert np.array_equal(oracle.decode(streams[i]).shape, (h, w, 3))
+
