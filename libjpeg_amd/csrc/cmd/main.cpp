@@ -218,8 +218,37 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
 }
 
 // Encoder direction (the reference CLI's `jpeg -bl -q n [-s HxV,HxV,HxV] [-z n] [-h] source.ppm target.jpg`, cmd/main.cpp ->
-// cmd/encodec.cpp): binary PNM (P5 / P6, maxval 255) in, baseline JPEG out, through the C ABI's mijpeg_encode_image.
+// cmd/encodec.cpp): binary PNM (P5 / P6, maxval 255) in, baseline JPEG out, as a tag/hook client of class JPEG:
+// JPEG::ProvideImage pulls the picture eight lines at a time through a bitmap hook that reads them from the file
+// (cmd/bitmaphook.cpp:102-340 in its encoder role), JPEG::Write pushes the stream through the file I/O hook.
 // -s takes the reference's SUBSAMPLING factors per component (1x1,2x2,2x2 = 4:2:0).
+struct SourceStripe {
+  FILE *in;
+  unsigned char *mem; // eight lines, interleaved
+  int width, depth, next_line;
+};
+
+static JPG_LONG SourceBitmapHook(struct JPG_Hook *hook, struct JPG_TagItem *tags)
+{
+  SourceStripe *s = (SourceStripe *)hook->hk_pData;
+  if (tags->GetTagData(JPGTAG_BIO_ACTION) != JPGFLAG_BIO_REQUEST) return 0;
+  const JPG_LONG comp = tags->GetTagData(JPGTAG_BIO_COMPONENT), miny = tags->GetTagData(JPGTAG_BIO_MINY), maxy = tags->GetTagData(JPGTAG_BIO_MAXY);
+  if (comp == 0) { // a new stripe: read its lines (the requests arrive top-down, component by component)
+    if (miny != s->next_line) return -1;
+    const size_t bytes = (size_t)(maxy - miny + 1) * (size_t)s->width * (size_t)s->depth;
+    if (fread(s->mem, 1, bytes, s->in) != bytes) return -1;
+    s->next_line = maxy + 1;
+  }
+  const JPG_LONG bpr = s->width * s->depth;
+  tags->SetTagPtr(JPGTAG_BIO_MEMORY, s->mem + comp - (ptrdiff_t)miny * bpr); // address of canvas pixel (0,0)
+  tags->SetTagData(JPGTAG_BIO_WIDTH, s->width);
+  tags->SetTagData(JPGTAG_BIO_HEIGHT, 8 + miny);
+  tags->SetTagData(JPGTAG_BIO_BYTESPERROW, bpr);
+  tags->SetTagData(JPGTAG_BIO_BYTESPERPIXEL, s->depth);
+  tags->SetTagData(JPGTAG_BIO_PIXELTYPE, CTYP_UBYTE);
+  return 0;
+}
+
 static int Encode(const char *src, const char *dst, int quality, const char *sub, int restart, bool optimize, int device)
 {
   FILE *in = fopen(src, "rb");
@@ -233,46 +262,50 @@ static int Encode(const char *src, const char *dst, int quality, const char *sub
   }
   fgetc(in); // the single white space behind the header
   const int nc = magic[1] == '6' ? 3 : 1;
-  const size_t bytes = (size_t)w * (size_t)h * (size_t)nc;
-  unsigned char *px = (unsigned char *)malloc(bytes);
-  if (!px || fread(px, 1, bytes, in) != bytes) {
-    fprintf(stderr, "%s: unexpected end of file\n", src);
-    fclose(in);
-    free(px);
-    return 10;
+  unsigned char subx[4] = {1, 1, 1, 1}, suby[4] = {1, 1, 1, 1};
+  if (sub && nc == 3) {
+    int sx[3], sy[3];
+    if (sscanf(sub, "%dx%d,%dx%d,%dx%d", &sx[0], &sy[0], &sx[1], &sy[1], &sx[2], &sy[2]) != 6) { fprintf(stderr, "-s expects e.g. 1x1,2x2,2x2\n"); fclose(in); return 5; }
+    for (int c = 0; c < 3; c++) { subx[c] = (unsigned char)sx[c]; suby[c] = (unsigned char)sy[c]; }
+  }
+  SourceStripe stripe = {in, (unsigned char *)malloc((size_t)w * (size_t)nc * 8), w, nc, 0};
+  FILE *out = fopen(dst, "wb");
+  if (!stripe.mem || !out) { perror(dst); fclose(in); if (out) fclose(out); free(stripe.mem); return 10; }
+  struct JPG_Hook bmhook(SourceBitmapHook, &stripe), filehook(FileHook, out);
+  struct JPG_TagItem ctags[] = {JPG_ValueTag(device >= 0 ? JPGTAG_MIJPEG_DEVICE : JPGTAG_TAG_IGNORE, device), JPG_EndTag};
+  class JPEG *jpeg = JPEG::Construct(ctags);
+  int rc = 0;
+  if (!jpeg) {
+    fprintf(stderr, "failed to construct the JPEG object (no MI355X device?)\n");
+    rc = 10;
+  } else {
+    struct JPG_TagItem itags[] = {JPG_PointerTag(JPGTAG_BIH_HOOK, &bmhook),
+                                  JPG_ValueTag(JPGTAG_ENCODER_LOOP_ON_INCOMPLETE, true),
+                                  JPG_ValueTag(JPGTAG_ENCODER_IMAGE_COMPLETE, false),
+                                  JPG_ValueTag(JPGTAG_IMAGE_WIDTH, w),
+                                  JPG_ValueTag(JPGTAG_IMAGE_HEIGHT, h),
+                                  JPG_ValueTag(JPGTAG_IMAGE_DEPTH, nc),
+                                  JPG_ValueTag(JPGTAG_IMAGE_PRECISION, 8),
+                                  JPG_ValueTag(JPGTAG_IMAGE_FRAMETYPE, JPGFLAG_BASELINE | (optimize ? JPGFLAG_OPTIMIZE_HUFFMAN : 0)),
+                                  JPG_ValueTag(JPGTAG_IMAGE_QUALITY, quality),
+                                  JPG_ValueTag(JPGTAG_IMAGE_RESTART_INTERVAL, restart),
+                                  JPG_PointerTag(JPGTAG_IMAGE_SUBX, subx),
+                                  JPG_PointerTag(JPGTAG_IMAGE_SUBY, suby),
+                                  JPG_ValueTag(JPGTAG_MATRIX_LTRAFO, JPGFLAG_MATRIX_COLORTRANSFORMATION_YCBCR),
+                                  JPG_EndTag};
+    struct JPG_TagItem iotags[] = {JPG_PointerTag(JPGTAG_HOOK_IOHOOK, &filehook), JPG_PointerTag(JPGTAG_HOOK_IOSTREAM, out), JPG_EndTag};
+    if (!jpeg->ProvideImage(itags) || !jpeg->Write(iotags)) {
+      const char *msg = NULL;
+      const JPG_LONG code = jpeg->LastError(msg);
+      fprintf(stderr, "encoding failed: error %ld %s\n", (long)code, msg ? msg : "");
+      rc = 10;
+    }
+    JPEG::Destruct(jpeg);
   }
   fclose(in);
-  int32_t hs[4] = {1, 1, 1, 1}, vs[4] = {1, 1, 1, 1};
-  if (sub && nc == 3) { // subsampling factors -> sampling factors
-    int sx[3], sy[3];
-    if (sscanf(sub, "%dx%d,%dx%d,%dx%d", &sx[0], &sy[0], &sx[1], &sy[1], &sx[2], &sy[2]) != 6) { fprintf(stderr, "-s expects e.g. 1x1,2x2,2x2\n"); free(px); return 5; }
-    int mx = 1, my = 1;
-    for (int c = 0; c < 3; c++) { if (sx[c] < 1 || sx[c] > 4 || sy[c] < 1 || sy[c] > 4) { fprintf(stderr, "subsampling factors must be 1..4\n"); free(px); return 5; } mx = sx[c] > mx ? sx[c] : mx; my = sy[c] > my ? sy[c] : my; }
-    for (int c = 0; c < 3; c++) {
-      if (mx % sx[c] || my % sy[c]) { fprintf(stderr, "unsupported combination of subsampling factors\n"); free(px); return 5; }
-      hs[c] = mx / sx[c];
-      vs[c] = my / sy[c];
-    }
-  }
-  mijpeg_decoder *d = NULL;
-  if (mijpeg_create(&d, device < 0 ? 0 : device) || !d) { fprintf(stderr, "no MI355X device available\n"); free(px); return 10; }
-  uint8_t *stream = NULL;
-  size_t size = 0;
-  int rc = mijpeg_encode_image(d, px, w, h, nc, (int64_t)w * nc, quality, hs, vs, restart, optimize ? 1 : 0, &stream, &size);
-  free(px);
-  if (rc) {
-    const char *msg = NULL;
-    mijpeg_last_error(d, &msg);
-    fprintf(stderr, "encoding failed: error %d %s\n", rc, msg ? msg : "");
-    mijpeg_destroy(d);
-    return 10;
-  }
-  mijpeg_destroy(d);
-  FILE *out = fopen(dst, "wb");
-  if (!out || fwrite(stream, 1, size, out) != size) { perror(dst); if (out) fclose(out); mijpeg_free(stream); return 10; }
   fclose(out);
-  mijpeg_free(stream);
-  return 0;
+  free(stripe.mem);
+  return rc;
 }
 
 int main(int argc, char **argv)

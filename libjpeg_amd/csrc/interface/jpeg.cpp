@@ -7,6 +7,9 @@
 //                    protocol per component), control/blockbitmaprequester.cpp:1229-1244 (the height the hook
 //                    reports bounds the block rows that are reconstructed)
 //   LastError        interface/jpeg.cpp:959-979
+//   ProvideImage     interface/jpeg.cpp:461-597 (image parameters from the tags, pixel data pulled stripe by stripe through
+//                    the bitmap hook with the same REQUEST / RELEASE protocol) -- baseline / sequential 8-bit frames
+//   Write            interface/jpeg.cpp:356-459 (the finished stream is pushed through the I/O hook, JPGFLAG_ACTION_WRITE)
 // Error convention: every call returns JPG_TRUE / JPG_FALSE, nothing is thrown across the boundary.
 #include "jpeg.hpp"
 
@@ -25,6 +28,11 @@ struct JPEG::Impl {
   std::vector<uint8_t> stream; // the codestream, pulled through the I/O hook
   mijpeg_info info;
   bool loaded = false;
+  // encoder direction: the picture as ProvideImage collects it, and its parameters
+  std::vector<uint8_t> picture;
+  int enc_width = 0, enc_height = 0, enc_depth = 0, enc_quality = 75, enc_restart = 0, enc_lines = 0;
+  bool enc_optimize = false, enc_ycbcr = true;
+  int32_t enc_hsamp[4] = {1, 1, 1, 1}, enc_vsamp[4] = {1, 1, 1, 1};
   int err = 0;
   std::string errmsg;
   int fail(int code, const char *msg)
@@ -278,8 +286,127 @@ JPG_LONG JPEG::LastWarning(const char *&warning)
   return 0;
 }
 
-JPG_LONG JPEG::Write(struct JPG_TagItem *) { return m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "the encoder is not part of the accelerated path"); }
-JPG_LONG JPEG::ProvideImage(struct JPG_TagItem *) { return m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "the encoder is not part of the accelerated path"); }
+JPG_LONG JPEG::ProvideImage(struct JPG_TagItem *tags)
+{
+  Impl *p = m_pImpl;
+  p->err = 0;
+  if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::ProvideImage requires a tag list");
+  if (p->picture.empty()) { // first call: the image parameters (interface/jpeg.cpp:461-560, codestream/encoder.cpp)
+    const JPG_LONG w = tags->GetTagData(JPGTAG_IMAGE_WIDTH, 0), h = tags->GetTagData(JPGTAG_IMAGE_HEIGHT, 0), depth = tags->GetTagData(JPGTAG_IMAGE_DEPTH, 3);
+    const JPG_LONG prec = tags->GetTagData(JPGTAG_IMAGE_PRECISION, 8), type = tags->GetTagData(JPGTAG_IMAGE_FRAMETYPE, JPGFLAG_BASELINE);
+    if (w < 1 || h < 1 || w > 65535 || h > 65535) return p->fail(JPGERR_OVERFLOW_PARAMETER, "image dimensions must be between 1 and 65535");
+    if ((depth != 1 && depth != 3) || prec != 8) return p->fail(JPGERR_NOT_IMPLEMENTED, "the accelerated encoder handles 8-bit images of one or three components");
+    if ((type & ~JPGFLAG_OPTIMIZE_HUFFMAN) != JPGFLAG_BASELINE && (type & ~JPGFLAG_OPTIMIZE_HUFFMAN) != JPGFLAG_SEQUENTIAL)
+      return p->fail(JPGERR_NOT_IMPLEMENTED, "the accelerated encoder writes baseline / sequential Huffman frames only");
+    p->enc_width = w; p->enc_height = h; p->enc_depth = depth;
+    p->enc_optimize = (type & JPGFLAG_OPTIMIZE_HUFFMAN) != 0;
+    p->enc_quality = tags->GetTagData(JPGTAG_IMAGE_QUALITY, 75);
+    p->enc_restart = tags->GetTagData(JPGTAG_IMAGE_RESTART_INTERVAL, 0);
+    p->enc_ycbcr = tags->GetTagData(JPGTAG_MATRIX_LTRAFO, JPGFLAG_MATRIX_COLORTRANSFORMATION_YCBCR) != JPGFLAG_MATRIX_COLORTRANSFORMATION_NONE;
+    if (depth == 3 && !p->enc_ycbcr) return p->fail(JPGERR_NOT_IMPLEMENTED, "the accelerated encoder codes three components as YCbCr");
+    const unsigned char *subx = (const unsigned char *)tags->GetTagPtr(JPGTAG_IMAGE_SUBX, nullptr), *suby = (const unsigned char *)tags->GetTagPtr(JPGTAG_IMAGE_SUBY, nullptr);
+    int mx = 1, my = 1;
+    for (int c = 0; c < depth; c++) {
+      const int sx = subx ? subx[c] : 1, sy = suby ? suby[c] : 1;
+      if (sx < 1 || sx > 4 || sy < 1 || sy > 4) return p->fail(JPGERR_OVERFLOW_PARAMETER, "subsampling factors must be between 1 and 4");
+      mx = sx > mx ? sx : mx;
+      my = sy > my ? sy : my;
+    }
+    for (int c = 0; c < depth; c++) { // subsampling factors -> sampling factors (marker/frame.cpp)
+      const int sx = subx ? subx[c] : 1, sy = suby ? suby[c] : 1;
+      if (mx % sx || my % sy) return p->fail(JPGERR_INVALID_PARAMETER, "unsupported combination of subsampling factors");
+      p->enc_hsamp[c] = mx / sx;
+      p->enc_vsamp[c] = my / sy;
+    }
+    p->picture.assign((size_t)w * (size_t)h * (size_t)depth, 0);
+    p->enc_lines = 0;
+  }
+  struct JPG_Hook *bmh = (struct JPG_Hook *)tags->GetTagPtr(JPGTAG_BIH_HOOK, nullptr);
+  if (!bmh) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no bitmap hook (JPGTAG_BIH_HOOK) specified");
+  const bool loop = tags->GetTagData(JPGTAG_ENCODER_LOOP_ON_INCOMPLETE, 0) != 0;
+  const int w = p->enc_width, h = p->enc_height, nc = p->enc_depth;
+  // eight lines per request, component by component (control/blockbitmaprequester.cpp:968-1011, interface/bitmaphook.cpp:130-248)
+  do {
+    if (p->enc_lines >= h) break;
+    const JPG_LONG miny = p->enc_lines, maxy = (miny + 7 < h ? miny + 7 : h - 1);
+    for (int c = 0; c < nc; c++) {
+      struct JPG_TagItem ht[] = {
+          JPG_ValueTag(JPGTAG_BIO_ACTION, JPGFLAG_BIO_REQUEST),
+          JPG_PointerTag(JPGTAG_BIO_MEMORY, nullptr),
+          JPG_ValueTag(JPGTAG_BIO_WIDTH, 0),
+          JPG_ValueTag(JPGTAG_BIO_HEIGHT, 0),
+          JPG_ValueTag(JPGTAG_BIO_BYTESPERROW, 0),
+          JPG_ValueTag(JPGTAG_BIO_BYTESPERPIXEL, 0),
+          JPG_ValueTag(JPGTAG_BIO_PIXELTYPE, CTYP_UBYTE),
+          JPG_ValueTag(JPGTAG_BIO_ROI, 0),
+          JPG_ValueTag(JPGTAG_BIO_COMPONENT, c),
+          JPG_PointerTag(JPGTAG_BIO_USERDATA, nullptr),
+          JPG_ValueTag(JPGTAG_BIO_MINX, 0),
+          JPG_ValueTag(JPGTAG_BIO_MINY, miny),
+          JPG_ValueTag(JPGTAG_BIO_MAXX, w - 1),
+          JPG_ValueTag(JPGTAG_BIO_MAXY, maxy),
+          JPG_ValueTag(JPGTAG_BIO_ALPHA, 0),
+          JPG_ValueTag(JPGTAG_BIO_PIXEL_MINX, 0),
+          JPG_ValueTag(JPGTAG_BIO_PIXEL_MINY, miny),
+          JPG_ValueTag(JPGTAG_BIO_PIXEL_MAXX, w - 1),
+          JPG_ValueTag(JPGTAG_BIO_PIXEL_MAXY, maxy),
+          JPG_ValueTag(JPGTAG_BIO_PIXEL_XORG, 0),
+          JPG_ValueTag(JPGTAG_BIO_PIXEL_YORG, 0),
+          JPG_EndTag};
+      JPG_LONG r = bmh->CallLong(ht);
+      if (r < 0) return p->fail(r, "BitMapHook signalled an error");
+      const unsigned char *mem = (const unsigned char *)ht[1].ti_Data.ti_pPtr;
+      const JPG_LONG bpr = ht[4].ti_Data.ti_lData, bpp = ht[5].ti_Data.ti_lData, type = ht[6].ti_Data.ti_lData;
+      if (!mem || type != CTYP_UBYTE) return p->fail(JPGERR_INVALID_PARAMETER, "the accelerated encoder expects CTYP_UBYTE pixel data from the bitmap hook");
+      for (JPG_LONG y = miny; y <= maxy; y++) { // mem is the address of canvas pixel (0,0)
+        const unsigned char *src = mem + (ptrdiff_t)y * bpr;
+        unsigned char *dst = p->picture.data() + ((size_t)y * (size_t)w) * (size_t)nc + (size_t)c;
+        for (int x = 0; x < w; x++) dst[(size_t)x * (size_t)nc] = src[(ptrdiff_t)x * bpp];
+      }
+      ht[0].ti_Data.ti_lData = JPGFLAG_BIO_RELEASE;
+      r = bmh->CallLong(ht);
+      if (r < 0) return p->fail(r, "BitMapHook signalled an error");
+    }
+    p->enc_lines = maxy + 1;
+  } while (loop);
+  tags->SetTagData(JPGTAG_ENCODER_IMAGE_COMPLETE, p->enc_lines >= h);
+  return JPG_TRUE;
+}
+
+JPG_LONG JPEG::Write(struct JPG_TagItem *tags)
+{
+  Impl *p = m_pImpl;
+  p->err = 0;
+  if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::Write requires a tag list with an I/O hook");
+  if (p->picture.empty() || p->enc_lines < p->enc_height) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no complete image has been provided that could be written");
+  struct JPG_Hook *io = (struct JPG_Hook *)tags->GetTagPtr(JPGTAG_HOOK_IOHOOK);
+  if (!io) return p->fail(JPGERR_MISSING_PARAMETER, "no I/O hook (JPGTAG_HOOK_IOHOOK) specified");
+  uint8_t *stream = nullptr;
+  size_t size = 0;
+  const int rc = mijpeg_encode_image(p->dec, p->picture.data(), p->enc_width, p->enc_height, p->enc_depth, (int64_t)p->enc_width * p->enc_depth, p->enc_quality,
+                                     p->enc_hsamp, p->enc_vsamp, p->enc_restart, p->enc_optimize ? 1 : 0, &stream, &size);
+  if (rc) return p->fail_from_decoder(rc);
+  for (size_t at = 0; at < size;) { // io/iostream.cpp: the stream goes out through the hook in pieces
+    const size_t n = size - at < ((size_t)1 << 20) ? size - at : ((size_t)1 << 20);
+    struct JPG_TagItem iotags[] = {
+        JPG_PointerTag(JPGTAG_FIO_HANDLE, tags->GetTagPtr(JPGTAG_HOOK_IOSTREAM)),
+        JPG_PointerTag(JPGTAG_FIO_BUFFER, stream + at),
+        JPG_ValueTag(JPGTAG_FIO_SIZE, (JPG_LONG)n),
+        JPG_ValueTag(JPGTAG_FIO_ACTION, JPGFLAG_ACTION_WRITE),
+        JPG_ValueTag(JPGTAG_FIO_SEEKMODE, JPGFLAG_OFFSET_CURRENT),
+        JPG_ValueTag(JPGTAG_FIO_OFFSET, 0),
+        JPG_PointerTag(JPGTAG_FIO_USERDATA, io->hk_pData),
+        JPG_EndTag};
+    const JPG_LONG put = io->CallLong(iotags);
+    if (put != (JPG_LONG)n) {
+      mijpeg_free(stream);
+      return p->fail(put < 0 ? put : JPGERR_INVALID_PARAMETER, "the I/O hook did not take the data");
+    }
+    at += n;
+  }
+  mijpeg_free(stream);
+  return JPG_TRUE;
+}
 JPG_LONG JPEG::PeekMarker(struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }
 JPG_LONG JPEG::ReadMarker(void *, JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }
 JPG_LONG JPEG::SkipMarker(JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }

@@ -1,7 +1,7 @@
 // jpeg.hpp -- class JPEG, the library object of the tag/hook API, decode half.
 // Mirrors the public surface of the reference's interface/jpeg.hpp:185-252 (same member names, argument
 // meaning, return conventions: JPG_TRUE / JPG_FALSE, error via LastError) on top of the C ABI of
-// include/mijpeg.h.  Calls of the encoder half fail with JPGERR_NOT_IMPLEMENTED.
+// include/mijpeg.h.  Encoder half: ProvideImage / Write for baseline frames; WriteMarker answers JPGERR_NOT_IMPLEMENTED.
 #ifndef MIJ_INTERFACE_JPEG_HPP
 #define MIJ_INTERFACE_JPEG_HPP
 #include "jpgtypes.hpp"
