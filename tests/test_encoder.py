@@ -133,3 +133,41 @@ def test_coefficients_outside_the_8_bit_range_are_refused():
     with pytest.raises(api.MijpegError):
         api.encode_coefficients(info, coef, optimize=True)
 
+
+
+def test_encoder_entry_points_reject_bad_arguments_without_a_device():
+    """Argument checks of the encoder-direction C ABI happen before anything touches a device."""
+    import ctypes as C
+
+    L = api.lib()
+    # frame layout
+    with pytest.raises(api.MijpegError):
+        api.frame_layout(0, 10, 3, (1, 1, 1), (1, 1, 1), [np.ones(64, int)])
+    with pytest.raises(api.MijpegError):
+        api.frame_layout(10, 10, 3, (3, 2, 1), (1, 1, 1), [np.ones(64, int)])  # 3 / 2: fractional subsampling factor
+    with pytest.raises(api.MijpegError):
+        api.frame_layout(10, 10, 3, (5, 1, 1), (1, 1, 1), [np.ones(64, int)])
+    info = api.frame_layout(16, 16, 3, (2, 1, 1), (2, 1, 1), [np.ones(64, int), np.ones(64, int)])
+    assert (info.mcus_x, info.mcus_y, info.blocks_w[0], info.blocks_w[1], info.coef_count) == (1, 1, 2, 1, 6 * 64)
+    # forward launch: null pointers, zero frames, a zero delta
+    with pytest.raises(api.MijpegError):
+        api.launch_forward(info, 0, 0, 1, 48, 768)
+    L.mijpeg_launch_forward.argtypes = [C.POINTER(api.MijpegForwardBatch), C.c_void_p]
+    b = api.MijpegForwardBatch()
+    C.memmove(C.byref(b.info), C.byref(info), C.sizeof(api.MijpegInfo))
+    b.pixels_dev, b.coef_dev, b.frames = 4096, 8192, 0
+    assert L.mijpeg_launch_forward(C.byref(b), None) != 0
+    # whole-picture encode on an object without a device
+    d = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        d.encode(np.zeros((16, 16, 3), np.uint8), 85, "420")
+    assert e.value.code == api.ERR_NOT_AVAILABLE
+    d.close()
+    # entropy coder: restart interval out of range, two components
+    coef = np.zeros(int(info.coef_count), np.int16)
+    with pytest.raises(api.MijpegError):
+        api.encode_coefficients(info, coef, restart_interval=70000)
+    info2 = api.frame_layout(16, 16, 1, (1,), (1,), [np.ones(64, int)], ycbcr=0)
+    info2.components = 2
+    with pytest.raises(api.MijpegError):
+        api.encode_coefficients(info2, np.zeros(int(info2.coef_count), np.int16))
