@@ -1253,6 +1253,13 @@ int mijpeg_launch_forward(const mijpeg_forward_batch *b, void *stream)
   }
   if (blocks > 0xffffffffull) return MIJPEG_ERR_INVALID_PARAMETER;
   a.first_block[f.components] = (uint32_t)blocks;
+  if (a.fast[0] && a.fast[1] && a.fast[2] && f.subx[0] == 1 && f.suby[0] == 1 && f.subx[1] == 2 && f.suby[1] == 2 && f.subx[2] == 2 && f.suby[2] == 2 &&
+      f.width >= 128 && f.height >= 128 && !getenv("MIJPEG_FORWARD_NO_TILES")) {
+    a.tiled420 = 1;
+    const int tx = f.width >> 7, ty = f.height >> 7;
+    a.fast_nbx[0] = tx * 16; a.fast_nby[0] = ty * 16;
+    for (int c = 1; c < 3; c++) { a.fast_nbx[c] = tx * 8; a.fast_nby[c] = ty * 8; }
+  }
   return launch_forward(a, (hipStream_t)stream) ? MIJPEG_ERR_DEVICE : MIJPEG_OK;
 }
 

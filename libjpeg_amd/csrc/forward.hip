@@ -211,6 +211,68 @@ __global__ __launch_bounds__(256) void fdct_blocks_kernel(const ForwardArgs a)
   transform_and_store(blk, a.invq[c], dst);
 }
 
+// 4:2:0, tiles of 128 x 128 pixels that lie wholly inside the picture: one workgroup of 256 lanes per tile.  Every lane reads
+// the 8 x 8 pixels of ONE luma block once (48 dwords, one memory round trip), computes Y, Cb and Cr of each, transforms the
+// luma block, and leaves the 4 x 4 box-filtered chroma samples of its pixels (sums of 2 x 2, >> 2) in LDS; after a
+// barrier 128 lanes pick up the 64 + 64 chroma blocks of the tile and transform them.  Compared with the per-component
+// kernels no pixel is fetched or unpacked twice.  grid (tiles_x * tiles_y, frames)
+__global__ __launch_bounds__(256, 2) void fdct420_tile_kernel(const ForwardArgs a)
+{
+  __shared__ short chroma[2][64 * 64]; // [Cb, Cr][64 lines of 64 samples]
+  const int tiles_x = a.width >> 7;
+  const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+  const unsigned frame = blockIdx.y;
+  const uint8_t *img = a.pixels + (int64_t)frame * a.pixel_frame_stride;
+  int16_t *coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+  const int lane = threadIdx.x;
+  const int lbx = lane & 15, lby = lane >> 4; // luma block inside the tile
+  const int x0 = tx * 128 + lbx * 8, y0 = ty * 128 + lby * 8;
+  {
+    unsigned dw[8][6];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const unsigned *line = reinterpret_cast<const unsigned *>(img + (int64_t)(y0 + r) * a.pixel_row_stride + (int64_t)x0 * 3);
+#pragma unroll
+      for (int i = 0; i < 6; i++) dw[r][i] = line[i];
+    }
+    int blk[64];
+    short *cb = chroma[0] + (lby * 4) * 64 + lbx * 4, *cr = chroma[1] + (lby * 4) * 64 + lbx * 4;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+      int sb[4] = {0, 0, 0, 0}, sr[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int j = 3 * i;
+          const unsigned *d = dw[r + rr];
+          const int r8 = (int)((d[j >> 2] >> (8 * (j & 3))) & 0xffu), g8 = (int)((d[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xffu),
+                    b8 = (int)((d[(j + 2) >> 2] >> (8 * ((j + 2) & 3))) & 0xffu);
+          blk[(r + rr) * 8 + i] = ycc_component(0, r8, g8, b8);
+          sb[i >> 1] += ycc_component(1, r8, g8, b8);
+          sr[i >> 1] += ycc_component(2, r8, g8, b8);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        cb[(r >> 1) * 64 + i] = (short)(sb[i] >> 2);
+        cr[(r >> 1) * 64 + i] = (short)(sr[i] >> 2);
+      }
+    }
+    transform_and_store(blk, a.invq[0], coef + a.coef_off[0] + ((int64_t)(y0 >> 3) * a.bw[0] + (x0 >> 3)) * 64);
+  }
+  __syncthreads();
+  if (lane < 128) {
+    const int c = 1 + (lane >> 6), n = lane & 63, cbx = n & 7, cby = n >> 3;
+    const short *src = chroma[c - 1] + (cby * 8) * 64 + cbx * 8;
+    int blk[64];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) blk[r * 8 + i] = src[r * 64 + i];
+    transform_and_store(blk, a.invq[c], coef + a.coef_off[c] + ((int64_t)(ty * 8 + cby) * a.bw[c] + (tx * 8 + cbx)) * 64);
+  }
+}
+
 // the interior blocks of component c: grid (blocks of 256 lanes over fast_nbx * fast_nby, frames)
 template <int SX, int SY>
 __global__ __launch_bounds__(256, SX * SY == 4 ? 2 : 3) void fdct_interior_kernel(const ForwardArgs a, int c)
@@ -230,8 +292,9 @@ int launch_forward(const ForwardArgs &a, hipStream_t stream)
 {
   const unsigned per_frame = a.first_block[a.ncomp];
   if (per_frame == 0 || a.frames < 1) return 0;
+  if (a.tiled420) hipLaunchKernelGGL(fdct420_tile_kernel, dim3((unsigned)(a.width >> 7) * (unsigned)(a.height >> 7), a.frames), dim3(256), 0, stream, a);
   for (int c = 0; c < a.ncomp; c++) {
-    if (!a.fast[c]) continue;
+    if (!a.fast[c] || a.tiled420) continue; // (with tiles, the generic kernel takes what lies outside them)
     const unsigned n = (unsigned)a.fast_nbx[c] * (unsigned)a.fast_nby[c];
     if (n == 0) continue;
     const dim3 grid((n + 255) / 256, a.frames);

@@ -42,7 +42,7 @@ for sub in os.environ.get("LAYOUTS", "420,422,444").split(","):
     api.launch_reconstruct(ref, coef.data_ptr(), out.data_ptr(), 1, W * 3, H * W * 3, n, stream=stream.cuda_stream)
     torch.cuda.synchronize()
     err = (out[0].cpu().numpy().reshape(H, W, 3).astype(np.int16) - img).astype(np.float64)
-    print(f"{sub}: fdct_interior_kernel x3 + fdct_blocks_kernel {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px); "
+    print(f"{sub}: {'fdct420_tile_kernel' if sub == '420' else 'fdct_interior_kernel x3'} + fdct_blocks_kernel {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px); "
           f"round trip through the fused decoder: PSNR {10*np.log10(255**2/np.mean(err**2)):.1f} dB", flush=True)
 # whole pipeline for one 8K picture in host memory (upload, kernels, download of the coefficients, entropy coder on the host cores)
 import time
