@@ -312,7 +312,7 @@ def main():
             result["end_to_end"]["encoder_direction"] = {
                 "forward_kernels": {"value": round(W * H * FE / fms / 1e3, 1), "unit": "Mpixels/s", "ms": round(fms, 3), "frames": FE,
                                     "algorithmic_GBps": round(W * H * FE * 6 / fms / 1e6, 1),
-                                    "note": "RGB in HBM -> YCbCr 4:2:0 -> FDCT -> quantiser -> int16 planes in HBM (fdct_interior_kernel x3 + fdct_blocks_kernel)"},
+                                    "note": "RGB in HBM -> YCbCr 4:2:0 -> FDCT -> quantiser -> int16 planes in HBM (fdct420_tile_kernel + fdct_blocks_kernel for the edges)"},
                 "encode_picture": {"value": round(W * H / min(te) / 1e6, 1), "unit": "Mpixels/s", "ms": round(min(te) * 1e3, 2), "stream_bytes": len(stream_bytes),
                                    "note": "one 8K picture in host memory -> baseline JPEG, restart interval 8, Annex K tables: the reference "
                                            "encoder's tables and coefficients (mijpeg_encode_image)"}}
