@@ -8,11 +8,16 @@
 // Everything is integer arithmetic; the results are the reference's bits (oracle/jpeg_oracle.c: oj_forward, pinned
 // against the coefficients the reference encoder writes).
 //
-// One lane, one coefficient block of one component: it gathers the subx*8 x suby*8 pixels its block covers straight
-// from the interleaved image (converting only the component it needs), averages, transforms, quantises and stores
-// 128 bytes.  No intermediate planes: the only HBM traffic is the image (3 bytes per pixel, re-read from L2 by the
-// chroma blocks) and the coefficients.  The integer work is in 32-bit wrapping arithmetic like the reference's LONG;
-// the quantiser is its 64-bit multiply-and-shift.
+// One lane, one coefficient block; no intermediate planes: the only HBM traffic is the image and the coefficients
+// (128-byte stores in the decoder's plane layout).  Three kernels share the blocks of a frame:
+//   fdct420_tile_kernel    4:2:0, 128 x 128 tiles wholly inside the picture: luma lanes read their pixels once and leave the
+//                          box-filtered chroma samples in LDS for the lanes that transform the chroma blocks
+//   fdct_interior_kernel   other layouts with subsampling factors 1 or 2: whole blocks inside the picture, pixels read as
+//                          dwords in batches, only the block's own component converted
+//   fdct_blocks_kernel     everything else (edges with pre-fill / mirror / missing lines, 3x and 4x factors, grey, identity
+//                          transformation): per-pixel gather
+// The integer work is in 32-bit wrapping arithmetic like the reference's LONG; the quantiser is its 64-bit
+// multiply-and-shift.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
