@@ -54,8 +54,9 @@ struct mijpeg_decoder {
   double phase_prepare = 0, phase_device = 0; // last device entropy decode: host tables / upload + kernel
   uint8_t *enc_dev = nullptr; // encoder direction: pixels + coefficients of one picture
   size_t enc_cap = 0;
-  uint8_t *henc_dev = nullptr, *henc_out_dev = nullptr; // device entropy coder: block / interval arrays; streams
-  size_t henc_cap = 0, henc_out_cap = 0;
+  uint8_t *henc_dev[2] = {nullptr, nullptr}, *henc_out_dev[2] = {nullptr, nullptr}; // device entropy coder, two jobs: arrays; streams
+  size_t henc_cap[2] = {0, 0}, henc_out_cap[2] = {0, 0};
+  uint64_t *henc_host = nullptr; // pinned: byte counts read back from the device, code tables on their way up
   uint8_t *walk_dev = nullptr, *walk_host = nullptr; // state of the device walk over streams without restart markers
   size_t walk_cap = 0, walk_host_cap = 0;
   int walk_rounds = 0;
@@ -136,8 +137,11 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->stage_host) (void)hipHostFree(d->stage_host);
     if (d->walk_dev) (void)hipFree(d->walk_dev);
     if (d->enc_dev) (void)hipFree(d->enc_dev);
-    if (d->henc_dev) (void)hipFree(d->henc_dev);
-    if (d->henc_out_dev) (void)hipFree(d->henc_out_dev);
+    for (int k = 0; k < 2; k++) {
+      if (d->henc_dev[k]) (void)hipFree(d->henc_dev[k]);
+      if (d->henc_out_dev[k]) (void)hipFree(d->henc_out_dev[k]);
+    }
+    if (d->henc_host) (void)hipHostFree(d->henc_host);
     if (d->walk_host) (void)hipHostFree(d->walk_host);
     for (hipEvent_t e : d->copy_events) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
@@ -1279,132 +1283,183 @@ void mijpeg_quality_tables(int quality, uint16_t luma[64], uint16_t chroma[64])
   }
 }
 
-// Entropy coding of one frame's coefficient planes on the device (hencode.hip) and download of the finished stream.
+// Entropy coding of one frame's coefficient planes on the device (hencode.hip) and download of the finished stream, as a
+// job of three stages with a host synchronisation in front of the second and the third (the byte counts the next stage
+// sizes its buffers and copies with come from the device).  Two jobs on two streams with two sets of buffers overlap:
+// mijpeg_encode_batch_device keeps the next frame's first stage in flight while it waits for the current frame.
+struct HencJob {
+  mijpeg_decoder *d = nullptr;
+  const mijpeg_info *f = nullptr;
+  int slot = 0, restart_interval = 0;
+  hipStream_t stream = nullptr;
+  HencArgs a;
+  EncTables tabs;
+  uint64_t *readback = nullptr; // pinned: [0] plain bytes, [1] 0xFF bytes
+  uint64_t *scratch = nullptr;
+  uint32_t chunks = 0;
+  uint8_t *result = nullptr;
+  size_t head_size = 0, ecs = 0;
+  std::vector<uint8_t> head;
+
+  static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+  int upload_tables()
+  {
+    HencTables *h = (HencTables *)((uint8_t *)d->henc_host + 64 + (size_t)slot * sizeof(HencTables)); // pinned, one per slot
+    memset(h, 0, sizeof(*h));
+    for (int t = 0; t < 2; t++) {
+      for (int k = 0; k < 16; k++) { h->dc_code[t][k] = tabs.dc[t].code[k]; h->dc_len[t][k] = tabs.dc[t].len[k]; }
+      for (int k = 0; k < 256; k++) { h->ac_code[t][k] = tabs.ac[t].code[k]; h->ac_len[t][k] = tabs.ac[t].len[k]; }
+    }
+    HIP_TRY(d, hipMemcpyAsync((void *)a.tables, h, sizeof(*h), hipMemcpyHostToDevice, stream));
+    return MIJPEG_OK;
+  }
+
+  // geometry, buffers, tables (optimised ones cost a synchronisation of their own), then count + prefix sums
+  int stage_a(mijpeg_decoder *dec, const mijpeg_info &info, const int16_t *coef_dev, int ri, int optimize, int slot_, hipStream_t st)
+  {
+    d = dec; f = &info; slot = slot_; stream = st; restart_interval = ri;
+    const int nc = info.components;
+    memset(&a, 0, sizeof(a));
+    a.coef = coef_dev;
+    a.ncomp = nc;
+    a.mcus_x = info.mcus_x;
+    a.total_mcus = info.mcus_x * info.mcus_y;
+    a.ri = ri ? ri : a.total_mcus;
+    int B = 0;
+    for (int c = 0; c < nc; c++) {
+      a.hs[c] = nc > 1 ? info.hsamp[c] : 1;
+      a.vs[c] = nc > 1 ? info.vsamp[c] : 1;
+      a.bw[c] = info.blocks_w[c];
+      a.nbx[c] = ((info.width + info.subx[c] - 1) / info.subx[c] + 7) >> 3;
+      a.nby[c] = ((info.height + info.suby[c] - 1) / info.suby[c] + 7) >> 3;
+      a.coef_off[c] = info.coef_offset[c];
+      for (int by = 0; by < a.vs[c]; by++)
+        for (int bx = 0; bx < a.hs[c]; bx++) {
+          if (B >= 64) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many blocks per MCU for the device entropy coder");
+          a.blk_comp[B] = (uint8_t)c;
+          a.blk_bx[B] = (uint8_t)bx;
+          a.blk_by[B] = (uint8_t)by;
+          B++;
+        }
+    }
+    a.blocks_per_mcu = B;
+    const uint64_t nblocks = (uint64_t)a.total_mcus * (uint64_t)B;
+    if (nblocks >= ((uint64_t)1 << 30)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "frame too large for the device entropy coder");
+    a.total_blocks = (uint32_t)nblocks;
+    a.n_intervals = (uint32_t)((a.total_mcus + a.ri - 1) / a.ri);
+    const uint32_t N = a.total_blocks, I = a.n_intervals;
+    // arena 1: tables, statistics, block and interval arrays, scan scratch
+    size_t o = 0;
+    const size_t o_tab = o; o = al(o + sizeof(HencTables));
+    const size_t o_hist = o; o = al(o + 4 * 256 * 4);
+    const size_t o_bits = o; o = al(o + (size_t)N * 4);
+    const size_t o_bitpos = o; o = al(o + ((size_t)N + 1) * 8);
+    const size_t o_ibytes = o; o = al(o + (size_t)I * 4);
+    const size_t o_istart = o; o = al(o + ((size_t)I + 1) * 8);
+    const size_t scratch_words = ((size_t)N / 1024 + 8) * 2 + 8192;
+    const size_t o_scratch = o; o = al(o + scratch_words * 8);
+    int rc = ensure_dev(d, (void **)&d->henc_dev[slot], &d->henc_cap[slot], o);
+    if (rc) return rc;
+    if (!d->henc_host) HIP_TRY(d, hipHostMalloc((void **)&d->henc_host, 64 + 2 * sizeof(HencTables), hipHostMallocDefault));
+    readback = d->henc_host + 2 * slot;
+    uint8_t *base = d->henc_dev[slot];
+    a.tables = (const HencTables *)(base + o_tab);
+    a.hist = (uint32_t *)(base + o_hist);
+    a.bits = (uint32_t *)(base + o_bits);
+    a.bitpos = (const uint64_t *)(base + o_bitpos);
+    a.ibytes = (uint32_t *)(base + o_ibytes);
+    a.istart = (const uint64_t *)(base + o_istart);
+    scratch = (uint64_t *)(base + o_scratch);
+    enc_standard_tables(tabs);
+    rc = upload_tables();
+    if (rc) return rc;
+    if (optimize) { // symbol statistics first, tables from them (Annex K.2)
+      HIP_TRY(d, hipMemsetAsync(base + o_hist, 0, 4 * 256 * 4, stream));
+      if (henc_count(a, true, stream)) return hip_fail(d, hipGetLastError(), "henc_count_kernel launch");
+      uint32_t hist[4][256];
+      HIP_TRY(d, hipMemcpyAsync(hist, base + o_hist, sizeof(hist), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(d, hipStreamSynchronize(stream));
+      enc_optimal_tables(tabs, hist, hist + 2, nc > 1 ? 2 : 1);
+      rc = upload_tables();
+      if (rc) return rc;
+    }
+    if (henc_count(a, false, stream)) return hip_fail(d, hipGetLastError(), "henc_count_kernel launch");
+    if (exclusive_scan_u32(a.bits, (uint64_t *)a.bitpos, N, scratch, stream)) return hip_fail(d, hipGetLastError(), "scan launch");
+    if (henc_interval_bytes(a, stream)) return hip_fail(d, hipGetLastError(), "henc_interval_bytes_kernel launch");
+    if (exclusive_scan_u32(a.ibytes, (uint64_t *)a.istart, I, scratch, stream)) return hip_fail(d, hipGetLastError(), "scan launch");
+    HIP_TRY(d, hipMemcpyAsync(&readback[0], a.istart + I, 8, hipMemcpyDeviceToHost, stream));
+    return MIJPEG_OK;
+  }
+
+  // plain stream, stuffing
+  int stage_b()
+  {
+    HIP_TRY(d, hipStreamSynchronize(stream));
+    const uint64_t plain_bytes = readback[0];
+    const uint32_t I = a.n_intervals;
+    // (coefficients the forward kernels make of 8-bit pixels always have a code: at most 11 / 10 bits, the host coder's check)
+    chunks = (uint32_t)((plain_bytes + 255) / 256);
+    size_t q = 0;
+    const size_t q_plain = q; q = al(q + (size_t)plain_bytes + 16);
+    const size_t q_ffc = q; q = al(q + (size_t)chunks * 4 + 4);
+    const size_t q_ffs = q; q = al(q + ((size_t)chunks + 1) * 8);
+    const size_t q_out = q; q = al(q + (size_t)plain_bytes * 2 + (size_t)I * 2 + 16);
+    const int rc = ensure_dev(d, (void **)&d->henc_out_dev[slot], &d->henc_out_cap[slot], q);
+    if (rc) return rc;
+    uint8_t *ob = d->henc_out_dev[slot];
+    a.plain = (uint32_t *)(ob + q_plain);
+    a.plain_bytes = plain_bytes;
+    a.ffcount = (uint32_t *)(ob + q_ffc);
+    a.ffstart = (const uint64_t *)(ob + q_ffs);
+    a.out = ob + q_out;
+    HIP_TRY(d, hipMemsetAsync(ob + q_plain, 0, al((size_t)plain_bytes + 16), stream));
+    if (henc_emit(a, stream)) return hip_fail(d, hipGetLastError(), "henc_emit_kernel launch");
+    if (henc_count_ff(a, stream)) return hip_fail(d, hipGetLastError(), "henc_count_ff_kernel launch");
+    if (exclusive_scan_u32(a.ffcount, (uint64_t *)a.ffstart, chunks, scratch, stream)) return hip_fail(d, hipGetLastError(), "scan launch");
+    if (henc_stuff(a, stream)) return hip_fail(d, hipGetLastError(), "henc_stuff_kernel launch");
+    HIP_TRY(d, hipMemcpyAsync(&readback[1], a.ffstart + chunks, 8, hipMemcpyDeviceToHost, stream));
+    return MIJPEG_OK;
+  }
+
+  // headers on the host, download of the entropy coded data behind them
+  int stage_c()
+  {
+    HIP_TRY(d, hipStreamSynchronize(stream));
+    ecs = (size_t)a.plain_bytes + (size_t)readback[1] + (size_t)(a.n_intervals - 1) * 2;
+    head.clear();
+    enc_write_headers(head, *f, tabs, restart_interval);
+    head_size = head.size();
+    result = (uint8_t *)malloc(head_size + ecs + 2);
+    if (!result) return set_error(d, MIJPEG_ERR_OUT_OF_MEMORY, "out of memory for the stream");
+    memcpy(result, head.data(), head_size);
+    const hipError_t e = hipMemcpyAsync(result + head_size, a.out, ecs, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) { free(result); result = nullptr; return hip_fail(d, e, "download of the stream"); }
+    return MIJPEG_OK;
+  }
+
+  int finish(uint8_t **out_stream, size_t *out_size)
+  {
+    const hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { free(result); result = nullptr; return hip_fail(d, e, "download of the stream"); }
+    result[head_size + ecs] = 0xff;
+    result[head_size + ecs + 1] = 0xd9;
+    *out_stream = result;
+    *out_size = head_size + ecs + 2;
+    result = nullptr;
+    return MIJPEG_OK;
+  }
+};
+
 static int device_entropy_code(mijpeg_decoder *d, const mijpeg_info &f, const int16_t *coef_dev, int restart_interval, int optimize,
                                uint8_t **stream, size_t *size)
 {
-  const int nc = f.components;
-  HencArgs a;
-  memset(&a, 0, sizeof(a));
-  a.coef = coef_dev;
-  a.ncomp = nc;
-  a.mcus_x = f.mcus_x;
-  a.total_mcus = f.mcus_x * f.mcus_y;
-  a.ri = restart_interval ? restart_interval : a.total_mcus;
-  int B = 0;
-  for (int c = 0; c < nc; c++) {
-    a.hs[c] = nc > 1 ? f.hsamp[c] : 1;
-    a.vs[c] = nc > 1 ? f.vsamp[c] : 1;
-    a.bw[c] = f.blocks_w[c];
-    a.nbx[c] = ((f.width + f.subx[c] - 1) / f.subx[c] + 7) >> 3;
-    a.nby[c] = ((f.height + f.suby[c] - 1) / f.suby[c] + 7) >> 3;
-    a.coef_off[c] = f.coef_offset[c];
-    for (int by = 0; by < a.vs[c]; by++)
-      for (int bx = 0; bx < a.hs[c]; bx++) {
-        if (B >= 64) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many blocks per MCU for the device entropy coder");
-        a.blk_comp[B] = (uint8_t)c;
-        a.blk_bx[B] = (uint8_t)bx;
-        a.blk_by[B] = (uint8_t)by;
-        B++;
-      }
-  }
-  a.blocks_per_mcu = B;
-  const uint64_t nblocks = (uint64_t)a.total_mcus * (uint64_t)B;
-  if (nblocks >= ((uint64_t)1 << 30)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "frame too large for the device entropy coder");
-  a.total_blocks = (uint32_t)nblocks;
-  a.n_intervals = (uint32_t)((a.total_mcus + a.ri - 1) / a.ri);
-  const uint32_t N = a.total_blocks, I = a.n_intervals;
-  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  // arena 1: tables, statistics, block and interval arrays, scan scratch
-  size_t o = 0;
-  const size_t o_tab = o; o = al(o + sizeof(HencTables));
-  const size_t o_hist = o; o = al(o + 4 * 256 * 4);
-  const size_t o_bits = o; o = al(o + (size_t)N * 4);
-  const size_t o_bitpos = o; o = al(o + ((size_t)N + 1) * 8);
-  const size_t o_ibytes = o; o = al(o + (size_t)I * 4);
-  const size_t o_istart = o; o = al(o + ((size_t)I + 1) * 8);
-  const size_t scratch_words = ((size_t)N / 1024 + 8) * 2 + 8192;
-  const size_t o_scratch = o; o = al(o + scratch_words * 8);
-  int rc = ensure_dev(d, (void **)&d->henc_dev, &d->henc_cap, o);
-  if (rc) return rc;
-  uint8_t *base = d->henc_dev;
-  a.tables = (const HencTables *)(base + o_tab);
-  a.hist = (uint32_t *)(base + o_hist);
-  a.bits = (uint32_t *)(base + o_bits);
-  a.bitpos = (const uint64_t *)(base + o_bitpos);
-  a.ibytes = (uint32_t *)(base + o_ibytes);
-  a.istart = (const uint64_t *)(base + o_istart);
-  uint64_t *scratch = (uint64_t *)(base + o_scratch);
-  EncTables tabs;
-  enc_standard_tables(tabs);
-  auto upload_tables = [&]() -> int {
-    HencTables h;
-    memset(&h, 0, sizeof(h));
-    for (int t = 0; t < 2; t++) {
-      for (int k = 0; k < 16; k++) { h.dc_code[t][k] = tabs.dc[t].code[k]; h.dc_len[t][k] = tabs.dc[t].len[k]; }
-      for (int k = 0; k < 256; k++) { h.ac_code[t][k] = tabs.ac[t].code[k]; h.ac_len[t][k] = tabs.ac[t].len[k]; }
-    }
-    HIP_TRY(d, hipMemcpyAsync(base + o_tab, &h, sizeof(h), hipMemcpyHostToDevice, d->stream));
-    HIP_TRY(d, hipStreamSynchronize(d->stream)); // h lives on this stack frame
-    return MIJPEG_OK;
-  };
-  rc = upload_tables();
-  if (rc) return rc;
-  if (optimize) { // symbol statistics first, tables from them (Annex K.2)
-    HIP_TRY(d, hipMemsetAsync(base + o_hist, 0, 4 * 256 * 4, d->stream));
-    if (henc_count(a, true, d->stream)) return hip_fail(d, hipGetLastError(), "henc_count_kernel launch");
-    uint32_t hist[4][256];
-    HIP_TRY(d, hipMemcpyAsync(hist, base + o_hist, sizeof(hist), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(d, hipStreamSynchronize(d->stream));
-    enc_optimal_tables(tabs, hist, hist + 2, nc > 1 ? 2 : 1);
-    rc = upload_tables();
-    if (rc) return rc;
-  }
-  if (henc_count(a, false, d->stream)) return hip_fail(d, hipGetLastError(), "henc_count_kernel launch");
-  if (exclusive_scan_u32(a.bits, (uint64_t *)a.bitpos, N, scratch, d->stream)) return hip_fail(d, hipGetLastError(), "scan launch");
-  if (henc_interval_bytes(a, d->stream)) return hip_fail(d, hipGetLastError(), "henc_interval_bytes_kernel launch");
-  if (exclusive_scan_u32(a.ibytes, (uint64_t *)a.istart, I, scratch, d->stream)) return hip_fail(d, hipGetLastError(), "scan launch");
-  uint64_t plain_bytes = 0;
-  HIP_TRY(d, hipMemcpyAsync(&plain_bytes, a.istart + I, 8, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(d, hipStreamSynchronize(d->stream));
-  // (coefficients the forward kernels make of 8-bit pixels always have a code: at most 11 / 10 bits, the host coder's check)
-  // arena 2: plain stream, 0xFF counts, stuffed stream
-  const uint32_t chunks = (uint32_t)((plain_bytes + 255) / 256);
-  size_t q = 0;
-  const size_t q_plain = q; q = al(q + (size_t)plain_bytes + 16);
-  const size_t q_ffc = q; q = al(q + (size_t)chunks * 4 + 4);
-  const size_t q_ffs = q; q = al(q + ((size_t)chunks + 1) * 8);
-  const size_t q_out = q; q = al(q + (size_t)plain_bytes * 2 + (size_t)I * 2 + 16);
-  rc = ensure_dev(d, (void **)&d->henc_out_dev, &d->henc_out_cap, q);
-  if (rc) return rc;
-  uint8_t *ob = d->henc_out_dev;
-  a.plain = (uint32_t *)(ob + q_plain);
-  a.plain_bytes = plain_bytes;
-  a.ffcount = (uint32_t *)(ob + q_ffc);
-  a.ffstart = (const uint64_t *)(ob + q_ffs);
-  a.out = ob + q_out;
-  HIP_TRY(d, hipMemsetAsync(ob + q_plain, 0, al((size_t)plain_bytes + 16), d->stream));
-  if (henc_emit(a, d->stream)) return hip_fail(d, hipGetLastError(), "henc_emit_kernel launch");
-  if (henc_count_ff(a, d->stream)) return hip_fail(d, hipGetLastError(), "henc_count_ff_kernel launch");
-  if (exclusive_scan_u32(a.ffcount, (uint64_t *)a.ffstart, chunks, scratch, d->stream)) return hip_fail(d, hipGetLastError(), "scan launch");
-  if (henc_stuff(a, d->stream)) return hip_fail(d, hipGetLastError(), "henc_stuff_kernel launch");
-  uint64_t ff_total = 0;
-  HIP_TRY(d, hipMemcpyAsync(&ff_total, a.ffstart + chunks, 8, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(d, hipStreamSynchronize(d->stream));
-  const size_t ecs = (size_t)plain_bytes + (size_t)ff_total + (size_t)(I - 1) * 2;
-  std::vector<uint8_t> head;
-  enc_write_headers(head, f, tabs, restart_interval);
-  uint8_t *p = (uint8_t *)malloc(head.size() + ecs + 2);
-  if (!p) return set_error(d, MIJPEG_ERR_OUT_OF_MEMORY, "out of memory for the stream");
-  memcpy(p, head.data(), head.size());
-  hipError_t e = hipMemcpyAsync(p + head.size(), a.out, ecs, hipMemcpyDeviceToHost, d->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-  if (e != hipSuccess) { free(p); return hip_fail(d, e, "download of the stream"); }
-  p[head.size() + ecs] = 0xff;
-  p[head.size() + ecs + 1] = 0xd9;
-  *stream = p;
-  *size = head.size() + ecs + 2;
-  return MIJPEG_OK;
+  HencJob job;
+  int rc = job.stage_a(d, f, coef_dev, restart_interval, optimize, 0, d->stream);
+  if (!rc) rc = job.stage_b();
+  if (!rc) rc = job.stage_c();
+  if (!rc) rc = job.finish(stream, size);
+  return rc;
 }
 
 int mijpeg_encode_batch_device(mijpeg_decoder *d, const mijpeg_forward_batch *b, int restart_interval, int optimize, uint8_t **streams, size_t *sizes)
@@ -1416,8 +1471,24 @@ int mijpeg_encode_batch_device(mijpeg_decoder *d, const mijpeg_forward_batch *b,
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = mijpeg_launch_forward(b, d->stream);
   if (rc) return set_error(d, rc, "forward kernel launch failed");
-  for (int f = 0; f < b->frames && !rc; f++)
-    rc = device_entropy_code(d, b->info, b->coef_dev + (int64_t)f * b->coef_frame_stride, restart_interval, optimize, &streams[f], &sizes[f]);
+  // frame f on stream f & 1 with buffer set f & 1: while the host waits for one frame's byte counts and download, the
+  // other frame's kernels run
+  if (!d->copy_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+  HIP_TRY(d, hipEventRecord(d->ev0, d->stream));
+  HIP_TRY(d, hipStreamWaitEvent(d->copy_stream, d->ev0, 0));
+  hipStream_t st[2] = {d->stream, d->copy_stream};
+  HencJob jobs[2];
+  auto coef_of = [&](int f) { return b->coef_dev + (int64_t)f * b->coef_frame_stride; };
+  rc = jobs[0].stage_a(d, b->info, coef_of(0), restart_interval, optimize, 0, st[0]);
+  for (int f = 0; f < b->frames && !rc; f++) {
+    HencJob &cur = jobs[f & 1], &nxt = jobs[(f + 1) & 1];
+    if (f + 1 < b->frames) rc = nxt.stage_a(d, b->info, coef_of(f + 1), restart_interval, optimize, (f + 1) & 1, st[(f + 1) & 1]);
+    if (!rc) rc = cur.stage_b();
+    if (!rc) rc = cur.stage_c();
+    if (!rc) rc = cur.finish(&streams[f], &sizes[f]);
+  }
+  (void)hipStreamSynchronize(d->copy_stream);
+  (void)hipStreamSynchronize(d->stream);
   if (rc)
     for (int f = 0; f < b->frames; f++) { free(streams[f]); streams[f] = nullptr; sizes[f] = 0; }
   d->timing[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); // mijpeg_last_timing: the whole call
