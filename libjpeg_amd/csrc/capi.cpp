@@ -1399,7 +1399,7 @@ struct HencJob {
     const uint64_t plain_bytes = readback[0];
     const uint32_t I = a.n_intervals;
     // (coefficients the forward kernels make of 8-bit pixels always have a code: at most 11 / 10 bits, the host coder's check)
-    chunks = (uint32_t)((plain_bytes + 255) / 256);
+    chunks = (uint32_t)((plain_bytes + HENC_STUFF_CHUNK - 1) / HENC_STUFF_CHUNK);
     size_t q = 0;
     const size_t q_plain = q; q = al(q + (size_t)plain_bytes + 16);
     const size_t q_ffc = q; q = al(q + (size_t)chunks * 4 + 4);

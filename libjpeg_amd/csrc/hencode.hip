@@ -9,7 +9,7 @@
 //   scan      exclusive prefix sums (bit position of every block), bytes per restart interval, their prefix sums
 //   emit      one lane per block: the code words, OR-ed into the plain stream at the block's bit position (blocks share
 //             words, hence atomicOr on a zeroed buffer); the last block of an interval pads with one-bits
-//   stuff     0xFF bytes per 256-byte chunk, prefix sums, then every chunk is copied to its place with a zero byte behind
+//   stuff     0xFF bytes per 64-byte chunk, prefix sums, then every chunk is copied to its place with a zero byte behind
 //             every 0xFF and the RSTn markers in front of the intervals
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void henc_emit_kernel(const HencArgs a)
 
 __device__ __forceinline__ uint32_t plain_byte(const uint32_t *plain, uint64_t u) { return (plain[u >> 2] >> (24 - 8 * (int)(u & 3))) & 0xffu; }
 
-constexpr int STUFF_CHUNK = 256;
+constexpr int STUFF_CHUNK = HENC_STUFF_CHUNK;
 
 __global__ __launch_bounds__(256) void henc_count_ff_kernel(const HencArgs a)
 {

@@ -15,6 +15,8 @@ struct HencTables {
 };
 static_assert(sizeof(HencTables) % 16 == 0, "copied to LDS in dwords");
 
+constexpr int HENC_STUFF_CHUNK = 64; // bytes of the plain stream one lane of the stuffing kernels handles
+
 struct HencArgs {
   const int16_t *coef;          // coefficient planes of the frame (decoder layout)
   const HencTables *tables;     // device
@@ -29,7 +31,7 @@ struct HencArgs {
   const uint64_t *istart;       // exclusive prefix sums of ibytes (n_intervals + 1 entries): byte offsets in the plain stream
   uint32_t *plain;              // plain (unstuffed) stream as big-endian 32-bit words, zeroed
   uint64_t plain_bytes;
-  uint32_t *ffcount;            // per 256-byte chunk of the plain stream: 0xFF bytes in it
+  uint32_t *ffcount;            // per HENC_STUFF_CHUNK bytes of the plain stream: 0xFF bytes in them
   const uint64_t *ffstart;      // exclusive prefix sums of ffcount (chunks + 1 entries)
   uint8_t *out;                 // entropy coded data with stuffing and RSTn markers
   uint32_t *hist;               // optional statistics: [2][256] DC symbol counts, [2][256] AC symbol counts

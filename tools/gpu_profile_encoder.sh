@@ -6,7 +6,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 LAYOUTS=420 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o t -- python $ROOT/tools/forward_bench.py > "$OUT/log.txt" 2>&1
-grep -v amdgpu.ids "$OUT/log.txt" | grep "encode one\|Gpixel" | head -12
+grep -v amdgpu.ids "$OUT/log.txt" | grep "encode one\|Gpixel\|resident in HBM" | head -12
 python - <<PY
 import csv, glob
 f = glob.glob("$OUT/t/**/t_kernel_stats.csv", recursive=True)
