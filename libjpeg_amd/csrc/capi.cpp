@@ -1261,8 +1261,8 @@ int mijpeg_launch_forward(const mijpeg_forward_batch *b, void *stream)
       f.width >= 128 && f.height >= 128 && !getenv("MIJPEG_FORWARD_NO_TILES")) {
     a.tiled420 = 1;
     const int tx = f.width >> 7, ty = f.height >> 7;
-    a.fast_nbx[0] = tx * 16; a.fast_nby[0] = ty * 16;
-    for (int c = 1; c < 3; c++) { a.fast_nbx[c] = tx * 8; a.fast_nby[c] = ty * 8; }
+    a.tile_nbx[0] = tx * 16; a.tile_nby[0] = ty * 16;
+    for (int c = 1; c < 3; c++) { a.tile_nbx[c] = tx * 8; a.tile_nby[c] = ty * 8; }
   }
   return launch_forward(a, (hipStream_t)stream) ? MIJPEG_ERR_DEVICE : MIJPEG_OK;
 }

@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256, SX * SY == 4 ? 2 : 3) void fdct_interior_kerne
   const unsigned n = (unsigned)a.fast_nbx[c] * (unsigned)a.fast_nby[c];
   if (gid >= n) return;
   const int by = (int)(gid / (unsigned)a.fast_nbx[c]), bx = (int)(gid - (unsigned)by * (unsigned)a.fast_nbx[c]);
+  if (a.tiled420 && bx < a.tile_nbx[c] && by < a.tile_nby[c]) return; // the tile kernel's
   int16_t *dst = a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[c] + ((int64_t)by * a.bw[c] + bx) * 64;
   const uint8_t *img = a.pixels + (int64_t)frame * a.pixel_frame_stride;
   int blk[64];
@@ -299,7 +300,7 @@ int launch_forward(const ForwardArgs &a, hipStream_t stream)
   if (per_frame == 0 || a.frames < 1) return 0;
   if (a.tiled420) hipLaunchKernelGGL(fdct420_tile_kernel, dim3((unsigned)(a.width >> 7) * (unsigned)(a.height >> 7), a.frames), dim3(256), 0, stream, a);
   for (int c = 0; c < a.ncomp; c++) {
-    if (!a.fast[c] || a.tiled420) continue; // (with tiles, the generic kernel takes what lies outside them)
+    if (!a.fast[c]) continue;
     const unsigned n = (unsigned)a.fast_nbx[c] * (unsigned)a.fast_nby[c];
     if (n == 0) continue;
     const dim3 grid((n + 255) / 256, a.frames);

@@ -16,9 +16,9 @@ struct ForwardArgs {
   // interior blocks -- whole blocks inside the picture: columns < fast_nbx, rows < fast_nby -- of components with subsampling
   // factors 1 or 2 go through fdct_interior_kernel when the lines can be read as dwords (RGB -> YCbCr frames only)
   int32_t fast[4], fast_nbx[4], fast_nby[4];
-  // 4:2:0 frames: the whole 128 x 128 tiles go through fdct420_tile_kernel; fast_nbx / fast_nby then describe the blocks the
-  // tiles cover (multiples of 16 luma / 8 chroma blocks) and the generic kernel takes the rest
-  int32_t tiled420;
+  // 4:2:0 frames: the whole 128 x 128 tiles go through fdct420_tile_kernel (blocks with column < tile_nbx and row < tile_nby);
+  // the interior kernels then only take the whole blocks to the right of and below the tiles
+  int32_t tiled420, tile_nbx[4], tile_nby[4];
   int32_t subx[4], suby[4];       // subsampling factors per component
   int32_t bw[4], bh[4];           // plane size in blocks (MCU padded)
   int32_t nbx[4], nby[4];         // blocks that cover samples: ceil(ceil(W / subx) / 8), ...
