@@ -12,6 +12,7 @@
 #include <new>
 #include <memory>
 #include <string>
+#include <thread>
 
 #include "../../include/mijpeg.h"
 #include "host_decoder.hpp"
@@ -52,6 +53,7 @@ struct mijpeg_decoder {
   size_t ent_host_cap = 0;
   bool host_planes_stale = false; // coefficients live on the device only
   double phase_prepare = 0, phase_device = 0; // last device entropy decode: host tables / upload + kernel
+  mijpeg_decoder *xt_helper = nullptr; // JPEG XT: second context that entropy-decodes the residual codestream concurrently
   uint8_t *enc_dev = nullptr; // encoder direction: pixels + coefficients of one picture
   size_t enc_cap = 0;
   uint8_t *henc_dev[2] = {nullptr, nullptr}, *henc_out_dev[2] = {nullptr, nullptr}; // device entropy coder, two jobs: arrays; streams
@@ -136,6 +138,7 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->ent_host) (void)hipHostFree(d->ent_host);
     if (d->stage_host) (void)hipHostFree(d->stage_host);
     if (d->walk_dev) (void)hipFree(d->walk_dev);
+    if (d->xt_helper) mijpeg_destroy(d->xt_helper);
     if (d->enc_dev) (void)hipFree(d->enc_dev);
     for (int k = 0; k < 2; k++) {
       if (d->henc_dev[k]) (void)hipFree(d->henc_dev[k]);
@@ -814,11 +817,26 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
   // JPEG XT: the planes of the residual frame follow those of the legacy frame in the same store
   int64_t own_count = 0;
   for (int c = 0; c < d->host.info.components; c++) own_count += (int64_t)d->host.info.blocks_w[c] * d->host.info.blocks_h[c] * 64;
-  rc = device_entropy_batch(d, &h, &d->data, &d->size, 1, min_intervals, d->coef_dev, own_count, res != nullptr);
-  if (!rc && res) {
+  if (!res) {
+    rc = device_entropy_batch(d, &h, &d->data, &d->size, 1, min_intervals, d->coef_dev, own_count, false);
+  } else {
+    // JPEG XT: the two codestreams are independent, so the residual one is decoded at the same time by a helper object
+    // (own stream, own buffers) on a thread of its own, straight into the planes behind the legacy frame's
+    if (!d->xt_helper && mijpeg_create(&d->xt_helper, d->device) != MIJPEG_OK) return set_error(d, MIJPEG_ERR_OUT_OF_MEMORY, "no helper decoder for the residual codestream");
     const uint8_t *rdata = res->stream_base();
     const size_t rsize = res->stream_size();
-    rc = device_entropy_batch(d, &res, &rdata, &rsize, 1, min_intervals, d->coef_dev + own_count, res->info.coef_count, true);
+    int rc2 = MIJPEG_OK;
+    std::thread helper([&]() {
+      if (hipSetDevice(d->device) != hipSuccess) { rc2 = MIJPEG_ERR_DEVICE; return; }
+      rc2 = device_entropy_batch(d->xt_helper, &res, &rdata, &rsize, 1, min_intervals, d->coef_dev + own_count, res->info.coef_count, true);
+    });
+    rc = device_entropy_batch(d, &h, &d->data, &d->size, 1, min_intervals, d->coef_dev, own_count, true);
+    helper.join();
+    if (!rc && rc2) {
+      const char *m = nullptr;
+      mijpeg_last_error(d->xt_helper, &m);
+      rc = set_error(d, rc2, m ? m : "residual codestream: device entropy decoding failed");
+    }
     if (!rc) {
       for (int c = 0; c < MIJPEG_MAX_COMPONENTS; c++) d->host.xt.residual.range_max[c] = res->info.range_max[c];
       d->host.info.fast_arith = 0; // as HostDecoder::decode has it: the fast flavours are chosen per kernel for XT
