@@ -350,6 +350,37 @@ __device__ __forceinline__ void dequant_idct_column(const u32x4 (&rows)[8], cons
   idct_1d<true, 12>(col[0], col[1], col[2], col[3], col[4], col[5], col[6], col[7]);
 }
 
+// One LINE (y = 0 or y = 7) of a block's samples: the first pass in full, then per column the inner product of its eight results
+// with the corresponding row of the transform's integer matrix (see dequant_idct_column).  FAST arithmetic, no level shift.
+__device__ __forceinline__ void dequant_idct_line(const u32x4 (&rows)[8], const int *__restrict__ q, bool last, int (&line)[8])
+{
+  constexpr int E2 = FIX9(0.541196100) + FIX9(0.765366865), E4 = 512, E6 = FIX9(0.541196100);
+  constexpr int O1 = FIX9(1.501321110) - FIX9(0.899976223) - FIX9(0.390180644) + FIX9(1.175875602), O3 = FIX9(1.175875602),
+                O5 = FIX9(1.175875602) - FIX9(0.390180644), O7 = FIX9(1.175875602) - FIX9(0.899976223);
+  int t[64];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const unsigned w[4] = {rows[r].x, rows[r].y, rows[r].z, rows[r].w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      t[r * 8 + 2 * i] = mul16_lo(w[i], q[r * 8 + 2 * i]);
+      t[r * 8 + 2 * i + 1] = mul16_hi(w[i], q[r * 8 + 2 * i + 1]);
+    }
+    idct_1d<true, 9>(t[r * 8 + 0], t[r * 8 + 1], t[r * 8 + 2], t[r * 8 + 3], t[r * 8 + 4], t[r * 8 + 5], t[r * 8 + 6], t[r * 8 + 7]);
+  }
+#pragma unroll
+  for (int x = 0; x < 8; x++) {
+    int even = (t[x] << 9) + (1 << 11), odd = __mul24(t[8 + x], O1);
+    even = mad24(t[16 + x], E2, even);
+    odd = mad24(t[24 + x], O3, odd);
+    even = mad24(t[32 + x], E4, even);
+    odd = mad24(t[40 + x], O5, odd);
+    even = mad24(t[48 + x], E6, even);
+    odd = mad24(t[56 + x], O7, odd);
+    line[x] = (last ? even - odd : even + odd) >> 12; // y = 7 : y = 0
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // colour transform of one pixel (colortrafo/ycbcrtrafo.cpp:842-850 + clamp :921-936)
 // FIX_BITS = 13, matrix = TO_FIX of {1,0,1.402; 1,-0.3441362861,-0.7141362859; 1,1.772,0}
@@ -1065,6 +1096,183 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
         }
       }
     }
+  }
+}
+
+// ==============================================================================================
+// fused 4:4:0 kernel (Y 1x1, Cb/Cr subsampled 1x2: what a losslessly rotated 4:2:2 picture is), packed chroma
+// ==============================================================================================
+// The 4:2:2 kernel turned by ninety degrees: chroma planes of full width and half height, so a 128x128 tile holds 16 x 8
+// chroma blocks per component = one transform round for the four waves; of the 16 blocks above and below them the
+// vertical filter needs a single LINE each (dequant_idct_line: the first pass in full, one inner product per column).
+// Vertical filter only (Upsampler<1,2>: VerticalFilterCore<2>, HorizontalFilterCore<1> = copy), same 16-bit gate.
+constexpr int F440_CROWS = 66, F440_CPITCH = 128;
+template <int MINW>
+__global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) unsigned cpair[F440_CROWS * F440_CPITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  { // XCD-aware tile order (see fused420_kernel)
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  // ------------------------------------------------------------------ phase A: chroma -> LDS halves
+  // line pr of the LDS plane is chroma line ty * 64 + pr - 1 (pr = 0 and 65: the lines above and below the tile)
+  {
+    const int comp = wave >> 1; // 0 = Cb (low halves), 1 = Cr (high halves); wave-uniform
+    const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
+    const int gx0 = tx * 16 + (wave & 1) * 8, gy0 = ty * 8; // this wave: eight block columns, the tile's eight block rows
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
+    u32x4 rows[8];
+    { // local block n = (lane >> 3) + 8 m: column n & 7 = lane >> 3, row n >> 3 = m
+      const int xx = min(gx0 + (lane >> 3), a.bw_c - 1);
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int yy = min(gy0 + m, a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
+      });
+      const int cbx = lane & 7, cby = lane >> 3;
+      if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
+        int v[64];
+        dequant_idct_sparse(rows, a.q[1 + comp], v);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          short *dst = cp + 2 * ((8 * cby + r + 1) * F440_CPITCH + 8 * ((wave & 1) * 8 + cbx));
+#pragma unroll
+          for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
+        }
+      }
+    }
+    { // halo lines: local block n = lane >> 3 (+ 8): side n & 1 (0: the block above, 1: the block below), column n >> 1
+      fetch_blocks16(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int n = (lane >> 3) + 8 * m;
+        const int xx = min(gx0 + (n >> 1), a.bw_c - 1), yy = min(max((n & 1) ? gy0 + 8 : gy0 - 1, 0), a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
+      });
+      const int side = lane & 1, cbx = lane >> 1, gy = side ? gy0 + 8 : gy0 - 1;
+      if (lane < 16 && gy >= 0 && gy < a.bh_c && gx0 + cbx < a.bw_c) {
+        int line[8];
+        dequant_idct_line(rows, a.q[1 + comp], side == 0, line); // the block above: its last line, the one below: its first
+        short *dst = cp + 2 * ((side ? F440_CROWS - 1 : 0) * F440_CPITCH + 8 * ((wave & 1) * 8 + cbx));
+#pragma unroll
+        for (int x = 0; x < 8; x++) dst[2 * x] = (short)line[x];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ edge fix-up (uniform branch): lines only
+  // (upsampler.cpp:100-112: the line above the first and below the last chroma line is that line again)
+  {
+    const int last_row = a.ch - 1 - ty * 64; // last valid chroma line, tile-relative
+    if ((ty == 0) | (last_row < 64)) {
+      if (tid < F440_CPITCH) {
+        unsigned *p = cpair + tid;
+        if (ty == 0) p[0] = p[F440_CPITCH];
+        if (last_row < 64) {
+          const unsigned v = p[(last_row + 1) * F440_CPITCH];
+          for (int pr = last_row + 2; pr < F440_CROWS; pr++) p[pr * F440_CPITCH] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ phase B: luma, upsampling, colour
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  u32x4 rows[8];
+  {
+    const int16_t *__restrict__ plane = coef + a.off_y;
+    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
+  int yv[64];
+  dequant_idct_sparse(rows, a.q[0], yv);
+
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = a.aligned8 && npx == 8;
+  // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns 8 bx + x
+  const unsigned *c_base = cpair + (4 * by) * F440_CPITCH + 8 * bx;
+  auto load8 = [](const unsigned *p, unsigned (&d)[8]) {
+    const u32x4 lo = *reinterpret_cast<const u32x4 *>(p), hi = *reinterpret_cast<const u32x4 *>(p + 4);
+    d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w; d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
+  };
+  unsigned cT[8], cC[8], cB[8];
+  load8(c_base, cT);
+  load8(c_base + F440_CPITCH, cC);
+  const int K = (2048 << 13) + 65536;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    load8(c_base + (m + 2) * F440_CPITCH, cB);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int l = 2 * m + half;
+      // vertical filter (upsampler.cpp:149-165), both components at once; no horizontal filter (HorizontalFilterCore<1>: a copy)
+      unsigned u[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) u[j] = tap13_pk(half ? cB[j] : cT[j], cC[j], (short)(((j & 1) ^ half) ? 1 : 2));
+      if (l < nln) {
+        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+        int rr[8], gg[8], bb[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          const int yk = (yv[l * 8 + x] << 13) + K;
+          rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
+          gg[x] = mad16_hi(u[x], -L_CR_G, mad16_lo(u[x], -L_CB_G, yk));
+          bb[x] = mad16_lo(u[x], L_CB_B, yk);
+        }
+        if (fast_store) {
+          unsigned h[12];
+#pragma unroll
+          for (int x = 0; x < 8; x += 2) {
+            h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
+            h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
+            h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
+          }
+          unsigned w[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+          __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
+          __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
+          __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+        } else {
+#pragma unroll
+          for (int x = 0; x < 8; x++)
+            if (x < npx) {
+              dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
+            }
+        }
+      }
+    }
+    // slide the three-line window
+#pragma unroll
+    for (int j = 0; j < 8; j++) { cT[j] = cC[j]; cC[j] = cB[j]; }
   }
 }
 
@@ -1910,6 +2118,13 @@ int launch_fused1(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
   hipLaunchKernelGGL(fused1_kernel, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused440(const Fused420Args &a, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  hipLaunchKernelGGL((fused440_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

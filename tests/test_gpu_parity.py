@@ -82,6 +82,48 @@ def test_fused422_vs_oracle(dec, oracle, w, h, flags):
     assert bad == 0, f"{bad} differing samples, first at {np.argwhere(out != exp)[:4].tolist()}"
 
 
+@pytest.mark.parametrize("flags", [0, api.FLAG_FORCE_SAFE])
+@pytest.mark.parametrize("w,h", EDGE_SIZES + [(512, 512), (1920, 1080), (999, 1000)])
+def test_fused440_vs_oracle(dec, oracle, w, h, flags):
+    """4:4:0 (Y 1x2 over chroma: a losslessly rotated 4:2:2 picture).  Pillow cannot write the layout: the streams come from
+    this library's own encoder, whose output the reference decoder (the oracle) reads like any other."""
+    ri = (w + 2 * h) % 5
+    data = dec.encode(synth.synth_image(w, h, 700 + w + h), 87, "440", ri, ri == 2)
+    f = dec.read(data)
+    assert (f.hsamp[0], f.vsamp[0], f.hsamp[1], f.vsamp[1]) == (1, 2, 1, 1)
+    # the fused kernel only exists in the fast flavour; FORCE_SAFE must route to the generic kernels
+    assert api.kernel_name(f, flags) == ("fused440_kernel" if flags == 0 else "idct_planes_kernel+upsample_color_kernel")
+    out = dec.reconstruct(flags)
+    exp = oracle.decode(data)
+    bad = int((out != exp).sum())
+    assert bad == 0, f"{bad} differing samples, first at {np.argwhere(out != exp)[:4].tolist()}"
+
+
+def test_fused440_packed_chroma_gate(dec, oracle):
+    """Same 16-bit filter arithmetic and gate as the other packed flavours; batches of frames through the C ABI."""
+    img = np.zeros((400, 272, 3), np.uint8)
+    img[:130] = (255, 0, 0)
+    img[130:260] = (0, 0, 255)
+    img[260:] = (0, 255, 0)
+    img[:, 100:150] = (255, 255, 0)
+    seen = set()
+    for q in (50, 75, 90, 100):
+        data = dec.encode(img, q, "440", 3)
+        f = dec.read(data)
+        name = api.kernel_name(f)
+        packed = f.fast_arith == 1 and f.range_max[1] < 2047 and f.range_max[2] < 2047
+        assert name == ("fused440_kernel" if packed else "idct_planes_kernel+upsample_color_kernel")
+        seen.add(name)
+        assert np.array_equal(dec.reconstruct(), oracle.decode(data)), q
+    assert "idct_planes_kernel+upsample_color_kernel" in seen  # saturated graphics lie beyond the gate
+    rng = np.random.default_rng(16)
+    img = rng.integers(0, 256, (208, 144, 3)).astype(np.uint8)
+    for q in (60, 95):
+        data = dec.encode(img, q, "440")
+        assert api.kernel_name(dec.read(data)) == "fused440_kernel"
+        assert np.array_equal(dec.reconstruct(), oracle.decode(data))
+
+
 @pytest.mark.parametrize("w,h", EDGE_SIZES + [(512, 512), (1920, 1080), (1001, 999)])
 def test_fused_single_component_vs_oracle(dec, oracle, w, h):
     """Grey scale frames: one lane per block, identity transformation; FORCE_GENERIC and FORCE_SAFE take the two-kernel path."""
