@@ -350,34 +350,28 @@ __device__ __forceinline__ void dequant_idct_column(const u32x4 (&rows)[8], cons
   idct_1d<true, 12>(col[0], col[1], col[2], col[3], col[4], col[5], col[6], col[7]);
 }
 
-// One LINE (y = 0 or y = 7) of a block's samples: the first pass in full, then per column the inner product of its eight results
-// with the corresponding row of the transform's integer matrix (see dequant_idct_column).  FAST arithmetic, no level shift.
-__device__ __forceinline__ void dequant_idct_line(const u32x4 (&rows)[8], const int *__restrict__ q, bool last, int (&line)[8])
+// One LINE (y = 0 or y = 7) of a block's samples, computed by the EIGHT lanes that fetched the block's eight 16-byte chunks
+// (chunk k = coefficient row k): every lane runs the first pass on its own row, weights the eight results with its entry of
+// the corresponding row of the transform's integer matrix (see dequant_idct_column: even - odd for y = 7, even + odd for
+// y = 0), and three DPP steps add the eight lanes' terms -- exact, the ring Z / 2^32 is associative.  qrow = the eight
+// (pre-shifted) deltas of row k; all eight lanes return all eight samples.  FAST arithmetic, no level shift.
+__device__ __forceinline__ void dequant_idct_line8(const u32x4 row, const int (&qrow)[8], int weight, int (&line)[8])
 {
-  constexpr int E2 = FIX9(0.541196100) + FIX9(0.765366865), E4 = 512, E6 = FIX9(0.541196100);
-  constexpr int O1 = FIX9(1.501321110) - FIX9(0.899976223) - FIX9(0.390180644) + FIX9(1.175875602), O3 = FIX9(1.175875602),
-                O5 = FIX9(1.175875602) - FIX9(0.390180644), O7 = FIX9(1.175875602) - FIX9(0.899976223);
-  int t[64];
+  const unsigned w[4] = {row.x, row.y, row.z, row.w};
+  int s[8];
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const unsigned w[4] = {rows[r].x, rows[r].y, rows[r].z, rows[r].w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      t[r * 8 + 2 * i] = mul16_lo(w[i], q[r * 8 + 2 * i]);
-      t[r * 8 + 2 * i + 1] = mul16_hi(w[i], q[r * 8 + 2 * i + 1]);
-    }
-    idct_1d<true, 9>(t[r * 8 + 0], t[r * 8 + 1], t[r * 8 + 2], t[r * 8 + 3], t[r * 8 + 4], t[r * 8 + 5], t[r * 8 + 6], t[r * 8 + 7]);
+  for (int i = 0; i < 4; i++) {
+    s[2 * i] = mul16_lo(w[i], qrow[2 * i]);
+    s[2 * i + 1] = mul16_hi(w[i], qrow[2 * i + 1]);
   }
+  idct_1d<true, 9>(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
 #pragma unroll
   for (int x = 0; x < 8; x++) {
-    int even = (t[x] << 9) + (1 << 11), odd = __mul24(t[8 + x], O1);
-    even = mad24(t[16 + x], E2, even);
-    odd = mad24(t[24 + x], O3, odd);
-    even = mad24(t[32 + x], E4, even);
-    odd = mad24(t[40 + x], O5, odd);
-    even = mad24(t[48 + x], E6, even);
-    odd = mad24(t[56 + x], O7, odd);
-    line[x] = (last ? even - odd : even + odd) >> 12; // y = 7 : y = 0
+    int p = __mul24(s[x], weight);
+    p += __builtin_amdgcn_update_dpp(0, p, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    p += __builtin_amdgcn_update_dpp(0, p, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    p += __builtin_amdgcn_update_dpp(0, p, 0x141, 0xF, 0xF, false); // row_half_mirror: the other quad of the eight
+    line[x] = (p + (1 << 11)) >> 12;
   }
 }
 
@@ -1157,20 +1151,33 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
         }
       }
     }
-    { // halo lines: local block n = lane >> 3 (+ 8): side n & 1 (0: the block above, 1: the block below), column n >> 1
-      fetch_blocks16(rows, stage, lane, [&](int m) -> const u32x4 * {
-        const int n = (lane >> 3) + 8 * m;
-        const int xx = min(gx0 + (n >> 1), a.bw_c - 1), yy = min(max((n & 1) ? gy0 + 8 : gy0 - 1, 0), a.bh_c - 1);
-        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
-      });
-      const int side = lane & 1, cbx = lane >> 1, gy = side ? gy0 + 8 : gy0 - 1;
-      if (lane < 16 && gy >= 0 && gy < a.bh_c && gx0 + cbx < a.bw_c) {
-        int line[8];
-        dequant_idct_line(rows, a.q[1 + comp], side == 0, line); // the block above: its last line, the one below: its first
-        short *dst = cp + 2 * ((side ? F440_CROWS - 1 : 0) * F440_CPITCH + 8 * ((wave & 1) * 8 + cbx));
+    { // halo lines: the lane's two chunks are row k = lane & 7 of the block above (m = 0) and below (m = 1) column lane >> 3
+      constexpr int W[8] = {512, FIX9(1.501321110) - FIX9(0.899976223) - FIX9(0.390180644) + FIX9(1.175875602), FIX9(0.541196100) + FIX9(0.765366865),
+                            FIX9(1.175875602), 512, FIX9(1.175875602) - FIX9(0.390180644), FIX9(0.541196100), FIX9(1.175875602) - FIX9(0.899976223)};
+      const int k = lane & 7, nb = lane >> 3;
+      const int xx = min(gx0 + nb, a.bw_c - 1);
+      const u32x4 above = *reinterpret_cast<const u32x4 *>(pbase + (unsigned)((max(gy0 - 1, 0) * a.bw_c + xx) * 128));
+      const u32x4 below = *reinterpret_cast<const u32x4 *>(pbase + (unsigned)((min(gy0 + 8, a.bh_c - 1) * a.bw_c + xx) * 128));
+      // the deltas of row k, per lane: read from the kernel argument segment itself (indexing the by-value struct with a lane
+      // dependent index would make the compiler copy it to scratch)
+      typedef const __attribute__((address_space(4))) int kernarg_int;
+      kernarg_int *qk = (kernarg_int *)__builtin_amdgcn_kernarg_segment_ptr() + (offsetof(Fused420Args, q) / sizeof(int) + (1 + comp) * 64 + k * 8);
+      int qrow[8];
 #pragma unroll
-        for (int x = 0; x < 8; x++) dst[2 * x] = (short)line[x];
-      }
+      for (int i = 0; i < 8; i++) qrow[i] = qk[i];
+      const int weight = W[k];
+      int line[8];
+      short *dst = cp + 2 * (8 * ((wave & 1) * 8 + nb) + k);
+      const bool col_ok = gx0 + nb < a.bw_c;
+      auto mine = [&](const int (&l)[8]) { // line[k] without a register-indexed access
+        const int a01 = (k & 1) ? l[1] : l[0], a23 = (k & 1) ? l[3] : l[2], a45 = (k & 1) ? l[5] : l[4], a67 = (k & 1) ? l[7] : l[6];
+        const int lo = (k & 2) ? a23 : a01, hi = (k & 2) ? a67 : a45;
+        return (short)((k & 4) ? hi : lo);
+      };
+      dequant_idct_line8(above, qrow, (k & 1) ? -weight : weight, line); // the block above: its last line (even - odd)
+      if (col_ok && gy0 > 0) dst[0] = mine(line);
+      dequant_idct_line8(below, qrow, weight, line); // the block below: its first line (even + odd)
+      if (col_ok && gy0 + 8 < a.bh_c) dst[2 * (F440_CROWS - 1) * F440_CPITCH] = mine(line);
     }
   }
   __syncthreads();
