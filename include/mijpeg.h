@@ -143,7 +143,13 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals);
  * the device, which a single image rarely does), into n coefficient stores that mijpeg_reconstruct_batch_device turns
  * into n frames (`frame_stride` bytes apart, interleaved samples, `row_stride` bytes per line) with ONE launch of the
  * reconstruction kernel.  Nothing but the compressed bytes crosses PCIe.  MIJPEG_ERR_NOT_AVAILABLE when the streams do
- * not form such a batch.  The stream bytes are only read during the call. */
+ * not form such a batch.  The stream bytes are only read during the call.
+ * Images may bring quantisation tables of their own (motion JPEG under rate control): the reconstruction launch then
+ * reads per-frame tables from device memory (mijpeg_batch.quant_dev below) and mijpeg_get_info reports, per component,
+ * the largest delta of any image.
+ * Streams: every call of a decoder object works on the object's own non-blocking stream.  Device memory handed to it
+ * (dst_device, device bitmaps, pixels to encode) must not have work pending on other streams when the call is made, and
+ * is complete when a call returns with sync != 0. */
 int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals);
 int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags,
                                     int sync);
@@ -208,10 +214,14 @@ int mijpeg_last_timing(mijpeg_decoder *d, double out_seconds[4]);
 
 /* Describes a batch of equally shaped frames whose coefficient planes are already on the device. */
 typedef struct mijpeg_batch {
-  mijpeg_info info;            /* geometry + quantiser tables (shared by the batch unless quant_dev) */
+  mijpeg_info info;            /* geometry + quantiser tables (shared by the batch unless quant_dev: then the
+                                  element-wise maxima over the frames, which the kernel selection looks at,
+                                  and range_max / fast_arith of the most demanding frame) */
   const int16_t *coef_dev;     /* frame f starts at coef_dev + f * coef_frame_stride (int16 units) */
   int64_t coef_frame_stride;
-  const uint16_t *quant_dev;   /* optional: per-frame tables [frames][4][64] u16 on the device      */
+  const uint16_t *quant_dev;   /* optional: per-frame tables [frames][4][64] u16 on the device: deltas of
+                                  COMPONENT c of frame f, natural order; plain JPEG only.  They are expanded
+                                  into the workspace (see mijpeg_workspace_bytes) by a small kernel in front */
   uint8_t *out_dev;            /* frame f pixels at out_dev + f * out_frame_stride (bytes)          */
   int64_t out_frame_stride;
   int64_t out_row_stride;      /* bytes per line                                                  */
@@ -223,7 +233,7 @@ typedef struct mijpeg_batch {
 } mijpeg_batch;
 
 /* Device scratch the batch needs (0 for the fused kernels of plain JPEG; the L tables for the fused JPEG XT kernel;
- * tables + int32 sample planes for the generic kernels). */
+ * tables + int32 sample planes for the generic kernels; plus frames x 1 KiB of expanded tables with quant_dev). */
 size_t mijpeg_workspace_bytes(const mijpeg_batch *batch);
 
 /* dequant + IDCT + upsample + colour transform + interleaved store for `frames` frames in one

@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -135,6 +136,15 @@ def lib():
     return _lib
 
 
+def _foreign_work_done() -> None:
+    """The decoder object works on a stream of its own (non-blocking): device buffers handed to it must not have work
+    pending on other streams -- a torch fill queued a moment ago, say (include/mijpeg.h states the requirement).  These
+    bindings are the tests' and bench.py's: they simply wait for torch's streams."""
+    t = sys.modules.get("torch")
+    if t is not None and t.cuda.is_available():
+        t.cuda.synchronize()
+
+
 class Decoder:
     """One image at a time.  device=None -> host-only object (parsing + Huffman decoding)."""
 
@@ -221,6 +231,7 @@ class Decoder:
     def encode_batch_device(self, info: MijpegInfo, pixels_dev: int, coef_dev: int, frames: int, pixel_row_stride: int, pixel_frame_stride: int,
                             restart_mcus: int = 0, optimize: bool = False):
         """mijpeg_encode_batch_device: frames resident in HBM -> list of baseline JPEG streams (forward kernels + device entropy coder)."""
+        _foreign_work_done()
         b = MijpegForwardBatch()
         C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
         b.pixels_dev, b.pixel_frame_stride, b.pixel_row_stride = pixels_dev, pixel_frame_stride, pixel_row_stride
@@ -287,6 +298,7 @@ class Decoder:
         return info
 
     def reconstruct_batch_device(self, dst_ptr: int, frame_stride: int, row_stride: int, flags: int = 0, sync: bool = True):
+        _foreign_work_done()
         self._check(lib().mijpeg_reconstruct_batch_device(self._h, dst_ptr, frame_stride, row_stride, flags, 1 if sync else 0))
 
     def reconstruct_unsampled(self, comp: int, flags: int = 0) -> np.ndarray:
@@ -307,6 +319,7 @@ class Decoder:
                                 flags: int = 0):
         """mijpeg_reconstruct_rect with MIJPEG_FLAG_DEVICE_OUTPUT: `ptrs[c]` is the device address of canvas pixel
         (0,0) of component c (0/None = component not wanted), strides in bytes as in the reference's ImageBitMap."""
+        _foreign_work_done()
         nc = self.info.components
         comp1 = nc - 1 if comp1 is None else comp1
         ptrs = list(ptrs) + [None] * (4 - len(ptrs))
@@ -323,6 +336,7 @@ class Decoder:
         return out
 
     def reconstruct_device(self, dst_ptr: int, row_stride: int, flags: int = 0, sync: bool = True):
+        _foreign_work_done()
         self._check(lib().mijpeg_reconstruct_device(self._h, dst_ptr, row_stride, flags, 1 if sync else 0))
 
     def timing(self):
@@ -381,8 +395,10 @@ def decode(data: bytes, device: int = 0, threads: int = 0, flags: int = 0) -> np
 
 def launch_reconstruct(info: MijpegInfo, coef_dev: int, out_dev: int, frames: int, out_row_stride: int,
                        out_frame_stride: int, coef_frame_stride: int | None = None, flags: int = 0,
-                       workspace: int = 0, workspace_bytes: int = 0, stream: int = 0, xt: MijpegXtParams | None = None) -> None:
-    """Stateless batch launch (device-resident coefficients -> device pixels), asynchronous."""
+                       workspace: int = 0, workspace_bytes: int = 0, stream: int = 0, xt: MijpegXtParams | None = None,
+                       quant_dev: int = 0) -> None:
+    """Stateless batch launch (device-resident coefficients -> device pixels), asynchronous.  quant_dev: device address of
+    per-frame tables, u16 [frames][4][64] (component, natural order); info.quant then holds the batch-wide maxima."""
     b = MijpegBatch()
     C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
     b.coef_dev = coef_dev
@@ -394,6 +410,7 @@ def launch_reconstruct(info: MijpegInfo, coef_dev: int, out_dev: int, frames: in
     b.flags = flags
     b.workspace = workspace
     b.workspace_bytes = workspace_bytes
+    b.quant_dev = quant_dev or None
     if xt is not None:
         b.xt = C.pointer(xt)
     rc = lib().mijpeg_launch_reconstruct(C.byref(b), stream)
@@ -455,11 +472,13 @@ def encode_coefficients(info: MijpegInfo, coef: np.ndarray, restart_interval: in
         L.mijpeg_free(p)
 
 
-def workspace_bytes(info: MijpegInfo, frames: int, flags: int = 0) -> int:
+def workspace_bytes(info: MijpegInfo, frames: int, flags: int = 0, own_tables: bool = False) -> int:
     b = MijpegBatch()
     C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
     b.frames = frames
     b.flags = flags
+    if own_tables:  # only asked whether it is set
+        b.quant_dev = 16
     return int(lib().mijpeg_workspace_bytes(C.byref(b)))
 
 

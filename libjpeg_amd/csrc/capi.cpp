@@ -71,6 +71,11 @@ struct mijpeg_decoder {
   std::vector<std::unique_ptr<HostDecoder>> batch_hosts;
   mijpeg_info batch_info{};
   int batch_frames = 0;
+  // batches whose images bring different quantisation tables: [frames][4][64] deltas per component, on the device
+  uint16_t *batch_quant_dev = nullptr;
+  size_t batch_quant_cap = 0;
+  bool batch_own_tables = false;
+  std::vector<uint16_t> batch_quant_host;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int err_code = 0;
@@ -134,6 +139,7 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->coef_dev) (void)hipFree(d->coef_dev);
     if (d->img_dev) (void)hipFree(d->img_dev);
     if (d->ws_dev) (void)hipFree(d->ws_dev);
+    if (d->batch_quant_dev) (void)hipFree(d->batch_quant_dev);
     if (d->ent_dev) (void)hipFree(d->ent_dev);
     if (d->ent_host) (void)hipHostFree(d->ent_host);
     if (d->stage_host) (void)hipHostFree(d->stage_host);
@@ -879,11 +885,13 @@ int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams,
   for (int i = 0; i < n; i++)
     if (const char *why = device_entropy_obstacle(*hosts[(size_t)i], sizes[i])) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
   const mijpeg_info &f0 = hosts[0]->info;
-  for (int i = 1; i < n; i++) { // one reconstruction launch serves the batch: the deltas must agree too
+  // one reconstruction launch serves the batch; images with tables of their own (motion JPEG under rate control) make it
+  // read per-frame tables from device memory instead of the kernel arguments
+  bool own_tables = false;
+  for (int i = 1; i < n && !own_tables; i++) {
     const mijpeg_info &f = hosts[(size_t)i]->info;
     for (int c = 0; c < f.components; c++)
-      if (memcmp(f.quant[f.quant_index[c]], f0.quant[f0.quant_index[c]], sizeof(f.quant[0])))
-        return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the images of a batch must share their quantisation tables");
+      if (memcmp(f.quant[f.quant_index[c]], f0.quant[f0.quant_index[c]], sizeof(f.quant[0]))) own_tables = true;
   }
   int rc = ensure_coef_store(d, (size_t)f0.coef_count * (size_t)n, false);
   if (rc) return rc;
@@ -897,6 +905,30 @@ int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams,
   d->timing[3] = d->phase_device;
   if (rc) return rc;
   d->batch_info = f0;
+  d->batch_own_tables = own_tables;
+  if (own_tables) {
+    // the batch's info then carries, per COMPONENT, the largest delta any image has at each position: what the range
+    // gates of the kernel selection look at
+    d->batch_quant_host.assign((size_t)n * 4 * 64, 1);
+    mijpeg_info &bi = d->batch_info;
+    for (int c = 0; c < f0.components; c++) {
+      bi.quant_index[c] = (uint8_t)c;
+      for (int k = 0; k < 64; k++) bi.quant[c][k] = 0;
+    }
+    for (int i = 0; i < n; i++) {
+      const mijpeg_info &f = hosts[(size_t)i]->info;
+      for (int c = 0; c < f.components; c++)
+        for (int k = 0; k < 64; k++) {
+          const uint16_t q = f.quant[f.quant_index[c]][k];
+          d->batch_quant_host[((size_t)i * 4 + c) * 64 + k] = q;
+          bi.quant[c][k] = std::max(bi.quant[c][k], q);
+        }
+    }
+    const size_t bytes = d->batch_quant_host.size() * sizeof(uint16_t);
+    rc = ensure_dev(d, (void **)&d->batch_quant_dev, &d->batch_quant_cap, bytes);
+    if (rc) return rc;
+    HIP_TRY(d, hipMemcpyAsync(d->batch_quant_dev, d->batch_quant_host.data(), bytes, hipMemcpyHostToDevice, d->stream));
+  }
   d->batch_info.fast_arith = 1;
   for (int i = 0; i < n; i++) { // the batch is as fast as its most demanding image
     const mijpeg_info &f = hosts[(size_t)i]->info;
@@ -921,6 +953,7 @@ int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t
   b.out_row_stride = row_stride;
   b.out_frame_stride = frame_stride;
   b.frames = d->batch_frames;
+  b.quant_dev = d->batch_own_tables ? d->batch_quant_dev : nullptr;
   b.flags = flags & ~(MIJPEG_FLAG_DEVICE_OUTPUT | MIJPEG_FLAG_NO_UPSAMPLING);
   const size_t ws = mijpeg_workspace_bytes(&b);
   if (ws) {
@@ -1080,19 +1113,23 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
 
 static const size_t LUT_BYTES = 3 * 4096 * sizeof(int32_t);
 
+// per-frame tables (quant_dev) are expanded to the transforms' operands (deltas << 4, int32) in the workspace
+static size_t expanded_tables_bytes(const mijpeg_batch *b) { return b->quant_dev ? (size_t)b->frames * 4 * 64 * sizeof(int32_t) : 0; }
+
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
 {
-  if (!b || use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused1(b)) return 0;
+  if (!b) return 0;
+  if (use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused1(b)) return expanded_tables_bytes(b);
   if (use_fusedxt(b)) return LUT_BYTES;
   // [LUT_BYTES: L lookup tables (JPEG XT, up to 3 x 4096 entries)] [per frame: int32 sample planes, one sample per
-  // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients]
-  return LUT_BYTES + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames;
+  // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients] [expanded per-frame tables]
+  return LUT_BYTES + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames + expanded_tables_bytes(b);
 }
 
 int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
 {
   if (!b || !b->coef_dev || !b->out_dev || b->frames < 1) return MIJPEG_ERR_INVALID_PARAMETER;
-  if (b->quant_dev) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: not yet
+  if (b->quant_dev && b->info.xt) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: plain JPEG only
   const mijpeg_info &f = b->info;
   if ((f.precision != 8 && f.precision != 12) || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
   if (f.xt && (!b->xt || f.components != 3)) return MIJPEG_ERR_MISSING_PARAMETER;
@@ -1101,6 +1138,14 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   int rc;
   const bool f444 = use_fused444(b), fxt = use_fusedxt(b), f422 = use_fused422(b), f440 = use_fused440(b), f1 = use_fused1(b);
   if (fxt && (!b->workspace || b->workspace_bytes < LUT_BYTES)) return MIJPEG_ERR_MISSING_PARAMETER;
+  const int32_t *qdev = nullptr;
+  if (b->quant_dev) {
+    const size_t need = mijpeg_workspace_bytes(b);
+    if (!b->workspace || b->workspace_bytes < need) return MIJPEG_ERR_MISSING_PARAMETER;
+    int32_t *dst = (int32_t *)((char *)b->workspace + (need - expanded_tables_bytes(b)));
+    if (launch_expand_deltas(b->quant_dev, dst, b->frames, s)) return MIJPEG_ERR_DEVICE;
+    qdev = dst;
+  }
   if (use_fused420(b) || f444 || fxt || f422 || f440 || f1) {
     FusedXtArgs xa;
     memset(&xa, 0, sizeof(xa));
@@ -1127,6 +1172,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.aligned8 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 7) == 0;
     for (int c = 0; c < 3; c++)
       for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
+    a.qdev = qdev;
     if (fxt) {
       const mijpeg_xt_params &x = *b->xt;
       const mijpeg_info &r = x.residual;
@@ -1163,6 +1209,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.ncomp = f.components;
     a.ycbcr = (f.ycbcr && !(b->flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM)) ? 1 : 0;
     a.frames = b->frames;
+    a.qdev = qdev;
     a.nplanes = f.components;
     a.sample_bytes = f.precision > 8 || f.xt ? 2 : 1;
     a.maxval = (1 << f.precision) - 1;

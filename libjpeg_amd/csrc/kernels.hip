@@ -441,10 +441,20 @@ constexpr int F420_CROWS = 66;            // chroma lines kept in LDS (64 + 2 ha
 constexpr int F420_CPITCH = 72;           // dwords per LDS chroma line; column pc <-> chroma x_rel = pc - 4
 constexpr int F420_THREADS = 256;
 
+// The deltas of component c of a frame: from the kernel arguments (scalar loads out of the kernarg segment), or -- QDEV, batches
+// whose frames bring their own tables -- from the per-frame tables in device memory (scalar loads all the same: the address is
+// wave-uniform).  One of the two survives constant folding, so the address space is known where the loads are emitted.
+template <bool QDEV, class Args>
+__device__ __forceinline__ const int *frame_deltas(const Args &a, int frame, int c)
+{
+  if (QDEV) return a.qdev + ((int64_t)frame * 4 + c) * 64;
+  return a.q[c];
+}
+
 // phase A of the 4:2:0 kernels with 32-bit chroma samples: the (8+2) x (8+2) chroma blocks of tile (tx, ty) -> LDS
-template <bool FAST>
+template <bool FAST, bool QDEV = false>
 __device__ __forceinline__ void f420_chroma_to_lds(const Fused420Args &a, const int16_t *__restrict__ coef, int (*cplane)[F420_CROWS * F420_CPITCH],
-                                                   u32x4 *stage, int lane, int wave, int tx, int ty)
+                                                   u32x4 *stage, int lane, int wave, int tx, int ty, int frame = 0)
 {
   const int comp = wave >> 1; // 0 = Cb, 1 = Cr (wave-uniform)
   const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
@@ -476,8 +486,9 @@ __device__ __forceinline__ void f420_chroma_to_lds(const Fused420Args &a, const 
   const int gx = gx0 + cbx, gy = gy0 + cby;
   if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
     int v[64];
-    if (FAST) dequant_idct_sparse(rows, a.q[1 + comp], v);
-    else dequant_idct<false>(rows, a.q[1 + comp], v, 128 << 7);
+    const int *q = frame_deltas<QDEV>(a, frame, 1 + comp);
+    if (FAST) dequant_idct_sparse(rows, q, v);
+    else dequant_idct<false>(rows, q, v, 128 << 7);
     int *cp = cplane[comp];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -525,7 +536,7 @@ __device__ __forceinline__ void f420_chroma_edges(const Fused420Args &a, int (*c
   }
 }
 
-template <bool FAST, int MINW>
+template <bool FAST, int MINW, bool QDEV>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) int cplane[2][F420_CROWS * F420_CPITCH];
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
-  f420_chroma_to_lds<FAST>(a, coef, cplane, stage, lane, wave, tx, ty);
+  f420_chroma_to_lds<FAST, QDEV>(a, coef, cplane, stage, lane, wave, tx, ty, frame);
   __syncthreads();
   f420_chroma_edges(a, cplane, tid, tx, ty);
 
@@ -575,8 +586,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  if (FAST) dequant_idct_sparse(rows, a.q[0], yv);
-  else dequant_idct<false>(rows, a.q[0], yv, 128 << 7);
+  if (FAST) dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  else dequant_idct<false>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 128 << 7);
 
   // uniform frame base + 32-bit lane offsets (a frame of pixels is far below 4 GB)
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -721,7 +732,7 @@ __device__ __forceinline__ unsigned tap13_pk(unsigned a, unsigned b, short r)
   return __builtin_bit_cast(unsigned, t);
 }
 
-template <int MINW>
+template <int MINW, bool QDEV>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420_CPITCH];
@@ -774,7 +785,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     const int gx = gx0 + cbx, gy = gy0 + cby;
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
       int v[64];
-      dequant_idct_sparse(rows, a.q[1 + comp], v);
+      dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
       short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
 #pragma unroll
       for (int r = 0; r < 8; r++) {
@@ -839,7 +850,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse(rows, a.q[0], yv);
+  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -925,7 +936,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
 // 4:2:0 flavour (FAST arithmetic, chroma range_max < 2047), same store path.  Algorithmic bytes: 4 B in + 3 B out per pixel.
 constexpr int F422_CROWS = 128;
 
-template <int MINW>
+template <int MINW, bool QDEV>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) unsigned cpair[F422_CROWS * F420_CPITCH];
@@ -967,7 +978,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
       const int cbx = lane & 7, cby = lane >> 3;
       if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
         int v[64];
-        dequant_idct_sparse(rows, a.q[1 + comp], v);
+        dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           short *dst = cp + 2 * ((8 * ((wave & 1) * 8 + cby) + r) * F420_CPITCH + 8 * cbx + 4);
@@ -985,7 +996,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
       const int side = lane & 1, cby = lane >> 1, gx = side ? gx0 + 8 : gx0 - 1;
       if (lane < 16 && gx >= 0 && gx < a.bw_c && gy0 + cby < a.bh_c) {
         int col[8];
-        dequant_idct_column(rows, a.q[1 + comp], side == 0, col); // left neighbour: its last column, right one: its first
+        dequant_idct_column(rows, frame_deltas<QDEV>(a, frame, 1 + comp), side == 0, col); // left neighbour: its last column, right one: its first
 #pragma unroll
         for (int r = 0; r < 8; r++) cp[2 * ((8 * ((wave & 1) * 8 + cby) + r) * F420_CPITCH + (side ? 68 : 3))] = (short)col[r];
       }
@@ -1026,7 +1037,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse(rows, a.q[0], yv);
+  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1101,7 +1112,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
 // vertical filter needs a single LINE each (dequant_idct_line: the first pass in full, one inner product per column).
 // Vertical filter only (Upsampler<1,2>: VerticalFilterCore<2>, HorizontalFilterCore<1> = copy), same 16-bit gate.
 constexpr int F440_CROWS = 66, F440_CPITCH = 128;
-template <int MINW>
+template <int MINW, bool QDEV>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) unsigned cpair[F440_CROWS * F440_CPITCH];
@@ -1142,7 +1153,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
       const int cbx = lane & 7, cby = lane >> 3;
       if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
         int v[64];
-        dequant_idct_sparse(rows, a.q[1 + comp], v);
+        dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           short *dst = cp + 2 * ((8 * cby + r + 1) * F440_CPITCH + 8 * ((wave & 1) * 8 + cbx));
@@ -1161,10 +1172,16 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
       // the deltas of row k, per lane: read from the kernel argument segment itself (indexing the by-value struct with a lane
       // dependent index would make the compiler copy it to scratch)
       typedef const __attribute__((address_space(4))) int kernarg_int;
-      kernarg_int *qk = (kernarg_int *)__builtin_amdgcn_kernarg_segment_ptr() + (offsetof(Fused420Args, q) / sizeof(int) + (1 + comp) * 64 + k * 8);
       int qrow[8];
+      if (QDEV) {
+        const int *qk = a.qdev + ((int64_t)frame * 4 + 1 + comp) * 64 + k * 8;
 #pragma unroll
-      for (int i = 0; i < 8; i++) qrow[i] = qk[i];
+        for (int i = 0; i < 8; i++) qrow[i] = qk[i];
+      } else {
+        kernarg_int *qk = (kernarg_int *)__builtin_amdgcn_kernarg_segment_ptr() + (offsetof(Fused420Args, q) / sizeof(int) + (1 + comp) * 64 + k * 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) qrow[i] = qk[i];
+      }
       const int weight = W[k];
       int line[8];
       short *dst = cp + 2 * (8 * ((wave & 1) * 8 + nb) + k);
@@ -1216,7 +1233,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse(rows, a.q[0], yv);
+  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1494,7 +1511,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
 // block fetch.  FAST arithmetic only, and only when the host's range check bounds every chroma sample by
 // 4 * range_max < 32768 (so the packing is exact); everything else takes the generic two-kernel path.
 // Algorithmic bytes: 3 x 2 B in + 3 B out = 9 B/pixel.
-template <int MINW>
+template <int MINW, bool QDEV>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
@@ -1534,12 +1551,12 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     u32x4 rows[8];
     int v[64];
     fetch(rows, a.off_cb);
-    dequant_idct_sparse(rows, a.q[1], v);
+    dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 1), v);
 #pragma unroll
     for (int i = 0; i < 32; i++) cbp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
     __builtin_amdgcn_sched_barrier(0); // keep the next component's loads from being hoisted above this transform (register pressure)
     fetch(rows, a.off_cr);
-    dequant_idct_sparse(rows, a.q[2], v);
+    dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 2), v);
 #pragma unroll
     for (int i = 0; i < 32; i++) crp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
     __builtin_amdgcn_sched_barrier(0);
@@ -1550,7 +1567,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     fetch(rows, a.off_y);
     const int X0 = gbx * 8, Y0 = gby * 8;
     if (X0 >= a.width || Y0 >= a.height) return;
-    dequant_idct_sparse(rows, a.q[0], yv);
+    dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
   }
   const int X0 = gbx * 8, Y0 = gby * 8;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -1612,6 +1629,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
 // One lane, one block: fetch, dequantise, transform, COLOR_TO_INT (x + 8) >> 4 with the level shift the fast transform
 // leaves out folded into the rounding constant, clamp, eight bytes per line.  Samples travel as packed int16 from the
 // addition on (range check: |sample * 16| <= 4 * range_max < 2^15).  Algorithmic bytes: 2 B in + 1 B out per pixel.
+template <bool QDEV>
 __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
@@ -1647,7 +1665,7 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return;
   int v[64];
-  dequant_idct_sparse(rows, a.q[0], v);
+  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), v);
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0;
   const int npx = min(8, a.width - X0);
@@ -1685,7 +1703,7 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
 // ==============================================================================================
 // generic path, kernel 1: dequant + IDCT of every block of every component into int32 sample planes
 // ==============================================================================================
-template <bool FAST>
+template <bool FAST, bool QDEV>
 __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
 {
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
@@ -1706,8 +1724,9 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   const int blk = first + lane;
   if (blk >= nblocks) return;
   int v[64];
-  if (FAST) dequant_idct_sparse(rows, a.q[comp], v, a.dcoff[comp]);
-  else dequant_idct<false>(rows, a.q[comp], v, a.dcoff[comp]);
+  const int *q = frame_deltas<QDEV>(a, frame, comp);
+  if (FAST) dequant_idct_sparse(rows, q, v, a.dcoff[comp]);
+  else dequant_idct<false>(rows, q, v, a.dcoff[comp]);
   const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
   const int pitch = a.bw[comp] * 8;
   int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
@@ -2093,8 +2112,11 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
   if (total == 0) return 0;
   // two workgroups per CU for both flavours (132 / 194 VGPRs)
-  if (!fast) hipLaunchKernelGGL((fused420_kernel<false, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused420_kernel<true, 2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) {
+    if (!fast) hipLaunchKernelGGL((fused420_kernel<false, 2, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused420_kernel<true, 2, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  } else if (!fast) hipLaunchKernelGGL((fused420_kernel<false, 2, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused420_kernel<true, 2, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -2103,7 +2125,8 @@ int launch_fused420p(const Fused420Args &a, hipStream_t stream)
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
   if (total == 0) return 0;
   // three workgroups per CU (109 VGPRs, 27 KB LDS): two or four measured slower (profiles/r01/summary_fused420p.txt)
-  hipLaunchKernelGGL((fused420p_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) hipLaunchKernelGGL((fused420p_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused420p_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -2117,21 +2140,24 @@ int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
 int launch_fused422(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  hipLaunchKernelGGL((fused422_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) hipLaunchKernelGGL((fused422_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused422_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
 int launch_fused1(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  hipLaunchKernelGGL(fused1_kernel, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) hipLaunchKernelGGL(fused1_kernel<true>, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL(fused1_kernel<false>, dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
 int launch_fused440(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  hipLaunchKernelGGL((fused440_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) hipLaunchKernelGGL((fused440_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused440_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -2139,11 +2165,23 @@ int launch_fused444(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
   if (total == 0) return 0;
-  static const int variant = getenv("MIJPEG_F444_VARIANT") ? atoi(getenv("MIJPEG_F444_VARIANT")) : 0; // tuning aid
-  if (variant == 1)
-    hipLaunchKernelGGL((fused444_kernel<2>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else // 168 VGPRs -> three waves per SIMD: 5 % faster than the unconstrained 171-register build
-    hipLaunchKernelGGL((fused444_kernel<3>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  // 168 VGPRs -> three waves per SIMD: 5 % faster than the unconstrained 171-register build
+  if (a.qdev) hipLaunchKernelGGL((fused444_kernel<2, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused444_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+// per-frame tables as the client hands them over (u16 deltas, [frames][4][64]) -> the operands of the transforms (<< 4, int32)
+__global__ __launch_bounds__(256) void expand_deltas_kernel(const uint16_t *__restrict__ in, int32_t *__restrict__ out, int n)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (int32_t)in[i] << 4;
+}
+
+int launch_expand_deltas(const uint16_t *in, int32_t *out, int frames, hipStream_t stream)
+{
+  const int n = frames * 4 * 64;
+  hipLaunchKernelGGL(expand_deltas_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n);
   return (int)hipGetLastError();
 }
 
@@ -2153,9 +2191,11 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   for (int c = 0; c < a.nplanes; c++) maxblocks = max(maxblocks, a.bw[c] * a.bh[c]);
   dim3 g1((maxblocks + 255) / 256, a.nplanes * a.frames);
   if (fast)
-    hipLaunchKernelGGL(idct_planes_kernel<true>, g1, dim3(256), 0, stream, a);
+    if (a.qdev) hipLaunchKernelGGL((idct_planes_kernel<true, true>), g1, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((idct_planes_kernel<true, false>), g1, dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL(idct_planes_kernel<false>, g1, dim3(256), 0, stream, a);
+    if (a.qdev) hipLaunchKernelGGL((idct_planes_kernel<false, true>), g1, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((idct_planes_kernel<false, false>), g1, dim3(256), 0, stream, a);
   if (a.wide_count > 0) {
     int wb = 0;
     for (int c = a.wide_first; c < a.wide_first + a.wide_count; c++) wb = max(wb, a.bw[c] * a.bh[c]);

@@ -24,6 +24,7 @@ struct Fused420Args {
   int32_t tiles_x, tiles_y, frames;
   int32_t aligned8;               // out, strides all multiples of 8 bytes -> 8-byte stores
   int32_t q[3][64];               // deltas << 4 per component (Y, Cb, Cr), natural order (idct.cpp:98-109)
+  const int32_t *qdev;            // or null: per-frame tables in device memory, [frames][4][64] deltas << 4 (replace q)
 };
 
 // fused JPEG XT profile C (8-bit 4:2:0 legacy frame + 12-bit 4:4:4 residual frame, see fusedxt420_kernel)
@@ -68,6 +69,7 @@ struct GenericArgs {
   int32_t wide_first, wide_count; // planes [wide_first, wide_first + wide_count) hold int32 coefficients at coef_off (in
                                   // int16 units) and are transformed by idct_planes_wide_kernel (IDCT<4,QUAD>)
   const int32_t *ltable;       // device: L lookup tables [3][ltable_entries]
+  const int32_t *qdev;         // or null: per-frame tables in device memory, [frames][4][64] deltas << 4 (replace q; not for JPEG XT)
 };
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
@@ -78,6 +80,7 @@ int launch_fused440(const Fused420Args &a, hipStream_t stream); // same argument
 int launch_fused422(const Fused420Args &a, hipStream_t stream); // same argument block; chroma planes bw_c x bh_y, cw = ceil(W/2), ch = H
 int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream);
 int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream);
+int launch_expand_deltas(const uint16_t *in, int32_t *out, int frames, hipStream_t stream); // u16 [frames][4][64] -> int32 << 4
 
 // Rectangle of the reconstructed interleaved frame -> bitmaps in DEVICE memory described like the reference's
 // ImageBitMap (interface/imagebitmap.hpp): per component the address of canvas pixel (0,0) and the two strides.

@@ -897,11 +897,96 @@ def test_batch_decode_on_the_device(oracle, w, h, sub, ri, n):
     d.close()
 
 
+@pytest.mark.parametrize("flags", [0, api.FLAG_FORCE_SAFE])
+@pytest.mark.parametrize("w,h,sub", [(640, 480, "420"), (333, 211, "444"), (515, 260, "422"), (301, 415, "440"), (400, 300, "gray"), (272, 144, "411")])
+def test_batch_whose_images_bring_their_own_quantisation_tables(oracle, w, h, sub, flags):
+    """Motion JPEG under rate control: same shape, another quality per frame.  One Huffman launch, one reconstruction launch
+    that reads per-frame tables from device memory (mijpeg_batch.quant_dev) instead of the kernel arguments."""
+    torch = _torch()
+    quals = [85, 40, 97, 85, 12, 70, 100]
+    n = len(quals)
+    nc = 1 if sub == "gray" else 3
+    imgs = [synth.synth_image(w, h, 800 + i, channels=nc) for i in range(n)]
+    d = api.Decoder(0)
+    if sub in ("440", "411"):  # Pillow cannot write these layouts: this library's own encoder does
+        streams = [d.encode(im, q, sub, 3, i % 2 == 1) for i, (im, q) in enumerate(zip(imgs, quals))]
+    else:
+        streams = [synth.encode_jpeg(im, q, "444" if sub == "gray" else sub, restart_mcus=3, optimize=(i % 2 == 1)) for i, (im, q) in enumerate(zip(imgs, quals))]
+    info = d.decode_batch_device(streams, min_intervals=1)
+    # the batch's info carries the largest delta of any image at each position
+    singles = [api.Decoder(0) for _ in range(2)]
+    q0 = max(int(singles[0].read(st).quant[0][63]) for st in streams)
+    assert int(info.quant[0][63]) == q0
+    row = w * nc
+    out = torch.zeros((n, h, row), dtype=torch.uint8, device="cuda")
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row, flags)
+    res = out.cpu().numpy().reshape(n, h, w, nc)
+    for i in range(n):
+        assert np.array_equal(res[i].squeeze(), oracle.decode(streams[i]).squeeze()), (i, quals[i])
+    # a batch of equal tables afterwards goes back to the kernel arguments
+    d.decode_batch_device([streams[0], streams[3]], min_intervals=1)
+    out2 = torch.zeros((2, h, row), dtype=torch.uint8, device="cuda")
+    d.reconstruct_batch_device(out2.data_ptr(), h * row, row, flags)
+    assert np.array_equal(out2.cpu().numpy().reshape(2, h, w, nc), res[[0, 3]])
+    for x in singles:
+        x.close()
+    d.close()
+
+
+def test_stateless_launch_with_per_frame_tables(oracle):
+    """mijpeg_launch_reconstruct with quant_dev: coefficient stores of two images side by side, their deltas as u16
+    [frames][4][64] in device memory, info.quant = the element-wise maximum."""
+    torch = _torch()
+    w, h = 384, 256
+    streams = [synth.synth_jpeg(w, h, 50 + i, q, "420", 4) for i, q in enumerate((90, 35, 75))]
+    n = len(streams)
+    d = api.Decoder(0)
+    infos, coefs = [], []
+    import ctypes as C
+    for st in streams:
+        f = api.MijpegInfo()
+        C.memmove(C.byref(f), C.byref(d.read(st)), C.sizeof(api.MijpegInfo))
+        infos.append(f)
+        store = np.zeros(int(f.coef_count), np.int16)
+        for c in range(3):
+            plane = d.coefficients(c).reshape(-1)
+            store[int(f.coef_offset[c]):int(f.coef_offset[c]) + plane.size] = plane
+        coefs.append(store)
+    info = api.MijpegInfo()
+    C.memmove(C.byref(info), C.byref(infos[0]), C.sizeof(api.MijpegInfo))
+    tabs = np.ones((n, 4, 64), np.uint16)
+    for i, f in enumerate(infos):
+        for c in range(3):
+            tabs[i, c] = np.array(f.quant[f.quant_index[c]][:], np.uint16)
+    for c in range(3):
+        info.quant_index[c] = c
+        for k in range(64):
+            info.quant[c][k] = int(tabs[:, c, k].max())
+        info.range_max[c] = max(int(f.range_max[c]) for f in infos)
+    coef = torch.from_numpy(np.stack(coefs)).cuda()
+    qd = torch.from_numpy(tabs.view(np.int16)).cuda()
+    row = w * 3
+    out = torch.zeros((n, h, row), dtype=torch.uint8, device="cuda")
+    for flags in (0, api.FLAG_FORCE_GENERIC):
+        out.zero_()
+        wsb = api.workspace_bytes(info, n, flags, own_tables=True)
+        assert wsb >= n * 4 * 64 * 4
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        with pytest.raises(api.MijpegError):  # the expanded tables live in the workspace
+            api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), n, row, h * row, flags=flags, quant_dev=qd.data_ptr())
+        api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), n, row, h * row, flags=flags, workspace=ws.data_ptr(), workspace_bytes=wsb,
+                               quant_dev=qd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().reshape(n, h, w, 3)
+        for i in range(n):
+            assert np.array_equal(res[i], oracle.decode(streams[i])), (flags, i)
+    d.close()
+
+
 def test_batch_decode_rejects_what_is_not_a_batch():
     d = api.Decoder(0)
     a = synth.synth_jpeg(320, 240, 1, 85, "420", 2)
     for other in (synth.synth_jpeg(336, 240, 1, 85, "420", 2),   # another width
-                  synth.synth_jpeg(320, 240, 1, 60, "420", 2),   # other quantisation tables
                   synth.synth_jpeg(320, 240, 1, 85, "444", 2)):  # another sampling
         with pytest.raises(api.MijpegError) as e:
             d.decode_batch_device([a, other], min_intervals=1)
