@@ -137,8 +137,8 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads);
  * After it, mijpeg_coefficients() downloads the planes on first use. */
 int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals);
 
-/* Batches (SURVEY config 4: many frames of one shape).  n codestreams of identical width, height, sampling and
- * quantisation tables, each qualifying for mijpeg_decode_coefficients_device, are parsed on the host in parallel, uploaded
+/* Batches (SURVEY config 4: many frames of one shape).  n codestreams of identical width, height and
+ * sampling, each qualifying for mijpeg_decode_coefficients_device, are parsed on the host in parallel, uploaded
  * and entropy-decoded by ONE kernel launch (every workgroup works on one image; the restart intervals of all images fill
  * the device, which a single image rarely does), into n coefficient stores that mijpeg_reconstruct_batch_device turns
  * into n frames (`frame_stride` bytes apart, interleaved samples, `row_stride` bytes per line) with ONE launch of the

@@ -29,12 +29,21 @@ for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
         hip.hipMemcpy(C.c_void_p(coef[f].data_ptr()), C.c_void_p(src), C.c_size_t(n * 2), 3)
     row = W * nc
     out = torch.empty((F, H, row), dtype=torch.uint8, device="cuda")
-    wsb = api.workspace_bytes(info, F)
+    own = os.environ.get("OWN_TABLES") == "1"  # per-frame tables in device memory (here: F copies of the same ones)
+    wsb = api.workspace_bytes(info, F, own_tables=own)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
+    qd = 0
+    if own:
+        tabs = np.ones((F, 4, 64), np.uint16)
+        for c in range(nc):
+            tabs[:, c] = np.array(info.quant[info.quant_index[c]][:], np.uint16)
+        qdev = torch.from_numpy(tabs.view(np.int16)).cuda()
+        qd = qdev.data_ptr()
 
     def step():
-        api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), F, row, H * row, n, workspace=ws.data_ptr(), workspace_bytes=wsb, stream=stream.cuda_stream)
+        api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), F, row, H * row, n, workspace=ws.data_ptr(), workspace_bytes=wsb, stream=stream.cuda_stream,
+                               quant_dev=qd)
 
     for _ in range(20):
         step()
@@ -48,5 +57,5 @@ for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
     ms = e0.elapsed_time(e1) / 20
     bpp = 2.0 * n / (W * H) + nc  # int16 coefficients in, bytes out
     ok = bool(np.array_equal(out[0].cpu().numpy().reshape(H, W, nc).squeeze(), d.reconstruct().squeeze()))
-    print(f"{sub:>5}: {api.kernel_name(info):<44} {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px) same as decoder object: {ok}", flush=True)
+    print(f"{sub:>5}: {api.kernel_name(info):<44} {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px) same as decoder object: {ok}{' (per-frame tables)' if own else ''}", flush=True)
     d.close()
