@@ -58,7 +58,7 @@ for t in range(N):
             if not np.array_equal(planes[c][:nby, :nbx], fwd[c][:nby, :nbx]):
                 bad += 1
                 print("ENCODE DIFFERENCE", t, w, h, esub, q, ri, opt, c, flush=True)
-        d.read(enc, entropy="auto")
+        kernels[api.kernel_name(d.read(enc, entropy="auto")) + " (own encoder's stream)"] += 1
         if not np.array_equal(d.reconstruct(), O.decode(enc)):
             bad += 1
             print("ENCODE->DECODE DIFFERENCE", t, w, h, esub, q, ri, flush=True)
