@@ -138,6 +138,24 @@ print("checked", n)
         assert "checked" in r.stdout
 
 
+def test_kernel_selection_and_workspace_need_no_device():
+    """mijpeg_kernel_name / mijpeg_workspace_bytes are host logic: the fused kernel per layout, and frames x 1 KiB more
+    scratch when the frames of a batch bring their own quantisation tables (mijpeg_batch.quant_dev)."""
+    d = api.Decoder(None)
+    expect = {"ref_80x48_420": "fused420p_kernel", "ref_100x9_422": "fused422_kernel", "ref_97x61_440": "fused440_kernel"}
+    for name, kernel in expect.items():
+        f = d.read(golden_jpeg(name))
+        assert f.fast_arith == 1
+        assert api.kernel_name(f) == kernel
+        assert api.kernel_name(f, api.FLAG_FORCE_SAFE) == ("fused420_kernel" if "420" in name else "idct_planes_kernel+upsample_color_kernel")
+        assert api.workspace_bytes(f, 5) == 0
+        assert api.workspace_bytes(f, 5, own_tables=True) == 5 * 4 * 64 * 4
+        generic = api.workspace_bytes(f, 5, api.FLAG_FORCE_GENERIC)
+        assert generic >= 5 * 4 * int(f.coef_count)
+        assert api.workspace_bytes(f, 5, api.FLAG_FORCE_GENERIC, own_tables=True) == generic + 5 * 4 * 64 * 4
+    d.close()
+
+
 def test_reconstruct_without_device_fails_loudly():
     d = api.Decoder(None)
     d.read(golden_jpeg("ref_80x48_420"))
