@@ -1012,6 +1012,26 @@ static bool is_440(const mijpeg_info &f)
          f.vsamp[2] == 1;
 }
 
+// The fused kernels address inside a frame with 32-bit byte offsets (planes and pixels; frames are 64 bits apart): frames
+// beyond that -- a 65535 x 65535 picture has 8.6 GB of luma coefficients and 12.9 GB of pixels -- take the generic kernels,
+// whose addressing is 64 bits wide throughout.
+static bool fits32(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  const uint64_t lim = 0xffffffffull;
+  for (int c = 0; c < f.components; c++)
+    if ((uint64_t)f.blocks_w[c] * (uint64_t)f.blocks_h[c] * 128u > lim) return false;
+  if (f.xt && b->xt)
+    for (int c = 0; c < b->xt->residual.components; c++)
+      if ((uint64_t)b->xt->residual.blocks_w[c] * (uint64_t)b->xt->residual.blocks_h[c] * 128u > lim) return false;
+  if (b->out_row_stride < 0) return false; // bottom-up bitmaps: the offsets are unsigned
+  // (a batch description without strides -- mijpeg_kernel_name, mijpeg_workspace_bytes asked ahead of time -- is taken to
+  // have tightly packed lines)
+  const uint64_t line = (uint64_t)f.width * (uint64_t)f.components * ((f.precision > 8 || f.xt) ? 2u : 1u);
+  const uint64_t rs = b->out_row_stride ? (uint64_t)b->out_row_stride : line;
+  return (uint64_t)f.height * rs + line <= lim;
+}
+
 static bool fast_ok(const mijpeg_batch *b)
 {
   // fast arithmetic: range check passed (host decoder) and every delta << 4 fits a signed 16-bit operand
@@ -1028,13 +1048,13 @@ static bool use_fused444(const mijpeg_batch *b)
 {
   const mijpeg_info &f = b->info;
   return is_444(f) && f.ycbcr && !f.xt && f.precision == 8 && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
-         f.range_max[1] < 8190 && f.range_max[2] < 8190;
+         f.range_max[1] < 8190 && f.range_max[2] < 8190 && fits32(b);
 }
 
 static bool use_fused420(const mijpeg_batch *b)
 {
   return is_420(b->info) && b->info.ycbcr && !b->info.xt && b->info.precision == 8 &&
-         !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM));
+         !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fits32(b);
 }
 
 // the packed flavour filters (Cb, Cr) pairs in 16 bits: every chroma sample * 16 is bounded by 4 * range_max, and the
@@ -1051,7 +1071,7 @@ static bool use_fused420p(const mijpeg_batch *b)
 static bool use_fusedxt(const mijpeg_batch *b)
 {
   const mijpeg_info &f = b->info;
-  if (!f.xt || !b->xt || !is_420(f) || f.precision != 8 || (b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_FORCE_SAFE))) return false;
+  if (!f.xt || !b->xt || !is_420(f) || f.precision != 8 || (b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_FORCE_SAFE)) || !fits32(b)) return false;
   // the legacy frame's range check (fast_arith itself is never set for XT frames: the generic kernels run SAFE on them)
   for (int c = 0; c < 3; c++) {
     if (f.range_max[c] >= 16384) return false;
@@ -1078,7 +1098,8 @@ static bool use_fused1(const mijpeg_batch *b)
 {
   const mijpeg_info &f = b->info;
   static const bool off = getenv("MIJPEG_NO_F1") != nullptr; // A-B comparisons
-  return !off && f.components == 1 && !f.xt && f.precision == 8 && !(b->flags & MIJPEG_FLAG_FORCE_GENERIC) && fast_ok(b) && f.range_max[0] < 8190;
+  return !off && f.components == 1 && !f.xt && f.precision == 8 && !(b->flags & MIJPEG_FLAG_FORCE_GENERIC) && fast_ok(b) && f.range_max[0] < 8190 &&
+         fits32(b);
 }
 
 // fused 4:2:2: packed 16-bit chroma filter like the packed 4:2:0 flavour, same bound
@@ -1087,7 +1108,7 @@ static bool use_fused422(const mijpeg_batch *b)
   const mijpeg_info &f = b->info;
   static const bool off = getenv("MIJPEG_NO_F422") != nullptr; // A-B comparisons
   return !off && is_422(f) && f.ycbcr && !f.xt && f.precision == 8 && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
-         f.range_max[1] < 2047 && f.range_max[2] < 2047;
+         f.range_max[1] < 2047 && f.range_max[2] < 2047 && fits32(b);
 }
 
 // fused 4:4:0 (what a losslessly rotated 4:2:2 picture is): the vertical half of the packed filter, same bound
@@ -1096,7 +1117,7 @@ static bool use_fused440(const mijpeg_batch *b)
   const mijpeg_info &f = b->info;
   static const bool off = getenv("MIJPEG_NO_F440") != nullptr; // A-B comparisons
   return !off && is_440(f) && f.ycbcr && !f.xt && f.precision == 8 && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
-         f.range_max[1] < 2047 && f.range_max[2] < 2047;
+         f.range_max[1] < 2047 && f.range_max[2] < 2047 && fits32(b);
 }
 
 const char *mijpeg_kernel_name(const mijpeg_batch *b)

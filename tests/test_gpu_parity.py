@@ -358,6 +358,38 @@ def test_batch_launch_device_resident(oracle):
     d.close()
 
 
+@pytest.mark.parametrize("sub", ["420", "422", "gray"])
+def test_frames_beyond_32_bit_offsets_take_the_generic_kernels(oracle, sub):
+    """The fused kernels address inside a frame with 32-bit offsets.  A destination whose lines are 1 MiB apart puts the last
+    lines of a 4200-line picture beyond 4 GiB: such a launch must run the generic kernels (64-bit addressing), bit-exact,
+    and must ask for their workspace; just below the limit the fused kernel runs into the same padded destination."""
+    torch = _torch()
+    w, h = 256, 4200
+    nc = 1 if sub == "gray" else 3
+    data = synth.encode_jpeg(synth.synth_image(w, h, 77, channels=nc), 85, "444" if sub == "gray" else sub, restart_mcus=4)
+    exp = oracle.decode(data).reshape(h, w * nc)
+    d = api.Decoder(0)
+    f = d.read(data)
+    coef = torch.from_numpy(np.concatenate([d.coefficients(c).reshape(-1) for c in range(nc)])).cuda()
+    assert api.workspace_bytes(f, 1) == 0  # tightly packed lines: a fused kernel
+    for stride, fused in ((1 << 20, False), (1 << 19, True)):
+        out = torch.empty(h * stride, dtype=torch.uint8, device="cuda")
+        if fused:
+            api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, stride, h * stride, stream=torch.cuda.current_stream().cuda_stream)
+        else:
+            with pytest.raises(api.MijpegError):  # the generic kernels' workspace is missing
+                api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, stride, h * stride, stream=torch.cuda.current_stream().cuda_stream)
+            wsb = api.workspace_bytes(f, 1, api.FLAG_FORCE_GENERIC)
+            ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+            api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, stride, h * stride, workspace=ws.data_ptr(), workspace_bytes=wsb,
+                                   stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = out.view(h, stride)[:, :w * nc].cpu().numpy()
+        assert np.array_equal(got, exp), (sub, stride)
+        del out
+    d.close()
+
+
 @pytest.mark.parametrize("sub", ["420", "444"])
 def test_unaligned_output_stride(oracle, sub):
     """Packed rows whose stride is not a multiple of 8 bytes (131 * 3 = 393) take the byte-store path of the fused
