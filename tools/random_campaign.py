@@ -63,7 +63,42 @@ for t in range(N):
             bad += 1
             print("ENCODE->DECODE DIFFERENCE", t, w, h, esub, q, ri, flush=True)
         kernels["(encoded streams)"] += 1
-print(f"{N} random streams ({skipped} refused by the test encoder), {time.time() - t0:.0f} s: {bad} differences")
+# batches whose frames bring their own tables (mijpeg_batch.quant_dev): random shapes, layouts and qualities
+NB = int(os.environ.get("N_BATCH", str(N // 20)))
+if NB:
+    import torch  # noqa: E402
+batch_frames = 0
+for t in range(NB):
+    w, h = int(rng.integers(8, 900)), int(rng.integers(8, 600))
+    sub = ["444", "422", "420", "gray", "440", "411"][int(rng.integers(0, 6))]
+    nc = 1 if sub == "gray" else 3
+    n = int(rng.integers(2, 9))
+    quals = [int(rng.choice([5, 25, 50, 75, 85, 92, 98, 100])) for _ in range(n)]
+    ri = int(rng.choice([1, 2, 5, 16]))
+    imgs = [synth.synth_image(w, h, 9000 + 10 * t + i, channels=nc) for i in range(n)]
+    if rng.integers(0, 3) == 0:
+        imgs = [rng.integers(0, 256, im.shape).astype(np.uint8) for im in imgs]
+    try:
+        if sub in ("440", "411"):
+            streams = [d.encode(im, q, sub, ri, bool(i & 1)) for i, (im, q) in enumerate(zip(imgs, quals))]
+        else:
+            streams = [synth.encode_jpeg(im, q, "444" if sub == "gray" else sub, restart_mcus=ri, optimize=bool(i & 1)) for i, (im, q) in enumerate(zip(imgs, quals))]
+    except OSError:  # the test encoder refuses some noise pictures
+        skipped += 1
+        continue
+    flags = int(rng.choice([0, 0, api.FLAG_FORCE_SAFE, api.FLAG_FORCE_GENERIC]))
+    info = d.decode_batch_device(streams, min_intervals=1)
+    row = w * nc
+    out = torch.zeros((n, h, row), dtype=torch.uint8, device="cuda")
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row, flags)
+    res = out.cpu().numpy().reshape(n, h, w, nc)
+    kernels[api.kernel_name(info, flags) + " (batch, tables per frame)"] += 1
+    for i in range(n):
+        batch_frames += 1
+        if not np.array_equal(res[i].squeeze(), O.decode(streams[i]).squeeze()):
+            bad += 1
+            print("BATCH DIFFERENCE", t, i, w, h, sub, quals, ri, flags, flush=True)
+print(f"{N} random streams ({skipped} refused by the test encoder), {NB} batches with tables per frame ({batch_frames} frames), {time.time() - t0:.0f} s: {bad} differences")
 print("reconstruction kernels:", dict(kernels))
 print("entropy decoder used:", dict(entropy))
 sys.exit(1 if bad else 0)
