@@ -1898,6 +1898,8 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
   if (max_y >= f.height) max_y = f.height - 1;
   if (min_comp < 0) min_comp = 0;
   if (max_comp >= nc) max_comp = nc - 1;
+  // an empty request after clipping is served by doing nothing (codestream/rectanglerequest.cpp clips alike)
+  if (min_x > max_x || min_y > max_y || min_comp > max_comp) return MIJPEG_OK;
   if (to_device) {
     ScatterArgs a;
     memset(&a, 0, sizeof(a));

@@ -92,29 +92,44 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
   struct JPG_Hook *io = (struct JPG_Hook *)tags->GetTagPtr(JPGTAG_HOOK_IOHOOK);
   if (!io) return p->fail(JPGERR_MISSING_PARAMETER, "no I/O hook (JPGTAG_HOOK_IOHOOK) specified");
   if (!p->loaded) {
-    // pull the whole codestream: the entropy decoder works on an in-memory stream
+    // pull the whole codestream: the entropy decoder works on an in-memory stream.  As io/iostream.cpp:173-197:
+    // only a return of 0 is the end of the file (short reads from pipes and sockets are normal), the hook may
+    // hand back a buffer of its own and a changed user data word, both are re-fetched after every call.
     p->stream.clear();
     const size_t chunk = 1 << 20;
+    JPG_LONG userdata = tags->GetTagData(JPGTAG_FIO_USERDATA, 0); // io/iostream.cpp:89-91
+    size_t have = 0;
     for (;;) {
-      const size_t at = p->stream.size();
-      p->stream.resize(at + chunk);
+      if (p->stream.size() - have < chunk / 2) p->stream.resize(have + chunk);
+      uint8_t *buf = p->stream.data() + have;
+      const size_t room = p->stream.size() - have;
       struct JPG_TagItem iotags[] = {
+          JPG_PointerTag(JPGTAG_FIO_BUFFER, buf),
+          JPG_ValueTag(JPGTAG_FIO_SIZE, (JPG_LONG)room),
           JPG_PointerTag(JPGTAG_FIO_HANDLE, tags->GetTagPtr(JPGTAG_HOOK_IOSTREAM)),
-          JPG_PointerTag(JPGTAG_FIO_BUFFER, p->stream.data() + at),
-          JPG_ValueTag(JPGTAG_FIO_SIZE, (JPG_LONG)chunk),
           JPG_ValueTag(JPGTAG_FIO_ACTION, JPGFLAG_ACTION_READ),
+          JPG_ValueTag(JPGTAG_FIO_USERDATA, userdata),
           JPG_ValueTag(JPGTAG_FIO_SEEKMODE, JPGFLAG_OFFSET_CURRENT),
           JPG_ValueTag(JPGTAG_FIO_OFFSET, 0),
-          JPG_PointerTag(JPGTAG_FIO_USERDATA, io->hk_pData),
           JPG_EndTag};
       const JPG_LONG got = io->CallLong(iotags);
       if (got < 0) {
         p->stream.clear();
-        return p->fail(got, "the I/O hook signalled an error");
+        return p->fail(got, "Client signalled an error on reading from the file hook");
       }
-      p->stream.resize(at + (size_t)got);
-      if ((size_t)got < chunk) break;
+      if (got == 0) break;
+      const uint8_t *from = (const uint8_t *)iotags[0].ti_Data.ti_pPtr;
+      userdata = iotags[4].ti_Data.ti_lData;
+      if (from != buf) { // the hook filled a buffer of its own
+        if ((size_t)got > room) p->stream.resize(have + (size_t)got);
+        memcpy(p->stream.data() + have, from, (size_t)got);
+      } else if ((size_t)got > room) {
+        p->stream.clear();
+        return p->fail(JPGERR_OVERFLOW_PARAMETER, "the I/O hook reports more bytes than the buffer holds");
+      }
+      have += (size_t)got;
     }
+    p->stream.resize(have);
     if (p->stream.empty()) return p->fail(JPGERR_STREAM_EMPTY, "the I/O hook delivered no data");
     int rc = mijpeg_set_input(p->dec, p->stream.data(), p->stream.size());
     if (rc) return p->fail_from_decoder(rc);

@@ -11,6 +11,7 @@
 #include "jpeg_oracle.h"
 
 #include <math.h>
+#include <setjmp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -39,17 +40,84 @@ static void build_scan_order(void)
 }
 
 /* ------------------------------------------------------------------------------------------
- * Header parsing (marker/frame.cpp:111-..., marker/scan.cpp:163-..., marker/quantization.cpp:474-537,
- * coding/huffmantemplate.cpp:878-905, codestream/tables.cpp:1003-...).
+ * The codestream state machine, restated from the reference *including its behaviour on damaged
+ * streams*: which conditions it throws on (JPG_THROW -> the whole Read fails, no picture), which it only
+ * warns about and decodes through (JPG_WARN), how the entropy parser resynchronises at restart
+ * markers and how the bit reader behaves at markers and at the end of the data.
+ *
+ *   interface/jpeg.cpp:244-354          JPEG::ReadInternal (the driver loop)
+ *   codestream/decoder.cpp:77-108       SOI
+ *   codestream/tables.cpp:1003-1418     Tables::ParseTablesIncremental (one marker segment per call)
+ *   codestream/image.cpp:616-650, 480-600   frame header, "found a double frame header"
+ *   marker/frame.cpp:111-208, 796-899, 1016-1123   SOF, StartParseScan / ScanForScanHeader, ParseTrailer
+ *   marker/scan.cpp:163-315, 985-994    SOS, parser selection
+ *   codestream/entropyparser.{hpp:147-160, cpp:117-201}   BeginReadMCU / ParseRestartMarker
+ *   codestream/sequentialscan.cpp:112-141, 266-274, 381-428, 678-773
+ *   codestream/refinementscan.cpp:225-233, 305-345, 584-700
+ *   io/bitstream.{hpp:106-210, cpp:56-137}, io/bytestream.hpp:176-244, io/iostream.cpp:538-618
+ *   coding/huffmandecoder.hpp:103-124, coding/huffmantemplate.cpp:802-905, marker/huffmantable.cpp:127-169
+ *   marker/quantization.cpp:474-537, marker/restartintervalmarker.cpp:80-102, marker/adobemarker.cpp:96-117,
+ *   marker/jfifmarker.cpp:103-129, marker/exifmarker.cpp:117-128, boxes/box.cpp:93-200
+ * Errors leave through longjmp like the reference's JPG_THROW (std/setjmp based, tools/environment.hpp); the
+ * reference's error code (JPGERR_*, interface/parameters.hpp:1156-1228) is kept in oj_info.ref_error.
  * ---------------------------------------------------------------------------------------- */
+#define RS_INVALID_PARAMETER (-1024)
+#define RS_UNEXPECTED_EOF (-1025)
+#define RS_OVERFLOW_PARAMETER (-1028)
+#define RS_OBJECT_DOESNT_EXIST (-1031)
+#define RS_NOT_IMPLEMENTED (-1034)
+#define RS_MALFORMED_STREAM (-1038)
+#define RS_OUT_OF_MEMORY (-2048)
+
+/* io/bytestream.hpp over a memory buffer.  Get() past the end returns EOF; PeekWord() needs two bytes and
+ * leaves the position alone; LastUnDo() takes back the last byte unless the last Get() hit the end
+ * (the refill then left an empty buffer: bytestream.hpp:229-236, iostream.cpp:132-197); SkipBytes() over the
+ * end does not fail with the reference's seekable file hook (iostream.cpp:327-365 caches the seek), the
+ * following reads return EOF. */
+#define BS_EOF (-1L)
+typedef struct {
+  const uint8_t *d;
+  size_t n, pos;
+  int at_eof; /* the last Get() failed */
+} oj_bs;
+
+static void bs_open(oj_bs *s, const uint8_t *d, size_t n) { s->d = d; s->n = n; s->pos = 0; s->at_eof = 0; }
+static long bs_get(oj_bs *s)
+{
+  if (s->pos >= s->n) { s->at_eof = 1; return BS_EOF; }
+  s->at_eof = 0;
+  return s->d[s->pos++];
+}
+static long bs_peekword(oj_bs *s)
+{
+  if (s->pos + 2 > s->n) return BS_EOF;
+  return ((long)s->d[s->pos] << 8) | s->d[s->pos + 1];
+}
+static long bs_getword(oj_bs *s)
+{
+  long a = bs_get(s), b;
+  if (a == BS_EOF) return BS_EOF;
+  b = bs_get(s);
+  if (b == BS_EOF) return BS_EOF;
+  return (a << 8) | b;
+}
+static void bs_lastundo(oj_bs *s) { if (!s->at_eof && s->pos > 0) s->pos--; }
+static void bs_skip(oj_bs *s, long n)
+{
+  if (n <= 0) return;
+  if ((size_t)n > s->n - s->pos) s->pos = s->n; else s->pos += (size_t)n;
+}
+
+/* One Huffman table as the DHT marker delivered it (coding/huffmantemplate.cpp:878-905: sixteen counts, then
+ * as many values as they add up to -- up to 4080, nothing checks 256) and its decoder, built on first use. */
 typedef struct {
   int defined;
   uint8_t counts[16];
-  uint8_t values[256];
+  uint8_t values[16 * 255];
   int nvalues;
-  /* canonical decode tables, T.81 F.2.2.3 (equivalent to the two-level LUT the reference builds
-   * in coding/huffmantemplate.cpp:802-874) */
-  int32_t mincode[17], maxcode[18], valptr[17];
+  int built;
+  uint32_t first[17];  /* left-aligned 16-bit code of the first code word of length l */
+  int32_t valptr[17];
 } oj_huff;
 
 /* One JPEG XT box, reassembled from its APP11 segments (boxes/box.cpp:88-200). */
@@ -58,75 +126,422 @@ typedef struct {
   uint16_t en;
   uint8_t *data;
   size_t len, cap;
+  uint64_t boxsize; /* payload bytes the box header announces (LBox - 8, XLBox - 16) */
+  int complete;     /* all of them arrived and the content was parsed */
 } oj_box;
 
 #define OJ_MAX_BOXES 64
+enum { FT_BASELINE = 0, FT_SEQUENTIAL = 1, FT_PROGRESSIVE = 2 };
+
 typedef struct {
+  jmp_buf jb;
+  int err;          /* reference error code of the throw */
+  int unsupported;  /* the throw is ours: a coding process outside the accelerated path */
+  int warnings;
   const uint8_t *data;
   size_t len;
   oj_info *info;
-  oj_huff dc[4], ac[4];
-  int restart_interval;
-  int have_frame;
-  int need_dnl; /* SOF carried zero lines */
+  /* tables (codestream/tables.hpp) */
+  int have_quant, have_huff;
+  oj_huff huff[8]; /* 0..3 DC, 4..7 AC (marker/huffmantable.cpp:153) */
+  uint32_t restart_interval;
+  /* frame */
+  int have_frame, frame_type;
+  int need_dnl;
   int progressive; /* SOF2 */
   int hidden;      /* JPEG XT: bits of every coefficient that travel in hidden refinement scans (RSPC box) */
-  oj_box *boxes; /* optional: where APP11 boxes are collected (OJ_MAX_BOXES entries) */
+  oj_box *boxes;   /* where APP11 boxes are collected (OJ_MAX_BOXES entries); the caller's array or walk()'s own */
   int nboxes;
+  int walk_all;    /* the caller wants the boxes: walk all scans even without planes */
+  int nested;      /* this is the residual codestream of a RESI box */
+  int32_t *const *planes; /* NULL: headers only */
 } oj_parser;
+
+static void rs_throw(oj_parser *ps, int code)
+{
+  ps->err = code;
+  longjmp(ps->jb, 1);
+}
+static void rs_unsupported(oj_parser *ps)
+{
+  ps->unsupported = 1;
+  rs_throw(ps, RS_NOT_IMPLEMENTED);
+}
+#define RS_WARN(ps) ((ps)->warnings++)
 
 static int rd16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
 
-static void huff_build(oj_huff *h)
+/* HuffmanTemplate::BuildDecoder, coding/huffmantemplate.cpp:802-874.  The reference fills a two-level 8+8 bit
+ * table; code words are handed out in increasing order without gaps, so "the code word whose range holds the next
+ * sixteen bits" is the same function.  Throws where the reference throws. */
+static void huff_build(oj_parser *ps, oj_huff *h)
 {
-  int l, code = 0, k = 0;
-  for (l = 1; l <= 16; l++) {
-    h->valptr[l] = k;
-    h->mincode[l] = code;
-    code += h->counts[l - 1];
-    k += h->counts[l - 1];
-    h->maxcode[l] = h->counts[l - 1] ? code - 1 : -1;
-    code <<= 1;
-  }
-  h->maxcode[17] = 0x7fffffff;
-}
-
-static int parse_dqt(oj_parser *ps, const uint8_t *p, int n)
-{
-  /* marker/quantization.cpp:474-537: Pq/Tq byte, then 64 entries in zig-zag order, stored
-   * de-zigzagged (:502-527). */
-  while (n > 0) {
-    int pq = p[0] >> 4, tq = p[0] & 15, i;
-    if (tq > 3 || pq > 1) return OJ_ERR_MALFORMED;
-    if (n < 1 + 64 * (pq + 1)) return OJ_ERR_MALFORMED;
-    for (i = 0; i < 64; i++) {
-      int v = pq ? rd16(p + 1 + 2 * i) : p[1 + i];
-      ps->info->quant[tq][g_scan_order[i]] = (uint16_t)v;
+  uint32_t code = 0;
+  int i, j, k = 0;
+  for (i = 0; i < 16; i++) {
+    h->first[i + 1] = code;
+    h->valptr[i + 1] = k;
+    for (j = 0; j < h->counts[i]; j++) {
+      const uint32_t last = code + (1u << (15 - i));
+      if (last > 0x10000u) rs_throw(ps, RS_MALFORMED_STREAM); /* "entry depends on more bits than available" */
+      if ((code >> (15 - i)) >= (1u << (i + 1)) - 1) RS_WARN(ps); /* all-1 code */
+      code = last;
+      k++;
     }
-    ps->info->quant_defined[tq] = 1;
-    p += 1 + 64 * (pq + 1);
-    n -= 1 + 64 * (pq + 1);
   }
-  return OJ_OK;
+  h->built = 1;
 }
 
-static int parse_dht(oj_parser *ps, const uint8_t *p, int n)
+/* Annex K.3.3 tables: what HuffmanTable::DCTemplateOf / ACTemplateOf (marker/huffmantable.cpp:186-228) install when
+ * a scan selects a table no DHT segment defined (as long as one DHT segment exists at all).  The reference picks its
+ * defaults by frame type, precision and scan index (coding/huffmantemplate.cpp:140-790); for baseline and sequential
+ * 8-bit frames they are the tables of the standard, regenerated here from the standard's description.  Other frame
+ * types: not restated (reported as unsupported). */
+static void huff_default(oj_parser *ps, oj_huff *h, int ac, int chroma)
 {
-  while (n > 0) {
-    int tc = p[0] >> 4, th = p[0] & 15, i, total = 0;
+  static const uint8_t dc_l_bits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+  static const uint8_t dc_c_bits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+  static const uint8_t ac_l_bits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+  static const uint8_t ac_c_bits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+  static const uint8_t ac_l_head[] = {0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61,
+                                      0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52,
+                                      0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82};
+  static const uint8_t ac_c_head[] = {0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61,
+                                      0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33,
+                                      0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1};
+  int i, n = 0;
+  if (ps->frame_type == FT_PROGRESSIVE || ps->info->precision != 8) rs_unsupported(ps);
+  memset(h, 0, sizeof(*h));
+  if (!ac) {
+    memcpy(h->counts, chroma ? dc_c_bits : dc_l_bits, 16);
+    for (i = 0; i < 12; i++) h->values[n++] = (uint8_t)i;
+  } else {
+    /* K.5 / K.6: the code words of up to 15 bits in the order the standard lists them, then all the remaining
+     * run/size pairs (sizes 1..10) in numerical order as 16-bit codes */
+    const uint8_t *head = chroma ? ac_c_head : ac_l_head;
+    const int nhead = chroma ? (int)sizeof(ac_c_head) : (int)sizeof(ac_l_head);
+    uint8_t used[256];
+    int r, s;
+    memcpy(h->counts, chroma ? ac_c_bits : ac_l_bits, 16);
+    memset(used, 0, sizeof(used));
+    for (i = 0; i < nhead; i++) { h->values[n++] = head[i]; used[head[i]] = 1; }
+    for (r = 0; r < 16; r++)
+      for (s = 1; s <= 10; s++) {
+        const int v = (r << 4) | s;
+        if (!used[v]) h->values[n++] = (uint8_t)v;
+      }
+  }
+  h->nvalues = n;
+  h->defined = 1;
+}
+
+/* Quantization::ParseMarker, marker/quantization.cpp:474-537 */
+static void rs_parse_dqt(oj_parser *ps, oj_bs *io)
+{
+  long len = bs_getword(io);
+  if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
+  len -= 2;
+  while (len > 2) {
+    uint16_t deltas[64];
+    long type = bs_get(io), target;
+    int i;
+    if (type == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+    target = type & 15;
+    type >>= 4;
+    if (type != 0 && type != 1) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (target > 3) rs_throw(ps, RS_MALFORMED_STREAM);
+    len -= 1;
+    if (type == 0) {
+      if (len < 64) rs_throw(ps, RS_MALFORMED_STREAM);
+      for (i = 0; i < 64; i++) {
+        long v = bs_get(io);
+        if (v == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+        deltas[g_scan_order[i]] = (uint16_t)v;
+      }
+      len -= 64;
+    } else {
+      if (len < 128) rs_throw(ps, RS_MALFORMED_STREAM);
+      for (i = 0; i < 64; i++) {
+        long v = bs_getword(io);
+        if (v == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+        deltas[g_scan_order[i]] = (uint16_t)v;
+      }
+      len -= 128;
+    }
+    memcpy(ps->info->quant[target], deltas, sizeof(deltas));
+    ps->info->quant_defined[target] = 1;
+  }
+  ps->have_quant = 1; /* m_pQuant exists as soon as a DQT marker was seen, tables.cpp:1007-1009 */
+  if (len != 0) rs_throw(ps, RS_MALFORMED_STREAM);
+}
+
+/* HuffmanTable::ParseMarker, marker/huffmantable.cpp:127-169 + HuffmanTemplate::ParseMarker */
+static void rs_parse_dht(oj_parser *ps, oj_bs *io)
+{
+  long len = bs_getword(io);
+  if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
+  len -= 2;
+  while (len > 0) {
+    long t = bs_get(io);
+    size_t p = io->pos, q;
     oj_huff *h;
-    if (tc > 1 || th > 3 || n < 17) return OJ_ERR_MALFORMED;
-    h = tc ? &ps->ac[th] : &ps->dc[th];
-    for (i = 0; i < 16; i++) { h->counts[i] = p[1 + i]; total += p[1 + i]; }
-    if (total > 256 || n < 17 + total) return OJ_ERR_MALFORMED;
-    memcpy(h->values, p + 17, (size_t)total);
+    int i, total = 0;
+    if (t == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+    len--;
+    if ((t >> 4) > 1) rs_throw(ps, RS_MALFORMED_STREAM);
+    if ((t & 15) > 3) rs_throw(ps, RS_MALFORMED_STREAM);
+    h = &ps->huff[(t & 3) | ((t & 0xf0) >> 2)];
+    memset(h, 0, sizeof(*h));
+    for (i = 0; i < 16; i++) {
+      long cnt = bs_get(io);
+      if (cnt == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+      h->counts[i] = (uint8_t)cnt;
+      total += (int)cnt;
+    }
+    for (i = 0; i < total; i++) {
+      long v = bs_get(io);
+      if (v == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+      h->values[i] = (uint8_t)v;
+    }
     h->nvalues = total;
     h->defined = 1;
-    huff_build(h);
-    p += 17 + total;
-    n -= 17 + total;
+    q = io->pos - p;
+    if (q > (size_t)len) rs_throw(ps, RS_MALFORMED_STREAM);
+    len -= (long)q;
   }
-  return OJ_OK;
+  ps->have_huff = 1;
+}
+
+/* Box::ParseBoxMarker, boxes/box.cpp:93-200: the segment framing only (en, z, LBox, TBox [, XLBox], payload); what the
+ * boxes mean is checked where they are used.  `length` is the marker length, CI already removed from the stream. */
+static void rs_parse_box_marker(oj_parser *ps, oj_bs *io, long length)
+{
+  long overhead = 2 + 2 + 2 + 4 + 4 + 4, blen, dt;
+  uint16_t en;
+  uint64_t lbox;
+  uint32_t tbox;
+  int b;
+  if (length <= overhead) rs_throw(ps, RS_MALFORMED_STREAM);
+  en = (uint16_t)bs_getword(io);
+  bs_getword(io); bs_getword(io); /* sequence number: segments arrive in order */
+  lbox = (uint64_t)(uint32_t)(bs_getword(io) << 16);
+  lbox |= (uint64_t)(bs_getword(io) & 0xffff);
+  blen = length - overhead;
+  if (lbox != 1 && lbox < 8) rs_throw(ps, RS_MALFORMED_STREAM);
+  tbox = (uint32_t)(bs_getword(io) << 16);
+  dt = bs_getword(io);
+  if (dt == BS_EOF) rs_throw(ps, RS_UNEXPECTED_EOF);
+  tbox |= (uint32_t)dt;
+  if (lbox == 1) {
+    overhead += 8;
+    if (length <= overhead) rs_throw(ps, RS_MALFORMED_STREAM);
+    lbox = (uint64_t)(bs_getword(io) & 0xffff) << 48;
+    lbox |= (uint64_t)(bs_getword(io) & 0xffff) << 32;
+    lbox |= (uint64_t)(bs_getword(io) & 0xffff) << 16;
+    dt = bs_getword(io);
+    if (dt == BS_EOF) rs_throw(ps, RS_UNEXPECTED_EOF);
+    if (lbox < 8 + 8) rs_throw(ps, RS_MALFORMED_STREAM);
+    lbox |= (uint64_t)dt;
+    blen -= 8;
+    lbox -= 8;
+  }
+  lbox -= 8; /* the box length and type are not payload */
+  switch (tbox) { /* Box::CreateBox, boxes/box.cpp:391-428: boxes of unknown type are skipped, nothing about them is checked */
+  case 0x52455349u: case 0x46494e45u: case 0x5246494eu: case 0x414c4641u: case 0x4146494eu: case 0x41524553u:
+  case 0x41525246u:                                     /* RESI FINE RFIN ALFA AFIN ARES ARRF */
+  case 0x53504543u: case 0x41535043u:                   /* SPEC ASPC */
+  case 0x544f4e45u: case 0x46544f4eu: case 0x43555256u: /* TONE FTON CURV */
+  case 0x4d545258u: case 0x4c43484bu: case 0x66747970u: /* MTRX LCHK ftyp */
+    break;
+  default:
+    bs_skip(io, blen);
+    return;
+  }
+  for (b = 0; b < ps->nboxes; b++)
+    if (ps->boxes[b].type == tbox && ps->boxes[b].en == en) break;
+  if (b < ps->nboxes) {
+    if (ps->boxes[b].boxsize != lbox) rs_throw(ps, RS_MALFORMED_STREAM); /* "box size is not consistent across APP11 markers" */
+    if (ps->boxes[b].complete) rs_throw(ps, RS_MALFORMED_STREAM);        /* "received box data beyond box length" */
+  } else {
+    if (ps->nboxes == OJ_MAX_BOXES) rs_unsupported(ps);
+    memset(&ps->boxes[b], 0, sizeof(oj_box));
+    ps->boxes[b].type = tbox; ps->boxes[b].en = en; ps->boxes[b].boxsize = lbox;
+    ps->nboxes++;
+  }
+  if ((size_t)blen > io->n - io->pos) blen = (long)(io->n - io->pos);
+  if (ps->boxes[b].len + (size_t)blen > ps->boxes[b].cap) {
+    size_t cap = (ps->boxes[b].len + (size_t)blen) * 2 + 64;
+    uint8_t *nd = (uint8_t *)realloc(ps->boxes[b].data, cap);
+    if (!nd) rs_throw(ps, RS_OUT_OF_MEMORY);
+    ps->boxes[b].data = nd; ps->boxes[b].cap = cap;
+  }
+  memcpy(ps->boxes[b].data + ps->boxes[b].len, io->d + io->pos, (size_t)blen);
+  ps->boxes[b].len += (size_t)blen;
+  io->pos += (size_t)blen;
+  if (ps->boxes[b].len > ps->boxes[b].boxsize) rs_throw(ps, RS_MALFORMED_STREAM); /* "more data in the application marker than indicated" */
+  if (ps->boxes[b].len == ps->boxes[b].boxsize) {
+    const oj_box *bx = &ps->boxes[b];
+    ps->boxes[b].complete = 1;
+    if (tbox == 0x66747970u) { /* 'ftyp': FileTypeBox::ParseBoxContent, boxes/filetypebox.cpp:71-120 */
+      if (bx->boxsize < 8) rs_throw(ps, RS_MALFORMED_STREAM);
+      if (memcmp(bx->data, "jpxt", 4) != 0) rs_throw(ps, RS_MALFORMED_STREAM); /* "file is not compatible to JPEG XT" */
+      if ((bx->boxsize - 8) & 3) rs_throw(ps, RS_MALFORMED_STREAM);
+    }
+  }
+}
+
+/* Tables::ParseTablesIncremental, codestream/tables.cpp:1003-1418: one marker segment of the tables/misc section.
+ * Returns 0 when the next marker does not belong to it (SOFn, SOS, EOI, DHP) or the stream ended. */
+static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
+{
+  long marker = bs_peekword(io);
+  switch (marker) {
+  case 0xffdb: bs_getword(io); rs_parse_dqt(ps, io); break;
+  case 0xffc4: bs_getword(io); rs_parse_dht(ps, io); break;
+  case 0xffcc: rs_unsupported(ps); break; /* DAC: arithmetic coding conditioning, not on this path */
+  case 0xffdd: { /* RestartIntervalMarker::ParseMarker, marker/restartintervalmarker.cpp:80-102 (not the JPEG LS flavour) */
+    long len;
+    bs_getword(io);
+    len = bs_getword(io);
+    if (len < 4 || len > 4) rs_throw(ps, RS_MALFORMED_STREAM);
+    len = bs_getword(io);
+    if (len == BS_EOF) rs_throw(ps, RS_UNEXPECTED_EOF);
+    ps->restart_interval = (uint32_t)(len & 0xffff);
+    break;
+  }
+  case 0xfffe: { /* COM */
+    long size;
+    bs_getword(io);
+    size = bs_getword(io);
+    if (size == BS_EOF) rs_throw(ps, RS_UNEXPECTED_EOF);
+    if (size <= 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    bs_skip(io, size - 2);
+    break;
+  }
+  case 0xfff8: rs_throw(ps, RS_MALFORMED_STREAM); break; /* LSE outside JPEG LS */
+  case 0xffe0: { /* APP0: JFIF is parsed (marker/jfifmarker.cpp:103-129), anything else skipped */
+    long len;
+    bs_getword(io);
+    len = bs_getword(io);
+    if (len >= 2 + 5 + 2 + 1 + 2 + 2 + 1 + 1) {
+      const char *id = "JFIF";
+      while (*id) { len--; if (bs_get(io) != *id) break; id++; }
+      if (*id == 0) {
+        len--;
+        if (bs_get(io) == 0) {
+          long unit, l = (len + 5) & 0xffff;
+          if (l < 2 + 5 + 2 + 1 + 2 + 2 + 1 + 1) rs_throw(ps, RS_MALFORMED_STREAM);
+          bs_get(io); bs_get(io);
+          unit = bs_get(io);
+          if ((unit & 0xff) > 2) rs_throw(ps, RS_MALFORMED_STREAM); /* UBYTE unit > Centimeter; EOF reads as 0xff */
+          bs_getword(io); bs_getword(io);
+          l -= 2 + 5 + 2 + 1 + 2 + 2;
+          if (l > 0) bs_skip(io, l);
+          break;
+        }
+      }
+    }
+    if (len <= 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    bs_skip(io, len - 2);
+    break;
+  }
+  case 0xffe1: { /* APP1: Exif header checked (marker/exifmarker.cpp:117-128) */
+    long len;
+    bs_getword(io);
+    len = bs_getword(io);
+    if (len >= 2 + 4 + 2 + 2 + 2 + 4 + 2) {
+      const char *id = "Exif";
+      while (*id) { len--; if (bs_get(io) != *id) break; id++; }
+      if (*id == 0) {
+        len -= 2;
+        if (bs_getword(io) == 0) {
+          long l = (len + 4 + 2) & 0xffff;
+          if (l < 2 + 4 + 2 + 2 + 2 + 4 + 2 + 4) rs_throw(ps, RS_MALFORMED_STREAM);
+          l -= 2 + 4 + 2;
+          if (l > 0) bs_skip(io, l);
+          break;
+        }
+      }
+    }
+    if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    bs_skip(io, len - 2);
+    break;
+  }
+  case 0xffeb: { /* APP11: JPEG XT boxes */
+    long len;
+    bs_getword(io);
+    len = bs_getword(io);
+    if (len >= 2 + 2 + 2 + 4 + 4 + 4) {
+      if (bs_peekword(io) == 0x4a50) {
+        bs_getword(io);
+        if (ps->nested) rs_throw(ps, RS_MALFORMED_STREAM); /* "Found a box in the residual codestream." */
+        rs_parse_box_marker(ps, io, len & 0xffff);
+        break;
+      }
+    }
+    if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    bs_skip(io, len - 2);
+    break;
+  }
+  case 0xffee: { /* APP14: Adobe (marker/adobemarker.cpp:96-117), only at its exact size */
+    long len;
+    bs_getword(io);
+    len = bs_getword(io);
+    if (len == 2 + 5 + 2 + 2 + 2 + 1) {
+      const char *id = "Adobe";
+      while (*id) { len--; if (bs_get(io) != *id) break; id++; }
+      if (*id == 0) {
+        long version, color;
+        if (((len + 5) & 0xffff) != 2 + 5 + 2 + 2 + 2 + 1) rs_throw(ps, RS_MALFORMED_STREAM);
+        version = bs_getword(io) & 0xffff;
+        if (version != 100 && version != 101) rs_throw(ps, RS_MALFORMED_STREAM);
+        bs_getword(io); bs_getword(io);
+        color = bs_get(io);
+        if (color < 0 || color > 2) rs_throw(ps, RS_MALFORMED_STREAM);
+        ps->info->adobe_transform = (int)color;
+        break;
+      }
+    }
+    if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    bs_skip(io, len - 2);
+    break;
+  }
+  case 0xffdf: rs_throw(ps, RS_MALFORMED_STREAM); break; /* EXP outside a hierarchical process (size / content errors are MALFORMED as well) */
+  case 0xffc8: { /* JPG extensions */
+    long len;
+    bs_getword(io);
+    len = bs_getword(io);
+    if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    bs_skip(io, len - 2);
+    break;
+  }
+  case 0xffc0: case 0xffc1: case 0xffc2: case 0xffc3: case 0xffc5: case 0xffc6: case 0xffc7: case 0xffc9:
+  case 0xffca: case 0xffcb: case 0xffcd: case 0xffce: case 0xffcf: case 0xffb1: case 0xffb2: case 0xffb3:
+  case 0xffb9: case 0xffba: case 0xffbb: case 0xffd9: case 0xffda: case 0xffde: case 0xfff7:
+    return 0;
+  case 0xffff: bs_get(io); break; /* a filler byte */
+  case 0xffd0: case 0xffd1: case 0xffd2: case 0xffd3: case 0xffd4: case 0xffd5: case 0xffd6: case 0xffd7:
+    bs_getword(io);
+    RS_WARN(ps); /* stray restart marker */
+    break;
+  default:
+    if (marker >= 0xffc0 && (marker < 0xffd0 || marker >= 0xffd8) && marker < 0xfff0) {
+      long size;
+      bs_getword(io);
+      size = bs_getword(io);
+      if (size == BS_EOF) rs_throw(ps, RS_UNEXPECTED_EOF);
+      if (size <= 2) rs_throw(ps, RS_MALFORMED_STREAM);
+      bs_skip(io, size - 2);
+    } else {
+      long dt;
+      RS_WARN(ps); /* "found invalid marker, probably a marker size is out of range" (covers EOF = -1 as well) */
+      bs_get(io);
+      do { dt = bs_get(io); } while (dt != 0xff && dt != BS_EOF);
+      if (dt == 0xff) bs_lastundo(io);
+      else return 0;
+    }
+  }
+  return 1;
 }
 
 static void frame_geometry(oj_info *f)
@@ -144,199 +559,258 @@ static void frame_geometry(oj_info *f)
   }
 }
 
-static int parse_sof(oj_parser *ps, const uint8_t *p, int n)
+/* Image::ParseFrameHeader + Frame::ParseMarker + Component::ParseMarker: codestream/image.cpp:616-650,
+ * marker/frame.cpp:111-208, marker/component.cpp:86-111, marker/component.hpp:99-107 */
+static void rs_parse_frame_header(oj_parser *ps, oj_bs *io)
 {
   oj_info *f = ps->info;
-  int c;
-  if (n < 6) return OJ_ERR_MALFORMED;
-  f->precision = p[0];
-  f->height = rd16(p + 1);
-  f->width = rd16(p + 3);
-  f->ncomp = p[5];
-  if (f->precision != 8 && f->precision != 12) return OJ_ERR_UNSUPPORTED;
-  if (f->ncomp < 1 || f->ncomp > OJ_MAX_COMP || n < 6 + 3 * f->ncomp) return OJ_ERR_MALFORMED;
-  if (f->width == 0) return OJ_ERR_MALFORMED;
-  ps->need_dnl = f->height == 0; /* height arrives in a DNL marker behind the first scan (entropyparser.cpp:204-249) */
-  f->hmax = f->vmax = 1;
+  long marker = bs_peekword(io), len, data;
+  int c, type = -1;
+  if (marker == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+  if (marker == 0xffd9) rs_throw(ps, RS_MALFORMED_STREAM);
+  marker = bs_getword(io);
+  switch (marker) {
+  case 0xffc0: type = FT_BASELINE; break;
+  case 0xffc1: type = FT_SEQUENTIAL; break;
+  case 0xffc2: type = FT_PROGRESSIVE; break;
+  case 0xffc3: case 0xffc5: case 0xffc6: case 0xffc7: case 0xffc9: case 0xffca: case 0xffcb: case 0xffcd: case 0xffce:
+  case 0xffcf: case 0xffb1: case 0xffb2: case 0xffb3: case 0xffb9: case 0xffba: case 0xffbb: case 0xfff7: case 0xffde:
+    break; /* lossless, arithmetic, hierarchical, residual-only, JPEG LS: other coding processes */
+  default: rs_throw(ps, RS_MALFORMED_STREAM); /* "unexpected marker while parsing the image, decoder out of sync" */
+  }
+  if (ps->have_frame) rs_throw(ps, RS_MALFORMED_STREAM); /* "found a double frame header" */
+  if (type < 0) rs_unsupported(ps);
+  ps->frame_type = type;
+  ps->progressive = ps->frame_type == FT_PROGRESSIVE;
+  len = bs_getword(io);
+  if (len < 8) rs_throw(ps, RS_MALFORMED_STREAM);
+  f->precision = (int)(bs_get(io) & 0xff);
+  if (ps->frame_type == FT_BASELINE ? f->precision != 8 : (f->precision != 8 && f->precision != 12)) rs_throw(ps, RS_MALFORMED_STREAM);
+  data = bs_getword(io);
+  if (data == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+  f->height = (int)data;
+  data = bs_getword(io);
+  if (data == BS_EOF || data == 0) rs_throw(ps, RS_MALFORMED_STREAM);
+  f->width = (int)data;
+  data = bs_get(io);
+  if (data == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+  if (data <= 0 || data > (ps->frame_type == FT_PROGRESSIVE ? 4 : 255)) rs_throw(ps, RS_MALFORMED_STREAM);
+  len -= 8;
+  if (len != 3 * data) rs_throw(ps, RS_MALFORMED_STREAM);
+  if (data > OJ_MAX_COMP) rs_unsupported(ps); /* more than four components: not on the accelerated path */
+  f->ncomp = (int)data;
+  f->hmax = f->vmax = 0;
   for (c = 0; c < f->ncomp; c++) {
-    f->comp_id[c] = p[6 + 3 * c];
-    f->hs[c] = p[7 + 3 * c] >> 4;
-    f->vs[c] = p[7 + 3 * c] & 15;
-    f->tq[c] = p[8 + 3 * c];
-    if (f->hs[c] < 1 || f->hs[c] > 4 || f->vs[c] < 1 || f->vs[c] > 4 || f->tq[c] > 3)
-      return OJ_ERR_MALFORMED;
+    data = bs_get(io);
+    if (data == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+    f->comp_id[c] = (int)data;
+    data = bs_get(io);
+    if (data == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+    f->hs[c] = (int)(data >> 4);
+    f->vs[c] = (int)(data & 15);
+    if (f->hs[c] == 0 || f->vs[c] == 0) rs_throw(ps, RS_MALFORMED_STREAM);
+    data = bs_get(io);
+    if (data < 0 || data > 3) rs_throw(ps, RS_MALFORMED_STREAM);
+    f->tq[c] = (int)data;
     if (f->hs[c] > f->hmax) f->hmax = f->hs[c];
     if (f->vs[c] > f->vmax) f->vmax = f->vs[c];
   }
-  for (c = 0; c < f->ncomp; c++) /* marker/component.cpp: subsampling = max / own; must divide evenly */
-    if (f->hmax % f->hs[c] || f->vmax % f->vs[c]) return OJ_ERR_UNSUPPORTED;
+  for (c = 0; c < f->ncomp; c++)
+    if (f->hmax % f->hs[c] || f->vmax % f->vs[c]) rs_throw(ps, RS_NOT_IMPLEMENTED); /* non-integer subsampling factors */
+  ps->need_dnl = f->height == 0;
   frame_geometry(f);
+  /* Image::CreateFrameBuffer ends with m_pImageBuffer->PrepareForDecoding() (codestream/image.cpp:604-607):
+   * upsamplers exist for factors up to 4 (upsampling/upsamplerbase.cpp:330-476) */
+  for (c = 0; c < f->ncomp; c++)
+    if (f->subx[c] > 4 || f->suby[c] > 4) rs_throw(ps, RS_NOT_IMPLEMENTED);
   ps->have_frame = 1;
-  return OJ_OK;
+  f->scan_state_valid = ps->planes != NULL || ps->walk_all; /* a header-only walk does not see all scans */
 }
 
 /* Height from the DNL marker that must follow the entropy coded data of the first scan
- * (EntropyParser::ParseDNLMarker, codestream/entropyparser.cpp:204-249): FFDC, length 4, number of lines > 0. */
-static int resolve_dnl(oj_parser *ps, const uint8_t *ecs, const uint8_t *end)
+ * (EntropyParser::ParseDNLMarker, codestream/entropyparser.cpp:204-249): FFDC, length 4, number of lines > 0.
+ * Found by looking ahead (well-formed streams only; the reference discovers it while decoding). */
+static void resolve_dnl(oj_parser *ps, const uint8_t *ecs, const uint8_t *end)
 {
   const uint8_t *q = ecs;
   int h;
   while (q + 1 < end && !(q[0] == 0xff && q[1] != 0x00 && q[1] != 0xff && !(q[1] >= 0xd0 && q[1] <= 0xd7))) q++;
-  if (q + 6 > end || q[1] != 0xdc) return OJ_ERR_MALFORMED; /* the reference then fails on the frame height as well */
-  if (rd16(q + 2) != 4) return OJ_ERR_MALFORMED;
+  if (q + 6 > end || q[1] != 0xdc) rs_throw(ps, RS_MALFORMED_STREAM); /* the reference then fails on the frame height as well */
+  if (rd16(q + 2) != 4) rs_throw(ps, RS_MALFORMED_STREAM);
   h = rd16(q + 4);
-  if (h == 0) return OJ_ERR_MALFORMED;
+  if (h == 0) rs_throw(ps, RS_MALFORMED_STREAM);
   ps->info->height = h;
   frame_geometry(ps->info);
   ps->need_dnl = 0;
-  return OJ_OK;
 }
 
 /* ------------------------------------------------------------------------------------------
- * Bit reader: io/bitstream.cpp:56-118 (byte-stuffing flavour) + io/bitstream.hpp:106-210.
- * FF 00 -> FF; any other FF xx is a marker: the reader stays in front of it and hands out
- * zero bits from then on.
+ * Bit reader: io/bitstream.hpp:106-210 + io/bitstream.cpp:56-137, byte-stuffing flavour, stated literally.
+ * FF 00 -> FF.  In front of any other FF xx (a marker) Fill() stops and adds EIGHT zero bits per call; at the end of
+ * the data it adds zero bytes until the window is full.  A read that still finds too few bits throws -- which is how
+ * an unassigned Huffman code (length 0xff in the reference's table) and a truncated restart interval fail.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
-  const uint8_t *p, *end;
-  uint32_t acc; /* MSB-first window */
-  int nbits;
-  int marker; /* sitting at a marker / end of data */
+  oj_parser *ps;
+  oj_bs *io;
+  uint32_t b;
+  int bits;
+  int marker, eof;
 } oj_bits;
 
-static void bits_init(oj_bits *b, const uint8_t *p, const uint8_t *end)
-{
-  b->p = p; b->end = end; b->acc = 0; b->nbits = 0; b->marker = 0;
-}
+static void bits_open(oj_bits *s, oj_parser *ps, oj_bs *io) { s->ps = ps; s->io = io; s->b = 0; s->bits = 0; s->marker = 0; s->eof = 0; }
 
-static void bits_fill(oj_bits *b)
+static void bits_fill(oj_bits *s)
 {
-  while (b->nbits <= 24) {
-    uint32_t c = 0;
-    if (!b->marker) {
-      if (b->p >= b->end) {
-        b->marker = 1;
-      } else if (b->p[0] == 0xff) {
-        if (b->p + 1 < b->end && b->p[1] == 0x00) { c = 0xff; b->p += 2; }
-        else b->marker = 1;
+  do {
+    long dt = bs_get(s->io);
+    if (dt == 0xff) {
+      bs_lastundo(s->io);
+      if (bs_peekword(s->io) == 0xff00) {
+        bs_getword(s->io);
+        s->b |= (uint32_t)0xff << (24 - s->bits);
+        s->bits += 8;
       } else {
-        c = *b->p++;
+        s->marker = 1;
+        s->bits += 8;
+        break;
       }
+    } else if (dt == BS_EOF) {
+      s->eof = 1;
+      s->bits += 8;
+    } else {
+      s->b |= (uint32_t)dt << (24 - s->bits);
+      s->bits += 8;
     }
-    b->acc |= c << (24 - b->nbits);
-    b->nbits += 8;
-  }
+  } while (s->bits <= 24);
 }
 
-static uint32_t bits_get(oj_bits *b, int n)
+static void bits_report_error(oj_bits *s)
+{
+  if (s->eof) rs_throw(s->ps, RS_UNEXPECTED_EOF);
+  if (s->marker) rs_throw(s->ps, RS_UNEXPECTED_EOF);
+  rs_throw(s->ps, RS_MALFORMED_STREAM);
+}
+
+static uint32_t bits_get(oj_bits *s, int n)
 {
   uint32_t v;
-  if (n == 0) return 0;
-  if (b->nbits < n) bits_fill(b);
-  v = b->acc >> (32 - n);
-  b->acc <<= n;
-  b->nbits -= n;
+  if (n > s->bits) {
+    bits_fill(s);
+    if (n > s->bits) bits_report_error(s);
+  }
+  v = s->b >> (32 - n);
+  s->b <<= n;
+  s->bits -= n;
   return v;
 }
 
-/* coding/huffmandecoder.hpp:103-124 in its T.81 F.2.2.3 form. Returns -1 for an unassigned code. */
-static int huff_get(oj_bits *b, const oj_huff *h)
+static uint32_t bits_peekword(oj_bits *s)
 {
-  int32_t code = 0;
+  if (s->bits < 16) bits_fill(s);
+  return s->b >> 16;
+}
+
+static void bits_skip(oj_bits *s, int size)
+{
+  if (size > s->bits) bits_report_error(s);
+  s->b <<= size;
+  s->bits -= size;
+}
+
+/* HuffmanDecoder::Get, coding/huffmandecoder.hpp:103-124 */
+static int huff_get(oj_bits *s, const oj_huff *h)
+{
+  const uint32_t data = bits_peekword(s);
   int l;
   for (l = 1; l <= 16; l++) {
-    code = (code << 1) | (int32_t)bits_get(b, 1);
-    if (h->maxcode[l] >= 0 && code <= h->maxcode[l] && code >= h->mincode[l])
-      return h->values[h->valptr[l] + (code - h->mincode[l])];
-  }
-  return -1;
-}
-
-/* codestream/sequentialscan.cpp:678-773 for ScanStart=0, ScanStop=63, lowbit=0, non-residual,
- * non-progressive. */
-static int decode_block(oj_bits *b, const oj_huff *dc, const oj_huff *ac, int32_t *prevdc,
-                        int32_t *block)
-{
-  int s = huff_get(b, dc), k;
-  int32_t diff = 0;
-  if (s < 0) return OJ_ERR_MALFORMED;
-  if (s > 0) {
-    if (s > 15) return OJ_ERR_MALFORMED; /* :686-688 */
-    diff = (int32_t)bits_get(b, s);
-    if (diff < (1 << (s - 1))) diff += (int32_t)((-1L) * (1L << s)) + 1; /* :690-692 */
-  }
-  *prevdc += diff;
-  block[0] = *prevdc;
-  k = 1;
-  do {
-    int rs = huff_get(b, ac), r, ss;
-    if (rs < 0) return OJ_ERR_MALFORMED;
-    r = rs >> 4; ss = rs & 15;
-    if (ss == 0) {
-      if (r == 15) { k += 16; continue; } /* ZRL, :713-715 */
-      if (r == 0) break;                  /* EOB, :718-722 */
-      return OJ_ERR_MALFORMED;            /* :747-750 (EOB runs exist only in progressive mode) */
+    if (h->counts[l - 1]) {
+      const uint32_t lo = h->first[l], hi = lo + ((uint32_t)h->counts[l - 1] << (16 - l));
+      if (data >= lo && data < hi) {
+        bits_skip(s, l);
+        return h->values[h->valptr[l] + (int)((data - lo) >> (16 - l))];
+      }
     }
-    k += r;
-    diff = (int32_t)bits_get(b, ss);
-    if (diff < (1 << (ss - 1))) diff += (int32_t)((-1L) * (1L << ss)) + 1;
-    if (k >= 64) return OJ_ERR_MALFORMED; /* :763-765 */
-    block[g_scan_order[k]] = diff;
-    k++;
-  } while (k <= 63);
-  return OJ_OK;
+  }
+  bits_skip(s, 0xff); /* unassigned code: the table holds length 0xff there -> ReportError */
+  return 0;
 }
 
-/* Progressive first passes: codestream/sequentialscan.cpp:678-773 with spectral selection [ss, se], point transform
- * al and EOB runs (`skip`, :716-722). */
-static int decode_block_first(oj_bits *b, const oj_huff *dc, const oj_huff *ac, int32_t *prevdc, int32_t *block,
-                              int ss, int se, int al, int *skip)
+/* One entropy coded scan and its parser state (EntropyParser + SequentialScan / RefinementScan members) */
+typedef struct {
+  oj_parser *ps;
+  oj_bs *io;
+  oj_bits bits;
+  int ns, ci[OJ_MAX_COMP];
+  const oj_huff *dc[OJ_MAX_COMP], *ac[OJ_MAX_COMP];
+  int ss, se, lowbit;
+  int refinement;      /* RefinementScan instead of SequentialScan */
+  int progressive_run; /* m_bProgressive: EOB runs are legal (sequentialscan.cpp:84-87) */
+  int32_t pred[OJ_MAX_COMP];
+  int skip[OJ_MAX_COMP];
+  uint32_t ri, togo;
+  long next_rst;
+  int valid;
+} oj_scan;
+
+/* SequentialScan::DecodeBlock, codestream/sequentialscan.cpp:678-773 (not residual, not large range, not differential) */
+static void decode_block(oj_scan *sc, int32_t *block, const oj_huff *dc, const oj_huff *ac, int32_t *prevdc, int *skip)
 {
-  if (ss == 0) {
-    int s = huff_get(b, dc);
+  oj_bits *b = &sc->bits;
+  if (sc->ss == 0) {
     int32_t diff = 0;
-    if (s < 0 || s > 15) return OJ_ERR_MALFORMED;
-    if (s) { diff = (int32_t)bits_get(b, s); if (diff < (1 << (s - 1))) diff += (int32_t)((-1L) * (1L << s)) + 1; }
+    const int value = huff_get(b, dc);
+    if (value > 0) {
+      const int32_t v = 1 << ((value - 1) & 31);
+      if (value > 15) rs_throw(sc->ps, RS_MALFORMED_STREAM);
+      diff = (int32_t)bits_get(b, value);
+      if (diff < v) diff += (int32_t)((-1L) * (1L << value)) + 1;
+    }
     *prevdc += diff;
-    block[0] = (int32_t)((uint32_t)*prevdc << al);
+    block[0] = (int32_t)((uint32_t)*prevdc << sc->lowbit);
   }
-  if (se) {
-    if (*skip > 0) { (*skip)--; return OJ_OK; }
-    {
-      int k = ss ? ss : 1;
+  if (sc->se) {
+    if (*skip > 0) {
+      (*skip)--;
+    } else {
+      int k = sc->ss ? sc->ss : 1;
       do {
-        int rs = huff_get(b, ac), r, s;
+        const int rs = huff_get(b, ac);
+        int r = rs >> 4;
+        const int s = rs & 15;
         int32_t diff;
-        if (rs < 0) return OJ_ERR_MALFORMED;
-        r = rs >> 4; s = rs & 15;
         if (s == 0) {
           if (r == 15) { k += 16; continue; }
-          *skip = 1 << r;
-          if (r) *skip |= (int)bits_get(b, r);
-          (*skip)--;
-          break;
+          if (r == 0 || sc->progressive_run) {
+            *skip = 1 << r;
+            if (r) *skip |= (int)bits_get(b, r);
+            *skip = (*skip - 1) & 0xffff; /* UWORD */
+            break;
+          }
+          rs_throw(sc->ps, RS_MALFORMED_STREAM);
         }
         k += r;
         diff = (int32_t)bits_get(b, s);
         if (diff < (1 << (s - 1))) diff += (int32_t)((-1L) * (1L << s)) + 1;
-        if (k >= 64) return OJ_ERR_MALFORMED;
-        block[g_scan_order[k]] = (int32_t)((uint32_t)diff << al);
+        if (k >= 64) rs_throw(sc->ps, RS_MALFORMED_STREAM);
+        block[g_scan_order[k]] = (int32_t)((uint32_t)diff << sc->lowbit);
         k++;
-      } while (k <= se);
+      } while (k <= sc->se);
     }
   }
-  return OJ_OK;
 }
 
-/* Successive approximation refinement: codestream/refinementscan.cpp:584-700 */
-static int decode_block_refine(oj_bits *b, const oj_huff *ac, int32_t *block, int ss, int se, int al, int *skip)
+/* RefinementScan::DecodeBlock, codestream/refinementscan.cpp:584-700 */
+static void decode_block_refine(oj_scan *sc, int32_t *block, const oj_huff *ac, int *skip)
 {
-  if (ss == 0) block[0] |= (int32_t)(bits_get(b, 1) << al);
-  if (se) {
-    int k = ss, run = 0;
+  oj_bits *b = &sc->bits;
+  const int al = sc->lowbit;
+  if (sc->ss == 0) block[0] |= (int32_t)(bits_get(b, 1) << al);
+  if (sc->se) {
+    int k = sc->ss, run = 0;
     int32_t s = 0;
     int enter_at_start = 0;
-    if (*skip > 0) { run = se - ss + 1; (*skip)--; }
+    if (*skip > 0) { run = (sc->se - sc->ss + 1) & 0xff; (*skip)--; }
     else { k--; enter_at_start = 1; }
     do {
       int32_t data;
@@ -350,218 +824,373 @@ static int decode_block_refine(oj_bits *b, const oj_huff *ac, int32_t *block, in
           continue;
         }
         block[g_scan_order[k]] = (int32_t)((uint32_t)s << al);
-        if (k == se) break;
+        if (k == sc->se) break;
       }
       enter_at_start = 0;
       {
-        int rs = huff_get(b, ac), r;
-        if (rs < 0) return OJ_ERR_MALFORMED;
-        r = rs >> 4; s = rs & 15;
+        const int rs = huff_get(b, ac), r = rs >> 4;
+        s = rs & 15;
         if (s == 0) {
           if (r == 15) run = r;
           else {
             *skip = 1 << r;
             if (r) *skip |= (int)bits_get(b, r);
-            (*skip)--;
-            run = se - k + 1;
+            *skip = (*skip - 1) & 0xffff;
+            run = (sc->se - k + 1) & 0xff;
           }
+        } else if (s != 1) {
+          RS_WARN(sc->ps); /* :667 "unexpected Huffman symbol in refinement coding": leave the block unrefined, go on */
+          run = 0;
+          s = 0;
         } else {
-          if (s != 1) return OJ_ERR_MALFORMED; /* the reference warns and leaves the block unrefined */
           if (bits_get(b, 1) == 0) s = -s;
           run = r;
         }
       }
-    } while (++k <= se);
+    } while (++k <= sc->se);
   }
-  return OJ_OK;
 }
 
-/* One scan: codestream/sequentialscan.cpp:381-428 (ParseMCU) driven row by row, restart handling as
- * in codestream/entropyparser.hpp:147-160 / entropyparser.cpp:117-135 (happy path only: a missing or
- * wrong RSTn is reported as OJ_ERR_MALFORMED instead of being resynchronised). */
-static int decode_scan_ex(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *ecs,
-                          const uint8_t *end, int32_t *const planes[OJ_MAX_COMP],
-                          const uint8_t **next, int hidden_scan);
-
-static int decode_scan(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *ecs,
-                       const uint8_t *end, int32_t *const planes[OJ_MAX_COMP],
-                       const uint8_t **next)
+/* SequentialScan::Restart / RefinementScan::Restart, sequentialscan.cpp:266-274, refinementscan.cpp:225-233 */
+static void scan_restart(oj_scan *sc)
 {
-  return decode_scan_ex(ps, sos, n, ecs, end, planes, next, 0);
+  int i;
+  for (i = 0; i < sc->ns; i++) { sc->pred[i] = 0; sc->skip[i] = 0; }
+  bits_open(&sc->bits, sc->ps, sc->io);
 }
 
-/* hidden_scan: the scan comes from a FINE / RFIN box (marker/scan.cpp:899-980): always a successive approximation
- * refinement of one bit, its Al counts from the true LSB.  Visible scans of a frame with hidden bits address the bits
- * above them: Al + hidden (marker/scan.cpp:353-437). */
-static int decode_scan_ex(oj_parser *ps, const uint8_t *sos, int n, const uint8_t *ecs,
-                          const uint8_t *end, int32_t *const planes[OJ_MAX_COMP],
-                          const uint8_t **next, int hidden_scan)
+/* EntropyParser::ParseRestartMarker, codestream/entropyparser.cpp:117-201 */
+static void parse_restart_marker(oj_scan *sc)
 {
-  const int progressive = ps->progressive || hidden_scan || ps->hidden > 0;
-  const oj_info *f = ps->info;
-  int ns = sos[0], ci[OJ_MAX_COMP], td[OJ_MAX_COMP], ta[OJ_MAX_COMP], i, c;
-  int32_t pred[OJ_MAX_COMP] = {0, 0, 0, 0};
-  int mx, my, mcus_x, mcus_y, togo, rstn = 0;
-  int ss, se, ah, al, skip[OJ_MAX_COMP] = {0, 0, 0, 0};
-  oj_bits b;
-  if (ns < 1 || ns > f->ncomp || n < 1 + 2 * ns + 3) return OJ_ERR_MALFORMED;
-  for (i = 0; i < ns; i++) {
-    int id = sos[1 + 2 * i];
-    for (c = 0; c < f->ncomp; c++) if (f->comp_id[c] == id) break;
-    if (c == f->ncomp) return OJ_ERR_MALFORMED;
-    ci[i] = c; td[i] = sos[2 + 2 * i] >> 4; ta[i] = sos[2 + 2 * i] & 15;
-    if (td[i] > 3 || ta[i] > 3) return OJ_ERR_MALFORMED;
+  oj_bs *io = sc->io;
+  long dt = bs_peekword(io);
+  while (dt == 0xffff) { bs_get(io); dt = bs_peekword(io); }
+  if (dt == sc->next_rst) {
+    bs_getword(io);
+    scan_restart(sc);
+    sc->next_rst = (sc->next_rst + 1) & 0xfff7;
+    sc->togo = sc->ri;
+    sc->valid = 1;
+    return;
   }
-  ss = sos[1 + 2 * ns]; se = sos[2 + 2 * ns]; ah = sos[3 + 2 * ns] >> 4; al = sos[3 + 2 * ns] & 15;
-  if (!ps->progressive && !hidden_scan) {
-    if (ss != 0 || se != 63 || ah != 0 || al != 0) return OJ_ERR_MALFORMED;
-  } else if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) {
-    return OJ_ERR_MALFORMED; /* T.81 G.1.1.1.1 */
+  RS_WARN(sc->ps); /* "entropy coder is out of sync, trying to advance to the next marker" */
+  for (;;) {
+    dt = bs_get(io);
+    if (dt == BS_EOF) rs_throw(sc->ps, RS_UNEXPECTED_EOF);
+    if (dt != 0xff) continue;
+    bs_lastundo(io);
+    dt = bs_peekword(io);
+    if (dt >= 0xffd0 && dt < 0xffd8) {
+      if (dt == sc->next_rst) { /* the decoder was behind and is back in step */
+        bs_getword(io);
+        scan_restart(sc);
+        sc->next_rst = (sc->next_rst + 1) & 0xfff7;
+        sc->togo = sc->ri;
+        sc->valid = 1;
+        return;
+      } else if (((dt - sc->next_rst) & 7) >= 4) {
+        bs_getword(io); /* likely a marker the decoder already passed: drop it, keep looking */
+      } else {
+        /* the marker is ahead: this segment is lost, leave the marker where it is and look at it again
+         * when the next interval starts */
+        sc->valid = 0;
+        sc->next_rst = (sc->next_rst + 1) & 0xfff7;
+        sc->togo = sc->ri;
+        return;
+      }
+    } else if (dt >= 0xffc0 && dt < 0xfff0) { /* some other marker: the scan is over, the rest is lost */
+      sc->valid = 0;
+      sc->next_rst = (sc->next_rst + 1) & 0xfff7;
+      sc->togo = sc->ri;
+      return;
+    } else {
+      bs_get(io); /* garbage, FF00, or a lone FF in front of the end: eat one byte */
+    }
   }
-  if (hidden_scan) { if (ah != al + 1) return OJ_ERR_MALFORMED; } /* "hidden refinement must refine by one bit per scan" */
-  else al += ps->hidden;
-  for (i = 0; i < ns; i++) {
-    if ((ss == 0 && ah == 0 && !ps->dc[td[i]].defined) || (se > 0 && !ps->ac[ta[i]].defined)) return OJ_ERR_MALFORMED;
+}
+
+/* Scan::ParseMarker (marker/scan.cpp:163-315) for `type`, then Scan::CreateParser / StartParseScan (:355-470, 985-994),
+ * SequentialScan::StartParseScan (sequentialscan.cpp:112-141), then the MCU loop of JPEG::ReadInternal
+ * (interface/jpeg.cpp:318-348) with SequentialScan::ParseMCU / RefinementScan::ParseMCU.
+ * hidden_scan: the scan comes from a FINE / RFIN box (Scan::StartParseHiddenRefinementScan, marker/scan.cpp:899-980):
+ * parsed as a progressive scan that must refine by one bit, its Al counts from the true LSB.  Visible scans of a frame
+ * with hidden bits address the bits above them: Al + hidden. */
+static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
+{
+  oj_info *f = ps->info;
+  oj_scan sc;
+  long len, data;
+  int id[OJ_MAX_COMP], td[OJ_MAX_COMP], ta[OJ_MAX_COMP], i, j, c, ah, al, type;
+  int mx, my, mcus_x, mcus_y;
+  memset(&sc, 0, sizeof(sc));
+  sc.ps = ps; sc.io = io;
+  type = hidden_scan ? FT_PROGRESSIVE : ps->frame_type;
+  len = bs_getword(io);
+  if (len < 8) rs_throw(ps, RS_MALFORMED_STREAM);
+  data = bs_get(io);
+  if (data < 1 || data > 4) rs_throw(ps, RS_MALFORMED_STREAM);
+  sc.ns = (int)data;
+  if (len != sc.ns * 2 + 6) rs_throw(ps, RS_MALFORMED_STREAM);
+  for (i = 0; i < sc.ns; i++) {
+    data = bs_get(io);
+    if (data == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+    id[i] = (int)data;
+    for (j = 0; j < i; j++) if (id[j] == id[i]) rs_throw(ps, RS_MALFORMED_STREAM);
+    data = bs_get(io);
+    if (data == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+    td[i] = (int)(data >> 4); ta[i] = (int)(data & 15);
+    if (td[i] > 3 || ta[i] > 3) rs_throw(ps, RS_MALFORMED_STREAM);
   }
-  if (ns > 1) { mcus_x = f->mcus_x; mcus_y = f->mcus_y; }
+  data = bs_get(io);
+  if (data == BS_EOF || data > 63) rs_throw(ps, RS_MALFORMED_STREAM);
+  sc.ss = (int)data;
+  data = bs_get(io);
+  if (data == BS_EOF || data > 63) rs_throw(ps, RS_MALFORMED_STREAM);
+  sc.se = (int)data;
+  data = bs_get(io);
+  if (data == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+  ah = (int)(data >> 4); al = (int)(data & 15);
+  if (ah > 13) rs_throw(ps, RS_MALFORMED_STREAM);
+  if (type == FT_PROGRESSIVE) {
+    if (ah && ah != al + 1) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (sc.se < sc.ss) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (sc.ss == 0 && sc.se != 0) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (sc.ss && sc.ns != 1) rs_throw(ps, RS_MALFORMED_STREAM);
+  } else {
+    if (sc.se != 63 || sc.ss != 0) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (ah != 0) rs_throw(ps, RS_MALFORMED_STREAM);
+  }
+  if (hidden_scan) {
+    if (ah != al + 1) rs_throw(ps, RS_MALFORMED_STREAM); /* "hidden refinement must refine by one bit per scan" */
+    sc.refinement = 1;
+    sc.lowbit = al;
+  } else {
+    sc.refinement = type == FT_PROGRESSIVE && ah != 0;
+    sc.lowbit = al + ps->hidden;
+  }
+  sc.progressive_run = sc.ss > 0 || sc.se < 63 || sc.lowbit > ps->hidden; /* sequentialscan.cpp:84-87 */
+  /* Scan::CreateParser: all components must exist (Frame::FindComponent throws OBJECT_DOESNT_EXIST) */
+  for (i = 0; i < sc.ns; i++) {
+    for (c = 0; c < f->ncomp; c++) if (f->comp_id[c] == id[i]) break;
+    if (c == f->ncomp) rs_throw(ps, RS_OBJECT_DOESNT_EXIST);
+    sc.ci[i] = c;
+  }
+  /* EntropyParser::EntropyParser, entropyparser.cpp:60-82 */
+  sc.ri = ps->restart_interval;
+  sc.next_rst = 0xffd0;
+  sc.togo = sc.ri;
+  sc.valid = 1;
+  f->restart_interval = (int)ps->restart_interval;
+  /* Huffman decoders: Tables::FindDC/ACHuffmanTable (tables.cpp:1423-1452) */
+  for (i = 0; i < sc.ns; i++) {
+    if (sc.ss == 0 && !sc.refinement) {
+      oj_huff *h = &ps->huff[td[i]];
+      if (!ps->have_huff) rs_throw(ps, RS_OBJECT_DOESNT_EXIST);
+      if (!h->defined) huff_default(ps, h, 0, td[i] != 0);
+      if (!h->built) huff_build(ps, h);
+      sc.dc[i] = h;
+    }
+    if (sc.se) {
+      oj_huff *h = &ps->huff[4 + ta[i]];
+      if (!ps->have_huff) rs_throw(ps, RS_OBJECT_DOESNT_EXIST);
+      if (!h->defined) huff_default(ps, h, 1, ta[i] != 0);
+      if (!h->built) huff_build(ps, h);
+      sc.ac[i] = h;
+    }
+  }
+  /* BlockBuffer::ResetToStartOfScan (control/blockbuffer.cpp:177-208): the transform of a component is built, with
+   * the quantiser table in force NOW, when the component first appears in a scan (codestream/tables.cpp:1741-1750) */
+  for (i = 0; i < sc.ns; i++) {
+    c = sc.ci[i];
+    if (!f->comp_seen[c]) {
+      if (!ps->have_quant) rs_throw(ps, RS_OBJECT_DOESNT_EXIST);
+      if (!f->quant_defined[f->tq[c]]) rs_throw(ps, RS_OBJECT_DOESNT_EXIST);
+      memcpy(f->cquant[c], f->quant[f->tq[c]], sizeof(f->cquant[c]));
+      f->comp_seen[c] = 1;
+    }
+  }
+  if (ps->need_dnl) resolve_dnl(ps, io->d + io->pos, io->d + io->n);
+  if (!ps->planes) { /* headers only: skip the entropy coded data */
+    const uint8_t *q = io->d + io->pos, *end = io->d + io->n;
+    while (q + 1 < end && !(q[0] == 0xff && q[1] != 0x00 && q[1] != 0xff && !(q[1] >= 0xd0 && q[1] <= 0xd7))) q++;
+    if (q + 1 >= end) q = end;
+    io->pos = (size_t)(q - io->d);
+    return;
+  }
+  if (sc.ns > 1) { mcus_x = f->mcus_x; mcus_y = f->mcus_y; }
   else {
-    /* single-component scan: 1x1 MCUs over ceil(cw/8) x ceil(ch/8) blocks
-     * (sequentialscan.cpp:396-397; marker/component.cpp) */
-    mcus_x = (f->cw[ci[0]] + 7) >> 3; mcus_y = (f->ch[ci[0]] + 7) >> 3;
+    /* single-component scan: 1x1 MCUs over ceil(cw/8) x ceil(ch/8) blocks (sequentialscan.cpp:396-397) */
+    mcus_x = (f->cw[sc.ci[0]] + 7) >> 3; mcus_y = (f->ch[sc.ci[0]] + 7) >> 3;
   }
-  bits_init(&b, ecs, end);
-  togo = ps->restart_interval;
+  bits_open(&sc.bits, ps, io);
   for (my = 0; my < mcus_y; my++) {
     for (mx = 0; mx < mcus_x; mx++) {
-      if (ps->restart_interval) {
-        if (togo == 0) {
-          /* entropyparser.cpp:117-135: skip FF fillers, require RSTn, reset predictors and the bit
-           * buffer (sequentialscan.cpp:266-274) */
-          const uint8_t *p = b.p;
-          while (p + 1 < end && p[0] == 0xff && p[1] == 0xff) p++;
-          if (p + 1 >= end || p[0] != 0xff || p[1] != 0xd0 + rstn) return OJ_ERR_MALFORMED;
-          rstn = (rstn + 1) & 7;
-          bits_init(&b, p + 2, end);
-          for (i = 0; i < OJ_MAX_COMP; i++) { pred[i] = 0; skip[i] = 0; }
-          togo = ps->restart_interval;
-        }
-        togo--;
+      /* EntropyParser::BeginReadMCU, entropyparser.hpp:147-160 */
+      if (sc.ri) {
+        if (sc.togo == 0) parse_restart_marker(&sc);
+        sc.togo--;
       }
-      for (i = 0; i < ns; i++) {
-        int bx, by, w = (ns > 1) ? f->hs[ci[i]] : 1, h = (ns > 1) ? f->vs[ci[i]] : 1;
-        c = ci[i];
+      for (i = 0; i < sc.ns; i++) {
+        int bx, by, w = (sc.ns > 1) ? f->hs[sc.ci[i]] : 1, h = (sc.ns > 1) ? f->vs[sc.ci[i]] : 1;
+        c = sc.ci[i];
         for (by = 0; by < h; by++)
           for (bx = 0; bx < w; bx++) {
             int32_t dummy[64];
-            int X = mx * w + bx, Y = my * h + by, rc;
-            int32_t *blk = (X < f->bw[c] && Y < f->bh[c]) ? planes[c] + ((size_t)Y * f->bw[c] + X) * 64
-                                                          : dummy;
-            if (!progressive) rc = decode_block(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk);
-            else if (ah == 0) rc = decode_block_first(&b, &ps->dc[td[i]], &ps->ac[ta[i]], &pred[i], blk, ss, se, al, &skip[i]);
-            else rc = decode_block_refine(&b, &ps->ac[ta[i]], blk, ss, se, al, &skip[i]);
-            if (rc) return rc;
+            int X = mx * w + bx, Y = my * h + by, k;
+            int32_t *blk = (X < f->bw[c] && Y < f->bh[c]) ? ps->planes[c] + ((size_t)Y * f->bw[c] + X) * 64 : dummy;
+            if (blk == dummy) memset(dummy, 0, sizeof(dummy));
+            if (sc.valid) {
+              if (sc.refinement) decode_block_refine(&sc, blk, sc.ac[i], &sc.skip[i]);
+              else decode_block(&sc, blk, sc.dc[i], sc.ac[i], &sc.pred[i], &sc.skip[i]);
+            } else if (!sc.refinement) {
+              /* sequentialscan.cpp:416-420: block[i] = 0 for i = ScanStart..ScanStop -- natural positions, not zigzag */
+              for (k = sc.ss; k <= sc.se; k++) blk[k] = 0;
+            }
           }
       }
     }
   }
-  /* advance to the next marker */
-  {
-    const uint8_t *p = b.p;
-    while (p + 1 < end && !(p[0] == 0xff && p[1] != 0x00 && p[1] != 0xff)) p++;
-    *next = p;
+}
+
+/* Frame::ScanForScanHeader, marker/frame.cpp:863-899 */
+static int rs_scan_for_scan_header(oj_parser *ps, oj_bs *io)
+{
+  long data = bs_getword(io);
+  if (data != 0xffda) {
+    RS_WARN(ps);
+    if (data == BS_EOF) return 0;
+    do {
+      bs_lastundo(io);
+      do { data = bs_get(io); } while (data != 0xff && data != BS_EOF);
+      if (data == BS_EOF) break;
+      bs_lastundo(io);
+      data = bs_getword(io);
+      if (data == BS_EOF) break;
+    } while (data != 0xffda);
   }
-  return OJ_OK;
+  return data == 0xffda;
+}
+
+/* Frame::ParseTrailer, marker/frame.cpp:1016-1123 (no hidden refinement boxes here: those are driven by the XT code).
+ * 1: another scan follows, 0: the frame is over. */
+static int rs_frame_trailer(oj_parser *ps, oj_bs *io)
+{
+  for (;;) {
+    long marker = bs_peekword(io);
+    switch (marker) {
+    case 0xffb1: case 0xffb2: case 0xffb3: case 0xffb9: case 0xffba: case 0xffbb: case 0xffc0: case 0xffc1: case 0xffc2:
+    case 0xffc3: case 0xffc9: case 0xffca: case 0xffcb: case 0xfff7:
+      RS_WARN(ps); return 0;
+    case 0xffde: RS_WARN(ps); return 0;
+    case 0xffc5: case 0xffc6: case 0xffc7: case 0xffcd: case 0xffce: case 0xffcf:
+      RS_WARN(ps); return 0;
+    case 0xffda: return 1;
+    case 0xffd9: return 0;
+    case 0xffff: bs_get(io); break;
+    case 0xffd0: case 0xffd1: case 0xffd2: case 0xffd3: case 0xffd4: case 0xffd5: case 0xffd6: case 0xffd7:
+      bs_getword(io); RS_WARN(ps); break;
+    case BS_EOF: RS_WARN(ps); return 0;
+    default:
+      if (marker < 0xff00) {
+        RS_WARN(ps);
+        bs_get(io);
+        do { marker = bs_get(io); } while (marker != 0xff && marker != BS_EOF);
+        if (marker == BS_EOF) { RS_WARN(ps); return 0; }
+        bs_lastundo(io);
+      } else {
+        while (rs_tables_incremental(ps, io)) {} /* Tables::ParseTables, tables.cpp:968-980 */
+      }
+    }
+  }
+}
+
+/* Image::ParseTrailer, codestream/image.cpp:1408-1497. 1: something that is not the end follows. */
+static int rs_image_trailer(oj_parser *ps, oj_bs *io)
+{
+  for (;;) {
+    long marker = bs_peekword(io);
+    if (marker == 0xffd9) { bs_getword(io); return 0; }
+    else if (marker == 0xffff) bs_get(io);
+    else if (marker == BS_EOF) { RS_WARN(ps); return 0; }
+    else if (marker < 0xff00) {
+      RS_WARN(ps);
+      bs_get(io);
+      do { marker = bs_get(io); } while (marker != 0xff && marker != BS_EOF);
+      if (marker == BS_EOF) { RS_WARN(ps); return 0; }
+      bs_lastundo(io);
+    } else return 1;
+  }
+}
+
+/* JPEG::ReadInternal, interface/jpeg.cpp:244-354, for one codestream. */
+static void rs_run(oj_parser *ps, oj_bs *io)
+{
+  oj_info *f = ps->info;
+  if (!g_scan_order_ready) build_scan_order();
+  f->adobe_transform = -1;
+  /* Decoder::ParseHeaderIncremental, codestream/decoder.cpp:77-108 */
+  if (bs_getword(io) != 0xffd8) rs_throw(ps, RS_MALFORMED_STREAM);
+  while (rs_tables_incremental(ps, io)) {}
+  for (;;) { /* frames */
+    rs_parse_frame_header(ps, io);
+    for (;;) { /* scans: Frame::StartParseScan, marker/frame.cpp:796-861 */
+      while (rs_tables_incremental(ps, io)) {}
+      if (rs_scan_for_scan_header(ps, io)) {
+        rs_scan(ps, io, 0);
+        if (!ps->planes && !ps->walk_all) return; /* header-only walk stops behind the first scan header */
+        if (rs_frame_trailer(ps, io)) continue;
+        if (!rs_image_trailer(ps, io)) return;
+        break; /* next frame: a second frame header throws */
+      } else {
+        /* no scan: end of frame (interface/jpeg.cpp:305-317) */
+        if (rs_frame_trailer(ps, io)) continue;
+        if (!rs_image_trailer(ps, io)) return;
+        rs_throw(ps, RS_INVALID_PARAMETER); /* the reference dereferences a NULL frame here */
+      }
+    }
+  }
+}
+
+/* Maps the outcome of the state machine to the oracle's return codes. */
+static int rs_result(const oj_parser *ps, int thrown)
+{
+  if (!thrown) return OJ_OK;
+  if (ps->unsupported) return OJ_ERR_UNSUPPORTED;
+  if (ps->err == RS_UNEXPECTED_EOF) return OJ_ERR_EOF;
+  if (ps->err == RS_OUT_OF_MEMORY) return OJ_ERR_NOMEM;
+  return OJ_ERR_MALFORMED;
 }
 
 static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
 {
-  const uint8_t *p = ps->data, *end = ps->data + ps->len;
-  oj_info *f = ps->info;
-  int rc;
-  if (!g_scan_order_ready) build_scan_order();
-  if (ps->len < 4 || p[0] != 0xff || p[1] != 0xd8) return OJ_ERR_MALFORMED;
-  p += 2;
-  f->adobe_transform = -1;
-  for (;;) {
-    int m, n;
-    if (p + 2 > end) return OJ_ERR_EOF;
-    if (p[0] != 0xff) return OJ_ERR_MALFORMED;
-    while (p + 1 < end && p[1] == 0xff) p++; /* fill bytes */
-    m = p[1];
-    p += 2;
-    if (m == 0xd9) break; /* EOI */
-    if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
-    if (p + 2 > end) return OJ_ERR_EOF;
-    n = rd16(p);
-    if (n < 2 || p + n > end) return OJ_ERR_EOF;
-    switch (m) {
-    case 0xdb: rc = parse_dqt(ps, p + 2, n - 2); if (rc) return rc; break;
-    case 0xc4: rc = parse_dht(ps, p + 2, n - 2); if (rc) return rc; break;
-    case 0xdd: if (n < 4) return OJ_ERR_MALFORMED; ps->restart_interval = rd16(p + 2); break;
-    case 0xc0: case 0xc1: case 0xc2: /* baseline, extended sequential, progressive (Huffman) */
-      if (ps->have_frame) return OJ_ERR_MALFORMED;
-      ps->progressive = m == 0xc2;
-      rc = parse_sof(ps, p + 2, n - 2); if (rc) return rc; break;
-    case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb:
-    case 0xcd: case 0xce: case 0xcf:
-      return OJ_ERR_UNSUPPORTED;
-    case 0xeb: /* APP11 "JP": one segment of a box: en(2) z(4) lbox(4) tbox(4) [xlbox(8)] payload; boxes/box.cpp:88-150 */
-      if (ps->boxes && n >= 2 + 2 + 2 + 4 + 4 + 4 && p[2] == 0x4a && p[3] == 0x50) {
-        const uint8_t *q = p + 4;
-        uint16_t en = (uint16_t)rd16(q);
-        uint32_t lbox = ((uint32_t)rd16(q + 6) << 16) | (uint32_t)rd16(q + 8);
-        uint32_t tbox = ((uint32_t)rd16(q + 10) << 16) | (uint32_t)rd16(q + 12);
-        const uint8_t *pay = q + 14;
-        int blen = n - 2 - 2 - 2 - 4 - 4 - 4, b;
-        if (lbox == 1) { pay += 8; blen -= 8; }
-        if (blen < 0) return OJ_ERR_MALFORMED;
-        for (b = 0; b < ps->nboxes; b++)
-          if (ps->boxes[b].type == tbox && ps->boxes[b].en == en) break;
-        if (b == ps->nboxes) {
-          if (ps->nboxes == OJ_MAX_BOXES) return OJ_ERR_UNSUPPORTED;
-          memset(&ps->boxes[b], 0, sizeof(oj_box));
-          ps->boxes[b].type = tbox; ps->boxes[b].en = en;
-          ps->nboxes++;
-        }
-        if (ps->boxes[b].len + (size_t)blen > ps->boxes[b].cap) {
-          size_t cap = (ps->boxes[b].len + (size_t)blen) * 2 + 64;
-          uint8_t *nd = (uint8_t *)realloc(ps->boxes[b].data, cap);
-          if (!nd) return OJ_ERR_NOMEM;
-          ps->boxes[b].data = nd; ps->boxes[b].cap = cap;
-        }
-        memcpy(ps->boxes[b].data + ps->boxes[b].len, pay, (size_t)blen); /* segments arrive in sequence order */
-        ps->boxes[b].len += (size_t)blen;
-      }
-      break;
-    case 0xee: /* APP14 Adobe: marker/adobemarker.cpp; "Adobe" + version(2) flags0(2) flags1(2) transform(1) */
-      if (n >= 14 && memcmp(p + 2, "Adobe", 5) == 0) f->adobe_transform = p[13];
-      break;
-    case 0xda: {
-      const uint8_t *next = NULL;
-      if (!ps->have_frame) return OJ_ERR_MALFORMED;
-      f->restart_interval = ps->restart_interval;
-      if (ps->need_dnl) { rc = resolve_dnl(ps, p + n, end); if (rc) return rc; }
-      if (!planes && !ps->boxes) goto done; /* header-only walk stops at the first scan (unless boxes are wanted) */
-      if (!planes) { /* skip the entropy coded data */
-        const uint8_t *q = p + n;
-        while (q + 1 < end && !(q[0] == 0xff && q[1] != 0x00 && q[1] != 0xff && !(q[1] >= 0xd0 && q[1] <= 0xd7))) q++;
-        p = q;
-        continue;
-      }
-      rc = decode_scan(ps, p + 2, n - 2, p + n, end, planes, &next);
-      if (rc) return rc;
-      p = next;
-      continue;
-    }
-    default: break; /* APPn, COM, ...: skipped */
-    }
-    p += n;
+  oj_bs io;
+  oj_box *volatile own = NULL;
+  volatile int thrown = 0;
+  ps->planes = planes;
+  ps->err = 0; ps->unsupported = 0; ps->warnings = 0;
+  if (!ps->boxes) { /* the boxes are followed even when nobody asks for them: their framing is checked */
+    own = (oj_box *)calloc(OJ_MAX_BOXES, sizeof(oj_box));
+    if (!own) return OJ_ERR_NOMEM;
+    ps->boxes = own; ps->nboxes = 0;
   }
-done:
-  if (!ps->have_frame) return OJ_ERR_MALFORMED;
-  /* codestream/tables.cpp:2021-2030: three components and no Adobe "None" -> YCbCr, else identity */
-  f->ycbcr = (f->ncomp == 3 && f->adobe_transform != 0) ? 1 : 0;
-  return OJ_OK;
+  bs_open(&io, ps->data, ps->len);
+  if (setjmp(ps->jb) == 0) rs_run(ps, &io);
+  else thrown = 1;
+  if (!thrown) {
+    oj_info *f = ps->info;
+    if (!ps->have_frame) { thrown = 1; ps->err = RS_MALFORMED_STREAM; }
+    /* codestream/tables.cpp:2021-2030: three components and no Adobe "None" -> YCbCr, else identity */
+    f->ycbcr = (f->ncomp == 3 && f->adobe_transform != 0) ? 1 : 0;
+  }
+  if (own) {
+    int b;
+    for (b = 0; b < ps->nboxes; b++) free(own[b].data);
+    free(own);
+    ps->boxes = NULL; ps->nboxes = 0;
+  }
+  ps->info->ref_error = thrown ? ps->err : 0;
+  ps->info->warnings = ps->warnings;
+  return rs_result(ps, thrown);
 }
 
 int oj_read_info(const uint8_t *data, size_t len, oj_info *info)
@@ -578,13 +1207,20 @@ int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
 {
   oj_parser ps;
   oj_info tmp;
-  int c;
+  oj_info *out = (oj_info *)info; /* the scan state (per-component tables, components seen, error code) is reported back */
+  int c, rc;
   memset(&ps, 0, sizeof(ps));
   memset(&tmp, 0, sizeof(tmp));
   ps.data = data; ps.len = len; ps.info = &tmp;
   for (c = 0; c < info->ncomp; c++)
     memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
-  return walk(&ps, planes);
+  rc = walk(&ps, planes);
+  memcpy(out->cquant, tmp.cquant, sizeof(tmp.cquant));
+  memcpy(out->comp_seen, tmp.comp_seen, sizeof(tmp.comp_seen));
+  out->scan_state_valid = tmp.scan_state_valid;
+  out->ref_error = tmp.ref_error;
+  out->warnings = tmp.warnings;
+  return rc;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -892,16 +1528,21 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
   const int32_t dcshift = (int32_t)(1 << (f->precision - 1)) << 4;
   const int64_t maxval = ((int64_t)1 << f->precision) - 1;
   for (c = 0; c < f->ncomp; c++) {
-    if (!f->quant_defined[f->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
+    /* the component's transform carries the table that was in force at its first scan (control/blockbuffer.cpp:177-208) */
+    const uint16_t *q = f->scan_state_valid ? f->cquant[c] : f->quant[f->tq[c]];
+    if (!f->scan_state_valid && !f->quant_defined[f->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
     samp[c] = (int32_t *)malloc((size_t)f->bw[c] * f->bh[c] * 64 * sizeof(int32_t));
     if (!samp[c]) { rc = OJ_ERR_NOMEM; goto out; }
-    oj_idct_plane(samp[c], planes[c], f->bw[c], f->bh[c], f->quant[f->tq[c]], f->precision);
+    if (f->scan_state_valid && !f->comp_seen[c]) /* no scan, no transform: samples are 0 (blockbitmaprequester.cpp:1047-1054, 1100-1104) */
+      memset(samp[c], 0, (size_t)f->bw[c] * f->bh[c] * 64 * sizeof(int32_t));
+    else
+      oj_idct_plane(samp[c], planes[c], f->bw[c], f->bh[c], q, f->precision);
     if (xt) { /* residual: same transform, level shift 2^(Pr-1) (control/residualblockhelper.cpp:191-202) */
       const oj_info *r = xt->rinfo;
       if (!r->quant_defined[r->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
       rsamp[c] = (int32_t *)malloc((size_t)r->bw[c] * r->bh[c] * 64 * sizeof(int32_t));
       if (!rsamp[c]) { rc = OJ_ERR_NOMEM; goto out; }
-      oj_idct_plane(rsamp[c], xt->rplanes[c], r->bw[c], r->bh[c], r->quant[r->tq[c]], r->precision);
+      oj_idct_plane(rsamp[c], xt->rplanes[c], r->bw[c], r->bh[c], r->scan_state_valid ? r->cquant[c] : r->quant[r->tq[c]], r->precision);
     }
   }
   for (Y0 = 0; Y0 < f->height; Y0 += 8)
@@ -1000,32 +1641,19 @@ static void free_boxes(oj_box *boxes, int n) { int i; for (i = 0; i < n; i++) fr
  * (marker/frame.cpp:805-818, 1063-1071). */
 static int decode_hidden_scans(oj_parser *ps, const oj_box *boxes, int nboxes, uint32_t type, int32_t *const planes[OJ_MAX_COMP])
 {
-  int en;
+  volatile int en;
+  ps->planes = planes;
   for (en = 0;; en++) {
     const oj_box *bx = NULL;
-    const uint8_t *p, *end, *next;
-    int b, rc, done = 0;
+    oj_bs bio;
+    int b;
     for (b = 0; b < nboxes; b++) if (boxes[b].type == type && boxes[b].en == en) bx = &boxes[b];
     if (!bx) return OJ_OK;
-    p = bx->data; end = bx->data + bx->len;
-    while (!done) {
-      int m, n;
-      if (p + 4 > end || p[0] != 0xff) return OJ_ERR_MALFORMED;
-      m = p[1]; n = rd16(p + 2);
-      if (n < 2 || p + 2 + n > end) return OJ_ERR_MALFORMED;
-      switch (m) {
-      case 0xc4: rc = parse_dht(ps, p + 4, n - 2); if (rc) return rc; break;
-      case 0xdb: rc = parse_dqt(ps, p + 4, n - 2); if (rc) return rc; break;
-      case 0xdd: if (n < 4) return OJ_ERR_MALFORMED; ps->restart_interval = rd16(p + 4); break;
-      case 0xda:
-        rc = decode_scan_ex(ps, p + 4, n - 2, p + 2 + n, end, planes, &next, 1);
-        if (rc) return rc;
-        done = 1;
-        break;
-      default: break;
-      }
-      p += 2 + n;
-    }
+    /* Frame::StartParseScan, marker/frame.cpp:805-822: tables, then the scan header, from the box's own stream */
+    bs_open(&bio, bx->data, bx->len);
+    if (setjmp(ps->jb)) return rs_result(ps, 1);
+    while (rs_tables_incremental(ps, &bio)) {}
+    if (rs_scan_for_scan_header(ps, &bio)) rs_scan(ps, &bio, 1);
   }
 }
 
@@ -1046,7 +1674,7 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   size_t j;
   *pixels = NULL;
   memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(tables, 0, sizeof(tables));
-  ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes;
+  ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes; ps.walk_all = 1;
   rc = walk(&ps, NULL);
   if (rc) { free_boxes(boxes, ps.nboxes); return rc; }
   for (b = 0; b < ps.nboxes; b++) {
@@ -1130,7 +1758,7 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
     oj_info ltmp, rtmp;
     memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
     ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
-    rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r;
+    rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r; rs.nested = 1;
     for (c = 0; c < 3; c++) {
       memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
       memset(rplanes[c], 0, (size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
@@ -1140,6 +1768,9 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
     if (!rc) rc = walk(&rs, rplanes);
     if (!rc) rc = decode_hidden_scans(&rs, boxes, ps.nboxes, BOXID('R', 'F', 'I', 'N'), rplanes);
     if (rc) goto out;
+    memcpy(info->cquant, ltmp.cquant, sizeof(ltmp.cquant)); memcpy(info->comp_seen, ltmp.comp_seen, sizeof(ltmp.comp_seen));
+    memcpy(rinfo.cquant, rtmp.cquant, sizeof(rtmp.cquant)); memcpy(rinfo.comp_seen, rtmp.comp_seen, sizeof(rtmp.comp_seen));
+    info->scan_state_valid = ltmp.scan_state_valid; rinfo.scan_state_valid = rtmp.scan_state_valid;
     info->precision += hidden_l;
     rinfo.precision += hidden_r;
   }

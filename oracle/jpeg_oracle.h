@@ -54,6 +54,15 @@ typedef struct {
   int ycbcr;                 /* 1: L-transformation is YCbCr->RGB, 0: identity               */
   uint16_t quant[4][64];     /* quantiser deltas, natural (de-zigzagged) order               */
   int quant_defined[4];
+  /* State of the scans (filled by oj_decode_coefficients / oj_decode): the reference builds a component's
+   * transform, with the quantiser table in force at that moment, when the component first appears in a scan
+   * (control/blockbuffer.cpp:177-208); a component that appears in no scan has no transform and reconstructs
+   * as sample value 0 (control/blockbitmaprequester.cpp:1047-1054). */
+  int scan_state_valid;      /* cquant / comp_seen below are meaningful                      */
+  uint16_t cquant[OJ_MAX_COMP][64];
+  int comp_seen[OJ_MAX_COMP];
+  int ref_error;             /* the reference's JPGERR_* code of a failed decode, else 0     */
+  int warnings;              /* number of JPG_WARN conditions passed (damaged but decodable) */
 } oj_info;
 
 /* Parse the headers only.  Returns OJ_OK or a negative error. */

@@ -25,6 +25,8 @@ class OjInfo(C.Structure):
         ("cw", C.c_int * 4), ("ch", C.c_int * 4), ("restart_interval", C.c_int),
         ("adobe_transform", C.c_int), ("ycbcr", C.c_int), ("quant", (C.c_uint16 * 64) * 4),
         ("quant_defined", C.c_int * 4),
+        ("scan_state_valid", C.c_int), ("cquant", (C.c_uint16 * 64) * 4), ("comp_seen", C.c_int * 4),
+        ("ref_error", C.c_int), ("warnings", C.c_int),
     ]
 
 
@@ -170,6 +172,37 @@ def upsample_block(plane: np.ndarray, cw: int, ch: int, sx: int, sy: int, X0: in
 
 
 # ---------------------------------------------------------------------------- real reference
+def decode_status(data: bytes, max_bytes: int = 1 << 28):
+    """Whole decode the way the reference CLI does it, damaged streams included:
+    -> (pixels or None, ref_error, warnings).  ref_error is the JPGERR_* code the reference fails with (0: decoded);
+    pixels are (H, W, ncomp) uint8, or uint16 for 12-bit frames.  rc -2 (a coding process outside the path) and frames
+    beyond max_bytes of coefficients -> ref_error None."""
+    info = OjInfo()
+    rc = lib().oj_read_info(data, len(data), C.byref(info))
+    if rc == -2:
+        return None, None, info.warnings
+    if rc:
+        return None, info.ref_error, info.warnings
+    if sum(info.bh[c] * info.bw[c] for c in range(info.ncomp)) * 256 > max_bytes:
+        return None, None, info.warnings  # a damaged frame header announces a giant picture: not worth the memory
+    planes = [np.zeros((info.bh[c], info.bw[c], 64), np.int32) for c in range(info.ncomp)]
+    ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - info.ncomp))
+    rc = lib().oj_decode_coefficients(data, len(data), C.byref(info), ptrs)
+    if rc == -2:
+        return None, None, info.warnings
+    if rc:
+        return None, info.ref_error, info.warnings
+    if info.precision == 8:
+        out = np.zeros((info.height, info.width, info.ncomp), np.uint8)
+        rc = lib().oj_reconstruct(C.byref(info), ptrs, out.ctypes.data, -1)
+    else:
+        out = np.zeros((info.height, info.width, info.ncomp), np.uint16)
+        rc = lib().oj_reconstruct16(C.byref(info), ptrs, out.ctypes.data, -1)
+    if rc:
+        raise ValueError(f"oracle: reconstruction failed rc={rc}")
+    return out, 0, info.warnings
+
+
 def have_reference() -> bool:
     return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
 
@@ -183,6 +216,57 @@ def read_pnm(path: str) -> np.ndarray:
     w, h = map(int, dims.split())
     ch = 3 if magic == b"P6" else 1
     return np.frombuffer(rest, np.uint8, w * h * ch).reshape(h, w, ch)
+
+
+def read_pnm_any(path: str) -> np.ndarray:
+    """P5 / P6 with 8 or 16 bit samples (big endian, as cmd/bitmaphook.cpp writes them)."""
+    with open(path, "rb") as f:
+        d = f.read()
+    magic, rest = d.split(b"\n", 1)
+    dims, rest = rest.split(b"\n", 1)
+    maxv, rest = rest.split(b"\n", 1)
+    w, h = map(int, dims.split())
+    sb = 2 if int(maxv) > 255 else 1
+    ch = 1 if magic == b"P5" else max(3, len(rest) // (w * h * sb))  # four-component frames go out as "P6" with 4 samples per pixel
+    if sb == 2:
+        return np.frombuffer(rest, ">u2", w * h * ch).reshape(h, w, ch).astype(np.uint16)
+    return np.frombuffer(rest, np.uint8, w * h * ch).reshape(h, w, ch).copy()
+
+
+def reference_decode_status(data: bytes, extra_args=(), timeout=10):
+    """Run the real reference CLI on a possibly damaged stream: -> (pixels or None, error).  error is 0 when a picture
+    was written, the JPGERR_* code the CLI prints otherwise (cmd/reconstruct.cpp:360-364), or "crash:<signal>"."""
+    import re
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        src, dst = os.path.join(d, "in.jpg"), os.path.join(d, "out.ppm")
+        with open(src, "wb") as f:
+            f.write(data)
+        try:
+            r = subprocess.run([REF_BIN, *extra_args, src, dst], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            return None, "timeout"
+        if r.returncode < 0:
+            return None, f"crash:{-r.returncode}"
+        m = re.search(rb"failed - error (-?\d+)", r.stderr)
+        if m:
+            return None, int(m.group(1))
+        if not os.path.exists(dst):
+            return None, "no output"
+        try:
+            with open(dst, "rb") as f:
+                head = f.read(2)
+            if head in (b"P5", b"P6"):
+                return read_pnm_any(dst), 0
+            # frames of two or four components go out as PGX: a list of raw planes with a header file each
+            planes = []
+            for line in open(dst).read().split():
+                m = re.match(rb"PG ML \+(\d+) (\d+) (\d+)", open(line[:-4] + ".h", "rb").read())
+                bits, w, h = (int(x) for x in m.groups())
+                planes.append(np.fromfile(line, np.uint8 if bits <= 8 else ">u2").reshape(h, w))
+            return np.stack(planes, axis=-1).astype(np.uint8 if planes[0].dtype == np.uint8 else np.uint16), 0
+        except Exception:
+            return None, "short output"
 
 
 def write_ppm(path: str, img: np.ndarray) -> None:
