@@ -2,7 +2,9 @@
 // decoding into planar int16 coefficient planes.  No HIP in here: this part also runs (and is
 // tested) on a box without a GPU.
 //
-// Reference behaviour reproduced (happy path; corrupt streams are reported, not resynchronised):
+// Reference behaviour reproduced, damaged streams included (the state machine of JPEG::ReadInternal with its
+// warn-and-continue paths and the restart marker resynchronisation of codestream/entropyparser.cpp:117-201; see the
+// RefWalker class in host_decoder.cpp):
 //   codestream/tables.cpp:1003-...      marker dispatch (DQT, DHT, DRI, APP14)
 //   marker/quantization.cpp:474-537     DQT, stored de-zigzagged
 //   coding/huffmantemplate.cpp:802-905  DHT -> decoder tables
@@ -28,6 +30,8 @@ namespace mij {
 
 struct HuffTable {
   bool defined = false;
+  bool built = false; // decoder tables below are valid (built when a scan first uses the table, as the reference does)
+  bool oversize = false; // the DHT segment listed more than 256 values
   uint8_t counts[16] = {0};
   uint8_t values[256] = {0};
   // decoder: LOOKAHEAD-bit direct table, entry = (length << 8) | symbol, 0 = longer code
@@ -53,6 +57,10 @@ struct Scan {
   size_t ecs_begin = 0, ecs_end = 0; // entropy coded data [begin, end) in the input
   std::vector<size_t> interval_begin; // byte offset of every restart interval (first = ecs_begin)
   const uint8_t *base = nullptr;      // stream the offsets refer to; null = the decoder's input (hidden scans live in boxes)
+  // what the reference's parser for this scan is (marker/scan.cpp:355-470, codestream/sequentialscan.cpp:72-94)
+  bool refinement = false;      // RefinementScan instead of SequentialScan
+  bool progressive_run = false; // EOB runs are legal (m_bProgressive)
+  int lowbit = 0;               // point transform incl. hidden bits
 };
 
 struct StreamError {
@@ -65,6 +73,8 @@ struct XtBox {
   uint32_t type = 0;
   uint16_t en = 0;
   std::vector<uint8_t> data;
+  uint64_t boxsize = 0;  // payload bytes the box header announces
+  bool complete = false; // all of them arrived
 };
 
 // "Virtual restart intervals" of a scan without restart markers: exact restart points (byte, bits to skip, DC
@@ -90,6 +100,12 @@ public:
   // bands of frame MCU rows become final (while later bands are still being decoded when the
   // last scan is interleaved; otherwise once at the end).  Used for streaming uploads; may be empty.
   int decode(int16_t *coef, int threads, const std::function<void(int, int)> &on_rows_done);
+  // The stream is damaged in a way the parallel decoders (host and device) must not touch: restart markers missing,
+  // out of sequence or in excess, or a sequential scan with a point transform.  decode() then walks the stream
+  // sequentially the way the reference does (resynchronisation, grey intervals; RefWalker in host_decoder.cpp).
+  bool needs_sequential() const { return needs_sequential_; }
+  // conditions the reference only warns about that the last parse / decode passed (stray markers, resynchronisation ...)
+  int warnings() const { return warnings_; }
 
   // Walk scan `scan` (Huffman sequential, no restart markers needed) speculatively in parallel and return its virtual
   // restart intervals; nonzero if the scan does not lend itself to it (the caller then decodes on the host).
@@ -112,11 +128,27 @@ public:
   double huffman_seconds = 0;
 
 private:
+  friend class RefWalker;
   const uint8_t *data_ = nullptr;
   size_t size_ = 0;
   HuffTable dc_[4], ac_[4];
   uint16_t quant_[4][64];
   bool quant_defined_[4] = {false, false, false, false};
+  bool have_quant_ = false, have_huff_ = false; // a DQT / DHT marker was seen at all
+  int frame_type_ = 0;                          // 0 baseline (SOF0), 1 extended sequential (SOF1), 2 progressive (SOF2)
+  // the transform of a component uses the quantiser table that was in force when the component first appeared in a
+  // scan; a component that appears in no scan reconstructs as sample value 0 (control/blockbuffer.cpp:177-208,
+  // control/blockbitmaprequester.cpp:1047-1054)
+  bool comp_seen_[MIJPEG_MAX_COMPONENTS] = {false, false, false, false};
+  uint16_t comp_quant_[MIJPEG_MAX_COMPONENTS][64];
+  bool needs_sequential_ = false;
+  bool parsed_ = false;
+  int warnings_ = 0;
+  void reset_stream_state();
+  void publish_tables(bool header_only);
+  template <class T> int decode_sequential(T *coef, int threads);
+  template <class T> void fill_unseen_components(T *coef);
+  template <class T> void range_pass(const T *coef, int threads, std::atomic<uint32_t> (&qmax_all)[MIJPEG_MAX_COMPONENTS]);
   int restart_interval_ = 0;
   int adobe_transform_ = -1;
   bool have_frame_ = false;
@@ -136,14 +168,11 @@ private:
   int64_t plane_offset_[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0}; // component planes inside this frame's own store
   int finish_xt(bool header_only);
   int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
-  int parse_dht(const uint8_t *q, int len);
   template <class T> int decode_t(T *coef, int threads, const std::function<void(int, int)> &on_rows_done);
   template <class T> int decode_scan_speculative(T *coef, const Scan &s, int threads, uint32_t (&qmax_out)[MIJPEG_MAX_COMPONENTS],
                                                  VirtualIntervals *plan_only = nullptr);
   int fail(int code, const char *msg);
-  int parse_sof(const uint8_t *p, int n);
   int frame_geometry();
-  int parse_sos(const uint8_t *p, int n, size_t ecs_begin);
   void find_intervals(Scan &s);
 };
 
