@@ -185,12 +185,13 @@ class Decoder:
     def read(self, data: bytes, threads: int = 0, entropy: str = "host") -> MijpegInfo:
         """JPEG::Read: parse everything and entropy-decode all scans (uploads when a device is attached).
         entropy = "host" (restart-interval parallel on the CPU), "gpu" (on the device, error if the stream does not
-        qualify) or "auto" (device when it qualifies)."""
+        qualify), "auto" (device when it qualifies and has enough restart intervals to occupy it) or "prefer-gpu" (device
+        whenever it qualifies, however small; host otherwise -- damaged streams always end up there)."""
         self._data = data
         self._check(lib().mijpeg_set_input(self._h, data, len(data)))
         self.entropy_used = "host"
-        if entropy in ("gpu", "auto"):
-            rc = lib().mijpeg_decode_coefficients_device(self._h, 1 if entropy == "gpu" else 0)
+        if entropy in ("gpu", "auto", "prefer-gpu"):
+            rc = lib().mijpeg_decode_coefficients_device(self._h, 0 if entropy == "auto" else 1)
             if rc == 0:
                 self.entropy_used = "gpu"
             elif rc != ERR_NOT_AVAILABLE or entropy == "gpu":

@@ -308,6 +308,8 @@ static const char *device_entropy_obstacle(const HostDecoder &h, size_t size, bo
 {
   const mijpeg_info &f = h.info;
   // one Huffman sequential scan over all components (or a single-component frame)
+  if (h.needs_sequential())
+    return "on-device entropy decoding: the stream is damaged; the host decoder walks it with the reference's resynchronisation (entropyparser.cpp:117-201)";
   if (f.progressive) return "on-device entropy decoding: progressive frames are decoded on the host";
   if (f.xt && !xt_part) return "on-device entropy decoding: not for this JPEG XT stream";
   if (f.precision != 8 && !(xt_part && f.precision == 12)) return "on-device entropy decoding: 8-bit frames (12-bit residual frames of JPEG XT) only";
@@ -315,6 +317,8 @@ static const char *device_entropy_obstacle(const HostDecoder &h, size_t size, bo
   const Scan &s = h.scans[0];
   if (s.ncomp != f.components) return "on-device entropy decoding: the scan does not cover all components";
   if (size > 0xfffffff0ull) return "on-device entropy decoding: stream too long";
+  for (int c = 0; c < f.components; c++)
+    if (f.hsamp[c] > 4 || f.vsamp[c] > 4) return "on-device entropy decoding: MCUs of more than 4 x 4 blocks of a component are decoded on the host";
   return nullptr;
 }
 
@@ -526,10 +530,11 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
       nint = (total_mcus + s.restart_interval - 1) / s.restart_interval;
       if (nint > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too many restart intervals");
       if ((int64_t)s.interval_begin.size() < nint)
-        return set_error(d, MIJPEG_ERR_UNEXPECTED_EOF, "entropy coded segment ends before all restart intervals were found");
+        return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "restart markers missing: the host decoder resynchronises like the reference (entropyparser.cpp:117-201)");
       const std::vector<uint8_t> &rst = hosts[i]->restart_codes(0);
       for (int64_t k = 0; k + 1 < nint; k++)
-        if (rst[(size_t)k] != 0xd0 + (k & 7)) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "restart markers are out of sequence");
+        if (rst[(size_t)k] != 0xd0 + (k & 7))
+          return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "restart markers out of sequence: the host decoder resynchronises like the reference (entropyparser.cpp:117-201)");
     } else {
       // no restart markers: the host's self-synchronising walk finds exact restart points ("virtual intervals"),
       // about 16 K of them, and the device decodes from there

@@ -107,3 +107,89 @@ def cases(data: bytes, count: int, seed: int, where: str = "any"):
     for i in range(count):
         kind = KINDS[i % len(KINDS)]
         yield kind, corrupt(data, kind, rng, where)
+
+
+def product_vs_oracle(blob: bytes):
+    """libjpeg_amd's host entropy decoder (no device) against the oracle: verdict (decoded / error code), coefficients of
+    every component that appears in a scan, the quantiser table each component ends up with.  -> (verdict, detail)."""
+    import ctypes as C
+
+    from libjpeg_amd import api
+    from oracle import oracle as O
+    info = O.OjInfo()
+    orc = O.lib().oj_read_info(blob, len(blob), C.byref(info))
+    planes = None
+    if orc == 0:
+        if sum(info.bh[c] * info.bw[c] for c in range(info.ncomp)) * 256 > (1 << 28):
+            return "skip", None
+        planes = [np.zeros((info.bh[c], info.bw[c], 64), np.int32) for c in range(info.ncomp)]
+        ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - info.ncomp))
+        orc = O.lib().oj_decode_coefficients(blob, len(blob), C.byref(info), ptrs)
+    if orc == -2:
+        return "skip", None
+    oerr = info.ref_error if orc else 0
+    d = api.Decoder(None)
+    try:
+        try:
+            f = d.read(blob, entropy="host")
+            perr = 0
+        except api.MijpegError as e:
+            perr = e.code
+        if perr == -1028 and oerr != -1028:
+            return "int16-gate", None  # a coefficient beyond the 16-bit store: documented limit of the accelerated path
+        if (perr == 0) != (oerr == 0):
+            return "decode-vs-error", (oerr, perr)
+        if perr:
+            return ("ok" if perr == oerr else "code"), (oerr, perr)
+        for c in range(info.ncomp):
+            got = d.coefficients(c)
+            q = np.array(f.quant[f.quant_index[c]][:], np.int32)
+            if info.comp_seen[c]:
+                if not np.array_equal(got, planes[c]):
+                    return "coefficients", (c, int(np.count_nonzero(got != planes[c])))
+                if not np.array_equal(q, np.array(info.cquant[c][:], np.int32)):
+                    return "quant", c
+            else:
+                if not (np.all(q == 1) and np.all(got[..., 0] == -(1 << (info.precision + 2))) and not got[..., 1:].any()):
+                    return "unseen-component", c
+        return "ok", None
+    finally:
+        d.close()
+
+
+def expected_of(blob: bytes, use_reference: bool):
+    """What the reference does with `blob`: (pixels or None, error).  From the real binary (oracle/_ref/jpeg) where it is
+    present, else from the oracle's restatement.  error None = nothing to compare with (coding process outside the path,
+    giant frame announced by a damaged header, or the reference itself hangs)."""
+    from oracle import oracle as O
+    if use_reference:
+        px, err = O.reference_decode_status(blob)
+        if err == "timeout":
+            return None, None
+        return px, err
+    px, err, _ = O.decode_status(blob)
+    return px, err
+
+
+def product_pixels_vs_expected(dec, blob: bytes, exp_px, exp_err):
+    """The product end to end -- host entropy decoder with the reference's resynchronisation, reconstruction kernels on the
+    GPU, through the C ABI -- against the reference's verdict and pixels.  -> (verdict, detail)."""
+    from libjpeg_amd import api
+    if exp_err is None:
+        return "skip", None
+    try:
+        dec.read(blob, entropy="host")
+        perr = 0
+    except api.MijpegError as e:
+        perr = e.code
+    if perr == -1028 and exp_err != -1028:
+        return "int16-gate", None
+    if (perr == 0) != (exp_err == 0):
+        return "decode-vs-error", (exp_err, perr)
+    if perr:
+        return ("ok" if perr == exp_err else "code"), (exp_err, perr)
+    out = dec.reconstruct()
+    if out.shape != exp_px.shape:
+        return "shape", (exp_px.shape, out.shape)
+    nd = int(np.count_nonzero(out != exp_px))
+    return ("ok" if nd == 0 else "pixels"), nd

@@ -1,0 +1,213 @@
+"""Damaged codestreams: same input, same result as the reference.
+
+The reference does not give up on a damaged entropy-coded segment: EntropyParser::ParseRestartMarker
+(codestream/entropyparser.cpp:117-201) resynchronises at the restart markers (a marker that is BEHIND the expected one is
+dropped and the search goes on, one that is AHEAD invalidates the segment, whose MCUs are zeroed,
+codestream/sequentialscan.cpp:416-420), the bit reader feeds zero bits at markers and at the end of the data
+(io/bitstream.cpp:56-137), refinement scans warn and continue (codestream/refinementscan.cpp:667).  Three layers:
+
+  * the oracle's restatement of that behaviour against committed goldens (tests/golden/damaged/, written by the real
+    reference through tests/golden/make_damaged.py) and, where oracle/_ref/jpeg exists, against the binary itself on
+    seeded corruptions (CPU);
+  * the product's host entropy decoder against the oracle on seeded corruptions, coefficient by coefficient (CPU);
+  * -m gpu: the product end to end (host decoder + reconstruction kernels, through the C ABI) against the reference
+    binary (it travels to the GPU box as oracle/_ref/jpeg; the oracle stands in where it is absent): error code AND pixels.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import damage
+from conftest import GOLDEN_DIR, MANIFEST, golden_jpeg
+from libjpeg_amd import api
+
+DAMAGED_DIR = os.path.join(GOLDEN_DIR, "damaged")
+with open(os.path.join(DAMAGED_DIR, "manifest.json")) as _f:
+    DAMAGED = json.load(_f)
+
+# plain JPEG fixtures (JPEG XT and DNL frames are outside the damaged-stream contract)
+BASES = sorted(k for k, v in MANIFEST.items() if not v.get("big") and v.get("kind") != "xt_float32" and "dnl" not in k)
+
+
+def damaged_jpeg(name):
+    with open(os.path.join(DAMAGED_DIR, name + ".jpg"), "rb") as f:
+        return f.read()
+
+
+def damaged_pixels(name):
+    ent = DAMAGED[name]
+    if ent["error"] != 0:
+        return None
+    with open(os.path.join(DAMAGED_DIR, name + ".bin"), "rb") as f:
+        return np.frombuffer(f.read(), np.uint8).reshape(ent["height"], ent["width"], ent["channels"])
+
+
+def seeded(count_per_file, seed, where="any", bases=BASES):
+    for fi, name in enumerate(bases):
+        data = golden_jpeg(name)
+        for kind, blob in damage.cases(data, count_per_file, seed * 1000 + fi, where):
+            yield name, kind, blob
+
+
+# ------------------------------------------------------------------------------------------------ oracle
+@pytest.mark.parametrize("name", sorted(DAMAGED))
+def test_oracle_on_handmade_damage(oracle, name):
+    """The restatement against what the real reference wrote for the committed hand-made cases."""
+    ent = DAMAGED[name]
+    px, err, _ = oracle.decode_status(damaged_jpeg(name))
+    assert err == ent["error"], f"{name}: reference {ent['error']}, oracle {err}"
+    if err == 0:
+        assert np.array_equal(px, damaged_pixels(name)), name
+
+
+def test_handmade_damage_differs_from_the_clean_picture(oracle):
+    """The fixtures are not trivially equal to the undamaged decode (the resynchronisation really is exercised)."""
+    differing = 0
+    for name, ent in DAMAGED.items():
+        if ent["error"] == 0:
+            clean = oracle.decode(golden_jpeg(ent["base"]))
+            differing += int(not np.array_equal(clean, damaged_pixels(name)))
+    assert differing >= 8
+
+
+def test_oracle_against_live_reference_on_seeded_damage(oracle):
+    """600 seeded corruptions: verdict and pixels of the restatement == the real binary's (build container only)."""
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/jpeg not built")
+    from concurrent.futures import ThreadPoolExecutor
+
+    work = list(seeded(15, 42))[:600]
+
+    def one(item):
+        name, kind, blob = item
+        opx, oerr, _ = oracle.decode_status(blob)
+        if oerr is None:
+            return None
+        rpx, rerr = oracle.reference_decode_status(blob)
+        if rerr == "timeout":
+            return None
+        if rerr != oerr:
+            return f"{name}/{kind}: reference {rerr}, oracle {oerr}"
+        if rerr == 0 and not (rpx.shape == opx.shape and np.array_equal(rpx, opx)):
+            return f"{name}/{kind}: pixels differ"
+        return ""
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(one, work))
+    bad = [r for r in res if r]
+    assert not bad, bad[:10]
+    assert sum(r == "" for r in res) >= 500
+
+
+# ------------------------------------------------------------------------------------------------ product, host side
+@pytest.mark.parametrize("name", sorted(DAMAGED))
+def test_host_decoder_on_handmade_damage(oracle, name):
+    verdict, detail = damage.product_vs_oracle(damaged_jpeg(name))
+    assert verdict == "ok", (name, verdict, detail)
+    # and the error code is the reference's own
+    ent = DAMAGED[name]
+    d = api.Decoder(None)
+    try:
+        try:
+            d.read(damaged_jpeg(name))
+            code = 0
+        except api.MijpegError as e:
+            code = e.code
+    finally:
+        d.close()
+    assert code == ent["error"]
+
+
+def test_host_decoder_against_oracle_on_seeded_damage(oracle):
+    """Coefficients, quantiser tables and error codes of the product's host decoder on 1200 seeded corruptions."""
+    stats = {}
+    bad = []
+    for where, seed in (("any", 5), ("entropy", 6)):
+        for name, kind, blob in seeded(18, seed, where):
+            verdict, detail = damage.product_vs_oracle(blob)
+            stats[verdict] = stats.get(verdict, 0) + 1
+            if verdict not in ("ok", "skip", "int16-gate"):
+                bad.append((name, kind, verdict, detail))
+    assert not bad, bad[:10]
+    assert stats.get("ok", 0) >= 1100, stats
+    assert stats.get("int16-gate", 0) <= 5, stats
+
+
+def test_parallel_and_sequential_host_walks_agree_on_damage(oracle):
+    """Thread count must not matter: the restart-parallel plan falls back to the sequential walk on any irregularity."""
+    d1, d8 = api.Decoder(None), api.Decoder(None)
+    n = 0
+    for name, kind, blob in seeded(6, 9, "entropy", ["pil_200x120_420_dri8", "ref_75x45_420_dri2", "ref_97x61_3x3", "refprog_64x64_444_dri5"]):
+        res = []
+        for d, t in ((d1, 1), (d8, 8)):
+            try:
+                f = d.read(blob, threads=t)
+                res.append((0, [d.coefficients(c) for c in range(f.components)]))
+            except api.MijpegError as e:
+                res.append((e.code, []))
+        assert res[0][0] == res[1][0], (name, kind)
+        for a, b in zip(res[0][1], res[1][1]):
+            assert np.array_equal(a, b), (name, kind)
+        n += 1
+    d1.close()
+    d8.close()
+    assert n == 24
+
+
+# ------------------------------------------------------------------------------------------------ product, end to end
+@pytest.fixture(scope="module")
+def dec():
+    d = api.Decoder(0)
+    yield d
+    d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(DAMAGED))
+def test_gpu_handmade_damage_pixels_and_rc(dec, name):
+    ent = DAMAGED[name]
+    verdict, detail = damage.product_pixels_vs_expected(dec, damaged_jpeg(name), damaged_pixels(name), ent["error"])
+    assert verdict == "ok", (name, verdict, detail)
+
+
+@pytest.mark.gpu
+def test_gpu_seeded_damage_pixels_and_rc_equal_the_reference(oracle, dec):
+    """>= 500 seeded corruptions (byte flips, dropped / duplicated / reordered intervals, renumbered and removed markers,
+    truncation, insertions, zero and FF runs) of the plain JPEG fixtures: the product's return code and pixels equal those of
+    oracle/_ref/jpeg, the real reference binary.  Where the binary is absent the oracle's restatement (pinned against it by
+    the CPU tests above and tools/damage_campaign.py) stands in."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    use_ref = oracle.have_reference()
+    work = list(seeded(10, 77)) + list(seeded(10, 78, "entropy"))
+    with ThreadPoolExecutor(16) as ex:
+        expected = list(ex.map(lambda w: damage.expected_of(w[2], use_ref), work))
+    stats = {}
+    bad = []
+    for (name, kind, blob), (epx, eerr) in zip(work, expected):
+        verdict, detail = damage.product_pixels_vs_expected(dec, blob, epx, eerr)
+        stats[verdict] = stats.get(verdict, 0) + 1
+        if verdict not in ("ok", "skip", "int16-gate"):
+            bad.append((name, kind, verdict, detail))
+    print("damaged-stream parity against", "oracle/_ref/jpeg" if use_ref else "the oracle", stats)
+    assert not bad, bad[:10]
+    assert stats.get("ok", 0) >= 500, stats
+    assert stats.get("int16-gate", 0) <= 5, stats
+
+
+@pytest.mark.gpu
+def test_gpu_damaged_big_frame_through_the_fused_kernel(oracle, dec):
+    """A frame large enough for the restart-parallel host plan and the fused 4:2:0 kernel, with intervals dropped,
+    duplicated and a marker renumbered: pixels equal the oracle's (and the reference's, where present)."""
+    from libjpeg_amd import synth
+    data = synth.synth_jpeg(640, 368, 31, 85, "420", 4)
+    rng = np.random.default_rng(5)
+    for kind in ("drop_interval", "dup_interval", "swap_intervals", "renumber_rst", "drop_marker_only", "flip3", "truncate"):
+        blob = damage.corrupt(data, kind, rng, "entropy")
+        epx, eerr = damage.expected_of(blob, oracle.have_reference())
+        opx, oerr, _ = oracle.decode_status(blob)
+        assert oerr == eerr and (eerr != 0 or np.array_equal(opx, epx)), kind
+        verdict, detail = damage.product_pixels_vs_expected(dec, blob, epx, eerr)
+        assert verdict == "ok", (kind, verdict, detail)

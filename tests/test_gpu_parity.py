@@ -430,6 +430,7 @@ def test_adversarial_coefficients_safe_flavour(oracle, generic):
         for i in range(64):
             info.quant[t][i] = int(rng.integers(1, 256))
             f.quant[t][i] = info.quant[t][i]
+    info.scan_state_valid = 0  # the tables edited here, not the ones the scans of `data` latched per component
     f.fast_arith = 0
     exp = oracle.reconstruct(info, planes)
     coef = torch.from_numpy(np.concatenate([p.astype(np.int16).reshape(-1) for p in planes])).cuda()
@@ -461,6 +462,7 @@ def test_extreme_coefficients_at_the_packed_chroma_gate(oracle):
         for i in range(64):
             info.quant[t][i] = 1 if i else 2
             f.quant[t][i] = info.quant[t][i]
+    info.scan_state_valid = 0  # see above
     planes = []
     for c in range(3):
         shape = (info.bh[c], info.bw[c], 64)
@@ -756,25 +758,27 @@ def test_device_entropy_decoder_eligibility_and_errors(dec):
     sos = good.find(b"\xff\xda")
     rng = np.random.default_rng(3)
     host = api.Decoder(0)
-    seen = 0
+    seen = on_device = 0
     for trial in range(40):
         bad = bytearray(good)
         for pos in rng.integers(sos + 20, len(bad) - 2, size=8):
             if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:
                 bad[pos] = int(rng.integers(0, 255))
         codes = []
-        for d, mode in ((host, "host"), (dec, "gpu")):
+        for d, mode in ((host, "host"), (dec, "prefer-gpu")):
             try:
                 d.read(bytes(bad), entropy=mode)
                 codes.append(0)
             except api.MijpegError as e:
                 codes.append(e.code)
         assert codes[0] == codes[1], (trial, codes)
+        on_device += dec.entropy_used == "gpu"
         if codes[0] == 0:
             _same_coefficients(dec, host, 3)
         else:
             seen += 1
-    assert seen > 0
+    # the flips rarely touch a marker: most of these streams keep their restart markers in sequence and stay on the device
+    assert on_device > 20, on_device
     host.close()
 
 
