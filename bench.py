@@ -5,10 +5,18 @@ A "step" is one pass of the hot path (fused dequant + IDCT + chroma upsample + Y
 batch of F synthetic 8K (7680x4320) 4:2:0 baseline frames whose int16 coefficient planes are already
 resident in HBM; pixels are written to HBM.  value = decoded Mpixels/s over all ranks.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--size 8k|4k]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--size 8k|4k] [--workload both|headline|batch4k]
 
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL barrier only: frames
 are independent, nothing is exchanged).  Rank 0 prints ONE JSON line.
+
+Beside the headline the same line carries
+  "batch4k"        BASELINE config 4 as written: 256 distinct 4K 4:2:0 Q85 DRI=8 streams in host memory, image-sharded
+                   over the ranks (strong scaling), bytes -> pixels in HBM, each rank on its share of the host cores;
+  "roofline_dense" the headline launch on content that defeats the sparse shortcuts (every coefficient non-zero) and on
+                   content beyond the 16-bit chroma gate (32-bit kernel flavour);
+  roofline.traffic HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a child of this script
+                   (null when rocprofv3 is not usable, e.g. when this process is itself being profiled).
 """
 import argparse
 import json
@@ -20,6 +28,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# the ranks of one node share its cores: each rank's host pool (header parsing, marker search, host Huffman decoding) gets
+# cores / world of them.  Must be in the environment before libmijpeg.so is loaded.
+_WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+if _WORLD > 1:
+    os.environ.setdefault("MIJPEG_THREADS", str(max(1, min(64, (os.cpu_count() or 1) // _WORLD))))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -62,6 +76,216 @@ def cpu_baseline(jpeg_bytes, width, height):
                 sample=f"5 in-memory decodes of one {width}x{height} 4:2:0 frame by oracle/liboracle.so, median {best * 1e3:.0f} ms")
 
 
+def cpu_baseline_all_cores(streams, width, height):
+    """The reference on ALL host cores: `nproc` concurrent whole-process decodes of distinct frames (one process per core;
+    the reference is single-threaded), aggregate Mpixels/s.  Output goes to /dev/null (writing the PPMs of hundreds of
+    concurrent processes into /dev/shm would measure the page allocator); bounded by the memory the box has free."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+
+    if not O.have_reference():
+        return None
+    nproc = os.cpu_count() or 1
+    try:
+        with open("/proc/meminfo") as f:
+            avail_kb = next(int(line.split()[1]) for line in f if line.startswith("MemAvailable"))
+        per_proc = (width * height * 3 // 2) * 4 * 2 + width * height * 4  # LONG coefficient store + line buffers, generous
+        nproc = max(1, min(nproc, int(avail_kb * 1024 * 0.5 / per_proc)))
+    except (OSError, StopIteration, ValueError):
+        pass
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        files = []
+        for i in range(nproc):
+            fn = os.path.join(d, f"in{i}.jpg")
+            with open(fn, "wb") as f:
+                f.write(streams[i % len(streams)])
+            files.append(fn)
+
+        def one(fn):
+            subprocess.run([O.REF_BIN, fn, "/dev/null"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+        best = None
+        for _ in range(2):
+            t = time.perf_counter()
+            with ThreadPoolExecutor(nproc) as ex:
+                list(ex.map(one, files))
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+    return dict(value=round(nproc * width * height / best / 1e6, 1), unit="Mpixels/s", cores=nproc, kind="reference",
+                sample=f"{nproc} concurrent whole-process decodes of {min(nproc, len(streams))} distinct {width}x{height} 4:2:0 Q85 DRI=8 frames by "
+                       f"oracle/_ref/jpeg (files in /dev/shm -> /dev/null), best of 2 rounds: {best * 1e3:.0f} ms; host has {os.cpu_count()} logical cores")
+
+
+# ---- HBM traffic of the headline launch, measured where it is reported ------------------------------------------------
+TRAFFIC_FRAMES = 8
+
+
+def traffic_child(path):
+    """Child process of measure_traffic(): 3 launches of the headline kernel on TRAFFIC_FRAMES frames whose coefficient planes
+    the parent left in `path` -- nothing else, so that the rocprofv3 pass around it is short."""
+    blob = np.load(path, allow_pickle=False)
+    info = api.MijpegInfo.from_buffer_copy(blob["info"].tobytes())
+    planes = torch.from_numpy(blob["planes"]).cuda()
+    W, H, n = info.width, info.height, int(info.coef_count)
+    coef = torch.empty((TRAFFIC_FRAMES, n), dtype=torch.int16, device="cuda")
+    for f in range(TRAFFIC_FRAMES):
+        coef[f].copy_(planes[f % planes.shape[0]])
+    row = W * 3
+    out = torch.empty((TRAFFIC_FRAMES, H, row), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), TRAFFIC_FRAMES, row, H * row, n, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
+def measure_traffic(info, host_planes, kernel, frames):
+    """roofline.traffic: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md) over
+    a child of this script, counters of `kernel` per launch, FETCH_SIZE doubled per the guide's gfx950 correction (wide
+    coalesced reads are tallied at half their bytes), KB -> bytes, scaled from the child's TRAFFIC_FRAMES frames per launch
+    to `frames`.  -> (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ):
+        return None, "this process runs under rocprofv3 itself: no nested counter pass"
+    tmp = tempfile.mkdtemp(prefix="mijpeg_traffic_", dir="/tmp")
+    try:
+        path = os.path.join(tmp, "planes.npz")
+        np.savez(path, info=np.frombuffer(bytes(info), np.uint8), planes=np.stack(host_planes))
+        vals = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            outdir = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run([rocprof, "--pmc", ctr, "--output-format", "csv", "-d", outdir, "-o", "t", "--", sys.executable,
+                                os.path.abspath(__file__), "--traffic-child", path], cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, timeout=240)
+            got = []
+            for fn in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+                with open(fn) as fh:
+                    for rowd in csv.DictReader(fh):
+                        if kernel in rowd["Kernel_Name"] and rowd["Counter_Name"] == ctr:
+                            got.append(float(rowd["Counter_Value"]))
+            if not got:
+                return None, f"rocprofv3 --pmc {ctr} produced no rows for {kernel} (exit {r.returncode})"
+            vals[ctr] = sum(got) / len(got)
+        per_launch = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        note = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes run by this process over a child doing 3 launches of {TRAFFIC_FRAMES} "
+                f"frames (FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB doubled per the gfx950 correction, WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB), "
+                f"scaled x{frames}/{TRAFFIC_FRAMES}")
+        return int(per_launch * frames / TRAFFIC_FRAMES), note
+    except Exception as e:  # noqa: BLE001 -- the counters are a report, never a reason to lose the benchmark
+        return None, f"traffic pass failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---- the headline launch on other content ------------------------------------------------------------------------------
+def dense_roofline(info0, F, W, H, stream, steps):
+    """The same launch (F frames, one kernel) on coefficient planes made on the device:
+       "dense"       every one of the 64 coefficients of every block non-zero (+-1, +-2): no zero rows, no zero columns, nothing
+                     for the sparse shortcuts of the transform, yet inside the 16-bit gates (same kernel as the headline);
+       "beyond_gate" chroma amplitudes past the packed 16-bit gate (sum |c| q >= 2047 per block, what saturated graphics and
+                     low-Q tables produce): the 32-bit flavour runs.
+    fast_arith / range_max are computed from the planes exactly as the decoder computes them (max over the blocks of a
+    component of sum_k |c_k| q_k), so the kernel selection is the one a stream with these coefficients would get."""
+    res = {}
+    n = int(info0.coef_count)
+    row = W * 3
+    out = torch.empty((F, H, row), dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4321)
+    # magnitudes (luma, chroma) and DC amplitude: with the Q85 tables (sum of the chroma deltas 1666) "dense" stays below the
+    # packed-chroma gate of 2047, "beyond_gate" lands between 2047 and the 16384 of the fast arithmetic
+    for name, hi_luma, hi_chroma, dc_amp in (("dense", 2, 1, 60), ("beyond_gate", 3, 3, 200)):
+        info = api.MijpegInfo.from_buffer_copy(bytes(info0))
+        one = torch.empty((2, n), dtype=torch.int16, device="cuda")
+        for c in range(info.components):
+            nb = info.blocks_w[c] * info.blocks_h[c]
+            q = torch.tensor(list(info.quant[info.quant_index[c]]), dtype=torch.int32, device="cuda")
+            mag = torch.randint(1, (hi_luma if c == 0 else hi_chroma) + 1, (2, nb, 64), generator=g, device="cuda", dtype=torch.int32)
+            sgn = torch.randint(0, 2, (2, nb, 64), generator=g, device="cuda", dtype=torch.int32) * 2 - 1
+            blk = mag * sgn
+            blk[:, :, 0] = torch.randint(-dc_amp, dc_amp + 1, (2, nb), generator=g, device="cuda", dtype=torch.int32)
+            info.range_max[c] = int((blk.abs() * q).sum(dim=2).max())
+            off = int(info.coef_offset[c])
+            one[:, off:off + nb * 64] = blk.reshape(2, -1).to(torch.int16)
+        info.fast_arith = 1 if max(info.range_max[c] for c in range(info.components)) < 16384 else 0
+        coef = torch.empty((F, n), dtype=torch.int16, device="cuda")
+        for f in range(F):
+            coef[f].copy_(one[f % 2])
+        del one
+        for _ in range(6):
+            api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), F, row, H * row, n, stream=stream.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), F, row, H * row, n, stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        alg = W * H * F * BYTES_PER_PIXEL_420
+        ach = alg / (ms * 1e-3) / 1e9
+        res[name] = {"kernel": api.kernel_name(info), "kernel_ms": round(ms, 4), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(ach / HBM_PEAK_GBPS, 4), "value_Mpixels_s": round(W * H * F / ms / 1e3, 1),
+                     "range_max": [int(info.range_max[c]) for c in range(info.components)], "fast_arith": int(info.fast_arith)}
+        del coef
+    res["note"] = ("same launch shape as the headline (frames, geometry, quantiser tables), coefficient planes synthesised on the device: "
+                   "'dense' = all 64 coefficients of every block non-zero; 'beyond_gate' = chroma sum|c|q past 2047")
+    return res
+
+
+# ---- BASELINE config 4 ----------------------------------------------------------------------------------------------------
+def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
+    """256 x 4K 4:2:0 Q85 DRI=8 (seeds 1000..1255), image-sharded, bytes in host memory -> pixels in HBM; strong scaling."""
+    from libjpeg_amd import batch
+
+    cfg = dict(batch.CONFIG4, frames=frames_total)
+    mine = sharding.frames_of_rank(frames_total, rank, world)
+    t = time.perf_counter()
+    streams = batch.make_streams(mine, cfg, workers=max(1, min(64, (os.cpu_count() or 1) // (2 * world))))
+    gen_s = time.perf_counter() - t
+    best = None
+    for chunk, depth in ((32, 2), (16, 3)):
+        r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=1, chunk=chunk, depth=depth)
+        r["shard"].close()
+        r.pop("shard")
+        r.update(chunk=chunk, depth=depth)
+        if best is None or r["seconds"] < best["seconds"]:
+            best = r
+    W, H = cfg["width"], cfg["height"]
+    ms = best["seconds"] * 1e3 / steps
+    rank_ms = [best["rank_ms"]]
+    if dist is not None:
+        tt = torch.zeros(world, dtype=torch.float64, device="cuda")
+        tt[rank] = best["rank_ms"]
+        dist.all_reduce(tt)
+        rank_ms = [float(x) for x in tt]
+    res = {"metric": "decoded Mpixels/s, 256 x 4K 4:2:0 Q85 DRI=8 streams in host memory -> pixels in HBM (BASELINE configs[3])",
+           "value": round(best["total_pixels"] / best["seconds"] / 1e6, 1), "unit": "Mpixels/s", "scaling": "strong", "n_gpus": world,
+           "frames": frames_total, "frames_per_rank": len(mine), "ms_per_batch": round(ms, 2), "ms_per_frame": round(ms / frames_total, 4),
+           "per_rank_ms": [round(x, 2) for x in rank_ms], "steps": steps, "chunk_frames": best["chunk"], "decoder_objects": best["depth"],
+           "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(),
+           "stream_bytes_total": int(sum(len(v) for v in streams.values())) if world == 1 else None,
+           "generation_s": round(gen_s, 1),
+           "note": "per rank: parallel header parse + restart marker search (host pool = cores / ranks) -> H2D of the compressed bytes -> "
+                   "huffman_scan_kernel -> fused kernel, pixels stay in HBM; RCCL barriers around the timed region only; max over ranks"}
+    if with_cpu and rank == 0 and world == 1:
+        try:
+            some = [streams[i] for i in mine[:min(len(mine), os.cpu_count() or 1)]]
+            res["cpu_baseline"] = cpu_baseline_all_cores(some, W, H)
+        except Exception as e:  # noqa: BLE001
+            res["cpu_baseline"] = {"value": None, "error": repr(e)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,7 +299,17 @@ def main():
     ap.add_argument("--subsampling", default="420", choices=["420", "444"], help="420 = the BASELINE workload; 444 for side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--no-dense", action="store_true", help="skip roofline_dense")
+    ap.add_argument("--workload", default="both", choices=["both", "headline", "batch4k"],
+                    help="headline = the 8K kernel benchmark only; batch4k adds BASELINE config 4 (256 x 4K streams -> pixels, sharded)")
+    ap.add_argument("--batch-frames", type=int, default=256, help="frames of the config 4 batch (256 as written)")
+    ap.add_argument("--batch-steps", type=int, default=3)
+    ap.add_argument("--traffic-child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.traffic_child:
+        traffic_child(args.traffic_child)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -160,22 +394,25 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32 (int16 coefficients in, u8 pixels out)", "data": "synthetic",
         "config": {"workload": f"{F} x {W}x{H} {args.subsampling[0]}:{args.subsampling[1]}:{args.subsampling[2]} Q85 DRI=8 baseline frames per GPU per step (BASELINE configs[2] frame shape, "
-                               f"device-resident coefficient planes)", "frames_per_gpu": F, "kernel": api.kernel_name(info), "settle_launches": settle_launches,
+                               f"device-resident coefficient planes; 2 distinct pictures per rank repeated over the {F} frames: {F * n * 2 >> 20} MiB in + "
+                               f"{F * H * row >> 20} MiB out per launch, far beyond the 256 MiB Infinity Cache)", "frames_per_gpu": F, "kernel": api.kernel_name(info), "settle_launches": settle_launches,
                    "fast_arith": int(info.fast_arith), "parallelism": f"image-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)},
     }
 
-    # HBM bytes per launch measured by the PMC passes (tools/gpu_profile.sh): counters cannot be read from inside this
-    # process, so the number measured for this exact workload is carried in profiles/ next to the CSVs it came from
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
-            t = json.load(f).get(api.kernel_name(info))
-        if t and (t["width"], t["height"]) == (W, H):
-            result["roofline"]["traffic"] = int(t["traffic_bytes"] * F / t["frames"])  # counters were collected on t["frames"] frames per launch
-    except (OSError, ValueError, KeyError):
-        pass
+    if rank == 0 and world == 1 and not args.no_traffic:
+        tb, tnote = measure_traffic(info, host_planes, api.kernel_name(info), F)
+        result["roofline"]["traffic"] = tb
+        result["roofline"]["traffic_note"] = tnote
+    else:
+        result["roofline"]["traffic_note"] = "not measured in this run (N > 1 or --no-traffic)"
+    if rank == 0 and world == 1 and not args.no_dense and args.subsampling == "420":
+        try:
+            result["roofline_dense"] = dense_roofline(info, F, W, H, stream, max(5, args.steps // 2))
+        except Exception as e:  # noqa: BLE001
+            result["roofline_dense"] = {"error": repr(e)}
 
     if rank == 0 and not args.no_end_to_end:
         # whole decode of one frame through the decoder object: host Huffman (all cores) + streaming H2D +
@@ -328,9 +565,19 @@ def main():
                                            "encoder's tables and coefficients (mijpeg_encode_image)"}}
         except Exception as e:  # a side measurement never costs the headline number
             result["end_to_end"]["encoder_direction"] = {"error": repr(e)}
+    if args.workload in ("both", "batch4k"):
+        del coef, out
+        torch.cuda.empty_cache()
+        try:
+            b4 = batch4k(rank, world, local_rank, dist, args.batch_steps, args.batch_frames, not args.no_cpu_baseline)
+            result["batch4k"] = b4
+        except Exception as e:  # noqa: BLE001 -- all ranks take the same path: a failure here is symmetric
+            result["batch4k"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(jpegs[0], W, H)
+            if isinstance(result.get("batch4k"), dict) and result["batch4k"].get("cpu_baseline"):
+                result["cpu_baseline"]["all_cores"] = result["batch4k"]["cpu_baseline"]
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     dec.close()

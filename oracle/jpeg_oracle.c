@@ -398,7 +398,27 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
   switch (marker) {
   case 0xffdb: bs_getword(io); rs_parse_dqt(ps, io); break;
   case 0xffc4: bs_getword(io); rs_parse_dht(ps, io); break;
-  case 0xffcc: rs_unsupported(ps); break; /* DAC: arithmetic coding conditioning, not on this path */
+  case 0xffcc: { /* DAC, ACTable::ParseMarker (marker/actable.cpp:119-149) with ACTemplate::ParseDCMarker / ParseACMarker
+                  * (coding/actemplate.cpp:71-107): parsed and checked; the conditioning never matters to Huffman scans */
+    long len;
+    bs_getword(io);
+    len = bs_getword(io);
+    if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    len -= 2;
+    while (len > 0) {
+      long t = bs_get(io), v;
+      if (t == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+      len--;
+      if ((t >> 4) > 1) rs_throw(ps, RS_MALFORMED_STREAM); /* "undefined conditioning table type" */
+      v = bs_get(io);
+      if (v == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
+      if ((t >> 4) == 1) {
+        if (v < 1 || v > 63) rs_throw(ps, RS_MALFORMED_STREAM);
+      } else if ((v >> 4) < (v & 0x0f)) rs_throw(ps, RS_MALFORMED_STREAM);
+      len--;
+    }
+    break;
+  }
   case 0xffdd: { /* RestartIntervalMarker::ParseMarker, marker/restartintervalmarker.cpp:80-102 (not the JPEG LS flavour) */
     long len;
     bs_getword(io);

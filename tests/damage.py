@@ -163,6 +163,8 @@ def expected_of(blob: bytes, use_reference: bool):
     giant frame announced by a damaged header, or the reference itself hangs)."""
     from oracle import oracle as O
     if use_reference:
+        if O.decode_status(blob)[1] is None:
+            return None, None  # the damage turned the stream into something outside the path (arithmetic, lossless, ... frame types)
         px, err = O.reference_decode_status(blob)
         if err == "timeout":
             return None, None

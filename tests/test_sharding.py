@@ -68,3 +68,54 @@ def test_frames_of_rank_partitions():
             parts = [sharding.frames_of_rank(n, r, world) for r in range(world)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+BATCH_WORKER = textwrap.dedent("""
+    import os, sys, hashlib
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from libjpeg_amd import batch
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cfg = dict(batch.CONFIG4, width=208, height=112, frames=12)    # config 4's recipe at a size the CPU suite can afford
+    streams = batch.make_streams(range(cfg["frames"]), cfg, workers=1)
+    r = batch.run_sharded(streams, cfg["frames"], rank, world, None, dist, steps=2, warmup=1)   # device=None: host entropy decoder
+    assert r["total_pixels"] == 2 * cfg["frames"] * cfg["width"] * cfg["height"], r["total_pixels"]
+    assert r["frames"] == list(range(rank, cfg["frames"], world))
+    shard = r["shard"]
+    for k, i in enumerate(r["frames"]):
+        info, planes = O.decode_coefficients(streams[i])
+        for c in range(3):
+            assert np.array_equal(shard.coefficients[k][c], planes[c]), (i, c)
+    shard.close()
+    print("RANK", rank, "frames", r["frames"], "ok", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_config4_driver_two_ranks_gloo(tmp_path):
+    """The batch driver of BASELINE config 4 (libjpeg_amd/batch.run_sharded: frames r, r+N, ..., barriers around the timed
+    region, SUM of the pixels, MAX of the time) on two gloo ranks with the host entropy decoder as the per-rank work; every
+    frame's coefficients equal the oracle's."""
+    script = tmp_path / "batch_worker.py"
+    script.write_text(BATCH_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", MIJPEG_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "frames [0, 2, 4, 6, 8, 10] ok" in outs[0] and "frames [1, 3, 5, 7, 9, 11] ok" in outs[1]
+
+
+def test_host_threads_are_divided_among_the_ranks():
+    from libjpeg_amd import batch
+
+    cores = os.cpu_count() or 1
+    assert batch.host_threads(1) == min(64, cores)
+    assert batch.host_threads(8) == max(1, min(64, cores // 8))
+    assert batch.host_threads(8) * 8 <= max(cores, 8)
