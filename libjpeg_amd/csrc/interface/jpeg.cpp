@@ -28,6 +28,51 @@ struct JPEG::Impl {
   std::vector<uint8_t> stream; // the codestream, pulled through the I/O hook
   mijpeg_info info;
   bool loaded = false;
+  // incremental reading (JPGTAG_DECODER_STOP) and the marker calls: the position the reference's IOStream would stand at
+  // while the headers are walked marker by marker, and the byte ranges the client took out of the stream itself
+  enum Phase { P_NONE, P_SOI, P_TABLES, P_FRAME, P_PRESCAN_INIT, P_PRESCAN, P_DECODE, P_DONE } phase = P_NONE;
+  bool pulled = false;
+  size_t cursor = 0;
+  std::vector<std::pair<size_t, size_t>> taken; // [from, to) ranges removed by ReadMarker / SkipMarker, ascending
+  std::vector<uint8_t> effective;               // the stream without them (only built when something was taken)
+  long peekword() const { return cursor + 2 > stream.size() ? -1L : ((long)stream[cursor] << 8) | stream[cursor + 1]; }
+  void take(size_t n)
+  {
+    if (n == 0) return;
+    if (!taken.empty() && taken.back().second == cursor) taken.back().second = cursor + n;
+    else taken.push_back(std::make_pair(cursor, cursor + n));
+    cursor += n;
+  }
+  // Positions only, no validation (the full parse of the final Read validates): where Tables::ParseTablesIncremental
+  // (codestream/tables.cpp:1003-1418) stands after one call.  false: the marker here does not belong to the tables /
+  // miscellaneous section (frame header, scan header, EOI, DHP) or the data ran out.
+  bool tables_step()
+  {
+    const long m = peekword();
+    if (m < 0) return false;
+    switch (m) {
+    case 0xffc0: case 0xffc1: case 0xffc2: case 0xffc3: case 0xffc5: case 0xffc6: case 0xffc7: case 0xffc9: case 0xffca: case 0xffcb:
+    case 0xffcd: case 0xffce: case 0xffcf: case 0xffb1: case 0xffb2: case 0xffb3: case 0xffb9: case 0xffba: case 0xffbb:
+    case 0xffd9: case 0xffda: case 0xffde: case 0xfff7:
+      return false;
+    case 0xffff: cursor += 1; return true;                // a fill byte in front of a marker
+    case 0xffd0: case 0xffd1: case 0xffd2: case 0xffd3: case 0xffd4: case 0xffd5: case 0xffd6: case 0xffd7:
+      cursor += 2; return true;                           // stray restart marker: warned about and ignored
+    default: break;
+    }
+    if (m >= 0xffc0 && m < 0xfff0) { // length-prefixed segment (tables, APPn, COM, EXP, ...): LSE (fff8) is an error anyway
+      if (cursor + 4 > stream.size()) { cursor = stream.size(); return true; }
+      const size_t len = ((size_t)stream[cursor + 2] << 8) | stream[cursor + 3];
+      cursor = cursor + 2 + len > stream.size() ? stream.size() : cursor + 2 + (len < 2 ? 2 : len);
+      return true;
+    }
+    // "found invalid marker": advance to the next 0xff by hand (tables.cpp:1399-1413)
+    cursor += 1;
+    while (cursor < stream.size()) {
+      if (stream[cursor++] == 0xff) { cursor--; return true; }
+    }
+    return false;
+  }
   // encoder direction: the picture as ProvideImage collects it, and its parameters
   std::vector<uint8_t> picture;
   int enc_width = 0, enc_height = 0, enc_depth = 0, enc_quality = 75, enc_restart = 0, enc_lines = 0;
@@ -87,11 +132,11 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
   Impl *p = m_pImpl;
   p->err = 0;
   if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::Read requires a tag list with an I/O hook");
-  if (tags->GetTagData(JPGTAG_DECODER_STOP, 0))
-    return p->fail(JPGERR_NOT_IMPLEMENTED, "incremental reading (JPGTAG_DECODER_STOP) is not available on the accelerated path");
-  struct JPG_Hook *io = (struct JPG_Hook *)tags->GetTagPtr(JPGTAG_HOOK_IOHOOK);
-  if (!io) return p->fail(JPGERR_MISSING_PARAMETER, "no I/O hook (JPGTAG_HOOK_IOHOOK) specified");
-  if (!p->loaded) {
+  const JPG_LONG stopflags = tags->GetTagData(JPGTAG_DECODER_STOP, 0);
+  if (p->loaded || p->phase == Impl::P_DONE) return JPG_TRUE; // "if (!m_bDecoding) return" (interface/jpeg.cpp:262-263)
+  if (!p->pulled) {
+    struct JPG_Hook *io = (struct JPG_Hook *)tags->GetTagPtr(JPGTAG_HOOK_IOHOOK);
+    if (!io) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no IOHook defined to read the data from");
     // pull the whole codestream: the entropy decoder works on an in-memory stream.  As io/iostream.cpp:173-197:
     // only a return of 0 is the end of the file (short reads from pipes and sockets are normal), the hook may
     // hand back a buffer of its own and a changed user data word, both are re-fetched after every call.
@@ -131,19 +176,88 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
     }
     p->stream.resize(have);
     if (p->stream.empty()) return p->fail(JPGERR_STREAM_EMPTY, "the I/O hook delivered no data");
-    int rc = mijpeg_set_input(p->dec, p->stream.data(), p->stream.size());
-    if (rc) return p->fail_from_decoder(rc);
-    const int threads = tags->GetTagData(JPGTAG_MIJPEG_THREADS, getenv("MIJPEG_THREADS") ? atoi(getenv("MIJPEG_THREADS")) : 0);
-    // streams with enough restart intervals are entropy-decoded on the device (JPGTAG_MIJPEG_ENTROPY /
-    // MIJPEG_ENTROPY: 0 = automatic, 1 = always on the host)
-    const int entropy = tags->GetTagData(JPGTAG_MIJPEG_ENTROPY, getenv("MIJPEG_ENTROPY") ? atoi(getenv("MIJPEG_ENTROPY")) : 0);
-    rc = entropy == 1 ? MIJPEG_ERR_NOT_AVAILABLE : mijpeg_decode_coefficients_device(p->dec, 0);
-    if (rc == MIJPEG_ERR_NOT_AVAILABLE) rc = mijpeg_decode_coefficients(p->dec, threads);
-    if (rc) return p->fail_from_decoder(rc);
-    mijpeg_get_info(p->dec, &p->info);
-    p->loaded = true;
+    p->pulled = true;
+    p->phase = Impl::P_SOI;
+    p->cursor = 0;
   }
-  return JPG_TRUE;
+  // The header walk of JPEG::ReadInternal (interface/jpeg.cpp:276-318) over the in-memory stream, one marker segment per
+  // step, returning where the stop flags ask for it.  Without stop flags it falls straight through to the decode.
+  for (;;) {
+    switch (p->phase) {
+    case Impl::P_SOI: // Decoder::ParseHeaderIncremental, first call (codestream/decoder.cpp:94-104)
+      if (p->peekword() != 0xffd8) {
+        p->phase = Impl::P_DONE;
+        return p->fail(JPGERR_MALFORMED_STREAM, "stream does not contain a JPEG file, SOI marker missing");
+      }
+      p->cursor = 2;
+      p->phase = Impl::P_TABLES;
+      if (stopflags & JPGFLAG_DECODER_STOP_IMAGE) return JPG_TRUE;
+      break;
+    case Impl::P_TABLES: // ... later calls: one marker of the tables / misc section each
+      if (p->tables_step()) {
+        if (stopflags & JPGFLAG_DECODER_STOP_IMAGE) return JPG_TRUE;
+      } else {
+        p->phase = Impl::P_FRAME;
+        if (stopflags & JPGFLAG_DECODER_STOP_IMAGE) return JPG_TRUE;
+      }
+      break;
+    case Impl::P_FRAME: { // Image::StartParseFrame -> ParseFrameHeader (codestream/image.cpp:616-683): the frame header
+      const long m = p->peekword();
+      if (m >= 0 && m != 0xffd9 && p->cursor + 4 <= p->stream.size()) {
+        const size_t len = ((size_t)p->stream[p->cursor + 2] << 8) | p->stream[p->cursor + 3];
+        p->cursor = p->cursor + 2 + len > p->stream.size() ? p->stream.size() : p->cursor + 2 + (len < 2 ? 2 : len);
+        p->phase = Impl::P_PRESCAN_INIT;
+        if (stopflags & JPGFLAG_DECODER_STOP_FRAME) return JPG_TRUE;
+      } else {
+        p->phase = Impl::P_DECODE; // EOF / EOI here: the full parse reports it
+      }
+      break;
+    }
+    case Impl::P_PRESCAN_INIT: // Frame::StartParseScan (marker/frame.cpp:821-831): its first call only arms the table parser
+      p->phase = Impl::P_PRESCAN;
+      if (stopflags & JPGFLAG_DECODER_STOP_FRAME) return JPG_TRUE;
+      break;
+    case Impl::P_PRESCAN: // ... the later ones take the tables between the frame header and the scan, one per call
+      if (p->tables_step()) {
+        if (stopflags & JPGFLAG_DECODER_STOP_FRAME) return JPG_TRUE;
+      } else {
+        p->phase = Impl::P_DECODE;
+      }
+      break;
+    case Impl::P_DECODE: {
+      // From the first scan header on everything happens in this call: the stop flags for scans, rows and MCUs have
+      // nothing finer to stop at (the scans are decoded in parallel, not MCU by MCU); INTEGRATION.md says so.
+      const uint8_t *data = p->stream.data();
+      size_t size = p->stream.size();
+      if (!p->taken.empty()) { // what the client consumed through ReadMarker / SkipMarker never reaches the parser
+        p->effective.clear();
+        size_t at = 0;
+        for (const auto &r : p->taken) {
+          p->effective.insert(p->effective.end(), p->stream.begin() + (ptrdiff_t)at, p->stream.begin() + (ptrdiff_t)r.first);
+          at = r.second;
+        }
+        p->effective.insert(p->effective.end(), p->stream.begin() + (ptrdiff_t)at, p->stream.end());
+        data = p->effective.data();
+        size = p->effective.size();
+      }
+      p->phase = Impl::P_DONE;
+      int rc = mijpeg_set_input(p->dec, data, size);
+      if (rc) return p->fail_from_decoder(rc);
+      const int threads = tags->GetTagData(JPGTAG_MIJPEG_THREADS, getenv("MIJPEG_THREADS") ? atoi(getenv("MIJPEG_THREADS")) : 0);
+      // streams with enough restart intervals are entropy-decoded on the device (JPGTAG_MIJPEG_ENTROPY /
+      // MIJPEG_ENTROPY: 0 = automatic, 1 = always on the host)
+      const int entropy = tags->GetTagData(JPGTAG_MIJPEG_ENTROPY, getenv("MIJPEG_ENTROPY") ? atoi(getenv("MIJPEG_ENTROPY")) : 0);
+      rc = entropy == 1 ? MIJPEG_ERR_NOT_AVAILABLE : mijpeg_decode_coefficients_device(p->dec, 0);
+      if (rc == MIJPEG_ERR_NOT_AVAILABLE) rc = mijpeg_decode_coefficients(p->dec, threads);
+      if (rc) return p->fail_from_decoder(rc);
+      mijpeg_get_info(p->dec, &p->info);
+      p->loaded = true;
+      p->cursor = p->stream.size(); // the reference stands behind the EOI now
+      return JPG_TRUE;
+    }
+    default: return JPG_TRUE;
+    }
+  }
 }
 
 JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
@@ -422,7 +536,46 @@ JPG_LONG JPEG::Write(struct JPG_TagItem *tags)
   mijpeg_free(stream);
   return JPG_TRUE;
 }
-JPG_LONG JPEG::PeekMarker(struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }
-JPG_LONG JPEG::ReadMarker(void *, JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }
-JPG_LONG JPEG::SkipMarker(JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "marker access requires incremental reading"); return -1; }
+
+// interface/jpeg.cpp:505-575: the 16 bits at the position reading stopped at, 0 for the markers that can only be handled by
+// the library (frame and scan headers, EOI, DHP), -1 at the end of the data or when no decoding is in progress.
+JPG_LONG JPEG::PeekMarker(struct JPG_TagItem *)
+{
+  Impl *p = m_pImpl;
+  if (!p->pulled) { p->fail(JPGERR_OBJECT_DOESNT_EXIST, "decoding not in progress"); return -1; }
+  const long m = p->peekword();
+  switch (m) {
+  case 0xffc0: case 0xffc1: case 0xffc2: case 0xffc3: case 0xffc5: case 0xffc6: case 0xffc7: case 0xffc8: case 0xffc9: case 0xffca:
+  case 0xffcb: case 0xffcd: case 0xffce: case 0xffcf: case 0xffb1: case 0xffb2: case 0xffb3: case 0xffb9: case 0xffba: case 0xffbb:
+  case 0xffd9: case 0xffda: case 0xffde: case 0xfff7:
+    return 0;
+  default: return (JPG_LONG)m;
+  }
+}
+
+// interface/jpeg.cpp:577-611: the client takes bytes out of the stream itself; the library never sees them.
+JPG_LONG JPEG::ReadMarker(void *buffer, JPG_LONG bufsize, struct JPG_TagItem *)
+{
+  Impl *p = m_pImpl;
+  if (!p->pulled) { p->fail(JPGERR_OBJECT_DOESNT_EXIST, "decoding not in progress"); return -1; }
+  if (p->phase == Impl::P_DONE || bufsize < 0 || !buffer) return bufsize == 0 ? 0 : -1;
+  const size_t left = p->stream.size() - p->cursor;
+  const size_t n = (size_t)bufsize < left ? (size_t)bufsize : left;
+  memcpy(buffer, p->stream.data() + p->cursor, n);
+  p->take(n);
+  return (JPG_LONG)n;
+}
+
+// interface/jpeg.cpp:613-645
+JPG_LONG JPEG::SkipMarker(JPG_LONG bytes, struct JPG_TagItem *)
+{
+  Impl *p = m_pImpl;
+  if (!p->pulled) { p->fail(JPGERR_OBJECT_DOESNT_EXIST, "decoding not in progress"); return -1; }
+  if (p->phase == Impl::P_DONE) return 0;
+  if (bytes > 0) {
+    const size_t left = p->stream.size() - p->cursor;
+    p->take((size_t)bytes < left ? (size_t)bytes : left);
+  }
+  return 0;
+}
 JPG_LONG JPEG::WriteMarker(void *, JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "the encoder is not part of the accelerated path"); return -1; }

@@ -622,6 +622,33 @@ def test_the_references_own_client_runs_on_this_library(tmp_path, name):
         assert hashlib.sha256(data[len(header):]).hexdigest() == ent["pixels_sha256"]
 
 
+@pytest.mark.parametrize("name", ["ref_75x45_420_dri2", "pil_200x120_420_dri8", "pilprog_75x45_420", "pil_70x40_gray"])
+def test_the_references_marker_injection_client_runs_on_this_library(tmp_path, name):
+    """oracle/_ref/jpeg_dropin_inject = the same unchanged cmd/reconstruct.cpp compiled with -DTEST_MARKER_INJECTION
+    (cmd/reconstruct.cpp:80-119): JPEG::Read with JPGTAG_DECODER_STOP = STOP_FRAME, PeekMarker after every step, APP9 segments
+    taken out with ReadMarker + SkipMarker, then the remaining Read.  APP9 segments are injected behind every header segment;
+    the picture must be the reference's picture of the clean stream."""
+    import os
+    import subprocess
+
+    from conftest import GOLDEN_DIR, ROOT
+    from test_marker_calls import inject
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "jpeg_dropin_inject")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/jpeg_dropin_inject is built from the reference sources (make -C oracle dropin)")
+    ent = MANIFEST[name]
+    src = tmp_path / "in.jpg"
+    src.write_bytes(inject(golden_jpeg(name), 0))
+    out = tmp_path / "out.pnm"
+    r = subprocess.run([exe, str(src), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+    data = out.read_bytes()
+    header = b"P%d\n%d %d\n255\n" % (6 if ent["channels"] == 3 else 5, ent["width"], ent["height"])
+    assert data.startswith(header)
+    assert hashlib.sha256(data[len(header):]).hexdigest() == ent["pixels_sha256"]
+
+
 @pytest.mark.parametrize("entropy", ["0", "1"])
 def test_cli_4k_with_restart_markers_device_and_host_entropy(tmp_path, oracle, entropy):
     """A 4K frame with 16 200 restart intervals goes through the on-device entropy decoder inside JPEG::Read

@@ -1,0 +1,116 @@
+"""JPEG::Read with JPGTAG_DECODER_STOP and PeekMarker / ReadMarker / SkipMarker (interface/jpeg.cpp:244-354, 505-645) of the
+source-compatible class JPEG: tests/cxx/marker_calls.cpp -- the protocol of the reference's own marker injection test,
+cmd/reconstruct.cpp:80-119 -- is compiled against libjpeg_amd's interface headers and run host-only (MIJPEG_DEVICE=-1).
+Where the reference's objects are present (oracle/_ref/obj, build container) the SAME source is also linked against the
+real reference library and the traces are compared line by line."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN_DIR, MANIFEST, ROOT
+
+SRC = os.path.join(ROOT, "tests", "cxx", "marker_calls.cpp")
+CASES = ["pil_200x120_420_dri8", "ref_75x45_420_dri2", "pil_70x40_gray", "pilprog_75x45_420", "refprog_64x64_444_dri5", "xt_64x48_444",
+         "p12_64x48_444", "ref_97x61_3x3"]
+
+
+def inject(data: bytes, extra: int, where: str = "all") -> bytes:
+    """An APP9 segment behind the marker segments in front of the first SOS -- where = "pre": those in front of the frame
+    header (what a client sees with STOP_IMAGE), "post": the frame header and those behind it (STOP_FRAME), "all" -- each
+    followed by `extra` raw bytes (an EOI and half a DHT header among them) that only a client which removes them keeps
+    away from the parser."""
+    out = bytearray(data[:2])
+    p, k = 2, 0
+    seen_frame = False
+    while data[p + 1] != 0xDA:
+        m = data[p + 1]
+        ln = (data[p + 2] << 8) | data[p + 3]
+        out += data[p:p + 2 + ln]
+        p += 2 + ln
+        seen_frame = seen_frame or (0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC))
+        nxt = data[p + 1]
+        next_is_frame = 0xC0 <= nxt <= 0xCF and nxt not in (0xC4, 0xC8, 0xCC)
+        if where == "all" or (where == "post" and seen_frame) or (where == "pre" and not seen_frame and not next_is_frame):
+            out += b"\xff\xe9\x00\x06" + bytes([k, k + 1, 0xFF, 0xD9]) + (b"\xff\xd9\xff\xc4\x00" + bytes(range(16)))[:extra]
+            k += 1
+    return bytes(out + data[p:])
+
+
+@pytest.fixture(scope="module")
+def clients(tmp_path_factory):
+    d = tmp_path_factory.mktemp("marker_calls")
+    ours = str(d / "ours")
+    subprocess.run(["g++", "-O1", "-w", "-I", os.path.join(ROOT, "libjpeg_amd", "csrc"), SRC, "-o", ours, "-L", os.path.join(ROOT, "libjpeg_amd"),
+                    "-lmijpeg", "-Wl,-rpath," + os.path.join(ROOT, "libjpeg_amd")], check=True)
+    ref = None
+    objs = [o for o in glob.glob(os.path.join(ROOT, "oracle", "_ref", "obj", "**", "*.o"), recursive=True) if os.sep + "cmd" + os.sep not in o]
+    refsrc = os.environ.get("LIBJPEG_REFERENCE", "/root/reference")
+    if objs and os.path.isdir(refsrc):
+        ref = str(d / "ref")
+        subprocess.run(["g++", "-O1", "-w", "-DUSE_AUTOCONF", "-fno-exceptions", "-I", refsrc, "-I", os.path.join(ROOT, "oracle", "_ref", "gen"), SRC,
+                        *objs, "-o", ref, "-lm"], check=True)
+    return ours, ref
+
+
+def run(exe, path, mode, extra=0):
+    r = subprocess.run([exe, path, mode, str(extra)], capture_output=True, text=True, timeout=60, env=dict(os.environ, MIJPEG_DEVICE="-1"))
+    return r.returncode, r.stdout.strip().splitlines()
+
+
+def same_trace(a, b):
+    """Line by line; the very last peek of the stop loop may read 0 (a scan header) on one side and -1 (end of data) on the
+    other for multi-scan streams -- this library decodes all scans in the call that meets the first scan header, the
+    reference returns between scans; both values end the client's loop."""
+    if len(a) != len(b):
+        return False
+    for x, y in zip(a, b):
+        if x != y and not ({x, y} == {"peek 0", "peek ffffffff"}):
+            return False
+    return True
+
+
+@pytest.mark.parametrize("mode", ["image", "frame"])
+@pytest.mark.parametrize("name", CASES)
+def test_stop_flags_and_marker_calls(clients, tmp_path, name, mode):
+    ours, ref = clients
+    ent = MANIFEST[name]
+    src = os.path.join(GOLDEN_DIR, name + ".jpg")
+    rc, lines = run(ours, src, mode)
+    assert rc == 0 and f"info {ent['width']} {ent['height']} {ent['channels']}" in lines, lines
+    assert lines[0].startswith("peek ff") and lines[-1] == "peek-after -1"
+    with open(src, "rb") as f:
+        data = f.read()
+    # STOP_IMAGE stops at the segments in front of the frame header, STOP_FRAME at those behind it; the others are parsed by
+    # the library itself, which skips a well-formed APP9 and trips over the garbage
+    visible = "pre" if mode == "image" else "post"
+    for extra, where in ((0, "all"), (9, visible), (9, "all")):
+        inj = tmp_path / f"inj{extra}{where}.jpg"
+        inj.write_bytes(inject(data, extra, where))
+        rc, got = run(ours, str(inj), mode, extra)
+        if extra == 0 or where == visible:
+            assert rc == 0 and any(l.startswith("took") for l in got) and f"info {ent['width']} {ent['height']} {ent['channels']}" in got, got
+        else:
+            assert rc == 1 and any(l.startswith("error -10") for l in got), got
+        if ref:
+            rrc, exp = run(ref, str(inj), mode, extra)
+            assert rrc == rc and same_trace(got, exp), (got, exp)
+    if ref:
+        rrc, exp = run(ref, src, mode)
+        assert rrc == 0 and same_trace(lines, exp), (lines, exp)
+
+
+def test_consumed_bytes_never_reach_the_parser(clients, tmp_path):
+    """With STOP_IMAGE the client removes 'APP9 + 9 garbage bytes' (an EOI among them) behind every header segment: the
+    decode must be that of the clean stream; without the client's help the same bytes end the parse."""
+    ours, _ = clients
+    name = "pil_200x120_420_dri8"
+    with open(os.path.join(GOLDEN_DIR, name + ".jpg"), "rb") as f:
+        data = f.read()
+    inj = tmp_path / "inj.jpg"
+    inj.write_bytes(inject(data, 9, "pre"))
+    rc, lines = run(ours, str(inj), "image", 9)
+    assert rc == 0 and "info 200 120 3" in lines
+    rc, lines = run(ours, str(inj), "image", 0)  # the client takes the APP9 segments only: the garbage stays
+    assert rc == 1, lines
