@@ -253,7 +253,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
     streams = batch.make_streams(mine, cfg, workers=max(1, min(64, (os.cpu_count() or 1) // (2 * world))))
     gen_s = time.perf_counter() - t
     best = None
-    for chunk, depth in ((32, 2), (16, 3)):
+    for chunk, depth in ((16, 4), (32, 3)):
         r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=1, chunk=chunk, depth=depth)
         r["shard"].close()
         r.pop("shard")
@@ -275,8 +275,10 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
            "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(),
            "stream_bytes_total": int(sum(len(v) for v in streams.values())) if world == 1 else None,
            "generation_s": round(gen_s, 1),
-           "note": "per rank: parallel header parse + restart marker search (host pool = cores / ranks) -> H2D of the compressed bytes -> "
-                   "huffman_scan_kernel -> fused kernel, pixels stay in HBM; RCCL barriers around the timed region only; max over ranks"}
+           "note": "per rank: `decoder_objects` decoder objects driven round-robin by one thread, `chunk_frames` frames each: parallel header parse + "
+                   "restart marker search + gather into pinned memory (host pool = cores / ranks) while the previous chunks' H2D of the compressed "
+                   "bytes, huffman_scan_kernel and fused kernel run on their streams; pixels stay in HBM; RCCL barriers around the timed "
+                   "region only; max over ranks"}
     if with_cpu and rank == 0 and world == 1:
         try:
             some = [streams[i] for i in mine[:min(len(mine), os.cpu_count() or 1)]]

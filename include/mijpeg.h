@@ -151,6 +151,16 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals);
  * (dst_device, device bitmaps, pixels to encode) must not have work pending on other streams when the call is made, and
  * is complete when a call returns with sync != 0. */
 int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals);
+/* The same in two halves, for pipelines that keep several decoder objects in flight from one thread: submit parses the headers,
+ * gathers the streams into pinned memory and ENQUEUES upload and Huffman kernel on the object's stream, then returns (the stream
+ * bytes are only read during the call); finish waits for them and evaluates what the kernel reported (errors, range check).
+ * mijpeg_reconstruct_batch_device and mijpeg_get_info finish a submitted batch themselves.  While one object's batch is on the
+ * device the host prepares the next one with another object: see libjpeg_amd/batch.py (BASELINE config 4).  Batches of streams
+ * without restart markers are decoded completely by submit (their device walk needs the host between its rounds). */
+int mijpeg_submit_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals);
+int mijpeg_finish_batch_device(mijpeg_decoder *d);
+/* Wait for everything the object has enqueued on its stream (e.g. a reconstruction launched with sync = 0). */
+int mijpeg_synchronize(mijpeg_decoder *d);
 int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags,
                                     int sync);
 

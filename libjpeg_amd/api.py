@@ -109,6 +109,8 @@ def lib():
         L.mijpeg_decode_coefficients.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_decode_coefficients_device.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]
+        L.mijpeg_submit_batch_device.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]
+        L.mijpeg_finish_batch_device.argtypes = [C.c_void_p]
         L.mijpeg_reconstruct_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_int]
         L.mijpeg_device_walk_rounds.argtypes = [C.c_void_p]
         L.mijpeg_device_walk_rounds.restype = C.c_int
@@ -298,8 +300,29 @@ class Decoder:
         self.batch_frames = n
         return info
 
-    def reconstruct_batch_device(self, dst_ptr: int, frame_stride: int, row_stride: int, flags: int = 0, sync: bool = True):
-        _foreign_work_done()
+    def submit_batch_device(self, streams, min_intervals: int = 0) -> None:
+        """mijpeg_submit_batch_device: parse, gather, enqueue upload + Huffman kernel; returns without waiting for the device."""
+        n = len(streams)
+        self._batch = list(streams)
+        arr = (C.c_char_p * n)(*self._batch)
+        sizes = (C.c_size_t * n)(*[len(s) for s in self._batch])
+        self._check(lib().mijpeg_submit_batch_device(self._h, arr, sizes, n, min_intervals))
+        self.batch_frames = n
+
+    def finish_batch_device(self) -> MijpegInfo:
+        """mijpeg_finish_batch_device: wait for a submitted batch, raise what its decode reported."""
+        self._check(lib().mijpeg_finish_batch_device(self._h))
+        info = MijpegInfo()
+        self._check(lib().mijpeg_get_info(self._h, C.byref(info)))
+        self.info = info
+        return info
+
+    def reconstruct_batch_device(self, dst_ptr: int, frame_stride: int, row_stride: int, flags: int = 0, sync: bool = True,
+                                 wait_foreign: bool = True):
+        """wait_foreign=False: the caller vouches that nothing is pending on other streams for the destination (pipelines that
+        must not stall the device between their stages)."""
+        if wait_foreign:
+            _foreign_work_done()
         self._check(lib().mijpeg_reconstruct_batch_device(self._h, dst_ptr, frame_stride, row_stride, flags, 1 if sync else 0))
 
     def reconstruct_unsampled(self, comp: int, flags: int = 0) -> np.ndarray:
@@ -339,6 +362,13 @@ class Decoder:
     def reconstruct_device(self, dst_ptr: int, row_stride: int, flags: int = 0, sync: bool = True):
         _foreign_work_done()
         self._check(lib().mijpeg_reconstruct_device(self._h, dst_ptr, row_stride, flags, 1 if sync else 0))
+
+    def synchronize(self):
+        """Wait for everything this object has enqueued on its stream (mijpeg_finish_batch_device is the batch flavour;
+        a reconstruction launched with sync=False is waited for by the next synchronous call on the object: this one)."""
+        L = lib()
+        L.mijpeg_synchronize.argtypes = [C.c_void_p]
+        self._check(L.mijpeg_synchronize(self._h))
 
     def timing(self):
         t = (C.c_double * 4)()

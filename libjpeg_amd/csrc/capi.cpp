@@ -71,6 +71,10 @@ struct mijpeg_decoder {
   std::vector<std::unique_ptr<HostDecoder>> batch_hosts;
   mijpeg_info batch_info{};
   int batch_frames = 0;
+  // a submitted batch whose device work has not been waited for yet (mijpeg_submit_batch_device)
+  int pend_n = 0;
+  const uint32_t *pend_status = nullptr;
+  std::chrono::steady_clock::time_point pend_t0;
   // batches whose images bring different quantisation tables: [frames][4][64] deltas per component, on the device
   uint16_t *batch_quant_dev = nullptr;
   size_t batch_quant_cap = 0;
@@ -268,6 +272,10 @@ int mijpeg_device_walk_rounds(mijpeg_decoder *d) { return d ? d->walk_rounds : 0
 int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info)
 {
   if (!d || !info) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->batch_frames < 0) { // a submitted batch: the range check is known once its Huffman kernel is through
+    const int rc = mijpeg_finish_batch_device(d);
+    if (rc) return rc;
+  }
   if (d->batch_frames > 0) { // frame shape of the batch, range check of its most demanding image
     *info = d->batch_info;
     return MIJPEG_OK;
@@ -500,10 +508,28 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
   return MIJPEG_OK;
 }
 
+// What the Huffman kernel left in the status words of n images: errors, and per image the range check that selects the
+// arithmetic flavour of the reconstruction (fast_arith / range_max).
+static int evaluate_entropy_status(mijpeg_decoder *d, HostDecoder *const *hosts, int n, const uint32_t *status_host)
+{
+  for (int i = 0; i < n; i++) {
+    const uint32_t *st = status_host + 8 * i;
+    if (st[0] == HUFF_ERR_OVERFLOW) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
+    if (st[0]) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "entropy coded data is malformed (Huffman decoder out of sync)");
+    mijpeg_info &f = hosts[i]->info;
+    f.fast_arith = 1;
+    for (int c = 0; c < f.components; c++) {
+      f.range_max[c] = (int32_t)std::min<uint32_t>(st[1 + c], 0x7fffffffu);
+      if (f.range_max[c] >= 16384) f.fast_arith = 0;
+    }
+  }
+  return MIJPEG_OK;
+}
+
 // Entropy-decode n parsed images of identical frame geometry on the device, image i into coef_dev + i * frame_stride.
 // infos[i] receives fast_arith / range_max.  Returns MIJPEG_OK, MIJPEG_ERR_NOT_AVAILABLE (nothing touched) or an error.
 static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, const uint8_t *const *datas, const size_t *sizes, int n,
-                                int min_intervals, int16_t *coef_dev, int64_t frame_stride, bool xt_part = false)
+                                int min_intervals, int16_t *coef_dev, int64_t frame_stride, bool xt_part = false, bool defer = false)
 {
   const mijpeg_info &f0 = hosts[0]->info;
   const Scan &s0 = hosts[0]->scans[0];
@@ -636,8 +662,20 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     }
     HuffDevTable *tabs = (HuffDevTable *)(hp + off_tab + (size_t)i * table_blob);
     HuffDevAux *aux = (HuffDevAux *)(tabs + ntab);
+    // images that bring the tables of the image in front of them (every frame of a camera or an encoder run does) share its
+    // blob: nothing to build, and the workgroups of both read the same lines
+    bool same_tables = i > 0;
+    if (same_tables) {
+      const mijpeg_info &fp = hosts[i - 1]->info;
+      const Scan &sp = hosts[i - 1]->scans[0];
+      for (int k = 0; k < s.ncomp && same_tables; k++) {
+        const int c = s.sc[k].comp;
+        same_tables = s.dc[k].same_code(sp.dc[k]) && s.ac[k].same_code(sp.ac[k]) &&
+                      !memcmp(f.quant[f.quant_index[c]], fp.quant[fp.quant_index[c]], sizeof(f.quant[0]));
+      }
+    }
     memset(aux, 0, sizeof(*aux));
-    for (int k = 0; k < s.ncomp; k++) {
+    for (int k = 0; k < s.ncomp && !same_tables; k++) {
       const HuffTable *src[2] = {&s.dc[k], &s.ac[k]};
       for (int t = 0; t < 2; t++) {
         HuffDevTable &dst = tabs[2 * k + t];
@@ -667,7 +705,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     im.total_mcus = s.mcus_x * s.mcus_y;
     im.mcus_x = s.mcus_x;
     im.coef_base = (int64_t)i * frame_stride;
-    im.table_off = (uint32_t)((size_t)i * table_blob);
+    im.table_off = same_tables ? images[i - 1].table_off : (uint32_t)((size_t)i * table_blob);
     im.status_off = (uint32_t)(i * 8);
     for (int64_t k = 0; k < nint; k += per_group) {
       groups[g].image = (uint32_t)i;
@@ -707,7 +745,8 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
   if (needs_clear) HIP_TRY(d, hipMemsetAsync(coef_dev, 0, (size_t)n * (size_t)frame_stride * sizeof(int16_t), d->stream));
   const int repeat = getenv("MIJPEG_HUFF_REPEAT") ? atoi(getenv("MIJPEG_HUFF_REPEAT")) : 1; // experiments: steady-state kernel time
-  const bool small = n == 1 || stream_bytes < ((size_t)8 << 20);
+  // (a deferred batch always goes through the pinned gathering area: the caller's bytes are only read during the call)
+  const bool small = !defer && (n == 1 || stream_bytes < ((size_t)8 << 20));
   if (small) {
     for (int i = 0; i < n; i++)
       HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
@@ -729,7 +768,13 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
       d->stage_cap = stream_bytes;
     }
     if (!d->copy_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
-    const int groups_of = std::max(4, (n + 7) / 8); // at least four images per launch keep the waves full
+    // Images per upload + launch.  A launch is latency-bound (the serial symbol chain of its longest restart interval,
+    // ~0.3 ms) until it holds several waves per SIMD: ~128 K restart intervals; more, smaller launches only pay when the
+    // batch is so large that the upload of one part hides behind the decode of another (profiles/r02/batch4k_*.txt:
+    // 32 x 4K frames in one launch 0.80 ms, in eight launches of four 8 x 0.39 ms).
+    const int64_t per_image = std::max<int64_t>(1, total_intervals / n);
+    int groups_of = (int)std::max<int64_t>(std::max(4, (n + 7) / 8), (131072 + per_image - 1) / per_image);
+    if (const char *e = getenv("MIJPEG_BATCH_GROUP")) groups_of = std::max(1, atoi(e)); // tuning
     const int ngroups = (n + groups_of - 1) / groups_of;
     while ((int)d->copy_events.size() < ngroups) {
       hipEvent_t e;
@@ -779,26 +824,22 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   HIP_TRY(d, hipMemcpyAsync(status_host, d->ent_dev + off_status, status_bytes, hipMemcpyDeviceToHost, d->stream));
   uint32_t *walk_status_host = (uint32_t *)d->walk_host; // the walk's staging buffer is free again
   if (any_dwalk) HIP_TRY(d, hipMemcpyAsync(walk_status_host, d->walk_status_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
+  d->phase_prepare = std::chrono::duration<double>(tb1 - tb0).count(); // interval tables, Huffman tables
+  if (defer && !any_dwalk) { // mijpeg_submit_batch_device: the caller waits later (finish_entropy_batch)
+    d->pend_n = n;
+    d->pend_status = status_host;
+    d->pend_t0 = tb1;
+    d->phase_device = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb1).count(); // so far: gathering + enqueueing
+    return MIJPEG_OK;
+  }
   HIP_TRY(d, hipStreamSynchronize(d->stream));
   if (any_dwalk)
     for (int i = 0; i < n; i++) {
       if (walk_status_host[i] & 2) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
       if (walk_status_host[i]) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "speculative decoding settled on something that is not a decode of the image");
     }
-  d->phase_prepare = std::chrono::duration<double>(tb1 - tb0).count();                              // interval tables, Huffman tables
   d->phase_device = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb1).count();  // upload + kernel + status
-  for (int i = 0; i < n; i++) {
-    const uint32_t *st = status_host + 8 * i;
-    if (st[0] == HUFF_ERR_OVERFLOW) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
-    if (st[0]) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "entropy coded data is malformed (Huffman decoder out of sync)");
-    mijpeg_info &f = hosts[i]->info;
-    f.fast_arith = 1;
-    for (int c = 0; c < f.components; c++) {
-      f.range_max[c] = (int32_t)std::min<uint32_t>(st[1 + c], 0x7fffffffu);
-      if (f.range_max[c] >= 16384) f.fast_arith = 0;
-    }
-  }
-  return MIJPEG_OK;
+  return evaluate_entropy_status(d, hosts, n, status_host);
 }
 
 int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
@@ -866,13 +907,20 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
 // ------------------------------------------------------------------------------------------------
 // batches: n streams of one geometry -> n coefficient stores -> n frames, two kernel launches in all
 // ------------------------------------------------------------------------------------------------
-int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)
+// Aggregation over the images of a decoded batch: what one reconstruction launch for all of them needs to know.
+static int finish_batch(mijpeg_decoder *d);
+
+static int submit_batch(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals, bool defer)
 {
   if (!d || !streams || !sizes || n < 1) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "decoder was created without a device");
   HIP_TRY(d, hipSetDevice(d->device));
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
+  if (d->pend_n) { // a submitted batch nobody waited for: its staging buffers are about to be reused
+    d->pend_n = 0;
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+  }
   d->batch_frames = 0;
   d->batch_hosts.resize((size_t)n);
   for (auto &h : d->batch_hosts)
@@ -903,12 +951,37 @@ int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams,
   d->img_valid = false;
   d->uploaded = false;
   d->decoded = false;
-  rc = device_entropy_batch(d, hosts.data(), streams, sizes, n, min_intervals, d->coef_dev, f0.coef_count);
+  d->pend_n = 0;
+  rc = device_entropy_batch(d, hosts.data(), streams, sizes, n, min_intervals, d->coef_dev, f0.coef_count, false, defer);
   d->timing[0] = std::chrono::duration<double>(clk::now() - t0).count();
   d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count();
   d->timing[2] = d->phase_prepare;
   d->timing[3] = d->phase_device;
-  if (rc) return rc;
+  if (rc) { d->pend_n = 0; return rc; }
+  d->batch_own_tables = own_tables;
+  d->batch_frames = -n; // decoded (or on its way) but not aggregated yet
+  if (d->pend_n) return MIJPEG_OK; // deferred: finish_batch() waits
+  return finish_batch(d);
+}
+
+static int finish_batch(mijpeg_decoder *d)
+{
+  const int n = d->batch_frames < 0 ? -d->batch_frames : 0;
+  if (n == 0) return d->batch_frames > 0 ? MIJPEG_OK : set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no batch has been submitted");
+  d->batch_frames = 0;
+  std::vector<HostDecoder *> hosts((size_t)n);
+  for (int i = 0; i < n; i++) hosts[(size_t)i] = d->batch_hosts[(size_t)i].get();
+  if (d->pend_n) { // wait for the upload and the Huffman kernel of the submitted batch, then look at what it reported
+    const int pn = d->pend_n;
+    d->pend_n = 0;
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    d->phase_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - d->pend_t0).count();
+    const int rc = evaluate_entropy_status(d, hosts.data(), pn, d->pend_status);
+    if (rc) return rc;
+  }
+  const mijpeg_info &f0 = hosts[0]->info;
+  const bool own_tables = d->batch_own_tables;
+  int rc = MIJPEG_OK;
   d->batch_info = f0;
   d->batch_own_tables = own_tables;
   if (own_tables) {
@@ -944,11 +1017,41 @@ int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams,
   return MIJPEG_OK;
 }
 
+int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)
+{
+  return submit_batch(d, streams, sizes, n, min_intervals, false);
+}
+
+int mijpeg_submit_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)
+{
+  return submit_batch(d, streams, sizes, n, min_intervals, true);
+}
+
+int mijpeg_synchronize(mijpeg_decoder *d)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0 || !d->stream) return MIJPEG_OK;
+  HIP_TRY(d, hipSetDevice(d->device));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  return MIJPEG_OK;
+}
+
+int mijpeg_finish_batch_device(mijpeg_decoder *d)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
+  return finish_batch(d);
+}
+
 int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags, int sync)
 {
   if (!d || !dst_device) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
+  if (d->batch_frames < 0) { // submitted with mijpeg_submit_batch_device: wait for it now
+    const int rc = finish_batch(d);
+    if (rc) return rc;
+  }
   if (d->batch_frames < 1) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded batch: call mijpeg_decode_batch_device first");
-  HIP_TRY(d, hipSetDevice(d->device));
   mijpeg_batch b;
   memset(&b, 0, sizeof(b));
   b.info = d->batch_info;

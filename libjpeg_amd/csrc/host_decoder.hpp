@@ -18,6 +18,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <atomic>
 #include <functional>
@@ -40,6 +41,7 @@ struct HuffTable {
   int32_t maxcode[18]; // maxcode[l] for codes of length l (left-aligned compare uses plain codes)
   int32_t valoff[17];  // values index = code + valoff[l]
   bool build(); // false: the code lengths over-subscribe the code space
+  bool same_code(const HuffTable &o) const { return !memcmp(counts, o.counts, sizeof(counts)) && !memcmp(values, o.values, sizeof(values)); }
 };
 
 struct ScanComponent {
