@@ -88,10 +88,12 @@ typedef struct mijpeg_info {
 
 /* JPEG XT (ISO/IEC 18477-7) profile C parameters of the loaded stream, valid when info.xt != 0:
  * what ColorTransformerFactory::InstallIntegerParameters (colortrafo/colortransformerfactory.cpp:300-594)
- * installs into YCbCrTrafo<UWORD,3,Residual|Extended|ClampFlag|Float,...>.  Supported subset: explicit (TONE box)
- * or identity L tables, identity Q and R2 tables, standard YCbCr / identity L and R transformations, identity C
- * transformation, residual codestream = Huffman sequential 12 bit, hidden refinement scans (-R / -rR of the reference
- * encoder: FINE / RFIN boxes, up to four bits each). */
+ * installs into YCbCrTrafo<UWORD,3,Residual|Extended|ClampFlag|Float,...>.  Supported: explicit (TONE box), parametric
+ * (CURV box) or identity L tables, parametric or identity Q and R2 tables, standard or free-form (MTRX box) L, R and C
+ * transformations, residual codestream = Huffman sequential / progressive 8..12 bit with the fixpoint DCT or the DCT
+ * bypass, hidden refinement scans (-R / -rR of the reference encoder: FINE / RFIN boxes, up to four bits each).
+ * Not supported (JPGERR_NOT_IMPLEMENTED): lossless coding (part 8: integer DCT, RCT, residual scan types), profiles A / B
+ * (float tables, pre/post scaling), alpha channels. */
 typedef struct mijpeg_xt_params {
   mijpeg_info residual;      /* residual codestream: geometry and quantiser tables; its coef_offset[] are offsets
                                 into the SAME per-frame coefficient buffer, behind the legacy planes            */
@@ -106,6 +108,19 @@ typedef struct mijpeg_xt_params {
   int32_t out_max;           /* 2^(8 + extra range bits) - 1 = 65535                                            */
   int32_t out_shift;         /* (out_max + 1) / 2                                                               */
   int32_t is_float, clamp;   /* output conversion box: cast to float, clamping                                  */
+  /* Beyond what the reference's encoder writes by default (all of it decodes like the reference, bit for bit):
+   * free-form L / R / C transformations (MTRX boxes, the encoder's -xyz / -cxyz), parametric curves (CURV boxes) as L, Q
+   * or R2 tables, a residual DCT bypass (RDCT box).  `general` != 0 when any of these is in use: the reconstruction
+   * then runs the unfused kernels with the literal 64-bit merge and table gathers. */
+  int32_t general;
+  int32_t lmat[9], rmat[9], cmat[9]; /* 13 fractional bits (ColorTrafo::FIX_BITS); the standard matrices when not free-form */
+  int32_t rdct_bypass;       /* RDCT box: no residual DCT, samples = coefficient * (delta[63] << 4) + 2^(Pr-1)
+                                (control/residualblockhelper.cpp:203-231) */
+  int32_t noise_shaping;     /* ... with the 2x2 averaging of that function                                         */
+  int32_t qtable_entries;    /* 2^(residual precision + hidden bits + 4)                                             */
+  const int32_t *qtable[3];  /* HOST memory, owned by the decoder object: Q table per component, qtable_entries each;
+                                NULL = the identity (a shift)                                                        */
+  const int32_t *r2table[3]; /* HOST memory: R2 table per component, 2^20 entries; NULL = the identity (x + 8) >> 4  */
 } mijpeg_xt_params;
 
 /* ---- decoder object (one image at a time; one object = one host thread at a time) ---------- */
@@ -208,6 +223,11 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
 
 /* Error of the last failing call on this object (JPEG::LastError). Returns the code, 0 if none. */
 int mijpeg_last_error(mijpeg_decoder *d, const char **message);
+
+/* JPEG::LastWarning (interface/jpeg.cpp:970-979): 0, or the code of what the reference warns about at the loaded stream --
+ * MIJPEG_ERR_PHASE_ERROR: the LCHK checksum box of a JPEG XT file does not fit its legacy codestream (interface/jpeg.cpp:222-238;
+ * computed when first asked for), MIJPEG_ERR_MALFORMED_STREAM: a damaged codestream that was decoded with resynchronisation. */
+int mijpeg_last_warning(mijpeg_decoder *d, const char **message);
 
 /* Diagnostics: number of scans without restart markers that the host decoder decoded in parallel (self-synchronising
  * speculative decoding) since the library was loaded; *pieces (may be NULL) = ranges they were stitched from. */

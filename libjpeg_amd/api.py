@@ -45,6 +45,9 @@ class MijpegXtParams(C.Structure):
         ("residual", MijpegInfo), ("ltable", (C.c_int32 * 4096) * 3), ("ltable_entries", C.c_int32), ("hidden_bits", C.c_int32),
         ("residual_hidden_bits", C.c_int32), ("residual_wide", C.c_int32), ("ltrafo_ycbcr", C.c_int32), ("rtrafo_ycbcr", C.c_int32),
         ("out_max", C.c_int32), ("out_shift", C.c_int32), ("is_float", C.c_int32), ("clamp", C.c_int32),
+        ("general", C.c_int32), ("lmat", C.c_int32 * 9), ("rmat", C.c_int32 * 9), ("cmat", C.c_int32 * 9),
+        ("rdct_bypass", C.c_int32), ("noise_shaping", C.c_int32), ("qtable_entries", C.c_int32),
+        ("qtable", C.c_void_p * 3), ("r2table", C.c_void_p * 3),
     ]
 
 
@@ -362,6 +365,14 @@ class Decoder:
     def reconstruct_device(self, dst_ptr: int, row_stride: int, flags: int = 0, sync: bool = True):
         _foreign_work_done()
         self._check(lib().mijpeg_reconstruct_device(self._h, dst_ptr, row_stride, flags, 1 if sync else 0))
+
+    def last_warning(self):
+        """JPEG::LastWarning: (code, message) -- (0, None) when the reference would not warn."""
+        L = lib()
+        L.mijpeg_last_warning.argtypes = [C.c_void_p, C.POINTER(C.c_char_p)]
+        msg = C.c_char_p()
+        code = L.mijpeg_last_warning(self._h, C.byref(msg))
+        return code, (msg.value.decode() if msg.value else None)
 
     def synchronize(self):
         """Wait for everything this object has enqueued on its stream (mijpeg_finish_batch_device is the batch flavour;

@@ -1086,6 +1086,13 @@ int mijpeg_last_error(mijpeg_decoder *d, const char **message)
   return d->err_code;
 }
 
+int mijpeg_last_warning(mijpeg_decoder *d, const char **message)
+{
+  if (message) *message = nullptr;
+  if (!d || !d->data) return 0;
+  return d->host.last_warning(message);
+}
+
 int mijpeg_last_timing(mijpeg_decoder *d, double out_seconds[4])
 {
   if (!d || !out_seconds) return MIJPEG_ERR_INVALID_PARAMETER;
@@ -1190,6 +1197,7 @@ static bool use_fusedxt(const mijpeg_batch *b)
   if (off) return false;
   const mijpeg_xt_params &x = *b->xt;
   const mijpeg_info &r = x.residual;
+  if (x.general) return false; // free-form matrices, table gathers, DCT bypass: xt_merge_general_kernel
   if (x.hidden_bits || x.residual_hidden_bits || x.residual_wide || x.ltable_entries != 256 || !x.ltrafo_ycbcr || r.precision != 12 || r.components != 3 ||
       x.out_max != 65535 || x.out_shift != 32768)
     return false;
@@ -1242,6 +1250,18 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
 
 static const size_t LUT_BYTES = 3 * 4096 * sizeof(int32_t);
 
+// JPEG XT with real Q / R2 tables (mijpeg_xt_params.general): they travel in the workspace behind everything else
+static size_t xt_table_bytes(const mijpeg_batch *b)
+{
+  if (!b->info.xt || !b->xt || !b->xt->general) return 0;
+  size_t n = 0;
+  for (int c = 0; c < 3; c++) {
+    if (b->xt->qtable[c]) n += (size_t)b->xt->qtable_entries * sizeof(int32_t);
+    if (b->xt->r2table[c]) n += ((size_t)1 << 20) * sizeof(int32_t);
+  }
+  return n;
+}
+
 // per-frame tables (quant_dev) are expanded to the transforms' operands (deltas << 4, int32) in the workspace
 static size_t expanded_tables_bytes(const mijpeg_batch *b) { return b->quant_dev ? (size_t)b->frames * 4 * 64 * sizeof(int32_t) : 0; }
 
@@ -1252,7 +1272,7 @@ size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
   if (use_fusedxt(b)) return LUT_BYTES;
   // [LUT_BYTES: L lookup tables (JPEG XT, up to 3 x 4096 entries)] [per frame: int32 sample planes, one sample per
   // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients] [expanded per-frame tables]
-  return LUT_BYTES + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames + expanded_tables_bytes(b);
+  return LUT_BYTES + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames + expanded_tables_bytes(b) + xt_table_bytes(b);
 }
 
 int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
@@ -1271,7 +1291,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   if (b->quant_dev) {
     const size_t need = mijpeg_workspace_bytes(b);
     if (!b->workspace || b->workspace_bytes < need) return MIJPEG_ERR_MISSING_PARAMETER;
-    int32_t *dst = (int32_t *)((char *)b->workspace + (need - expanded_tables_bytes(b)));
+    int32_t *dst = (int32_t *)((char *)b->workspace + (need - expanded_tables_bytes(b) - xt_table_bytes(b)));
     if (launch_expand_deltas(b->quant_dev, dst, b->frames, s)) return MIJPEG_ERR_DEVICE;
     qdev = dst;
   }
@@ -1387,6 +1407,33 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
         if (hipMemcpyAsync((int32_t *)b->workspace + (size_t)c * x.ltable_entries, x.ltable[c], (size_t)x.ltable_entries * sizeof(int32_t),
                            hipMemcpyHostToDevice, s) != hipSuccess)
           return MIJPEG_ERR_DEVICE;
+      if (x.general) {
+        if (x.qtable_entries != (1 << (rprec + 4))) return MIJPEG_ERR_INVALID_PARAMETER;
+        a.xt_general = 1;
+        a.rbypass = x.rdct_bypass;
+        a.rnoise = x.noise_shaping;
+        a.rdcshift = (1 << rprec) >> 1;
+        memcpy(a.lmat, x.lmat, sizeof(a.lmat));
+        memcpy(a.rmat, x.rmat, sizeof(a.rmat));
+        memcpy(a.cmat, x.cmat, sizeof(a.cmat));
+        char *tp = (char *)b->workspace + (mijpeg_workspace_bytes(b) - xt_table_bytes(b));
+        for (int c = 0; c < 3; c++) {
+          // only the highest-frequency delta is used, with the colour bits folded in (residualblockhelper.cpp:351-364)
+          a.rquant63[c] = (int32_t)x.residual.quant[x.residual.quant_index[c]][63] << 4;
+          if (x.qtable[c]) {
+            const size_t n = (size_t)x.qtable_entries * sizeof(int32_t);
+            if (hipMemcpyAsync(tp, x.qtable[c], n, hipMemcpyHostToDevice, s) != hipSuccess) return MIJPEG_ERR_DEVICE;
+            a.qlut[c] = (const int32_t *)tp;
+            tp += n;
+          }
+          if (x.r2table[c]) {
+            const size_t n = ((size_t)1 << 20) * sizeof(int32_t);
+            if (hipMemcpyAsync(tp, x.r2table[c], n, hipMemcpyHostToDevice, s) != hipSuccess) return MIJPEG_ERR_DEVICE;
+            a.r2lut[c] = (const int32_t *)tp;
+            tp += n;
+          }
+        }
+      }
     }
     rc = launch_generic(a, fast, s);
   }

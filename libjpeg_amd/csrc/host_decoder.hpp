@@ -108,6 +108,10 @@ public:
   bool needs_sequential() const { return needs_sequential_; }
   // conditions the reference only warns about that the last parse / decode passed (stray markers, resynchronisation ...)
   int warnings() const { return warnings_; }
+  // JPEG::LastWarning: 0, or the code of what the reference warns about at this stream (message in *msg): the LCHK checksum of
+  // a JPEG XT file that does not fit its legacy codestream (interface/jpeg.cpp:222-238), or a damaged codestream the decoder
+  // resynchronised in.  The checksum is computed when this is first asked for.
+  int last_warning(const char **msg);
 
   // Walk scan `scan` (Huffman sequential, no restart markers needed) speculatively in parallel and return its virtual
   // restart intervals; nonzero if the scan does not lend itself to it (the caller then decodes on the host).
@@ -146,6 +150,9 @@ private:
   bool needs_sequential_ = false;
   bool parsed_ = false;
   int warnings_ = 0;
+  bool have_lchk_ = false;
+  uint32_t lchk_value_ = 0;
+  int checksum_state_ = -1; // -1: not computed yet, 0: fits, 1: mismatch
   void reset_stream_state();
   void publish_tables(bool header_only);
   template <class T> int decode_sequential(T *coef, int threads);
@@ -163,6 +170,7 @@ private:
   std::vector<std::vector<size_t>> scan_interval_end_;
   std::vector<std::vector<uint8_t>> scan_rst_code_;
   std::vector<XtBox> boxes_;
+  std::vector<int32_t> xt_q_[3], xt_r2_[3]; // Q / R2 tables of a JPEG XT stream when they are not the identities (xt.qtable / r2table point here)
   HostDecoder *residual_ = nullptr;
   bool nested_ = false; // this object decodes a residual codestream
   int hidden_ = 0;      // JPEG XT: low bits of every coefficient that arrive in hidden refinement scans

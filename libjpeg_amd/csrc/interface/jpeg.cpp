@@ -411,8 +411,10 @@ JPG_LONG JPEG::LastError(const char *&error)
 
 JPG_LONG JPEG::LastWarning(const char *&warning)
 {
-  warning = nullptr;
-  return 0;
+  const char *m = nullptr;
+  const int code = m_pImpl->loaded ? mijpeg_last_warning(m_pImpl->dec, &m) : 0;
+  warning = m;
+  return code;
 }
 
 JPG_LONG JPEG::ProvideImage(struct JPG_TagItem *tags)

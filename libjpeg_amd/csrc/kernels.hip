@@ -2105,6 +2105,123 @@ __global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
 }
 
 // ==============================================================================================
+// JPEG XT beyond the encoder's default subset: free-form L / R / C transformations (MTRX boxes), Q and R2 tables that are
+// real tables (parametric curves), residual planes that bypassed the DCT.  The literal chain of YCbCrTrafo::YCbCr2RGB
+// (colortrafo/ycbcrtrafo.cpp:750-955) in 64-bit sums, table gathers from HBM (up to 2^20 entries each: not LDS material).
+// ==============================================================================================
+template <int LAYOUT, int RLAYOUT>
+__global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs a)
+{
+  const int groups = (a.width + 7) >> 3;
+  const int gxi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Y = blockIdx.y;
+  const int frame = blockIdx.z;
+  if (gxi >= groups) return;
+  const int X0 = gxi * 8;
+  int s[3][8], rs[3][8];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    upsample_plane_line<LAYOUT>(a, c, c, frame, X0, Y, s[c]);
+    upsample_plane_line<RLAYOUT>(a, 3 + c, c, frame, X0, Y, rs[c]);
+  }
+  uint16_t *dst = reinterpret_cast<uint16_t *>(a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride) + (int64_t)X0 * 3;
+  const int npx = min(8, a.width - X0);
+  const int rmax16 = ((1 << a.rprecision) << 4) - 1; // ((m_lRMax + 1) << COLOR_BITS) - 1
+  const int omax16 = ((a.out_max + 1) << 4) - 1;
+  const int qshift = 16 - a.rprecision;
+  const int pinf = (a.out_max >> 1) - (a.out_max >> 6) - 1;
+  const int minf = -pinf - 1;
+  for (int x = 0; x < npx; x++) {
+    // residual chain: Q table, R transformation (FIX_COLOR_TO_INTCOLOR), R2 table
+    long long q3[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int idx = min(max(rs[c][x], 0), rmax16);
+      q3[c] = a.qlut[c] ? (long long)a.qlut[c][idx] : (long long)idx << qshift;
+    }
+    long long rr[3];
+    if (a.rtrafo_ycbcr) {
+      const long long ry = q3[0], rcb = q3[1] - ((long long)a.out_shift << 4), rcr = q3[2] - ((long long)a.out_shift << 4);
+#pragma unroll
+      for (int c = 0; c < 3; c++) rr[c] = (ry * a.rmat[3 * c] + rcb * a.rmat[3 * c + 1] + rcr * a.rmat[3 * c + 2] + 4096) >> 13;
+    } else {
+      rr[0] = q3[0]; rr[1] = q3[1]; rr[2] = q3[2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int idx = (int)min(max(rr[c], 0ll), (long long)omax16);
+      rr[c] = a.r2lut[c] ? (long long)a.r2lut[c][idx] : (long long)((idx + 8) >> 4);
+    }
+    // legacy chain: L transformation (FIX_COLOR_TO_INT), L table, C transformation (FIX_TO_INT)
+    long long v[3];
+    if (a.ycbcr) {
+      const long long yy = s[0][x], cb = (long long)s[1][x] - a.dcshift, cr = (long long)s[2][x] - a.dcshift;
+#pragma unroll
+      for (int c = 0; c < 3; c++) v[c] = (yy * a.lmat[3 * c] + cb * a.lmat[3 * c + 1] + cr * a.lmat[3 * c + 2] + 65536) >> 17;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++) v[c] = ((long long)s[c][x] + 8) >> 4;
+    }
+    long long lv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) lv[c] = a.ltable[c * a.ltable_entries + (int)min(max(v[c], 0ll), (long long)a.maxval)];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      long long m = ((lv[0] * a.cmat[3 * c] + lv[1] * a.cmat[3 * c + 1] + lv[2] * a.cmat[3 * c + 2] + 4096) >> 13) + rr[c] - a.out_shift;
+      if (a.is_float) {
+        m = min(max(m, (long long)minf), (long long)pinf);
+        const short w = (short)m;
+        dst[3 * x + c] = (uint16_t)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS
+      } else {
+        dst[3 * x + c] = (uint16_t)min(max(m, 0ll), (long long)a.out_max);
+      }
+    }
+  }
+}
+
+// Residual planes whose DCT was bypassed (RDCT box): ResidualBlockHelper::DequantizeResidual without a transform,
+// control/residualblockhelper.cpp:203-231 -- sample = coefficient * (delta[63] << 4) + 2^(Pr-1), optionally the 2 x 2 noise
+// shaping average.  One thread per block; planes 3..5 of the sample workspace (they overwrite what idct_planes_kernel put there).
+__global__ __launch_bounds__(256) void bypass_planes_kernel(const GenericArgs a)
+{
+  const int c = blockIdx.y % 3, frame = blockIdx.y / 3, p = 3 + c;
+  const int nblocks = a.bw[p] * a.bh[p];
+  const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk >= nblocks) return;
+  const bool wide = p >= a.wide_first && p < a.wide_first + a.wide_count; // int32 coefficients (two int16 slots each)
+  const int16_t *plane = a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[p];
+  int res[64];
+  if (wide) {
+    const int *src = reinterpret_cast<const int *>(plane) + (int64_t)blk * 64;
+#pragma unroll
+    for (int i = 0; i < 64; i++) res[i] = src[i];
+  } else {
+    const int16_t *src = plane + (int64_t)blk * 64;
+#pragma unroll
+    for (int i = 0; i < 64; i++) res[i] = src[i];
+  }
+  const int quant = a.rquant63[c], dcs = a.rdcshift;
+  const int by = blk / a.bw[p], bx = blk - by * a.bw[p];
+  const int pitch = a.bw[p] * 8;
+  int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[p] + ((int64_t)by * 8) * pitch + bx * 8;
+  for (int y = 0; y < 64; y += 16)
+    for (int x = 0; x < 8; x += 2) {
+      int avg = 0;
+      if (a.rnoise)
+        for (int dy = 0; dy < 16; dy += 8)
+          for (int dx = 0; dx < 2; dx++) avg += res[x + dx + y + dy] * quant;
+      avg = (avg + 2) >> 2;
+      for (int dy = 0; dy < 16; dy += 8)
+        for (int dx = 0; dx < 2; dx++) {
+          const int i = x + dx + y + dy;
+          int v = res[i] * quant;
+          if (a.rnoise && v > avg - quant && v < avg + quant) v = avg;
+          dst[(int64_t)(i >> 3) * pitch + (i & 7)] = v + dcs;
+        }
+    }
+}
+
+// ==============================================================================================
 // launchers
 // ==============================================================================================
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
@@ -2213,7 +2330,16 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   };
   const int lay = layout_of(0, a.ncomp);
 #define LAUNCH_COLOR(F, L) hipLaunchKernelGGL((upsample_color_kernel<F, L>), g2, dim3(bs), 0, stream, a)
-#define LAUNCH_XT(L, R) hipLaunchKernelGGL((xt_merge_kernel<L, R>), g2, dim3(bs), 0, stream, a)
+#define LAUNCH_XT(L, R)                                                                       \
+  do {                                                                                         \
+    if (a.xt_general) hipLaunchKernelGGL((xt_merge_general_kernel<L, R>), g2, dim3(bs), 0, stream, a); \
+    else hipLaunchKernelGGL((xt_merge_kernel<L, R>), g2, dim3(bs), 0, stream, a);              \
+  } while (0)
+  if (a.xt && a.rbypass) {
+    int rb = 0;
+    for (int c = 3; c < 6; c++) rb = max(rb, a.bw[c] * a.bh[c]);
+    hipLaunchKernelGGL(bypass_planes_kernel, dim3((rb + 255) / 256, 3 * a.frames), dim3(256), 0, stream, a);
+  }
   if (a.xt) {
     const int rlay = layout_of(3, 3);
     if (rlay == layout_id(1, 1) && lay == layout_id(2, 2)) LAUNCH_XT(layout_id(2, 2), layout_id(1, 1));

@@ -70,6 +70,14 @@ struct GenericArgs {
                                   // int16 units) and are transformed by idct_planes_wide_kernel (IDCT<4,QUAD>)
   const int32_t *ltable;       // device: L lookup tables [3][ltable_entries]
   const int32_t *qdev;         // or null: per-frame tables in device memory, [frames][4][64] deltas << 4 (replace q; not for JPEG XT)
+  // JPEG XT beyond the default subset (mijpeg_xt_params.general): literal 64-bit merge with matrices and table gathers
+  int32_t xt_general;
+  int32_t rbypass, rnoise;     // RDCT box: residual planes are dequantised without a DCT (bypass_planes_kernel)
+  int32_t rquant63[3];         // ... with delta[63] << 4 of the residual component
+  int32_t rdcshift;            // ... and the level shift 2^(Pr-1), NOT scaled (control/residualblockhelper.cpp:196, 225)
+  int32_t lmat[9], rmat[9], cmat[9];
+  const int32_t *qlut[3];      // device, 2^(Pr + 4) entries each, or null = identity
+  const int32_t *r2lut[3];     // device, 2^20 entries each, or null = identity
 };
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);

@@ -1530,10 +1530,35 @@ typedef struct {
   const oj_info *rinfo;             /* residual frame geometry */
   int32_t *const *rplanes;          /* residual coefficient planes */
   const int32_t *ltable[3];         /* L lookup tables (2^8 entries) or NULL = none (identity) */
-  int ltrafo_ycbcr, rtrafo_ycbcr;   /* 1: YCbCr matrix, 0: identity */
+  int ltrafo_ycbcr, rtrafo_ycbcr;   /* 1: matrix branch (standard YCbCr or free-form, lmat / rmat), 0: identity branch */
+  int64_t lmat[9], rmat[9], cmat[9]; /* L, R and C transformations, 13 fractional bits (DefineLTransformation etc.) */
+  const int32_t *qlut[3];           /* Q tables, 2^(Pr + 4) entries, NULL = the identity (a shift) */
+  const int32_t *r2lut[3];          /* R2 tables, 2^(16 + 4) entries, NULL = the identity (x + 8) >> 4 */
+  int rbypass, rnoise;              /* RDCT box: residual DCT bypassed (control/residualblockhelper.cpp:203-231), noise shaping */
   int64_t outmax, outshift;         /* 2^(8 + extra bits) - 1 and its half */
   int is_float, clamp;              /* OCON: cast to float (half codes), clamping */
 } oj_xt;
+
+/* ResidualBlockHelper::DequantizeResidual without a DCT (control/residualblockhelper.cpp:203-231, quantiser of
+ * AllocateBuffers :351-364): one block, residual coefficients in their stored (natural) positions -> samples * 16. */
+static void xt_bypass_block(int32_t *dst, const int32_t *res, int32_t quant, int noise, int32_t dcshift)
+{
+  int x, y, dx, dy;
+  for (y = 0; y < 64; y += 16)
+    for (x = 0; x < 8; x += 2) {
+      int32_t avg = 0;
+      if (noise)
+        for (dy = 0; dy < 16; dy += 8)
+          for (dx = 0; dx < 2; dx++) avg += res[x + dx + y + dy] * quant;
+      avg = (avg + 2) >> 2;
+      for (dy = 0; dy < 16; dy += 8)
+        for (dx = 0; dx < 2; dx++) {
+          int32_t v = res[x + dx + y + dy] * quant;
+          if (noise && v > avg - quant && v < avg + quant) v = avg;
+          dst[x + dx + y + dy] = v + dcshift;
+        }
+    }
+}
 
 /* Output: pixels8 (precision 8, no XT) or pixels16 (precision 12, or XT: 16 bit codes). */
 static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint8_t *pixels8, uint16_t *pixels16,
@@ -1562,7 +1587,19 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
       if (!r->quant_defined[r->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
       rsamp[c] = (int32_t *)malloc((size_t)r->bw[c] * r->bh[c] * 64 * sizeof(int32_t));
       if (!rsamp[c]) { rc = OJ_ERR_NOMEM; goto out; }
-      oj_idct_plane(rsamp[c], xt->rplanes[c], r->bw[c], r->bh[c], r->scan_state_valid ? r->cquant[c] : r->quant[r->tq[c]], r->precision);
+      if (xt->rbypass) {
+        /* only the highest-frequency delta is used, times 2^COLOR_BITS; the level shift is NOT scaled (:196, :225) */
+        const uint16_t *rq = r->scan_state_valid ? r->cquant[c] : r->quant[r->tq[c]];
+        const int32_t quant = (int32_t)rq[63] << 4, dcs = (int32_t)(1 << r->precision) >> 1;
+        int bx, by, i;
+        for (by = 0; by < r->bh[c]; by++)
+          for (bx = 0; bx < r->bw[c]; bx++) {
+            int32_t blk[64];
+            xt_bypass_block(blk, xt->rplanes[c] + ((size_t)by * r->bw[c] + bx) * 64, quant, xt->rnoise, dcs);
+            for (i = 0; i < 64; i++) rsamp[c][((size_t)by * 8 + (i >> 3)) * ((size_t)r->bw[c] * 8) + (size_t)bx * 8 + (i & 7)] = blk[i];
+          }
+      } else
+        oj_idct_plane(rsamp[c], xt->rplanes[c], r->bw[c], r->bh[c], r->scan_state_valid ? r->cquant[c] : r->quant[r->tq[c]], r->precision);
     }
   }
   for (Y0 = 0; Y0 < f->height; Y0 += 8)
@@ -1581,37 +1618,44 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
           int k = y * 8 + x;
           int64_t v[OJ_MAX_COMP];
           if (ycc && f->ncomp == 3) {
+            const int64_t *M = xt ? xt->lmat : L;
             int64_t yy = blk[0][k], cb = (int64_t)blk[1][k] - dcshift, cr = (int64_t)blk[2][k] - dcshift;
-            v[0] = (yy * L[0] + cb * L[1] + cr * L[2] + 65536) >> 17;
-            v[1] = (yy * L[3] + cb * L[4] + cr * L[5] + 65536) >> 17;
-            v[2] = (yy * L[6] + cb * L[7] + cr * L[8] + 65536) >> 17;
+            v[0] = (yy * M[0] + cb * M[1] + cr * M[2] + 65536) >> 17;
+            v[1] = (yy * M[3] + cb * M[4] + cr * M[5] + 65536) >> 17;
+            v[2] = (yy * M[6] + cb * M[7] + cr * M[8] + 65536) >> 17;
           } else {
             for (c = 0; c < f->ncomp; c++) v[c] = ((int64_t)blk[c][k] + 8) >> 4;
           }
           if (xt) {
-            /* colortrafo/ycbcrtrafo.cpp:750-829 (residual), :861-878 (L-LUT, C = identity, merge), :897-955 (half clamp) */
+            /* colortrafo/ycbcrtrafo.cpp:750-829 (residual), :861-878 (L-LUT, C transformation, merge), :897-955 (half clamp) */
             const oj_info *r = xt->rinfo;
             const int64_t rmax16 = ((((int64_t)1 << r->precision)) << 4) - 1; /* ((m_lRMax + 1) << COLOR_BITS) - 1 */
             const int64_t omax16 = ((xt->outmax + 1) << 4) - 1;
-            int64_t rr[3];
-            /* Q tables: identity, 2^(Pr + 4) -> 2^(16 + 4): scales by 2^(16 - Pr)  (parametrictonemappingbox.cpp:387-430) */
-            int64_t ry = clampmax(rblk[0][k], rmax16) << (16 - r->precision);
-            int64_t rcb = clampmax(rblk[1][k], rmax16) << (16 - r->precision);
-            int64_t rcr = clampmax(rblk[2][k], rmax16) << (16 - r->precision);
-            if (xt->rtrafo_ycbcr) {
-              rcb -= xt->outshift << 4; rcr -= xt->outshift << 4;
-              rr[0] = (ry * L[0] + rcb * L[1] + rcr * L[2] + 4096) >> 13; /* FIX_COLOR_TO_INTCOLOR */
-              rr[1] = (ry * L[3] + rcb * L[4] + rcr * L[5] + 4096) >> 13;
-              rr[2] = (ry * L[6] + rcb * L[7] + rcr * L[8] + 4096) >> 13;
-            } else {
-              rr[0] = ry; rr[1] = rcb; rr[2] = rcr;
-            }
-            /* R2 tables: identity 2^(16 + 4) -> 2^16: floor(x / 16 + 0.5) */
-            for (c = 0; c < 3; c++) rr[c] = (clampmax(rr[c], omax16) + 8) >> 4;
+            int64_t rr[3], q3[3], lv[3];
+            /* Q tables (APPLY_LUT: index clamped to the table); the identity, 2^(Pr + 4) -> 2^(16 + 4), scales by 2^(16 - Pr)
+             * (parametrictonemappingbox.cpp:387-430) */
             for (c = 0; c < 3; c++) {
-              int64_t lv = xt->ltable[c] ? xt->ltable[c][clampmax(v[c], maxval)] : v[c];
-              v[c] = lv + rr[c] - xt->outshift; /* C transformation = identity: FIX_TO_INT(x * 8192) == x */
+              const int64_t idx = clampmax(rblk[c][k], rmax16);
+              q3[c] = xt->qlut[c] ? xt->qlut[c][idx] : idx << (16 - r->precision);
             }
+            if (xt->rtrafo_ycbcr) {
+              const int64_t *M = xt->rmat;
+              const int64_t ry = q3[0], rcb = q3[1] - (xt->outshift << 4), rcr = q3[2] - (xt->outshift << 4);
+              rr[0] = (ry * M[0] + rcb * M[1] + rcr * M[2] + 4096) >> 13; /* FIX_COLOR_TO_INTCOLOR */
+              rr[1] = (ry * M[3] + rcb * M[4] + rcr * M[5] + 4096) >> 13;
+              rr[2] = (ry * M[6] + rcb * M[7] + rcr * M[8] + 4096) >> 13;
+            } else {
+              rr[0] = q3[0]; rr[1] = q3[1]; rr[2] = q3[2];
+            }
+            /* R2 tables; the identity 2^(16 + 4) -> 2^16 is floor(x / 16 + 0.5) */
+            for (c = 0; c < 3; c++) {
+              const int64_t idx = clampmax(rr[c], omax16);
+              rr[c] = xt->r2lut[c] ? xt->r2lut[c][idx] : (idx + 8) >> 4;
+            }
+            for (c = 0; c < 3; c++) lv[c] = xt->ltable[c] ? xt->ltable[c][clampmax(v[c], maxval)] : v[c];
+            /* C transformation, FIX_TO_INT (the identity leaves the values alone: (x * 8192 + 4096) >> 13 == x) */
+            for (c = 0; c < 3; c++)
+              v[c] = ((lv[0] * xt->cmat[3 * c] + lv[1] * xt->cmat[3 * c + 1] + lv[2] * xt->cmat[3 * c + 2] + 4096) >> 13) + rr[c] - xt->outshift;
             if (xt->is_float && xt->clamp) {
               const int64_t pinf = (xt->outmax >> 1) - (xt->outmax >> 6) - 1;
               const int64_t minf = invert_negs((int16_t)(uint16_t)(pinf | 0x8000));
@@ -1677,6 +1721,118 @@ static int decode_hidden_scans(oj_parser *ps, const oj_box *boxes, int nboxes, u
   }
 }
 
+
+/* Non-linear point transformations a merging specification can name (boxes/namespace.cpp:60-91): explicit tables (TONE,
+ * boxes/inversetonemappingbox.cpp) and parametric curves (CURV, boxes/parametrictonemappingbox.cpp). */
+typedef struct {
+  int kind;          /* 0: none, 1: TONE, 2: CURV */
+  int entries, resbits;
+  int32_t *lut;      /* TONE */
+  int type, e;       /* CURV */
+  float p[4];
+} oj_nlt;
+
+/* IEEEDecode, tools/numerics.cpp:56-89 */
+static float ieee_decode(uint32_t bits)
+{
+  float f;
+  if (((bits >> 23) & 0xff) == 0xff) return (bits >> 31) ? -HUGE_VALF : HUGE_VALF;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+/* ParametricToneMappingBox::TableValue, boxes/parametrictonemappingbox.cpp:199-272.  *err: the curve is invalid (INVALID_PARAMETER).
+ * The reference is built for the x87 unit with -ffast-math (Makefile_Settings.gcc:13): sums and products of an expression stay in
+ * 80-bit registers, only the arguments and results of pow / exp / log pass through 64 bits.  long double arithmetic around
+ * double library calls reproduces that (pinned by tests/golden/xt_craft_* against the reference binary). */
+static long double curve_value(const oj_nlt *t, double v, int *err)
+{
+  const long double p1 = t->p[0], p2 = t->p[1], p3 = t->p[2], p4 = t->p[3];
+  switch (t->type) {
+  case 0: return 0.0L;
+  case 1: return 1.0L;
+  case 2: return v;
+  case 4: return v >= p1 ? (long double)pow((double)((v + p3) / (1.0L + p3)), (double)p2)
+                         : (long double)pow((double)((p1 + p3) / (1.0L + p3)), (double)p2) * v / p1;
+  case 5: if (t->p[1] >= t->p[0]) return v * (p2 - p1) + p1; *err = 1; return 0.0L;
+  case 6: if (t->p[1] > t->p[0]) return p3 * (long double)exp((double)(v * (p2 - p1) + p1)) + p4; *err = 1; return 0.0L;
+  case 7:
+    if (p1 > 0.0L) return (v > 0.0 || (p3 > 0.0L && v >= 0.0)) ? (long double)log((double)((long double)pow((double)(p1 * v), (double)p2) + p3)) + p4 : -HUGE_VALL;
+    return (v > 0.0 || (p3 > 0.0L && v >= 0.0)) ? -(long double)log((double)((long double)pow((double)(-p1 * v), (double)p2) + p3)) + p4 : HUGE_VALL;
+  case 8: return v > 0.0 ? (p2 - p1) * (long double)pow(v, (double)p3) + p1 : p1;
+  }
+  return 0.0L;
+}
+
+/* ToneMapperBox::ScaledTableOf for an integer path: -> malloc'ed table of 2^(inbits + infract) entries, *rc = reference error.
+ * TONE: inversetonemappingbox.cpp:192-212 (the table itself, if it fits); CURV: parametrictonemappingbox.cpp:387-430. */
+static int32_t *scaled_table(const oj_nlt *t, int inbits, int outbits, int infract, int outfract, int *rc)
+{
+  int32_t *tab;
+  uint32_t i, max;
+  *rc = 0;
+  if (t->kind == 1) {
+    if (outbits + outfract != 8 + t->resbits || inbits > 16 || (1u << inbits) != (uint32_t)t->entries || infract != 0) { *rc = -1024; return NULL; }
+    tab = (int32_t *)malloc((size_t)t->entries * sizeof(int32_t));
+    if (tab) memcpy(tab, t->lut, (size_t)t->entries * sizeof(int32_t));
+    return tab;
+  }
+  max = 1u << (inbits + infract);
+  tab = (int32_t *)malloc((size_t)max * sizeof(int32_t));
+  if (!tab) return NULL;
+  {
+    const double inscale = inbits > 1 ? 1.0 / (double)((((uint32_t)1 << inbits) - (uint32_t)t->e) << infract) : 1.0 / (double)(1 << infract);
+    const double outscale = outbits > 1 ? 1.0 * (double)((((uint32_t)1 << outbits) - (uint32_t)t->e) << outfract) : 1.0 * (double)(1 << outfract);
+    int err = 0;
+    for (i = 0; i < max; i++) {
+      const double w = floor((double)((long double)outscale * curve_value(t, i * inscale, &err) + 0.5L));
+      /* LONG(double): out-of-range conversions yield the x86 "integer indefinite" value */
+      tab[i] = (w >= -2147483648.0 && w < 2147483648.0) ? (int32_t)w : INT32_MIN;
+    }
+    if (err) { free(tab); *rc = -1024; return NULL; }
+  }
+  return tab;
+}
+
+/* One TONE / CURV / MTRX box into the registries (first definition of an index wins: the lists are searched front to back). */
+static int register_box(uint32_t type, const uint8_t *d, size_t len, oj_nlt *nlt, int64_t (*mtx)[9], int *have_mtx)
+{
+  if (type == BOXID('T', 'O', 'N', 'E')) {
+    /* boxes/inversetonemappingbox.cpp:72-118: index/residual-bits byte, then 2^n entries of 16 (or 32) bits */
+    int idx, n, i, wide;
+    if (len < 1 + 512 || !(len & 1)) return OJ_ERR_MALFORMED;
+    idx = d[0] >> 4; wide = (d[0] & 15) > 8;
+    n = (int)((len - 1) >> (wide ? 2 : 1));
+    if (wide && ((len - 1) & 3)) return OJ_ERR_MALFORMED;
+    if (n & (n - 1)) return OJ_ERR_MALFORMED;
+    if (nlt[idx].kind) return OJ_OK;
+    nlt[idx].kind = 1; nlt[idx].entries = n; nlt[idx].resbits = d[0] & 15;
+    nlt[idx].lut = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    if (!nlt[idx].lut) return OJ_ERR_NOMEM;
+    for (i = 0; i < n; i++) nlt[idx].lut[i] = wide ? (int32_t)(((uint32_t)rd16(d + 1 + 4 * i) << 16) | rd16(d + 3 + 4 * i)) : rd16(d + 1 + 2 * i);
+  } else if (type == BOXID('C', 'U', 'R', 'V')) {
+    /* boxes/parametrictonemappingbox.cpp:84-149 */
+    int idx, ty, i;
+    if (len != 2 + 16) return OJ_ERR_MALFORMED;
+    idx = d[0] >> 4; ty = d[0] & 15;
+    if (ty == 3 || ty > 8) return OJ_ERR_MALFORMED;
+    if ((d[1] & 15) || (d[1] >> 4) > 1) return OJ_ERR_MALFORMED;
+    if (nlt[idx].kind) return OJ_OK;
+    nlt[idx].kind = 2; nlt[idx].type = ty; nlt[idx].e = d[1] >> 4;
+    for (i = 0; i < 4; i++) nlt[idx].p[i] = ieee_decode(((uint32_t)rd16(d + 2 + 4 * i) << 16) | rd16(d + 4 + 4 * i));
+  } else if (type == BOXID('M', 'T', 'R', 'X')) {
+    /* boxes/lineartransformationbox.cpp:62-99: id (5..15) and fractional bits (13), nine 16-bit entries */
+    int id, i;
+    if (len != 1 + 18) return OJ_ERR_MALFORMED;
+    id = d[0] >> 4;
+    if (id < 5 || (d[0] & 15) != 13) return OJ_ERR_MALFORMED;
+    if (have_mtx[id]) return OJ_OK;
+    have_mtx[id] = 1;
+    for (i = 0; i < 9; i++) mtx[id][i] = (int16_t)rd16(d + 1 + 2 * i);
+  }
+  return OJ_OK;
+}
+
 int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float)
 {
   oj_box boxes[OJ_MAX_BOXES];
@@ -1684,36 +1840,29 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   oj_info rinfo;
   oj_xt xt;
   int32_t *planes[OJ_MAX_COMP] = {0, 0, 0, 0}, *rplanes[OJ_MAX_COMP] = {0, 0, 0, 0};
-  int32_t *tables[16];
-  int tabsize[16] = {0};
+  oj_nlt nlt[16];
+  int64_t mtx[16][9];
+  int have_mtx[16] = {0};
+  int32_t *owned[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; /* tables built here: L, Q, R2 per component */
   int hidden_l = 0, hidden_r = 0; /* RSPC: bits of the legacy / residual coefficients in hidden refinement scans */
-  int32_t *identity = NULL;
   const oj_box *spec = NULL, *resi = NULL;
-  int ltrafo = 255, rtrafo = 255, ctrafo = 255, lidx[4] = {255, 255, 255, 255}, have_lpts = 0;
-  int ocon = -1, b, c, rc;
+  int ltrafo = 255, rtrafo = 255, ctrafo = 255, lidx[4] = {255, 255, 255, 255}, qidx[4] = {255, 255, 255, 255}, r2idx[4] = {255, 255, 255, 255};
+  int ocon = -1, rdct = 0, b, c, rc;
   size_t j;
+  static const int64_t std_ycc[9] = {FIX13(1.0), FIX13(0.0), FIX13(1.40200), FIX13(1.0), -FIX13(0.3441362861), -FIX13(0.7141362859),
+                                     FIX13(1.0), FIX13(1.772), FIX13(0.0)};
+  static const int64_t std_id[9] = {8192, 0, 0, 0, 8192, 0, 0, 0, 8192};
   *pixels = NULL;
-  memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(tables, 0, sizeof(tables));
+  memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(nlt, 0, sizeof(nlt)); memset(&xt, 0, sizeof(xt));
   ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes; ps.walk_all = 1;
   rc = walk(&ps, NULL);
   if (rc) { free_boxes(boxes, ps.nboxes); return rc; }
   for (b = 0; b < ps.nboxes; b++) {
     if (boxes[b].type == BOXID('S', 'P', 'E', 'C')) spec = &boxes[b];
     if (boxes[b].type == BOXID('R', 'E', 'S', 'I')) resi = &boxes[b];
-    if (boxes[b].type == BOXID('T', 'O', 'N', 'E')) {
-      /* boxes/inversetonemappingbox.cpp: index/residual-bits byte, then 2^n 16-bit entries (n = 8 + hidden bits) */
-      const oj_box *t = &boxes[b];
-      int idx, n, i;
-      if (t->len < 1 + 512 || !(t->len & 1)) { rc = OJ_ERR_MALFORMED; goto out; }
-      idx = t->data[0] >> 4; n = (int)((t->len - 1) >> 1);
-      if ((t->data[0] & 15) > 8 || n < 256 || n > 4096 || (n & (n - 1))) { rc = OJ_ERR_UNSUPPORTED; goto out; }
-      tabsize[idx] = n;
-      tables[idx] = (int32_t *)malloc((size_t)n * sizeof(int32_t));
-      if (!tables[idx]) { rc = OJ_ERR_NOMEM; goto out; }
-      for (i = 0; i < n; i++) tables[idx][i] = rd16(t->data + 1 + 2 * i);
-    }
   }
   if (!spec || !resi || info->ncomp != 3 || info->precision != 8) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  /* the specification's own boxes are searched first (primary list), then the file's (boxes/namespace.cpp:60-125) */
   for (j = 0; j + 8 <= spec->len;) { /* superbox: LBox(4) TBox(4) payload (boxes/superbox.cpp) */
     uint32_t l = ((uint32_t)rd16(spec->data + j) << 16) | (uint32_t)rd16(spec->data + j + 2);
     uint32_t t = ((uint32_t)rd16(spec->data + j + 4) << 16) | (uint32_t)rd16(spec->data + j + 6);
@@ -1722,47 +1871,80 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
     if (t == BOXID('L', 'T', 'R', 'F')) ltrafo = pl[0] >> 4;
     else if (t == BOXID('R', 'T', 'R', 'F')) rtrafo = pl[0] >> 4;
     else if (t == BOXID('C', 'T', 'R', 'F')) ctrafo = pl[0] >> 4;
-    else if (t == BOXID('L', 'P', 'T', 'S')) { have_lpts = 1; lidx[0] = pl[0] >> 4; lidx[1] = pl[0] & 15; lidx[2] = pl[1] >> 4; lidx[3] = pl[1] & 15; }
+    else if (t == BOXID('L', 'P', 'T', 'S')) { lidx[0] = pl[0] >> 4; lidx[1] = pl[0] & 15; lidx[2] = pl[1] >> 4; lidx[3] = pl[1] & 15; }
+    else if (t == BOXID('Q', 'P', 'T', 'S')) { qidx[0] = pl[0] >> 4; qidx[1] = pl[0] & 15; qidx[2] = pl[1] >> 4; qidx[3] = pl[1] & 15; }
+    else if (t == BOXID('R', 'P', 'T', 'S')) { r2idx[0] = pl[0] >> 4; r2idx[1] = pl[0] & 15; r2idx[2] = pl[1] >> 4; r2idx[3] = pl[1] & 15; }
     else if (t == BOXID('O', 'C', 'O', 'N')) ocon = pl[0];
     else if (t == BOXID('R', 'S', 'P', 'C')) { /* boxes/refinementspecbox.cpp:57-83 */
       hidden_l = pl[0] >> 4; hidden_r = pl[0] & 15;
       if (hidden_l > 4 || hidden_r > 4) { rc = OJ_ERR_MALFORMED; goto out; }
     }
-    else if (t == BOXID('L', 'D', 'C', 'T') || t == BOXID('R', 'D', 'C', 'T')) { if ((pl[0] >> 4) != 0 && (pl[0] >> 4) != 2) { rc = OJ_ERR_UNSUPPORTED; goto out; } }
-    else { rc = OJ_ERR_UNSUPPORTED; goto out; } /* Q/R/R2/S tables, D/S transformations, ...: outside the subset */
+    else if (t == BOXID('L', 'D', 'C', 'T')) { if ((pl[0] >> 4) != 0 || (pl[0] & 15)) { rc = OJ_ERR_UNSUPPORTED; goto out; } } /* only the fixpoint DCT in the base */
+    else if (t == BOXID('R', 'D', 'C', 'T')) { /* boxes/dctbox.cpp:60-92: 0 = fixpoint DCT, 2 = integer DCT (outside the subset), 3 = bypass (+ noise shaping) */
+      rdct = pl[0];
+      if ((rdct >> 4) != 0 && (rdct >> 4) != 3) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+      if ((rdct & 15) > 1 || ((rdct & 15) && (rdct >> 4) != 3)) { rc = OJ_ERR_MALFORMED; goto out; }
+    }
+    else if (t == BOXID('T', 'O', 'N', 'E') || t == BOXID('C', 'U', 'R', 'V') || t == BOXID('M', 'T', 'R', 'X')) {
+      rc = register_box(t, pl, l - 8, nlt, mtx, have_mtx);
+      if (rc) goto out;
+    }
+    else { rc = OJ_ERR_UNSUPPORTED; goto out; } /* L2 / R / S / P tables, D and S transformations, float boxes: profiles A and B */
     j += l;
+  }
+  for (b = 0; b < ps.nboxes; b++) {
+    rc = register_box(boxes[b].type, boxes[b].data, boxes[b].len, nlt, mtx, have_mtx);
+    if (rc) goto out;
   }
   /* codestream/tables.cpp:1994-2031 and the R analogue: undefined -> YCbCr for three components */
   if (ltrafo == 255) ltrafo = 2;
   if (rtrafo == 255) rtrafo = 2;
-  if ((ltrafo != 1 && ltrafo != 2) || (rtrafo != 1 && rtrafo != 2) || (ctrafo != 255 && ctrafo != 1)) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  if (ltrafo == 0 || ltrafo == 3 || ltrafo == 4) { rc = OJ_ERR_MALFORMED; goto out; } /* "the base transformation ... is invalid" */
+  if (rtrafo == 3) { rc = OJ_ERR_MALFORMED; goto out; }
+  if (rtrafo == 4 || rtrafo == 0) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* RCT (lossless coding, part 8), zero */
+  if (ctrafo != 255 && ctrafo != 1 && ctrafo < 5) { rc = OJ_ERR_MALFORMED; goto out; }
+  if ((ltrafo >= 5 && !have_mtx[ltrafo]) || (rtrafo >= 5 && !have_mtx[rtrafo]) || (ctrafo != 255 && ctrafo >= 5 && !have_mtx[ctrafo])) { rc = OJ_ERR_MALFORMED; goto out; }
   if (ocon < 0 || (ocon & 0x08) || (ocon & 0x01)) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* lossless / output lookup */
-  memset(&xt, 0, sizeof(xt));
   xt.outmax = ((int64_t)1 << (8 + (ocon >> 4))) - 1;
   xt.outshift = (xt.outmax + 1) >> 1;
   xt.is_float = (ocon & 0x04) ? 1 : 0;
   xt.clamp = (ocon & 0x02) ? 1 : 0;
   if (!xt.clamp || xt.outmax != 65535) { rc = OJ_ERR_UNSUPPORTED; goto out; }
-  xt.ltrafo_ycbcr = ltrafo == 2; xt.rtrafo_ycbcr = rtrafo == 2;
-  for (c = 0; c < 3; c++) {
-    const int entries = 256 << hidden_l; /* the L table is indexed with 8 + hidden bits (codestream/tables.cpp:549) */
-    if (have_lpts) {
-      if (!tables[lidx[c]]) { rc = OJ_ERR_MALFORMED; goto out; } /* "the L lookup table specified in the codestream does not exist" */
-      if (tabsize[lidx[c]] != entries) { rc = OJ_ERR_MALFORMED; goto out; }
-      xt.ltable[c] = tables[lidx[c]];
-    } else { /* identity, e = 1: floor((2^16 - 1) * (i / (2^n - 1)) + 0.5), = 257 i for n = 8 */
-      if (!identity) {
-        int i;
-        identity = (int32_t *)malloc((size_t)entries * sizeof(int32_t));
-        if (!identity) { rc = OJ_ERR_NOMEM; goto out; }
-        for (i = 0; i < entries; i++) identity[i] = (int32_t)floor(65535.0 * ((double)i / (double)(entries - 1)) + 0.5);
-      }
-      xt.ltable[c] = identity;
-    }
-  }
-  /* the residual codestream is an ordinary codestream of its own (codestream/image.cpp:1264-1300) */
+  /* free-form matrices run through the YCbCr branches of the transformer (colortransformerfactory.cpp:1036-1058) */
+  xt.ltrafo_ycbcr = ltrafo != 1; xt.rtrafo_ycbcr = rtrafo != 1;
+  memcpy(xt.lmat, ltrafo >= 5 ? mtx[ltrafo] : ltrafo == 2 ? std_ycc : std_id, sizeof(xt.lmat));
+  memcpy(xt.rmat, rtrafo >= 5 ? mtx[rtrafo] : rtrafo == 2 ? std_ycc : std_id, sizeof(xt.rmat));
+  memcpy(xt.cmat, (ctrafo != 255 && ctrafo >= 5) ? mtx[ctrafo] : std_id, sizeof(xt.cmat));
+  xt.rbypass = (rdct >> 4) == 3; xt.rnoise = rdct & 1;
+  /* the residual codestream is needed for the table dimensions */
   rc = oj_read_info(resi->data, resi->len, &rinfo);
   if (rc) goto out;
+  for (c = 0; c < 3; c++) {
+    /* L: ScaledTableOf(8 + hidden bits, 16, 0, 0), default = identity with e = 1; Q: (Pr + hidden bits, 16, 4, 4) and
+     * R2: (16, 16, 4, 0), defaults = identities with e = 0 (colortransformerfactory.cpp:312-345, 435-474, 486-520) */
+    oj_nlt id1, id0;
+    const oj_nlt *t;
+    const int pr = rinfo.precision + hidden_r;
+    memset(&id1, 0, sizeof(id1)); id1.kind = 2; id1.type = 2; id1.e = 1;
+    memset(&id0, 0, sizeof(id0)); id0.kind = 2; id0.type = 2; id0.e = 0;
+    t = lidx[c] == 255 ? &id1 : &nlt[lidx[c]];
+    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; } /* OBJECT_DOESNT_EXIST "the L lookup table specified in the codestream does not exist" */
+    owned[c] = scaled_table(t, 8 + hidden_l, 16, 0, 0, &rc);
+    if (!owned[c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
+    xt.ltable[c] = owned[c];
+    if (pr > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+    t = qidx[c] == 255 ? &id0 : &nlt[qidx[c]];
+    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; }
+    owned[3 + c] = scaled_table(t, pr, 16, 4, 4, &rc);
+    if (!owned[3 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
+    xt.qlut[c] = owned[3 + c];
+    t = r2idx[c] == 255 ? &id0 : &nlt[r2idx[c]];
+    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; }
+    owned[6 + c] = scaled_table(t, 16, 16, 4, 0, &rc);
+    if (!owned[6 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
+    xt.r2lut[c] = owned[6 + c];
+  }
+  /* the residual codestream is an ordinary codestream of its own (codestream/image.cpp:1264-1300) */
   if (rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp) { rc = OJ_ERR_MALFORMED; goto out; }
   if (rinfo.precision + hidden_r > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   info->ycbcr = xt.ltrafo_ycbcr;
@@ -1802,8 +1984,8 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   if (is_float) *is_float = xt.is_float;
 out:
   for (c = 0; c < OJ_MAX_COMP; c++) { free(planes[c]); free(rplanes[c]); }
-  for (c = 0; c < 16; c++) free(tables[c]);
-  free(identity);
+  for (c = 0; c < 16; c++) free(nlt[c].lut);
+  for (c = 0; c < 9; c++) free(owned[c]);
   free_boxes(boxes, ps.nboxes);
   return rc;
 }

@@ -137,6 +137,21 @@ def decode_xt(data: bytes):
     return out, bool(isf.value)
 
 
+def decode_xt_status(data: bytes):
+    """-> (codes or None, is_float, ref_error): ref_error = 0, the JPGERR_* code the reference fails with where the oracle knows
+    it (merging specification errors), or None (outside the oracle's subset / other failure)."""
+    info = OjInfo()
+    px = C.c_void_p()
+    isf = C.c_int(0)
+    rc = lib().oj_decode_xt(data, len(data), C.byref(info), C.byref(px), C.byref(isf))
+    if rc:
+        return None, False, (info.ref_error if (rc != -2 and info.ref_error) else None)
+    n = info.width * info.height * 3
+    out = np.ctypeslib.as_array((C.c_uint16 * n).from_address(px.value)).reshape(info.height, info.width, 3).copy()
+    lib().oj_free(px)
+    return out, bool(isf.value), 0
+
+
 def half_codes_to_float(codes: np.ndarray) -> np.ndarray:
     """cmd/iohelpers.hpp:60-77 (HalfToDouble) for finite codes: exact, so numpy's float16 view does the same."""
     return codes.view(np.float16).astype(np.float32)
