@@ -262,3 +262,22 @@ def test_mutated_streams_never_crash():
                 outcomes["error"] += 1
     d.close()
     assert outcomes["error"] > 100 and outcomes["ok"] + outcomes["error"] == 150 * len(names)
+
+
+def test_host_decoder_under_thread_sanitizer():
+    """tools/tsan_host.sh: the restart-parallel and the speculative decode on the shared worker pool, and several decoder
+    objects decoding (also damaged) streams from different caller threads, under -fsanitize=thread: no data race, and the
+    8-thread decode equals the 1-thread decode."""
+    import os
+    import shutil
+    import subprocess
+
+    from conftest import ROOT
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "tsan_host.sh")], capture_output=True, text=True, timeout=600)
+    if "unsupported option" in r.stderr or "cannot find -ltsan" in r.stderr or "libtsan" in r.stderr and r.returncode != 0 and "WARNING" not in r.stderr:
+        pytest.skip("this toolchain has no ThreadSanitizer runtime")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "mismatched 0" in r.stdout and "ThreadSanitizer" not in r.stderr

@@ -1,0 +1,15 @@
+#!/bin/bash
+# ThreadSanitizer run of the multi-threaded host decoder (no GPU needed).  Exit code != 0 on a data race or a mismatch.
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -I"$ROOT/include" "$ROOT/tools/tsan_host.cpp" "$ROOT/libjpeg_amd/csrc/host_decoder.cpp" "$ROOT/libjpeg_amd/csrc/encoder.cpp" -o /tmp/tsan_host
+# big enough for the parallel paths: restart intervals, and a scan without restart markers for the speculative decoder
+python3 - <<PY
+import sys
+sys.path.insert(0, "$ROOT")
+from libjpeg_amd import synth
+open("/tmp/tsan_dri.jpg", "wb").write(synth.synth_jpeg(1280, 720, 3, 85, "420", 4))
+open("/tmp/tsan_nodri.jpg", "wb").write(synth.synth_jpeg(1280, 720, 4, 90, "420", 0))
+open("/tmp/tsan_prog.jpg", "wb").write(synth.synth_jpeg(640, 480, 5, 85, "420", 8, progressive=True))
+PY
+TSAN_OPTIONS="halt_on_error=1 exitcode=66" /tmp/tsan_host /tmp/tsan_dri.jpg /tmp/tsan_nodri.jpg /tmp/tsan_prog.jpg "$ROOT"/tests/golden/pil_200x120_420_dri8.jpg "$ROOT"/tests/golden/ref_75x45_420_dri2.jpg "$ROOT"/tests/golden/xt_129x71_420.jpg "$ROOT"/tests/golden/refprog_64x64_444_dri5.jpg
