@@ -16,7 +16,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmijpeg.so")
+LIB_PATH = os.environ.get("MIJPEG_LIBRARY") or os.path.join(HERE, "libmijpeg.so")  # MIJPEG_LIBRARY: another build of the same library (kernel experiments)
 
 FLAG_NO_COLOR_TRANSFORM = 1
 FLAG_FORCE_GENERIC = 2

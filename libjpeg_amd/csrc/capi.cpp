@@ -41,7 +41,11 @@ struct mijpeg_decoder {
   uint8_t *img_host = nullptr; // pinned
   size_t img_host_cap = 0;
   bool img_valid = false;      // img_dev holds the reconstructed frame for img_flags
-  bool img_host_valid = false; // ... and img_host its copy
+  bool img_host_valid = false; // ... and img_host its copy (being filled band by band, see band_events)
+  // the device-to-host copy of the reconstructed frame travels in bands of lines, one event each: a rectangle request
+  // waits for the bands it touches only, so the first stripes of a frame are served while the rest is still on its way
+  std::vector<hipEvent_t> band_events;
+  int band_lines = 0, bands = 0, bands_waited = 0;
   uint32_t img_flags = 0;
   int img_view = -1;           // component of a non-upsampled reconstruction, -1: the whole picture
   int32_t *ws_dev = nullptr;
@@ -157,6 +161,7 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->henc_host) (void)hipHostFree(d->henc_host);
     if (d->walk_host) (void)hipHostFree(d->walk_host);
     for (hipEvent_t e : d->copy_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->band_events) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
@@ -596,7 +601,38 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   }
   a.waves_per_group = a.lanes >= 32 ? 2 : 4;
   const int per_group = a.lanes * a.waves_per_group; // intervals of one workgroup
-  const int ntab = 2 * s0.ncomp;
+  // Tables in LDS: components that bring the same Huffman code (Cb and Cr practically always do) share one copy -- the
+  // workgroup's LDS footprint decides how many of them a CU holds.  The sharing pattern is that of image 0 and must hold
+  // for every image of the launch; the device walk indexes its tables by component and keeps one per component.
+  int tab_slot[MIJPEG_MAX_COMPONENTS][2];
+  int ntab = 0;
+  {
+    bool walk_any = false;
+    for (int i = 0; i < n; i++) walk_any |= dwalk[(size_t)i] > 0;
+    bool share = !walk_any && !getenv("MIJPEG_HUFF_NO_TABLE_SHARING");
+    for (int pass = 0; pass < 2; pass++) {
+      ntab = 0;
+      for (int k = 0; k < s0.ncomp; k++)
+        for (int t = 0; t < 2; t++) {
+          tab_slot[k][t] = -1;
+          for (int j = 0; j < k && share && tab_slot[k][t] < 0; j++)
+            if ((t ? s0.ac[k].same_code(s0.ac[j]) : s0.dc[k].same_code(s0.dc[j]))) tab_slot[k][t] = tab_slot[j][t];
+          if (tab_slot[k][t] < 0) tab_slot[k][t] = ntab++;
+        }
+      if (!share) break;
+      bool holds = true; // ... in every image?
+      for (int i = 1; i < n && holds; i++) {
+        const Scan &s = hosts[i]->scans[0];
+        for (int k = 0; k < s.ncomp && holds; k++)
+          for (int j = 0; j < k && holds; j++) {
+            if (tab_slot[k][0] == tab_slot[j][0] && !s.dc[k].same_code(s.dc[j])) holds = false;
+            if (tab_slot[k][1] == tab_slot[j][1] && !s.ac[k].same_code(s.ac[j])) holds = false;
+          }
+      }
+      if (holds) break;
+      share = false;
+    }
+  }
   const size_t table_blob = (size_t)ntab * sizeof(HuffDevTable) + sizeof(HuffDevAux);
 
   // device buffer: [streams, each padded][ibegin][iend][tables of every image][images][groups][status]
@@ -678,7 +714,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     for (int k = 0; k < s.ncomp && !same_tables; k++) {
       const HuffTable *src[2] = {&s.dc[k], &s.ac[k]};
       for (int t = 0; t < 2; t++) {
-        HuffDevTable &dst = tabs[2 * k + t];
+        HuffDevTable &dst = tabs[tab_slot[k][t]];
         memset(&dst, 0, sizeof(dst));
         memcpy(dst.fast, src[t]->fast, sizeof(dst.fast));
         if (t == 1) // AC: flag the symbols that only exist in progressive scans (EOB runs)
@@ -724,8 +760,8 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     a.vs[k] = s0.ncomp > 1 ? f0.vsamp[c] : 1;
     a.bw[k] = f0.blocks_w[c];
     a.coef_off[k] = f0.coef_offset[c];
-    a.dc_tab[k] = 2 * k;
-    a.ac_tab[k] = 2 * k + 1;
+    a.dc_tab[k] = tab_slot[k][0];
+    a.ac_tab[k] = tab_slot[k][1];
   }
   a.data = d->ent_dev;
   a.ibegin = (const uint32_t *)(d->ent_dev + off_ib);
@@ -2022,7 +2058,7 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
     auto t0 = clk::now();
     HIP_TRY(d, hipStreamSynchronize(d->stream)); // uploads complete
     auto t1 = clk::now();
-    rc = reconstruct_view(d, view, d->img_dev, (int64_t)row, flags, 1);
+    rc = reconstruct_view(d, view, d->img_dev, (int64_t)row, flags, to_device ? 1 : 0); // host requests: the copy below follows in stream order
     if (rc) return rc;
     d->timing[1] = std::chrono::duration<double>(t1 - t0).count();
     d->timing[2] = std::chrono::duration<double>(clk::now() - t1).count();
@@ -2041,12 +2077,30 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
       HIP_TRY(d, hipHostMalloc((void **)&d->img_host, padded, hipHostMallocDefault));
       d->img_host_cap = padded;
     }
-    auto t2 = clk::now();
-    HIP_TRY(d, hipMemcpyAsync(d->img_host, d->img_dev, padded, hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(d, hipStreamSynchronize(d->stream));
-    d->timing[3] = std::chrono::duration<double>(clk::now() - t2).count();
+    // bands of about 4 MiB (at least 8 lines): enqueue all of them now, wait for them as they are asked for
+    d->band_lines = (int)std::max<size_t>(8, (((size_t)4 << 20) / std::max<size_t>(row, 1) + 7) & ~(size_t)7);
+    d->bands = (f.height + d->band_lines - 1) / d->band_lines;
+    while ((int)d->band_events.size() < d->bands) {
+      hipEvent_t e;
+      HIP_TRY(d, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      d->band_events.push_back(e);
+    }
+    for (int b = 0; b < d->bands; b++) {
+      const size_t y0 = (size_t)b * d->band_lines, y1 = std::min<size_t>(f.height, y0 + d->band_lines);
+      HIP_TRY(d, hipMemcpyAsync(d->img_host + y0 * row, d->img_dev + y0 * row, (y1 - y0) * row, hipMemcpyDeviceToHost, d->stream));
+      HIP_TRY(d, hipEventRecord(d->band_events[(size_t)b], d->stream));
+    }
+    d->bands_waited = 0;
     d->img_host_valid = true;
   }
+  // bands [0, upto] of the host copy have arrived when this returns
+  auto wait_bands = [&](int upto) -> int {
+    auto t2 = clk::now();
+    for (; d->bands_waited <= upto && d->bands_waited < d->bands; d->bands_waited++)
+      HIP_TRY(d, hipEventSynchronize(d->band_events[(size_t)d->bands_waited]));
+    d->timing[3] += std::chrono::duration<double>(clk::now() - t2).count();
+    return MIJPEG_OK;
+  };
   if (min_x < 0) min_x = 0;
   if (min_y < 0) min_y = 0;
   if (max_x >= f.width) max_x = f.width - 1;
@@ -2090,15 +2144,23 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
         memcpy((uint8_t *)dst[0] + (ptrdiff_t)y * bytes_per_row[0] + (ptrdiff_t)min_x * nc * sb,
                d->img_host + (size_t)y * row + (size_t)min_x * nc * sb, line);
     };
-    // big rectangles (whole frames) are copied by the worker pool: one memcpy stream per worker
+    // big rectangles (whole frames) are copied by the worker pool, one memcpy stream per worker, in a few slabs: the
+    // workers copy slab k while the bands of slab k + 1 are still arriving
     const int parts = (int)std::min<size_t>((size_t)std::min(default_threads(), 16), line * lines / (4u << 20));
     if (parts > 1) {
-      parallel_for(parts, [&](int i) { copy_lines(min_y + (int)((int64_t)lines * i / parts), min_y + (int)((int64_t)lines * (i + 1) / parts)); });
+      const int slabs = std::min(4, std::max(1, lines / (8 * d->band_lines)));
+      for (int k = 0; k < slabs; k++) {
+        const int s0 = min_y + (int)((int64_t)lines * k / slabs), s1 = min_y + (int)((int64_t)lines * (k + 1) / slabs);
+        if (const int rc = wait_bands((s1 - 1) / d->band_lines)) return rc;
+        parallel_for(parts, [&](int i) { copy_lines(s0 + (int)((int64_t)(s1 - s0) * i / parts), s0 + (int)((int64_t)(s1 - s0) * (i + 1) / parts)); });
+      }
     } else {
+      if (const int rc = wait_bands(max_y / d->band_lines)) return rc;
       copy_lines(min_y, max_y + 1);
     }
     return MIJPEG_OK;
   }
+  if (const int rc = wait_bands(max_y / d->band_lines)) return rc;
   for (int c = min_comp; c <= max_comp; c++) {
     if (!dst[c]) continue;
     for (int y = min_y; y <= max_y; y++) {

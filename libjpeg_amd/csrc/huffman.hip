@@ -29,7 +29,10 @@ namespace mij {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RING = 128;             // bytes of stream staged per lane
+#ifndef MIJPEG_HUFF_RING
+#define MIJPEG_HUFF_RING 128
+#endif
+constexpr int RING = MIJPEG_HUFF_RING; // bytes of stream staged per lane (power of two, >= 64)
 constexpr int RING_PITCH = RING + 16; // + mirror of the first 16 bytes so that an 8-byte read never wraps
 constexpr int LANE_LDS = 128 + RING_PITCH + 16; // coefficient slot + ring + block index (padded: 16-byte granules)
 

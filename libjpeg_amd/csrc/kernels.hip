@@ -86,6 +86,15 @@ __device__ __forceinline__ int mad16_hi(unsigned pk, int k, int c)
   return d;
 }
 
+// d = lo(pk) * klo + hi(pk) * khi + c in ONE issue slot (v_dot2_i32_i16): the two chroma terms of the green channel when a
+// position's (Cb, Cr) travel as the halves of one register
+__device__ __forceinline__ int dot2_16(unsigned pk, int klo, int khi, int c)
+{
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 k = {(short)klo, (short)khi};
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pk), k, c, false);
+}
+
 // {lo16(hi), lo16(lo)} -> one register.  volatile: the packing must happen where it is written (right after the
 // transform), otherwise the compiler keeps all 64 unpacked samples alive and packs lazily at the use.
 __device__ __forceinline__ unsigned pack_lo16_now(int hi, int lo)
@@ -894,8 +903,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
         for (int x = 0; x < 8; x++) {
           const int yk = (yv[l * 8 + x] << 13) + K;
           rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
-          gg[x] = mad16_hi(u[x], -L_CR_G, mad16_lo(u[x], -L_CB_G, yk));
           bb[x] = mad16_lo(u[x], L_CB_B, yk);
+          gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
         }
         if (fast_store) {
           unsigned h[12];
@@ -1074,8 +1083,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
         for (int x = 0; x < 8; x++) {
           const int yk = (yv[l * 8 + x] << 13) + K;
           rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
-          gg[x] = mad16_hi(u[x], -L_CR_G, mad16_lo(u[x], -L_CB_G, yk));
           bb[x] = mad16_lo(u[x], L_CB_B, yk);
+          gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
         }
         if (fast_store) {
           unsigned h[12];
@@ -1267,8 +1276,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
         for (int x = 0; x < 8; x++) {
           const int yk = (yv[l * 8 + x] << 13) + K;
           rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
-          gg[x] = mad16_hi(u[x], -L_CR_G, mad16_lo(u[x], -L_CB_G, yk));
           bb[x] = mad16_lo(u[x], L_CB_B, yk);
+          gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
         }
         if (fast_store) {
           unsigned h[12];
