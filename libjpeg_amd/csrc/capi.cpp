@@ -2078,7 +2078,8 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
       d->img_host_cap = padded;
     }
     // bands of about 4 MiB (at least 8 lines): enqueue all of them now, wait for them as they are asked for
-    d->band_lines = (int)std::max<size_t>(8, (((size_t)4 << 20) / std::max<size_t>(row, 1) + 7) & ~(size_t)7);
+    static const long band_mib = getenv("MIJPEG_RECT_BAND_MIB") ? atol(getenv("MIJPEG_RECT_BAND_MIB")) : 4; // tuning; <= 0: one band
+    d->band_lines = band_mib <= 0 ? f.height : (int)std::max<size_t>(8, (((size_t)band_mib << 20) / std::max<size_t>(row, 1) + 7) & ~(size_t)7);
     d->bands = (f.height + d->band_lines - 1) / d->band_lines;
     while ((int)d->band_events.size() < d->bands) {
       hipEvent_t e;
