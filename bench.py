@@ -253,7 +253,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
     streams = batch.make_streams(mine, cfg, workers=max(1, min(64, (os.cpu_count() or 1) // (2 * world))))
     gen_s = time.perf_counter() - t
     best = None
-    for chunk, depth in ((16, 4), (32, 3)):
+    for chunk, depth in ((64, 2), (32, 2), (16, 4)):
         r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=1, chunk=chunk, depth=depth)
         r["shard"].close()
         r.pop("shard")
