@@ -520,7 +520,9 @@ static int evaluate_entropy_status(mijpeg_decoder *d, HostDecoder *const *hosts,
   for (int i = 0; i < n; i++) {
     const uint32_t *st = status_host + 8 * i;
     if (st[0] == HUFF_ERR_OVERFLOW) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
-    if (st[0]) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "entropy coded data is malformed (Huffman decoder out of sync)");
+    // Damaged entropy coded data: which error the reference reports (or whether it decodes on after a resynchronisation)
+    // depends on its sequential walk; the host decoder restates that walk, the device decoder does not try to
+    if (st[0]) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the entropy coded data is damaged: the host decoder walks such streams like the reference does (DESIGN 4.0)");
     mijpeg_info &f = hosts[i]->info;
     f.fast_arith = 1;
     for (int c = 0; c < f.components; c++) {

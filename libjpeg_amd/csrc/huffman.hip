@@ -222,6 +222,8 @@ __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ void dev_exact_position(const DevBits &br, uint32_t &byte, uint32_t &skip);
+
 // LDS of a workgroup: [tables | aux][per wave: lanes x 128-byte block slot | lanes x ring | lanes x block number]
 __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
 {
@@ -317,6 +319,15 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
           pend1 = br.fetch(pend_at + 16);
         }
     }
+  }
+  // Virtual restart intervals come from a self-synchronising walk: on a damaged stream the walk can heal what a sequential
+  // decoder (the reference) trips over.  A lane that decoded its MCUs must stand exactly where its successor starts;
+  // otherwise the stream goes to the host decoder, which does what the reference does.
+  if (img.virt && decoding && !err && interval + 1 < img.n_intervals) {
+    uint32_t byte, skip;
+    dev_exact_position(br, byte, skip);
+    const uint32_t nidx = img.first_interval + (uint32_t)interval + 1u;
+    if (byte != a.ibegin[nidx] || skip != (uint32_t)a.iskip[nidx]) err = HUFF_ERR_DESYNC;
   }
   if (err) atomicMax(&status[0], (uint32_t)err);
 #pragma unroll

@@ -8,6 +8,7 @@ namespace mij {
 
 constexpr int HUFF_DEV_LOOKAHEAD = 10;
 constexpr int HUFF_ERR_MALFORMED = 1, HUFF_ERR_OVERFLOW = 2;
+constexpr int HUFF_ERR_DESYNC = 3; // a virtual restart interval did not end where the next one begins: the stream is damaged
 constexpr int HUFF_DEV_INVALID = 0x8000; // direct-table flag: AC symbol that does not exist in sequential scans
 constexpr int HUFF_STREAM_PAD = 256; // bytes the device copy of the stream is padded with (the readers prefetch ahead)
 

@@ -98,6 +98,55 @@ for t in range(NB):
         if not np.array_equal(res[i].squeeze(), O.decode(streams[i]).squeeze()):
             bad += 1
             print("BATCH DIFFERENCE", t, i, w, h, sub, quals, ri, flags, flush=True)
+# damaged streams: random pictures and layouts, one seeded corruption each (tests/damage.py), through the decoder object with
+# entropy = "prefer-gpu" (device where the stream still qualifies, the host walk with the reference's resynchronisation where
+# not): return code and pixels against oracle/_ref/jpeg where it is present, else against the oracle's restatement
+ND = int(os.environ.get("N_DAMAGED", str(N // 2)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import damage  # noqa: E402
+
+use_ref = O.have_reference()
+dstats = collections.Counter()
+for t in range(ND):
+    w, h = int(rng.integers(16, 900)), int(rng.integers(16, 600))
+    sub = ["444", "422", "420", "gray"][int(rng.integers(0, 4))]
+    q = int(rng.choice([20, 50, 75, 85, 95]))
+    dri = int(rng.choice([0, 1, 2, 4, 8, 8, 20]))
+    prog = bool(rng.integers(0, 8) == 0)
+    img = synth.synth_image(w, h, 7000 + t, channels=1 if sub == "gray" else 3)
+    try:
+        data = synth.encode_jpeg(img, q, sub if sub != "gray" else "444", restart_mcus=dri, optimize=bool(rng.integers(0, 2)), progressive=prog)
+    except OSError:
+        skipped += 1
+        continue
+    kind = damage.KINDS[int(rng.integers(0, len(damage.KINDS)))]
+    blob = damage.corrupt(data, kind, rng, "entropy" if rng.integers(0, 3) else "any")
+    epx, eerr = damage.expected_of(blob, use_ref)
+    if eerr is None:
+        dstats["skip"] += 1
+        continue
+    try:
+        d.read(blob, entropy="prefer-gpu")
+        perr = 0
+    except api.MijpegError as e:
+        perr = e.code
+    verdict = "ok"
+    if perr == -1028 and eerr != -1028:
+        verdict = "int16-gate"
+    elif perr != eerr:
+        verdict = "code"
+    elif perr == 0:
+        got = d.reconstruct()
+        if got.shape != epx.shape or not np.array_equal(got, epx):
+            verdict = "pixels"
+    dstats[verdict + (" (device entropy)" if perr == 0 and d.entropy_used == "gpu" else "")] += 1
+    if verdict in ("code", "pixels"):
+        bad += 1
+        print("DAMAGED DIFFERENCE", t, w, h, sub, q, dri, prog, kind, verdict, eerr, perr, flush=True)
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "campaign_fail"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "campaign_fail", f"damaged_{t}_{kind}_{eerr}_{perr}.jpg"), "wb") as fo:
+            fo.write(blob)
+print(f"{ND} damaged streams against {'oracle/_ref/jpeg' if use_ref else 'the oracle'}:", dict(dstats))
 print(f"{N} random streams ({skipped} refused by the test encoder), {NB} batches with tables per frame ({batch_frames} frames), {time.time() - t0:.0f} s: {bad} differences")
 print("reconstruction kernels:", dict(kernels))
 print("entropy decoder used:", dict(entropy))
