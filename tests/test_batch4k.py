@@ -42,3 +42,66 @@ def test_config4_shards_are_what_the_whole_batch_is(oracle):
         for k, i in enumerate(r["frames"]):
             assert np.array_equal(r["shard"].pixels(k), oracle.decode(streams[i])), (rank, i)
         r["shard"].close()
+
+
+@pytest.mark.gpu
+def test_submit_finish_pipeline_semantics(oracle):
+    """mijpeg_submit_batch_device / mijpeg_finish_batch_device: the two halves give what the one call gives; a batch nobody
+    waited for is waited for by the next submit; what the Huffman kernel reports arrives with finish; batches without restart
+    markers (device walk: needs the host between its rounds) are complete when submit returns."""
+    import torch
+
+    from libjpeg_amd import api, synth
+
+    w, h = 416, 240
+    good = [synth.synth_jpeg(w, h, 300 + i, 85, "420", 2) for i in range(6)]
+    exp = [oracle.decode(s) for s in good]
+    row = w * 3
+    out = torch.zeros((6, h, row), dtype=torch.uint8, device="cuda")
+    d = api.Decoder(0)
+    # 1. submit, then reconstruct (which finishes it)
+    d.submit_batch_device(good, 1)
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row)
+    for i in range(6):
+        assert np.array_equal(out[i].cpu().numpy().reshape(h, w, 3), exp[i])
+    # 2. submit twice in a row: the first batch is simply superseded
+    d.submit_batch_device(good[:3], 1)
+    d.submit_batch_device(good[3:], 1)
+    info = d.finish_batch_device()
+    assert info.width == w and d.batch_frames == 3
+    out.zero_()
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row)
+    for i in range(3):
+        assert np.array_equal(out[i].cpu().numpy().reshape(h, w, 3), exp[3 + i])
+    # 3. finish without anything submitted: an error, not a crash
+    d2 = api.Decoder(0)
+    with pytest.raises(api.MijpegError) as e:
+        d2.finish_batch_device()
+    assert e.value.code == -1031
+    # 4. a member whose entropy coded data is damaged inside an interval: submit cannot know, finish reports NOT_AVAILABLE
+    #    (the caller decodes such a stream on its own: the host walk gives the reference's verdict)
+    bad = bytearray(good[2])
+    sos = bad.find(b"\xff\xda")
+    pos = sos + 200
+    while bad[pos] == 0xFF or bad[pos - 1] == 0xFF or bad[pos + 1] == 0xFF:
+        pos += 1
+    verdicts = set()
+    for delta in range(1, 60):  # some flip in this range breaks an interval beyond repair
+        b2 = bytearray(bad)
+        b2[pos] = (b2[pos] + 37 * delta) & 0xFE
+        d2.submit_batch_device([good[0], bytes(b2), good[1]], 1)
+        try:
+            d2.finish_batch_device()
+            verdicts.add(0)
+        except api.MijpegError as err:
+            verdicts.add(err.code)
+    assert verdicts <= {0, api.ERR_NOT_AVAILABLE} and api.ERR_NOT_AVAILABLE in verdicts, verdicts
+    # 5. no restart markers: decoded by the time submit returns, same pixels
+    plain = [synth.synth_jpeg(640, 400, 400 + i, 85, "420", 0) for i in range(2)]
+    out2 = torch.zeros((2, 400, 640 * 3), dtype=torch.uint8, device="cuda")
+    d2.submit_batch_device(plain, 1)
+    d2.reconstruct_batch_device(out2.data_ptr(), 400 * 640 * 3, 640 * 3)
+    for i in range(2):
+        assert np.array_equal(out2[i].cpu().numpy().reshape(400, 640, 3), oracle.decode(plain[i]))
+    d.close()
+    d2.close()
