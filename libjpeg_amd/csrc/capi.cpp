@@ -1256,13 +1256,15 @@ static bool use_fused1(const mijpeg_batch *b)
          fits32(b);
 }
 
-// fused 4:2:2: packed 16-bit chroma filter like the packed 4:2:0 flavour, same bound
+// fused 4:2:2 / 4:4:0: chroma samples travel through LDS as int16 pairs (range_max < 8190, the fused 4:4:4 kernel's bound);
+// below the packed 4:2:0 flavour's bound (2047) the filter runs on the pairs, between the two on unpacked 32-bit values
+static bool chroma_packed(const mijpeg_info &f) { return f.range_max[1] < 2047 && f.range_max[2] < 2047; }
 static bool use_fused422(const mijpeg_batch *b)
 {
   const mijpeg_info &f = b->info;
   static const bool off = getenv("MIJPEG_NO_F422") != nullptr; // A-B comparisons
   return !off && is_422(f) && f.ycbcr && !f.xt && f.precision == 8 && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
-         f.range_max[1] < 2047 && f.range_max[2] < 2047 && fits32(b);
+         f.range_max[1] < 8190 && f.range_max[2] < 8190 && fits32(b);
 }
 
 // fused 4:4:0 (what a losslessly rotated 4:2:2 picture is): the vertical half of the packed filter, same bound
@@ -1271,7 +1273,7 @@ static bool use_fused440(const mijpeg_batch *b)
   const mijpeg_info &f = b->info;
   static const bool off = getenv("MIJPEG_NO_F440") != nullptr; // A-B comparisons
   return !off && is_440(f) && f.ycbcr && !f.xt && f.precision == 8 && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
-         f.range_max[1] < 2047 && f.range_max[2] < 2047 && fits32(b);
+         f.range_max[1] < 8190 && f.range_max[2] < 8190 && fits32(b);
 }
 
 const char *mijpeg_kernel_name(const mijpeg_batch *b)
@@ -1279,8 +1281,8 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (!b) return "";
   if (use_fusedxt(b)) return "fusedxt420_kernel";
   if (use_fused420p(b)) return "fused420p_kernel";
-  if (use_fused422(b)) return "fused422_kernel";
-  if (use_fused440(b)) return "fused440_kernel";
+  if (use_fused422(b)) return chroma_packed(b->info) ? "fused422_kernel" : "fused422_kernel<wide>";
+  if (use_fused440(b)) return chroma_packed(b->info) ? "fused440_kernel" : "fused440_kernel<wide>";
   if (use_fused1(b)) return "fused1_kernel";
   return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : b->info.xt ? "idct_planes_kernel+xt_merge_kernel"
                                                                                                  : "idct_planes_kernel+upsample_color_kernel";
@@ -1379,7 +1381,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
       xa.ext.aligned16 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 15) == 0;
       rc = launch_fusedxt420(xa, s);
     } else
-      rc = f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, s) : f440 ? launch_fused440(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
+      rc = f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

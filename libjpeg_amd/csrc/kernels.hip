@@ -945,7 +945,11 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
 // 4:2:0 flavour (FAST arithmetic, chroma range_max < 2047), same store path.  Algorithmic bytes: 4 B in + 3 B out per pixel.
 constexpr int F422_CROWS = 128;
 
-template <int MINW, bool QDEV>
+// WIDE: the samples still travel through LDS as int16 pairs (|sample * 16| <= 4 * range_max < 2^15 for range_max < 8190,
+// the fused 4:4:4 kernel's bound, which legitimate 8-bit content cannot exceed: sum |c| q <= 8 sqrt(64 * 128^2) by
+// Cauchy-Schwarz), but the filter runs on unpacked 32-bit values: frames between the packed gate (2047) and 8190 --
+// saturated colours with hard edges -- stay on a fused kernel instead of falling to the generic pair.
+template <int MINW, bool QDEV, bool WIDE>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) unsigned cpair[F422_CROWS * F420_CPITCH];
@@ -1068,23 +1072,42 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
       unsigned v[6];
       load6(c_base + l * F420_CPITCH, v);
       unsigned u[8];
-      u[7] = tap13_pk(v[5], v[4], 1);
-      u[6] = tap13_pk(v[3], v[4], 2);
-      u[5] = tap13_pk(v[4], v[3], 1);
-      u[4] = tap13_pk(v[2], v[3], 2);
-      u[3] = tap13_pk(v[3], v[2], 1);
-      u[2] = tap13_pk(v[1], v[2], 2);
-      u[1] = tap13_pk(u[2], v[1], 1); // src[1] has already been overwritten by out[2]
-      u[0] = tap13_pk(v[0], v[1], 2);
+      int ub[8], ur[8]; // WIDE: the two components on their own, 32 bits
+      if (WIDE) {
+        int vb[6], vr[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { vb[j] = (int)(short)(v[j] & 0xffffu); vr[j] = (int)v[j] >> 16; }
+#define MIJ_HFILTER(o, s)                                                                                        \
+        o[7] = tap13(s[5], s[4], 1); o[6] = tap13(s[3], s[4], 2); o[5] = tap13(s[4], s[3], 1); o[4] = tap13(s[2], s[3], 2); \
+        o[3] = tap13(s[3], s[2], 1); o[2] = tap13(s[1], s[2], 2); o[1] = tap13(o[2], s[1], 1); o[0] = tap13(s[0], s[1], 2);
+        MIJ_HFILTER(ub, vb)
+        MIJ_HFILTER(ur, vr)
+#undef MIJ_HFILTER
+      } else {
+        u[7] = tap13_pk(v[5], v[4], 1);
+        u[6] = tap13_pk(v[3], v[4], 2);
+        u[5] = tap13_pk(v[4], v[3], 1);
+        u[4] = tap13_pk(v[2], v[3], 2);
+        u[3] = tap13_pk(v[3], v[2], 1);
+        u[2] = tap13_pk(v[1], v[2], 2);
+        u[1] = tap13_pk(u[2], v[1], 1); // src[1] has already been overwritten by out[2]
+        u[0] = tap13_pk(v[0], v[1], 2);
+      }
       if (l < nln) {
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         int rr[8], gg[8], bb[8];
 #pragma unroll
         for (int x = 0; x < 8; x++) {
           const int yk = (yv[l * 8 + x] << 13) + K;
-          rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
-          bb[x] = mad16_lo(u[x], L_CB_B, yk);
-          gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
+          if (WIDE) {
+            rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
+            bb[x] = mad24(ub[x], L_CB_B, yk);
+            gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
+          } else {
+            rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
+            bb[x] = mad16_lo(u[x], L_CB_B, yk);
+            gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
+          }
         }
         if (fast_store) {
           unsigned h[12];
@@ -1121,7 +1144,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
 // vertical filter needs a single LINE each (dequant_idct_line: the first pass in full, one inner product per column).
 // Vertical filter only (Upsampler<1,2>: VerticalFilterCore<2>, HorizontalFilterCore<1> = copy), same 16-bit gate.
 constexpr int F440_CROWS = 66, F440_CPITCH = 128;
-template <int MINW, bool QDEV>
+template <int MINW, bool QDEV, bool WIDE> // WIDE: see fused422_kernel
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) unsigned cpair[F440_CROWS * F440_CPITCH];
@@ -1267,17 +1290,33 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
       const int l = 2 * m + half;
       // vertical filter (upsampler.cpp:149-165), both components at once; no horizontal filter (HorizontalFilterCore<1>: a copy)
       unsigned u[8];
+      int ub[8], ur[8]; // WIDE: the two components on their own, 32 bits
 #pragma unroll
-      for (int j = 0; j < 8; j++) u[j] = tap13_pk(half ? cB[j] : cT[j], cC[j], (short)(((j & 1) ^ half) ? 1 : 2));
+      for (int j = 0; j < 8; j++) {
+        const unsigned o = half ? cB[j] : cT[j];
+        const int r = ((j & 1) ^ half) ? 1 : 2;
+        if (WIDE) {
+          ub[j] = tap13((int)(short)(o & 0xffffu), (int)(short)(cC[j] & 0xffffu), r);
+          ur[j] = tap13((int)o >> 16, (int)cC[j] >> 16, r);
+        } else {
+          u[j] = tap13_pk(o, cC[j], (short)r);
+        }
+      }
       if (l < nln) {
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         int rr[8], gg[8], bb[8];
 #pragma unroll
         for (int x = 0; x < 8; x++) {
           const int yk = (yv[l * 8 + x] << 13) + K;
-          rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
-          bb[x] = mad16_lo(u[x], L_CB_B, yk);
-          gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
+          if (WIDE) {
+            rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
+            bb[x] = mad24(ub[x], L_CB_B, yk);
+            gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
+          } else {
+            rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
+            bb[x] = mad16_lo(u[x], L_CB_B, yk);
+            gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
+          }
         }
         if (fast_store) {
           unsigned h[12];
@@ -2263,11 +2302,16 @@ int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused422(const Fused420Args &a, hipStream_t stream)
+int launch_fused422(const Fused420Args &a, bool wide, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  if (a.qdev) hipLaunchKernelGGL((fused422_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused422_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (wide) {
+    if (a.qdev) hipLaunchKernelGGL((fused422_kernel<3, true, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused422_kernel<3, false, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  } else {
+    if (a.qdev) hipLaunchKernelGGL((fused422_kernel<3, true, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused422_kernel<3, false, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  }
   return (int)hipGetLastError();
 }
 
@@ -2279,11 +2323,16 @@ int launch_fused1(const Fused420Args &a, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused440(const Fused420Args &a, hipStream_t stream)
+int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  if (a.qdev) hipLaunchKernelGGL((fused440_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused440_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (wide) {
+    if (a.qdev) hipLaunchKernelGGL((fused440_kernel<3, true, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused440_kernel<3, false, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  } else {
+    if (a.qdev) hipLaunchKernelGGL((fused440_kernel<3, true, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused440_kernel<3, false, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  }
   return (int)hipGetLastError();
 }
 

@@ -111,11 +111,12 @@ def test_fused440_packed_chroma_gate(dec, oracle):
         data = dec.encode(img, q, "440", 3)
         f = dec.read(data)
         name = api.kernel_name(f)
-        packed = f.fast_arith == 1 and f.range_max[1] < 2047 and f.range_max[2] < 2047
-        assert name == ("fused440_kernel" if packed else "idct_planes_kernel+upsample_color_kernel")
+        worst = max(f.range_max[1], f.range_max[2])
+        assert f.fast_arith == 1
+        assert name == ("fused440_kernel" if worst < 2047 else "fused440_kernel<wide>" if worst < 8190 else "idct_planes_kernel+upsample_color_kernel")
         seen.add(name)
         assert np.array_equal(dec.reconstruct(), oracle.decode(data)), q
-    assert "idct_planes_kernel+upsample_color_kernel" in seen  # saturated graphics lie beyond the gate
+    assert "fused440_kernel<wide>" in seen  # saturated graphics lie beyond the packed gate: 32-bit filters, still fused
     rng = np.random.default_rng(16)
     img = rng.integers(0, 256, (208, 144, 3)).astype(np.uint8)
     for q in (60, 95):
@@ -151,11 +152,12 @@ def test_fused422_packed_chroma_gate(dec, oracle):
         data = synth.encode_jpeg(img, q, "422", restart_mcus=3)
         f = dec.read(data)
         name = api.kernel_name(f)
-        packed = f.fast_arith == 1 and f.range_max[1] < 2047 and f.range_max[2] < 2047
-        assert name == ("fused422_kernel" if packed else "idct_planes_kernel+upsample_color_kernel")
+        worst = max(f.range_max[1], f.range_max[2])
+        assert f.fast_arith == 1
+        assert name == ("fused422_kernel" if worst < 2047 else "fused422_kernel<wide>" if worst < 8190 else "idct_planes_kernel+upsample_color_kernel")
         seen.add(name)
         assert np.array_equal(dec.reconstruct(), oracle.decode(data)), q
-    assert "idct_planes_kernel+upsample_color_kernel" in seen  # saturated graphics lie beyond the gate
+    assert "fused422_kernel<wide>" in seen  # saturated graphics lie beyond the packed gate: 32-bit filters, still fused
     rng = np.random.default_rng(6)
     img = rng.integers(0, 256, (144, 208, 3)).astype(np.uint8)
     for q in (60, 95):
@@ -447,13 +449,19 @@ def test_adversarial_coefficients_safe_flavour(oracle, generic):
     assert bad == 0, f"{bad} differing samples"
 
 
-def test_extreme_coefficients_at_the_packed_chroma_gate(oracle):
-    """The packed 4:2:0 flavour is admitted by sum |c| q < 2047 per chroma block.  Blocks that sit right at that bound
-    with every sign pattern (DC-only, single AC, dense) drive the 16-bit filter sums to their limits; the result must
-    still be the reference's."""
+@pytest.mark.parametrize("sub,chroma_budget,kernel", [("420", 2046, "fused420p_kernel"), ("422", 2046, "fused422_kernel"), ("440", 2046, "fused440_kernel"),
+                                                      ("422", 8189, "fused422_kernel<wide>"), ("440", 8189, "fused440_kernel<wide>"),
+                                                      ("420", 8189, "fused420_kernel"), ("444", 8189, "fused444_kernel")])
+def test_extreme_coefficients_at_the_packed_chroma_gate(dec, oracle, sub, chroma_budget, kernel):
+    """The packed flavours are admitted by sum |c| q < 2047 per chroma block, the int16 sample store of the 4:2:2 / 4:4:0 /
+    4:4:4 kernels by < 8190.  Blocks that sit right at those bounds with every sign pattern (DC-only, single AC, dense) drive
+    the 16-bit filter sums / the 16-bit samples to their limits; the result must still be the reference's."""
     torch = _torch()
     d = api.Decoder(0)
-    data = synth.synth_jpeg(272, 144, 5, 85, "420", 0)
+    if sub == "440":
+        data = dec.encode(synth.synth_image(272, 144, 5), 85, "440", 0)
+    else:
+        data = synth.synth_jpeg(272, 144, 5, 85, sub, 0)
     f = d.read(data)
     d.close()
     rng = np.random.default_rng(77)
@@ -469,7 +477,7 @@ def test_extreme_coefficients_at_the_packed_chroma_gate(oracle):
         p = np.zeros(shape, np.int32)
         kind = rng.integers(0, 4, size=shape[:2])
         sign = rng.choice([-1, 1], size=shape[:2])
-        budget = 2046 if c else 8000
+        budget = chroma_budget if c else 8000
         p[..., 0] = np.where(kind == 0, sign * (budget // 2), 0)  # DC alone: q[0] = 2
         k = rng.integers(1, 64, size=shape[:2])
         for by in range(shape[0]):
@@ -487,9 +495,9 @@ def test_extreme_coefficients_at_the_packed_chroma_gate(oracle):
     for c in range(3):
         q = np.array(info.quant[info.tq[c]], np.int64)
         f.range_max[c] = int((np.abs(planes[c]).astype(np.int64) * q).sum(axis=2).max())
-    assert f.range_max[1] <= 2046 and f.range_max[2] <= 2046
+    assert f.range_max[1] <= chroma_budget and f.range_max[2] <= chroma_budget
     f.fast_arith = 1
-    assert api.kernel_name(f) == "fused420p_kernel"
+    assert api.kernel_name(f) == kernel
     exp = oracle.reconstruct(info, planes)
     coef = torch.from_numpy(np.concatenate([p.astype(np.int16).reshape(-1) for p in planes])).cuda()
     row = 272 * 3

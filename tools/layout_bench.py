@@ -16,6 +16,17 @@ W, H, F = 7680, 4320, 8
 hip = C.cdll.LoadLibrary("libamdhip64.so")
 for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
     img = synth.synth_image(W, H, 1234, channels=1 if sub == "gray" else 3)
+    if os.environ.get("SATURATED") == "1" and sub != "gray":
+        # saturated graphics over the synthetic picture: hard-edged bars of pure colours push the chroma range check of the
+        # frame past the packed gate (sum |c| q >= 2047 in some block), which selects the wide / 32-bit flavours
+        img = img.copy()
+        img[:, 1000:1400] = (255, 0, 0)
+        img[:, 1400:1800] = (0, 0, 255)
+        img[2000:2300] = (255, 255, 0)
+        img[2300:2600] = (0, 255, 0)
+        img[3000:3200:5, 3000:3400] = (255, 0, 255)   # thin lines, thin columns: strong chroma AC in every layout
+        img[3000:3200, 3400:3800:5] = (0, 255, 255)
+        img[3300:3500:6, 3000:3800:6] = (255, 0, 0)
     d = api.Decoder(0)
     # Pillow has no 4:4:0: that stream comes from this library's own encoder
     data = d.encode(img, 85, "440", 8) if sub == "440" else synth.encode_jpeg(img, 85, "444" if sub == "gray" else sub, restart_mcus=8)
@@ -57,5 +68,5 @@ for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
     ms = e0.elapsed_time(e1) / 20
     bpp = 2.0 * n / (W * H) + nc  # int16 coefficients in, bytes out
     ok = bool(np.array_equal(out[0].cpu().numpy().reshape(H, W, nc).squeeze(), d.reconstruct().squeeze()))
-    print(f"{sub:>5}: {api.kernel_name(info):<44} {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px) same as decoder object: {ok}{' (per-frame tables)' if own else ''}", flush=True)
+    print(f"{sub:>5}: range_max {list(info.range_max)[:nc]} {api.kernel_name(info):<44} {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px) same as decoder object: {ok}{' (per-frame tables)' if own else ''}", flush=True)
     d.close()
