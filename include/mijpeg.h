@@ -171,7 +171,9 @@ int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams,
  * bytes are only read during the call); finish waits for them and evaluates what the kernel reported (errors, range check).
  * mijpeg_reconstruct_batch_device and mijpeg_get_info finish a submitted batch themselves.  While one object's batch is on the
  * device the host prepares the next one with another object: see libjpeg_amd/batch.py (BASELINE config 4).  Batches of streams
- * without restart markers are decoded completely by submit (their device walk needs the host between its rounds). */
+ * without restart markers get a fixed, generous number of device-walk rounds (rounds in which nothing changes cost
+ * microseconds); finish answers MIJPEG_ERR_NOT_AVAILABLE in the unlikely case that the walk had not settled by then, and
+ * mijpeg_decode_batch_device, which looks at the walk between its rounds, decodes such a batch. */
 int mijpeg_submit_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals);
 int mijpeg_finish_batch_device(mijpeg_decoder *d);
 /* Wait for everything the object has enqueued on its stream (e.g. a reconstruction launched with sync = 0). */

@@ -78,6 +78,9 @@ struct mijpeg_decoder {
   // a submitted batch whose device work has not been waited for yet (mijpeg_submit_batch_device)
   int pend_n = 0;
   const uint32_t *pend_status = nullptr;
+  int pend_walk_round = 0;                       // > 0: the batch went through the device walk with this many rounds, unchecked
+  const uint32_t *pend_walk_flags = nullptr;     // "something changed" per round (pinned)
+  const uint32_t *pend_walk_status = nullptr;    // per image (pinned)
   std::chrono::steady_clock::time_point pend_t0;
   // batches whose images bring different quantisation tables: [frames][4][64] deltas per component, on the device
   uint16_t *batch_quant_dev = nullptr;
@@ -342,7 +345,7 @@ static const char *device_entropy_obstacle(const HostDecoder &h, size_t size, bo
 // `images_host` is the staging copy of the HuffImage array (first_interval = start of the image's interval entries).
 static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int n, const std::vector<int> &dwalk, const HuffScanArgs &scan,
                               const HuffImage *images_dev, uint32_t *ibegin_dev, uint8_t *iskip_dev, int16_t *ipred_dev,
-                              const HuffImage *images_host)
+                              const HuffImage *images_host, bool defer = false)
 {
   const mijpeg_info &f0 = hosts[0]->info;
   const Scan &s0 = hosts[0]->scans[0];
@@ -445,16 +448,25 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
   // the initial guess: every subsequence starts at its boundary (behind a stuffed zero if it falls on one) with the
   // first block of an MCU; for the first subsequence of an image that is no guess
   {
+    // (one cache miss per subsequence in the caller's stream: spread over the pool, 7.7 -> 0.6 ms for 16 8K frames)
     uint64_t *st = (uint64_t *)(wh + o_state);
-    for (int i = 0; i < n; i++) {
-      const Scan &s = hosts[i]->scans[0];
-      const uint8_t *base = hosts[i]->stream_base();
-      for (uint32_t k = 0; k < img_nsub[(size_t)i]; k++) {
-        size_t q = s.ecs_begin + (size_t)k * sub_bytes;
-        if (k > 0 && base[q] == 0x00 && base[q - 1] == 0xff) q++;
-        st[img_sub0[(size_t)i] + k] = (uint64_t)q;
+    std::vector<std::pair<int, uint32_t>> parts; // image, first subsequence of a run of 4096
+    for (int i = 0; i < n; i++)
+      for (uint32_t k = 0; k < img_nsub[(size_t)i]; k += 4096) parts.emplace_back(i, k);
+    const int workers = std::max(1, std::min<int>((int)parts.size(), std::min(default_threads(), 16)));
+    parallel_for(workers, [&](int wkr) {
+      for (size_t pi = (size_t)wkr; pi < parts.size(); pi += (size_t)workers) {
+        const int i = parts[pi].first;
+        const Scan &s = hosts[i]->scans[0];
+        const uint8_t *base = hosts[i]->stream_base();
+        const uint32_t k1 = std::min(img_nsub[(size_t)i], parts[pi].second + 4096);
+        for (uint32_t k = parts[pi].second; k < k1; k++) {
+          size_t q = s.ecs_begin + (size_t)k * sub_bytes;
+          if (k > 0 && base[q] == 0x00 && base[q - 1] == 0xff) q++;
+          st[img_sub0[(size_t)i] + k] = (uint64_t)q;
+        }
       }
-    }
+    });
   }
   HIP_TRY(d, hipMemcpyAsync(wd, wh, o_up_end, hipMemcpyHostToDevice, d->stream));
   HIP_TRY(d, hipMemsetAsync(wd + o_flags, 0, o_zero_end - o_flags, d->stream));
@@ -488,7 +500,20 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
   uint32_t *flags_host = (uint32_t *)(wh + o_up_end);
   static const int first_bunch = getenv("MIJPEG_WALK_ROUNDS") ? std::max(1, std::min(MAX_ROUNDS, atoi(getenv("MIJPEG_WALK_ROUNDS")))) : 8;
   int round = 0;
-  for (;;) {
+  if (defer) {
+    // mijpeg_submit_batch_device: nobody looks at the flags between the rounds.  Enough rounds for the states to settle are
+    // launched in one go -- a round in which no lane is dirty costs a few microseconds (its workgroups leave before they
+    // load their tables) -- and whoever waits for the batch checks that the last one changed nothing (finish_batch).
+    const int rounds = std::min(MAX_ROUNDS, sub_bytes >= 512 ? 16 : sub_bytes >= 256 ? 24 : 40);
+    while (round < rounds) {
+      w.round = (uint32_t)++round;
+      if (launch_huffman_walk(w, false, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_walk_kernel launch");
+    }
+    HIP_TRY(d, hipMemcpyAsync(flags_host, wd + o_flags, (size_t)(MAX_ROUNDS + 1) * 4, hipMemcpyDeviceToHost, d->stream));
+    d->pend_walk_round = round;
+    d->pend_walk_flags = flags_host;
+  }
+  for (; !defer;) {
     const int upto = round == 0 ? first_bunch : std::min(MAX_ROUNDS, round + 4);
     while (round < upto) {
       w.round = (uint32_t)++round;
@@ -500,7 +525,7 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
     if (round == MAX_ROUNDS) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "speculative decoding did not settle");
   }
   d->walk_rounds = 1;
-  for (int r = 1; r <= round; r++)
+  for (int r = 1; r <= round && !defer; r++)
     if (flags_host[r]) d->walk_rounds = r + 1; // rounds that were needed: the last one that changed something, and one to see it
   if (launch_huffman_walk_scan(w, n, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_walk_scan_kernel launch");
   // one interval size for the launch: the images share their geometry, hence their MCUs per virtual interval
@@ -779,6 +804,10 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   a.coef = coef_dev;
   a.status = (uint32_t *)(d->ent_dev + off_status);
   const auto tb1 = std::chrono::steady_clock::now();
+  static const bool trace_phases = getenv("MIJPEG_TRACE_SUBMIT") != nullptr; // diagnostics: host time of the steps below, on stderr
+  auto mark = [&](const char *what) {
+    if (trace_phases) fprintf(stderr, "[mijpeg] %-28s %8.3f ms\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tb1).count() * 1e3);
+  };
   HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part, hipMemcpyHostToDevice, d->stream));
   HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
   if (needs_clear) HIP_TRY(d, hipMemsetAsync(coef_dev, 0, (size_t)n * (size_t)frame_stride * sizeof(int16_t), d->stream));
@@ -790,7 +819,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
       HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
     if (any_dwalk) {
       const int wrc = device_walk_images(d, hosts, n, dwalk, a, (const HuffImage *)(d->ent_dev + off_img), (uint32_t *)(d->ent_dev + off_ib),
-                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images);
+                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images, defer);
       if (wrc) return wrc;
     }
     for (int r = 0; r < std::max(1, repeat); r++)
@@ -805,6 +834,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
       HIP_TRY(d, hipHostMalloc((void **)&d->stage_host, stream_bytes, hipHostMallocDefault));
       d->stage_cap = stream_bytes;
     }
+    mark("staging buffer ready");
     if (!d->copy_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     // Images per upload + launch.  A launch is latency-bound (the serial symbol chain of its longest restart interval,
     // ~0.3 ms) until it holds several waves per SIMD: ~128 K restart intervals; more, smaller launches only pay when the
@@ -850,10 +880,12 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
         if (launch_huffman_scan(part, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
       wg0 = wg1;
     }
+    mark("groups gathered + enqueued");
     if (any_dwalk) {
       const int wrc = device_walk_images(d, hosts, n, dwalk, a, (const HuffImage *)(d->ent_dev + off_img), (uint32_t *)(d->ent_dev + off_ib),
-                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images);
+                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images, defer);
       if (wrc) return wrc;
+      mark("device walk enqueued");
       for (int r = 0; r < std::max(1, repeat); r++)
         if (launch_huffman_scan(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_scan_kernel launch");
     }
@@ -863,9 +895,12 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   uint32_t *walk_status_host = (uint32_t *)d->walk_host; // the walk's staging buffer is free again
   if (any_dwalk) HIP_TRY(d, hipMemcpyAsync(walk_status_host, d->walk_status_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
   d->phase_prepare = std::chrono::duration<double>(tb1 - tb0).count(); // interval tables, Huffman tables
-  if (defer && !any_dwalk) { // mijpeg_submit_batch_device: the caller waits later (finish_entropy_batch)
+  mark("status copies enqueued");
+  if (!any_dwalk) d->pend_walk_round = 0;
+  if (defer) { // mijpeg_submit_batch_device: the caller waits later (finish_batch)
     d->pend_n = n;
     d->pend_status = status_host;
+    d->pend_walk_status = any_dwalk ? walk_status_host : nullptr;
     d->pend_t0 = tb1;
     d->phase_device = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb1).count(); // so far: gathering + enqueueing
     return MIJPEG_OK;
@@ -1014,6 +1049,18 @@ static int finish_batch(mijpeg_decoder *d)
     d->pend_n = 0;
     HIP_TRY(d, hipStreamSynchronize(d->stream));
     d->phase_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - d->pend_t0).count();
+    if (d->pend_walk_round > 0) { // streams without restart markers: did the walk settle within the rounds it was given?
+      const int rounds = d->pend_walk_round;
+      d->pend_walk_round = 0;
+      if (d->pend_walk_flags[rounds]) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "speculative decoding did not settle in the rounds a submitted batch gets: decode it with mijpeg_decode_batch_device");
+      d->walk_rounds = 1;
+      for (int r = 1; r <= rounds; r++)
+        if (d->pend_walk_flags[r]) d->walk_rounds = r + 1;
+      for (int i = 0; i < pn && d->pend_walk_status; i++) {
+        if (d->pend_walk_status[i] & 2) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
+        if (d->pend_walk_status[i]) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "speculative decoding settled on something that is not a decode of the image");
+      }
+    }
     const int rc = evaluate_entropy_status(d, hosts.data(), pn, d->pend_status);
     if (rc) return rc;
   }
