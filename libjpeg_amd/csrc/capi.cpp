@@ -580,6 +580,10 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     if (f.width != f0.width || f.height != f0.height || f.components != f0.components || memcmp(f.hsamp, f0.hsamp, sizeof(f.hsamp)) ||
         memcmp(f.vsamp, f0.vsamp, sizeof(f.vsamp)))
       return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the images of a batch must share width, height and sampling factors");
+    // ... and what the one reconstruction launch applies to all of them: the colour transformation (an Adobe marker may
+    // switch it off per image), the sample precision, being a JPEG XT stream or not
+    if (f.ycbcr != f0.ycbcr || f.precision != f0.precision || f.xt != f0.xt)
+      return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the images of a batch must share colour transformation and precision");
     for (int k = 0; k < s.ncomp; k++)
       if (s.sc[k].comp != s0.sc[k].comp) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the images of a batch must share the component order of their scan");
     const int64_t total_mcus = (int64_t)s.mcus_x * s.mcus_y;

@@ -1056,8 +1056,13 @@ def test_stateless_launch_with_per_frame_tables(oracle):
 def test_batch_decode_rejects_what_is_not_a_batch():
     d = api.Decoder(0)
     a = synth.synth_jpeg(320, 240, 1, 85, "420", 2)
+    # an Adobe marker with transform = 0 switches the colour transformation off for that image only: one reconstruction
+    # launch cannot serve both (APP14 segment as marker/adobemarker.cpp lays it out, right behind SOI)
+    import struct
+    adobe_rgb = a[:2] + b"\xff\xee" + struct.pack(">H", 14) + b"Adobe" + struct.pack(">HHHB", 100, 0, 0, 0) + a[2:]
     for other in (synth.synth_jpeg(336, 240, 1, 85, "420", 2),   # another width
-                  synth.synth_jpeg(320, 240, 1, 85, "444", 2)):  # another sampling
+                  synth.synth_jpeg(320, 240, 1, 85, "444", 2),   # another sampling
+                  adobe_rgb):                                    # another colour transformation
         with pytest.raises(api.MijpegError) as e:
             d.decode_batch_device([a, other], min_intervals=1)
         assert e.value.code == api.ERR_NOT_AVAILABLE
