@@ -1511,13 +1511,18 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
         for (int c = 0; c < 3; c++) {
           // only the highest-frequency delta is used, with the colour bits folded in (residualblockhelper.cpp:351-364)
           a.rquant63[c] = (int32_t)x.residual.quant[x.residual.quant_index[c]][63] << 4;
-          if (x.qtable[c]) {
+          // (components that share a table share its copy)
+          for (int j = 0; j < c; j++) {
+            if (x.qtable[c] && x.qtable[j] == x.qtable[c]) a.qlut[c] = a.qlut[j];
+            if (x.r2table[c] && x.r2table[j] == x.r2table[c]) a.r2lut[c] = a.r2lut[j];
+          }
+          if (x.qtable[c] && !a.qlut[c]) {
             const size_t n = (size_t)x.qtable_entries * sizeof(int32_t);
             if (hipMemcpyAsync(tp, x.qtable[c], n, hipMemcpyHostToDevice, s) != hipSuccess) return MIJPEG_ERR_DEVICE;
             a.qlut[c] = (const int32_t *)tp;
             tp += n;
           }
-          if (x.r2table[c]) {
+          if (x.r2table[c] && !a.r2lut[c]) {
             const size_t n = ((size_t)1 << 20) * sizeof(int32_t);
             if (hipMemcpyAsync(tp, x.r2table[c], n, hipMemcpyHostToDevice, s) != hipSuccess) return MIJPEG_ERR_DEVICE;
             a.r2lut[c] = (const int32_t *)tp;
