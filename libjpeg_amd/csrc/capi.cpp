@@ -1210,6 +1210,12 @@ static bool is_422(const mijpeg_info &f)
          f.vsamp[2] == 1;
 }
 
+static bool is_411(const mijpeg_info &f)
+{
+  return f.components == 3 && f.hsamp[0] == 4 && f.vsamp[0] == 1 && f.hsamp[1] == 1 && f.vsamp[1] == 1 && f.hsamp[2] == 1 &&
+         f.vsamp[2] == 1;
+}
+
 static bool is_440(const mijpeg_info &f)
 {
   return f.components == 3 && f.hsamp[0] == 1 && f.vsamp[0] == 2 && f.hsamp[1] == 1 && f.vsamp[1] == 1 && f.hsamp[2] == 1 &&
@@ -1318,6 +1324,15 @@ static bool use_fused422(const mijpeg_batch *b)
          f.range_max[1] < 8190 && f.range_max[2] < 8190 && fits32(b);
 }
 
+// fused 4:1:1: int16 pairs in LDS, 32-bit four-fold filter
+static bool use_fused411(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  static const bool off = getenv("MIJPEG_NO_F411") != nullptr; // A-B comparisons
+  return !off && is_411(f) && f.ycbcr && !f.xt && f.precision == 8 && !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fast_ok(b) &&
+         f.range_max[1] < 8190 && f.range_max[2] < 8190 && fits32(b);
+}
+
 // fused 4:4:0 (what a losslessly rotated 4:2:2 picture is): the vertical half of the packed filter, same bound
 static bool use_fused440(const mijpeg_batch *b)
 {
@@ -1334,6 +1349,7 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (use_fused420p(b)) return "fused420p_kernel";
   if (use_fused422(b)) return chroma_packed(b->info) ? "fused422_kernel" : "fused422_kernel<wide>";
   if (use_fused440(b)) return chroma_packed(b->info) ? "fused440_kernel" : "fused440_kernel<wide>";
+  if (use_fused411(b)) return "fused411_kernel";
   if (use_fused1(b)) return "fused1_kernel";
   return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : b->info.xt ? "idct_planes_kernel+xt_merge_kernel"
                                                                                                  : "idct_planes_kernel+upsample_color_kernel";
@@ -1359,7 +1375,7 @@ static size_t expanded_tables_bytes(const mijpeg_batch *b) { return b->quant_dev
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
 {
   if (!b) return 0;
-  if (use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused1(b)) return expanded_tables_bytes(b);
+  if (use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused411(b) || use_fused1(b)) return expanded_tables_bytes(b);
   if (use_fusedxt(b)) return LUT_BYTES;
   // [LUT_BYTES: L lookup tables (JPEG XT, up to 3 x 4096 entries)] [per frame: int32 sample planes, one sample per
   // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients] [expanded per-frame tables]
@@ -1376,7 +1392,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   const bool fast = fast_ok(b);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  const bool f444 = use_fused444(b), fxt = use_fusedxt(b), f422 = use_fused422(b), f440 = use_fused440(b), f1 = use_fused1(b);
+  const bool f444 = use_fused444(b), fxt = use_fusedxt(b), f422 = use_fused422(b), f440 = use_fused440(b), f411 = use_fused411(b), f1 = use_fused1(b);
   if (fxt && (!b->workspace || b->workspace_bytes < LUT_BYTES)) return MIJPEG_ERR_MISSING_PARAMETER;
   const int32_t *qdev = nullptr;
   if (b->quant_dev) {
@@ -1386,7 +1402,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     if (launch_expand_deltas(b->quant_dev, dst, b->frames, s)) return MIJPEG_ERR_DEVICE;
     qdev = dst;
   }
-  if (use_fused420(b) || f444 || fxt || f422 || f440 || f1) {
+  if (use_fused420(b) || f444 || fxt || f422 || f440 || f411 || f1) {
     FusedXtArgs xa;
     memset(&xa, 0, sizeof(xa));
     Fused420Args &a = xa.base;
@@ -1404,8 +1420,8 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     a.bh_y = f.blocks_h[0];
     a.bw_c = f.blocks_w[1];
     a.bh_c = f.blocks_h[1];
-    a.cw = f440 ? f.width : (f.width + 1) / 2;
-    a.ch = f422 ? f.height : (f.height + 1) / 2;
+    a.cw = f440 ? f.width : f411 ? (f.width + 3) / 4 : (f.width + 1) / 2;
+    a.ch = (f422 || f411) ? f.height : (f.height + 1) / 2;
     a.tiles_x = (f.width + 127) / 128;
     a.tiles_y = (f.height + 127) / 128;
     a.frames = b->frames;
@@ -1432,7 +1448,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
       xa.ext.aligned16 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 15) == 0;
       rc = launch_fusedxt420(xa, s);
     } else
-      rc = f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
+      rc = f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

@@ -1137,6 +1137,179 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
 }
 
 // ==============================================================================================
+// fused 4:1:1 kernel (Y 1x1, Cb/Cr subsampled 4x1: DV-style sampling, `jpeg -s 1x1,4x1,4x1`)
+// ==============================================================================================
+// The 4:2:2 kernel with the four-fold horizontal core (HorizontalFilterCore<4>, upsampling/upsampler.cpp:367-387:
+// out[0..7] of a block from the chroma samples c[-1], c[0], c[1], c[2] with the weights (3,5) (1,7) (1,7) (3,5) and their
+// mirror images; the in-place order of the reference touches no sample it still needs, so the taps see the original four).
+// A 128x128 tile holds 4 x 16 chroma blocks per component -- one round for waves 0 (Cb) and 2 (Cr) -- and the last / first
+// COLUMN of the 16 blocks left / right of them, transformed column-only by waves 1 and 3.  Samples travel through LDS as
+// (Cb, Cr) int16 pairs (chroma range_max < 8190), the filter and the colour stage run on unpacked 32-bit values (the WIDE
+// arithmetic of fused422_kernel: the weights up to 7 leave no room for 16-bit sums).  Algorithmic bytes: 3 B in + 3 B out.
+__device__ __forceinline__ int f8(int wa, int x, int wb, int y, int r);
+constexpr int F411_CPITCH = 40; // dwords per LDS chroma line; column pc <-> chroma x_rel = pc - 4 (3 and 36: the halo columns)
+
+template <int MINW, bool QDEV>
+__global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) unsigned cpair[F422_CROWS * F411_CPITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  { // XCD-aware tile order (see fused420_kernel)
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  // ------------------------------------------------------------------ phase A: chroma -> LDS halves
+  {
+    const int comp = wave >> 1; // 0 = Cb (low halves), 1 = Cr (high halves); wave-uniform
+    const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
+    const int gx0 = tx * 4, gy0 = ty * 16;
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
+    // (two static indices and a select: a run-time index into the by-value argument block would send the block to scratch)
+    const int *qc = QDEV ? frame_deltas<QDEV>(a, frame, 1 + comp) : (comp ? a.q[2] : a.q[1]);
+    u32x4 rows[8];
+    if ((wave & 1) == 0) { // the 4 x 16 blocks of the tile: local block n is column n & 3, row n >> 2
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int n = (lane >> 3) + 8 * m;
+        const int xx = min(gx0 + (n & 3), a.bw_c - 1), yy = min(gy0 + (n >> 2), a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
+      });
+      const int cbx = lane & 3, cby = lane >> 2;
+      if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
+        int v[64];
+        dequant_idct_sparse(rows, qc, v);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          short *dst = cp + 2 * ((8 * cby + r) * F411_CPITCH + 8 * cbx + 4);
+#pragma unroll
+          for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
+        }
+      }
+    } else { // halo columns: local block n (0..31) is side n & 1 (0: left neighbour, 1: right neighbour), row n >> 1
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int n = min((lane >> 3) + 8 * m, 31);
+        const int xx = min(max((n & 1) ? gx0 + 4 : gx0 - 1, 0), a.bw_c - 1), yy = min(gy0 + (n >> 1), a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
+      });
+      const int side = lane & 1, cby = lane >> 1, gx = side ? gx0 + 4 : gx0 - 1;
+      if (lane < 32 && gx >= 0 && gx < a.bw_c && gy0 + cby < a.bh_c) {
+        int col[8];
+        dequant_idct_column(rows, qc, side == 0, col); // left neighbour: its last column, right one: its first
+#pragma unroll
+        for (int r = 0; r < 8; r++) cp[2 * ((8 * cby + r) * F411_CPITCH + (side ? 36 : 3))] = (short)col[r];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ edge fix-up (uniform branch): columns only
+  {
+    const int last_col = a.cw - 1 - tx * 32; // last valid chroma column, tile-relative
+    if ((tx == 0) | (last_col < 32)) {
+      if (tid < F422_CROWS) { // one thread per stored line
+        unsigned *p = cpair + tid * F411_CPITCH;
+        if (tx == 0) p[3] = p[4];
+        if (last_col < 32) {
+          const unsigned v = p[last_col + 4];
+          for (int pc = last_col + 5; pc <= 36; pc++) p[pc] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ phase B: luma, upsampling, colour
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  u32x4 rows[8];
+  {
+    const int16_t *__restrict__ plane = coef + a.off_y;
+    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
+  int yv[64];
+  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = a.aligned8 && npx == 8;
+  // chroma window of this block: lines 8 by + l, columns x_rel = 2 bx - 1 .. 2 bx + 2, i.e. pc = 2 bx + 3 .. 2 bx + 6
+  const unsigned *c_base = cpair + (8 * by) * F411_CPITCH + 2 * bx + 3;
+  const int K = (2048 << 13) + 65536;
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    const unsigned *p = c_base + l * F411_CPITCH;
+    const unsigned w[4] = {p[0], p[1], p[2], p[3]};
+    int cb[4], cr[4], ub[8], ur[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { cb[j] = (int)(short)(w[j] & 0xffffu); cr[j] = (int)w[j] >> 16; }
+    // no vertical filter; the four-fold horizontal core on c[-1], c[0], c[1], c[2] = s[0..3]
+#define MIJ_HFILTER4(o, s)                                                                                   \
+    o[0] = f8(3, s[0], 5, s[1], 2); o[1] = f8(1, s[0], 7, s[1], 1); o[2] = f8(1, s[2], 7, s[1], 2); o[3] = f8(3, s[2], 5, s[1], 1); \
+    o[4] = f8(3, s[1], 5, s[2], 2); o[5] = f8(1, s[1], 7, s[2], 1); o[6] = f8(1, s[3], 7, s[2], 2); o[7] = f8(3, s[3], 5, s[2], 1);
+    MIJ_HFILTER4(ub, cb)
+    MIJ_HFILTER4(ur, cr)
+#undef MIJ_HFILTER4
+    if (l < nln) {
+      uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+      int rr[8], gg[8], bb[8];
+#pragma unroll
+      for (int x = 0; x < 8; x++) {
+        const int yk = (yv[l * 8 + x] << 13) + K;
+        rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
+        bb[x] = mad24(ub[x], L_CB_B, yk);
+        gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
+      }
+      if (fast_store) {
+        unsigned h[12];
+#pragma unroll
+        for (int x = 0; x < 8; x += 2) {
+          h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
+          h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
+          h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
+        }
+        unsigned wd[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) wd[i] = h[2 * i] | (h[2 * i + 1] << 16);
+        u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+        __builtin_nontemporal_store(u32x2{wd[0], wd[1]}, d2);
+        __builtin_nontemporal_store(u32x2{wd[2], wd[3]}, d2 + 1);
+        __builtin_nontemporal_store(u32x2{wd[4], wd[5]}, d2 + 2);
+      } else {
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+          if (x < npx) {
+            dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
+          }
+      }
+    }
+  }
+}
+
+// ==============================================================================================
 // fused 4:4:0 kernel (Y 1x1, Cb/Cr subsampled 1x2: what a losslessly rotated 4:2:2 picture is), packed chroma
 // ==============================================================================================
 // The 4:2:2 kernel turned by ninety degrees: chroma planes of full width and half height, so a 128x128 tile holds 16 x 8
@@ -2312,6 +2485,14 @@ int launch_fused422(const Fused420Args &a, bool wide, hipStream_t stream)
     if (a.qdev) hipLaunchKernelGGL((fused422_kernel<3, true, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
     else hipLaunchKernelGGL((fused422_kernel<3, false, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   }
+  return (int)hipGetLastError();
+}
+
+int launch_fused411(const Fused420Args &a, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  if (a.qdev) hipLaunchKernelGGL((fused411_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused411_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

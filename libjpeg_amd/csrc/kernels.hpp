@@ -84,7 +84,8 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
 int launch_fused420p(const Fused420Args &a, hipStream_t stream); // FAST only, chroma samples within int16 filter range
 int launch_fused444(const Fused420Args &a, hipStream_t stream); // same argument block; all planes bw_y x bh_y
 int launch_fused1(const Fused420Args &a, hipStream_t stream);   // single component: plane off_y, bw_y x bh_y blocks, one byte per pixel
-int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream); // same argument block; chroma planes bw_y x bh_c, cw = W, ch = ceil(H/2)
+int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream);
+int launch_fused411(const Fused420Args &a, hipStream_t stream); // same argument block; chroma planes bw_c x bh_y, cw = ceil(W/4), ch = H // same argument block; chroma planes bw_y x bh_c, cw = W, ch = ceil(H/2)
 int launch_fused422(const Fused420Args &a, bool wide, hipStream_t stream); // wide: 32-bit filters for chroma ranges between the packed gate and 8190 // same argument block; chroma planes bw_c x bh_y, cw = ceil(W/2), ch = H
 int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream);
 int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream);

@@ -99,6 +99,28 @@ def test_fused440_vs_oracle(dec, oracle, w, h, flags):
     assert bad == 0, f"{bad} differing samples, first at {np.argwhere(out != exp)[:4].tolist()}"
 
 
+@pytest.mark.parametrize("flags", [0, api.FLAG_FORCE_SAFE])
+@pytest.mark.parametrize("w,h", EDGE_SIZES + [(512, 512), (1920, 1080), (1003, 998), (129, 40), (31, 300), (33, 9)])
+def test_fused411_vs_oracle(dec, oracle, w, h, flags):
+    """4:1:1 (chroma subsampled 4x1): the four-fold horizontal core of upsampling/upsampler.cpp:367-387 in a fused kernel.
+    Streams from this library's own encoder (Pillow cannot write the layout) and saturated content among them."""
+    ri = (w + 2 * h) % 5
+    img = synth.synth_image(w, h, 800 + w + h)
+    if (w + h) % 3 == 0:
+        img = img.copy()
+        img[:, w // 3: w // 3 + 7] = (255, 0, 0)
+        img[:, w // 2: w // 2 + 3] = (0, 0, 255)
+    data = dec.encode(img, 87, "411", ri, ri == 2)
+    f = dec.read(data)
+    assert (f.hsamp[0], f.vsamp[0], f.hsamp[1], f.vsamp[1]) == (4, 1, 1, 1)
+    worst = max(f.range_max[1], f.range_max[2])
+    assert api.kernel_name(f, flags) == ("fused411_kernel" if flags == 0 and worst < 8190 else "idct_planes_kernel+upsample_color_kernel")
+    out = dec.reconstruct(flags)
+    exp = oracle.decode(data)
+    bad = int((out != exp).sum())
+    assert bad == 0, f"{bad} differing samples, first at {np.argwhere(out != exp)[:4].tolist()}"
+
+
 def test_fused440_packed_chroma_gate(dec, oracle):
     """Same 16-bit filter arithmetic and gate as the other packed flavours; batches of frames through the C ABI."""
     img = np.zeros((400, 272, 3), np.uint8)
@@ -451,15 +473,15 @@ def test_adversarial_coefficients_safe_flavour(oracle, generic):
 
 @pytest.mark.parametrize("sub,chroma_budget,kernel", [("420", 2046, "fused420p_kernel"), ("422", 2046, "fused422_kernel"), ("440", 2046, "fused440_kernel"),
                                                       ("422", 8189, "fused422_kernel<wide>"), ("440", 8189, "fused440_kernel<wide>"),
-                                                      ("420", 8189, "fused420_kernel"), ("444", 8189, "fused444_kernel")])
+                                                      ("420", 8189, "fused420_kernel"), ("444", 8189, "fused444_kernel"), ("411", 8189, "fused411_kernel")])
 def test_extreme_coefficients_at_the_packed_chroma_gate(dec, oracle, sub, chroma_budget, kernel):
     """The packed flavours are admitted by sum |c| q < 2047 per chroma block, the int16 sample store of the 4:2:2 / 4:4:0 /
     4:4:4 kernels by < 8190.  Blocks that sit right at those bounds with every sign pattern (DC-only, single AC, dense) drive
     the 16-bit filter sums / the 16-bit samples to their limits; the result must still be the reference's."""
     torch = _torch()
     d = api.Decoder(0)
-    if sub == "440":
-        data = dec.encode(synth.synth_image(272, 144, 5), 85, "440", 0)
+    if sub in ("440", "411"):
+        data = dec.encode(synth.synth_image(272, 144, 5), 85, sub, 0)
     else:
         data = synth.synth_jpeg(272, 144, 5, 85, sub, 0)
     f = d.read(data)

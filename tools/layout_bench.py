@@ -29,7 +29,7 @@ for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
         img[3300:3500:6, 3000:3800:6] = (255, 0, 0)
     d = api.Decoder(0)
     # Pillow has no 4:4:0: that stream comes from this library's own encoder
-    data = d.encode(img, 85, "440", 8) if sub == "440" else synth.encode_jpeg(img, 85, "444" if sub == "gray" else sub, restart_mcus=8)
+    data = d.encode(img, 85, sub, 8) if sub in ("440", "411") else synth.encode_jpeg(img, 85, "444" if sub == "gray" else sub, restart_mcus=8)
     info = d.read(data)
     n = int(info.coef_count)
     nc = info.components
