@@ -1405,3 +1405,29 @@ def test_encode_batch_of_frames_resident_in_hbm(dec, oracle):
         assert streams[i] == dec.encode(imgs[i], 80, "420", 4, True), i
         assert np.array_equal(oracle.decode(streams[i]).shape, (h, w, 3))
 
+
+
+def test_rectangle_service_band_waits(dec, oracle):
+    """The host copy of a reconstructed frame arrives in bands (one event each); requests wait for the bands they touch.
+    Requests in any order, mixed with device-side requests and with other flags, over frames of changing size, always return
+    the frame's pixels."""
+    torch = _torch()
+    rng = np.random.default_rng(99)
+    for w, h, sub in ((4000, 3000, "420"), (640, 480, "444"), (5000, 2500, "422")):
+        data = synth.synth_jpeg(w, h, 60 + w, 85, sub, 8)
+        f = dec.read(data)
+        exp = oracle.decode(data)
+        out = np.zeros((h, w, 3), np.uint8)
+        # bottom stripe first (waits for every band), then random stripes, then the top
+        ys = [h - 8] + [int(y) & ~7 for y in rng.integers(0, h - 8, 12)] + [0]
+        for y in ys:
+            dec.reconstruct_rect(0, y, w - 1, min(h, y + 8) - 1, out=out)
+            assert np.array_equal(out[y:y + 8], exp[y:y + 8]), (w, h, y)
+        # a device-side request in between, then another colour mode (new reconstruction, new bands), then the first again
+        dev = torch.zeros((h, w * 3), dtype=torch.uint8, device="cuda")
+        dec.reconstruct_rect_device(0, 0, w - 1, h - 1, [dev.data_ptr() + c for c in range(3)], [3] * 3, [w * 3] * 3)
+        assert np.array_equal(dev.cpu().numpy().reshape(h, w, 3), exp)
+        raw = dec.reconstruct(api.FLAG_NO_COLOR_TRANSFORM)
+        assert np.array_equal(raw, oracle.decode(data, use_ycbcr=0))
+        full = dec.reconstruct()
+        assert np.array_equal(full, exp)
