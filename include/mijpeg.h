@@ -147,8 +147,10 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads);
 /* The same on the GPU: the host only parses the headers and locates the restart markers, the compressed
  * bytes are uploaded (a few MB instead of ~100 MB of coefficients) and one device thread decodes one restart interval.
  * Available for single-scan Huffman sequential 8-bit frames with a restart interval and at least min_intervals
- * restart intervals (<= 0: library default, below which the host decoder is the faster one); otherwise returns
- * MIJPEG_ERR_NOT_AVAILABLE without side effects and the caller uses mijpeg_decode_coefficients.
+ * restart intervals (<= 0: library default, below which the host decoder is the faster one); otherwise -- and for every
+ * stream that turns out to be damaged (irregular restart markers, an error inside an interval, a virtual interval that does
+ * not end where the next begins): the reference's behaviour on those is that of its sequential walk, which the host decoder
+ * restates -- it returns MIJPEG_ERR_NOT_AVAILABLE and the caller uses mijpeg_decode_coefficients on the same object.
  * After it, mijpeg_coefficients() downloads the planes on first use. */
 int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals);
 

@@ -32,6 +32,8 @@ struct JPEG::Impl {
   // while the headers are walked marker by marker, and the byte ranges the client took out of the stream itself
   enum Phase { P_NONE, P_SOI, P_TABLES, P_FRAME, P_PRESCAN_INIT, P_PRESCAN, P_DECODE, P_DONE } phase = P_NONE;
   bool pulled = false;
+  int read_err = 0;            // what a failed Read reported (repeated by further Read calls)
+  std::string read_errmsg;
   size_t cursor = 0;
   std::vector<std::pair<size_t, size_t>> taken; // [from, to) ranges removed by ReadMarker / SkipMarker, ascending
   std::vector<uint8_t> effective;               // the stream without them (only built when something was taken)
@@ -133,7 +135,9 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
   p->err = 0;
   if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::Read requires a tag list with an I/O hook");
   const JPG_LONG stopflags = tags->GetTagData(JPGTAG_DECODER_STOP, 0);
-  if (p->loaded || p->phase == Impl::P_DONE) return JPG_TRUE; // "if (!m_bDecoding) return" (interface/jpeg.cpp:262-263)
+  if (p->loaded) return JPG_TRUE; // "if (!m_bDecoding) return" (interface/jpeg.cpp:262-263)
+  if (p->phase == Impl::P_DONE) // the decode failed before: reading on cannot succeed either
+    return p->fail(p->read_err ? p->read_err : JPGERR_MALFORMED_STREAM, p->read_errmsg.empty() ? "the stream could not be decoded" : p->read_errmsg.c_str());
   if (!p->pulled) {
     struct JPG_Hook *io = (struct JPG_Hook *)tags->GetTagPtr(JPGTAG_HOOK_IOHOOK);
     if (!io) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no IOHook defined to read the data from");
@@ -187,6 +191,8 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
     case Impl::P_SOI: // Decoder::ParseHeaderIncremental, first call (codestream/decoder.cpp:94-104)
       if (p->peekword() != 0xffd8) {
         p->phase = Impl::P_DONE;
+        p->read_err = JPGERR_MALFORMED_STREAM;
+        p->read_errmsg = "stream does not contain a JPEG file, SOI marker missing";
         return p->fail(JPGERR_MALFORMED_STREAM, "stream does not contain a JPEG file, SOI marker missing");
       }
       p->cursor = 2;
@@ -241,15 +247,21 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
         size = p->effective.size();
       }
       p->phase = Impl::P_DONE;
+      auto failed = [&](int code) { // remember it for later Read calls
+        const JPG_LONG r = p->fail_from_decoder(code);
+        p->read_err = p->err;
+        p->read_errmsg = p->errmsg;
+        return r;
+      };
       int rc = mijpeg_set_input(p->dec, data, size);
-      if (rc) return p->fail_from_decoder(rc);
+      if (rc) return failed(rc);
       const int threads = tags->GetTagData(JPGTAG_MIJPEG_THREADS, getenv("MIJPEG_THREADS") ? atoi(getenv("MIJPEG_THREADS")) : 0);
       // streams with enough restart intervals are entropy-decoded on the device (JPGTAG_MIJPEG_ENTROPY /
       // MIJPEG_ENTROPY: 0 = automatic, 1 = always on the host)
       const int entropy = tags->GetTagData(JPGTAG_MIJPEG_ENTROPY, getenv("MIJPEG_ENTROPY") ? atoi(getenv("MIJPEG_ENTROPY")) : 0);
       rc = entropy == 1 ? MIJPEG_ERR_NOT_AVAILABLE : mijpeg_decode_coefficients_device(p->dec, 0);
       if (rc == MIJPEG_ERR_NOT_AVAILABLE) rc = mijpeg_decode_coefficients(p->dec, threads);
-      if (rc) return p->fail_from_decoder(rc);
+      if (rc) return failed(rc);
       mijpeg_get_info(p->dec, &p->info);
       p->loaded = true;
       p->cursor = p->stream.size(); // the reference stands behind the EOI now
