@@ -154,7 +154,10 @@ def measure_traffic(info, host_planes, kernel, frames):
         return None, "rocprofv3 not found"
     if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ):
         return None, "this process runs under rocprofv3 itself: no nested counter pass"
-    tmp = tempfile.mkdtemp(prefix="mijpeg_traffic_", dir="/tmp")
+    try:
+        tmp = tempfile.mkdtemp(prefix="mijpeg_traffic_", dir="/tmp" if os.path.isdir("/tmp") else None)
+    except OSError as e:
+        return None, f"no scratch directory for the counter passes: {e!r}"
     try:
         path = os.path.join(tmp, "planes.npz")
         np.savez(path, info=np.frombuffer(bytes(info), np.uint8), planes=np.stack(host_planes))
@@ -165,7 +168,7 @@ def measure_traffic(info, host_planes, kernel, frames):
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k, None)
             r = subprocess.run([rocprof, "--pmc", ctr, "--output-format", "csv", "-d", outdir, "-o", "t", "--", sys.executable,
-                                os.path.abspath(__file__), "--traffic-child", path], cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                                os.path.abspath(__file__), "--traffic-child", path], cwd=tmp, env=env, stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, timeout=240)
             got = []
             for fn in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
