@@ -84,6 +84,11 @@ typedef struct mijpeg_info {
   int32_t xt;                /* 1 = JPEG XT profile C stream: output = 16-bit codes, see mijpeg_xt_params     */
   int32_t is_float;          /* JPGTAG_IMAGE_IS_FLOAT: the 16-bit codes are half-float bit patterns          */
   int32_t progressive;       /* 1 = progressive frame (SOF2): informational, the reconstruction is the same         */
+  int32_t coef_wide;         /* 1 = the planes hold int32 coefficients, two int16 slots each (coef_offset[] and coef_count
+                                stay in int16 units and count both slots).  Set by mijpeg_decode_coefficients for the
+                                streams -- damaged ones -- whose DC prediction or point transform leaves the 16-bit range:
+                                the reference keeps LONG coefficients (coding/blockrow.hpp) and so does this frame; it is
+                                reconstructed by the unfused kernels with the reference's 32-bit transform          */
 } mijpeg_info;
 
 /* JPEG XT (ISO/IEC 18477-7) profile C parameters of the loaded stream, valid when info.xt != 0:
@@ -189,8 +194,10 @@ int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info);
 /* JPEG XT parameters of the loaded stream (MIJPEG_ERR_OBJECT_DOESNT_EXIST if it is a plain JPEG). */
 int mijpeg_get_xt_params(mijpeg_decoder *d, mijpeg_xt_params *xt);
 
-/* Host view of a decoded component plane: blocks_h x blocks_w x 64 int16. */
+/* Host view of a decoded component plane: blocks_h x blocks_w x 64 int16 (NULL for a frame with info.coef_wide). */
 const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component);
+/* ... of a frame with info.coef_wide: blocks_h x blocks_w x 64 int32 (NULL for every other frame). */
+const int32_t *mijpeg_coefficients32(mijpeg_decoder *d, int component);
 
 /* Device pointer of the uploaded frame (coef_count int16) or NULL. */
 const int16_t *mijpeg_device_coefficients(mijpeg_decoder *d);

@@ -37,6 +37,7 @@ class MijpegInfo(C.Structure):
         ("ycbcr", C.c_int32), ("fast_arith", C.c_int32), ("coef_offset", C.c_int64 * 4),
         ("coef_count", C.c_int64), ("quant", (C.c_uint16 * 64) * 4), ("range_max", C.c_int32 * 4),
         ("sample_bytes", C.c_int32), ("xt", C.c_int32), ("is_float", C.c_int32), ("progressive", C.c_int32),
+        ("coef_wide", C.c_int32),
     ]
 
 
@@ -121,6 +122,8 @@ def lib():
         L.mijpeg_speculative_scans.restype = C.c_int64
         L.mijpeg_coefficients.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_coefficients.restype = C.c_void_p
+        L.mijpeg_coefficients32.argtypes = [C.c_void_p, C.c_int]
+        L.mijpeg_coefficients32.restype = C.c_void_p
         L.mijpeg_device_coefficients.argtypes = [C.c_void_p]
         L.mijpeg_device_coefficients.restype = C.c_void_p
         L.mijpeg_reconstruct_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int]
@@ -260,11 +263,12 @@ class Decoder:
 
     def coefficients(self, comp: int) -> np.ndarray:
         f = self.info
-        p = lib().mijpeg_coefficients(self._h, comp)
+        wide = bool(f.coef_wide)  # a damaged stream whose coefficients left the 16-bit range: int32 planes
+        p = (lib().mijpeg_coefficients32 if wide else lib().mijpeg_coefficients)(self._h, comp)
         if not p:
             raise MijpegError(-1031, "no decoded coefficients")
         n = f.blocks_w[comp] * f.blocks_h[comp] * 64
-        arr = np.ctypeslib.as_array((C.c_int16 * n).from_address(p))
+        arr = np.ctypeslib.as_array(((C.c_int32 if wide else C.c_int16) * n).from_address(p))
         return arr.reshape(f.blocks_h[comp], f.blocks_w[comp], 64).copy()
 
     def device_coefficients(self) -> int:

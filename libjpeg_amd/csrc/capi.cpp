@@ -254,6 +254,21 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   }
   rc = d->host.decode(d->coef_host, threads, cb);
   d->timing[0] = d->host.huffman_seconds;
+  if (rc == MIJPEG_ERR_OVERFLOW_PARAMETER && !d->host.is_xt()) {
+    // A coefficient beyond the 16-bit store -- only damaged streams get there: a DC prediction that runs away, a point
+    // transform on garbage.  The reference keeps LONG coefficients and reconstructs what they hold; so does this frame,
+    // in int32 planes (info.coef_wide) that the unfused kernels transform with the reference's 32-bit arithmetic.
+    if (d->device >= 0) HIP_TRY(d, hipStreamSynchronize(d->stream)); // band uploads of the first attempt read coef_host
+    rc = d->host.parse(d->data, d->size, false);
+    if (rc) return set_error(d, rc, d->host.error.message);
+    rc = ensure_coef_store(d, (size_t)f.coef_count * 2);
+    if (rc) return rc;
+    rc = d->host.decode_wide((int32_t *)d->coef_host, threads);
+    d->timing[0] += d->host.huffman_seconds;
+    if (rc) return set_error(d, rc, d->host.error.message);
+    if (d->device >= 0 && copy_err == hipSuccess)
+      copy_err = hipMemcpyAsync(d->coef_dev, d->coef_host, (size_t)f.coef_count * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
+  }
   if (rc) return set_error(d, rc, d->host.error.message);
   if (d->device >= 0 && d->host.is_xt() && copy_err == hipSuccess) {
     // the residual codestream's planes sit behind the legacy planes in the same buffer
@@ -301,9 +316,19 @@ int mijpeg_get_xt_params(mijpeg_decoder *d, mijpeg_xt_params *xt)
   return MIJPEG_OK;
 }
 
+const int32_t *mijpeg_coefficients32(mijpeg_decoder *d, int component)
+{
+  if (!d || !d->decoded || component < 0 || component >= d->host.info.components || !d->host.info.coef_wide) return nullptr;
+  return (const int32_t *)(d->coef_host + d->host.info.coef_offset[component]); // wide frames are decoded on the host
+}
+
 const int16_t *mijpeg_coefficients(mijpeg_decoder *d, int component)
 {
   if (!d || !d->decoded || component < 0 || component >= d->host.info.components) return nullptr;
+  if (d->host.info.coef_wide) {
+    set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "the frame holds 32-bit coefficients (info.coef_wide): mijpeg_coefficients32");
+    return nullptr;
+  }
   if (d->host_planes_stale) { // decoded on the device: fetch once
     if (hipSetDevice(d->device) != hipSuccess) return nullptr;
     if (ensure_coef_store(d, (size_t)d->host.info.coef_count, true)) return nullptr;
@@ -544,7 +569,9 @@ static int evaluate_entropy_status(mijpeg_decoder *d, HostDecoder *const *hosts,
 {
   for (int i = 0; i < n; i++) {
     const uint32_t *st = status_host + 8 * i;
-    if (st[0] == HUFF_ERR_OVERFLOW) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
+    // A DC prediction that leaves the 16-bit store (only damaged streams get there): the host decoder keeps 32-bit planes
+    if (st[0] == HUFF_ERR_OVERFLOW)
+      return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "on-device entropy decoding: a DC coefficient leaves the 16 bit coefficient store (damaged stream); the host decoder keeps 32-bit coefficients for it");
     // Damaged entropy coded data: which error the reference reports (or whether it decodes on after a resynchronisation)
     // depends on its sequential walk; the host decoder restates that walk, the device decoder does not try to
     if (st[0]) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the entropy coded data is damaged: the host decoder walks such streams like the reference does (DESIGN 4.0)");
@@ -912,7 +939,8 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   HIP_TRY(d, hipStreamSynchronize(d->stream));
   if (any_dwalk)
     for (int i = 0; i < n; i++) {
-      if (walk_status_host[i] & 2) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
+      if (walk_status_host[i] & 2)
+        return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "on-device entropy decoding: a DC coefficient leaves the 16 bit coefficient store (damaged stream); the host decoder keeps 32-bit coefficients for it");
       if (walk_status_host[i]) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "speculative decoding settled on something that is not a decode of the image");
     }
   d->phase_device = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb1).count();  // upload + kernel + status
@@ -1061,7 +1089,8 @@ static int finish_batch(mijpeg_decoder *d)
       for (int r = 1; r <= rounds; r++)
         if (d->pend_walk_flags[r]) d->walk_rounds = r + 1;
       for (int i = 0; i < pn && d->pend_walk_status; i++) {
-        if (d->pend_walk_status[i] & 2) return set_error(d, MIJPEG_ERR_OVERFLOW_PARAMETER, "DC coefficient exceeds the 16 bit coefficient store");
+        if (d->pend_walk_status[i] & 2)
+          return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "on-device entropy decoding: a DC coefficient leaves the 16 bit coefficient store (damaged stream); the host decoder keeps 32-bit coefficients for it");
         if (d->pend_walk_status[i]) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "speculative decoding settled on something that is not a decode of the image");
       }
     }
@@ -1229,6 +1258,7 @@ static bool fits32(const mijpeg_batch *b)
 {
   const mijpeg_info &f = b->info;
   const uint64_t lim = 0xffffffffull;
+  if (f.coef_wide) return false; // int32 coefficients (damaged stream): the unfused kernels' business
   for (int c = 0; c < f.components; c++)
     if ((uint64_t)f.blocks_w[c] * (uint64_t)f.blocks_h[c] * 128u > lim) return false;
   if (f.xt && b->xt)
@@ -1351,6 +1381,7 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (use_fused440(b)) return chroma_packed(b->info) ? "fused440_kernel" : "fused440_kernel<wide>";
   if (use_fused411(b)) return "fused411_kernel";
   if (use_fused1(b)) return "fused1_kernel";
+  if (b->info.coef_wide) return "idct_planes_long_kernel+upsample_color_kernel";
   return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : b->info.xt ? "idct_planes_kernel+xt_merge_kernel"
                                                                                                  : "idct_planes_kernel+upsample_color_kernel";
 }
@@ -1389,7 +1420,8 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   const mijpeg_info &f = b->info;
   if ((f.precision != 8 && f.precision != 12) || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
   if (f.xt && (!b->xt || f.components != 3)) return MIJPEG_ERR_MISSING_PARAMETER;
-  const bool fast = fast_ok(b);
+  if (f.coef_wide && (f.xt || b->quant_dev)) return MIJPEG_ERR_INVALID_PARAMETER; // int32 planes: single plain JPEG frames only
+  const bool fast = fast_ok(b) && !f.coef_wide;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   const bool f444 = use_fused444(b), fxt = use_fusedxt(b), f422 = use_fused422(b), f440 = use_fused440(b), f411 = use_fused411(b), f1 = use_fused1(b);
@@ -1488,6 +1520,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     // (Frame::HiddenPrecisionOf, marker/frame.cpp:368-373)
     const int lprec = f.precision + (f.xt ? b->xt->hidden_bits : 0);
     for (int c = 0; c < f.components; c++) plane(c, f, c, lprec);
+    if (f.coef_wide) { a.wide_first = 0; a.wide_count = f.components; a.wide_long = 1; }
     a.maxval = (1 << lprec) - 1;
     a.dcshift = (1 << (lprec - 1)) << 4;
     if (f.xt) {

@@ -102,6 +102,11 @@ public:
   // bands of frame MCU rows become final (while later bands are still being decoded when the
   // last scan is interleaved; otherwise once at the end).  Used for streaming uploads; may be empty.
   int decode(int16_t *coef, int threads, const std::function<void(int, int)> &on_rows_done);
+  // The same into int32 planes (same plane offsets, counted in int32 elements), for the streams decode() turns down with
+  // MIJPEG_ERR_OVERFLOW_PARAMETER: damaged ones whose DC prediction (or point transform) leaves the 16-bit range.  The
+  // reference keeps LONG coefficients and reconstructs whatever they hold.  Plain JPEG only.  On success info.coef_wide
+  // is set and info.coef_offset[] / coef_count count the two int16 slots of every coefficient.
+  int decode_wide(int32_t *coef, int threads);
   // The stream is damaged in a way the parallel decoders (host and device) must not touch: restart markers missing,
   // out of sequence or in excess, or a sequential scan with a point transform.  decode() then walks the stream
   // sequentially the way the reference does (resynchronisation, grey intervals; RefWalker in host_decoder.cpp).

@@ -2025,6 +2025,46 @@ __global__ __launch_bounds__(64) void idct_planes_wide_kernel(const GenericArgs 
 }
 
 // ==============================================================================================
+// generic path, kernel 1l: planes of a frame with info.coef_wide -- a damaged stream whose DC prediction (or point
+// transform) left the 16-bit range.  The reference keeps LONG coefficients and transforms them with the frame's ordinary
+// IDCT<0,LONG> (dct/idct.cpp:225-335): the statements of idct_planes_kernel's SAFE flavour in wrapping 32-bit
+// arithmetic, on int32 coefficients.  One lane per block; rare, and about correctness only.
+// ==============================================================================================
+__global__ __launch_bounds__(64) void idct_planes_long_kernel(const GenericArgs a)
+{
+  const int comp = a.wide_first + blockIdx.y % a.wide_count, frame = blockIdx.y / a.wide_count;
+  const int nblocks = a.bw[comp] * a.bh[comp];
+  const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk >= nblocks) return;
+  const int32_t *__restrict__ src =
+      reinterpret_cast<const int32_t *>(a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp]) + (int64_t)blk * 64;
+  int v[64];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const i32x4 c = reinterpret_cast<const i32x4 *>(src)[r];
+    v[r * 4 + 0] = mulc<false>(c.x, a.q[comp][r * 4 + 0]);
+    v[r * 4 + 1] = mulc<false>(c.y, a.q[comp][r * 4 + 1]);
+    v[r * 4 + 2] = mulc<false>(c.z, a.q[comp][r * 4 + 2]);
+    v[r * 4 + 3] = mulc<false>(c.w, a.q[comp][r * 4 + 3]);
+  }
+  v[0] = addw(v[0], a.dcoff[comp]);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    idct_1d<false, 9>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+#pragma unroll
+  for (int c = 0; c < 8; c++) idct_1d<false, 12>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+  const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
+  const int pitch = a.bw[comp] * 8;
+  int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    i32x4 *d = reinterpret_cast<i32x4 *>(dst + (int64_t)r * pitch);
+    d[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
+    d[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
+  }
+}
+
+// ==============================================================================================
 // generic path, kernel 2: one thread = one line of one 8-pixel output group; upsample every
 // component (any factor 1..4) exactly like the reference's buffer code, transform, store.
 // ==============================================================================================
@@ -2555,7 +2595,8 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   if (a.wide_count > 0) {
     int wb = 0;
     for (int c = a.wide_first; c < a.wide_first + a.wide_count; c++) wb = max(wb, a.bw[c] * a.bh[c]);
-    hipLaunchKernelGGL(idct_planes_wide_kernel, dim3((wb + 63) / 64, a.wide_count * a.frames), dim3(64), 0, stream, a);
+    if (a.wide_long) hipLaunchKernelGGL(idct_planes_long_kernel, dim3((wb + 63) / 64, a.wide_count * a.frames), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(idct_planes_wide_kernel, dim3((wb + 63) / 64, a.wide_count * a.frames), dim3(64), 0, stream, a);
   }
   const int groups = (a.width + 7) >> 3;
   const int bs = groups >= 256 ? 256 : 64;

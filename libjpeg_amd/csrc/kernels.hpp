@@ -67,7 +67,8 @@ struct GenericArgs {
   int32_t legacy32;            // legacy colour stage may run in 32 bits (8-bit frame that passed the range check)
   int32_t ltable_entries;      // entries per L table: 256 << hidden bits of the legacy frame
   int32_t wide_first, wide_count; // planes [wide_first, wide_first + wide_count) hold int32 coefficients at coef_off (in
-                                  // int16 units) and are transformed by idct_planes_wide_kernel (IDCT<4,QUAD>)
+                                  // int16 units) and are transformed by idct_planes_wide_kernel (IDCT<4,QUAD>) ...
+  int32_t wide_long;              // ... or, set, by idct_planes_long_kernel (IDCT<0,LONG>): frames with info.coef_wide
   const int32_t *ltable;       // device: L lookup tables [3][ltable_entries]
   const int32_t *qdev;         // or null: per-frame tables in device memory, [frames][4][64] deltas << 4 (replace q; not for JPEG XT)
   // JPEG XT beyond the default subset (mijpeg_xt_params.general): literal 64-bit merge with matrices and table gathers

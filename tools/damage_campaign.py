@@ -72,7 +72,7 @@ def main():
     with ProcessPoolExecutor(a.jobs) as ex:
         for (path, kind, verdict, detail), w in zip(ex.map(one, work, chunksize=8), work):
             stats[verdict] = stats.get(verdict, 0) + 1
-            if verdict not in ("ok", "skip", "ref-hangs", "int16-gate"):
+            if verdict not in ("ok", "skip", "ref-hangs"):
                 bad += 1
                 print(f"{verdict:16s} {path:36s} {kind:16s} {detail}")
                 if a.save:

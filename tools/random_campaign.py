@@ -131,9 +131,7 @@ for t in range(ND):
     except api.MijpegError as e:
         perr = e.code
     verdict = "ok"
-    if perr == -1028 and eerr != -1028:
-        verdict = "int16-gate"
-    elif perr != eerr:
+    if perr != eerr:
         verdict = "code"
     elif perr == 0:
         got = d.reconstruct()
