@@ -1297,6 +1297,37 @@ static bool use_fused420(const mijpeg_batch *b)
          !(b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM)) && fits32(b);
 }
 
+// 12-bit 4:2:0 frames (SOF1, P = 12) inside the ranges the 12-bit flavour of the fused kernel is exact for: every delta << 4 a
+// signed 16-bit operand; sum |c| q < 49152 bounds every butterfly intermediate by 1573 * 16 * 49152 < 2^31 (first pass;
+// the second pass sees at most 22.2 * range_max per column) and every multiplicand by 2^23; chroma sum |c| q < 45056 bounds
+// the chroma samples (times 16) by 4.02 * 45056 + 2 < 181 200 (|basis| <= 1/4 per coefficient, the 9-bit constants and the
+// roundings add < 0.5 %), whose products with the colour constants (11485; 2819 + 5850; 14516 taken as 4 * 3629) fit 32 bits
+static bool use_fused420_12(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  static const bool off = getenv("MIJPEG_NO_F420_12") != nullptr; // A-B comparisons
+  if (off || !is_420(f) || !f.ycbcr || f.xt || f.precision != 12 ||
+      (b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM | MIJPEG_FLAG_FORCE_SAFE)) || !fits32(b))
+    return false;
+  if (f.range_max[0] <= 0 || f.range_max[0] >= 49152 || f.range_max[1] >= 45056 || f.range_max[2] >= 45056) return false;
+  for (int c = 0; c < 3; c++)
+    for (int i = 0; i < 64; i++)
+      if (f.quant[f.quant_index[c]][i] > 2047) return false;
+  return true;
+}
+
+// 12-bit single-component frames: the butterflies' bound alone
+static bool use_fused1_12(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  static const bool off = getenv("MIJPEG_NO_F1_12") != nullptr; // A-B comparisons
+  if (off || f.components != 1 || f.xt || f.precision != 12 || (b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_FORCE_SAFE)) || !fits32(b)) return false;
+  if (f.range_max[0] <= 0 || f.range_max[0] >= 49152) return false;
+  for (int i = 0; i < 64; i++)
+    if (f.quant[f.quant_index[0]][i] > 2047) return false;
+  return true;
+}
+
 // the packed flavour filters (Cb, Cr) pairs in 16 bits: every chroma sample * 16 is bounded by 4 * range_max, and the
 // filter sums a + 3 b + r by four times that
 static bool use_fused420p(const mijpeg_batch *b)
@@ -1381,6 +1412,8 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (use_fused440(b)) return chroma_packed(b->info) ? "fused440_kernel" : "fused440_kernel<wide>";
   if (use_fused411(b)) return "fused411_kernel";
   if (use_fused1(b)) return "fused1_kernel";
+  if (use_fused420_12(b)) return "fused420_kernel<12>";
+  if (use_fused1_12(b)) return "fused1_kernel<12>";
   if (b->info.coef_wide) return "idct_planes_long_kernel+upsample_color_kernel";
   return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : b->info.xt ? "idct_planes_kernel+xt_merge_kernel"
                                                                                                  : "idct_planes_kernel+upsample_color_kernel";
@@ -1406,7 +1439,7 @@ static size_t expanded_tables_bytes(const mijpeg_batch *b) { return b->quant_dev
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
 {
   if (!b) return 0;
-  if (use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused411(b) || use_fused1(b)) return expanded_tables_bytes(b);
+  if (use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused411(b) || use_fused1(b) || use_fused420_12(b) || use_fused1_12(b)) return expanded_tables_bytes(b);
   if (use_fusedxt(b)) return LUT_BYTES;
   // [LUT_BYTES: L lookup tables (JPEG XT, up to 3 x 4096 entries)] [per frame: int32 sample planes, one sample per
   // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients] [expanded per-frame tables]
@@ -1425,6 +1458,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
   hipStream_t s = (hipStream_t)stream;
   int rc;
   const bool f444 = use_fused444(b), fxt = use_fusedxt(b), f422 = use_fused422(b), f440 = use_fused440(b), f411 = use_fused411(b), f1 = use_fused1(b);
+  const bool f420_12 = use_fused420_12(b), f1_12 = use_fused1_12(b);
   if (fxt && (!b->workspace || b->workspace_bytes < LUT_BYTES)) return MIJPEG_ERR_MISSING_PARAMETER;
   const int32_t *qdev = nullptr;
   if (b->quant_dev) {
@@ -1434,7 +1468,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     if (launch_expand_deltas(b->quant_dev, dst, b->frames, s)) return MIJPEG_ERR_DEVICE;
     qdev = dst;
   }
-  if (use_fused420(b) || f444 || fxt || f422 || f440 || f411 || f1) {
+  if (use_fused420(b) || f444 || fxt || f422 || f440 || f411 || f1 || f420_12 || f1_12) {
     FusedXtArgs xa;
     memset(&xa, 0, sizeof(xa));
     Fused420Args &a = xa.base;
@@ -1480,7 +1514,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
       xa.ext.aligned16 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 15) == 0;
       rc = launch_fusedxt420(xa, s);
     } else
-      rc = f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
+      rc = f420_12 ? launch_fused420_12(a, s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

@@ -545,9 +545,12 @@ __device__ __forceinline__ void f420_chroma_edges(const Fused420Args &a, int (*c
   }
 }
 
-template <bool FAST, int MINW, bool QDEV>
+// P = 12 (FAST only): 12-bit frames (SOF1, P = 12) -- the same transforms and filters on samples sixteen times as large, the
+// colour stage rearranged so that it stays inside 32 bits (see there), 16-bit samples out (clamp 4095).
+template <bool FAST, int MINW, bool QDEV, int P = 8>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fused420Args a)
 {
+  static_assert(P == 8 || (P == 12 && FAST), "12-bit frames: FAST flavour only (the host checks the ranges)");
   __shared__ __attribute__((aligned(16))) int cplane[2][F420_CROWS * F420_CPITCH];
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
 
@@ -600,10 +603,10 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 
   // uniform frame base + 32-bit lane offsets (a frame of pixels is far below 4 GB)
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
-  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * (P == 12 ? 6u : 3u);
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = a.aligned8 && npx == 8;
+  const bool fast_store = (P == 12 ? (((uintptr_t)a.out | (uintptr_t)a.out_frame_stride | (uintptr_t)a.row_stride) & 15) == 0 : a.aligned8 != 0) && npx == 8;
 
   // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns pc = 4 bx + 3 + j
   const int *cb_base = cplane[0] + (4 * by) * F420_CPITCH + 4 * bx;
@@ -651,7 +654,45 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
       hfilt(vr, ur);
       if (l < nln) {
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
-        if (FAST) {
+        if (FAST && P == 12) {
+          // (y * 8192 + (cb - 32768) * Lb + (cr - 32768) * Lr + 65536) >> 17, clamped to [0, 4095] (ycbcrtrafo.cpp:842-856,
+          // :921-936; the reference accumulates in 64 bits).  With y = y' + 32768, cb - 32768 = cb' (no level shift in the
+          // transforms) and c L = q 2^13 + r, 0 <= r < 2^13:  ((y' + 32776 + q) 2^13 + r) >> 17 = (y' + 32776 + q) >> 4
+          // exactly.  The products must fit 32 bits: |c| <= 4.02 * 45056 + 2 < 181 200 by the host's range check (an IDCT
+          // output times 16 is at most 4 sum |c_k| q_k; the 9-bit constants and the two roundings add < 0.5 %), times 11485
+          // < 2^31; Lb = 14516 = 4 * 3629 is applied as (c * 3629) >> 11, which is the same number.
+          static_assert(L_CB_B % 4 == 0, "the blue product is taken at a quarter of the constant");
+          const int KY = 32768 + 8;
+          int rr[8], gg[8], bb[8];
+#pragma unroll
+          for (int x = 0; x < 8; x++) {
+            const int yk = yv[l * 8 + x] + KY;
+            rr[x] = (yk + (__mul24(ur[x], L_CR_R) >> 13)) >> 4;
+            gg[x] = (yk + (mad24(ur[x], -L_CR_G, __mul24(ub[x], -L_CB_G)) >> 13)) >> 4;
+            bb[x] = (yk + (__mul24(ub[x], L_CB_B / 4) >> 11)) >> 4;
+          }
+          auto c12 = [](int v) { return (unsigned)min(max(v, 0), 4095); };
+          if (fast_store) {
+            unsigned w[12]; // 48 bytes r0 g0 b0 r1 ... b7, 16-bit samples
+#pragma unroll
+            for (int x = 0; x < 8; x += 2) {
+              w[3 * (x / 2) + 0] = c12(rr[x]) | (c12(gg[x]) << 16);
+              w[3 * (x / 2) + 1] = c12(bb[x]) | (c12(rr[x + 1]) << 16);
+              w[3 * (x / 2) + 2] = c12(gg[x + 1]) | (c12(bb[x + 1]) << 16);
+            }
+            u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+            __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
+            __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
+            __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+          } else {
+            uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
+#pragma unroll
+            for (int x = 0; x < 8; x++)
+              if (x < npx) {
+                d16[3 * x] = (uint16_t)c12(rr[x]); d16[3 * x + 1] = (uint16_t)c12(gg[x]); d16[3 * x + 2] = (uint16_t)c12(bb[x]);
+              }
+          }
+        } else if (FAST) {
           // y, cb, cr arrive WITHOUT the level shift (DCOFF = false): with y = y' + 2048 and cb - 2048 = cb' the
           // reference's (y * 8192 + (cb - 2048) * Lb + (cr - 2048) * Lr + 65536) >> 17 becomes
           // (y' * 8192 + K + cb' * Lb + cr' * Lr) >> 17 with one constant K for all three channels
@@ -1850,7 +1891,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
 // One lane, one block: fetch, dequantise, transform, COLOR_TO_INT (x + 8) >> 4 with the level shift the fast transform
 // leaves out folded into the rounding constant, clamp, eight bytes per line.  Samples travel as packed int16 from the
 // addition on (range check: |sample * 16| <= 4 * range_max < 2^15).  Algorithmic bytes: 2 B in + 1 B out per pixel.
-template <bool QDEV>
+// P = 12: 12-bit frames -- the same transform, 16-bit samples out (clamp 4095), samples as 32-bit values throughout.
+template <bool QDEV, int P = 8>
 __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
@@ -1888,10 +1930,35 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
   int v[64];
   dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), v);
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
-  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * (P == 12 ? 2u : 1u);
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = a.aligned8 && npx == 8;
+  const bool fast_store = (P == 12 ? (((uintptr_t)a.out | (uintptr_t)a.out_frame_stride | (uintptr_t)a.row_stride) & 15) == 0 : a.aligned8 != 0) && npx == 8;
+  if (P == 12) {
+    // COLOR_TO_INT with the level shift 2^11 << 4 the transform left out: (x + 32768 + 8) >> 4, clamped to [0, 4095]
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+      if (l < nln) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const unsigned lo = (unsigned)min(max((v[l * 8 + 2 * i] + (32768 + 8)) >> 4, 0), 4095);
+          const unsigned hi = (unsigned)min(max((v[l * 8 + 2 * i + 1] + (32768 + 8)) >> 4, 0), 4095);
+          w[i] = lo | (hi << 16);
+        }
+        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+        if (fast_store) {
+          __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4 *>(dst));
+        } else {
+          uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
+#pragma unroll
+          for (int x = 0; x < 8; x++)
+            if (x < npx) d16[x] = (uint16_t)(w[x >> 1] >> (16 * (x & 1)));
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int l = 0; l < 8; l++) {
     if (l < nln) {
@@ -2498,6 +2565,15 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
+int launch_fused420_12(const Fused420Args &a, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  if (total == 0) return 0;
+  if (a.qdev) hipLaunchKernelGGL((fused420_kernel<true, 2, true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused420_kernel<true, 2, false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
 int launch_fused420p(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
@@ -2539,8 +2615,16 @@ int launch_fused411(const Fused420Args &a, hipStream_t stream)
 int launch_fused1(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  if (a.qdev) hipLaunchKernelGGL(fused1_kernel<true>, dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL(fused1_kernel<false>, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) hipLaunchKernelGGL((fused1_kernel<true, 8>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused1_kernel<false, 8>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused1_12(const Fused420Args &a, hipStream_t stream)
+{
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  if (a.qdev) hipLaunchKernelGGL((fused1_kernel<true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused1_kernel<false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -63,3 +63,37 @@ def synth_hdr(width: int, height: int, seed: int = 99) -> np.ndarray:
     gain = np.exp2(4.0 * np.sin(x / 400.0) + 2.0 * np.cos(y / 300.0))[..., None]
     noise = 1.0 + rng.normal(0.0, 0.01, size=(height, width, 3)).astype(np.float32)
     return np.maximum(base ** 2.2 * gain * noise, 1e-4).astype(np.float32)
+
+
+def to_12bit(jpeg8: bytes, scale: int = 16) -> bytes:
+    """An 8-bit Huffman sequential JPEG (baseline tables, 8-bit quantiser entries) -> the 12-bit extended sequential stream
+    (SOF1, P = 12) with the same entropy coded data and every quantiser delta multiplied by `scale` (16-bit DQT entries): the
+    picture it decodes to is the 8-bit one times `scale` -- synthetic 12-bit content of any size without a 12-bit encoder.
+    (There is no network and no 12-bit Pillow; the reference's own encoder writes the small 12-bit fixtures of tests/golden.)"""
+    out = bytearray(jpeg8[:2])
+    p = 2
+    while p + 4 <= len(jpeg8):
+        assert jpeg8[p] == 0xFF, "marker expected"
+        m = jpeg8[p + 1]
+        ln = (jpeg8[p + 2] << 8) | jpeg8[p + 3]
+        seg = jpeg8[p + 4:p + 2 + ln]
+        if m == 0xDB:  # DQT: Pq = 0 tables -> Pq = 1, deltas * scale
+            q, body = 0, bytearray()
+            while q < len(seg):
+                pq, tq = seg[q] >> 4, seg[q] & 15
+                assert pq == 0, "8-bit quantiser tables expected"
+                body.append(0x10 | tq)
+                for v in seg[q + 1:q + 65]:
+                    w = min(65535, v * scale)
+                    body += bytes((w >> 8, w & 255))
+                q += 65
+            out += bytes((0xFF, 0xDB, (len(body) + 2) >> 8, (len(body) + 2) & 255)) + body
+        elif m == 0xC0 or m == 0xC1:  # SOF0 / SOF1, P = 8 -> SOF1, P = 12
+            out += bytes((0xFF, 0xC1)) + jpeg8[p + 2:p + 4] + bytes((12,)) + seg[1:]
+        else:
+            out += jpeg8[p:p + 2 + ln]
+        p += 2 + ln
+        if m == 0xDA:
+            out += jpeg8[p:]
+            break
+    return bytes(out)

@@ -1431,3 +1431,149 @@ def test_rectangle_service_band_waits(dec, oracle):
         assert np.array_equal(raw, oracle.decode(data, use_ycbcr=0))
         full = dec.reconstruct()
         assert np.array_equal(full, exp)
+
+
+# ------------------------------------------------------------------------------------------------------
+# 12-bit 4:2:0 frames on the fused kernel (fused420_kernel<12>)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,dri,scale", [(200, 120, 8, 16), (272, 144, 0, 16), (129, 71, 3, 9), (640, 368, 4, 16), (1, 1, 0, 16), (17, 250, 1, 5)])
+def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale):
+    """12-bit extended sequential 4:2:0 frames (synth.to_12bit: the 8-bit stream's entropy coded data with deltas times
+    `scale`): the 12-bit flavour of the fused kernel against the oracle (which the CPU tests pin against the reference binary
+    on the same kind of stream), against the unfused kernels, and through the stripe service."""
+    data = synth.to_12bit(synth.synth_jpeg(w, h, 11 + w, 85, "420", dri), scale)
+    f = dec.read(data)
+    assert f.precision == 12 and f.sample_bytes == 2
+    assert api.kernel_name(f) == "fused420_kernel<12>", list(f.range_max)
+    exp = oracle.decode16(data)
+    out = dec.reconstruct()
+    assert out.dtype == np.uint16 and np.array_equal(out, exp)
+    assert np.array_equal(dec.reconstruct(api.FLAG_FORCE_GENERIC), exp)
+    stripes = np.zeros_like(out)
+    for y in range(0, h, 16):
+        dec.reconstruct_rect(0, y, w - 1, min(h, y + 16) - 1, out=stripes)
+    assert np.array_equal(stripes, exp)
+    if oracle.have_reference() and w > 1:
+        rpx, rerr = oracle.reference_decode_status(data)
+        assert rerr == 0 and np.array_equal(np.asarray(rpx).reshape(exp.shape), exp)
+
+
+@pytest.mark.parametrize("luma_budget,chroma_budget,fused", [(49151, 45055, True), (49151, 45056, False), (49152, 1000, False), (30000, 45055, True), (45055, 32767, True)])
+def test_extreme_coefficients_at_the_12bit_gates(oracle, luma_budget, chroma_budget, fused):
+    """fused420_kernel<12> is admitted by sum |c| q < 49152 (the 32-bit butterflies) and < 45056 for the chroma planes (the
+    32-bit colour products).  Blocks right at those bounds with every sign pattern (DC-only, one AC coefficient, dense) must still come
+    out like the reference's 64-bit arithmetic; one step beyond, the unfused kernels take the frame (and agree as well)."""
+    torch = _torch()
+    W, H = 272, 144
+    d = api.Decoder(0)
+    data = synth.to_12bit(synth.synth_jpeg(W, H, 5, 85, "420", 0))
+    f = d.read(data)
+    d.close()
+    rng = np.random.default_rng(luma_budget + chroma_budget)
+    info, _ = oracle.decode_coefficients(data)
+    for t in range(4):
+        for i in range(64):
+            info.quant[t][i] = 3 if i else 4
+            f.quant[t][i] = info.quant[t][i]
+    info.scan_state_valid = 0
+    planes = []
+    for c in range(3):
+        shape = (info.bh[c], info.bw[c], 64)
+        p = np.zeros(shape, np.int32)
+        kind = rng.integers(0, 4, size=shape[:2])
+        sign = rng.choice([-1, 1], size=shape[:2])
+        budget = chroma_budget if c else luma_budget
+        p[..., 0] = np.where(kind == 0, sign * (budget // 4), 0)  # DC alone: q[0] = 4
+        k = rng.integers(1, 64, size=shape[:2])
+        for by in range(shape[0]):
+            for bx in range(shape[1]):
+                if kind[by, bx] == 1:
+                    p[by, bx, k[by, bx]] = sign[by, bx] * (budget // 3)  # one AC coefficient carries everything
+                elif kind[by, bx] >= 2:
+                    v = rng.integers(-40, 41, size=64)
+                    v[0] = 0
+                    v = (v * ((budget // 3) / max(1, int(np.abs(v).sum())))).astype(np.int64)
+                    v[1] += np.sign(v[1] or 1) * (budget // 3 - int(np.abs(v).sum()))
+                    p[by, bx] = v
+        # one block per plane spends the budget to the last unit: DC (q = 4) plus one AC step (q = 3)
+        p[0, 0] = 0
+        nb = next(b for b in range(4) if (budget - 3 * b) % 4 == 0)
+        p[0, 0, 0] = (budget - 3 * nb) // 4
+        p[0, 0, 9] = -nb
+        planes.append(p)
+    for c in range(3):
+        q = np.array(info.quant[info.tq[c]], np.int64)
+        f.range_max[c] = int((np.abs(planes[c]).astype(np.int64) * q).sum(axis=2).max())
+    assert f.range_max[0] <= luma_budget and f.range_max[1] <= chroma_budget and f.range_max[2] <= chroma_budget
+    assert f.range_max[0] == luma_budget and f.range_max[1] == chroma_budget, list(f.range_max)
+    assert (api.kernel_name(f) == "fused420_kernel<12>") == fused, (api.kernel_name(f), list(f.range_max))
+    exp = oracle.reconstruct16(info, planes)
+    coef = torch.from_numpy(np.concatenate([p.astype(np.int16).reshape(-1) for p in planes])).cuda()
+    row = W * 6
+    out = torch.zeros((H, row), dtype=torch.uint8, device="cuda")
+    ws_bytes = api.workspace_bytes(f, 1)
+    ws = torch.zeros(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
+    api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, row, H * row, workspace=ws.data_ptr(), workspace_bytes=ws_bytes,
+                           stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy().view(np.uint16).reshape(H, W, 3)
+    bad = int((res != exp).sum())
+    assert bad == 0, f"{api.kernel_name(f)}: {bad} differing samples, first at {np.argwhere(res != exp)[:4].tolist()}"
+
+
+def test_fused420_12bit_large_frame_properties(dec):
+    """A 4K 12-bit frame: fused and unfused kernels agree band by band; an odd row stride takes the unaligned store path."""
+    data = synth.to_12bit(synth.synth_jpeg(3840, 2160, 77, 85, "420", 8))
+    f = dec.read(data)
+    assert api.kernel_name(f) == "fused420_kernel<12>", list(f.range_max)
+    a = dec.reconstruct()
+    b = dec.reconstruct(api.FLAG_FORCE_GENERIC)
+    assert [_sha(a[y:y + 135]) for y in range(0, 2160, 135)] == [_sha(b[y:y + 135]) for y in range(0, 2160, 135)]
+
+
+@pytest.mark.parametrize("w,h,scale", [(200, 120, 16), (129, 71, 9), (1000, 700, 16), (1, 1, 16), (7, 300, 3)])
+def test_fused1_12bit_vs_oracle(dec, oracle, w, h, scale):
+    """12-bit single-component frames (what medical pictures are) on fused1_kernel<12>: against the oracle, the unfused kernels,
+    the reference binary where present; plus one block per gate value through the stateless launch."""
+    import io
+
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(synth.synth_image(w, h, 21 + w)).convert("L").save(b, "JPEG", quality=85)
+    data = synth.to_12bit(b.getvalue(), scale)
+    f = dec.read(data)
+    assert f.precision == 12 and f.components == 1 and api.kernel_name(f) == "fused1_kernel<12>", list(f.range_max)
+    exp = oracle.decode16(data)
+    out = dec.reconstruct()
+    assert out.dtype == np.uint16 and np.array_equal(out.reshape(exp.shape), exp)
+    assert np.array_equal(dec.reconstruct(api.FLAG_FORCE_GENERIC).reshape(exp.shape), exp)
+    if oracle.have_reference() and w > 1:
+        rpx, rerr = oracle.reference_decode_status(data)
+        assert rerr == 0 and np.array_equal(np.asarray(rpx).reshape(exp.shape), exp)
+    # the gate: sum |c| q = 49151 in every block (DC alone, one AC coefficient, both signs) stays on the kernel, 49152 leaves it
+    torch = _torch()
+    info, _ = oracle.decode_coefficients(data)
+    for i in range(64):
+        info.quant[0][i] = 1
+        f.quant[0][i] = 1
+    info.scan_state_valid = 0
+    rng = np.random.default_rng(w)
+    p = np.zeros((info.bh[0], info.bw[0], 64), np.int32)
+    k = rng.integers(0, 64, size=p.shape[:2])
+    sgn = rng.choice([-1, 1], size=p.shape[:2])
+    for by in range(p.shape[0]):
+        for bx in range(p.shape[1]):
+            p[by, bx, k[by, bx]] = sgn[by, bx] * 24575
+            p[by, bx, (k[by, bx] + 7) % 64] = -sgn[by, bx] * 24576
+    f.range_max[0] = 49151
+    assert api.kernel_name(f) == "fused1_kernel<12>"
+    f.range_max[0] = 49152
+    assert api.kernel_name(f) != "fused1_kernel<12>"
+    f.range_max[0] = 49151
+    expg = oracle.reconstruct16(info, [p])
+    coef = torch.from_numpy(p.astype(np.int16).reshape(-1)).cuda()
+    row = w * 2
+    outg = torch.zeros((h, row), dtype=torch.uint8, device="cuda")
+    api.launch_reconstruct(f, coef.data_ptr(), outg.data_ptr(), 1, row, h * row, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(outg.cpu().numpy().view(np.uint16).reshape(expg.shape), expg)

@@ -15,6 +15,8 @@ from libjpeg_amd import api, synth  # noqa: E402
 W, H, F = 7680, 4320, 8
 hip = C.cdll.LoadLibrary("libamdhip64.so")
 for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
+    p12 = sub.endswith("_12")  # 12-bit frame: the 8-bit stream's entropy coded data with deltas times 16 (synth.to_12bit)
+    sub = sub[:-3] if p12 else sub
     img = synth.synth_image(W, H, 1234, channels=1 if sub == "gray" else 3)
     if os.environ.get("SATURATED") == "1" and sub != "gray":
         # saturated graphics over the synthetic picture: hard-edged bars of pure colours push the chroma range check of the
@@ -30,6 +32,8 @@ for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
     d = api.Decoder(0)
     # Pillow has no 4:4:0: that stream comes from this library's own encoder
     data = d.encode(img, 85, sub, 8) if sub in ("440", "411") else synth.encode_jpeg(img, 85, "444" if sub == "gray" else sub, restart_mcus=8)
+    if p12:
+        data = synth.to_12bit(data)
     info = d.read(data)
     n = int(info.coef_count)
     nc = info.components
@@ -38,7 +42,8 @@ for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
     torch.cuda.synchronize()
     for f in range(F):
         hip.hipMemcpy(C.c_void_p(coef[f].data_ptr()), C.c_void_p(src), C.c_size_t(n * 2), 3)
-    row = W * nc
+    sb = 2 if p12 else 1
+    row = W * nc * sb
     out = torch.empty((F, H, row), dtype=torch.uint8, device="cuda")
     own = os.environ.get("OWN_TABLES") == "1"  # per-frame tables in device memory (here: F copies of the same ones)
     wsb = api.workspace_bytes(info, F, own_tables=own)
@@ -66,7 +71,9 @@ for sub in os.environ.get("LAYOUTS", "420,444,422,440,gray").split(","):
     e1.record(stream)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    bpp = 2.0 * n / (W * H) + nc  # int16 coefficients in, bytes out
-    ok = bool(np.array_equal(out[0].cpu().numpy().reshape(H, W, nc).squeeze(), d.reconstruct().squeeze()))
-    print(f"{sub:>5}: range_max {list(info.range_max)[:nc]} {api.kernel_name(info):<44} {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px) same as decoder object: {ok}{' (per-frame tables)' if own else ''}", flush=True)
+    bpp = 2.0 * n / (W * H) + nc * sb  # int16 coefficients in, bytes out
+    got = out[0].cpu().numpy()
+    ok = bool(np.array_equal((got.view(np.uint16) if p12 else got).reshape(H, W, nc).squeeze(), d.reconstruct().squeeze()))
+    sub = sub + ("_12" if p12 else "")
+    print(f"{sub:>6}: range_max {list(info.range_max)[:nc]} {api.kernel_name(info):<44} {ms:7.3f} ms/launch {W*H*F/ms/1e6:8.1f} Gpixel/s {W*H*F*bpp/ms/1e6:7.0f} GB/s algorithmic ({bpp:.1f} B/px) same as decoder object: {ok}{' (per-frame tables)' if own else ''}", flush=True)
     d.close()
