@@ -135,6 +135,23 @@ def test_oracle_vs_live_reference(oracle, w, h, q, sub, dri, seed):
     assert np.array_equal(oracle.decode(data), oracle.reference_decode(data))
 
 
+@pytest.mark.parametrize("w,h,sub,dri,scale", [(200, 120, "420", 8, 16), (97, 61, "444", 0, 16), (129, 71, "422", 3, 9), (64, 48, "420", 0, 40), (33, 200, "420", 1, 3)])
+def test_oracle_vs_live_reference_12bit(oracle, w, h, sub, dri, scale):
+    """12-bit streams made by synth.to_12bit (SOF1, P = 12, 16-bit quantiser entries over an 8-bit stream's entropy coded
+    data): the restatement against the reference binary -- these streams are the 12-bit content of the GPU parity tests and of
+    tools/layout_bench.py.  With `scale` 16 the picture is the 8-bit one times sixteen, give or take the rounding."""
+    j8 = synth.synth_jpeg(w, h, 300 + w, 85, sub, dri)
+    data = synth.to_12bit(j8, scale)
+    px = oracle.decode16(data)
+    assert px.dtype == np.uint16 and px.shape == (h, w, 3) and px.max() <= 4095
+    if scale == 16:
+        assert np.abs(px.astype(int) - 16 * oracle.decode(j8).astype(int)).max() <= 24
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/jpeg not built (needs /root/reference)")
+    rpx, rerr = oracle.reference_decode_status(data)
+    assert rerr == 0 and np.array_equal(np.asarray(rpx).reshape(px.shape), px)
+
+
 # ------------------------------------------------------------------------------------------------------
 # encoder direction (SURVEY 8f-4): forward colour transformation + box downsampling + forward DCT + quantiser
 # ------------------------------------------------------------------------------------------------------
