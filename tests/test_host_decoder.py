@@ -22,9 +22,20 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/mijpeg.h but not exported"
 
 
-def test_info_struct_layout_matches_header():
-    # sizeof(mijpeg_info): 4*4 + 5*16 + 8 + 2*16 + 12 (+4 pad) + 32 + 8 + 512
-    assert ctypes.sizeof(api.MijpegInfo) == 16 + 80 + 8 + 32 + 16 + 32 + 8 + 512 + 16 + 16
+def test_info_struct_layout_matches_header(tmp_path):
+    """The ctypes mirrors of libjpeg_amd/api.py against include/mijpeg.h as the C compiler lays it out: sizes and the offsets of
+    the last members."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mijpeg.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mijpeg_info), offsetof(mijpeg_info, coef_wide), '
+                   'offsetof(mijpeg_info, coef_count), sizeof(mijpeg_xt_params), offsetof(mijpeg_xt_params, r2table), sizeof(mijpeg_batch)); return 0; }\n')
+    exe = tmp_path / "layout"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [ctypes.sizeof(api.MijpegInfo), api.MijpegInfo.coef_wide.offset, api.MijpegInfo.coef_count.offset,
+                   ctypes.sizeof(api.MijpegXtParams), api.MijpegXtParams.r2table.offset, ctypes.sizeof(api.MijpegBatch)]
 
 
 @pytest.mark.parametrize("name", SMALL_CASES)
