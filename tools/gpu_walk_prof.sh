@@ -20,9 +20,10 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pw -o t -- pyth
 python - <<PY
 import csv
 r=[x for x in csv.DictReader(open("/tmp/pw/t_kernel_trace.csv"))]
-idx=[i for i,x in enumerate(r) if "huffman_scan_kernel" in x["Kernel_Name"]][-1]
+last=lambda x: "huffman_scan_kernel" in x["Kernel_Name"] or "huffman_subscan_kernel" in x["Kernel_Name"]
+idx=[i for i,x in enumerate(r) if last(x)][-1]
 j=idx
-while j>0 and "huffman_scan_kernel" not in r[j-1]["Kernel_Name"]: j-=1
+while j>0 and not last(r[j-1]): j-=1
 seg=[x for x in r[j:idx+1] if "huffman" in x["Kernel_Name"]]
 t0=int(seg[0]["Start_Timestamp"])
 for x in seg:
