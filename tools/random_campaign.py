@@ -145,6 +145,45 @@ for t in range(ND):
         with open(os.path.join(ROOT, "gpurun_out", "campaign_fail", f"damaged_{t}_{kind}_{eerr}_{perr}.jpg"), "wb") as fo:
             fo.write(blob)
 print(f"{ND} damaged streams against {'oracle/_ref/jpeg' if use_ref else 'the oracle'}:", dict(dstats))
+# 12-bit frames (synth.to_12bit over random 8-bit streams, random delta scale: the fused 12-bit kernels and, beyond their
+# gates, the unfused ones) and frames whose DC predictions leave 16 bits (damage.runaway_dc: int32 coefficient planes)
+N12 = int(os.environ.get("N_12BIT", str(N // 4)))
+k12 = collections.Counter()
+for t in range(N12):
+    w, h = int(rng.integers(1, 900)), int(rng.integers(1, 600))
+    sub = ["444", "422", "420", "gray", "420", "gray"][int(rng.integers(0, 6))]
+    q = int(rng.choice([30, 60, 85, 95]))
+    dri = int(rng.choice([0, 0, 1, 8]))
+    img = synth.synth_image(w, h, 9000 + t, channels=1 if sub == "gray" else 3)
+    if rng.integers(0, 3) == 0:
+        img = (img > 128).astype(np.uint8) * 255
+    data = synth.to_12bit(synth.encode_jpeg(img, q, sub if sub != "gray" else "444", restart_mcus=dri), int(rng.choice([1, 5, 16, 16, 23, 64])))
+    exp = O.decode16(data)
+    f = d.read(data, entropy=["host", "prefer-gpu"][int(rng.integers(0, 2))])
+    k12[api.kernel_name(f)] += 1
+    got = d.reconstruct()
+    if got.shape != exp.shape or not np.array_equal(got, exp) or not np.array_equal(d.reconstruct(api.FLAG_FORCE_GENERIC), exp):
+        bad += 1
+        print("12-BIT DIFFERENCE", t, w, h, sub, q, dri, list(f.range_max), flush=True)
+print(f"{N12} 12-bit streams against the oracle:", dict(k12))
+NR = int(os.environ.get("N_RUNAWAY", str(N // 10)))
+kr = collections.Counter()
+for t in range(NR):
+    w, h = int(rng.integers(40, 700)), int(rng.integers(40, 500))
+    sub = ["444", "422", "420"][int(rng.integers(0, 3))]
+    base = synth.encode_jpeg(synth.synth_image(w, h, 9500 + t), 85, sub, restart_mcus=0)
+    blob = damage.runaway_dc(base, 100 + t, drift=int(rng.choice([300, 900, 1800])))
+    epx, eerr = damage.expected_of(blob, use_ref)
+    try:
+        f = d.read(blob, entropy="prefer-gpu")
+        perr = 0
+    except api.MijpegError as e:
+        perr = e.code
+    kr["wide" if perr == 0 and f.coef_wide else "16-bit"] += 1
+    if perr != eerr or (perr == 0 and not np.array_equal(d.reconstruct(), np.asarray(epx).reshape(d.reconstruct().shape))):
+        bad += 1
+        print("RUNAWAY DIFFERENCE", t, w, h, sub, eerr, perr, flush=True)
+print(f"{NR} runaway-DC streams against {'oracle/_ref/jpeg' if use_ref else 'the oracle'}:", dict(kr))
 print(f"{N} random streams ({skipped} refused by the test encoder), {NB} batches with tables per frame ({batch_frames} frames), {time.time() - t0:.0f} s: {bad} differences")
 print("reconstruction kernels:", dict(kernels))
 print("entropy decoder used:", dict(entropy))
