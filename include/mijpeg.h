@@ -240,6 +240,14 @@ int mijpeg_last_error(mijpeg_decoder *d, const char **message);
  * computed when first asked for), MIJPEG_ERR_MALFORMED_STREAM: a damaged codestream that was decoded with resynchronisation. */
 int mijpeg_last_warning(mijpeg_decoder *d, const char **message);
 
+/* Diagnostics: the entropy coded data of the first scan of the parsed stream (mijpeg_read_header is not enough:
+ * mijpeg_decode_coefficients or a device decode must have parsed it) the way the device decoder receives it -- without the
+ * byte stuffing and without the markers, restart interval k at begin[k] (n_begin entries are filled at most), copied in
+ * pieces of at most piece_bytes source bytes like the parallel gather does.  Returns the number of bytes (also when dst is
+ * NULL or too small: nothing is copied then), or a negative error code.  *n_intervals (may be NULL): restart intervals. */
+int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, uint32_t *begin, size_t n_begin, size_t piece_bytes,
+                              int32_t *n_intervals);
+
 /* Diagnostics: number of scans without restart markers that the host decoder decoded in parallel (self-synchronising
  * speculative decoding) since the library was loaded; *pieces (may be NULL) = ranges they were stitched from. */
 int64_t mijpeg_speculative_scans(int64_t *pieces);

@@ -284,6 +284,23 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   return MIJPEG_OK;
 }
 
+int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, uint32_t *begin, size_t n_begin, size_t piece_bytes,
+                              int32_t *n_intervals)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (!d->parsed || d->host.scans.empty()) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no parsed stream");
+  std::vector<uint32_t> b;
+  const size_t total = d->host.unstuffed_layout(0, b);
+  if (n_intervals) *n_intervals = (int32_t)b.size();
+  for (size_t k = 0; k < b.size() && k < n_begin && begin; k++) begin[k] = b[k];
+  if (dst && capacity >= total) {
+    std::vector<HostDecoder::UnstuffPiece> pieces;
+    d->host.unstuff_pieces(0, b, piece_bytes ? piece_bytes : ((size_t)1 << 20), pieces);
+    for (const auto &p : pieces) d->host.unstuff_piece(0, b, p, dst);
+  }
+  return (int64_t)total;
+}
+
 int64_t mijpeg_speculative_scans(int64_t *pieces)
 {
   if (pieces) *pieces = g_speculative_pieces.load();

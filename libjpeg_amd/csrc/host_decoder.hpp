@@ -58,6 +58,14 @@ struct Scan {
   int mcus_x = 0, mcus_y = 0; // MCU grid of THIS scan
   size_t ecs_begin = 0, ecs_end = 0; // entropy coded data [begin, end) in the input
   std::vector<size_t> interval_begin; // byte offset of every restart interval (first = ecs_begin)
+  // What the device decoder reads is the entropy coded data WITHOUT the byte stuffing (unstuff_scan below): per interval the
+  // number of bytes that leaves -- up to the first FF that is not followed by 00 (the marker, or a fill byte in front of it:
+  // the reference's bit reader stops there, io/bitstream.cpp:96-101), FF 00 counted once -- and, for intervals that span
+  // several search chunks, positions inside them with the number of stuffed pairs in front (so that pieces of a long
+  // interval can be copied in parallel)
+  std::vector<uint32_t> interval_ulen;
+  struct StuffCheckpoint { size_t pos; uint32_t interval; uint32_t pairs; };
+  std::vector<StuffCheckpoint> stuff_ckpt;
   const uint8_t *base = nullptr;      // stream the offsets refer to; null = the decoder's input (hidden scans live in boxes)
   // what the reference's parser for this scan is (marker/scan.cpp:355-470, codestream/sequentialscan.cpp:72-94)
   bool refinement = false;      // RefinementScan instead of SequentialScan
@@ -121,6 +129,17 @@ public:
   // Walk scan `scan` (Huffman sequential, no restart markers needed) speculatively in parallel and return its virtual
   // restart intervals; nonzero if the scan does not lend itself to it (the caller then decodes on the host).
   int plan_virtual_intervals(size_t scan, int mcus_per_interval, int threads, VirtualIntervals &out);
+
+  // The entropy coded data of scan `scan` without its byte stuffing and without the markers: interval k's bytes at
+  // begin[k] (relative to the start of the copy), interval_ulen[k] of them, back to back.  unstuffed_layout fills `begin` and
+  // returns the total; unstuff_pieces lists the copy as independent pieces (each at most ~piece_bytes of source) that
+  // unstuff_piece carries out -- the callers spread them over their workers.
+  struct UnstuffPiece { uint32_t k0, k1; size_t src0, src1; size_t dst; };
+  size_t unstuffed_layout(size_t scan, std::vector<uint32_t> &begin) const;
+  void unstuff_pieces(size_t scan, const std::vector<uint32_t> &begin, size_t piece_bytes, std::vector<UnstuffPiece> &out) const;
+  void unstuff_piece(size_t scan, const std::vector<uint32_t> &begin, const UnstuffPiece &p, uint8_t *dst) const;
+  // unstuffed offset (relative to the copy) of stream offset `pos` inside interval k of the scan (pos at a byte that is kept)
+  size_t unstuffed_offset(size_t scan, const std::vector<uint32_t> &begin, uint32_t k, size_t pos) const;
 
   const uint8_t *stream_base() const { return data_; } // the parsed input
   size_t stream_size() const { return size_; }

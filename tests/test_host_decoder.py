@@ -292,3 +292,93 @@ def test_host_decoder_under_thread_sanitizer():
         pytest.skip("this toolchain has no ThreadSanitizer runtime")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "mismatched 0" in r.stdout and "ThreadSanitizer" not in r.stderr
+
+
+def _unstuffed_reference(data: bytes):
+    """Python restatement: entropy coded data of the first scan, per restart interval the bytes up to the first FF that is not
+    followed by 00, FF 00 as FF."""
+    import damage
+    es = damage.entropy_start(data)
+    out, begins, cur, p = bytearray(), [0], bytearray(), es
+    stopped = False
+    while p < len(data):
+        b = data[p]
+        if b != 0xFF:
+            if not stopped:
+                cur.append(b)
+            p += 1
+            continue
+        nxt = data[p + 1] if p + 1 < len(data) else None
+        if nxt == 0x00:
+            if not stopped:
+                cur.append(0xFF)
+            p += 2
+        elif nxt == 0xFF:
+            stopped = True
+            p += 1
+        elif nxt is not None and 0xD0 <= nxt <= 0xD7:
+            out += cur
+            begins.append(len(out))
+            cur, stopped = bytearray(), False
+            p += 2
+        else:
+            break
+    out += cur
+    return bytes(out), begins
+
+
+def test_unstuffed_scan_matches_a_python_restatement():
+    """What the device decoder is fed (mijpeg_unstuffed_scan): for streams with and without restart markers, noise (many FF
+    bytes), fill bytes in front of markers, and -- in a subprocess with tiny search chunks and tiny copy pieces -- every seam
+    between the parallel pieces, stuffed pairs that straddle one included."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from libjpeg_amd import api, synth
+from test_host_decoder import _unstuffed_reference
+import damage
+rng = np.random.default_rng(3)
+streams = []
+for dri in (0, 1, 3, 8):
+    streams.append(synth.encode_jpeg(rng.integers(0, 256, (72, 104, 3)).astype(np.uint8), 97, "420", restart_mcus=dri))   # noise
+    streams.append(synth.synth_jpeg(200, 120, 5 + dri, 85, "444", dri))
+# fill bytes in front of the restart markers and of EOI
+s = bytearray(streams[2]); out = bytearray(); i = 0
+es = damage.entropy_start(bytes(s))
+while i < len(s):
+    if i >= es and s[i] == 0xFF and i + 1 < len(s) and (0xD0 <= s[i + 1] <= 0xD9):
+        out += b"\\xff\\xff"
+    out.append(s[i]); i += 1
+streams.append(bytes(out))
+L = api.lib()
+L.mijpeg_unstuffed_scan.restype = C.c_int64
+L.mijpeg_unstuffed_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32)]
+n = 0
+for data in streams:
+    exp, begins = _unstuffed_reference(data)
+    d = api.Decoder(None)
+    d.read(data)
+    for piece in (16, 100, 1 << 20):
+        nint = C.c_int32(0)
+        total = L.mijpeg_unstuffed_scan(d._h, None, 0, None, 0, piece, C.byref(nint))
+        assert total == len(exp), (total, len(exp))
+        assert nint.value == len(begins)
+        buf = (C.c_uint8 * (total + 16))(*([0xAA] * (total + 16)))
+        b = (C.c_uint32 * nint.value)()
+        assert L.mijpeg_unstuffed_scan(d._h, buf, total, b, nint.value, piece, None) == total
+        assert bytes(buf[:total]) == exp, piece
+        assert bytes(buf[total:]) == b"\\xaa" * 16
+        assert list(b) == begins
+    d.close()
+    n += 1
+print("checked", n)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    for chunk in ("0", "16", "61"):
+        env = dict(os.environ)
+        if chunk != "0":
+            env["MIJPEG_MARKER_CHUNK"] = chunk
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "checked 9" in r.stdout
