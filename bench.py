@@ -256,11 +256,13 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
     streams = batch.make_streams(mine, cfg, workers=max(1, min(64, (os.cpu_count() or 1) // (2 * world))))
     gen_s = time.perf_counter() - t
     best = None
-    for chunk, depth in ((64, 2), (32, 2), (16, 4)):
+    tried = []
+    for chunk, depth in ((16, 4), (32, 2), (64, 2)):
         r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=1, chunk=chunk, depth=depth)
         r["shard"].close()
         r.pop("shard")
         r.update(chunk=chunk, depth=depth)
+        tried.append({"chunk_frames": chunk, "decoder_objects": depth, "ms_per_batch": round(r["seconds"] * 1e3 / steps, 2)})
         if best is None or r["seconds"] < best["seconds"]:
             best = r
     W, H = cfg["width"], cfg["height"]
@@ -277,7 +279,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
            "per_rank_ms": [round(x, 2) for x in rank_ms], "steps": steps, "chunk_frames": best["chunk"], "decoder_objects": best["depth"],
            "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(),
            "stream_bytes_total": int(sum(len(v) for v in streams.values())) if world == 1 else None,
-           "generation_s": round(gen_s, 1),
+           "generation_s": round(gen_s, 1), "settings_tried": tried,
            "note": "per rank: `decoder_objects` decoder objects driven round-robin by one thread, `chunk_frames` frames each: parallel header parse + "
                    "restart marker search + gather into pinned memory (host pool = cores / ranks) while the previous chunks' H2D of the compressed "
                    "bytes, huffman_scan_kernel and fused kernel run on their streams; pixels stay in HBM; RCCL barriers around the timed "

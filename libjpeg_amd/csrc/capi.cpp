@@ -289,14 +289,14 @@ int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, 
 {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->parsed || d->host.scans.empty()) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no parsed stream");
-  std::vector<uint32_t> b;
-  const size_t total = d->host.unstuffed_layout(0, b);
+  const std::vector<uint32_t> &b = d->host.scans[0].interval_ubegin;
+  const size_t total = d->host.scans[0].unstuffed_size;
   if (n_intervals) *n_intervals = (int32_t)b.size();
   for (size_t k = 0; k < b.size() && k < n_begin && begin; k++) begin[k] = b[k];
   if (dst && capacity >= total) {
     std::vector<HostDecoder::UnstuffPiece> pieces;
-    d->host.unstuff_pieces(0, b, piece_bytes ? piece_bytes : ((size_t)1 << 20), pieces);
-    for (const auto &p : pieces) d->host.unstuff_piece(0, b, p, dst);
+    d->host.unstuff_pieces(0, piece_bytes ? piece_bytes : ((size_t)1 << 20), pieces);
+    for (const auto &p : pieces) d->host.unstuff_piece(0, p, dst);
   }
   return (int64_t)total;
 }
@@ -385,9 +385,34 @@ static const char *device_entropy_obstacle(const HostDecoder &h, size_t size, bo
 // (block numbers, DC predictors: huffman_walk_scan_kernel), and one EMIT walk that writes the interval tables the
 // decode kernel reads.  The host only looks at the per-round "something changed" flags.
 // `images_host` is the staging copy of the HuffImage array (first_interval = start of the image's interval entries).
+// Where the device's copy of image i's entropy coded data goes inside the launch's stream buffer (and inside the pinned
+// gathering area): a slot of the stream's own size -- known before the stream is parsed, so a batch's workers can write the
+// copy while they search it for markers -- rounded to 16 bytes, plus the pad the kernels' prefetch may run into.
+static size_t stream_slots(const size_t *sizes, int n, std::vector<size_t> &stream_off)
+{
+  stream_off.resize((size_t)n);
+  size_t off = 0;
+  for (int i = 0; i < n; i++) {
+    stream_off[(size_t)i] = off;
+    off += ((sizes[i] + 15) & ~(size_t)15) + HUFF_STREAM_PAD;
+  }
+  return off;
+}
+
+static int ensure_stage(mijpeg_decoder *d, size_t bytes)
+{
+  if (d->stage_cap >= bytes) return MIJPEG_OK;
+  if (d->stage_host) (void)hipHostFree(d->stage_host);
+  d->stage_host = nullptr;
+  d->stage_cap = 0;
+  HIP_TRY(d, hipHostMalloc((void **)&d->stage_host, bytes, hipHostMallocDefault));
+  d->stage_cap = bytes;
+  return MIJPEG_OK;
+}
+
 static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int n, const std::vector<int> &dwalk, const HuffScanArgs &scan,
                               const HuffImage *images_dev, uint32_t *ibegin_dev, uint8_t *iskip_dev, int16_t *ipred_dev,
-                              const HuffImage *images_host, bool defer = false)
+                              const HuffImage *images_host, const std::vector<size_t> &usize, bool defer = false)
 {
   const mijpeg_info &f0 = hosts[0]->info;
   const Scan &s0 = hosts[0]->scans[0];
@@ -410,7 +435,7 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
   size_t longest = 0, all_bytes = 0;
   for (int i = 0; i < n; i++)
     if (dwalk[(size_t)i]) {
-      const size_t len = hosts[i]->scans[0].ecs_end - hosts[i]->scans[0].ecs_begin;
+      const size_t len = usize[(size_t)i]; // (the device's copy: entropy coded data without the byte stuffing)
       longest = std::max(longest, len);
       all_bytes += len;
     }
@@ -423,12 +448,13 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
   uint32_t nsub_total = 0;
   for (int i = 0; i < n; i++) {
     const Scan &s = hosts[i]->scans[0];
-    img_e0[(size_t)i] = (uint32_t)s.ecs_begin;
-    img_e1[(size_t)i] = (uint32_t)s.ecs_end;
+    (void)s;
+    img_e0[(size_t)i] = 0;
+    img_e1[(size_t)i] = (uint32_t)usize[(size_t)i];
     img_int0[(size_t)i] = images_host[i].first_interval;
     img_sub0[(size_t)i] = nsub_total;
     if (dwalk[(size_t)i]) {
-      img_nsub[(size_t)i] = (uint32_t)((s.ecs_end - s.ecs_begin + sub_bytes - 1) / sub_bytes);
+      img_nsub[(size_t)i] = (uint32_t)((usize[(size_t)i] + sub_bytes - 1) / sub_bytes);
       nsub_total += img_nsub[(size_t)i];
     }
   }
@@ -490,25 +516,10 @@ static int device_walk_images(mijpeg_decoder *d, HostDecoder *const *hosts, int 
   // the initial guess: every subsequence starts at its boundary (behind a stuffed zero if it falls on one) with the
   // first block of an MCU; for the first subsequence of an image that is no guess
   {
-    // (one cache miss per subsequence in the caller's stream: spread over the pool, 7.7 -> 0.6 ms for 16 8K frames)
+    // (positions in the device's copy, which has no byte stuffing: nothing of the stream is looked at here)
     uint64_t *st = (uint64_t *)(wh + o_state);
-    std::vector<std::pair<int, uint32_t>> parts; // image, first subsequence of a run of 4096
     for (int i = 0; i < n; i++)
-      for (uint32_t k = 0; k < img_nsub[(size_t)i]; k += 4096) parts.emplace_back(i, k);
-    const int workers = std::max(1, std::min<int>((int)parts.size(), std::min(default_threads(), 16)));
-    parallel_for(workers, [&](int wkr) {
-      for (size_t pi = (size_t)wkr; pi < parts.size(); pi += (size_t)workers) {
-        const int i = parts[pi].first;
-        const Scan &s = hosts[i]->scans[0];
-        const uint8_t *base = hosts[i]->stream_base();
-        const uint32_t k1 = std::min(img_nsub[(size_t)i], parts[pi].second + 4096);
-        for (uint32_t k = parts[pi].second; k < k1; k++) {
-          size_t q = s.ecs_begin + (size_t)k * sub_bytes;
-          if (k > 0 && base[q] == 0x00 && base[q - 1] == 0xff) q++;
-          st[img_sub0[(size_t)i] + k] = (uint64_t)q;
-        }
-      }
-    });
+      for (uint32_t k = 0; k < img_nsub[(size_t)i]; k++) st[img_sub0[(size_t)i] + k] = (uint64_t)k * sub_bytes;
   }
   HIP_TRY(d, hipMemcpyAsync(wd, wh, o_up_end, hipMemcpyHostToDevice, d->stream));
   HIP_TRY(d, hipMemsetAsync(wd + o_flags, 0, o_zero_end - o_flags, d->stream));
@@ -711,12 +722,19 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   const size_t table_blob = (size_t)ntab * sizeof(HuffDevTable) + sizeof(HuffDevAux);
 
   // device buffer: [streams, each padded][ibegin][iend][tables of every image][images][groups][status]
-  std::vector<size_t> stream_off((size_t)n);
-  size_t off = 0;
+  // What travels to the device is the entropy coded data of every image WITHOUT its byte stuffing and without the markers,
+  // one restart interval behind the other (HostDecoder::unstuff_piece; the marker search counted what leaves): the kernels
+  // address it by plain bit positions (huffman.hip, DevBits).
+  std::vector<size_t> usize((size_t)n);
+  std::vector<size_t> stream_off;
+  size_t off = stream_slots(sizes, n, stream_off);
   int64_t n_groups = 0;
   for (int i = 0; i < n; i++) {
-    stream_off[(size_t)i] = off;
-    off += ((sizes[i] + 15) & ~(size_t)15) + HUFF_STREAM_PAD;
+    usize[(size_t)i] = hosts[i]->scans[0].unstuffed_size;
+    if (usize[(size_t)i] >= ((size_t)1 << 28)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "entropy coded segment too large for the device decoder's bit addresses");
+    if (usize[(size_t)i] > sizes[i]) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "entropy coded segment larger than its stream");
+    if (!dwalk[(size_t)i] && !virt[(size_t)i] && (int64_t)hosts[i]->scans[0].interval_ubegin.size() < nints[(size_t)i])
+      return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "restart intervals missing");
     n_groups += (nints[(size_t)i] + per_group - 1) / per_group;
   }
   if (off > 0xfffffff0ull || n_groups > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "batch too large for one launch");
@@ -753,22 +771,36 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     const Scan &s = hosts[i]->scans[0];
     const int64_t nint = nints[(size_t)i];
     const std::vector<size_t> &iend = hosts[i]->interval_ends(0);
+    (void)iend;
     if (dwalk[(size_t)i]) { // filled in by the EMIT walk on the device
-      for (int64_t k = 0; k < nint; k++) { ib[first + k] = (uint32_t)s.ecs_begin; ie[first + k] = (uint32_t)s.ecs_end; }
+      for (int64_t k = 0; k < nint; k++) { ib[first + k] = 0; ie[first + k] = (uint32_t)usize[(size_t)i]; }
       memset(hp + off_isk + first, 0, (size_t)nint);
       memset(hp + off_ipr + (size_t)first * 8, 0, (size_t)nint * 8);
     } else if (virt[(size_t)i]) {
+      // the host's walk reports stream offsets: into the copy's (stuffed pairs in front of each, counted as the offsets go up)
       const VirtualIntervals &vi = *virt[(size_t)i];
       uint8_t *isk = hp + off_isk;
       int16_t *ipr = (int16_t *)(hp + off_ipr);
+      const uint8_t *base = s.base ? s.base : datas[i];
+      size_t at = s.ecs_begin, pairs = 0;
       for (int64_t k = 0; k < nint; k++) {
-        ib[first + k] = vi.byte_off[(size_t)k];
-        ie[first + k] = (uint32_t)s.ecs_end;
+        const size_t pos = vi.byte_off[(size_t)k];
+        while (at < pos) {
+          const uint8_t *q = (const uint8_t *)memchr(base + at, 0xff, pos - at);
+          if (!q) break;
+          at = (size_t)(q - base);
+          if (base[at + 1] == 0x00) { pairs++; at += 2; }
+          else at++;
+        }
+        at = std::max(at, pos);
+        ib[first + k] = (uint32_t)(pos - s.ecs_begin - pairs);
+        ie[first + k] = (uint32_t)usize[(size_t)i];
         isk[first + k] = vi.bit_skip[(size_t)k];
         memcpy(ipr + (first + k) * 4, &vi.pred[(size_t)k * 4], 8);
       }
     } else {
-      for (int64_t k = 0; k < nint; k++) { ib[first + k] = (uint32_t)s.interval_begin[(size_t)k]; ie[first + k] = (uint32_t)iend[(size_t)k]; }
+      memcpy(ib + first, s.interval_ubegin.data(), (size_t)nint * 4);
+      memcpy(ie + first, s.interval_uend.data(), (size_t)nint * 4);
       if (any_virtual) memset(hp + off_isk + first, 0, (size_t)nint);
     }
     HuffDevTable *tabs = (HuffDevTable *)(hp + off_tab + (size_t)i * table_blob);
@@ -862,12 +894,41 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   const int repeat = getenv("MIJPEG_HUFF_REPEAT") ? atoi(getenv("MIJPEG_HUFF_REPEAT")) : 1; // experiments: steady-state kernel time
   // (a deferred batch always goes through the pinned gathering area: the caller's bytes are only read during the call)
   const bool small = !defer && (n == 1 || stream_bytes < ((size_t)8 << 20));
+  {
+    const int src = ensure_stage(d, stream_bytes);
+    if (src) return src;
+  }
+  // the unstuffing gather of images [g0, g1) into the pinned area, spread over the pool: pieces of ~256 KiB of source
+  // (images whose marker search wrote the copy already -- a batch's workers do, set_unstuff_sink -- have nothing left to do)
+  auto gather = [&](int g0, int g1) {
+    struct Job { int image; HostDecoder::UnstuffPiece piece; };
+    std::vector<Job> jobs;
+    std::vector<HostDecoder::UnstuffPiece> ps;
+    for (int i = g0; i < g1; i++) {
+      if (hosts[i]->scans[0].unstuffed_at == d->stage_host + stream_off[(size_t)i]) continue;
+      ps.clear();
+      hosts[i]->unstuff_pieces(0, (size_t)256 << 10, ps);
+      for (const auto &p : ps) jobs.push_back(Job{i, p});
+    }
+    // (the sweep runs at about half of memcpy's rate: twice the workers the plain copy had)
+    if (jobs.empty()) return;
+    const int workers = std::max(1, std::min<int>((int)jobs.size(), std::min(default_threads(), 32)));
+    parallel_for(workers, [&](int w) {
+      for (size_t k = (size_t)w; k < jobs.size(); k += (size_t)workers) {
+        const int i = jobs[k].image;
+        hosts[i]->unstuff_piece(0, jobs[k].piece, d->stage_host + stream_off[(size_t)i]);
+      }
+    });
+  };
   if (small) {
+    gather(0, n);
+    // (only what the copies occupy: a slot is as large as its stream, headers and all)
     for (int i = 0; i < n; i++)
-      HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], datas[i], sizes[i], hipMemcpyHostToDevice, d->stream));
+      HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_off[(size_t)i], d->stage_host + stream_off[(size_t)i], ((usize[(size_t)i] + 15) & ~(size_t)15) + HUFF_STREAM_PAD,
+                                hipMemcpyHostToDevice, d->stream));
     if (any_dwalk) {
       const int wrc = device_walk_images(d, hosts, n, dwalk, a, (const HuffImage *)(d->ent_dev + off_img), (uint32_t *)(d->ent_dev + off_ib),
-                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images, defer);
+                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images, usize, defer);
       if (wrc) return wrc;
     }
     for (int r = 0; r < std::max(1, repeat); r++)
@@ -875,13 +936,6 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   } else {
     // large batches, in up to eight groups of images: the pool threads gather a group's streams into pinned memory, its
     // DMA runs on a copy stream while the next group is gathered and while the kernel decodes the previous one
-    if (d->stage_cap < stream_bytes) {
-      if (d->stage_host) (void)hipHostFree(d->stage_host);
-      d->stage_host = nullptr;
-      d->stage_cap = 0;
-      HIP_TRY(d, hipHostMalloc((void **)&d->stage_host, stream_bytes, hipHostMallocDefault));
-      d->stage_cap = stream_bytes;
-    }
     mark("staging buffer ready");
     if (!d->copy_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     // Images per upload + launch.  A launch is latency-bound (the serial symbol chain of its longest restart interval,
@@ -903,17 +957,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     int64_t wg0 = 0;
     for (int gi = 0, g0 = 0; g0 < n; g0 += groups_of, gi++) {
       const int g1 = std::min(n, g0 + groups_of);
-      std::vector<std::pair<int, size_t>> pieces; // image, offset: 1 MiB pieces spread over the workers
-      for (int i = g0; i < g1; i++)
-        for (size_t o = 0; o < sizes[i]; o += (size_t)1 << 20) pieces.emplace_back(i, o);
-      const int workers = std::min<int>((int)pieces.size(), std::min(default_threads(), 16));
-      parallel_for(workers, [&](int w) {
-        for (size_t k = (size_t)w; k < pieces.size(); k += (size_t)workers) {
-          const int i = pieces[k].first;
-          const size_t o = pieces[k].second, len = std::min<size_t>((size_t)1 << 20, sizes[i] - o);
-          memcpy(d->stage_host + stream_off[(size_t)i] + o, datas[i] + o, len);
-        }
-      });
+      gather(g0, g1);
       const size_t b0 = stream_off[(size_t)g0], b1 = g1 < n ? stream_off[(size_t)g1] : stream_bytes;
       HIP_TRY(d, hipMemcpyAsync(d->ent_dev + b0, d->stage_host + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
       HIP_TRY(d, hipEventRecord(d->copy_events[(size_t)gi], d->copy_stream));
@@ -931,7 +975,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     mark("groups gathered + enqueued");
     if (any_dwalk) {
       const int wrc = device_walk_images(d, hosts, n, dwalk, a, (const HuffImage *)(d->ent_dev + off_img), (uint32_t *)(d->ent_dev + off_ib),
-                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images, defer);
+                                         d->ent_dev + off_isk, (int16_t *)(d->ent_dev + off_ipr), images, usize, defer);
       if (wrc) return wrc;
       mark("device walk enqueued");
       for (int r = 0; r < std::max(1, repeat); r++)
@@ -1047,11 +1091,23 @@ static int submit_batch(mijpeg_decoder *d, const uint8_t *const *streams, const 
   d->batch_hosts.resize((size_t)n);
   for (auto &h : d->batch_hosts)
     if (!h) h.reset(new HostDecoder());
-  // headers and restart markers of all streams, one stream per worker
+  // headers and restart markers of all streams, one stream per worker -- which writes the device's copy of the entropy
+  // coded data (no byte stuffing, no markers) into the stream's slot of the pinned gathering area while it is at it
   std::vector<int> rcs((size_t)n, 0);
-  parallel_for(std::min(n, default_threads()), [&](int w) {
-    for (int i = w; i < n; i += std::min(n, default_threads())) rcs[(size_t)i] = d->batch_hosts[(size_t)i]->parse(streams[i], sizes[i], false);
-  });
+  {
+    std::vector<size_t> slot;
+    const size_t total = stream_slots(sizes, n, slot);
+    const int src = ensure_stage(d, total);
+    if (src) return src;
+    parallel_for(std::min(n, default_threads()), [&](int w) {
+      for (int i = w; i < n; i += std::min(n, default_threads())) {
+        // (a worker walks ~3 GB/s this way: good for the many small streams of a batch; a large stream is searched in
+        // parallel chunks and gathered in parallel pieces instead -- device_entropy_batch sees which it was)
+        if (sizes[i] <= ((size_t)2 << 20) || n >= default_threads()) d->batch_hosts[(size_t)i]->set_unstuff_sink(d->stage_host + slot[(size_t)i], sizes[i]);
+        rcs[(size_t)i] = d->batch_hosts[(size_t)i]->parse(streams[i], sizes[i], false);
+      }
+    });
+  }
   for (int i = 0; i < n; i++)
     if (rcs[(size_t)i]) return set_error(d, rcs[(size_t)i], d->batch_hosts[(size_t)i]->error.message);
   const auto t_parsed = clk::now();

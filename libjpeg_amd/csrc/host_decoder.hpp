@@ -64,6 +64,9 @@ struct Scan {
   // several search chunks, positions inside them with the number of stuffed pairs in front (so that pieces of a long
   // interval can be copied in parallel)
   std::vector<uint32_t> interval_ulen;
+  std::vector<uint32_t> interval_ubegin, interval_uend; // ... and where that puts every interval in the copy (back to back)
+  size_t unstuffed_size = 0;
+  const uint8_t *unstuffed_at = nullptr; // the copy already exists here: the marker search wrote it as it went (set_unstuff_sink)
   struct StuffCheckpoint { size_t pos; uint32_t interval; uint32_t pairs; };
   std::vector<StuffCheckpoint> stuff_ckpt;
   const uint8_t *base = nullptr;      // stream the offsets refer to; null = the decoder's input (hidden scans live in boxes)
@@ -131,15 +134,16 @@ public:
   int plan_virtual_intervals(size_t scan, int mcus_per_interval, int threads, VirtualIntervals &out);
 
   // The entropy coded data of scan `scan` without its byte stuffing and without the markers: interval k's bytes at
-  // begin[k] (relative to the start of the copy), interval_ulen[k] of them, back to back.  unstuffed_layout fills `begin` and
-  // returns the total; unstuff_pieces lists the copy as independent pieces (each at most ~piece_bytes of source) that
-  // unstuff_piece carries out -- the callers spread them over their workers.
+  // Scan::interval_ubegin[k] (relative to the start of the copy), interval_ulen[k] of them, back to back, Scan::unstuffed_size
+  // in all.  unstuff_pieces lists the copy as independent pieces (each at most ~piece_bytes of source) that unstuff_piece
+  // carries out -- the callers spread them over their workers.
   struct UnstuffPiece { uint32_t k0, k1; size_t src0, src1; size_t dst; };
-  size_t unstuffed_layout(size_t scan, std::vector<uint32_t> &begin) const;
-  void unstuff_pieces(size_t scan, const std::vector<uint32_t> &begin, size_t piece_bytes, std::vector<UnstuffPiece> &out) const;
-  void unstuff_piece(size_t scan, const std::vector<uint32_t> &begin, const UnstuffPiece &p, uint8_t *dst) const;
-  // unstuffed offset (relative to the copy) of stream offset `pos` inside interval k of the scan (pos at a byte that is kept)
-  size_t unstuffed_offset(size_t scan, const std::vector<uint32_t> &begin, uint32_t k, size_t pos) const;
+  // Batches (one stream per worker anyway): let the marker search of the FIRST scan of the next parse() write the copy while
+  // it walks the segment -- one pass over the stream instead of two.  `capacity` bytes at dst (the stream's size is enough).
+  // Scan::unstuffed_at tells whether it did (it does not when the search runs in parallel chunks).
+  void set_unstuff_sink(uint8_t *dst, size_t capacity) { sink_ = dst; sink_cap_ = capacity; }
+  void unstuff_pieces(size_t scan, size_t piece_bytes, std::vector<UnstuffPiece> &out) const;
+  void unstuff_piece(size_t scan, const UnstuffPiece &p, uint8_t *dst) const;
 
   const uint8_t *stream_base() const { return data_; } // the parsed input
   size_t stream_size() const { return size_; }
@@ -171,6 +175,8 @@ private:
   // control/blockbitmaprequester.cpp:1047-1054)
   bool comp_seen_[MIJPEG_MAX_COMPONENTS] = {false, false, false, false};
   uint16_t comp_quant_[MIJPEG_MAX_COMPONENTS][64];
+  uint8_t *sink_ = nullptr;
+  size_t sink_cap_ = 0;
   bool needs_sequential_ = false;
   bool parsed_ = false;
   int warnings_ = 0;

@@ -33,110 +33,101 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define MIJPEG_HUFF_RING 128
 #endif
 constexpr int RING = MIJPEG_HUFF_RING; // bytes of stream staged per lane (power of two, >= 64)
-constexpr int RING_PITCH = RING + 16; // + mirror of the first 16 bytes so that an 8-byte read never wraps
+constexpr int RING_PITCH = RING;       // the reader only ever loads aligned dwords: no mirror behind the end
 constexpr int LANE_LDS = 128 + RING_PITCH + 16; // coefficient slot + ring + block index (padded: 16-byte granules)
 
-// Bit reader over the device copy of the stream, through the lane's LDS ring.
-// ring holds the stream bytes [fill - 128, fill) at offset (address & 127); fill is a multiple of 16.
-// A refill step takes the leading ordinary bytes (up to four, none 0xFF, all before the end of the interval) of the
-// dword at the read position at once; a leading 0xFF is the stuffed pair FF 00 -> FF, or a marker in front of which
-// the reader parks and supplies zero bits: the rules of BitStream<false>::Fill (io/bitstream.cpp:56-118).
-// Invariant after refill(): n >= 32, i.e. the high dword of acc is valid, which is enough for one Huffman code
-// (<= 16 bits) plus its value bits (<= 15).  The stream buffer is padded (HUFF_STREAM_PAD) so that topping up past
-// the end of the last interval stays inside the allocation.
+// Bit reader over the device copy of the entropy coded data, through the lane's LDS ring.
+//
+// The host uploads the data WITHOUT its byte stuffing and without the markers (HostDecoder::unstuff_piece: FF 00 -> FF is
+// BitStream<false>::Fill's rule, io/bitstream.cpp:56-118), one restart interval behind the other.  A position in it is a
+// plain bit address, and the window of the next 32 bits comes out of three registers that hold the big-endian stream dwords
+// d, d + 1, d + 2 with one 64-bit shift.  Per symbol: a shift and a compare tell whether the window moved on to the next
+// dword (at most one: a code and its value bits are 31 bits at most); the dword that then becomes B2 is read from the ring
+// every time (same address while the window stays) -- it is first needed a symbol later, so the LDS round trip is off the
+// symbol-to-symbol chain.  Round 1 carried the stuffing to the device: 0xFF detection, a 64-bit accumulator refilled four
+// bytes at a time and the parked / phantom-bit bookkeeping cost about 40 instructions per symbol; this reader costs 15.
+//
+// From `endbit` on (the end of the restart interval) the reader supplies zero bits, as the reference's does in front of a
+// marker (io/bitstream.cpp:96-101).  ring holds the stream bytes [fill - RING, fill) at offset (address & (RING - 1)); fill is a
+// multiple of 16.  The fast path needs bp + 32 <= lim = min(endbit, 8 * fill - 64): the window lies inside the interval and
+// dword d + 2 is in the ring; everything else -- the last symbols of an interval, a block that outran the prefetch -- goes
+// through slow().  The stream buffer is padded (HUFF_STREAM_PAD) so that topping up past the end of the last interval stays
+// inside the allocation.
 struct DevBits {
-  const uint8_t *base; // device copy of the stream (16-byte aligned)
+  const uint8_t *base; // device copy of the data (16-byte aligned)
   uint8_t *ring;       // LDS
-  uint32_t pos, end;   // byte offsets into the stream
-  uint32_t fill;
-  uint32_t rx0, rx1;   // ring dwords at pos & ~3
-  uint64_t acc;
-  int n;
-  int phantom; // zero bits supplied since the reader parked (the walk kernels need to know where the data really ends)
-  uint32_t hist; // bit i: the (i + 1)-th last byte taken was the FF of a stuffed pair, i.e. two stream bytes (walk kernels)
-  bool parked;
+  uint32_t bp;         // next unread bit: 8 * byte address + bit, most significant first
+  uint32_t endbit;     // end of the interval
+  uint32_t fill;       // stream bytes committed to the ring so far
+  uint32_t lim;
+  uint32_t d;          // stream dword in B0
+  uint32_t B0, B1, B2;
+  uint32_t win;
 
   __device__ __forceinline__ u32x4 fetch(uint32_t at) const { return *reinterpret_cast<const u32x4 *>(base + at); }
+  __device__ __forceinline__ void set_lim() { lim = min(endbit, 8u * fill - 64u); }
   __device__ __forceinline__ void commit(u32x4 v)
   {
-    const uint32_t o = fill & (RING - 1);
-    *reinterpret_cast<u32x4 *>(ring + o) = v;
-    if (o == 0) *reinterpret_cast<u32x4 *>(ring + RING) = v;
+    *reinterpret_cast<u32x4 *>(ring + (fill & (RING - 1))) = v;
     fill += 16;
+    set_lim();
   }
-  __device__ __forceinline__ bool room() const { return fill - pos <= RING - 16; }
-  __device__ __forceinline__ void open(const uint8_t *stream, uint8_t *lds_ring, uint32_t begin, uint32_t stop)
+  // a chunk may go in when it does not overwrite the dword the window starts in (slow() loads from there on)
+  __device__ __forceinline__ bool room() const { return (int)(fill - ((bp >> 5) << 2)) <= RING - 16; }
+  __device__ __forceinline__ uint32_t ld(uint32_t dword) const
+  {
+    return __builtin_bswap32(*reinterpret_cast<const uint32_t *>(ring + ((dword << 2) & (RING - 1))));
+  }
+  __device__ __forceinline__ void idle() // a lane that does not decode: never touches a ring (its would alias a decoding lane's)
+  {
+    bp = endbit = fill = lim = d = 0;
+    B0 = B1 = B2 = win = 0;
+  }
+  __device__ __forceinline__ void open(const uint8_t *stream, uint8_t *lds_ring, uint32_t begin, uint32_t stop, uint32_t skip_bits = 0)
   {
     base = stream;
     ring = lds_ring;
-    pos = begin;
-    end = stop;
+    bp = 8u * begin + skip_bits;
+    endbit = 8u * stop;
     fill = begin & ~15u;
-    acc = 0;
-    n = 0;
-    phantom = 0;
-    hist = 0;
-    parked = false;
     const u32x4 c0 = fetch(fill), c1 = fetch(fill + 16), c2 = fetch(fill + 32), c3 = fetch(fill + 48);
     commit(c0);
     commit(c1);
     commit(c2);
     commit(c3);
-    peek_ring();
+    d = bp >> 5;
+    B0 = ld(d);
+    B1 = ld(d + 1);
+    B2 = ld(d + 2);
+    win = 0;
   }
-  // request the two ring dwords that hold the four bytes at pos (after topping the ring up if a long block outran it)
-  __device__ __forceinline__ void peek_ring()
-  {
-    while (__builtin_expect(pos + 4 > fill, 0)) commit(fetch(fill)); // a block that outran the prefetch (rare)
-    const uint32_t *r = reinterpret_cast<const uint32_t *>(ring + (pos & (RING - 4)));
-    rx0 = r[0];
-    rx1 = r[1];
-  }
-  // Common step without any branch: a lane that is short of bits (n < 32) and looks at four ordinary bytes that lie
-  // inside the interval and whose successors are in the ring takes them; everything else (0xFF, end of the interval,
-  // ring outrun by a long block) goes through refill_slow(), which is rarely entered.
   __device__ __forceinline__ void refill()
   {
-    const uint32_t x = __builtin_amdgcn_alignbyte(rx1, rx0, pos & 3u); // the four bytes at pos, little endian
-    const uint32_t ff = (~x - 0x01010101u) & x & 0x80808080u;          // nonzero: one of them is 0xFF
-    const bool take = (n < 32) & !parked & (ff == 0) & (end - pos >= 4u) & (fill - pos >= 8u);
-    const uint32_t xs = take ? __builtin_bswap32(x) : 0u;
-    acc |= (uint64_t)xs << ((32 - n) & 63);
-    n += take ? 32 : 0;
-    pos += take ? 4u : 0u;
-    hist <<= take ? 4 : 0;
-    const uint32_t *r = reinterpret_cast<const uint32_t *>(ring + (pos & (RING - 4)));
-    rx0 = r[0]; // consumed by the next step: the LDS round trip is off the symbol-to-symbol chain
-    rx1 = r[1];
-    if (__builtin_expect(n < 32, 0)) refill_slow();
+    if (__builtin_expect(bp + 32u > lim, 0)) { slow(); return; }
+    const uint32_t nd = bp >> 5;
+    const uint32_t nx = ld(nd + 2);
+    const bool adv = nd != d;
+    B0 = adv ? B1 : B0;
+    B1 = adv ? B2 : B1;
+    B2 = nx;
+    d = nd;
+    win = (uint32_t)(((((uint64_t)B0) << 32 | B1) << (bp & 31u)) >> 32);
   }
-  __device__ __forceinline__ void refill_slow()
+  __device__ __forceinline__ void slow()
   {
-    while (n < 32) {
-      const uint32_t avail = end - pos;
-      if (parked || avail == 0) { parked = true; n += 32; phantom += 32; continue; }
-      const uint32_t x = __builtin_amdgcn_alignbyte(rx1, rx0, pos & 3u);
-      const uint32_t ff = (~x - 0x01010101u) & x & 0x80808080u;          // lowest set bit marks the first 0xFF
-      const uint32_t k = min(ff ? (uint32_t)__builtin_ctz(ff) >> 3 : 4u, avail); // leading ordinary bytes
-      if (k) {
-        const int drop = 32 - 8 * (int)k;
-        const uint32_t xs = (__builtin_bswap32(x) >> drop) << drop;
-        acc |= (uint64_t)xs << (32 - n);
-        n += 8 * (int)k;
-        pos += k;
-        hist <<= k;
-        peek_ring();
-      } else if (avail >= 2 && (x & 0xff00u) == 0) { // FF 00
-        acc |= (uint64_t)0xff << (56 - n);
-        n += 8;
-        pos += 2;
-        hist = (hist << 1) | 1u;
-        peek_ring();
-      } else parked = true;
-    }
+    const uint32_t nd = bp >> 5;
+    while ((nd + 3u) * 4u > fill) commit(fetch(fill)); // a block that outran the prefetch (rare)
+    B0 = ld(nd);
+    B1 = ld(nd + 1);
+    B2 = ld(nd + 2);
+    d = nd;
+    uint32_t w = (uint32_t)(((((uint64_t)B0) << 32 | B1) << (bp & 31u)) >> 32);
+    const int avail = (int)(endbit - bp); // bits of the interval that are left; zero bits behind them
+    if (avail < 32) w = avail <= 0 ? 0u : w & (~0u << (32 - avail));
+    win = w;
   }
-  __device__ __forceinline__ uint32_t window() const { return (uint32_t)(acc >> 32); }
-  __device__ __forceinline__ void skip(int k) { acc <<= k; n -= k; }
+  __device__ __forceinline__ uint32_t window() const { return win; }
+  __device__ __forceinline__ void skip(int k) { bp += (uint32_t)k; }
 };
 
 // Huffman code at the top of the 32-bit window -> (length << 8) | symbol, 0 if no code matches.  For AC tables bit 15
@@ -254,23 +245,19 @@ __global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
   int16_t *coef = a.coef + img.coef_base;
   uint32_t *status = a.status + img.status_off;
 
-  DevBits br; // lanes that do not decode never touch a ring (theirs would alias a decoding lane's)
+  DevBits br;
   br.base = stream;
   br.ring = rings + ln * RING_PITCH;
-  br.pos = br.end = br.fill = 0;
-  br.rx0 = br.rx1 = 0;
-  br.acc = 0;
-  br.n = 0;
-  br.phantom = 0;
-  br.parked = true;
-  if (decoding) br.open(stream, rings + ln * RING_PITCH, a.ibegin[img.first_interval + interval], a.iend[img.first_interval + interval]);
+  br.idle();
   int pred[4] = {0, 0, 0, 0};
-  if (img.virt && decoding) { // a restart point found by the host's walk: mid-byte, with the predictors accumulated so far
+  if (decoding) {
     const uint32_t idx = img.first_interval + (uint32_t)interval;
-    br.refill();
-    br.skip(a.iskip[idx]);
+    // (virtual intervals: a restart point found by a walk -- mid-byte, with the predictors accumulated so far)
+    br.open(stream, rings + ln * RING_PITCH, a.ibegin[idx], a.iend[idx], img.virt ? (uint32_t)a.iskip[idx] : 0u);
+    if (img.virt) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) pred[k] = a.ipred[idx * 4 + k];
+      for (int k = 0; k < 4; k++) pred[k] = a.ipred[idx * 4 + k];
+    }
   }
   // the next 32 bytes of the stream travel in registers for the duration of one block
   uint32_t pend_at = br.fill;
@@ -381,15 +368,12 @@ __device__ __forceinline__ int dev_walk_block(DevBits &br, const HuffDevTable *d
   return bad ? 1 : 0;
 }
 
-// Where the reader stands, as (byte that holds the next unread bit, bits of it already used): step back over the
-// bytes whose bits are still buffered; `hist` knows which of them took two stream bytes.
+// Where the reader stands, as (byte that holds the next unread bit, bits of it already used).
 __device__ __forceinline__ void dev_exact_position(const DevBits &br, uint32_t &byte, uint32_t &skip)
 {
-  const int real = br.n - br.phantom;
-  if (real <= 0) { byte = br.end; skip = 0; return; }
-  const int back = (real + 7) >> 3; // <= 8
-  byte = br.pos - (uint32_t)back - (uint32_t)__builtin_popcount(br.hist & ((1u << back) - 1u));
-  skip = (uint32_t)(8 * back - real);
+  if (br.bp >= br.endbit) { byte = br.endbit >> 3; skip = 0; return; } // (zero bits behind the data are no position)
+  byte = br.bp >> 3;
+  skip = br.bp & 7u;
 }
 
 template <bool EMIT>
@@ -429,9 +413,7 @@ __global__ __launch_bounds__(256) void huffman_walk_kernel(const HuffWalkArgs a)
   const uint64_t st = a.state[si];
 
   DevBits br;
-  br.open(stream, rings + lane * RING_PITCH, walk_state_byte(st), e1);
-  br.refill();
-  br.skip((int)walk_state_skip(st));
+  br.open(stream, rings + lane * RING_PITCH, walk_state_byte(st), e1, walk_state_skip(st));
   int j = (int)walk_state_phase(st);
   uint32_t pend_at = br.fill;
   u32x4 pend0 = br.fetch(pend_at), pend1 = br.fetch(pend_at + 16);
@@ -447,7 +429,6 @@ __global__ __launch_bounds__(256) void huffman_walk_kernel(const HuffWalkArgs a)
   }
   uint32_t end_byte = e1, end_skip = 0;
   for (;;) {
-    br.refill();
     if (EMIT) {
       if (nb >= my_blocks || g >= a.total_blocks) break;
       if (g % a.emit_every == 0) {
@@ -460,20 +441,19 @@ __global__ __launch_bounds__(256) void huffman_walk_kernel(const HuffWalkArgs a)
         for (int k = 0; k < 4; k++) a.ipred[idx * 4 + k] = (int16_t)pred[k];
       }
     } else {
-      if (br.parked && br.n - br.phantom <= 0) break; // the data end here
-      if (br.pos >= limit) { // possibly in the successor's range already (pos runs ahead by the buffered bits)
-        uint32_t q, sk;
-        dev_exact_position(br, q, sk);
-        if (q >= limit) { end_byte = q; end_skip = sk; break; }
+      if (br.bp >= br.endbit) break; // the data end here
+      if ((br.bp >> 3) >= limit) { // in the successor's range
+        end_byte = br.bp >> 3;
+        end_skip = br.bp & 7u;
+        break;
       }
     }
     const int k = blk_comp[j];
     int dcdiff = 0;
     const int bad = dev_walk_block(br, tabs + 2 * k, tabs + 2 * k + 1, dcdiff);
-    if (br.parked && br.n - br.phantom < 0) break; // ran over the end of the data inside a block
+    if (br.bp > br.endbit) break; // ran over the end of the data inside a block
     if (bad) {
       if (EMIT) break; // cannot happen on the path the rounds agreed on
-      br.refill();
       br.skip(1); // not a block: move on by one bit and guess again
       j = 0;
     } else {
