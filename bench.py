@@ -257,7 +257,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
     gen_s = time.perf_counter() - t
     best = None
     tried = []
-    for chunk, depth in ((16, 4), (32, 2), (64, 2)):
+    for chunk, depth in ((16, 4), (24, 4), (32, 2), (32, 3), (64, 2)):
         r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=1, chunk=chunk, depth=depth)
         r["shard"].close()
         r.pop("shard")

@@ -243,7 +243,8 @@ int mijpeg_last_warning(mijpeg_decoder *d, const char **message);
 /* Diagnostics: the entropy coded data of the first scan of the parsed stream (mijpeg_read_header is not enough:
  * mijpeg_decode_coefficients or a device decode must have parsed it) the way the device decoder receives it -- without the
  * byte stuffing and without the markers, restart interval k at begin[k] (n_begin entries are filled at most), copied in
- * pieces of at most piece_bytes source bytes like the parallel gather does.  Returns the number of bytes (also when dst is
+ * pieces of at most piece_bytes source bytes like the parallel gather does (piece_bytes = 1: the stream is parsed again and the
+ * marker search writes the copy while it walks the segment, as a batch's workers do; capacity >= stream size + 64 then).  Returns the number of bytes (also when dst is
  * NULL or too small: nothing is copied then), or a negative error code.  *n_intervals (may be NULL): restart intervals. */
 int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, uint32_t *begin, size_t n_begin, size_t piece_bytes,
                               int32_t *n_intervals);

@@ -289,6 +289,16 @@ int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, 
 {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->parsed || d->host.scans.empty()) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no parsed stream");
+  if (piece_bytes == 1 && dst) { // the other producer: the marker search writes the copy itself (what a batch's workers do)
+    if (capacity < d->size + 64) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "the sink needs the stream's size (+ 64 bytes of slack)");
+    d->host.set_unstuff_sink(dst, d->size);
+    const int rc = d->host.parse(d->data, d->size, false);
+    if (rc) return set_error(d, rc, d->host.error.message);
+    if (d->host.scans.empty() || d->host.scans[0].unstuffed_at != dst) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the marker search did not write the copy");
+    if (n_intervals) *n_intervals = (int32_t)d->host.scans[0].interval_ubegin.size();
+    for (size_t k = 0; k < d->host.scans[0].interval_ubegin.size() && k < n_begin && begin; k++) begin[k] = d->host.scans[0].interval_ubegin[k];
+    return (int64_t)d->host.scans[0].unstuffed_size;
+  }
   const std::vector<uint32_t> &b = d->host.scans[0].interval_ubegin;
   const size_t total = d->host.scans[0].unstuffed_size;
   if (n_intervals) *n_intervals = (int32_t)b.size();

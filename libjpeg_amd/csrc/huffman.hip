@@ -2,10 +2,12 @@
 //
 // One THREAD decodes one restart interval: the intervals are independent by construction (DC predictors and the bit
 // buffer are reset at every RSTn, codestream/sequentialscan.cpp:266-274), the host only pre-scans the entropy coded
-// segment for the marker positions (memchr, ~0.4 ms for an 8K frame) and uploads the compressed bytes (a few MB)
-// instead of ~100 MB of coefficients.  Semantics are those of the host decoder (host_decoder.cpp), i.e. of
+// segment for the marker positions (~0.4 ms for an 8K frame) and uploads the compressed bytes (a few MB) instead of
+// ~100 MB of coefficients.  Semantics are those of the host decoder (host_decoder.cpp), i.e. of
 // SequentialScan::DecodeBlock (codestream/sequentialscan.cpp:678-773) and BitStream<false>::Fill
-// (io/bitstream.cpp:56-118): FF00 -> FF, zero bits once parked in front of a marker.
+// (io/bitstream.cpp:56-118): FF00 -> FF -- which the host applies while it copies the data into the upload buffer
+// (HostDecoder::unstuff_piece / the marker search's sink), so that the kernels address plain bits -- and zero bits once
+// the reader stands at the marker that ends its interval.
 //
 // This is latency-bound pointer chasing, not bandwidth-bound work, so everything is arranged to keep the serial
 // chain of one interval short and to run many chains side by side:

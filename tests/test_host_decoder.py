@@ -334,7 +334,7 @@ def test_unstuffed_scan_matches_a_python_restatement():
     import subprocess
     import sys
     code = """
-import sys, numpy as np, ctypes as C
+import sys, os, numpy as np, ctypes as C
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 from libjpeg_amd import api, synth
 from test_host_decoder import _unstuffed_reference
@@ -371,6 +371,13 @@ for data in streams:
         assert bytes(buf[:total]) == exp, piece
         assert bytes(buf[total:]) == b"\\xaa" * 16
         assert list(b) == begins
+    # the other producer: the marker search writes the copy as it goes (batches)
+    big = (C.c_uint8 * (len(data) + 64))()
+    got = L.mijpeg_unstuffed_scan(d._h, big, len(data) + 64, b, nint.value, 1, None)
+    if os.environ.get("MIJPEG_MARKER_CHUNK"):
+        assert got == -1029  # (tiny search chunks: the search runs in parallel pieces and leaves the copy to the gather)
+    else:
+        assert got == len(exp) and bytes(big[:got]) == exp and list(b) == begins
     d.close()
     n += 1
 print("checked", n)
