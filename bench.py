@@ -104,7 +104,9 @@ def cpu_baseline_all_cores(streams, width, height):
             files.append(fn)
 
         def one(fn):
-            subprocess.run([O.REF_BIN, fn, "/dev/null"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            # (every core the box gives us, not only the socket this rank's threads were bound to)
+            subprocess.run([O.REF_BIN, fn, "/dev/null"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           preexec_fn=lambda: os.sched_setaffinity(0, FULL_AFFINITY))
 
         best = None
         for _ in range(2):
@@ -246,6 +248,10 @@ def dense_roofline(info0, F, W, H, stream, steps):
 
 
 # ---- BASELINE config 4 ----------------------------------------------------------------------------------------------------
+NUMA_BINDING = None  # what sharding.bind_to_gpu_node did for this rank (main() sets it)
+FULL_AFFINITY = os.sched_getaffinity(0)  # before any binding: the CPU baselines run on all of it
+
+
 def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
     """256 x 4K 4:2:0 Q85 DRI=8 (seeds 1000..1255), image-sharded, bytes in host memory -> pixels in HBM; strong scaling."""
     from libjpeg_amd import batch
@@ -257,8 +263,9 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
     gen_s = time.perf_counter() - t
     best = None
     tried = []
-    for chunk, depth in ((16, 4), (24, 4), (32, 2), (32, 3), (64, 2)):
-        r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=1, chunk=chunk, depth=depth)
+    # (the clock governor needs ~100 ms of load to settle, DESIGN 5: the first setting warms up for that long, untimed)
+    for ci, (chunk, depth) in enumerate(((16, 4), (24, 4), (32, 2), (32, 3), (64, 2))):
+        r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=10 if ci == 0 else 2, chunk=chunk, depth=depth)
         r["shard"].close()
         r.pop("shard")
         r.update(chunk=chunk, depth=depth)
@@ -279,7 +286,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
            "per_rank_ms": [round(x, 2) for x in rank_ms], "steps": steps, "chunk_frames": best["chunk"], "decoder_objects": best["depth"],
            "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(),
            "stream_bytes_total": int(sum(len(v) for v in streams.values())) if world == 1 else None,
-           "generation_s": round(gen_s, 1), "settings_tried": tried,
+           "generation_s": round(gen_s, 1), "settings_tried": tried, "numa_binding": NUMA_BINDING,
            "note": "per rank: `decoder_objects` decoder objects driven round-robin by one thread, `chunk_frames` frames each: parallel header parse + "
                    "restart marker search + gather into pinned memory (host pool = cores / ranks) while the previous chunks' H2D of the compressed "
                    "bytes, huffman_scan_kernel and fused kernel run on their streams; pixels stay in HBM; RCCL barriers around the timed "
@@ -311,7 +318,7 @@ def main():
     ap.add_argument("--workload", default="both", choices=["both", "headline", "batch4k"],
                     help="headline = the 8K kernel benchmark only; batch4k adds BASELINE config 4 (256 x 4K streams -> pixels, sharded)")
     ap.add_argument("--batch-frames", type=int, default=256, help="frames of the config 4 batch (256 as written)")
-    ap.add_argument("--batch-steps", type=int, default=3)
+    ap.add_argument("--batch-steps", type=int, default=5)
     ap.add_argument("--traffic-child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.traffic_child:
@@ -324,6 +331,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the reconstruction path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    # one process per GPU, on the socket its GPU hangs off (before the library creates its worker pool); MIJPEG_BENCH_NO_NUMA=1: as is
+    global NUMA_BINDING
+    NUMA_BINDING = None if os.environ.get("MIJPEG_BENCH_NO_NUMA") else sharding.bind_to_gpu_node(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_

@@ -48,3 +48,38 @@ def reduce_result(units, elapsed, dist=None):
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(round(float(u[0]))), float(t[0])
+
+
+def bind_to_gpu_node(device_index: int):
+    """Host side of "one process per GPU": run this rank's threads (the library's worker pool is created by the first call that
+    needs it and inherits the affinity) on the NUMA node its GPU hangs off -- the streams it parses, the pinned upload buffer and
+    the PCIe root of the device then sit on one socket.  Returns {"node": n, "cpus": k} or None when the topology cannot be read
+    (no sysfs, no PCI address, a single node) -- nothing is changed then."""
+    import os
+
+    try:
+        import torch
+
+        p = torch.cuda.get_device_properties(device_index)
+        dom, bus, dev = getattr(p, "pci_domain_id", None), getattr(p, "pci_bus_id", None), getattr(p, "pci_device_id", None)
+        if bus is None or dev is None:
+            return None
+        path = f"/sys/bus/pci/devices/{(dom or 0):04x}:{bus:02x}:{dev:02x}.0/numa_node"
+        with open(path) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        if not cpus or cpus == allowed:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"node": node, "cpus": len(cpus)}
+    except Exception:  # noqa: BLE001 -- a hint, never a reason to fail
+        return None

@@ -119,3 +119,13 @@ def test_host_threads_are_divided_among_the_ranks():
     assert batch.host_threads(1) == min(64, cores)
     assert batch.host_threads(8) == max(1, min(64, cores // 8))
     assert batch.host_threads(8) * 8 <= max(cores, 8)
+
+
+def test_bind_to_gpu_node_is_a_hint_that_never_fails():
+    """Without a GPU (or without sysfs topology) nothing happens and nothing is raised; the affinity stays what it was."""
+    import os
+
+    from libjpeg_amd import sharding
+    before = os.sched_getaffinity(0)
+    assert sharding.bind_to_gpu_node(0) is None
+    assert os.sched_getaffinity(0) == before
