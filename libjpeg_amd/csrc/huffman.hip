@@ -135,6 +135,14 @@ struct DevBits {
 // Huffman code at the top of the 32-bit window -> (length << 8) | symbol, 0 if no code matches.  For AC tables bit 15
 // flags the symbols that do not exist in sequential scans (s == 0 with a run other than 0 and 15, :747-750); the host
 // sets it in the direct table, the fallback for long codes sets it here.
+// a + b, saturating at 2^32 - 1 (one full-rate instruction)
+__device__ __forceinline__ uint32_t add_sat_u32(uint32_t a, uint32_t b)
+{
+  uint32_t d;
+  asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 template <bool AC> __device__ __forceinline__ uint32_t dev_lookup(uint32_t win, const HuffDevTable *h)
 {
   uint32_t e = h->fast[win >> (32 - HUFF_DEV_LOOKAHEAD)];
@@ -182,7 +190,9 @@ __device__ __forceinline__ int dev_block(DevBits &br, const HuffDevTable *dc, co
   win = br.window();
   e = dev_lookup<true>(win, ac);
   *reinterpret_cast<int16_t *>(slot + swz16) = (int16_t)pred;
-  uint32_t qsum = (uint32_t)abs(pred) * (zq[0] >> 16);
+  // range check sum |c| q: both factors fit 16 bits (24-bit multiply), the sum saturates -- the host cuts at 2^31 - 1 like its
+  // own decoder does (evaluate_entropy_status), and anything beyond that has saturated or is beyond it for good
+  uint32_t qsum = __umul24((uint32_t)abs(pred), zq[0] >> 16);
   int kk = 1;
   bool bad = false;
   for (;;) {
@@ -200,7 +210,7 @@ __device__ __forceinline__ int dev_block(DevBits &br, const HuffDevTable *dc, co
     const uint32_t z = zq[kk]; // kk <= 63 + 15, the table is padded; in flight together with the lookup below
     e = dev_lookup<true>(win, ac);
     *reinterpret_cast<int16_t *>(slot + ((z & 0xffffu) ^ (uint32_t)swz16)) = (int16_t)val;
-    qsum = min(qsum + (uint32_t)abs(val) * (z >> 16), 0x7fffffffu); // saturating like the host decoder
+    qsum = add_sat_u32(qsum, __umul24((uint32_t)abs(val), z >> 16));
     if (last) break;
     kk++;
   }
