@@ -9,10 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402,F401
 
-from libjpeg_amd import batch  # noqa: E402
+from libjpeg_amd import batch, sharding  # noqa: E402
 
 
 def main():
+    if not os.environ.get("MIJPEG_BENCH_NO_NUMA"):
+        print("NUMA binding:", sharding.bind_to_gpu_node(0))  # like bench.py: this process on the socket its GPU hangs off
     n = int(os.environ.get("CFG_FRAMES", "128"))
     dri = int(os.environ.get("CFG_DRI", "8"))
     cfg = dict(batch.CONFIG4, frames=n, restart_mcus=dri)
