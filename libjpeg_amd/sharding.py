@@ -77,7 +77,7 @@ def bind_to_gpu_node(device_index: int):
             cpus.update(range(int(a), int(b or a) + 1))
         allowed = os.sched_getaffinity(0)
         cpus &= allowed
-        if not cpus or cpus == allowed:
+        if not cpus or cpus == allowed or len(cpus) * 8 < len(allowed):  # (nothing to gain, or a sliver of what we may use)
             return None
         os.sched_setaffinity(0, cpus)
         return {"node": node, "cpus": len(cpus)}
