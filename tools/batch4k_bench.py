@@ -17,7 +17,7 @@ def main():
         print("NUMA binding:", sharding.bind_to_gpu_node(0))  # like bench.py: this process on the socket its GPU hangs off
     n = int(os.environ.get("CFG_FRAMES", "128"))
     dri = int(os.environ.get("CFG_DRI", "8"))
-    cfg = dict(batch.CONFIG4, frames=n, restart_mcus=dri)
+    cfg = dict(batch.CONFIG4, frames=n, restart_mcus=dri, quality=int(os.environ.get("CFG_Q", batch.CONFIG4["quality"])))
     if os.environ.get("CFG_8K"):
         cfg.update(width=7680, height=4320)
     t = time.perf_counter()
