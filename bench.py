@@ -269,7 +269,10 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu):
     best = None
     tried = []
     # (the clock governor needs ~100 ms of load to settle, DESIGN 5: the first setting warms up for that long, untimed)
-    for ci, (chunk, depth) in enumerate(((16, 4), (24, 4), (32, 2), (32, 3), (64, 2))):
+    # (pipeline settings worth trying depend on how many frames a rank has: with 256 / 8 = 32 of them, chunks of 16 would leave
+    # the pipeline two stages deep)
+    settings = ((16, 4), (24, 4), (32, 2), (32, 3), (64, 2)) if len(mine) >= 128 else ((8, 4), (16, 4), (16, 2), (4, 8), (max(1, len(mine)), 1))
+    for ci, (chunk, depth) in enumerate(settings):
         r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=10 if ci == 0 else 2, chunk=chunk, depth=depth)
         r["shard"].close()
         r.pop("shard")

@@ -2,6 +2,7 @@
 //   g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined tools/fuzz_host.cpp libjpeg_amd/csrc/host_decoder.cpp -o /tmp/fuzz_host
 //   /tmp/fuzz_host tests/golden/*.jpg
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iterator>
 #include <vector>
@@ -24,7 +25,20 @@ int main(int argc, char **argv)
       default: { size_t at = 2 + rnd() % (d.size() - 2); std::vector<uint8_t> g(1 + rnd() % 40); for (auto &x : g) x = (uint8_t)rnd(); d.insert(d.begin() + at, g.begin(), g.end()); }
       }
       mij::HostDecoder h;
+      // the device's copy of the entropy coded data (no byte stuffing, no markers): written by the marker search itself
+      // (the sink, every other trial) or afterwards in pieces; both must stay inside what the stream's size allows
+      std::vector<uint8_t> sink(d.size() + 64, 0xAA);
+      if (t & 8) h.set_unstuff_sink(sink.data(), d.size());
       int rc = h.parse(d.data(), d.size(), false);
+      if (!rc && !h.scans.empty()) {
+        const mij::Scan &s0 = h.scans[0];
+        if (s0.unstuffed_size > d.size()) { printf("unstuffed size beyond the stream: %s trial %d\n", argv[a], t); return 1; }
+        std::vector<uint8_t> copy(d.size() + 64, 0x55); // (+ the slack the vector copy may touch)
+        std::vector<mij::HostDecoder::UnstuffPiece> pieces;
+        h.unstuff_pieces(0, (t % 3 == 0) ? 64 : (size_t)1 << 16, pieces);
+        for (const auto &p : pieces) h.unstuff_piece(0, p, copy.data());
+        if (s0.unstuffed_at == sink.data() && memcmp(sink.data(), copy.data(), s0.unstuffed_size)) { printf("sink and pieces disagree: %s trial %d\n", argv[a], t); return 1; }
+      }
       if (!rc) {
         std::vector<int16_t> c((size_t)h.info.coef_count + 64);
         rc = h.decode(c.data(), 2, nullptr);
