@@ -695,7 +695,11 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     const int l = atoi(e);
     if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) a.lanes = l;
   }
-  a.waves_per_group = a.lanes >= 32 ? 2 : 4;
+  // one wave per SIMD and workgroup: with two-wave workgroups (which round 1 chose for the LDS they leave to others) the same
+  // eight waves per CU decode 37 % slower (0.60 against 0.38 ms per 32 4K frames; 3, 5, 6 waves: 0.55, 0.58, 0.48) -- the
+  // waves of a workgroup go to the SIMDs in cyclic order, and only a multiple of four loads them evenly
+  a.waves_per_group = 4;
+  if (const char *e = getenv("MIJPEG_HUFF_WAVES")) a.waves_per_group = std::max(1, std::min(8, atoi(e))); // tuning
   const int per_group = a.lanes * a.waves_per_group; // intervals of one workgroup
   // Tables in LDS: components that bring the same Huffman code (Cb and Cr practically always do) share one copy -- the
   // workgroup's LDS footprint decides how many of them a CU holds.  The sharing pattern is that of image 0 and must hold

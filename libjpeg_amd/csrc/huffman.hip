@@ -228,7 +228,7 @@ __device__ __forceinline__ void wave_lds_sync()
 __device__ __forceinline__ void dev_exact_position(const DevBits &br, uint32_t &byte, uint32_t &skip);
 
 // LDS of a workgroup: [tables | aux][per wave: lanes x 128-byte block slot | lanes x ring | lanes x block number]
-__global__ __launch_bounds__(256) void huffman_scan_kernel(const HuffScanArgs a)
+__global__ __launch_bounds__(512) void huffman_scan_kernel(const HuffScanArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const int table_bytes = a.ntables * (int)sizeof(HuffDevTable) + (int)sizeof(HuffDevAux);
