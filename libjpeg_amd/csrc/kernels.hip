@@ -2056,7 +2056,7 @@ __device__ __forceinline__ void idct_1d_quad(const long long (&s)[8], long long 
   o[3] = tmp13 + o0; o[4] = tmp13 - o0;
 }
 
-__global__ __launch_bounds__(64) void idct_planes_wide_kernel(const GenericArgs a)
+__global__ __launch_bounds__(256) void idct_planes_wide_kernel(const GenericArgs a)
 {
   const int comp = a.wide_first + blockIdx.y % a.wide_count, frame = blockIdx.y / a.wide_count;
   const int nblocks = a.bw[comp] * a.bh[comp];
@@ -2097,7 +2097,7 @@ __global__ __launch_bounds__(64) void idct_planes_wide_kernel(const GenericArgs 
 // IDCT<0,LONG> (dct/idct.cpp:225-335): the statements of idct_planes_kernel's SAFE flavour in wrapping 32-bit
 // arithmetic, on int32 coefficients.  One lane per block; rare, and about correctness only.
 // ==============================================================================================
-__global__ __launch_bounds__(64) void idct_planes_long_kernel(const GenericArgs a)
+__global__ __launch_bounds__(256) void idct_planes_long_kernel(const GenericArgs a)
 {
   const int comp = a.wide_first + blockIdx.y % a.wide_count, frame = blockIdx.y / a.wide_count;
   const int nblocks = a.bw[comp] * a.bh[comp];
@@ -2679,8 +2679,9 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   if (a.wide_count > 0) {
     int wb = 0;
     for (int c = a.wide_first; c < a.wide_first + a.wide_count; c++) wb = max(wb, a.bw[c] * a.bh[c]);
-    if (a.wide_long) hipLaunchKernelGGL(idct_planes_long_kernel, dim3((wb + 63) / 64, a.wide_count * a.frames), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(idct_planes_wide_kernel, dim3((wb + 63) / 64, a.wide_count * a.frames), dim3(64), 0, stream, a);
+    // (workgroups of four waves: one per SIMD)
+    if (a.wide_long) hipLaunchKernelGGL(idct_planes_long_kernel, dim3((wb + 255) / 256, a.wide_count * a.frames), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(idct_planes_wide_kernel, dim3((wb + 255) / 256, a.wide_count * a.frames), dim3(256), 0, stream, a);
   }
   const int groups = (a.width + 7) >> 3;
   const int bs = groups >= 256 ? 256 : 64;
