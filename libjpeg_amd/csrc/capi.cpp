@@ -784,8 +784,6 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     const mijpeg_info &f = hosts[i]->info;
     const Scan &s = hosts[i]->scans[0];
     const int64_t nint = nints[(size_t)i];
-    const std::vector<size_t> &iend = hosts[i]->interval_ends(0);
-    (void)iend;
     if (dwalk[(size_t)i]) { // filled in by the EMIT walk on the device
       for (int64_t k = 0; k < nint; k++) { ib[first + k] = 0; ie[first + k] = (uint32_t)usize[(size_t)i]; }
       memset(hp + off_isk + first, 0, (size_t)nint);
