@@ -687,10 +687,12 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
 
   HuffScanArgs a;
   memset(&a, 0, sizeof(a));
-  // decoding lanes per wave: ~2048 waves keep the 1024 SIMDs busy; beyond that, fuller waves amortise the VALU
-  // (measured on 8K 4:2:0: 259200 intervals -> 64, 64800 -> 16, 32400 -> 8, 8100 -> 2..4)
+  // decoding lanes per wave: about a thousand waves (one per SIMD) are what a small launch wants -- fewer lanes per wave
+  // mean more waves that each issue the same instructions for less, fuller waves mean longer steps (the slowest lane's
+  // block).  Measured with the bit-addressed reader and four-wave workgroups on one 8K 4:2:0 frame with 16200 intervals
+  // (tools/gpu_huff_lanes.sh): 1 lane 0.81 ms, 2: 0.52, 4: 0.33, 8: 0.26, 16: 0.26, 32: 0.27.
   a.lanes = 64;
-  while (a.lanes > 1 && total_intervals / a.lanes < 2048) a.lanes >>= 1;
+  while (a.lanes > 1 && total_intervals / a.lanes < 768) a.lanes >>= 1;
   if (const char *e = getenv("MIJPEG_HUFF_LANES")) { // tuning
     const int l = atoi(e);
     if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) a.lanes = l;
