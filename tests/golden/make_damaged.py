@@ -91,6 +91,14 @@ def build_cases():
     cases["header_bad_sampling"] = ("ref_75x45_420_dri2", bytes(d), "frame header with sampling factors 5x5")
     d = bytearray(e); del d[e.find(b"\xff\xc4"):e.find(b"\xff\xc4") + 2 + ((e[e.find(b"\xff\xc4") + 2] << 8) | e[e.find(b"\xff\xc4") + 3])]
     cases["header_missing_dht"] = ("ref_75x45_420_dri2", bytes(d), "first DHT segment removed")
+    # a point transform in a SEQUENTIAL scan (Al = 2 in the SOS header; no encoder writes that, a flipped byte does): the
+    # reference's sequential parser applies it (coefficients * 4) -- with and without restart markers
+    for src_name in ("ref_80x48_420", "ref_75x45_420_dri2"):
+        h = base(src_name)
+        p = h.find(b"\xff\xda")
+        d = bytearray(h)
+        d[p + 2 + ((h[p + 2] << 8) | h[p + 3]) - 1] = 0x02  # Ah | Al, the last byte of the scan header
+        cases["sequential_point_transform_" + ("dri2" if "dri2" in src_name else "nodri")] = (src_name, bytes(d), "Al = 2 in the header of a sequential scan")
     g = base("pil_70x40_gray")
     p = g.find(b"\xff\xc0")
     d = bytearray(g); d[p + 11] = 0xA3
