@@ -1642,6 +1642,11 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
     const int lprec = f.precision + (f.xt ? b->xt->hidden_bits : 0);
     for (int c = 0; c < f.components; c++) plane(c, f, c, lprec);
     if (f.coef_wide) { a.wide_first = 0; a.wide_count = f.components; a.wide_long = 1; }
+    // int16 sample planes between the two kernels: |sample * 16| <= 2048 (level shift) + 4 * range_max must fit 16 bits
+    static const bool int32_planes = getenv("MIJPEG_GENERIC_INT32") != nullptr; // A-B comparisons
+    a.narrow = fast && !f.xt && f.precision == 8 && !f.coef_wide && !int32_planes;
+    for (int c = 0; c < f.components && a.narrow; c++)
+      if (f.range_max[c] >= 7600) a.narrow = 0;
     a.maxval = (1 << lprec) - 1;
     a.dcshift = (1 << (lprec - 1)) << 4;
     if (f.xt) {

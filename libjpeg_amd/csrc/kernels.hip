@@ -25,6 +25,7 @@
 // the reference's wrap-around LONG arithmetic and its 64-bit colour accumulation for any input.
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1991,9 +1992,13 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
 // ==============================================================================================
 // generic path, kernel 1: dequant + IDCT of every block of every component into int32 sample planes
 // ==============================================================================================
-template <bool FAST, bool QDEV>
+// NARROW (FAST only, 8-bit frames whose samples times 16 -- level shift included -- fit 16 bits: the host checks): the
+// sample planes hold int16, half the bytes written here and read back by the second kernel.
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+template <bool FAST, bool QDEV, bool NARROW = false>
 __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
 {
+  static_assert(FAST || !NARROW, "int16 sample planes need the range check of the fast flavour");
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2017,6 +2022,14 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   else dequant_idct<false>(rows, q, v, a.dcoff[comp]);
   const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
   const int pitch = a.bw[comp] * 8;
+  if (NARROW) {
+    short *dst = reinterpret_cast<short *>(a.samples) + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      *reinterpret_cast<i16x8 *>(dst + (int64_t)r * pitch) = i16x8{(short)v[r * 8 + 0], (short)v[r * 8 + 1], (short)v[r * 8 + 2], (short)v[r * 8 + 3],
+                                                                  (short)v[r * 8 + 4], (short)v[r * 8 + 5], (short)v[r * 8 + 6], (short)v[r * 8 + 7]};
+    return;
+  }
   int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
 #pragma unroll
   for (int r = 0; r < 8; r++) {
@@ -2142,13 +2155,14 @@ __device__ __forceinline__ int f8(int wa, int x, int wb, int y, int r)
   return (int)((unsigned)wa * (unsigned)x + (unsigned)wb * (unsigned)y + (unsigned)r) >> 3;
 }
 
-__device__ __forceinline__ void upsample_line_any(const int *__restrict__ plane, int pitch, int cw, int ch, int sx, int sy, int X0, int Y,
+template <class T>
+__device__ __forceinline__ void upsample_line_any(const T *__restrict__ plane, int pitch, int cw, int ch, int sx, int sy, int X0, int Y,
                                                int (&o)[8])
 {
   const int y = Y / sy, ymod = Y - y * sy;
   const int cur = min(y, ch - 1), top = min(max(y - 1, 0), ch - 1), bot = min(cur + 1, ch - 1);
   const int x = (sx > 1) ? X0 / sx - 1 : X0; // chroma column of buffer entry 0
-  const int *pc = plane + (int64_t)cur * pitch, *pt = plane + (int64_t)top * pitch, *pb = plane + (int64_t)bot * pitch;
+  const T *pc = plane + (int64_t)cur * pitch, *pt = plane + (int64_t)top * pitch, *pb = plane + (int64_t)bot * pitch;
   int v[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -2230,18 +2244,24 @@ __device__ __forceinline__ void upsample_line_any(const int *__restrict__ plane,
 
 // Compile-time specialisations of the same arithmetic for the layouts that matter (1x1, 2x1, 1x2, 2x2); groups that lie
 // inside the plane skip the index clamps, and 1x1 lines are two 16-byte loads.
-template <int SX, int SY>
-__device__ __forceinline__ void upsample_line_t(const int *__restrict__ plane, int pitch, int cw, int ch, int X0, int Y, int (&o)[8])
+template <int SX, int SY, class T>
+__device__ __forceinline__ void upsample_line_t(const T *__restrict__ plane, int pitch, int cw, int ch, int X0, int Y, int (&o)[8])
 {
   const int y = Y / SY, ymod = Y - y * SY;
   const int cur = min(y, ch - 1), top = min(max(y - 1, 0), ch - 1), bot = min(cur + 1, ch - 1);
   const int x = (SX > 1) ? X0 / SX - 1 : X0;
-  const int *pc = plane + (int64_t)cur * pitch, *pv = plane + (int64_t)(ymod == 0 ? top : bot) * pitch;
+  const T *pc = plane + (int64_t)cur * pitch, *pv = plane + (int64_t)(ymod == 0 ? top : bot) * pitch;
   int v[8];
   if (SX == 1 && SY == 1) {
-    if (x + 7 < cw) { // X0 is a multiple of 8 and the pitch a multiple of 8 samples: 32-byte aligned
-      const i32x4 a = *reinterpret_cast<const i32x4 *>(pc + x), b = *reinterpret_cast<const i32x4 *>(pc + x + 4);
-      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    if (x + 7 < cw) { // X0 is a multiple of 8 and the pitch a multiple of 8 samples: aligned to the eight samples
+      if constexpr (sizeof(T) == 2) {
+        const i16x8 a = *reinterpret_cast<const i16x8 *>(pc + x);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = a[j];
+      } else {
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(pc + x), b = *reinterpret_cast<const i32x4 *>(pc + x + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; j++) o[j] = pc[min(x + j, cw - 1)];
@@ -2275,14 +2295,15 @@ __device__ __forceinline__ void upsample_line_t(const int *__restrict__ plane, i
 // components subsampled by (CSX, CSY) in {1,2} x {1,2}; LAYOUT_ANY = runtime factors (everything else).
 constexpr int LAYOUT_ANY = 0;
 constexpr int layout_id(int csx, int csy) { return csx * 4 + csy; }
-template <int LAYOUT>
+template <int LAYOUT, bool NARROW = false>
 __device__ __forceinline__ void upsample_plane_line(const GenericArgs &a, int p, int comp, int frame, int X0, int Y, int (&o)[8])
 {
-  const int *plane = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[p];
-  if constexpr (LAYOUT == LAYOUT_ANY) upsample_line_any(plane, a.bw[p] * 8, a.cw[p], a.ch[p], a.subx[p], a.suby[p], X0, Y, o);
+  using T = typename std::conditional<NARROW, short, int>::type; // (NARROW: int16 sample planes, same offsets in samples)
+  const T *plane = reinterpret_cast<const T *>(a.samples) + (int64_t)frame * a.sample_frame_stride + a.sample_off[p];
+  if constexpr (LAYOUT == LAYOUT_ANY) upsample_line_any<T>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], a.subx[p], a.suby[p], X0, Y, o);
   else {
-    if (comp == 0) upsample_line_t<1, 1>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
-    else upsample_line_t<LAYOUT / 4, LAYOUT % 4>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
+    if (comp == 0) upsample_line_t<1, 1, T>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
+    else upsample_line_t<LAYOUT / 4, LAYOUT % 4, T>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
   }
 }
 
@@ -2298,7 +2319,7 @@ __device__ __forceinline__ void ycc_to_rgb_wide(int y, int cb, int cr, int dcshi
 }
 __device__ __forceinline__ long long clampll(long long v, long long hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
-template <bool FAST, int LAYOUT>
+template <bool FAST, int LAYOUT, bool NARROW = false>
 __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a)
 {
   const int groups = (a.width + 7) >> 3;
@@ -2310,7 +2331,7 @@ __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a
   int s[MAXC][8];
 #pragma unroll
   for (int c = 0; c < MAXC; c++) {
-    if (c < a.ncomp) upsample_plane_line<LAYOUT>(a, c, c, frame, X0, Y, s[c]);
+    if (c < a.ncomp) upsample_plane_line<LAYOUT, NARROW>(a, c, c, frame, X0, Y, s[c]);
   }
   uint8_t *dst = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride + (int64_t)X0 * a.ncomp * a.sample_bytes;
   const int npx = min(8, a.width - X0);
@@ -2670,7 +2691,11 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   int maxblocks = 0;
   for (int c = 0; c < a.nplanes; c++) maxblocks = max(maxblocks, a.bw[c] * a.bh[c]);
   dim3 g1((maxblocks + 255) / 256, a.nplanes * a.frames);
-  if (fast)
+  const bool narrow = fast && a.narrow && !a.xt && a.wide_count == 0;
+  if (narrow)
+    if (a.qdev) hipLaunchKernelGGL((idct_planes_kernel<true, true, true>), g1, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((idct_planes_kernel<true, false, true>), g1, dim3(256), 0, stream, a);
+  else if (fast)
     if (a.qdev) hipLaunchKernelGGL((idct_planes_kernel<true, true>), g1, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((idct_planes_kernel<true, false>), g1, dim3(256), 0, stream, a);
   else
@@ -2712,6 +2737,14 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
     else if (rlay == layout_id(1, 1) && lay == layout_id(2, 1)) LAUNCH_XT(layout_id(2, 1), layout_id(1, 1));
     else if (rlay == layout_id(2, 2) && lay == layout_id(2, 2)) LAUNCH_XT(layout_id(2, 2), layout_id(2, 2));
     else LAUNCH_XT(LAYOUT_ANY, LAYOUT_ANY);
+  } else if (narrow) {
+#define LAUNCH_COLOR_NARROW(L) hipLaunchKernelGGL((upsample_color_kernel<true, L, true>), g2, dim3(bs), 0, stream, a)
+    if (lay == layout_id(1, 1)) LAUNCH_COLOR_NARROW(layout_id(1, 1));
+    else if (lay == layout_id(2, 2)) LAUNCH_COLOR_NARROW(layout_id(2, 2));
+    else if (lay == layout_id(2, 1)) LAUNCH_COLOR_NARROW(layout_id(2, 1));
+    else if (lay == layout_id(1, 2)) LAUNCH_COLOR_NARROW(layout_id(1, 2));
+    else LAUNCH_COLOR_NARROW(LAYOUT_ANY);
+#undef LAUNCH_COLOR_NARROW
   } else if (fast) {
     if (lay == layout_id(1, 1)) LAUNCH_COLOR(true, layout_id(1, 1));
     else if (lay == layout_id(2, 2)) LAUNCH_COLOR(true, layout_id(2, 2));

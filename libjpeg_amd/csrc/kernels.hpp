@@ -68,6 +68,8 @@ struct GenericArgs {
   int32_t ltable_entries;      // entries per L table: 256 << hidden bits of the legacy frame
   int32_t wide_first, wide_count; // planes [wide_first, wide_first + wide_count) hold int32 coefficients at coef_off (in
                                   // int16 units) and are transformed by idct_planes_wide_kernel (IDCT<4,QUAD>) ...
+  int32_t narrow;                 // the sample planes may hold int16 (8-bit frame, every sample times 16 incl. its level shift inside
+                                  // 16 bits: range_max < 7600): half the bytes between the two kernels
   int32_t wide_long;              // ... or, set, by idct_planes_long_kernel (IDCT<0,LONG>): frames with info.coef_wide
   const int32_t *ltable;       // device: L lookup tables [3][ltable_entries]
   const int32_t *qdev;         // or null: per-frame tables in device memory, [frames][4][64] deltas << 4 (replace q; not for JPEG XT)
