@@ -175,8 +175,10 @@ private:
   // control/blockbitmaprequester.cpp:1047-1054)
   bool comp_seen_[MIJPEG_MAX_COMPONENTS] = {false, false, false, false};
   uint16_t comp_quant_[MIJPEG_MAX_COMPONENTS][64];
-  uint8_t *sink_ = nullptr;
+  uint8_t *sink_ = nullptr; // set_unstuff_sink: armed for the NEXT parse() only ...
   size_t sink_cap_ = 0;
+  uint8_t *active_sink_ = nullptr; // ... which takes it over (and forgets it whatever becomes of the parse)
+  size_t active_cap_ = 0;
   bool needs_sequential_ = false;
   bool parsed_ = false;
   int warnings_ = 0;
