@@ -515,7 +515,7 @@ def main():
         del bout
         from libjpeg_amd import batch as batch_mod
         tp_best, tp_cfg = None, None
-        for chunk, depth in ((8, 3), (16, 2)):
+        for chunk, depth in ((8, 4), (8, 3), (4, 4), (16, 2)):
             sh = batch_mod.BatchShard([jpegs[i % 2] for i in range(nbatch)], local_rank, chunk, depth)
             sh.run()
             for _ in range(3):
