@@ -232,6 +232,40 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
                             const int32_t bytes_per_pixel[MIJPEG_MAX_COMPONENTS],
                             const int32_t bytes_per_row[MIJPEG_MAX_COMPONENTS]);
 
+/* JPEG::DisplayRectangle AS THE REFERENCE RUNS IT: one call of a sequence.  mijpeg_reconstruct_rect above answers every
+ * request from the plain picture; the reference does not -- BlockBitmapRequester::ReconstructRegion
+ * (control/blockbitmaprequester.cpp:1013-1272) walks row cursors that never rewind and upsampler line buffers
+ * (upsampling/upsamplerbase.cpp:138-327) that persist between calls, so a request shows what the calls before it left:
+ * on the upsampling path every call moves the cursor of every unsubsampled component, requested or not (:1214-1223 -- the
+ * reference's own PGX loop, cmd/reconstruct.cpp:272-303, therefore writes planes of zeros for the later unsubsampled
+ * components of a two- or four-component frame with mixed sampling); components outside the requested range enter the colour
+ * transformation as zeros; the colour transformer of the first request stays (colortrafo/colortransformerfactory.cpp:220-221);
+ * rectangles whose corner is off the 8-pixel grid see subsampled components displaced (upsampling/upsampler.cpp:85-86 against
+ * colortrafo/ycbcrtrafo.cpp:683-686); stripes that are skipped or repeated read the rows the cursors stand at.  This entry
+ * point keeps that state per decoder object (reset by every decode) and reproduces all of it; top-down requests of whole
+ * component sets -- every sane client -- are recognised as the plain picture and served from the cached frame.
+ * bitmaps[c] describes what the bitmap hook returned for component c (requested components only are read): address of canvas
+ * pixel (0,0), strides in bytes, BIO_WIDTH / BIO_HEIGHT (the height bounds the block rows that are reconstructed, :1229-1244;
+ * blocks that start outside the extent are not written, interface/imagebitmap.cpp:58-129).  data == NULL: nothing is
+ * written for that component but the state advances.  flags: MIJPEG_FLAG_NO_UPSAMPLING, _NO_COLOR_TRANSFORM, _DEVICE_OUTPUT.
+ * Not modelled: rectangles narrower than the frame that move sideways between calls read line-buffer memory the reference
+ * never initialised; JPEG XT frames are served as the plain picture. */
+typedef struct mijpeg_bitmap {
+  void *data;
+  int32_t bytes_per_pixel, bytes_per_row;
+  uint32_t width, height;
+} mijpeg_bitmap;
+int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
+                        uint32_t flags, const mijpeg_bitmap bitmaps[MIJPEG_MAX_COMPONENTS]);
+/* Diagnostics, no device needed (mijpeg_read_header is enough): advance the request state exactly like mijpeg_display_rect
+ * would and report the plan instead of pixels -- out[0..7] = nothing shown, plain picture, YCbCr transformer, view component,
+ * region min_x, min_y, max_x, max_y; then per component: cursor after the call, first / last block row with a row map, upsampler
+ * window start / end (lines), number of mapped block rows that are zeros. */
+int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
+                        uint32_t flags, const uint32_t bm_height[MIJPEG_MAX_COMPONENTS], int32_t out[8 + 6 * MIJPEG_MAX_COMPONENTS]);
+/* Diagnostics: coefficient row the cursor of `component` stands at after the mijpeg_display_rect calls so far. */
+int mijpeg_display_cursor(mijpeg_decoder *d, int component);
+
 /* Error of the last failing call on this object (JPEG::LastError). Returns the code, 0 if none. */
 int mijpeg_last_error(mijpeg_decoder *d, const char **message);
 

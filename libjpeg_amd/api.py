@@ -68,6 +68,10 @@ class MijpegForwardBatch(C.Structure):
     ]
 
 
+class MijpegBitmap(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("bytes_per_pixel", C.c_int32), ("bytes_per_row", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 class MijpegError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"mijpeg error {code}: {message}")
@@ -129,6 +133,9 @@ def lib():
         L.mijpeg_reconstruct_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int]
         L.mijpeg_reconstruct_rect.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_uint32, P(C.c_void_p), P(C.c_int32), P(C.c_int32)]
         L.mijpeg_reconstruct_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32]
+        L.mijpeg_display_rect.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_uint32, P(MijpegBitmap)]
+        L.mijpeg_display_plan.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_uint32, P(C.c_uint32), P(C.c_int32)]
+        L.mijpeg_display_cursor.argtypes = [C.c_void_p, C.c_int]
         L.mijpeg_host_alloc.argtypes = [C.c_size_t]
         L.mijpeg_host_alloc.restype = C.c_void_p
         L.mijpeg_host_free.argtypes = [C.c_void_p]
@@ -293,6 +300,47 @@ class Decoder:
         bpr = (C.c_int32 * 4)(*([out.strides[0]] * 4))
         self._check(lib().mijpeg_reconstruct_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags, dst, bpp, bpr))
         return out
+
+    def display_rect(self, canvas: np.ndarray, x0, y0, x1, y1, comp0=0, comp1=None, flags: int = 0, bm_height: int | None = None) -> None:
+        """mijpeg_display_rect: one JPEG::DisplayRectangle call of a sequence (the object keeps the reference's state between
+        calls).  canvas: (ncomp, H, W) planar uint8 / uint16, written in place; bm_height: BIO_HEIGHT the hook would report."""
+        f = self.info
+        nc = f.components
+        comp1 = nc - 1 if comp1 is None else comp1
+        sb = canvas.dtype.itemsize
+        H, W = canvas.shape[1:]
+        maps = (MijpegBitmap * 4)()
+        for c in range(nc):
+            maps[c].data = canvas[c].ctypes.data
+            maps[c].bytes_per_pixel = sb
+            maps[c].bytes_per_row = canvas.strides[1]
+            maps[c].width = W
+            maps[c].height = H if bm_height is None else bm_height
+        self._check(lib().mijpeg_display_rect(self._h, x0, y0, x1, y1, comp0, comp1, flags, maps))
+
+    def reconstruct_cli(self, flags: int = 0) -> np.ndarray:
+        """What the reference's command line shows of the image (cmd/reconstruct.cpp:272-342 with upsampling): frames of one
+        or three components are requested in stripes over all components -- the plain picture --, frames of two or four
+        component by component (PGX), where the state JPEG::DisplayRectangle keeps between calls shows (mijpeg_display_rect).
+        -> (H, W, C).  Like the reference's loop it can run once per decoded image."""
+        f = self.info
+        if f.components in (1, 3):
+            return self.reconstruct(flags)
+        canvas = np.zeros((f.components, f.height, f.width), np.uint8 if max(1, f.sample_bytes) == 1 else np.uint16)
+        for c in range(f.components):
+            for y in range(0, f.height, 8):
+                self.display_rect(canvas, 0, y, f.width - 1, min(y + 7, f.height - 1), c, c, flags, bm_height=y + 8)
+        return np.ascontiguousarray(np.moveaxis(canvas, 0, -1))
+
+    def display_plan(self, x0, y0, x1, y1, comp0, comp1, flags: int, bm_height: int):
+        """mijpeg_display_plan (no device needed): advance the request state, return the plan as a dict."""
+        out = (C.c_int32 * 32)()
+        hh = (C.c_uint32 * 4)(bm_height, bm_height, bm_height, bm_height)
+        self._check(lib().mijpeg_display_plan(self._h, x0, y0, x1, y1, comp0, comp1, flags, hh, out))
+        o = list(out)
+        return dict(nothing=o[0], plain=o[1], ycc=o[2], view=o[3], region=tuple(o[4:8]),
+                    comps=[dict(cursor=o[8 + 6 * c], g0=o[9 + 6 * c], g1=o[10 + 6 * c], wstart=o[11 + 6 * c], wlimit=o[12 + 6 * c],
+                                zeros=o[13 + 6 * c]) for c in range(4)])
 
     def decode_batch_device(self, streams, min_intervals: int = 0) -> MijpegInfo:
         """mijpeg_decode_batch_device: n streams of one shape -> n coefficient stores in HBM with one Huffman kernel launch."""

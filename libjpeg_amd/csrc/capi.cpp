@@ -21,6 +21,7 @@
 #include "forward.hpp"
 #include "hencode.hpp"
 #include "kernels.hpp"
+#include "request_model.hpp"
 
 using namespace mij;
 
@@ -48,6 +49,14 @@ struct mijpeg_decoder {
   int band_lines = 0, bands = 0, bands_waited = 0;
   uint32_t img_flags = 0;
   int img_view = -1;           // component of a non-upsampled reconstruction, -1: the whole picture
+  // mijpeg_display_rect: the reference's state between DisplayRectangle calls (request_model.hpp) and the buffers of the
+  // requests that do not show the plain picture
+  RequestModel model;
+  bool model_valid = false;
+  uint8_t *req_dev = nullptr, *req_host = nullptr; // frame-sized interleaved image (device; pinned host)
+  size_t req_dev_cap = 0, req_host_cap = 0;
+  int32_t *rowmap_dev = nullptr;
+  size_t rowmap_cap = 0;
   int32_t *ws_dev = nullptr;
   size_t ws_cap = 0; // bytes
   // on-device entropy decoding: stream bytes, interval offsets, tables, status word
@@ -181,7 +190,7 @@ int mijpeg_set_input(mijpeg_decoder *d, const uint8_t *data, size_t size)
   if (!data || !size) return set_error(d, MIJPEG_ERR_STREAM_EMPTY, "empty input stream");
   d->data = data;
   d->size = size;
-  d->parsed = d->decoded = d->uploaded = d->img_valid = false;
+  d->parsed = d->decoded = d->uploaded = d->img_valid = d->model_valid = false;
   return MIJPEG_OK;
 }
 
@@ -233,7 +242,7 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   const mijpeg_info &f = d->host.info;
   rc = ensure_coef_store(d, (size_t)f.coef_count);
   if (rc) return rc;
-  d->img_valid = false;
+  d->img_valid = d->model_valid = false;
   d->uploaded = false;
   d->host_planes_stale = false;
   d->batch_frames = 0;
@@ -1043,7 +1052,7 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
   }
   rc = ensure_coef_store(d, (size_t)d->host.info.coef_count, false);
   if (rc) return rc;
-  d->img_valid = false;
+  d->img_valid = d->model_valid = false;
   d->uploaded = false;
   d->decoded = false;
   // JPEG XT: the planes of the residual frame follow those of the legacy frame in the same store
@@ -1140,7 +1149,7 @@ static int submit_batch(mijpeg_decoder *d, const uint8_t *const *streams, const 
   }
   int rc = ensure_coef_store(d, (size_t)f0.coef_count * (size_t)n, false);
   if (rc) return rc;
-  d->img_valid = false;
+  d->img_valid = d->model_valid = false;
   d->uploaded = false;
   d->decoded = false;
   d->pend_n = 0;
@@ -1533,9 +1542,22 @@ size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
   return LUT_BYTES + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames + expanded_tables_bytes(b) + xt_table_bytes(b);
 }
 
-int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
+// What a rectangle request that does not show the plain picture adds to a launch (request_model.hpp; GenericArgs::rowmap ...)
+struct RequestExtra {
+  const int32_t *rowmap_dev;
+  int32_t rowmap_stride;
+  int32_t corner_x, corner_y, y_base, y_count;
+  int32_t wstart[MIJPEG_MAX_COMPONENTS], wlimit[MIJPEG_MAX_COMPONENTS];
+  int32_t ycc;
+};
+static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const RequestExtra *rx);
+
+int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream) { return launch_reconstruct_ex(b, stream, nullptr); }
+
+static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const RequestExtra *rx)
 {
   if (!b || !b->coef_dev || !b->out_dev || b->frames < 1) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (rx && (b->info.xt || !(b->flags & MIJPEG_FLAG_FORCE_GENERIC))) return MIJPEG_ERR_INVALID_PARAMETER;
   if (b->quant_dev && b->info.xt) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: plain JPEG only
   const mijpeg_info &f = b->info;
   if ((f.precision != 8 && f.precision != 12) || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
@@ -1705,6 +1727,20 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
           }
         }
       }
+    }
+    if (rx) {
+      a.rowmap = rx->rowmap_dev;
+      a.rowmap_stride = rx->rowmap_stride;
+      a.request = 1;
+      a.req_x0 = rx->corner_x;
+      a.req_y0 = rx->corner_y;
+      a.y_base = rx->y_base;
+      a.y_count = rx->y_count;
+      for (int c = 0; c < f.components; c++) {
+        a.wstart[c] = rx->wstart[c];
+        a.wlimit[c] = rx->wlimit[c];
+      }
+      a.ycbcr = rx->ycc; // the colour transformer the first request built (colortransformerfactory.cpp:220-221)
     }
     rc = launch_generic(a, fast, s);
   }
@@ -2237,6 +2273,10 @@ int mijpeg_reconstruct_host(mijpeg_decoder *d, void *dst_host, int64_t row_strid
   return MIJPEG_OK;
 }
 
+static int serve_rect(mijpeg_decoder *d, int view, uint32_t flags, bool to_device, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y,
+                      int32_t min_comp, int32_t max_comp, void *const dst[MIJPEG_MAX_COMPONENTS],
+                      const int32_t bytes_per_pixel[MIJPEG_MAX_COMPONENTS], const int32_t bytes_per_row[MIJPEG_MAX_COMPONENTS]);
+
 int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp,
                             int32_t max_comp, uint32_t flags, void *const dst[MIJPEG_MAX_COMPONENTS],
                             const int32_t bytes_per_pixel[MIJPEG_MAX_COMPONENTS],
@@ -2266,9 +2306,6 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
     min_y = (std::max(min_y, 0) + sy - 1) / sy;
     max_y = (max_y + sy) / sy - 1;
   }
-  const mijpeg_info f = view_of(d->host.info, view);
-  const int sb = f.sample_bytes > 0 ? f.sample_bytes : 1; // bytes per sample
-  const int nc = f.components;
   void *vdst[MIJPEG_MAX_COMPONENTS] = {dst[0], dst[1], dst[2], dst[3]};
   int32_t vbpp[MIJPEG_MAX_COMPONENTS] = {bytes_per_pixel[0], bytes_per_pixel[1], bytes_per_pixel[2], bytes_per_pixel[3]};
   int32_t vbpr[MIJPEG_MAX_COMPONENTS] = {bytes_per_row[0], bytes_per_row[1], bytes_per_row[2], bytes_per_row[3]};
@@ -2278,9 +2315,18 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
     vbpr[0] = bytes_per_row[view];
     min_comp = max_comp = 0;
   }
-  dst = vdst;
-  bytes_per_pixel = vbpp;
-  bytes_per_row = vbpr;
+  return serve_rect(d, view, flags, to_device, min_x, min_y, max_x, max_y, min_comp, max_comp, vdst, vbpp, vbpr);
+}
+
+// The rectangle [min_x, max_x] x [min_y, max_y] (on the grid of `view`: the canvas, or a component's own samples) of the
+// plain picture, components [min_comp, max_comp] of the view, into the bitmaps.
+static int serve_rect(mijpeg_decoder *d, int view, uint32_t flags, bool to_device, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y,
+                      int32_t min_comp, int32_t max_comp, void *const dst[MIJPEG_MAX_COMPONENTS],
+                      const int32_t bytes_per_pixel[MIJPEG_MAX_COMPONENTS], const int32_t bytes_per_row[MIJPEG_MAX_COMPONENTS])
+{
+  const mijpeg_info f = view_of(d->host.info, view);
+  const int sb = f.sample_bytes > 0 ? f.sample_bytes : 1; // bytes per sample
+  const int nc = f.components;
   // the whole frame is reconstructed once per (stream, flags, view) and then served rectangle by rectangle,
   // which is what the stripe loop of cmd/reconstruct.cpp:334-342 asks for
   const size_t row = ((size_t)f.width * nc * sb + 7) & ~(size_t)7;
@@ -2414,6 +2460,260 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
     }
   }
   return MIJPEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// JPEG::DisplayRectangle as a sequence of calls: request_model.hpp plans, this serves
+// ------------------------------------------------------------------------------------------------
+// Frame description for a request that does not show the plain picture: the whole picture, or -- without upsampling --
+// the grid of component `view` with every component of the frame on it (the ones that were not asked for are zeros; only
+// a colour transformer left over from earlier upsampled requests makes them matter).
+static mijpeg_info request_frame(const mijpeg_info &f, int view, bool all_components)
+{
+  if (view < 0) return f;
+  if (!all_components) return view_of(f, view);
+  mijpeg_info v = f;
+  v.width = (f.width + f.subx[view] - 1) / f.subx[view];
+  v.height = (f.height + f.suby[view] - 1) / f.suby[view];
+  for (int c = 0; c < f.components; c++) {
+    v.hsamp[c] = v.vsamp[c] = v.subx[c] = v.suby[c] = 1;
+    v.blocks_w[c] = f.blocks_w[view];
+    v.blocks_h[c] = f.blocks_h[view];
+    v.coef_offset[c] = f.coef_offset[view]; // read only where the row map says so: component `view`
+    v.quant_index[c] = f.quant_index[view];
+    v.range_max[c] = f.range_max[view];
+  }
+  v.mcus_x = v.blocks_w[0];
+  v.mcus_y = v.blocks_h[0];
+  return v;
+}
+
+int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
+                        uint32_t flags, const mijpeg_bitmap bitmaps[MIJPEG_MAX_COMPONENTS])
+{
+  if (!d || !bitmaps) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
+  if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
+  const mijpeg_info &f = d->host.info;
+  const bool to_device = (flags & MIJPEG_FLAG_DEVICE_OUTPUT) != 0;
+  const bool upsample = !(flags & MIJPEG_FLAG_NO_UPSAMPLING);
+  const bool ctrafo = !(flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM);
+  const uint32_t pass = flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_FORCE_SAFE);
+  if (min_comp < 0) min_comp = 0;
+  if (max_comp >= f.components) max_comp = f.components - 1;
+  if (!upsample && min_comp != max_comp && min_comp <= max_comp)
+    return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "if upsampling is disabled, components can only be reconstructed one by one");
+  void *dst[MIJPEG_MAX_COMPONENTS];
+  int32_t bpp[MIJPEG_MAX_COMPONENTS], bpr[MIJPEG_MAX_COMPONENTS];
+  uint32_t bm_h[MIJPEG_MAX_COMPONENTS], bm_w[MIJPEG_MAX_COMPONENTS];
+  for (int c = 0; c < MIJPEG_MAX_COMPONENTS; c++) {
+    dst[c] = bitmaps[c].data;
+    bpp[c] = bitmaps[c].bytes_per_pixel;
+    bpr[c] = bitmaps[c].bytes_per_row;
+    bm_w[c] = bitmaps[c].width;
+    bm_h[c] = bitmaps[c].height;
+  }
+  if (d->host.is_xt()) {
+    // JPEG XT: the residual image has cursors of its own in the reference; requests are served as the plain picture
+    // (top-down stripes and whole frames, which is what its clients do, are the same thing there)
+    uint32_t maxmcu = 0xffffffffu;
+    for (int c = min_comp; c <= max_comp; c++) maxmcu = std::min(maxmcu, (bm_h[c] >> 3) - 1u);
+    if (maxmcu != 0xffffffffu && (int64_t)max_y > (int64_t)maxmcu * 8 + 7) max_y = (int32_t)(maxmcu * 8 + 7);
+    if (max_y < min_y) return MIJPEG_OK;
+    return mijpeg_reconstruct_rect(d, min_x, min_y, max_x, max_y, min_comp, max_comp, flags, dst, bpp, bpr);
+  }
+  if (!d->model_valid) {
+    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0);
+    d->model_valid = true;
+  }
+  const RequestPlan p = d->model.request(min_x, min_y, max_x, max_y, min_comp, max_comp, upsample, ctrafo, bm_h);
+  if (p.nothing) return MIJPEG_OK;
+  // BitmapCtrl::ExtractBitmap (interface/imagebitmap.cpp:58-129): a block whose corner lies outside the bitmap the hook
+  // described is blank -- nothing of it is written; one that starts inside is written in full
+  int32_t cx1[MIJPEG_MAX_COMPONENTS], cy1[MIJPEG_MAX_COMPONENTS];
+  auto last_inside = [](int32_t lo, int32_t hi, uint32_t extent) -> int32_t { // last sample of the blocks whose corner is below extent
+    if ((uint32_t)lo >= extent) return lo - 1;
+    const int64_t last_block = ((int64_t)extent - 1) >> 3; // the last block whose (aligned) corner is inside
+    return (int32_t)std::min<int64_t>(hi, std::max<int64_t>(last_block, lo >> 3) * 8 + 7);
+  };
+  for (int c = 0; c < f.components; c++) {
+    cx1[c] = last_inside(p.min_x, p.max_x, bm_w[c]);
+    cy1[c] = last_inside(p.min_y, p.max_y, bm_h[c]);
+  }
+  const int vc = p.view; // without upsampling the single component of the view is number 0 there
+  if (p.plain) {
+    const uint32_t fl = pass | (p.ycc || !f.ycbcr ? 0u : MIJPEG_FLAG_NO_COLOR_TRANSFORM) | (vc >= 0 ? MIJPEG_FLAG_NO_COLOR_TRANSFORM : 0u);
+    // components with the same writable extent go out together (all of them, normally: one interleaved copy)
+    for (int c = min_comp; c <= max_comp;) {
+      int e = c;
+      while (e + 1 <= max_comp && cx1[e + 1] == cx1[c] && cy1[e + 1] == cy1[c]) e++;
+      if (cx1[c] >= p.min_x && cy1[c] >= p.min_y) {
+        int rc;
+        if (vc >= 0) {
+          void *vdst[MIJPEG_MAX_COMPONENTS] = {dst[vc], nullptr, nullptr, nullptr};
+          int32_t vbpp[MIJPEG_MAX_COMPONENTS] = {bpp[vc], 0, 0, 0}, vbpr[MIJPEG_MAX_COMPONENTS] = {bpr[vc], 0, 0, 0};
+          rc = serve_rect(d, vc, fl, to_device, p.min_x, p.min_y, cx1[c], cy1[c], 0, 0, vdst, vbpp, vbpr);
+        } else
+          rc = serve_rect(d, -1, fl, to_device, p.min_x, p.min_y, cx1[c], cy1[c], c, e, dst, bpp, bpr);
+        if (rc) return rc;
+      }
+      c = e + 1;
+    }
+    return MIJPEG_OK;
+  }
+  // ---- not the plain picture: row maps, zeros, displaced upsampler output -> the generic kernels on this request's lines
+  HIP_TRY(d, hipSetDevice(d->device));
+  const bool all_on_view = vc >= 0 && p.ycc;
+  mijpeg_batch b;
+  memset(&b, 0, sizeof(b));
+  b.info = request_frame(f, vc, all_on_view);
+  b.info.ycbcr = p.ycc ? 1 : 0;
+  const mijpeg_info &g = b.info;
+  const int nc = g.components, sb = g.sample_bytes > 0 ? g.sample_bytes : 1;
+  const size_t row = ((size_t)g.width * nc * sb + 7) & ~(size_t)7, padded = row * g.height;
+  int rc = ensure_dev(d, (void **)&d->req_dev, &d->req_dev_cap, padded);
+  if (rc) return rc;
+  // row maps: identity outside what the plan defines; components that were not asked for are zeros
+  int stride = 1;
+  for (int c = 0; c < nc; c++) stride = std::max(stride, g.blocks_h[c]);
+  std::vector<int32_t> maps((size_t)nc * stride);
+  bool all_zero = !p.ycc;
+  for (int c = 0; c < nc; c++) {
+    const int pc = vc >= 0 ? (all_on_view ? c : vc) : c; // component of the frame behind plane c of the request frame
+    int32_t *m = maps.data() + (size_t)c * stride;
+    for (int r = 0; r < stride; r++) m[r] = r;
+    if (!p.requested[pc]) {
+      for (int r = 0; r < stride; r++) m[r] = -1;
+      continue;
+    }
+    // (a component that appears in no scan carries coefficients that transform to zeros in every row: host_decoder.cpp)
+    for (int r = p.g0[pc]; r <= p.g1[pc] && r < stride && r < (int)p.rowmap[pc].size(); r++) {
+      m[r] = p.rowmap[pc][(size_t)r];
+      if (m[r] >= 0) all_zero = false;
+    }
+  }
+  const int y_count = p.max_y - p.min_y + 1;
+  if (all_zero) {
+    // every sample the request shows is the transform of "no row": 0 through the filters and the identity transformation
+    HIP_TRY(d, hipMemsetAsync(d->req_dev + (size_t)p.min_y * row, 0, (size_t)y_count * row, d->stream));
+  } else {
+    rc = ensure_dev(d, (void **)&d->rowmap_dev, &d->rowmap_cap, maps.size() * sizeof(int32_t));
+    if (rc) return rc;
+    HIP_TRY(d, hipMemcpyAsync(d->rowmap_dev, maps.data(), maps.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream)); // `maps` is pageable and leaves scope; uploads of the coefficients are complete too
+    b.coef_dev = d->coef_dev + (vc >= 0 && !all_on_view ? f.coef_offset[vc] : 0);
+    b.coef_frame_stride = g.coef_count;
+    b.out_dev = d->req_dev;
+    b.out_row_stride = (int64_t)row;
+    b.out_frame_stride = (int64_t)padded;
+    b.frames = 1;
+    b.flags = pass | MIJPEG_FLAG_FORCE_GENERIC | (p.ycc ? 0u : MIJPEG_FLAG_NO_COLOR_TRANSFORM);
+    const size_t ws = mijpeg_workspace_bytes(&b);
+    if (ws) {
+      rc = ensure_dev(d, (void **)&d->ws_dev, &d->ws_cap, ws);
+      if (rc) return rc;
+      b.workspace = d->ws_dev;
+      b.workspace_bytes = d->ws_cap;
+    }
+    RequestExtra rx;
+    memset(&rx, 0, sizeof(rx));
+    rx.rowmap_dev = d->rowmap_dev;
+    rx.rowmap_stride = stride;
+    rx.corner_x = p.corner_x;
+    rx.corner_y = p.corner_y;
+    rx.y_base = p.min_y;
+    rx.y_count = y_count;
+    rx.ycc = p.ycc ? 1 : 0;
+    for (int c = 0; c < nc; c++) {
+      const int pc = vc >= 0 ? vc : c;
+      const bool up = vc < 0 && p.upsampling_path && p.upsampler[pc] && p.requested[pc];
+      rx.wstart[c] = up ? p.wstart[pc] : 0;
+      rx.wlimit[c] = up ? p.wlimit[pc] : (g.height + g.suby[c] - 1) / g.suby[c];
+    }
+    rc = launch_reconstruct_ex(&b, d->stream, &rx);
+    if (rc) return set_error(d, rc, rc == MIJPEG_ERR_DEVICE ? std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError())
+                                                             : std::string("reconstruction not available for this request"));
+  }
+  // hand the lines out
+  for (int c = min_comp; c <= max_comp; c++) {
+    if (!dst[c] || cx1[c] < p.min_x || cy1[c] < p.min_y) continue;
+    const int plane = vc >= 0 ? (all_on_view ? c : 0) : c;
+    if (to_device) {
+      ScatterArgs a;
+      memset(&a, 0, sizeof(a));
+      a.src = d->req_dev;
+      a.src_row = (int64_t)row;
+      a.ncomp = nc;
+      a.sample_bytes = sb;
+      a.x0 = p.min_x;
+      a.y0 = p.min_y;
+      a.w = cx1[c] - p.min_x + 1;
+      a.h = cy1[c] - p.min_y + 1;
+      a.c0 = a.c1 = plane;
+      a.dst[plane] = (uint8_t *)dst[c];
+      a.bytes_per_pixel[plane] = bpp[c];
+      a.bytes_per_row[plane] = bpr[c];
+      if (launch_scatter_rect(a, d->stream)) return hip_fail(d, hipGetLastError(), "scatter_rect_kernel launch");
+    }
+  }
+  if (to_device) {
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    return MIJPEG_OK;
+  }
+  if (d->req_host_cap < padded) {
+    if (d->req_host) (void)hipHostFree(d->req_host);
+    d->req_host = nullptr;
+    d->req_host_cap = 0;
+    HIP_TRY(d, hipHostMalloc((void **)&d->req_host, padded, hipHostMallocDefault));
+    d->req_host_cap = padded;
+  }
+  HIP_TRY(d, hipMemcpyAsync(d->req_host + (size_t)p.min_y * row, d->req_dev + (size_t)p.min_y * row, (size_t)y_count * row, hipMemcpyDeviceToHost,
+                            d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  for (int c = min_comp; c <= max_comp; c++) {
+    if (!dst[c] || cx1[c] < p.min_x || cy1[c] < p.min_y) continue;
+    const int plane = vc >= 0 ? (all_on_view ? c : 0) : c;
+    const int n = cx1[c] - p.min_x + 1;
+    for (int y = p.min_y; y <= cy1[c]; y++) {
+      const uint8_t *src = d->req_host + (size_t)y * row + ((size_t)p.min_x * nc + plane) * sb;
+      uint8_t *out = (uint8_t *)dst[c] + (ptrdiff_t)y * bpr[c] + (ptrdiff_t)p.min_x * bpp[c];
+      if (sb == 1)
+        for (int x = 0; x < n; x++) out[(ptrdiff_t)x * bpp[c]] = src[(size_t)x * nc];
+      else
+        for (int x = 0; x < n; x++) memcpy(out + (ptrdiff_t)x * bpp[c], src + (size_t)x * nc * 2, 2);
+    }
+  }
+  return MIJPEG_OK;
+}
+
+int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
+                        uint32_t flags, const uint32_t bm_height[MIJPEG_MAX_COMPONENTS], int32_t out[8 + 6 * MIJPEG_MAX_COMPONENTS])
+{
+  if (!d || !bm_height || !out) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->host.info.components < 1 || d->host.info.width < 1) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no parsed stream: call mijpeg_read_header first");
+  const mijpeg_info &f = d->host.info;
+  if (!d->model_valid) {
+    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0);
+    d->model_valid = true;
+  }
+  const RequestPlan p = d->model.request(min_x, min_y, max_x, max_y, min_comp, max_comp, !(flags & MIJPEG_FLAG_NO_UPSAMPLING),
+                                         !(flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM), bm_height);
+  out[0] = p.nothing; out[1] = p.plain; out[2] = p.ycc; out[3] = p.view;
+  out[4] = p.min_x; out[5] = p.min_y; out[6] = p.max_x; out[7] = p.max_y;
+  for (int c = 0; c < MIJPEG_MAX_COMPONENTS; c++) {
+    int32_t *o = out + 8 + 6 * c;
+    o[0] = d->model.cursor(c); o[1] = p.g0[c]; o[2] = p.g1[c]; o[3] = p.wstart[c]; o[4] = p.wlimit[c];
+    int zeros = 0;
+    for (int g = p.g0[c]; g <= p.g1[c] && g < (int)p.rowmap[c].size(); g++) zeros += p.rowmap[c][(size_t)g] < 0;
+    o[5] = zeros;
+  }
+  return MIJPEG_OK;
+}
+
+int mijpeg_display_cursor(mijpeg_decoder *d, int component)
+{
+  if (!d || component < 0 || component >= MIJPEG_MAX_COMPONENTS || !d->model_valid) return 0;
+  return d->model.cursor(component);
 }
 
 } // extern "C"

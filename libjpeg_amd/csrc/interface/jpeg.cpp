@@ -339,8 +339,6 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
   if (!bmh) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no bitmap hook (JPGTAG_BIH_HOOK) specified");
 
   // REQUEST: one hook call per component with the tag layout of interface/bitmaphook.cpp:130-161
-  void *dst[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
-  int32_t bpp[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0}, bpr[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
   struct Bitmap { void *mem; JPG_LONG width, height, bpr, bpp, type; void *user; } bm[MIJPEG_MAX_COMPONENTS];
   auto call_hook = [&](int c, int action, Bitmap &b) -> JPG_LONG {
     const int sx = f.subx[c], sy = f.suby[c];
@@ -379,7 +377,8 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
     }
     return r;
   };
-  JPG_LONG maxmcu = 0x7fffffff;
+  mijpeg_bitmap maps[MIJPEG_MAX_COMPONENTS];
+  memset(maps, 0, sizeof(maps));
   for (int c = c0; c <= c1; c++) {
     bm[c] = Bitmap{nullptr, 0, 0, 0, 0, f.sample_bytes == 2 ? CTYP_UWORD : CTYP_UBYTE, nullptr};
     const JPG_LONG r = call_hook(c, JPGFLAG_BIO_REQUEST, bm[c]);
@@ -387,23 +386,20 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
     const JPG_LONG want = f.sample_bytes == 2 ? CTYP_UWORD : CTYP_UBYTE;
     if (bm[c].type != want && bm[c].type != 0) // control/bitmapctrl.cpp:152-158: types must fit the data
       return p->fail(JPGERR_INVALID_PARAMETER, "pixel type of the user bitmap does not fit the sample precision of the image");
-    dst[c] = bm[c].type ? bm[c].mem : nullptr; // pixel type 0 = "no memory for this component"
-    bpp[c] = bm[c].bpp;
-    bpr[c] = bm[c].bpr;
-    // blockbitmaprequester.cpp:1229-1244: the reported height bounds the reconstructed block rows
-    const JPG_LONG m = (JPG_LONG)(((uint32_t)bm[c].height) >> 3) - 1;
-    if (m < maxmcu) maxmcu = m;
+    maps[c].data = bm[c].type ? bm[c].mem : nullptr; // pixel type 0 = "no memory for this component"
+    maps[c].bytes_per_pixel = bm[c].bpp;
+    maps[c].bytes_per_row = bm[c].bpr;
+    // blockbitmaprequester.cpp:1229-1244: the reported height bounds the reconstructed block rows; a blank bitmap puts no
+    // constraint on the dimensions (interface/imagebitmap.cpp:118-121)
+    maps[c].width = bm[c].type ? (uint32_t)bm[c].width : 0x7fffffffu;
+    maps[c].height = (uint32_t)bm[c].height;
   }
-  int rc = MIJPEG_OK;
-  // the block rows the bitmap covers are counted on the grid that is reconstructed: the canvas, or the component's own
-  const JPG_LONG lines_per_row = upsample ? 1 : f.suby[c0];
-  const JPG_LONG ylimit = (maxmcu >= 0x0fffffff / lines_per_row) ? maxy : (maxmcu + 1) * 8 * lines_per_row - 1;
-  const JPG_LONG y1 = maxy < ylimit ? maxy : ylimit;
-  if (maxmcu >= 0 && y1 >= miny)
-    rc = mijpeg_reconstruct_rect(p->dec, minx, miny, maxx, y1, c0, c1,
-                                 (ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM) | (device_bitmaps ? MIJPEG_FLAG_DEVICE_OUTPUT : 0) |
-                                     (upsample ? 0 : MIJPEG_FLAG_NO_UPSAMPLING),
-                                 dst, bpp, bpr);
+  // the request joins the sequence of requests this object has seen: row cursors and upsampler buffers of the reference's
+  // BlockBitmapRequester carry over from call to call, see mijpeg_display_rect
+  const int rc = mijpeg_display_rect(p->dec, minx, miny, maxx, maxy, c0, c1,
+                                     (ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM) | (device_bitmaps ? MIJPEG_FLAG_DEVICE_OUTPUT : 0) |
+                                         (upsample ? 0 : MIJPEG_FLAG_NO_UPSAMPLING),
+                                     maps);
   // RELEASE is always delivered, also after a failure, so the client can let go of its buffers
   JPG_LONG hookerr = 0;
   for (int c = c0; c <= c1; c++) {

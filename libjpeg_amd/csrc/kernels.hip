@@ -2010,8 +2010,13 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   if (comp >= a.wide_first && comp < a.wide_first + a.wide_count) return; // idct_planes_wide_kernel's
   const int16_t *__restrict__ plane = a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp];
   u32x4 rows[8];
+  const int32_t *__restrict__ rowmap = a.rowmap ? a.rowmap + comp * a.rowmap_stride : nullptr;
   fetch_blocks(rows, stage_all[wave], lane, [&](int m) -> const u32x4 * {
-    const int n = min(first + (lane >> 3) + 8 * m, nblocks - 1);
+    int n = min(first + (lane >> 3) + 8 * m, nblocks - 1);
+    if (rowmap) { // the block row's coefficients come from another row (rows of zeros read row 0 and are zeroed below)
+      const int gy = n / a.bw[comp];
+      n += (max(rowmap[gy], 0) - gy) * a.bw[comp];
+    }
     return reinterpret_cast<const u32x4 *>(plane + (int64_t)n * 64) + (lane & 7);
   });
   const int blk = first + lane;
@@ -2021,6 +2026,10 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   if (FAST) dequant_idct_sparse(rows, q, v, a.dcoff[comp]);
   else dequant_idct<false>(rows, q, v, a.dcoff[comp]);
   const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
+  if (rowmap && rowmap[by] < 0) {
+#pragma unroll
+    for (int i = 0; i < 64; i++) v[i] = 0;
+  }
   const int pitch = a.bw[comp] * 8;
   if (NARROW) {
     short *dst = reinterpret_cast<short *>(a.samples) + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
@@ -2075,8 +2084,11 @@ __global__ __launch_bounds__(256) void idct_planes_wide_kernel(const GenericArgs
   const int nblocks = a.bw[comp] * a.bh[comp];
   const int blk = blockIdx.x * blockDim.x + threadIdx.x;
   if (blk >= nblocks) return;
+  const int32_t *__restrict__ rowmap = a.rowmap ? a.rowmap + comp * a.rowmap_stride : nullptr;
+  const int sblk = rowmap ? blk + (max(rowmap[blk / a.bw[comp]], 0) - blk / a.bw[comp]) * a.bw[comp] : blk;
+  const bool zeros = rowmap && rowmap[blk / a.bw[comp]] < 0;
   const int32_t *__restrict__ src =
-      reinterpret_cast<const int32_t *>(a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp]) + (int64_t)blk * 64;
+      reinterpret_cast<const int32_t *>(a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp]) + (int64_t)sblk * 64;
   int tmp[64];
 #pragma unroll
   for (int r = 0; r < 8; r++) {
@@ -2100,7 +2112,7 @@ __global__ __launch_bounds__(256) void idct_planes_wide_kernel(const GenericArgs
     for (int k = 0; k < 8; k++) s[k] = tmp[k * 8 + x];
     idct_1d_quad(s, o, true);
 #pragma unroll
-    for (int k = 0; k < 8; k++) dst[(int64_t)k * pitch + x] = (int)((o[k] + 2048) >> 12);
+    for (int k = 0; k < 8; k++) dst[(int64_t)k * pitch + x] = zeros ? 0 : (int)((o[k] + 2048) >> 12);
   }
 }
 
@@ -2116,8 +2128,11 @@ __global__ __launch_bounds__(256) void idct_planes_long_kernel(const GenericArgs
   const int nblocks = a.bw[comp] * a.bh[comp];
   const int blk = blockIdx.x * blockDim.x + threadIdx.x;
   if (blk >= nblocks) return;
+  const int32_t *__restrict__ rowmap = a.rowmap ? a.rowmap + comp * a.rowmap_stride : nullptr;
+  const int sblk = rowmap ? blk + (max(rowmap[blk / a.bw[comp]], 0) - blk / a.bw[comp]) * a.bw[comp] : blk;
+  const bool zeros = rowmap && rowmap[blk / a.bw[comp]] < 0;
   const int32_t *__restrict__ src =
-      reinterpret_cast<const int32_t *>(a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp]) + (int64_t)blk * 64;
+      reinterpret_cast<const int32_t *>(a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp]) + (int64_t)sblk * 64;
   int v[64];
 #pragma unroll
   for (int r = 0; r < 16; r++) {
@@ -2133,6 +2148,10 @@ __global__ __launch_bounds__(256) void idct_planes_long_kernel(const GenericArgs
     idct_1d<false, 9>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
 #pragma unroll
   for (int c = 0; c < 8; c++) idct_1d<false, 12>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+  if (zeros) {
+#pragma unroll
+    for (int i = 0; i < 64; i++) v[i] = 0;
+  }
   const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
   const int pitch = a.bw[comp] * 8;
   int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[comp] + ((int64_t)by * 8) * pitch + bx * 8;
@@ -2155,18 +2174,24 @@ __device__ __forceinline__ int f8(int wa, int x, int wb, int y, int r)
   return (int)((unsigned)wa * (unsigned)x + (unsigned)wb * (unsigned)y + (unsigned)r) >> 3;
 }
 
+// (lo: first line the filter may read -- 0, or the start of the upsampler's buffered window for rectangle requests, where
+// ch is the window's end)
 template <class T>
 __device__ __forceinline__ void upsample_line_any(const T *__restrict__ plane, int pitch, int cw, int ch, int sx, int sy, int X0, int Y,
-                                               int (&o)[8])
+                                               int (&o)[8], int lo = 0, int defcols = 0)
 {
   const int y = Y / sy, ymod = Y - y * sy;
-  const int cur = min(y, ch - 1), top = min(max(y - 1, 0), ch - 1), bot = min(cur + 1, ch - 1);
+  const int cur = min(y, ch - 1), top = min(max(y - 1, lo), ch - 1), bot = min(cur + 1, ch - 1);
   const int x = (sx > 1) ? X0 / sx - 1 : X0; // chroma column of buffer entry 0
   const T *pc = plane + (int64_t)cur * pitch, *pt = plane + (int64_t)top * pitch, *pb = plane + (int64_t)bot * pitch;
   int v[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    const int col = min(max(x + j, 0), cw - 1);
+    // line buffer of the reference: entry -1 and entry cw replicate the edge samples (upsamplerbase.cpp:322-323); behind
+    // that the buffer still holds what the transform of the last block left there, which only a displaced read sees
+    // (defcols: samples per line that the blocks of the plane cover)
+    int col = min(max(x + j, 0), cw - 1);
+    if (defcols && x + j > cw) col = min(x + j, defcols - 1);
     const int c = pc[col];
     const int odd = j & 1;
     int val = c;
@@ -2300,8 +2325,17 @@ __device__ __forceinline__ void upsample_plane_line(const GenericArgs &a, int p,
 {
   using T = typename std::conditional<NARROW, short, int>::type; // (NARROW: int16 sample planes, same offsets in samples)
   const T *plane = reinterpret_cast<const T *>(a.samples) + (int64_t)frame * a.sample_frame_stride + a.sample_off[p];
-  if constexpr (LAYOUT == LAYOUT_ANY) upsample_line_any<T>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], a.subx[p], a.suby[p], X0, Y, o);
-  else {
+  if constexpr (LAYOUT == LAYOUT_ANY) {
+    if (a.request && (a.subx[p] > 1 || a.suby[p] > 1)) {
+      // Upsampler::UpsampleRegion starts at the corner of the rectangle (upsampler.cpp:85-86), the colour transformer reads
+      // the result at (x & 7, y & 7): displaced in the request's first row / column of blocks; the vertical filter stops
+      // at the buffered window
+      const int Xd = (X0 == (a.req_x0 & ~7)) ? a.req_x0 : X0;
+      const int Yd = ((Y & ~7) == (a.req_y0 & ~7)) ? a.req_y0 + (Y & 7) : Y;
+      upsample_line_any<T>(plane, a.bw[p] * 8, a.cw[p], a.wlimit[p], a.subx[p], a.suby[p], Xd, Yd, o, a.wstart[p], ((a.cw[p] + 7) >> 3) * 8);
+    } else
+      upsample_line_any<T>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], a.subx[p], a.suby[p], X0, Y, o);
+  } else {
     if (comp == 0) upsample_line_t<1, 1, T>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
     else upsample_line_t<LAYOUT / 4, LAYOUT % 4, T>(plane, a.bw[p] * 8, a.cw[p], a.ch[p], X0, Y, o);
   }
@@ -2324,7 +2358,7 @@ __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a
 {
   const int groups = (a.width + 7) >> 3;
   const int gxi = blockIdx.x * blockDim.x + threadIdx.x;
-  const int Y = blockIdx.y;
+  const int Y = blockIdx.y + a.y_base;
   const int frame = blockIdx.z;
   if (gxi >= groups) return;
   const int X0 = gxi * 8;
@@ -2710,7 +2744,7 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
   }
   const int groups = (a.width + 7) >> 3;
   const int bs = groups >= 256 ? 256 : 64;
-  dim3 g2((groups + bs - 1) / bs, a.height, a.frames);
+  dim3 g2((groups + bs - 1) / bs, a.y_count > 0 ? a.y_count : a.height, a.frames);
   // layout of planes [first, first + 3): luma 1x1 and equal chroma factors in {1,2}^2 get a specialised instance
   auto layout_of = [&](int first, int n) {
     if (n != 3 || a.subx[first] != 1 || a.suby[first] != 1 || a.subx[first + 1] != a.subx[first + 2] || a.suby[first + 1] != a.suby[first + 2] ||
@@ -2718,7 +2752,7 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
       return LAYOUT_ANY;
     return layout_id(a.subx[first + 1], a.suby[first + 1]);
   };
-  const int lay = layout_of(0, a.ncomp);
+  const int lay = a.request ? LAYOUT_ANY : layout_of(0, a.ncomp); // requests: window and displacement live in the runtime-factor instance
 #define LAUNCH_COLOR(F, L) hipLaunchKernelGGL((upsample_color_kernel<F, L>), g2, dim3(bs), 0, stream, a)
 #define LAUNCH_XT(L, R)                                                                       \
   do {                                                                                         \

@@ -81,6 +81,15 @@ struct GenericArgs {
   int32_t lmat[9], rmat[9], cmat[9];
   const int32_t *qlut[3];      // device, 2^(Pr + 4) entries each, or null = identity
   const int32_t *r2lut[3];     // device, 2^20 entries each, or null = identity
+  // Rectangle requests whose result is not the plain picture (request_model.hpp): the first kernel transforms, for block
+  // row g of plane p, the coefficient row rowmap[p * rowmap_stride + g] (-1: the samples are 0, dct/idct.cpp:336-338); the
+  // second kernel works on lines [y_base, y_base + grid.y), reads subsampled planes inside their upsampler's window
+  // [wstart, wlimit) and displaces them in the first row / column of blocks of the request (corner req_x0, req_y0).
+  const int32_t *rowmap;       // device, or null
+  int32_t rowmap_stride;
+  int32_t request;             // 1: window / displacement semantics below are in force (LAYOUT_ANY instances only)
+  int32_t req_x0, req_y0, y_base, y_count; // y_count: lines the second kernel works on (0: the whole frame)
+  int32_t wstart[MAXP], wlimit[MAXP];
 };
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);

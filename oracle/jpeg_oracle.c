@@ -1388,27 +1388,23 @@ static int32_t line_at(const int32_t *plane, int pitch, int cw, int row, int idx
   return plane[(size_t)row * pitch + clampi(idx - 1, 0, cw - 1)];
 }
 
-void oj_upsample_block(int32_t out[64], const int32_t *plane, int pitch, int cw, int ch, int sx,
-                       int sy, int X0, int Y0)
+/* The two filter cores over lines addressed by number: `at(ctx, row, idx)` is line `row`'s m_pData[idx]; rows advance
+ * like the reference's list walk (`if (bot->m_pNext) bot = bot->m_pNext`) with `limit` = one past the last line there is. */
+typedef int32_t (*oj_line_fn)(const void *ctx, int row, int idx);
+static void upsample_core(int32_t out[64], oj_line_fn at, const void *ctx, int top, int cur, int bot, int limit, int x,
+                          int sx, int sy, int xmod, int ymod)
 {
-  /* upsampler.cpp:83-117 */
-  int y = Y0 / sy, x = X0 / sx + 1, l, j;
-  int top = y > 0 ? y - 1 : 0, cur = y, bot;
-  int ymod = Y0 % sy, xmod = X0 % sx;
+  int l, j;
   int32_t *target = out;
-  if (cur > ch - 1) cur = ch - 1; /* blocks entirely below the last stored line are never output */
-  if (top > ch - 1) top = ch - 1;
-  bot = cur + 1 < ch ? cur + 1 : cur;
-  if (sx > 1) x--;
-#define T(j) line_at(plane, pitch, cw, top, x + (j))
-#define C(j) line_at(plane, pitch, cw, cur, x + (j))
-#define B(j) line_at(plane, pitch, cw, bot, x + (j))
-#define ADVANCE() do { top = cur; cur = bot; if (bot + 1 < ch) bot++; } while (0)
+#define T(j) at(ctx, top, x + (j))
+#define C(j) at(ctx, cur, x + (j))
+#define B(j) at(ctx, bot, x + (j))
+#define ADVANCE() do { top = cur; cur = bot; if (bot + 1 < limit) bot++; } while (0)
   for (l = 0; l < 8; l++, target += 8) {
     switch (sy) {
     case 1: /* :118-131 */
       for (j = 0; j < 8; j++) target[j] = C(j);
-      if (cur + 1 < ch) cur++;
+      if (cur + 1 < limit) cur++;
       break;
     case 2: /* :136-168 */
       if (ymod == 0) {
@@ -1513,6 +1509,28 @@ void oj_upsample_block(int32_t out[64], const int32_t *plane, int pitch, int cw,
   }
 #undef F2
 #undef F8
+}
+
+typedef struct { const int32_t *plane; int pitch, cw; } oj_plane_ctx;
+static int32_t plane_line_at(const void *ctx, int row, int idx)
+{
+  const oj_plane_ctx *p = (const oj_plane_ctx *)ctx;
+  return line_at(p->plane, p->pitch, p->cw, row, idx);
+}
+
+void oj_upsample_block(int32_t out[64], const int32_t *plane, int pitch, int cw, int ch, int sx,
+                       int sy, int X0, int Y0)
+{
+  /* upsampler.cpp:83-117 */
+  oj_plane_ctx ctx;
+  int y = Y0 / sy, x = X0 / sx + 1;
+  int top = y > 0 ? y - 1 : 0, cur = y, bot;
+  ctx.plane = plane; ctx.pitch = pitch; ctx.cw = cw;
+  if (cur > ch - 1) cur = ch - 1; /* blocks entirely below the last stored line are never output */
+  if (top > ch - 1) top = ch - 1;
+  bot = cur + 1 < ch ? cur + 1 : cur;
+  if (sx > 1) x--;
+  upsample_core(out, plane_line_at, &ctx, top, cur, bot, ch, x, sx, sy, X0 % sx, Y0 % sy);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1689,6 +1707,334 @@ int oj_reconstruct16(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint1
   return reconstruct_ex(f, planes, NULL, pixels, use_ycbcr, NULL);
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * The rectangle service as a sequence of requests: JPEG::DisplayRectangle (interface/jpeg.cpp:694-722) ->
+ * Image::ReconstructRegion (codestream/image.cpp:1087-1123) -> BlockBitmapRequester::RequestUserDataForDecoding /
+ * ReconstructRegion (control/blockbitmaprequester.cpp:1229-1272), restated LITERALLY with the state the reference
+ * keeps between calls: one row cursor per component into its list of coefficient rows (m_pppQImage, only ever advanced:
+ * nothing resets it while decoding) and the line buffer of every subsampled component's upsampler
+ * (upsampling/upsamplerbase.cpp).  A cursor behind the last row reads NULL and a NULL row transforms to SAMPLE value 0
+ * (dct/idct.cpp:336-338).  What follows from it -- and what whole-frame reconstruction cannot show:
+ *  - on the upsampling path every call advances the cursor of EVERY component without an upsampler, requested or not
+ *    (:1214-1223), so the reference's own component-by-component PGX loop (cmd/reconstruct.cpp:272-303) delivers zero
+ *    planes for the second, third ... unsubsampled component of a frame that also has a subsampled one;
+ *  - components outside the requested range enter the colour transformation as 0 (:1190-1193, :1047-1054);
+ *  - the upsampler hands out 8x8 samples starting AT the rectangle's corner (upsampler.cpp:85-86) while the colour
+ *    transformer reads its source block at (x & 7, y & 7) (colortrafo/ycbcrtrafo.cpp:683-686): rectangles that do not
+ *    start on the block grid see subsampled components displaced in their first row / column of blocks;
+ *  - requests that skip or repeat stripes read the rows the cursors happen to stand at;
+ *  - the colour transformer is chosen by the first request and kept (colortransformerfactory.cpp:220-221).
+ * Not modelled: JPEG XT residuals, alpha channels, and reads of line-buffer memory the reference never initialised
+ * (rectangles narrower than the frame that move sideways between calls): OJ_ERR_UNSUPPORTED.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int sx, sy, width, total; /* m_ucSubX/Y, m_ulWidth, m_lTotalLines (upsamplerbase.cpp:61-77) */
+  int pw, ph;               /* m_ulPixelWidth / Height */
+  int y, h;                 /* m_lY, m_lHeight: lines [y, y + h) are buffered */
+  int32_t **line;           /* line[k] = m_pData of line y + k, width + 2 + 8 LONGs */
+  int cap;
+} oj_up;
+
+struct oj_requester {
+  oj_info f;
+  const int32_t *planes[OJ_MAX_COMP];
+  int cur[OJ_MAX_COMP];   /* m_pppQImage[c]: index of the row it stands at; >= rows[c]: NULL */
+  int rows[OJ_MAX_COMP];  /* rows the scans created: ceil(ch / 8) (control/blockbuffer.cpp:212-265) */
+  oj_up *up[OJ_MAX_COMP]; /* m_ppUpsampler (blockbitmaprequester.cpp:298-322) */
+  int subsampling;        /* m_bSubsampling */
+  int trafo_built, ycc;   /* the colour transformer is built by the first request that reconstructs something and kept
+                             (colortrafo/colortransformerfactory.cpp:220-221): later JPGTAG_MATRIX_LTRAFO values change nothing */
+};
+
+static void up_free(oj_up *u)
+{
+  int k;
+  if (!u) return;
+  for (k = 0; k < u->h; k++) free(u->line[k]);
+  free(u->line);
+  free(u);
+}
+
+/* upsamplerbase.cpp:163-212 SetBufferedRegion + :218-259 ExtendBufferedRegion; min_y / max_y in blocks; returns the first
+ * block row the caller has to define (the rectangle the reference hands back), or a negative error */
+static int up_set_buffered_region(oj_up *u, int min_y, int max_y)
+{
+  int maxy;
+  while (u->y < (min_y << 3)) {
+    if (u->h > 0) {
+      free(u->line[0]);
+      memmove(u->line, u->line + 1, (size_t)(u->h - 1) * sizeof(*u->line));
+      u->h--;
+    }
+    u->y++;
+  }
+  if (u->y > (min_y << 3)) { /* part of the buffer lies below the top line: dispose of it */
+    int k;
+    for (k = 0; k < u->h; k++) free(u->line[k]);
+    u->h = 0;
+    u->y = min_y << 3;
+  }
+  min_y = (u->y + u->h + 7) >> 3;
+  maxy = (1 + max_y) << 3;
+  if (maxy > u->total) maxy = u->total;
+  while (u->y + u->h < maxy) {
+    if (u->h >= u->cap) {
+      int32_t **nl = (int32_t **)realloc(u->line, (size_t)(u->cap + 64) * sizeof(*u->line));
+      if (!nl) return OJ_ERR_NOMEM;
+      u->line = nl;
+      u->cap += 64;
+    }
+    u->line[u->h] = (int32_t *)calloc((size_t)u->width + 2 + 8, sizeof(int32_t));
+    if (!u->line[u->h]) return OJ_ERR_NOMEM;
+    u->h++;
+  }
+  return min_y;
+}
+
+/* upsamplerbase.cpp:300-327 */
+static int up_define_region(oj_up *u, int bx, int by, const int32_t *data)
+{
+  int k = (by << 3) - u->y, cnt = 8;
+  if (k < 0 || k >= u->h) return OJ_ERR_UNSUPPORTED; /* the reference asserts */
+  do {
+    int32_t *dest = u->line[k] + 1;
+    memcpy(dest + (bx << 3), data, 8 * sizeof(int32_t));
+    dest[-1] = dest[0];
+    dest[u->width] = dest[u->width - 1];
+    k++;
+    data += 8;
+  } while (--cnt && k < u->h);
+  return OJ_OK;
+}
+
+static int32_t up_line_at(const void *ctx, int row, int idx)
+{
+  const oj_up *u = (const oj_up *)ctx;
+  return u->line[row - u->y][idx];
+}
+
+/* upsampler.cpp:83-117 UpsampleRegion for the rectangle whose corner is (min_x, min_y) */
+static int up_upsample_region(const oj_up *u, int min_x, int min_y, int32_t out[64])
+{
+  int y = min_y / u->sy, x = min_x / u->sx + 1;
+  int top, cur, bot;
+  if (y < u->y || y >= u->y + u->h) return OJ_ERR_UNSUPPORTED; /* "must be in the buffer" */
+  top = u->y;
+  if (y - 1 > top) top = y - 1;
+  cur = top;
+  if (y > u->y) cur++;
+  if (cur >= u->y + u->h) return OJ_ERR_UNSUPPORTED;
+  bot = cur + 1 < u->y + u->h ? cur + 1 : cur;
+  if (u->sx > 1) x--;
+  upsample_core(out, up_line_at, u, top, cur, bot, u->y + u->h, x, u->sx, u->sy, min_x % u->sx, min_y % u->sy);
+  return OJ_OK;
+}
+
+oj_requester *oj_requester_new(const oj_info *f, int32_t *const planes[OJ_MAX_COMP])
+{
+  oj_requester *rq = (oj_requester *)calloc(1, sizeof(*rq));
+  int c;
+  if (!rq) return NULL;
+  rq->f = *f;
+  for (c = 0; c < f->ncomp; c++) {
+    rq->planes[c] = planes[c];
+    rq->rows[c] = (f->ch[c] + 7) >> 3;
+    if (f->subx[c] > 1 || f->suby[c] > 1) { /* blockbitmaprequester.cpp:310-318 */
+      oj_up *u = (oj_up *)calloc(1, sizeof(*u));
+      if (!u) { oj_requester_free(rq); return NULL; }
+      u->sx = f->subx[c]; u->sy = f->suby[c];
+      u->pw = f->width; u->ph = f->height;
+      u->width = (f->width + u->sx - 1) / u->sx;
+      u->total = (f->height + u->sy - 1) / u->sy;
+      rq->up[c] = u;
+      rq->subsampling = 1;
+    }
+  }
+  return rq;
+}
+
+int oj_requester_cursor(const oj_requester *rq, int c) { return rq->cur[c]; }
+
+void oj_requester_free(oj_requester *rq)
+{
+  int c;
+  if (!rq) return;
+  for (c = 0; c < OJ_MAX_COMP; c++) up_free(rq->up[c]);
+  free(rq);
+}
+
+static const int32_t *rq_row_block(const oj_requester *rq, int c, int bx)
+{
+  if (rq->cur[c] >= rq->rows[c]) return NULL; /* *m_pppQImage[c] == NULL */
+  return rq->planes[c] + ((size_t)rq->cur[c] * rq->f.bw[c] + bx) * 64;
+}
+
+static void rq_idct(const oj_requester *rq, int c, const int32_t *src, int32_t dst[64])
+{
+  const oj_info *f = &rq->f;
+  if (f->scan_state_valid && !f->comp_seen[c]) { memset(dst, 0, 64 * sizeof(int32_t)); return; } /* m_ppDCT[c] == NULL */
+  oj_idct_block(dst, src, f->scan_state_valid ? f->cquant[c] : f->quant[f->tq[c]], f->precision);
+}
+
+/* colortrafo/ycbcrtrafo.cpp:679-1009 for the rectangle r = [x0, x1] x [y0, y1] inside one block: reads the sources at
+ * (x & 7, y & 7), writes through the bitmaps that are there */
+static void rq_color(const oj_requester *rq, int ycc, int x0, int y0, int x1, int y1, int32_t src[OJ_MAX_COMP][64],
+                     void *const dst[OJ_MAX_COMP], const int bpp[OJ_MAX_COMP], const int bpr[OJ_MAX_COMP],
+                     const int bm_width[OJ_MAX_COMP], const int bm_height[OJ_MAX_COMP], int sample_bytes)
+{
+  const oj_info *f = &rq->f;
+  const int64_t L[9] = {FIX13(1.0), FIX13(0.0), FIX13(1.40200), FIX13(1.0), -FIX13(0.3441362861), -FIX13(0.7141362859),
+                        FIX13(1.0), FIX13(1.772), FIX13(0.0)};
+  const int32_t dcshift = (int32_t)(1 << (f->precision - 1)) << 4;
+  const int64_t maxval = ((int64_t)1 << f->precision) - 1;
+  int x, y, c;
+  for (y = y0; y <= y1; y++)
+    for (x = x0; x <= x1; x++) {
+      const int k = (y & 7) * 8 + (x & 7);
+      int64_t v[OJ_MAX_COMP];
+      if (ycc) {
+        int64_t yy = src[0][k], cb = (int64_t)src[1][k] - dcshift, cr = (int64_t)src[2][k] - dcshift;
+        v[0] = (yy * L[0] + cb * L[1] + cr * L[2] + 65536) >> 17;
+        v[1] = (yy * L[3] + cb * L[4] + cr * L[5] + 65536) >> 17;
+        v[2] = (yy * L[6] + cb * L[7] + cr * L[8] + 65536) >> 17;
+      } else
+        for (c = 0; c < f->ncomp; c++) v[c] = ((int64_t)src[c][k] + 8) >> 4;
+      for (c = 0; c < f->ncomp; c++) {
+        uint8_t *p;
+        if (!dst[c]) continue;
+        /* BitmapCtrl::ExtractBitmap -> interface/imagebitmap.cpp:58-129: a block whose corner lies outside the bitmap the
+         * hook described is blank, nothing of it is written (a block that starts inside is written in full) */
+        if ((uint32_t)bm_width[c] <= (uint32_t)x0 || (uint32_t)bm_height[c] <= (uint32_t)y0) continue;
+        p = (uint8_t *)dst[c] + (ptrdiff_t)y * bpr[c] + (ptrdiff_t)x * bpp[c];
+        if (sample_bytes == 2) { uint16_t w = (uint16_t)clampmax(v[c], maxval); memcpy(p, &w, 2); }
+        else *p = (uint8_t)clampmax(v[c], maxval);
+      }
+    }
+}
+
+int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int max_y, int c0, int c1, int upsample, int ctrafo,
+                         void *const dst[OJ_MAX_COMP], const int bpp[OJ_MAX_COMP], const int bpr[OJ_MAX_COMP],
+                         const int bm_width[OJ_MAX_COMP], const int bm_height[OJ_MAX_COMP], int sample_bytes)
+{
+  const oj_info *f = &rq->f;
+  void *bm[OJ_MAX_COMP] = {0, 0, 0, 0};
+  uint32_t maxmcu = 0xffffffffu;
+  int c, ycc, rc;
+  if (sample_bytes != (f->precision > 8 ? 2 : 1)) return OJ_ERR_UNSUPPORTED;
+  /* codestream/rectanglerequest.cpp:62-190: clipped to the canvas; without upsampling no colour transformation */
+  if (min_x < 0) min_x = 0;
+  if (min_y < 0) min_y = 0;
+  if (max_x > f->width - 1) max_x = f->width - 1;
+  if (max_y > f->height - 1) max_y = f->height - 1;
+  if (c0 < 0) c0 = 0;
+  if (c1 > f->ncomp - 1) c1 = f->ncomp - 1;
+  if (!upsample) ctrafo = 0;
+  /* blockbitmaprequester.cpp:1229-1244: only the requested components have bitmaps; their heights bound the block rows
+   * (ULONG arithmetic: a height below 8 wraps to "no bound") */
+  for (c = c0; c <= c1; c++) {
+    const uint32_t m = ((uint32_t)bm_height[c] >> 3) - 1u;
+    bm[c] = dst[c];
+    if (m < maxmcu) maxmcu = m;
+  }
+  if (min_x > max_x || min_y > max_y) return OJ_OK; /* codestream/image.cpp:1115: empty regions are not reconstructed */
+  if (c0 > c1) return OJ_OK;
+  /* BlockBitmapRequester::ColorTrafoOf -> colortransformerfactory.cpp: YCbCr for three components unless switched off */
+  if (!rq->trafo_built) {
+    rq->trafo_built = 1;
+    rq->ycc = ctrafo && f->ycbcr && f->ncomp == 3;
+  }
+  ycc = rq->ycc;
+  if (rq->subsampling && upsample) {
+    uint32_t minx = (uint32_t)min_x >> 3, maxx = (uint32_t)max_x >> 3, miny = (uint32_t)min_y >> 3, maxy = (uint32_t)max_y >> 3, bx, by;
+    int r_min_y, r_max_y;
+    /* PullQData, :1079-1112 */
+    for (c = c0; c <= c1; c++) {
+      oj_up *u = rq->up[c];
+      int bwidth, bheight, rx, ry, b_min_x, b_max_x, b_min_y, b_max_y, yy, xx;
+      if (!u) continue;
+      /* upsamplerbase.cpp:138-156 SetBufferedImageRegion */
+      bwidth = ((u->pw + u->sx - 1) / u->sx + 7) >> 3;
+      bheight = ((u->ph + u->sy - 1) / u->sy + 7) >> 3;
+      rx = u->sx > 1; ry = u->sy > 1;
+      b_min_x = (min_x / u->sx - rx) >> 3;
+      b_max_x = (max_x / u->sx + rx) >> 3;
+      b_min_y = (min_y / u->sy - ry) >> 3;
+      b_max_y = (max_y / u->sy + ry) >> 3;
+      if (b_min_x < 0) b_min_x = 0;
+      if (b_max_x >= bwidth) b_max_x = bwidth - 1;
+      if (b_min_y < 0) b_min_y = 0;
+      if (b_max_y >= bheight) b_max_y = bheight - 1;
+      b_min_y = up_set_buffered_region(u, b_min_y, b_max_y);
+      if (b_min_y < 0) return b_min_y;
+      for (yy = b_min_y; yy <= b_max_y; yy++) {
+        for (xx = b_min_x; xx <= b_max_x; xx++) {
+          int32_t blk[64];
+          rq_idct(rq, c, rq_row_block(rq, c, xx), blk);
+          if ((rc = up_define_region(u, xx, yy, blk)) != OJ_OK) return rc;
+        }
+        if (rq->cur[c] < rq->rows[c]) rq->cur[c]++;
+      }
+    }
+    /* PushReconstructedData, :1151-1224 */
+    if (maxy > maxmcu) maxy = maxmcu;
+    for (by = miny, r_min_y = min_y; by <= maxy; by++, r_min_y = r_max_y + 1) {
+      int r_min_x, r_max_x;
+      r_max_y = (r_min_y & -8) + 7;
+      if (r_max_y > max_y) r_max_y = max_y;
+      for (bx = minx, r_min_x = min_x; bx <= maxx; bx++, r_min_x = r_max_x + 1) {
+        int32_t src[OJ_MAX_COMP][64];
+        r_max_x = (r_min_x & -8) + 7;
+        if (r_max_x > max_x) r_max_x = max_x;
+        for (c = 0; c < f->ncomp; c++) {
+          if (c >= c0 && c <= c1) {
+            if (rq->up[c]) {
+              if ((rc = up_upsample_region(rq->up[c], r_min_x, r_min_y, src[c])) != OJ_OK) return rc;
+            } else
+              rq_idct(rq, c, rq_row_block(rq, c, (int)bx), src[c]);
+          } else
+            memset(src[c], 0, sizeof(src[c]));
+        }
+        rq_color(rq, ycc, r_min_x, r_min_y, r_max_x, r_max_y, src, bm, bpp, bpr, bm_width, bm_height, sample_bytes);
+      }
+      for (c = 0; c < f->ncomp; c++) /* every component without an upsampler, requested or not (:1214-1217) */
+        if (!rq->up[c] && rq->cur[c] < rq->rows[c]) rq->cur[c]++;
+    }
+  } else {
+    /* ReconstructUnsampled, :1013-1074, on the region of control/bitmapctrl.cpp:273-294 */
+    uint32_t minx, maxx, miny, maxy, bx, by;
+    int r_min_y, r_max_y;
+    if (!upsample) {
+      int sx, sy;
+      if (c0 != c1) return OJ_ERR_MALFORMED; /* JPGERR_INVALID_PARAMETER in the reference */
+      sx = f->subx[c0]; sy = f->suby[c0];
+      min_x = (min_x + sx - 1) / sx;
+      max_x = (max_x + sx) / sx - 1;
+      min_y = (min_y + sy - 1) / sy;
+      max_y = (max_y + sy) / sy - 1;
+    }
+    minx = (uint32_t)min_x >> 3; maxx = (uint32_t)max_x >> 3; miny = (uint32_t)min_y >> 3; maxy = (uint32_t)max_y >> 3;
+    if (maxy > maxmcu) maxy = maxmcu;
+    for (by = miny, r_min_y = min_y; by <= maxy; by++, r_min_y = r_max_y + 1) {
+      int r_min_x, r_max_x;
+      r_max_y = (r_min_y & -8) + 7;
+      if (r_max_y > max_y) r_max_y = max_y;
+      for (bx = minx, r_min_x = min_x; bx <= maxx; bx++, r_min_x = r_max_x + 1) {
+        int32_t src[OJ_MAX_COMP][64];
+        r_max_x = (r_min_x & -8) + 7;
+        if (r_max_x > max_x) r_max_x = max_x;
+        for (c = 0; c < f->ncomp; c++) {
+          if (c >= c0 && c <= c1) rq_idct(rq, c, rq_row_block(rq, c, (int)bx), src[c]);
+          else memset(src[c], 0, sizeof(src[c]));
+        }
+        rq_color(rq, ycc, r_min_x, r_min_y, r_max_x, r_max_y, src, bm, bpp, bpr, bm_width, bm_height, sample_bytes);
+      }
+      for (c = c0; c <= c1; c++) /* only the requested ones (:1066-1071) */
+        if (rq->cur[c] < rq->rows[c]) rq->cur[c]++;
+    }
+  }
+  return OJ_OK;
+}
 
 /* ------------------------------------------------------------------------------------------
  * JPEG XT (ISO/IEC 18477) profile C, the subset the reference's encoder writes for

@@ -98,6 +98,21 @@ int oj_reconstruct(const oj_info *info, int32_t *const planes[OJ_MAX_COMP], uint
 /* Same for frames of precision 12 (and 8): 16-bit samples out. */
 int oj_reconstruct16(const oj_info *info, int32_t *const planes[OJ_MAX_COMP], uint16_t *pixels, int use_ycbcr);
 
+/* The rectangle service as the reference runs it: a SEQUENCE of JPEG::DisplayRectangle calls against one decoded image,
+ * with the state the reference keeps between them (row cursors per component, upsampler line buffers):
+ * control/blockbitmaprequester.cpp:1013-1272, upsampling/upsamplerbase.cpp:138-327.  planes are borrowed.
+ * oj_requester_display = one call: rectangle and component range inclusive as in JPGTAG_DECODER_MINX.. / MINCOMPONENT..,
+ * `upsample` / `ctrafo` = JPGTAG_DECODER_UPSAMPLE / JPGTAG_MATRIX_LTRAFO != NONE; per requested component the bitmap the
+ * hook would return: dst[c] = address of pixel (0,0) (NULL: no memory), strides in bytes, bm_width / bm_height[c] = BIO_WIDTH /
+ * BIO_HEIGHT (the height bounds the block rows that are reconstructed, :1229-1244; blocks that start outside are not written); sample_bytes 1 (precision 8) or 2.  Plain JPEG only. */
+typedef struct oj_requester oj_requester;
+oj_requester *oj_requester_new(const oj_info *info, int32_t *const planes[OJ_MAX_COMP]);
+void oj_requester_free(oj_requester *rq);
+int oj_requester_cursor(const oj_requester *rq, int c); /* row the component's cursor stands at (== rows: behind the last) */
+int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int max_y, int c0, int c1, int upsample, int ctrafo,
+                         void *const dst[OJ_MAX_COMP], const int bpp[OJ_MAX_COMP], const int bpr[OJ_MAX_COMP],
+                         const int bm_width[OJ_MAX_COMP], const int bm_height[OJ_MAX_COMP], int sample_bytes);
+
 /* JPEG XT profile C (subset: explicit L table, identity Q/R2 tables, standard matrices, no refinement scans):
  * 16-bit codes out (half-float bit patterns when *is_float). colortrafo/ycbcrtrafo.cpp:750-955. */
 int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float);

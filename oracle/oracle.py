@@ -61,6 +61,13 @@ def lib():
         L.oj_forward.argtypes = [C.POINTER(OjInfo), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.oj_fdct_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.oj_free.restype = None
+        L.oj_requester_new.restype = C.c_void_p
+        L.oj_requester_new.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
+        L.oj_requester_free.argtypes = [C.c_void_p]
+        L.oj_requester_free.restype = None
+        L.oj_requester_cursor.argtypes = [C.c_void_p, C.c_int]
+        L.oj_requester_display.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
         _lib = L
     return _lib
 
@@ -207,6 +214,13 @@ def decode_status(data: bytes, max_bytes: int = 1 << 28):
         return None, None, info.warnings
     if rc:
         return None, info.ref_error, info.warnings
+    if info.ncomp in (2, 4):
+        # the CLI writes such frames component by component (PGX, cmd/reconstruct.cpp:272-303), and the library's state
+        # between those calls shows: see oj_requester in jpeg_oracle.c
+        _, rcs, canvas = run_requests(data, cli_requests(info.width, info.height, info.ncomp), decoded=(info, planes))
+        if any(rcs):
+            raise ValueError(f"oracle: request sequence failed {rcs}")
+        return np.ascontiguousarray(np.moveaxis(canvas, 0, -1)), 0, info.warnings
     if info.precision == 8:
         out = np.zeros((info.height, info.width, info.ncomp), np.uint8)
         rc = lib().oj_reconstruct(C.byref(info), ptrs, out.ctypes.data, -1)
@@ -216,6 +230,69 @@ def decode_status(data: bytes, max_bytes: int = 1 << 28):
     if rc:
         raise ValueError(f"oracle: reconstruction failed rc={rc}")
     return out, 0, info.warnings
+
+
+REF_RECT_CALLS = os.path.join(HERE, "_ref", "rect_calls_ref")
+
+
+def cli_requests(width: int, height: int, ncomp: int, ctrafo: int = 1):
+    """The DisplayRectangle calls of the reference's command line (cmd/reconstruct.cpp:272-342, cmd/bitmaphook.cpp:122) with
+    upsampling on: one or three components -> stripes of eight lines over all components; otherwise (PGX) the same stripes
+    component by component.  Tuples as tests/cxx/rect_calls.cpp reads them."""
+    stripes = [(y, min(y + 7, height - 1)) for y in range(0, height, 8)]
+    if ncomp in (1, 3):
+        return [(0, y0, -1, y1, 0, ncomp - 1, 1, ctrafo, 8) for y0, y1 in stripes]
+    return [(0, y0, -1, y1, c, c, 1, ctrafo, 8) for c in range(ncomp) for y0, y1 in stripes]
+
+
+def run_requests(data: bytes, requests, cursors=None, decoded=None):
+    """A sequence of JPEG::DisplayRectangle calls through the oracle's stateful restatement (oj_requester): requests =
+    [(minx, miny, maxx, maxy, c0, c1, upsample, ctrafo, hmode)] as tests/cxx/rect_calls.cpp reads them ->
+    (info, [return code per call], canvas planes (ncomp, H, W) initialised to 0xAA)."""
+    info, planes = decoded if decoded is not None else decode_coefficients(data)
+    planes = [np.ascontiguousarray(p, np.int32) for p in planes]
+    sb = 2 if info.precision > 8 else 1
+    W, H, nc = info.width, info.height, info.ncomp
+    canvas = np.full((nc, H, W), 0xAAAA if sb == 2 else 0xAA, np.uint16 if sb == 2 else np.uint8)
+    ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - nc))
+    rq = lib().oj_requester_new(C.byref(info), ptrs)
+    rcs = []
+    try:
+        for minx, miny, maxx, maxy, c0, c1, ups, ctrafo, hmode in requests:
+            maxx = W - 1 if maxx < 0 else maxx
+            maxy = H - 1 if maxy < 0 else maxy
+            dst = (C.c_void_p * 4)(*[canvas[c].ctypes.data for c in range(nc)] + [None] * (4 - nc))
+            bpp = (C.c_int * 4)(sb, sb, sb, sb)
+            bpr = (C.c_int * 4)(W * sb, W * sb, W * sb, W * sb)
+            hh = miny + hmode if hmode else H
+            bmh = (C.c_int * 4)(hh, hh, hh, hh)
+            bmw = (C.c_int * 4)(W, W, W, W)
+            rcs.append(lib().oj_requester_display(rq, minx, miny, maxx, maxy, c0, c1, ups, ctrafo, dst, bpp, bpr, bmw, bmh, sb))
+            if cursors is not None:  # the row each component's cursor stands at after the call
+                cursors.append([lib().oj_requester_cursor(rq, c) for c in range(nc)])
+    finally:
+        lib().oj_requester_free(rq)
+    return info, rcs, canvas
+
+
+def run_requests_client(exe: str, data: bytes, requests, env=None, timeout=60):
+    """The same sequence through tests/cxx/rect_calls.cpp linked against the real reference (REF_RECT_CALLS) or against
+    libmijpeg.so -> (stdout lines, canvas planes or None)."""
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        src, scr, dst = os.path.join(d, "in.jpg"), os.path.join(d, "script"), os.path.join(d, "out.bin")
+        with open(src, "wb") as f:
+            f.write(data)
+        with open(scr, "w") as f:
+            for r in requests:
+                f.write(" ".join(str(int(v)) for v in r) + "\n")
+        r = subprocess.run([exe, src, scr, dst], capture_output=True, text=True, timeout=timeout, env=env)
+        lines = r.stdout.strip().splitlines()
+        if not os.path.exists(dst) or not lines or not lines[0].startswith("info"):
+            return lines, None
+        W, H, nc, prec = (int(v) for v in lines[0].split()[1:5])
+        raw = np.fromfile(dst, np.uint16 if prec > 8 else np.uint8)
+        return lines, raw.reshape(nc, H, W)
 
 
 def have_reference() -> bool:
