@@ -121,6 +121,20 @@ static int hip_fail(mijpeg_decoder *d, hipError_t e, const char *what)
     if (e_ != hipSuccess) return hip_fail(d, e_, #call);  \
   } while (0)
 
+// A batch that was submitted (mijpeg_submit_batch_device) and not waited for still reads the pinned staging buffers
+// (ent_host, stage_host, status words) from its asynchronous uploads: every entry point that rewrites them settles it first.
+static int settle_pending(mijpeg_decoder *d)
+{
+  if (!d->pend_n) return MIJPEG_OK;
+  d->pend_n = 0;
+  if (d->device >= 0) {
+    HIP_TRY(d, hipSetDevice(d->device));
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    if (d->copy_stream) HIP_TRY(d, hipStreamSynchronize(d->copy_stream));
+  }
+  return MIJPEG_OK;
+}
+
 extern "C" {
 
 const char *mijpeg_version(void) { return "libjpeg_amd/mijpeg 0.1 (gfx950)"; }
@@ -236,6 +250,8 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
   if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
+  if (const int prc = settle_pending(d)) return prc;
+  d->batch_frames = 0;
   int rc = d->host.parse(d->data, d->size, false);
   if (rc) return set_error(d, rc, d->host.error.message);
   d->parsed = true;
@@ -298,6 +314,7 @@ int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, 
 {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->parsed || d->host.scans.empty()) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no parsed stream");
+  if (const int prc = settle_pending(d)) return prc;
   if (piece_bytes == 1 && dst) { // the other producer: the marker search writes the copy itself (what a batch's workers do)
     if (capacity < d->size + 64) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "the sink needs the stream's size (+ 64 bytes of slack)");
     d->host.set_unstuff_sink(dst, d->size);
@@ -1037,6 +1054,7 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
   if (d->device < 0) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "decoder was created without a device");
   HIP_TRY(d, hipSetDevice(d->device));
+  if (const int prc = settle_pending(d)) return prc;
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
   int rc = d->host.parse(d->data, d->size, false);
@@ -1106,10 +1124,7 @@ static int submit_batch(mijpeg_decoder *d, const uint8_t *const *streams, const 
   HIP_TRY(d, hipSetDevice(d->device));
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
-  if (d->pend_n) { // a submitted batch nobody waited for: its staging buffers are about to be reused
-    d->pend_n = 0;
-    HIP_TRY(d, hipStreamSynchronize(d->stream));
-  }
+  if (const int prc = settle_pending(d)) return prc; // a submitted batch nobody waited for: its staging buffers are about to be reused
   d->batch_frames = 0;
   d->batch_hosts.resize((size_t)n);
   for (auto &h : d->batch_hosts)
@@ -1158,7 +1173,11 @@ static int submit_batch(mijpeg_decoder *d, const uint8_t *const *streams, const 
   d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count();
   d->timing[2] = d->phase_prepare;
   d->timing[3] = d->phase_device;
-  if (rc) { d->pend_n = 0; return rc; }
+  if (rc) { // copies may have been enqueued before the failure: nothing of this batch stays in flight
+    d->pend_n = 1;
+    (void)settle_pending(d);
+    return rc;
+  }
   d->batch_own_tables = own_tables;
   d->batch_frames = -n; // decoded (or on its way) but not aggregated yet
   if (d->pend_n) return MIJPEG_OK; // deferred: finish_batch() waits
@@ -1707,7 +1726,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
         char *tp = (char *)b->workspace + (mijpeg_workspace_bytes(b) - xt_table_bytes(b));
         for (int c = 0; c < 3; c++) {
           // only the highest-frequency delta is used, with the colour bits folded in (residualblockhelper.cpp:351-364)
-          a.rquant63[c] = (int32_t)x.residual.quant[x.residual.quant_index[c]][63] << 4;
+          a.rquant63[c] = ((int32_t)x.residual.quant[x.residual.quant_index[c]][63] << 4) & 0xffff; // m_usQuantization is a UWORD: deltas >= 4096 wrap
           // (components that share a table share its copy)
           for (int j = 0; j < c; j++) {
             if (x.qtable[c] && x.qtable[j] == x.qtable[c]) a.qlut[c] = a.qlut[j];

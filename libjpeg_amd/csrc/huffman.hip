@@ -328,6 +328,11 @@ __global__ __launch_bounds__(512) void huffman_scan_kernel(const HuffScanArgs a)
     const uint32_t nidx = img.first_interval + (uint32_t)interval + 1u;
     if (byte != a.ibegin[nidx] || skip != (uint32_t)a.iskip[nidx]) err = HUFF_ERR_DESYNC;
   }
+  // The bit-addressed reader hands out zero bits behind the interval's data without complaint.  An interval whose codes
+  // stayed valid while it consumed more bits than it holds is a damaged one: the host decoder calls it dirty and walks the
+  // stream sequentially, the reference fails once a request needs more than eight such bits (io/bitstream.hpp Get / Fill).
+  // Every kind of interval -- real, virtual, the last one -- reports it, and the stream goes to the host.
+  if (decoding && !err && br.bp > br.endbit) err = HUFF_ERR_DESYNC;
   if (err) atomicMax(&status[0], (uint32_t)err);
 #pragma unroll
   for (int k = 0; k < 4; k++)

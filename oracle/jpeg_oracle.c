@@ -1608,7 +1608,7 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
       if (xt->rbypass) {
         /* only the highest-frequency delta is used, times 2^COLOR_BITS; the level shift is NOT scaled (:196, :225) */
         const uint16_t *rq = r->scan_state_valid ? r->cquant[c] : r->quant[r->tq[c]];
-        const int32_t quant = (int32_t)rq[63] << 4, dcs = (int32_t)(1 << r->precision) >> 1;
+        const int32_t quant = ((int32_t)rq[63] << 4) & 0xffff /* UWORD m_usQuantization <<= rbits, residualblockhelper.cpp:351-364 */, dcs = (int32_t)(1 << r->precision) >> 1;
         int bx, by, i;
         for (by = 0; by < r->bh[c]; by++)
           for (bx = 0; bx < r->bw[c]; bx++) {

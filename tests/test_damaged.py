@@ -196,6 +196,37 @@ def test_gpu_seeded_damage_pixels_and_rc_equal_the_reference(oracle, dec):
 
 
 @pytest.mark.gpu
+def test_gpu_device_entropy_decoder_never_differs_on_damage(oracle, dec):
+    """entropy="prefer-gpu": the on-device Huffman decoder may only ever answer what the host walk (= the reference) answers.
+    Damaged intervals -- among them ones whose codes stay valid but that run past their data (the bit-addressed reader
+    supplies zero bits there) -- must be reported and handed to the host: return code and pixels equal the reference's."""
+    from libjpeg_amd import synth
+    streams = [golden_jpeg(n) for n in ("pil_200x120_420_dri8", "ref_75x45_420_dri2", "pil_33x17_420_dri1")]
+    streams.append(synth.synth_jpeg(320, 200, 3, 85, "420", 2))
+    use_ref = oracle.have_reference()
+    stats, on_device = {}, 0
+    for si, data in enumerate(streams):
+        rng = np.random.default_rng(900 + si)
+        for kind in ("truncate", "zero_run", "ff_run", "flip1", "flipbits", "insert", "del1", "drop_interval", "ff00_to_ffxx", "rst_burst") * 8:
+            blob = damage.corrupt(data, kind, rng, "entropy")
+            epx, eerr = damage.expected_of(blob, use_ref)
+            if eerr is None:
+                continue
+            try:
+                dec.read(blob, entropy="prefer-gpu")
+                perr = 0
+                on_device += dec.entropy_used == "gpu"
+            except api.MijpegError as e:
+                perr = e.code
+            assert (perr == 0) == (eerr == 0) and (perr == eerr or perr == 0), (si, kind, eerr, perr)
+            if perr == 0:
+                assert np.array_equal(dec.reconstruct_cli(), epx), (si, kind, dec.entropy_used)
+            stats[kind] = stats.get(kind, 0) + 1
+    assert sum(stats.values()) >= 250, stats
+    assert on_device >= 20  # some damage leaves a stream the device decodes like the reference does; most goes to the host
+
+
+@pytest.mark.gpu
 def test_gpu_damaged_big_frame_through_the_fused_kernel(oracle, dec):
     """A frame large enough for the restart-parallel host plan and the fused 4:2:0 kernel, with intervals dropped,
     duplicated and a marker renumbered: pixels equal the oracle's (and the reference's, where present)."""
