@@ -183,6 +183,11 @@ int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams,
  * mijpeg_decode_batch_device, which looks at the walk between its rounds, decodes such a batch. */
 int mijpeg_submit_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals);
 int mijpeg_finish_batch_device(mijpeg_decoder *d);
+/* Capacity planning / diagnostics: the HOST half of mijpeg_submit_batch_device alone -- header parse, restart marker search
+ * and the copy of the entropy coded data without its byte stuffing into the staging area, one stream per pool worker -- with
+ * no device involved (works on host-only objects).  This is what a rank's cores do per chunk of a batch; `bench.py
+ * --emulate-world N` runs it in neighbour processes to load the host the way the other ranks of a node would. */
+int mijpeg_prepare_batch_host(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n);
 /* Wait for everything the object has enqueued on its stream (e.g. a reconstruction launched with sync = 0). */
 int mijpeg_synchronize(mijpeg_decoder *d);
 int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags,

@@ -101,7 +101,8 @@ def lib():
         # one process do not see each other's device state.  Importing torch first makes the dynamic linker
         # resolve libamdhip64 to the copy that is already loaded.  Without torch the system ROCm runtime is used.
         try:
-            import torch  # noqa: F401
+            if not os.environ.get("MIJPEG_NO_TORCH"):  # (host-only helper processes have no use for it)
+                import torch  # noqa: F401
         except Exception:  # torch is plumbing, not a dependency of the C ABI
             pass
         L = C.CDLL(LIB_PATH)
@@ -355,6 +356,15 @@ class Decoder:
         self.batch_frames = n
         return info
 
+    def prepare_batch_host(self, streams) -> None:
+        """mijpeg_prepare_batch_host: the host half of a batch submit alone (no device needed)."""
+        n = len(streams)
+        arr = (C.c_char_p * n)(*streams)
+        sizes = (C.c_size_t * n)(*[len(s) for s in streams])
+        L = lib()
+        L.mijpeg_prepare_batch_host.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int]
+        self._check(L.mijpeg_prepare_batch_host(self._h, arr, sizes, n))
+
     def submit_batch_device(self, streams, min_intervals: int = 0) -> None:
         """mijpeg_submit_batch_device: parse, gather, enqueue upload + Huffman kernel; returns without waiting for the device."""
         n = len(streams)
@@ -566,11 +576,13 @@ def encode_coefficients(info: MijpegInfo, coef: np.ndarray, restart_interval: in
         L.mijpeg_free(p)
 
 
-def workspace_bytes(info: MijpegInfo, frames: int, flags: int = 0, own_tables: bool = False) -> int:
+def workspace_bytes(info: MijpegInfo, frames: int, flags: int = 0, own_tables: bool = False, xt: "MijpegXtParams | None" = None) -> int:
     b = MijpegBatch()
     C.memmove(C.byref(b.info), C.byref(info), C.sizeof(MijpegInfo))
     b.frames = frames
     b.flags = flags
+    if xt is not None:
+        b.xt = C.pointer(xt)
     if own_tables:  # only asked whether it is set
         b.quant_dev = 16
     return int(lib().mijpeg_workspace_bytes(C.byref(b)))

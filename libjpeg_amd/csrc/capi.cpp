@@ -77,8 +77,11 @@ struct mijpeg_decoder {
   int walk_rounds = 0;
   uint32_t *walk_status_dev = nullptr;
   hipStream_t copy_stream = nullptr;          // uploads of a batch's streams, ahead of the kernels that decode them
+  hipEvent_t ent_free = nullptr;              // behind the last kernel / copy that reads ent_dev
+  bool ent_free_valid = false;
   std::vector<hipEvent_t> copy_events;
   uint8_t *stage_host = nullptr;  // pinned gathering area for the streams of a batch
+  std::vector<uint8_t> host_stage; // the same for host-only objects (mijpeg_prepare_batch_host)
   size_t stage_cap = 0;
   // batches (mijpeg_decode_batch_device): one parsed decoder per stream, frame 0's info with the batch's worst range
   std::vector<std::unique_ptr<HostDecoder>> batch_hosts;
@@ -186,6 +189,10 @@ void mijpeg_destroy(mijpeg_decoder *d)
     }
     if (d->henc_host) (void)hipHostFree(d->henc_host);
     if (d->walk_host) (void)hipHostFree(d->walk_host);
+    if (d->req_dev) (void)hipFree(d->req_dev);
+    if (d->req_host) (void)hipHostFree(d->req_host);
+    if (d->rowmap_dev) (void)hipFree(d->rowmap_dev);
+    if (d->ent_free) (void)hipEventDestroy(d->ent_free);
     for (hipEvent_t e : d->copy_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->band_events) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
@@ -649,6 +656,36 @@ static int evaluate_entropy_status(mijpeg_decoder *d, HostDecoder *const *hosts,
   return MIJPEG_OK;
 }
 
+// Second-level tables of a device Huffman table: every code longer than the direct table's ten bits, grouped by its first
+// ten bits, in a 64-entry table indexed by the six bits that follow (entry = (length << 8) | symbol [| HUFF_DEV_INVALID], as
+// in the direct table).  Codes whose prefix finds no table left keep the direct entry 0: the kernels walk the canonical
+// arrays for those.
+static void fill_second_level(HuffDevTable &dst, const HuffTable &h, bool ac)
+{
+  int prefix_of[HUFF_DEV_SUBTABLES], used = 0;
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; l++) {
+    for (int i = 0; i < h.counts[l - 1]; i++, code++, k++) {
+      if (l <= HUFF_DEV_LOOKAHEAD || k >= 256) continue;
+      if (code >= (1 << l)) return; // over-subscribed lengths: the host refuses such tables anyway
+      const int prefix = code >> (l - HUFF_DEV_LOOKAHEAD), rest = l - HUFF_DEV_LOOKAHEAD; // 1..6 bits behind the prefix
+      int t = 0;
+      while (t < used && prefix_of[t] != prefix) t++;
+      if (t == used) {
+        if (used == HUFF_DEV_SUBTABLES) continue;
+        prefix_of[used++] = prefix;
+        dst.fast[prefix] = (uint16_t)(HUFF_DEV_SUB | t);
+      }
+      const uint32_t sym = h.values[k];
+      uint16_t e = (uint16_t)(((uint32_t)l << 8) | sym);
+      if (ac && (sym & 15) == 0 && sym != 0 && sym != 0xf0) e |= HUFF_DEV_INVALID;
+      const int first = (code & ((1 << rest) - 1)) << (6 - rest);
+      for (int j = 0; j < (1 << (6 - rest)); j++) dst.sub[t][first + j] = e;
+    }
+    code <<= 1;
+  }
+}
+
 // Entropy-decode n parsed images of identical frame geometry on the device, image i into coef_dev + i * frame_stride.
 // infos[i] receives fast_arith / range_max.  Returns MIJPEG_OK, MIJPEG_ERR_NOT_AVAILABLE (nothing touched) or an error.
 static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, const uint8_t *const *datas, const size_t *sizes, int n,
@@ -867,6 +904,8 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
         if (t == 1) // AC: flag the symbols that only exist in progressive scans (EOB runs)
           for (auto &e : dst.fast)
             if (e && (e & 15) == 0 && (e & 0xff) != 0 && (e & 0xff) != 0xf0) e |= HUFF_DEV_INVALID;
+        static const bool no_sub = getenv("MIJPEG_HUFF_NO_SUBTABLES") != nullptr; // A-B measurements: long codes walk the canonical arrays
+        if (!no_sub) fill_second_level(dst, *src[t], t == 1);
         memcpy(dst.maxcode, src[t]->maxcode, sizeof(dst.maxcode));
         memcpy(dst.valoff, src[t]->valoff, sizeof(dst.valoff));
         memcpy(dst.values, src[t]->values, sizeof(dst.values));
@@ -991,9 +1030,11 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
       HIP_TRY(d, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       d->copy_events.push_back(e);
     }
-    // the copy stream must not overtake work that still reads the buffer from an earlier call
-    HIP_TRY(d, hipEventRecord(d->ev0, d->stream));
-    HIP_TRY(d, hipStreamWaitEvent(d->copy_stream, d->ev0, 0));
+    // the copy stream must not overtake work that still reads the buffer from an earlier call: the Huffman kernels and the
+    // status copy of the previous batch (ent_free, recorded behind them).  NOT everything on d->stream: the reconstruction
+    // kernel of the previous batch does not touch this buffer, and an upload that waits for it leaves the link idle for the
+    // length of that kernel in every round of a pipeline (profiles/r03/batch4k_timeline.txt)
+    if (d->ent_free_valid) HIP_TRY(d, hipStreamWaitEvent(d->copy_stream, d->ent_free, 0));
     int64_t wg0 = 0;
     for (int gi = 0, g0 = 0; g0 < n; g0 += groups_of, gi++) {
       const int g1 = std::min(n, g0 + groups_of);
@@ -1026,6 +1067,9 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   HIP_TRY(d, hipMemcpyAsync(status_host, d->ent_dev + off_status, status_bytes, hipMemcpyDeviceToHost, d->stream));
   uint32_t *walk_status_host = (uint32_t *)d->walk_host; // the walk's staging buffer is free again
   if (any_dwalk) HIP_TRY(d, hipMemcpyAsync(walk_status_host, d->walk_status_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
+  if (!d->ent_free) HIP_TRY(d, hipEventCreateWithFlags(&d->ent_free, hipEventDisableTiming));
+  HIP_TRY(d, hipEventRecord(d->ent_free, d->stream)); // from here on nothing enqueued so far reads the entropy buffers
+  d->ent_free_valid = true;
   d->phase_prepare = std::chrono::duration<double>(tb1 - tb0).count(); // interval tables, Huffman tables
   mark("status copies enqueued");
   if (!any_dwalk) d->pend_walk_round = 0;
@@ -1253,6 +1297,38 @@ static int finish_batch(mijpeg_decoder *d)
 int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)
 {
   return submit_batch(d, streams, sizes, n, min_intervals, false);
+}
+
+int mijpeg_prepare_batch_host(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n)
+{
+  if (!d || !streams || !sizes || n < 1) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (const int prc = settle_pending(d)) return prc;
+  d->batch_frames = 0;
+  d->batch_hosts.resize((size_t)n);
+  for (auto &h : d->batch_hosts)
+    if (!h) h.reset(new HostDecoder());
+  std::vector<size_t> slot;
+  const size_t total = stream_slots(sizes, n, slot);
+  uint8_t *stage;
+  if (d->device >= 0) {
+    HIP_TRY(d, hipSetDevice(d->device));
+    if (const int src = ensure_stage(d, total)) return src;
+    stage = d->stage_host;
+  } else {
+    if (d->host_stage.size() < total) d->host_stage.resize(total);
+    stage = d->host_stage.data();
+  }
+  std::vector<int> rcs((size_t)n, 0);
+  const int workers = std::min(n, default_threads());
+  parallel_for(workers, [&](int w) {
+    for (int i = w; i < n; i += workers) {
+      d->batch_hosts[(size_t)i]->set_unstuff_sink(stage + slot[(size_t)i], sizes[i]);
+      rcs[(size_t)i] = d->batch_hosts[(size_t)i]->parse(streams[i], sizes[i], false);
+    }
+  });
+  for (int i = 0; i < n; i++)
+    if (rcs[(size_t)i]) return set_error(d, rcs[(size_t)i], d->batch_hosts[(size_t)i]->error.message);
+  return MIJPEG_OK;
 }
 
 int mijpeg_submit_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)

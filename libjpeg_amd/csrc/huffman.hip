@@ -146,6 +146,7 @@ __device__ __forceinline__ uint32_t add_sat_u32(uint32_t a, uint32_t b)
 template <bool AC> __device__ __forceinline__ uint32_t dev_lookup(uint32_t win, const HuffDevTable *h)
 {
   uint32_t e = h->fast[win >> (32 - HUFF_DEV_LOOKAHEAD)];
+  if (e & HUFF_DEV_SUB) e = h->sub[e & (HUFF_DEV_SUBTABLES - 1)][(win >> (32 - HUFF_DEV_LOOKAHEAD - 6)) & 63u]; // a code of 11..16 bits
   if (__builtin_expect(e == 0, 0)) {
     const int code16 = (int)(win >> 16);
     for (int l = HUFF_DEV_LOOKAHEAD + 1; l <= 16; l++) {

@@ -10,17 +10,23 @@ constexpr int HUFF_DEV_LOOKAHEAD = 10;
 constexpr int HUFF_ERR_MALFORMED = 1, HUFF_ERR_OVERFLOW = 2;
 constexpr int HUFF_ERR_DESYNC = 3; // a virtual restart interval did not end where the next one begins: the stream is damaged
 constexpr int HUFF_DEV_INVALID = 0x8000; // direct-table flag: AC symbol that does not exist in sequential scans
+constexpr int HUFF_DEV_SUB = 0x4000;     // direct-table flag: a longer code; the low bits name the second-level table of this prefix
+constexpr int HUFF_DEV_SUBTABLES = 8;    // second-level tables per Huffman table (Annex K tables need five)
 constexpr int HUFF_STREAM_PAD = 256; // bytes the device copy of the stream is padded with (the readers prefetch ahead)
 
 // One Huffman table in device form: direct lookup for codes up to 10 bits ((length << 8) | symbol [| HUFF_DEV_INVALID
-// in AC tables], 0 = longer code),
-// canonical max-code / value-offset arrays for the rest (same layout as HuffTable in host_decoder.hpp).
+// in AC tables]); longer codes: HUFF_DEV_SUB | t sends the lookup to second-level table t, indexed by the next six bits
+// (same entry format) -- canonical codes longer than ten bits share very few ten-bit prefixes (all ones but the tail: five
+// in the Annex K tables), and with 64 lanes per wave SOME lane meets a long code in every other symbol step, so what the
+// wave pays for them is what it pays per step; 0 = a prefix beyond the second-level tables (pathological code lengths):
+// canonical max-code / value-offset walk (same layout as HuffTable in host_decoder.hpp).
 struct HuffDevTable {
   uint16_t fast[1 << HUFF_DEV_LOOKAHEAD];
+  uint16_t sub[HUFF_DEV_SUBTABLES][64];
   int32_t maxcode[18];
   int32_t valoff[17];
   uint8_t values[256];
-  uint8_t pad[4]; // size multiple of 16 (2448 bytes)
+  uint8_t pad[4]; // size multiple of 16 (3472 bytes)
 };
 static_assert(sizeof(HuffDevTable) % 16 == 0, "tables are copied to LDS in dwords");
 

@@ -23,12 +23,13 @@ def main():
     t = time.perf_counter()
     streams = batch.make_streams(range(n), cfg)
     print(f"generated {n} streams in {time.perf_counter() - t:.1f} s, {sum(len(s) for s in streams.values()) / n / 1e6:.2f} MB each")
-    settings = [(int(c), int(d)) for c, d in (s.split("x") for s in os.environ.get("SETTINGS", "32x2,16x3,64x2,32x1,128x1").split(","))]
-    for chunk, depth in settings:
-        r = batch.run_sharded(streams, n, 0, 1, 0, None, steps=int(os.environ.get("STEPS", "3")), warmup=1, chunk=chunk, depth=depth)
+    # CHUNKxDEPTH, a trailing r = ramped schedule (small chunks at both ends)
+    settings = [(int(c), int(d.rstrip("r")), d.endswith("r")) for c, d in (s.split("x") for s in os.environ.get("SETTINGS", "32x2,16x3,64x2,32x1,128x1").split(","))]
+    for chunk, depth, ramp in settings:
+        r = batch.run_sharded(streams, n, 0, 1, 0, None, steps=int(os.environ.get("STEPS", "3")), warmup=1, chunk=chunk, depth=depth, ramp=ramp)
         ms = r["seconds"] * 1e3 / int(os.environ.get("STEPS", "3"))
         px = cfg["width"] * cfg["height"] * n
-        print(f"chunk {chunk:4d} depth {depth}: {ms:8.2f} ms per batch, {ms / n:.4f} ms per frame, {px / ms / 1e6:8.1f} Gpixel/s   chunk ms {['%.1f' % x for x in r['shard'].chunk_ms[:6]]}")
+        print(f"chunk {chunk:4d} depth {depth}{' ramp' if ramp else '     '}: {ms:8.2f} ms per batch, {ms / n:.4f} ms per frame, {px / ms / 1e6:8.1f} Gpixel/s   chunk ms {['%.1f' % x for x in r['shard'].chunk_ms[:6]]}")
         ph = [p for p in r["shard"].chunk_phases_ms if p]
         if ph:
             print("      decode call / parse / prepare / upload+huffman+status ms, mean over chunks:", ["%.2f" % (sum(p[k] for p in ph) / len(ph)) for k in range(4)])
