@@ -1606,8 +1606,11 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (use_fused420_12(b)) return "fused420_kernel<12>";
   if (use_fused1_12(b)) return "fused1_kernel<12>";
   if (b->info.coef_wide) return "idct_planes_long_kernel+upsample_color_kernel";
-  return use_fused420(b) ? "fused420_kernel" : use_fused444(b) ? "fused444_kernel" : b->info.xt ? "idct_planes_kernel+xt_merge_kernel"
-                                                                                                 : "idct_planes_kernel+upsample_color_kernel";
+  if (use_fused420(b)) return "fused420_kernel";
+  if (use_fused444(b)) return "fused444_kernel";
+  if (b->info.xt) return "idct_planes_kernel+xt_merge_kernel";
+  if (b->quant_dev || (b->flags & MIJPEG_FLAG_FORCE_GENERIC) || getenv("MIJPEG_NO_FUSED_TILE")) return "idct_planes_kernel+upsample_color_kernel";
+  return "fused_tile_kernel";
 }
 
 static const size_t LUT_BYTES = 3 * 4096 * sizeof(int32_t);
@@ -1837,7 +1840,12 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       }
       a.ycbcr = rx->ycc; // the colour transformer the first request built (colortransformerfactory.cpp:220-221)
     }
-    rc = launch_generic(a, fast, s);
+    // plain JPEG frames of any layout go through LDS in one pass (fused_tile_kernel); the pair with its sample planes in HBM
+    // stays for JPEG XT, int32 coefficient planes, per-frame tables in device memory, rectangle requests and MIJPEG_FLAG_FORCE_GENERIC
+    static const bool no_tile = getenv("MIJPEG_NO_FUSED_TILE") != nullptr; // A-B measurements
+    const bool tile = !rx && !f.xt && !f.coef_wide && !qdev && !(b->flags & MIJPEG_FLAG_FORCE_GENERIC) && !no_tile;
+    rc = tile ? launch_fused_tile(a, fast, s) : -1;
+    if (rc == -1) rc = launch_generic(a, fast, s);
   }
   return rc ? MIJPEG_ERR_DEVICE : MIJPEG_OK;
 }

@@ -90,6 +90,8 @@ struct GenericArgs {
   int32_t request;             // 1: window / displacement semantics below are in force (LAYOUT_ANY instances only)
   int32_t req_x0, req_y0, y_base, y_count; // y_count: lines the second kernel works on (0: the whole frame)
   int32_t wstart[MAXP], wlimit[MAXP];
+  // fused tile kernel (launch_fused_tile fills these): tile size in pixels (whole MCUs) and tile grid
+  int32_t tile_w, tile_h, tiles_x, tiles_y;
 };
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
@@ -103,6 +105,9 @@ int launch_fused411(const Fused420Args &a, hipStream_t stream); // same argument
 int launch_fused422(const Fused420Args &a, bool wide, hipStream_t stream); // wide: 32-bit filters for chroma ranges between the packed gate and 8190 // same argument block; chroma planes bw_c x bh_y, cw = ceil(W/2), ch = H
 int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream);
 int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream);
+// The same frames in one pass through LDS (plain JPEG: no residual planes, int16 coefficients, tables by value): any sampling
+// layout, 1..4 components, 8 or 12 bit.  Uses the plane description of GenericArgs; no workspace.
+int launch_fused_tile(const GenericArgs &a, bool fast, hipStream_t stream);
 int launch_expand_deltas(const uint16_t *in, int32_t *out, int frames, hipStream_t stream); // u16 [frames][4][64] -> int32 << 4
 
 // Rectangle of the reconstructed interleaved frame -> bitmaps in DEVICE memory described like the reference's

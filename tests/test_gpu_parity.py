@@ -61,8 +61,8 @@ def test_fused420_tile_edges_vs_oracle(dec, oracle, w, h, flags):
 def test_fused444_vs_oracle(dec, oracle, w, h, flags):
     data = synth.synth_jpeg(w, h, 300 + w + h, 88, "444", (w + h) % 5)
     f = dec.read(data)
-    # the fused kernel only exists in the fast flavour; FORCE_SAFE must route to the generic kernels
-    assert api.kernel_name(f, flags) == ("fused444_kernel" if flags == 0 else "idct_planes_kernel+upsample_color_kernel")
+    # the dedicated kernel only exists in the fast flavour; FORCE_SAFE must route to the one-pass tile kernel (SAFE arithmetic)
+    assert api.kernel_name(f, flags) == ("fused444_kernel" if flags == 0 else "fused_tile_kernel")
     out = dec.reconstruct(flags)
     exp = oracle.decode(data)
     bad = int((out != exp).sum())
@@ -74,8 +74,8 @@ def test_fused444_vs_oracle(dec, oracle, w, h, flags):
 def test_fused422_vs_oracle(dec, oracle, w, h, flags):
     data = synth.synth_jpeg(w, h, 500 + w + h, 87, "422", (w + 2 * h) % 5)
     f = dec.read(data)
-    # the fused kernel only exists in the fast flavour; FORCE_SAFE must route to the generic kernels
-    assert api.kernel_name(f, flags) == ("fused422_kernel" if flags == 0 else "idct_planes_kernel+upsample_color_kernel")
+    # the dedicated kernel only exists in the fast flavour; FORCE_SAFE must route to the one-pass tile kernel (SAFE arithmetic)
+    assert api.kernel_name(f, flags) == ("fused422_kernel" if flags == 0 else "fused_tile_kernel")
     out = dec.reconstruct(flags)
     exp = oracle.decode(data)
     bad = int((out != exp).sum())
@@ -91,8 +91,8 @@ def test_fused440_vs_oracle(dec, oracle, w, h, flags):
     data = dec.encode(synth.synth_image(w, h, 700 + w + h), 87, "440", ri, ri == 2)
     f = dec.read(data)
     assert (f.hsamp[0], f.vsamp[0], f.hsamp[1], f.vsamp[1]) == (1, 2, 1, 1)
-    # the fused kernel only exists in the fast flavour; FORCE_SAFE must route to the generic kernels
-    assert api.kernel_name(f, flags) == ("fused440_kernel" if flags == 0 else "idct_planes_kernel+upsample_color_kernel")
+    # the dedicated kernel only exists in the fast flavour; FORCE_SAFE must route to the one-pass tile kernel (SAFE arithmetic)
+    assert api.kernel_name(f, flags) == ("fused440_kernel" if flags == 0 else "fused_tile_kernel")
     out = dec.reconstruct(flags)
     exp = oracle.decode(data)
     bad = int((out != exp).sum())
@@ -114,7 +114,7 @@ def test_fused411_vs_oracle(dec, oracle, w, h, flags):
     f = dec.read(data)
     assert (f.hsamp[0], f.vsamp[0], f.hsamp[1], f.vsamp[1]) == (4, 1, 1, 1)
     worst = max(f.range_max[1], f.range_max[2])
-    assert api.kernel_name(f, flags) == ("fused411_kernel" if flags == 0 and worst < 8190 else "idct_planes_kernel+upsample_color_kernel")
+    assert api.kernel_name(f, flags) == ("fused411_kernel" if flags == 0 and worst < 8190 else "fused_tile_kernel")
     out = dec.reconstruct(flags)
     exp = oracle.decode(data)
     bad = int((out != exp).sum())
@@ -135,7 +135,7 @@ def test_fused440_packed_chroma_gate(dec, oracle):
         name = api.kernel_name(f)
         worst = max(f.range_max[1], f.range_max[2])
         assert f.fast_arith == 1
-        assert name == ("fused440_kernel" if worst < 2047 else "fused440_kernel<wide>" if worst < 8190 else "idct_planes_kernel+upsample_color_kernel")
+        assert name == ("fused440_kernel" if worst < 2047 else "fused440_kernel<wide>" if worst < 8190 else "fused_tile_kernel")
         seen.add(name)
         assert np.array_equal(dec.reconstruct(), oracle.decode(data)), q
     assert "fused440_kernel<wide>" in seen  # saturated graphics lie beyond the packed gate: 32-bit filters, still fused
@@ -155,7 +155,7 @@ def test_fused_single_component_vs_oracle(dec, oracle, w, h):
         data = synth.encode_jpeg(img, q, "444", restart_mcus=ri)
         f = dec.read(data)
         assert f.components == 1
-        assert api.kernel_name(f) == "fused1_kernel" and api.kernel_name(f, api.FLAG_FORCE_SAFE) == "idct_planes_kernel+upsample_color_kernel"
+        assert api.kernel_name(f) == "fused1_kernel" and api.kernel_name(f, api.FLAG_FORCE_SAFE) == "fused_tile_kernel"
         exp = oracle.decode(data)
         out = dec.reconstruct()
         assert np.array_equal(out.squeeze(), exp.squeeze())
@@ -176,7 +176,7 @@ def test_fused422_packed_chroma_gate(dec, oracle):
         name = api.kernel_name(f)
         worst = max(f.range_max[1], f.range_max[2])
         assert f.fast_arith == 1
-        assert name == ("fused422_kernel" if worst < 2047 else "fused422_kernel<wide>" if worst < 8190 else "idct_planes_kernel+upsample_color_kernel")
+        assert name == ("fused422_kernel" if worst < 2047 else "fused422_kernel<wide>" if worst < 8190 else "fused_tile_kernel")
         seen.add(name)
         assert np.array_equal(dec.reconstruct(), oracle.decode(data)), q
     assert "fused422_kernel<wide>" in seen  # saturated graphics lie beyond the packed gate: 32-bit filters, still fused
@@ -1577,3 +1577,56 @@ def test_fused1_12bit_vs_oracle(dec, oracle, w, h, scale):
     api.launch_reconstruct(f, coef.data_ptr(), outg.data_ptr(), 1, row, h * row, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(outg.cpu().numpy().view(np.uint16).reshape(expg.shape), expg)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused_tile_kernel: every layout without a dedicated fused kernel in one pass through LDS (round 3)
+@pytest.mark.gpu
+def test_fused_tile_kernel_on_random_layouts(oracle):
+    """One to four components, sampling factors 1..4 x 1..4, sizes 1..140 (tiles cut by the frame, halo blocks at every edge),
+    DRI: the one-pass kernel (FAST, its int16 and int32 sample planes, and SAFE arithmetic) and the two-kernel pair it
+    replaces all equal the oracle's whole-frame reconstruction; 12-bit twins of some of them as well."""
+    import craft
+    from libjpeg_amd import synth
+    dec = api.Decoder(0)
+    names = set()
+    n = 0
+    for t in range(160):
+        rng = np.random.default_rng(88000 + t)
+        samp, w, h, dri = craft.random_layout(rng)
+        data = craft.craft_stream(rng, samp, w, h, dri, ac_density=0.15 if t % 3 else 0.02)
+        if t % 5 == 0 and len(samp) in (1, 3):
+            data = synth.to_12bit(data, 16)
+        info, planes = oracle.decode_coefficients(data)
+        exp = oracle.reconstruct(info, planes) if info.precision == 8 else oracle.reconstruct16(info, planes)
+        f = dec.read(data, entropy="host")
+        names.add(api.kernel_name(f))
+        for flags in (0, api.FLAG_FORCE_SAFE, api.FLAG_FORCE_GENERIC):
+            got = dec.reconstruct(flags)
+            assert np.array_equal(got, exp), (t, samp, w, h, dri, info.precision, flags, api.kernel_name(f, flags))
+        n += 1
+    dec.close()
+    assert "fused_tile_kernel" in names and n == 160
+
+
+@pytest.mark.gpu
+def test_fused_tile_kernel_on_big_frames(oracle):
+    """Frames of many tiles in layouts the dedicated kernels do not cover -- CMYK, 3x1, 1x4, luma subsampled against chroma,
+    two components -- with dense content: hashes of the one-pass kernel equal those of the generic pair (which the test above
+    and the goldens tie to the oracle), and one of them is checked against the oracle directly."""
+    import craft
+    dec = api.Decoder(0)
+    layouts = [[(1, 1)] * 4, [(3, 1), (1, 1), (1, 1)], [(1, 4), (1, 1), (1, 1)], [(1, 1), (2, 2), (2, 2)], [(2, 1), (1, 2)], [(4, 2), (2, 1), (1, 2), (2, 2)]]
+    for k, samp in enumerate(layouts):
+        rng = np.random.default_rng(4400 + k)
+        w, h = 1000 + 37 * k, 700 + 13 * k
+        data = craft.craft_stream(rng, samp, w, h, dri=[0, 7][k % 2], ac_density=0.12)
+        f = dec.read(data, entropy="host")
+        assert api.kernel_name(f) == "fused_tile_kernel"
+        a = dec.reconstruct(0)
+        b = dec.reconstruct(api.FLAG_FORCE_GENERIC)
+        c = dec.reconstruct(api.FLAG_FORCE_SAFE)
+        assert np.array_equal(a, b) and np.array_equal(a, c), samp
+        if k == 1:
+            assert np.array_equal(a, oracle.decode(data))
+    dec.close()

@@ -158,7 +158,8 @@ def test_kernel_selection_and_workspace_need_no_device():
         f = d.read(golden_jpeg(name))
         assert f.fast_arith == 1
         assert api.kernel_name(f) == kernel
-        assert api.kernel_name(f, api.FLAG_FORCE_SAFE) == ("fused420_kernel" if "420" in name else "idct_planes_kernel+upsample_color_kernel")
+        assert api.kernel_name(f, api.FLAG_FORCE_SAFE) == ("fused420_kernel" if "420" in name else "fused_tile_kernel")
+        assert api.kernel_name(f, api.FLAG_FORCE_GENERIC) == "idct_planes_kernel+upsample_color_kernel"
         assert api.workspace_bytes(f, 5) == 0
         assert api.workspace_bytes(f, 5, own_tables=True) == 5 * 4 * 64 * 4
         generic = api.workspace_bytes(f, 5, api.FLAG_FORCE_GENERIC)
