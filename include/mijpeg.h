@@ -271,6 +271,14 @@ int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
 /* Diagnostics: coefficient row the cursor of `component` stands at after the mijpeg_display_rect calls so far. */
 int mijpeg_display_cursor(mijpeg_decoder *d, int component);
 
+/* The scans of the decoded frame in codestream order: first_byte[k] = offset (in the input of mijpeg_set_input) of the first
+ * entropy coded byte of scan k, i.e. where the reference stands when JPEG::Read returns with JPGFLAG_DECODER_STOP_SCAN
+ * (interface/jpeg.cpp:310-353), end_byte[k] = offset of the marker that follows the scan's data.  JPEG XT scans that live in
+ * boxes come last: first_byte = the marker behind the codestream's last scan (where the reference's input stands while it
+ * parses them from memory), end_byte = 0.  Either array may be NULL.  Returns the number of scans (also when capacity is
+ * smaller) or a negative error. */
+int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_byte, int capacity);
+
 /* Error of the last failing call on this object (JPEG::LastError). Returns the code, 0 if none. */
 int mijpeg_last_error(mijpeg_decoder *d, const char **message);
 

@@ -2789,6 +2789,32 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
   return MIJPEG_OK;
 }
 
+int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_byte, int capacity)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  // scans of the codestream itself first; then -- JPEG XT -- the scans that live in boxes (hidden refinement scans of the legacy
+  // frame, the residual codestream and its refinement scans): the reference parses them from memory streams while its
+  // input stands at the marker behind the legacy frame's last scan (the EOI)
+  int n = 0, boxed = 0;
+  uint64_t behind = 0;
+  for (const Scan &sc : d->host.scans) {
+    if (sc.base) { boxed++; continue; }
+    if (n < capacity) {
+      if (first_byte) first_byte[n] = (uint64_t)sc.ecs_begin;
+      if (end_byte) end_byte[n] = (uint64_t)sc.ecs_end;
+    }
+    behind = (uint64_t)sc.ecs_end;
+    n++;
+  }
+  if (HostDecoder *res = d->host.residual()) boxed += (int)res->scans.size();
+  for (int k = 0; k < boxed; k++, n++)
+    if (n < capacity) {
+      if (first_byte) first_byte[n] = behind;
+      if (end_byte) end_byte[n] = 0;
+    }
+  return n;
+}
+
 int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
                         uint32_t flags, const uint32_t bm_height[MIJPEG_MAX_COMPONENTS], int32_t out[8 + 6 * MIJPEG_MAX_COMPONENTS])
 {

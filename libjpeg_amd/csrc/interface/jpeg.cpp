@@ -30,7 +30,13 @@ struct JPEG::Impl {
   bool loaded = false;
   // incremental reading (JPGTAG_DECODER_STOP) and the marker calls: the position the reference's IOStream would stand at
   // while the headers are walked marker by marker, and the byte ranges the client took out of the stream itself
-  enum Phase { P_NONE, P_SOI, P_TABLES, P_FRAME, P_PRESCAN_INIT, P_PRESCAN, P_DECODE, P_DONE } phase = P_NONE;
+  enum Phase { P_NONE, P_SOI, P_TABLES, P_FRAME, P_PRESCAN_INIT, P_PRESCAN, P_DECODE, P_SCANS, P_DONE } phase = P_NONE;
+  // JPGFLAG_DECODER_STOP_SCAN: where the reference stands when it returns with a scan header parsed (the first entropy coded
+  // byte of every scan), in the order of the scans; the scans are decoded -- in parallel -- by the call that meets the first one
+  std::vector<size_t> scan_stops, scan_ends; // first entropy coded byte / first byte behind the data of every scan of the codestream
+  size_t boxed_stops = 0;                   // JPEG XT: further scans that live in boxes
+  size_t next_stop = 0;
+  bool between = false;                     // walking the marker segments between two scans
   bool pulled = false;
   int read_err = 0;            // what a failed Read reported (repeated by further Read calls)
   std::string read_errmsg;
@@ -135,7 +141,7 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
   p->err = 0;
   if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::Read requires a tag list with an I/O hook");
   const JPG_LONG stopflags = tags->GetTagData(JPGTAG_DECODER_STOP, 0);
-  if (p->loaded) return JPG_TRUE; // "if (!m_bDecoding) return" (interface/jpeg.cpp:262-263)
+  if (p->loaded && p->phase != Impl::P_SCANS) return JPG_TRUE; // "if (!m_bDecoding) return" (interface/jpeg.cpp:262-263)
   if (p->phase == Impl::P_DONE) // the decode failed before: reading on cannot succeed either
     return p->fail(p->read_err ? p->read_err : JPGERR_MALFORMED_STREAM, p->read_errmsg.empty() ? "the stream could not be decoded" : p->read_errmsg.c_str());
   if (!p->pulled) {
@@ -264,6 +270,69 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
       if (rc) return failed(rc);
       mijpeg_get_info(p->dec, &p->info);
       p->loaded = true;
+      // interface/jpeg.cpp:310-353: with JPGFLAG_DECODER_STOP_SCAN the reference returns every time Frame::StartParseScan has
+      // parsed a scan header -- the client sees the stream positioned at that scan's entropy coded data -- and decodes the scan
+      // in the next call.  Here all scans are decoded by now (in parallel); the calls that follow walk the same positions.
+      p->scan_stops.clear();
+      p->scan_ends.clear();
+      p->next_stop = 0;
+      p->between = false;
+      {
+        uint64_t at[256], end[256];
+        const int ns = mijpeg_scan_offsets(p->dec, at, end, 256);
+        auto in_stream = [&](uint64_t off) { // offsets count the bytes the parser saw: what the client took out lies in front of them in `stream`
+          size_t pos = (size_t)off;
+          for (const auto &r : p->taken)
+            if (r.first <= pos) pos += r.second - r.first;
+          return pos < p->stream.size() ? pos : p->stream.size();
+        };
+        p->boxed_stops = 0;
+        for (int k = 0; k < ns && k < 256; k++) {
+          if (end[k] == 0) { p->boxed_stops++; continue; }
+          p->scan_stops.push_back(in_stream(at[k]));
+          p->scan_ends.push_back(in_stream(end[k]));
+        }
+      }
+      p->phase = Impl::P_SCANS;
+      break;
+    }
+    case Impl::P_SCANS: {
+      // The reference's walk from scan to scan (interface/jpeg.cpp:296-353, marker/frame.cpp:794-862), positions only: behind
+      // a scan's data Frame::StartParseScan takes the marker segments in front of the next scan header one per call (each a
+      // return under JPGFLAG_DECODER_STOP_FRAME), then parses the header (a return under JPGFLAG_DECODER_STOP_SCAN, with the
+      // stream at the scan's entropy coded data).  The scans themselves are decoded already.
+      const size_t k = p->next_stop;
+      if (k < p->scan_stops.size()) {
+        if (k > 0) {
+          if (!p->between) {
+            p->between = true;
+            p->cursor = p->scan_ends[k - 1];
+          }
+          if (p->cursor < p->scan_stops[k] && p->tables_step() && p->cursor <= p->scan_stops[k]) {
+            if (stopflags & JPGFLAG_DECODER_STOP_FRAME) return JPG_TRUE;
+            break;
+          }
+        }
+        p->between = false;
+        p->cursor = p->scan_stops[k];
+        p->next_stop++;
+        if (stopflags & JPGFLAG_DECODER_STOP_SCAN) return JPG_TRUE;
+        break;
+      }
+      if (k < p->scan_stops.size() + p->boxed_stops) { // scans from boxes: the input stands behind the last scan of the codestream
+        p->cursor = p->scan_ends.empty() ? p->stream.size() : p->scan_ends.back();
+        if (!p->between) {
+          // JPEG XT: the frame of the residual image starts here (Image::StartParseFrame on its box, a return under
+          // JPGFLAG_DECODER_STOP_FRAME; the returns its own table walk adds stand at the same byte of the input and are not
+          // told apart from it)
+          p->between = true;
+          if (stopflags & JPGFLAG_DECODER_STOP_FRAME) return JPG_TRUE;
+        }
+        p->next_stop++;
+        if (stopflags & JPGFLAG_DECODER_STOP_SCAN) return JPG_TRUE;
+        break;
+      }
+      p->phase = Impl::P_DONE;
       p->cursor = p->stream.size(); // the reference stands behind the EOI now
       return JPG_TRUE;
     }

@@ -1,7 +1,7 @@
 // Test client for the incremental half of class JPEG (interface/jpeg.hpp): JPEG::Read with JPGTAG_DECODER_STOP,
 // PeekMarker / ReadMarker / SkipMarker -- the protocol of the reference's own marker injection test
 // (cmd/reconstruct.cpp:80-119), here with STOP_IMAGE or STOP_FRAME chosen on the command line and every step printed.
-//   marker_calls <in.jpg> <image|frame> [skip-garbage-bytes]
+//   marker_calls <in.jpg> <image|frame|scan> [skip-garbage-bytes]    (scan: Read with JPGFLAG_DECODER_STOP_SCAN until the data ends)
 // Prints one line per Read: "peek <hex>" and, for APP9 (ffe9) segments, "took <n>"; finally "info <w> <h> <depth>".
 // Build: g++ -I libjpeg_amd/csrc tests/cxx/marker_calls.cpp -L libjpeg_amd -lmijpeg
 #include <stdio.h>
@@ -32,7 +32,8 @@ int main(int argc, char **argv)
   if (argc < 3) return 2;
   FILE *in = fopen(argv[1], "rb");
   if (!in) return 2;
-  const JPG_LONG stop = !strcmp(argv[2], "image") ? JPGFLAG_DECODER_STOP_IMAGE : JPGFLAG_DECODER_STOP_FRAME;
+  const bool scans = !strcmp(argv[2], "scan"); // JPGFLAG_DECODER_STOP_SCAN: one Read per scan header, until the data ends
+  const JPG_LONG stop = !strcmp(argv[2], "image") ? JPGFLAG_DECODER_STOP_IMAGE : scans ? JPGFLAG_DECODER_STOP_SCAN : JPGFLAG_DECODER_STOP_FRAME;
   const long extra = argc > 3 ? atol(argv[3]) : 0; // raw bytes behind every APP9 segment that the client removes as well
   struct JPG_Hook filehook(FileHook, in);
   class JPEG *jpeg = JPEG::Construct(NULL);
@@ -56,7 +57,7 @@ int main(int argc, char **argv)
         printf("took %ld\n", (long)(2 + size + extra));
       }
     }
-  } while (marker && marker != -1L && ok && ++guard < 1000);
+  } while ((scans ? marker != -1L : (marker && marker != -1L)) && ok && ++guard < 1000);
   tags->SetTagData(JPGTAG_DECODER_STOP, 0);
   if (!ok || !jpeg->Read(tags)) {
     const char *msg = NULL;
