@@ -426,9 +426,9 @@ def emulate_world_child(n_world, stream_dir, frames_total, steps):
     from libjpeg_amd import batch
 
     torch.cuda.set_device(0)
-    full = sorted(os.sched_getaffinity(0))
+    full = sorted(int(c) for c in os.environ["MIJPEG_EMU_ALL_CPUS"].split(",")) if os.environ.get("MIJPEG_EMU_ALL_CPUS") else sorted(os.sched_getaffinity(0))
     binding = None if os.environ.get("MIJPEG_BENCH_NO_NUMA") else sharding.bind_to_gpu_node(0)
-    near = sorted(os.sched_getaffinity(0))
+    near = sorted(os.sched_getaffinity(0)) # (the parent may have bound itself -- and so this child -- already)
     far = [c for c in full if c not in set(near)] or near
     mine = sharding.frames_of_rank(frames_total, 0, n_world)
     streams = {}
@@ -445,7 +445,7 @@ def emulate_world_child(n_world, stream_dir, frames_total, steps):
     time.sleep(2.5)  # the neighbours are loaded and looping
     best, tried = None, []
     t_begin = time.perf_counter()
-    for chunk, depth, ramp in ((8, 4, False), (16, 2, False), (8, 4, True), (4, 8, False)):
+    for chunk, depth, ramp in ((16, 2, False), (8, 4, False), (11, 3, False), (16, 3, False)):
         if time.perf_counter() - t_begin > seconds - 5.0:
             break
         r = batch.run_sharded(streams, frames_total, 0, n_world, 0, None, steps=steps, warmup=3, chunk=chunk, depth=depth, ramp=ramp)
@@ -462,7 +462,9 @@ def emulate_world_child(n_world, stream_dir, frames_total, steps):
     W, H = SIZES["4k"]
     print(json.dumps({"world": n_world, "rank0_frames": len(mine), "rank0_ms": round(best, 3), "settings_tried": tried,
                       "projected_value": round(frames_total * W * H / (best * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
-                      "host_threads": api.default_threads(), "numa_binding": binding, "neighbour_passes": passes,
+                      "host_threads": api.default_threads(), "numa_binding": binding or {"inherited_cpus": len(near)},
+                      "neighbours_on_this_socket": max(1, n_world // 2) - 1, "neighbours_elsewhere_cpus": len(far) if far is not near else 0,
+                      "neighbour_passes": passes,
                       "measured_while_neighbours_ran": bool(loaded_until < seconds - 2.5)}))
 
 
@@ -473,7 +475,8 @@ def emulate_world(n_world, streams, frames_total, steps):
         for i, data in streams.items():
             with open(os.path.join(d, f"{i}.jpg"), "wb") as f:
                 f.write(data)
-        env = dict(os.environ, MIJPEG_THREADS=str(max(1, min(64, (os.cpu_count() or 1) // n_world))))
+        env = dict(os.environ, MIJPEG_THREADS=str(max(1, min(64, (os.cpu_count() or 1) // n_world))),
+                   MIJPEG_EMU_ALL_CPUS=",".join(map(str, sorted(FULL_AFFINITY))))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--emulate-world-child", str(n_world), "--emulate-dir", d,
                             "--batch-frames", str(frames_total), "--batch-steps", str(steps)], env=env, capture_output=True, text=True, timeout=180)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

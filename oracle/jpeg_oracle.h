@@ -113,7 +113,8 @@ int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int 
                          void *const dst[OJ_MAX_COMP], const int bpp[OJ_MAX_COMP], const int bpr[OJ_MAX_COMP],
                          const int bm_width[OJ_MAX_COMP], const int bm_height[OJ_MAX_COMP], int sample_bytes);
 
-/* JPEG XT profile C (subset: explicit L table, identity Q/R2 tables, standard matrices, no refinement scans):
+/* JPEG XT profile C (explicit, parametric and identity tables, free-form matrices, DCT bypass, hidden refinement scans --
+ * what tests/golden/xt_general/ pins against the reference decoder):
  * 16-bit codes out (half-float bit patterns when *is_float). colortrafo/ycbcrtrafo.cpp:750-955. */
 int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float);
 float oj_half_to_float(uint16_t h);
