@@ -1545,9 +1545,13 @@ static bool use_fusedxt(const mijpeg_batch *b)
   const mijpeg_xt_params &x = *b->xt;
   const mijpeg_info &r = x.residual;
   if (x.general) return false; // free-form matrices, table gathers, DCT bypass: xt_merge_general_kernel
-  if (x.hidden_bits || x.residual_hidden_bits || x.residual_wide || x.ltable_entries != 256 || !x.ltrafo_ycbcr || r.precision != 12 || r.components != 3 ||
-      x.out_max != 65535 || x.out_shift != 32768)
+  // hidden bits in the RESIDUAL frame (-rR n: 13..16-bit samples, int32 coefficients) have a kernel of their own
+  // (fusedxtw420_kernel); hidden bits in the legacy frame change its precision and stay on the three-kernel path
+  if (x.hidden_bits || x.residual_hidden_bits < 0 || x.residual_hidden_bits > 4 || (x.residual_wide != 0) != (x.residual_hidden_bits > 0) ||
+      x.ltable_entries != 256 || !x.ltrafo_ycbcr || r.precision != 12 || r.components != 3 || x.out_max != 65535 || x.out_shift != 32768)
     return false;
+  static const bool no_wide = getenv("MIJPEG_NO_FUSEDXTW") != nullptr; // A-B comparisons
+  if (x.residual_hidden_bits && no_wide) return false;
   for (int c = 0; c < 3; c++) {
     if (r.subx[c] != 1 || r.suby[c] != 1 || r.blocks_w[c] != r.blocks_w[0] || r.blocks_h[c] != r.blocks_h[0] || r.range_max[c] >= 65536) return false;
     for (int i = 0; i < 64; i++)
@@ -1597,7 +1601,7 @@ static bool use_fused440(const mijpeg_batch *b)
 const char *mijpeg_kernel_name(const mijpeg_batch *b)
 {
   if (!b) return "";
-  if (use_fusedxt(b)) return "fusedxt420_kernel";
+  if (use_fusedxt(b)) return b->xt->residual_hidden_bits ? "fusedxtw420_kernel" : "fusedxt420_kernel";
   if (use_fused420p(b)) return "fused420p_kernel";
   if (use_fused422(b)) return chroma_packed(b->info) ? "fused422_kernel" : "fused422_kernel<wide>";
   if (use_fused440(b)) return chroma_packed(b->info) ? "fused440_kernel" : "fused440_kernel<wide>";
@@ -1719,6 +1723,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       xa.ext.out_max = x.out_max;
       xa.ext.out_shift = x.out_shift;
       xa.ext.aligned16 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 15) == 0;
+      xa.ext.rprecision = r.precision + x.residual_hidden_bits;
       rc = launch_fusedxt420(xa, s);
     } else
       rc = f420_12 ? launch_fused420_12(a, s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);

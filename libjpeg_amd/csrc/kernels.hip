@@ -1765,6 +1765,235 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
 }
 
 // ==============================================================================================
+// fused JPEG XT profile C kernel for residual frames with HIDDEN BITS (the reference encoder's -rR n, RFIN boxes):
+// 8-bit 4:2:0 legacy frame + 4:4:4 residual frame of 13..16 bits whose coefficients are int32
+// ==============================================================================================
+// fusedxt420_kernel's decomposition with three differences.
+// (1) The residual coefficients are int32 (two int16 slots each in the frame's buffer: 256-byte blocks, fetched in two halves).
+// (2) A residual frame of more than 12 bits is transformed by the reference with IDCT<4,QUAD> (codestream/tables.cpp:1876-1891):
+//     64-bit butterflies, but `(dptr[0 << 3] + dptr[4 << 3]) << FIX_BITS` of the second pass is a LONG expression
+//     (dct/idct.cpp:297-298) and WRAPS: with the level shift 2^(P-1) << 7 sitting in row 0 the sum times 512 leaves 32 bits
+//     whenever it reaches 2^22.  Everything else is exact, so the result is the exact transform minus k 2^32 >> 12 = k 2^20 in the
+//     four outputs that the wrapped term feeds (rows 0, 7, 3, 4 for s0 + s4; 1, 6, 2, 5 for s0 - s4), k = the number of times
+//     (s0 +- s4 + level) 512 wraps: floor((t + 2^22) / 2^23).  The exact transform is the FAST 32-bit one without level shift
+//     (exact for sum |c| q < 2^16, the host's gate) plus the level shift, which passes both rounding shifts as 2^(P+3).
+//     Checked against the oracle's literal 64-bit restatement on random blocks for P = 13..16 before it was written down here.
+// (3) The residual samples do not fit 16 bits: after the Q table of the subset (clamp to [0, 2^(P+4)), scale to 2^20) each is
+//     a 20-bit number; minus 2^19 -- what the R transformation subtracts from the chroma ones anyway -- the three of a pixel
+//     are kept in two registers (20 + 12 | 20 + 12 bits).  The R transformation runs on them in 64-bit multiply-adds
+//     (|d| < 2^19 times a 14-bit constant), the rest of the merge is fusedxt420_kernel's.
+// 128 registers for the block's residual instead of 96: one wave per SIMD less than the 12-bit kernel.
+__device__ __forceinline__ void idct_column_quadwrap(int &s0, int &s1, int &s2, int &s3, int &s4, int &s5, int &s6, int &s7, int level7)
+{
+  // where the reference's LONG expression wraps (see above): t = s0 +- s4 + (level shift << 7), k = floor((t + 2^22) / 2^23)
+  const int k0 = (s0 + s4 + level7 + (1 << 22)) >> 23, k1 = (s0 - s4 + level7 + (1 << 22)) >> 23;
+  idct_1d<true, 12>(s0, s1, s2, s3, s4, s5, s6, s7);
+  const int f0 = k0 << 20, f1 = k1 << 20;
+  s0 -= f0; s7 -= f0; s3 -= f0; s4 -= f0;
+  s1 -= f1; s6 -= f1; s2 -= f1; s5 -= f1;
+}
+
+__global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fused420Args a, const FusedXtExtra x)
+{
+  __shared__ __attribute__((aligned(16))) int cplane[2][F420_CROWS * F420_CPITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+  __shared__ int ltab[3 * 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  unsigned logical;
+  {
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, xc = b & 7, i = b >> 3;
+    logical = xc * q + min(xc, r) + i;
+  }
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift;
+  f420_chroma_to_lds<true>(a, coef, cplane, stage, lane, wave, tx, ty);
+  __syncthreads();
+  f420_chroma_edges(a, cplane, tid, tx, ty);
+
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+  const int X0 = (gbx0 + bx) * 8, Y0 = (ty * F420_TILE_BLOCKS + by) * 8;
+  u32x4 rows[8];
+
+  // ------------------------------------------------------------------ residual blocks -> 20-bit samples minus 2^19, packed
+  const int rprec = x.rprecision;                 // 13..16
+  const int level7 = 1 << (rprec + 6);            // (2^(P-1)) << 7: the level shift as the column pass sees it in row 0
+  const int level_out = 1 << (rprec + 3);         // ... and as it leaves the transform
+  const int rmax = (1 << (rprec + 4)) - 1, qshift = 16 - rprec;
+  unsigned rA[64], rB[64];
+  auto residual_block = [&](int64_t off, const int *__restrict__ q, int which) {
+    const char *plane = reinterpret_cast<const char *>(coef + off);
+    int v[64];
+#pragma unroll
+    for (int h = 0; h < 2; h++) { // coefficients 32 h .. 32 h + 31 of every block: rows 4 h .. 4 h + 3
+      const int x0 = gbx0 + (lane >> 3);
+      const char *pbase = plane + (lane & 7) * 16 + h * 128;
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int xx = min(x0 + 8 * (m & 1), x.bw_r - 1), yy = min(gby0 + (m >> 1), x.bh_r - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * x.bw_r + xx) * 256));
+      });
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int base = 32 * h + 4 * k;
+        v[base + 0] = __mul24((int)rows[k].x, q[base + 0]);
+        v[base + 1] = __mul24((int)rows[k].y, q[base + 1]);
+        v[base + 2] = __mul24((int)rows[k].z, q[base + 2]);
+        v[base + 3] = __mul24((int)rows[k].w, q[base + 3]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      idct_1d<true, 9>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+      idct_column_quadwrap(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], level7);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      // Q table of the subset: clamp to [0, 2^(P+4)), scale to 2^20; kept minus 2^19
+      const int d = (min(max(v[i] + level_out, 0), rmax) << qshift) - (1 << 19);
+      if (which == 0) rA[i] = (unsigned)d & 0xfffffu;
+      else if (which == 1) rB[i] = (unsigned)d & 0xfffffu;
+      else {
+        rA[i] |= ((unsigned)d & 0xfffu) << 20;
+        rB[i] |= (unsigned)(d >> 12) << 20; // twelve bits with the sign: what the arithmetic shift of the unpacking wants
+      }
+    }
+  };
+  residual_block(x.off_r[0], x.rq[0], 0);
+  residual_block(x.off_r[1], x.rq[1], 1);
+  residual_block(x.off_r[2], x.rq[2], 2);
+
+  // ------------------------------------------------------------------ legacy luma
+  {
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(coef + a.off_y) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int xx = min(x0 + 8 * (m & 1), a.bw_y - 1), yy = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_y + xx) * 128));
+    });
+  }
+  int yv[64];
+  dequant_idct_sparse(rows, a.q[0], yv);
+
+  const bool active = X0 < a.width && Y0 < a.height;
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 6u;
+  const int npx = min(8, a.width - X0);
+  const int nln = active ? min(8, a.height - Y0) : 0;
+  const bool fast_store = x.aligned16 && npx == 8;
+
+  const int *cb_base = cplane[0] + (4 * by) * F420_CPITCH + 4 * bx;
+  const int *cr_base = cplane[1] + (4 * by) * F420_CPITCH + 4 * bx;
+  auto load6 = [](const int *p, int (&d)[6]) {
+    const i32x4 mid = *reinterpret_cast<const i32x4 *>(p + 4);
+    d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
+  };
+  const int pinf = (x.out_max >> 1) - (x.out_max >> 6) - 1, minf = -pinf - 1;
+  const unsigned pinf2 = (unsigned)pinf * 0x10001u, minf2 = ((unsigned)minf & 0xffffu) * 0x10001u;
+  const int omax16 = ((x.out_max + 1) << 4) - 1;
+
+  int cbT[6], cbC[6], cbB[6], crT[6], crC[6], crB[6];
+  load6(cb_base, cbT); load6(cb_base + F420_CPITCH, cbC);
+  load6(cr_base, crT); load6(cr_base + F420_CPITCH, crC);
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    load6(cb_base + (m + 2) * F420_CPITCH, cbB);
+    load6(cr_base + (m + 2) * F420_CPITCH, crB);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int l = 2 * m + half;
+      int vb[6], vr[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const int rnd = ((j & 1) ^ half) ? 1 : 2;
+        vb[j] = tap13(half ? cbB[j] : cbT[j], cbC[j], rnd);
+        vr[j] = tap13(half ? crB[j] : crT[j], crC[j], rnd);
+      }
+      int ub[8], ur[8];
+      auto hfilt = [](const int (&v)[6], int (&o)[8]) {
+        o[7] = tap13(v[5], v[4], 1);
+        o[6] = tap13(v[3], v[4], 2);
+        o[5] = tap13(v[4], v[3], 1);
+        o[4] = tap13(v[2], v[3], 2);
+        o[3] = tap13(v[3], v[2], 1);
+        o[2] = tap13(v[1], v[2], 2);
+        o[1] = tap13(o[2], v[1], 1); // src[1] has already been overwritten by out[2]
+        o[0] = tap13(v[0], v[1], 2);
+      };
+      hfilt(vb, ub);
+      hfilt(vr, ur);
+      int mm[24];
+      const int K = (2048 << 13) + 65536;
+#pragma unroll
+      for (int xx = 0; xx < 8; xx++) {
+        const int yk = (yv[l * 8 + xx] << 13) + K;
+        const int lr = clamp255(mad24(ur[xx], L_CR_R, yk) >> 17);
+        const int lg = clamp255(mad24(ur[xx], -L_CR_G, mad24(ub[xx], -L_CB_G, yk)) >> 17);
+        const int lb = clamp255(mad24(ub[xx], L_CB_B, yk) >> 17);
+        const int lv[3] = {ltab[lr], ltab[256 + lg], ltab[512 + lb]};
+        // residual chain (colortrafo/ycbcrtrafo.cpp:750-829): the three 20-bit samples minus 2^19
+        const int i = l * 8 + xx;
+        const int d0 = ((int)(rA[i] << 12)) >> 12, d1 = ((int)(rB[i] << 12)) >> 12;
+        const int d2 = (((int)rB[i] >> 20) << 12) | (int)(rA[i] >> 20);
+        int rr[3];
+        if (x.rtrafo_ycbcr) {
+          // (ry 8192 + rcb Lb + rcr Lr + 4096) >> 13 with ry = d0 + 2^19 a whole number of 8192ths: ry + ((d L + 4096) >> 13)
+          const int qy = d0 + (1 << 19);
+          rr[0] = qy + (int)(((long long)d2 * L_CR_R + 4096) >> 13);
+          rr[1] = qy + (int)(((long long)d1 * -L_CB_G + (long long)d2 * -L_CR_G + 4096) >> 13);
+          rr[2] = qy + (int)(((long long)d1 * L_CB_B + 4096) >> 13);
+        } else {
+          rr[0] = d0 + (1 << 19); rr[1] = d1 + (1 << 19); rr[2] = d2 + (1 << 19);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) mm[3 * xx + c] = lv[c] + ((min(max(rr[c], 0), omax16) + 8) >> 4); // R2 table of the subset
+      }
+      unsigned w[12];
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        if (x.is_float) {
+          unsigned pk, sg;
+          asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(pk) : "v"(mm[2 * i]), "v"(mm[2 * i + 1]));
+          asm("v_pk_max_i16 %0, %1, %2" : "=v"(pk) : "v"(pk), "v"(minf2));
+          asm("v_pk_min_i16 %0, %1, %2" : "=v"(pk) : "v"(pk), "v"(pinf2));
+          asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(sg) : "v"(pk));
+          w[i] = pk ^ (sg & 0x7fff7fffu);
+        } else {
+          w[i] = (unsigned)min(max(mm[2 * i], 0), x.out_max) | ((unsigned)min(max(mm[2 * i + 1], 0), x.out_max) << 16);
+        }
+      }
+      if (l < nln) {
+        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+        if (fast_store) {
+          u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+          __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
+          __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
+          __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+        } else {
+          unsigned short *d16 = reinterpret_cast<unsigned short *>(dst);
+#pragma unroll
+          for (int k = 0; k < 24; k++)
+            if (k < 3 * npx) d16[k] = (unsigned short)(w[k >> 1] >> ((k & 1) * 16));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) { cbT[j] = cbC[j]; cbC[j] = cbB[j]; crT[j] = crC[j]; crC[j] = crB[j]; }
+  }
+}
+
+// ==============================================================================================
 // fused 4:4:4 kernel (three components, no subsampling, YCbCr): ReconstructUnsampled,
 // control/blockbitmaprequester.cpp:1013-1074
 // ==============================================================================================
@@ -2945,7 +3174,8 @@ int launch_fused420p(const Fused420Args &a, hipStream_t stream)
 int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
 {
   const unsigned total = (unsigned)x.base.tiles_x * x.base.tiles_y * x.base.frames;
-  hipLaunchKernelGGL(fusedxt420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
+  if (x.ext.rprecision > 12) hipLaunchKernelGGL(fusedxtw420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
+  else hipLaunchKernelGGL(fusedxt420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   return (int)hipGetLastError();
 }
 

@@ -35,6 +35,8 @@ struct FusedXtExtra {
   const int32_t *ltable;      // device: [3][256]
   int32_t rtrafo_ycbcr, is_float, out_max, out_shift;
   int32_t aligned16;          // out, strides multiples of 16 bytes
+  int32_t rprecision;         // residual precision incl. hidden bits: 12 -> fusedxt420_kernel (int16 residual coefficients);
+                              // 13..16 -> fusedxtw420_kernel (int32 coefficients, two int16 slots each; bw_r in blocks of 256 bytes)
 };
 struct FusedXtArgs {
   Fused420Args base;          // legacy frame, geometry; out = 16-bit samples, strides in bytes

@@ -104,6 +104,12 @@ case("xt_129x71_420_R2_rR3_dri3", 129, 71, 7, "xt", args=["-r", "-q", "85", "-Q"
 case("xt_64x48_444_R1_rR1", 64, 48, 8, "xt", args=["-r", "-q", "70", "-Q", "80", "-h", "-profile", "c", "-r12", "-R", "1", "-rR", "1"])
 case("xt_200x120_420_R3_rR4", 200, 120, 9, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-R", "3", "-rR", "4",
                                                         "-s", "1x1,2x2,2x2"])
+# hidden bits in the residual frame only, on a 4:2:0 legacy frame: BASELINE config 5's -rR variant in small, the shape
+# fusedxtw420_kernel serves (round 3); one of them spans several 128-pixel tiles
+case("xt_129x71_420_rR2", 129, 71, 41, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-rR", "2", "-s", "1x1,2x2,2x2"])
+case("xt_200x120_420_rR4", 200, 120, 42, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-rR", "4", "-s", "1x1,2x2,2x2"])
+case("xt_260x140_420_rR4_q60", 260, 140, 43, "xt", args=["-r", "-q", "60", "-Q", "75", "-h", "-profile", "c", "-r12", "-rR", "4", "-s", "1x1,2x2,2x2"])
+case("xt_129x71_420_rR1_dri2", 129, 71, 44, "xt", args=["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-rR", "1", "-s", "1x1,2x2,2x2", "-z", "2"])
 # plain 12-bit extended sequential (SOF1, P = 12): what the residual codestream of profile C is made of
 case("p12_64x48_444", 64, 48, 30, "p12", args=["-q", "85"])
 case("p12_120x90_420_dri3", 120, 90, 31, "p12", args=["-q", "85", "-s", "1x1,2x2,2x2", "-z", "3"])
@@ -141,7 +147,14 @@ def main():
     O.build()
     assert O.have_reference(), "oracle/_ref/jpeg missing: run `make -C oracle ref`"
     manifest = {}
+    only = None
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":  # add cases to the committed set without touching the others
+        only = set(sys.argv[2].split(","))
+        with open(os.path.join(OUT, "manifest.json")) as f:
+            manifest = json.load(f)
     for c in CASES:
+        if only is not None and c["name"] not in only:
+            continue
         if c["enc"] == "cmyk":
             import io
             import subprocess

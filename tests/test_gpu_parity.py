@@ -285,9 +285,12 @@ def test_xt_profile_c_golden(dec, oracle, name):
     ent = MANIFEST[name]
     f = dec.read(golden_jpeg(name))
     assert f.xt == 1 and f.is_float == 1 and f.sample_bytes == 2
-    # 8-bit 4:2:0 legacy + 12-bit 4:4:4 residual without hidden bits has a fused kernel; everything else takes three
-    fused = "_420" in name and "_R" not in name and "_rR" not in name
-    assert api.kernel_name(f, xt=dec.xt_params()) == ("fusedxt420_kernel" if fused else "idct_planes_kernel+xt_merge_kernel")
+    # 8-bit 4:2:0 legacy + 4:4:4 residual has fused kernels -- 12-bit residual: fusedxt420_kernel, residual with hidden bits
+    # (-rR n: 13..16 bits, int32 coefficients, the reference's wrapping IDCT<4,QUAD>): fusedxtw420_kernel (round 3); hidden
+    # bits in the legacy frame (-R n) and 4:4:4 / 4:2:2 legacy frames take the three-kernel path
+    fused = "_420" in name and "_R" not in name
+    assert api.kernel_name(f, xt=dec.xt_params()) == (("fusedxtw420_kernel" if "_rR" in name else "fusedxt420_kernel") if fused else
+                                                      "idct_planes_kernel+xt_merge_kernel")
     codes = dec.reconstruct()
     assert codes.dtype == np.uint16 and codes.shape == (ent["height"], ent["width"], 3)
     if fused:
@@ -309,6 +312,23 @@ def test_12bit_golden(dec, oracle, name):
     exp = golden_pixels(name)
     assert np.array_equal(out, exp if exp is not None else oracle.decode16(golden_jpeg(name)))
     assert hashlib.sha256(np.ascontiguousarray(out, "<u2").tobytes()).hexdigest() == ent["pixels_sha256"]
+
+
+def test_xt_hidden_residual_bits_1080p_vs_oracle(dec, oracle):
+    """Config 5's -rR 4 variant on a frame of many tiles: fusedxtw420_kernel (int32 residual coefficients, the wrap of the
+    reference's IDCT<4,QUAD> as a correction of the exact 32-bit transform, 20-bit residual samples) against the oracle's
+    literal 64-bit restatement and against the three-kernel path."""
+    if not oracle.have_reference():
+        pytest.skip("needs oracle/_ref/jpeg to encode the HDR stream")
+    for rr, size in ((4, (1920, 1080)), (3, (1000, 600))):
+        data = oracle.reference_encode_hdr(synth.synth_hdr(size[0], size[1], 99 + rr),
+                                           ["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-rR", str(rr), "-s", "1x1,2x2,2x2"])
+        f = dec.read(data)
+        assert api.kernel_name(f, xt=dec.xt_params()) == "fusedxtw420_kernel"
+        codes = dec.reconstruct()
+        exp, _ = oracle.decode_xt(data)
+        assert np.array_equal(codes, exp), rr
+        assert np.array_equal(dec.reconstruct(api.FLAG_FORCE_GENERIC), exp), rr
 
 
 def test_xt_4k_vs_oracle(dec, oracle):
