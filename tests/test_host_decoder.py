@@ -390,3 +390,52 @@ print("checked", n)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "checked 9" in r.stdout
+
+
+def test_scan_offsets_are_where_the_scan_headers_end():
+    """mijpeg_scan_offsets (what JPGFLAG_DECODER_STOP_SCAN returns at): every SOS of the codestream, first entropy coded byte
+    behind its header, and the marker that follows the scan's data; JPEG XT scans from boxes come last with end 0."""
+    import ctypes as C
+    L = api.lib()
+    L.mijpeg_scan_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+    for name in ("pilprog_75x45_420", "pil_200x120_420_dri8", "xt_129x71_420_rR2"):
+        data = golden_jpeg(name)
+        d = api.Decoder(None)
+        d.read(data)
+        first, end = (C.c_uint64 * 64)(), (C.c_uint64 * 64)()
+        n = L.mijpeg_scan_offsets(d._h, first, end, 64)
+        sos = []
+        p = 2
+        while p + 4 <= len(data):  # walk the marker segments and the entropy coded data between them
+            assert data[p] == 0xFF
+            m = data[p + 1]
+            if m == 0xD9:
+                break
+            ln = (data[p + 2] << 8) | data[p + 3]
+            p += 2 + ln
+            if m == 0xDA:
+                sos.append(p)
+                while not (data[p] == 0xFF and data[p + 1] != 0 and not 0xD0 <= data[p + 1] <= 0xD7):
+                    p += 1
+        main = [k for k in range(n) if end[k] != 0]
+        assert [first[k] for k in main] == sos, name
+        for k in main:
+            assert data[end[k]] == 0xFF and data[end[k] + 1] not in (0,) and not 0xD0 <= data[end[k] + 1] <= 0xD7
+        if name.startswith("xt_"):
+            assert n > len(main) and all(first[k] == end[main[-1]] for k in range(n) if end[k] == 0)
+        else:
+            assert n == len(main)
+        d.close()
+
+
+def test_prepare_batch_host_is_the_host_half_of_a_batch_submit():
+    """mijpeg_prepare_batch_host on a host-only object: header parse + marker search + unstuffed copy of every stream, the
+    reference's error for a stream that is none."""
+    from libjpeg_amd import synth
+    streams = [synth.synth_jpeg(160 + 8 * i, 96, i, 85, "420", 4) for i in range(6)]
+    d = api.Decoder(None)
+    d.prepare_batch_host(streams)
+    d.prepare_batch_host(streams[:2])
+    with pytest.raises(api.MijpegError):
+        d.prepare_batch_host([streams[0], b"\xff\xd8 not a jpeg at all"])
+    d.close()

@@ -129,3 +129,20 @@ def test_bind_to_gpu_node_is_a_hint_that_never_fails():
     before = os.sched_getaffinity(0)
     assert sharding.bind_to_gpu_node(0) is None
     assert os.sched_getaffinity(0) == before
+
+
+def test_batch_schedule_covers_every_frame_once():
+    """BatchShard.schedule: contiguous chunks that cover the shard, at most `chunk` frames each; the ramped schedule starts and
+    ends with smaller chunks (the pipeline's fill and drain) and is the plain one for shards too small to ramp."""
+    from libjpeg_amd.batch import BatchShard
+    for n in (1, 7, 32, 100, 256, 1000):
+        for chunk in (1, 8, 24, 32, 40):
+            for ramp in (False, True):
+                s = BatchShard.schedule(n, chunk, ramp)
+                assert s[0][0] == 0 and s[-1][1] == n
+                assert all(a[1] == b[0] for a, b in zip(s, s[1:]))
+                assert all(0 < b - a <= chunk for a, b in s)
+    r = BatchShard.schedule(256, 24, True)
+    sizes = [b - a for a, b in r]
+    assert sizes[0] < sizes[1] < sizes[2] and sizes[-1] < sizes[-2] < sizes[-3] and sizes[:2] == sizes[-2:][::-1]
+    assert BatchShard.schedule(32, 24, True) == BatchShard.schedule(32, 24, False)
