@@ -2640,6 +2640,13 @@ __global__ __launch_bounds__(256) void upsample_color_kernel(const GenericArgs a
 // group's 8 x ncomp samples as whole dwords.  Nothing but coefficients in and samples out touches HBM: traffic = algorithmic
 // bytes + the halo blocks.  Samples carry their level shift (dcoff), as in the generic pair, so SAFE arithmetic and 12-bit
 // frames share the code.
+// n / s for the subsampling factors 1..4 (uniform s): shifts and one constant division instead of the ~35 instructions of a
+// division by a run-time value
+__device__ __forceinline__ int div_small(int n, int s) { return s == 1 ? n : s == 2 ? n >> 1 : s == 4 ? n >> 2 : n / 3; }
+// n / w for 0 <= n < 2^15 and a small uniform w (blocks per line of a tile plane, groups per line of a tile), rw = 1.0f / w:
+// (n + 0.5) * rw lies at least 0.5 / w away from every integer, far more than the product's rounding error
+__device__ __forceinline__ int div_recip(int n, float rw) { return (int)(((float)n + 0.5f) * rw); }
+
 template <class T>
 __device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int cw, int ch, int sx, int sy, int X0, int Y, int (&o)[8])
 {
@@ -2661,7 +2668,7 @@ __device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int c
   //   sy 2: (n + 3 c + r) >> 2, r = 2,1 (even, odd column) above / 1,2 below
   //   sy 3: the same for phases 0 and 2, phase 1 is the line itself
   //   sy 4: phases 0,3: (3 n + 5 c + r) >> 3; 1,2: (n + 7 c + r) >> 3; r = 4,3 except phase 1: 3,4
-  const int y = Y / sy, ymod = Y - y * sy;
+  const int y = div_small(Y, sy), ymod = Y - y * sy;
   const int cur = min(y, ch - 1);
   const bool above = sy == 4 ? ymod < 2 : ymod == 0;
   const int other = above ? min(max(y - 1, 0), ch - 1) : min(cur + 1, ch - 1);
@@ -2669,7 +2676,8 @@ __device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int c
   const unsigned wn = (sy == 4 && (ymod == 0 || ymod == 3)) ? 3u : 1u, wc = (sy == 4 ? 8u : 4u) - wn;
   const int sh = sy == 4 ? 3 : 2;
   const unsigned r_even = sy == 4 ? (ymod == 1 ? 3u : 4u) : (above ? 2u : 1u), r_odd = sy == 4 ? (ymod == 1 ? 4u : 3u) : (above ? 1u : 2u);
-  const int x = (sx > 1) ? X0 / sx - 1 : X0;
+  const int xq = div_small(X0, sx);
+  const int x = (sx > 1) ? xq - 1 : X0;
   const T *pc = plane + cur * pitch, *pn = plane + other * pitch;
   int v[8];
 #pragma unroll
@@ -2698,7 +2706,7 @@ __device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int c
   } else if (sx == 3) {
     // the three column phases (X0 mod 3) as selects over the same eight taps: out[k] is either a sample or a tap of two
     // neighbours; evaluate the three arrangements' inputs by index arithmetic would cost more than the three short branches
-    const int xmod = X0 % 3;
+    const int xmod = X0 - 3 * xq;
     if (xmod == 0) {
       v[7] = v[3];
       v[6] = tap13(v[2], v[3], 2);
@@ -2775,8 +2783,8 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
     bx0[c] = by0[c] = nbx[c] = nby[c] = base[c] = 0;
     if (c < a.ncomp) {
       const int sx = a.subx[c], sy = a.suby[c];
-      const int cx0 = max(px0 / sx - (sx > 1 ? 1 : 0), 0), cx1 = min(px1 / sx + (sx > 1 ? 1 : 0), a.cw[c] - 1);
-      const int cy0 = max(py0 / sy - (sy > 1 ? 1 : 0), 0), cy1 = min(py1 / sy + (sy > 1 ? 1 : 0), a.ch[c] - 1);
+      const int cx0 = max(div_small(px0, sx) - (sx > 1 ? 1 : 0), 0), cx1 = min(div_small(px1, sx) + (sx > 1 ? 1 : 0), a.cw[c] - 1);
+      const int cy0 = max(div_small(py0, sy) - (sy > 1 ? 1 : 0), 0), cy1 = min(div_small(py1, sy) + (sy > 1 ? 1 : 0), a.ch[c] - 1);
       bx0[c] = cx0 >> 3; by0[c] = cy0 >> 3;
       nbx[c] = (cx1 >> 3) - bx0[c] + 1; nby[c] = (cy1 >> 3) - by0[c] + 1;
       base[c] = off;
@@ -2791,6 +2799,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
   for (int c = 0; c < MAXC; c++) {
     if (c >= a.ncomp) break;
     const int nblk = nbx[c] * nby[c], w = nbx[c], pitch = w * 8;
+    const float rw = 1.0f / (float)w;
     const int16_t *__restrict__ plane = coef + a.coef_off[c];
     const int gbase = by0[c] * a.bw[c] + bx0[c], bw = a.bw[c];
     for (int b0 = 0; b0 < nblk; b0 += 64, chunk++) { // wave-uniform: all 64 lanes take part in the fetch
@@ -2798,7 +2807,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
       u32x4 rows[8];
       fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
         const int n = min(b0 + (lane >> 3) + 8 * m, nblk - 1);
-        const int y = n / w, x = n - y * w;
+        const int y = div_recip(n, rw), x = n - y * w;
         return reinterpret_cast<const u32x4 *>(plane + (int64_t)(gbase + y * bw + x) * 64) + (lane & 7);
       });
       const int blk = b0 + lane;
@@ -2806,7 +2815,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
         int v[64];
         if (FAST) dequant_idct_sparse(rows, a.q[c], v, a.dcoff[c]);
         else dequant_idct<false>(rows, a.q[c], v, a.dcoff[c]);
-        const int y = blk / w, x = blk - y * w;
+        const int y = div_recip(blk, rw), x = blk - y * w;
         T *dst = planes + base[c] + (y * 8) * pitch + x * 8;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -2828,8 +2837,9 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
   const int nc = a.ncomp, sb = a.sample_bytes;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const bool aligned = (((uintptr_t)a.out | (uintptr_t)a.out_frame_stride | (uintptr_t)a.row_stride) & 7) == 0;
+  const float rgroups = 1.0f / (float)groups;
   for (int it = tid; it < groups * lines; it += 256) {
-    const int ly = it / groups, g = it - ly * groups;
+    const int ly = div_recip(it, rgroups), g = it - ly * groups;
     const int X0 = px0 + 8 * g, Y = py0 + ly;
     int s[MAXC][8];
 #pragma unroll
@@ -2841,18 +2851,18 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
       }
     }
     const int npx = min(8, a.width - X0);
-    // the group's samples as 16-bit values: component-interleaved, pixel after pixel
-    unsigned short px[8 * MAXC];
+    // the group's samples, clamped: component-interleaved, pixel after pixel
+    unsigned px[8 * MAXC];
 #pragma unroll
     for (int x = 0; x < 8; x++) {
       if (sb == 1) {
         if (a.ycbcr && nc == 3) {
           int r, gg, b;
           ycc_to_rgb<FAST>(s[0][x], s[1][x], s[2][x], r, gg, b);
-          px[x * MAXC + 0] = (unsigned short)r; px[x * MAXC + 1] = (unsigned short)gg; px[x * MAXC + 2] = (unsigned short)b; px[x * MAXC + 3] = 0;
+          px[x * MAXC + 0] = (unsigned)r; px[x * MAXC + 1] = (unsigned)gg; px[x * MAXC + 2] = (unsigned)b; px[x * MAXC + 3] = 0;
         } else {
 #pragma unroll
-          for (int c = 0; c < MAXC; c++) px[x * MAXC + c] = c < nc ? (unsigned short)color_to_int<FAST>(s[c][x]) : (unsigned short)0;
+          for (int c = 0; c < MAXC; c++) px[x * MAXC + c] = c < nc ? (unsigned)color_to_int<FAST>(s[c][x]) : (unsigned)0;
         }
       } else {
         if (a.ycbcr && nc == 3) {
@@ -2864,17 +2874,17 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
             const int r = (yk + (__mul24(cr, L_CR_R) >> 13)) >> 4;
             const int gg = (yk + (mad24(cr, -L_CR_G, __mul24(cb, -L_CB_G)) >> 13)) >> 4;
             const int b = (yk + (__mul24(cb, L_CB_B / 4) >> 11)) >> 4;
-            px[x * MAXC + 0] = (unsigned short)min(max(r, 0), a.maxval); px[x * MAXC + 1] = (unsigned short)min(max(gg, 0), a.maxval);
-            px[x * MAXC + 2] = (unsigned short)min(max(b, 0), a.maxval); px[x * MAXC + 3] = 0;
+            px[x * MAXC + 0] = (unsigned)min(max(r, 0), a.maxval); px[x * MAXC + 1] = (unsigned)min(max(gg, 0), a.maxval);
+            px[x * MAXC + 2] = (unsigned)min(max(b, 0), a.maxval); px[x * MAXC + 3] = 0;
           } else {
             long long r, gg, b;
             ycc_to_rgb_wide(s[0][x], s[1][x], s[2][x], a.dcshift, r, gg, b);
-            px[x * MAXC + 0] = (unsigned short)clampll(r, a.maxval); px[x * MAXC + 1] = (unsigned short)clampll(gg, a.maxval);
-            px[x * MAXC + 2] = (unsigned short)clampll(b, a.maxval); px[x * MAXC + 3] = 0;
+            px[x * MAXC + 0] = (unsigned)clampll(r, a.maxval); px[x * MAXC + 1] = (unsigned)clampll(gg, a.maxval);
+            px[x * MAXC + 2] = (unsigned)clampll(b, a.maxval); px[x * MAXC + 3] = 0;
           }
         } else {
 #pragma unroll
-          for (int c = 0; c < MAXC; c++) px[x * MAXC + c] = c < nc ? (unsigned short)clampll(((long long)s[c][x] + 8) >> 4, a.maxval) : (unsigned short)0;
+          for (int c = 0; c < MAXC; c++) px[x * MAXC + c] = c < nc ? (unsigned)clampll(((long long)s[c][x] + 8) >> 4, a.maxval) : (unsigned)0;
         }
       }
     }
@@ -2891,7 +2901,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const int e = 4 * k + j; // byte e of the group: pixel e / N, component e % N
-              v |= (unsigned)(px[(e / N) * MAXC + (e % N)] & 0xffu) << (8 * j);
+              v |= px[(e / N) * MAXC + (e % N)] << (8 * j); // (clamped to the sample range: no mask)
             }
             w[k] = v;
           }
@@ -2903,7 +2913,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
 #pragma unroll
           for (int k = 0; k < 4 * N; k++) {
             const int e0 = 2 * k, e1 = 2 * k + 1;
-            w[k] = (unsigned)px[(e0 / N) * MAXC + (e0 % N)] | ((unsigned)px[(e1 / N) * MAXC + (e1 % N)] << 16);
+            w[k] = px[(e0 / N) * MAXC + (e0 % N)] | (px[(e1 / N) * MAXC + (e1 % N)] << 16);
           }
           u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
 #pragma unroll
@@ -2922,7 +2932,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
         for (int c = 0; c < MAXC; c++) {
           if (c >= nc) break;
           if (sb == 1) dst[nc * x + c] = (uint8_t)px[x * MAXC + c];
-          else reinterpret_cast<uint16_t *>(dst)[nc * x + c] = px[x * MAXC + c];
+          else reinterpret_cast<uint16_t *>(dst)[nc * x + c] = (uint16_t)px[x * MAXC + c];
         }
       }
     }
