@@ -445,7 +445,7 @@ def emulate_world_child(n_world, stream_dir, frames_total, steps):
     time.sleep(2.5)  # the neighbours are loaded and looping
     best, tried = None, []
     t_begin = time.perf_counter()
-    for chunk, depth, ramp in ((16, 2, False), (8, 4, False), (11, 3, False), (16, 3, False)):
+    for chunk, depth, ramp in ((8, 4, False), (11, 3, False), (16, 3, False), (16, 2, False)):
         if time.perf_counter() - t_begin > seconds - 5.0:
             break
         r = batch.run_sharded(streams, frames_total, 0, n_world, 0, None, steps=steps, warmup=3, chunk=chunk, depth=depth, ramp=ramp)
@@ -509,7 +509,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
     # (pipeline settings worth trying depend on how many frames a rank has: with 256 / 8 = 32 of them, chunks of 16 would leave
     # the pipeline two stages deep)
     # (chunk frames, decoder objects, ramped schedule: small chunks at both ends of the batch -- libjpeg_amd/batch.py)
-    settings = (((32, 4, True), (24, 4, True), (32, 3, True), (24, 4, False), (40, 4, True)) if len(mine) >= 128 else
+    settings = (((24, 4, False), (28, 4, True), (32, 4, True), (24, 4, True), (32, 4, False)) if len(mine) >= 128 else
                 ((8, 4, True), (8, 4, False), (16, 4, False), (16, 2, False), (4, 8, False), (max(1, len(mine)), 1, False)))
     for ci, (chunk, depth, ramp) in enumerate(settings):
         r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=10 if ci == 0 else 2, chunk=chunk, depth=depth,

@@ -1170,8 +1170,8 @@ static int submit_batch(mijpeg_decoder *d, const uint8_t *const *streams, const 
   const auto t0 = clk::now();
   if (const int prc = settle_pending(d)) return prc; // a submitted batch nobody waited for: its staging buffers are about to be reused
   d->batch_frames = 0;
-  d->batch_hosts.resize((size_t)n);
-  for (auto &h : d->batch_hosts)
+  if (d->batch_hosts.size() < (size_t)n) d->batch_hosts.resize((size_t)n); // never shrinks: a pipeline's chunks differ in size, and
+  for (auto &h : d->batch_hosts)                                         // a parser that is thrown away takes its grown vectors along
     if (!h) h.reset(new HostDecoder());
   // headers and restart markers of all streams, one stream per worker -- which writes the device's copy of the entropy
   // coded data (no byte stuffing, no markers) into the stream's slot of the pinned gathering area while it is at it
@@ -1304,8 +1304,8 @@ int mijpeg_prepare_batch_host(mijpeg_decoder *d, const uint8_t *const *streams, 
   if (!d || !streams || !sizes || n < 1) return MIJPEG_ERR_INVALID_PARAMETER;
   if (const int prc = settle_pending(d)) return prc;
   d->batch_frames = 0;
-  d->batch_hosts.resize((size_t)n);
-  for (auto &h : d->batch_hosts)
+  if (d->batch_hosts.size() < (size_t)n) d->batch_hosts.resize((size_t)n); // never shrinks: a pipeline's chunks differ in size, and
+  for (auto &h : d->batch_hosts)                                         // a parser that is thrown away takes its grown vectors along
     if (!h) h.reset(new HostDecoder());
   std::vector<size_t> slot;
   const size_t total = stream_slots(sizes, n, slot);
