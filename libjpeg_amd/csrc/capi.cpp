@@ -1519,6 +1519,22 @@ static bool use_fused1_12(const mijpeg_batch *b)
   return true;
 }
 
+// 12-bit frames of the other layouts (fused_tile_kernel): the same bounds, the chroma one for every component -- 32-bit
+// butterflies and colour products as in use_fused420_12; the upsampling filters weigh two samples (< 2^18 each with the level
+// shift) with at most 8 in total, far inside the 24-bit operands and 32-bit sums of the kernel's fast flavour
+static bool tile_fast12(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  static const bool off = getenv("MIJPEG_NO_TILE_FAST12") != nullptr; // A-B comparisons
+  if (off || f.xt || f.precision != 12 || f.coef_wide || (b->flags & MIJPEG_FLAG_FORCE_SAFE) || f.range_max[0] <= 0) return false;
+  for (int c = 0; c < f.components; c++) {
+    if (f.range_max[c] >= 45056) return false;
+    for (int i = 0; i < 64; i++)
+      if (f.quant[f.quant_index[c]][i] > 2047) return false;
+  }
+  return true;
+}
+
 // the packed flavour filters (Cb, Cr) pairs in 16 bits: every chroma sample * 16 is bounded by 4 * range_max, and the
 // filter sums a + 3 b + r by four times that
 static bool use_fused420p(const mijpeg_batch *b)
@@ -1849,7 +1865,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     // stays for JPEG XT, int32 coefficient planes, per-frame tables in device memory, rectangle requests and MIJPEG_FLAG_FORCE_GENERIC
     static const bool no_tile = getenv("MIJPEG_NO_FUSED_TILE") != nullptr; // A-B measurements
     const bool tile = !rx && !f.xt && !f.coef_wide && !qdev && !(b->flags & MIJPEG_FLAG_FORCE_GENERIC) && !no_tile;
-    rc = tile ? launch_fused_tile(a, fast, s) : -1;
+    rc = tile ? launch_fused_tile(a, fast || tile_fast12(b), s) : -1;
     if (rc == -1) rc = launch_generic(a, fast, s);
   }
   return rc ? MIJPEG_ERR_DEVICE : MIJPEG_OK;

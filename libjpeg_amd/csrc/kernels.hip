@@ -61,6 +61,13 @@ __device__ __forceinline__ int mad24(int a, int k, int c)
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
   return d;
 }
+// (the same with a per-lane factor)
+__device__ __forceinline__ int mad24v(int a, int b, int c)
+{
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ int mul16_lo(unsigned w, int q)
 {
   int d;
@@ -105,18 +112,27 @@ __device__ __forceinline__ unsigned pack_lo16_now(int hi, int lo)
   return d;
 }
 
-// (xa >> 17, xb >> 17), each clamped to [0,255], as two bytes in bits 0..15 (lo = a, hi = b):
-// v_perm_b32 gathers the two high halves (= x >> 16 as int16), one packed shift finishes the >> 17,
-// v_sat_pk_u8_i16 clamps and packs: 1.5 instructions per sample.
-__device__ __forceinline__ unsigned shift17_sat_pack2(int xa, int xb)
+// (a >> SH, b >> SH, c >> SH, d >> SH), each clamped to [0,255], as the four bytes of a dword (a lowest): gfx950's
+// v_ashr_pk_u8_i32 shifts, saturates and packs TWO samples into 16 bits of its destination and leaves the other 16 alone
+// (tools/microbench/ashr_pk.hip prints what the hardware does), op_sel:[0,0,0,1] names the upper half: half an instruction
+// per sample.  (Always through this helper: matched from C code by the compiler of ROCm 7.2, the instruction's result is
+// taken to have zeros in its upper half, which the hardware does not write.)
+template <int SH>
+__device__ __forceinline__ unsigned ashr_sat_pack4(int a, int b, int c, int d)
 {
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const unsigned hi = __builtin_amdgcn_perm((unsigned)xb, (unsigned)xa, 0x07060302u);
-  s16x2 p = __builtin_bit_cast(s16x2, hi);
-  p = p >> (short)1;
-  unsigned d;
-  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(p));
-  return d;
+  unsigned w;
+  asm("v_ashr_pk_u8_i32 %0, %1, %2, %5\n\tv_ashr_pk_u8_i32 %0, %3, %4, %5 op_sel:[0,0,0,1]" : "=&v"(w) : "v"(a), "v"(b), "v"(c), "v"(d), "n"(SH));
+  return w;
+}
+// the 24 bytes r0 g0 b0 r1 ... b7 of eight pixels from their colour sums (17 fraction bits, rounding inside)
+__device__ __forceinline__ void rgb_shift17_sat_pack(const int (&rr)[8], const int (&gg)[8], const int (&bb)[8], unsigned (&w)[6])
+{
+#pragma unroll
+  for (int x = 0; x < 8; x += 4) {
+    w[3 * (x / 4) + 0] = ashr_sat_pack4<17>(rr[x], gg[x], bb[x], rr[x + 1]);
+    w[3 * (x / 4) + 1] = ashr_sat_pack4<17>(gg[x + 1], bb[x + 1], rr[x + 2], gg[x + 2]);
+    w[3 * (x / 4) + 2] = ashr_sat_pack4<17>(bb[x + 2], rr[x + 3], gg[x + 3], bb[x + 3]);
+  }
 }
 
 // floor((x + 2^(n-1)) / 2^n) with the addition carried out beyond 32 bits, as the reference's
@@ -708,16 +724,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
           }
           if (fast_store) {
             // 24 bytes r0 g0 b0 r1 ... b7: clamp + pack two samples per instruction pair
-            unsigned h[12];
-#pragma unroll
-            for (int x = 0; x < 8; x += 2) {
-              h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
-              h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
-              h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
-            }
             unsigned w[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+            rgb_shift17_sat_pack(rr, gg, bb, w);
             u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
             __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
             __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
@@ -949,16 +957,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
           gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
         }
         if (fast_store) {
-          unsigned h[12];
-#pragma unroll
-          for (int x = 0; x < 8; x += 2) {
-            h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
-            h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
-            h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
-          }
           unsigned w[6];
-#pragma unroll
-          for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+          rgb_shift17_sat_pack(rr, gg, bb, w);
           u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
           __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
           __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
@@ -1152,16 +1152,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
           }
         }
         if (fast_store) {
-          unsigned h[12];
-#pragma unroll
-          for (int x = 0; x < 8; x += 2) {
-            h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
-            h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
-            h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
-          }
           unsigned w[6];
-#pragma unroll
-          for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+          rgb_shift17_sat_pack(rr, gg, bb, w);
           u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
           __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
           __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
@@ -1326,16 +1318,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
         gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
       }
       if (fast_store) {
-        unsigned h[12];
-#pragma unroll
-        for (int x = 0; x < 8; x += 2) {
-          h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
-          h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
-          h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
-        }
         unsigned wd[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) wd[i] = h[2 * i] | (h[2 * i + 1] << 16);
+        rgb_shift17_sat_pack(rr, gg, bb, wd);
         u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
         __builtin_nontemporal_store(u32x2{wd[0], wd[1]}, d2);
         __builtin_nontemporal_store(u32x2{wd[2], wd[3]}, d2 + 1);
@@ -1534,16 +1518,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
           }
         }
         if (fast_store) {
-          unsigned h[12];
-#pragma unroll
-          for (int x = 0; x < 8; x += 2) {
-            h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
-            h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
-            h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
-          }
           unsigned w[6];
-#pragma unroll
-          for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+          rgb_shift17_sat_pack(rr, gg, bb, w);
           u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
           __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
           __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
@@ -2088,16 +2064,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
       }
       uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
       if (fast_store) {
-        unsigned h[12];
-#pragma unroll
-        for (int x = 0; x < 8; x += 2) {
-          h[3 * (x / 2) + 0] = shift17_sat_pack2(rr[x], gg[x]);
-          h[3 * (x / 2) + 1] = shift17_sat_pack2(bb[x], rr[x + 1]);
-          h[3 * (x / 2) + 2] = shift17_sat_pack2(gg[x + 1], bb[x + 1]);
-        }
         unsigned w[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) w[i] = h[2 * i] | (h[2 * i + 1] << 16);
+        rgb_shift17_sat_pack(rr, gg, bb, w);
         u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
         __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
         __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
@@ -2192,20 +2160,10 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
 #pragma unroll
   for (int l = 0; l < 8; l++) {
     if (l < nln) {
-      unsigned b4[2]; // four clamped samples each
+      unsigned b4[2]; // four clamped samples each: level shift, COLOR_TO_INT's rounding, shift, clamp
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        unsigned p[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-          unsigned pk;
-          asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(pk) : "v"(v[l * 8 + 4 * h + 2 * i] + (2048 + 8)), "v"(v[l * 8 + 4 * h + 2 * i + 1] + (2048 + 8)));
-          s16x2 t = __builtin_bit_cast(s16x2, pk);
-          t = t >> (short)4;
-          asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p[i]) : "v"(t));
-        }
-        b4[h] = p[0] | (p[1] << 16);
-      }
+      for (int h = 0; h < 2; h++)
+        b4[h] = ashr_sat_pack4<4>(v[l * 8 + 4 * h] + (2048 + 8), v[l * 8 + 4 * h + 1] + (2048 + 8), v[l * 8 + 4 * h + 2] + (2048 + 8), v[l * 8 + 4 * h + 3] + (2048 + 8));
       uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
       if (fast_store) {
         __builtin_nontemporal_store(u32x2{b4[0], b4[1]}, reinterpret_cast<u32x2 *>(dst));
@@ -2646,108 +2604,138 @@ __device__ __forceinline__ int div_small(int n, int s) { return s == 1 ? n : s =
 // n / w for 0 <= n < 2^15 and a small uniform w (blocks per line of a tile plane, groups per line of a tile), rw = 1.0f / w:
 // (n + 0.5) * rw lies at least 0.5 / w away from every integer, far more than the product's rounding error
 __device__ __forceinline__ int div_recip(int n, float rw) { return (int)(((float)n + 0.5f) * rw); }
+// one of four uniform values by a uniform index: scalar selects, no register indexing
+__device__ __forceinline__ int pick4(const int (&v)[MAXC], int c) { return c == 0 ? v[0] : c == 1 ? v[1] : c == 2 ? v[2] : v[3]; }
+
+// A plane line in LDS is preceded by TILE_PAD samples (and one such piece follows the plane): the column left of a line's first
+// sample and the column right of its last one exist in memory, image-edge tiles fill them with the replicated edge sample
+// (upsamplerbase.cpp:322-323), and phase B reads its columns without clamping any of them.
+constexpr int TILE_PAD = 8;
+
+// (wn n + wc c + r) >> sh: vertical filter with the phase's weights as data
+template <bool FAST>
+__device__ __forceinline__ int tile_vmix(int n, int c, int wn, int wc, int r, int sh)
+{
+  if (FAST) return mad24v(c, wc, mad24v(n, wn, r)) >> sh; // |sample * 16| < 2^20 (range check): nothing wraps, 24-bit operands
+  return (int)((unsigned)wn * (unsigned)n + (unsigned)wc * (unsigned)c + (unsigned)r) >> sh;
+}
+template <bool FAST>
+__device__ __forceinline__ int tile_f8(int wa, int x, int wb, int y, int r)
+{
+  if (FAST) return mad24(x, wa, mad24(y, wb, r)) >> 3;
+  return f8(wa, x, wb, y, r);
+}
 
 template <class T>
-__device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int cw, int ch, int sx, int sy, int X0, int Y, int (&o)[8])
+__device__ __forceinline__ void tile_load8(const T *p, int (&o)[8])
 {
-  if (sx == 1 && sy == 1 && X0 + 7 < cw) { // the common case of the full-resolution components: eight samples, one load
-    const T *pc = plane + min(Y, ch - 1) * pitch + X0;
-    if constexpr (sizeof(T) == 2) {
-      const i16x8 v = *reinterpret_cast<const i16x8 *>(pc);
+  if constexpr (sizeof(T) == 2) {
+    const i16x8 v = *reinterpret_cast<const i16x8 *>(p);
 #pragma unroll
-      for (int j = 0; j < 8; j++) o[j] = v[j];
-    } else {
-      const i32x4 v0 = *reinterpret_cast<const i32x4 *>(pc), v1 = *reinterpret_cast<const i32x4 *>(pc + 4);
-      o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
-    }
-    return;
+    for (int j = 0; j < 8; j++) o[j] = v[j];
+  } else {
+    const i32x4 v0 = *reinterpret_cast<const i32x4 *>(p), v1 = *reinterpret_cast<const i32x4 *>(p + 4);
+    o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
   }
-  // upsample_line_any's arithmetic with the vertical phase as DATA: in this kernel the lanes of a wave sit on different lines, so
-  // the phase (Y mod sy) differs between them -- a branch per phase would make the wave walk every one of them.  Each phase
-  // mixes the current line with ONE neighbour (above for the upper phases, below for the lower ones; upsampler.cpp:136-271):
+}
+
+// Eight output samples of one component on output line Y from column X0 on (both relative to the plane's sample (0, 0), X0 a
+// multiple of 8): upsample_line_any's arithmetic on the LDS plane.  plane points at sample (0, 0); ch = lines the plane
+// holds of the image.
+template <bool FAST, class T>
+__device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int ch, int sx, int sy, int X0, int Y, int (&o)[8])
+{
+  // the vertical phase as DATA: in this kernel the lanes of a wave sit on different lines, so the phase (Y mod sy) differs
+  // between them -- a branch per phase would make the wave walk every one of them.  Each phase mixes the current line with ONE
+  // neighbour (above for the upper phases, below for the lower ones; upsampler.cpp:136-271):
   //   sy 2: (n + 3 c + r) >> 2, r = 2,1 (even, odd column) above / 1,2 below
-  //   sy 3: the same for phases 0 and 2, phase 1 is the line itself
+  //   sy 3: the same for phases 0 and 2, phase 1 is the line itself (weights 0 and 4, r = 0)
   //   sy 4: phases 0,3: (3 n + 5 c + r) >> 3; 1,2: (n + 7 c + r) >> 3; r = 4,3 except phase 1: 3,4
   const int y = div_small(Y, sy), ymod = Y - y * sy;
   const int cur = min(y, ch - 1);
+  const T *pc = plane + cur * pitch;
+  if (sx == 1 && sy == 1) { // the full-resolution components: eight samples, one load
+    tile_load8(pc + X0, o);
+    return;
+  }
   const bool above = sy == 4 ? ymod < 2 : ymod == 0;
   const int other = above ? min(max(y - 1, 0), ch - 1) : min(cur + 1, ch - 1);
-  const bool mix = sy > 1 && !(sy == 3 && ymod == 1);
-  const unsigned wn = (sy == 4 && (ymod == 0 || ymod == 3)) ? 3u : 1u, wc = (sy == 4 ? 8u : 4u) - wn;
+  const bool mix = !(sy == 3 && ymod == 1);
   const int sh = sy == 4 ? 3 : 2;
-  const unsigned r_even = sy == 4 ? (ymod == 1 ? 3u : 4u) : (above ? 2u : 1u), r_odd = sy == 4 ? (ymod == 1 ? 4u : 3u) : (above ? 1u : 2u);
+  const int wn = !mix ? 0 : (sy == 4 && (ymod == 0 || ymod == 3)) ? 3 : 1, wc = (1 << sh) - wn;
+  const int r_even = !mix ? 0 : sy == 4 ? (ymod == 1 ? 3 : 4) : (above ? 2 : 1), r_odd = !mix ? 0 : sy == 4 ? (ymod == 1 ? 4 : 3) : (above ? 1 : 2);
+  const T *pn = plane + other * pitch;
+  if (sx == 1) { // vertical filter only (sy > 1): two aligned loads
+    int c[8], n[8];
+    tile_load8(pc + X0, c);
+    tile_load8(pn + X0, n);
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = tile_vmix<FAST>(n[j], c[j], wn, wc, (j & 1) ? r_odd : r_even, sh);
+    return;
+  }
   const int xq = div_small(X0, sx);
-  const int x = (sx > 1) ? xq - 1 : X0;
-  const T *pc = plane + cur * pitch, *pn = plane + other * pitch;
-  int v[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int col = min(max(x + j, 0), cw - 1);
-    const int c = pc[col];
-    int val = c;
-    if (sy > 1) { // (uniform)
-      const int n = pn[col];
-      const int m = (int)(wn * (unsigned)n + wc * (unsigned)c + ((j & 1) ? r_odd : r_even)) >> sh;
-      val = mix ? m : c;
-    }
-    v[j] = val;
-  }
-  // horizontal cores: upsample_line_any's statements (the in-place order of the reference)
+  pc += xq - 1; pn += xq - 1; // buffer entry 0 of the reference's line buffer: the column left of the group's first one
+  auto in = [&](int j) -> int { // buffer entry j after the vertical core
+    const int c = pc[j];
+    return sy > 1 ? tile_vmix<FAST>(pn[j], c, wn, wc, (j & 1) ? r_odd : r_even, sh) : c;
+  };
+  // horizontal cores: upsample_line_any's statements (the in-place order of the reference), on the entries each one reads
   if (sx == 2) {
-    v[7] = tap13(v[5], v[4], 1);
-    v[6] = tap13(v[3], v[4], 2);
-    v[5] = tap13(v[4], v[3], 1);
-    v[4] = tap13(v[2], v[3], 2);
-    v[3] = tap13(v[3], v[2], 1);
-    const int s0 = v[1];
-    v[2] = tap13(s0, v[2], 2);
-    v[1] = tap13(v[2], s0, 1);
-    v[0] = tap13(v[0], s0, 2);
+    const int v0 = in(0), v1 = in(1), v2 = in(2), v3 = in(3), v4 = in(4), v5 = in(5);
+    o[7] = tap13(v5, v4, 1);
+    o[6] = tap13(v3, v4, 2);
+    o[5] = tap13(v4, v3, 1);
+    o[4] = tap13(v2, v3, 2);
+    o[3] = tap13(v3, v2, 1);
+    o[2] = tap13(v1, v2, 2);
+    o[1] = tap13(o[2], v1, 1); // (in-place aliasing of the reference: src[1] already holds out[2])
+    o[0] = tap13(v0, v1, 2);
   } else if (sx == 3) {
-    // the three column phases (X0 mod 3) as selects over the same eight taps: out[k] is either a sample or a tap of two
-    // neighbours; evaluate the three arrangements' inputs by index arithmetic would cost more than the three short branches
+    // the three column phases (X0 mod 3): out[k] is either a sample or a tap of two neighbours
     const int xmod = X0 - 3 * xq;
+    const int v1 = in(1), v2 = in(2), v3 = in(3);
     if (xmod == 0) {
-      v[7] = v[3];
-      v[6] = tap13(v[2], v[3], 2);
-      v[5] = tap13(v[3], v[2], 1);
-      v[4] = v[2];
-      v[3] = tap13(v[1], v[2], 2);
-      v[2] = tap13(v[2], v[1], 1);
-      v[0] = tap13(v[0], v[1], 2);
+      const int v0 = in(0);
+      o[7] = v3;
+      o[6] = tap13(v2, v3, 2);
+      o[5] = tap13(v3, v2, 1);
+      o[4] = v2;
+      o[3] = tap13(v1, v2, 2);
+      o[2] = tap13(v2, v1, 1);
+      o[1] = v1;
+      o[0] = tap13(v0, v1, 2);
     } else if (xmod == 1) {
-      v[7] = tap13(v[4], v[3], 1);
-      v[6] = v[3];
-      v[5] = tap13(v[2], v[3], 2);
-      v[4] = tap13(v[3], v[2], 1);
-      v[3] = v[2];
-      const int s0 = v[1];
-      v[2] = tap13(s0, v[2], 2);
-      v[1] = tap13(v[2], s0, 1);
-      v[0] = s0;
+      const int v4 = in(4);
+      o[7] = tap13(v4, v3, 1);
+      o[6] = v3;
+      o[5] = tap13(v2, v3, 2);
+      o[4] = tap13(v3, v2, 1);
+      o[3] = v2;
+      o[2] = tap13(v1, v2, 2);
+      o[1] = tap13(o[2], v1, 1);
+      o[0] = v1;
     } else {
-      v[7] = tap13(v[3], v[4], 2);
-      v[6] = tap13(v[4], v[3], 1);
-      v[5] = v[3];
-      v[4] = tap13(v[2], v[3], 2);
-      v[3] = tap13(v[3], v[2], 1);
-      const int s0 = v[1];
-      v[1] = tap13(s0, v[2], 2);
-      v[0] = tap13(v[2], s0, 1);
+      const int v4 = in(4);
+      o[7] = tap13(v3, v4, 2);
+      o[6] = tap13(v4, v3, 1);
+      o[5] = v3;
+      o[4] = tap13(v2, v3, 2);
+      o[3] = tap13(v3, v2, 1);
+      o[2] = v2;
+      o[1] = tap13(v1, v2, 2);
+      o[0] = tap13(v2, v1, 1);
     }
-  } else if (sx == 4) {
-    v[7] = f8(3, v[3], 5, v[2], 1);
-    v[6] = f8(1, v[3], 7, v[2], 2);
-    v[5] = f8(1, v[1], 7, v[2], 1);
-    v[4] = f8(3, v[1], 5, v[2], 2);
-    const int s0 = v[1];
-    v[3] = f8(3, v[2], 5, s0, 1);
-    v[2] = f8(1, v[2], 7, s0, 2);
-    v[1] = f8(1, v[0], 7, s0, 1);
-    v[0] = f8(3, v[0], 5, s0, 2);
+  } else {
+    const int v0 = in(0), v1 = in(1), v2 = in(2), v3 = in(3);
+    o[7] = tile_f8<FAST>(3, v3, 5, v2, 1);
+    o[6] = tile_f8<FAST>(1, v3, 7, v2, 2);
+    o[5] = tile_f8<FAST>(1, v1, 7, v2, 1);
+    o[4] = tile_f8<FAST>(3, v1, 5, v2, 2);
+    o[3] = tile_f8<FAST>(3, v2, 5, v1, 1);
+    o[2] = tile_f8<FAST>(1, v2, 7, v1, 2);
+    o[1] = tile_f8<FAST>(1, v0, 7, v1, 1);
+    o[0] = tile_f8<FAST>(3, v0, 5, v1, 2);
   }
-#pragma unroll
-  for (int j = 0; j < 8; j++) o[j] = v[j];
 }
 
 template <bool FAST, bool NARROW>
@@ -2775,168 +2763,200 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
   const int px1 = min(px0 + a.tile_w, a.width) - 1, py1 = min(py0 + a.tile_h, a.height) - 1;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
-  // geometry of the component planes in LDS: first block column / row, blocks held, pitch; xo / yo = sample at local (0, 0)
-  int bx0[MAXC], by0[MAXC], nbx[MAXC], nby[MAXC], base[MAXC];
-  int off = 0;
+  // geometry of the component planes in LDS: first block column / row, blocks held; base = index of sample (0, 0), which is
+  // sample (bx0 * 8, by0 * 8) of the component; a line takes nbx * 8 + TILE_PAD samples
+  int bx0[MAXC], by0[MAXC], nbx[MAXC], nby[MAXC], base[MAXC], nchunk[MAXC];
+  int off = 0, chunks = 0;
+  bool edge = false;
 #pragma unroll
   for (int c = 0; c < MAXC; c++) {
-    bx0[c] = by0[c] = nbx[c] = nby[c] = base[c] = 0;
+    bx0[c] = by0[c] = nbx[c] = nby[c] = base[c] = nchunk[c] = 0;
     if (c < a.ncomp) {
       const int sx = a.subx[c], sy = a.suby[c];
       const int cx0 = max(div_small(px0, sx) - (sx > 1 ? 1 : 0), 0), cx1 = min(div_small(px1, sx) + (sx > 1 ? 1 : 0), a.cw[c] - 1);
       const int cy0 = max(div_small(py0, sy) - (sy > 1 ? 1 : 0), 0), cy1 = min(div_small(py1, sy) + (sy > 1 ? 1 : 0), a.ch[c] - 1);
       bx0[c] = cx0 >> 3; by0[c] = cy0 >> 3;
       nbx[c] = (cx1 >> 3) - bx0[c] + 1; nby[c] = (cy1 >> 3) - by0[c] + 1;
-      base[c] = off;
-      off += nbx[c] * nby[c] * 64;
+      base[c] = off + TILE_PAD;
+      off += nby[c] * 8 * (nbx[c] * 8 + TILE_PAD) + TILE_PAD;
+      nchunk[c] = (nbx[c] * nby[c] + 63) >> 6;
+      chunks += nchunk[c];
+      if (sx > 1) edge |= (bx0[c] == 0) | (a.cw[c] - bx0[c] * 8 <= nbx[c] * 8);
     }
   }
   // ------------------------------------------------------------------ phase A: blocks -> sample planes in LDS
   // the (component, 64 blocks) chunks of the tile go to the four waves in turn: every wave transforms a quarter of the
-  // tile's blocks whatever the components' sizes are
-  int chunk = 0;
+  // tile's blocks whatever the components' sizes are.  One copy of the code for all components (the component is a uniform
+  // run-time value here: phase A alone would otherwise be four times three transforms long).
+  for (int chunk = wave; chunk < chunks; chunk += 4) {
+    int c = 0, k = chunk;
 #pragma unroll
-  for (int c = 0; c < MAXC; c++) {
-    if (c >= a.ncomp) break;
-    const int nblk = nbx[c] * nby[c], w = nbx[c], pitch = w * 8;
+    for (int i = 0; i + 1 < MAXC; i++)
+      if (c == i && k >= nchunk[i]) { k -= nchunk[i]; c = i + 1; }
+    const int w = pick4(nbx, c), nblk = w * pick4(nby, c), pitch = w * 8 + TILE_PAD, b0 = k * 64;
     const float rw = 1.0f / (float)w;
-    const int16_t *__restrict__ plane = coef + a.coef_off[c];
-    const int gbase = by0[c] * a.bw[c] + bx0[c], bw = a.bw[c];
-    for (int b0 = 0; b0 < nblk; b0 += 64, chunk++) { // wave-uniform: all 64 lanes take part in the fetch
-      if ((chunk & 3) != wave) continue;
-      u32x4 rows[8];
-      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
-        const int n = min(b0 + (lane >> 3) + 8 * m, nblk - 1);
-        const int y = div_recip(n, rw), x = n - y * w;
-        return reinterpret_cast<const u32x4 *>(plane + (int64_t)(gbase + y * bw + x) * 64) + (lane & 7);
-      });
-      const int blk = b0 + lane;
-      if (blk < nblk) {
-        int v[64];
-        if (FAST) dequant_idct_sparse(rows, a.q[c], v, a.dcoff[c]);
-        else dequant_idct<false>(rows, a.q[c], v, a.dcoff[c]);
-        const int y = div_recip(blk, rw), x = blk - y * w;
-        T *dst = planes + base[c] + (y * 8) * pitch + x * 8;
+    const int bw = c == 0 ? a.bw[0] : c == 1 ? a.bw[1] : c == 2 ? a.bw[2] : a.bw[3];
+    const int64_t coff = c == 0 ? a.coef_off[0] : c == 1 ? a.coef_off[1] : c == 2 ? a.coef_off[2] : a.coef_off[3];
+    const int dcoff = c == 0 ? a.dcoff[0] : c == 1 ? a.dcoff[1] : c == 2 ? a.dcoff[2] : a.dcoff[3];
+    const int *__restrict__ q = a.q[c];
+    const char *__restrict__ first = reinterpret_cast<const char *>(coef + coff) + (int64_t)(pick4(by0, c) * bw + pick4(bx0, c)) * 128;
+    u32x4 rows[8];
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int n = min(b0 + (lane >> 3) + 8 * m, nblk - 1);
+      const int y = div_recip(n, rw), x = mad24(y, -w, n);
+      return reinterpret_cast<const u32x4 *>(first + (((unsigned)mad24(y, bw, x) << 7) | ((unsigned)(lane & 7) << 4)));
+    });
+    const int blk = b0 + lane;
+    if (blk < nblk) {
+      int v[64];
+      if (FAST) dequant_idct_sparse(rows, q, v, dcoff);
+      else dequant_idct<false>(rows, q, v, dcoff);
+      const int y = div_recip(blk, rw), x = mad24(y, -w, blk);
+      T *dst = planes + pick4(base, c) + (y * 8) * pitch + x * 8;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          if constexpr (NARROW) {
-            *reinterpret_cast<i16x8 *>(dst + r * pitch) = i16x8{(short)v[r * 8 + 0], (short)v[r * 8 + 1], (short)v[r * 8 + 2], (short)v[r * 8 + 3],
-                                                                (short)v[r * 8 + 4], (short)v[r * 8 + 5], (short)v[r * 8 + 6], (short)v[r * 8 + 7]};
-          } else {
-            i32x4 *d = reinterpret_cast<i32x4 *>(dst + r * pitch);
-            d[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
-            d[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
-          }
+      for (int r = 0; r < 8; r++) {
+        if constexpr (NARROW) {
+          *reinterpret_cast<i16x8 *>(dst + r * pitch) = i16x8{(short)v[r * 8 + 0], (short)v[r * 8 + 1], (short)v[r * 8 + 2], (short)v[r * 8 + 3],
+                                                              (short)v[r * 8 + 4], (short)v[r * 8 + 5], (short)v[r * 8 + 6], (short)v[r * 8 + 7]};
+        } else {
+          i32x4 *d = reinterpret_cast<i32x4 *>(dst + r * pitch);
+          d[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
+          d[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
         }
       }
     }
   }
   __syncthreads();
+  if (edge) { // (uniform) tiles on the left / right image edge: the replicated columns of the horizontally subsampled planes
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      if (c < a.ncomp && a.subx[c] > 1) {
+        const int pitch = nbx[c] * 8 + TILE_PAD, last = a.cw[c] - bx0[c] * 8 - 1; // last column of the image, plane-relative
+        for (int r = tid; r < nby[c] * 8; r += 256) {
+          T *line = planes + base[c] + r * pitch;
+          if (bx0[c] == 0) line[-1] = line[0];
+          if (last < nbx[c] * 8) {
+            const T v = line[last];
+            for (int k = last + 1; k <= nbx[c] * 8; k++) line[k] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
   // ------------------------------------------------------------------ phase B: lines of 8-pixel groups
   const int groups = (px1 - px0 + 8) >> 3, lines = py1 - py0 + 1;
-  const int nc = a.ncomp, sb = a.sample_bytes;
+  const int sb = a.sample_bytes;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const bool aligned = (((uintptr_t)a.out | (uintptr_t)a.out_frame_stride | (uintptr_t)a.row_stride) & 7) == 0;
   const float rgroups = 1.0f / (float)groups;
-  for (int it = tid; it < groups * lines; it += 256) {
-    const int ly = div_recip(it, rgroups), g = it - ly * groups;
-    const int X0 = px0 + 8 * g, Y = py0 + ly;
-    int s[MAXC][8];
+  // one instance per component count: the loops over components and the sample packing have static shapes
+  auto phase_b = [&](auto NCc) {
+    constexpr int NC = decltype(NCc)::value;
+    for (int it = tid; it < groups * lines; it += 256) {
+      const int ly = div_recip(it, rgroups), g = mad24(ly, -groups, it);
+      const int X0 = px0 + 8 * g, Y = py0 + ly;
+      int s[NC][8];
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-      if (c < nc) {
+      for (int c = 0; c < NC; c++) {
         const int sx = a.subx[c], sy = a.suby[c], xo = bx0[c] * 8, yo = by0[c] * 8;
-        // local coordinates: the plane's (0, 0) is sample (xo, yo) of the component; the image-edge clamps move with it
-        tile_plane_line<T>(planes + base[c], nbx[c] * 8, min(a.cw[c] - xo, nbx[c] * 8), min(a.ch[c] - yo, nby[c] * 8), sx, sy, X0 - xo * sx, Y - yo * sy, s[c]);
+        // plane coordinates: (0, 0) is sample (xo, yo) of the component; the image's last line moves with it
+        tile_plane_line<FAST, T>(planes + base[c], nbx[c] * 8 + TILE_PAD, min(a.ch[c] - yo, nby[c] * 8), sx, sy, X0 - xo * sx, Y - yo * sy, s[c]);
       }
-    }
-    const int npx = min(8, a.width - X0);
-    // the group's samples, clamped: component-interleaved, pixel after pixel
-    unsigned px[8 * MAXC];
-#pragma unroll
-    for (int x = 0; x < 8; x++) {
+      // the group's samples as the dwords of the output line: 2 NC of them (8-bit samples) or 4 NC (16-bit samples)
+      unsigned w[4 * NC];
       if (sb == 1) {
-        if (a.ycbcr && nc == 3) {
-          int r, gg, b;
-          ycc_to_rgb<FAST>(s[0][x], s[1][x], s[2][x], r, gg, b);
-          px[x * MAXC + 0] = (unsigned)r; px[x * MAXC + 1] = (unsigned)gg; px[x * MAXC + 2] = (unsigned)b; px[x * MAXC + 3] = 0;
-        } else {
+        if (FAST && NC == 3 && a.ycbcr) {
+          // the colour stage of the fused 4:2:0 kernel: constants carry level shift and rounding, two samples per clamp
+          const int KR = 65536 - 2048 * L_CR_R, KG = 65536 + 2048 * (L_CB_G + L_CR_G), KB = 65536 - 2048 * L_CB_B;
+          int rr[8], gg[8], bb[8];
 #pragma unroll
-          for (int c = 0; c < MAXC; c++) px[x * MAXC + c] = c < nc ? (unsigned)color_to_int<FAST>(s[c][x]) : (unsigned)0;
+          for (int x = 0; x < 8; x++) {
+            const int y13 = s[0][x] << 13, cb = s[NC > 1 ? 1 : 0][x], cr = s[NC > 2 ? 2 : 0][x];
+            rr[x] = mad24(cr, L_CR_R, y13 + KR);
+            gg[x] = mad24(cb, -L_CB_G, mad24(cr, -L_CR_G, y13 + KG));
+            bb[x] = mad24(cb, L_CB_B, y13 + KB);
+          }
+          unsigned w6[6];
+          rgb_shift17_sat_pack(rr, gg, bb, w6);
+#pragma unroll
+          for (int i = 0; i < 6; i++) w[i % (4 * NC)] = w6[i];
+        } else {
+          int px[8 * NC]; // sample e of the group: pixel e / NC, component e % NC
+#pragma unroll
+          for (int x = 0; x < 8; x++) {
+            if (NC == 3 && a.ycbcr) { // (SAFE arithmetic here)
+              int r, gg, b;
+              ycc_to_rgb<FAST>(s[0][x], s[NC > 1 ? 1 : 0][x], s[NC > 2 ? 2 : 0][x], r, gg, b);
+              px[x * NC] = r; px[x * NC + (NC > 1 ? 1 : 0)] = gg; px[x * NC + (NC > 2 ? 2 : 0)] = b;
+            } else {
+#pragma unroll
+              for (int c = 0; c < NC; c++) px[x * NC + c] = FAST ? s[c][x] + 8 : color_to_int<false>(s[c][x]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 2 * NC; k++) {
+            if (FAST) w[k] = ashr_sat_pack4<4>(px[4 * k], px[4 * k + 1], px[4 * k + 2], px[4 * k + 3]); // COLOR_TO_INT + clamp (identity)
+            else w[k] = ashr_sat_pack4<0>(px[4 * k], px[4 * k + 1], px[4 * k + 2], px[4 * k + 3]);
+          }
         }
       } else {
-        if (a.ycbcr && nc == 3) {
-          if (FAST) {
-            // the reference's 64-bit sum (y 8192 + c' L + 65536) >> 17 with c' = c - level shift in 32 bits: c' L = q 2^13 + r,
-            // 0 <= r < 2^13, gives ((y + 8 + q) 2^13 + r) >> 17 = (y + 8 + q) >> 4 exactly (fused420_kernel<12> has the proof;
-            // FAST means sum |c| q < 16384 per block, so |c'| < 66 000 and the products stay below 2^31)
-            const int yk = s[0][x] + 8, cb = s[1][x] - a.dcshift, cr = s[2][x] - a.dcshift;
-            const int r = (yk + (__mul24(cr, L_CR_R) >> 13)) >> 4;
-            const int gg = (yk + (mad24(cr, -L_CR_G, __mul24(cb, -L_CB_G)) >> 13)) >> 4;
-            const int b = (yk + (__mul24(cb, L_CB_B / 4) >> 11)) >> 4;
-            px[x * MAXC + 0] = (unsigned)min(max(r, 0), a.maxval); px[x * MAXC + 1] = (unsigned)min(max(gg, 0), a.maxval);
-            px[x * MAXC + 2] = (unsigned)min(max(b, 0), a.maxval); px[x * MAXC + 3] = 0;
-          } else {
-            long long r, gg, b;
-            ycc_to_rgb_wide(s[0][x], s[1][x], s[2][x], a.dcshift, r, gg, b);
-            px[x * MAXC + 0] = (unsigned)clampll(r, a.maxval); px[x * MAXC + 1] = (unsigned)clampll(gg, a.maxval);
-            px[x * MAXC + 2] = (unsigned)clampll(b, a.maxval); px[x * MAXC + 3] = 0;
-          }
-        } else {
+        unsigned px[8 * NC];
 #pragma unroll
-          for (int c = 0; c < MAXC; c++) px[x * MAXC + c] = c < nc ? (unsigned)clampll(((long long)s[c][x] + 8) >> 4, a.maxval) : (unsigned)0;
-        }
-      }
-    }
-    uint8_t *dst = out_frame + (int64_t)Y * a.row_stride + (int64_t)X0 * nc * sb;
-    if (aligned && npx == 8) {
-      // 8 * nc * sb bytes = a whole number of 8-byte pieces: build them from the samples with static indices per layout
-      auto store_bytes = [&](auto NC) {
-        constexpr int N = decltype(NC)::value;
-        if (sb == 1) {
-          unsigned w[2 * N];
-#pragma unroll
-          for (int k = 0; k < 2 * N; k++) {
-            unsigned v = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const int e = 4 * k + j; // byte e of the group: pixel e / N, component e % N
-              v |= px[(e / N) * MAXC + (e % N)] << (8 * j); // (clamped to the sample range: no mask)
+        for (int x = 0; x < 8; x++) {
+          if (NC == 3 && a.ycbcr) {
+            if (FAST) {
+              // the reference's 64-bit sum (y 8192 + c' L + 65536) >> 17 with c' = c - level shift in 32 bits: c' L = q 2^13 + r,
+              // 0 <= r < 2^13, gives ((y + 8 + q) 2^13 + r) >> 17 = (y + 8 + q) >> 4 exactly (fused420_kernel<12> has the proof;
+              // FAST bounds the chroma samples times 16 by 181 200, see use_fused420_12 in capi.cpp: the products stay inside
+              // 32 bits, the operands inside 24)
+              const int yk = s[0][x] + 8, cb = s[NC > 1 ? 1 : 0][x] - a.dcshift, cr = s[NC > 2 ? 2 : 0][x] - a.dcshift;
+              const int r = (yk + (__mul24(cr, L_CR_R) >> 13)) >> 4;
+              const int gg = (yk + (mad24(cr, -L_CR_G, __mul24(cb, -L_CB_G)) >> 13)) >> 4;
+              const int b = (yk + (__mul24(cb, L_CB_B / 4) >> 11)) >> 4;
+              px[x * NC] = (unsigned)min(max(r, 0), a.maxval); px[x * NC + (NC > 1 ? 1 : 0)] = (unsigned)min(max(gg, 0), a.maxval);
+              px[x * NC + (NC > 2 ? 2 : 0)] = (unsigned)min(max(b, 0), a.maxval);
+            } else {
+              long long r, gg, b;
+              ycc_to_rgb_wide(s[0][x], s[NC > 1 ? 1 : 0][x], s[NC > 2 ? 2 : 0][x], a.dcshift, r, gg, b);
+              px[x * NC] = (unsigned)clampll(r, a.maxval); px[x * NC + (NC > 1 ? 1 : 0)] = (unsigned)clampll(gg, a.maxval);
+              px[x * NC + (NC > 2 ? 2 : 0)] = (unsigned)clampll(b, a.maxval);
             }
-            w[k] = v;
+          } else {
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+              px[x * NC + c] = FAST ? (unsigned)min(max((s[c][x] + 8) >> 4, 0), a.maxval) : (unsigned)clampll(((long long)s[c][x] + 8) >> 4, a.maxval);
           }
-          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
-#pragma unroll
-          for (int k = 0; k < N; k++) d2[k] = u32x2{w[2 * k], w[2 * k + 1]};
-        } else {
-          unsigned w[4 * N];
-#pragma unroll
-          for (int k = 0; k < 4 * N; k++) {
-            const int e0 = 2 * k, e1 = 2 * k + 1;
-            w[k] = px[(e0 / N) * MAXC + (e0 % N)] | (px[(e1 / N) * MAXC + (e1 % N)] << 16);
-          }
-          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
-#pragma unroll
-          for (int k = 0; k < 2 * N; k++) d2[k] = u32x2{w[2 * k], w[2 * k + 1]};
         }
-      };
-      if (nc == 1) store_bytes(std::integral_constant<int, 1>{});
-      else if (nc == 2) store_bytes(std::integral_constant<int, 2>{});
-      else if (nc == 3) store_bytes(std::integral_constant<int, 3>{});
-      else store_bytes(std::integral_constant<int, 4>{});
-    } else {
 #pragma unroll
-      for (int x = 0; x < 8; x++) {
-        if (x >= npx) break;
+        for (int k = 0; k < 4 * NC; k++) w[k] = px[2 * k] | (px[2 * k + 1] << 16);
+      }
+      uint8_t *dst = out_frame + (int64_t)Y * a.row_stride + (int64_t)X0 * (NC * sb);
+      const int npx = min(8, a.width - X0);
+      if (aligned && npx == 8) { // 8 * NC * sb bytes = a whole number of 8-byte pieces
+        u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+        if (sb == 1) {
 #pragma unroll
-        for (int c = 0; c < MAXC; c++) {
-          if (c >= nc) break;
-          if (sb == 1) dst[nc * x + c] = (uint8_t)px[x * MAXC + c];
-          else reinterpret_cast<uint16_t *>(dst)[nc * x + c] = (uint16_t)px[x * MAXC + c];
+          for (int k = 0; k < NC; k++) d2[k] = u32x2{w[2 * k], w[2 * k + 1]};
+        } else {
+#pragma unroll
+          for (int k = 0; k < 2 * NC; k++) d2[k] = u32x2{w[2 * k], w[2 * k + 1]};
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8 * NC; e++) { // sample e of the group: pixel e / NC, component e % NC
+          if (e < npx * NC) {
+            if (sb == 1) dst[e] = (uint8_t)(w[e >> 2] >> (8 * (e & 3)));
+            else reinterpret_cast<uint16_t *>(dst)[e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+          }
         }
       }
     }
-  }
+  };
+  if (a.ncomp == 1) phase_b(std::integral_constant<int, 1>{});
+  else if (a.ncomp == 2) phase_b(std::integral_constant<int, 2>{});
+  else if (a.ncomp == 3) phase_b(std::integral_constant<int, 3>{});
+  else phase_b(std::integral_constant<int, 4>{});
 }
 
 // ==============================================================================================
@@ -3280,7 +3300,7 @@ static size_t fused_tile_geometry(GenericArgs &a, bool narrow)
       for (int c = 0; c < a.ncomp; c++) {
         // (a tile of whole MCUs starts on a block boundary of every component; the halo sample on each side costs one more block)
         const int wx = a.tile_w / (8 * a.subx[c]) + (a.subx[c] > 1 ? 2 : 0), wy = a.tile_h / (8 * a.suby[c]) + (a.suby[c] > 1 ? 2 : 0);
-        samples += (size_t)wx * wy * 64;
+        samples += (size_t)wy * 8 * (wx * 8 + TILE_PAD) + TILE_PAD;
       }
       const size_t lds = 4 * 128 * 16 + samples * (narrow ? 2 : 4);
       if (lds <= 64 * 1024) { // (a 52 KB budget -- three workgroups per CU -- halves the tile of 12-bit 4:4:4 frames: 164 -> 121 Gpixel/s)
