@@ -1718,7 +1718,6 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     a.tiles_x = (f.width + 127) / 128;
     a.tiles_y = (f.height + 127) / 128;
     a.frames = b->frames;
-    a.aligned8 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 7) == 0;
     for (int c = 0; c < 3; c++)
       for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
     a.qdev = qdev;
@@ -1738,7 +1737,6 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       xa.ext.is_float = x.is_float;
       xa.ext.out_max = x.out_max;
       xa.ext.out_shift = x.out_shift;
-      xa.ext.aligned16 = (((uintptr_t)b->out_dev | (uintptr_t)b->out_frame_stride | (uintptr_t)b->out_row_stride) & 15) == 0;
       xa.ext.rprecision = r.precision + x.residual_hidden_bits;
       rc = launch_fusedxt420(xa, s);
     } else

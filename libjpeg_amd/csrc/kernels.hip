@@ -35,6 +35,10 @@ namespace mij {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// the same at any byte address: lines of the caller's bitmap start wherever its row stride puts them, and gfx950 stores
+// dwordx2 / dwordx4 at any address (tools/microbench/unaligned_store.hip); the only thing the fast stores need is a full group
+typedef u32x2 u32x2_any __attribute__((aligned(1)));
+typedef u32x4 u32x4_any __attribute__((aligned(1)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // ----------------------------------------------------------------------------------------------
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * (P == 12 ? 6u : 3u);
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = (P == 12 ? (((uintptr_t)a.out | (uintptr_t)a.out_frame_stride | (uintptr_t)a.row_stride) & 15) == 0 : a.aligned8 != 0) && npx == 8;
+  const bool fast_store = npx == 8;
 
   // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns pc = 4 bx + 3 + j
   const int *cb_base = cplane[0] + (4 * by) * F420_CPITCH + 4 * bx;
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
               w[3 * (x / 2) + 1] = c12(bb[x]) | (c12(rr[x + 1]) << 16);
               w[3 * (x / 2) + 2] = c12(gg[x + 1]) | (c12(bb[x + 1]) << 16);
             }
-            u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+            u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
             __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
             __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
             __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
             // 24 bytes r0 g0 b0 r1 ... b7: clamp + pack two samples per instruction pair
             unsigned w[6];
             rgb_shift17_sat_pack(rr, gg, bb, w);
-            u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+            u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
             __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
             __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
             __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
             unsigned w[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) w[i] = px[4 * i] | (px[4 * i + 1] << 8) | (px[4 * i + 2] << 16) | (px[4 * i + 3] << 24);
-            u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+            u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
             __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
             __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
             __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = a.aligned8 && npx == 8;
+  const bool fast_store = npx == 8;
   // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns pc = 4 bx + 3 + j
   const unsigned *c_base = cpair + (4 * by) * F420_CPITCH + 4 * bx;
   auto load6 = [](const unsigned *p, unsigned (&d)[6]) { // p is 16-byte aligned; wanted: p[3..8]
@@ -959,7 +963,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
         if (fast_store) {
           unsigned w[6];
           rgb_shift17_sat_pack(rr, gg, bb, w);
-          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+          u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
           __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
           __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
           __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
@@ -1098,7 +1102,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = a.aligned8 && npx == 8;
+  const bool fast_store = npx == 8;
   // chroma window of this block: lines pr = 8 by + l, columns pc = 4 bx + 3 + j
   const unsigned *c_base = cpair + (8 * by) * F420_CPITCH + 4 * bx;
   auto load6 = [](const unsigned *p, unsigned (&d)[6]) { // p is 16-byte aligned; wanted: p[3..8]
@@ -1154,7 +1158,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
         if (fast_store) {
           unsigned w[6];
           rgb_shift17_sat_pack(rr, gg, bb, w);
-          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+          u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
           __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
           __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
           __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
@@ -1289,7 +1293,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = a.aligned8 && npx == 8;
+  const bool fast_store = npx == 8;
   // chroma window of this block: lines 8 by + l, columns x_rel = 2 bx - 1 .. 2 bx + 2, i.e. pc = 2 bx + 3 .. 2 bx + 6
   const unsigned *c_base = cpair + (8 * by) * F411_CPITCH + 2 * bx + 3;
   const int K = (2048 << 13) + 65536;
@@ -1320,7 +1324,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
       if (fast_store) {
         unsigned wd[6];
         rgb_shift17_sat_pack(rr, gg, bb, wd);
-        u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+        u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
         __builtin_nontemporal_store(u32x2{wd[0], wd[1]}, d2);
         __builtin_nontemporal_store(u32x2{wd[2], wd[3]}, d2 + 1);
         __builtin_nontemporal_store(u32x2{wd[4], wd[5]}, d2 + 2);
@@ -1470,7 +1474,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = a.aligned8 && npx == 8;
+  const bool fast_store = npx == 8;
   // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns 8 bx + x
   const unsigned *c_base = cpair + (4 * by) * F440_CPITCH + 8 * bx;
   auto load8 = [](const unsigned *p, unsigned (&d)[8]) {
@@ -1520,7 +1524,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
         if (fast_store) {
           unsigned w[6];
           rgb_shift17_sat_pack(rr, gg, bb, w);
-          u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+          u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
           __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
           __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
           __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
@@ -1626,7 +1630,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 6u;
   const int npx = min(8, a.width - X0);
   const int nln = active ? min(8, a.height - Y0) : 0;
-  const bool fast_store = x.aligned16 && npx == 8;
+  const bool fast_store = npx == 8;
 
   const int *cb_base = cplane[0] + (4 * by) * F420_CPITCH + 4 * bx;
   const int *cr_base = cplane[1] + (4 * by) * F420_CPITCH + 4 * bx;
@@ -1723,7 +1727,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
       if (l < nln) {
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         if (fast_store) {
-          u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+          u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
           __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
           __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
           __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
@@ -1867,7 +1871,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 6u;
   const int npx = min(8, a.width - X0);
   const int nln = active ? min(8, a.height - Y0) : 0;
-  const bool fast_store = x.aligned16 && npx == 8;
+  const bool fast_store = npx == 8;
 
   const int *cb_base = cplane[0] + (4 * by) * F420_CPITCH + 4 * bx;
   const int *cr_base = cplane[1] + (4 * by) * F420_CPITCH + 4 * bx;
@@ -1952,7 +1956,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
       if (l < nln) {
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         if (fast_store) {
-          u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+          u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
           __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
           __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
           __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
@@ -2042,7 +2046,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = a.aligned8 && npx == 8;
+  const bool fast_store = npx == 8;
   const int K = (2048 << 13) + 65536;
 #pragma unroll
   for (int l = 0; l < 8; l++) {
@@ -2066,7 +2070,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
       if (fast_store) {
         unsigned w[6];
         rgb_shift17_sat_pack(rr, gg, bb, w);
-        u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+        u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
         __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
         __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
         __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
@@ -2131,7 +2135,7 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * (P == 12 ? 2u : 1u);
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
-  const bool fast_store = (P == 12 ? (((uintptr_t)a.out | (uintptr_t)a.out_frame_stride | (uintptr_t)a.row_stride) & 15) == 0 : a.aligned8 != 0) && npx == 8;
+  const bool fast_store = npx == 8;
   if (P == 12) {
     // COLOR_TO_INT with the level shift 2^11 << 4 the transform left out: (x + 32768 + 8) >> 4, clamped to [0, 4095]
 #pragma unroll
@@ -2146,7 +2150,7 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
         }
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         if (fast_store) {
-          __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4 *>(dst));
+          __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4_any *>(dst));
         } else {
           uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
 #pragma unroll
@@ -2166,7 +2170,7 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
         b4[h] = ashr_sat_pack4<4>(v[l * 8 + 4 * h] + (2048 + 8), v[l * 8 + 4 * h + 1] + (2048 + 8), v[l * 8 + 4 * h + 2] + (2048 + 8), v[l * 8 + 4 * h + 3] + (2048 + 8));
       uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
       if (fast_store) {
-        __builtin_nontemporal_store(u32x2{b4[0], b4[1]}, reinterpret_cast<u32x2 *>(dst));
+        __builtin_nontemporal_store(u32x2{b4[0], b4[1]}, reinterpret_cast<u32x2_any *>(dst));
       } else {
 #pragma unroll
         for (int x = 0; x < 8; x++)
@@ -2611,6 +2615,9 @@ __device__ __forceinline__ int pick4(const int (&v)[MAXC], int c) { return c == 
 // sample and the column right of its last one exist in memory, image-edge tiles fill them with the replicated edge sample
 // (upsamplerbase.cpp:322-323), and phase B reads its columns without clamping any of them.
 constexpr int TILE_PAD = 8;
+#ifndef TILE_MINW
+#define TILE_MINW 3
+#endif
 
 // (wn n + wc c + r) >> sh: vertical filter with the phase's weights as data
 template <bool FAST>
@@ -2639,48 +2646,71 @@ __device__ __forceinline__ void tile_load8(const T *p, int (&o)[8])
   }
 }
 
-// Eight output samples of one component on output line Y from column X0 on (both relative to the plane's sample (0, 0), X0 a
-// multiple of 8): upsample_line_any's arithmetic on the LDS plane.  plane points at sample (0, 0); ch = lines the plane
-// holds of the image.
-template <bool FAST, class T>
-__device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int ch, int sx, int sy, int X0, int Y, int (&o)[8])
+// What phase B needs to know about a component: uniform values, computed once per workgroup.
+struct TileComp {
+  int sx, sy;             // subsampling factors
+  int rx, ry;             // 2^16 / s + 1: n / s = (n * r) >> 16 for the n of a tile (< 2^12)
+  int pitch;              // samples per plane line in LDS
+  int lines;              // lines of the image the plane holds: the vertical filter clamps to lines - 1
+  int base;               // index of sample (0, 0) of the plane
+  int xoff, yoff;         // pixel coordinates of that sample
+  int sh;                 // shift of the vertical filter: 2, or 3 for sy = 4
+  unsigned long long vt;  // the vertical filter's four phases, 16 bits each (tile_vphases)
+};
+// The vertical cores of upsampling/upsampler.cpp:136-271 as data: in this kernel the lanes of a wave sit on different lines, so
+// the phase (Y mod sy) differs between them -- a branch per phase would make the wave walk every one of them.  Each phase
+// mixes the current line c with ONE neighbour n (above for the upper phases, below for the lower ones) as
+// (wn n + wc c + r) >> sh, wc = 2^sh - wn, r alternating between even and odd columns:
+//   sy 2: (n + 3 c + r) >> 2, r = 2,1 (even, odd column) above / 1,2 below
+//   sy 3: the same for phases 0 and 2, phase 1 is the line itself (weights 0 and 4, r = 0)
+//   sy 4: phases 0,3: (3 n + 5 c + r) >> 3; 1,2: (n + 7 c + r) >> 3; r = 4,3 except phase 1: 3,4
+// An entry: wn | r_even << 2 | r_odd << 5 | d << 8, the neighbour is line y - 1 + d (0: above, 2: below, 1: the line itself).
+__device__ __forceinline__ constexpr unsigned long long tile_vphase(int wn, int re, int ro, int d) { return (unsigned long long)(wn | re << 2 | ro << 5 | d << 8); }
+__device__ __forceinline__ unsigned long long tile_vphases(int sy)
 {
-  // the vertical phase as DATA: in this kernel the lanes of a wave sit on different lines, so the phase (Y mod sy) differs
-  // between them -- a branch per phase would make the wave walk every one of them.  Each phase mixes the current line with ONE
-  // neighbour (above for the upper phases, below for the lower ones; upsampler.cpp:136-271):
-  //   sy 2: (n + 3 c + r) >> 2, r = 2,1 (even, odd column) above / 1,2 below
-  //   sy 3: the same for phases 0 and 2, phase 1 is the line itself (weights 0 and 4, r = 0)
-  //   sy 4: phases 0,3: (3 n + 5 c + r) >> 3; 1,2: (n + 7 c + r) >> 3; r = 4,3 except phase 1: 3,4
-  const int y = div_small(Y, sy), ymod = Y - y * sy;
-  const int cur = min(y, ch - 1);
-  const T *pc = plane + cur * pitch;
-  if (sx == 1 && sy == 1) { // the full-resolution components: eight samples, one load
-    tile_load8(pc + X0, o);
+  constexpr unsigned long long up = tile_vphase(1, 2, 1, 0), down = tile_vphase(1, 1, 2, 2), self = tile_vphase(0, 0, 0, 1);
+  constexpr unsigned long long v2 = up | down << 16, v3 = up | self << 16 | down << 32;
+  constexpr unsigned long long v4 = tile_vphase(3, 4, 3, 0) | tile_vphase(1, 3, 4, 0) << 16 | tile_vphase(1, 4, 3, 2) << 32 | tile_vphase(3, 4, 3, 2) << 48;
+  return sy == 2 ? v2 : sy == 3 ? v3 : sy == 4 ? v4 : self;
+}
+
+// Eight output samples of one component on pixel line Y from pixel column X0 on (X0 a multiple of 8): upsample_line_any's
+// arithmetic on the LDS plane, without a branch that differs between lanes.
+template <bool FAST, class T>
+__device__ __forceinline__ void tile_plane_line(const T *planes, const TileComp &k, int X0, int Y, int (&o)[8])
+{
+  const int Xl = X0 - k.xoff, Yl = Y - k.yoff;
+  if (k.sx == 1 && k.sy == 1) { // the full-resolution components: eight samples, one load
+    tile_load8(planes + k.base + mad24(min(Yl, k.lines - 1), k.pitch, Xl), o);
     return;
   }
-  const bool above = sy == 4 ? ymod < 2 : ymod == 0;
-  const int other = above ? min(max(y - 1, 0), ch - 1) : min(cur + 1, ch - 1);
-  const bool mix = !(sy == 3 && ymod == 1);
-  const int sh = sy == 4 ? 3 : 2;
-  const int wn = !mix ? 0 : (sy == 4 && (ymod == 0 || ymod == 3)) ? 3 : 1, wc = (1 << sh) - wn;
-  const int r_even = !mix ? 0 : sy == 4 ? (ymod == 1 ? 3 : 4) : (above ? 2 : 1), r_odd = !mix ? 0 : sy == 4 ? (ymod == 1 ? 4 : 3) : (above ? 1 : 2);
-  const T *pn = plane + other * pitch;
-  if (sx == 1) { // vertical filter only (sy > 1): two aligned loads
+  const int y = k.sy == 1 ? Yl : (int)((unsigned)__mul24(Yl, k.ry) >> 16);
+  const int cur = min(y, k.lines - 1);
+  const T *pc = planes + k.base + __mul24(cur, k.pitch), *pn = pc;
+  int wn = 0, wc = 0, r_even = 0, r_odd = 0;
+  if (k.sy > 1) { // (uniform)
+    const int ymod = mad24(y, -k.sy, Yl);
+    const unsigned e = (unsigned)(k.vt >> (ymod << 4));
+    wn = e & 3; wc = (1 << k.sh) - wn; r_even = (e >> 2) & 7; r_odd = (e >> 5) & 7;
+    const int other = min(max(y - 1 + (int)((e >> 8) & 3), 0), k.lines - 1);
+    pn = planes + k.base + __mul24(other, k.pitch);
+  }
+  if (k.sx == 1) { // vertical filter only: two aligned loads
     int c[8], n[8];
-    tile_load8(pc + X0, c);
-    tile_load8(pn + X0, n);
+    tile_load8(pc + Xl, c);
+    tile_load8(pn + Xl, n);
 #pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = tile_vmix<FAST>(n[j], c[j], wn, wc, (j & 1) ? r_odd : r_even, sh);
+    for (int j = 0; j < 8; j++) o[j] = tile_vmix<FAST>(n[j], c[j], wn, wc, (j & 1) ? r_odd : r_even, k.sh);
     return;
   }
-  const int xq = div_small(X0, sx);
+  const int xq = (int)((unsigned)__mul24(Xl, k.rx) >> 16);
   pc += xq - 1; pn += xq - 1; // buffer entry 0 of the reference's line buffer: the column left of the group's first one
   auto in = [&](int j) -> int { // buffer entry j after the vertical core
     const int c = pc[j];
-    return sy > 1 ? tile_vmix<FAST>(pn[j], c, wn, wc, (j & 1) ? r_odd : r_even, sh) : c;
+    return k.sy > 1 ? tile_vmix<FAST>(pn[j], c, wn, wc, (j & 1) ? r_odd : r_even, k.sh) : c;
   };
   // horizontal cores: upsample_line_any's statements (the in-place order of the reference), on the entries each one reads
-  if (sx == 2) {
+  if (k.sx == 2) {
     const int v0 = in(0), v1 = in(1), v2 = in(2), v3 = in(3), v4 = in(4), v5 = in(5);
     o[7] = tap13(v5, v4, 1);
     o[6] = tap13(v3, v4, 2);
@@ -2690,41 +2720,20 @@ __device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int c
     o[2] = tap13(v1, v2, 2);
     o[1] = tap13(o[2], v1, 1); // (in-place aliasing of the reference: src[1] already holds out[2])
     o[0] = tap13(v0, v1, 2);
-  } else if (sx == 3) {
-    // the three column phases (X0 mod 3): out[k] is either a sample or a tap of two neighbours
-    const int xmod = X0 - 3 * xq;
-    const int v1 = in(1), v2 = in(2), v3 = in(3);
-    if (xmod == 0) {
-      const int v0 = in(0);
-      o[7] = v3;
-      o[6] = tap13(v2, v3, 2);
-      o[5] = tap13(v3, v2, 1);
-      o[4] = v2;
-      o[3] = tap13(v1, v2, 2);
-      o[2] = tap13(v2, v1, 1);
-      o[1] = v1;
-      o[0] = tap13(v0, v1, 2);
-    } else if (xmod == 1) {
-      const int v4 = in(4);
-      o[7] = tap13(v4, v3, 1);
-      o[6] = v3;
-      o[5] = tap13(v2, v3, 2);
-      o[4] = tap13(v3, v2, 1);
-      o[3] = v2;
-      o[2] = tap13(v1, v2, 2);
-      o[1] = tap13(o[2], v1, 1);
-      o[0] = v1;
-    } else {
-      const int v4 = in(4);
-      o[7] = tap13(v3, v4, 2);
-      o[6] = tap13(v4, v3, 1);
-      o[5] = v3;
-      o[4] = tap13(v2, v3, 2);
-      o[3] = tap13(v3, v2, 1);
-      o[2] = v2;
-      o[1] = tap13(v1, v2, 2);
-      o[0] = tap13(v2, v1, 1);
-    }
+  } else if (k.sx == 3) {
+    // the group starts in one of three column phases (X0 mod 3), which differ between the lanes: the ten output samples from
+    // pixel 3 xq on -- u[t] = a tap of two neighbours or, in the middle of a column, the sample itself -- and every lane
+    // takes eight of them from its phase on
+    const int xmod = Xl - 3 * xq;
+    const int v0 = in(0), v1 = in(1), v2 = in(2), v3 = in(3), v4 = in(4);
+    const int u0 = tap13(v0, v1, 2), u2 = tap13(v2, v1, 1), u3 = tap13(v1, v2, 2), u5 = tap13(v3, v2, 1), u6 = tap13(v2, v3, 2), u8 = tap13(v4, v3, 1),
+              u9 = tap13(v3, v4, 2);
+    const int u[10] = {u0, v1, u2, u3, v2, u5, u6, v3, u8, u9};
+    const bool m1 = xmod == 1, m2 = xmod == 2;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = m2 ? u[j + 2] : m1 ? u[j + 1] : u[j];
+    // (in-place aliasing of the reference in phase 1: its second output reads src[1] when that already holds out[2])
+    o[1] = m1 ? tap13(u3, v1, 1) : o[1];
   } else {
     const int v0 = in(0), v1 = in(1), v2 = in(2), v3 = in(3);
     o[7] = tile_f8<FAST>(3, v3, 5, v2, 1);
@@ -2739,7 +2748,7 @@ __device__ __forceinline__ void tile_plane_line(const T *plane, int pitch, int c
 }
 
 template <bool FAST, bool NARROW>
-__global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
+__global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const GenericArgs a)
 {
   using T = typename std::conditional<NARROW, short, int>::type;
   extern __shared__ __attribute__((aligned(16))) uint8_t tile_lds[];
@@ -2764,21 +2773,25 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   // geometry of the component planes in LDS: first block column / row, blocks held; base = index of sample (0, 0), which is
-  // sample (bx0 * 8, by0 * 8) of the component; a line takes nbx * 8 + TILE_PAD samples
-  int bx0[MAXC], by0[MAXC], nbx[MAXC], nby[MAXC], base[MAXC], nchunk[MAXC];
+  // sample (bx0 * 8, by0 * 8) of the component; a line takes nbx * 8 samples and TILE_PAD more in front of it (needed by the
+  // horizontally subsampled components only, but a pitch of 64 or 128 samples would send the block rows of phase A's
+  // stores to the same banks: CMYK 335 -> 296 Gpixel/s without the pad)
+  int bx0[MAXC], by0[MAXC], nbx[MAXC], nby[MAXC], base[MAXC], nchunk[MAXC], ppitch[MAXC];
   int off = 0, chunks = 0;
   bool edge = false;
 #pragma unroll
   for (int c = 0; c < MAXC; c++) {
-    bx0[c] = by0[c] = nbx[c] = nby[c] = base[c] = nchunk[c] = 0;
+    bx0[c] = by0[c] = nbx[c] = nby[c] = base[c] = nchunk[c] = ppitch[c] = 0;
     if (c < a.ncomp) {
       const int sx = a.subx[c], sy = a.suby[c];
       const int cx0 = max(div_small(px0, sx) - (sx > 1 ? 1 : 0), 0), cx1 = min(div_small(px1, sx) + (sx > 1 ? 1 : 0), a.cw[c] - 1);
       const int cy0 = max(div_small(py0, sy) - (sy > 1 ? 1 : 0), 0), cy1 = min(div_small(py1, sy) + (sy > 1 ? 1 : 0), a.ch[c] - 1);
       bx0[c] = cx0 >> 3; by0[c] = cy0 >> 3;
       nbx[c] = (cx1 >> 3) - bx0[c] + 1; nby[c] = (cy1 >> 3) - by0[c] + 1;
-      base[c] = off + TILE_PAD;
-      off += nby[c] * 8 * (nbx[c] * 8 + TILE_PAD) + TILE_PAD;
+      const int pad = TILE_PAD;
+      ppitch[c] = nbx[c] * 8 + pad;
+      base[c] = off + pad;
+      off += nby[c] * 8 * ppitch[c] + pad;
       nchunk[c] = (nbx[c] * nby[c] + 63) >> 6;
       chunks += nchunk[c];
       if (sx > 1) edge |= (bx0[c] == 0) | (a.cw[c] - bx0[c] * 8 <= nbx[c] * 8);
@@ -2793,7 +2806,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
 #pragma unroll
     for (int i = 0; i + 1 < MAXC; i++)
       if (c == i && k >= nchunk[i]) { k -= nchunk[i]; c = i + 1; }
-    const int w = pick4(nbx, c), nblk = w * pick4(nby, c), pitch = w * 8 + TILE_PAD, b0 = k * 64;
+    const int w = pick4(nbx, c), nblk = w * pick4(nby, c), pitch = pick4(ppitch, c), b0 = k * 64;
     const float rw = 1.0f / (float)w;
     const int bw = c == 0 ? a.bw[0] : c == 1 ? a.bw[1] : c == 2 ? a.bw[2] : a.bw[3];
     const int64_t coff = c == 0 ? a.coef_off[0] : c == 1 ? a.coef_off[1] : c == 2 ? a.coef_off[2] : a.coef_off[3];
@@ -2801,11 +2814,12 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
     const int *__restrict__ q = a.q[c];
     const char *__restrict__ first = reinterpret_cast<const char *>(coef + coff) + (int64_t)(pick4(by0, c) * bw + pick4(bx0, c)) * 128;
     u32x4 rows[8];
-    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+    auto chunkptr = [&](int m) -> const u32x4 * {
       const int n = min(b0 + (lane >> 3) + 8 * m, nblk - 1);
       const int y = div_recip(n, rw), x = mad24(y, -w, n);
       return reinterpret_cast<const u32x4 *>(first + (((unsigned)mad24(y, bw, x) << 7) | ((unsigned)(lane & 7) << 4)));
-    });
+    };
+    fetch_blocks(rows, stage, lane, chunkptr);
     const int blk = b0 + lane;
     if (blk < nblk) {
       int v[64];
@@ -2831,7 +2845,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
       if (c < a.ncomp && a.subx[c] > 1) {
-        const int pitch = nbx[c] * 8 + TILE_PAD, last = a.cw[c] - bx0[c] * 8 - 1; // last column of the image, plane-relative
+        const int pitch = ppitch[c], last = a.cw[c] - bx0[c] * 8 - 1; // last column of the image, plane-relative
         for (int r = tid; r < nby[c] * 8; r += 256) {
           T *line = planes + base[c] + r * pitch;
           if (bx0[c] == 0) line[-1] = line[0];
@@ -2848,8 +2862,20 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
   const int groups = (px1 - px0 + 8) >> 3, lines = py1 - py0 + 1;
   const int sb = a.sample_bytes;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
-  const bool aligned = (((uintptr_t)a.out | (uintptr_t)a.out_frame_stride | (uintptr_t)a.row_stride) & 7) == 0;
   const float rgroups = 1.0f / (float)groups;
+  TileComp comp[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    const int sx = c < a.ncomp ? a.subx[c] : 1, sy = c < a.ncomp ? a.suby[c] : 1;
+    comp[c].sx = sx; comp[c].sy = sy;
+    comp[c].rx = 65536 / sx + 1; comp[c].ry = 65536 / sy + 1;
+    comp[c].pitch = ppitch[c];
+    comp[c].lines = min(a.ch[c] - by0[c] * 8, nby[c] * 8);
+    comp[c].base = base[c];
+    comp[c].xoff = bx0[c] * 8 * sx; comp[c].yoff = by0[c] * 8 * sy;
+    comp[c].sh = sy == 4 ? 3 : 2;
+    comp[c].vt = tile_vphases(sy);
+  }
   // one instance per component count: the loops over components and the sample packing have static shapes
   auto phase_b = [&](auto NCc) {
     constexpr int NC = decltype(NCc)::value;
@@ -2858,11 +2884,7 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
       const int X0 = px0 + 8 * g, Y = py0 + ly;
       int s[NC][8];
 #pragma unroll
-      for (int c = 0; c < NC; c++) {
-        const int sx = a.subx[c], sy = a.suby[c], xo = bx0[c] * 8, yo = by0[c] * 8;
-        // plane coordinates: (0, 0) is sample (xo, yo) of the component; the image's last line moves with it
-        tile_plane_line<FAST, T>(planes + base[c], nbx[c] * 8 + TILE_PAD, min(a.ch[c] - yo, nby[c] * 8), sx, sy, X0 - xo * sx, Y - yo * sy, s[c]);
-      }
+      for (int c = 0; c < NC; c++) tile_plane_line<FAST, T>(planes, comp[c], X0, Y, s[c]);
       // the group's samples as the dwords of the output line: 2 NC of them (8-bit samples) or 4 NC (16-bit samples)
       unsigned w[4 * NC];
       if (sb == 1) {
@@ -2933,8 +2955,8 @@ __global__ __launch_bounds__(256) void fused_tile_kernel(const GenericArgs a)
       }
       uint8_t *dst = out_frame + (int64_t)Y * a.row_stride + (int64_t)X0 * (NC * sb);
       const int npx = min(8, a.width - X0);
-      if (aligned && npx == 8) { // 8 * NC * sb bytes = a whole number of 8-byte pieces
-        u32x2 *d2 = reinterpret_cast<u32x2 *>(dst);
+      if (npx == 8) { // 8 * NC * sb bytes = a whole number of 8-byte pieces (at any address: u32x2_any)
+        u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
         if (sb == 1) {
 #pragma unroll
           for (int k = 0; k < NC; k++) d2[k] = u32x2{w[2 * k], w[2 * k + 1]};
@@ -3291,23 +3313,39 @@ static size_t fused_tile_geometry(GenericArgs &a, bool narrow)
   int hmax = 1, vmax = 1;
   for (int c = 0; c < a.ncomp; c++) { hmax = max(hmax, a.subx[c]); vmax = max(vmax, a.suby[c]); }
   const int mw = 8 * hmax, mh = 8 * vmax;
-  const int want_w[3] = {hmax > 1 ? 128 : 64, 64, 32}, want_h[2] = {64, 32};
+  static const int env_w = getenv("MIJPEG_TILE_W") ? atoi(getenv("MIJPEG_TILE_W")) : 0, env_h = getenv("MIJPEG_TILE_H") ? atoi(getenv("MIJPEG_TILE_H")) : 0; // A-B measurements
+  // a subsampled direction pays a block row / column of halo on each side of the tile: twice the extent there halves its share
+  // (1x4 frames: 327 -> 479 Gpixel/s with 128 lines instead of 64)
+  const int want_w[3] = {env_w ? env_w : hmax > 1 ? 128 : 64, 64, 32};
+  int want_h[4] = {env_h ? env_h : vmax > 1 ? 128 : 64, 64, 48, 32};
+  if (want_h[0] == 64) { want_h[1] = 48; want_h[2] = 32; want_h[3] = 16; }
+  auto plane_bytes = [&](int tw, int th) {
+    size_t samples = 0;
+    for (int c = 0; c < a.ncomp; c++) {
+      // (a tile of whole MCUs starts on a block boundary of every component; the halo sample on each side costs one more block)
+      const int wx = tw / (8 * a.subx[c]) + (a.subx[c] > 1 ? 2 : 0), wy = th / (8 * a.suby[c]) + (a.suby[c] > 1 ? 2 : 0);
+      samples += (size_t)wy * 8 * (wx * 8 + TILE_PAD) + TILE_PAD;
+    }
+    return samples * (narrow ? 2 : 4);
+  };
+  // LDS per workgroup: 64 KB at most (two workgroups per CU); a tile that needs more than 160 / 3 KB gives way to the next
+  // smaller one if that has at least three quarters of its lines and fits three times (12-bit 4:4:4: 64 x 48 pixels, 244 -> 270
+  // Gpixel/s).  (Halving the fetch staging instead was measured: the second fetch routine alone, never called, cost every
+  // layout 3 to 8 %.)
+  const size_t two = 64 * 1024, three = (160 * 1024 / 3) & ~(size_t)255, staging = 4 * 128 * 16;
   for (int iw = 0; iw < 3; iw++)
-    for (int ih = 0; ih < 2; ih++) {
-      a.tile_w = mw * max(1, want_w[iw] / mw);
-      a.tile_h = mh * max(1, want_h[ih] / mh);
-      size_t samples = 0;
-      for (int c = 0; c < a.ncomp; c++) {
-        // (a tile of whole MCUs starts on a block boundary of every component; the halo sample on each side costs one more block)
-        const int wx = a.tile_w / (8 * a.subx[c]) + (a.subx[c] > 1 ? 2 : 0), wy = a.tile_h / (8 * a.suby[c]) + (a.suby[c] > 1 ? 2 : 0);
-        samples += (size_t)wy * 8 * (wx * 8 + TILE_PAD) + TILE_PAD;
+    for (int ih = 0; ih < 4; ih++) {
+      const int tw = mw * max(1, want_w[iw] / mw);
+      int th = mh * max(1, want_h[ih] / mh);
+      if (plane_bytes(tw, th) + staging > two) continue;
+      if (plane_bytes(tw, th) + staging > three && ih + 1 < 4 && !env_h) {
+        const int th2 = mh * max(1, want_h[ih + 1] / mh);
+        if (th2 * 4 >= th * 3 && plane_bytes(tw, th2) + staging <= three) th = th2;
       }
-      const size_t lds = 4 * 128 * 16 + samples * (narrow ? 2 : 4);
-      if (lds <= 64 * 1024) { // (a 52 KB budget -- three workgroups per CU -- halves the tile of 12-bit 4:4:4 frames: 164 -> 121 Gpixel/s)
-        a.tiles_x = (a.width + a.tile_w - 1) / a.tile_w;
-        a.tiles_y = (a.height + a.tile_h - 1) / a.tile_h;
-        return lds;
-      }
+      a.tile_w = tw; a.tile_h = th;
+      a.tiles_x = (a.width + a.tile_w - 1) / a.tile_w;
+      a.tiles_y = (a.height + a.tile_h - 1) / a.tile_h;
+      return plane_bytes(tw, th) + staging;
     }
   return 0;
 }

@@ -22,7 +22,6 @@ struct Fused420Args {
   int32_t bw_y, bh_y, bw_c, bh_c; // coefficient plane sizes in blocks (MCU padded)
   int32_t cw, ch;                 // valid chroma samples: ceil(W/2), ceil(H/2)
   int32_t tiles_x, tiles_y, frames;
-  int32_t aligned8;               // out, strides all multiples of 8 bytes -> 8-byte stores
   int32_t q[3][64];               // deltas << 4 per component (Y, Cb, Cr), natural order (idct.cpp:98-109)
   const int32_t *qdev;            // or null: per-frame tables in device memory, [frames][4][64] deltas << 4 (replace q)
 };
@@ -34,7 +33,6 @@ struct FusedXtExtra {
   int32_t rq[3][64];          // residual deltas << 4
   const int32_t *ltable;      // device: [3][256]
   int32_t rtrafo_ycbcr, is_float, out_max, out_shift;
-  int32_t aligned16;          // out, strides multiples of 16 bytes
   int32_t rprecision;         // residual precision incl. hidden bits: 12 -> fusedxt420_kernel (int16 residual coefficients);
                               // 13..16 -> fusedxtw420_kernel (int32 coefficients, two int16 slots each; bw_r in blocks of 256 bytes)
 };

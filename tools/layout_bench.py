@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from libjpeg_amd import api, synth  # noqa: E402
 
-W, H, F = 7680, 4320, 8
+W, H, F = int(os.environ.get("W", "7680")), int(os.environ.get("H", "4320")), 8  # W=7678: lines that start at any byte address
 hip = C.cdll.LoadLibrary("libamdhip64.so")
 HEADER_EDITS = {"3x1": ((3, 1, 1), (1, 1, 1)), "1x4": ((1, 1, 1), (4, 1, 1)), "lumasub": ((1, 2, 2), (1, 2, 2)), "3x3": ((3, 1, 1), (3, 1, 1))}
 
