@@ -657,9 +657,9 @@ static int evaluate_entropy_status(mijpeg_decoder *d, HostDecoder *const *hosts,
 }
 
 // Second-level tables of a device Huffman table: every code longer than the direct table's ten bits, grouped by its first
-// ten bits, in a 64-entry table indexed by the six bits that follow (entry = (length << 8) | symbol [| HUFF_DEV_INVALID], as
-// in the direct table).  Codes whose prefix finds no table left keep the direct entry 0: the kernels walk the canonical
-// arrays for those.
+// ten bits, in a 64-entry table indexed by the six bits that follow (entries as in the direct table: huff_dev_entry).  Codes
+// whose prefix finds no table left keep the direct entry HUFF_DEV_SUB | HUFF_DEV_NO_SUB: the kernels walk the canonical arrays
+// for those.
 static void fill_second_level(HuffDevTable &dst, const HuffTable &h, bool ac)
 {
   int prefix_of[HUFF_DEV_SUBTABLES], used = 0;
@@ -676,9 +676,7 @@ static void fill_second_level(HuffDevTable &dst, const HuffTable &h, bool ac)
         prefix_of[used++] = prefix;
         dst.fast[prefix] = (uint16_t)(HUFF_DEV_SUB | t);
       }
-      const uint32_t sym = h.values[k];
-      uint16_t e = (uint16_t)(((uint32_t)l << 8) | sym);
-      if (ac && (sym & 15) == 0 && sym != 0 && sym != 0xf0) e |= HUFF_DEV_INVALID;
+      const uint16_t e = (uint16_t)huff_dev_entry(l, h.values[k], ac);
       const int first = (code & ((1 << rest) - 1)) << (6 - rest);
       for (int j = 0; j < (1 << (6 - rest)); j++) dst.sub[t][first + j] = e;
     }
@@ -900,10 +898,11 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
       for (int t = 0; t < 2; t++) {
         HuffDevTable &dst = tabs[tab_slot[k][t]];
         memset(&dst, 0, sizeof(dst));
-        memcpy(dst.fast, src[t]->fast, sizeof(dst.fast));
-        if (t == 1) // AC: flag the symbols that only exist in progressive scans (EOB runs)
-          for (auto &e : dst.fast)
-            if (e && (e & 15) == 0 && (e & 0xff) != 0 && (e & 0xff) != 0xf0) e |= HUFF_DEV_INVALID;
+        // the host's direct table ((length << 8) | symbol, 0 = a longer code or none) in the device's entry format
+        for (int x = 0; x < (1 << HUFF_DEV_LOOKAHEAD); x++) {
+          const uint16_t he = src[t]->fast[x];
+          dst.fast[x] = he ? (uint16_t)huff_dev_entry(he >> 8, he & 0xffu, t == 1) : (uint16_t)(HUFF_DEV_SUB | HUFF_DEV_NO_SUB);
+        }
         static const bool no_sub = getenv("MIJPEG_HUFF_NO_SUBTABLES") != nullptr; // A-B measurements: long codes walk the canonical arrays
         if (!no_sub) fill_second_level(dst, *src[t], t == 1);
         memcpy(dst.maxcode, src[t]->maxcode, sizeof(dst.maxcode));

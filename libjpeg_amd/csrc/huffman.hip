@@ -63,7 +63,8 @@ struct DevBits {
   uint32_t fill;       // stream bytes committed to the ring so far
   uint32_t lim;
   uint32_t d;          // stream dword in B0
-  uint32_t B0, B1, B2;
+  uint32_t B0, B1;     // stream dwords d, d + 1 (big-endian: bit 31 first)
+  uint32_t R2;         // dword d + 2 as the ring holds it (bytes not swapped yet: nothing waits for this load before the next symbol)
   uint32_t win;
 
   __device__ __forceinline__ u32x4 fetch(uint32_t at) const { return *reinterpret_cast<const u32x4 *>(base + at); }
@@ -76,14 +77,12 @@ struct DevBits {
   }
   // a chunk may go in when it does not overwrite the dword the window starts in (slow() loads from there on)
   __device__ __forceinline__ bool room() const { return (int)(fill - ((bp >> 5) << 2)) <= RING - 16; }
-  __device__ __forceinline__ uint32_t ld(uint32_t dword) const
-  {
-    return __builtin_bswap32(*reinterpret_cast<const uint32_t *>(ring + ((dword << 2) & (RING - 1))));
-  }
+  __device__ __forceinline__ uint32_t ld_raw(uint32_t dword) const { return *reinterpret_cast<const uint32_t *>(ring + ((dword << 2) & (RING - 1))); }
+  __device__ __forceinline__ uint32_t ld(uint32_t dword) const { return __builtin_bswap32(ld_raw(dword)); }
   __device__ __forceinline__ void idle() // a lane that does not decode: never touches a ring (its would alias a decoding lane's)
   {
     bp = endbit = fill = lim = d = 0;
-    B0 = B1 = B2 = win = 0;
+    B0 = B1 = R2 = win = 0;
   }
   __device__ __forceinline__ void open(const uint8_t *stream, uint8_t *lds_ring, uint32_t begin, uint32_t stop, uint32_t skip_bits = 0)
   {
@@ -100,18 +99,17 @@ struct DevBits {
     d = bp >> 5;
     B0 = ld(d);
     B1 = ld(d + 1);
-    B2 = ld(d + 2);
+    R2 = ld_raw(d + 2);
     win = 0;
   }
   __device__ __forceinline__ void refill()
   {
     if (__builtin_expect(bp + 32u > lim, 0)) { slow(); return; }
     const uint32_t nd = bp >> 5;
-    const uint32_t nx = ld(nd + 2);
     const bool adv = nd != d;
     B0 = adv ? B1 : B0;
-    B1 = adv ? B2 : B1;
-    B2 = nx;
+    B1 = adv ? __builtin_bswap32(R2) : B1; // (read when the window stood one dword earlier)
+    R2 = ld_raw(nd + 2);
     d = nd;
     win = (uint32_t)(((((uint64_t)B0) << 32 | B1) << (bp & 31u)) >> 32);
   }
@@ -121,7 +119,7 @@ struct DevBits {
     while ((nd + 3u) * 4u > fill) commit(fetch(fill)); // a block that outran the prefetch (rare)
     B0 = ld(nd);
     B1 = ld(nd + 1);
-    B2 = ld(nd + 2);
+    R2 = ld_raw(nd + 2);
     d = nd;
     uint32_t w = (uint32_t)(((((uint64_t)B0) << 32 | B1) << (bp & 31u)) >> 32);
     const int avail = (int)(endbit - bp); // bits of the interval that are left; zero bits behind them
@@ -132,9 +130,9 @@ struct DevBits {
   __device__ __forceinline__ void skip(int k) { bp += (uint32_t)k; }
 };
 
-// Huffman code at the top of the 32-bit window -> (length << 8) | symbol, 0 if no code matches.  For AC tables bit 15
-// flags the symbols that do not exist in sequential scans (s == 0 with a run other than 0 and 15, :747-750); the host
-// sets it in the direct table, the fallback for long codes sets it here.
+// Huffman code at the top of the 32-bit window -> (tot << 8) | symbol, tot = code length + value bits that follow (what the
+// reader moves on by), or HUFF_DEV_INVALID: no code matches, a DC symbol beyond 15, an AC symbol that does not exist in
+// sequential scans (s == 0 with a run other than 0 and 15, :747-750).
 // a + b, saturating at 2^32 - 1 (one full-rate instruction)
 __device__ __forceinline__ uint32_t add_sat_u32(uint32_t a, uint32_t b)
 {
@@ -146,16 +144,19 @@ __device__ __forceinline__ uint32_t add_sat_u32(uint32_t a, uint32_t b)
 template <bool AC> __device__ __forceinline__ uint32_t dev_lookup(uint32_t win, const HuffDevTable *h)
 {
   uint32_t e = h->fast[win >> (32 - HUFF_DEV_LOOKAHEAD)];
-  if (e & HUFF_DEV_SUB) e = h->sub[e & (HUFF_DEV_SUBTABLES - 1)][(win >> (32 - HUFF_DEV_LOOKAHEAD - 6)) & 63u]; // a code of 11..16 bits
-  if (__builtin_expect(e == 0, 0)) {
-    const int code16 = (int)(win >> 16);
-    for (int l = HUFF_DEV_LOOKAHEAD + 1; l <= 16; l++) {
-      const int code = code16 >> (16 - l);
-      if (code <= h->maxcode[l]) {
-        const uint32_t sym = h->values[(code + h->valoff[l]) & 0xff];
-        e = ((uint32_t)l << 8) | sym;
-        if (AC && (sym & 15) == 0 && sym != 0 && sym != 0xf0) e |= HUFF_DEV_INVALID;
-        break;
+  if (__builtin_expect((e & HUFF_DEV_SUB) != 0, 0)) { // a code of 11..16 bits (or none at all): ONE rarely taken branch per symbol
+    const uint32_t t = e & 15u;
+    e = t < (uint32_t)HUFF_DEV_SUBTABLES ? h->sub[t][(win >> (32 - HUFF_DEV_LOOKAHEAD - 6)) & 63u] : 0u;
+    if (e == 0) { // a prefix beyond the second-level tables: canonical walk
+      e = HUFF_DEV_INVALID;
+      const int code16 = (int)(win >> 16);
+      for (int l = HUFF_DEV_LOOKAHEAD + 1; l <= 16; l++) {
+        const int code = code16 >> (16 - l);
+        if (code <= h->maxcode[l]) {
+          const uint32_t sym = h->values[(code + h->valoff[l]) & 0xff];
+          e = huff_dev_entry(l, sym, AC);
+          break;
+        }
       }
     }
   }
@@ -182,8 +183,8 @@ __device__ __forceinline__ int dev_block(DevBits &br, const HuffDevTable *dc, co
   br.refill();
   uint32_t win = br.window();
   uint32_t e = dev_lookup<false>(win, dc);
-  int s = (int)(e & 0xff), tot = (int)(e >> 8) + s;
-  if (e == 0 || s > 15) return HUFF_ERR_MALFORMED; // ":686 DC coefficient decoding out of sync"
+  int s = (int)(e & 0xff), tot = (int)((e >> 8) & 31u);
+  if (e & HUFF_DEV_INVALID) return HUFF_ERR_MALFORMED; // ":686 DC coefficient decoding out of sync"
   pred += dev_value(win, tot, s);
   br.skip(tot);
   if (pred != (int16_t)pred) return HUFF_ERR_OVERFLOW;
@@ -194,26 +195,26 @@ __device__ __forceinline__ int dev_block(DevBits &br, const HuffDevTable *dc, co
   // range check sum |c| q: both factors fit 16 bits (24-bit multiply), the sum saturates -- the host cuts at 2^31 - 1 like its
   // own decoder does (evaluate_entropy_status), and anything beyond that has saturated or is beyond it for good
   uint32_t qsum = __umul24((uint32_t)abs(pred), zq[0] >> 16);
-  int kk = 1;
+  const uint32_t *zqm1 = zq - 1;
+  int kk = 1; // scan position the next symbol's run starts from
   bool bad = false;
   for (;;) {
     const int rs = (int)(e & 0xff);
     s = rs & 15;
-    tot = (int)((e >> 8) & 31u) + s;
+    tot = (int)((e >> 8) & 31u);
     const int val = dev_value(win, tot, s);
     br.skip(tot);
-    kk += rs >> 4;
+    kk += (rs >> 4) + 1; // one behind the position of this coefficient
     // no code / a symbol of progressive scans only (:747-750) / ":763 AC coefficient decoding out of sync"
-    bad |= (e - 1u >= (uint32_t)HUFF_DEV_INVALID - 1u) | ((s != 0) & (kk > 63));
-    const bool last = (rs == 0) | bad | (kk >= 63); // EOB, error, or position 63 reached (by a coefficient or a ZRL)
+    bad |= (e >= (uint32_t)HUFF_DEV_INVALID) | ((s != 0) & (kk > 64));
+    const bool last = (rs == 0) | bad | (kk >= 64); // EOB, error, or position 63 reached (by a coefficient or a ZRL)
     br.refill();
     win = br.window();
-    const uint32_t z = zq[kk]; // kk <= 63 + 15, the table is padded; in flight together with the lookup below
+    const uint32_t z = zqm1[kk]; // position <= 63 + 15, the table is padded; in flight together with the lookup below
     e = dev_lookup<true>(win, ac);
     *reinterpret_cast<int16_t *>(slot + ((z & 0xffffu) ^ (uint32_t)swz16)) = (int16_t)val;
     qsum = add_sat_u32(qsum, __umul24((uint32_t)abs(val), z >> 16));
     if (last) break;
-    kk++;
   }
   qmax = max(qmax, qsum);
   return bad ? HUFF_ERR_MALFORMED : 0;
@@ -364,8 +365,8 @@ __device__ __forceinline__ int dev_walk_block(DevBits &br, const HuffDevTable *d
   br.refill();
   uint32_t win = br.window();
   uint32_t e = dev_lookup<false>(win, dc);
-  int s = (int)(e & 0xff), tot = (int)(e >> 8) + s;
-  if (e == 0 || s > 15) return 1;
+  int s = (int)(e & 0xff), tot = (int)((e >> 8) & 31u);
+  if (e & HUFF_DEV_INVALID) return 1;
   dcdiff = dev_value(win, tot, s);
   br.skip(tot);
   int kk = 1;
@@ -376,12 +377,11 @@ __device__ __forceinline__ int dev_walk_block(DevBits &br, const HuffDevTable *d
     e = dev_lookup<true>(win, ac);
     const int rs = (int)(e & 0xff);
     s = rs & 15;
-    tot = (int)((e >> 8) & 31u) + s;
+    tot = (int)((e >> 8) & 31u);
     br.skip(tot);
-    kk += rs >> 4;
-    bad |= (e - 1u >= (uint32_t)HUFF_DEV_INVALID - 1u) | ((s != 0) & (kk > 63));
-    if ((rs == 0) | bad | (kk >= 63)) break;
-    kk++;
+    kk += (rs >> 4) + 1;
+    bad |= (e >= (uint32_t)HUFF_DEV_INVALID) | ((s != 0) & (kk > 64));
+    if ((rs == 0) | bad | (kk >= 64)) break;
   }
   return bad ? 1 : 0;
 }

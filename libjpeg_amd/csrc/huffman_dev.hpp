@@ -14,12 +14,26 @@ constexpr int HUFF_DEV_SUB = 0x4000;     // direct-table flag: a longer code; th
 constexpr int HUFF_DEV_SUBTABLES = 8;    // second-level tables per Huffman table (Annex K tables need five)
 constexpr int HUFF_STREAM_PAD = 256; // bytes the device copy of the stream is padded with (the readers prefetch ahead)
 
-// One Huffman table in device form: direct lookup for codes up to 10 bits ((length << 8) | symbol [| HUFF_DEV_INVALID
-// in AC tables]); longer codes: HUFF_DEV_SUB | t sends the lookup to second-level table t, indexed by the next six bits
-// (same entry format) -- canonical codes longer than ten bits share very few ten-bit prefixes (all ones but the tail: five
-// in the Annex K tables), and with 64 lanes per wave SOME lane meets a long code in every other symbol step, so what the
-// wave pays for them is what it pays per step; 0 = a prefix beyond the second-level tables (pathological code lengths):
-// canonical max-code / value-offset walk (same layout as HuffTable in host_decoder.hpp).
+// One Huffman table in device form: direct lookup for codes up to 10 bits, entry = (tot << 8) | symbol with tot = code length
+// + value bits behind the code -- what the reader moves on by: 31 at most -- or HUFF_DEV_INVALID: an AC symbol that does not
+// exist in sequential scans, a DC symbol beyond 15.  Longer codes: HUFF_DEV_SUB | t sends the lookup to second-level table t,
+// indexed by the next six bits (same entry format) -- canonical codes longer than ten bits share very few ten-bit prefixes
+// (all ones but the tail: five in the Annex K tables), and with 64 lanes per wave SOME lane meets a long code in every other
+// symbol step, so what the wave pays for them is what it pays per step; t = HUFF_DEV_NO_SUB (and ten-bit prefixes of no code
+// at all): canonical max-code / value-offset walk (same layout as HuffTable in host_decoder.hpp).
+constexpr int HUFF_DEV_NO_SUB = 15;
+// entry of a code of `length` bits for `symbol` (host: table upload; device: the canonical walk)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t huff_dev_entry(int length, uint32_t symbol, bool ac)
+{
+  const uint32_t s = ac ? (symbol & 15u) : symbol;
+  if (s > 15u) return (uint32_t)HUFF_DEV_INVALID;
+  uint32_t e = ((uint32_t)(length + (int)s) << 8) | symbol;
+  if (ac && s == 0 && symbol != 0 && symbol != 0xf0) e |= (uint32_t)HUFF_DEV_INVALID;
+  return e;
+}
 struct HuffDevTable {
   uint16_t fast[1 << HUFF_DEV_LOOKAHEAD];
   uint16_t sub[HUFF_DEV_SUBTABLES][64];
