@@ -1718,7 +1718,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     a.tiles_y = (f.height + 127) / 128;
     a.frames = b->frames;
     for (int c = 0; c < 3; c++)
-      for (int i = 0; i < 64; i++) a.q[c][i] = (int32_t)f.quant[f.quant_index[c]][i] << 4;
+      fill_deltas(a.q[c], f.quant[f.quant_index[c]]);
     a.qdev = qdev;
     if (fxt) {
       const mijpeg_xt_params &x = *b->xt;
@@ -1773,7 +1773,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       a.cw[p] = (g.width + g.subx[c] - 1) / g.subx[c];
       a.ch[p] = (g.height + g.suby[c] - 1) / g.suby[c];
       a.dcoff[p] = (1 << (precision - 1)) << 7;
-      for (int i = 0; i < 64; i++) a.q[p][i] = (int32_t)g.quant[g.quant_index[c]][i] << 4;
+      fill_deltas(a.q[p], g.quant[g.quant_index[c]]);
     };
     // JPEG XT frames reconstruct at their precision plus the bits that travelled in hidden refinement scans
     // (Frame::HiddenPrecisionOf, marker/frame.cpp:368-373)

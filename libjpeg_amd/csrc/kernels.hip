@@ -272,6 +272,84 @@ __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *
     idct_1d<FAST, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
 }
 
+// The same with the FIRST pass in 16-bit arithmetic (FAST, 8-bit frames: the range check bounds sum |c| delta of a block by
+// 16384, so every dequantised coefficient -- without the << 4 the reference's deltas carry -- and the level shift 1024 on top
+// of the DC term fit 16 bits).  Before its rounding shift the pass is a product of the eight inputs with a matrix of integers
+// (sums of the butterfly's 9-bit constants, |entry| <= 710): written out as v_dot2_i32_i16 inner products over the pairs
+// (s0,s4) (s2,s6) for the even half and (s1,s5) (s3,s7) for the odd half, the accumulator of one feeding the next --
+// exact, the ring Z / 2^32 is distributive -- and the factor 16 that left the deltas taken out of the rounding:
+// (16 x + 256) >> 9 = (x + 16) >> 5.  v_perm_b32 pairs the coefficients as the products want them, v_pk_mul_lo_u16
+// dequantises two at a time with the packed deltas behind q[64] (fill_deltas): 38 issue slots per row where
+// dequantisation + butterfly took 52; with columns 4..7 zero 28 for 35.  The second pass sees 18-bit values and stays.
+__device__ __forceinline__ unsigned pk_mul_lo16(unsigned a, unsigned q)
+{
+  unsigned d;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(q));
+  return d;
+}
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b)
+{
+  unsigned d;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b));
+  return d;
+}
+#define PK16(lo, hi) ((int)(((unsigned)(lo) & 0xffffu) | ((unsigned)(hi) << 16)))
+__device__ __forceinline__ int sdot2(unsigned pk, int k, int c)
+{
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pk), __builtin_bit_cast(s16x2, k), c, false);
+}
+template <int NR, int NC>
+__device__ __forceinline__ void dequant_idct16(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff)
+{
+  constexpr int C0541 = FIX9(0.541196100), C0765 = FIX9(0.765366865), C1847 = FIX9(1.847759065), C1175 = FIX9(1.175875602),
+                C1961 = FIX9(1.961570560), C0390 = FIX9(0.390180644), C0899 = FIX9(0.899976223), C0298 = FIX9(0.298631336),
+                C2562 = FIX9(2.562915447), C2053 = FIX9(2.053119869), C3072 = FIX9(3.072711026), C1501 = FIX9(1.501321110);
+  const unsigned *__restrict__ qp = reinterpret_cast<const unsigned *>(q + QROW_PACKED);
+  const unsigned dc16 = (unsigned)(dcoff >> 4) & 0xffffu; // the level shift, added to the DC term (low half of the first pair of row 0)
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    int t10, t11, t12, t13, o0, o1, o2, o3;
+    if (NC == 8) {
+      // pairs (c0,c4) (c1,c5) (c2,c6) (c3,c7) from the row's dwords (c0,c1) (c2,c3) (c4,c5) (c6,c7)
+      unsigned s04 = pk_mul_lo16(__builtin_amdgcn_perm(rows[k].z, rows[k].x, 0x05040100u), qp[k * 4 + 0]);
+      const unsigned s15 = pk_mul_lo16(__builtin_amdgcn_perm(rows[k].z, rows[k].x, 0x07060302u), qp[k * 4 + 1]);
+      const unsigned s26 = pk_mul_lo16(__builtin_amdgcn_perm(rows[k].w, rows[k].y, 0x05040100u), qp[k * 4 + 2]);
+      const unsigned s37 = pk_mul_lo16(__builtin_amdgcn_perm(rows[k].w, rows[k].y, 0x07060302u), qp[k * 4 + 3]);
+      if (k == 0) s04 = pk_add16(s04, dc16);
+      const int A = sdot2(s04, PK16(512, 512), 16), B = sdot2(s04, PK16(512, -512), 16); // (s0 +- s4) << 9, rounding inside
+      t10 = sdot2(s26, PK16(C0541 + C0765, C0541), A);
+      t13 = sdot2(s26, PK16(-(C0541 + C0765), -C0541), A);
+      t11 = sdot2(s26, PK16(C0541, C0541 - C1847), B);
+      t12 = sdot2(s26, PK16(-C0541, C1847 - C0541), B);
+      o0 = sdot2(s37, PK16(C1175 - C1961, -C0899 + C0298 + C1175 - C1961), sdot2(s15, PK16(-C0899 + C1175, C1175), 0));
+      o1 = sdot2(s37, PK16(-C2562 + C1175, C1175), sdot2(s15, PK16(C1175 - C0390, -C2562 + C2053 + C1175 - C0390), 0));
+      o2 = sdot2(s37, PK16(-C2562 + C3072 + C1175 - C1961, C1175 - C1961), sdot2(s15, PK16(C1175, -C2562 + C1175), 0));
+      o3 = sdot2(s37, PK16(C1175, -C0899 + C1175), sdot2(s15, PK16(-C0899 + C1501 + C1175 - C0390, C1175 - C0390), 0));
+    } else {
+      // columns 4..7 are zero: pairs (c0,c2) (c1,c3)
+      unsigned s02 = pk_mul_lo16(__builtin_amdgcn_perm(rows[k].y, rows[k].x, 0x05040100u), qp[32 + k * 2 + 0]);
+      const unsigned s13 = pk_mul_lo16(__builtin_amdgcn_perm(rows[k].y, rows[k].x, 0x07060302u), qp[32 + k * 2 + 1]);
+      if (k == 0) s02 = pk_add16(s02, dc16);
+      t10 = sdot2(s02, PK16(512, C0541 + C0765), 16);
+      t13 = sdot2(s02, PK16(512, -(C0541 + C0765)), 16);
+      t11 = sdot2(s02, PK16(512, C0541), 16);
+      t12 = sdot2(s02, PK16(512, -C0541), 16);
+      o0 = sdot2(s13, PK16(-C0899 + C1175, C1175 - C1961), 0);
+      o1 = sdot2(s13, PK16(C1175 - C0390, -C2562 + C1175), 0);
+      o2 = sdot2(s13, PK16(C1175, -C2562 + C3072 + C1175 - C1961), 0);
+      o3 = sdot2(s13, PK16(-C0899 + C1501 + C1175 - C0390, C1175), 0);
+    }
+    v[k * 8 + 0] = (t10 + o3) >> 5; v[k * 8 + 7] = (t10 - o3) >> 5;
+    v[k * 8 + 1] = (t11 + o2) >> 5; v[k * 8 + 6] = (t11 - o2) >> 5;
+    v[k * 8 + 2] = (t12 + o1) >> 5; v[k * 8 + 5] = (t12 - o1) >> 5;
+    v[k * 8 + 3] = (t13 + o0) >> 5; v[k * 8 + 4] = (t13 - o0) >> 5;
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    idct_1d<true, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+}
+
 // True if coefficient rows 4..7 (the upper half of the vertical frequencies) are zero in every block the wave holds:
 // the usual case for chroma and for smooth luma.  Wave-uniform, so the caller branches without divergence.
 __device__ __forceinline__ bool rows_4_to_7_zero(const u32x4 (&rows)[8])
@@ -291,9 +369,18 @@ __device__ __forceinline__ bool cols_4_to_7_zero(const u32x4 (&rows)[8])
   return __builtin_amdgcn_ballot_w64(o != 0) == 0;
 }
 
-// dequant_idct<true> with the pruned paths where the data allow it
+// dequant_idct<true> with the pruned paths where the data allow it.  PK16ROW: q is a row of the kernel's argument block (the
+// packed deltas follow the 64) and the frame has 8-bit samples -- the first pass runs in 16 bits (dequant_idct16).
+template <bool PK16ROW = false>
 __device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff = 0)
 {
+  if (PK16ROW) {
+    if (rows_4_to_7_zero(rows)) {
+      if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff); // (the pruned butterfly is as short as the products)
+      else dequant_idct16<4, 8>(rows, q, v, dcoff);
+    } else dequant_idct16<8, 8>(rows, q, v, dcoff);
+    return;
+  }
   if (rows_4_to_7_zero(rows)) {
     if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff);
     else dequant_idct<true, 4, 8>(rows, q, v, dcoff);
@@ -482,7 +569,7 @@ __device__ __forceinline__ const int *frame_deltas(const Args &a, int frame, int
 }
 
 // phase A of the 4:2:0 kernels with 32-bit chroma samples: the (8+2) x (8+2) chroma blocks of tile (tx, ty) -> LDS
-template <bool FAST, bool QDEV = false>
+template <bool FAST, bool QDEV = false, bool PK = false>
 __device__ __forceinline__ void f420_chroma_to_lds(const Fused420Args &a, const int16_t *__restrict__ coef, int (*cplane)[F420_CROWS * F420_CPITCH],
                                                    u32x4 *stage, int lane, int wave, int tx, int ty, int frame = 0)
 {
@@ -517,7 +604,7 @@ __device__ __forceinline__ void f420_chroma_to_lds(const Fused420Args &a, const 
   if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
     int v[64];
     const int *q = frame_deltas<QDEV>(a, frame, 1 + comp);
-    if (FAST) dequant_idct_sparse(rows, q, v);
+    if (FAST) dequant_idct_sparse<PK>(rows, q, v);
     else dequant_idct<false>(rows, q, v, 128 << 7);
     int *cp = cplane[comp];
 #pragma unroll
@@ -596,7 +683,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
-  f420_chroma_to_lds<FAST, QDEV>(a, coef, cplane, stage, lane, wave, tx, ty, frame);
+  f420_chroma_to_lds<FAST, QDEV, !QDEV && P == 8>(a, coef, cplane, stage, lane, wave, tx, ty, frame);
   __syncthreads();
   f420_chroma_edges(a, cplane, tid, tx, ty);
 
@@ -619,7 +706,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  if (FAST) dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  if (FAST) dequant_idct_sparse<!QDEV && P == 8>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
   else dequant_idct<false>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 128 << 7);
 
   // uniform frame base + 32-bit lane offsets (a frame of pixels is far below 4 GB)
@@ -848,7 +935,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     const int gx = gx0 + cbx, gy = gy0 + cby;
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
       int v[64];
-      dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
+      dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
       short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
 #pragma unroll
       for (int r = 0; r < 8; r++) {
@@ -913,7 +1000,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1037,7 +1124,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
       const int cbx = lane & 7, cby = lane >> 3;
       if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
         int v[64];
-        dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
+        dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           short *dst = cp + 2 * ((8 * ((wave & 1) * 8 + cby) + r) * F420_CPITCH + 8 * cbx + 4);
@@ -1096,7 +1183,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1229,7 +1316,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
       const int cbx = lane & 3, cby = lane >> 2;
       if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
         int v[64];
-        dequant_idct_sparse(rows, qc, v);
+        dequant_idct_sparse<!QDEV>(rows, qc, v);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           short *dst = cp + 2 * ((8 * cby + r) * F411_CPITCH + 8 * cbx + 4);
@@ -1287,7 +1374,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1388,7 +1475,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
       const int cbx = lane & 7, cby = lane >> 3;
       if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
         int v[64];
-        dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
+        dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           short *dst = cp + 2 * ((8 * cby + r + 1) * F440_CPITCH + 8 * ((wave & 1) * 8 + cbx));
@@ -1413,7 +1500,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
 #pragma unroll
         for (int i = 0; i < 8; i++) qrow[i] = qk[i];
       } else {
-        kernarg_int *qk = (kernarg_int *)__builtin_amdgcn_kernarg_segment_ptr() + (offsetof(Fused420Args, q) / sizeof(int) + (1 + comp) * 64 + k * 8);
+        kernarg_int *qk = (kernarg_int *)__builtin_amdgcn_kernarg_segment_ptr() + (offsetof(Fused420Args, q) / sizeof(int) + (1 + comp) * QROW + k * 8);
 #pragma unroll
         for (int i = 0; i < 8; i++) qrow[i] = qk[i];
       }
@@ -1468,7 +1555,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -2023,12 +2110,12 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     u32x4 rows[8];
     int v[64];
     fetch(rows, a.off_cb);
-    dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 1), v);
+    dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 1), v);
 #pragma unroll
     for (int i = 0; i < 32; i++) cbp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
     __builtin_amdgcn_sched_barrier(0); // keep the next component's loads from being hoisted above this transform (register pressure)
     fetch(rows, a.off_cr);
-    dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 2), v);
+    dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 2), v);
 #pragma unroll
     for (int i = 0; i < 32; i++) crp[i] = pack_lo16_now(v[2 * i + 1], v[2 * i]);
     __builtin_amdgcn_sched_barrier(0);
@@ -2039,7 +2126,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     fetch(rows, a.off_y);
     const int X0 = gbx * 8, Y0 = gby * 8;
     if (X0 >= a.width || Y0 >= a.height) return;
-    dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+    dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
   }
   const int X0 = gbx * 8, Y0 = gby * 8;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -2130,7 +2217,7 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return;
   int v[64];
-  dequant_idct_sparse(rows, frame_deltas<QDEV>(a, frame, 0), v);
+  dequant_idct_sparse<!QDEV && P == 8>(rows, frame_deltas<QDEV>(a, frame, 0), v);
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * (P == 12 ? 2u : 1u);
   const int npx = min(8, a.width - X0);
@@ -2823,7 +2910,7 @@ __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const Generi
     const int blk = b0 + lane;
     if (blk < nblk) {
       int v[64];
-      if (FAST) dequant_idct_sparse(rows, q, v, dcoff);
+      if (FAST) dequant_idct_sparse<NARROW>(rows, q, v, dcoff);
       else dequant_idct<false>(rows, q, v, dcoff);
       const int y = div_recip(blk, rw), x = mad24(y, -w, blk);
       T *dst = planes + pick4(base, c) + (y * 8) * pitch + x * 8;

@@ -9,6 +9,20 @@ namespace mij {
 
 constexpr int MAXC = 4;
 
+// A component's dequantisation operands as the kernels take them: 64 deltas << 4 (natural order, dct/idct.cpp:98-109) and,
+// behind them, the same deltas (not shifted) packed in pairs of 16 bits for the transforms' first pass in 16-bit arithmetic
+// (dequant_idct16 in kernels.hip): per coefficient row k the pairs (0,4) (1,5) (2,6) (3,7), then for rows 0..3 the pairs
+// (0,2) (1,3) of the pruned pass.
+constexpr int QROW_PACKED = 64, QROW = 64 + 32 + 8;
+inline void fill_deltas(int32_t (&dst)[QROW], const uint16_t *delta)
+{
+  for (int i = 0; i < 64; i++) dst[i] = (int32_t)delta[i] << 4;
+  for (int k = 0; k < 8; k++)
+    for (int j = 0; j < 4; j++) dst[QROW_PACKED + k * 4 + j] = (int32_t)((uint32_t)delta[k * 8 + j] | ((uint32_t)delta[k * 8 + j + 4] << 16));
+  for (int k = 0; k < 4; k++)
+    for (int j = 0; j < 2; j++) dst[QROW_PACKED + 32 + k * 2 + j] = (int32_t)((uint32_t)delta[k * 8 + j] | ((uint32_t)delta[k * 8 + j + 2] << 16));
+}
+
 // fused 4:2:0 (Y 1x1, Cb/Cr 2x2 subsampled).  Passed by value: the quantiser tables travel in the
 // kernarg segment and are read with scalar loads.
 struct Fused420Args {
@@ -22,7 +36,7 @@ struct Fused420Args {
   int32_t bw_y, bh_y, bw_c, bh_c; // coefficient plane sizes in blocks (MCU padded)
   int32_t cw, ch;                 // valid chroma samples: ceil(W/2), ceil(H/2)
   int32_t tiles_x, tiles_y, frames;
-  int32_t q[3][64];               // deltas << 4 per component (Y, Cb, Cr), natural order (idct.cpp:98-109)
+  int32_t q[3][QROW];             // per component (Y, Cb, Cr): fill_deltas
   const int32_t *qdev;            // or null: per-frame tables in device memory, [frames][4][64] deltas << 4 (replace q)
 };
 
@@ -57,7 +71,7 @@ struct GenericArgs {
   int32_t width, height, ncomp, ycbcr, frames, nplanes;
   int32_t bw[MAXP], bh[MAXP], cw[MAXP], ch[MAXP], subx[MAXP], suby[MAXP];
   int32_t dcoff[MAXP];         // level shift of the plane's transform: 2^(P-1) << 7 (dct/idct.cpp:231)
-  int32_t q[MAXP][64];         // deltas << 4
+  int32_t q[MAXP][QROW];       // fill_deltas
   // output stage
   int32_t sample_bytes;        // 1: 8-bit samples, 2: 16-bit samples
   int32_t maxval;              // 2^P - 1: clamp of the integer output

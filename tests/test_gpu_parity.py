@@ -498,6 +498,19 @@ def test_extreme_coefficients_at_the_packed_chroma_gate(dec, oracle, sub, chroma
     """The packed flavours are admitted by sum |c| q < 2047 per chroma block, the int16 sample store of the 4:2:2 / 4:4:0 /
     4:4:4 kernels by < 8190.  Blocks that sit right at those bounds with every sign pattern (DC-only, single AC, dense) drive
     the 16-bit filter sums / the 16-bit samples to their limits; the result must still be the reference's."""
+    _extreme_coefficients(dec, oracle, sub, 8000, chroma_budget, kernel)
+
+
+@pytest.mark.parametrize("sub,chroma_budget,kernel", [("420", 2046, "fused420p_kernel"), ("420", 8189, "fused420_kernel"), ("444", 8189, "fused444_kernel"),
+                                                      ("422", 2046, "fused422_kernel"), ("440", 8189, "fused440_kernel<wide>"), ("411", 8189, "fused411_kernel")])
+def test_extreme_coefficients_at_the_16bit_first_pass(dec, oracle, sub, chroma_budget, kernel):
+    """The first transform pass of the fast 8-bit kernels runs on 16-bit dequantised coefficients (dequant_idct16): admitted by
+    the range check sum |c| q < 16384 per block.  Luma blocks at 16383 -- the DC term alone (level shift on top), one AC
+    coefficient of either sign, dense blocks that add up to it -- must come out as the reference's."""
+    _extreme_coefficients(dec, oracle, sub, 16383, chroma_budget, kernel)
+
+
+def _extreme_coefficients(dec, oracle, sub, luma_budget, chroma_budget, kernel):
     torch = _torch()
     d = api.Decoder(0)
     if sub in ("440", "411"):
@@ -519,7 +532,7 @@ def test_extreme_coefficients_at_the_packed_chroma_gate(dec, oracle, sub, chroma
         p = np.zeros(shape, np.int32)
         kind = rng.integers(0, 4, size=shape[:2])
         sign = rng.choice([-1, 1], size=shape[:2])
-        budget = chroma_budget if c else 8000
+        budget = chroma_budget if c else luma_budget
         p[..., 0] = np.where(kind == 0, sign * (budget // 2), 0)  # DC alone: q[0] = 2
         k = rng.integers(1, 64, size=shape[:2])
         for by in range(shape[0]):
