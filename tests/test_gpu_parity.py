@@ -434,23 +434,28 @@ def test_frames_beyond_32_bit_offsets_take_the_generic_kernels(oracle, sub):
     d.close()
 
 
-@pytest.mark.parametrize("sub", ["420", "444"])
+@pytest.mark.parametrize("sub", ["420", "444", "422", "gray"])
 def test_unaligned_output_stride(oracle, sub):
-    """Packed rows whose stride is not a multiple of 8 bytes (131 * 3 = 393) take the byte-store path of the fused
-    kernels; a padded destination must not be written outside the picture."""
+    """Bitmaps whose lines start at any byte address (row strides 393 = 131 * 3, 395, 400, 401; base addresses + 0, 1, 3, 6):
+    the kernels store every full 8-pixel group as dwordx2 / dwordx4 wherever it lies (gfx950 does; rounds 1-2 fell to byte
+    stores unless everything was 8-byte aligned); a padded destination must not be written outside the picture."""
     torch = _torch()
     d = api.Decoder(0)
-    data = synth.synth_jpeg(131, 77, 9, 85, sub, 0)
+    nc = 1 if sub == "gray" else 3
+    data = synth.encode_jpeg(synth.synth_image(131, 77, 9, channels=nc), 85, "444" if sub == "gray" else sub)
     f = d.read(data)
-    coef = torch.from_numpy(np.concatenate([d.coefficients(c).reshape(-1) for c in range(3)])).cuda()
+    coef = torch.from_numpy(np.concatenate([d.coefficients(c).reshape(-1) for c in range(nc)])).cuda()
     d.close()
-    for row in (393, 400):
-        out = torch.full((77, row), 0xAB, dtype=torch.uint8, device="cuda")
-        api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, row, 77 * row, stream=torch.cuda.current_stream().cuda_stream)
+    exp = oracle.decode(data).reshape(77, 131 * nc)
+    line = 131 * nc
+    for row, base in ((line, 0), (line, 1), (line + 2, 3), (line + 7, 6), (line + 8, 0), (line + 8, 1)):
+        buf = torch.full((77 * row + 16,), 0xAB, dtype=torch.uint8, device="cuda")
+        api.launch_reconstruct(f, coef.data_ptr(), buf.data_ptr() + base, 1, row, 77 * row, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        res = out.cpu().numpy()
-        assert np.array_equal(res[:, :393].reshape(77, 131, 3), oracle.decode(data)), f"row stride {row}"
-        assert (res[:, 393:] == 0xAB).all()
+        flat = buf.cpu().numpy()
+        res = flat[base:base + 77 * row].reshape(77, row)
+        assert np.array_equal(res[:, :line], exp), f"row stride {row}, base + {base}"
+        assert (res[:, line:] == 0xAB).all() and (flat[:base] == 0xAB).all() and (flat[base + 77 * row:] == 0xAB).all()
 
 
 @pytest.mark.parametrize("generic", [False, True])
