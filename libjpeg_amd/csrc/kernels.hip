@@ -1670,7 +1670,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift; // the merge subtracts it anyway
-  f420_chroma_to_lds<true>(a, coef, cplane, stage, lane, wave, tx, ty);
+  f420_chroma_to_lds<true, false, true>(a, coef, cplane, stage, lane, wave, tx, ty); // (the legacy frame passed the 16384 range check: use_fusedxt)
   __syncthreads();
   f420_chroma_edges(a, cplane, tid, tx, ty);
 
@@ -1710,7 +1710,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   // ------------------------------------------------------------------ legacy luma
   fetch_plane(coef + a.off_y, a.bw_y, a.bh_y);
   int yv[64];
-  dequant_idct_sparse(rows, a.q[0], yv);
+  dequant_idct_sparse<true>(rows, a.q[0], yv);
 
   const bool active = X0 < a.width && Y0 < a.height;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -1884,7 +1884,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift;
-  f420_chroma_to_lds<true>(a, coef, cplane, stage, lane, wave, tx, ty);
+  f420_chroma_to_lds<true, false, true>(a, coef, cplane, stage, lane, wave, tx, ty); // (the legacy frame passed the 16384 range check: use_fusedxt)
   __syncthreads();
   f420_chroma_edges(a, cplane, tid, tx, ty);
 
@@ -1951,7 +1951,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
     });
   }
   int yv[64];
-  dequant_idct_sparse(rows, a.q[0], yv);
+  dequant_idct_sparse<true>(rows, a.q[0], yv);
 
   const bool active = X0 < a.width && Y0 < a.height;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
