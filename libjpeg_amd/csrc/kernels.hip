@@ -159,11 +159,12 @@ __device__ __forceinline__ int round_shift(int x)
 // becomes mad(tz1, -c9, mad(ttmp0, c5, z3)); the rounding constant is folded into the even part.
 // NZ = 4 (FAST only): s4..s7 are known to be zero and are not read; every term they feed is dropped and constants that
 // multiply the same input are added up (still exact: the ring Z / 2^32 is distributive), 31 slots instead of 44.
+// R: what the even part starts from -- the rounding constant 2^(SHIFT-1), plus whatever multiple of 2^SHIFT the caller wants
+// added to every output for free (FAST flavours only; LUMA_FOLD_R below).
 template <bool FAST, int SHIFT, int NZ = 8>
-__device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int &s4, int &s5, int &s6, int &s7)
+__device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int &s4, int &s5, int &s6, int &s7, const int R = 1 << (SHIFT - 1))
 {
   if (FAST && NZ == 4) {
-    const int R = 1 << (SHIFT - 1);
     // even part (7): tmp2 = z1, tmp3 = s2 * (c0.541 + c0.765)
     const int t0 = (s0 << 9) + R;
     const int tmp2 = __mul24(s2, FIX9(0.541196100));
@@ -184,7 +185,6 @@ __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int 
     return;
   }
   if (FAST) {
-    const int R = 1 << (SHIFT - 1);
     // even part (12)
     const int t0 = ((s0 + s4) << 9) + R;
     const int t1 = ((s0 - s4) << 9) + R;
@@ -245,8 +245,13 @@ __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int 
 // NR = 4 (FAST only): coefficient rows 4..7 are known to be zero (see rows_4_to_7_zero): they are neither dequantised nor
 // transformed, and the second pass runs the pruned butterfly.
 // NC = 4 (with NR = 4): coefficient columns 4..7 are zero too; the first pass is pruned the same way.
+// Luma of the fast 8-bit YCbCr kernels: the colour stage wants y * 8192 + (2048 << 13) + 65536 = (y + 2048 + 8) << 13 -- level
+// shift and the rounding of its >> 17 -- and a multiple of 4096 added in front of the second pass's >> 12 comes out as that
+// multiple / 4096 on every sample, exactly: the two constants ride in the pass's rounding constant and the colour stage is left
+// with the shift.
+constexpr int LUMA_FOLD_R = 2048 + ((2048 + 8) << 12);
 template <bool FAST, int NR = 8, int NC = 8>
-__device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff)
+__device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff, const int colr = 2048)
 {
 #pragma unroll
   for (int k = 0; k < NR; k++) {
@@ -269,7 +274,7 @@ __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *
                          v[r * 8 + 6], v[r * 8 + 7]);
 #pragma unroll
   for (int c = 0; c < 8; c++)
-    idct_1d<FAST, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+    idct_1d<FAST, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], colr);
 }
 
 // The same with the FIRST pass in 16-bit arithmetic (FAST, 8-bit frames: the range check bounds sum |c| delta of a block by
@@ -300,7 +305,7 @@ __device__ __forceinline__ int sdot2(unsigned pk, int k, int c)
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pk), __builtin_bit_cast(s16x2, k), c, false);
 }
 template <int NR, int NC>
-__device__ __forceinline__ void dequant_idct16(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff)
+__device__ __forceinline__ void dequant_idct16(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff, const int colr = 2048)
 {
   constexpr int C0541 = FIX9(0.541196100), C0765 = FIX9(0.765366865), C1847 = FIX9(1.847759065), C1175 = FIX9(1.175875602),
                 C1961 = FIX9(1.961570560), C0390 = FIX9(0.390180644), C0899 = FIX9(0.899976223), C0298 = FIX9(0.298631336),
@@ -347,7 +352,7 @@ __device__ __forceinline__ void dequant_idct16(const u32x4 (&rows)[8], const int
   }
 #pragma unroll
   for (int c = 0; c < 8; c++)
-    idct_1d<true, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+    idct_1d<true, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], colr);
 }
 
 // True if coefficient rows 4..7 (the upper half of the vertical frequencies) are zero in every block the wave holds:
@@ -372,19 +377,19 @@ __device__ __forceinline__ bool cols_4_to_7_zero(const u32x4 (&rows)[8])
 // dequant_idct<true> with the pruned paths where the data allow it.  PK16ROW: q is a row of the kernel's argument block (the
 // packed deltas follow the 64) and the frame has 8-bit samples -- the first pass runs in 16 bits (dequant_idct16).
 template <bool PK16ROW = false>
-__device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff = 0)
+__device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff = 0, const int colr = 2048)
 {
   if (PK16ROW) {
     if (rows_4_to_7_zero(rows)) {
-      if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff); // (the pruned butterfly is as short as the products)
-      else dequant_idct16<4, 8>(rows, q, v, dcoff);
-    } else dequant_idct16<8, 8>(rows, q, v, dcoff);
+      if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff, colr); // (the pruned butterfly is as short as the products)
+      else dequant_idct16<4, 8>(rows, q, v, dcoff, colr);
+    } else dequant_idct16<8, 8>(rows, q, v, dcoff, colr);
     return;
   }
   if (rows_4_to_7_zero(rows)) {
-    if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff);
-    else dequant_idct<true, 4, 8>(rows, q, v, dcoff);
-  } else dequant_idct<true, 8, 8>(rows, q, v, dcoff);
+    if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff, colr);
+    else dequant_idct<true, 4, 8>(rows, q, v, dcoff, colr);
+  } else dequant_idct<true, 8, 8>(rows, q, v, dcoff, colr);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  if (FAST) dequant_idct_sparse<!QDEV && P == 8>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  if (FAST) dequant_idct_sparse<!QDEV && P == 8>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, P == 8 ? LUMA_FOLD_R : 2048);
   else dequant_idct<false>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 128 << 7);
 
   // uniform frame base + 32-bit lane offsets (a frame of pixels is far below 4 GB)
@@ -804,11 +809,10 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
           // y, cb, cr arrive WITHOUT the level shift (DCOFF = false): with y = y' + 2048 and cb - 2048 = cb' the
           // reference's (y * 8192 + (cb - 2048) * Lb + (cr - 2048) * Lr + 65536) >> 17 becomes
           // (y' * 8192 + K + cb' * Lb + cr' * Lr) >> 17 with one constant K for all three channels
-          const int K = (2048 << 13) + 65536;
           int rr[8], gg[8], bb[8];
 #pragma unroll
           for (int x = 0; x < 8; x++) {
-            const int yk = (yv[l * 8 + x] << 13) + K;
+            const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
             rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
             gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
             bb[x] = mad24(ub[x], L_CB_B, yk);
@@ -1000,7 +1004,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1016,7 +1020,6 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   unsigned cT[6], cC[6], cB[6];
   load6(c_base, cT);
   load6(c_base + F420_CPITCH, cC);
-  const int K = (2048 << 13) + 65536;
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     load6(c_base + (m + 2) * F420_CPITCH, cB);
@@ -1042,7 +1045,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
         int rr[8], gg[8], bb[8];
 #pragma unroll
         for (int x = 0; x < 8; x++) {
-          const int yk = (yv[l * 8 + x] << 13) + K;
+          const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
           rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
           bb[x] = mad16_lo(u[x], L_CB_B, yk);
           gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
@@ -1183,7 +1186,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1196,7 +1199,6 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
     const u32x4 mid = *reinterpret_cast<const u32x4 *>(p + 4);
     d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
   };
-  const int K = (2048 << 13) + 65536;
 #pragma unroll
   for (int l = 0; l < 8; l++) {
     {
@@ -1231,7 +1233,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
         int rr[8], gg[8], bb[8];
 #pragma unroll
         for (int x = 0; x < 8; x++) {
-          const int yk = (yv[l * 8 + x] << 13) + K;
+          const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
           if (WIDE) {
             rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
             bb[x] = mad24(ub[x], L_CB_B, yk);
@@ -1374,7 +1376,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1383,7 +1385,6 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
   const bool fast_store = npx == 8;
   // chroma window of this block: lines 8 by + l, columns x_rel = 2 bx - 1 .. 2 bx + 2, i.e. pc = 2 bx + 3 .. 2 bx + 6
   const unsigned *c_base = cpair + (8 * by) * F411_CPITCH + 2 * bx + 3;
-  const int K = (2048 << 13) + 65536;
 #pragma unroll
   for (int l = 0; l < 8; l++) {
     const unsigned *p = c_base + l * F411_CPITCH;
@@ -1403,7 +1404,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
       int rr[8], gg[8], bb[8];
 #pragma unroll
       for (int x = 0; x < 8; x++) {
-        const int yk = (yv[l * 8 + x] << 13) + K;
+        const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
         rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
         bb[x] = mad24(ub[x], L_CB_B, yk);
         gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
@@ -1555,7 +1556,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1571,7 +1572,6 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
   unsigned cT[8], cC[8], cB[8];
   load8(c_base, cT);
   load8(c_base + F440_CPITCH, cC);
-  const int K = (2048 << 13) + 65536;
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     load8(c_base + (m + 2) * F440_CPITCH, cB);
@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
         int rr[8], gg[8], bb[8];
 #pragma unroll
         for (int x = 0; x < 8; x++) {
-          const int yk = (yv[l * 8 + x] << 13) + K;
+          const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
           if (WIDE) {
             rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
             bb[x] = mad24(ub[x], L_CB_B, yk);
@@ -1710,7 +1710,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   // ------------------------------------------------------------------ legacy luma
   fetch_plane(coef + a.off_y, a.bw_y, a.bh_y);
   int yv[64];
-  dequant_idct_sparse<true>(rows, a.q[0], yv);
+  dequant_idct_sparse<true>(rows, a.q[0], yv, 0, LUMA_FOLD_R);
 
   const bool active = X0 < a.width && Y0 < a.height;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -1760,11 +1760,10 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
       hfilt(vb, ub);
       hfilt(vr, ur);
       int mm[24]; // legacy + residual - output shift, R G B of the eight pixels
-      const int K = (2048 << 13) + 65536; // level shifts of the FAST transforms + rounding, see fused420_kernel
 #pragma unroll
       for (int xx = 0; xx < 8; xx++) {
         // legacy chain: L transformation, clamp to 8 bits, L table (output shift already subtracted)
-        const int yk = (yv[l * 8 + xx] << 13) + K;
+        const int yk = yv[l * 8 + xx] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
         const int lr = clamp255(mad24(ur[xx], L_CR_R, yk) >> 17);
         const int lg = clamp255(mad24(ur[xx], -L_CR_G, mad24(ub[xx], -L_CB_G, yk)) >> 17);
         const int lb = clamp255(mad24(ub[xx], L_CB_B, yk) >> 17);
@@ -1951,7 +1950,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
     });
   }
   int yv[64];
-  dequant_idct_sparse<true>(rows, a.q[0], yv);
+  dequant_idct_sparse<true>(rows, a.q[0], yv, 0, LUMA_FOLD_R);
 
   const bool active = X0 < a.width && Y0 < a.height;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -2001,10 +2000,9 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
       hfilt(vb, ub);
       hfilt(vr, ur);
       int mm[24];
-      const int K = (2048 << 13) + 65536;
 #pragma unroll
       for (int xx = 0; xx < 8; xx++) {
-        const int yk = (yv[l * 8 + xx] << 13) + K;
+        const int yk = yv[l * 8 + xx] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
         const int lr = clamp255(mad24(ur[xx], L_CR_R, yk) >> 17);
         const int lg = clamp255(mad24(ur[xx], -L_CR_G, mad24(ub[xx], -L_CB_G, yk)) >> 17);
         const int lb = clamp255(mad24(ub[xx], L_CB_B, yk) >> 17);
@@ -2126,7 +2124,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     fetch(rows, a.off_y);
     const int X0 = gbx * 8, Y0 = gby * 8;
     if (X0 >= a.width || Y0 >= a.height) return;
-    dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+    dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
   }
   const int X0 = gbx * 8, Y0 = gby * 8;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -2134,14 +2132,13 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
   const int npx = min(8, a.width - X0);
   const int nln = min(8, a.height - Y0);
   const bool fast_store = npx == 8;
-  const int K = (2048 << 13) + 65536;
 #pragma unroll
   for (int l = 0; l < 8; l++) {
     if (l < nln) {
       int rr[8], gg[8], bb[8];
 #pragma unroll
       for (int x = 0; x < 8; x++) {
-        const int yk = (yv[l * 8 + x] << 13) + K;
+        const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
         const unsigned cb2 = cbp[(l * 8 + x) >> 1], cr2 = crp[(l * 8 + x) >> 1];
         if (x & 1) {
           rr[x] = mad16_hi(cr2, L_CR_R, yk);
