@@ -76,6 +76,26 @@ def cpu_baseline(jpeg_bytes, width, height):
                 sample=f"5 in-memory decodes of one {width}x{height} 4:2:0 frame by oracle/liboracle.so, median {best * 1e3:.0f} ms")
 
 
+def drop_in_client(binary, jpeg_bytes, reps):
+    """tools/cxx/stripe_loop.cpp: a C++ client of class JPEG decodes the frame from memory with ONE DisplayRectangle request and
+    with the eight-line stripe loop of cmd/reconstruct.cpp (bitmap in host memory).  `binary` is that source linked with
+    libmijpeg.so (libjpeg_amd/bin/stripe_loop) or with the reference library (oracle/_ref/stripe_loop_ref, cpu_baseline only)."""
+    import re
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        src = os.path.join(d, "in.jpg")
+        with open(src, "wb") as f:
+            f.write(jpeg_bytes)
+        out = subprocess.run([binary, src, str(reps)], check=True, capture_output=True, text=True, timeout=300).stdout
+    m = re.search(r"Read ([0-9.]+) ms; whole frame in one request ([0-9.]+) ms.*stripe loop ([0-9.]+) ms.*first stripe ([0-9.]+) ms after Read.*\((equal|DIFFERENT)\)", out)
+    if not m:
+        return {"error": out[-300:]}
+    return {"read_ms": float(m.group(1)), "whole_frame_request_ms": float(m.group(2)), "stripe_loop_ms": float(m.group(3)),
+            "first_stripe_after_read_ms": float(m.group(4)), "both_ways_same_pixels": m.group(5) == "equal", "repetitions": reps,
+            "note": "bytes in host memory -> Construct + Read + DisplayRectangle(s) + Destruct -> interleaved RGB in host memory, best of the "
+                    "repetitions; stripe loop = 8 lines per request, the hook reports BIO_HEIGHT = miny + 8 (cmd/reconstruct.cpp, cmd/bitmaphook.cpp)"}
+
+
 def cpu_baseline_all_cores(streams, width, height):
     """The reference on ALL host cores: `nproc` concurrent whole-process decodes of distinct frames (one process per core;
     the reference is single-threaded), aggregate Mpixels/s.  Output goes to /dev/null (writing the PPMs of hundreds of
@@ -756,6 +776,13 @@ def main():
                                 "note": "one frame, PCIe and host inclusive: bytes -> host Huffman (restart-interval parallel) -> "
                                         "pinned H2D (streamed) -> kernel -> D2H -> copy into the caller's interleaved bitmap"}
     if rank == 0 and world == 1 and not args.no_end_to_end:
+        # the drop-in boundary from a client's seat: class JPEG through its hooks, one request and the reference CLI's stripe loop
+        client = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjpeg_amd", "bin", "stripe_loop")
+        try:
+            result["end_to_end"]["drop_in_client"] = drop_in_client(client, jpegs[0], 6) if os.path.exists(client) else {"skipped": "libjpeg_amd/bin/stripe_loop is not built"}
+        except Exception as e:  # noqa: BLE001 -- a side measurement never costs the headline number
+            result["end_to_end"]["drop_in_client"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_end_to_end:
         # the same, pipelined over a batch of frames (config 4's end-to-end shape): two decoder objects / streams
         from libjpeg_amd import pipeline
 
@@ -918,6 +945,9 @@ def main():
             result["cpu_baseline"] = cpu_baseline(jpegs[0], W, H)
             if isinstance(result.get("batch4k"), dict) and result["batch4k"].get("cpu_baseline"):
                 result["cpu_baseline"]["all_cores"] = result["batch4k"]["cpu_baseline"]
+            ref_client = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "stripe_loop_ref")
+            if os.path.exists(ref_client):  # the reference library under the same client as end_to_end.drop_in_client (one core)
+                result["cpu_baseline"]["drop_in_client"] = drop_in_client(ref_client, jpegs[0], 2)
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     dec.close()

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <new>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -124,6 +125,59 @@ static int hip_fail(mijpeg_decoder *d, hipError_t e, const char *what)
     if (e_ != hipSuccess) return hip_fail(d, e_, #call);  \
   } while (0)
 
+// The large buffers of destroyed decoder objects -- pinned coefficient store and frame, their device mirrors -- wait here for
+// the next object on the same device: a client that constructs a JPEG object per picture (cmd/reconstruct.cpp does) would
+// otherwise pin ~200 MB of pages per 8K picture, 17 ms of the 24 ms such a decode took from Construct to Destruct.  At most
+// four buffers per kind and 2 GiB in all are kept; a request takes the smallest buffer that fits and is at most twice as large.
+namespace {
+struct BufferCache {
+  struct Entry { void *p; size_t bytes; int device; bool pinned; };
+  std::mutex m;
+  std::vector<Entry> kept;
+  void *take(int device, bool pinned, size_t bytes, size_t *got)
+  {
+    std::lock_guard<std::mutex> lock(m);
+    int best = -1;
+    for (int i = 0; i < (int)kept.size(); i++)
+      if (kept[(size_t)i].device == device && kept[(size_t)i].pinned == pinned && kept[(size_t)i].bytes >= bytes && kept[(size_t)i].bytes <= 2 * bytes &&
+          (best < 0 || kept[(size_t)i].bytes < kept[(size_t)best].bytes))
+        best = i;
+    if (best < 0) return nullptr;
+    void *p = kept[(size_t)best].p;
+    *got = kept[(size_t)best].bytes;
+    kept.erase(kept.begin() + best);
+    return p;
+  }
+  // false: not kept, the caller frees it
+  bool give(int device, bool pinned, void *p, size_t bytes)
+  {
+    static const bool off = getenv("MIJPEG_NO_BUFFER_CACHE") != nullptr; // A-B measurements
+    if (off || bytes < ((size_t)1 << 20)) return false;
+    std::lock_guard<std::mutex> lock(m);
+    size_t total = bytes, same = 0;
+    for (const Entry &e : kept) {
+      total += e.bytes;
+      same += e.device == device && e.pinned == pinned;
+    }
+    if (same >= 4 || total > ((size_t)2 << 30)) return false;
+    kept.push_back(Entry{p, bytes, device, pinned});
+    return true;
+  }
+};
+BufferCache &buffer_cache()
+{
+  static BufferCache *c = new BufferCache; // (never destroyed: the HIP runtime may be gone when static destructors run)
+  return *c;
+}
+} // namespace
+static void release_big(int device, bool pinned, void *p, size_t bytes)
+{
+  if (!p) return;
+  if (buffer_cache().give(device, pinned, p, bytes)) return;
+  if (pinned) (void)hipHostFree(p);
+  else (void)hipFree(p);
+}
+
 // A batch that was submitted (mijpeg_submit_batch_device) and not waited for still reads the pinned staging buffers
 // (ent_host, stage_host, status words) from its asynchronous uploads: every entry point that rewrites them settles it first.
 static int settle_pending(mijpeg_decoder *d)
@@ -171,10 +225,11 @@ void mijpeg_destroy(mijpeg_decoder *d)
   if (d->device >= 0) {
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
-    if (d->coef_host) (void)hipHostFree(d->coef_host);
-    if (d->img_host) (void)hipHostFree(d->img_host);
-    if (d->coef_dev) (void)hipFree(d->coef_dev);
-    if (d->img_dev) (void)hipFree(d->img_dev);
+    if (d->copy_stream) (void)hipStreamSynchronize(d->copy_stream); // (the buffers below may go to another object)
+    release_big(d->device, true, d->coef_host, d->coef_host_cap * sizeof(int16_t));
+    release_big(d->device, true, d->img_host, d->img_host_cap);
+    release_big(d->device, false, d->coef_dev, d->coef_dev_cap * sizeof(int16_t));
+    release_big(d->device, false, d->img_dev, d->img_dev_cap);
     if (d->ws_dev) (void)hipFree(d->ws_dev);
     if (d->batch_quant_dev) (void)hipFree(d->batch_quant_dev);
     if (d->ent_dev) (void)hipFree(d->ent_dev);
@@ -230,24 +285,35 @@ static int ensure_dev(mijpeg_decoder *d, void **ptr, size_t *cap, size_t bytes);
 static int ensure_coef_store(mijpeg_decoder *d, size_t count, bool need_host = true)
 {
   if (need_host && d->coef_host_cap < count) {
+    size_t cap = count;
     if (d->device >= 0) {
-      if (d->coef_host) (void)hipHostFree(d->coef_host);
+      release_big(d->device, true, d->coef_host, d->coef_host_cap * sizeof(int16_t));
       d->coef_host = nullptr;
       d->coef_host_cap = 0;
-      HIP_TRY(d, hipHostMalloc((void **)&d->coef_host, count * sizeof(int16_t), hipHostMallocDefault));
+      size_t got = 0;
+      if (void *p = buffer_cache().take(d->device, true, count * sizeof(int16_t), &got)) {
+        d->coef_host = (int16_t *)p;
+        cap = got / sizeof(int16_t);
+      } else HIP_TRY(d, hipHostMalloc((void **)&d->coef_host, count * sizeof(int16_t), hipHostMallocDefault));
     } else {
       free(d->coef_host);
       d->coef_host = (int16_t *)malloc(count * sizeof(int16_t));
       if (!d->coef_host) return set_error(d, MIJPEG_ERR_OUT_OF_MEMORY, "out of memory for the coefficient store");
     }
-    d->coef_host_cap = count;
+    d->coef_host_cap = cap;
   }
   if (d->device >= 0 && d->coef_dev_cap < count) {
-    if (d->coef_dev) (void)hipFree(d->coef_dev);
+    release_big(d->device, false, d->coef_dev, d->coef_dev_cap * sizeof(int16_t));
     d->coef_dev = nullptr;
     d->coef_dev_cap = 0;
-    HIP_TRY(d, hipMalloc((void **)&d->coef_dev, count * sizeof(int16_t)));
-    d->coef_dev_cap = count;
+    size_t got = 0;
+    if (void *p = buffer_cache().take(d->device, false, count * sizeof(int16_t), &got)) {
+      d->coef_dev = (int16_t *)p;
+      d->coef_dev_cap = got / sizeof(int16_t);
+    } else {
+      HIP_TRY(d, hipMalloc((void **)&d->coef_dev, count * sizeof(int16_t)));
+      d->coef_dev_cap = count;
+    }
   }
   return MIJPEG_OK;
 }
@@ -2285,9 +2351,15 @@ int mijpeg_encode_image_ex(mijpeg_decoder *d, const uint8_t *pixels, int32_t wid
 static int ensure_dev(mijpeg_decoder *d, void **ptr, size_t *cap, size_t bytes)
 {
   if (*cap >= bytes) return MIJPEG_OK;
-  if (*ptr) (void)hipFree(*ptr);
+  release_big(d->device, false, *ptr, *cap);
   *ptr = nullptr;
   *cap = 0;
+  size_t got = 0;
+  if (void *p = buffer_cache().take(d->device, false, bytes, &got)) {
+    *ptr = p;
+    *cap = got;
+    return MIJPEG_OK;
+  }
   HIP_TRY(d, hipMalloc(ptr, bytes));
   *cap = bytes;
   return MIJPEG_OK;
@@ -2473,11 +2545,17 @@ static int serve_rect(mijpeg_decoder *d, int view, uint32_t flags, bool to_devic
   if (!to_device && !d->img_host_valid) {
     HIP_TRY(d, hipSetDevice(d->device));
     if (d->img_host_cap < padded) {
-      if (d->img_host) (void)hipHostFree(d->img_host);
+      release_big(d->device, true, d->img_host, d->img_host_cap);
       d->img_host = nullptr;
       d->img_host_cap = 0;
-      HIP_TRY(d, hipHostMalloc((void **)&d->img_host, padded, hipHostMallocDefault));
-      d->img_host_cap = padded;
+      size_t got = 0;
+      if (void *p = buffer_cache().take(d->device, true, padded, &got)) {
+        d->img_host = (uint8_t *)p;
+        d->img_host_cap = got;
+      } else {
+        HIP_TRY(d, hipHostMalloc((void **)&d->img_host, padded, hipHostMallocDefault));
+        d->img_host_cap = padded;
+      }
     }
     // bands of about 4 MiB (at least 8 lines): enqueue all of them now, wait for them as they are asked for
     static const long band_mib = getenv("MIJPEG_RECT_BAND_MIB") ? atol(getenv("MIJPEG_RECT_BAND_MIB")) : 4; // tuning; <= 0: one band
