@@ -439,3 +439,41 @@ def test_prepare_batch_host_is_the_host_half_of_a_batch_submit():
     with pytest.raises(api.MijpegError):
         d.prepare_batch_host([streams[0], b"\xff\xd8 not a jpeg at all"])
     d.close()
+
+
+def test_pipelined_scans_leave_the_same_coefficient_store():
+    """Progressive frames and JPEG XT frames with hidden refinement scans: the scans without restart intervals run side by side,
+    a scan trailing the one it refines by an MCU row, and a residual frame decodes while the calling thread takes the legacy
+    frame.  The whole coefficient store (legacy and residual planes) must be what scan after scan, frame after frame leaves
+    (MIJPEG_NO_SCAN_PIPELINE / MIJPEG_NO_FRAME_OVERLAP, read once per process: two child processes), at 1, 4 and 16 threads."""
+    import glob
+    import subprocess
+    import sys
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "tests", "golden", "*.jpg")) if "prog" in os.path.basename(f) or "xt_" in os.path.basename(f))
+    assert len(files) >= 20
+    code = r"""
+import sys, ctypes as C, hashlib
+sys.path.insert(0, %r)
+from libjpeg_amd import api
+L = api.lib()
+L.mijpeg_coefficients.restype = C.c_void_p
+for path in sys.argv[1:]:
+    data = open(path, "rb").read()
+    for thr in (1, 4, 16):
+        d = api.Decoder(None)
+        f = d.read(data, thr)
+        base = L.mijpeg_coefficients(d._h, 0) - int(f.coef_offset[0]) * 2
+        n = int(f.coef_count) * (4 if f.coef_wide else 2)
+        print(path, thr, hashlib.sha256(bytes((C.c_uint8 * n).from_address(base))).hexdigest(), list(f.range_max)[:f.components])
+        d.close()
+""" % ROOT
+    outs = []
+    for extra in ({}, {"MIJPEG_NO_SCAN_PIPELINE": "1", "MIJPEG_NO_FRAME_OVERLAP": "1"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code] + files, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.splitlines())
+    assert len(outs[0]) == 3 * len(files) and outs[0] == outs[1]
+    # ... and the thread count changes nothing either
+    for i in range(0, len(outs[0]), 3):
+        assert len({" ".join(ln.split()[2:]) for ln in outs[0][i:i + 3]}) == 1, outs[0][i:i + 3]

@@ -11,5 +11,7 @@ from libjpeg_amd import synth
 open("/tmp/tsan_dri.jpg", "wb").write(synth.synth_jpeg(1280, 720, 3, 85, "420", 4))
 open("/tmp/tsan_nodri.jpg", "wb").write(synth.synth_jpeg(1280, 720, 4, 90, "420", 0))
 open("/tmp/tsan_prog.jpg", "wb").write(synth.synth_jpeg(640, 480, 5, 85, "420", 8, progressive=True))
+# no restart intervals: the scans of the frame run as a pipeline, a scan one MCU row behind the scan it refines
+open("/tmp/tsan_prog_nodri.jpg", "wb").write(synth.synth_jpeg(640, 480, 6, 85, "420", 0, progressive=True))
 PY
-TSAN_OPTIONS="halt_on_error=1 exitcode=66" /tmp/tsan_host /tmp/tsan_dri.jpg /tmp/tsan_nodri.jpg /tmp/tsan_prog.jpg "$ROOT"/tests/golden/pil_200x120_420_dri8.jpg "$ROOT"/tests/golden/ref_75x45_420_dri2.jpg "$ROOT"/tests/golden/xt_129x71_420.jpg "$ROOT"/tests/golden/refprog_64x64_444_dri5.jpg
+TSAN_OPTIONS="halt_on_error=1 exitcode=66" /tmp/tsan_host /tmp/tsan_dri.jpg /tmp/tsan_nodri.jpg /tmp/tsan_prog.jpg "$ROOT"/tests/golden/pil_200x120_420_dri8.jpg "$ROOT"/tests/golden/ref_75x45_420_dri2.jpg "$ROOT"/tests/golden/xt_129x71_420.jpg "$ROOT"/tests/golden/refprog_64x64_444_dri5.jpg /tmp/tsan_prog_nodri.jpg "$ROOT"/tests/golden/xt_200x120_420_rR4.jpg "$ROOT"/tests/golden/xt_129x71_420_R2_rR3_dri3.jpg
