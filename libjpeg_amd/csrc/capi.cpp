@@ -177,6 +177,14 @@ static void release_big(int device, bool pinned, void *p, size_t bytes)
   if (pinned) (void)hipHostFree(p);
   else (void)hipFree(p);
 }
+// everything this object has enqueued is done (before one of its buffers changes hands while the object lives on: rare, a
+// buffer only grows when a larger picture arrives)
+static void quiesce(mijpeg_decoder *d)
+{
+  if (d->device < 0) return;
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->copy_stream) (void)hipStreamSynchronize(d->copy_stream);
+}
 
 // A batch that was submitted (mijpeg_submit_batch_device) and not waited for still reads the pinned staging buffers
 // (ent_host, stage_host, status words) from its asynchronous uploads: every entry point that rewrites them settles it first.
@@ -287,6 +295,7 @@ static int ensure_coef_store(mijpeg_decoder *d, size_t count, bool need_host = t
   if (need_host && d->coef_host_cap < count) {
     size_t cap = count;
     if (d->device >= 0) {
+      quiesce(d); // (the buffer may go to another object: nothing of this one may still read or write it)
       release_big(d->device, true, d->coef_host, d->coef_host_cap * sizeof(int16_t));
       d->coef_host = nullptr;
       d->coef_host_cap = 0;
@@ -303,6 +312,7 @@ static int ensure_coef_store(mijpeg_decoder *d, size_t count, bool need_host = t
     d->coef_host_cap = cap;
   }
   if (d->device >= 0 && d->coef_dev_cap < count) {
+    quiesce(d);
     release_big(d->device, false, d->coef_dev, d->coef_dev_cap * sizeof(int16_t));
     d->coef_dev = nullptr;
     d->coef_dev_cap = 0;
@@ -2351,6 +2361,7 @@ int mijpeg_encode_image_ex(mijpeg_decoder *d, const uint8_t *pixels, int32_t wid
 static int ensure_dev(mijpeg_decoder *d, void **ptr, size_t *cap, size_t bytes)
 {
   if (*cap >= bytes) return MIJPEG_OK;
+  quiesce(d);
   release_big(d->device, false, *ptr, *cap);
   *ptr = nullptr;
   *cap = 0;
@@ -2545,6 +2556,7 @@ static int serve_rect(mijpeg_decoder *d, int view, uint32_t flags, bool to_devic
   if (!to_device && !d->img_host_valid) {
     HIP_TRY(d, hipSetDevice(d->device));
     if (d->img_host_cap < padded) {
+      quiesce(d);
       release_big(d->device, true, d->img_host, d->img_host_cap);
       d->img_host = nullptr;
       d->img_host_cap = 0;
