@@ -89,6 +89,16 @@ typedef struct mijpeg_info {
                                 streams -- damaged ones -- whose DC prediction or point transform leaves the 16-bit range:
                                 the reference keeps LONG coefficients (coding/blockrow.hpp) and so does this frame; it is
                                 reconstructed by the unfused kernels with the reference's 32-bit transform          */
+  int32_t dnl;               /* 1 = the frame header carried zero lines and the height arrived in a DNL marker behind the first
+                                scan.  The reference has set up its buffers by then and the traces stay in the picture
+                                (DESIGN.md "DNL frames"): block rows are created MCU row by MCU row without a bound until
+                                the marker is seen (control/blockbuffer.cpp:212-265), and the upsamplers never learn the
+                                height (control/blockbitmaprequester.cpp:298-322, upsampling/upsamplerbase.cpp:61-75): their
+                                line buffers have no bottom edge.  For such frames blocks_h[] counts one MCU row more than
+                                mcus_y * vsamp[] -- the row the first scan creates behind the picture when it meets the marker
+                                only there -- and rows[] below tells how far the scans really got                        */
+  int32_t rows[MIJPEG_MAX_COMPONENTS]; /* set by decode_coefficients for dnl frames: block rows of the component the scans created;
+                                a row below that reads as NULL and transforms to sample value 0 (dct/idct.cpp:336-338)    */
 } mijpeg_info;
 
 /* JPEG XT (ISO/IEC 18477-7) profile C parameters of the loaded stream, valid when info.xt != 0:

@@ -37,7 +37,7 @@ class MijpegInfo(C.Structure):
         ("ycbcr", C.c_int32), ("fast_arith", C.c_int32), ("coef_offset", C.c_int64 * 4),
         ("coef_count", C.c_int64), ("quant", (C.c_uint16 * 64) * 4), ("range_max", C.c_int32 * 4),
         ("sample_bytes", C.c_int32), ("xt", C.c_int32), ("is_float", C.c_int32), ("progressive", C.c_int32),
-        ("coef_wide", C.c_int32),
+        ("coef_wide", C.c_int32), ("dnl", C.c_int32), ("rows", C.c_int32 * 4),
     ]
 
 

@@ -1520,11 +1520,27 @@ static bool is_440(const mijpeg_info &f)
 // The fused kernels address inside a frame with 32-bit byte offsets (planes and pixels; frames are 64 bits apart): frames
 // beyond that -- a 65535 x 65535 picture has 8.6 GB of luma coefficients and 12.9 GB of pixels -- take the generic kernels,
 // whose addressing is 64 bits wide throughout.
+// DNL frames (mijpeg_info::dnl): the vertical filter of a subsampled component reads the line below the picture's last one,
+// and when the picture ends on a block row boundary that line belongs to the block row the first scan creates behind the
+// picture -- unless it met the marker before it got there.  Then the row does not exist, the reference reads NULL and
+// transforms it to samples of value 0 (control/blockbitmaprequester.cpp:1097-1108, dct/idct.cpp:336-338): no coefficients
+// give that, the unfused kernels write the zeros themselves (GenericArgs::zero_from).
+static bool dnl_row_missing(const mijpeg_info &f)
+{
+  if (!f.dnl) return false;
+  for (int c = 0; c < f.components; c++) {
+    const int ch = (f.height + f.suby[c] - 1) / f.suby[c];
+    if (f.suby[c] > 1 && (ch & 7) == 0 && f.rows[c] <= (ch >> 3)) return true;
+  }
+  return false;
+}
+
 static bool fits32(const mijpeg_batch *b)
 {
   const mijpeg_info &f = b->info;
   const uint64_t lim = 0xffffffffull;
   if (f.coef_wide) return false; // int32 coefficients (damaged stream): the unfused kernels' business
+  if (dnl_row_missing(f)) return false; // (the fused kernels have no way to say "this block row is NULL")
   for (int c = 0; c < f.components; c++)
     if ((uint64_t)f.blocks_w[c] * (uint64_t)f.blocks_h[c] * 128u > lim) return false;
   if (f.xt && b->xt)
@@ -1704,7 +1720,7 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (use_fused420(b)) return "fused420_kernel";
   if (use_fused444(b)) return "fused444_kernel";
   if (b->info.xt) return "idct_planes_kernel+xt_merge_kernel";
-  if (b->quant_dev || (b->flags & MIJPEG_FLAG_FORCE_GENERIC) || getenv("MIJPEG_NO_FUSED_TILE")) return "idct_planes_kernel+upsample_color_kernel";
+  if (b->quant_dev || (b->flags & MIJPEG_FLAG_FORCE_GENERIC) || getenv("MIJPEG_NO_FUSED_TILE") || dnl_row_missing(b->info)) return "idct_planes_kernel+upsample_color_kernel";
   return "fused_tile_kernel";
 }
 
@@ -1790,6 +1806,10 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     a.bh_c = f.blocks_h[1];
     a.cw = f440 ? f.width : f411 ? (f.width + 3) / 4 : (f.width + 1) / 2;
     a.ch = (f422 || f411) ? f.height : (f.height + 1) / 2;
+    // DNL frames: the reference's upsamplers never learnt the height (upsampling/upsamplerbase.cpp:61-75), their line buffers
+    // have no bottom edge: below the last chroma line comes what the block rows hold (the padding of the last one, then the
+    // MCU row the first scan created behind the picture: the store has it, include/mijpeg.h) instead of that line again
+    if (f.dnl && !(f422 || f411) && f.components > 1) a.ch = a.bh_c * 8;
     a.tiles_x = (f.width + 127) / 128;
     a.tiles_y = (f.height + 127) / 128;
     a.frames = b->frames;
@@ -1848,6 +1868,10 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       a.suby[p] = g.suby[c];
       a.cw[p] = (g.width + g.subx[c] - 1) / g.subx[c];
       a.ch[p] = (g.height + g.suby[c] - 1) / g.suby[c];
+      if (g.dnl && g.suby[c] > 1) { // no bottom edge, see above; rows nobody created are NULL: zeros
+        if ((a.ch[p] & 7) == 0 && g.rows[c] <= (a.ch[p] >> 3)) a.zero_from[p] = g.rows[c];
+        a.ch[p] = g.blocks_h[c] * 8;
+      }
       a.dcoff[p] = (1 << (precision - 1)) << 7;
       fill_deltas(a.q[p], g.quant[g.quant_index[c]]);
     };
@@ -1937,7 +1961,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     // plain JPEG frames of any layout go through LDS in one pass (fused_tile_kernel); the pair with its sample planes in HBM
     // stays for JPEG XT, int32 coefficient planes, per-frame tables in device memory, rectangle requests and MIJPEG_FLAG_FORCE_GENERIC
     static const bool no_tile = getenv("MIJPEG_NO_FUSED_TILE") != nullptr; // A-B measurements
-    const bool tile = !rx && !f.xt && !f.coef_wide && !qdev && !(b->flags & MIJPEG_FLAG_FORCE_GENERIC) && !no_tile;
+    const bool tile = !rx && !f.xt && !f.coef_wide && !qdev && !(b->flags & MIJPEG_FLAG_FORCE_GENERIC) && !no_tile && !dnl_row_missing(f);
     rc = tile ? launch_fused_tile(a, fast || tile_fast12(b), s) : -1;
     if (rc == -1) rc = launch_generic(a, fast, s);
   }
@@ -2734,7 +2758,7 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
     return mijpeg_reconstruct_rect(d, min_x, min_y, max_x, max_y, min_comp, max_comp, flags, dst, bpp, bpr);
   }
   if (!d->model_valid) {
-    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0);
+    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0, f.dnl != 0, f.rows, f.blocks_h);
     d->model_valid = true;
   }
   const RequestPlan p = d->model.request(min_x, min_y, max_x, max_y, min_comp, max_comp, upsample, ctrafo, bm_h);
@@ -2839,7 +2863,7 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
       const int pc = vc >= 0 ? vc : c;
       const bool up = vc < 0 && p.upsampling_path && p.upsampler[pc] && p.requested[pc];
       rx.wstart[c] = up ? p.wstart[pc] : 0;
-      rx.wlimit[c] = up ? p.wlimit[pc] : (g.height + g.suby[c] - 1) / g.suby[c];
+      rx.wlimit[c] = up ? p.wlimit[pc] : (g.dnl && g.suby[c] > 1) ? g.blocks_h[c] * 8 : (g.height + g.suby[c] - 1) / g.suby[c];
     }
     rc = launch_reconstruct_ex(&b, d->stream, &rx);
     if (rc) return set_error(d, rc, rc == MIJPEG_ERR_DEVICE ? std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError())
@@ -2930,7 +2954,7 @@ int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
   if (d->host.info.components < 1 || d->host.info.width < 1) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no parsed stream: call mijpeg_read_header first");
   const mijpeg_info &f = d->host.info;
   if (!d->model_valid) {
-    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0);
+    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0, f.dnl != 0, f.rows, f.blocks_h);
     d->model_valid = true;
   }
   const RequestPlan p = d->model.request(min_x, min_y, max_x, max_y, min_comp, max_comp, !(flags & MIJPEG_FLAG_NO_UPSAMPLING),

@@ -194,6 +194,12 @@ private:
   int adobe_transform_ = -1;
   bool have_frame_ = false;
   bool need_dnl_ = false; // SOF carried zero lines
+  // ... then the height is what the first scan's parser comes to while it decodes (EntropyParser::ParseDNLMarker looks for the
+  // marker at every MCU, codestream/entropyparser.hpp:147-152): parse() decodes that scan without keeping anything to learn
+  // the height -- and the block rows the scan makes (control/blockbuffer.cpp:212-265 has no bound while the height is 0) --
+  // the way the reference will; decode() then knows both
+  int dnl_height_ = 0;
+  int dnl_rows_made_[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
   bool progressive_ = false; // SOF2
   int comp_id_[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
   // per scan: end offset of every restart interval and the RSTn code that terminated it
@@ -209,6 +215,8 @@ private:
   bool parsing_hidden_ = false;
   int64_t plane_offset_[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0}; // component planes inside this frame's own store
   int finish_xt(bool header_only);
+  int spec_without_residual(const XtBox &spec);
+  int spec_ltrafo_ = 255; // L transformation a merging specification WITHOUT a residual names (255: none; codestream/tables.cpp:1994-2021)
   int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
   template <class T> int decode_t(T *coef, int threads, const std::function<void(int, int)> &on_rows_done);
   template <class T> int decode_scan_speculative(T *coef, const Scan &s, int threads, uint32_t (&qmax_out)[MIJPEG_MAX_COMPONENTS],

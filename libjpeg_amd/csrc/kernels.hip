@@ -2301,7 +2301,7 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const GenericArgs a)
   if (FAST) dequant_idct_sparse(rows, q, v, a.dcoff[comp]);
   else dequant_idct<false>(rows, q, v, a.dcoff[comp]);
   const int by = blk / a.bw[comp], bx = blk - by * a.bw[comp];
-  if (rowmap && rowmap[by] < 0) {
+  if ((rowmap && rowmap[by] < 0) || (a.zero_from[comp] > 0 && by >= a.zero_from[comp])) {
 #pragma unroll
     for (int i = 0; i < 64; i++) v[i] = 0;
   }
@@ -2361,7 +2361,7 @@ __global__ __launch_bounds__(256) void idct_planes_wide_kernel(const GenericArgs
   if (blk >= nblocks) return;
   const int32_t *__restrict__ rowmap = a.rowmap ? a.rowmap + comp * a.rowmap_stride : nullptr;
   const int sblk = rowmap ? blk + (max(rowmap[blk / a.bw[comp]], 0) - blk / a.bw[comp]) * a.bw[comp] : blk;
-  const bool zeros = rowmap && rowmap[blk / a.bw[comp]] < 0;
+  const bool zeros = (rowmap && rowmap[blk / a.bw[comp]] < 0) || (a.zero_from[comp] > 0 && blk / a.bw[comp] >= a.zero_from[comp]);
   const int32_t *__restrict__ src =
       reinterpret_cast<const int32_t *>(a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp]) + (int64_t)sblk * 64;
   int tmp[64];
@@ -2405,7 +2405,7 @@ __global__ __launch_bounds__(256) void idct_planes_long_kernel(const GenericArgs
   if (blk >= nblocks) return;
   const int32_t *__restrict__ rowmap = a.rowmap ? a.rowmap + comp * a.rowmap_stride : nullptr;
   const int sblk = rowmap ? blk + (max(rowmap[blk / a.bw[comp]], 0) - blk / a.bw[comp]) * a.bw[comp] : blk;
-  const bool zeros = rowmap && rowmap[blk / a.bw[comp]] < 0;
+  const bool zeros = (rowmap && rowmap[blk / a.bw[comp]] < 0) || (a.zero_from[comp] > 0 && blk / a.bw[comp] >= a.zero_from[comp]);
   const int32_t *__restrict__ src =
       reinterpret_cast<const int32_t *>(a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[comp]) + (int64_t)sblk * 64;
   int v[64];

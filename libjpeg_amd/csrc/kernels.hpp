@@ -104,6 +104,9 @@ struct GenericArgs {
   int32_t request;             // 1: window / displacement semantics below are in force (LAYOUT_ANY instances only)
   int32_t req_x0, req_y0, y_base, y_count; // y_count: lines the second kernel works on (0: the whole frame)
   int32_t wstart[MAXP], wlimit[MAXP];
+  // DNL frames (mijpeg_info::dnl): block rows of plane p from zero_from[p] on were never created -- the reference reads NULL
+  // there and transforms it to sample value 0 (dct/idct.cpp:336-338); 0 = every row is there
+  int32_t zero_from[MAXP];
   // fused tile kernel (launch_fused_tile fills these): tile size in pixels (whole MCUs) and tile grid
   int32_t tile_w, tile_h, tiles_x, tiles_y;
 };

@@ -53,9 +53,15 @@ struct RequestPlan {
 
 class RequestModel {
 public:
-  void reset(int ncomp, int width, int height, const int32_t *subx, const int32_t *suby, bool frame_ycbcr)
+  // dnl: the frame's height arrived in a DNL marker, i.e. after the reference built its upsamplers -- they took 0 for "unknown"
+  // and made it 2^31 - 1 lines (upsampling/upsamplerbase.cpp:61-75), so nothing clips their buffered region at the bottom of
+  // the picture (:138-156, :218-228) -- and after its first scan created block rows without knowing where to stop
+  // (control/blockbuffer.cpp:212-265): rows[c] of them exist (the store keeps store_rows[c]).
+  void reset(int ncomp, int width, int height, const int32_t *subx, const int32_t *suby, bool frame_ycbcr, bool dnl = false,
+             const int32_t *rows = nullptr, const int32_t *store_rows = nullptr)
   {
     nc_ = ncomp; w_ = width; h_ = height; frame_ycbcr_ = frame_ycbcr;
+    dnl_ = dnl && rows && store_rows;
     subsampling_ = false;
     trafo_built_ = false;
     ycc_ = false;
@@ -64,6 +70,7 @@ public:
       sy_[c] = c < ncomp ? suby[c] : 1;
       cur_[c] = 0;
       rows_[c] = c < ncomp ? (((height + sy_[c] - 1) / sy_[c]) + 7) >> 3 : 0; // control/blockbuffer.cpp:212-265
+      if (dnl_ && c < ncomp) rows_[c] = std::min(rows[c], store_rows[c]);
       up_[c] = c < ncomp && (sx_[c] > 1 || sy_[c] > 1);                       // blockbitmaprequester.cpp:310-318
       subsampling_ = subsampling_ || up_[c];
       uy_[c] = uh_[c] = 0;
@@ -103,7 +110,8 @@ public:
       for (int c = c0; c <= c1; c++) {
         if (!up_[c]) continue;
         const int sx = sx_[c], sy = sy_[c];
-        const int total = (h_ + sy - 1) / sy, bheight = (total + 7) >> 3;
+        const int total = dnl_ ? (int)((0x7fffffffu + (uint32_t)sy - 1) / (uint32_t)sy) : (h_ + sy - 1) / sy;
+        const int bheight = (int)(((uint32_t)total + 7u) >> 3);
         int gmin = (min_y / sy - (sy > 1 ? 1 : 0)) >> 3, gmax = (max_y / sy + (sy > 1 ? 1 : 0)) >> 3;
         gmin = std::max(gmin, 0);
         gmax = std::min(gmax, bheight - 1);
@@ -147,8 +155,8 @@ public:
           if (!p.requested[c]) continue;
           p.g0[c] = uy_[c] >> 3;
           p.g1[c] = p.g0[c] + (int)tags_[c].size() - 1;
-          p.rowmap[c].assign((size_t)rows_[c], -1);
-          for (int g = p.g0[c]; g <= p.g1[c] && g < rows_[c]; g++) p.rowmap[c][(size_t)g] = tags_[c][(size_t)(g - p.g0[c])];
+          p.rowmap[c].assign((size_t)std::max(rows_[c], dnl_ ? p.g1[c] + 1 : 0), -1);
+          for (int g = p.g0[c]; g <= p.g1[c] && g < (int)p.rowmap[c].size(); g++) p.rowmap[c][(size_t)g] = tags_[c][(size_t)(g - p.g0[c])];
           p.wstart[c] = uy_[c];
           p.wlimit[c] = uy_[c] + uh_[c];
         } else {
@@ -208,7 +216,7 @@ public:
         // the filter window must reach as far as the image-bound filter would read: the last line shown plus one
         // (plus / minus one line where there is a vertical filter)
         const int halo = sy_[c] > 1 ? 1 : 0;
-        const int need = std::min((p.max_y / sy_[c]) + halo, (h_ + sy_[c] - 1) / sy_[c] - 1);
+        const int need = dnl_ ? (p.max_y / sy_[c]) + halo : std::min((p.max_y / sy_[c]) + halo, (h_ + sy_[c] - 1) / sy_[c] - 1);
         if (p.wlimit[c] <= need || p.wstart[c] > std::max(p.min_y / sy_[c] - halo, 0)) plain = false;
       }
     }
@@ -218,7 +226,7 @@ public:
 
 private:
   int nc_ = 0, w_ = 0, h_ = 0;
-  bool frame_ycbcr_ = false, subsampling_ = false, trafo_built_ = false, ycc_ = false;
+  bool frame_ycbcr_ = false, subsampling_ = false, trafo_built_ = false, ycc_ = false, dnl_ = false;
   int sx_[4] = {1, 1, 1, 1}, sy_[4] = {1, 1, 1, 1};
   int cur_[4] = {0, 0, 0, 0}, rows_[4] = {0, 0, 0, 0};
   bool up_[4] = {false, false, false, false};

@@ -148,6 +148,8 @@ typedef struct {
   /* frame */
   int have_frame, frame_type;
   int need_dnl;
+  int known_height; /* decode pass of a DNL frame: the height the header pass (which decodes the first scan to find it) came to */
+  int known_bh[OJ_MAX_COMP]; /* ... and the block rows it made room for */
   int progressive; /* SOF2 */
   int hidden;      /* JPEG XT: bits of every coefficient that travel in hidden refinement scans (RSPC box) */
   oj_box *boxes;   /* where APP11 boxes are collected (OJ_MAX_BOXES entries); the caller's array or walk()'s own */
@@ -576,6 +578,8 @@ static void frame_geometry(oj_info *f)
     f->bh[c] = f->mcus_y * f->vs[c];
     f->cw[c] = (f->width + f->subx[c] - 1) / f->subx[c];
     f->ch[c] = (f->height + f->suby[c] - 1) / f->suby[c];
+    f->rows[c] = (f->ch[c] + 7) >> 3; /* rows a scan creates when the height is known (control/blockbuffer.cpp:212-265) */
+    if (f->dnl) f->bh[c] += f->vs[c]; /* one MCU row more: what the first scan may create below the picture, see jpeg_oracle.h */
   }
 }
 
@@ -647,19 +651,15 @@ static void rs_parse_frame_header(oj_parser *ps, oj_bs *io)
   f->scan_state_valid = ps->planes != NULL || ps->walk_all; /* a header-only walk does not see all scans */
 }
 
-/* Height from the DNL marker that must follow the entropy coded data of the first scan
- * (EntropyParser::ParseDNLMarker, codestream/entropyparser.cpp:204-249): FFDC, length 4, number of lines > 0.
- * Found by looking ahead (well-formed streams only; the reference discovers it while decoding). */
-static void resolve_dnl(oj_parser *ps, const uint8_t *ecs, const uint8_t *end)
+/* Frame::PostImageHeight (marker/frame.cpp:1241-1258) for a frame whose header carried zero lines: the DNL marker the
+ * first scan ran into delivered them (EntropyParser::ParseDNLMarker, codestream/entropyparser.cpp:204-249).  The reference
+ * discovers the marker WHILE it decodes -- no look-ahead can tell what it makes of a damaged segment -- so the header pass
+ * (oj_read_info) decodes the first scan of such a frame as well, without keeping the coefficients, and the decode pass is
+ * told the height it came to. */
+static void post_image_height(oj_parser *ps, int h)
 {
-  const uint8_t *q = ecs;
-  int h;
-  while (q + 1 < end && !(q[0] == 0xff && q[1] != 0x00 && q[1] != 0xff && !(q[1] >= 0xd0 && q[1] <= 0xd7))) q++;
-  if (q + 6 > end || q[1] != 0xdc) rs_throw(ps, RS_MALFORMED_STREAM); /* the reference then fails on the frame height as well */
-  if (rd16(q + 2) != 4) rs_throw(ps, RS_MALFORMED_STREAM);
-  h = rd16(q + 4);
-  if (h == 0) rs_throw(ps, RS_MALFORMED_STREAM);
   ps->info->height = h;
+  ps->info->dnl = 1;
   frame_geometry(ps->info);
   ps->need_dnl = 0;
 }
@@ -771,6 +771,7 @@ typedef struct {
   uint32_t ri, togo;
   long next_rst;
   int valid;
+  int scan_for_dnl, dnl_found; /* m_bScanForDNL, m_bDNLFound (codestream/entropyparser.cpp:79-80) */
 } oj_scan;
 
 /* SequentialScan::DecodeBlock, codestream/sequentialscan.cpp:678-773 (not residual, not large range, not differential) */
@@ -879,12 +880,36 @@ static void scan_restart(oj_scan *sc)
   bits_open(&sc->bits, sc->ps, sc->io);
 }
 
+/* EntropyParser::ParseDNLMarker, codestream/entropyparser.cpp:204-249.  It looks at the BYTE stream, whose position is
+ * where the bit reader's prefetch stopped (up to four bytes ahead of the bits in use, io/bitstream.cpp:56-118): the
+ * marker is "found" -- and every later MCU of the scan skipped -- while the last MCUs' bits still wait in the window. */
+static int parse_dnl_marker(oj_scan *sc)
+{
+  oj_bs *io = sc->io;
+  long dt;
+  if (sc->dnl_found) return 1;
+  dt = bs_peekword(io);
+  while (dt == 0xffff) { bs_get(io); dt = bs_peekword(io); }
+  if (dt != 0xffdc) return 0;
+  bs_getword(io);
+  dt = bs_getword(io);
+  if (dt != 4) rs_throw(sc->ps, RS_MALFORMED_STREAM);
+  dt = bs_getword(io);
+  if (dt == BS_EOF) rs_throw(sc->ps, RS_UNEXPECTED_EOF);
+  if (dt == 0) rs_throw(sc->ps, RS_MALFORMED_STREAM);
+  if (sc->ps->need_dnl) post_image_height(sc->ps, (int)dt);
+  else if (dt != sc->ps->info->height) rs_unsupported(sc->ps); /* (the decode pass reads the marker the header pass read) */
+  sc->dnl_found = 1;
+  return 1;
+}
+
 /* EntropyParser::ParseRestartMarker, codestream/entropyparser.cpp:117-201 */
 static void parse_restart_marker(oj_scan *sc)
 {
   oj_bs *io = sc->io;
   long dt = bs_peekword(io);
   while (dt == 0xffff) { bs_get(io); dt = bs_peekword(io); }
+  if (dt == 0xffdc && sc->scan_for_dnl) { parse_dnl_marker(sc); return; } /* :127-128: no restart, the counter stays at 0 */
   if (dt == sc->next_rst) {
     bs_getword(io);
     scan_restart(sc);
@@ -941,7 +966,7 @@ static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
   oj_scan sc;
   long len, data;
   int id[OJ_MAX_COMP], td[OJ_MAX_COMP], ta[OJ_MAX_COMP], i, j, c, ah, al, type;
-  int mx, my, mcus_x, mcus_y;
+  int mx, my, mcus_x, mcus_y, rows_made[OJ_MAX_COMP] = {0, 0, 0, 0};
   memset(&sc, 0, sizeof(sc));
   sc.ps = ps; sc.io = io;
   type = hidden_scan ? FT_PROGRESSIVE : ps->frame_type;
@@ -1029,8 +1054,12 @@ static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
       f->comp_seen[c] = 1;
     }
   }
-  if (ps->need_dnl) resolve_dnl(ps, io->d + io->pos, io->d + io->n);
-  if (!ps->planes) { /* headers only: skip the entropy coded data */
+  sc.scan_for_dnl = ps->need_dnl; /* EntropyParser::EntropyParser: the frame height is still 0 */
+  if (ps->need_dnl && ps->known_height > 0) {
+    post_image_height(ps, ps->known_height);
+    for (c = 0; c < f->ncomp; c++) f->bh[c] = ps->known_bh[c];
+  }
+  if (!ps->planes && !sc.scan_for_dnl) { /* headers only: skip the entropy coded data */
     const uint8_t *q = io->d + io->pos, *end = io->d + io->n;
     while (q + 1 < end && !(q[0] == 0xff && q[1] != 0x00 && q[1] != 0xff && !(q[1] >= 0xd0 && q[1] <= 0xd7))) q++;
     if (q + 1 >= end) q = end;
@@ -1042,13 +1071,40 @@ static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
     /* single-component scan: 1x1 MCUs over ceil(cw/8) x ceil(ch/8) blocks (sequentialscan.cpp:396-397) */
     mcus_x = (f->cw[sc.ci[0]] + 7) >> 3; mcus_y = (f->ch[sc.ci[0]] + 7) >> 3;
   }
+  /* BlockBuffer::ResetToStartOfScan / StartMCUQuantizerRow (control/blockbuffer.cpp:177-265) with m_ulPixelHeight == 0:
+   * every MCU row gets all its block rows, nothing bounds their number until the DNL marker delivered the height;
+   * from then on rows end at ceil(ch / 8) as usual.  rows[] counts what exists afterwards. */
   bits_open(&sc.bits, ps, io);
-  for (my = 0; my < mcus_y; my++) {
+  for (my = 0; sc.scan_for_dnl || my < mcus_y; my++) {
+    if (sc.scan_for_dnl) {
+      int more = 1;
+      for (i = 0; i < sc.ns; i++) {
+        const int h = (sc.ns > 1) ? f->vs[sc.ci[i]] : 1;
+        int ymin, ymax;
+        c = sc.ci[i];
+        ymin = my * h * 8;
+        ymax = ymin + h * 8;
+        if (sc.dnl_found) {
+          if (ymin > f->ch[c]) ymin = f->ch[c]; /* m_pulY stopped at the clipped end of the previous row */
+          if (ymax > f->ch[c]) ymax = f->ch[c];
+        }
+        if (ymin < ymax) { if (my * h + ((ymax - ymin + 7) >> 3) > rows_made[c]) rows_made[c] = my * h + ((ymax - ymin + 7) >> 3); }
+        else more = 0;
+      }
+      if (!more) break;
+      /* a scan that never comes to a DNL marker goes on until the reference runs out of memory: nothing to compare with */
+      if (my > 65536 / 8 + 8) rs_unsupported(ps);
+    }
     for (mx = 0; mx < mcus_x; mx++) {
+      int valid;
       /* EntropyParser::BeginReadMCU, entropyparser.hpp:147-160 */
-      if (sc.ri) {
-        if (sc.togo == 0) parse_restart_marker(&sc);
-        sc.togo--;
+      if (sc.scan_for_dnl && parse_dnl_marker(&sc)) valid = 0;
+      else {
+        if (sc.ri) {
+          if (sc.togo == 0) parse_restart_marker(&sc);
+          sc.togo--;
+        }
+        valid = sc.valid;
       }
       for (i = 0; i < sc.ns; i++) {
         int bx, by, w = (sc.ns > 1) ? f->hs[sc.ci[i]] : 1, h = (sc.ns > 1) ? f->vs[sc.ci[i]] : 1;
@@ -1057,9 +1113,13 @@ static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
           for (bx = 0; bx < w; bx++) {
             int32_t dummy[64];
             int X = mx * w + bx, Y = my * h + by, k;
-            int32_t *blk = (X < f->bw[c] && Y < f->bh[c]) ? ps->planes[c] + ((size_t)Y * f->bw[c] + X) * 64 : dummy;
+            /* DNL frames: a row below ceil(ch / 8) is there iff the first scan created it -- later scans reach it through
+             * the list (`if (q) q = q->NextOf()`, sequentialscan.cpp:423).  (While the first scan of such a frame runs
+             * every row it is at exists; the header pass keeps no coefficients.) */
+            int32_t *blk = (ps->planes && X < f->bw[c] && Y < f->bh[c] && (!f->dnl || sc.scan_for_dnl || Y < f->rows[c]))
+                               ? ps->planes[c] + ((size_t)Y * f->bw[c] + X) * 64 : dummy;
             if (blk == dummy) memset(dummy, 0, sizeof(dummy));
-            if (sc.valid) {
+            if (valid) {
               if (sc.refinement) decode_block_refine(&sc, blk, sc.ac[i], &sc.skip[i]);
               else decode_block(&sc, blk, sc.dc[i], sc.ac[i], &sc.pred[i], &sc.skip[i]);
             } else if (!sc.refinement) {
@@ -1068,6 +1128,16 @@ static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
             }
           }
       }
+    }
+  }
+  if (sc.scan_for_dnl) {
+    if (ps->need_dnl) rs_throw(ps, RS_MALFORMED_STREAM); /* (unreachable: the loop ends behind the marker or by a throw) */
+    for (i = 0; i < sc.ns; i++) {
+      c = sc.ci[i];
+      f->rows[c] = rows_made[c];
+      /* a damaged segment (restart markers that make the parser skip intervals ...) can leave more rows than one MCU row
+       * behind the picture, and the command line's component-by-component requests walk through all of them */
+      if (!ps->planes && rows_made[c] > f->bh[c]) f->bh[c] = rows_made[c];
     }
   }
 }
@@ -1181,6 +1251,48 @@ static int rs_result(const oj_parser *ps, int thrown)
   return OJ_ERR_MALFORMED;
 }
 
+#define BOXID_(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
+/* A merging specification box in a file that has no residual codestream -- what the reference's encoder writes for `-c`
+ * (SPEC{OCON, LTRF = identity}, codestream/tables.cpp:625-632) and for grey scale pictures.  Tables::LTrafoTypeOf
+ * (codestream/tables.cpp:1994-2021) takes the L transformation from the box before it looks at the Adobe marker or the
+ * component count; the transformer is the Extended flavour (colortransformerfactory.cpp:232-236): identity L tables, identity
+ * C transformation, nothing to merge, clamp to 2^P - 1 (colortrafo/ycbcrtrafo.cpp:861-878, 921-936) -- the plain picture.
+ * Returns 0 and sets f->ycbcr, or the reference's error code, or 1: a specification this restatement does not follow. */
+static int spec_without_residual(const oj_box *spec, const oj_box *boxes, int nboxes, oj_info *f)
+{
+  int ltrafo = 255, ctrafo = 255, ocon = -1, tables = 0, hidden = 0, have_mtx[16] = {0}, b;
+  size_t j;
+  for (j = 0; j + 8 <= spec->len;) {
+    const uint32_t l = ((uint32_t)rd16(spec->data + j) << 16) | (uint32_t)rd16(spec->data + j + 2);
+    const uint32_t t = ((uint32_t)rd16(spec->data + j + 4) << 16) | (uint32_t)rd16(spec->data + j + 6);
+    const uint8_t *pl = spec->data + j + 8;
+    if (l < 9 || j + l > spec->len) return 1;
+    if (t == BOXID_('L', 'T', 'R', 'F')) ltrafo = pl[0] >> 4;
+    else if (t == BOXID_('C', 'T', 'R', 'F')) ctrafo = pl[0] >> 4;
+    else if (t == BOXID_('O', 'C', 'O', 'N')) ocon = pl[0];
+    else if (t == BOXID_('R', 'S', 'P', 'C')) hidden = pl[0];
+    else if (t == BOXID_('R', 'T', 'R', 'F') || t == BOXID_('R', 'D', 'C', 'T') || t == BOXID_('L', 'D', 'C', 'T')) { if (t == BOXID_('L', 'D', 'C', 'T') && pl[0]) return 1; }
+    else {
+      if (t == BOXID_('M', 'T', 'R', 'X') && l >= 9) have_mtx[pl[0] >> 4] = 1;
+      tables = 1; /* point transformations, tables, matrices, anything else */
+    }
+    j += l;
+  }
+  for (b = 0; b < nboxes; b++)
+    if (boxes[b].type == BOXID_('M', 'T', 'R', 'X') && boxes[b].len >= 1) have_mtx[boxes[b].data[0] >> 4] = 1;
+  if (f->ncomp == 1 && ltrafo != 255) return RS_MALFORMED_STREAM; /* "Base transformation box exists even though the number of components is one" */
+  if (ltrafo == 0 || ltrafo == 3 || ltrafo == 4) return RS_MALFORMED_STREAM; /* Zero, JPEG_LS, RCT: "Found an invalid base transformation" */
+  /* a free-form transformation nobody defined: "the base transformation specified in the codestream does not exist"
+   * (colortransformerfactory.cpp:379-383) */
+  if (ltrafo != 255 && ltrafo >= 5 && !have_mtx[ltrafo]) return RS_OBJECT_DOESNT_EXIST;
+  if (tables || hidden || (ctrafo != 255 && ctrafo != 1) || (ltrafo != 255 && ltrafo >= 5)) return 1;
+  if (ocon >= 0 && ((ocon >> 4) != 0 || (ocon & 0x0d) || !(ocon & 0x02))) return 1; /* more bits, lossless, float, lookup, or wrap-around */
+  if (ltrafo == 2 && f->ncomp != 3) return 1;
+  if (ltrafo == 2) f->ycbcr = 1;
+  else if (ltrafo == 1) f->ycbcr = 0;
+  return 0;
+}
+
 static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
 {
   oj_bs io;
@@ -1199,8 +1311,25 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
   if (!thrown) {
     oj_info *f = ps->info;
     if (!ps->have_frame) { thrown = 1; ps->err = RS_MALFORMED_STREAM; }
+    /* a frame that announced a DNL marker and never met one keeps zero lines; reading it succeeds, and the first request
+     * for pixels fails: "Rectangle MaxY underflow, must be >= 0" (codestream/rectanglerequest.cpp:107-115, cmd/reconstruct.cpp:334-342) */
+    else if (f->height == 0) { thrown = 1; ps->err = RS_OVERFLOW_PARAMETER; }
     /* codestream/tables.cpp:2021-2030: three components and no Adobe "None" -> YCbCr, else identity */
     f->ycbcr = (f->ncomp == 3 && f->adobe_transform != 0) ? 1 : 0;
+    if (!thrown && !ps->nested) {
+      const oj_box *spec = NULL, *resi = NULL;
+      int b;
+      for (b = 0; b < ps->nboxes; b++) {
+        if (ps->boxes[b].type == BOXID_('S', 'P', 'E', 'C')) spec = &ps->boxes[b];
+        if (ps->boxes[b].type == BOXID_('R', 'E', 'S', 'I')) resi = &ps->boxes[b];
+      }
+      if (spec && !resi && spec->complete) {
+        const int v = spec_without_residual(spec, ps->boxes, ps->nboxes, f);
+        /* (a header-only walk has not seen the whole file: it takes the transformation, the verdict waits for the full walk) */
+        if (v == 1) { if (planes) { thrown = 1; ps->unsupported = 1; ps->err = RS_NOT_IMPLEMENTED; } }
+        else if (v) { thrown = 1; ps->err = v; }
+      }
+    }
   }
   if (own) {
     int b;
@@ -1232,6 +1361,8 @@ int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
   memset(&ps, 0, sizeof(ps));
   memset(&tmp, 0, sizeof(tmp));
   ps.data = data; ps.len = len; ps.info = &tmp;
+  ps.known_height = info->dnl ? info->height : 0;
+  for (c = 0; c < OJ_MAX_COMP; c++) ps.known_bh[c] = info->bh[c];
   for (c = 0; c < info->ncomp; c++)
     memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
   rc = walk(&ps, planes);
@@ -1240,6 +1371,8 @@ int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
   out->scan_state_valid = tmp.scan_state_valid;
   out->ref_error = tmp.ref_error;
   out->warnings = tmp.warnings;
+  if (tmp.dnl) memcpy(out->rows, tmp.rows, sizeof(tmp.rows));
+  if (!rc) out->ycbcr = tmp.ycbcr; /* the full walk has seen every box */
   return rc;
 }
 
@@ -1600,6 +1733,8 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
       memset(samp[c], 0, (size_t)f->bw[c] * f->bh[c] * 64 * sizeof(int32_t));
     else
       oj_idct_plane(samp[c], planes[c], f->bw[c], f->bh[c], q, f->precision);
+    if (f->dnl && f->rows[c] < f->bh[c]) /* rows nobody created: NULL -> sample value 0 (blockbitmaprequester.cpp:1097-1108, idct.cpp:336-338) */
+      memset(samp[c] + (size_t)f->rows[c] * 8 * f->bw[c] * 8, 0, (size_t)(f->bh[c] - f->rows[c]) * f->bw[c] * 64 * sizeof(int32_t));
     if (xt) { /* residual: same transform, level shift 2^(Pr-1) (control/residualblockhelper.cpp:191-202) */
       const oj_info *r = xt->rinfo;
       if (!r->quant_defined[r->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
@@ -1624,7 +1759,9 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
     for (X0 = 0; X0 < f->width; X0 += 8) {
       int32_t blk[OJ_MAX_COMP][64], rblk[OJ_MAX_COMP][64];
       for (c = 0; c < f->ncomp; c++) {
-        oj_upsample_block(blk[c], samp[c], f->bw[c] * 8, f->cw[c], f->ch[c], f->subx[c], f->suby[c], X0, Y0);
+        /* DNL frames: the upsampler was built with the height unknown (upsamplerbase.cpp:61-75) and its buffer has no
+         * bottom edge -- the line below the picture is whatever the next block row holds (:138-156, :218-228) */
+        oj_upsample_block(blk[c], samp[c], f->bw[c] * 8, f->cw[c], f->dnl ? f->bh[c] * 8 : f->ch[c], f->subx[c], f->suby[c], X0, Y0);
         if (xt) {
           const oj_info *r = xt->rinfo;
           oj_upsample_block(rblk[c], rsamp[c], r->bw[c] * 8, r->cw[c], r->ch[c], r->subx[c], r->suby[c], X0, Y0);
@@ -1839,14 +1976,14 @@ oj_requester *oj_requester_new(const oj_info *f, int32_t *const planes[OJ_MAX_CO
   rq->f = *f;
   for (c = 0; c < f->ncomp; c++) {
     rq->planes[c] = planes[c];
-    rq->rows[c] = (f->ch[c] + 7) >> 3;
+    rq->rows[c] = f->dnl ? f->rows[c] : (f->ch[c] + 7) >> 3;
     if (f->subx[c] > 1 || f->suby[c] > 1) { /* blockbitmaprequester.cpp:310-318 */
       oj_up *u = (oj_up *)calloc(1, sizeof(*u));
       if (!u) { oj_requester_free(rq); return NULL; }
       u->sx = f->subx[c]; u->sy = f->suby[c];
-      u->pw = f->width; u->ph = f->height;
+      u->pw = f->width; u->ph = f->dnl ? 0x7fffffff : f->height; /* `if (pixelheight == 0) pixelheight = ~0U >> 1`, upsamplerbase.cpp:65-67 */
       u->width = (f->width + u->sx - 1) / u->sx;
-      u->total = (f->height + u->sy - 1) / u->sy;
+      u->total = (int)(((uint32_t)u->ph + (uint32_t)u->sy - 1) / (uint32_t)u->sy);
       rq->up[c] = u;
       rq->subsampling = 1;
     }
@@ -1866,7 +2003,7 @@ void oj_requester_free(oj_requester *rq)
 
 static const int32_t *rq_row_block(const oj_requester *rq, int c, int bx)
 {
-  if (rq->cur[c] >= rq->rows[c]) return NULL; /* *m_pppQImage[c] == NULL */
+  if (rq->cur[c] >= rq->rows[c] || rq->cur[c] >= rq->f.bh[c]) return NULL; /* *m_pppQImage[c] == NULL (or a row the oracle does not keep) */
   return rq->planes[c] + ((size_t)rq->cur[c] * rq->f.bw[c] + bx) * 64;
 }
 
@@ -1955,7 +2092,7 @@ int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int 
       if (!u) continue;
       /* upsamplerbase.cpp:138-156 SetBufferedImageRegion */
       bwidth = ((u->pw + u->sx - 1) / u->sx + 7) >> 3;
-      bheight = ((u->ph + u->sy - 1) / u->sy + 7) >> 3;
+      bheight = (int)((((uint32_t)u->ph + (uint32_t)u->sy - 1) / (uint32_t)u->sy + 7) >> 3);
       rx = u->sx > 1; ry = u->sy > 1;
       b_min_x = (min_x / u->sx - rx) >> 3;
       b_max_x = (max_x / u->sx + rx) >> 3;

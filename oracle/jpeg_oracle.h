@@ -63,6 +63,19 @@ typedef struct {
   int comp_seen[OJ_MAX_COMP];
   int ref_error;             /* the reference's JPGERR_* code of a failed decode, else 0     */
   int warnings;              /* number of JPG_WARN conditions passed (damaged but decodable) */
+  /* Frames whose height arrives in a DNL marker (SOF Y = 0).  The reference sets up its buffers while the height is still
+   * unknown and the differences stay visible: the block rows are created one MCU row at a time without a bound until the
+   * marker is seen (control/blockbuffer.cpp:212-265 with m_ulPixelHeight == 0), and the upsamplers never learn the height
+   * (control/blockbitmaprequester.cpp:298-322, upsampling/upsamplerbase.cpp:61-75).  For such frames bh[c] counts one MCU row
+   * more than mcus_y * vs[c]: the first scan creates it when it meets the marker only at the first MCU of the row behind the
+   * picture, i.e. whenever the last MCU is longer than the bit reader's prefetch.  Whole-frame requests reach its first block
+   * row (index ceil(ch / 8), when ch % 8 == 0) as the vertical filter's `bot` line; the component-by-component requests of
+   * the command line (cmd/reconstruct.cpp:272-303) walk the cursors of unsubsampled components through all of it.
+   * rows[c] is the number of block rows the scans created (filled by oj_decode_coefficients; smaller than bh[c] when the
+   * marker was seen early, larger only in streams whose DNL height contradicts the data -- those rows are not kept) -- a
+   * row that was not created reads as NULL and transforms to sample value 0 (dct/idct.cpp:336-338). */
+  int dnl;
+  int rows[OJ_MAX_COMP];
 } oj_info;
 
 /* Parse the headers only.  Returns OJ_OK or a negative error. */
@@ -70,7 +83,7 @@ int oj_read_info(const uint8_t *data, size_t len, oj_info *info);
 
 /* Entropy-decode every scan into quantised coefficient planes.
  * planes[c] must hold bw[c]*bh[c]*64 int32 (natural order inside a block, blocks row-major);
- * they are zero-initialised here (coding/blockrow.cpp:77-87). */
+ * they are zero-initialised here (coding/blockrow.cpp:77-87).  Reports info->rows[] (and the scan state) back. */
 int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
                            int32_t *const planes[OJ_MAX_COMP]);
 

@@ -110,3 +110,26 @@ def random_layout(rng: np.random.Generator):
         if nc > 1 and sum(s[0] * s[1] for s in samp) > 10:
             continue
         return samp, int(rng.integers(1, 141)), int(rng.integers(1, 141)), int(rng.choice([0, 0, 1, 2, 5]))
+
+
+def to_dnl(data: bytes) -> bytes:
+    """The same frame with its number of lines in a DNL marker: SOF Y = 0 and FFDC 0004 <lines> right behind the entropy coded
+    data of the first scan (what the reference's encoder writes for -n, marker/frame.cpp:290-300; decoder side
+    codestream/entropyparser.cpp:204-249)."""
+    d = bytearray(data)
+    i, sof, sos = 2, None, None
+    while i < len(d):
+        assert d[i] == 0xFF
+        m, ln = d[i + 1], (d[i + 2] << 8) | d[i + 3]
+        if m in (0xC0, 0xC1, 0xC2):
+            sof = i
+        if m == 0xDA:
+            sos = i
+            break
+        i += 2 + ln
+    lines = bytes(d[sof + 5:sof + 7])
+    d[sof + 5:sof + 7] = b"\0\0"
+    q = sos + 2 + ((d[sos + 2] << 8) | d[sos + 3])
+    while not (d[q] == 0xFF and d[q + 1] != 0 and d[q + 1] != 0xFF and not 0xD0 <= d[q + 1] <= 0xD7):
+        q += 1
+    return bytes(d[:q]) + b"\xff\xdc\x00\x04" + lines + bytes(d[q:])

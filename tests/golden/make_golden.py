@@ -68,6 +68,15 @@ case("ref_64x40_q100", 64, 40, 15, "ref", args=["-bl", "-q", "100"])
 # number of lines in a DNL marker behind the first scan (SOF carries 0; codestream/entropyparser.cpp:204-249)
 case("ref_97x61_420_dnl", 97, 61, 60, "ref", args=["-bl", "-n", "-q", "80", "-s", "1x1,2x2,2x2"])
 case("ref_50x70_444_dnl_dri2", 50, 70, 61, "ref", args=["-bl", "-n", "-q", "80", "-z", "2"])
+# merging specification boxes WITHOUT a residual codestream: the reference's encoder writes SPEC{OCON, LTRF = identity} (+ Adobe
+# transform 0) for -c, and SPEC{OCON} for every grey scale picture that is not baseline; Tables::LTrafoTypeOf takes the box's
+# transformation first (codestream/tables.cpp:1994-2021)
+for _i, (_n, _s) in enumerate([("444", "1x1,1x1,1x1"), ("420", "1x1,2x2,2x2"), ("422", "1x1,2x1,2x1"), ("440", "1x1,1x2,1x2"),
+                               ("411", "1x1,4x1,4x1"), ("3x3", "1x1,3x3,3x3"), ("lumasub", "2x2,1x1,1x1")]):
+    case(f"refc_83x47_{_n}", 83, 47, 70 + _i, "ref", args=["-q", "85", "-c", "-s", _s] + (["-v"] if _i % 3 == 2 else []) + (["-z", "3"] if _i % 3 == 1 else []))
+case("refc_64x40_444_prog", 64, 40, 78, "ref", args=["-q", "90", "-v", "-c"])
+case("refspec_70x40_gray", 70, 40, 79, "refgray", args=["-q", "80"])
+case("refspec_70x41_gray_prog_dri", 70, 41, 80, "refgray", args=["-q", "80", "-v", "-z", "4"])
 case("pil_80x48_444", 80, 48, 20, "pil", quality=75, sub="444", dri=0)
 case("pil_75x45_420_dri2", 75, 45, 21, "pil", quality=85, sub="420", dri=2)
 case("pil_33x17_420_dri1", 33, 17, 22, "pil", quality=85, sub="420", dri=1)
@@ -202,6 +211,8 @@ def main():
         img = synth.synth_image(c["w"], c["h"], c["seed"])
         if c["enc"] == "ref":
             data = O.reference_encode(img, c["args"])
+        elif c["enc"] == "refgray":
+            data = O.reference_encode(img[:, :, :1], c["args"])
         else:
             if c["sub"] == "gray":
                 data = synth.encode_jpeg(img[..., 0], c["quality"], restart_mcus=c["dri"], progressive=c.get("progressive", False))

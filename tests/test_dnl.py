@@ -1,0 +1,346 @@
+"""Frames whose height arrives in a DNL marker.
+
+The reference sets up its block rows and its upsamplers while the height is still unknown, and it looks for the marker in the
+byte stream in front of every MCU while its bit reader has read ahead:
+  * upsampling: the line buffers have no bottom edge (upsampling/upsamplerbase.cpp:61-75, 138-156, 218-228): below the last
+    line of a vertically subsampled component comes what the next block row holds -- the padding of the last one, the MCU row
+    the first scan created behind the picture (control/blockbuffer.cpp:212-265 has no bound while the height is 0), or NULL =
+    sample value 0 when the scan met the marker before it got there (control/blockbitmaprequester.cpp:1097-1108,
+    dct/idct.cpp:336-338) -- instead of that line again (upsampling/upsampler.cpp:106-108);
+  * entropy: EntropyParser::BeginReadMCU peeks the byte stream for FFDC (codestream/entropyparser.hpp:147-152,
+    entropyparser.cpp:204-249) where the bit reader's prefetch stands (io/bitstream.cpp:56-118): MCUs whose bits already sit
+    in the window when the marker comes into view are skipped.
+Layers: the oracle against tests/golden/dnl/ (written by the real reference, tests/golden/make_dnl.py) and against the binary
+live; the product's host decoder against the oracle (coefficients, rows made, error codes, damaged streams); -m gpu: the
+product's pixels through the C ABI against the goldens, the reference and the oracle.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import craft
+import damage
+from conftest import GOLDEN_DIR
+from libjpeg_amd import api, synth
+
+DNL_DIR = os.path.join(GOLDEN_DIR, "dnl")
+with open(os.path.join(DNL_DIR, "manifest.json")) as _f:
+    DNL = json.load(_f)
+NAMES = sorted(DNL)
+
+SAMPLINGS = ["1x1,2x2,2x2", "1x1,1x2,1x2", "2x2,1x1,1x1", "1x1,1x3,1x3", "1x1,1x4,1x4", "1x1,2x2,1x1", "1x1,2x1,2x1", "1x1,1x1,1x1"]
+
+
+def dnl_jpeg(name):
+    with open(os.path.join(DNL_DIR, name + ".jpg"), "rb") as f:
+        return f.read()
+
+
+def sha(px):
+    return hashlib.sha256(np.ascontiguousarray(px).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------------------------------------ oracle
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_equals_what_the_reference_wrote(oracle, name):
+    ent = DNL[name]
+    px, err, _ = oracle.decode_status(dnl_jpeg(name))
+    assert err == 0 and px.shape == (ent["height"], ent["width"], ent["channels"])
+    assert sha(px) == ent["pixels_sha256"], name
+
+
+def test_the_goldens_show_the_quirks(oracle):
+    """The fixtures are not what the same frames give with the height in the header: bottom lines of subsampled components,
+    blocks of the last MCUs."""
+    differing = 0
+    for name in NAMES:
+        data = dnl_jpeg(name)
+        if DNL[name]["channels"] != 3:
+            continue
+        sof = next(i for i in range(2, len(data)) if data[i] == 0xFF and data[i + 1] in (0xC0, 0xC1, 0xC2))
+        q = data.index(b"\xff\xdc\x00\x04")
+        plain = data[:sof + 5] + data[q + 4:q + 6] + data[sof + 7:q] + data[q + 6:]
+        differing += int(not np.array_equal(oracle.decode(plain), oracle.decode_status(data)[0]))
+    assert differing >= 80
+
+
+def test_oracle_against_live_reference_sweep(oracle):
+    """8 samplings x 12 heights x {baseline, progressive, restart intervals}: 288 streams of the reference's own encoder (-n),
+    decoded by the binary and by the restatement: no difference (build container only)."""
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/jpeg not built")
+    from concurrent.futures import ThreadPoolExecutor
+    work = [(s, h, m) for s in SAMPLINGS for h in (8, 16, 24, 31, 32, 33, 40, 46, 48, 63, 64, 70) for m in (["-bl"], ["-v"], ["-z", "2"])]
+
+    def one(item):
+        s, h, m = item
+        data = oracle.reference_encode(synth.synth_image(88, h, 4321 + h), m + ["-q", "85", "-n", "-s", s])
+        rpx, rerr = oracle.reference_decode_status(data)
+        opx, oerr, _ = oracle.decode_status(data)
+        return (rerr, oerr) == (0, 0) and rpx.shape == opx.shape and np.array_equal(rpx, opx)
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(one, work))
+    assert len(res) == 288 and all(res), [w for w, r in zip(work, res) if not r][:10]
+
+
+def test_oracle_against_live_reference_on_crafted_layouts(oracle):
+    """Hand-written frames of one to four components with any sampling factors (tests/craft.py), flat to dense content, with
+    and without restart intervals: the command line writes the two- and four-component ones component by component."""
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/jpeg not built")
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(t):
+        rng = np.random.default_rng(88000 + t)
+        samp, w, h, dri = craft.random_layout(rng)
+        data = craft.to_dnl(craft.craft_stream(rng, samp, w, h, dri, ac_density=float(rng.choice([0.0, 0.02, 0.08, 0.3]))))
+        rpx, rerr = oracle.reference_decode_status(data)
+        opx, oerr, _ = oracle.decode_status(data)
+        return (rerr, oerr) == (0, 0) and rpx.shape == opx.shape and np.array_equal(rpx, opx)
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(one, range(200)))
+    assert all(res), [t for t, r in enumerate(res) if not r][:10]
+
+
+def _damaged(count_per_file, seed, names=None):
+    names = names or ([n for n in NAMES if DNL[n]["channels"] in (1, 3)][::9] + [n for n in NAMES if "craft" in n][:5])
+    for fi, name in enumerate(names):
+        data = dnl_jpeg(name)
+        for where in ("any", "entropy"):
+            for kind, blob in damage.cases(data, count_per_file, seed * 1000 + fi + (500 if where == "entropy" else 0), where):
+                yield name, kind, blob
+
+
+def test_oracle_against_live_reference_on_damaged_dnl_streams(oracle):
+    """Seeded corruptions of DNL frames: the marker moved, removed, doubled, its height changed, restart markers renumbered,
+    data truncated ...: verdict and pixels of the restatement == the binary's.  (Streams whose first scan never comes to a DNL
+    marker make the reference create block rows until its memory runs out: nothing to compare with.)"""
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/jpeg not built")
+    from concurrent.futures import ThreadPoolExecutor
+    work = list(_damaged(10, 31))
+
+    def one(item):
+        name, kind, blob = item
+        opx, oerr, _ = oracle.decode_status(blob)
+        if oerr is None:
+            return None
+        rpx, rerr = oracle.reference_decode_status(blob)
+        if rerr == "timeout":
+            return None
+        if rerr != oerr:
+            return f"{name}/{kind}: reference {rerr}, oracle {oerr}"
+        if rerr == 0 and not (rpx.shape == opx.shape and np.array_equal(rpx, opx)):
+            return f"{name}/{kind}: pixels differ"
+        return ""
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(one, work))
+    bad = [r for r in res if r]
+    assert not bad, bad[:10]
+    assert sum(r == "" for r in res) >= 400
+
+
+def test_oracle_requester_on_dnl_frames_against_live_reference(oracle):
+    """Sequences of JPEG::DisplayRectangle calls against DNL frames: which lines the upsamplers buffer depends on the requests."""
+    if not os.path.exists(oracle.REF_RECT_CALLS):
+        pytest.skip("oracle/_ref/rect_calls_ref not built")
+    from concurrent.futures import ThreadPoolExecutor
+
+    from test_rect_calls import cli_scripts, random_script
+
+    def one(t):
+        rng = np.random.default_rng(91000 + t)
+        samp, w, h, dri = craft.random_layout(rng)
+        data = craft.to_dnl(craft.craft_stream(rng, samp, w, h, dri))
+        scripts = dict(cli_scripts(w, h, samp)) if t % 3 == 0 else {}
+        scripts["random"] = random_script(rng, w, h, len(samp), aligned=t % 4 == 1, monotone=t % 2 == 0)
+        bad = []
+        for sname, req in scripts.items():
+            _, ref = oracle.run_requests_client(oracle.REF_RECT_CALLS, data, req)
+            _, rcs, ora = oracle.run_requests(data, req)
+            if ref is None or any(rcs) or not np.array_equal(ref, ora):
+                bad.append((t, samp, w, h, sname))
+        return bad
+
+    with ThreadPoolExecutor(8) as ex:
+        bad = [b for r in ex.map(one, range(150)) for b in r]
+    assert not bad, bad[:5]
+
+
+# ------------------------------------------------------------------------------------------------ product, host side
+@pytest.mark.parametrize("name", NAMES[::3])
+def test_host_decoder_coefficients_and_rows(oracle, name):
+    """The literal walk of the product's host decoder: the same coefficients (skipped MCUs, rows behind the picture), the same
+    count of block rows per component, the same store as the oracle."""
+    data = dnl_jpeg(name)
+    oi, planes = oracle.decode_coefficients(data)
+    d = api.Decoder(None)
+    try:
+        h = d.read_header(data)
+        assert (h.height, h.dnl) == (oi.height, 1)
+        f = d.read(data, 3)
+        assert f.dnl == 1 and [f.rows[c] for c in range(f.components)] == [oi.rows[c] for c in range(oi.ncomp)]
+        for c in range(f.components):
+            assert (f.blocks_w[c], f.blocks_h[c]) == (oi.bw[c], oi.bh[c])
+            assert np.array_equal(d.coefficients(c), planes[c].astype(np.int16)), (name, c)
+    finally:
+        d.close()
+
+
+def test_host_decoder_on_damaged_dnl_streams(oracle):
+    stats, bad = {}, []
+    for name, kind, blob in _damaged(14, 32):
+        verdict, detail = damage.product_vs_oracle(blob)
+        stats[verdict] = stats.get(verdict, 0) + 1
+        if verdict not in ("ok", "skip"):
+            bad.append((name, kind, verdict, detail))
+    assert not bad, bad[:10]
+    assert stats.get("ok", 0) >= 600, stats
+
+
+def test_request_model_cursors_on_dnl_frames():
+    from oracle import oracle as O
+    from test_rect_calls import random_script
+    for t in range(150):
+        rng = np.random.default_rng(93000 + t)
+        samp, w, h, dri = craft.random_layout(rng)
+        data = craft.to_dnl(craft.craft_stream(rng, samp, w, h, dri))
+        req = random_script(rng, w, h, len(samp), fullwidth=False, aligned=(t % 3 == 0), monotone=(t % 2 == 0))
+        cur = []
+        O.run_requests(data, req, cursors=cur)
+        d = api.Decoder(None)
+        d.read(data)
+        for i, (x0, y0, x1, y1, c0, c1, ups, ct, hm) in enumerate(req):
+            x1 = w - 1 if x1 < 0 else x1
+            y1 = h - 1 if y1 < 0 else y1
+            plan = d.display_plan(x0, y0, x1, y1, c0, c1, (0 if ct else api.FLAG_NO_COLOR_TRANSFORM) | (0 if ups else api.FLAG_NO_UPSAMPLING),
+                                  (y0 + hm) if hm else h)
+            assert [plan["comps"][c]["cursor"] for c in range(len(samp))] == cur[i], (t, samp, w, h, i, req[i])
+        d.close()
+
+
+# ------------------------------------------------------------------------------------------------ product, pixels
+@pytest.fixture(scope="module")
+def dec():
+    d = api.Decoder(0)
+    yield d
+    d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_pixels_equal_what_the_reference_wrote(dec, name):
+    ent = DNL[name]
+    dec.read(dnl_jpeg(name), entropy="host")
+    out = dec.reconstruct_cli()
+    assert out.shape == (ent["height"], ent["width"], ent["channels"])
+    assert sha(out) == ent["pixels_sha256"], (name, api.kernel_name(dec.info))
+
+
+@pytest.mark.gpu
+def test_gpu_every_kernel_family_sees_dnl_frames(oracle, dec):
+    """Which kernel reconstructs a DNL frame: the fused ones when every block row the filters read is there, the unfused pair
+    (GenericArgs::zero_from) when the first scan met the marker before it made the row behind the picture."""
+    seen = {}
+    for name in NAMES:
+        if DNL[name]["channels"] != 3:
+            continue
+        dec.read(dnl_jpeg(name), entropy="host")
+        k = api.kernel_name(dec.info)
+        seen[k] = seen.get(k, 0) + 1
+        assert np.array_equal(dec.reconstruct(), oracle.decode_status(dnl_jpeg(name))[0]), (name, k)
+        assert np.array_equal(dec.reconstruct(flags=api.FLAG_FORCE_GENERIC), oracle.decode_status(dnl_jpeg(name))[0]), (name, "generic")
+    print(seen)
+    for k in ("fused420p_kernel", "fused440_kernel", "fused422_kernel", "fused_tile_kernel", "idct_planes_kernel+upsample_color_kernel"):
+        assert seen.get(k, 0) >= 1, (k, seen)
+
+
+@pytest.mark.gpu
+def test_gpu_4k_dnl_frame_through_the_fused_kernel(oracle, dec):
+    """BASELINE config 2's shape with its height in a DNL marker, restart interval 8 (`-n -z 8`): fused420p_kernel, byte-equal
+    to the reference binary where it is present (oracle/_ref/jpeg travels to the GPU box) and to the oracle."""
+    if oracle.have_reference():
+        data = oracle.reference_encode(synth.synth_image(3840, 2160, 1234), ["-bl", "-q", "85", "-n", "-s", "1x1,2x2,2x2", "-z", "8"])
+        exp, err = oracle.reference_decode_status(data, timeout=120)
+        assert err == 0
+    else:
+        data = craft.to_dnl(synth.synth_jpeg(3840, 2160, 1234, 85, "420", 8))
+        exp = None
+    opx, oerr, _ = oracle.decode_status(data)
+    assert oerr == 0 and (exp is None or np.array_equal(opx, exp))
+    plain = oracle.decode(data[:data.index(b"\xff\xdc\x00\x04")].replace(b"\x08\x00\x00\x0f\x00", b"\x08\x08\x70\x0f\x00", 1) + data[data.index(b"\xff\xdc\x00\x04") + 6:])
+    assert np.count_nonzero(plain != opx) > 1000 and not (plain[:-1] != opx[:-1]).any()  # line 2159, and only that line
+    f = dec.read(data, entropy="host")
+    assert f.dnl == 1 and api.kernel_name(f) == "fused420p_kernel"
+    assert np.array_equal(dec.reconstruct(), opx)
+
+
+@pytest.mark.gpu
+def test_gpu_dnl_random_layouts_and_request_sequences(oracle, dec):
+    """Random layouts of one to four components as DNL frames: whole pictures the command line's way, and sequences of
+    mijpeg_display_rect calls, against the oracle (pinned against the reference by the CPU tests above)."""
+    from test_rect_calls import cli_scripts, random_script
+    n = 0
+    for t in range(120):
+        rng = np.random.default_rng(95000 + t)
+        samp, w, h, dri = craft.random_layout(rng)
+        data = craft.to_dnl(craft.craft_stream(rng, samp, w, h, dri, ac_density=float(rng.choice([0.0, 0.05, 0.3]))))
+        exp, err, _ = oracle.decode_status(data)
+        assert err == 0
+        dec.read(data, entropy="host")
+        assert np.array_equal(dec.reconstruct_cli(), exp), (t, samp, w, h, dri)
+        scripts = dict(cli_scripts(w, h, samp)) if t % 2 == 0 else {}
+        scripts["random"] = random_script(rng, w, h, len(samp), aligned=t % 4 == 1, monotone=t % 3 != 0)
+        for sname, req in scripts.items():
+            _, rcs, want = oracle.run_requests(data, req)
+            assert not any(rcs)
+            dec.read(data, entropy="host")
+            canvas = np.full(want.shape, 0xAA, want.dtype)
+            for (x0, y0, x1, y1, c0, c1, ups, ct, hm) in req:
+                x1 = w - 1 if x1 < 0 else x1
+                y1 = h - 1 if y1 < 0 else y1
+                flags = (0 if ct else api.FLAG_NO_COLOR_TRANSFORM) | (0 if ups else api.FLAG_NO_UPSAMPLING)
+                try:
+                    dec.display_rect(canvas, x0, y0, x1, y1, c0, c1, flags, bm_height=(y0 + hm) if hm else h)
+                except api.MijpegError as e:
+                    assert e.code == -1024 and not ups and c0 != c1
+            assert np.array_equal(canvas, want), (t, samp, w, h, dri, sname)
+            n += 1
+    assert n >= 250
+
+
+@pytest.mark.gpu
+def test_gpu_damaged_dnl_streams_pixels_and_rc(oracle, dec):
+    from concurrent.futures import ThreadPoolExecutor
+    use_ref = oracle.have_reference()
+    work = list(_damaged(8, 33))
+    with ThreadPoolExecutor(16) as ex:
+        expected = list(ex.map(lambda w: damage.expected_of(w[2], use_ref), work))
+    stats, bad = {}, []
+    for (name, kind, blob), (epx, eerr) in zip(work, expected):
+        verdict, detail = damage.product_pixels_vs_expected(dec, blob, epx, eerr)
+        stats[verdict] = stats.get(verdict, 0) + 1
+        if verdict not in ("ok", "skip"):
+            bad.append((name, kind, verdict, detail))
+    print("damaged DNL streams against", "oracle/_ref/jpeg" if use_ref else "the oracle", stats)
+    assert not bad, bad[:10]
+    assert stats.get("ok", 0) >= 300, stats
+
+
+@pytest.mark.gpu
+def test_gpu_device_entropy_decoder_declines_dnl_frames(oracle, dec):
+    """entropy="gpu" refuses (the device decoders do not model the byte-stream peek); "prefer-gpu" hands the frame to the host
+    walk; a batch that holds one is refused as a whole."""
+    data = dnl_jpeg("dnl_420_48_dri2")
+    with pytest.raises(api.MijpegError) as e:
+        dec.read(data, entropy="gpu")
+    assert e.value.code == -1029
+    dec.read(data, entropy="prefer-gpu")
+    assert dec.entropy_used == "host"
+    assert np.array_equal(dec.reconstruct(), oracle.decode_status(data)[0])

@@ -161,7 +161,8 @@ def _covered(info, planes, c):
 
 
 FORWARD_GOLDEN = [n for n, e in MANIFEST.items() if e.get("encoder") == "ref" and e.get("channels") == 3 and "seed" in e
-                  and "-n" not in e["args"] and "sof1" not in n and not n.startswith("xt_") and "lumasub" not in n]
+                  and "-n" not in e["args"] and "-c" not in e["args"] and "sof1" not in n and not n.startswith("xt_") and "lumasub" not in n]
+# (-c: no forward colour transformation; oracle.forward(info, img, 1) applies one)
 
 
 @pytest.mark.parametrize("name", FORWARD_GOLDEN)

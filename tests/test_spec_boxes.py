@@ -1,0 +1,102 @@
+"""Merging specification boxes in files that carry no residual codestream.
+
+Tables::LTrafoTypeOf (codestream/tables.cpp:1994-2021) asks the box first: its LTRF decides the L transformation, whatever the
+Adobe marker says; Zero / JPEG_LS / RCT and a box in a one-component frame are MALFORMED_STREAM; a free-form number nobody
+defined is OBJECT_DOESNT_EXIST (colortrafo/colortransformerfactory.cpp:379-383).  The reference's encoder writes such files
+for `-c` (SPEC{OCON, LTRF = identity}, tables.cpp:625-632) and for every grey scale picture that is not baseline (SPEC{OCON}).
+The goldens refc_* / refspec_* (tests/golden/make_golden.py) pin the pictures; here: the variants of the box.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_jpeg
+from libjpeg_amd import api
+
+
+def patch(data, tag, val):
+    i = data.index(tag) + 4
+    return data[:i] + bytes([val]) + data[i + 1:]
+
+
+def remove_adobe(data):
+    i = data.index(b"\xff\xee\x00\x0eAdobe")
+    return data[:i] + data[i + 16:]
+
+
+def add_ltrf(data, v):
+    """Append an LTRF box to the merging specification of a file whose SPEC box fits one APP11 segment."""
+    i = data.index(b"SPEC")
+    seg = data.rindex(b"\xff\xeb", 0, i)
+    ln = (data[seg + 2] << 8) | data[seg + 3]
+    body = bytearray(data[seg:seg + 2 + ln]) + b"\x00\x00\x00\x09LTRF" + bytes([v])
+    body[2:4] = (ln + 9).to_bytes(2, "big")
+    body[12:16] = (int.from_bytes(body[12:16], "big") + 9).to_bytes(4, "big")  # LBox of the SPEC box
+    return data[:seg] + bytes(body) + data[seg + 2 + ln:]
+
+
+def variants():
+    base = golden_jpeg("refc_83x47_420")
+    gray = golden_jpeg("refspec_70x40_gray")
+    # name -> (stream, error the reference answers, YCbCr in force)
+    out = {"base": (base, 0, 0), "ltrf_identity": (patch(base, b"LTRF", 0x10), 0, 0), "ltrf_ycbcr": (patch(base, b"LTRF", 0x20), 0, 1),
+           "ltrf_ycbcr_no_adobe": (remove_adobe(patch(base, b"LTRF", 0x20)), 0, 1), "ltrf_identity_no_adobe": (remove_adobe(base), 0, 0),
+           "ltrf_zero": (patch(base, b"LTRF", 0x00), -1038, None), "ltrf_jpegls": (patch(base, b"LTRF", 0x30), -1038, None),
+           "ltrf_rct": (patch(base, b"LTRF", 0x40), -1038, None), "ltrf_freeform_5": (patch(base, b"LTRF", 0x50), -1031, None),
+           "ltrf_freeform_15": (patch(base, b"LTRF", 0xF0), -1031, None), "gray": (gray, 0, 0), "gray_with_ltrf": (add_ltrf(gray, 0x10), -1038, None)}
+    return out
+
+
+VARIANTS = variants()
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_oracle_and_host_decoder_on_box_variants(oracle, name):
+    data, err, ycc = VARIANTS[name]
+    if oracle.have_reference():
+        rpx, rerr = oracle.reference_decode_status(data)
+        assert rerr == err, (name, rerr)
+    opx, oerr, _ = oracle.decode_status(data)
+    assert oerr == err
+    if err == 0 and oracle.have_reference():
+        assert np.array_equal(opx, rpx), name
+    d = api.Decoder(None)
+    try:
+        try:
+            f = d.read(data)
+            assert err == 0 and f.ycbcr == ycc and f.xt == 0
+            _, planes = oracle.decode_coefficients(data)
+            for c in range(f.components):
+                assert np.array_equal(d.coefficients(c), planes[c].astype(np.int16))
+        except api.MijpegError as e:
+            assert e.code == err, (name, e)
+    finally:
+        d.close()
+
+
+def test_the_box_wins_over_the_adobe_marker(oracle):
+    """Same coefficients, Adobe transform 0 in both, LTRF identity vs YCbCr: different pictures."""
+    a, b = oracle.decode(VARIANTS["ltrf_identity"][0]), oracle.decode(VARIANTS["ltrf_ycbcr"][0])
+    assert a.shape == b.shape and not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("ocon", [0x00, 0x03, 0x06, 0x12, 0x0A])
+def test_output_conversions_beyond_the_plain_picture_are_declined(ocon):
+    """Wrap-around instead of clamping, output lookup, float cast, extra range bits, lossless: nothing the plain picture has."""
+    d = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        d.read(patch(VARIANTS["base"][0], b"OCON", ocon))
+    assert e.value.code == -1034
+    d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(k for k, v in VARIANTS.items() if v[1] == 0))
+def test_gpu_pixels_of_box_variants(oracle, name):
+    data = VARIANTS[name][0]
+    exp = oracle.reference_decode(data) if oracle.have_reference() else oracle.decode(data)
+    d = api.Decoder(0)
+    try:
+        d.read(data)
+        assert np.array_equal(d.reconstruct(), exp), name
+    finally:
+        d.close()
