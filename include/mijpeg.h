@@ -415,6 +415,14 @@ int mijpeg_encode_batch_device(mijpeg_decoder *d, const mijpeg_forward_batch *ba
 /* Worker threads mijpeg_decode_coefficients uses for threads <= 0 (MIJPEG_THREADS overrides; default min(cores, 64)). */
 int mijpeg_default_threads(void);
 
+/* The large buffers of destroyed decoder objects (pinned coefficient store and frame, their device mirrors) wait in a process-wide
+ * cache for the next object on the same device -- a client that constructs a JPEG object per picture would otherwise pin and
+ * unpin ~200 MB per 8K picture.  At most four buffers per kind and MIJPEG_BUFFER_CACHE_MB megabytes in all (environment,
+ * default 2048, 0 = keep nothing) are kept; a buffer enters the cache only after the device has gone idle, so kernels a client
+ * launched on its own streams against mijpeg_device_coefficients() / a mijpeg_batch never race with the next owner.
+ * mijpeg_trim_cache() hands everything the cache holds back to the runtime and returns the number of bytes freed. */
+size_t mijpeg_trim_cache(void);
+
 /* Library / build identification. */
 const char *mijpeg_version(void);
 

@@ -488,6 +488,13 @@ def speculative_scans():
     return int(n), int(p.value)
 
 
+def trim_cache() -> int:
+    """Free the buffers destroyed decoder objects left in the process-wide cache; returns the bytes freed."""
+    L = lib()
+    L.mijpeg_trim_cache.restype = C.c_size_t
+    return int(L.mijpeg_trim_cache())
+
+
 def default_threads() -> int:
     L = lib()
     L.mijpeg_default_threads.restype = C.c_int

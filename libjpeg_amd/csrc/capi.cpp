@@ -159,9 +159,40 @@ struct BufferCache {
       total += e.bytes;
       same += e.device == device && e.pinned == pinned;
     }
-    if (same >= 4 || total > ((size_t)2 << 30)) return false;
+    if (same >= 4 || total > limit_bytes()) return false;
     kept.push_back(Entry{p, bytes, device, pinned});
     return true;
+  }
+  // MIJPEG_BUFFER_CACHE_MB: what the cache may hold in all (default 2048, 0 = keep nothing)
+  static size_t limit_bytes()
+  {
+    static const size_t lim = [] {
+      const char *e = getenv("MIJPEG_BUFFER_CACHE_MB");
+      return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)2 << 30;
+    }();
+    return lim;
+  }
+  // mijpeg_trim_cache: hand everything back to the runtime
+  size_t trim()
+  {
+    std::vector<Entry> gone;
+    {
+      std::lock_guard<std::mutex> lock(m);
+      gone.swap(kept);
+    }
+    size_t bytes = 0;
+    for (const Entry &e : gone) {
+      bytes += e.bytes;
+      if (e.pinned) (void)hipHostFree(e.p);
+      else {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(e.device);
+        (void)hipFree(e.p);
+        (void)hipSetDevice(cur);
+      }
+    }
+    return bytes;
   }
 };
 BufferCache &buffer_cache()
@@ -173,6 +204,10 @@ BufferCache &buffer_cache()
 static void release_big(int device, bool pinned, void *p, size_t bytes)
 {
   if (!p) return;
+  // hipFree / hipHostFree wait for the device before they take the memory away, and the buffers were handed to clients
+  // (mijpeg_device_coefficients, mijpeg_batch: kernels on the client's own streams may still read them).  A buffer that changes
+  // hands through the cache instead gets the same guarantee: nothing on the device is in flight when the next owner writes it.
+  if (bytes >= ((size_t)1 << 20) && device >= 0) (void)hipDeviceSynchronize();
   if (buffer_cache().give(device, pinned, p, bytes)) return;
   if (pinned) (void)hipHostFree(p);
   else (void)hipFree(p);
@@ -205,6 +240,8 @@ extern "C" {
 const char *mijpeg_version(void) { return "libjpeg_amd/mijpeg 0.1 (gfx950)"; }
 
 int mijpeg_default_threads(void) { return default_threads(); }
+
+size_t mijpeg_trim_cache(void) { return buffer_cache().trim(); }
 
 int mijpeg_create(mijpeg_decoder **out, int device)
 {

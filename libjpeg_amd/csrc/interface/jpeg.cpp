@@ -278,8 +278,10 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
       p->next_stop = 0;
       p->between = false;
       {
-        uint64_t at[256], end[256];
-        const int ns = mijpeg_scan_offsets(p->dec, at, end, 256);
+        // (a progressive frame may bring hundreds of scans: ask for the count first)
+        const int ns = mijpeg_scan_offsets(p->dec, nullptr, nullptr, 0);
+        std::vector<uint64_t> at((size_t)std::max(ns, 1)), end((size_t)std::max(ns, 1));
+        mijpeg_scan_offsets(p->dec, at.data(), end.data(), ns);
         auto in_stream = [&](uint64_t off) { // offsets count the bytes the parser saw: what the client took out lies in front of them in `stream`
           size_t pos = (size_t)off;
           for (const auto &r : p->taken)
@@ -287,10 +289,10 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
           return pos < p->stream.size() ? pos : p->stream.size();
         };
         p->boxed_stops = 0;
-        for (int k = 0; k < ns && k < 256; k++) {
-          if (end[k] == 0) { p->boxed_stops++; continue; }
-          p->scan_stops.push_back(in_stream(at[k]));
-          p->scan_ends.push_back(in_stream(end[k]));
+        for (int k = 0; k < ns; k++) {
+          if (end[(size_t)k] == 0) { p->boxed_stops++; continue; }
+          p->scan_stops.push_back(in_stream(at[(size_t)k]));
+          p->scan_ends.push_back(in_stream(end[(size_t)k]));
         }
       }
       p->phase = Impl::P_SCANS;

@@ -477,3 +477,29 @@ for path in sys.argv[1:]:
     # ... and the thread count changes nothing either
     for i in range(0, len(outs[0]), 3):
         assert len({" ".join(ln.split()[2:]) for ln in outs[0][i:i + 3]}) == 1, outs[0][i:i + 3]
+
+
+def test_scan_pipeline_honours_the_callers_thread_bound():
+    """A JPEG XT stream with hidden refinement scans (-R 3 -rR 4: 3 + 16 scans in boxes) decoded with threads = 2 in a fresh process: the
+    worker pool grows by the two threads asked for (plus the one that drives the residual frame), not by one per scan; the
+    coefficients are those of the unbounded decode."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, hashlib
+sys.path.insert(0, %r)
+from libjpeg_amd import api
+data = open(%r, "rb").read()
+before = len(os.listdir("/proc/self/task"))
+d = api.Decoder(None)
+f = d.read(data, threads=2)
+after = len(os.listdir("/proc/self/task"))
+h = hashlib.sha256(b"".join(d.coefficients(c).tobytes() for c in range(f.components))).hexdigest()
+d.close()
+d = api.Decoder(None)
+f = d.read(data, threads=16)
+h16 = hashlib.sha256(b"".join(d.coefficients(c).tobytes() for c in range(f.components))).hexdigest()
+print(after - before, h == h16)
+''' % (ROOT, os.path.join(ROOT, "tests", "golden", "xt_200x120_420_R3_rR4.jpg"))
+    out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) <= 3 and out[1] == "True", out
