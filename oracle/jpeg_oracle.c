@@ -2402,6 +2402,9 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   /* the residual codestream is needed for the table dimensions */
   rc = oj_read_info(resi->data, resi->len, &rinfo);
   if (rc) goto out;
+  /* Image::ParseResidualStream (codestream/image.cpp:1289-1299) compares right behind the residual frame header, where a
+   * residual codestream with a DNL marker still has zero lines: "residual image dimensions do not match ..." */
+  if (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto out; }
   for (c = 0; c < 3; c++) {
     /* L: ScaledTableOf(8 + hidden bits, 16, 0, 0), default = identity with e = 1; Q: (Pr + hidden bits, 16, 4, 4) and
      * R2: (16, 16, 4, 0), defaults = identities with e = 0 (colortransformerfactory.cpp:312-345, 435-474, 486-520) */

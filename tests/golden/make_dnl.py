@@ -84,6 +84,15 @@ def main():
         data = craft.to_dnl(craft.craft_stream(rng, samp, w, h, dri=dri, ac_density=dens))
         add(f"dnl_craft_{n}", data, kind="craft", samp=samp, dri=dri)
         n += 1
+    # JPEG XT with -n: the residual codestream brings its height in a DNL marker as well, and the reference compares the two
+    # frames' dimensions right behind the residual frame header (codestream/image.cpp:1289-1299): refused
+    for k, extra in enumerate((["-n"], ["-n", "-z", "2", "-s", "1x1,2x2,2x2"])):
+        data = O.reference_encode_hdr(synth.synth_hdr(64, 48, 5 + k) * 4.0, ["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12"] + extra)
+        px, err = O.reference_decode_status(data)
+        assert px is None and err == -1038, err
+        with open(os.path.join(OUT, f"dnl_xt_{k}.jpg"), "wb") as f:
+            f.write(data)
+        manifest[f"dnl_xt_{k}"] = dict(kind="xt", error=err, jpeg_sha256=sha(data))
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print(len(manifest), "cases")

@@ -29,7 +29,8 @@ from libjpeg_amd import api, synth
 DNL_DIR = os.path.join(GOLDEN_DIR, "dnl")
 with open(os.path.join(DNL_DIR, "manifest.json")) as _f:
     DNL = json.load(_f)
-NAMES = sorted(DNL)
+NAMES = sorted(k for k, v in DNL.items() if v["kind"] != "xt")
+XT_NAMES = sorted(k for k, v in DNL.items() if v["kind"] == "xt")
 
 SAMPLINGS = ["1x1,2x2,2x2", "1x1,1x2,1x2", "2x2,1x1,1x1", "1x1,1x3,1x3", "1x1,1x4,1x4", "1x1,2x2,1x1", "1x1,2x1,2x1", "1x1,1x1,1x1"]
 
@@ -202,6 +203,20 @@ def test_host_decoder_on_damaged_dnl_streams(oracle):
             bad.append((name, kind, verdict, detail))
     assert not bad, bad[:10]
     assert stats.get("ok", 0) >= 600, stats
+
+
+@pytest.mark.parametrize("name", XT_NAMES)
+def test_jpeg_xt_with_dnl_residual_is_refused_like_the_reference(oracle, name):
+    """`jpeg -r ... -n`: the residual codestream's frame header says zero lines where the reference compares it with the legacy
+    frame (codestream/image.cpp:1289-1299): MALFORMED_STREAM from the reference, the oracle and the product."""
+    data = dnl_jpeg(name)
+    assert DNL[name]["error"] == -1038
+    assert oracle.decode_xt_status(data)[1:] == (False, -1038) or oracle.decode_xt_status(data)[-1] == -1038
+    d = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        d.read(data)
+    assert e.value.code == -1038 and "residual image dimensions" in str(e.value)
+    d.close()
 
 
 def test_request_model_cursors_on_dnl_frames():
