@@ -587,6 +587,25 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
                                  "note": "this rank's frames: bytes -> pixels in HBM (above) + D2H of the interleaved RGB frames into pinned host memory, "
                                          "32 frames at a time, decode and download not overlapped; the link carries 18 x more bytes down than up"}
         del pinned
+        # ... and with both directions of the link in use: every chunk's pixels go down behind its reconstruction kernel while
+        # the later chunks' bytes go up (BatchShard.run(download_to=...), mijpeg_stream_wait)
+        full = torch.empty(tuple(out.shape), dtype=torch.uint8).pin_memory()
+        best_fd = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            last_shard.run(download_to=full)
+            dt = time.perf_counter() - t
+            best_fd = dt if best_fd is None else min(best_fd, dt)
+        ok = bool(torch.equal(full[-1], out[-1].cpu()) and torch.equal(full[0], out[0].cpu()))
+        res["pixels_to_host"]["full_duplex"] = {
+            "ms": round(best_fd * 1e3, 2), "value": round(out.shape[0] * W * H / best_fd / 1e6, 1), "unit": "Mpixels/s",
+            "of_download_alone": round(best_fd / best_dl, 3), "chunk_frames": last_shard.chunk, "decoder_objects": last_shard.depth,
+            "host_copy_equals_device": ok,
+            "note": "bytes in host memory -> pixels in pinned host memory, one pass: the download of chunk i runs under the upload, the "
+                    "Huffman kernel and the reconstruction of chunks i+1.. (a download stream waits for the decoder object's stream, "
+                    "not the host); the batch takes the download's time instead of decode + download"}
+        del full
     except Exception as e:  # noqa: BLE001
         res["pixels_to_host"] = {"error": repr(e)}
     last_shard.close()

@@ -200,6 +200,12 @@ int mijpeg_finish_batch_device(mijpeg_decoder *d);
 int mijpeg_prepare_batch_host(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n);
 /* Wait for everything the object has enqueued on its stream (e.g. a reconstruction launched with sync = 0). */
 int mijpeg_synchronize(mijpeg_decoder *d);
+/* ... or let a stream of the CLIENT's wait for it instead of the host: everything the object has enqueued so far (uploads, entropy
+ * kernels, a reconstruction launched with sync = 0) happens before whatever the client enqueues on `client_stream` (a hipStream_t;
+ * NULL = the null stream) after this call.  The host does not block.  What config 4's other half uses: the download of a chunk's
+ * pixels waits for that chunk's reconstruction kernel and for nothing else, so PCIe carries pixels down while the next chunks'
+ * bytes go up (libjpeg_amd/batch.py, `download_to`). */
+int mijpeg_stream_wait(mijpeg_decoder *d, void *client_stream);
 int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags,
                                     int sync);
 

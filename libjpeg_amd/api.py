@@ -450,6 +450,13 @@ class Decoder:
         L.mijpeg_synchronize.argtypes = [C.c_void_p]
         self._check(L.mijpeg_synchronize(self._h))
 
+    def stream_wait(self, client_stream: int = 0):
+        """Everything this object has enqueued so far happens before what the caller enqueues on `client_stream` (a hipStream_t as
+        an integer, e.g. torch.cuda.Stream().cuda_stream) from now on; the host does not block (mijpeg_stream_wait)."""
+        L = lib()
+        L.mijpeg_stream_wait.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(L.mijpeg_stream_wait(self._h, C.c_void_p(client_stream)))
+
     def timing(self):
         t = (C.c_double * 4)()
         lib().mijpeg_last_timing(self._h, t)

@@ -102,6 +102,7 @@ struct mijpeg_decoder {
   std::vector<uint16_t> batch_quant_host;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t chain_ev = nullptr; // mijpeg_stream_wait
   int err_code = 0;
   std::string err_msg;
   double timing[4] = {0, 0, 0, 0};
@@ -298,6 +299,7 @@ void mijpeg_destroy(mijpeg_decoder *d)
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->chain_ev) (void)hipEventDestroy(d->chain_ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
   } else {
     free(d->coef_host);
@@ -1454,6 +1456,17 @@ int mijpeg_synchronize(mijpeg_decoder *d)
   if (d->device < 0 || !d->stream) return MIJPEG_OK;
   HIP_TRY(d, hipSetDevice(d->device));
   HIP_TRY(d, hipStreamSynchronize(d->stream));
+  return MIJPEG_OK;
+}
+
+int mijpeg_stream_wait(mijpeg_decoder *d, void *client_stream)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (d->device < 0 || !d->stream) return MIJPEG_OK;
+  HIP_TRY(d, hipSetDevice(d->device));
+  if (!d->chain_ev) HIP_TRY(d, hipEventCreateWithFlags(&d->chain_ev, hipEventDisableTiming));
+  HIP_TRY(d, hipEventRecord(d->chain_ev, d->stream));
+  HIP_TRY(d, hipStreamWaitEvent((hipStream_t)client_stream, d->chain_ev, 0));
   return MIJPEG_OK;
 }
 

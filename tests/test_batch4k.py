@@ -105,3 +105,23 @@ def test_submit_finish_pipeline_semantics(oracle):
         assert np.array_equal(out2[i].cpu().numpy().reshape(400, 640, 3), oracle.decode(plain[i]))
     d.close()
     d2.close()
+
+
+@pytest.mark.gpu
+def test_full_duplex_download_delivers_every_frame(oracle):
+    """BatchShard.run(download_to=pinned): each chunk's pixels leave for host memory behind its own reconstruction kernel
+    (mijpeg_stream_wait) while later chunks are uploaded and decoded; when run() returns every frame is in host memory and
+    equals the oracle's decode.  Two passes over the same buffers (the second overwrites the first's frames in order)."""
+    import torch
+
+    cfg = dict(batch.CONFIG4, width=640, height=368, frames=24)
+    streams = batch.make_streams(range(24), cfg)
+    shard = batch.BatchShard([streams[i] for i in range(24)], 0, chunk=5, depth=3)
+    host = torch.zeros(tuple(shard.out.shape), dtype=torch.uint8).pin_memory()
+    for _ in range(2):
+        host.zero_()
+        shard.run(download_to=host)
+        for i in range(24):
+            exp = oracle.decode(streams[i])
+            assert np.array_equal(host[i].numpy().reshape(exp.shape), exp), i
+    shard.close()
