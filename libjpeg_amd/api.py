@@ -279,6 +279,20 @@ class Decoder:
         arr = np.ctypeslib.as_array(((C.c_int32 if wide else C.c_int16) * n).from_address(p))
         return arr.reshape(f.blocks_h[comp], f.blocks_w[comp], 64).copy()
 
+    def residual_coefficients(self, comp: int) -> np.ndarray:
+        """JPEG XT: the residual codestream's planes, which follow the legacy ones in the same coefficient buffer
+        (mijpeg_xt_params.residual.coef_offset, in int16 units): int32 when the residual frame has hidden bits."""
+        x = self.xt_params()
+        base = lib().mijpeg_coefficients(self._h, 0)
+        if not base or not self.info.xt:
+            raise MijpegError(-1031, "no decoded residual coefficients")
+        r = x.residual
+        wide = bool(x.residual_wide)
+        n = r.blocks_w[comp] * r.blocks_h[comp] * 64
+        addr = base + 2 * int(r.coef_offset[comp])
+        arr = np.ctypeslib.as_array(((C.c_int32 if wide else C.c_int16) * n).from_address(addr))
+        return arr.reshape(r.blocks_h[comp], r.blocks_w[comp], 64).copy()
+
     def device_coefficients(self) -> int:
         return lib().mijpeg_device_coefficients(self._h) or 0
 

@@ -220,7 +220,7 @@ private:
   int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
   template <class T> int decode_t(T *coef, int threads, const std::function<void(int, int)> &on_rows_done);
   template <class T> int decode_scan_speculative(T *coef, const Scan &s, int threads, uint32_t (&qmax_out)[MIJPEG_MAX_COMPONENTS],
-                                                 VirtualIntervals *plan_only = nullptr);
+                                                 VirtualIntervals *plan_only = nullptr, bool first_pass = false);
   int fail(int code, const char *msg);
   int frame_geometry();
   void find_intervals(Scan &s);

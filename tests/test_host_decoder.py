@@ -503,3 +503,43 @@ print(after - before, h == h16)
 ''' % (ROOT, os.path.join(ROOT, "tests", "golden", "xt_200x120_420_R3_rR4.jpg"))
     out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout.split()
     assert int(out[0]) <= 3 and out[1] == "True", out
+
+
+def test_mask_based_refinement_pass_equals_the_plain_one():
+    """The AC refinement pass that keeps a block's history as bit masks (BMI2 / AVX2, picked at run time) and the parallel first
+    full-band pass against the position-by-position decoder (MIJPEG_NO_REFINE_MASKS / MIJPEG_NO_SPEC_FIRST_PASS, a process of its
+    own): the same coefficients on progressive pictures, JPEG XT frames with hidden refinement scans and damaged versions of both."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from libjpeg_amd import api
+import damage
+from conftest import MANIFEST, golden_jpeg
+names = sorted(n for n in MANIFEST if not MANIFEST[n].get("big") and ("prog" in n or "R" in n.split("_")[-1] or "_R" in n or "rR" in n))
+d = api.Decoder(None)
+out = []
+for fi, n in enumerate(names):
+    blobs = [golden_jpeg(n)] + [b for _, b in damage.cases(golden_jpeg(n), 6, 7000 + fi, "entropy")]
+    for blob in blobs:
+        for th in (1, 5):
+            try:
+                f = d.read(blob, threads=th)
+                h = hashlib.sha256(b"".join(d.coefficients(c).tobytes() for c in range(f.components)))
+                if f.xt:
+                    x = d.xt_params()
+                    h.update(bytes(str((x.hidden_bits, x.residual_hidden_bits)), "ascii"))
+                    for c in range(3):
+                        h.update(d.residual_coefficients(c).tobytes())
+                out.append(h.hexdigest()[:16])
+            except api.MijpegError as e:
+                out.append(str(e.code))
+print(len(names), hashlib.sha256(" ".join(out).encode()).hexdigest())
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    res = []
+    for env in ({}, {"MIJPEG_NO_REFINE_MASKS": "1", "MIJPEG_NO_SPEC_FIRST_PASS": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True, env=dict(os.environ, **env))
+        res.append(r.stdout.split())
+    assert res[0] == res[1] and int(res[0][0]) >= 12, res
