@@ -139,6 +139,16 @@ __device__ __forceinline__ void rgb_shift17_sat_pack(const int (&rr)[8], const i
   }
 }
 
+// ... and their way out: 24 bytes at base + off, base uniform (SGPR pair), off per lane (32 bits, the fused kernels' frames
+// fit: fits32 in capi.cpp).  The store instructions take the pair and the offset as they are (`saddr` form); written as a
+// pointer the compiler widens the offset and adds in 64 bits first, three VALU instructions per line of a block.
+__device__ __forceinline__ void store24_nt(uint8_t *__restrict__ base, unsigned off, const unsigned (&w)[6])
+{
+  const u32x4 lo = {w[0], w[1], w[2], w[3]};
+  const u32x2 hi = {w[4], w[5]};
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx2 %0, %3, %2 offset:16 nt" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
+}
+
 // floor((x + 2^(n-1)) / 2^n) with the addition carried out beyond 32 bits, as the reference's
 // `(x + (1L << (n-1))) >> n` does on LP64 (dct/idct.cpp:70-78).
 template <bool FAST, int N>
@@ -161,51 +171,58 @@ __device__ __forceinline__ int round_shift(int x)
 // multiply the same input are added up (still exact: the ring Z / 2^32 is distributive), 31 slots instead of 44.
 // R: what the even part starts from -- the rounding constant 2^(SHIFT-1), plus whatever multiple of 2^SHIFT the caller wants
 // added to every output for free (FAST flavours only; LUMA_FOLD_R below).
-template <bool FAST, int SHIFT, int NZ = 8>
+// X2 (FAST only): every constant of the pass doubled and no final shift -- the outputs are TWICE the sums in front of the
+// rounding shift, exactly (the pass is linear over Z / 2^32, and v_mad_i32_i24 sees the same 24-bit inputs and constants below
+// 2^13).  What the luma of the fast 8-bit YCbCr kernels wants: the colour stage needs y << 13 = (sum >> 12) << 13, which is the
+// doubled sum with its low 13 bits cleared -- one v_and_b32 per sample where the single sum takes a shift and the mask (R then
+// holds twice the constants, see LUMA_FOLD_R2).
+template <bool FAST, int SHIFT, int NZ = 8, bool X2 = false>
 __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int &s4, int &s5, int &s6, int &s7, const int R = 1 << (SHIFT - 1))
 {
+  constexpr int M = X2 ? 2 : 1, OSH = X2 ? 0 : SHIFT;
+  static_assert(!X2 || FAST, "the doubled pass is a FAST flavour");
   if (FAST && NZ == 4) {
     // even part (7): tmp2 = z1, tmp3 = s2 * (c0.541 + c0.765)
-    const int t0 = (s0 << 9) + R;
-    const int tmp2 = __mul24(s2, FIX9(0.541196100));
-    const int tmp3 = __mul24(s2, FIX9(0.541196100) + FIX9(0.765366865));
+    const int t0 = (s0 << (X2 ? 10 : 9)) + R;
+    const int tmp2 = __mul24(s2, M * FIX9(0.541196100));
+    const int tmp3 = __mul24(s2, M * (FIX9(0.541196100) + FIX9(0.765366865)));
     const int t10 = t0 + tmp3, t13 = t0 - tmp3, t11 = t0 + tmp2, t12 = t0 - tmp2;
     // odd part (8): tz1 = tz4 = s1, tz2 = tz3 = s3
-    const int z5 = __mul24(s3 + s1, FIX9(1.175875602));
-    const int z3 = mad24(s3, -FIX9(1.961570560), z5);
-    const int z4 = mad24(s1, -FIX9(0.390180644), z5);
-    const int o0 = mad24(s1, -FIX9(0.899976223), z3);
-    const int o1 = mad24(s3, -FIX9(2.562915447), z4);
-    const int o2 = mad24(s3, FIX9(3.072711026) - FIX9(2.562915447), z3);
-    const int o3 = mad24(s1, FIX9(1.501321110) - FIX9(0.899976223), z4);
-    s0 = (t10 + o3) >> SHIFT; s7 = (t10 - o3) >> SHIFT;
-    s1 = (t11 + o2) >> SHIFT; s6 = (t11 - o2) >> SHIFT;
-    s2 = (t12 + o1) >> SHIFT; s5 = (t12 - o1) >> SHIFT;
-    s3 = (t13 + o0) >> SHIFT; s4 = (t13 - o0) >> SHIFT;
+    const int z5 = __mul24(s3 + s1, M * FIX9(1.175875602));
+    const int z3 = mad24(s3, M * -FIX9(1.961570560), z5);
+    const int z4 = mad24(s1, M * -FIX9(0.390180644), z5);
+    const int o0 = mad24(s1, M * -FIX9(0.899976223), z3);
+    const int o1 = mad24(s3, M * -FIX9(2.562915447), z4);
+    const int o2 = mad24(s3, M * (FIX9(3.072711026) - FIX9(2.562915447)), z3);
+    const int o3 = mad24(s1, M * (FIX9(1.501321110) - FIX9(0.899976223)), z4);
+    s0 = (t10 + o3) >> OSH; s7 = (t10 - o3) >> OSH;
+    s1 = (t11 + o2) >> OSH; s6 = (t11 - o2) >> OSH;
+    s2 = (t12 + o1) >> OSH; s5 = (t12 - o1) >> OSH;
+    s3 = (t13 + o0) >> OSH; s4 = (t13 - o0) >> OSH;
     return;
   }
   if (FAST) {
     // even part (12)
-    const int t0 = ((s0 + s4) << 9) + R;
-    const int t1 = ((s0 - s4) << 9) + R;
-    const int z1 = __mul24(s2 + s6, FIX9(0.541196100));
-    const int tmp2 = mad24(s6, -FIX9(1.847759065), z1);
-    const int tmp3 = mad24(s2, FIX9(0.765366865), z1);
+    const int t0 = ((s0 + s4) << (X2 ? 10 : 9)) + R;
+    const int t1 = ((s0 - s4) << (X2 ? 10 : 9)) + R;
+    const int z1 = __mul24(s2 + s6, M * FIX9(0.541196100));
+    const int tmp2 = mad24(s6, M * -FIX9(1.847759065), z1);
+    const int tmp3 = mad24(s2, M * FIX9(0.765366865), z1);
     const int t10 = t0 + tmp3, t13 = t0 - tmp3, t11 = t1 + tmp2, t12 = t1 - tmp2;
     // odd part (16)
     const int tz1 = s7 + s1, tz2 = s5 + s3, tz3 = s7 + s3, tz4 = s5 + s1;
-    const int z5 = __mul24(tz3 + tz4, FIX9(1.175875602));
-    const int z3 = mad24(tz3, -FIX9(1.961570560), z5);
-    const int z4 = mad24(tz4, -FIX9(0.390180644), z5);
-    const int o0 = mad24(tz1, -FIX9(0.899976223), mad24(s7, FIX9(0.298631336), z3));
-    const int o1 = mad24(tz2, -FIX9(2.562915447), mad24(s5, FIX9(2.053119869), z4));
-    const int o2 = mad24(tz2, -FIX9(2.562915447), mad24(s3, FIX9(3.072711026), z3));
-    const int o3 = mad24(tz1, -FIX9(0.899976223), mad24(s1, FIX9(1.501321110), z4));
+    const int z5 = __mul24(tz3 + tz4, M * FIX9(1.175875602));
+    const int z3 = mad24(tz3, M * -FIX9(1.961570560), z5);
+    const int z4 = mad24(tz4, M * -FIX9(0.390180644), z5);
+    const int o0 = mad24(tz1, M * -FIX9(0.899976223), mad24(s7, M * FIX9(0.298631336), z3));
+    const int o1 = mad24(tz2, M * -FIX9(2.562915447), mad24(s5, M * FIX9(2.053119869), z4));
+    const int o2 = mad24(tz2, M * -FIX9(2.562915447), mad24(s3, M * FIX9(3.072711026), z3));
+    const int o3 = mad24(tz1, M * -FIX9(0.899976223), mad24(s1, M * FIX9(1.501321110), z4));
     // outputs (16)
-    s0 = (t10 + o3) >> SHIFT; s7 = (t10 - o3) >> SHIFT;
-    s1 = (t11 + o2) >> SHIFT; s6 = (t11 - o2) >> SHIFT;
-    s2 = (t12 + o1) >> SHIFT; s5 = (t12 - o1) >> SHIFT;
-    s3 = (t13 + o0) >> SHIFT; s4 = (t13 - o0) >> SHIFT;
+    s0 = (t10 + o3) >> OSH; s7 = (t10 - o3) >> OSH;
+    s1 = (t11 + o2) >> OSH; s6 = (t11 - o2) >> OSH;
+    s2 = (t12 + o1) >> OSH; s5 = (t12 - o1) >> OSH;
+    s3 = (t13 + o0) >> OSH; s4 = (t13 - o0) >> OSH;
     return;
   }
   // SAFE: the reference's statement order in wrapping 32-bit arithmetic
@@ -250,7 +267,10 @@ __device__ __forceinline__ void idct_1d(int &s0, int &s1, int &s2, int &s3, int 
 // multiple / 4096 on every sample, exactly: the two constants ride in the pass's rounding constant and the colour stage is left
 // with the shift.
 constexpr int LUMA_FOLD_R = 2048 + ((2048 + 8) << 12);
-template <bool FAST, int NR = 8, int NC = 8>
+// ... and with the second pass doubled (idct_1d X2) the outputs are 2 * (sum + LUMA_FOLD_R): luma13() of one is the y << 13 above
+constexpr int LUMA_FOLD_R2 = 2 * LUMA_FOLD_R;
+__device__ __forceinline__ int luma13(int doubled_sum) { return doubled_sum & (int)0xffffe000; }
+template <bool FAST, int NR = 8, int NC = 8, bool X2 = false>
 __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff, const int colr = 2048)
 {
 #pragma unroll
@@ -274,7 +294,7 @@ __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *
                          v[r * 8 + 6], v[r * 8 + 7]);
 #pragma unroll
   for (int c = 0; c < 8; c++)
-    idct_1d<FAST, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], colr);
+    idct_1d<FAST, 12, NR, X2>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], colr);
 }
 
 // The same with the FIRST pass in 16-bit arithmetic (FAST, 8-bit frames: the range check bounds sum |c| delta of a block by
@@ -304,7 +324,7 @@ __device__ __forceinline__ int sdot2(unsigned pk, int k, int c)
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pk), __builtin_bit_cast(s16x2, k), c, false);
 }
-template <int NR, int NC>
+template <int NR, int NC, bool X2 = false>
 __device__ __forceinline__ void dequant_idct16(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff, const int colr = 2048)
 {
   constexpr int C0541 = FIX9(0.541196100), C0765 = FIX9(0.765366865), C1847 = FIX9(1.847759065), C1175 = FIX9(1.175875602),
@@ -352,7 +372,7 @@ __device__ __forceinline__ void dequant_idct16(const u32x4 (&rows)[8], const int
   }
 #pragma unroll
   for (int c = 0; c < 8; c++)
-    idct_1d<true, 12, NR>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], colr);
+    idct_1d<true, 12, NR, X2>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], colr);
 }
 
 // True if coefficient rows 4..7 (the upper half of the vertical frequencies) are zero in every block the wave holds:
@@ -376,20 +396,20 @@ __device__ __forceinline__ bool cols_4_to_7_zero(const u32x4 (&rows)[8])
 
 // dequant_idct<true> with the pruned paths where the data allow it.  PK16ROW: q is a row of the kernel's argument block (the
 // packed deltas follow the 64) and the frame has 8-bit samples -- the first pass runs in 16 bits (dequant_idct16).
-template <bool PK16ROW = false>
+template <bool PK16ROW = false, bool X2 = false>
 __device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff = 0, const int colr = 2048)
 {
   if (PK16ROW) {
     if (rows_4_to_7_zero(rows)) {
-      if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff, colr); // (the pruned butterfly is as short as the products)
-      else dequant_idct16<4, 8>(rows, q, v, dcoff, colr);
-    } else dequant_idct16<8, 8>(rows, q, v, dcoff, colr);
+      if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4, X2>(rows, q, v, dcoff, colr); // (the pruned butterfly is as short as the products)
+      else dequant_idct16<4, 8, X2>(rows, q, v, dcoff, colr);
+    } else dequant_idct16<8, 8, X2>(rows, q, v, dcoff, colr);
     return;
   }
   if (rows_4_to_7_zero(rows)) {
-    if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4>(rows, q, v, dcoff, colr);
-    else dequant_idct<true, 4, 8>(rows, q, v, dcoff, colr);
-  } else dequant_idct<true, 8, 8>(rows, q, v, dcoff, colr);
+    if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4, X2>(rows, q, v, dcoff, colr);
+    else dequant_idct<true, 4, 8, X2>(rows, q, v, dcoff, colr);
+  } else dequant_idct<true, 8, 8, X2>(rows, q, v, dcoff, colr);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -711,7 +731,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  if (FAST) dequant_idct_sparse<!QDEV && P == 8>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, P == 8 ? LUMA_FOLD_R : 2048);
+  if (FAST) dequant_idct_sparse<!QDEV && P == 8, P == 8>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, P == 8 ? LUMA_FOLD_R2 : 2048); // (8 bit: doubled sums, luma13)
   else dequant_idct<false>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 128 << 7);
 
   // uniform frame base + 32-bit lane offsets (a frame of pixels is far below 4 GB)
@@ -812,7 +832,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
           int rr[8], gg[8], bb[8];
 #pragma unroll
           for (int x = 0; x < 8; x++) {
-            const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
+            const int yk = luma13(yv[l * 8 + x]); // (level shift and rounding are inside: LUMA_FOLD_R2)
             rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
             gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
             bb[x] = mad24(ub[x], L_CB_B, yk);
@@ -883,6 +903,19 @@ __device__ __forceinline__ unsigned tap13_pk(unsigned a, unsigned b, short r)
 {
   const s16x2 va = __builtin_bit_cast(s16x2, a), vb = __builtin_bit_cast(s16x2, b);
   const s16x2 t = (va + vb * (short)3 + r) >> (short)2;
+  return __builtin_bit_cast(unsigned, t);
+}
+// the same in two steps for a centre sample that two output lines share: 3 b + r once per rounding (v_pk_mad_u16), then
+// (a + that) >> 2 per line -- 3 instructions per tap where a shared 3 b costs 3.5
+__device__ __forceinline__ unsigned centre3_pk(unsigned b, short r)
+{
+  unsigned d;
+  asm("v_pk_mad_u16 %0, %1, 3, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(b), "n"(r));
+  return d;
+}
+__device__ __forceinline__ unsigned tap_sum_pk(unsigned a, unsigned w)
+{
+  const s16x2 t = (__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, w)) >> (short)2;
   return __builtin_bit_cast(unsigned, t);
 }
 
@@ -1004,7 +1037,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
+  dequant_idct_sparse<!QDEV, true>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R2);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1017,59 +1050,67 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     const u32x4 mid = *reinterpret_cast<const u32x4 *>(p + 4);
     d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
   };
-  unsigned cT[6], cC[6], cB[6];
-  load6(c_base, cT);
-  load6(c_base + F420_CPITCH, cC);
+  // Blocks that lie wholly inside the picture -- all of them, for every wave but those on the right and bottom edges -- take a
+  // copy of the loop without the per-line exec masks (wave-uniform choice: one ballot)
+  auto lines = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    unsigned cT[6], cC[6], cB[6];
+    load6(c_base, cT);
+    load6(c_base + F420_CPITCH, cC);
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
-    load6(c_base + (m + 2) * F420_CPITCH, cB);
+    for (int m = 0; m < 4; m++) {
+      load6(c_base + (m + 2) * F420_CPITCH, cB);
+      // 3 * centre + rounding, both roundings, for the two lines that share the centre line
+      unsigned w1[6], w2[6];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const int l = 2 * m + half;
-      // vertical filter (upsampler.cpp:149-165), both components at once
-      unsigned v[6];
+      for (int j = 0; j < 6; j++) { w1[j] = centre3_pk(cC[j], 1); w2[j] = centre3_pk(cC[j], 2); }
 #pragma unroll
-      for (int j = 0; j < 6; j++) v[j] = tap13_pk(half ? cB[j] : cT[j], cC[j], (short)(((j & 1) ^ half) ? 1 : 2));
-      // horizontal filter in place (upsampler.cpp:291-303); src[k] = v[k + 1]
-      unsigned u[8];
-      u[7] = tap13_pk(v[5], v[4], 1);
-      u[6] = tap13_pk(v[3], v[4], 2);
-      u[5] = tap13_pk(v[4], v[3], 1);
-      u[4] = tap13_pk(v[2], v[3], 2);
-      u[3] = tap13_pk(v[3], v[2], 1);
-      u[2] = tap13_pk(v[1], v[2], 2);
-      u[1] = tap13_pk(u[2], v[1], 1); // src[1] has already been overwritten by out[2]
-      u[0] = tap13_pk(v[0], v[1], 2);
-      if (l < nln) {
-        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
-        int rr[8], gg[8], bb[8];
+      for (int half = 0; half < 2; half++) {
+        const int l = 2 * m + half;
+        // vertical filter (upsampler.cpp:149-165), both components at once
+        unsigned v[6];
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
-          const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
-          rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
-          bb[x] = mad16_lo(u[x], L_CB_B, yk);
-          gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
-        }
-        if (fast_store) {
-          unsigned w[6];
-          rgb_shift17_sat_pack(rr, gg, bb, w);
-          u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
-          __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
-          __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
-          __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
-        } else {
+        for (int j = 0; j < 6; j++) v[j] = tap_sum_pk(half ? cB[j] : cT[j], ((j & 1) ^ half) ? w1[j] : w2[j]);
+        // horizontal filter in place (upsampler.cpp:291-303); src[k] = v[k + 1]
+        unsigned u[8];
+        u[7] = tap13_pk(v[5], v[4], 1);
+        u[6] = tap13_pk(v[3], v[4], 2);
+        u[5] = tap13_pk(v[4], v[3], 1);
+        u[4] = tap13_pk(v[2], v[3], 2);
+        u[3] = tap13_pk(v[3], v[2], 1);
+        u[2] = tap13_pk(v[1], v[2], 2);
+        u[1] = tap13_pk(u[2], v[1], 1); // src[1] has already been overwritten by out[2]
+        u[0] = tap13_pk(v[0], v[1], 2);
+        if (FULL || l < nln) {
+          int rr[8], gg[8], bb[8];
 #pragma unroll
-          for (int x = 0; x < 8; x++)
-            if (x < npx) {
-              dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
-            }
+          for (int x = 0; x < 8; x++) {
+            const int yk = luma13(yv[l * 8 + x]); // (level shift and rounding are inside: LUMA_FOLD_R2)
+            rr[x] = mad16_hi(u[x], L_CR_R, yk); // still scaled by 2^17
+            bb[x] = mad16_lo(u[x], L_CB_B, yk);
+            gg[x] = dot2_16(u[x], -L_CB_G, -L_CR_G, yk);
+          }
+          if (FULL || fast_store) {
+            unsigned w[6];
+            rgb_shift17_sat_pack(rr, gg, bb, w);
+            store24_nt(out_frame, out_off + (unsigned)l * (unsigned)a.row_stride, w);
+          } else {
+            uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+#pragma unroll
+            for (int x = 0; x < 8; x++)
+              if (x < npx) {
+                dst[3 * x] = (uint8_t)clamp255(rr[x] >> 17); dst[3 * x + 1] = (uint8_t)clamp255(gg[x] >> 17); dst[3 * x + 2] = (uint8_t)clamp255(bb[x] >> 17);
+              }
+          }
         }
       }
-    }
-    // slide the three-line window
+      // slide the three-line window
 #pragma unroll
-    for (int j = 0; j < 6; j++) { cT[j] = cC[j]; cC[j] = cB[j]; }
-  }
+      for (int j = 0; j < 6; j++) { cT[j] = cC[j]; cC[j] = cB[j]; }
+    }
+  };
+  if (__builtin_amdgcn_ballot_w64(npx != 8 || nln != 8) == 0) lines(std::true_type{});
+  else lines(std::false_type{});
 }
 
 // ==============================================================================================
@@ -1186,7 +1227,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
+  dequant_idct_sparse<!QDEV, true>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R2);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1229,11 +1270,10 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
         u[0] = tap13_pk(v[0], v[1], 2);
       }
       if (l < nln) {
-        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         int rr[8], gg[8], bb[8];
 #pragma unroll
         for (int x = 0; x < 8; x++) {
-          const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
+          const int yk = luma13(yv[l * 8 + x]); // (level shift and rounding are inside: LUMA_FOLD_R2)
           if (WIDE) {
             rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
             bb[x] = mad24(ub[x], L_CB_B, yk);
@@ -1247,11 +1287,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
         if (fast_store) {
           unsigned w[6];
           rgb_shift17_sat_pack(rr, gg, bb, w);
-          u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
-          __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
-          __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
-          __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+          store24_nt(out_frame, out_off + (unsigned)l * (unsigned)a.row_stride, w);
         } else {
+          uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
 #pragma unroll
           for (int x = 0; x < 8; x++)
             if (x < npx) {
@@ -1376,7 +1414,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
+  dequant_idct_sparse<!QDEV, true>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R2);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1404,7 +1442,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
       int rr[8], gg[8], bb[8];
 #pragma unroll
       for (int x = 0; x < 8; x++) {
-        const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
+        const int yk = luma13(yv[l * 8 + x]); // (level shift and rounding are inside: LUMA_FOLD_R2)
         rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
         bb[x] = mad24(ub[x], L_CB_B, yk);
         gg[x] = mad24(ur[x], -L_CR_G, mad24(ub[x], -L_CB_G, yk));
@@ -1556,7 +1594,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
+  dequant_idct_sparse<!QDEV, true>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R2);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -1593,11 +1631,10 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
         }
       }
       if (l < nln) {
-        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         int rr[8], gg[8], bb[8];
 #pragma unroll
         for (int x = 0; x < 8; x++) {
-          const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
+          const int yk = luma13(yv[l * 8 + x]); // (level shift and rounding are inside: LUMA_FOLD_R2)
           if (WIDE) {
             rr[x] = mad24(ur[x], L_CR_R, yk); // still scaled by 2^17
             bb[x] = mad24(ub[x], L_CB_B, yk);
@@ -1611,11 +1648,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
         if (fast_store) {
           unsigned w[6];
           rgb_shift17_sat_pack(rr, gg, bb, w);
-          u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
-          __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
-          __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
-          __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+          store24_nt(out_frame, out_off + (unsigned)l * (unsigned)a.row_stride, w);
         } else {
+          uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
 #pragma unroll
           for (int x = 0; x < 8; x++)
             if (x < npx) {
@@ -1710,7 +1745,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   // ------------------------------------------------------------------ legacy luma
   fetch_plane(coef + a.off_y, a.bw_y, a.bh_y);
   int yv[64];
-  dequant_idct_sparse<true>(rows, a.q[0], yv, 0, LUMA_FOLD_R);
+  dequant_idct_sparse<true, true>(rows, a.q[0], yv, 0, LUMA_FOLD_R2);
 
   const bool active = X0 < a.width && Y0 < a.height;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -1763,7 +1798,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
 #pragma unroll
       for (int xx = 0; xx < 8; xx++) {
         // legacy chain: L transformation, clamp to 8 bits, L table (output shift already subtracted)
-        const int yk = yv[l * 8 + xx] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
+        const int yk = luma13(yv[l * 8 + xx]); // (level shift and rounding are inside: LUMA_FOLD_R2)
         const int lr = clamp255(mad24(ur[xx], L_CR_R, yk) >> 17);
         const int lg = clamp255(mad24(ur[xx], -L_CR_G, mad24(ub[xx], -L_CB_G, yk)) >> 17);
         const int lb = clamp255(mad24(ub[xx], L_CB_B, yk) >> 17);
@@ -1950,7 +1985,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
     });
   }
   int yv[64];
-  dequant_idct_sparse<true>(rows, a.q[0], yv, 0, LUMA_FOLD_R);
+  dequant_idct_sparse<true, true>(rows, a.q[0], yv, 0, LUMA_FOLD_R2);
 
   const bool active = X0 < a.width && Y0 < a.height;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -2002,7 +2037,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
       int mm[24];
 #pragma unroll
       for (int xx = 0; xx < 8; xx++) {
-        const int yk = yv[l * 8 + xx] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
+        const int yk = luma13(yv[l * 8 + xx]); // (level shift and rounding are inside: LUMA_FOLD_R2)
         const int lr = clamp255(mad24(ur[xx], L_CR_R, yk) >> 17);
         const int lg = clamp255(mad24(ur[xx], -L_CR_G, mad24(ub[xx], -L_CB_G, yk)) >> 17);
         const int lb = clamp255(mad24(ub[xx], L_CB_B, yk) >> 17);
@@ -2124,7 +2159,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
     fetch(rows, a.off_y);
     const int X0 = gbx * 8, Y0 = gby * 8;
     if (X0 >= a.width || Y0 >= a.height) return;
-    dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R);
+    dequant_idct_sparse<!QDEV, true>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R2);
   }
   const int X0 = gbx * 8, Y0 = gby * 8;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -2138,7 +2173,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
       int rr[8], gg[8], bb[8];
 #pragma unroll
       for (int x = 0; x < 8; x++) {
-        const int yk = yv[l * 8 + x] << 13; // (level shift and rounding are inside: LUMA_FOLD_R)
+        const int yk = luma13(yv[l * 8 + x]); // (level shift and rounding are inside: LUMA_FOLD_R2)
         const unsigned cb2 = cbp[(l * 8 + x) >> 1], cr2 = crp[(l * 8 + x) >> 1];
         if (x & 1) {
           rr[x] = mad16_hi(cr2, L_CR_R, yk);
