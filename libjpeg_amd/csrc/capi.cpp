@@ -528,6 +528,7 @@ static const char *device_entropy_obstacle(const HostDecoder &h, size_t size, bo
     return "on-device entropy decoding: the stream is damaged; the host decoder walks it with the reference's resynchronisation (entropyparser.cpp:117-201)";
   if (f.progressive) return "on-device entropy decoding: progressive frames are decoded on the host";
   if (f.xt && !xt_part) return "on-device entropy decoding: not for this JPEG XT stream";
+  if (!h.residual_merged()) return "on-device entropy decoding: the legacy codestream has no EOI marker (the host decoder decides what is merged)";
   if (f.precision != 8 && !(xt_part && f.precision == 12)) return "on-device entropy decoding: 8-bit frames (12-bit residual frames of JPEG XT) only";
   if (h.scans.size() != 1 || h.hidden_bits()) return "on-device entropy decoding: the frame has more than one scan";
   const Scan &s = h.scans[0];

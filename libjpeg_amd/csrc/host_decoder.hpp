@@ -149,6 +149,8 @@ public:
   size_t stream_size() const { return size_; }
   HostDecoder *residual() const { return residual_; } // JPEG XT: decoder of the residual codestream
   int hidden_bits() const { return hidden_; }
+  // JPEG XT: the legacy codestream came to its EOI, i.e. the reference merges the residual codestream (else nothing: see decode_t)
+  bool residual_merged() const { return eoi_image_; }
 
   mijpeg_info info{};
   // restart-interval byte ranges of scan i (valid after parse(..., false)): [interval_begin[k], interval_ends(i)[k])
@@ -218,6 +220,10 @@ private:
   int spec_without_residual(const XtBox &spec);
   int spec_ltrafo_ = 255; // L transformation a merging specification WITHOUT a residual names (255: none; codestream/tables.cpp:1994-2021)
   int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
+  std::vector<std::pair<size_t, size_t>> seq_spans_; // what the scans of a sequentially walked stream read (RefWalker::spans)
+  StreamError residual_error_; // JPEG XT: what is wrong with the residual codestream's header, reported behind the legacy frame's decode
+  bool eoi_frame_ = true, eoi_image_ = true; // the walk's frame / image trailer stood at an EOI (RefWalker::frame_eoi / image_eoi)
+  std::vector<const XtBox *> hidden_src_; // this frame's hidden refinement scans in box order (elements of the legacy decoder's boxes_)
   template <class T> int decode_t(T *coef, int threads, const std::function<void(int, int)> &on_rows_done);
   template <class T> int decode_scan_speculative(T *coef, const Scan &s, int threads, uint32_t (&qmax_out)[MIJPEG_MAX_COMPONENTS],
                                                  VirtualIntervals *plan_only = nullptr, bool first_pass = false);

@@ -148,6 +148,9 @@ typedef struct {
   /* frame */
   int have_frame, frame_type;
   int need_dnl;
+  int eoi_frame, eoi_image; /* the frame trailer / the image trailer stood at an EOI marker: only there does the reference turn to
+                               the hidden refinement scans (marker/frame.cpp:1063-1070) and to the residual codestream
+                               (codestream/image.cpp:1416-1431) -- a file whose codestream runs out without one has neither */
   int known_height; /* decode pass of a DNL frame: the height the header pass (which decodes the first scan to find it) came to */
   int known_bh[OJ_MAX_COMP]; /* ... and the block rows it made room for */
   int progressive; /* SOF2 */
@@ -1175,7 +1178,7 @@ static int rs_frame_trailer(oj_parser *ps, oj_bs *io)
     case 0xffc5: case 0xffc6: case 0xffc7: case 0xffcd: case 0xffce: case 0xffcf:
       RS_WARN(ps); return 0;
     case 0xffda: return 1;
-    case 0xffd9: return 0;
+    case 0xffd9: ps->eoi_frame = 1; return 0;
     case 0xffff: bs_get(io); break;
     case 0xffd0: case 0xffd1: case 0xffd2: case 0xffd3: case 0xffd4: case 0xffd5: case 0xffd6: case 0xffd7:
       bs_getword(io); RS_WARN(ps); break;
@@ -1199,7 +1202,7 @@ static int rs_image_trailer(oj_parser *ps, oj_bs *io)
 {
   for (;;) {
     long marker = bs_peekword(io);
-    if (marker == 0xffd9) { bs_getword(io); return 0; }
+    if (marker == 0xffd9) { ps->eoi_image = 1; bs_getword(io); return 0; }
     else if (marker == 0xffff) bs_get(io);
     else if (marker == BS_EOF) { RS_WARN(ps); return 0; }
     else if (marker < 0xff00) {
@@ -1688,6 +1691,8 @@ typedef struct {
   int rbypass, rnoise;              /* RDCT box: residual DCT bypassed (control/residualblockhelper.cpp:203-231), noise shaping */
   int64_t outmax, outshift;         /* 2^(8 + extra bits) - 1 and its half */
   int is_float, clamp;              /* OCON: cast to float (half codes), clamping */
+  int no_residual;                  /* the legacy codestream never came to its EOI: the reference has not parsed the residual
+                                       codestream and merges nothing (rr = m_lOutDCShift, colortrafo/ycbcrtrafo.cpp:744-746) */
 } oj_xt;
 
 /* ResidualBlockHelper::DequantizeResidual without a DCT (control/residualblockhelper.cpp:203-231, quantiser of
@@ -1735,7 +1740,7 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
       oj_idct_plane(samp[c], planes[c], f->bw[c], f->bh[c], q, f->precision);
     if (f->dnl && f->rows[c] < f->bh[c]) /* rows nobody created: NULL -> sample value 0 (blockbitmaprequester.cpp:1097-1108, idct.cpp:336-338) */
       memset(samp[c] + (size_t)f->rows[c] * 8 * f->bw[c] * 8, 0, (size_t)(f->bh[c] - f->rows[c]) * f->bw[c] * 64 * sizeof(int32_t));
-    if (xt) { /* residual: same transform, level shift 2^(Pr-1) (control/residualblockhelper.cpp:191-202) */
+    if (xt && !xt->no_residual) { /* residual: same transform, level shift 2^(Pr-1) (control/residualblockhelper.cpp:191-202) */
       const oj_info *r = xt->rinfo;
       if (!r->quant_defined[r->tq[c]]) { rc = OJ_ERR_MALFORMED; goto out; }
       rsamp[c] = (int32_t *)malloc((size_t)r->bw[c] * r->bh[c] * 64 * sizeof(int32_t));
@@ -1762,7 +1767,7 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
         /* DNL frames: the upsampler was built with the height unknown (upsamplerbase.cpp:61-75) and its buffer has no
          * bottom edge -- the line below the picture is whatever the next block row holds (:138-156, :218-228) */
         oj_upsample_block(blk[c], samp[c], f->bw[c] * 8, f->cw[c], f->dnl ? f->bh[c] * 8 : f->ch[c], f->subx[c], f->suby[c], X0, Y0);
-        if (xt) {
+        if (xt && !xt->no_residual) {
           const oj_info *r = xt->rinfo;
           oj_upsample_block(rblk[c], rsamp[c], r->bw[c] * 8, r->cw[c], r->ch[c], r->subx[c], r->suby[c], X0, Y0);
         }
@@ -1787,6 +1792,7 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
             const int64_t rmax16 = ((((int64_t)1 << r->precision)) << 4) - 1; /* ((m_lRMax + 1) << COLOR_BITS) - 1 */
             const int64_t omax16 = ((xt->outmax + 1) << 4) - 1;
             int64_t rr[3], q3[3], lv[3];
+            if (xt->no_residual) { rr[0] = rr[1] = rr[2] = xt->outshift; goto merge; }
             /* Q tables (APPLY_LUT: index clamped to the table); the identity, 2^(Pr + 4) -> 2^(16 + 4), scales by 2^(16 - Pr)
              * (parametrictonemappingbox.cpp:387-430) */
             for (c = 0; c < 3; c++) {
@@ -1807,6 +1813,7 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
               const int64_t idx = clampmax(rr[c], omax16);
               rr[c] = xt->r2lut[c] ? xt->r2lut[c][idx] : (idx + 8) >> 4;
             }
+          merge:
             for (c = 0; c < 3; c++) lv[c] = xt->ltable[c] ? xt->ltable[c][clampmax(v[c], maxval)] : v[c];
             /* C transformation, FIX_TO_INT (the identity leaves the values alone: (x * 8192 + 4096) >> 13 == x) */
             for (c = 0; c < 3; c++)
@@ -2401,10 +2408,30 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   xt.rbypass = (rdct >> 4) == 3; xt.rnoise = rdct & 1;
   /* the residual codestream is needed for the table dimensions */
   rc = oj_read_info(resi->data, resi->len, &rinfo);
-  if (rc) goto out;
   /* Image::ParseResidualStream (codestream/image.cpp:1289-1299) compares right behind the residual frame header, where a
    * residual codestream with a DNL marker still has zero lines: "residual image dimensions do not match ..." */
-  if (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto out; }
+  if (!rc && (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height)) { rinfo.ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; }
+  if (rc) {
+    /* ... but the reference only gets there behind the legacy codestream's EOI: whatever stops the legacy codestream first
+     * is what it reports (and without an EOI it never looks at the residual: not followed here) */
+    const int rrc = rc, rerr = rinfo.ref_error;
+    oj_parser ls;
+    oj_info ltmp;
+    memset(&ls, 0, sizeof(ls)); memset(&ltmp, 0, sizeof(ltmp));
+    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
+    for (c = 0; c < 3; c++) {
+      planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
+      if (!planes[c]) { rc = OJ_ERR_NOMEM; goto out; }
+    }
+    rc = walk(&ls, planes);
+    if (rc) info->ref_error = ltmp.ref_error;
+    if (!rc && ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) info->ref_error = ls.err; }
+    if (!rc) {
+      if (ls.eoi_image) { rc = rrc; info->ref_error = rerr; }
+      else rc = OJ_ERR_UNSUPPORTED;
+    }
+    goto out;
+  }
   for (c = 0; c < 3; c++) {
     /* L: ScaledTableOf(8 + hidden bits, 16, 0, 0), default = identity with e = 1; Q: (Pr + hidden bits, 16, 4, 4) and
      * R2: (16, 16, 4, 0), defaults = identities with e = 0 (colortransformerfactory.cpp:312-345, 435-474, 486-520) */
@@ -2452,10 +2479,16 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
       memset(rplanes[c], 0, (size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
     }
     rc = walk(&ls, planes);
-    if (!rc) rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes);
-    if (!rc) rc = walk(&rs, rplanes);
-    if (!rc) rc = decode_hidden_scans(&rs, boxes, ps.nboxes, BOXID('R', 'F', 'I', 'N'), rplanes);
-    if (rc) goto out;
+    if (rc) info->ref_error = ltmp.ref_error;
+    /* (hidden scans and residual only behind an EOI, see eoi_frame / eoi_image) */
+    if (!rc && ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) info->ref_error = ls.err; }
+    if (!rc && ls.eoi_image) {
+      rc = walk(&rs, rplanes);
+      if (rc) info->ref_error = rtmp.ref_error;
+      if (!rc && rs.eoi_frame) { rc = decode_hidden_scans(&rs, boxes, ps.nboxes, BOXID('R', 'F', 'I', 'N'), rplanes); if (rc) info->ref_error = rs.err; }
+    } else if (!rc)
+      xt.no_residual = 1;
+    if (rc) goto out; /* (the reference's error code travels in info->ref_error) */
     memcpy(info->cquant, ltmp.cquant, sizeof(ltmp.cquant)); memcpy(info->comp_seen, ltmp.comp_seen, sizeof(ltmp.comp_seen));
     memcpy(rinfo.cquant, rtmp.cquant, sizeof(rtmp.cquant)); memcpy(rinfo.comp_seen, rtmp.comp_seen, sizeof(rtmp.comp_seen));
     info->scan_state_valid = ltmp.scan_state_valid; rinfo.scan_state_valid = rtmp.scan_state_valid;
