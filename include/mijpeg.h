@@ -136,6 +136,9 @@ typedef struct mijpeg_xt_params {
   const int32_t *qtable[3];  /* HOST memory, owned by the decoder object: Q table per component, qtable_entries each;
                                 NULL = the identity (a shift)                                                        */
   const int32_t *r2table[3]; /* HOST memory: R2 table per component, 2^20 entries; NULL = the identity (x + 8) >> 4  */
+  int32_t no_residual;       /* 1: the legacy codestream never came to an EOI marker, the reference has not parsed the residual
+                                codestream and merges nothing (codestream/image.cpp:1416-1431; rr = m_lOutDCShift,
+                                colortrafo/ycbcrtrafo.cpp:744-746): the residual planes are zeros and the merge ignores them     */
 } mijpeg_xt_params;
 
 /* ---- decoder object (one image at a time; one object = one host thread at a time) ---------- */

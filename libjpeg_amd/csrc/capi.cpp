@@ -1703,6 +1703,7 @@ static bool use_fusedxt(const mijpeg_batch *b)
   const mijpeg_xt_params &x = *b->xt;
   const mijpeg_info &r = x.residual;
   if (x.general) return false; // free-form matrices, table gathers, DCT bypass: xt_merge_general_kernel
+  if (x.no_residual) return false; // (a legacy codestream without its EOI: the unfused merge kernels know how to merge nothing)
   // hidden bits in the RESIDUAL frame (-rR n: 13..16-bit samples, int32 coefficients) have a kernel of their own
   // (fusedxtw420_kernel); hidden bits in the legacy frame change its precision and stay on the three-kernel path
   if (x.hidden_bits || x.residual_hidden_bits < 0 || x.residual_hidden_bits > 4 || (x.residual_wide != 0) != (x.residual_hidden_bits > 0) ||
@@ -1955,6 +1956,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       a.out_max = x.out_max;
       a.is_float = x.is_float;
       a.rprecision = rprec;
+      a.xt_no_residual = x.no_residual;
       a.legacy32 = lprec == 8 && f.range_max[0] < 16384 && f.range_max[1] < 16384 && f.range_max[2] < 16384 &&
                    !(b->flags & MIJPEG_FLAG_FORCE_SAFE);
       a.ltable = (const int32_t *)b->workspace;

@@ -3158,6 +3158,7 @@ __global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) rr[c] = (min(max(rr[c], 0), omax16) + 8) >> 4;
+    if (a.xt_no_residual) rr[0] = rr[1] = rr[2] = a.out_shift; // nothing to merge (colortrafo/ycbcrtrafo.cpp:744-746)
     // legacy chain
     int v[3];
     if (a.ycbcr) {
@@ -3238,6 +3239,7 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
       const int idx = (int)min(max(rr[c], 0ll), (long long)omax16);
       rr[c] = a.r2lut[c] ? (long long)a.r2lut[c][idx] : (long long)((idx + 8) >> 4);
     }
+    if (a.xt_no_residual) rr[0] = rr[1] = rr[2] = a.out_shift; // nothing to merge (colortrafo/ycbcrtrafo.cpp:744-746)
     // legacy chain: L transformation (FIX_COLOR_TO_INT), L table, C transformation (FIX_TO_INT)
     long long v[3];
     if (a.ycbcr) {

@@ -78,6 +78,7 @@ struct GenericArgs {
   int32_t dcshift;             // 2^(P-1) << 4: chroma level shift seen by the colour transformation
   // JPEG XT profile C merge (colortrafo/ycbcrtrafo.cpp:750-955)
   int32_t xt, rtrafo_ycbcr, out_shift, out_max, is_float, rprecision;
+  int32_t xt_no_residual;      // mijpeg_xt_params::no_residual: the residual chain's result is the output shift
   int32_t legacy32;            // legacy colour stage may run in 32 bits (8-bit frame that passed the range check)
   int32_t ltable_entries;      // entries per L table: 256 << hidden bits of the legacy frame
   int32_t wide_first, wide_count; // planes [wide_first, wide_first + wide_count) hold int32 coefficients at coef_off (in

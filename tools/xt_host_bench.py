@@ -39,7 +39,7 @@ def main():
     print("stream:", os.path.getsize(STREAM), "bytes;", os.cpu_count(), "cores")
     variants = [("as built", {}), ("no mask refinement", {"MIJPEG_NO_REFINE_MASKS": "1"}), ("no parallel first pass", {"MIJPEG_NO_SPEC_FIRST_PASS": "1"}),
                 ("neither (round 3)", {"MIJPEG_NO_REFINE_MASKS": "1", "MIJPEG_NO_SPEC_FIRST_PASS": "1"}),
-                ("no scan pipeline", {"MIJPEG_NO_SCAN_PIPELINE": "1"}), ("no chain affinity", {"MIJPEG_NO_CHAIN_AFFINITY": "1"})]
+                ("no scan pipeline", {"MIJPEG_NO_SCAN_PIPELINE": "1"})]
     for name, env in variants:
         print(name)
         r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, STREAM, threads)], env=dict(os.environ, **env), capture_output=True, text=True)
