@@ -149,6 +149,42 @@ __device__ __forceinline__ void store24_nt(uint8_t *__restrict__ base, unsigned 
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx2 %0, %3, %2 offset:16 nt" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
 }
 
+// The same 24 bytes when the line's address is NOT a multiple of four (m = address & 3: a packed frame whose width is not a
+// multiple of four pixels has such lines): gfx950 stores dwords at any address, but at a third more time per launch
+// (`profiles/r03/layouts.txt`, W = 7678).  The sixteen lanes of a row own 384 consecutive bytes; each lane takes the last m bytes
+// of its left neighbour (one DPP move, row_shr:1), shifts its six dwords by m bytes (v_alignbyte_b32) and stores 24 bytes at
+// the dword boundary m bytes in front of its own position.  The row's first lane has no neighbour inside the wave: it stores
+// its first 4 - m bytes as bytes and the rest aligned; the row's last lane adds the m bytes that are left over.  bx = lane & 15;
+// every lane of the wave must be active (the caller checks), m is wave-uniform and 1..3.
+__device__ __forceinline__ void store24_nt_shifted(uint8_t *__restrict__ base, unsigned off, const unsigned (&w)[6], int bx, int m)
+{
+  const unsigned left = (unsigned)__builtin_amdgcn_update_dpp((int)w[5], (int)w[5], 0x111, 0xF, 0xF, false); // row_shr:1
+  const unsigned sh = (unsigned)(4 - m);
+  unsigned d[6];
+  d[0] = __builtin_amdgcn_alignbyte(w[0], left, sh);
+#pragma unroll
+  for (int k = 1; k < 6; k++) d[k] = __builtin_amdgcn_alignbyte(w[k], w[k - 1], sh);
+  const unsigned at = off - (unsigned)m; // a multiple of four
+  if (bx != 0) store24_nt(base, at, d);
+  else {
+    // bytes m..3 of the first dword are this lane's own first 4 - m bytes
+    uint8_t *p = base + off;
+    if (m == 1) { p[0] = (uint8_t)w[0]; *reinterpret_cast<uint16_t *>(p + 1) = (uint16_t)(w[0] >> 8); }
+    else if (m == 2) *reinterpret_cast<uint16_t *>(p) = (uint16_t)w[0];
+    else p[0] = (uint8_t)w[0];
+    u32x4 *q = reinterpret_cast<u32x4 *>(base + (at + 4)); // (dword aligned; 16-byte alignment is not needed)
+    __builtin_nontemporal_store(u32x4{d[1], d[2], d[3], d[4]}, reinterpret_cast<u32x4_any *>(q));
+    __builtin_nontemporal_store(d[5], reinterpret_cast<unsigned *>(base + (at + 20)));
+  }
+  if (bx == 15) { // the last m bytes of the row
+    uint8_t *p = base + (at + 24);
+    const unsigned t = w[5] >> (8 * sh);
+    if (m == 1) p[0] = (uint8_t)t;
+    else if (m == 2) *reinterpret_cast<uint16_t *>(p) = (uint16_t)t;
+    else { *reinterpret_cast<uint16_t *>(p) = (uint16_t)t; p[2] = (uint8_t)(t >> 16); }
+  }
+}
+
 // floor((x + 2^(n-1)) / 2^n) with the addition carried out beyond 32 bits, as the reference's
 // `(x + (1L << (n-1))) >> n` does on LP64 (dct/idct.cpp:70-78).
 template <bool FAST, int N>
@@ -1052,8 +1088,10 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   };
   // Blocks that lie wholly inside the picture -- all of them, for every wave but those on the right and bottom edges -- take a
   // copy of the loop without the per-line exec masks (wave-uniform choice: one ballot)
-  auto lines = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
+  // (a third copy, FULL with every lane active, for frames whose lines do not all start on a dword: store24_nt_shifted)
+  const unsigned base_lo = (unsigned)(uintptr_t)out_frame;
+  auto lines = [&](auto full_tag, auto shift_tag) {
+    constexpr bool FULL = decltype(full_tag)::value, SHIFTED = decltype(shift_tag)::value;
     unsigned cT[6], cC[6], cB[6];
     load6(c_base, cT);
     load6(c_base + F420_CPITCH, cC);
@@ -1093,7 +1131,10 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
           if (FULL || fast_store) {
             unsigned w[6];
             rgb_shift17_sat_pack(rr, gg, bb, w);
-            store24_nt(out_frame, out_off + (unsigned)l * (unsigned)a.row_stride, w);
+            const unsigned off = out_off + (unsigned)l * (unsigned)a.row_stride;
+            const int m = SHIFTED ? (int)__builtin_amdgcn_readfirstlane((base_lo + (unsigned)l * (unsigned)a.row_stride) & 3u) : 0;
+            if (SHIFTED && m) store24_nt_shifted(out_frame, off, w, bx, m);
+            else store24_nt(out_frame, off, w);
           } else {
             uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
 #pragma unroll
@@ -1109,8 +1150,10 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
       for (int j = 0; j < 6; j++) { cT[j] = cC[j]; cC[j] = cB[j]; }
     }
   };
-  if (__builtin_amdgcn_ballot_w64(npx != 8 || nln != 8) == 0) lines(std::true_type{});
-  else lines(std::false_type{});
+  const bool whole = __builtin_amdgcn_ballot_w64(npx != 8 || nln != 8) == 0;
+  if (whole && ((base_lo | (unsigned)a.row_stride) & 3u) && __builtin_amdgcn_ballot_w64(true) == ~0ull) lines(std::true_type{}, std::true_type{});
+  else if (whole) lines(std::true_type{}, std::false_type{});
+  else lines(std::false_type{}, std::false_type{});
 }
 
 // ==============================================================================================

@@ -458,6 +458,31 @@ def test_unaligned_output_stride(oracle, sub):
         assert (res[:, line:] == 0xAB).all() and (flat[:base] == 0xAB).all() and (flat[base + 77 * row:] == 0xAB).all()
 
 
+def test_unaligned_output_stride_whole_tiles(oracle):
+    """The same with tiles that lie wholly inside the picture (every lane of a wave holds a whole block): lines at byte addresses
+    1, 2, 3 mod 4 take the shifted store of the packed 4:2:0 kernel -- a DPP move from the left neighbour, v_alignbyte_b32, aligned
+    stores, the row's first and last bytes by hand (store24_nt_shifted).  Widths 398 and 401 (packed lines of 1194 = 2 mod 4 and
+    1203 = 3 mod 4 bytes), padded strides of every residue, base addresses + 0..3; nothing outside the picture is written."""
+    torch = _torch()
+    for w, h in ((398, 300), (401, 272)):
+        d = api.Decoder(0)
+        data = synth.synth_jpeg(w, h, 21 + w, 85, "420", 0)
+        f = d.read(data)
+        assert api.kernel_name(f) == "fused420p_kernel"
+        coef = torch.from_numpy(np.concatenate([d.coefficients(c).reshape(-1) for c in range(3)])).cuda()
+        d.close()
+        line = w * 3
+        exp = oracle.decode(data).reshape(h, line)
+        for row, base in ((line, 0), (line, 1), (line, 2), (line, 3), (line + 1, 0), (line + 3, 2), (line + 5, 1), (line + 6, 0)):
+            buf = torch.full((h * row + 16,), 0xAB, dtype=torch.uint8, device="cuda")
+            api.launch_reconstruct(f, coef.data_ptr(), buf.data_ptr() + base, 1, row, h * row, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            flat = buf.cpu().numpy()
+            res = flat[base:base + h * row].reshape(h, row)
+            assert np.array_equal(res[:, :line], exp), f"{w}x{h}: row stride {row}, base + {base}: {np.count_nonzero(res[:, :line] != exp)} bytes differ"
+            assert (res[:, line:] == 0xAB).all() and (flat[:base] == 0xAB).all() and (flat[base + h * row:] == 0xAB).all()
+
+
 @pytest.mark.parametrize("generic", [False, True])
 def test_adversarial_coefficients_safe_flavour(oracle, generic):
     """Coefficients no encoder would produce (|c| up to 32767, q up to 255): intermediates wrap around 2^32.
