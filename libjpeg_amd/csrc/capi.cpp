@@ -310,7 +310,9 @@ void mijpeg_destroy(mijpeg_decoder *d)
 int mijpeg_set_input(mijpeg_decoder *d, const uint8_t *data, size_t size)
 {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
-  if (!data || !size) return set_error(d, MIJPEG_ERR_STREAM_EMPTY, "empty input stream");
+  if (!data) return set_error(d, MIJPEG_ERR_STREAM_EMPTY, "empty input stream");
+  // a stream of no bytes: the reference's first GetWord meets the end of file, which is its SOI error (codestream/decoder.cpp:92-96)
+  if (!size) return set_error(d, MIJPEG_ERR_MALFORMED_STREAM, "stream does not contain a JPEG file, SOI marker missing");
   d->data = data;
   d->size = size;
   d->parsed = d->decoded = d->uploaded = d->img_valid = d->model_valid = false;
@@ -1600,7 +1602,7 @@ static bool fits32(const mijpeg_batch *b)
   if (b->out_row_stride < 0) return false; // bottom-up bitmaps: the offsets are unsigned
   // (a batch description without strides -- mijpeg_kernel_name, mijpeg_workspace_bytes asked ahead of time -- is taken to
   // have tightly packed lines)
-  const uint64_t line = (uint64_t)f.width * (uint64_t)f.components * ((f.precision > 8 || f.xt) ? 2u : 1u);
+  const uint64_t line = (uint64_t)f.width * (uint64_t)f.components * (f.xt ? (uint64_t)(f.sample_bytes > 1 ? 2 : 1) : f.precision > 8 ? 2u : 1u);
   const uint64_t rs = b->out_row_stride ? (uint64_t)b->out_row_stride : line;
   return (uint64_t)f.height * rs + line <= lim;
 }
@@ -1785,7 +1787,7 @@ static size_t xt_table_bytes(const mijpeg_batch *b)
   size_t n = 0;
   for (int c = 0; c < 3; c++) {
     if (b->xt->qtable[c]) n += (size_t)b->xt->qtable_entries * sizeof(int32_t);
-    if (b->xt->r2table[c]) n += ((size_t)1 << 20) * sizeof(int32_t);
+    if (b->xt->r2table[c]) n += ((size_t)(b->xt->out_max + 1) << 4) * sizeof(int32_t);
   }
   return n;
 }
@@ -1906,7 +1908,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     a.frames = b->frames;
     a.qdev = qdev;
     a.nplanes = f.components;
-    a.sample_bytes = f.precision > 8 || f.xt ? 2 : 1;
+    a.sample_bytes = f.xt ? (b->xt->out_max > 255 ? 2 : 1) : f.precision > 8 ? 2 : 1;
     a.maxval = (1 << f.precision) - 1;
     a.dcshift = (1 << (f.precision - 1)) << 4;
     int64_t sample_off = 0;
@@ -1989,7 +1991,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
             tp += n;
           }
           if (x.r2table[c] && !a.r2lut[c]) {
-            const size_t n = ((size_t)1 << 20) * sizeof(int32_t);
+            const size_t n = ((size_t)(x.out_max + 1) << 4) * sizeof(int32_t);
             if (hipMemcpyAsync(tp, x.r2table[c], n, hipMemcpyHostToDevice, s) != hipSuccess) return MIJPEG_ERR_DEVICE;
             a.r2lut[c] = (const int32_t *)tp;
             tp += n;

@@ -185,7 +185,8 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
       have += (size_t)got;
     }
     p->stream.resize(have);
-    if (p->stream.empty()) return p->fail(JPGERR_STREAM_EMPTY, "the I/O hook delivered no data");
+    // (codestream/decoder.cpp:92-96: an empty stream fails the SOI test like any other non-JPEG)
+    if (p->stream.empty()) return p->fail(JPGERR_MALFORMED_STREAM, "stream does not contain a JPEG file, SOI marker missing");
     p->pulled = true;
     p->phase = Impl::P_SOI;
     p->cursor = 0;
@@ -352,8 +353,16 @@ JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
   tags->SetTagData(JPGTAG_IMAGE_WIDTH, f.width);
   tags->SetTagData(JPGTAG_IMAGE_HEIGHT, f.height);
   tags->SetTagData(JPGTAG_IMAGE_DEPTH, f.components);
-  // JPEG XT: the image precision includes the extra range bits of the output conversion (8 + 8)
-  tags->SetTagData(JPGTAG_IMAGE_PRECISION, f.xt ? 16 : f.precision);
+  // JPEG XT: the image precision includes the extra range bits of the output conversion (8 + 8 for the encoder's HDR files,
+  // 8 + 0 for its integer ones)
+  int prec = f.precision;
+  if (f.xt) {
+    mijpeg_xt_params x;
+    prec = 16;
+    if (mijpeg_get_xt_params(p->dec, &x) == MIJPEG_OK)
+      for (prec = 1; (1 << prec) <= x.out_max; prec++) {}
+  }
+  tags->SetTagData(JPGTAG_IMAGE_PRECISION, prec);
   const JPG_LONG n = tags->GetTagData(JPGTAG_IMAGE_SUBLENGTH, 0);
   if (n > 0) {
     uint8_t *sx = (uint8_t *)tags->GetTagPtr(JPGTAG_IMAGE_SUBX), *sy = (uint8_t *)tags->GetTagPtr(JPGTAG_IMAGE_SUBY);

@@ -142,11 +142,16 @@ __device__ __forceinline__ void rgb_shift17_sat_pack(const int (&rr)[8], const i
 // ... and their way out: 24 bytes at base + off, base uniform (SGPR pair), off per lane (32 bits, the fused kernels' frames
 // fit: fits32 in capi.cpp).  The store instructions take the pair and the offset as they are (`saddr` form); written as a
 // pointer the compiler widens the offset and adds in 64 bits first, three VALU instructions per line of a block.
+// NT = false: ordinary stores.  A frame whose lines are not multiples of 128 bytes long has tile rows that share their first and
+// last cache line with the neighbouring tiles' rows; streaming stores push those half-written lines out one half at a time,
+// ordinary ones let the L2 put the halves together first (the neighbouring tiles run on the same XCD, one after the other).
+template <bool NT = true>
 __device__ __forceinline__ void store24_nt(uint8_t *__restrict__ base, unsigned off, const unsigned (&w)[6])
 {
   const u32x4 lo = {w[0], w[1], w[2], w[3]};
   const u32x2 hi = {w[4], w[5]};
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx2 %0, %3, %2 offset:16 nt" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
+  if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx2 %0, %3, %2 offset:16 nt" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx2 %0, %3, %2 offset:16" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
 }
 
 // The same 24 bytes when the line's address is NOT a multiple of four (m = address & 3: a packed frame whose width is not a
@@ -165,7 +170,7 @@ __device__ __forceinline__ void store24_nt_shifted(uint8_t *__restrict__ base, u
 #pragma unroll
   for (int k = 1; k < 6; k++) d[k] = __builtin_amdgcn_alignbyte(w[k], w[k - 1], sh);
   const unsigned at = off - (unsigned)m; // a multiple of four
-  if (bx != 0) store24_nt(base, at, d);
+  if (bx != 0) store24_nt<false>(base, at, d);
   else {
     // bytes m..3 of the first dword are this lane's own first 4 - m bytes
     uint8_t *p = base + off;
@@ -173,8 +178,8 @@ __device__ __forceinline__ void store24_nt_shifted(uint8_t *__restrict__ base, u
     else if (m == 2) *reinterpret_cast<uint16_t *>(p) = (uint16_t)w[0];
     else p[0] = (uint8_t)w[0];
     u32x4 *q = reinterpret_cast<u32x4 *>(base + (at + 4)); // (dword aligned; 16-byte alignment is not needed)
-    __builtin_nontemporal_store(u32x4{d[1], d[2], d[3], d[4]}, reinterpret_cast<u32x4_any *>(q));
-    __builtin_nontemporal_store(d[5], reinterpret_cast<unsigned *>(base + (at + 20)));
+    *reinterpret_cast<u32x4_any *>(q) = u32x4{d[1], d[2], d[3], d[4]};
+    *reinterpret_cast<unsigned *>(base + (at + 20)) = d[5];
   }
   if (bx == 15) { // the last m bytes of the row
     uint8_t *p = base + (at + 24);
@@ -1134,6 +1139,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
             const unsigned off = out_off + (unsigned)l * (unsigned)a.row_stride;
             const int m = SHIFTED ? (int)__builtin_amdgcn_readfirstlane((base_lo + (unsigned)l * (unsigned)a.row_stride) & 3u) : 0;
             if (SHIFTED && m) store24_nt_shifted(out_frame, off, w, bx, m);
+            else if (SHIFTED) store24_nt<false>(out_frame, off, w);
             else store24_nt(out_frame, off, w);
           } else {
             uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
@@ -3303,6 +3309,9 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
         m = min(max(m, (long long)minf), (long long)pinf);
         const short w = (short)m;
         dst[3 * x + c] = (uint16_t)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS
+      } else if (a.sample_bytes == 1) { // an output of at most eight bits (OCON without extra range bits: jpeg -r on 8-bit input)
+        reinterpret_cast<uint8_t *>(a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride)[3 * (X0 + x) + c] =
+            (uint8_t)min(max(m, 0ll), (long long)a.out_max);
       } else {
         dst[3 * x + c] = (uint16_t)min(max(m, 0ll), (long long)a.out_max);
       }

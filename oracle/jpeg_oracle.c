@@ -2399,7 +2399,8 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   xt.outshift = (xt.outmax + 1) >> 1;
   xt.is_float = (ocon & 0x04) ? 1 : 0;
   xt.clamp = (ocon & 0x02) ? 1 : 0;
-  if (!xt.clamp || xt.outmax != 65535) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  if (!xt.clamp) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* (wrap-around output: not followed) */
+  if (xt.is_float && xt.outmax != 65535) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   /* free-form matrices run through the YCbCr branches of the transformer (colortransformerfactory.cpp:1036-1058) */
   xt.ltrafo_ycbcr = ltrafo != 1; xt.rtrafo_ycbcr = rtrafo != 1;
   memcpy(xt.lmat, ltrafo >= 5 ? mtx[ltrafo] : ltrafo == 2 ? std_ycc : std_id, sizeof(xt.lmat));
@@ -2438,22 +2439,23 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
     oj_nlt id1, id0;
     const oj_nlt *t;
     const int pr = rinfo.precision + hidden_r;
+    const int outbits = 8 + (ocon >> 4); /* JPGTAG_IMAGE_PRECISION of the output: 8 + extra range bits (integer JPEG XT of an 8-bit picture: 8) */
     memset(&id1, 0, sizeof(id1)); id1.kind = 2; id1.type = 2; id1.e = 1;
     memset(&id0, 0, sizeof(id0)); id0.kind = 2; id0.type = 2; id0.e = 0;
     t = lidx[c] == 255 ? &id1 : &nlt[lidx[c]];
     if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; } /* OBJECT_DOESNT_EXIST "the L lookup table specified in the codestream does not exist" */
-    owned[c] = scaled_table(t, 8 + hidden_l, 16, 0, 0, &rc);
+    owned[c] = scaled_table(t, 8 + hidden_l, outbits, 0, 0, &rc);
     if (!owned[c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
     xt.ltable[c] = owned[c];
     if (pr > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     t = qidx[c] == 255 ? &id0 : &nlt[qidx[c]];
     if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; }
-    owned[3 + c] = scaled_table(t, pr, 16, 4, 4, &rc);
+    owned[3 + c] = scaled_table(t, pr, outbits, 4, 4, &rc);
     if (!owned[3 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
     xt.qlut[c] = owned[3 + c];
     t = r2idx[c] == 255 ? &id0 : &nlt[r2idx[c]];
     if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; }
-    owned[6 + c] = scaled_table(t, 16, 16, 4, 0, &rc);
+    owned[6 + c] = scaled_table(t, outbits, outbits, 4, 0, &rc);
     if (!owned[6 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
     xt.r2lut[c] = owned[6 + c];
   }
