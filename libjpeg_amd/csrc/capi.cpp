@@ -1773,7 +1773,7 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (b->info.coef_wide) return "idct_planes_long_kernel+upsample_color_kernel";
   if (use_fused420(b)) return "fused420_kernel";
   if (use_fused444(b)) return "fused444_kernel";
-  if (b->info.xt) return "idct_planes_kernel+xt_merge_kernel";
+  if (b->info.xt) return b->xt && b->xt->general ? "idct_planes_kernel+xt_merge_general_kernel" : "idct_planes_kernel+xt_merge_kernel";
   if (b->quant_dev || (b->flags & MIJPEG_FLAG_FORCE_GENERIC) || getenv("MIJPEG_NO_FUSED_TILE") || dnl_row_missing(b->info)) return "idct_planes_kernel+upsample_color_kernel";
   return "fused_tile_kernel";
 }
