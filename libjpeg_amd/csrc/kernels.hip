@@ -454,6 +454,34 @@ __device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], cons
 }
 
 // ----------------------------------------------------------------------------------------------
+// Tile order of the fused kernels.  Consecutive workgroup ids land on different XCDs (id % 8).  XCD x takes every eighth ROW of
+// tiles, over the frames of the launch: neighbouring tiles -- which read each other's halo blocks -- share an L2, and the eight
+// XCDs work on eight adjacent tile rows of the same frame at any time.  Rounds 1-3 gave every XCD one contiguous eighth of the
+// launch (its own frame, with 8 frames per launch): same L2 sharing, but the traffic-only copy of the headline kernel
+// (tools/microbench/stream_ceiling) showed HBM delivering 3-4 % less for eight far-apart write fronts than for one, and the
+// kernel itself runs at that copy's speed: 0.644-0.648 -> 0.667-0.674 of 8 TB/s on one box (profiles/r04/headline_variants.txt).
+// The single-component kernel keeps the old order (its launch measured 3 % slower with the new one, profiles/r04/layouts_tile_order.txt);
+// MIJ_TILE_ORDER 1 gives it to all kernels for A-B builds.  ~0u: a padding workgroup (the launch has whole groups of 8 tile rows).
+// ----------------------------------------------------------------------------------------------
+#ifndef MIJ_TILE_ORDER
+#define MIJ_TILE_ORDER 2
+#endif
+template <int ORDER = MIJ_TILE_ORDER> __device__ __forceinline__ unsigned tile_of_workgroup(unsigned b, unsigned tiles_x, unsigned tile_rows)
+{
+  if (ORDER == 2) {
+    const unsigned x = b & 7, i = b >> 3; // i-th workgroup of XCD x
+    const unsigned row8 = i / tiles_x, col = i - row8 * tiles_x, row = row8 * 8 + x;
+    return row < tile_rows ? row * tiles_x + col : ~0u;
+  }
+  const unsigned total = tiles_x * tile_rows, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+  return x * q + min(x, r) + i;
+}
+template <int ORDER = MIJ_TILE_ORDER> static unsigned workgroups_for_tiles(unsigned tiles_x, unsigned tile_rows)
+{
+  return ORDER == 2 ? ((tile_rows + 7u) / 8u) * 8u * tiles_x : tiles_x * tile_rows;
+}
+
+// ----------------------------------------------------------------------------------------------
 // Coalesced block fetch: the wave reads 64 blocks x 128 B with eight 1-KiB-per-instruction loads
 // (lane i takes the i-th 16-byte chunk), then hands every lane the eight rows of ITS block through a
 // 2 KB LDS staging buffer, 16 blocks at a time.  The chunk position inside a block is XOR-swizzled
@@ -462,6 +490,32 @@ __device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], cons
 // chunkptr(m) returns the address of the lane's m-th 16-byte chunk; blocks outside the plane are redirected to a
 // clamped (valid) block whose result is simply never used, so the loads need no predication.
 // ----------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void load_blocks(u32x4 (&raw)[8], F chunkptr)
+{
+#pragma unroll
+  for (int m = 0; m < 8; m++) raw[m] = *chunkptr(m); // m-th load of this lane: chunk (lane & 7) of local block (lane >> 3) + 8 m
+}
+// (the two halves of fetch_blocks: a kernel that has other work between issuing the loads and needing the rows calls them apart)
+__device__ __forceinline__ void transpose_blocks(u32x4 (&rows)[8], u32x4 *stage, int lane, const u32x4 (&raw)[8])
+{
+  const int k = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int nb = (lane >> 3) + 8 * t;
+      stage[nb * 8 + (k ^ (nb & 7))] = raw[2 * j + t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if ((lane >> 4) == j) {
+      const int nb = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 8; r++) rows[r] = stage[nb * 8 + (r ^ (nb & 7))];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
 template <class F>
 __device__ __forceinline__ void fetch_blocks(u32x4 (&rows)[8], u32x4 *stage, int lane, F chunkptr)
 {
@@ -733,15 +787,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give every XCD
-  // a contiguous run of logical tiles: neighbouring tiles (which re-read each other's chroma halo) then
-  // share an L2.
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  {
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
-    logical = x * q + min(x, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -939,6 +986,32 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 // Everything else (tile shape, halo, edge replication, in-place aliasing of output column 1, store path) is
 // identical, and so are the results: wherever nothing overflows, int16 and int32 arithmetic agree.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+// F420P_PREFETCH: where the luma blocks of phase B are requested -- 0 at the start of phase B, 1 in front of the barrier, 2 in
+// front of phase A's transform (32 more registers across it; with F420P_MINW 4 the allocation still leaves four workgroups per CU).
+// Measured on one box (profiles/r04/headline_variants.txt): reference-encoded frames 0.617 -> 0.635, dense blocks 0.583 -> 0.595.
+#ifndef F420P_PREFETCH
+#define F420P_PREFETCH 2
+#endif
+#ifndef F420P_ROT
+#define F420P_ROT 0
+#endif
+// F420P_ROT: every line of the packed chroma plane starts a few dwords further right than the line's index alone says --
+// rot(pr) = the chroma block row it belongs to + 2 x bit 2 of the line.  The lanes of a wave that store the same sample of their
+// blocks (phase A: one ds_write_b16 per sample, blocks 8 columns / 8 lines apart) then spread over 16 banks instead of 4, and
+// the two block rows a 32-lane group reads in phase B no longer meet in the same banks.
+#if F420P_ROT
+constexpr int F420P_PITCH = 80; // 68 columns + the largest rotation (9 + 2) fit
+__device__ __forceinline__ int f420p_rot(int pr) { return ((pr + 7) >> 3) + 2 * ((pr >> 2) & 1); }
+#else
+constexpr int F420P_PITCH = F420_CPITCH;
+__device__ __forceinline__ int f420p_rot(int) { return 0; }
+#endif
+#ifndef F420P_TEMPORAL
+#define F420P_TEMPORAL 0 // 1: the pixel stores of aligned frames without the nt hint as well
+#endif
+#ifndef F420P_MINW
+#define F420P_MINW 4 // workgroups per CU the register allocation must leave room for (the per-frame-table build keeps 3: it spills at 4)
+#endif
 
 __device__ __forceinline__ unsigned tap13_pk(unsigned a, unsigned b, short r)
 {
@@ -963,7 +1036,7 @@ __device__ __forceinline__ unsigned tap_sum_pk(unsigned a, unsigned w)
 template <int MINW, bool QDEV>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fused420Args a)
 {
-  __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420_CPITCH];
+  __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420P_PITCH];
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
 
   const int tid = threadIdx.x;
@@ -971,17 +1044,27 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  { // XCD-aware tile order (see fused420_kernel)
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
-    logical = x * q + min(x, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+#if F420P_PREFETCH
+  // the luma blocks of phase B are requested early: their latency hides behind phase A (2: behind its transform as well)
+  u32x4 yraw[8];
+  auto luma_loads = [&]() {
+    const int16_t *__restrict__ plane = coef + a.off_y;
+    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    load_blocks(yraw, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  };
+#endif
 
   // ------------------------------------------------------------------ phase A: chroma -> LDS halves
   {
@@ -1011,6 +1094,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     const int idx = base + lane;
     const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
     const int gx = gx0 + cbx, gy = gy0 + cby;
+#if F420P_PREFETCH == 2
+    luma_loads();
+#endif
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
       int v[64];
       dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
@@ -1018,13 +1104,14 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
 #pragma unroll
       for (int r = 0; r < 8; r++) {
         const int pr = 8 * cby + r - 7;
+        const int line = pr * F420P_PITCH + (F420P_ROT ? cby + 2 * (((r - 7) >> 2) & 1) : 0); // (+ f420p_rot(pr), spelled in r)
         if (pr >= 0 && pr < F420_CROWS) {
           if (cbx == 0) {
-            cp[2 * (pr * F420_CPITCH + 3)] = (short)v[r * 8 + 7];
+            cp[2 * (line + 3)] = (short)v[r * 8 + 7];
           } else if (cbx == F420_CGRID - 1) {
-            cp[2 * (pr * F420_CPITCH + 68)] = (short)v[r * 8 + 0];
+            cp[2 * (line + 68)] = (short)v[r * 8 + 0];
           } else {
-            short *dst = cp + 2 * (pr * F420_CPITCH + 8 * cbx - 4);
+            short *dst = cp + 2 * (line + 8 * cbx - 4);
 #pragma unroll
             for (int x = 0; x < 8; x++) dst[2 * x] = (short)v[r * 8 + x];
           }
@@ -1032,6 +1119,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
       }
     }
   }
+#if F420P_PREFETCH == 1
+  luma_loads();
+#endif
   __syncthreads();
 
   // ------------------------------------------------------------------ edge fix-up (uniform branch)
@@ -1041,7 +1131,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     const bool edge = (tx == 0) | (ty == 0) | (last_col < 64) | (last_row < 64);
     if (edge) {
       if (tid < F420_CROWS) { // one thread per stored line: replicate columns
-        unsigned *p = cpair + tid * F420_CPITCH;
+        unsigned *p = cpair + tid * F420P_PITCH + f420p_rot(tid);
         if (tx == 0) p[3] = p[4];
         if (last_col < 64) {
           const unsigned v = p[last_col + 4];
@@ -1050,11 +1140,11 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
       }
       __syncthreads();
       if (tid < F420_CROWS) { // one thread per stored column: replicate lines
-        unsigned *p = cpair + 3 + tid;
-        if (ty == 0) p[0] = p[F420_CPITCH];
+        auto at = [&](int pr) -> unsigned & { return cpair[pr * F420P_PITCH + f420p_rot(pr) + 3 + tid]; };
+        if (ty == 0) at(0) = at(1);
         if (last_row < 64) {
-          const unsigned v = p[(last_row + 1) * F420_CPITCH];
-          for (int pr = last_row + 2; pr < F420_CROWS; pr++) p[pr * F420_CPITCH] = v;
+          const unsigned v = at(last_row + 1);
+          for (int pr = last_row + 2; pr < F420_CROWS; pr++) at(pr) = v;
         }
       }
       __syncthreads();
@@ -1065,6 +1155,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int bx = lane & 15, by = wave * 4 + (lane >> 4);
   const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
   u32x4 rows[8];
+#if F420P_PREFETCH
+  transpose_blocks(rows, stage, lane, yraw);
+#else
   {
     const int16_t *__restrict__ plane = coef + a.off_y;
     const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
@@ -1075,6 +1168,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
       return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
     });
   }
+#endif
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
@@ -1086,11 +1180,23 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int nln = min(8, a.height - Y0);
   const bool fast_store = npx == 8;
   // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns pc = 4 bx + 3 + j
+#if F420P_ROT
+  const unsigned *c_line[6]; // the six lines of this block's window, each with its own start
+#pragma unroll
+  for (int j = 0; j < 6; j++) c_line[j] = cpair + (4 * by + j) * F420P_PITCH + f420p_rot(4 * by + j) + 4 * bx;
+  auto load6 = [](const unsigned *p, unsigned (&d)[6]) { // wanted: p[3..8] (dword pairs: no alignment to count on)
+#pragma unroll
+    for (int j = 0; j < 6; j++) d[j] = p[3 + j];
+  };
+#define F420P_LINE(j) c_line[j]
+#else
   const unsigned *c_base = cpair + (4 * by) * F420_CPITCH + 4 * bx;
   auto load6 = [](const unsigned *p, unsigned (&d)[6]) { // p is 16-byte aligned; wanted: p[3..8]
     const u32x4 mid = *reinterpret_cast<const u32x4 *>(p + 4);
     d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
   };
+#define F420P_LINE(j) (c_base + (j) * F420_CPITCH)
+#endif
   // Blocks that lie wholly inside the picture -- all of them, for every wave but those on the right and bottom edges -- take a
   // copy of the loop without the per-line exec masks (wave-uniform choice: one ballot)
   // (a third copy, FULL with every lane active, for frames whose lines do not all start on a dword: store24_nt_shifted)
@@ -1098,11 +1204,11 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   auto lines = [&](auto full_tag, auto shift_tag) {
     constexpr bool FULL = decltype(full_tag)::value, SHIFTED = decltype(shift_tag)::value;
     unsigned cT[6], cC[6], cB[6];
-    load6(c_base, cT);
-    load6(c_base + F420_CPITCH, cC);
+    load6(F420P_LINE(0), cT);
+    load6(F420P_LINE(1), cC);
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-      load6(c_base + (m + 2) * F420_CPITCH, cB);
+      load6(F420P_LINE(m + 2), cB);
       // 3 * centre + rounding, both roundings, for the two lines that share the centre line
       unsigned w1[6], w2[6];
 #pragma unroll
@@ -1140,7 +1246,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
             const int m = SHIFTED ? (int)__builtin_amdgcn_readfirstlane((base_lo + (unsigned)l * (unsigned)a.row_stride) & 3u) : 0;
             if (SHIFTED && m) store24_nt_shifted(out_frame, off, w, bx, m);
             else if (SHIFTED) store24_nt<false>(out_frame, off, w);
-            else store24_nt(out_frame, off, w);
+            else store24_nt<!F420P_TEMPORAL>(out_frame, off, w);
           } else {
             uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
 #pragma unroll
@@ -1160,6 +1266,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   if (whole && ((base_lo | (unsigned)a.row_stride) & 3u) && __builtin_amdgcn_ballot_w64(true) == ~0ull) lines(std::true_type{}, std::true_type{});
   else if (whole) lines(std::true_type{}, std::false_type{});
   else lines(std::false_type{}, std::false_type{});
+#undef F420P_LINE
 }
 
 // ==============================================================================================
@@ -1186,12 +1293,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  { // XCD-aware tile order (see fused420_kernel)
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
-    logical = x * q + min(x, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -1374,12 +1477,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  { // XCD-aware tile order (see fused420_kernel)
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
-    logical = x * q + min(x, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -1533,12 +1632,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  { // XCD-aware tile order (see fused420_kernel)
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
-    logical = x * q + min(x, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -1741,12 +1836,8 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  {
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, xc = b & 7, i = b >> 3;
-    logical = xc * q + min(xc, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -1954,12 +2045,8 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  {
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, xc = b & 7, i = b >> 3;
-    logical = xc * q + min(xc, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -2161,12 +2248,8 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  {
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
-    logical = x * q + min(x, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -2271,12 +2354,8 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  {
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
-    logical = x * q + min(x, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup<1>(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -2926,12 +3005,8 @@ __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const Generi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all + wave * 128;
 
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
-  unsigned logical;
-  { // consecutive tiles of a frame on one XCD (its L2 then serves the halo blocks the neighbours share)
-    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, xc = b & 7, i = b >> 3;
-    logical = xc * q + min(xc, r) + i;
-  }
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
   const int tile = logical - frame * tiles_per_frame;
@@ -3366,7 +3441,7 @@ __global__ __launch_bounds__(256) void bypass_planes_kernel(const GenericArgs a)
 // ==============================================================================================
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   // two workgroups per CU for both flavours (132 / 194 VGPRs)
   if (a.qdev) {
@@ -3379,7 +3454,7 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
 
 int launch_fused420_12(const Fused420Args &a, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   if (a.qdev) hipLaunchKernelGGL((fused420_kernel<true, 2, true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused420_kernel<true, 2, false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
@@ -3388,17 +3463,17 @@ int launch_fused420_12(const Fused420Args &a, hipStream_t stream)
 
 int launch_fused420p(const Fused420Args &a, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   // three workgroups per CU (109 VGPRs, 27 KB LDS): two or four measured slower (profiles/r01/summary_fused420p.txt)
   if (a.qdev) hipLaunchKernelGGL((fused420p_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused420p_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused420p_kernel<F420P_MINW, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
 int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
 {
-  const unsigned total = (unsigned)x.base.tiles_x * x.base.tiles_y * x.base.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)x.base.tiles_x, (unsigned)x.base.tiles_y * (unsigned)x.base.frames);
   if (x.ext.rprecision > 12) hipLaunchKernelGGL(fusedxtw420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   else hipLaunchKernelGGL(fusedxt420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   return (int)hipGetLastError();
@@ -3406,7 +3481,7 @@ int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
 
 int launch_fused422(const Fused420Args &a, bool wide, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (wide) {
     if (a.qdev) hipLaunchKernelGGL((fused422_kernel<3, true, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
     else hipLaunchKernelGGL((fused422_kernel<3, false, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
@@ -3419,7 +3494,7 @@ int launch_fused422(const Fused420Args &a, bool wide, hipStream_t stream)
 
 int launch_fused411(const Fused420Args &a, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (a.qdev) hipLaunchKernelGGL((fused411_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused411_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
@@ -3427,7 +3502,7 @@ int launch_fused411(const Fused420Args &a, hipStream_t stream)
 
 int launch_fused1(const Fused420Args &a, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles<1>((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (a.qdev) hipLaunchKernelGGL((fused1_kernel<true, 8>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused1_kernel<false, 8>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
@@ -3435,7 +3510,7 @@ int launch_fused1(const Fused420Args &a, hipStream_t stream)
 
 int launch_fused1_12(const Fused420Args &a, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles<1>((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (a.qdev) hipLaunchKernelGGL((fused1_kernel<true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused1_kernel<false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
@@ -3443,7 +3518,7 @@ int launch_fused1_12(const Fused420Args &a, hipStream_t stream)
 
 int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (wide) {
     if (a.qdev) hipLaunchKernelGGL((fused440_kernel<3, true, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
     else hipLaunchKernelGGL((fused440_kernel<3, false, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
@@ -3456,7 +3531,7 @@ int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream)
 
 int launch_fused444(const Fused420Args &a, hipStream_t stream)
 {
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   // 168 VGPRs -> three waves per SIMD: 5 % faster than the unconstrained 171-register build
   if (a.qdev) hipLaunchKernelGGL((fused444_kernel<2, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
@@ -3529,7 +3604,7 @@ int launch_fused_tile(const GenericArgs &a0, bool fast, hipStream_t stream)
   const bool narrow = fast && a.narrow;
   const size_t lds = fused_tile_geometry(a, narrow);
   if (!lds) return -1;
-  const unsigned total = (unsigned)a.tiles_x * a.tiles_y * a.frames;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (narrow) hipLaunchKernelGGL((fused_tile_kernel<true, true>), dim3(total), dim3(256), lds, stream, a);
   else if (fast) hipLaunchKernelGGL((fused_tile_kernel<true, false>), dim3(total), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL((fused_tile_kernel<false, false>), dim3(total), dim3(256), lds, stream, a);

@@ -1,0 +1,228 @@
+// What does HBM deliver for the headline launch's traffic, without the arithmetic?  Three kernels over the buffers of 8 x 8K 4:2:0
+// frames (coefficients int16 planar: 3 B/pixel in, interleaved RGB: 3 B/pixel out):
+//   copy     : the ideal -- every lane reads 16 contiguous bytes and writes 16 contiguous bytes, grid-stride, dwordx4 both ways;
+//   pattern  : the fused kernel's access pattern -- one workgroup per 128 x 128 tile (XCD-aware order), phase A reads the
+//              10 x 10 chroma blocks of both planes (1 KB per wave-instruction), phase B the 16 x 16 luma blocks, then every lane
+//              writes the 8 lines of its 8 x 8 block as 24-byte pieces (dwordx4 + dwordx2, non-temporal), lines 23 040 B apart;
+//   pattern-t: the same with temporal stores.
+// The stored values are a cheap mix of what was loaded, so nothing is optimised away.  Prints ms per launch and TB/s of the
+// 6 B/pixel both ways.  Build: hipcc --offload-arch=gfx950 -O3 tools/microbench/stream_ceiling.hip -o tools/microbench/stream_ceiling
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int W = 7680, H = 4320, FRAMES = 8;
+constexpr int BWY = W / 8, BHY = H / 8, BWC = W / 16, BHC = H / 16;
+constexpr int64_t COEF_FRAME = (int64_t)BWY * BHY * 64 + 2ll * BWC * BHC * 64; // int16 units
+constexpr int64_t OUT_FRAME = (int64_t)W * H * 3;
+constexpr int TX = W / 128, TY = (H + 127) / 128;
+
+__global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ in, u32x4 *__restrict__ out, int64_t n_in, int64_t n_out)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u32x4 acc = {0, 0, 0, 0};
+  // the two streams are equally long here (3 B/pixel each way): one load and one store per iteration
+  for (; i < n_in && i < n_out; i += stride) {
+    const u32x4 v = in[i];
+    acc ^= v;
+    __builtin_nontemporal_store(v + acc, out + i);
+  }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256, 4) void pattern_kernel(const int16_t *__restrict__ coef_all, uint8_t *__restrict__ out_all)
+{
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned total = TX * TY * FRAMES;
+  unsigned logical;
+  {
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  }
+  const int frame = logical / (TX * TY), tile = logical - frame * (TX * TY);
+  const int ty = tile / TX, tx = tile - ty * TX;
+  const int16_t *coef = coef_all + frame * COEF_FRAME;
+  const int64_t off_cb = (int64_t)BWY * BHY * 64, off_cr = off_cb + (int64_t)BWC * BHC * 64;
+  u32x4 acc = {0, 0, 0, 0};
+  { // phase A: waves 0, 1 Cb, waves 2, 3 Cr; 100 blocks each over two waves
+    const int16_t *plane = coef + (wave >> 1 ? off_cr : off_cb);
+    const int gx0 = tx * 8 - 1, gy0 = ty * 8 - 1, base = (wave & 1) * 64;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int i = min(base + (lane >> 3) + 8 * m, 99), y = i / 10, x = i - y * 10;
+      const int gx = min(max(gx0 + x, 0), BWC - 1), gy = min(max(gy0 + y, 0), BHC - 1);
+      acc ^= *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(plane) + (lane & 7) * 16 + (unsigned)((gy * BWC + gx) * 128));
+    }
+  }
+  __syncthreads();
+  { // phase B: 16 x 4 luma blocks per wave
+    const int gbx0 = tx * 16, gby0 = ty * 16 + wave * 4;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int x = min(gbx0 + (lane >> 3) + 8 * (m & 1), BWY - 1), y = min(gby0 + (m >> 1), BHY - 1);
+      acc ^= *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(coef) + (lane & 7) * 16 + (unsigned)((y * BWY + x) * 128));
+    }
+  }
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int X0 = (tx * 16 + bx) * 8, Y0 = (ty * 16 + by) * 8;
+  if (Y0 >= H) return;
+  uint8_t *dst = out_all + frame * OUT_FRAME + (int64_t)Y0 * (W * 3) + X0 * 3;
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    const u32x4 a = acc + (uint32_t)l;
+    const u32x2 b = {acc.x ^ (uint32_t)l, acc.w + (uint32_t)l};
+    if (NT) {
+      __builtin_nontemporal_store(a, reinterpret_cast<u32x4 *>(dst + l * (W * 3)));
+      __builtin_nontemporal_store(b, reinterpret_cast<u32x2 *>(dst + l * (W * 3) + 16));
+    } else {
+      *reinterpret_cast<u32x4 *>(dst + l * (W * 3)) = a;
+      *reinterpret_cast<u32x2 *>(dst + l * (W * 3) + 16) = b;
+    }
+  }
+}
+
+
+// The same with the tile shape, the order of the tiles and the two directions as parameters: TBX x TBY luma blocks per workgroup
+// (TBX * TBY = 256: one block per lane; a line of a wave's stores is min(TBX, 64) * 24 contiguous bytes), MODE 0 = reads and
+// writes, 1 = reads only (one dword per lane written), 2 = writes only; ORDER 0 = blockIdx is the tile, 1 = XCD-aware.
+template <int TBX, int TBY, int MODE, bool NT>
+__global__ __launch_bounds__(256, 4) void shape_kernel(const int16_t *__restrict__ coef_all, uint8_t *__restrict__ out_all, int order)
+{
+  static_assert(TBX * TBY == 256, "one luma block per lane");
+  constexpr int TXN = W / (8 * TBX), TYN = (H / 8 + TBY - 1) / TBY, CGX = TBX / 2 + 2, CGY = TBY / 2 + 2, NC = CGX * CGY;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned total = TXN * TYN * FRAMES;
+  unsigned logical = blockIdx.x;
+  if (order == 1) {
+    const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    logical = x * q + min(x, r) + i;
+  } else if (order >= 2) { // XCD x takes runs of `order` consecutive tiles, every eighth run (60 = a tile row of the 16 x 16 shape)
+    const unsigned b = blockIdx.x, x = b & 7, i = b >> 3, rl = (unsigned)order;
+    logical = ((i / rl) * 8 + x) * rl + i % rl;
+    if (logical >= total) return;
+  }
+  const int frame = logical / (TXN * TYN), tile = logical - frame * (TXN * TYN);
+  const int ty = tile / TXN, tx = tile - ty * TXN;
+  const int16_t *coef = coef_all + frame * COEF_FRAME;
+  const int64_t off_cb = (int64_t)BWY * BHY * 64, off_cr = off_cb + (int64_t)BWC * BHC * 64;
+  u32x4 acc = {(uint32_t)tid, 0, 0, 0};
+  if (MODE != 2) {
+    { // chroma grid incl. halo, both planes: 2 * NC blocks over 4 waves, 8 blocks per wave-instruction
+      const int gx0 = tx * (TBX / 2) - 1, gy0 = ty * (TBY / 2) - 1;
+      for (int i0 = wave * 8 + (lane >> 3); i0 < 2 * NC; i0 += 32) {
+        const int pl = i0 >= NC, i = i0 - pl * NC, y = i / CGX, x = i - y * CGX;
+        const int gx = min(max(gx0 + x, 0), BWC - 1), gy = min(max(gy0 + y, 0), BHC - 1);
+        acc ^= *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(coef + (pl ? off_cr : off_cb)) + (lane & 7) * 16 + (unsigned)((gy * BWC + gx) * 128));
+      }
+    }
+    __syncthreads();
+    { // luma: 256 blocks, 8 adjacent blocks per wave-instruction
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int b = wave * 64 + m * 8 + (lane >> 3), bx = b % TBX, by = b / TBX;
+        const int x = min(tx * TBX + bx, BWY - 1), y = min(ty * TBY + by, BHY - 1);
+        acc ^= *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(coef) + (lane & 7) * 16 + (unsigned)((y * BWY + x) * 128));
+      }
+    }
+  }
+  const int bx = tid % TBX, by = tid / TBX;
+  const int X0 = (tx * TBX + bx) * 8, Y0 = (ty * TBY + by) * 8;
+  if (Y0 >= H) return;
+  uint8_t *dst = out_all + frame * OUT_FRAME + (int64_t)Y0 * (W * 3) + X0 * 3;
+  if (MODE == 1) {
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *reinterpret_cast<uint32_t *>(dst) = acc.x; // (never: keeps the loads alive)
+    return;
+  }
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    const u32x4 a = acc + (uint32_t)l;
+    const u32x2 b = {acc.x ^ (uint32_t)l, acc.w + (uint32_t)l};
+    if (NT) {
+      __builtin_nontemporal_store(a, reinterpret_cast<u32x4 *>(dst + l * (W * 3)));
+      __builtin_nontemporal_store(b, reinterpret_cast<u32x2 *>(dst + l * (W * 3) + 16));
+    } else {
+      *reinterpret_cast<u32x4 *>(dst + l * (W * 3)) = a;
+      *reinterpret_cast<u32x2 *>(dst + l * (W * 3) + 16) = b;
+    }
+  }
+}
+
+template <class F> static float time_ms(F launch, int reps)
+{
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int i = 0; i < 60; i++) launch(); // clock settling
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; i++) launch();
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
+int main()
+{
+  const int64_t coef_bytes = COEF_FRAME * 2 * FRAMES, out_bytes = OUT_FRAME * FRAMES;
+  int16_t *coef;
+  uint8_t *out;
+  if (hipMalloc(&coef, coef_bytes + 4096) != hipSuccess || hipMalloc(&out, out_bytes + 4096) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  hipMemset(coef, 1, coef_bytes);
+  hipMemset(out, 0, out_bytes);
+  const double gb = (double)(coef_bytes + out_bytes) * 1e-9;
+  printf("8 x 8K 4:2:0 frames: %.1f MB in + %.1f MB out per launch\n", coef_bytes * 1e-6, out_bytes * 1e-6);
+  const int tiles = TX * TY * FRAMES;
+  const int LDS = 40 * 1024; // dynamic LDS nobody touches: four workgroups per CU, the fused kernel's occupancy
+  for (int blocks : {2048, 8192, 32768, 131072, 388800}) {
+    const float ms = time_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, 0, (const u32x4 *)coef, (u32x4 *)out, coef_bytes / 16, out_bytes / 16); }, 200);
+    printf("copy      %6d workgroups: %.4f ms/launch  %.2f TB/s  (%.3f of 8)\n", blocks, ms, gb / ms, gb / ms / 8.0);
+  }
+  {
+    const float ms = time_ms([&] { hipLaunchKernelGGL((pattern_kernel<true>), dim3(tiles), dim3(256), LDS, 0, coef, out); }, 200);
+    printf("pattern   %6d workgroups: %.4f ms/launch  %.2f TB/s  (%.3f of 8)  non-temporal stores\n", tiles, ms, gb / ms, gb / ms / 8.0);
+  }
+  {
+    const float ms = time_ms([&] { hipLaunchKernelGGL((pattern_kernel<false>), dim3(tiles), dim3(256), LDS, 0, coef, out); }, 200);
+    printf("pattern-t %6d workgroups: %.4f ms/launch  %.2f TB/s  (%.3f of 8)  temporal stores\n", tiles, ms, gb / ms, gb / ms / 8.0);
+  }
+
+  // shapes, orders, directions
+  auto shape = [&](const char *name, auto kernel, int tbx, int tby, int order, double bytes) {
+    int n = (W / (8 * tbx)) * ((H / 8 + tby - 1) / tby) * FRAMES;
+    if (order >= 2) n = (n + 8 * order - 1) / (8 * order) * (8 * order);
+    const float ms = time_ms([&] { hipLaunchKernelGGL(kernel, dim3(n), dim3(256), LDS, 0, coef, out, order); }, 200);
+    printf("%-28s %2d x %2d blocks, order %d: %.4f ms/launch  %.2f TB/s  (%.3f of 8)\n", name, tbx, tby, order, ms, bytes * 1e-9 / ms, bytes * 1e-9 / ms / 8.0);
+  };
+  const double both = (double)(coef_bytes + out_bytes), rd = (double)coef_bytes, wr = (double)out_bytes;
+  for (int order : {4, 15, 30, 60, 120, 240, 480}) { // run lengths (16 x 16: 60 tiles per row, 34 rows per frame)
+    shape("read+write nt", shape_kernel<16, 16, 0, true>, 16, 16, order, both);
+    shape("read+write temporal", shape_kernel<16, 16, 0, false>, 16, 16, order, both);
+  }
+  for (int order : {30, 60, 120}) { // 32 x 8: 30 tiles per row, 68 rows per frame
+    shape("read+write nt", shape_kernel<32, 8, 0, true>, 32, 8, order, both);
+    shape("read only", shape_kernel<16, 16, 1, true>, 16, 16, order, rd);
+    shape("write only nt", shape_kernel<16, 16, 2, true>, 16, 16, order, wr);
+  }
+  for (int order = 0; order < 2; order++) {
+    shape("read+write nt", shape_kernel<16, 16, 0, true>, 16, 16, order, both);
+    shape("read+write temporal", shape_kernel<16, 16, 0, false>, 16, 16, order, both);
+    shape("read+write nt", shape_kernel<32, 8, 0, true>, 32, 8, order, both);
+    shape("read+write temporal", shape_kernel<32, 8, 0, false>, 32, 8, order, both);
+    shape("read+write nt", shape_kernel<64, 4, 0, true>, 64, 4, order, both);
+    shape("read+write temporal", shape_kernel<64, 4, 0, false>, 64, 4, order, both);
+    shape("read only", shape_kernel<16, 16, 1, true>, 16, 16, order, rd);
+    shape("read only", shape_kernel<64, 4, 1, true>, 64, 4, order, rd);
+    shape("write only nt", shape_kernel<16, 16, 2, true>, 16, 16, order, wr);
+    shape("write only temporal", shape_kernel<16, 16, 2, false>, 16, 16, order, wr);
+    shape("write only nt", shape_kernel<64, 4, 2, true>, 64, 4, order, wr);
+    shape("write only temporal", shape_kernel<64, 4, 2, false>, 64, 4, order, wr);
+  }
+  if (hipDeviceSynchronize() != hipSuccess) { printf("device error\n"); return 1; }
+  return 0;
+}
