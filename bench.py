@@ -757,6 +757,20 @@ def main():
         result["roofline"]["traffic_note"] = tnote
     else:
         result["roofline"]["traffic_note"] = "not measured in this run (N > 1 or --no-traffic)"
+    # what HBM gives this launch's traffic without the arithmetic (a side measurement: never fails the line)
+    mb = os.path.join(ROOT, "tools", "microbench", "stream_ceiling")
+    if rank == 0 and world == 1 and not args.no_traffic and args.subsampling == "420" and os.path.exists(mb):
+        try:
+            torch.cuda.synchronize()
+            t = json.loads(subprocess.run([mb, "--brief"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+            result["roofline"]["traffic_only"] = {
+                "pattern_ms_per_8_frames": t["pattern_ms"], "pattern_frac": t["pattern_frac"], "copy_ms_per_8_frames": t["copy_ms"], "copy_frac": t["copy_frac"],
+                "kernel_ms_per_8_frames": round(kernel_ms * 8 / F, 4),
+                "note": "tools/microbench/stream_ceiling --brief on the same GPU right after the timed steps: 'pattern' = the fused kernel's loads and stores (tile shape, "
+                        "tile order, halo re-reads, 24-byte non-temporal line pieces) with no arithmetic between them, 'copy' = the best of three grid sizes of a plain "
+                        "16-byte-per-lane copy of the same 3 + 3 bytes per pixel; fractions of the same 8 TB/s"}
+        except Exception as e:  # noqa: BLE001
+            result["roofline"]["traffic_only"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_dense and args.subsampling == "420":
         try:
             result["roofline_dense"] = dense_roofline(info, F, W, H, stream, max(5, args.steps // 2))

@@ -460,25 +460,33 @@ __device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], cons
 // launch (its own frame, with 8 frames per launch): same L2 sharing, but the traffic-only copy of the headline kernel
 // (tools/microbench/stream_ceiling) showed HBM delivering 3-4 % less for eight far-apart write fronts than for one, and the
 // kernel itself runs at that copy's speed: 0.644-0.648 -> 0.667-0.674 of 8 TB/s on one box (profiles/r04/headline_variants.txt).
-// The single-component kernel keeps the old order (its launch measured 3 % slower with the new one, profiles/r04/layouts_tile_order.txt);
+// The 12-bit 4:2:0 kernel keeps the old order (13 % slower with the new one), and so does the single-component kernel (no
+// difference beyond the noise; profiles/r04/layouts_tile_order.txt); runs shorter than a tile row (MIJ_TILE_RUN) measured the same;
 // MIJ_TILE_ORDER 1 gives it to all kernels for A-B builds.  ~0u: a padding workgroup (the launch has whole groups of 8 tile rows).
 // ----------------------------------------------------------------------------------------------
 #ifndef MIJ_TILE_ORDER
 #define MIJ_TILE_ORDER 2
 #endif
+#ifndef MIJ_TILE_RUN
+#define MIJ_TILE_RUN 0 // consecutive tiles an XCD takes at a time; 0: a tile row
+#endif
 template <int ORDER = MIJ_TILE_ORDER> __device__ __forceinline__ unsigned tile_of_workgroup(unsigned b, unsigned tiles_x, unsigned tile_rows)
 {
   if (ORDER == 2) {
     const unsigned x = b & 7, i = b >> 3; // i-th workgroup of XCD x
-    const unsigned row8 = i / tiles_x, col = i - row8 * tiles_x, row = row8 * 8 + x;
-    return row < tile_rows ? row * tiles_x + col : ~0u;
+    const unsigned run = MIJ_TILE_RUN ? MIJ_TILE_RUN : tiles_x, g = i / run, t = ((g * 8 + x) * run) + (i - g * run);
+    return t < tiles_x * tile_rows ? t : ~0u;
   }
   const unsigned total = tiles_x * tile_rows, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
   return x * q + min(x, r) + i;
 }
+#ifndef XT_TILE_ORDER
+#define XT_TILE_ORDER 2 // the JPEG XT kernels: 0.339 -> 0.332 ms per 8 x 4K frames with the tile-row order (profiles/r04/layouts_tile_order.txt)
+#endif
 template <int ORDER = MIJ_TILE_ORDER> static unsigned workgroups_for_tiles(unsigned tiles_x, unsigned tile_rows)
 {
-  return ORDER == 2 ? ((tile_rows + 7u) / 8u) * 8u * tiles_x : tiles_x * tile_rows;
+  const unsigned run = MIJ_TILE_RUN ? MIJ_TILE_RUN : tiles_x;
+  return ORDER == 2 ? (tiles_x * tile_rows + 8u * run - 1u) / (8u * run) * (8u * run) : tiles_x * tile_rows;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -787,7 +795,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  const unsigned logical = tile_of_workgroup<P == 8 ? MIJ_TILE_ORDER : 1>(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
   if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
@@ -986,28 +994,11 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 // Everything else (tile shape, halo, edge replication, in-place aliasing of output column 1, store path) is
 // identical, and so are the results: wherever nothing overflows, int16 and int32 arithmetic agree.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-// F420P_PREFETCH: where the luma blocks of phase B are requested -- 0 at the start of phase B, 1 in front of the barrier, 2 in
-// front of phase A's transform (32 more registers across it; with F420P_MINW 4 the allocation still leaves four workgroups per CU).
+// F420P_PREFETCH: the luma blocks of phase B are requested in front of phase A's transform (32 more registers across it; with
+// F420P_MINW 4 the allocation still leaves four workgroups per CU); 0: at the start of phase B, for A-B builds.
 // Measured on one box (profiles/r04/headline_variants.txt): reference-encoded frames 0.617 -> 0.635, dense blocks 0.583 -> 0.595.
 #ifndef F420P_PREFETCH
-#define F420P_PREFETCH 2
-#endif
-#ifndef F420P_ROT
-#define F420P_ROT 0
-#endif
-// F420P_ROT: every line of the packed chroma plane starts a few dwords further right than the line's index alone says --
-// rot(pr) = the chroma block row it belongs to + 2 x bit 2 of the line.  The lanes of a wave that store the same sample of their
-// blocks (phase A: one ds_write_b16 per sample, blocks 8 columns / 8 lines apart) then spread over 16 banks instead of 4, and
-// the two block rows a 32-lane group reads in phase B no longer meet in the same banks.
-#if F420P_ROT
-constexpr int F420P_PITCH = 80; // 68 columns + the largest rotation (9 + 2) fit
-__device__ __forceinline__ int f420p_rot(int pr) { return ((pr + 7) >> 3) + 2 * ((pr >> 2) & 1); }
-#else
-constexpr int F420P_PITCH = F420_CPITCH;
-__device__ __forceinline__ int f420p_rot(int) { return 0; }
-#endif
-#ifndef F420P_TEMPORAL
-#define F420P_TEMPORAL 0 // 1: the pixel stores of aligned frames without the nt hint as well
+#define F420P_PREFETCH 1
 #endif
 #ifndef F420P_MINW
 #define F420P_MINW 4 // workgroups per CU the register allocation must leave room for (the per-frame-table build keeps 3: it spills at 4)
@@ -1036,7 +1027,7 @@ __device__ __forceinline__ unsigned tap_sum_pk(unsigned a, unsigned w)
 template <int MINW, bool QDEV>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fused420Args a)
 {
-  __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420P_PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420_CPITCH];
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
 
   const int tid = threadIdx.x;
@@ -1052,7 +1043,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 #if F420P_PREFETCH
-  // the luma blocks of phase B are requested early: their latency hides behind phase A (2: behind its transform as well)
+  // the luma blocks of phase B are requested early: their latency hides behind phase A's transform
   u32x4 yraw[8];
   auto luma_loads = [&]() {
     const int16_t *__restrict__ plane = coef + a.off_y;
@@ -1094,7 +1085,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     const int idx = base + lane;
     const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
     const int gx = gx0 + cbx, gy = gy0 + cby;
-#if F420P_PREFETCH == 2
+#if F420P_PREFETCH
     luma_loads();
 #endif
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
@@ -1104,7 +1095,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
 #pragma unroll
       for (int r = 0; r < 8; r++) {
         const int pr = 8 * cby + r - 7;
-        const int line = pr * F420P_PITCH + (F420P_ROT ? cby + 2 * (((r - 7) >> 2) & 1) : 0); // (+ f420p_rot(pr), spelled in r)
+        const int line = pr * F420_CPITCH;
         if (pr >= 0 && pr < F420_CROWS) {
           if (cbx == 0) {
             cp[2 * (line + 3)] = (short)v[r * 8 + 7];
@@ -1119,9 +1110,6 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
       }
     }
   }
-#if F420P_PREFETCH == 1
-  luma_loads();
-#endif
   __syncthreads();
 
   // ------------------------------------------------------------------ edge fix-up (uniform branch)
@@ -1131,7 +1119,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     const bool edge = (tx == 0) | (ty == 0) | (last_col < 64) | (last_row < 64);
     if (edge) {
       if (tid < F420_CROWS) { // one thread per stored line: replicate columns
-        unsigned *p = cpair + tid * F420P_PITCH + f420p_rot(tid);
+        unsigned *p = cpair + tid * F420_CPITCH;
         if (tx == 0) p[3] = p[4];
         if (last_col < 64) {
           const unsigned v = p[last_col + 4];
@@ -1140,7 +1128,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
       }
       __syncthreads();
       if (tid < F420_CROWS) { // one thread per stored column: replicate lines
-        auto at = [&](int pr) -> unsigned & { return cpair[pr * F420P_PITCH + f420p_rot(pr) + 3 + tid]; };
+        auto at = [&](int pr) -> unsigned & { return cpair[pr * F420_CPITCH + 3 + tid]; };
         if (ty == 0) at(0) = at(1);
         if (last_row < 64) {
           const unsigned v = at(last_row + 1);
@@ -1180,23 +1168,12 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int nln = min(8, a.height - Y0);
   const bool fast_store = npx == 8;
   // chroma window of this block: lines pr = 4 by + m (+0 top, +1 cur, +2 bot), columns pc = 4 bx + 3 + j
-#if F420P_ROT
-  const unsigned *c_line[6]; // the six lines of this block's window, each with its own start
-#pragma unroll
-  for (int j = 0; j < 6; j++) c_line[j] = cpair + (4 * by + j) * F420P_PITCH + f420p_rot(4 * by + j) + 4 * bx;
-  auto load6 = [](const unsigned *p, unsigned (&d)[6]) { // wanted: p[3..8] (dword pairs: no alignment to count on)
-#pragma unroll
-    for (int j = 0; j < 6; j++) d[j] = p[3 + j];
-  };
-#define F420P_LINE(j) c_line[j]
-#else
   const unsigned *c_base = cpair + (4 * by) * F420_CPITCH + 4 * bx;
   auto load6 = [](const unsigned *p, unsigned (&d)[6]) { // p is 16-byte aligned; wanted: p[3..8]
     const u32x4 mid = *reinterpret_cast<const u32x4 *>(p + 4);
     d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
   };
-#define F420P_LINE(j) (c_base + (j) * F420_CPITCH)
-#endif
+
   // Blocks that lie wholly inside the picture -- all of them, for every wave but those on the right and bottom edges -- take a
   // copy of the loop without the per-line exec masks (wave-uniform choice: one ballot)
   // (a third copy, FULL with every lane active, for frames whose lines do not all start on a dword: store24_nt_shifted)
@@ -1204,11 +1181,11 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   auto lines = [&](auto full_tag, auto shift_tag) {
     constexpr bool FULL = decltype(full_tag)::value, SHIFTED = decltype(shift_tag)::value;
     unsigned cT[6], cC[6], cB[6];
-    load6(F420P_LINE(0), cT);
-    load6(F420P_LINE(1), cC);
+    load6(c_base, cT);
+    load6(c_base + F420_CPITCH, cC);
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-      load6(F420P_LINE(m + 2), cB);
+      load6(c_base + (m + 2) * F420_CPITCH, cB);
       // 3 * centre + rounding, both roundings, for the two lines that share the centre line
       unsigned w1[6], w2[6];
 #pragma unroll
@@ -1246,7 +1223,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
             const int m = SHIFTED ? (int)__builtin_amdgcn_readfirstlane((base_lo + (unsigned)l * (unsigned)a.row_stride) & 3u) : 0;
             if (SHIFTED && m) store24_nt_shifted(out_frame, off, w, bx, m);
             else if (SHIFTED) store24_nt<false>(out_frame, off, w);
-            else store24_nt<!F420P_TEMPORAL>(out_frame, off, w);
+            else store24_nt(out_frame, off, w);
           } else {
             uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
 #pragma unroll
@@ -1266,7 +1243,6 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   if (whole && ((base_lo | (unsigned)a.row_stride) & 3u) && __builtin_amdgcn_ballot_w64(true) == ~0ull) lines(std::true_type{}, std::true_type{});
   else if (whole) lines(std::true_type{}, std::false_type{});
   else lines(std::false_type{}, std::false_type{});
-#undef F420P_LINE
 }
 
 // ==============================================================================================
@@ -1836,7 +1812,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  const unsigned logical = tile_of_workgroup<XT_TILE_ORDER>(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
   if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
@@ -2045,7 +2021,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  const unsigned logical = tile_of_workgroup<XT_TILE_ORDER>(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
   if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int frame = logical / tiles_per_frame;
@@ -3454,7 +3430,7 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
 
 int launch_fused420_12(const Fused420Args &a, hipStream_t stream)
 {
-  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
+  const unsigned total = workgroups_for_tiles<1>((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   if (a.qdev) hipLaunchKernelGGL((fused420_kernel<true, 2, true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused420_kernel<true, 2, false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
@@ -3465,7 +3441,7 @@ int launch_fused420p(const Fused420Args &a, hipStream_t stream)
 {
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
-  // three workgroups per CU (109 VGPRs, 27 KB LDS): two or four measured slower (profiles/r01/summary_fused420p.txt)
+  // four workgroups per CU (127 VGPRs with the luma prefetch, 27 KB LDS); the per-frame-table build three (133 VGPRs)
   if (a.qdev) hipLaunchKernelGGL((fused420p_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused420p_kernel<F420P_MINW, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
@@ -3473,7 +3449,7 @@ int launch_fused420p(const Fused420Args &a, hipStream_t stream)
 
 int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
 {
-  const unsigned total = workgroups_for_tiles((unsigned)x.base.tiles_x, (unsigned)x.base.tiles_y * (unsigned)x.base.frames);
+  const unsigned total = workgroups_for_tiles<XT_TILE_ORDER>((unsigned)x.base.tiles_x, (unsigned)x.base.tiles_y * (unsigned)x.base.frames);
   if (x.ext.rprecision > 12) hipLaunchKernelGGL(fusedxtw420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   else hipLaunchKernelGGL(fusedxt420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   return (int)hipGetLastError();

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -167,8 +168,9 @@ template <class F> static float time_ms(F launch, int reps)
   return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+  const bool brief = argc > 1 && !strcmp(argv[1], "--brief"); // bench.py: one JSON line -- the ideal copy and the kernel's own pattern
   const int64_t coef_bytes = COEF_FRAME * 2 * FRAMES, out_bytes = OUT_FRAME * FRAMES;
   int16_t *coef;
   uint8_t *out;
@@ -176,9 +178,23 @@ int main()
   hipMemset(coef, 1, coef_bytes);
   hipMemset(out, 0, out_bytes);
   const double gb = (double)(coef_bytes + out_bytes) * 1e-9;
-  printf("8 x 8K 4:2:0 frames: %.1f MB in + %.1f MB out per launch\n", coef_bytes * 1e-6, out_bytes * 1e-6);
   const int tiles = TX * TY * FRAMES;
   const int LDS = 40 * 1024; // dynamic LDS nobody touches: four workgroups per CU, the fused kernel's occupancy
+  if (brief) {
+    float copy_ms = 1e9f;
+    for (int blocks : {32768, 131072, 388800}) {
+      const float ms = time_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, 0, (const u32x4 *)coef, (u32x4 *)out, coef_bytes / 16, out_bytes / 16); }, 100);
+      if (ms < copy_ms) copy_ms = ms;
+    }
+    const int order = TX; // the fused kernels' tile order: runs of one tile row per XCD
+    const int n = (tiles + 8 * order - 1) / (8 * order) * (8 * order);
+    const float pat_ms = time_ms([&] { hipLaunchKernelGGL((shape_kernel<16, 16, 0, true>), dim3(n), dim3(256), LDS, 0, coef, out, order); }, 100);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("{\"error\": \"device\"}\n"); return 1; }
+    printf("{\"frames\": %d, \"bytes_per_launch\": %lld, \"copy_ms\": %.4f, \"copy_frac\": %.4f, \"pattern_ms\": %.4f, \"pattern_frac\": %.4f}\n", FRAMES,
+           (long long)(coef_bytes + out_bytes), copy_ms, gb / copy_ms / 8.0, pat_ms, gb / pat_ms / 8.0);
+    return 0;
+  }
+  printf("8 x 8K 4:2:0 frames: %.1f MB in + %.1f MB out per launch\n", coef_bytes * 1e-6, out_bytes * 1e-6);
   for (int blocks : {2048, 8192, 32768, 131072, 388800}) {
     const float ms = time_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, 0, (const u32x4 *)coef, (u32x4 *)out, coef_bytes / 16, out_bytes / 16); }, 200);
     printf("copy      %6d workgroups: %.4f ms/launch  %.2f TB/s  (%.3f of 8)\n", blocks, ms, gb / ms, gb / ms / 8.0);
