@@ -461,32 +461,47 @@ __device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], cons
 // (tools/microbench/stream_ceiling) showed HBM delivering 3-4 % less for eight far-apart write fronts than for one, and the
 // kernel itself runs at that copy's speed: 0.644-0.648 -> 0.667-0.674 of 8 TB/s on one box (profiles/r04/headline_variants.txt).
 // The 12-bit 4:2:0 kernel keeps the old order (13 % slower with the new one), and so does the single-component kernel (no
-// difference beyond the noise; profiles/r04/layouts_tile_order.txt); runs shorter than a tile row (MIJ_TILE_RUN) measured the same;
+// difference beyond the noise; profiles/r04/layouts_tile_order.txt); runs of 8, 15 or 30 tiles instead of a tile row measured the same;
 // MIJ_TILE_ORDER 1 gives it to all kernels for A-B builds.  ~0u: a padding workgroup (the launch has whole groups of 8 tile rows).
 // ----------------------------------------------------------------------------------------------
 #ifndef MIJ_TILE_ORDER
 #define MIJ_TILE_ORDER 2
 #endif
-#ifndef MIJ_TILE_RUN
-#define MIJ_TILE_RUN 0 // consecutive tiles an XCD takes at a time; 0: a tile row
-#endif
 template <int ORDER = MIJ_TILE_ORDER> __device__ __forceinline__ unsigned tile_of_workgroup(unsigned b, unsigned tiles_x, unsigned tile_rows)
 {
   if (ORDER == 2) {
     const unsigned x = b & 7, i = b >> 3; // i-th workgroup of XCD x
-    const unsigned run = MIJ_TILE_RUN ? MIJ_TILE_RUN : tiles_x, g = i / run, t = ((g * 8 + x) * run) + (i - g * run);
-    return t < tiles_x * tile_rows ? t : ~0u;
+    const unsigned g = i / tiles_x, row = g * 8 + x;
+    return row < tile_rows ? row * tiles_x + (i - g * tiles_x) : ~0u;
   }
   const unsigned total = tiles_x * tile_rows, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
   return x * q + min(x, r) + i;
+}
+// The same for the kernels on Fused420Args, with the two divisions by launch constants as multiplications (Fused420Args::magic_*,
+// filled by the launchers: floor(2^32 / d) + 1, exact while dividend * d < 2^32 -- 0 where that cannot be promised, and the
+// kernel divides): the workgroup's position costs scalar instructions only.  frame < 0: a padding workgroup.
+struct TilePos { int frame, tx, ty; };
+__device__ __forceinline__ unsigned div_by(unsigned x, unsigned d, unsigned magic) { return magic ? __umulhi(x, magic) : x / d; }
+template <int ORDER = MIJ_TILE_ORDER> __device__ __forceinline__ TilePos tile_position(unsigned b, const Fused420Args &a)
+{
+  const unsigned tiles_x = (unsigned)a.tiles_x, tiles_y = (unsigned)a.tiles_y;
+  if (ORDER == 2) {
+    const unsigned x = b & 7, i = b >> 3;                                    // i-th workgroup of XCD x
+    const unsigned g = div_by(i, tiles_x, a.magic_tx), col = i - g * tiles_x; // its g-th tile row, column col
+    const unsigned row = g * 8 + x, frame = div_by(row, tiles_y, a.magic_ty);
+    if (row >= tiles_y * (unsigned)a.frames) return TilePos{-1, 0, 0};
+    return TilePos{(int)frame, (int)col, (int)(row - frame * tiles_y)};
+  }
+  const unsigned logical = tile_of_workgroup<1>(b, tiles_x, tiles_y * (unsigned)a.frames);
+  const unsigned row = div_by(logical, tiles_x, a.magic_tx), col = logical - row * tiles_x, frame = div_by(row, tiles_y, a.magic_ty);
+  return TilePos{(int)frame, (int)col, (int)(row - frame * tiles_y)};
 }
 #ifndef XT_TILE_ORDER
 #define XT_TILE_ORDER 2 // the JPEG XT kernels: 0.339 -> 0.332 ms per 8 x 4K frames with the tile-row order (profiles/r04/layouts_tile_order.txt)
 #endif
 template <int ORDER = MIJ_TILE_ORDER> static unsigned workgroups_for_tiles(unsigned tiles_x, unsigned tile_rows)
 {
-  const unsigned run = MIJ_TILE_RUN ? MIJ_TILE_RUN : tiles_x;
-  return ORDER == 2 ? (tiles_x * tile_rows + 8u * run - 1u) / (8u * run) * (8u * run) : tiles_x * tile_rows;
+  return ORDER == 2 ? ((tile_rows + 7u) / 8u) * 8u * tiles_x : tiles_x * tile_rows;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -795,12 +810,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup<P == 8 ? MIJ_TILE_ORDER : 1>(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position<P == 8 ? MIJ_TILE_ORDER : 1>(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
 
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
@@ -1035,12 +1047,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 #if F420P_PREFETCH
   // the luma blocks of phase B are requested early: their latency hides behind phase A's transform
@@ -1269,12 +1278,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   // ------------------------------------------------------------------ phase A: chroma -> LDS halves
@@ -1453,12 +1459,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused411_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   // ------------------------------------------------------------------ phase A: chroma -> LDS halves
@@ -1608,12 +1611,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   // ------------------------------------------------------------------ phase A: chroma -> LDS halves
@@ -1812,12 +1812,9 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup<XT_TILE_ORDER>(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position<XT_TILE_ORDER>(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift; // the merge subtracts it anyway
@@ -2021,12 +2018,9 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup<XT_TILE_ORDER>(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position<XT_TILE_ORDER>(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift;
@@ -2224,12 +2218,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   const int bx = lane & 15, by = wave * 4 + (lane >> 4);
@@ -2330,12 +2321,9 @@ __global__ __launch_bounds__(F420_THREADS, 4) void fused1_kernel(const Fused420A
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   u32x4 *stage = stage_all[wave];
 
-  const unsigned logical = tile_of_workgroup<1>(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
-  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
-  const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int frame = logical / tiles_per_frame;
-  const int tile = logical - frame * tiles_per_frame;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const TilePos tp = tile_position<1>(blockIdx.x, a); // (tile order: see there)
+  if (tp.frame < 0) return; // the launch is padded to whole groups of eight tile rows
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
   const int bx = lane & 15, by = wave * 4 + (lane >> 4);
@@ -3415,8 +3403,22 @@ __global__ __launch_bounds__(256) void bypass_planes_kernel(const GenericArgs a)
 // ==============================================================================================
 // launchers
 // ==============================================================================================
-int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
+// floor(2^32 / d) + 1 for the two divisions of tile_position, when every dividend the launch can produce keeps x * d < 2^32
+static Fused420Args with_tile_magic(const Fused420Args &a0)
 {
+  Fused420Args a = a0;
+  const uint64_t tiles_x = (uint64_t)a.tiles_x, tiles_y = (uint64_t)a.tiles_y, rows = tiles_y * (uint64_t)a.frames + 8;
+  const auto magic = [](uint64_t d, uint64_t max_dividend) -> uint32_t {
+    return d > 1 && max_dividend * d < (1ull << 32) ? (uint32_t)((1ull << 32) / d) + 1u : 0u; // (d = 1: 2^32 + 1 does not fit)
+  };
+  a.magic_tx = magic(tiles_x, rows * tiles_x); // dividends: a workgroup's index inside its XCD, or a tile number
+  a.magic_ty = magic(tiles_y, rows);
+  return a;
+}
+
+int launch_fused420(const Fused420Args &a0, bool fast, hipStream_t stream)
+{
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   // two workgroups per CU for both flavours (132 / 194 VGPRs)
@@ -3428,8 +3430,9 @@ int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused420_12(const Fused420Args &a, hipStream_t stream)
+int launch_fused420_12(const Fused420Args &a0, hipStream_t stream)
 {
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles<1>((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   if (a.qdev) hipLaunchKernelGGL((fused420_kernel<true, 2, true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
@@ -3437,8 +3440,9 @@ int launch_fused420_12(const Fused420Args &a, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused420p(const Fused420Args &a, hipStream_t stream)
+int launch_fused420p(const Fused420Args &a0, hipStream_t stream)
 {
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   // four workgroups per CU (127 VGPRs with the luma prefetch, 27 KB LDS); the per-frame-table build three (133 VGPRs)
@@ -3447,16 +3451,19 @@ int launch_fused420p(const Fused420Args &a, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fusedxt420(const FusedXtArgs &x, hipStream_t stream)
+int launch_fusedxt420(const FusedXtArgs &x0, hipStream_t stream)
 {
+  FusedXtArgs x = x0;
+  x.base = with_tile_magic(x0.base);
   const unsigned total = workgroups_for_tiles<XT_TILE_ORDER>((unsigned)x.base.tiles_x, (unsigned)x.base.tiles_y * (unsigned)x.base.frames);
   if (x.ext.rprecision > 12) hipLaunchKernelGGL(fusedxtw420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   else hipLaunchKernelGGL(fusedxt420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   return (int)hipGetLastError();
 }
 
-int launch_fused422(const Fused420Args &a, bool wide, hipStream_t stream)
+int launch_fused422(const Fused420Args &a0, bool wide, hipStream_t stream)
 {
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (wide) {
     if (a.qdev) hipLaunchKernelGGL((fused422_kernel<3, true, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
@@ -3468,32 +3475,36 @@ int launch_fused422(const Fused420Args &a, bool wide, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused411(const Fused420Args &a, hipStream_t stream)
+int launch_fused411(const Fused420Args &a0, hipStream_t stream)
 {
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (a.qdev) hipLaunchKernelGGL((fused411_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused411_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
-int launch_fused1(const Fused420Args &a, hipStream_t stream)
+int launch_fused1(const Fused420Args &a0, hipStream_t stream)
 {
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles<1>((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (a.qdev) hipLaunchKernelGGL((fused1_kernel<true, 8>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused1_kernel<false, 8>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
-int launch_fused1_12(const Fused420Args &a, hipStream_t stream)
+int launch_fused1_12(const Fused420Args &a0, hipStream_t stream)
 {
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles<1>((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (a.qdev) hipLaunchKernelGGL((fused1_kernel<true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused1_kernel<false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
-int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream)
+int launch_fused440(const Fused420Args &a0, bool wide, hipStream_t stream)
 {
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (wide) {
     if (a.qdev) hipLaunchKernelGGL((fused440_kernel<3, true, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
@@ -3505,8 +3516,9 @@ int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused444(const Fused420Args &a, hipStream_t stream)
+int launch_fused444(const Fused420Args &a0, hipStream_t stream)
 {
+  const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   // 168 VGPRs -> three waves per SIMD: 5 % faster than the unconstrained 171-register build

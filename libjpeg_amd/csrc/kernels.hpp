@@ -38,6 +38,7 @@ struct Fused420Args {
   int32_t tiles_x, tiles_y, frames;
   int32_t q[3][QROW];             // per component (Y, Cb, Cr): fill_deltas
   const int32_t *qdev;            // or null: per-frame tables in device memory, [frames][4][64] deltas << 4 (replace q)
+  uint32_t magic_tx, magic_ty;    // set by the launchers: floor(2^32 / tiles_x) + 1 and the same for tiles_y, or 0 (kernels.hip tile_position)
 };
 
 // fused JPEG XT profile C (8-bit 4:2:0 legacy frame + 12-bit 4:4:4 residual frame, see fusedxt420_kernel)
