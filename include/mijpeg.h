@@ -272,8 +272,14 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
  * pixel (0,0), strides in bytes, BIO_WIDTH / BIO_HEIGHT (the height bounds the block rows that are reconstructed, :1229-1244;
  * blocks that start outside the extent are not written, interface/imagebitmap.cpp:58-129).  data == NULL: nothing is
  * written for that component but the state advances.  flags: MIJPEG_FLAG_NO_UPSAMPLING, _NO_COLOR_TRANSFORM, _DEVICE_OUTPUT.
- * Not modelled: rectangles narrower than the frame that move sideways between calls read line-buffer memory the reference
- * never initialised; JPEG XT frames are served as the plain picture. */
+ * JPEG XT frames: the residual image has cursors and upsamplers of its own beside the legacy image's (:228-232, 356-372,
+ * 1118-1146, 1197-1222) and both follow every request -- reproduced for what the reference's command line asks for (all three
+ * components, upsampling and colour transformation on) with any order and size of rectangles; a request that walks the
+ * residual cursor of a component without upsampler behind its last row makes the reference dereference a NULL row
+ * (:1057-1058, :1201-1202): MIJPEG_ERR_OBJECT_DOESNT_EXIST here.  Component subsets of an XT frame (they merge with what a
+ * scratch buffer holds from the block before) and XT requests without upsampling or colour transformation are served as the
+ * plain picture.  Not modelled either: rectangles narrower than the frame that move sideways between calls read line-buffer
+ * memory the reference never initialised. */
 typedef struct mijpeg_bitmap {
   void *data;
   int32_t bytes_per_pixel, bytes_per_row;
@@ -287,7 +293,8 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
  * window start / end (lines), number of mapped block rows that are zeros. */
 int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
                         uint32_t flags, const uint32_t bm_height[MIJPEG_MAX_COMPONENTS], int32_t out[8 + 6 * MIJPEG_MAX_COMPONENTS]);
-/* Diagnostics: coefficient row the cursor of `component` stands at after the mijpeg_display_rect calls so far. */
+/* Diagnostics: coefficient row the cursor of `component` stands at after the mijpeg_display_rect calls so far (JPEG XT:
+ * 4 + c = component c of the residual image, which has cursors of its own, control/blockbitmaprequester.cpp:228-232). */
 int mijpeg_display_cursor(mijpeg_decoder *d, int component);
 
 /* The scans of the decoded frame in codestream order: first_byte[k] = offset (in the input of mijpeg_set_input) of the first

@@ -357,6 +357,10 @@ class Decoder:
                     comps=[dict(cursor=o[8 + 6 * c], g0=o[9 + 6 * c], g1=o[10 + 6 * c], wstart=o[11 + 6 * c], wlimit=o[12 + 6 * c],
                                 zeros=o[13 + 6 * c]) for c in range(4)])
 
+    def display_cursor(self, component: int) -> int:
+        """mijpeg_display_cursor: the row the cursor of `component` stands at (JPEG XT: 4 + c = the residual image's)."""
+        return int(lib().mijpeg_display_cursor(self._h, component))
+
     def decode_batch_device(self, streams, min_intervals: int = 0) -> MijpegInfo:
         """mijpeg_decode_batch_device: n streams of one shape -> n coefficient stores in HBM with one Huffman kernel launch."""
         n = len(streams)

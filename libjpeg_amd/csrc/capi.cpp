@@ -52,7 +52,7 @@ struct mijpeg_decoder {
   int img_view = -1;           // component of a non-upsampled reconstruction, -1: the whole picture
   // mijpeg_display_rect: the reference's state between DisplayRectangle calls (request_model.hpp) and the buffers of the
   // requests that do not show the plain picture
-  RequestModel model;
+  RequestModel model, rmodel; // (rmodel: the residual image of a JPEG XT frame)
   bool model_valid = false;
   uint8_t *req_dev = nullptr, *req_host = nullptr; // frame-sized interleaved image (device; pinned host)
   size_t req_dev_cap = 0, req_host_cap = 0;
@@ -1810,7 +1810,7 @@ struct RequestExtra {
   const int32_t *rowmap_dev;
   int32_t rowmap_stride;
   int32_t corner_x, corner_y, y_base, y_count;
-  int32_t wstart[MIJPEG_MAX_COMPONENTS], wlimit[MIJPEG_MAX_COMPONENTS];
+  int32_t wstart[MAXP], wlimit[MAXP]; // per plane (JPEG XT: legacy planes, then residual planes)
   int32_t ycc;
 };
 static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const RequestExtra *rx);
@@ -1820,7 +1820,7 @@ int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream) { return laun
 static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const RequestExtra *rx)
 {
   if (!b || !b->coef_dev || !b->out_dev || b->frames < 1) return MIJPEG_ERR_INVALID_PARAMETER;
-  if (rx && (b->info.xt || !(b->flags & MIJPEG_FLAG_FORCE_GENERIC))) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (rx && !(b->flags & MIJPEG_FLAG_FORCE_GENERIC)) return MIJPEG_ERR_INVALID_PARAMETER;
   if (b->quant_dev && b->info.xt) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: plain JPEG only
   const mijpeg_info &f = b->info;
   if ((f.precision != 8 && f.precision != 12) || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
@@ -2007,11 +2007,11 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       a.req_y0 = rx->corner_y;
       a.y_base = rx->y_base;
       a.y_count = rx->y_count;
-      for (int c = 0; c < f.components; c++) {
+      for (int c = 0; c < a.nplanes && c < MAXP; c++) {
         a.wstart[c] = rx->wstart[c];
         a.wlimit[c] = rx->wlimit[c];
       }
-      a.ycbcr = rx->ycc; // the colour transformer the first request built (colortransformerfactory.cpp:220-221)
+      if (!f.xt) a.ycbcr = rx->ycc; // the colour transformer the first request built (colortransformerfactory.cpp:220-221)
     }
     // plain JPEG frames of any layout go through LDS in one pass (fused_tile_kernel); the pair with its sample planes in HBM
     // stays for JPEG XT, int32 coefficient planes, per-frame tables in device memory, rectangle requests and MIJPEG_FLAG_FORCE_GENERIC
@@ -2778,6 +2778,84 @@ static mijpeg_info request_frame(const mijpeg_info &f, int view, bool all_compon
   return v;
 }
 
+// The request models of a decoded image start with its first DisplayRectangle call (every decode resets them): one for a plain
+// frame; two for a JPEG XT frame -- legacy and residual image share m_bSubsampling (request_model.hpp)
+static void ensure_request_models(mijpeg_decoder *d)
+{
+  if (d->model_valid) return;
+  const mijpeg_info &f = d->host.info;
+  if (d->host.is_xt() && f.components == 3) {
+    const mijpeg_info &r = d->host.xt.residual;
+    bool lsub = false, rsub = false;
+    for (int c = 0; c < 3; c++) {
+      lsub = lsub || f.subx[c] > 1 || f.suby[c] > 1;
+      rsub = rsub || r.subx[c] > 1 || r.suby[c] > 1;
+    }
+    d->model.reset(3, f.width, f.height, f.subx, f.suby, true, false, nullptr, nullptr, rsub);
+    d->rmodel.reset(3, f.width, f.height, r.subx, r.suby, true, false, nullptr, nullptr, lsub);
+  } else
+    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0, f.dnl != 0, f.rows, f.blocks_h);
+  d->model_valid = true;
+}
+
+// The lines a request reconstructed into d->req_dev (row bytes each, nc interleaved samples of sb bytes) go out to the client's
+// bitmaps: columns [min_x, cx1[c]], lines [min_y, cy1[c]] of component c
+static int hand_out_request(mijpeg_decoder *d, int min_x, int min_y, int y_count, const int32_t *cx1, const int32_t *cy1, int min_comp, int max_comp,
+                            int nc, int sb, size_t row, size_t padded, int vc, bool all_on_view, bool to_device, void *const *dst, const int32_t *bpp,
+                            const int32_t *bpr)
+{
+  // hand the lines out
+  for (int c = min_comp; c <= max_comp; c++) {
+    if (!dst[c] || cx1[c] < min_x || cy1[c] < min_y) continue;
+    const int plane = vc >= 0 ? (all_on_view ? c : 0) : c;
+    if (to_device) {
+      ScatterArgs a;
+      memset(&a, 0, sizeof(a));
+      a.src = d->req_dev;
+      a.src_row = (int64_t)row;
+      a.ncomp = nc;
+      a.sample_bytes = sb;
+      a.x0 = min_x;
+      a.y0 = min_y;
+      a.w = cx1[c] - min_x + 1;
+      a.h = cy1[c] - min_y + 1;
+      a.c0 = a.c1 = plane;
+      a.dst[plane] = (uint8_t *)dst[c];
+      a.bytes_per_pixel[plane] = bpp[c];
+      a.bytes_per_row[plane] = bpr[c];
+      if (launch_scatter_rect(a, d->stream)) return hip_fail(d, hipGetLastError(), "scatter_rect_kernel launch");
+    }
+  }
+  if (to_device) {
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    return MIJPEG_OK;
+  }
+  if (d->req_host_cap < padded) {
+    if (d->req_host) (void)hipHostFree(d->req_host);
+    d->req_host = nullptr;
+    d->req_host_cap = 0;
+    HIP_TRY(d, hipHostMalloc((void **)&d->req_host, padded, hipHostMallocDefault));
+    d->req_host_cap = padded;
+  }
+  HIP_TRY(d, hipMemcpyAsync(d->req_host + (size_t)min_y * row, d->req_dev + (size_t)min_y * row, (size_t)y_count * row, hipMemcpyDeviceToHost,
+                            d->stream));
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  for (int c = min_comp; c <= max_comp; c++) {
+    if (!dst[c] || cx1[c] < min_x || cy1[c] < min_y) continue;
+    const int plane = vc >= 0 ? (all_on_view ? c : 0) : c;
+    const int n = cx1[c] - min_x + 1;
+    for (int y = min_y; y <= cy1[c]; y++) {
+      const uint8_t *src = d->req_host + (size_t)y * row + ((size_t)min_x * nc + plane) * sb;
+      uint8_t *out = (uint8_t *)dst[c] + (ptrdiff_t)y * bpr[c] + (ptrdiff_t)min_x * bpp[c];
+      if (sb == 1)
+        for (int x = 0; x < n; x++) out[(ptrdiff_t)x * bpp[c]] = src[(size_t)x * nc];
+      else
+        for (int x = 0; x < n; x++) memcpy(out + (ptrdiff_t)x * bpp[c], src + (size_t)x * nc * 2, 2);
+    }
+  }
+  return MIJPEG_OK;
+}
+
 int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
                         uint32_t flags, const mijpeg_bitmap bitmaps[MIJPEG_MAX_COMPONENTS])
 {
@@ -2804,18 +2882,108 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
     bm_h[c] = bitmaps[c].height;
   }
   if (d->host.is_xt()) {
-    // JPEG XT: the residual image has cursors of its own in the reference; requests are served as the plain picture
-    // (top-down stripes and whole frames, which is what its clients do, are the same thing there)
-    uint32_t maxmcu = 0xffffffffu;
-    for (int c = min_comp; c <= max_comp; c++) maxmcu = std::min(maxmcu, (bm_h[c] >> 3) - 1u);
-    if (maxmcu != 0xffffffffu && (int64_t)max_y > (int64_t)maxmcu * 8 + 7) max_y = (int32_t)(maxmcu * 8 + 7);
-    if (max_y < min_y) return MIJPEG_OK;
-    return mijpeg_reconstruct_rect(d, min_x, min_y, max_x, max_y, min_comp, max_comp, flags, dst, bpp, bpr);
+    // JPEG XT: the residual image has row cursors and upsamplers of its own beside the legacy image's
+    // (control/blockbitmaprequester.cpp:228-232, 356-372, 1118-1146, 1197-1222): one request model per image, fed the same
+    // requests.  In the contract: what the reference's command line asks for -- all three components, upsampling and colour
+    // transformation on -- with any order and size of rectangles.  (A component subset merges with whatever m_ppDTemp holds from
+    // the block before, a request without the transformation builds another transformer: served as the plain picture.)
+    const mijpeg_xt_params &x = d->host.xt;
+    auto plain_picture = [&]() -> int {
+      uint32_t maxmcu = 0xffffffffu;
+      for (int c = min_comp; c <= max_comp; c++) maxmcu = std::min(maxmcu, (bm_h[c] >> 3) - 1u);
+      if (maxmcu != 0xffffffffu && (int64_t)max_y > (int64_t)maxmcu * 8 + 7) max_y = (int32_t)(maxmcu * 8 + 7);
+      if (max_y < min_y) return MIJPEG_OK;
+      return mijpeg_reconstruct_rect(d, min_x, min_y, max_x, max_y, min_comp, max_comp, flags, dst, bpp, bpr);
+    };
+    if (!upsample || !ctrafo || min_comp != 0 || max_comp != 2 || f.components != 3) return plain_picture();
+    const mijpeg_info &r = x.residual;
+    ensure_request_models(d);
+    const RequestPlan pl = d->model.request(min_x, min_y, max_x, max_y, 0, 2, true, true, bm_h);
+    const RequestPlan pr = x.no_residual ? pl : d->rmodel.request(min_x, min_y, max_x, max_y, 0, 2, true, true, bm_h);
+    if (pl.nothing) return MIJPEG_OK;
+    // a residual component without an upsampler whose cursor stands behind its last row: `rrow->BlockAt(x)` on a NULL row
+    // (:1057-1058, :1201-1202) -- the reference does not survive this request
+    if (!x.no_residual)
+      for (int c = 0; c < 3; c++)
+        if (!(pr.upsampling_path && pr.upsampler[c]))
+          for (int g = pr.g0[c]; g <= pr.g1[c]; g++)
+            if (g >= (int)pr.rowmap[c].size() || pr.rowmap[c][(size_t)g] < 0)
+              return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST,
+                               "the request walks the residual image's row cursor behind its last row (the reference dereferences a NULL row here)");
+    if (pl.plain && (x.no_residual || pr.plain)) return plain_picture();
+    // ---- not the plain picture: both images through the unfused kernels with their row maps on this request's lines
+    int32_t cx1[MIJPEG_MAX_COMPONENTS], cy1[MIJPEG_MAX_COMPONENTS];
+    for (int c = 0; c < 3; c++) {
+      auto last_in = [](int32_t lo, int32_t hi, uint32_t extent) -> int32_t {
+        if ((uint32_t)lo >= extent) return lo - 1;
+        const int64_t last_block = ((int64_t)extent - 1) >> 3;
+        return (int32_t)std::min<int64_t>(hi, std::max<int64_t>(last_block, lo >> 3) * 8 + 7);
+      };
+      cx1[c] = last_in(pl.min_x, pl.max_x, bm_w[c]);
+      cy1[c] = last_in(pl.min_y, pl.max_y, bm_h[c]);
+    }
+    HIP_TRY(d, hipSetDevice(d->device));
+    mijpeg_batch b;
+    memset(&b, 0, sizeof(b));
+    b.info = f;
+    b.xt = &x;
+    const int sb = f.sample_bytes > 0 ? f.sample_bytes : 2;
+    const size_t row = ((size_t)f.width * 3 * sb + 7) & ~(size_t)7, padded = row * f.height;
+    int rc = ensure_dev(d, (void **)&d->req_dev, &d->req_dev_cap, padded);
+    if (rc) return rc;
+    int stride = 1;
+    for (int c = 0; c < 3; c++) stride = std::max(stride, std::max(f.blocks_h[c], r.blocks_h[c]));
+    std::vector<int32_t> maps((size_t)6 * stride);
+    for (int pn = 0; pn < 6; pn++) {
+      const RequestPlan &p = pn < 3 ? pl : pr;
+      const int c = pn % 3;
+      int32_t *m = maps.data() + (size_t)pn * stride;
+      for (int g = 0; g < stride; g++) m[g] = g;
+      if (pn >= 3 && x.no_residual) continue;
+      for (int g = p.g0[c]; g <= p.g1[c] && g < stride && g < (int)p.rowmap[c].size(); g++) m[g] = p.rowmap[c][(size_t)g];
+    }
+    rc = ensure_dev(d, (void **)&d->rowmap_dev, &d->rowmap_cap, maps.size() * sizeof(int32_t));
+    if (rc) return rc;
+    HIP_TRY(d, hipMemcpyAsync(d->rowmap_dev, maps.data(), maps.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream)); // `maps` is pageable and leaves scope
+    b.coef_dev = d->coef_dev;
+    b.coef_frame_stride = f.coef_count;
+    b.out_dev = d->req_dev;
+    b.out_row_stride = (int64_t)row;
+    b.out_frame_stride = (int64_t)padded;
+    b.frames = 1;
+    b.flags = pass | MIJPEG_FLAG_FORCE_GENERIC;
+    const size_t ws = mijpeg_workspace_bytes(&b);
+    if (ws) {
+      rc = ensure_dev(d, (void **)&d->ws_dev, &d->ws_cap, ws);
+      if (rc) return rc;
+      b.workspace = d->ws_dev;
+      b.workspace_bytes = d->ws_cap;
+    }
+    const int y_count = pl.max_y - pl.min_y + 1;
+    RequestExtra rx;
+    memset(&rx, 0, sizeof(rx));
+    rx.rowmap_dev = d->rowmap_dev;
+    rx.rowmap_stride = stride;
+    rx.corner_x = pl.corner_x;
+    rx.corner_y = pl.corner_y;
+    rx.y_base = pl.min_y;
+    rx.y_count = y_count;
+    rx.ycc = 1;
+    for (int pn = 0; pn < 6; pn++) {
+      const RequestPlan &p = pn < 3 ? pl : pr;
+      const mijpeg_info &g = pn < 3 ? f : r;
+      const int c = pn % 3;
+      const bool up = p.upsampling_path && p.upsampler[c] && !(pn >= 3 && x.no_residual);
+      rx.wstart[pn] = up ? p.wstart[c] : 0;
+      rx.wlimit[pn] = up ? p.wlimit[c] : (f.height + g.suby[c] - 1) / g.suby[c];
+    }
+    rc = launch_reconstruct_ex(&b, d->stream, &rx);
+    if (rc) return set_error(d, rc, rc == MIJPEG_ERR_DEVICE ? std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError())
+                                                             : std::string("reconstruction not available for this request"));
+    return hand_out_request(d, pl.min_x, pl.min_y, y_count, cx1, cy1, 0, 2, 3, sb, row, padded, -1, false, to_device, dst, bpp, bpr);
   }
-  if (!d->model_valid) {
-    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0, f.dnl != 0, f.rows, f.blocks_h);
-    d->model_valid = true;
-  }
+  ensure_request_models(d);
   const RequestPlan p = d->model.request(min_x, min_y, max_x, max_y, min_comp, max_comp, upsample, ctrafo, bm_h);
   if (p.nothing) return MIJPEG_OK;
   // BitmapCtrl::ExtractBitmap (interface/imagebitmap.cpp:58-129): a block whose corner lies outside the bitmap the hook
@@ -2924,56 +3092,7 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
     if (rc) return set_error(d, rc, rc == MIJPEG_ERR_DEVICE ? std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError())
                                                              : std::string("reconstruction not available for this request"));
   }
-  // hand the lines out
-  for (int c = min_comp; c <= max_comp; c++) {
-    if (!dst[c] || cx1[c] < p.min_x || cy1[c] < p.min_y) continue;
-    const int plane = vc >= 0 ? (all_on_view ? c : 0) : c;
-    if (to_device) {
-      ScatterArgs a;
-      memset(&a, 0, sizeof(a));
-      a.src = d->req_dev;
-      a.src_row = (int64_t)row;
-      a.ncomp = nc;
-      a.sample_bytes = sb;
-      a.x0 = p.min_x;
-      a.y0 = p.min_y;
-      a.w = cx1[c] - p.min_x + 1;
-      a.h = cy1[c] - p.min_y + 1;
-      a.c0 = a.c1 = plane;
-      a.dst[plane] = (uint8_t *)dst[c];
-      a.bytes_per_pixel[plane] = bpp[c];
-      a.bytes_per_row[plane] = bpr[c];
-      if (launch_scatter_rect(a, d->stream)) return hip_fail(d, hipGetLastError(), "scatter_rect_kernel launch");
-    }
-  }
-  if (to_device) {
-    HIP_TRY(d, hipStreamSynchronize(d->stream));
-    return MIJPEG_OK;
-  }
-  if (d->req_host_cap < padded) {
-    if (d->req_host) (void)hipHostFree(d->req_host);
-    d->req_host = nullptr;
-    d->req_host_cap = 0;
-    HIP_TRY(d, hipHostMalloc((void **)&d->req_host, padded, hipHostMallocDefault));
-    d->req_host_cap = padded;
-  }
-  HIP_TRY(d, hipMemcpyAsync(d->req_host + (size_t)p.min_y * row, d->req_dev + (size_t)p.min_y * row, (size_t)y_count * row, hipMemcpyDeviceToHost,
-                            d->stream));
-  HIP_TRY(d, hipStreamSynchronize(d->stream));
-  for (int c = min_comp; c <= max_comp; c++) {
-    if (!dst[c] || cx1[c] < p.min_x || cy1[c] < p.min_y) continue;
-    const int plane = vc >= 0 ? (all_on_view ? c : 0) : c;
-    const int n = cx1[c] - p.min_x + 1;
-    for (int y = p.min_y; y <= cy1[c]; y++) {
-      const uint8_t *src = d->req_host + (size_t)y * row + ((size_t)p.min_x * nc + plane) * sb;
-      uint8_t *out = (uint8_t *)dst[c] + (ptrdiff_t)y * bpr[c] + (ptrdiff_t)p.min_x * bpp[c];
-      if (sb == 1)
-        for (int x = 0; x < n; x++) out[(ptrdiff_t)x * bpp[c]] = src[(size_t)x * nc];
-      else
-        for (int x = 0; x < n; x++) memcpy(out + (ptrdiff_t)x * bpp[c], src + (size_t)x * nc * 2, 2);
-    }
-  }
-  return MIJPEG_OK;
+  return hand_out_request(d, p.min_x, p.min_y, y_count, cx1, cy1, min_comp, max_comp, nc, sb, row, padded, vc, all_on_view, to_device, dst, bpp, bpr);
 }
 
 int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_byte, int capacity)
@@ -3008,13 +3127,14 @@ int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
   if (!d || !bm_height || !out) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->host.info.components < 1 || d->host.info.width < 1) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no parsed stream: call mijpeg_read_header first");
   const mijpeg_info &f = d->host.info;
-  if (!d->model_valid) {
-    d->model.reset(f.components, f.width, f.height, f.subx, f.suby, f.ycbcr != 0, f.dnl != 0, f.rows, f.blocks_h);
-    d->model_valid = true;
-  }
+  ensure_request_models(d);
   const RequestPlan p = d->model.request(min_x, min_y, max_x, max_y, min_comp, max_comp, !(flags & MIJPEG_FLAG_NO_UPSAMPLING),
                                          !(flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM), bm_height);
-  out[0] = p.nothing; out[1] = p.plain; out[2] = p.ycc; out[3] = p.view;
+  bool rplain = true;
+  if (d->host.is_xt() && f.components == 3 && !d->host.xt.no_residual) // (the residual image: cursors through mijpeg_display_cursor(4 + c))
+    rplain = d->rmodel.request(min_x, min_y, max_x, max_y, min_comp, max_comp, !(flags & MIJPEG_FLAG_NO_UPSAMPLING),
+                               !(flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM), bm_height).plain;
+  out[0] = p.nothing; out[1] = p.plain && rplain; out[2] = p.ycc; out[3] = p.view;
   out[4] = p.min_x; out[5] = p.min_y; out[6] = p.max_x; out[7] = p.max_y;
   for (int c = 0; c < MIJPEG_MAX_COMPONENTS; c++) {
     int32_t *o = out + 8 + 6 * c;
@@ -3028,8 +3148,8 @@ int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
 
 int mijpeg_display_cursor(mijpeg_decoder *d, int component)
 {
-  if (!d || component < 0 || component >= MIJPEG_MAX_COMPONENTS || !d->model_valid) return 0;
-  return d->model.cursor(component);
+  if (!d || component < 0 || component >= 2 * MIJPEG_MAX_COMPONENTS || !d->model_valid) return 0;
+  return component >= MIJPEG_MAX_COMPONENTS ? d->rmodel.cursor(component - MIJPEG_MAX_COMPONENTS) : d->model.cursor(component);
 }
 
 } // extern "C"

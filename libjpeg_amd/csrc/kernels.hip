@@ -3200,7 +3200,7 @@ __global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
 {
   const int groups = (a.width + 7) >> 3;
   const int gxi = blockIdx.x * blockDim.x + threadIdx.x;
-  const int Y = blockIdx.y;
+  const int Y = a.y_base + blockIdx.y; // (rectangle requests: the lines of the request only)
   const int frame = blockIdx.z;
   if (gxi >= groups) return;
   const int X0 = gxi * 8;
@@ -3289,7 +3289,7 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
 {
   const int groups = (a.width + 7) >> 3;
   const int gxi = blockIdx.x * blockDim.x + threadIdx.x;
-  const int Y = blockIdx.y;
+  const int Y = a.y_base + blockIdx.y; // (rectangle requests: the lines of the request only)
   const int frame = blockIdx.z;
   if (gxi >= groups) return;
   const int X0 = gxi * 8;
@@ -3369,18 +3369,26 @@ __global__ __launch_bounds__(256) void bypass_planes_kernel(const GenericArgs a)
   if (blk >= nblocks) return;
   const bool wide = p >= a.wide_first && p < a.wide_first + a.wide_count; // int32 coefficients (two int16 slots each)
   const int16_t *plane = a.coef + (int64_t)frame * a.coef_frame_stride + a.coef_off[p];
+  const int by = blk / a.bw[p], bx = blk - by * a.bw[p];
+  // rectangle requests: the block row's coefficients come from the row the residual image's cursor stood at (GenericArgs::rowmap);
+  // a row that does not exist keeps what idct_planes_kernel made of it
+  int sblk = blk;
+  if (a.rowmap) {
+    const int srow = a.rowmap[p * a.rowmap_stride + by];
+    if (srow < 0) return;
+    sblk = srow * a.bw[p] + bx;
+  }
   int res[64];
   if (wide) {
-    const int *src = reinterpret_cast<const int *>(plane) + (int64_t)blk * 64;
+    const int *src = reinterpret_cast<const int *>(plane) + (int64_t)sblk * 64;
 #pragma unroll
     for (int i = 0; i < 64; i++) res[i] = src[i];
   } else {
-    const int16_t *src = plane + (int64_t)blk * 64;
+    const int16_t *src = plane + (int64_t)sblk * 64;
 #pragma unroll
     for (int i = 0; i < 64; i++) res[i] = src[i];
   }
   const int quant = a.rquant63[c], dcs = a.rdcshift;
-  const int by = blk / a.bw[p], bx = blk - by * a.bw[p];
   const int pitch = a.bw[p] * 8;
   int *dst = a.samples + (int64_t)frame * a.sample_frame_stride + a.sample_off[p] + ((int64_t)by * 8) * pitch + bx * 8;
   for (int y = 0; y < 64; y += 16)
@@ -3644,7 +3652,7 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
     hipLaunchKernelGGL(bypass_planes_kernel, dim3((rb + 255) / 256, 3 * a.frames), dim3(256), 0, stream, a);
   }
   if (a.xt) {
-    const int rlay = layout_of(3, 3);
+    const int rlay = a.request ? LAYOUT_ANY : layout_of(3, 3);
     if (rlay == layout_id(1, 1) && lay == layout_id(2, 2)) LAUNCH_XT(layout_id(2, 2), layout_id(1, 1));
     else if (rlay == layout_id(1, 1) && lay == layout_id(1, 1)) LAUNCH_XT(layout_id(1, 1), layout_id(1, 1));
     else if (rlay == layout_id(1, 1) && lay == layout_id(2, 1)) LAUNCH_XT(layout_id(2, 1), layout_id(1, 1));

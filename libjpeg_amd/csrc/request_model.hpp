@@ -57,12 +57,15 @@ public:
   // and made it 2^31 - 1 lines (upsampling/upsamplerbase.cpp:61-75), so nothing clips their buffered region at the bottom of
   // the picture (:138-156, :218-228) -- and after its first scan created block rows without knowing where to stop
   // (control/blockbuffer.cpp:212-265): rows[c] of them exist (the store keeps store_rows[c]).
+  // other_image_subsampled: JPEG XT -- the legacy and the residual image of one frame share m_bSubsampling
+  // (control/blockbitmaprequester.cpp:318, 370): a subsampled component in EITHER image puts both on the upsampling path, where
+  // every component without an upsampler advances with every block row shown (:1214-1222).  One model per image, same requests.
   void reset(int ncomp, int width, int height, const int32_t *subx, const int32_t *suby, bool frame_ycbcr, bool dnl = false,
-             const int32_t *rows = nullptr, const int32_t *store_rows = nullptr)
+             const int32_t *rows = nullptr, const int32_t *store_rows = nullptr, bool other_image_subsampled = false)
   {
     nc_ = ncomp; w_ = width; h_ = height; frame_ycbcr_ = frame_ycbcr;
     dnl_ = dnl && rows && store_rows;
-    subsampling_ = false;
+    subsampling_ = other_image_subsampled;
     trafo_built_ = false;
     ycc_ = false;
     for (int c = 0; c < 4; c++) {
@@ -78,6 +81,8 @@ public:
     }
   }
   int cursor(int c) const { return cur_[c]; }
+  bool subsampled() const { for (int c = 0; c < nc_; c++) if (up_[c]) return true; return false; }
+  int rows(int c) const { return rows_[c]; }
   bool transformer_built() const { return trafo_built_; }
 
   // One DisplayRectangle call.  Rectangle and component range as the tags give them (inclusive; clipped here like

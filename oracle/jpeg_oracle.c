@@ -1716,6 +1716,54 @@ static void xt_bypass_block(int32_t *dst, const int32_t *res, int32_t quant, int
     }
 }
 
+/* One pixel of the JPEG XT merge: v = the legacy sample after the L transformation (integer), rk = the residual samples * 16
+ * as the residual transform (or the bypass) left them.  colortrafo/ycbcrtrafo.cpp:750-829 (residual), :861-878 (L-LUT,
+ * C transformation, merge), :897-955 (half clamp). */
+static void xt_merge_pixel(const oj_xt *xt, int64_t maxval, const int64_t vin[3], const int32_t rk[3], uint16_t out[3])
+{
+  const oj_info *r = xt->rinfo;
+  const int64_t rmax16 = ((((int64_t)1 << r->precision)) << 4) - 1; /* ((m_lRMax + 1) << COLOR_BITS) - 1 */
+  const int64_t omax16 = ((xt->outmax + 1) << 4) - 1;
+  int64_t rr[3], q3[3], lv[3], v[3];
+  int c;
+  if (xt->no_residual) { rr[0] = rr[1] = rr[2] = xt->outshift; goto merge; }
+  /* Q tables (APPLY_LUT: index clamped to the table); the identity, 2^(Pr + 4) -> 2^(16 + 4), scales by 2^(16 - Pr)
+   * (parametrictonemappingbox.cpp:387-430) */
+  for (c = 0; c < 3; c++) {
+    const int64_t idx = clampmax(rk[c], rmax16);
+    q3[c] = xt->qlut[c] ? xt->qlut[c][idx] : idx << (16 - r->precision);
+  }
+  if (xt->rtrafo_ycbcr) {
+    const int64_t *M = xt->rmat;
+    const int64_t ry = q3[0], rcb = q3[1] - (xt->outshift << 4), rcr = q3[2] - (xt->outshift << 4);
+    rr[0] = (ry * M[0] + rcb * M[1] + rcr * M[2] + 4096) >> 13; /* FIX_COLOR_TO_INTCOLOR */
+    rr[1] = (ry * M[3] + rcb * M[4] + rcr * M[5] + 4096) >> 13;
+    rr[2] = (ry * M[6] + rcb * M[7] + rcr * M[8] + 4096) >> 13;
+  } else {
+    rr[0] = q3[0]; rr[1] = q3[1]; rr[2] = q3[2];
+  }
+  /* R2 tables; the identity 2^(16 + 4) -> 2^16 is floor(x / 16 + 0.5) */
+  for (c = 0; c < 3; c++) {
+    const int64_t idx = clampmax(rr[c], omax16);
+    rr[c] = xt->r2lut[c] ? xt->r2lut[c][idx] : (idx + 8) >> 4;
+  }
+merge:
+  for (c = 0; c < 3; c++) lv[c] = xt->ltable[c] ? xt->ltable[c][clampmax(vin[c], maxval)] : vin[c];
+  /* C transformation, FIX_TO_INT (the identity leaves the values alone: (x * 8192 + 4096) >> 13 == x) */
+  for (c = 0; c < 3; c++)
+    v[c] = ((lv[0] * xt->cmat[3 * c] + lv[1] * xt->cmat[3 * c + 1] + lv[2] * xt->cmat[3 * c + 2] + 4096) >> 13) + rr[c] - xt->outshift;
+  if (xt->is_float && xt->clamp) {
+    const int64_t pinf = (xt->outmax >> 1) - (xt->outmax >> 6) - 1;
+    const int64_t minf = invert_negs((int16_t)(uint16_t)(pinf | 0x8000));
+    for (c = 0; c < 3; c++) {
+      int64_t t = v[c] > pinf ? pinf : (v[c] < minf ? minf : v[c]);
+      out[c] = (uint16_t)invert_negs((int16_t)t);
+    }
+  } else {
+    for (c = 0; c < 3; c++) out[c] = (uint16_t)clampmax(v[c], xt->outmax);
+  }
+}
+
 /* Output: pixels8 (precision 8, no XT) or pixels16 (precision 12, or XT: 16 bit codes). */
 static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint8_t *pixels8, uint16_t *pixels16,
                           int use_ycbcr, const oj_xt *xt)
@@ -1787,47 +1835,9 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
             for (c = 0; c < f->ncomp; c++) v[c] = ((int64_t)blk[c][k] + 8) >> 4;
           }
           if (xt) {
-            /* colortrafo/ycbcrtrafo.cpp:750-829 (residual), :861-878 (L-LUT, C transformation, merge), :897-955 (half clamp) */
-            const oj_info *r = xt->rinfo;
-            const int64_t rmax16 = ((((int64_t)1 << r->precision)) << 4) - 1; /* ((m_lRMax + 1) << COLOR_BITS) - 1 */
-            const int64_t omax16 = ((xt->outmax + 1) << 4) - 1;
-            int64_t rr[3], q3[3], lv[3];
-            if (xt->no_residual) { rr[0] = rr[1] = rr[2] = xt->outshift; goto merge; }
-            /* Q tables (APPLY_LUT: index clamped to the table); the identity, 2^(Pr + 4) -> 2^(16 + 4), scales by 2^(16 - Pr)
-             * (parametrictonemappingbox.cpp:387-430) */
-            for (c = 0; c < 3; c++) {
-              const int64_t idx = clampmax(rblk[c][k], rmax16);
-              q3[c] = xt->qlut[c] ? xt->qlut[c][idx] : idx << (16 - r->precision);
-            }
-            if (xt->rtrafo_ycbcr) {
-              const int64_t *M = xt->rmat;
-              const int64_t ry = q3[0], rcb = q3[1] - (xt->outshift << 4), rcr = q3[2] - (xt->outshift << 4);
-              rr[0] = (ry * M[0] + rcb * M[1] + rcr * M[2] + 4096) >> 13; /* FIX_COLOR_TO_INTCOLOR */
-              rr[1] = (ry * M[3] + rcb * M[4] + rcr * M[5] + 4096) >> 13;
-              rr[2] = (ry * M[6] + rcb * M[7] + rcr * M[8] + 4096) >> 13;
-            } else {
-              rr[0] = q3[0]; rr[1] = q3[1]; rr[2] = q3[2];
-            }
-            /* R2 tables; the identity 2^(16 + 4) -> 2^16 is floor(x / 16 + 0.5) */
-            for (c = 0; c < 3; c++) {
-              const int64_t idx = clampmax(rr[c], omax16);
-              rr[c] = xt->r2lut[c] ? xt->r2lut[c][idx] : (idx + 8) >> 4;
-            }
-          merge:
-            for (c = 0; c < 3; c++) lv[c] = xt->ltable[c] ? xt->ltable[c][clampmax(v[c], maxval)] : v[c];
-            /* C transformation, FIX_TO_INT (the identity leaves the values alone: (x * 8192 + 4096) >> 13 == x) */
-            for (c = 0; c < 3; c++)
-              v[c] = ((lv[0] * xt->cmat[3 * c] + lv[1] * xt->cmat[3 * c + 1] + lv[2] * xt->cmat[3 * c + 2] + 4096) >> 13) + rr[c] - xt->outshift;
-            if (xt->is_float && xt->clamp) {
-              const int64_t pinf = (xt->outmax >> 1) - (xt->outmax >> 6) - 1;
-              const int64_t minf = invert_negs((int16_t)(uint16_t)(pinf | 0x8000));
-              for (c = 0; c < 3; c++) {
-                int64_t t = v[c] > pinf ? pinf : (v[c] < minf ? minf : v[c]);
-                pixels16[pix + c] = (uint16_t)invert_negs((int16_t)t);
-              }
-            } else {
-              for (c = 0; c < 3; c++) pixels16[pix + c] = (uint16_t)clampmax(v[c], xt->outmax);
-            }
+            int32_t rk[3] = {0, 0, 0};
+            if (!xt->no_residual) { rk[0] = rblk[0][k]; rk[1] = rblk[1][k]; rk[2] = rblk[2][k]; }
+            xt_merge_pixel(xt, maxval, v, rk, pixels16 + pix);
           } else if (pixels8) {
             for (c = 0; c < f->ncomp; c++) pixels8[pix + c] = (uint8_t)clampmax(v[c], maxval);
           } else {
@@ -1869,8 +1879,11 @@ int oj_reconstruct16(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], uint1
  *    start on the block grid see subsampled components displaced in their first row / column of blocks;
  *  - requests that skip or repeat stripes read the rows the cursors happen to stand at;
  *  - the colour transformer is chosen by the first request and kept (colortransformerfactory.cpp:220-221).
- * Not modelled: JPEG XT residuals, alpha channels, and reads of line-buffer memory the reference never initialised
- * (rectangles narrower than the frame that move sideways between calls): OJ_ERR_UNSUPPORTED.
+ * JPEG XT (oj_xt_requester_new): the residual image's cursors and upsamplers run beside the legacy image's, for requests over all
+ * three components with upsampling and colour transformation on; a request that reads a residual row behind the last one is
+ * where the reference dereferences NULL: OJ_ERR_UNSUPPORTED at that call.
+ * Not modelled: component subsets / no transformation on XT frames, alpha channels, and reads of line-buffer memory the reference
+ * never initialised (rectangles narrower than the frame that move sideways between calls): OJ_ERR_UNSUPPORTED.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
   int sx, sy, width, total; /* m_ucSubX/Y, m_ulWidth, m_lTotalLines (upsamplerbase.cpp:61-77) */
@@ -1889,7 +1902,17 @@ struct oj_requester {
   int subsampling;        /* m_bSubsampling */
   int trafo_built, ycc;   /* the colour transformer is built by the first request that reconstructs something and kept
                              (colortrafo/colortransformerfactory.cpp:220-221): later JPGTAG_MATRIX_LTRAFO values change nothing */
+  /* JPEG XT: the residual image's side of the same state (m_pppRImage, m_ppResidualUpsampler; blockbitmaprequester.cpp:
+   * 228-232, 356-372, 1118-1146, 1197-1222) and the merge the colour transformer performs (oj_xt) */
+  const oj_xt *xt;
+  const oj_info *rf;
+  const int32_t *rplanes[OJ_MAX_COMP];
+  int rcur[OJ_MAX_COMP], rrows[OJ_MAX_COMP];
+  oj_up *rup[OJ_MAX_COMP];
+  struct oj_xt_ctx *owner; /* what oj_xt_requester_new decoded and built; freed with the requester */
 };
+struct oj_xt_ctx;
+static void xt_ctx_free(struct oj_xt_ctx *ctx);
 
 static void up_free(oj_up *u)
 {
@@ -1998,13 +2021,14 @@ oj_requester *oj_requester_new(const oj_info *f, int32_t *const planes[OJ_MAX_CO
   return rq;
 }
 
-int oj_requester_cursor(const oj_requester *rq, int c) { return rq->cur[c]; }
+int oj_requester_cursor(const oj_requester *rq, int c) { return c >= OJ_MAX_COMP ? rq->rcur[c - OJ_MAX_COMP] : rq->cur[c]; } /* (4 + c: the residual image's) */
 
 void oj_requester_free(oj_requester *rq)
 {
   int c;
   if (!rq) return;
-  for (c = 0; c < OJ_MAX_COMP; c++) up_free(rq->up[c]);
+  for (c = 0; c < OJ_MAX_COMP; c++) { up_free(rq->up[c]); up_free(rq->rup[c]); }
+  if (rq->owner) xt_ctx_free(rq->owner);
   free(rq);
 }
 
@@ -2057,6 +2081,63 @@ static void rq_color(const oj_requester *rq, int ycc, int x0, int y0, int x1, in
     }
 }
 
+/* ResidualBlockHelper::DequantizeResidual (control/residualblockhelper.cpp:150-231) of one residual block: the residual
+ * frame's own transform with its level shift 2^(Pr-1), or -- RDCT box -- the bypass.  src may be NULL (a row nobody created:
+ * the transform's NULL branch, dct/idct.cpp:336-338). */
+static void rq_residual_block(const oj_requester *rq, int c, const int32_t *src, int32_t dst[64])
+{
+  const oj_info *r = rq->rf;
+  const uint16_t *q = r->scan_state_valid ? r->cquant[c] : r->quant[r->tq[c]];
+  if (rq->xt->rbypass && src) {
+    const int32_t quant = ((int32_t)q[63] << 4) & 0xffff, dcs = (int32_t)(1 << r->precision) >> 1;
+    xt_bypass_block(dst, src, quant, rq->xt->rnoise, dcs);
+  } else
+    oj_idct_block(dst, src, q, r->precision);
+}
+static const int32_t *rq_rrow_block(const oj_requester *rq, int c, int bx)
+{
+  if (rq->rcur[c] >= rq->rrows[c] || rq->rcur[c] >= rq->rf->bh[c]) return NULL;
+  return rq->rplanes[c] + ((size_t)rq->rcur[c] * rq->rf->bw[c] + bx) * 64;
+}
+
+/* colortrafo/ycbcrtrafo.cpp:679-955 with a residual, for the rectangle [x0, x1] x [y0, y1] inside one block: L transformation,
+ * then the merge of xt_merge_pixel; 16-bit codes (or 8-bit samples when the output has no extra range bits) */
+static void rq_color_xt(const oj_requester *rq, int x0, int y0, int x1, int y1, int32_t src[OJ_MAX_COMP][64], int32_t rsrc[OJ_MAX_COMP][64],
+                        void *const dst[OJ_MAX_COMP], const int bpp[OJ_MAX_COMP], const int bpr[OJ_MAX_COMP],
+                        const int bm_width[OJ_MAX_COMP], const int bm_height[OJ_MAX_COMP], int sample_bytes)
+{
+  const oj_info *f = &rq->f;
+  const oj_xt *xt = rq->xt;
+  const int32_t dcshift = (int32_t)(1 << (f->precision - 1)) << 4;
+  const int64_t maxval = ((int64_t)1 << f->precision) - 1;
+  int x, y, c;
+  for (y = y0; y <= y1; y++)
+    for (x = x0; x <= x1; x++) {
+      const int k = (y & 7) * 8 + (x & 7);
+      int64_t v[3];
+      int32_t rk[3];
+      uint16_t o[3];
+      if (xt->ltrafo_ycbcr) {
+        const int64_t *M = xt->lmat;
+        const int64_t yy = src[0][k], cb = (int64_t)src[1][k] - dcshift, cr = (int64_t)src[2][k] - dcshift;
+        v[0] = (yy * M[0] + cb * M[1] + cr * M[2] + 65536) >> 17;
+        v[1] = (yy * M[3] + cb * M[4] + cr * M[5] + 65536) >> 17;
+        v[2] = (yy * M[6] + cb * M[7] + cr * M[8] + 65536) >> 17;
+      } else
+        for (c = 0; c < 3; c++) v[c] = ((int64_t)src[c][k] + 8) >> 4;
+      for (c = 0; c < 3; c++) rk[c] = rsrc[c][k];
+      xt_merge_pixel(xt, maxval, v, rk, o);
+      for (c = 0; c < 3; c++) {
+        uint8_t *p;
+        if (!dst[c]) continue;
+        if ((uint32_t)bm_width[c] <= (uint32_t)x0 || (uint32_t)bm_height[c] <= (uint32_t)y0) continue;
+        p = (uint8_t *)dst[c] + (ptrdiff_t)y * bpr[c] + (ptrdiff_t)x * bpp[c];
+        if (sample_bytes == 2) memcpy(p, &o[c], 2);
+        else *p = (uint8_t)o[c];
+      }
+    }
+}
+
 int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int max_y, int c0, int c1, int upsample, int ctrafo,
                          void *const dst[OJ_MAX_COMP], const int bpp[OJ_MAX_COMP], const int bpr[OJ_MAX_COMP],
                          const int bm_width[OJ_MAX_COMP], const int bm_height[OJ_MAX_COMP], int sample_bytes)
@@ -2065,7 +2146,13 @@ int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int 
   void *bm[OJ_MAX_COMP] = {0, 0, 0, 0};
   uint32_t maxmcu = 0xffffffffu;
   int c, ycc, rc;
-  if (sample_bytes != (f->precision > 8 ? 2 : 1)) return OJ_ERR_UNSUPPORTED;
+  if (rq->xt) {
+    /* JPEG XT: what is restated is what the reference's command line asks for -- all three components, upsampling and colour
+     * transformation on -- in any order and size of rectangles.  (A component subset merges with what m_ppDTemp still holds from
+     * the block before; without the transformation another transformer is built: neither is restated.) */
+    if (sample_bytes != (rq->xt->outmax > 255 ? 2 : 1)) return OJ_ERR_UNSUPPORTED;
+    if (!upsample || !ctrafo || c0 > 0 || c1 < 2) return OJ_ERR_UNSUPPORTED;
+  } else if (sample_bytes != (f->precision > 8 ? 2 : 1)) return OJ_ERR_UNSUPPORTED;
   /* codestream/rectanglerequest.cpp:62-190: clipped to the canvas; without upsampling no colour transformation */
   if (min_x < 0) min_x = 0;
   if (min_y < 0) min_y = 0;
@@ -2120,6 +2207,33 @@ int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int 
         if (rq->cur[c] < rq->rows[c]) rq->cur[c]++;
       }
     }
+    /* PullRData, :1118-1146: the same for the residual image's upsamplers */
+    for (c = c0; rq->xt && c <= c1; c++) {
+      oj_up *u = rq->rup[c];
+      int bwidth, bheight, rx, ry, b_min_x, b_max_x, b_min_y, b_max_y, yy, xx;
+      if (!u) continue;
+      bwidth = ((u->pw + u->sx - 1) / u->sx + 7) >> 3;
+      bheight = (int)((((uint32_t)u->ph + (uint32_t)u->sy - 1) / (uint32_t)u->sy + 7) >> 3);
+      rx = u->sx > 1; ry = u->sy > 1;
+      b_min_x = (min_x / u->sx - rx) >> 3;
+      b_max_x = (max_x / u->sx + rx) >> 3;
+      b_min_y = (min_y / u->sy - ry) >> 3;
+      b_max_y = (max_y / u->sy + ry) >> 3;
+      if (b_min_x < 0) b_min_x = 0;
+      if (b_max_x >= bwidth) b_max_x = bwidth - 1;
+      if (b_min_y < 0) b_min_y = 0;
+      if (b_max_y >= bheight) b_max_y = bheight - 1;
+      b_min_y = up_set_buffered_region(u, b_min_y, b_max_y);
+      if (b_min_y < 0) return b_min_y;
+      for (yy = b_min_y; yy <= b_max_y; yy++) {
+        for (xx = b_min_x; xx <= b_max_x; xx++) {
+          int32_t blk[64];
+          rq_residual_block(rq, c, rq_rrow_block(rq, c, xx), blk);
+          if ((rc = up_define_region(u, xx, yy, blk)) != OJ_OK) return rc;
+        }
+        if (rq->rcur[c] < rq->rrows[c]) rq->rcur[c]++;
+      }
+    }
     /* PushReconstructedData, :1151-1224 */
     if (maxy > maxmcu) maxy = maxmcu;
     for (by = miny, r_min_y = min_y; by <= maxy; by++, r_min_y = r_max_y + 1) {
@@ -2139,10 +2253,26 @@ int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int 
           } else
             memset(src[c], 0, sizeof(src[c]));
         }
-        rq_color(rq, ycc, r_min_x, r_min_y, r_max_x, r_max_y, src, bm, bpp, bpr, bm_width, bm_height, sample_bytes);
+        if (rq->xt) {
+          int32_t rsrc[OJ_MAX_COMP][64];
+          memset(rsrc, 0, sizeof(rsrc));
+          for (c = 0; c < 3 && !rq->xt->no_residual; c++) {
+            if (rq->rup[c]) {
+              if ((rc = up_upsample_region(rq->rup[c], r_min_x, r_min_y, rsrc[c])) != OJ_OK) return rc;
+            } else {
+              const int32_t *rb = rq_rrow_block(rq, c, (int)bx);
+              if (!rb) return OJ_ERR_UNSUPPORTED; /* `rrow->BlockAt(x)` on a NULL row (:1201-1202): the reference crashes here */
+              rq_residual_block(rq, c, rb, rsrc[c]);
+            }
+          }
+          rq_color_xt(rq, r_min_x, r_min_y, r_max_x, r_max_y, src, rsrc, bm, bpp, bpr, bm_width, bm_height, sample_bytes);
+        } else
+          rq_color(rq, ycc, r_min_x, r_min_y, r_max_x, r_max_y, src, bm, bpp, bpr, bm_width, bm_height, sample_bytes);
       }
-      for (c = 0; c < f->ncomp; c++) /* every component without an upsampler, requested or not (:1214-1217) */
+      for (c = 0; c < f->ncomp; c++) { /* every component without an upsampler, requested or not (:1214-1222) */
         if (!rq->up[c] && rq->cur[c] < rq->rows[c]) rq->cur[c]++;
+        if (rq->xt && !rq->rup[c] && rq->rcur[c] < rq->rrows[c]) rq->rcur[c]++;
+      }
     }
   } else {
     /* ReconstructUnsampled, :1013-1074, on the region of control/bitmapctrl.cpp:273-294 */
@@ -2171,10 +2301,22 @@ int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int 
           if (c >= c0 && c <= c1) rq_idct(rq, c, rq_row_block(rq, c, (int)bx), src[c]);
           else memset(src[c], 0, sizeof(src[c]));
         }
-        rq_color(rq, ycc, r_min_x, r_min_y, r_max_x, r_max_y, src, bm, bpp, bpr, bm_width, bm_height, sample_bytes);
+        if (rq->xt) {
+          int32_t rsrc[OJ_MAX_COMP][64];
+          memset(rsrc, 0, sizeof(rsrc));
+          for (c = c0; c <= c1 && !rq->xt->no_residual; c++) {
+            const int32_t *rb = rq_rrow_block(rq, c, (int)bx);
+            if (!rb) return OJ_ERR_UNSUPPORTED; /* `rrow->BlockAt(x)` on a NULL row (:1057-1058) */
+            rq_residual_block(rq, c, rb, rsrc[c]);
+          }
+          rq_color_xt(rq, r_min_x, r_min_y, r_max_x, r_max_y, src, rsrc, bm, bpp, bpr, bm_width, bm_height, sample_bytes);
+        } else
+          rq_color(rq, ycc, r_min_x, r_min_y, r_max_x, r_max_y, src, bm, bpp, bpr, bm_width, bm_height, sample_bytes);
       }
-      for (c = c0; c <= c1; c++) /* only the requested ones (:1066-1071) */
+      for (c = c0; c <= c1; c++) { /* only the requested ones (:1066-1071) */
         if (rq->cur[c] < rq->rows[c]) rq->cur[c]++;
+        if (rq->xt && rq->rcur[c] < rq->rrows[c]) rq->rcur[c]++;
+      }
     }
   }
   return OJ_OK;
@@ -2323,7 +2465,25 @@ static int register_box(uint32_t type, const uint8_t *d, size_t len, oj_nlt *nlt
   return OJ_OK;
 }
 
-int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float)
+/* what a requester on a JPEG XT stream owns: both frames' coefficient planes, the tables of the merge, the residual frame's
+ * description */
+struct oj_xt_ctx {
+  oj_xt xt;
+  oj_info rinfo;
+  int32_t *planes[OJ_MAX_COMP], *rplanes[OJ_MAX_COMP];
+  int32_t *owned[9];
+};
+static void xt_ctx_free(struct oj_xt_ctx *ctx)
+{
+  int c;
+  if (!ctx) return;
+  for (c = 0; c < OJ_MAX_COMP; c++) { free(ctx->planes[c]); free(ctx->rplanes[c]); }
+  for (c = 0; c < 9; c++) free(ctx->owned[c]);
+  free(ctx);
+}
+
+/* pixels != NULL: the whole picture (oj_decode_xt); rq_out != NULL: a requester that keeps what was decoded (oj_xt_requester_new) */
+static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, oj_requester **rq_out)
 {
   oj_box boxes[OJ_MAX_BOXES];
   oj_parser ps;
@@ -2342,7 +2502,8 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
   static const int64_t std_ycc[9] = {FIX13(1.0), FIX13(0.0), FIX13(1.40200), FIX13(1.0), -FIX13(0.3441362861), -FIX13(0.7141362859),
                                      FIX13(1.0), FIX13(1.772), FIX13(0.0)};
   static const int64_t std_id[9] = {8192, 0, 0, 0, 8192, 0, 0, 0, 8192};
-  *pixels = NULL;
+  if (pixels) *pixels = NULL;
+  if (rq_out) *rq_out = NULL;
   memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(nlt, 0, sizeof(nlt)); memset(&xt, 0, sizeof(xt));
   ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes; ps.walk_all = 1;
   rc = walk(&ps, NULL);
@@ -2498,16 +2659,65 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
     rinfo.precision += hidden_r;
   }
   xt.rinfo = &rinfo; xt.rplanes = rplanes;
+  if (is_float) *is_float = xt.is_float;
+  if (rq_out) {
+    /* BlockBitmapRequester::PrepareForDecoding, control/blockbitmaprequester.cpp:298-372: cursors at the first rows of both
+     * images, upsamplers for the subsampled components of either */
+    struct oj_xt_ctx *ctx = (struct oj_xt_ctx *)calloc(1, sizeof(*ctx));
+    oj_requester *rq;
+    if (!ctx) { rc = OJ_ERR_NOMEM; goto out; }
+    ctx->xt = xt;
+    ctx->rinfo = rinfo;
+    ctx->xt.rinfo = &ctx->rinfo;
+    ctx->xt.rplanes = ctx->rplanes;
+    rq = oj_requester_new(info, planes);
+    if (!rq) { free(ctx); rc = OJ_ERR_NOMEM; goto out; }
+    rq->xt = &ctx->xt;
+    rq->rf = &ctx->rinfo;
+    rq->owner = ctx;
+    for (c = 0; c < 3; c++) {
+      ctx->planes[c] = planes[c]; planes[c] = NULL; /* (the requester reads them through rq->planes) */
+      ctx->rplanes[c] = rplanes[c]; rplanes[c] = NULL;
+      rq->rplanes[c] = ctx->rplanes[c];
+      rq->rrows[c] = (rinfo.ch[c] + 7) >> 3;
+      if (rinfo.subx[c] > 1 || rinfo.suby[c] > 1) {
+        oj_up *u = (oj_up *)calloc(1, sizeof(*u));
+        if (!u) { oj_requester_free(rq); rc = OJ_ERR_NOMEM; goto out; }
+        u->sx = rinfo.subx[c]; u->sy = rinfo.suby[c];
+        u->pw = info->width; u->ph = info->height;
+        u->width = (info->width + u->sx - 1) / u->sx;
+        u->total = (info->height + u->sy - 1) / u->sy;
+        rq->rup[c] = u;
+        rq->subsampling = 1;
+      }
+    }
+    for (c = 0; c < 9; c++) { ctx->owned[c] = owned[c]; owned[c] = NULL; }
+    *rq_out = rq;
+    goto out;
+  }
   *pixels = (uint16_t *)malloc((size_t)info->width * info->height * 3 * sizeof(uint16_t));
   if (!*pixels) { rc = OJ_ERR_NOMEM; goto out; }
   rc = reconstruct_ex(info, planes, NULL, *pixels, xt.ltrafo_ycbcr, &xt);
   if (rc) { free(*pixels); *pixels = NULL; }
-  if (is_float) *is_float = xt.is_float;
 out:
   for (c = 0; c < OJ_MAX_COMP; c++) { free(planes[c]); free(rplanes[c]); }
   for (c = 0; c < 16; c++) free(nlt[c].lut);
   for (c = 0; c < 9; c++) free(owned[c]);
   free_boxes(boxes, ps.nboxes);
+  return rc;
+}
+
+int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float)
+{
+  return xt_decode_common(data, len, info, pixels, is_float, NULL);
+}
+
+/* A requester (oj_requester_display / _cursor / _free) on a JPEG XT stream: both codestreams decoded, the residual image's
+ * cursors and upsamplers beside the legacy image's.  *out_max = 2^(8 + extra range bits) - 1: samples of 2 bytes above 255. */
+int oj_xt_requester_new(const uint8_t *data, size_t len, oj_info *info, oj_requester **rq, int *is_float, int *out_max)
+{
+  const int rc = xt_decode_common(data, len, info, NULL, is_float, rq);
+  if (!rc && out_max) *out_max = (int)(*rq)->xt->outmax;
   return rc;
 }
 

@@ -121,7 +121,10 @@ int oj_reconstruct16(const oj_info *info, int32_t *const planes[OJ_MAX_COMP], ui
 typedef struct oj_requester oj_requester;
 oj_requester *oj_requester_new(const oj_info *info, int32_t *const planes[OJ_MAX_COMP]);
 void oj_requester_free(oj_requester *rq);
-int oj_requester_cursor(const oj_requester *rq, int c); /* row the component's cursor stands at (== rows: behind the last) */
+int oj_requester_cursor(const oj_requester *rq, int c); /* row the component's cursor stands at (== rows: behind the last); 4 + c: the residual image's */
+/* the same on a JPEG XT stream (profile C): the residual image has cursors and upsamplers of its own
+ * (control/blockbitmaprequester.cpp:1118-1146, 1197-1222).  Requests: all three components, upsampling and colour transformation on. */
+int oj_xt_requester_new(const uint8_t *data, size_t len, oj_info *info, oj_requester **rq, int *is_float, int *out_max);
 int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int max_y, int c0, int c1, int upsample, int ctrafo,
                          void *const dst[OJ_MAX_COMP], const int bpp[OJ_MAX_COMP], const int bpr[OJ_MAX_COMP],
                          const int bm_width[OJ_MAX_COMP], const int bm_height[OJ_MAX_COMP], int sample_bytes);

@@ -64,6 +64,7 @@ def lib():
         L.oj_free.restype = None
         L.oj_requester_new.restype = C.c_void_p
         L.oj_requester_new.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
+        L.oj_xt_requester_new.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.oj_requester_free.argtypes = [C.c_void_p]
         L.oj_requester_free.restype = None
         L.oj_requester_cursor.argtypes = [C.c_void_p, C.c_int]
@@ -274,6 +275,36 @@ def run_requests(data: bytes, requests, cursors=None, decoded=None):
     finally:
         lib().oj_requester_free(rq)
     return info, rcs, canvas
+
+
+def run_requests_xt(data: bytes, requests, cursors=None):
+    """run_requests on a JPEG XT stream (profile C): the residual image's cursors and upsamplers beside the legacy image's
+    (oj_xt_requester_new) -> (info, [return code per call], canvas planes (3, H, W) of uint16 codes -- or uint8 samples when the
+    output conversion has no extra range bits -- initialised to 0xAA.., is_float).  cursors: per call the six cursor rows (legacy, residual)."""
+    info, rq, is_float, out_max = OjInfo(), C.c_void_p(), C.c_int(0), C.c_int(0)
+    rc = lib().oj_xt_requester_new(data, len(data), C.byref(info), C.byref(rq), C.byref(is_float), C.byref(out_max))
+    if rc:
+        raise OracleError(rc, "oj_xt_requester_new")
+    sb = 2 if out_max.value > 255 else 1
+    W, H, nc = info.width, info.height, 3
+    canvas = np.full((nc, H, W), 0xAAAA if sb == 2 else 0xAA, np.uint16 if sb == 2 else np.uint8)
+    rcs = []
+    try:
+        for minx, miny, maxx, maxy, c0, c1, ups, ctrafo, hmode in requests:
+            maxx = W - 1 if maxx < 0 else maxx
+            maxy = H - 1 if maxy < 0 else maxy
+            dst = (C.c_void_p * 4)(*[canvas[c].ctypes.data for c in range(nc)] + [None])
+            bpp = (C.c_int * 4)(sb, sb, sb, sb)
+            bpr = (C.c_int * 4)(W * sb, W * sb, W * sb, W * sb)
+            hh = miny + hmode if hmode else H
+            bmh = (C.c_int * 4)(hh, hh, hh, hh)
+            bmw = (C.c_int * 4)(W, W, W, W)
+            rcs.append(lib().oj_requester_display(rq, minx, miny, maxx, maxy, c0, c1, ups, ctrafo, dst, bpp, bpr, bmw, bmh, sb))
+            if cursors is not None:
+                cursors.append([lib().oj_requester_cursor(rq, c) for c in range(3)] + [lib().oj_requester_cursor(rq, 4 + c) for c in range(3)])
+    finally:
+        lib().oj_requester_free(rq)
+    return info, rcs, canvas, bool(is_float.value)
 
 
 def run_requests_client(exe: str, data: bytes, requests, env=None, timeout=60):
