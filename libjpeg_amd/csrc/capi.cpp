@@ -2910,8 +2910,8 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
             if (g >= (int)pr.rowmap[c].size() || pr.rowmap[c][(size_t)g] < 0)
               return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST,
                                "the request walks the residual image's row cursor behind its last row (the reference dereferences a NULL row here)");
-    if (pl.plain && (x.no_residual || pr.plain)) return plain_picture();
-    // ---- not the plain picture: both images through the unfused kernels with their row maps on this request's lines
+    // BitmapCtrl::ExtractBitmap (interface/imagebitmap.cpp:58-129): blocks whose corner lies outside the bitmap the hook described
+    // are not written
     int32_t cx1[MIJPEG_MAX_COMPONENTS], cy1[MIJPEG_MAX_COMPONENTS];
     for (int c = 0; c < 3; c++) {
       auto last_in = [](int32_t lo, int32_t hi, uint32_t extent) -> int32_t {
@@ -2922,6 +2922,19 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
       cx1[c] = last_in(pl.min_x, pl.max_x, bm_w[c]);
       cy1[c] = last_in(pl.min_y, pl.max_y, bm_h[c]);
     }
+    if (pl.plain && (x.no_residual || pr.plain)) {
+      for (int c = 0; c <= 2;) { // components with the same writable extent go out together (all of them, normally)
+        int e = c;
+        while (e + 1 <= 2 && cx1[e + 1] == cx1[c] && cy1[e + 1] == cy1[c]) e++;
+        if (cx1[c] >= pl.min_x && cy1[c] >= pl.min_y) {
+          const int rc = mijpeg_reconstruct_rect(d, pl.min_x, pl.min_y, cx1[c], cy1[c], c, e, flags, dst, bpp, bpr);
+          if (rc) return rc;
+        }
+        c = e + 1;
+      }
+      return MIJPEG_OK;
+    }
+    // ---- not the plain picture: both images through the unfused kernels with their row maps on this request's lines
     HIP_TRY(d, hipSetDevice(d->device));
     mijpeg_batch b;
     memset(&b, 0, sizeof(b));
