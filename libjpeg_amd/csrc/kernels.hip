@@ -1012,6 +1012,9 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 #ifndef F420P_PREFETCH
 #define F420P_PREFETCH 1
 #endif
+#ifndef F420P_TEMPORAL
+#define F420P_TEMPORAL 0 // A-B builds: 1 = the pixel stores of aligned frames without the nt hint as well
+#endif
 #ifndef F420P_MINW
 #define F420P_MINW 4 // workgroups per CU the register allocation must leave room for (the per-frame-table build keeps 3: it spills at 4)
 #endif
@@ -1232,7 +1235,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
             const int m = SHIFTED ? (int)__builtin_amdgcn_readfirstlane((base_lo + (unsigned)l * (unsigned)a.row_stride) & 3u) : 0;
             if (SHIFTED && m) store24_nt_shifted(out_frame, off, w, bx, m);
             else if (SHIFTED) store24_nt<false>(out_frame, off, w);
-            else store24_nt(out_frame, off, w);
+            else store24_nt<!F420P_TEMPORAL>(out_frame, off, w);
           } else {
             uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
 #pragma unroll
