@@ -99,6 +99,8 @@ __global__ __launch_bounds__(256, 4) void shape_kernel(const int16_t *__restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned total = TXN * TYN * FRAMES;
   unsigned logical = blockIdx.x;
+  const int order_in = order;
+  order = order < 0 ? -order : order;
   if (order == 1) {
     const unsigned b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
     logical = x * q + min(x, r) + i;
@@ -137,6 +139,20 @@ __global__ __launch_bounds__(256, 4) void shape_kernel(const int16_t *__restrict
   uint8_t *dst = out_all + frame * OUT_FRAME + (int64_t)Y0 * (W * 3) + X0 * 3;
   if (MODE == 1) {
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *reinterpret_cast<uint32_t *>(dst) = acc.x; // (never: keeps the loads alive)
+    return;
+  }
+  if (order_in < 0) {
+    // paired stores (order < 0 selects them; the tile order is -order): the 48 bytes of two neighbouring lanes leave as three
+    // 16-byte-aligned dwordx4 stores -- every lane one (even lane: bytes 0-15 of the pair, odd lane: bytes 32-47), the even
+    // lane a second one for bytes 16-31 (its own last 8 and the odd lane's first 8, which two v_mov_dpp would fetch)
+    uint8_t *pair = dst - (tid & 1) * 24; // start of the pair's 48 bytes
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+      const u32x4 a = acc + (uint32_t)l;
+      const u32x4 b = {acc.x ^ (uint32_t)l, acc.w + (uint32_t)l, (uint32_t)__shfl_xor((int)acc.y, 1), (uint32_t)__shfl_xor((int)acc.z, 1)};
+      __builtin_nontemporal_store(a, reinterpret_cast<u32x4 *>(pair + l * (W * 3) + (tid & 1) * 32));
+      if (!(tid & 1)) __builtin_nontemporal_store(b, reinterpret_cast<u32x4 *>(pair + l * (W * 3) + 16));
+    }
     return;
   }
 #pragma unroll
@@ -211,7 +227,8 @@ int main(int argc, char **argv)
   // shapes, orders, directions
   auto shape = [&](const char *name, auto kernel, int tbx, int tby, int order, double bytes) {
     int n = (W / (8 * tbx)) * ((H / 8 + tby - 1) / tby) * FRAMES;
-    if (order >= 2) n = (n + 8 * order - 1) / (8 * order) * (8 * order);
+    const int ao = order < 0 ? -order : order;
+    if (ao >= 2) n = (n + 8 * ao - 1) / (8 * ao) * (8 * ao);
     const float ms = time_ms([&] { hipLaunchKernelGGL(kernel, dim3(n), dim3(256), LDS, 0, coef, out, order); }, 200);
     printf("%-28s %2d x %2d blocks, order %d: %.4f ms/launch  %.2f TB/s  (%.3f of 8)\n", name, tbx, tby, order, ms, bytes * 1e-9 / ms, bytes * 1e-9 / ms / 8.0);
   };
@@ -219,6 +236,12 @@ int main(int argc, char **argv)
   for (int order : {4, 15, 30, 60, 120, 240, 480}) { // run lengths (16 x 16: 60 tiles per row, 34 rows per frame)
     shape("read+write nt", shape_kernel<16, 16, 0, true>, 16, 16, order, both);
     shape("read+write temporal", shape_kernel<16, 16, 0, false>, 16, 16, order, both);
+  }
+  for (int rep = 0; rep < 3; rep++) { // the kernel's stores against paired 16-byte-aligned ones (negative order), tile-row order
+    shape("read+write nt, 24-byte pieces", shape_kernel<16, 16, 0, true>, 16, 16, 60, both);
+    shape("read+write nt, paired 16 B", shape_kernel<16, 16, 0, true>, 16, 16, -60, both);
+    shape("write only nt, 24-byte pieces", shape_kernel<16, 16, 2, true>, 16, 16, 60, wr);
+    shape("write only nt, paired 16 B", shape_kernel<16, 16, 2, true>, 16, 16, -60, wr);
   }
   for (int order : {30, 60, 120}) { // 32 x 8: 30 tiles per row, 68 rows per frame
     shape("read+write nt", shape_kernel<32, 8, 0, true>, 32, 8, order, both);
