@@ -1,5 +1,5 @@
 // fuzz_host.cpp -- mutation fuzzing of the host decoder under AddressSanitizer / UBSan.
-//   g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined tools/fuzz_host.cpp libjpeg_amd/csrc/host_decoder.cpp -o /tmp/fuzz_host
+//   g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined tools/fuzz_host.cpp libjpeg_amd/csrc/host_decoder.cpp libjpeg_amd/csrc/encoder.cpp -o /tmp/fuzz_host
 //   /tmp/fuzz_host tests/golden/*.jpg
 #include <cstdio>
 #include <cstring>
