@@ -1759,6 +1759,21 @@ static bool use_fused440(const mijpeg_batch *b)
          f.range_max[1] < 8190 && f.range_max[2] < 8190 && fits32(b);
 }
 
+// every component 1 x 1, three or four of them, 8 bit, no colour transformation, fast arithmetic: fused_flat_kernel
+// (CMYK; RGB stored as such -- Adobe transform 0, a merging specification with the identity L transformation, the caller's
+// MIJPEG_FLAG_NO_COLOR_TRANSFORM on a 4:4:4 frame)
+static bool use_fused_flat(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  static const bool off = getenv("MIJPEG_NO_FUSED_FLAT") != nullptr; // A-B measurements
+  if (off || f.xt || f.precision != 8 || f.coef_wide || b->quant_dev || (f.components != 3 && f.components != 4)) return false;
+  if (b->flags & MIJPEG_FLAG_FORCE_GENERIC) return false;
+  if (f.components == 3 && f.ycbcr && !(b->flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM)) return false;
+  for (int c = 0; c < f.components; c++)
+    if (f.subx[c] != 1 || f.suby[c] != 1 || f.blocks_w[c] != f.blocks_w[0] || f.blocks_h[c] != f.blocks_h[0]) return false;
+  return fast_ok(b) && fits32(b) && !dnl_row_missing(f);
+}
+
 const char *mijpeg_kernel_name(const mijpeg_batch *b)
 {
   if (!b) return "";
@@ -1774,6 +1789,7 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (use_fused420(b)) return "fused420_kernel";
   if (use_fused444(b)) return "fused444_kernel";
   if (b->info.xt) return b->xt && b->xt->general ? "idct_planes_kernel+xt_merge_general_kernel" : "idct_planes_kernel+xt_merge_kernel";
+  if (use_fused_flat(b)) return "fused_flat_kernel";
   if (b->quant_dev || (b->flags & MIJPEG_FLAG_FORCE_GENERIC) || getenv("MIJPEG_NO_FUSED_TILE") || dnl_row_missing(b->info)) return "idct_planes_kernel+upsample_color_kernel";
   return "fused_tile_kernel";
 }
@@ -2017,7 +2033,8 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     // stays for JPEG XT, int32 coefficient planes, per-frame tables in device memory, rectangle requests and MIJPEG_FLAG_FORCE_GENERIC
     static const bool no_tile = getenv("MIJPEG_NO_FUSED_TILE") != nullptr; // A-B measurements
     const bool tile = !rx && !f.xt && !f.coef_wide && !qdev && !(b->flags & MIJPEG_FLAG_FORCE_GENERIC) && !no_tile && !dnl_row_missing(f);
-    rc = tile ? launch_fused_tile(a, fast || tile_fast12(b), s) : -1;
+    rc = !rx && use_fused_flat(b) ? launch_fused_flat(a, s) : -1;
+    if (rc == -1) rc = tile ? launch_fused_tile(a, fast || tile_fast12(b), s) : -1;
     if (rc == -1) rc = launch_generic(a, fast, s);
   }
   return rc ? MIJPEG_ERR_DEVICE : MIJPEG_OK;

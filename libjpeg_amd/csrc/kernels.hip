@@ -153,6 +153,15 @@ __device__ __forceinline__ void store24_nt(uint8_t *__restrict__ base, unsigned 
   if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx2 %0, %3, %2 offset:16 nt" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx2 %0, %3, %2 offset:16" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
 }
+// 32 bytes at base + off (uniform base, 32-bit lane offset; any alignment), non-temporal.  One asm statement for both stores and
+// a wait state behind them: the compiler does not see stores in inline asm, so it does not keep the next VALU instruction from
+// overwriting the registers a store of more than 64 bits has yet to read (the first version of this, one statement per store,
+// got the second store's offset as its first pixel).  store24_nt: the 8-byte store behind the 16-byte one is that wait state.
+__device__ __forceinline__ void store32_nt(uint8_t *__restrict__ base, unsigned off, const unsigned (&w)[8])
+{
+  const u32x4 lo = {w[0], w[1], w[2], w[3]}, hi = {w[4], w[5], w[6], w[7]};
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx4 %0, %3, %2 offset:16 nt\n\ts_nop 0" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
+}
 
 // The same 24 bytes when the line's address is NOT a multiple of four (m = address & 3: a packed frame whose width is not a
 // multiple of four pixels has such lines): gfx950 stores dwords at any address, but at a third more time per launch
@@ -3412,6 +3421,112 @@ __global__ __launch_bounds__(256) void bypass_planes_kernel(const GenericArgs a)
 }
 
 // ==============================================================================================
+// fused kernel for frames whose components all have the sampling factors 1 x 1 and leave without a colour transformation:
+// CMYK (four components: Adobe files), RGB stored as such (three: Adobe transform 0, the reference's `jpeg -c`, a merging
+// specification with the identity L transformation)
+// ==============================================================================================
+// ReconstructUnsampled (control/blockbitmaprequester.cpp:1013-1074) with the identity transformation
+// (colortrafo/ycbcrtrafo.cpp:852-856, 921-936): sample = clamp((IDCT + 8) >> 4).  fused444_kernel's decomposition -- one lane
+// owns one block POSITION of a 128 x 128 tile and transforms its NC blocks in turn, nothing goes through LDS but the block
+// fetch -- with the samples of every component packed to bytes right behind its transform (v_ashr_pk_u8_i32: shift, clamp
+// and pack; the + 8 rides in the second pass's rounding constant), 16 dwords per component.  The interleaved line is a byte
+// permutation of those: a 4 x 4 byte transpose for four components (8 v_perm_b32 per 4 pixels), 6 per 4 pixels for three.
+// Algorithmic bytes: 2 NC in + NC out per pixel (CMYK 12, RGB 9).  The tile kernel took these layouts through LDS before
+// (CMYK 0.49 of 8 TB/s).
+#ifndef FLAT4_MINW
+#define FLAT4_MINW 2 // four components: 64 packed dwords + a transform's 96 do not fit the 170 registers of three workgroups per CU
+#endif
+template <int NC>
+__global__ __launch_bounds__(F420_THREADS, NC == 4 ? FLAT4_MINW : 3) void fused_flat_kernel(const GenericArgs a)
+{
+  static_assert(NC == 3 || NC == 4, "three or four components");
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const unsigned logical = tile_of_workgroup(blockIdx.x, (unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames); // (tile order: see there)
+  if (logical == ~0u) return; // the launch is padded to whole groups of eight tile rows
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int frame = logical / tiles_per_frame;
+  const int tile = logical - frame * tiles_per_frame;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+  const int x0 = gbx0 + (lane >> 3);
+  const int bw = a.bw[0], bh = a.bh[0]; // every plane has the same geometry
+  const int X0 = gbx * 8, Y0 = gby * 8;
+
+  unsigned pk[NC][16]; // component c, pixels 4 k .. 4 k + 3 of the block (row k / 2, half k % 2)
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    u32x4 rows[8];
+    int v[64];
+    const char *pbase = reinterpret_cast<const char *>(coef + a.coef_off[c]) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), bw - 1), y = min(gby0 + (m >> 1), bh - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * bw + x) * 128));
+    });
+    if (c == NC - 1 && (X0 >= a.width || Y0 >= a.height)) return; // (no barrier in this kernel; the last fetch needed every lane)
+    // level shift inside, + 8 of COLOR_TO_INT in the second pass's rounding constant: v = sample * 16 + 8
+    dequant_idct_sparse<true>(rows, a.q[c], v, a.dcoff[c], 2048 + (8 << 12));
+#pragma unroll
+    for (int k = 0; k < 16; k++) pk[c][k] = ashr_sat_pack4<4>(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    __builtin_amdgcn_sched_barrier(0); // keep the next component's loads from being hoisted above this transform (register pressure)
+  }
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * (unsigned)NC;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    if (l < nln) {
+      unsigned w[2 * NC]; // the line's 8 * NC bytes
+#pragma unroll
+      for (int h = 0; h < 2; h++) { // pixels 4 h .. 4 h + 3
+        const unsigned A = pk[0][2 * l + h], B = pk[1][2 * l + h], C = pk[2][2 * l + h];
+        if (NC == 4) {
+          const unsigned D = pk[NC - 1][2 * l + h];
+          const unsigned ab_lo = __builtin_amdgcn_perm(B, A, 0x05010400u), ab_hi = __builtin_amdgcn_perm(B, A, 0x07030602u);
+          const unsigned cd_lo = __builtin_amdgcn_perm(D, C, 0x05010400u), cd_hi = __builtin_amdgcn_perm(D, C, 0x07030602u);
+          w[4 * h + 0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);
+          w[4 * h + 1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+          w[4 * h + 2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+          w[4 * h + 3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+        } else {
+          // a0 b0 c0 a1 | b1 c1 a2 b2 | c2 a3 b3 c3
+          const unsigned t0 = __builtin_amdgcn_perm(B, A, 0x01000400u); // a0 b0 .. a1
+          const unsigned t1 = __builtin_amdgcn_perm(B, A, 0x06020005u); // b1 .. a2 b2
+          const unsigned t2 = __builtin_amdgcn_perm(B, A, 0x00070300u); // .. a3 b3 ..
+          w[3 * h + 0] = __builtin_amdgcn_perm(C, t0, 0x03040100u);    // c0 into byte 2
+          w[3 * h + 1] = __builtin_amdgcn_perm(C, t1, 0x03020500u);    // c1 into byte 1
+          w[3 * h + 2] = __builtin_amdgcn_perm(C, t2, 0x07020106u);    // c2 into byte 0, c3 into byte 3
+        }
+      }
+      if (npx == 8) {
+        const unsigned off = out_off + (unsigned)l * (unsigned)a.row_stride;
+        if (NC == 4) {
+          const unsigned w8[8] = {w[0], w[1], w[2], w[3], w[4 % (2 * NC)], w[5 % (2 * NC)], w[6 % (2 * NC)], w[7 % (2 * NC)]};
+          store32_nt(out_frame, off, w8);
+        } else {
+          const unsigned w6[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+          store24_nt(out_frame, off, w6);
+        }
+      } else {
+        uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+#pragma unroll
+        for (int e = 0; e < 8 * NC; e++)
+          if (e < npx * NC) dst[e] = (uint8_t)(w[e >> 2] >> (8 * (e & 3)));
+      }
+    }
+  }
+}
+
+// ==============================================================================================
 // launchers
 // ==============================================================================================
 // floor(2^32 / d) + 1 for the two divisions of tile_position, when every dividend the launch can produce keeps x * d < 2^32
@@ -3607,6 +3722,18 @@ int launch_fused_tile(const GenericArgs &a0, bool fast, hipStream_t stream)
   if (narrow) hipLaunchKernelGGL((fused_tile_kernel<true, true>), dim3(total), dim3(256), lds, stream, a);
   else if (fast) hipLaunchKernelGGL((fused_tile_kernel<true, false>), dim3(total), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL((fused_tile_kernel<false, false>), dim3(total), dim3(256), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused_flat(const GenericArgs &a0, hipStream_t stream)
+{
+  GenericArgs a = a0;
+  a.tiles_x = (a.width + 127) / 128;
+  a.tiles_y = (a.height + 127) / 128;
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
+  if (a.ncomp == 4) hipLaunchKernelGGL(fused_flat_kernel<4>, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else if (a.ncomp == 3) hipLaunchKernelGGL(fused_flat_kernel<3>, dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else return -1;
   return (int)hipGetLastError();
 }
 

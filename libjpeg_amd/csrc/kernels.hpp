@@ -127,6 +127,9 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream);
 // The same frames in one pass through LDS (plain JPEG: no residual planes, int16 coefficients, tables by value): any sampling
 // layout, 1..4 components, 8 or 12 bit.  Uses the plane description of GenericArgs; no workspace.
 int launch_fused_tile(const GenericArgs &a, bool fast, hipStream_t stream);
+// three or four components, all 1 x 1, 8 bit, fast arithmetic, no colour transformation (CMYK, RGB stored as such): one lane per
+// block position, no LDS round trip.  Uses the plane description of GenericArgs; no workspace.
+int launch_fused_flat(const GenericArgs &a, hipStream_t stream);
 int launch_expand_deltas(const uint16_t *in, int32_t *out, int frames, hipStream_t stream); // u16 [frames][4][64] -> int32 << 4
 
 // Rectangle of the reconstructed interleaved frame -> bitmaps in DEVICE memory described like the reference's

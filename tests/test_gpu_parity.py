@@ -1673,6 +1673,39 @@ def test_fused_tile_kernel_on_random_layouts(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h", EDGE_SIZES + [(640, 360), (1921, 1083)])
+@pytest.mark.parametrize("nc", [3, 4])
+def test_fused_flat_kernel_vs_oracle(dec, oracle, nc, w, h):
+    """Every component 1 x 1 and no colour transformation -- CMYK, RGB stored as such (four / three components): one lane per
+    block position, bytes packed behind every transform, the interleaved line a byte permutation (fused_flat_kernel).  Edge
+    sizes (tiles cut by the frame on both sides), DRI, dense and sparse content; SAFE and the unfused pair give the same."""
+    import craft
+    rng = np.random.default_rng(9100 + 7 * w + h + nc)
+    data = craft.craft_stream(rng, [(1, 1)] * nc, w, h, dri=(w + h) % 4, ac_density=0.02 if (w + h) % 3 else 0.2)
+    info, planes = oracle.decode_coefficients(data)
+    flags = api.FLAG_NO_COLOR_TRANSFORM if nc == 3 else 0
+    f = dec.read(data, entropy="host")
+    assert api.kernel_name(f, flags) == "fused_flat_kernel", list(f.range_max)
+    exp = oracle.reconstruct(info, planes, use_ycbcr=0)
+    out = dec.reconstruct(flags)
+    assert np.array_equal(out, exp), (nc, w, h, np.argwhere(out != exp)[:4].tolist())
+    assert np.array_equal(dec.reconstruct(flags | api.FLAG_FORCE_SAFE), exp) and np.array_equal(dec.reconstruct(flags | api.FLAG_FORCE_GENERIC), exp)
+
+
+@pytest.mark.gpu
+def test_fused_flat_kernel_on_the_references_rgb_files(dec, oracle):
+    """`jpeg -c` (RGB stored as such, a merging specification with the identity L transformation) at 4:4:4 and the CMYK fixture:
+    the files the kernel is for, against the reference decoder's pixels."""
+    names = [n for n in MANIFEST if n.startswith("refc_") and "444" in n] + ["pil_90x60_cmyk"]
+    assert len(names) >= 2
+    for name in names:
+        f = dec.read(golden_jpeg(name))
+        if all(f.subx[c] == 1 and f.suby[c] == 1 for c in range(f.components)) and f.components in (3, 4):
+            assert api.kernel_name(f) == "fused_flat_kernel", name
+        assert np.array_equal(dec.reconstruct(), golden_pixels(name)), name
+
+
+@pytest.mark.gpu
 def test_fused_tile_kernel_on_big_frames(oracle):
     """Frames of many tiles in layouts the dedicated kernels do not cover -- CMYK, 3x1, 1x4, luma subsampled against chroma,
     two components -- with dense content: hashes of the one-pass kernel equal those of the generic pair (which the test above
@@ -1685,7 +1718,7 @@ def test_fused_tile_kernel_on_big_frames(oracle):
         w, h = 1000 + 37 * k, 700 + 13 * k
         data = craft.craft_stream(rng, samp, w, h, dri=[0, 7][k % 2], ac_density=0.12)
         f = dec.read(data, entropy="host")
-        assert api.kernel_name(f) == "fused_tile_kernel"
+        assert api.kernel_name(f) == ("fused_flat_kernel" if k == 0 else "fused_tile_kernel")  # (four components 1 x 1: no LDS round trip)
         a = dec.reconstruct(0)
         b = dec.reconstruct(api.FLAG_FORCE_GENERIC)
         c = dec.reconstruct(api.FLAG_FORCE_SAFE)
