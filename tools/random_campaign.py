@@ -46,6 +46,27 @@ for t in range(N):
         if got.shape != exp.shape or not np.array_equal(got, exp):
             bad += 1
             print("DECODE DIFFERENCE", t, w, h, sub, q, dri, prog, opt, mode, flush=True)
+    # every component 1 x 1 without a colour transformation (fused_flat_kernel): the 4:4:4 stream read as RGB stored as such,
+    # and now and then a four-component (CMYK) file of the same picture
+    if sub == "444" and not prog:
+        info, planes = O.decode_coefficients(data)
+        f = d.read(data, entropy="host")
+        kernels[api.kernel_name(f, api.FLAG_NO_COLOR_TRANSFORM) + " (no transformation)"] += 1
+        if not np.array_equal(d.reconstruct(api.FLAG_NO_COLOR_TRANSFORM), O.reconstruct(info, planes, use_ycbcr=0)):
+            bad += 1
+            print("DECODE DIFFERENCE (no transformation)", t, w, h, q, dri, flush=True)
+        if t % 4 == 0:
+            import io
+
+            from PIL import Image
+            buf = io.BytesIO()
+            Image.fromarray(np.dstack([img, img[:, :, 1]]), "CMYK").save(buf, format="JPEG", quality=max(q, 5))
+            cm = buf.getvalue()
+            f = d.read(cm, entropy="host")
+            kernels[api.kernel_name(f) + " (CMYK)"] += 1
+            if not np.array_equal(d.reconstruct(), O.decode(cm)):
+                bad += 1
+                print("DECODE DIFFERENCE (CMYK)", t, w, h, q, flush=True)
     # encoder direction on the same picture (colour pictures only, the layouts the CLI offers)
     if sub != "gray" and t % 3 == 0:
         esub = ["444", "420", "422", "440", "411"][int(rng.integers(0, 5))]
