@@ -27,7 +27,7 @@ DAMAGED_DIR = os.path.join(GOLDEN_DIR, "damaged")
 with open(os.path.join(DAMAGED_DIR, "manifest.json")) as _f:
     DAMAGED = json.load(_f)
 
-# plain JPEG fixtures, the DNL ones among them (JPEG XT frames are outside the damaged-stream contract)
+# plain JPEG fixtures, the DNL ones among them (damaged JPEG XT streams: tests/test_xt_damaged.py)
 BASES = sorted(k for k, v in MANIFEST.items() if not v.get("big") and v.get("kind") != "xt_float32")
 
 
