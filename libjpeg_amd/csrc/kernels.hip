@@ -721,9 +721,24 @@ __device__ __forceinline__ const int *frame_deltas(const Args &a, int frame, int
 }
 
 // phase A of the 4:2:0 kernels with 32-bit chroma samples: the (8+2) x (8+2) chroma blocks of tile (tx, ty) -> LDS
-template <bool FAST, bool QDEV = false, bool PK = false>
+// F420P_PREFETCH: the luma blocks of phase B are requested in front of phase A's transform (32 more registers across it; with
+// F420P_MINW 4 the allocation still leaves four workgroups per CU); 0: at the start of phase B, for A-B builds.
+// Measured on one box (profiles/r04/headline_variants.txt): reference-encoded frames 0.617 -> 0.635, dense blocks 0.583 -> 0.595.
+#ifndef F420P_PREFETCH
+#define F420P_PREFETCH 1
+#endif
+#ifndef F420P_TEMPORAL
+#define F420P_TEMPORAL 0 // A-B builds: 1 = the pixel stores of aligned frames without the nt hint as well
+#endif
+#ifndef F420P_MINW
+#define F420P_MINW 4 // workgroups per CU the register allocation must leave room for (the per-frame-table build keeps 3: it spills at 4)
+#endif
+struct NoAfterFetch { __device__ __forceinline__ void operator()() const {} };
+// after_fetch: called between the chroma blocks' arrival and their transform -- where a caller requests the blocks it needs next
+// (fused420_kernel: the luma blocks of phase B; their latency then hides behind this transform)
+template <bool FAST, bool QDEV = false, bool PK = false, class AfterFetch = NoAfterFetch>
 __device__ __forceinline__ void f420_chroma_to_lds(const Fused420Args &a, const int16_t *__restrict__ coef, int (*cplane)[F420_CROWS * F420_CPITCH],
-                                                   u32x4 *stage, int lane, int wave, int tx, int ty, int frame = 0)
+                                                   u32x4 *stage, int lane, int wave, int tx, int ty, int frame = 0, AfterFetch after_fetch = AfterFetch())
 {
   const int comp = wave >> 1; // 0 = Cb, 1 = Cr (wave-uniform)
   const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
@@ -750,6 +765,8 @@ __device__ __forceinline__ void f420_chroma_to_lds(const Fused420Args &a, const 
       return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((gy * a.bw_c + gx) * 128));
     });
   }
+  after_fetch();
+  if constexpr (!std::is_same<AfterFetch, NoAfterFetch>::value) __builtin_amdgcn_sched_barrier(0); // (what it issued stays in front of the transform)
   const int idx = base + lane;
   const int cby = idx / F420_CGRID, cbx = idx - cby * F420_CGRID;
   const int gx = gx0 + cbx, gy = gy0 + cby;
@@ -825,26 +842,33 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
-  f420_chroma_to_lds<FAST, QDEV, !QDEV && P == 8>(a, coef, cplane, stage, lane, wave, tx, ty, frame);
+  // the luma blocks of phase B are requested in front of phase A's transform (see fused420p_kernel; two workgroups per CU leave
+  // the 32 registers)
+  u32x4 yraw[8];
+  auto luma_loads = [&]() {
+    const int16_t *__restrict__ plane = coef + a.off_y;
+    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+    // local block n = (lane >> 3) + 8 m sits at column n & 15 = (lane >> 3) + 8 (m & 1), row n >> 4 = m >> 1 of the wave's 16 x 4 blocks
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    load_blocks(yraw, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  };
+  // (8-bit frames only: the 12-bit flavour measured 30 % slower with it, profiles/r04/headline_variants.txt visit x)
+  constexpr bool PREFETCH = F420P_PREFETCH && P == 8;
+  if (PREFETCH) f420_chroma_to_lds<FAST, QDEV, !QDEV && P == 8>(a, coef, cplane, stage, lane, wave, tx, ty, frame, luma_loads);
+  else f420_chroma_to_lds<FAST, QDEV, !QDEV && P == 8>(a, coef, cplane, stage, lane, wave, tx, ty, frame);
   __syncthreads();
   f420_chroma_edges(a, cplane, tid, tx, ty);
 
   // ------------------------------------------------------------------ phase B: luma + colour
   const int bx = lane & 15, by = wave * 4 + (lane >> 4);
   const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
-  const int y_plane_w = a.bw_y;
   u32x4 rows[8];
-  {
-    const int16_t *__restrict__ plane = coef + a.off_y;
-    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
-    // local block n = (lane >> 3) + 8 m sits at column n & 15 = (lane >> 3) + 8 (m & 1), row n >> 4 = m >> 1 of the wave's 16 x 4 blocks
-    const int x0 = gbx0 + (lane >> 3);
-    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
-    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
-      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
-      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * y_plane_w + x) * 128));
-    });
-  }
+  if (!PREFETCH) luma_loads();
+  transpose_blocks(rows, stage, lane, yraw);
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
@@ -1015,18 +1039,6 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
 // Everything else (tile shape, halo, edge replication, in-place aliasing of output column 1, store path) is
 // identical, and so are the results: wherever nothing overflows, int16 and int32 arithmetic agree.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-// F420P_PREFETCH: the luma blocks of phase B are requested in front of phase A's transform (32 more registers across it; with
-// F420P_MINW 4 the allocation still leaves four workgroups per CU); 0: at the start of phase B, for A-B builds.
-// Measured on one box (profiles/r04/headline_variants.txt): reference-encoded frames 0.617 -> 0.635, dense blocks 0.583 -> 0.595.
-#ifndef F420P_PREFETCH
-#define F420P_PREFETCH 1
-#endif
-#ifndef F420P_TEMPORAL
-#define F420P_TEMPORAL 0 // A-B builds: 1 = the pixel stores of aligned frames without the nt hint as well
-#endif
-#ifndef F420P_MINW
-#define F420P_MINW 4 // workgroups per CU the register allocation must leave room for (the per-frame-table build keeps 3: it spills at 4)
-#endif
 
 __device__ __forceinline__ unsigned tap13_pk(unsigned a, unsigned b, short r)
 {
