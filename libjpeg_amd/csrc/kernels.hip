@@ -3554,6 +3554,12 @@ static Fused420Args with_tile_magic(const Fused420Args &a0)
   return a;
 }
 
+#ifndef F420_FAST_MINW
+#define F420_FAST_MINW 2 // workgroups per CU of the unpacked 4:2:0 kernel, fast flavour (A-B builds)
+#endif
+#ifndef F420_12_MINW
+#define F420_12_MINW 2
+#endif
 int launch_fused420(const Fused420Args &a0, bool fast, hipStream_t stream)
 {
   const Fused420Args a = with_tile_magic(a0);
@@ -3562,9 +3568,9 @@ int launch_fused420(const Fused420Args &a0, bool fast, hipStream_t stream)
   // two workgroups per CU for both flavours (132 / 194 VGPRs)
   if (a.qdev) {
     if (!fast) hipLaunchKernelGGL((fused420_kernel<false, 2, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-    else hipLaunchKernelGGL((fused420_kernel<true, 2, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused420_kernel<true, F420_FAST_MINW, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   } else if (!fast) hipLaunchKernelGGL((fused420_kernel<false, 2, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused420_kernel<true, 2, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused420_kernel<true, F420_FAST_MINW, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -3573,8 +3579,8 @@ int launch_fused420_12(const Fused420Args &a0, hipStream_t stream)
   const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles<1>((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
-  if (a.qdev) hipLaunchKernelGGL((fused420_kernel<true, 2, true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused420_kernel<true, 2, false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) hipLaunchKernelGGL((fused420_kernel<true, F420_12_MINW, true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused420_kernel<true, F420_12_MINW, false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
