@@ -25,6 +25,19 @@ def main():
     print(f"generated {n} streams in {time.perf_counter() - t:.1f} s, {sum(len(s) for s in streams.values()) / n / 1e6:.2f} MB each")
     # CHUNKxDEPTH, a trailing r = ramped schedule (small chunks at both ends)
     settings = [(int(c), int(d.rstrip("r")), d.endswith("r")) for c, d in (s.split("x") for s in os.environ.get("SETTINGS", "32x2,16x3,64x2,32x1,128x1").split(","))]
+    if os.environ.get("DOWNLOAD"):
+        # DOWNLOAD=1: pixels into pinned host memory, each chunk's download under the decode of the next ones (BatchShard.run(download_to))
+        import time as _t
+        for chunk, depth, ramp in settings:
+            shard = batch.BatchShard([streams[i] for i in range(n)], 0, chunk, depth, ramp)
+            host = torch.empty(shard.out.shape, dtype=shard.out.dtype).pin_memory()
+            shard.run(download_to=host)
+            ts = []
+            for _ in range(int(os.environ.get("STEPS", "3"))):
+                torch.cuda.synchronize(); t = _t.perf_counter(); shard.run(download_to=host); ts.append((_t.perf_counter() - t) * 1e3)
+            print(f"chunk {chunk:4d} depth {depth}{' ramp' if ramp else '     '}: bytes -> pixels in pinned host memory {min(ts):8.2f} ms per batch ({host.numel() / 1e9 / (min(ts) * 1e-3):.1f} GB/s down)")
+            shard.close()
+        return
     for chunk, depth, ramp in settings:
         r = batch.run_sharded(streams, n, 0, 1, 0, None, steps=int(os.environ.get("STEPS", "3")), warmup=1, chunk=chunk, depth=depth, ramp=ramp)
         ms = r["seconds"] * 1e3 / int(os.environ.get("STEPS", "3"))
