@@ -120,7 +120,7 @@ typedef struct mijpeg_xt_params {
   int32_t residual_wide;     /* 1: the residual planes hold int32 coefficients (two int16 slots each)           */
   int32_t ltrafo_ycbcr;      /* L transformation: 1 = YCbCr -> RGB, 0 = identity                                */
   int32_t rtrafo_ycbcr;      /* R transformation                                                                */
-  int32_t out_max;           /* 2^(8 + extra range bits) - 1 = 65535                                            */
+  int32_t out_max;           /* 2^(8 + extra range bits) - 1: 65535 (half-float codes, 16-bit integers) or 255              */
   int32_t out_shift;         /* (out_max + 1) / 2                                                               */
   int32_t is_float, clamp;   /* output conversion box: cast to float, clamping                                  */
   /* Beyond what the reference's encoder writes by default (all of it decodes like the reference, bit for bit):
@@ -139,6 +139,9 @@ typedef struct mijpeg_xt_params {
   int32_t no_residual;       /* 1: the legacy codestream never came to an EOI marker, the reference has not parsed the residual
                                 codestream and merges nothing (codestream/image.cpp:1416-1431; rr = m_lOutDCShift,
                                 colortrafo/ycbcrtrafo.cpp:744-746): the residual planes are zeros and the merge ignores them     */
+  int32_t ltrafo_standard;   /* 1: the L transformation is the STANDARD YCbCr one (not a free-form matrix): the one a request without
+                                colour transformation (MIJPEG_FLAG_NO_COLOR_TRANSFORM, the command line's -c) replaces by the
+                                identity -- and nothing else of the merge (colortrafo/colortransformerfactory.cpp:231-232)          */
 } mijpeg_xt_params;
 
 /* ---- decoder object (one image at a time; one object = one host thread at a time) ---------- */

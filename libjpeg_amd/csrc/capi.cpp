@@ -1690,6 +1690,15 @@ static bool use_fused420p(const mijpeg_batch *b)
 
 // JPEG XT profile C in the shape the fused kernel covers: 8-bit 4:2:0 legacy frame and 12-bit 4:4:4 residual frame without
 // hidden bits, L transformation on, both frames within the range the fast transforms are exact for
+// JPEG XT: the L transformation in force for this launch.  A request without colour transformation (the command line's -c)
+// replaces the STANDARD YCbCr transformation by the identity and leaves everything else of the merge alone
+// (colortrafo/colortransformerfactory.cpp:231-232: `if (ltrafo == YCbCr && disabletorgb) ltrafo = Identity`)
+static bool xt_ltrafo_ycbcr(const mijpeg_batch *b)
+{
+  const mijpeg_xt_params &x = *b->xt;
+  return x.ltrafo_ycbcr && !((b->flags & MIJPEG_FLAG_NO_COLOR_TRANSFORM) && x.ltrafo_standard);
+}
+
 static bool use_fusedxt(const mijpeg_batch *b)
 {
   const mijpeg_info &f = b->info;
@@ -1709,7 +1718,7 @@ static bool use_fusedxt(const mijpeg_batch *b)
   // hidden bits in the RESIDUAL frame (-rR n: 13..16-bit samples, int32 coefficients) have a kernel of their own
   // (fusedxtw420_kernel); hidden bits in the legacy frame change its precision and stay on the three-kernel path
   if (x.hidden_bits || x.residual_hidden_bits < 0 || x.residual_hidden_bits > 4 || (x.residual_wide != 0) != (x.residual_hidden_bits > 0) ||
-      x.ltable_entries != 256 || !x.ltrafo_ycbcr || r.precision != 12 || r.components != 3 || x.out_max != 65535 || x.out_shift != 32768)
+      x.ltable_entries != 256 || !xt_ltrafo_ycbcr(b) || r.precision != 12 || r.components != 3 || x.out_max != 65535 || x.out_shift != 32768)
     return false;
   static const bool no_wide = getenv("MIJPEG_NO_FUSEDXTW") != nullptr; // A-B comparisons
   if (x.residual_hidden_bits && no_wide) return false;
@@ -1968,7 +1977,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       a.ltable_entries = x.ltable_entries;
       a.nplanes = 6;
       a.xt = 1;
-      a.ycbcr = x.ltrafo_ycbcr; // the L transformation of the merging specification (the -c switch does not apply to XT here)
+      a.ycbcr = xt_ltrafo_ycbcr(b) ? 1 : 0; // the L transformation of the merging specification, or the identity the -c switch puts in its place
       a.rtrafo_ycbcr = x.rtrafo_ycbcr;
       a.out_shift = x.out_shift;
       a.out_max = x.out_max;

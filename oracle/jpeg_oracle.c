@@ -2483,7 +2483,10 @@ static void xt_ctx_free(struct oj_xt_ctx *ctx)
 }
 
 /* pixels != NULL: the whole picture (oj_decode_xt); rq_out != NULL: a requester that keeps what was decoded (oj_xt_requester_new) */
-static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, oj_requester **rq_out)
+/* disable_to_rgb: a request without colour transformation (cmd/reconstruct.cpp -c -> rr_bColorTrafo false ->
+ * ColorTransformerFactory::BuildColorTransformer(.., disabletorgb)): the standard YCbCr L transformation becomes the identity,
+ * nothing else changes (colortrafo/colortransformerfactory.cpp:231-232) */
+static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, oj_requester **rq_out, int disable_to_rgb)
 {
   oj_box boxes[OJ_MAX_BOXES];
   oj_parser ps;
@@ -2564,6 +2567,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   if (xt.is_float && xt.outmax != 65535) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   /* free-form matrices run through the YCbCr branches of the transformer (colortransformerfactory.cpp:1036-1058) */
   xt.ltrafo_ycbcr = ltrafo != 1; xt.rtrafo_ycbcr = rtrafo != 1;
+  if (disable_to_rgb && ltrafo == 2) xt.ltrafo_ycbcr = 0; /* MergingSpecBox::YCbCr only: a free-form matrix stays */
   memcpy(xt.lmat, ltrafo >= 5 ? mtx[ltrafo] : ltrafo == 2 ? std_ycc : std_id, sizeof(xt.lmat));
   memcpy(xt.rmat, rtrafo >= 5 ? mtx[rtrafo] : rtrafo == 2 ? std_ycc : std_id, sizeof(xt.rmat));
   memcpy(xt.cmat, (ctrafo != 255 && ctrafo >= 5) ? mtx[ctrafo] : std_id, sizeof(xt.cmat));
@@ -2709,14 +2713,20 @@ out:
 
 int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float)
 {
-  return xt_decode_common(data, len, info, pixels, is_float, NULL);
+  return xt_decode_common(data, len, info, pixels, is_float, NULL, 0);
+}
+
+/* ... as the reference's command line decodes it with -c (no colour transformation) */
+int oj_decode_xt_ex(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, int disable_to_rgb)
+{
+  return xt_decode_common(data, len, info, pixels, is_float, NULL, disable_to_rgb);
 }
 
 /* A requester (oj_requester_display / _cursor / _free) on a JPEG XT stream: both codestreams decoded, the residual image's
  * cursors and upsamplers beside the legacy image's.  *out_max = 2^(8 + extra range bits) - 1: samples of 2 bytes above 255. */
 int oj_xt_requester_new(const uint8_t *data, size_t len, oj_info *info, oj_requester **rq, int *is_float, int *out_max)
 {
-  const int rc = xt_decode_common(data, len, info, NULL, is_float, rq);
+  const int rc = xt_decode_common(data, len, info, NULL, is_float, rq, 0);
   if (!rc && out_max) *out_max = (int)(*rq)->xt->outmax;
   return rc;
 }

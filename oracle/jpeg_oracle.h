@@ -133,6 +133,9 @@ int oj_requester_display(oj_requester *rq, int min_x, int min_y, int max_x, int 
  * what tests/golden/xt_general/ pins against the reference decoder):
  * 16-bit codes out (half-float bit patterns when *is_float). colortrafo/ycbcrtrafo.cpp:750-955. */
 int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float);
+/* ... with disable_to_rgb: what `jpeg -c in.jpg out` shows -- the standard YCbCr L transformation replaced by the identity
+ * (colortrafo/colortransformerfactory.cpp:231-232), the rest of the merge unchanged */
+int oj_decode_xt_ex(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, int disable_to_rgb);
 float oj_half_to_float(uint16_t h);
 
 /* Convenience: whole decode.  *pixels is malloc'ed (free with oj_free). */

@@ -58,6 +58,7 @@ def lib():
         L.oj_reconstruct.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
         L.oj_reconstruct16.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
         L.oj_decode_xt.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L.oj_decode_xt_ex.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
         L.oj_free.argtypes = [C.c_void_p]
         L.oj_forward.argtypes = [C.POINTER(OjInfo), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.oj_fdct_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -146,13 +147,14 @@ def decode_xt(data: bytes):
     return out, bool(isf.value)
 
 
-def decode_xt_status(data: bytes):
+def decode_xt_status(data: bytes, no_color_transform: bool = False):
     """-> (codes or None, is_float, ref_error): ref_error = 0, the JPGERR_* code the reference fails with where the oracle knows
-    it (merging specification errors), or None (outside the oracle's subset / other failure)."""
+    it (merging specification errors), or None (outside the oracle's subset / other failure).
+    no_color_transform: as `jpeg -c in.jpg out` decodes it (the standard YCbCr L transformation replaced by the identity)."""
     info = OjInfo()
     px = C.c_void_p()
     isf = C.c_int(0)
-    rc = lib().oj_decode_xt(data, len(data), C.byref(info), C.byref(px), C.byref(isf))
+    rc = lib().oj_decode_xt_ex(data, len(data), C.byref(info), C.byref(px), C.byref(isf), 1 if no_color_transform else 0)
     if rc:
         return None, False, (info.ref_error if (rc != -2 and info.ref_error) else None)
     n = info.width * info.height * 3
@@ -422,13 +424,13 @@ def write_pfm(path: str, img: np.ndarray) -> None:
         f.write(np.ascontiguousarray(img[::-1], "<f4").tobytes())
 
 
-def reference_decode_hdr(data: bytes) -> np.ndarray:
+def reference_decode_hdr(data: bytes, extra_args=()) -> np.ndarray:
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
     with tempfile.TemporaryDirectory(dir=tmpdir) as d:
         src, dst = os.path.join(d, "in.jpg"), os.path.join(d, "out.pfm")
         with open(src, "wb") as f:
             f.write(data)
-        subprocess.run([REF_BIN, src, dst], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([REF_BIN, *extra_args, src, dst], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return read_pfm_reference(dst)
 
 
