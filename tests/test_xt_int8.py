@@ -120,3 +120,41 @@ def test_gpu_full_hd_round_trip(oracle, dec):
     dec.read(data)
     out = dec.reconstruct()
     assert out.dtype == np.uint8 and np.array_equal(out, codes.astype(np.uint8))
+
+
+# ------------------------------------------------------------------------------------------------ 16-bit integer output
+# The same files from a PPM with 16-bit samples: 8 extra range bits, clamping, no cast to float (tests/golden/make_xt_int16.py;
+# the reference decoder's PPM samples, plain and with -c).  4:2:0 runs the fused XT kernel with its integer clamp.
+DIR16 = os.path.join(GOLDEN_DIR, "xt_int16")
+with open(os.path.join(DIR16, "manifest.json")) as _f:
+    CASES16 = json.load(_f)
+
+
+def stream16(name):
+    with open(os.path.join(DIR16, name + ".jpg"), "rb") as f:
+        return f.read()
+
+
+def expected16(name, tag):
+    ent = CASES16[name]
+    return np.fromfile(os.path.join(DIR16, f"{name}.{tag}.bin"), "<u2").reshape(ent["height"], ent["width"], 3)
+
+
+@pytest.mark.parametrize("noct", [False, True])
+@pytest.mark.parametrize("name", sorted(CASES16))
+def test_oracle_16bit_integer_output(oracle, name, noct):
+    codes, is_float, err = oracle.decode_xt_status(stream16(name), no_color_transform=noct)
+    assert err == 0 and not is_float
+    assert np.array_equal(codes, expected16(name, "noct" if noct else "plain")), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noct", [False, True])
+@pytest.mark.parametrize("name", sorted(CASES16))
+def test_gpu_16bit_integer_output(dec, name, noct):
+    info = dec.read(stream16(name))
+    assert info.xt and not info.is_float and info.sample_bytes == 2 and dec.xt_params().out_max == 65535
+    out = dec.reconstruct(api.FLAG_NO_COLOR_TRANSFORM if noct else 0)
+    assert out.dtype == np.uint16 and np.array_equal(out, expected16(name, "noct" if noct else "plain")), name
+    if name == "w420_r12" and not noct:
+        assert api.kernel_name(info, xt=dec.xt_params()) == "fusedxt420_kernel"
