@@ -250,7 +250,11 @@ void mijpeg_host_free(void *p);
  * as in JPGTAG_DECODER_MINX..MAXY / MINCOMPONENT..MAXCOMPONENT (codestream/rectanglerequest.cpp:92-152).
  * With MIJPEG_FLAG_NO_UPSAMPLING (min_comp == max_comp required) the component is delivered at its own resolution
  * without colour transformation; the rectangle is still given on the canvas and shrinks by the subsampling factors
- * (control/bitmapctrl.cpp:273-294), dst[c] addresses the component's sample (0,0).
+ * (control/bitmapctrl.cpp:273-294), dst[c] addresses the component's sample (0,0).  JPEG XT frames return
+ * MIJPEG_ERR_OPERATION_UNIMPLEMENTED for it: the reference merges the one requested component with whatever its scratch
+ * buffers hold for the residuals of the OTHER two -- heap memory it never initialised during the first component's pass
+ * (control/blockbitmaprequester.cpp:379-388, 1054-1061; `MALLOC_PERTURB_=165 jpeg -U xt.jpg out.pgx` writes other planes
+ * than `jpeg -U xt.jpg out.pgx`), so there is no output to equal.
  * With MIJPEG_FLAG_DEVICE_OUTPUT the bitmaps live in device memory of the decoder's GPU and the pixels never leave
  * HBM ("device-side output"); the call returns when they are written. */
 int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y,
@@ -280,8 +284,9 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
  * components, upsampling and colour transformation on) with any order and size of rectangles; a request that walks the
  * residual cursor of a component without upsampler behind its last row makes the reference dereference a NULL row
  * (:1057-1058, :1201-1202): MIJPEG_ERR_OBJECT_DOESNT_EXIST here.  Component subsets of an XT frame (they merge with what a
- * scratch buffer holds from the block before) and XT requests without upsampling or colour transformation are served as the
- * plain picture.  Not modelled either: rectangles narrower than the frame that move sideways between calls read line-buffer
+ * scratch buffer holds from the block before) are served as the plain picture, XT requests without colour transformation as
+ * the plain picture with the identity in place of the standard YCbCr L transformation (what the reference's transformer
+ * does, mijpeg_xt_params.ltrafo_standard), XT requests without upsampling fail (see mijpeg_reconstruct_rect).  Not modelled either: rectangles narrower than the frame that move sideways between calls read line-buffer
  * memory the reference never initialised. */
 typedef struct mijpeg_bitmap {
   void *data;

@@ -2606,7 +2606,7 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
     if (min_comp != max_comp)
       return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "if upsampling is disabled, components can only be reconstructed one by one");
     if (d->host.is_xt())
-      return set_error(d, MIJPEG_ERR_OPERATION_UNIMPLEMENTED, "JPEG XT streams are not reconstructed without upsampling on this path");
+      return set_error(d, MIJPEG_ERR_OPERATION_UNIMPLEMENTED, "JPEG XT frames are not reconstructed without upsampling (the reference merges the component with residual scratch buffers it never initialised)");
     view = min_comp;
     flags |= MIJPEG_FLAG_NO_COLOR_TRANSFORM;
     const int sx = d->host.info.subx[view], sy = d->host.info.suby[view];
