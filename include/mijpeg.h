@@ -81,7 +81,7 @@ typedef struct mijpeg_info {
   int32_t range_max[MIJPEG_MAX_COMPONENTS]; /* set by decode_coefficients: max over the component's blocks of
                                 sum_k |c_k| * q_k (bounds every IDCT output by 4 * range_max) */
   int32_t sample_bytes;      /* bytes per output sample: 1 (precision 8), 2 (precision 12, JPEG XT)          */
-  int32_t xt;                /* 1 = JPEG XT profile C stream: output = 16-bit codes, see mijpeg_xt_params     */
+  int32_t xt;                /* 1 = JPEG XT profile C stream (three components or one): see mijpeg_xt_params     */
   int32_t is_float;          /* JPGTAG_IMAGE_IS_FLOAT: the 16-bit codes are half-float bit patterns          */
   int32_t progressive;       /* 1 = progressive frame (SOF2): informational, the reconstruction is the same         */
   int32_t coef_wide;         /* 1 = the planes hold int32 coefficients, two int16 slots each (coef_offset[] and coef_count

@@ -1797,6 +1797,7 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (b->info.coef_wide) return "idct_planes_long_kernel+upsample_color_kernel";
   if (use_fused420(b)) return "fused420_kernel";
   if (use_fused444(b)) return "fused444_kernel";
+  if (b->info.xt && b->info.components == 1) return "idct_planes_kernel+xt_merge1_kernel";
   if (b->info.xt) return b->xt && b->xt->general ? "idct_planes_kernel+xt_merge_general_kernel" : "idct_planes_kernel+xt_merge_kernel";
   if (use_fused_flat(b)) return "fused_flat_kernel";
   if (b->quant_dev || (b->flags & MIJPEG_FLAG_FORCE_GENERIC) || getenv("MIJPEG_NO_FUSED_TILE") || dnl_row_missing(b->info)) return "idct_planes_kernel+upsample_color_kernel";
@@ -1849,7 +1850,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
   if (b->quant_dev && b->info.xt) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED; // per-frame tables: plain JPEG only
   const mijpeg_info &f = b->info;
   if ((f.precision != 8 && f.precision != 12) || f.components < 1 || f.components > 4) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
-  if (f.xt && (!b->xt || f.components != 3)) return MIJPEG_ERR_MISSING_PARAMETER;
+  if (f.xt && (!b->xt || (f.components != 3 && f.components != 1))) return MIJPEG_ERR_MISSING_PARAMETER; // (one component: grey scale with a residual)
   if (f.coef_wide && (f.xt || b->quant_dev)) return MIJPEG_ERR_INVALID_PARAMETER; // int32 planes: single plain JPEG frames only
   const bool fast = fast_ok(b) && !f.coef_wide;
   hipStream_t s = (hipStream_t)stream;
@@ -1972,7 +1973,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       if (x.hidden_bits < 0 || x.hidden_bits > 4 || x.residual_hidden_bits < 0 || x.residual_hidden_bits > 4 || rprec > 16 ||
           x.ltable_entries != (256 << x.hidden_bits) || (x.residual_wide != 0) != (x.residual_hidden_bits > 0))
         return MIJPEG_ERR_INVALID_PARAMETER;
-      for (int c = 0; c < 3; c++) plane(3 + c, x.residual, c, rprec);
+      for (int c = 0; c < x.residual.components && c < 3; c++) plane(3 + c, x.residual, c, rprec); // (one component: planes 4, 5 stay empty)
       if (x.residual_wide) { a.wide_first = 3; a.wide_count = 3; }
       a.ltable_entries = x.ltable_entries;
       a.nplanes = 6;

@@ -3382,6 +3382,49 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
   }
 }
 
+// The merge for ONE component: a grey scale picture with a residual (`jpeg -r .. in.pgm`).  Every transformation is the identity
+// (codestream/tables.cpp:2003-2005, 2055-2060, 2079-2081; YCbCrTrafo<.., 1, .., Identity, Identity>, colortransformerfactory.cpp:
+// 681-757): out = clamp(L[(y + 8) >> 4] + R2[Q[residual]] - 2^(bits - 1)) with the tables (or their arithmetic identities at 16
+// bits) of component 0, as half-float code or integer, one or two bytes per sample.  Planes 0 (legacy) and 3 (residual).
+__global__ __launch_bounds__(256) void xt_merge1_kernel(const GenericArgs a)
+{
+  const int groups = (a.width + 7) >> 3;
+  const int gxi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Y = a.y_base + blockIdx.y;
+  const int frame = blockIdx.z;
+  if (gxi >= groups) return;
+  const int X0 = gxi * 8;
+  int s[8], rs[8];
+  upsample_plane_line<LAYOUT_ANY>(a, 0, 0, frame, X0, Y, s);
+  upsample_plane_line<LAYOUT_ANY>(a, 3, 0, frame, X0, Y, rs);
+  uint8_t *line = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride;
+  const int npx = min(8, a.width - X0);
+  const int rmax16 = ((1 << a.rprecision) << 4) - 1; // ((m_lRMax + 1) << COLOR_BITS) - 1
+  const int omax16 = ((a.out_max + 1) << 4) - 1;
+  const int qshift = 16 - a.rprecision;
+  const int pinf = (a.out_max >> 1) - (a.out_max >> 6) - 1;
+  const int minf = -pinf - 1;
+  for (int x = 0; x < npx; x++) {
+    const int idx = min(max(rs[x], 0), rmax16);
+    const long long q = a.qlut[0] ? (long long)a.qlut[0][idx] : (long long)idx << qshift;
+    const int idx2 = (int)min(max(q, 0ll), (long long)omax16);
+    long long rr = a.r2lut[0] ? (long long)a.r2lut[0][idx2] : (long long)((idx2 + 8) >> 4);
+    if (a.xt_no_residual) rr = a.out_shift; // nothing to merge (colortrafo/ycbcrtrafo.cpp:744-746)
+    const long long v = ((long long)s[x] + 8) >> 4;
+    const long long lv = a.ltable[(int)min(max(v, 0ll), (long long)a.maxval)];
+    long long m = lv + rr - a.out_shift;
+    if (a.is_float) {
+      m = min(max(m, (long long)minf), (long long)pinf);
+      const short w = (short)m;
+      reinterpret_cast<uint16_t *>(line)[X0 + x] = (uint16_t)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS
+    } else if (a.sample_bytes == 1) {
+      line[X0 + x] = (uint8_t)min(max(m, 0ll), (long long)a.out_max);
+    } else {
+      reinterpret_cast<uint16_t *>(line)[X0 + x] = (uint16_t)min(max(m, 0ll), (long long)a.out_max);
+    }
+  }
+}
+
 // Residual planes whose DCT was bypassed (RDCT box): ResidualBlockHelper::DequantizeResidual without a transform,
 // control/residualblockhelper.cpp:203-231 -- sample = coefficient * (delta[63] << 4) + 2^(Pr-1), optionally the 2 x 2 noise
 // shaping average.  One thread per block; planes 3..5 of the sample workspace (they overwrite what idct_planes_kernel put there).
@@ -3799,7 +3842,9 @@ int launch_generic(const GenericArgs &a, bool fast, hipStream_t stream)
     for (int c = 3; c < 6; c++) rb = max(rb, a.bw[c] * a.bh[c]);
     hipLaunchKernelGGL(bypass_planes_kernel, dim3((rb + 255) / 256, 3 * a.frames), dim3(256), 0, stream, a);
   }
-  if (a.xt) {
+  if (a.xt && a.ncomp == 1) {
+    hipLaunchKernelGGL(xt_merge1_kernel, g2, dim3(bs), 0, stream, a);
+  } else if (a.xt) {
     const int rlay = a.request ? LAYOUT_ANY : layout_of(3, 3);
     if (rlay == layout_id(1, 1) && lay == layout_id(2, 2)) LAUNCH_XT(layout_id(2, 2), layout_id(1, 1));
     else if (rlay == layout_id(1, 1) && lay == layout_id(1, 1)) LAUNCH_XT(layout_id(1, 1), layout_id(1, 1));

@@ -1691,6 +1691,7 @@ typedef struct {
   int rbypass, rnoise;              /* RDCT box: residual DCT bypassed (control/residualblockhelper.cpp:203-231), noise shaping */
   int64_t outmax, outshift;         /* 2^(8 + extra bits) - 1 and its half */
   int is_float, clamp;              /* OCON: cast to float (half codes), clamping */
+  int nc;                           /* components: 3, or 1 (grey scale; every transformation is the identity then) */
   int no_residual;                  /* the legacy codestream never came to its EOI: the reference has not parsed the residual
                                        codestream and merges nothing (rr = m_lOutDCShift, colortrafo/ycbcrtrafo.cpp:744-746) */
 } oj_xt;
@@ -1726,10 +1727,12 @@ static void xt_merge_pixel(const oj_xt *xt, int64_t maxval, const int64_t vin[3]
   const int64_t omax16 = ((xt->outmax + 1) << 4) - 1;
   int64_t rr[3], q3[3], lv[3], v[3];
   int c;
+  const int nc = xt->nc == 1 ? 1 : 3;
+  rr[0] = rr[1] = rr[2] = 0; q3[1] = q3[2] = 0; lv[1] = lv[2] = 0;
   if (xt->no_residual) { rr[0] = rr[1] = rr[2] = xt->outshift; goto merge; }
   /* Q tables (APPLY_LUT: index clamped to the table); the identity, 2^(Pr + 4) -> 2^(16 + 4), scales by 2^(16 - Pr)
    * (parametrictonemappingbox.cpp:387-430) */
-  for (c = 0; c < 3; c++) {
+  for (c = 0; c < nc; c++) {
     const int64_t idx = clampmax(rk[c], rmax16);
     q3[c] = xt->qlut[c] ? xt->qlut[c][idx] : idx << (16 - r->precision);
   }
@@ -1743,24 +1746,24 @@ static void xt_merge_pixel(const oj_xt *xt, int64_t maxval, const int64_t vin[3]
     rr[0] = q3[0]; rr[1] = q3[1]; rr[2] = q3[2];
   }
   /* R2 tables; the identity 2^(16 + 4) -> 2^16 is floor(x / 16 + 0.5) */
-  for (c = 0; c < 3; c++) {
+  for (c = 0; c < nc; c++) {
     const int64_t idx = clampmax(rr[c], omax16);
     rr[c] = xt->r2lut[c] ? xt->r2lut[c][idx] : (idx + 8) >> 4;
   }
 merge:
-  for (c = 0; c < 3; c++) lv[c] = xt->ltable[c] ? xt->ltable[c][clampmax(vin[c], maxval)] : vin[c];
+  for (c = 0; c < nc; c++) lv[c] = xt->ltable[c] ? xt->ltable[c][clampmax(vin[c], maxval)] : vin[c];
   /* C transformation, FIX_TO_INT (the identity leaves the values alone: (x * 8192 + 4096) >> 13 == x) */
   for (c = 0; c < 3; c++)
     v[c] = ((lv[0] * xt->cmat[3 * c] + lv[1] * xt->cmat[3 * c + 1] + lv[2] * xt->cmat[3 * c + 2] + 4096) >> 13) + rr[c] - xt->outshift;
   if (xt->is_float && xt->clamp) {
     const int64_t pinf = (xt->outmax >> 1) - (xt->outmax >> 6) - 1;
     const int64_t minf = invert_negs((int16_t)(uint16_t)(pinf | 0x8000));
-    for (c = 0; c < 3; c++) {
+    for (c = 0; c < nc; c++) {
       int64_t t = v[c] > pinf ? pinf : (v[c] < minf ? minf : v[c]);
       out[c] = (uint16_t)invert_negs((int16_t)t);
     }
   } else {
-    for (c = 0; c < 3; c++) out[c] = (uint16_t)clampmax(v[c], xt->outmax);
+    for (c = 0; c < nc; c++) out[c] = (uint16_t)clampmax(v[c], xt->outmax);
   }
 }
 
@@ -1836,7 +1839,8 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
           }
           if (xt) {
             int32_t rk[3] = {0, 0, 0};
-            if (!xt->no_residual) { rk[0] = rblk[0][k]; rk[1] = rblk[1][k]; rk[2] = rblk[2][k]; }
+            if (!xt->no_residual)
+              for (c = 0; c < f->ncomp; c++) rk[c] = rblk[c][k];
             xt_merge_pixel(xt, maxval, v, rk, pixels16 + pix);
           } else if (pixels8) {
             for (c = 0; c < f->ncomp; c++) pixels8[pix + c] = (uint8_t)clampmax(v[c], maxval);
@@ -2500,7 +2504,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   int hidden_l = 0, hidden_r = 0; /* RSPC: bits of the legacy / residual coefficients in hidden refinement scans */
   const oj_box *spec = NULL, *resi = NULL;
   int ltrafo = 255, rtrafo = 255, ctrafo = 255, lidx[4] = {255, 255, 255, 255}, qidx[4] = {255, 255, 255, 255}, r2idx[4] = {255, 255, 255, 255};
-  int ocon = -1, rdct = 0, b, c, rc;
+  int ocon = -1, rdct = 0, b, c, rc, nc = 3;
   size_t j;
   static const int64_t std_ycc[9] = {FIX13(1.0), FIX13(0.0), FIX13(1.40200), FIX13(1.0), -FIX13(0.3441362861), -FIX13(0.7141362859),
                                      FIX13(1.0), FIX13(1.772), FIX13(0.0)};
@@ -2515,7 +2519,9 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     if (boxes[b].type == BOXID('S', 'P', 'E', 'C')) spec = &boxes[b];
     if (boxes[b].type == BOXID('R', 'E', 'S', 'I')) resi = &boxes[b];
   }
-  if (!spec || !resi || info->ncomp != 3 || info->precision != 8) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  if (!spec || !resi || (info->ncomp != 3 && info->ncomp != 1) || info->precision != 8) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  nc = info->ncomp; /* three components, or one: a grey scale picture with a residual (`jpeg -r ... in.pgm`) */
+  xt.nc = nc;
   /* the specification's own boxes are searched first (primary list), then the file's (boxes/namespace.cpp:60-125) */
   for (j = 0; j + 8 <= spec->len;) { /* superbox: LBox(4) TBox(4) payload (boxes/superbox.cpp) */
     uint32_t l = ((uint32_t)rd16(spec->data + j) << 16) | (uint32_t)rd16(spec->data + j + 2);
@@ -2551,6 +2557,13 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     if (rc) goto out;
   }
   /* codestream/tables.cpp:1994-2031 and the R analogue: undefined -> YCbCr for three components */
+  if (nc == 1) {
+    /* one component: the L and C transformation boxes must not exist (tables.cpp:2003-2005, 2079-2081), everything is the identity;
+     * an R transformation other than the identity has no transformer (BuildIntegerTransformationSimple, colortransformerfactory.cpp:681-757) */
+    if (ltrafo != 255 || ctrafo != 255) { info->ref_error = -1038; rc = OJ_ERR_MALFORMED; goto out; }
+    if (rtrafo != 255 && rtrafo != 1) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+    ltrafo = rtrafo = 1;
+  }
   if (ltrafo == 255) ltrafo = 2;
   if (rtrafo == 255) rtrafo = 2;
   if (ltrafo == 0 || ltrafo == 3 || ltrafo == 4) { rc = OJ_ERR_MALFORMED; goto out; } /* "the base transformation ... is invalid" */
@@ -2585,7 +2598,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     oj_info ltmp;
     memset(&ls, 0, sizeof(ls)); memset(&ltmp, 0, sizeof(ltmp));
     ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
-    for (c = 0; c < 3; c++) {
+    for (c = 0; c < nc; c++) {
       planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
       if (!planes[c]) { rc = OJ_ERR_NOMEM; goto out; }
     }
@@ -2598,7 +2611,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     }
     goto out;
   }
-  for (c = 0; c < 3; c++) {
+  for (c = 0; c < nc; c++) {
     /* L: ScaledTableOf(8 + hidden bits, 16, 0, 0), default = identity with e = 1; Q: (Pr + hidden bits, 16, 4, 4) and
      * R2: (16, 16, 4, 0), defaults = identities with e = 0 (colortransformerfactory.cpp:312-345, 435-474, 486-520) */
     oj_nlt id1, id0;
@@ -2628,7 +2641,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   if (rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp) { rc = OJ_ERR_MALFORMED; goto out; }
   if (rinfo.precision + hidden_r > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   info->ycbcr = xt.ltrafo_ycbcr;
-  for (c = 0; c < 3; c++) {
+  for (c = 0; c < nc; c++) {
     planes[c] = (int32_t *)malloc((size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
     rplanes[c] = (int32_t *)malloc((size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
     if (!planes[c] || !rplanes[c]) { rc = OJ_ERR_NOMEM; goto out; }
@@ -2641,7 +2654,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
     ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
     rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r; rs.nested = 1;
-    for (c = 0; c < 3; c++) {
+    for (c = 0; c < nc; c++) {
       memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
       memset(rplanes[c], 0, (size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
     }
@@ -2679,7 +2692,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     rq->xt = &ctx->xt;
     rq->rf = &ctx->rinfo;
     rq->owner = ctx;
-    for (c = 0; c < 3; c++) {
+    for (c = 0; c < nc; c++) {
       ctx->planes[c] = planes[c]; planes[c] = NULL; /* (the requester reads them through rq->planes) */
       ctx->rplanes[c] = rplanes[c]; rplanes[c] = NULL;
       rq->rplanes[c] = ctx->rplanes[c];
@@ -2699,7 +2712,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     *rq_out = rq;
     goto out;
   }
-  *pixels = (uint16_t *)malloc((size_t)info->width * info->height * 3 * sizeof(uint16_t));
+  *pixels = (uint16_t *)malloc((size_t)info->width * info->height * (size_t)nc * sizeof(uint16_t));
   if (!*pixels) { rc = OJ_ERR_NOMEM; goto out; }
   rc = reconstruct_ex(info, planes, NULL, *pixels, xt.ltrafo_ycbcr, &xt);
   if (rc) { free(*pixels); *pixels = NULL; }

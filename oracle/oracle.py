@@ -141,8 +141,8 @@ def decode_xt(data: bytes):
     rc = lib().oj_decode_xt(data, len(data), C.byref(info), C.byref(px), C.byref(isf))
     if rc:
         raise ValueError(f"oracle: oj_decode_xt failed rc={rc}")
-    n = info.width * info.height * 3
-    out = np.ctypeslib.as_array((C.c_uint16 * n).from_address(px.value)).reshape(info.height, info.width, 3).copy()
+    n = info.width * info.height * info.ncomp
+    out = np.ctypeslib.as_array((C.c_uint16 * n).from_address(px.value)).reshape(info.height, info.width, info.ncomp).copy()
     lib().oj_free(px)
     return out, bool(isf.value)
 
@@ -157,8 +157,8 @@ def decode_xt_status(data: bytes, no_color_transform: bool = False):
     rc = lib().oj_decode_xt_ex(data, len(data), C.byref(info), C.byref(px), C.byref(isf), 1 if no_color_transform else 0)
     if rc:
         return None, False, (info.ref_error if (rc != -2 and info.ref_error) else None)
-    n = info.width * info.height * 3
-    out = np.ctypeslib.as_array((C.c_uint16 * n).from_address(px.value)).reshape(info.height, info.width, 3).copy()
+    n = info.width * info.height * info.ncomp
+    out = np.ctypeslib.as_array((C.c_uint16 * n).from_address(px.value)).reshape(info.height, info.width, info.ncomp).copy()
     lib().oj_free(px)
     return out, bool(isf.value), 0
 
