@@ -87,7 +87,8 @@ struct XtBox {
   uint16_t en = 0;
   std::vector<uint8_t> data;
   uint64_t boxsize = 0;  // payload bytes the box header announces
-  bool complete = false; // all of them arrived
+  uint64_t parsed = 0;   // payload bytes its segments announced so far (m_uqParsedBytes: counted even where the file ends inside one)
+  bool complete = false; // all of them announced: only then the reference's tables know the box (codestream/tables.cpp:1191-1283)
 };
 
 // "Virtual restart intervals" of a scan without restart markers: exact restart points (byte, bits to skip, DC
@@ -149,6 +150,8 @@ public:
   size_t stream_size() const { return size_; }
   HostDecoder *residual() const { return residual_; } // JPEG XT: decoder of the residual codestream
   int hidden_bits() const { return hidden_; }
+  // hidden refinement scans follow the visible ones (with a merging specification that never arrived they refine zero hidden bits)
+  bool has_hidden_scans() const { return hidden_ > 0 || !hidden_src_.empty(); }
   // JPEG XT: the legacy codestream came to its EOI, i.e. the reference merges the residual codestream (else nothing: see decode_t)
   bool residual_merged() const { return eoi_image_; }
 
@@ -222,6 +225,7 @@ private:
   int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
   std::vector<std::pair<size_t, size_t>> seq_spans_; // what the scans of a sequentially walked stream read (RefWalker::spans)
   StreamError residual_error_; // JPEG XT: what is wrong with the residual codestream's header, reported behind the legacy frame's decode
+  bool residual_unspecified_ = false; // a residual codestream and no merging specification: residual_error_ is the transformer's refusal
   bool eoi_frame_ = true, eoi_image_ = true; // the walk's frame / image trailer stood at an EOI (RefWalker::frame_eoi / image_eoi)
   std::vector<const XtBox *> hidden_src_; // this frame's hidden refinement scans in box order (elements of the legacy decoder's boxes_)
   template <class T> int decode_t(T *coef, int threads, const std::function<void(int, int)> &on_rows_done);

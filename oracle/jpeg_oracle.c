@@ -79,9 +79,10 @@ typedef struct {
   const uint8_t *d;
   size_t n, pos;
   int at_eof; /* the last Get() failed */
+  int in_memory; /* the memory stream of a box (bs_skip) */
 } oj_bs;
 
-static void bs_open(oj_bs *s, const uint8_t *d, size_t n) { s->d = d; s->n = n; s->pos = 0; s->at_eof = 0; }
+static void bs_open(oj_bs *s, const uint8_t *d, size_t n) { s->d = d; s->n = n; s->pos = 0; s->at_eof = 0; s->in_memory = 0; }
 static long bs_get(oj_bs *s)
 {
   if (s->pos >= s->n) { s->at_eof = 1; return BS_EOF; }
@@ -102,10 +103,16 @@ static long bs_getword(oj_bs *s)
   return (a << 8) | b;
 }
 static void bs_lastundo(oj_bs *s) { if (!s->at_eof && s->pos > 0) s->pos--; }
-static void bs_skip(oj_bs *s, long n)
+/* ByteStream::SkipBytes.  The file itself (IOStream over a seekable hook, io/iostream.cpp:327-365) caches a seek beyond its end
+ * and the next read finds EOF; the memory stream of a box -- the residual codestream, a refinement scan -- throws
+ * UNEXPECTED_EOF "unexpectedly hit the end of the stream while skipping bytes" (io/bytestream.cpp:231-276,
+ * io/decoderstream.hpp:212-216): returns 1 for that. */
+static int bs_skip(oj_bs *s, long n)
 {
-  if (n <= 0) return;
-  if ((size_t)n > s->n - s->pos) s->pos = s->n; else s->pos += (size_t)n;
+  if (n <= 0) return 0;
+  if ((size_t)n > s->n - s->pos) { s->pos = s->n; return s->in_memory; }
+  s->pos += (size_t)n;
+  return 0;
 }
 
 /* One Huffman table as the DHT marker delivered it (coding/huffmantemplate.cpp:878-905: sixteen counts, then
@@ -127,7 +134,8 @@ typedef struct {
   uint8_t *data;
   size_t len, cap;
   uint64_t boxsize; /* payload bytes the box header announces (LBox - 8, XLBox - 16) */
-  int complete;     /* all of them arrived and the content was parsed */
+  uint64_t parsed;  /* payload bytes its APP11 segments announced so far (m_uqParsedBytes: counted even where the file ends inside) */
+  int complete;     /* all of them arrived and the content was parsed: only then the tables know the box (tables.cpp:1191-1283) */
 } oj_box;
 
 #define OJ_MAX_BOXES 64
@@ -159,6 +167,8 @@ typedef struct {
   int nboxes;
   int walk_all;    /* the caller wants the boxes: walk all scans even without planes */
   int nested;      /* this is the residual codestream of a RESI box */
+  int legacy_eoi_gone; /* nested: the residual codestream ran dry in front of a scan header and the search for one took the legacy
+                        * stream's EOI (see rs_run) */
   int32_t *const *planes; /* NULL: headers only */
 } oj_parser;
 
@@ -359,7 +369,7 @@ static void rs_parse_box_marker(oj_parser *ps, oj_bs *io, long length)
   case 0x4d545258u: case 0x4c43484bu: case 0x66747970u: /* MTRX LCHK ftyp */
     break;
   default:
-    bs_skip(io, blen);
+    { if (bs_skip(io, blen)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     return;
   }
   for (b = 0; b < ps->nboxes; b++)
@@ -373,6 +383,7 @@ static void rs_parse_box_marker(oj_parser *ps, oj_bs *io, long length)
     ps->boxes[b].type = tbox; ps->boxes[b].en = en; ps->boxes[b].boxsize = lbox;
     ps->nboxes++;
   }
+  ps->boxes[b].parsed += (uint64_t)blen; /* boxes/box.cpp:183-184: what the segment announces, not what the stream still had */
   if ((size_t)blen > io->n - io->pos) blen = (long)(io->n - io->pos);
   if (ps->boxes[b].len + (size_t)blen > ps->boxes[b].cap) {
     size_t cap = (ps->boxes[b].len + (size_t)blen) * 2 + 64;
@@ -383,13 +394,13 @@ static void rs_parse_box_marker(oj_parser *ps, oj_bs *io, long length)
   memcpy(ps->boxes[b].data + ps->boxes[b].len, io->d + io->pos, (size_t)blen);
   ps->boxes[b].len += (size_t)blen;
   io->pos += (size_t)blen;
-  if (ps->boxes[b].len > ps->boxes[b].boxsize) rs_throw(ps, RS_MALFORMED_STREAM); /* "more data in the application marker than indicated" */
-  if (ps->boxes[b].len == ps->boxes[b].boxsize) {
+  if (ps->boxes[b].parsed > ps->boxes[b].boxsize) rs_throw(ps, RS_MALFORMED_STREAM); /* "more data in the application marker than indicated" */
+  if (ps->boxes[b].parsed == ps->boxes[b].boxsize) {
     const oj_box *bx = &ps->boxes[b];
     ps->boxes[b].complete = 1;
     if (tbox == 0x66747970u) { /* 'ftyp': FileTypeBox::ParseBoxContent, boxes/filetypebox.cpp:71-120 */
       if (bx->boxsize < 8) rs_throw(ps, RS_MALFORMED_STREAM);
-      if (memcmp(bx->data, "jpxt", 4) != 0) rs_throw(ps, RS_MALFORMED_STREAM); /* "file is not compatible to JPEG XT" */
+      if (bx->len < 4 || memcmp(bx->data, "jpxt", 4) != 0) rs_throw(ps, RS_MALFORMED_STREAM); /* "file is not compatible to JPEG XT" */
       if ((bx->boxsize - 8) & 3) rs_throw(ps, RS_MALFORMED_STREAM);
     }
   }
@@ -440,7 +451,7 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
     size = bs_getword(io);
     if (size == BS_EOF) rs_throw(ps, RS_UNEXPECTED_EOF);
     if (size <= 2) rs_throw(ps, RS_MALFORMED_STREAM);
-    bs_skip(io, size - 2);
+    { if (bs_skip(io, size - 2)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     break;
   }
   case 0xfff8: rs_throw(ps, RS_MALFORMED_STREAM); break; /* LSE outside JPEG LS */
@@ -461,13 +472,13 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
           if ((unit & 0xff) > 2) rs_throw(ps, RS_MALFORMED_STREAM); /* UBYTE unit > Centimeter; EOF reads as 0xff */
           bs_getword(io); bs_getword(io);
           l -= 2 + 5 + 2 + 1 + 2 + 2;
-          if (l > 0) bs_skip(io, l);
+          if (l > 0) { if (bs_skip(io, l)) rs_throw(ps, RS_UNEXPECTED_EOF); }
           break;
         }
       }
     }
     if (len <= 2) rs_throw(ps, RS_MALFORMED_STREAM);
-    bs_skip(io, len - 2);
+    { if (bs_skip(io, len - 2)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     break;
   }
   case 0xffe1: { /* APP1: Exif header checked (marker/exifmarker.cpp:117-128) */
@@ -483,13 +494,13 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
           long l = (len + 4 + 2) & 0xffff;
           if (l < 2 + 4 + 2 + 2 + 2 + 4 + 2 + 4) rs_throw(ps, RS_MALFORMED_STREAM);
           l -= 2 + 4 + 2;
-          if (l > 0) bs_skip(io, l);
+          if (l > 0) { if (bs_skip(io, l)) rs_throw(ps, RS_UNEXPECTED_EOF); }
           break;
         }
       }
     }
     if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
-    bs_skip(io, len - 2);
+    { if (bs_skip(io, len - 2)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     break;
   }
   case 0xffeb: { /* APP11: JPEG XT boxes */
@@ -505,7 +516,7 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
       }
     }
     if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
-    bs_skip(io, len - 2);
+    { if (bs_skip(io, len - 2)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     break;
   }
   case 0xffee: { /* APP14: Adobe (marker/adobemarker.cpp:96-117), only at its exact size */
@@ -528,7 +539,7 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
       }
     }
     if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
-    bs_skip(io, len - 2);
+    { if (bs_skip(io, len - 2)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     break;
   }
   case 0xffdf: rs_throw(ps, RS_MALFORMED_STREAM); break; /* EXP outside a hierarchical process (size / content errors are MALFORMED as well) */
@@ -537,7 +548,7 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
     bs_getword(io);
     len = bs_getword(io);
     if (len < 2) rs_throw(ps, RS_MALFORMED_STREAM);
-    bs_skip(io, len - 2);
+    { if (bs_skip(io, len - 2)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     break;
   }
   case 0xffc0: case 0xffc1: case 0xffc2: case 0xffc3: case 0xffc5: case 0xffc6: case 0xffc7: case 0xffc9:
@@ -556,7 +567,7 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
       size = bs_getword(io);
       if (size == BS_EOF) rs_throw(ps, RS_UNEXPECTED_EOF);
       if (size <= 2) rs_throw(ps, RS_MALFORMED_STREAM);
-      bs_skip(io, size - 2);
+      { if (bs_skip(io, size - 2)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     } else {
       long dt;
       RS_WARN(ps); /* "found invalid marker, probably a marker size is out of range" (covers EOF = -1 as well) */
@@ -1168,6 +1179,10 @@ static int rs_scan_for_scan_header(oj_parser *ps, oj_bs *io)
  * 1: another scan follows, 0: the frame is over. */
 static int rs_frame_trailer(oj_parser *ps, oj_bs *io)
 {
+  /* The residual codestream at its end: Image::InputStreamOf (codestream/image.cpp:978-996) hands out the LEGACY stream
+   * instead, and that one stands at its EOI (it stays in the buffer while the residual codestream is read, image.cpp:1416-1431).
+   * A residual frame whose data simply ends is therefore at "its" EOI, and its hidden refinement scans are read. */
+  if (ps->nested && !ps->legacy_eoi_gone && bs_peekword(io) == BS_EOF) { ps->eoi_frame = 1; return 0; }
   for (;;) {
     long marker = bs_peekword(io);
     switch (marker) {
@@ -1200,11 +1215,12 @@ static int rs_frame_trailer(oj_parser *ps, oj_bs *io)
 /* Image::ParseTrailer, codestream/image.cpp:1408-1497. 1: something that is not the end follows. */
 static int rs_image_trailer(oj_parser *ps, oj_bs *io)
 {
-  for (;;) {
+  int first;
+  for (first = 1;; first = 0) {
     long marker = bs_peekword(io);
     if (marker == 0xffd9) { ps->eoi_image = 1; bs_getword(io); return 0; }
     else if (marker == 0xffff) bs_get(io);
-    else if (marker == BS_EOF) { RS_WARN(ps); return 0; }
+    else if (marker == BS_EOF) { if (!(ps->nested && first && !ps->legacy_eoi_gone)) RS_WARN(ps); return 0; } /* (image.cpp:1320-1323: the residual codestream may simply end) */
     else if (marker < 0xff00) {
       RS_WARN(ps);
       bs_get(io);
@@ -1228,16 +1244,25 @@ static void rs_run(oj_parser *ps, oj_bs *io)
     rs_parse_frame_header(ps, io);
     for (;;) { /* scans: Frame::StartParseScan, marker/frame.cpp:796-861 */
       while (rs_tables_incremental(ps, io)) {}
+      /* (a residual codestream that is through here: the search for a scan header works on the legacy stream -- InputStreamOf,
+       * see rs_frame_trailer -- and takes its EOI away: one warning like at the end of this stream, but the trailers that
+       * follow find the end of the file, not an EOI) */
+      if (ps->nested && bs_peekword(io) == BS_EOF) ps->legacy_eoi_gone = 1;
       if (rs_scan_for_scan_header(ps, io)) {
         rs_scan(ps, io, 0);
         if (!ps->planes && !ps->walk_all) return; /* header-only walk stops behind the first scan header */
         if (rs_frame_trailer(ps, io)) continue;
         if (!rs_image_trailer(ps, io)) return;
+        /* The residual codestream: Image::ParseResidualStream (codestream/image.cpp:1318-1331) hands the SAME frame back when
+         * its image trailer finds a marker (the parent's m_pCurrent, m_bReceivedFrameHeader set): no frame header is read,
+         * the frame goes on looking for scans. */
+        if (ps->nested) continue;
         break; /* next frame: a second frame header throws */
       } else {
         /* no scan: end of frame (interface/jpeg.cpp:305-317) */
         if (rs_frame_trailer(ps, io)) continue;
         if (!rs_image_trailer(ps, io)) return;
+        if (ps->nested) continue;
         rs_throw(ps, RS_INVALID_PARAMETER); /* the reference dereferences a NULL frame here */
       }
     }
@@ -1282,7 +1307,7 @@ static int spec_without_residual(const oj_box *spec, const oj_box *boxes, int nb
     j += l;
   }
   for (b = 0; b < nboxes; b++)
-    if (boxes[b].type == BOXID_('M', 'T', 'R', 'X') && boxes[b].len >= 1) have_mtx[boxes[b].data[0] >> 4] = 1;
+    if (boxes[b].type == BOXID_('M', 'T', 'R', 'X') && boxes[b].complete && boxes[b].len >= 1) have_mtx[boxes[b].data[0] >> 4] = 1;
   if (f->ncomp == 1 && ltrafo != 255) return RS_MALFORMED_STREAM; /* "Base transformation box exists even though the number of components is one" */
   if (ltrafo == 0 || ltrafo == 3 || ltrafo == 4) return RS_MALFORMED_STREAM; /* Zero, JPEG_LS, RCT: "Found an invalid base transformation" */
   /* a free-form transformation nobody defined: "the base transformation specified in the codestream does not exist"
@@ -1309,6 +1334,7 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
     ps->boxes = own; ps->nboxes = 0;
   }
   bs_open(&io, ps->data, ps->len);
+  io.in_memory = ps->nested;
   if (setjmp(ps->jb) == 0) rs_run(ps, &io);
   else thrown = 1;
   if (!thrown) {
@@ -1323,10 +1349,11 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
       const oj_box *spec = NULL, *resi = NULL;
       int b;
       for (b = 0; b < ps->nboxes; b++) {
+        if (!ps->boxes[b].complete) continue; /* a box that never filled up stays in the list unparsed: nobody looks at it */
         if (ps->boxes[b].type == BOXID_('S', 'P', 'E', 'C')) spec = &ps->boxes[b];
         if (ps->boxes[b].type == BOXID_('R', 'E', 'S', 'I')) resi = &ps->boxes[b];
       }
-      if (spec && !resi && spec->complete) {
+      if (spec && !resi) {
         const int v = spec_without_residual(spec, ps->boxes, ps->nboxes, f);
         /* (a header-only walk has not seen the whole file: it takes the transformation, the verdict waits for the full walk) */
         if (v == 1) { if (planes) { thrown = 1; ps->unsupported = 1; ps->err = RS_NOT_IMPLEMENTED; } }
@@ -1354,21 +1381,37 @@ int oj_read_info(const uint8_t *data, size_t len, oj_info *info)
   return walk(&ps, NULL);
 }
 
-int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
-                           int32_t *const planes[OJ_MAX_COMP])
+static int decode_hidden_scans(oj_parser *ps, const oj_box *boxes, int nboxes, uint32_t type, int32_t *const planes[OJ_MAX_COMP]);
+
+static int decode_coefficients_as(const uint8_t *data, size_t len, const oj_info *info,
+                                  int32_t *const planes[OJ_MAX_COMP], int nested)
 {
   oj_parser ps;
   oj_info tmp;
+  oj_box *boxes = NULL;
   oj_info *out = (oj_info *)info; /* the scan state (per-component tables, components seen, error code) is reported back */
   int c, rc;
   memset(&ps, 0, sizeof(ps));
   memset(&tmp, 0, sizeof(tmp));
-  ps.data = data; ps.len = len; ps.info = &tmp;
+  ps.data = data; ps.len = len; ps.info = &tmp; ps.nested = nested;
   ps.known_height = info->dnl ? info->height : 0;
   for (c = 0; c < OJ_MAX_COMP; c++) ps.known_bh[c] = info->bh[c];
   for (c = 0; c < info->ncomp; c++)
     memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
+  if (!nested) { /* the boxes outlive the walk: refinement boxes are read behind the frame's last visible scan */
+    boxes = (oj_box *)calloc(OJ_MAX_BOXES, sizeof(oj_box));
+    if (!boxes) return OJ_ERR_NOMEM;
+    ps.boxes = boxes;
+  }
   rc = walk(&ps, planes);
+  /* Frame::ParseTrailer, marker/frame.cpp:1063-1070: at the EOI the frame turns to its FINE boxes whether or not a merging
+   * specification says how many bits hide in them -- with none (a plain JPEG, or a specification that never arrived) they
+   * refine the bits the visible scans left as they are */
+  if (!rc && boxes && ps.eoi_frame) {
+    rc = decode_hidden_scans(&ps, boxes, ps.nboxes, BOXID_('F', 'I', 'N', 'E'), planes);
+    if (rc) tmp.ref_error = ps.err;
+  }
+  if (boxes) { int b; for (b = 0; b < ps.nboxes; b++) free(boxes[b].data); free(boxes); }
   memcpy(out->cquant, tmp.cquant, sizeof(tmp.cquant));
   memcpy(out->comp_seen, tmp.comp_seen, sizeof(tmp.comp_seen));
   out->scan_state_valid = tmp.scan_state_valid;
@@ -1377,6 +1420,20 @@ int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
   if (tmp.dnl) memcpy(out->rows, tmp.rows, sizeof(tmp.rows));
   if (!rc) out->ycbcr = tmp.ycbcr; /* the full walk has seen every box */
   return rc;
+}
+
+int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
+                           int32_t *const planes[OJ_MAX_COMP])
+{
+  return decode_coefficients_as(data, len, info, planes, 0);
+}
+
+/* ... of a JPEG XT residual codestream (the payload of the RESI box), walked the way the reference walks it from inside the
+ * legacy image's trailer: Image::ParseResidualStream, codestream/image.cpp:1264-1334 (see rs_run). */
+int oj_decode_coefficients_residual(const uint8_t *data, size_t len, const oj_info *info,
+                                    int32_t *const planes[OJ_MAX_COMP])
+{
+  return decode_coefficients_as(data, len, info, planes, 1);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -2347,10 +2404,11 @@ static int decode_hidden_scans(oj_parser *ps, const oj_box *boxes, int nboxes, u
     const oj_box *bx = NULL;
     oj_bs bio;
     int b;
-    for (b = 0; b < nboxes; b++) if (boxes[b].type == type && boxes[b].en == en) bx = &boxes[b];
+    for (b = 0; b < nboxes; b++) if (boxes[b].type == type && boxes[b].en == en && boxes[b].complete) bx = &boxes[b]; /* Tables::RefinementDataOf, tables.cpp:872-891 */
     if (!bx) return OJ_OK;
     /* Frame::StartParseScan, marker/frame.cpp:805-822: tables, then the scan header, from the box's own stream */
     bs_open(&bio, bx->data, bx->len);
+    bio.in_memory = 1;
     if (setjmp(ps->jb)) return rs_result(ps, 1);
     while (rs_tables_incremental(ps, &bio)) {}
     if (rs_scan_for_scan_header(ps, &bio)) rs_scan(ps, &bio, 1);
@@ -2516,8 +2574,43 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   rc = walk(&ps, NULL);
   if (rc) { free_boxes(boxes, ps.nboxes); return rc; }
   for (b = 0; b < ps.nboxes; b++) {
+    if (!boxes[b].complete) continue; /* (tables.cpp:1191-1225: the tables learn of a box when its last byte was announced) */
     if (boxes[b].type == BOXID('S', 'P', 'E', 'C')) spec = &boxes[b];
     if (boxes[b].type == BOXID('R', 'E', 'S', 'I')) resi = &boxes[b];
+  }
+  if (resi && !spec && info->ncomp <= 4) {
+    /* A residual codestream and no merging specification (its APP11 segment damaged, or its box never complete): the command
+     * line reads the whole file first (cmd/reconstruct.cpp:119-121) -- whatever stops either codestream is reported -- and the
+     * first request for pixels builds the colour transformer: no specification, so the R transformation is "zero"
+     * (tables.cpp:2070-2071), and with a residual frame no transformer exists for that (colortransformerfactory.cpp:277-291):
+     * INVALID_PARAMETER "The combination of L and R transformation is non-standard and not supported".  Without an EOI behind
+     * the legacy codestream the residual frame never comes to be (image.cpp:1416-1431): a plain picture, not this function's. */
+    oj_parser ls, rs;
+    oj_info ltmp, rtmp;
+    memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
+    ls.data = data; ls.len = len; ls.info = &ltmp;
+    for (c = 0; c < info->ncomp; c++) {
+      planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
+      if (!planes[c]) { rc = OJ_ERR_NOMEM; goto out; }
+    }
+    rc = walk(&ls, planes);
+    if (rc) { info->ref_error = ltmp.ref_error; goto out; }
+    if (ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) { info->ref_error = ls.err; goto out; } }
+    if (!ls.eoi_image) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+    rc = oj_read_info(resi->data, resi->len, &rinfo);
+    if (!rc && (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp)) { rinfo.ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; }
+    if (rc) { info->ref_error = rinfo.ref_error; goto out; }
+    rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.nested = 1;
+    for (c = 0; c < rinfo.ncomp; c++) {
+      rplanes[c] = (int32_t *)calloc((size_t)rinfo.bw[c] * rinfo.bh[c] * 64, sizeof(int32_t));
+      if (!rplanes[c]) { rc = OJ_ERR_NOMEM; goto out; }
+    }
+    rc = walk(&rs, rplanes);
+    if (rc) { info->ref_error = rtmp.ref_error; goto out; }
+    if (rs.eoi_frame) { rc = decode_hidden_scans(&rs, boxes, ps.nboxes, BOXID('R', 'F', 'I', 'N'), rplanes); if (rc) { info->ref_error = rs.err; goto out; } }
+    info->ref_error = RS_INVALID_PARAMETER;
+    rc = OJ_ERR_MALFORMED;
+    goto out;
   }
   if (!spec || !resi || (info->ncomp != 3 && info->ncomp != 1) || info->precision != 8) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   nc = info->ncomp; /* three components, or one: a grey scale picture with a residual (`jpeg -r ... in.pgm`) */
@@ -2553,6 +2646,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     j += l;
   }
   for (b = 0; b < ps.nboxes; b++) {
+    if (!boxes[b].complete) continue;
     rc = register_box(boxes[b].type, boxes[b].data, boxes[b].len, nlt, mtx, have_mtx);
     if (rc) goto out;
   }

@@ -86,6 +86,9 @@ int oj_read_info(const uint8_t *data, size_t len, oj_info *info);
  * they are zero-initialised here (coding/blockrow.cpp:77-87).  Reports info->rows[] (and the scan state) back. */
 int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
                            int32_t *const planes[OJ_MAX_COMP]);
+/* the same for the payload of a JPEG XT RESI box: the residual codestream, walked as the legacy image's trailer walks it */
+int oj_decode_coefficients_residual(const uint8_t *data, size_t len, const oj_info *info,
+                                    int32_t *const planes[OJ_MAX_COMP]);
 
 /* Dequantise + inverse DCT of one block: dct/idct.cpp:226-339 with preshift = 4.
  * out = sample * 16, not clamped.  coef may be NULL (-> all zero, idct.cpp:336-338). */

@@ -49,6 +49,7 @@ def lib():
         L = C.CDLL(LIB)
         L.oj_read_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo)]
         L.oj_decode_coefficients.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
+        L.oj_decode_coefficients_residual.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
         L.oj_idct_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.oj_idct_block.restype = None
         L.oj_idct_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -103,6 +104,31 @@ def decode_coefficients(data: bytes, info: OjInfo | None = None):
     rc = lib().oj_decode_coefficients(data, len(data), C.byref(info), ptrs)
     if rc:
         raise ValueError(f"oracle: oj_decode_coefficients failed rc={rc}")
+    return info, planes
+
+
+def xt_box_payload(data: bytes, box_type: bytes) -> bytes | None:
+    """The payload of the first JPEG XT box of this type in front of the first scan, its APP11 segments put together (boxes/box.cpp:93-200;
+    well-formed framing assumed: for tests that damage what is INSIDE a box)."""
+    out, i, found = b"", 2, False
+    while i + 4 <= len(data) and data[i] == 0xFF and data[i + 1] != 0xDA:
+        ln = (data[i + 2] << 8) | data[i + 3]
+        if data[i + 1] == 0xEB and data[i + 4:i + 6] == b"JP" and data[i + 16:i + 20] == box_type:
+            out += data[i + 20:i + 2 + ln]
+            found = True
+        i += 2 + ln
+    return out if found else None
+
+
+def decode_residual_coefficients(data: bytes):
+    """JPEG XT: -> (info, planes) of the residual codestream in the file's RESI box, walked as the reference walks it."""
+    resi = xt_box_payload(data, b"RESI")
+    info = read_info(resi)
+    planes = [np.zeros((info.bh[c], info.bw[c], 64), np.int32) for c in range(info.ncomp)]
+    ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - info.ncomp))
+    rc = lib().oj_decode_coefficients_residual(resi, len(resi), C.byref(info), ptrs)
+    if rc:
+        raise ValueError(f"oracle: oj_decode_coefficients_residual failed rc={rc}")
     return info, planes
 
 
