@@ -225,6 +225,12 @@ private:
   int add_hidden_scans(uint32_t type, const std::vector<XtBox> &boxes, int hidden);
   std::vector<std::pair<size_t, size_t>> seq_spans_; // what the scans of a sequentially walked stream read (RefWalker::spans)
   StreamError residual_error_; // JPEG XT: what is wrong with the residual codestream's header, reported behind the legacy frame's decode
+  // JPEG XT: what the colour transformer refuses when the first request builds it (tables and transformations that do not exist
+  // or do not fit).  The reference has read the whole file by then: what stops either codestream comes first (late_verdict)
+  StreamError late_error_;
+  bool late_residual_only_ = false; // ... about a table of the residual's side: not looked up unless there is a residual frame to merge
+  bool plain_only_ = false;         // (the verdict's decoder of the legacy codestream alone: the boxes are not interpreted)
+  int late_verdict();
   bool residual_unspecified_ = false; // a residual codestream and no merging specification: residual_error_ is the transformer's refusal
   bool eoi_frame_ = true, eoi_image_ = true; // the walk's frame / image trailer stood at an EOI (RefWalker::frame_eoi / image_eoi)
   std::vector<const XtBox *> hidden_src_; // this frame's hidden refinement scans in box order (elements of the legacy decoder's boxes_)

@@ -2544,6 +2544,46 @@ static void xt_ctx_free(struct oj_xt_ctx *ctx)
   free(ctx);
 }
 
+/* The reference's command line reads the whole file before it asks for pixels (cmd/reconstruct.cpp:119-121): whatever stops the
+ * legacy codestream, its hidden scans, the residual codestream's header (looked at behind the legacy EOI, image.cpp:1416-1431)
+ * or the residual scans is reported before anything the colour transformer finds when the first request builds it
+ * (Tables::ColorTrafoOf, codestream/tables.cpp:1517-1555).  -> 0, or the error with the reference's code in *ref_error;
+ * *eoi_image: the legacy codestream came to its EOI, i.e. there is a residual frame for the transformer to merge. */
+static int xt_codestreams_verdict(const uint8_t *data, size_t len, const oj_info *info, const oj_box *boxes, int nboxes,
+                                  const oj_box *resi, int hidden_l, int hidden_r, int *ref_error, int *eoi_image)
+{
+  oj_parser ls, rs;
+  oj_info ltmp, rtmp, rinfo;
+  int32_t *planes[OJ_MAX_COMP] = {0, 0, 0, 0}, *rplanes[OJ_MAX_COMP] = {0, 0, 0, 0};
+  int c, rc;
+  memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
+  *ref_error = 0; *eoi_image = 0;
+  ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
+  for (c = 0; c < info->ncomp; c++) {
+    planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
+    if (!planes[c]) { rc = OJ_ERR_NOMEM; goto done; }
+  }
+  rc = walk(&ls, planes);
+  if (rc) { *ref_error = ltmp.ref_error; goto done; }
+  if (ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) { *ref_error = ls.err; goto done; } }
+  *eoi_image = ls.eoi_image;
+  if (!ls.eoi_image || !resi) goto done;
+  rc = oj_read_info(resi->data, resi->len, &rinfo);
+  if (!rc && (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp)) { rinfo.ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; }
+  if (rc) { *ref_error = rinfo.ref_error; goto done; }
+  rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r; rs.nested = 1;
+  for (c = 0; c < rinfo.ncomp; c++) {
+    rplanes[c] = (int32_t *)calloc((size_t)rinfo.bw[c] * rinfo.bh[c] * 64, sizeof(int32_t));
+    if (!rplanes[c]) { rc = OJ_ERR_NOMEM; goto done; }
+  }
+  rc = walk(&rs, rplanes);
+  if (rc) { *ref_error = rtmp.ref_error; goto done; }
+  if (rs.eoi_frame) { rc = decode_hidden_scans(&rs, boxes, nboxes, BOXID('R', 'F', 'I', 'N'), rplanes); if (rc) *ref_error = rs.err; }
+done:
+  for (c = 0; c < OJ_MAX_COMP; c++) { free(planes[c]); free(rplanes[c]); }
+  return rc;
+}
+
 /* pixels != NULL: the whole picture (oj_decode_xt); rq_out != NULL: a requester that keeps what was decoded (oj_xt_requester_new) */
 /* disable_to_rgb: a request without colour transformation (cmd/reconstruct.cpp -c -> rr_bColorTrafo false ->
  * ColorTransformerFactory::BuildColorTransformer(.., disabletorgb)): the standard YCbCr L transformation becomes the identity,
@@ -2562,7 +2602,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   int hidden_l = 0, hidden_r = 0; /* RSPC: bits of the legacy / residual coefficients in hidden refinement scans */
   const oj_box *spec = NULL, *resi = NULL;
   int ltrafo = 255, rtrafo = 255, ctrafo = 255, lidx[4] = {255, 255, 255, 255}, qidx[4] = {255, 255, 255, 255}, r2idx[4] = {255, 255, 255, 255};
-  int ocon = -1, rdct = 0, b, c, rc, nc = 3;
+  int ocon = -1, rdct = 0, b, c, rc, nc = 3, late_residual_only = 0;
   size_t j;
   static const int64_t std_ycc[9] = {FIX13(1.0), FIX13(0.0), FIX13(1.40200), FIX13(1.0), -FIX13(0.3441362861), -FIX13(0.7141362859),
                                      FIX13(1.0), FIX13(1.772), FIX13(0.0)};
@@ -2585,29 +2625,10 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
      * (tables.cpp:2070-2071), and with a residual frame no transformer exists for that (colortransformerfactory.cpp:277-291):
      * INVALID_PARAMETER "The combination of L and R transformation is non-standard and not supported".  Without an EOI behind
      * the legacy codestream the residual frame never comes to be (image.cpp:1416-1431): a plain picture, not this function's. */
-    oj_parser ls, rs;
-    oj_info ltmp, rtmp;
-    memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
-    ls.data = data; ls.len = len; ls.info = &ltmp;
-    for (c = 0; c < info->ncomp; c++) {
-      planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
-      if (!planes[c]) { rc = OJ_ERR_NOMEM; goto out; }
-    }
-    rc = walk(&ls, planes);
-    if (rc) { info->ref_error = ltmp.ref_error; goto out; }
-    if (ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) { info->ref_error = ls.err; goto out; } }
-    if (!ls.eoi_image) { rc = OJ_ERR_UNSUPPORTED; goto out; }
-    rc = oj_read_info(resi->data, resi->len, &rinfo);
-    if (!rc && (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp)) { rinfo.ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; }
-    if (rc) { info->ref_error = rinfo.ref_error; goto out; }
-    rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.nested = 1;
-    for (c = 0; c < rinfo.ncomp; c++) {
-      rplanes[c] = (int32_t *)calloc((size_t)rinfo.bw[c] * rinfo.bh[c] * 64, sizeof(int32_t));
-      if (!rplanes[c]) { rc = OJ_ERR_NOMEM; goto out; }
-    }
-    rc = walk(&rs, rplanes);
-    if (rc) { info->ref_error = rtmp.ref_error; goto out; }
-    if (rs.eoi_frame) { rc = decode_hidden_scans(&rs, boxes, ps.nboxes, BOXID('R', 'F', 'I', 'N'), rplanes); if (rc) { info->ref_error = rs.err; goto out; } }
+    int verr = 0, eoi = 0;
+    rc = xt_codestreams_verdict(data, len, info, boxes, ps.nboxes, resi, 0, 0, &verr, &eoi);
+    if (rc) { info->ref_error = verr; goto out; }
+    if (!eoi) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     info->ref_error = RS_INVALID_PARAMETER;
     rc = OJ_ERR_MALFORMED;
     goto out;
@@ -2654,7 +2675,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   if (nc == 1) {
     /* one component: the L and C transformation boxes must not exist (tables.cpp:2003-2005, 2079-2081), everything is the identity;
      * an R transformation other than the identity has no transformer (BuildIntegerTransformationSimple, colortransformerfactory.cpp:681-757) */
-    if (ltrafo != 255 || ctrafo != 255) { info->ref_error = -1038; rc = OJ_ERR_MALFORMED; goto out; }
+    if (ltrafo != 255 || ctrafo != 255) { info->ref_error = -1038; rc = OJ_ERR_MALFORMED; goto late; }
     if (rtrafo != 255 && rtrafo != 1) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     ltrafo = rtrafo = 1;
   }
@@ -2715,20 +2736,20 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     memset(&id1, 0, sizeof(id1)); id1.kind = 2; id1.type = 2; id1.e = 1;
     memset(&id0, 0, sizeof(id0)); id0.kind = 2; id0.type = 2; id0.e = 0;
     t = lidx[c] == 255 ? &id1 : &nlt[lidx[c]];
-    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; } /* OBJECT_DOESNT_EXIST "the L lookup table specified in the codestream does not exist" */
+    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto late; } /* OBJECT_DOESNT_EXIST "the L lookup table specified in the codestream does not exist" */
     owned[c] = scaled_table(t, 8 + hidden_l, outbits, 0, 0, &rc);
-    if (!owned[c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
+    if (!owned[c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; if (info->ref_error) goto late; goto out; }
     xt.ltable[c] = owned[c];
     if (pr > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     t = qidx[c] == 255 ? &id0 : &nlt[qidx[c]];
-    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; }
+    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; }
     owned[3 + c] = scaled_table(t, pr, outbits, 4, 4, &rc);
-    if (!owned[3 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
+    if (!owned[3 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; late_residual_only = 1; if (info->ref_error) goto late; goto out; }
     xt.qlut[c] = owned[3 + c];
     t = r2idx[c] == 255 ? &id0 : &nlt[r2idx[c]];
-    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; goto out; }
+    if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; }
     owned[6 + c] = scaled_table(t, outbits, outbits, 4, 0, &rc);
-    if (!owned[6 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; goto out; }
+    if (!owned[6 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; late_residual_only = 1; if (info->ref_error) goto late; goto out; }
     xt.r2lut[c] = owned[6 + c];
   }
   /* the residual codestream is an ordinary codestream of its own (codestream/image.cpp:1264-1300) */
@@ -2810,6 +2831,20 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   if (!*pixels) { rc = OJ_ERR_NOMEM; goto out; }
   rc = reconstruct_ex(info, planes, NULL, *pixels, xt.ltrafo_ycbcr, &xt);
   if (rc) { free(*pixels); *pixels = NULL; }
+  goto out;
+late:
+  /* What the colour transformer refuses when the first request builds it: the whole file has been read by then, and what
+   * stopped either codestream was reported instead (xt_codestreams_verdict).  A table of the residual's side is looked up only
+   * when there is a residual frame to merge -- without an EOI behind the legacy codestream the picture comes out without
+   * (not followed here). */
+  {
+    const int lrc = rc, lerr = info->ref_error;
+    int verr = 0, eoi = 0;
+    rc = xt_codestreams_verdict(data, len, info, boxes, ps.nboxes, resi, hidden_l, hidden_r, &verr, &eoi);
+    if (rc) info->ref_error = verr;
+    else if (!eoi && late_residual_only) { rc = OJ_ERR_UNSUPPORTED; info->ref_error = 0; }
+    else { rc = lrc; info->ref_error = lerr; }
+  }
 out:
   for (c = 0; c < OJ_MAX_COMP; c++) { free(planes[c]); free(rplanes[c]); }
   for (c = 0; c < 16; c++) free(nlt[c].lut);

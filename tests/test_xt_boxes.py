@@ -279,6 +279,54 @@ def test_residual_planes_of_a_scan_that_ends_in_a_marker(oracle):
     assert n >= 8
 
 
+# ------------------------------------------------------------------------------------------------ the transformer's refusals
+# tests/golden/xt_int8 holds three streams whose merging specification names tables that do not exist or do not fit: the colour
+# transformer refuses them when the first request builds it (Tables::ColorTrafoOf, codestream/tables.cpp:1517-1555).  The command
+# line has read the whole file by then (cmd/reconstruct.cpp:119-121): what stops either codestream is reported instead, and a
+# table of the residual's side is not even looked up when the legacy codestream has no EOI (no residual frame to merge).
+LATE = {"a_q_table_missing": -1031, "a_q_is_tone_box": -1031, "a_r2_linear_negative_slope": -1024}
+
+
+def late_cases(name):
+    """kind -> (stream, the reference's answer; 0: a picture -- the legacy one through the L tables)"""
+    with open(os.path.join(GOLDEN_DIR, "xt_int8", name + ".jpg"), "rb") as f:
+        data = f.read()
+    es = damage.entropy_start(data)
+    out = {"intact": (data, LATE[name])}
+    b = bytearray(data)
+    b[es + 100:es + 104] = bytes(4)
+    b[es + 140:es + 142] = b"\xff\xc4"  # a DHT marker in the legacy scan: "undefined Huffman table type"
+    out["legacy_scan"] = (bytes(b), -1038)
+    off, ln = segments(data, b"RESI")[-1]
+    b = bytearray(data)
+    b[off + ln - 120:off + ln - 114] = b"\x55" * 6  # the residual scan runs out of sync
+    out["residual_scan"] = (bytes(b), -1038)
+    out["no_eoi"] = (data[:-2], 0)
+    out["cut"] = (data[:es + 150], 0)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(LATE))
+def test_transformer_refusals_come_behind_both_codestreams(oracle, name):
+    d = api.Decoder(None)
+    for kind, (blob, expect) in late_cases(name).items():
+        if oracle.have_reference():
+            _, rerr = reference_status(oracle, blob, False)
+            assert rerr == expect, (name, kind, rerr)
+        _, _, oerr = oracle.decode_xt_status(blob)
+        try:
+            d.read(blob)
+            perr = 0
+        except api.MijpegError as e:
+            perr = e.code
+        if expect == 0:
+            # (the legacy picture through the L tables alone: outside the restatement, declined by the product)
+            assert oerr is None and perr == -1034, (name, kind, oerr, perr)
+        else:
+            assert oerr == expect and perr == expect, (name, kind, oerr, perr)
+    d.close()
+
+
 # ------------------------------------------------------------------------------------------------ product, pixels
 @pytest.mark.gpu
 def test_gpu_pixels_behind_a_damaged_residual_scan(oracle):
