@@ -329,6 +329,89 @@ static void rs_parse_dht(oj_parser *ps, oj_bs *io)
 
 /* Box::ParseBoxMarker, boxes/box.cpp:93-200: the segment framing only (en, z, LBox, TBox [, XLBox], payload); what the
  * boxes mean is checked where they are used.  `length` is the marker length, CI already removed from the stream. */
+/* The FORM of a merging specification, checked where its box completes: SuperBox::ParseBoxContent (boxes/superbox.cpp:93-206)
+ * frames the sub-boxes, MergingSpecBox::CreateBox / AcknowledgeBox (boxes/mergingspecbox.cpp:108-256) allow one box of each
+ * kind and one curve / matrix per index, each sub-box parses its own payload (outputconversionbox.cpp:93-127,
+ * colortrafobox.cpp:62-79, nonlineartrafobox.cpp:62-80, dctbox.cpp:61-90, refinementspecbox.cpp:58-82,
+ * parametrictonemappingbox.cpp:85-149, lineartransformationbox.cpp:62-99).  announced: the box length; have: the bytes that
+ * arrived (fewer when the file ends inside the box: reads beyond them find EOF). */
+#define SPEC_ID(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
+static void rs_check_merging_spec(oj_parser *ps, const uint8_t *d, size_t have, uint64_t announced)
+{
+  static const uint32_t once[16] = {
+    SPEC_ID('R', 'S', 'P', 'C'), SPEC_ID('O', 'C', 'O', 'N'), SPEC_ID('L', 'D', 'C', 'T'), SPEC_ID('R', 'D', 'C', 'T'),
+    SPEC_ID('L', 'T', 'R', 'F'), SPEC_ID('C', 'T', 'R', 'F'), SPEC_ID('R', 'T', 'R', 'F'), SPEC_ID('D', 'T', 'R', 'F'),
+    SPEC_ID('S', 'T', 'R', 'F'), SPEC_ID('L', 'P', 'T', 'S'), SPEC_ID('Q', 'P', 'T', 'S'), SPEC_ID('C', 'P', 'T', 'S'),
+    SPEC_ID('R', 'P', 'T', 'S'), SPEC_ID('S', 'P', 'T', 'S'), SPEC_ID('P', 'P', 'T', 'S'), SPEC_ID('D', 'P', 'T', 'S')};
+  int seen[16] = {0}, curve[16] = {0}, matrix[16] = {0};
+  uint64_t j = 0;
+  while (j < announced) {
+    const uint64_t left = announced - j;
+    uint64_t xl, overhead = 8, len;
+    uint32_t lbox, tbox;
+    const uint8_t *pl;
+    int k;
+#define SPEC_BYTE(n) ((j + overhead + (uint64_t)(n)) < have ? (long)pl[n] : -1L) /* ByteStream::Get at the end: EOF */
+    if (left < 8) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (j + 8 > have) rs_throw(ps, RS_UNEXPECTED_EOF);
+    lbox = ((uint32_t)d[j] << 24) | ((uint32_t)d[j + 1] << 16) | ((uint32_t)d[j + 2] << 8) | d[j + 3];
+    tbox = ((uint32_t)d[j + 4] << 24) | ((uint32_t)d[j + 5] << 16) | ((uint32_t)d[j + 6] << 8) | d[j + 7];
+    xl = lbox;
+    if (lbox == 1) {
+      if (left < 16) rs_throw(ps, RS_MALFORMED_STREAM);
+      if (j + 16 > have) rs_throw(ps, RS_UNEXPECTED_EOF);
+      for (xl = 0, k = 0; k < 8; k++) xl = (xl << 8) | d[j + 8 + k];
+      if (xl < 16) rs_throw(ps, RS_MALFORMED_STREAM);
+      overhead = 16;
+    } else if (lbox < 8) rs_throw(ps, RS_MALFORMED_STREAM); /* zero: "found a box size of zero within a superbox" */
+    if (left < xl) rs_throw(ps, RS_MALFORMED_STREAM);
+    len = xl - overhead;
+    pl = d + j + overhead;
+    for (k = 0; k < 16; k++)
+      if (tbox == once[k]) { if (seen[k]) rs_throw(ps, RS_MALFORMED_STREAM); seen[k] = 1; } /* "found a double ... box" */
+    if (tbox == SPEC_ID('R', 'S', 'P', 'C')) {
+      const long v = (len == 1) ? SPEC_BYTE(0) : 0;
+      if (len != 1 || (v >> 4) > 4 || (v & 15) > 4) rs_throw(ps, RS_MALFORMED_STREAM);
+    } else if (tbox == SPEC_ID('O', 'C', 'O', 'N')) {
+      long v;
+      if (len != 3) rs_throw(ps, RS_MALFORMED_STREAM);
+      v = SPEC_BYTE(0) & 0xff;
+      if ((v >> 4) > 8) rs_throw(ps, RS_MALFORMED_STREAM); /* "bit depths cannot be larger than 16" */
+      if (!(v & 1) && (SPEC_BYTE(1) != 0 || SPEC_BYTE(2) != 0)) rs_throw(ps, RS_MALFORMED_STREAM); /* "output conversion is disabled, but lookup information is not zero" */
+    } else if (tbox == SPEC_ID('L', 'D', 'C', 'T') || tbox == SPEC_ID('R', 'D', 'C', 'T')) {
+      long v;
+      int t, ns;
+      if (len != 1) rs_throw(ps, RS_MALFORMED_STREAM);
+      v = SPEC_BYTE(0);
+      t = (int)((v >> 4) & 0xff); ns = (int)(v & 15);
+      if ((t != 0 && t != 2 && t != 3) || ns > 1 || (ns && t != 3)) rs_throw(ps, RS_MALFORMED_STREAM);
+    } else if (tbox == SPEC_ID('L', 'T', 'R', 'F') || tbox == SPEC_ID('C', 'T', 'R', 'F') || tbox == SPEC_ID('R', 'T', 'R', 'F') ||
+               tbox == SPEC_ID('D', 'T', 'R', 'F') || tbox == SPEC_ID('S', 'T', 'R', 'F')) {
+      if (len != 1 || (SPEC_BYTE(0) & 15)) rs_throw(ps, RS_MALFORMED_STREAM); /* size; "the reserved field is not zero" */
+    } else if (tbox == SPEC_ID('L', 'P', 'T', 'S') || tbox == SPEC_ID('Q', 'P', 'T', 'S') || tbox == SPEC_ID('C', 'P', 'T', 'S') ||
+               tbox == SPEC_ID('R', 'P', 'T', 'S') || tbox == SPEC_ID('S', 'P', 'T', 'S') || tbox == SPEC_ID('P', 'P', 'T', 'S') ||
+               tbox == SPEC_ID('D', 'P', 'T', 'S')) {
+      if (len != 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    } else if (tbox == SPEC_ID('C', 'U', 'R', 'V')) {
+      int m, e;
+      if (len != 18) rs_throw(ps, RS_MALFORMED_STREAM);
+      m = (int)(SPEC_BYTE(0) & 0xff); e = (int)(SPEC_BYTE(1) & 0xff);
+      if ((m & 15) == 3 || (m & 15) > 8 || (e & 15) || (e >> 4) > 1) rs_throw(ps, RS_MALFORMED_STREAM);
+      if (curve[m >> 4]) rs_throw(ps, RS_MALFORMED_STREAM); /* "found an double parametric curve box for the same index" */
+      curve[m >> 4] = 1;
+    } else if (tbox == SPEC_ID('M', 'T', 'R', 'X')) {
+      long b;
+      if (len != 19) rs_throw(ps, RS_MALFORMED_STREAM);
+      b = SPEC_BYTE(0);
+      if (b < 0 || (b >> 4) < 5 || (b & 15) != 13 || j + overhead + len > have) rs_throw(ps, RS_MALFORMED_STREAM);
+      if (matrix[b >> 4]) rs_throw(ps, RS_MALFORMED_STREAM); /* "found an double linear transformation for the same index" */
+      matrix[b >> 4] = 1;
+    } else if (tbox == SPEC_ID('A', 'M', 'U', 'L')) rs_throw(ps, RS_MALFORMED_STREAM); /* alpha composition outside the alpha specification */
+#undef SPEC_BYTE
+    j += xl;
+  }
+}
+
 static void rs_parse_box_marker(oj_parser *ps, oj_bs *io, long length)
 {
   long overhead = 2 + 2 + 2 + 4 + 4 + 4, blen, dt;
@@ -398,6 +481,7 @@ static void rs_parse_box_marker(oj_parser *ps, oj_bs *io, long length)
   if (ps->boxes[b].parsed == ps->boxes[b].boxsize) {
     const oj_box *bx = &ps->boxes[b];
     ps->boxes[b].complete = 1;
+    if (tbox == 0x53504543u) rs_check_merging_spec(ps, bx->data, bx->len, bx->boxsize);
     if (tbox == 0x66747970u) { /* 'ftyp': FileTypeBox::ParseBoxContent, boxes/filetypebox.cpp:71-120 */
       if (bx->boxsize < 8) rs_throw(ps, RS_MALFORMED_STREAM);
       if (bx->len < 4 || memcmp(bx->data, "jpxt", 4) != 0) rs_throw(ps, RS_MALFORMED_STREAM); /* "file is not compatible to JPEG XT" */
@@ -1294,16 +1378,16 @@ static int spec_without_residual(const oj_box *spec, const oj_box *boxes, int nb
     const uint32_t l = ((uint32_t)rd16(spec->data + j) << 16) | (uint32_t)rd16(spec->data + j + 2);
     const uint32_t t = ((uint32_t)rd16(spec->data + j + 4) << 16) | (uint32_t)rd16(spec->data + j + 6);
     const uint8_t *pl = spec->data + j + 8;
-    if (l < 9 || j + l > spec->len) return 1;
+    if (l < 8 || j + l > spec->len) return 1;
     if (t == BOXID_('L', 'T', 'R', 'F')) ltrafo = pl[0] >> 4;
     else if (t == BOXID_('C', 'T', 'R', 'F')) ctrafo = pl[0] >> 4;
     else if (t == BOXID_('O', 'C', 'O', 'N')) ocon = pl[0];
     else if (t == BOXID_('R', 'S', 'P', 'C')) hidden = pl[0];
     else if (t == BOXID_('R', 'T', 'R', 'F') || t == BOXID_('R', 'D', 'C', 'T') || t == BOXID_('L', 'D', 'C', 'T')) { if (t == BOXID_('L', 'D', 'C', 'T') && pl[0]) return 1; }
-    else {
-      if (t == BOXID_('M', 'T', 'R', 'X') && l >= 9) have_mtx[pl[0] >> 4] = 1;
-      tables = 1; /* point transformations, tables, matrices, anything else */
-    }
+    else if (t == BOXID_('M', 'T', 'R', 'X')) { if (l >= 9) have_mtx[pl[0] >> 4] = 1; } /* (a matrix or a curve nobody names changes nothing) */
+    else if (t == BOXID_('F', 'T', 'R', 'X') || (t & 0xffffff) == (BOXID_(0, 'P', 'T', 'S')) || t == BOXID_('D', 'T', 'R', 'F') || t == BOXID_('S', 'T', 'R', 'F'))
+      tables = 1; /* point transformations, float matrices, transformations of the other profiles */
+    /* (a type MergingSpecBox::CreateBox does not know is skipped, boxes/superbox.cpp:161-176) */
     j += l;
   }
   for (b = 0; b < nboxes; b++)
@@ -2663,7 +2747,11 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
       rc = register_box(t, pl, l - 8, nlt, mtx, have_mtx);
       if (rc) goto out;
     }
-    else { rc = OJ_ERR_UNSUPPORTED; goto out; } /* L2 / R / S / P tables, D and S transformations, float boxes: profiles A and B */
+    else if (t == BOXID('C', 'P', 'T', 'S') || t == BOXID('D', 'P', 'T', 'S') || t == BOXID('S', 'P', 'T', 'S') || t == BOXID('P', 'P', 'T', 'S') ||
+             t == BOXID('D', 'T', 'R', 'F') || t == BOXID('S', 'T', 'R', 'F') || t == BOXID('F', 'T', 'R', 'X')) {
+      rc = OJ_ERR_UNSUPPORTED; goto out; /* L2 / R / S / P tables, D and S transformations, float matrices: profiles A and B */
+    }
+    /* (any other type: MergingSpecBox::CreateBox knows no such box and the superbox skips it, boxes/superbox.cpp:161-176) */
     j += l;
   }
   for (b = 0; b < ps.nboxes; b++) {

@@ -327,6 +327,81 @@ def test_transformer_refusals_come_behind_both_codestreams(oracle, name):
     d.close()
 
 
+# ------------------------------------------------------------------------------------------------ the specification's form
+# What is wrong with the FORM of a merging specification -- sub-box framing, a kind of box twice, payload sizes, reserved bits,
+# two curves or matrices for one index -- is found where the SPEC box completes (SuperBox::ParseBoxContent, boxes/superbox.cpp:
+# 93-206; MergingSpecBox::CreateBox / AcknowledgeBox, boxes/mergingspecbox.cpp:108-256; the sub-boxes' ParseBoxContent), with
+# or without a residual codestream: -1038 in front of everything that follows in the file.
+def malformed_specifications(data):
+    import struct
+    import xt_craft as X
+    curve = X.curv(9, "linear", 0, (0.0, 1.0, 0, 0))
+    matrix = bytes([0x5D]) + struct.pack(">9h", 8192, 0, 0, 0, 8192, 0, 0, 0, 8192)
+    raw = lambda lbox, tbox, payload: struct.pack(">L", lbox) + tbox + payload  # noqa: E731
+    return {
+        "ocon_twice": X.edit_spec(data, X.subbox(b"OCON", b"\x02\x00\x00")),
+        "ocon_size": X.edit_spec(data, X.subbox(b"OCON", b"\x02\x00"), drop=(b"OCON",)),
+        "ocon_lookup_bits": X.edit_spec(data, X.subbox(b"OCON", b"\x02\x00\x10"), drop=(b"OCON",)),
+        "ocon_nine_extra_bits": X.edit_spec(data, X.subbox(b"OCON", b"\x92\x00\x00"), drop=(b"OCON",)),
+        "ltrf_reserved": X.edit_spec(data, X.subbox(b"LTRF", b"\x21"), drop=(b"LTRF",)),
+        "ltrf_size": X.edit_spec(data, X.subbox(b"LTRF", b"\x20\x00"), drop=(b"LTRF",)),
+        "ctrf_twice": X.edit_spec(data, X.subbox(b"CTRF", b"\x10") + X.subbox(b"CTRF", b"\x10")),
+        "lpts_size": X.edit_spec(data, X.subbox(b"LPTS", b"\x00\x00\x00"), drop=(b"LPTS",)),
+        "spts_size": X.edit_spec(data, X.subbox(b"SPTS", b"\x00")),
+        "rdct_type": X.edit_spec(data, X.subbox(b"RDCT", b"\x10")),
+        "rdct_noise_without_bypass": X.edit_spec(data, X.subbox(b"RDCT", b"\x01")),
+        "ldct_size": X.edit_spec(data, X.subbox(b"LDCT", b"\x00\x00")),
+        "rspc_size": X.edit_spec(data, X.subbox(b"RSPC", b"\x00\x00"), drop=(b"RSPC",)),
+        "rspc_five": X.edit_spec(data, X.subbox(b"RSPC", b"\x50"), drop=(b"RSPC",)),
+        "two_curves_one_index": X.edit_spec(data, X.subbox(b"CURV", curve) + X.subbox(b"CURV", curve)),
+        "curve_type": X.edit_spec(data, X.subbox(b"CURV", bytes([0x93]) + curve[1:])),
+        "two_matrices_one_index": X.edit_spec(data, X.subbox(b"MTRX", matrix) + X.subbox(b"MTRX", matrix)),
+        "matrix_index": X.edit_spec(data, X.subbox(b"MTRX", bytes([0x4D]) + matrix[1:])),
+        "matrix_fraction": X.edit_spec(data, X.subbox(b"MTRX", bytes([0x5C]) + matrix[1:])),
+        "alpha_composition": X.edit_spec(data, X.subbox(b"AMUL", b"\x00\x00\x00\x00\x00\x00\x00")),
+        "child_length_zero": X.edit_spec(data, raw(0, b"XXXX", b"")),
+        "child_length_four": X.edit_spec(data, raw(4, b"XXXX", b"")),
+        "child_beyond_the_box": X.edit_spec(data, raw(64, b"XXXX", b"\x00")),
+        "child_header_cut": X.edit_spec(data, b"\x00\x00\x00"),
+        # ... and what is fine: an unknown child, a second curve for another index
+        "unknown_child": X.edit_spec(data, X.subbox(b"XXXX", b"\x01\x02\x03")),
+        "two_curves": X.edit_spec(data, X.subbox(b"CURV", curve) + X.subbox(b"CURV", X.curv(10, "linear", 0, (0.0, 1.0, 0, 0)))),
+    }
+
+
+SPEC_BASES = {"with_residual": os.path.join("xt_int8", "enc_444.jpg"), "without_residual": "refc_83x47_422.jpg"}
+FINE = ("unknown_child", "two_curves")
+
+
+@pytest.mark.parametrize("which", sorted(SPEC_BASES))
+def test_form_of_the_merging_specification(oracle, which):
+    with open(os.path.join(GOLDEN_DIR, SPEC_BASES[which]), "rb") as f:
+        data = f.read()
+    d = api.Decoder(None)
+    for kind, blob in malformed_specifications(data).items():
+        expect = 0 if kind in FINE else -1038
+        if oracle.have_reference():
+            _, rerr = reference_status(oracle, blob, False)
+            assert rerr == expect, (which, kind, rerr)
+        info = oracle.OjInfo()
+        import ctypes as C
+        rc = oracle.lib().oj_read_info(blob, len(blob), C.byref(info))
+        assert (info.ref_error if rc else 0) == expect, (which, kind, rc, info.ref_error)
+        if which == "with_residual":
+            assert oracle.decode_xt_status(blob)[2] == expect, (which, kind)
+        try:
+            d.read(blob)
+            perr = 0
+        except api.MijpegError as e:
+            perr = e.code
+        assert perr == expect, (which, kind, perr)
+        if expect:  # a header-only read says so as well
+            with pytest.raises(api.MijpegError) as e:
+                d.read_header(blob)
+            assert e.value.code == expect
+    d.close()
+
+
 # ------------------------------------------------------------------------------------------------ product, pixels
 @pytest.mark.gpu
 def test_gpu_pixels_behind_a_damaged_residual_scan(oracle):
@@ -360,3 +435,18 @@ def test_gpu_legacy_picture_where_the_residual_box_is_not_known(oracle):
         n += 1
     dec.close()
     assert n >= 6
+
+
+@pytest.mark.gpu
+def test_gpu_children_the_specification_does_not_know_change_nothing(oracle):
+    dec = api.Decoder(0)
+    for which, path in SPEC_BASES.items():
+        with open(os.path.join(GOLDEN_DIR, path), "rb") as f:
+            data = f.read()
+        dec.read(data)
+        want = dec.reconstruct().copy()
+        variants = malformed_specifications(data)
+        for kind in FINE:
+            dec.read(variants[kind])
+            assert np.array_equal(dec.reconstruct(), want), (which, kind)
+    dec.close()
