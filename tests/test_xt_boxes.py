@@ -37,6 +37,7 @@ BASES = {
     "half_420": ("xt_129x71_420.jpg", True),
     "grey_int": (os.path.join("xt_grey", "g8.jpg"), False),
     "grey_half": (os.path.join("xt_grey", "ghdr.jpg"), True),
+    "grey_half_hidden": (os.path.join("xt_grey", "ghdr_R1_rR3.jpg"), True),
     "int8_444": (os.path.join("xt_int8", "enc_444.jpg"), False),
     "int16_420_r12": (os.path.join("xt_int16", "w420_r12.jpg"), False),
 }
@@ -100,6 +101,16 @@ def handmade(name):
         lbox = int.from_bytes(b[o + 12:o + 16], "big") - cut
         b[o + 12:o + 16] = lbox.to_bytes(4, "big")
     out["resi_cut"] = (bytes(b), 0)
+    # a refinement box whose scan header is gone: skipped with a warning, the frame turns to the next box
+    # (Frame::StartParseScan, marker/frame.cpp:805-822, 857-860)
+    for kind, tbox in (("fine_without_scan", b"FINE"), ("rfin_without_scan", b"RFIN")):
+        boxes = segments(data, tbox)
+        if boxes:
+            o, l = boxes[0]
+            at = data.index(b"\xff\xda", o, o + 2 + l)
+            b = bytearray(data)
+            b[at + 1] = 0x01
+            out[kind] = (bytes(b), 0)
     return out
 
 
@@ -190,7 +201,7 @@ def test_host_decoder_verdicts(oracle):
             _, _, oerr = oracle.decode_xt_status(blob)
             assert oerr == expect, (name, kind, oerr)
     d.close()
-    assert declined <= 9
+    assert declined <= 12  # (the half-float bases: the legacy picture through L tables to float output is declined)
 
 
 def test_legacy_planes_where_the_residual_box_is_not_known(oracle):
@@ -407,7 +418,9 @@ def test_form_of_the_merging_specification(oracle, which):
 def test_gpu_pixels_behind_a_damaged_residual_scan(oracle):
     dec = api.Decoder(0)
     for name in BASES:
-        for kind in ("resi_ff", "resi_cut"):
+        for kind in ("resi_ff", "resi_cut", "fine_without_scan", "rfin_without_scan"):
+            if (name, kind) not in CASES:
+                continue
             blob, _ = CASES[(name, kind)]
             codes, _, oerr = oracle.decode_xt_status(blob)
             assert oerr == 0
