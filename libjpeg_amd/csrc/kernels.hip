@@ -3340,9 +3340,11 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
     }
     long long rr[3];
     if (a.rtrafo_ycbcr) {
-      const long long ry = q3[0], rcb = q3[1] - ((long long)a.out_shift << 4), rcr = q3[2] - ((long long)a.out_shift << 4);
+      // (LONG variables around QUAD products in the reference: a table entry beyond the range -- curves with parameters no
+      // encoder writes -- wraps where it narrows, colortrafo/ycbcrtrafo.cpp:776-789)
+      const long long ry = q3[0], rcb = (int)(q3[1] - ((long long)a.out_shift << 4)), rcr = (int)(q3[2] - ((long long)a.out_shift << 4));
 #pragma unroll
-      for (int c = 0; c < 3; c++) rr[c] = (ry * a.rmat[3 * c] + rcb * a.rmat[3 * c + 1] + rcr * a.rmat[3 * c + 2] + 4096) >> 13;
+      for (int c = 0; c < 3; c++) rr[c] = (int)((ry * a.rmat[3 * c] + rcb * a.rmat[3 * c + 1] + rcr * a.rmat[3 * c + 2] + 4096) >> 13);
     } else {
       rr[0] = q3[0]; rr[1] = q3[1]; rr[2] = q3[2];
     }
@@ -3367,7 +3369,7 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
     for (int c = 0; c < 3; c++) lv[c] = a.ltable[c * a.ltable_entries + (int)min(max(v[c], 0ll), (long long)a.maxval)];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      long long m = ((lv[0] * a.cmat[3 * c] + lv[1] * a.cmat[3 * c + 1] + lv[2] * a.cmat[3 * c + 2] + 4096) >> 13) + rr[c] - a.out_shift;
+      long long m = (int)(((lv[0] * a.cmat[3 * c] + lv[1] * a.cmat[3 * c + 1] + lv[2] * a.cmat[3 * c + 2] + 4096) >> 13) + rr[c] - a.out_shift); // (:868-879)
       if (a.is_float) {
         m = min(max(m, (long long)minf), (long long)pinf);
         const short w = (short)m;
@@ -3412,7 +3414,7 @@ __global__ __launch_bounds__(256) void xt_merge1_kernel(const GenericArgs a)
     if (a.xt_no_residual) rr = a.out_shift; // nothing to merge (colortrafo/ycbcrtrafo.cpp:744-746)
     const long long v = ((long long)s[x] + 8) >> 4;
     const long long lv = a.ltable[(int)min(max(v, 0ll), (long long)a.maxval)];
-    long long m = lv + rr - a.out_shift;
+    long long m = (int)(lv + rr - a.out_shift); // (a LONG: colortrafo/ycbcrtrafo.cpp:886-890)
     if (a.is_float) {
       m = min(max(m, (long long)minf), (long long)pinf);
       const short w = (short)m;

@@ -1861,6 +1861,7 @@ static void xt_bypass_block(int32_t *dst, const int32_t *res, int32_t quant, int
 /* One pixel of the JPEG XT merge: v = the legacy sample after the L transformation (integer), rk = the residual samples * 16
  * as the residual transform (or the bypass) left them.  colortrafo/ycbcrtrafo.cpp:750-829 (residual), :861-878 (L-LUT,
  * C transformation, merge), :897-955 (half clamp). */
+#define W32(x) ((int64_t)(int32_t)(uint32_t)(uint64_t)(x)) /* what a LONG keeps of it */
 static void xt_merge_pixel(const oj_xt *xt, int64_t maxval, const int64_t vin[3], const int32_t rk[3], uint16_t out[3])
 {
   const oj_info *r = xt->rinfo;
@@ -1879,10 +1880,12 @@ static void xt_merge_pixel(const oj_xt *xt, int64_t maxval, const int64_t vin[3]
   }
   if (xt->rtrafo_ycbcr) {
     const int64_t *M = xt->rmat;
-    const int64_t ry = q3[0], rcb = q3[1] - (xt->outshift << 4), rcr = q3[2] - (xt->outshift << 4);
-    rr[0] = (ry * M[0] + rcb * M[1] + rcr * M[2] + 4096) >> 13; /* FIX_COLOR_TO_INTCOLOR */
-    rr[1] = (ry * M[3] + rcb * M[4] + rcr * M[5] + 4096) >> 13;
-    rr[2] = (ry * M[6] + rcb * M[7] + rcr * M[8] + 4096) >> 13;
+    /* (LONG variables, QUAD products: a table entry beyond the range -- a curve with parameters no encoder writes -- wraps
+     * where the reference narrows, colortrafo/ycbcrtrafo.cpp:776-789, 868-879) */
+    const int64_t ry = q3[0], rcb = W32(q3[1] - (xt->outshift << 4)), rcr = W32(q3[2] - (xt->outshift << 4));
+    rr[0] = W32((ry * M[0] + rcb * M[1] + rcr * M[2] + 4096) >> 13); /* FIX_COLOR_TO_INTCOLOR */
+    rr[1] = W32((ry * M[3] + rcb * M[4] + rcr * M[5] + 4096) >> 13);
+    rr[2] = W32((ry * M[6] + rcb * M[7] + rcr * M[8] + 4096) >> 13);
   } else {
     rr[0] = q3[0]; rr[1] = q3[1]; rr[2] = q3[2];
   }
@@ -1895,7 +1898,7 @@ merge:
   for (c = 0; c < nc; c++) lv[c] = xt->ltable[c] ? xt->ltable[c][clampmax(vin[c], maxval)] : vin[c];
   /* C transformation, FIX_TO_INT (the identity leaves the values alone: (x * 8192 + 4096) >> 13 == x) */
   for (c = 0; c < 3; c++)
-    v[c] = ((lv[0] * xt->cmat[3 * c] + lv[1] * xt->cmat[3 * c + 1] + lv[2] * xt->cmat[3 * c + 2] + 4096) >> 13) + rr[c] - xt->outshift;
+    v[c] = W32(((lv[0] * xt->cmat[3 * c] + lv[1] * xt->cmat[3 * c + 1] + lv[2] * xt->cmat[3 * c + 2] + 4096) >> 13) + rr[c] - xt->outshift);
   if (xt->is_float && xt->clamp) {
     const int64_t pinf = (xt->outmax >> 1) - (xt->outmax >> 6) - 1;
     const int64_t minf = invert_negs((int16_t)(uint16_t)(pinf | 0x8000));

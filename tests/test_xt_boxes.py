@@ -463,3 +463,36 @@ def test_gpu_children_the_specification_does_not_know_change_nothing(oracle):
             dec.read(variants[kind])
             assert np.array_equal(dec.reconstruct(), want), (which, kind)
     dec.close()
+
+
+# ------------------------------------------------------------------------------------------------ tables beyond the range
+# tests/golden/xt_boxes/r2_curve_overflows.jpg: xt_int8/a_r2_exponential.jpg with the curve's second parameter at 1024 (one
+# byte of its CURV box): most entries of the R2 table leave 32 bits, LONG(double) makes 0x80000000 of them
+# (boxes/parametrictonemappingbox.cpp:411-421), and the merge adds that in LONG variables -- it wraps, and 410 samples saturate
+# at the top where sums in 64 bits would saturate at the bottom (colortrafo/ycbcrtrafo.cpp:776-789, 868-879).  The .bin holds
+# the reference decoder's samples.
+def overflowing_curve():
+    with open(os.path.join(GOLDEN_DIR, "xt_boxes", "r2_curve_overflows.jpg"), "rb") as f:
+        data = f.read()
+    want = np.fromfile(os.path.join(GOLDEN_DIR, "xt_boxes", "r2_curve_overflows.bin"), np.uint8).reshape(32, 48, 3)
+    return data, want
+
+
+def test_oracle_merges_in_32_bits(oracle):
+    data, want = overflowing_curve()
+    codes, is_float, err = oracle.decode_xt_status(data)
+    assert err == 0 and not is_float and np.array_equal(codes.astype(np.uint8), want) and codes.max() <= 255
+    assert np.count_nonzero(want == 255) >= 400
+    if oracle.have_reference():
+        rpx, rerr = reference_status(oracle, data, False)
+        assert rerr == 0 and np.array_equal(rpx, want)
+
+
+@pytest.mark.gpu
+def test_gpu_merges_in_32_bits(oracle):
+    data, want = overflowing_curve()
+    dec = api.Decoder(0)
+    dec.read(data)
+    out = dec.reconstruct()
+    dec.close()
+    assert out.shape == want.shape and np.array_equal(out, want)
