@@ -482,6 +482,32 @@ static void rs_parse_box_marker(oj_parser *ps, oj_bs *io, long length)
     const oj_box *bx = &ps->boxes[b];
     ps->boxes[b].complete = 1;
     if (tbox == 0x53504543u) rs_check_merging_spec(ps, bx->data, bx->len, bx->boxsize);
+    /* tables and matrices of the file's own list parse where they complete (inversetonemappingbox.cpp:72-118,
+     * parametrictonemappingbox.cpp:85-149, lineartransformationbox.cpp:62-99); a table index / matrix id may be taken once
+     * (codestream/tables.cpp:1247-1266; NameSpace::isUniqueNonlinearity counts TONE, FTON and CURV boxes) */
+    if (tbox == 0x544f4e45u || tbox == 0x43555256u || tbox == 0x4d545258u) {
+      const uint64_t n = bx->boxsize;
+      if (tbox == 0x544f4e45u) {
+        const uint64_t entries = (n - 1) >> 1;
+        if (n > 65536u * 2 + 1 || !(n & 1) || n < 512 || (entries & (entries - 1))) rs_throw(ps, RS_MALFORMED_STREAM);
+      } else if (tbox == 0x43555256u) {
+        int ty, e;
+        if (n != 18) rs_throw(ps, RS_MALFORMED_STREAM);
+        ty = bx->len > 0 ? (bx->data[0] & 15) : 15; e = bx->len > 1 ? bx->data[1] : 0xff;
+        if (ty == 3 || ty > 8 || (e & 15) || (e >> 4) > 1) rs_throw(ps, RS_MALFORMED_STREAM);
+      } else {
+        if (n != 19 || bx->len < n || (bx->data[0] >> 4) < 5 || (bx->data[0] & 15) != 13) rs_throw(ps, RS_MALFORMED_STREAM);
+      }
+      if (tbox != 0x43555256u && bx->len > 0) {
+        int same = 0, o;
+        for (o = 0; o < ps->nboxes; o++) {
+          const oj_box *ob = &ps->boxes[o];
+          if (!ob->complete || ob->len == 0 || (ob->data[0] >> 4) != (bx->data[0] >> 4)) continue;
+          if (tbox == 0x4d545258u ? ob->type == 0x4d545258u : (ob->type == 0x544f4e45u || ob->type == 0x43555256u)) same++;
+        }
+        if (same > 1) rs_throw(ps, RS_MALFORMED_STREAM); /* "found a doubly used table destination ..." */
+      }
+    }
     if (tbox == 0x66747970u) { /* 'ftyp': FileTypeBox::ParseBoxContent, boxes/filetypebox.cpp:71-120 */
       if (bx->boxsize < 8) rs_throw(ps, RS_MALFORMED_STREAM);
       if (bx->len < 4 || memcmp(bx->data, "jpxt", 4) != 0) rs_throw(ps, RS_MALFORMED_STREAM); /* "file is not compatible to JPEG XT" */

@@ -496,3 +496,57 @@ def test_gpu_merges_in_32_bits(oracle):
     out = dec.reconstruct()
     dec.close()
     assert out.shape == want.shape and np.array_equal(out, want)
+
+
+# ------------------------------------------------------------------------------------------------ the file's own tables
+# TONE, CURV and MTRX boxes of the file's list parse where they complete, and a table index / matrix id may be taken once
+# (codestream/tables.cpp:1247-1266) -- in a plain JPEG as well, where nobody would ever look the table up.
+def file_level_boxes():
+    import struct
+    import xt_craft as X
+    tone = lambda idx, n=256: bytes([idx << 4 | 8]) + b"".join(struct.pack(">H", (i * 255) & 0xFFFF) for i in range(n))  # noqa: E731
+    curve = lambda idx, ty=5: bytes([(idx << 4) | ty, 0]) + struct.pack(">4f", 0.0, 1.0, 0.0, 0.0)  # noqa: E731
+    matrix = lambda i, t=13: bytes([(i << 4) | t]) + struct.pack(">9h", 8192, 0, 0, 0, 8192, 0, 0, 0, 8192)  # noqa: E731
+    return {
+        "tone": (X.app11(b"TONE", tone(9)), 0),
+        "tone_even_size": (X.app11(b"TONE", tone(9) + b"\x00"), -1038),
+        "tone_short": (X.app11(b"TONE", tone(9, 128)), -1038),
+        "tone_not_a_power_of_two": (X.app11(b"TONE", tone(9, 300)), -1038),
+        "two_tones_one_index": (X.app11(b"TONE", tone(9)) + X.app11(b"TONE", tone(9), 2), -1038),
+        "two_tones": (X.app11(b"TONE", tone(9)) + X.app11(b"TONE", tone(10), 2), 0),
+        "curve_then_tone_one_index": (X.app11(b"CURV", curve(9)) + X.app11(b"TONE", tone(9)), -1038),
+        "tone_then_curve_one_index": (X.app11(b"TONE", tone(9)) + X.app11(b"CURV", curve(9)), 0),
+        "curve_type": (X.app11(b"CURV", curve(9, 3)), -1038),
+        "curve_size": (X.app11(b"CURV", curve(9) + b"\x00"), -1038),
+        "matrix": (X.app11(b"MTRX", matrix(7)), 0),
+        "two_matrices_one_id": (X.app11(b"MTRX", matrix(7)) + X.app11(b"MTRX", matrix(7), 2), -1038),
+        "matrix_id": (X.app11(b"MTRX", matrix(4)), -1038),
+        "matrix_fraction": (X.app11(b"MTRX", matrix(7, 12)), -1038),
+    }
+
+
+@pytest.mark.parametrize("which", ["plain", "xt"])
+def test_tables_of_the_files_own_list(oracle, which):
+    import ctypes as C
+    import xt_craft as X
+    if which == "plain":
+        data = golden_jpeg("ref_16x16_420")
+    else:
+        with open(os.path.join(GOLDEN_DIR, "xt_int8", "enc_444.jpg"), "rb") as f:
+            data = f.read()
+    d = api.Decoder(None)
+    for kind, (boxes, expect) in file_level_boxes().items():
+        blob = data[:2] + boxes + data[2:] if which == "plain" else X.edit_spec(data, new_boxes=boxes)
+        if oracle.have_reference():
+            _, rerr = reference_status(oracle, blob, False)
+            assert rerr == expect, (which, kind, rerr)
+        info = oracle.OjInfo()
+        rc = oracle.lib().oj_read_info(blob, len(blob), C.byref(info))
+        assert (info.ref_error if rc else 0) == expect, (which, kind, rc, info.ref_error)
+        try:
+            d.read(blob)
+            perr = 0
+        except api.MijpegError as e:
+            perr = e.code
+        assert perr == expect, (which, kind, perr)
+    d.close()
