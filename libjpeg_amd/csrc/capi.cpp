@@ -418,6 +418,10 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
     if (d->device >= 0 && copy_err == hipSuccess)
       copy_err = hipMemcpyAsync(d->coef_dev, d->coef_host, (size_t)f.coef_count * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
   }
+  // (a JPEG XT frame whose damaged scans leave the 16-bit store: the reference goes on in LONG coefficients, this path has no
+  // int32 planes for merged frames -- declined like every other subset it does not take, not reported as the stream's fault)
+  if (rc == MIJPEG_ERR_OVERFLOW_PARAMETER && d->host.is_xt() && d->host.error.message.find("coefficient store") != std::string::npos)
+    return set_error(d, MIJPEG_ERR_OPERATION_UNIMPLEMENTED, "JPEG XT frame with coefficients beyond the 16-bit store (a damaged scan) is not on the accelerated path");
   if (rc) return set_error(d, rc, d->host.error.message);
   if (d->device >= 0 && d->host.is_xt() && copy_err == hipSuccess) {
     // the residual codestream's planes sit behind the legacy planes in the same buffer
