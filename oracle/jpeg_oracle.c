@@ -2798,11 +2798,14 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   }
   if (ltrafo == 255) ltrafo = 2;
   if (rtrafo == 255) rtrafo = 2;
-  if (ltrafo == 0 || ltrafo == 3 || ltrafo == 4) { rc = OJ_ERR_MALFORMED; goto out; } /* "the base transformation ... is invalid" */
-  if (rtrafo == 3) { rc = OJ_ERR_MALFORMED; goto out; }
+  /* (what the colour transformer finds: behind both codestreams' verdicts, see `late`) */
+  if (ltrafo == 0 || ltrafo == 3 || ltrafo == 4) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto late; } /* "the base transformation ... is invalid" */
+  if (rtrafo == 3) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; }
   if (rtrafo == 4 || rtrafo == 0) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* RCT (lossless coding, part 8), zero */
-  if (ctrafo != 255 && ctrafo != 1 && ctrafo < 5) { rc = OJ_ERR_MALFORMED; goto out; }
-  if ((ltrafo >= 5 && !have_mtx[ltrafo]) || (rtrafo >= 5 && !have_mtx[rtrafo]) || (ctrafo != 255 && ctrafo >= 5 && !have_mtx[ctrafo])) { rc = OJ_ERR_MALFORMED; goto out; }
+  if (ctrafo != 255 && ctrafo != 1 && ctrafo < 5) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto late; }
+  /* OBJECT_DOESNT_EXIST "the base / color / residual transformation specified in the codestream does not exist" (colortransformerfactory.cpp:355-400, 528-566) */
+  if ((ltrafo >= 5 && !have_mtx[ltrafo]) || (ctrafo != 255 && ctrafo >= 5 && !have_mtx[ctrafo])) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; goto late; }
+  if (rtrafo >= 5 && !have_mtx[rtrafo]) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; } /* (looked up beside a residual frame only) */
   if (ocon < 0 || (ocon & 0x08) || (ocon & 0x01)) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* lossless / output lookup */
   xt.outmax = ((int64_t)1 << (8 + (ocon >> 4))) - 1;
   xt.outshift = (xt.outmax + 1) >> 1;

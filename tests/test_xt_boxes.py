@@ -295,13 +295,24 @@ def test_residual_planes_of_a_scan_that_ends_in_a_marker(oracle):
 # transformer refuses them when the first request builds it (Tables::ColorTrafoOf, codestream/tables.cpp:1517-1555).  The command
 # line has read the whole file by then (cmd/reconstruct.cpp:119-121): what stops either codestream is reported instead, and a
 # table of the residual's side is not even looked up when the legacy codestream has no EOI (no residual frame to merge).
-LATE = {"a_q_table_missing": -1031, "a_q_is_tone_box": -1031, "a_r2_linear_negative_slope": -1024}
+LATE = {"a_q_table_missing": -1031, "a_q_is_tone_box": -1031, "a_r2_linear_negative_slope": -1024,
+        # made here: transformations that name a matrix nobody defined -- the residual's is looked up beside a residual frame only,
+        # the base one always (colortransformerfactory.cpp:355-400, 528-566)
+        "craft_r_matrix_missing": -1031, "craft_l_matrix_missing": -1031}
+ALWAYS = ("craft_l_matrix_missing",)  # refusals that do not depend on a residual frame
 
 
 def late_cases(name):
     """kind -> (stream, the reference's answer; 0: a picture -- the legacy one through the L tables)"""
-    with open(os.path.join(GOLDEN_DIR, "xt_int8", name + ".jpg"), "rb") as f:
-        data = f.read()
+    if name.startswith("craft_"):
+        import xt_craft as X
+        with open(os.path.join(GOLDEN_DIR, "xt_int8", "enc_444.jpg"), "rb") as f:
+            data = f.read()
+        t = b"RTRF" if name == "craft_r_matrix_missing" else b"LTRF"
+        data = X.edit_spec(data, X.subbox(t, b"\x70"), drop=(t,))
+    else:
+        with open(os.path.join(GOLDEN_DIR, "xt_int8", name + ".jpg"), "rb") as f:
+            data = f.read()
     es = damage.entropy_start(data)
     out = {"intact": (data, LATE[name])}
     b = bytearray(data)
@@ -312,8 +323,8 @@ def late_cases(name):
     b = bytearray(data)
     b[off + ln - 120:off + ln - 114] = b"\x55" * 6  # the residual scan runs out of sync
     out["residual_scan"] = (bytes(b), -1038)
-    out["no_eoi"] = (data[:-2], 0)
-    out["cut"] = (data[:es + 150], 0)
+    out["no_eoi"] = (data[:-2], LATE[name] if name in ALWAYS else 0)
+    out["cut"] = (data[:es + 150], LATE[name] if name in ALWAYS else 0)
     return out
 
 

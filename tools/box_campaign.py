@@ -90,6 +90,11 @@ def header_cases(data, n, rng):
         for _ in range(int(rng.integers(1, 4))):
             b[int(rng.integers(2, hdr))] = int(rng.integers(0, 256))
         yield "hdr%d" % k, bytes(b)
+    for k in range(n // 2):  # a byte missing / a byte too many: segment and box lengths stop fitting
+        p = int(rng.integers(2, hdr))
+        yield "del%d" % k, data[:p] + data[p + 1:]
+        p = int(rng.integers(2, hdr))
+        yield "ins%d" % k, data[:p] + bytes([int(rng.integers(0, 256))]) + data[p:]
 
 
 def work_list(mode, seed):
