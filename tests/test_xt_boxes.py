@@ -561,3 +561,19 @@ def test_tables_of_the_files_own_list(oracle, which):
             perr = e.code
         assert perr == expect, (which, kind, perr)
     d.close()
+
+
+def test_refusal_beside_a_residual_scan_only_the_sequential_walk_rejects(oracle):
+    """tests/golden/xt_boxes/refused_spec_damaged_residual.jpg (tools/box_campaign.py xt 9: xt_int8/a_q_is_tone_box.jpg with two
+    bytes of its residual codestream hit): the residual scan decodes interval by interval without complaint and only the
+    reference's sequential walk runs out of sync -- the verdict in front of the transformer's -1031 has to take that walk."""
+    with open(os.path.join(GOLDEN_DIR, "xt_boxes", "refused_spec_damaged_residual.jpg"), "rb") as f:
+        blob = f.read()
+    if oracle.have_reference():
+        assert reference_status(oracle, blob, False)[1] == -1038
+    assert oracle.decode_xt_status(blob)[2] == -1038
+    d = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        d.read(blob)
+    d.close()
+    assert e.value.code == -1038 and "out of sync" in str(e.value)
