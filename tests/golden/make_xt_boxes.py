@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """tests/golden/xt_boxes/: a curve whose table leaves 32 bits (tests/test_xt_boxes.py, "tables beyond the range").
 xt_int8/a_r2_exponential.jpg with the second parameter of its CURV box at 1024.0 (first byte of the IEEE number: 0x3f -> 0x44);
-the .bin holds the samples oracle/_ref/jpeg (the reference decoder, `make -C oracle ref`) writes for it.  Build container only."""
+the .bin holds the samples oracle/_ref/jpeg (the reference decoder, `make -C oracle ref`) writes for it.  Build container only.
+refused_spec_damaged_residual.jpg is not made here: it is stream `a_q_is_tone_box / hdr8` of `python tools/box_campaign.py xt 9
+--keep DIR` (xt_int8/a_q_is_tone_box.jpg with bytes 556 and 1426 changed to e0 / 2d), kept as the campaign wrote it."""
 import os
 import subprocess
 import sys
