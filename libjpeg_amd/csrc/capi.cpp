@@ -423,7 +423,7 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   if (rc == MIJPEG_ERR_OVERFLOW_PARAMETER && d->host.is_xt() && d->host.error.message.find("coefficient store") != std::string::npos)
     return set_error(d, MIJPEG_ERR_OPERATION_UNIMPLEMENTED, "JPEG XT frame with coefficients beyond the 16-bit store (a damaged scan) is not on the accelerated path");
   if (rc) return set_error(d, rc, d->host.error.message);
-  if (d->device >= 0 && d->host.is_xt() && copy_err == hipSuccess) {
+  if (d->device >= 0 && d->host.residual() && copy_err == hipSuccess) {
     // the residual codestream's planes sit behind the legacy planes in the same buffer
     const size_t off = (size_t)d->host.xt.residual.coef_offset[0], cnt = (size_t)f.coef_count - off;
     copy_err = hipMemcpyAsync(d->coef_dev + off, d->coef_host + off, cnt * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
@@ -1978,6 +1978,8 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
           x.ltable_entries != (256 << x.hidden_bits) || (x.residual_wide != 0) != (x.residual_hidden_bits > 0))
         return MIJPEG_ERR_INVALID_PARAMETER;
       for (int c = 0; c < x.residual.components && c < 3; c++) plane(3 + c, x.residual, c, rprec); // (one component: planes 4, 5 stay empty)
+      if (!x.residual.components) // (no residual frame at all -- a specification without a residual codestream: the merge reads nothing there)
+        for (int pn = 3; pn < 6; pn++) a.subx[pn] = a.suby[pn] = 1;
       if (x.residual_wide) { a.wide_first = 3; a.wide_count = 3; }
       a.ltable_entries = x.ltable_entries;
       a.nplanes = 6;
@@ -1997,7 +1999,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
                            hipMemcpyHostToDevice, s) != hipSuccess)
           return MIJPEG_ERR_DEVICE;
       if (x.general) {
-        if (x.qtable_entries != (1 << (rprec + 4))) return MIJPEG_ERR_INVALID_PARAMETER;
+        if (x.residual.components && x.qtable_entries != (1 << (rprec + 4))) return MIJPEG_ERR_INVALID_PARAMETER; // (no residual frame: no Q tables)
         a.xt_general = 1;
         a.rbypass = x.rdct_bypass;
         a.rnoise = x.noise_shaping;
@@ -3020,7 +3022,7 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
       const int c = pn % 3;
       const bool up = p.upsampling_path && p.upsampler[c] && !(pn >= 3 && x.no_residual);
       rx.wstart[pn] = up ? p.wstart[c] : 0;
-      rx.wlimit[pn] = up ? p.wlimit[c] : (f.height + g.suby[c] - 1) / g.suby[c];
+      rx.wlimit[pn] = up ? p.wlimit[c] : (f.height + g.suby[c] - 1) / std::max(1, g.suby[c]);
     }
     rc = launch_reconstruct_ex(&b, d->stream, &rx);
     if (rc) return set_error(d, rc, rc == MIJPEG_ERR_DEVICE ? std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError())

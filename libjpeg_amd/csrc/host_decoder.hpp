@@ -160,7 +160,8 @@ public:
   const std::vector<size_t> &interval_ends(size_t scan) const { return scan_interval_end_[scan]; }
   const std::vector<uint8_t> &restart_codes(size_t scan) const { return scan_rst_code_[scan]; }
   // JPEG XT profile C: parameters and the decoder of the residual codestream (RESI box); null for plain JPEG
-  bool is_xt() const { return residual_ != nullptr; }
+  // (... or a merging specification that sends the legacy picture alone through the L chain: xt.no_residual, no residual())
+  bool is_xt() const { return residual_ != nullptr || lonly_; }
   mijpeg_xt_params xt{};
   std::vector<Scan> scans;
   StreamError error;
@@ -215,6 +216,7 @@ private:
   std::vector<XtBox> boxes_;
   std::vector<int32_t> xt_q_[3], xt_r2_[3]; // Q / R2 tables of a JPEG XT stream when they are not the identities (xt.qtable / r2table point here)
   HostDecoder *residual_ = nullptr;
+  bool lonly_ = false; // JPEG XT without a residual codestream: the L chain alone (finish_xt)
   bool nested_ = false; // this object decodes a residual codestream
   int hidden_ = 0;      // JPEG XT: low bits of every coefficient that arrive in hidden refinement scans
   bool parsing_hidden_ = false;

@@ -3232,7 +3232,11 @@ __global__ __launch_bounds__(256) void xt_merge_kernel(const GenericArgs a)
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     upsample_plane_line<LAYOUT>(a, c, c, frame, X0, Y, s[c]);
-    upsample_plane_line<RLAYOUT>(a, 3 + c, c, frame, X0, Y, rs[c]);
+    if (a.xt_no_residual) { // nothing to merge: there may be no residual planes at all (a specification without a residual codestream)
+#pragma unroll
+      for (int x = 0; x < 8; x++) rs[c][x] = 0;
+    } else
+      upsample_plane_line<RLAYOUT>(a, 3 + c, c, frame, X0, Y, rs[c]);
   }
   uint16_t *dst = reinterpret_cast<uint16_t *>(a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride) + (int64_t)X0 * 3;
   const int npx = min(8, a.width - X0);
@@ -3321,7 +3325,11 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     upsample_plane_line<LAYOUT>(a, c, c, frame, X0, Y, s[c]);
-    upsample_plane_line<RLAYOUT>(a, 3 + c, c, frame, X0, Y, rs[c]);
+    if (a.xt_no_residual) { // nothing to merge: there may be no residual planes at all (a specification without a residual codestream)
+#pragma unroll
+      for (int x = 0; x < 8; x++) rs[c][x] = 0;
+    } else
+      upsample_plane_line<RLAYOUT>(a, 3 + c, c, frame, X0, Y, rs[c]);
   }
   uint16_t *dst = reinterpret_cast<uint16_t *>(a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride) + (int64_t)X0 * 3;
   const int npx = min(8, a.width - X0);
@@ -3398,7 +3406,11 @@ __global__ __launch_bounds__(256) void xt_merge1_kernel(const GenericArgs a)
   const int X0 = gxi * 8;
   int s[8], rs[8];
   upsample_plane_line<LAYOUT_ANY>(a, 0, 0, frame, X0, Y, s);
-  upsample_plane_line<LAYOUT_ANY>(a, 3, 0, frame, X0, Y, rs);
+  if (a.xt_no_residual) { // (no residual plane to read)
+#pragma unroll
+    for (int x = 0; x < 8; x++) rs[x] = 0;
+  } else
+    upsample_plane_line<LAYOUT_ANY>(a, 3, 0, frame, X0, Y, rs);
   uint8_t *line = a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride;
   const int npx = min(8, a.width - X0);
   const int rmax16 = ((1 << a.rprecision) << 4) - 1; // ((m_lRMax + 1) << COLOR_BITS) - 1

@@ -166,6 +166,7 @@ typedef struct {
   oj_box *boxes;   /* where APP11 boxes are collected (OJ_MAX_BOXES entries); the caller's array or walk()'s own */
   int nboxes;
   int walk_all;    /* the caller wants the boxes: walk all scans even without planes */
+  int xt_legacy;   /* the legacy codestream of a JPEG XT decode: the caller follows the merging specification itself */
   int nested;      /* this is the residual codestream of a RESI box */
   int legacy_eoi_gone; /* nested: the residual codestream ran dry in front of a scan header and the search for one took the legacy
                         * stream's EOI (see rs_run) */
@@ -1455,7 +1456,7 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
     else if (f->height == 0) { thrown = 1; ps->err = RS_OVERFLOW_PARAMETER; }
     /* codestream/tables.cpp:2021-2030: three components and no Adobe "None" -> YCbCr, else identity */
     f->ycbcr = (f->ncomp == 3 && f->adobe_transform != 0) ? 1 : 0;
-    if (!thrown && !ps->nested) {
+    if (!thrown && !ps->nested && !ps->xt_legacy) {
       const oj_box *spec = NULL, *resi = NULL;
       int b;
       for (b = 0; b < ps->nboxes; b++) {
@@ -1890,8 +1891,8 @@ static void xt_bypass_block(int32_t *dst, const int32_t *res, int32_t quant, int
 #define W32(x) ((int64_t)(int32_t)(uint32_t)(uint64_t)(x)) /* what a LONG keeps of it */
 static void xt_merge_pixel(const oj_xt *xt, int64_t maxval, const int64_t vin[3], const int32_t rk[3], uint16_t out[3])
 {
-  const oj_info *r = xt->rinfo;
-  const int64_t rmax16 = ((((int64_t)1 << r->precision)) << 4) - 1; /* ((m_lRMax + 1) << COLOR_BITS) - 1 */
+  const oj_info *r = xt->rinfo; /* (NULL where nothing is merged) */
+  const int64_t rmax16 = r ? ((((int64_t)1 << r->precision)) << 4) - 1 : 0; /* ((m_lRMax + 1) << COLOR_BITS) - 1 */
   const int64_t omax16 = ((xt->outmax + 1) << 4) - 1;
   int64_t rr[3], q3[3], lv[3], v[3];
   int c;
@@ -2671,7 +2672,7 @@ static int xt_codestreams_verdict(const uint8_t *data, size_t len, const oj_info
   int c, rc;
   memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
   *ref_error = 0; *eoi_image = 0;
-  ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
+  ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1;
   for (c = 0; c < info->ncomp; c++) {
     planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
     if (!planes[c]) { rc = OJ_ERR_NOMEM; goto done; }
@@ -2701,7 +2702,8 @@ done:
 /* disable_to_rgb: a request without colour transformation (cmd/reconstruct.cpp -c -> rr_bColorTrafo false ->
  * ColorTransformerFactory::BuildColorTransformer(.., disabletorgb)): the standard YCbCr L transformation becomes the identity,
  * nothing else changes (colortrafo/colortransformerfactory.cpp:231-232) */
-static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, oj_requester **rq_out, int disable_to_rgb)
+static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, oj_requester **rq_out, int disable_to_rgb,
+                            int32_t **lplanes_out)
 {
   oj_box boxes[OJ_MAX_BOXES];
   oj_parser ps;
@@ -2715,14 +2717,14 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   int hidden_l = 0, hidden_r = 0; /* RSPC: bits of the legacy / residual coefficients in hidden refinement scans */
   const oj_box *spec = NULL, *resi = NULL;
   int ltrafo = 255, rtrafo = 255, ctrafo = 255, lidx[4] = {255, 255, 255, 255}, qidx[4] = {255, 255, 255, 255}, r2idx[4] = {255, 255, 255, 255};
-  int ocon = -1, rdct = 0, b, c, rc, nc = 3, late_residual_only = 0;
+  int ocon = -1, rdct = 0, b, c, rc, nc = 3, late_residual_only = 0, lonly = 0;
   size_t j;
   static const int64_t std_ycc[9] = {FIX13(1.0), FIX13(0.0), FIX13(1.40200), FIX13(1.0), -FIX13(0.3441362861), -FIX13(0.7141362859),
                                      FIX13(1.0), FIX13(1.772), FIX13(0.0)};
   static const int64_t std_id[9] = {8192, 0, 0, 0, 8192, 0, 0, 0, 8192};
   if (pixels) *pixels = NULL;
   if (rq_out) *rq_out = NULL;
-  memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(nlt, 0, sizeof(nlt)); memset(&xt, 0, sizeof(xt));
+  memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(nlt, 0, sizeof(nlt)); memset(&xt, 0, sizeof(xt)); memset(&rinfo, 0, sizeof(rinfo));
   ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes; ps.walk_all = 1;
   rc = walk(&ps, NULL);
   if (rc) { free_boxes(boxes, ps.nboxes); return rc; }
@@ -2746,7 +2748,14 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     rc = OJ_ERR_MALFORMED;
     goto out;
   }
-  if (!spec || !resi || (info->ncomp != 3 && info->ncomp != 1) || info->precision != 8) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  if (!spec || (info->ncomp != 3 && info->ncomp != 1) || info->precision != 8) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  /* A merging specification and no residual codestream -- what the reference's encoder writes for `-R n` without `-r` from a
+   * picture of more than eight bits (HDR or 16-bit integer): hidden refinement scans, an L table that expands 8 + n bits to
+   * the output's depth, an output conversion.  ColorTransformerFactory::BuildColorTransformer (colortransformerfactory.cpp:
+   * 262-283) builds the Extended transformer with R transformation "zero": the whole legacy chain -- L transformation, L tables,
+   * C transformation, clamp or cast to half float -- with nothing merged (rr = m_lOutDCShift, colortrafo/ycbcrtrafo.cpp:744-746,
+   * 861-878); InstallIntegerParameters (:300-594) looks at the L tables and the L and C transformations only (`residual` false). */
+  lonly = resi == NULL;
   nc = info->ncomp; /* three components, or one: a grey scale picture with a residual (`jpeg -r ... in.pgm`) */
   xt.nc = nc;
   /* the specification's own boxes are searched first (primary list), then the file's (boxes/namespace.cpp:60-125) */
@@ -2793,11 +2802,15 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     /* one component: the L and C transformation boxes must not exist (tables.cpp:2003-2005, 2079-2081), everything is the identity;
      * an R transformation other than the identity has no transformer (BuildIntegerTransformationSimple, colortransformerfactory.cpp:681-757) */
     if (ltrafo != 255 || ctrafo != 255) { info->ref_error = -1038; rc = OJ_ERR_MALFORMED; goto late; }
-    if (rtrafo != 255 && rtrafo != 1) { rc = OJ_ERR_UNSUPPORTED; goto out; }
-    ltrafo = rtrafo = 1;
+    if (!lonly && rtrafo != 255 && rtrafo != 1) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+    ltrafo = 1;
+    if (!lonly) rtrafo = 1;
   }
   if (ltrafo == 255) ltrafo = 2;
-  if (rtrafo == 255) rtrafo = 2;
+  /* Tables::RTrafoTypeOf (codestream/tables.cpp:2040-2075) is asked whether there is a residual or not: "Found an invalid
+   * residual transformation" for zero and JPEG_LS; any other value is never used without one */
+  if (lonly && (rtrafo == 0 || rtrafo == 3)) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto late; }
+  if (rtrafo == 255 || lonly) rtrafo = 2;
   /* (what the colour transformer finds: behind both codestreams' verdicts, see `late`) */
   if (ltrafo == 0 || ltrafo == 3 || ltrafo == 4) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto late; } /* "the base transformation ... is invalid" */
   if (rtrafo == 3) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; }
@@ -2806,11 +2819,18 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   /* OBJECT_DOESNT_EXIST "the base / color / residual transformation specified in the codestream does not exist" (colortransformerfactory.cpp:355-400, 528-566) */
   if ((ltrafo >= 5 && !have_mtx[ltrafo]) || (ctrafo != 255 && ctrafo >= 5 && !have_mtx[ctrafo])) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; goto late; }
   if (rtrafo >= 5 && !have_mtx[rtrafo]) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; } /* (looked up beside a residual frame only) */
+  if (ocon < 0 && lonly) ocon = 0x02; /* no output conversion box: no extra bits, clipping (boxes/mergingspecbox.cpp:323-331, 648-656) */
+  /* the lossless flag only changes the residual's side (codestream/tables.cpp:1643, 1687; marker/frame.cpp:595), the output
+   * lookup indices are read and never used by the decoder: without a residual neither matters */
+  if (lonly) ocon &= ~0x09;
   if (ocon < 0 || (ocon & 0x08) || (ocon & 0x01)) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* lossless / output lookup */
   xt.outmax = ((int64_t)1 << (8 + (ocon >> 4))) - 1;
   xt.outshift = (xt.outmax + 1) >> 1;
   xt.is_float = (ocon & 0x04) ? 1 : 0;
   xt.clamp = (ocon & 0x02) ? 1 : 0;
+  /* without a residual only the clamping flavours of the transformer exist (colortransformerfactory.cpp:698-725, 850-885):
+   * INVALID_PARAMETER "The combination of L and R transformation is non-standard and not supported" */
+  if (!xt.clamp && lonly) { info->ref_error = RS_INVALID_PARAMETER; rc = OJ_ERR_MALFORMED; goto late; }
   if (!xt.clamp) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* (wrap-around output: not followed) */
   if (xt.is_float && xt.outmax != 65535) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   /* free-form matrices run through the YCbCr branches of the transformer (colortransformerfactory.cpp:1036-1058) */
@@ -2821,10 +2841,10 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   memcpy(xt.cmat, (ctrafo != 255 && ctrafo >= 5) ? mtx[ctrafo] : std_id, sizeof(xt.cmat));
   xt.rbypass = (rdct >> 4) == 3; xt.rnoise = rdct & 1;
   /* the residual codestream is needed for the table dimensions */
-  rc = oj_read_info(resi->data, resi->len, &rinfo);
+  rc = lonly ? OJ_OK : oj_read_info(resi->data, resi->len, &rinfo);
   /* Image::ParseResidualStream (codestream/image.cpp:1289-1299) compares right behind the residual frame header, where a
    * residual codestream with a DNL marker still has zero lines: "residual image dimensions do not match ..." */
-  if (!rc && (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height)) { rinfo.ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; }
+  if (!rc && !lonly && (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height)) { rinfo.ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; }
   if (rc) {
     /* ... but the reference only gets there behind the legacy codestream's EOI: whatever stops the legacy codestream first
      * is what it reports (and without an EOI it never looks at the residual: not followed here) */
@@ -2832,7 +2852,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     oj_parser ls;
     oj_info ltmp;
     memset(&ls, 0, sizeof(ls)); memset(&ltmp, 0, sizeof(ltmp));
-    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
+    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1;
     for (c = 0; c < nc; c++) {
       planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
       if (!planes[c]) { rc = OJ_ERR_NOMEM; goto out; }
@@ -2860,6 +2880,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     owned[c] = scaled_table(t, 8 + hidden_l, outbits, 0, 0, &rc);
     if (!owned[c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; if (info->ref_error) goto late; goto out; }
     xt.ltable[c] = owned[c];
+    if (lonly) continue; /* (Q and R2 tables are looked up beside a residual frame only, colortransformerfactory.cpp:452, 496) */
     if (pr > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     t = qidx[c] == 255 ? &id0 : &nlt[qidx[c]];
     if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; }
@@ -2873,13 +2894,13 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     xt.r2lut[c] = owned[6 + c];
   }
   /* the residual codestream is an ordinary codestream of its own (codestream/image.cpp:1264-1300) */
-  if (rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp) { rc = OJ_ERR_MALFORMED; goto out; }
+  if (!lonly && (rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp)) { rc = OJ_ERR_MALFORMED; goto out; }
   if (rinfo.precision + hidden_r > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   info->ycbcr = xt.ltrafo_ycbcr;
   for (c = 0; c < nc; c++) {
     planes[c] = (int32_t *)malloc((size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
-    rplanes[c] = (int32_t *)malloc((size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
-    if (!planes[c] || !rplanes[c]) { rc = OJ_ERR_NOMEM; goto out; }
+    rplanes[c] = lonly ? NULL : (int32_t *)malloc((size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
+    if (!planes[c] || (!lonly && !rplanes[c])) { rc = OJ_ERR_NOMEM; goto out; }
   }
   {
     /* visible scans with their bits moved up by the hidden ones, then the hidden refinement scans; from here on both
@@ -2887,17 +2908,17 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     oj_parser ls, rs;
     oj_info ltmp, rtmp;
     memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
-    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l;
-    rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r; rs.nested = 1;
+    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1;
+    if (!lonly) { rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r; rs.nested = 1; }
     for (c = 0; c < nc; c++) {
       memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
-      memset(rplanes[c], 0, (size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
+      if (!lonly) memset(rplanes[c], 0, (size_t)rinfo.bw[c] * rinfo.bh[c] * 64 * sizeof(int32_t));
     }
     rc = walk(&ls, planes);
     if (rc) info->ref_error = ltmp.ref_error;
     /* (hidden scans and residual only behind an EOI, see eoi_frame / eoi_image) */
     if (!rc && ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) info->ref_error = ls.err; }
-    if (!rc && ls.eoi_image) {
+    if (!rc && ls.eoi_image && !lonly) {
       rc = walk(&rs, rplanes);
       if (rc) info->ref_error = rtmp.ref_error;
       if (!rc && rs.eoi_frame) { rc = decode_hidden_scans(&rs, boxes, ps.nboxes, BOXID('R', 'F', 'I', 'N'), rplanes); if (rc) info->ref_error = rs.err; }
@@ -2905,13 +2926,17 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
       xt.no_residual = 1;
     if (rc) goto out; /* (the reference's error code travels in info->ref_error) */
     memcpy(info->cquant, ltmp.cquant, sizeof(ltmp.cquant)); memcpy(info->comp_seen, ltmp.comp_seen, sizeof(ltmp.comp_seen));
-    memcpy(rinfo.cquant, rtmp.cquant, sizeof(rtmp.cquant)); memcpy(rinfo.comp_seen, rtmp.comp_seen, sizeof(rtmp.comp_seen));
+    if (!lonly) { memcpy(rinfo.cquant, rtmp.cquant, sizeof(rtmp.cquant)); memcpy(rinfo.comp_seen, rtmp.comp_seen, sizeof(rtmp.comp_seen)); }
     info->scan_state_valid = ltmp.scan_state_valid; rinfo.scan_state_valid = rtmp.scan_state_valid;
     info->precision += hidden_l;
     rinfo.precision += hidden_r;
   }
-  xt.rinfo = &rinfo; xt.rplanes = rplanes;
+  xt.rinfo = lonly ? NULL : &rinfo; xt.rplanes = rplanes;
   if (is_float) *is_float = xt.is_float;
+  if (lplanes_out) { /* the legacy frame's coefficients as the merge sees them (hidden bits included): the caller's now */
+    for (c = 0; c < nc; c++) { lplanes_out[c] = planes[c]; planes[c] = NULL; }
+    goto out;
+  }
   if (rq_out) {
     /* BlockBitmapRequester::PrepareForDecoding, control/blockbitmaprequester.cpp:298-372: cursors at the first rows of both
      * images, upsamplers for the subsampled components of either */
@@ -2920,7 +2945,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     if (!ctx) { rc = OJ_ERR_NOMEM; goto out; }
     ctx->xt = xt;
     ctx->rinfo = rinfo;
-    ctx->xt.rinfo = &ctx->rinfo;
+    ctx->xt.rinfo = lonly ? NULL : &ctx->rinfo;
     ctx->xt.rplanes = ctx->rplanes;
     rq = oj_requester_new(info, planes);
     if (!rq) { free(ctx); rc = OJ_ERR_NOMEM; goto out; }
@@ -2929,6 +2954,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     rq->owner = ctx;
     for (c = 0; c < nc; c++) {
       ctx->planes[c] = planes[c]; planes[c] = NULL; /* (the requester reads them through rq->planes) */
+      if (lonly) continue;
       ctx->rplanes[c] = rplanes[c]; rplanes[c] = NULL;
       rq->rplanes[c] = ctx->rplanes[c];
       rq->rrows[c] = (rinfo.ch[c] + 7) >> 3;
@@ -2975,20 +3001,28 @@ out:
 
 int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float)
 {
-  return xt_decode_common(data, len, info, pixels, is_float, NULL, 0);
+  return xt_decode_common(data, len, info, pixels, is_float, NULL, 0, NULL);
+}
+
+/* The legacy frame's coefficient planes as the JPEG XT merge sees them -- visible scans moved up by the hidden bits, hidden
+ * refinement scans applied: planes[c] is malloc'ed (bw[c] * bh[c] * 64 int32, free with oj_free); info->precision includes the
+ * hidden bits.  For the tests of the product's host decoder. */
+int oj_decode_xt_planes(const uint8_t *data, size_t len, oj_info *info, int32_t **planes)
+{
+  return xt_decode_common(data, len, info, NULL, NULL, NULL, 0, planes);
 }
 
 /* ... as the reference's command line decodes it with -c (no colour transformation) */
 int oj_decode_xt_ex(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, int disable_to_rgb)
 {
-  return xt_decode_common(data, len, info, pixels, is_float, NULL, disable_to_rgb);
+  return xt_decode_common(data, len, info, pixels, is_float, NULL, disable_to_rgb, NULL);
 }
 
 /* A requester (oj_requester_display / _cursor / _free) on a JPEG XT stream: both codestreams decoded, the residual image's
  * cursors and upsamplers beside the legacy image's.  *out_max = 2^(8 + extra range bits) - 1: samples of 2 bytes above 255. */
 int oj_xt_requester_new(const uint8_t *data, size_t len, oj_info *info, oj_requester **rq, int *is_float, int *out_max)
 {
-  const int rc = xt_decode_common(data, len, info, NULL, is_float, rq, 0);
+  const int rc = xt_decode_common(data, len, info, NULL, is_float, rq, 0, NULL);
   if (!rc && out_max) *out_max = (int)(*rq)->xt->outmax;
   return rc;
 }

@@ -139,6 +139,8 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
 /* ... with disable_to_rgb: what `jpeg -c in.jpg out` shows -- the standard YCbCr L transformation replaced by the identity
  * (colortrafo/colortransformerfactory.cpp:231-232), the rest of the merge unchanged */
 int oj_decode_xt_ex(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, int disable_to_rgb);
+/* the legacy frame's coefficient planes as that merge sees them (hidden refinement scans applied); planes[c]: oj_free */
+int oj_decode_xt_planes(const uint8_t *data, size_t len, oj_info *info, int32_t **planes);
 float oj_half_to_float(uint16_t h);
 
 /* Convenience: whole decode.  *pixels is malloc'ed (free with oj_free). */

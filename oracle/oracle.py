@@ -60,6 +60,7 @@ def lib():
         L.oj_reconstruct16.argtypes = [C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
         L.oj_decode_xt.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.oj_decode_xt_ex.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+        L.oj_decode_xt_planes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
         L.oj_free.argtypes = [C.c_void_p]
         L.oj_forward.argtypes = [C.POINTER(OjInfo), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.oj_fdct_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -171,6 +172,22 @@ def decode_xt(data: bytes):
     out = np.ctypeslib.as_array((C.c_uint16 * n).from_address(px.value)).reshape(info.height, info.width, info.ncomp).copy()
     lib().oj_free(px)
     return out, bool(isf.value)
+
+
+def decode_xt_planes(data: bytes):
+    """JPEG XT: -> (info, planes) of the LEGACY frame as the merge sees it: visible scans moved up by the hidden bits, the hidden
+    refinement scans of the FINE boxes applied (info.precision includes them)."""
+    info = OjInfo()
+    ptrs = (C.c_void_p * 4)()
+    rc = lib().oj_decode_xt_planes(data, len(data), C.byref(info), ptrs)
+    if rc:
+        raise ValueError(f"oracle: oj_decode_xt_planes failed rc={rc}")
+    planes = []
+    for c in range(info.ncomp):
+        n = info.bw[c] * info.bh[c] * 64
+        planes.append(np.ctypeslib.as_array((C.c_int32 * n).from_address(ptrs[c])).reshape(info.bh[c], info.bw[c], 64).copy())
+        lib().oj_free(ptrs[c])
+    return info, planes
 
 
 def decode_xt_status(data: bytes, no_color_transform: bool = False):

@@ -79,14 +79,45 @@ def test_the_box_wins_over_the_adobe_marker(oracle):
     assert a.shape == b.shape and not np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("ocon", [0x00, 0x03, 0x06, 0x12, 0x0A])
-def test_output_conversions_beyond_the_plain_picture_are_declined(ocon):
-    """Wrap-around instead of clamping, output lookup, float cast, extra range bits, lossless: nothing the plain picture has."""
+# (output conversion byte, what the reference binary answers, bytes per sample of its picture)
+OCON_VARIANTS = {0x00: (-1024, 0), 0x04: (-1024, 0), 0x03: (0, 1), 0x0A: (0, 1), 0x12: (0, 2), 0x82: (0, 2)}
+
+
+@pytest.mark.parametrize("ocon", sorted(OCON_VARIANTS))
+def test_output_conversions_beyond_the_plain_picture(oracle, ocon):
+    """Round 4 declined all of these.  Without clamping no transformer exists (INVALID_PARAMETER, colortransformerfactory.cpp:
+    698-725, 850-885); the output lookup indices and the lossless flag change nothing without a residual; extra range bits make
+    the L chain stretch the picture to 8 + n bits (identity L tables scaled by ScaledTableOf).  The reference binary's verdict
+    and picture where it is here, the oracle's, the product's host side."""
+    want, sb = OCON_VARIANTS[ocon]
+    blob = patch(VARIANTS["base"][0], b"OCON", ocon)
+    codes, is_float, oerr = oracle.decode_xt_status(blob)
+    assert oerr == want
+    if oracle.have_reference():
+        rpx, rerr = oracle.reference_decode_status(blob)
+        assert rerr == want
+        if want == 0:
+            assert rpx.dtype.itemsize == sb and np.array_equal(rpx.astype(np.uint16), codes)
     d = api.Decoder(None)
-    with pytest.raises(api.MijpegError) as e:
-        d.read(patch(VARIANTS["base"][0], b"OCON", ocon))
-    assert e.value.code == -1034
+    try:
+        f = d.read(blob)
+        assert want == 0 and f.xt == 1 and f.sample_bytes == sb and d.xt_params().no_residual == 1
+    except api.MijpegError as e:
+        assert e.code == want
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ocon", sorted(k for k, v in OCON_VARIANTS.items() if v[0] == 0))
+def test_gpu_output_conversions_beyond_the_plain_picture(oracle, ocon):
+    blob = patch(VARIANTS["base"][0], b"OCON", ocon)
+    codes, _, err = oracle.decode_xt_status(blob)
+    assert err == 0
+    d = api.Decoder(0)
+    d.read(blob)
+    out = d.reconstruct()
+    d.close()
+    assert out.dtype.itemsize == OCON_VARIANTS[ocon][1] and np.array_equal(out.astype(np.uint16).reshape(codes.shape), codes)
 
 
 @pytest.mark.gpu
