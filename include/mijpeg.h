@@ -135,10 +135,15 @@ typedef struct mijpeg_xt_params {
   int32_t qtable_entries;    /* 2^(residual precision + hidden bits + 4)                                             */
   const int32_t *qtable[3];  /* HOST memory, owned by the decoder object: Q table per component, qtable_entries each;
                                 NULL = the identity (a shift)                                                        */
-  const int32_t *r2table[3]; /* HOST memory: R2 table per component, 2^20 entries; NULL = the identity (x + 8) >> 4  */
-  int32_t no_residual;       /* 1: the legacy codestream never came to an EOI marker, the reference has not parsed the residual
-                                codestream and merges nothing (codestream/image.cpp:1416-1431; rr = m_lOutDCShift,
-                                colortrafo/ycbcrtrafo.cpp:744-746): the residual planes are zeros and the merge ignores them     */
+  const int32_t *r2table[3]; /* HOST memory: R2 table per component, (out_max + 1) << 4 entries (2^20 at 16 bits of output);
+                                NULL = the identity (x + 8) >> 4                                                     */
+  int32_t no_residual;       /* 1: nothing is merged (rr = m_lOutDCShift, colortrafo/ycbcrtrafo.cpp:744-746), the legacy picture goes
+                                through the L chain alone.  Either the legacy codestream never came to an EOI marker and the
+                                reference has not parsed the residual codestream (codestream/image.cpp:1416-1431): the residual
+                                planes are zeros and the merge ignores them.  Or the file has a merging specification and NO
+                                residual codestream (`jpeg -R n` without `-r` from HDR / 16-bit input; the transformer with R
+                                transformation "zero", colortrafo/colortransformerfactory.cpp:262-283): residual.components is 0,
+                                the coefficient store ends behind the legacy planes                                            */
   int32_t ltrafo_standard;   /* 1: the L transformation is the STANDARD YCbCr one (not a free-form matrix): the one a request without
                                 colour transformation (MIJPEG_FLAG_NO_COLOR_TRANSFORM, the command line's -c) replaces by the
                                 identity -- and nothing else of the merge (colortrafo/colortransformerfactory.cpp:231-232)          */

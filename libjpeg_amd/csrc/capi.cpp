@@ -149,20 +149,30 @@ struct BufferCache {
     kept.erase(kept.begin() + best);
     return p;
   }
-  // false: not kept, the caller frees it
-  bool give(int device, bool pinned, void *p, size_t bytes)
+  // would give() keep a buffer like this one right now?
+  bool has_room(int device, bool pinned, size_t bytes)
   {
     static const bool off = getenv("MIJPEG_NO_BUFFER_CACHE") != nullptr; // A-B measurements
     if (off || bytes < ((size_t)1 << 20)) return false;
     std::lock_guard<std::mutex> lock(m);
+    return room_locked(device, pinned, bytes);
+  }
+  // false: not kept, the caller frees it
+  bool give(int device, bool pinned, void *p, size_t bytes)
+  {
+    std::lock_guard<std::mutex> lock(m);
+    if (!room_locked(device, pinned, bytes)) return false;
+    kept.push_back(Entry{p, bytes, device, pinned});
+    return true;
+  }
+  bool room_locked(int device, bool pinned, size_t bytes) const
+  {
     size_t total = bytes, same = 0;
     for (const Entry &e : kept) {
       total += e.bytes;
       same += e.device == device && e.pinned == pinned;
     }
-    if (same >= 4 || total > limit_bytes()) return false;
-    kept.push_back(Entry{p, bytes, device, pinned});
-    return true;
+    return same < 4 && total <= limit_bytes();
   }
   // MIJPEG_BUFFER_CACHE_MB: what the cache may hold in all (default 2048, 0 = keep nothing)
   static size_t limit_bytes()
@@ -208,8 +218,18 @@ static void release_big(int device, bool pinned, void *p, size_t bytes)
   // hipFree / hipHostFree wait for the device before they take the memory away, and the buffers were handed to clients
   // (mijpeg_device_coefficients, mijpeg_batch: kernels on the client's own streams may still read them).  A buffer that changes
   // hands through the cache instead gets the same guarantee: nothing on the device is in flight when the next owner writes it.
-  if (bytes >= ((size_t)1 << 20) && device >= 0) (void)hipDeviceSynchronize();
-  if (buffer_cache().give(device, pinned, p, bytes)) return;
+  // Only a buffer that actually enters the cache needs it spelled out (and only its own device has to be idle): growing a
+  // workspace in the middle of a pipeline must not stall every stream of the process for a buffer that is freed anyway.
+  if (buffer_cache().has_room(device, pinned, bytes)) {
+    if (device >= 0) {
+      int cur = -1;
+      (void)hipGetDevice(&cur);
+      if (cur != device) (void)hipSetDevice(device);
+      (void)hipDeviceSynchronize();
+      if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    }
+    if (buffer_cache().give(device, pinned, p, bytes)) return; // (another thread may have filled the room meanwhile: freed then)
+  }
   if (pinned) (void)hipHostFree(p);
   else (void)hipFree(p);
 }
@@ -420,7 +440,7 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   }
   // (a JPEG XT frame whose damaged scans leave the 16-bit store: the reference goes on in LONG coefficients, this path has no
   // int32 planes for merged frames -- declined like every other subset it does not take, not reported as the stream's fault)
-  if (rc == MIJPEG_ERR_OVERFLOW_PARAMETER && d->host.is_xt() && d->host.error.message.find("coefficient store") != std::string::npos)
+  if (rc == MIJPEG_ERR_OVERFLOW_PARAMETER && d->host.is_xt() && d->host.left_16bit_store())
     return set_error(d, MIJPEG_ERR_OPERATION_UNIMPLEMENTED, "JPEG XT frame with coefficients beyond the 16-bit store (a damaged scan) is not on the accelerated path");
   if (rc) return set_error(d, rc, d->host.error.message);
   if (d->device >= 0 && d->host.residual() && copy_err == hipSuccess) {

@@ -162,6 +162,8 @@ public:
   // JPEG XT profile C: parameters and the decoder of the residual codestream (RESI box); null for plain JPEG
   // (... or a merging specification that sends the legacy picture alone through the L chain: xt.no_residual, no residual())
   bool is_xt() const { return residual_ != nullptr || lonly_; }
+  // the last decode() stopped at a coefficient beyond the 16-bit store: decode_wide() is the next step (plain JPEG), or a refusal
+  bool left_16bit_store() const { return left_16bit_store_; }
   mijpeg_xt_params xt{};
   std::vector<Scan> scans;
   StreamError error;
@@ -217,6 +219,8 @@ private:
   std::vector<int32_t> xt_q_[3], xt_r2_[3]; // Q / R2 tables of a JPEG XT stream when they are not the identities (xt.qtable / r2table point here)
   HostDecoder *residual_ = nullptr;
   bool lonly_ = false; // JPEG XT without a residual codestream: the L chain alone (finish_xt)
+  bool ignore_residual_ = false; // late_verdict parses again: the legacy codestream has no EOI, the residual codestream is never looked at
+  bool left_16bit_store_ = false; // the last decode stopped at a coefficient beyond the 16-bit store (OVERFLOW_PARAMETER): int32 planes next
   bool nested_ = false; // this object decodes a residual codestream
   int hidden_ = 0;      // JPEG XT: low bits of every coefficient that arrive in hidden refinement scans
   bool parsing_hidden_ = false;

@@ -2702,9 +2702,16 @@ done:
 /* disable_to_rgb: a request without colour transformation (cmd/reconstruct.cpp -c -> rr_bColorTrafo false ->
  * ColorTransformerFactory::BuildColorTransformer(.., disabletorgb)): the standard YCbCr L transformation becomes the identity,
  * nothing else changes (colortrafo/colortransformerfactory.cpp:231-232) */
-static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, oj_requester **rq_out, int disable_to_rgb,
+/* flags: XT_DISABLE_TO_RGB; XT_IGNORE_RESIDUAL (internal): the legacy codestream has no EOI, the reference never gets to the residual
+ * codestream (codestream/image.cpp:1416-1431) -- whatever is wrong with it or with the tables of its side -- and shows the legacy
+ * picture through the L chain alone */
+#define XT_DISABLE_TO_RGB 1
+#define XT_IGNORE_RESIDUAL 2
+static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, oj_requester **rq_out, int flags,
                             int32_t **lplanes_out)
 {
+  const int disable_to_rgb = flags & XT_DISABLE_TO_RGB;
+  int retry_lonly = 0;
   oj_box boxes[OJ_MAX_BOXES];
   oj_parser ps;
   oj_info rinfo;
@@ -2733,6 +2740,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     if (boxes[b].type == BOXID('S', 'P', 'E', 'C')) spec = &boxes[b];
     if (boxes[b].type == BOXID('R', 'E', 'S', 'I')) resi = &boxes[b];
   }
+  if ((flags & XT_IGNORE_RESIDUAL) && spec) resi = NULL;
   if (resi && !spec && info->ncomp <= 4) {
     /* A residual codestream and no merging specification (its APP11 segment damaged, or its box never complete): the command
      * line reads the whole file first (cmd/reconstruct.cpp:119-121) -- whatever stops either codestream is reported -- and the
@@ -2862,7 +2870,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     if (!rc && ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) info->ref_error = ls.err; }
     if (!rc) {
       if (ls.eoi_image) { rc = rrc; info->ref_error = rerr; }
-      else rc = OJ_ERR_UNSUPPORTED;
+      else retry_lonly = 1; /* the residual codestream that does not parse is never looked at */
     }
     goto out;
   }
@@ -2988,7 +2996,7 @@ late:
     int verr = 0, eoi = 0;
     rc = xt_codestreams_verdict(data, len, info, boxes, ps.nboxes, resi, hidden_l, hidden_r, &verr, &eoi);
     if (rc) info->ref_error = verr;
-    else if (!eoi && late_residual_only) { rc = OJ_ERR_UNSUPPORTED; info->ref_error = 0; }
+    else if (!eoi && late_residual_only) { retry_lonly = 1; info->ref_error = 0; }
     else { rc = lrc; info->ref_error = lerr; }
   }
 out:
@@ -2996,6 +3004,7 @@ out:
   for (c = 0; c < 16; c++) free(nlt[c].lut);
   for (c = 0; c < 9; c++) free(owned[c]);
   free_boxes(boxes, ps.nboxes);
+  if (retry_lonly && !(flags & XT_IGNORE_RESIDUAL)) return xt_decode_common(data, len, info, pixels, is_float, rq_out, flags | XT_IGNORE_RESIDUAL, lplanes_out);
   return rc;
 }
 
@@ -3015,7 +3024,7 @@ int oj_decode_xt_planes(const uint8_t *data, size_t len, oj_info *info, int32_t 
 /* ... as the reference's command line decodes it with -c (no colour transformation) */
 int oj_decode_xt_ex(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, int disable_to_rgb)
 {
-  return xt_decode_common(data, len, info, pixels, is_float, NULL, disable_to_rgb, NULL);
+  return xt_decode_common(data, len, info, pixels, is_float, NULL, disable_to_rgb ? XT_DISABLE_TO_RGB : 0, NULL);
 }
 
 /* A requester (oj_requester_display / _cursor / _free) on a JPEG XT stream: both codestreams decoded, the residual image's
