@@ -318,6 +318,22 @@ int mijpeg_display_cursor(mijpeg_decoder *d, int component);
  * smaller) or a negative error. */
 int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_byte, int capacity);
 
+/* JPEG XT alpha channel (the reference: Image::ParseAlphaChannel, codestream/image.cpp:1337-1404; JPEG::GetInformation's
+ * JPGTAG_ALPHA_MODE / JPGTAG_ALPHA_TAGLIST / JPGTAG_ALPHA_MATTE, interface/jpeg.cpp:870-945; JPEG::DisplayRectangle with
+ * JPGTAG_BIH_ALPHAHOOK and JPGTAG_DECODER_INCLUDE_ALPHA, codestream/image.cpp:1087-1123, cmd/reconstruct.cpp:154-217, 268-319).
+ * The alpha channel is an image of its own -- one component, its own tables, optionally its own residual codestream and hidden
+ * refinement scans, its own merging specification -- that the reference decodes inside JPEG::Read behind the picture's
+ * codestreams: mijpeg_decode_coefficients (host or device) decodes it as well, and what is wrong with it fails that call like it
+ * fails JPEG::Read.  The decoder does not composite: the plane is handed out beside the picture.
+ * mijpeg_alpha_channel: the decoder object of the alpha image, owned by `d` and valid until `d` decodes again or is destroyed; every
+ * call that works on a decoded object works on it (mijpeg_get_info, mijpeg_get_xt_params, mijpeg_reconstruct_rect,
+ * mijpeg_display_rect with cursors of its own, mijpeg_coefficients).  NULL (and MIJPEG_ERR_OBJECT_DOESNT_EXIST on `d`) when the
+ * decoded file has none -- no complete ALFA box, or a legacy codestream that never came to its EOI.
+ * mijpeg_alpha_info: *mode = the compositing method of the AMUL box (0 opaque, 1 regular, 2 premultiplied, 3 matte removal;
+ * -1: the alpha merging specification has no such box and JPEG::GetInformation reports no alpha channel), matte = its colour. */
+mijpeg_decoder *mijpeg_alpha_channel(mijpeg_decoder *d);
+int mijpeg_alpha_info(mijpeg_decoder *d, int32_t *mode, int32_t matte[3]);
+
 /* Error of the last failing call on this object (JPEG::LastError). Returns the code, 0 if none. */
 int mijpeg_last_error(mijpeg_decoder *d, const char **message);
 

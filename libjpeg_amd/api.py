@@ -142,6 +142,9 @@ def lib():
         L.mijpeg_host_free.argtypes = [C.c_void_p]
         L.mijpeg_host_free.restype = None
         L.mijpeg_last_error.argtypes = [C.c_void_p, P(C.c_char_p)]
+        L.mijpeg_alpha_channel.argtypes = [C.c_void_p]
+        L.mijpeg_alpha_channel.restype = C.c_void_p
+        L.mijpeg_alpha_info.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_int32)]
         L.mijpeg_last_timing.argtypes = [C.c_void_p, P(C.c_double)]
         L.mijpeg_launch_reconstruct.argtypes = [P(MijpegBatch), C.c_void_p]
         L.mijpeg_kernel_name.argtypes = [P(MijpegBatch)]
@@ -174,8 +177,31 @@ class Decoder:
 
     def close(self):
         if self._h:
-            lib().mijpeg_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                lib().mijpeg_destroy(self._h)
             self._h = C.c_void_p()
+
+    def alpha_channel(self) -> "Decoder | None":
+        """The decoder object of the file's alpha channel (JPEG XT ALFA box), owned by this one and valid until it reads again; None
+        when the decoded file has none.  Its `info` is the alpha image's (one component)."""
+        h = lib().mijpeg_alpha_channel(self._h)
+        if not h:
+            return None
+        a = Decoder.__new__(Decoder)
+        a._h = C.c_void_p(h)
+        a._borrowed = True
+        a._data = None
+        a._owner = self  # keep the owning object alive
+        a.info = MijpegInfo()
+        a._check(lib().mijpeg_get_info(a._h, C.byref(a.info)))
+        return a
+
+    def alpha_info(self):
+        """-> (mode, (r, g, b)): compositing method and matte colour of the alpha merging specification's AMUL box (mode -1: none)."""
+        mode = C.c_int32(-1)
+        matte = (C.c_int32 * 3)()
+        self._check(lib().mijpeg_alpha_info(self._h, C.byref(mode), matte))
+        return mode.value, tuple(matte)
 
     def __del__(self):
         try:

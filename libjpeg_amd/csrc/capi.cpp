@@ -68,6 +68,11 @@ struct mijpeg_decoder {
   bool host_planes_stale = false; // coefficients live on the device only
   double phase_prepare = 0, phase_device = 0; // last device entropy decode: host tables / upload + kernel
   mijpeg_decoder *xt_helper = nullptr; // JPEG XT: second context that entropy-decodes the residual codestream concurrently
+  // JPEG XT alpha channel: an image of its own (ALFA box), decoded by a decoder object of its own that this one owns
+  // (mijpeg_alpha_channel); its codestream is copied here because every parse of the file rebuilds the boxes
+  mijpeg_decoder *alpha = nullptr;
+  bool alpha_ready = false;
+  std::vector<uint8_t> alpha_data;
   uint8_t *enc_dev = nullptr; // encoder direction: pixels + coefficients of one picture
   size_t enc_cap = 0;
   uint8_t *henc_dev[2] = {nullptr, nullptr}, *henc_out_dev[2] = {nullptr, nullptr}; // device entropy coder, two jobs: arrays; streams
@@ -324,6 +329,7 @@ void mijpeg_destroy(mijpeg_decoder *d)
   } else {
     free(d->coef_host);
   }
+  if (d->alpha) mijpeg_destroy(d->alpha);
   delete d;
 }
 
@@ -386,6 +392,41 @@ static int ensure_coef_store(mijpeg_decoder *d, size_t count, bool need_host = t
       d->coef_dev_cap = count;
     }
   }
+  return MIJPEG_OK;
+}
+
+// The alpha channel of a JPEG XT file: the reference turns to the ALFA box behind the legacy codestream's EOI (and the residual
+// codestream), inside JPEG::Read (Image::ParseTrailer, codestream/image.cpp:1430-1460): what is wrong with it fails the read,
+// whether or not the client will ask for alpha.  Here a decoder object of its own -- same device, the file's boxes under the
+// names an image's decoder looks for (HostDecoder::alpha_boxes) -- decodes it right behind the picture's codestreams.
+static int decode_alpha_channel(mijpeg_decoder *d, int threads)
+{
+  d->alpha_ready = false;
+  if (!d->host.has_alpha()) return MIJPEG_OK;
+  const uint8_t *p = nullptr;
+  size_t n = 0;
+  if (!d->host.alpha_stream(&p, &n)) return MIJPEG_OK;
+  if (!d->alpha && mijpeg_create(&d->alpha, d->device) != MIJPEG_OK)
+    return set_error(d, MIJPEG_ERR_OUT_OF_MEMORY, "no decoder object for the alpha channel");
+  d->alpha_data.assign(p, p + n);
+  d->alpha->host.preset_boxes(d->host.alpha_boxes());
+  int rc = n ? mijpeg_set_input(d->alpha, d->alpha_data.data(), n)
+             : set_error(d->alpha, MIJPEG_ERR_MALFORMED_STREAM, "Alpha channel codestream is invalid, SOI marker missing.");
+  if (!rc) rc = mijpeg_decode_coefficients(d->alpha, threads);
+  if (!rc) {
+    const mijpeg_info &a = d->alpha->host.info, &f = d->host.info;
+    if (a.width != f.width || a.height != f.height) // codestream/image.cpp:1370-1380
+      rc = set_error(d->alpha, MIJPEG_ERR_MALFORMED_STREAM, "Malformed stream - residual image dimensions do not match the dimensions of the legacy image");
+    else if (a.components != 1)
+      rc = set_error(d->alpha, MIJPEG_ERR_MALFORMED_STREAM, "Malformed stream - the alpha channel may only consist of a single component");
+  }
+  if (rc) {
+    const char *m = nullptr;
+    mijpeg_last_error(d->alpha, &m);
+    d->decoded = false; // the read has failed: no picture either (JPEG::Read returns false)
+    return set_error(d, rc, m ? m : "the alpha channel does not decode");
+  }
+  d->alpha_ready = true;
   return MIJPEG_OK;
 }
 
@@ -454,7 +495,7 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
     (void)hipEventRecord(d->ev1, d->stream);
     d->uploaded = true;
   }
-  return MIJPEG_OK;
+  return decode_alpha_channel(d, threads);
 }
 
 int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, uint32_t *begin, size_t n_begin, size_t piece_bytes,
@@ -1293,7 +1334,7 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
   d->decoded = true;
   d->uploaded = true;
   d->host_planes_stale = true;
-  return MIJPEG_OK;
+  return decode_alpha_channel(d, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1545,6 +1586,25 @@ int mijpeg_last_error(mijpeg_decoder *d, const char **message)
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (message) *message = d->err_code ? d->err_msg.c_str() : nullptr;
   return d->err_code;
+}
+
+mijpeg_decoder *mijpeg_alpha_channel(mijpeg_decoder *d)
+{
+  if (!d) return nullptr;
+  if (!d->decoded || !d->alpha_ready) {
+    set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "the decoded stream has no alpha channel");
+    return nullptr;
+  }
+  return d->alpha;
+}
+
+int mijpeg_alpha_info(mijpeg_decoder *d, int32_t *mode, int32_t matte[3])
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (!d->decoded || !d->alpha_ready) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "the decoded stream has no alpha channel");
+  if (mode) *mode = d->host.alpha_mode();
+  for (int k = 0; k < 3 && matte; k++) matte[k] = (int32_t)d->host.alpha_matte()[k];
+  return MIJPEG_OK;
 }
 
 int mijpeg_last_warning(mijpeg_decoder *d, const char **message)

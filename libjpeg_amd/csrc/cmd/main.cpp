@@ -1,11 +1,12 @@
 // main.cpp -- `jpeg` command line front end of the MI355X path: the decode half of the reference CLI.
-//   jpeg [-c] [-U] [-t threads] [-d device] in.jpg out.ppm
+//   jpeg [-c] [-U] [-al alpha.pgm] [-t threads] [-d device] in.jpg out.ppm
 // reproduces cmd/main.cpp:746-747 -> cmd/reconstruct.cpp:68-376 for the streams this path handles: the
 // image (8 bit -> PNM, 12 bit -> 16-bit PNM, JPEG XT profile C -> PFM) is reconstructed stripe by stripe (eight lines per JPEG::DisplayRectangle call) through a file I/O
 // hook and a bitmap hook, and written as binary PNM (P6 for three components, P5 for one) -- byte for
 // byte what the reference binary writes.  -c disables the colour transformation (reference: -c); -U disables the
 // upsampling (reference: -U): like images with neither one nor three components, the components then go one by one
-// into PGX files (out_N.h + out_N.raw, listed in `out`), cmd/reconstruct.cpp:208-306.
+// into PGX files (out_N.h + out_N.raw, listed in `out`), cmd/reconstruct.cpp:208-306.  -al names the file the alpha channel of a
+// JPEG XT file goes to (PGM / 16-bit PGM / one-channel PFM), cmd/reconstruct.cpp:154-217, 319-342: no compositing, like the reference.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -114,7 +115,7 @@ static JPG_LONG BitmapHook(struct JPG_Hook *hook, struct JPG_TagItem *tags)
   return 0;
 }
 
-static int Reconstruct(const char *infile, const char *outfile, bool colortrafo, bool upsample, int threads, int device)
+static int Reconstruct(const char *infile, const char *outfile, bool colortrafo, const char *alpha, bool upsample, int threads, int device)
 {
   FILE *in = fopen(infile, "rb");
   if (!in) { perror("failed to open the input file"); return 10; }
@@ -128,9 +129,13 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
   int ok = jpeg->Read(rtags);
   if (ok) {
     unsigned char subx[4], suby[4];
+    // cmd/reconstruct.cpp:126-146: the alpha channel's description arrives in a tag list of its own
+    struct JPG_TagItem atags[] = {JPG_ValueTag(JPGTAG_IMAGE_PRECISION, 0), JPG_ValueTag(JPGTAG_IMAGE_IS_FLOAT, 0),
+                                  JPG_ValueTag(JPGTAG_IMAGE_OUTPUT_CONVERSION, 1), JPG_EndTag};
     struct JPG_TagItem itags[] = {JPG_ValueTag(JPGTAG_IMAGE_WIDTH, 0), JPG_ValueTag(JPGTAG_IMAGE_HEIGHT, 0), JPG_ValueTag(JPGTAG_IMAGE_DEPTH, 0),
                                   JPG_ValueTag(JPGTAG_IMAGE_PRECISION, 0), JPG_ValueTag(JPGTAG_IMAGE_IS_FLOAT, 0),
-                                  JPG_ValueTag(JPGTAG_IMAGE_OUTPUT_CONVERSION, 0), JPG_PointerTag(JPGTAG_IMAGE_SUBX, subx),
+                                  JPG_ValueTag(JPGTAG_IMAGE_OUTPUT_CONVERSION, 0), JPG_ValueTag(JPGTAG_ALPHA_MODE, JPGFLAG_ALPHA_OPAQUE),
+                                  JPG_PointerTag(JPGTAG_ALPHA_TAGLIST, atags), JPG_PointerTag(JPGTAG_IMAGE_SUBX, subx),
                                   JPG_PointerTag(JPGTAG_IMAGE_SUBY, suby), JPG_ValueTag(JPGTAG_IMAGE_SUBLENGTH, 4), JPG_EndTag};
     ok = jpeg->GetInformation(itags);
     if (ok) {
@@ -138,7 +143,11 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
       const unsigned depth = itags->GetTagData(JPGTAG_IMAGE_DEPTH), prec = itags->GetTagData(JPGTAG_IMAGE_PRECISION);
       const bool pfm = itags->GetTagData(JPGTAG_IMAGE_IS_FLOAT) != 0, convert = itags->GetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION) != 0;
       const bool writepgx = (depth != 1 && depth != 3) || !upsample; // cmd/reconstruct.cpp:218-222
-      if (depth > 4 || prec > 16 || (pfm && (!convert || writepgx))) {
+      // cmd/reconstruct.cpp:154-166: an alpha file name and a compositing method other than "opaque" -- else alpha is ignored
+      const bool doalpha = alpha && itags->GetTagData(JPGTAG_ALPHA_MODE, JPGFLAG_ALPHA_OPAQUE) != 0 && !writepgx;
+      const unsigned aprec = doalpha ? atags->GetTagData(JPGTAG_IMAGE_PRECISION) : 0;
+      const bool apfm = doalpha && atags->GetTagData(JPGTAG_IMAGE_IS_FLOAT) != 0, aconvert = doalpha && atags->GetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION) != 0;
+      if (depth > 4 || prec > 16 || (pfm && (!convert || writepgx)) || aprec > 16 || (apfm && !aconvert)) {
         fprintf(stderr, "only images of up to four components of up to 16 bits (PNM/PGX), or JPEG XT profile C with output conversion (PFM), are written by this front end\n");
         ok = 0; rc = 5;
       } else {
@@ -151,6 +160,17 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
         sb.pgx = writepgx;
         memset(sb.pgxfiles, 0, sizeof(sb.pgxfiles));
         sb.target = fopen(outfile, "wb");
+        StripeBuffer asb; // the alpha channel's stripe: one component (cmd/reconstruct.cpp:182-196)
+        memset(&asb, 0, sizeof(asb));
+        if (doalpha) {
+          asb.bytes = aprec > 8 ? 2 : 1;
+          asb.halffloat = apfm;
+          asb.mem = (unsigned char *)malloc((size_t)width * 8 * asb.bytes);
+          asb.width = width; asb.height = height; asb.depth = 1;
+          asb.upsampling = true;
+          asb.target = fopen(alpha, "wb");
+          if (!asb.mem || !asb.target) { perror("failed to open the alpha output file"); ok = 0; rc = 10; }
+        }
         if (upsample) { // cmd/reconstruct.cpp:227-232: the subsampling factors are all implicitly 1 then
           memset(subx, 1, sizeof(subx));
           memset(suby, 1, sizeof(suby));
@@ -187,21 +207,27 @@ static int Reconstruct(const char *infile, const char *outfile, bool colortrafo,
           for (unsigned i = 0; i < depth; i++)
             if (sb.pgxfiles[i]) fclose(sb.pgxfiles[i]);
         } else {
-          struct JPG_Hook bmhook(BitmapHook, &sb);
+          struct JPG_Hook bmhook(BitmapHook, &sb), alphahook(BitmapHook, &asb);
           // cmd/reconstruct.cpp:321-323
           fprintf(sb.target, "P%c\n%u %u\n%u\n", pfm ? (depth > 1 ? 'F' : 'f') : (depth > 1 ? '6' : '5'), width, height,
                   pfm ? 1u : (1u << prec) - 1);
+          if (doalpha && asb.target) // cmd/reconstruct.cpp:325-328
+            fprintf(asb.target, "P%c\n%u %u\n%u\n", apfm ? 'f' : '5', width, height, apfm ? 1u : (1u << aprec) - 1);
           for (unsigned y = 0; y < height && ok; y += 8) { // cmd/reconstruct.cpp:334-342
             const unsigned last = y + 8 < height ? y + 8 : height;
-            struct JPG_TagItem dtags[] = {JPG_PointerTag(JPGTAG_BIH_HOOK, &bmhook), JPG_ValueTag(JPGTAG_DECODER_MINY, y),
+            struct JPG_TagItem dtags[] = {JPG_PointerTag(JPGTAG_BIH_HOOK, &bmhook), JPG_PointerTag(JPGTAG_BIH_ALPHAHOOK, &alphahook),
+                                          JPG_ValueTag(JPGTAG_DECODER_MINY, y),
                                           JPG_ValueTag(JPGTAG_DECODER_MAXY, last - 1), JPG_ValueTag(JPGTAG_DECODER_UPSAMPLE, 1),
                                           JPG_ValueTag(JPGTAG_MATRIX_LTRAFO, colortrafo ? JPGFLAG_MATRIX_COLORTRANSFORMATION_YCBCR
                                                                                          : JPGFLAG_MATRIX_COLORTRANSFORMATION_NONE),
+                                          JPG_ValueTag(JPGTAG_DECODER_INCLUDE_ALPHA, doalpha && asb.target ? 1 : 0),
                                           JPG_EndTag};
             ok = jpeg->DisplayRectangle(dtags);
           }
         }
         if (sb.target) fclose(sb.target);
+        if (asb.target) fclose(asb.target);
+        free(asb.mem);
         free(sb.mem);
       }
     }
@@ -313,7 +339,7 @@ int main(int argc, char **argv)
   bool colortrafo = true, upsample = true;
   int threads = 0, device = -1;
   int quality = -1, restart = 0;
-  const char *sub = NULL;
+  const char *sub = NULL, *alpha = NULL;
   bool optimize = false;
   while (argc > 3) {
     if (!strcmp(argv[1], "-q") && argc > 4) { quality = atoi(argv[2]); argv += 2; argc -= 2; continue; }
@@ -323,12 +349,13 @@ int main(int argc, char **argv)
     if (!strcmp(argv[1], "-bl")) { argv++; argc--; continue; } // baseline is what the encoder writes anyway
     if (!strcmp(argv[1], "-c")) { colortrafo = false; argv++; argc--; }
     else if (!strcmp(argv[1], "-U")) { upsample = false; argv++; argc--; }
+    else if (!strcmp(argv[1], "-al") && argc > 4) { alpha = argv[2]; argv += 2; argc -= 2; }
     else if (!strcmp(argv[1], "-t") && argc > 4) { threads = atoi(argv[2]); argv += 2; argc -= 2; }
     else if (!strcmp(argv[1], "-d") && argc > 4) { device = atoi(argv[2]); argv += 2; argc -= 2; }
     else break;
   }
   if (argc != 3) {
-    fprintf(stderr, "usage: %s [-c] [-U] [-t threads] [-d device] source.jpg target.ppm\n"
+    fprintf(stderr, "usage: %s [-c] [-U] [-al alpha.pgm] [-t threads] [-d device] source.jpg target.ppm\n"
                     "  reconstructs a Huffman sequential JPEG on an MI355X and writes a binary PNM,\n"
                     "  byte-identical to the output of the reference `jpeg source.jpg target.ppm`\n"
                     "       %s -q quality [-bl] [-s 1x1,2x2,2x2] [-z restart-interval] [-h] [-d device] source.ppm target.jpg\n"
@@ -336,5 +363,5 @@ int main(int argc, char **argv)
     return 5;
   }
   if (quality >= 0) return Encode(argv[1], argv[2], quality, sub, restart, optimize, device);
-  return Reconstruct(argv[1], argv[2], colortrafo, upsample, threads, device);
+  return Reconstruct(argv[1], argv[2], colortrafo, alpha, upsample, threads, device);
 }

@@ -162,6 +162,16 @@ public:
   // JPEG XT profile C: parameters and the decoder of the residual codestream (RESI box); null for plain JPEG
   // (... or a merging specification that sends the legacy picture alone through the L chain: xt.no_residual, no residual())
   bool is_xt() const { return residual_ != nullptr || lonly_; }
+  // JPEG XT alpha channel (after a parse of the whole file): the file has a complete ALFA box and the legacy codestream came to
+  // the EOI behind which the reference turns to it (codestream/image.cpp:1430-1460); its codestream; the boxes its decoder sees;
+  // compositing method (-1: no AMUL box) and matte colour of the alpha merging specification (interface/jpeg.cpp:919-945)
+  bool has_alpha() const { return have_alpha_ && eoi_image_; }
+  bool alpha_stream(const uint8_t **data, size_t *size) const;
+  std::vector<XtBox> alpha_boxes() const;
+  int alpha_mode() const { return alpha_mode_; }
+  const uint32_t *alpha_matte() const { return alpha_matte_; }
+  // this object decodes an alpha channel's codestream: `boxes` are the file's, translated (alpha_boxes of the file's decoder)
+  void preset_boxes(std::vector<XtBox> boxes) { preset_boxes_ = std::move(boxes); alpha_child_ = true; }
   // the last decode() stopped at a coefficient beyond the 16-bit store: decode_wide() is the next step (plain JPEG), or a refusal
   bool left_16bit_store() const { return left_16bit_store_; }
   mijpeg_xt_params xt{};
@@ -219,6 +229,10 @@ private:
   std::vector<int32_t> xt_q_[3], xt_r2_[3]; // Q / R2 tables of a JPEG XT stream when they are not the identities (xt.qtable / r2table point here)
   HostDecoder *residual_ = nullptr;
   bool lonly_ = false; // JPEG XT without a residual codestream: the L chain alone (finish_xt)
+  bool have_alpha_ = false, alpha_child_ = false;
+  int alpha_mode_ = -1;
+  uint32_t alpha_matte_[3] = {0, 0, 0};
+  std::vector<XtBox> preset_boxes_;
   bool ignore_residual_ = false; // late_verdict parses again: the legacy codestream has no EOI, the residual codestream is never looked at
   bool left_16bit_store_ = false; // the last decode stopped at a coefficient beyond the 16-bit store (OVERFLOW_PARAMETER): int32 planes next
   bool nested_ = false; // this object decodes a residual codestream

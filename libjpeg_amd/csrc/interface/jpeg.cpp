@@ -355,14 +355,17 @@ JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
   tags->SetTagData(JPGTAG_IMAGE_DEPTH, f.components);
   // JPEG XT: the image precision includes the extra range bits of the output conversion (8 + 8 for the encoder's HDR files,
   // 8 + 0 for its integer ones)
-  int prec = f.precision;
-  if (f.xt) {
-    mijpeg_xt_params x;
-    prec = 16;
-    if (mijpeg_get_xt_params(p->dec, &x) == MIJPEG_OK)
-      for (prec = 1; (1 << prec) <= x.out_max; prec++) {}
-  }
-  tags->SetTagData(JPGTAG_IMAGE_PRECISION, prec);
+  auto precision_of = [](mijpeg_decoder *dec, const mijpeg_info &g) {
+    int prec = g.precision;
+    if (g.xt) {
+      mijpeg_xt_params x;
+      prec = 16;
+      if (mijpeg_get_xt_params(dec, &x) == MIJPEG_OK)
+        for (prec = 1; (1 << prec) <= x.out_max; prec++) {}
+    }
+    return prec;
+  };
+  tags->SetTagData(JPGTAG_IMAGE_PRECISION, precision_of(p->dec, f));
   const JPG_LONG n = tags->GetTagData(JPGTAG_IMAGE_SUBLENGTH, 0);
   if (n > 0) {
     uint8_t *sx = (uint8_t *)tags->GetTagPtr(JPGTAG_IMAGE_SUBX), *sy = (uint8_t *)tags->GetTagPtr(JPGTAG_IMAGE_SUBY);
@@ -377,9 +380,29 @@ JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
   // (IS_FLOAT) which the client expands itself (OUTPUT_CONVERSION); plain JPEG: integer output
   tags->SetTagData(JPGTAG_IMAGE_IS_FLOAT, f.xt && f.is_float ? 1 : 0);
   tags->SetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION, f.xt && f.is_float ? 1 : 0);
-  // no alpha channel: the reference neutralises these two tags (jpeg.cpp:946-951)
-  if (struct JPG_TagItem *t = tags->FindTagItem(JPGTAG_ALPHA_MODE)) t->ti_Tag = JPGTAG_TAG_IGNORE;
-  if (struct JPG_TagItem *t = tags->FindTagItem(JPGTAG_ALPHA_TAGLIST)) t->ti_Tag = JPGTAG_TAG_IGNORE;
+  // The alpha channel (interface/jpeg.cpp:919-951): with an alpha merging specification that carries a compositing box and an
+  // alpha image that has been read, the method, the matte colour and -- in the client's JPGTAG_ALPHA_TAGLIST -- precision and
+  // output conversion of the alpha image; without, the reference neutralises the two tags
+  struct JPG_TagItem *alphatag = tags->FindTagItem(JPGTAG_ALPHA_MODE), *alphalist = tags->FindTagItem(JPGTAG_ALPHA_TAGLIST);
+  int32_t mode = -1, matte[3] = {0, 0, 0};
+  mijpeg_decoder *adec = mijpeg_alpha_channel(p->dec);
+  mijpeg_info a;
+  if (adec && mijpeg_alpha_info(p->dec, &mode, matte) == MIJPEG_OK && mode >= 0 && mijpeg_get_info(adec, &a) == MIJPEG_OK) {
+    if (alphatag) alphatag->ti_Data.ti_lData = mode;
+    for (int k = 0; k < 3; k++) tags->SetTagData(JPGTAG_ALPHA_MATTE(k), matte[k]);
+    if (alphalist) {
+      struct JPG_TagItem *al = (struct JPG_TagItem *)alphalist->ti_Data.ti_pPtr;
+      if (al) {
+        // (Image::PrecisionOf of the alpha image: its frame's precision plus the extra range bits of ITS specification)
+        al->SetTagData(JPGTAG_IMAGE_PRECISION, precision_of(adec, a));
+        al->SetTagData(JPGTAG_IMAGE_IS_FLOAT, a.xt && a.is_float ? 1 : 0);
+        al->SetTagData(JPGTAG_IMAGE_OUTPUT_CONVERSION, a.xt && a.is_float ? 1 : 0);
+      }
+    }
+  } else {
+    if (alphatag) alphatag->ti_Tag = JPGTAG_TAG_IGNORE;
+    if (alphalist) alphalist->ti_Tag = JPGTAG_TAG_IGNORE;
+  }
   return JPG_TRUE;
 }
 
@@ -391,8 +414,8 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
   const mijpeg_info &f = p->info;
   // codestream/rectanglerequest.cpp:62-190: defaults = whole canvas, requests are clipped, negatives are errors
   JPG_LONG minx = 0, miny = 0, maxx = f.width - 1, maxy = f.height - 1, c0 = 0, c1 = f.components - 1;
-  bool upsample = true, ctrafo = true, device_bitmaps = false;
-  struct JPG_Hook *bmh = nullptr;
+  bool upsample = true, ctrafo = true, device_bitmaps = false, include_alpha = false;
+  struct JPG_Hook *bmh = nullptr, *alphahook = nullptr;
   for (const struct JPG_TagItem *t = tags ? tags->FirstTagItem() : nullptr; t; t = t->NextTagItem()) {
     const JPG_LONG v = t->ti_Data.ti_lData;
     switch (t->ti_Tag) {
@@ -405,6 +428,8 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
     case JPGTAG_DECODER_UPSAMPLE: upsample = v != 0; break;
     case JPGTAG_MATRIX_LTRAFO: ctrafo = v != JPGFLAG_MATRIX_COLORTRANSFORMATION_NONE; break;
     case JPGTAG_BIH_HOOK: bmh = (struct JPG_Hook *)t->ti_Data.ti_pPtr; break;
+    case JPGTAG_BIH_ALPHAHOOK: alphahook = (struct JPG_Hook *)t->ti_Data.ti_pPtr; break;
+    case JPGTAG_DECODER_INCLUDE_ALPHA: include_alpha = v != 0; break;
     case JPGTAG_MIJPEG_DEVICE_BITMAPS: device_bitmaps = v != 0; break;
     default: break;
     }
@@ -420,8 +445,8 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
 
   // REQUEST: one hook call per component with the tag layout of interface/bitmaphook.cpp:130-161
   struct Bitmap { void *mem; JPG_LONG width, height, bpr, bpp, type; void *user; } bm[MIJPEG_MAX_COMPONENTS];
-  auto call_hook = [&](int c, int action, Bitmap &b) -> JPG_LONG {
-    const int sx = f.subx[c], sy = f.suby[c];
+  auto call_hook = [&](struct JPG_Hook *hook, const mijpeg_info &g, bool alpha, int c, int action, Bitmap &b) -> JPG_LONG {
+    const int sx = g.subx[c], sy = g.suby[c];
     struct JPG_TagItem ht[] = {
         JPG_ValueTag(JPGTAG_BIO_ACTION, action),
         JPG_PointerTag(JPGTAG_BIO_MEMORY, b.mem),
@@ -437,7 +462,7 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
         JPG_ValueTag(JPGTAG_BIO_MINY, miny),
         JPG_ValueTag(JPGTAG_BIO_MAXX, maxx),
         JPG_ValueTag(JPGTAG_BIO_MAXY, maxy),
-        JPG_ValueTag(JPGTAG_BIO_ALPHA, 0),
+        JPG_ValueTag(JPGTAG_BIO_ALPHA, alpha ? 1 : 0),
         JPG_ValueTag(JPGTAG_BIO_PIXEL_MINX, (minx + sx - 1) / sx),
         JPG_ValueTag(JPGTAG_BIO_PIXEL_MINY, (miny + sy - 1) / sy),
         JPG_ValueTag(JPGTAG_BIO_PIXEL_MAXX, (maxx + sx) / sx - 1),
@@ -445,7 +470,7 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
         JPG_ValueTag(JPGTAG_BIO_PIXEL_XORG, 0),
         JPG_ValueTag(JPGTAG_BIO_PIXEL_YORG, 0),
         JPG_EndTag};
-    const JPG_LONG r = bmh->CallLong(ht);
+    const JPG_LONG r = hook ? hook->CallLong(ht) : 0; // (no hook: the bitmap stays blank, interface/bitmaphook.cpp:186-190)
     if (action == JPGFLAG_BIO_REQUEST) {
       b.mem = ht[1].ti_Data.ti_pPtr;
       b.width = ht[2].ti_Data.ti_lData;
@@ -461,7 +486,7 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
   memset(maps, 0, sizeof(maps));
   for (int c = c0; c <= c1; c++) {
     bm[c] = Bitmap{nullptr, 0, 0, 0, 0, f.sample_bytes == 2 ? CTYP_UWORD : CTYP_UBYTE, nullptr};
-    const JPG_LONG r = call_hook(c, JPGFLAG_BIO_REQUEST, bm[c]);
+    const JPG_LONG r = call_hook(bmh, f, false, c, JPGFLAG_BIO_REQUEST, bm[c]);
     if (r < 0) return p->fail(r, "BitMapHook signalled an error");
     const JPG_LONG want = f.sample_bytes == 2 ? CTYP_UWORD : CTYP_UBYTE;
     if (bm[c].type != want && bm[c].type != 0) // control/bitmapctrl.cpp:152-158: types must fit the data
@@ -474,19 +499,55 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
     maps[c].width = bm[c].type ? (uint32_t)bm[c].width : 0x7fffffffu;
     maps[c].height = (uint32_t)bm[c].height;
   }
+  // The alpha channel beside the picture (Image::ReconstructRegion, codestream/image.cpp:1087-1123): its one component is
+  // requested from the alpha hook behind the picture's components, reconstructed behind the picture, released in front of it
+  mijpeg_decoder *adec = include_alpha ? mijpeg_alpha_channel(p->dec) : nullptr;
+  mijpeg_info ainfo;
+  Bitmap abm{nullptr, 0, 0, 0, 0, 0, nullptr};
+  mijpeg_bitmap amaps[MIJPEG_MAX_COMPONENTS];
+  memset(amaps, 0, sizeof(amaps));
+  if (adec && mijpeg_get_info(adec, &ainfo) != MIJPEG_OK) adec = nullptr;
+  if (adec) {
+    const JPG_LONG want = ainfo.sample_bytes == 2 ? CTYP_UWORD : CTYP_UBYTE;
+    abm.type = want;
+    const JPG_LONG r = call_hook(alphahook, ainfo, true, 0, JPGFLAG_BIO_REQUEST, abm);
+    if (r < 0) return p->fail(r, "BitMapHook signalled an error");
+    if (abm.type != want && abm.type != 0)
+      return p->fail(JPGERR_INVALID_PARAMETER, "pixel type of the user bitmap does not fit the sample precision of the image");
+    amaps[0].data = abm.type ? abm.mem : nullptr;
+    amaps[0].bytes_per_pixel = abm.bpp;
+    amaps[0].bytes_per_row = abm.bpr;
+    amaps[0].width = abm.type ? (uint32_t)abm.width : 0x7fffffffu;
+    amaps[0].height = (uint32_t)abm.height;
+  }
   // the request joins the sequence of requests this object has seen: row cursors and upsampler buffers of the reference's
   // BlockBitmapRequester carry over from call to call, see mijpeg_display_rect
+  int arc = 0;
   const int rc = mijpeg_display_rect(p->dec, minx, miny, maxx, maxy, c0, c1,
                                      (ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM) | (device_bitmaps ? MIJPEG_FLAG_DEVICE_OUTPUT : 0) |
                                          (upsample ? 0 : MIJPEG_FLAG_NO_UPSAMPLING),
                                      maps);
+  if (adec && !rc)
+    arc = mijpeg_display_rect(adec, minx, miny, maxx, maxy, 0, 0,
+                              (ctrafo ? 0 : MIJPEG_FLAG_NO_COLOR_TRANSFORM) | (device_bitmaps ? MIJPEG_FLAG_DEVICE_OUTPUT : 0) |
+                                  (upsample ? 0 : MIJPEG_FLAG_NO_UPSAMPLING),
+                              amaps);
   // RELEASE is always delivered, also after a failure, so the client can let go of its buffers
   JPG_LONG hookerr = 0;
+  if (adec) {
+    const JPG_LONG r = call_hook(alphahook, ainfo, true, 0, JPGFLAG_BIO_RELEASE, abm);
+    if (r < 0) hookerr = r;
+  }
   for (int c = c0; c <= c1; c++) {
-    const JPG_LONG r = call_hook(c, JPGFLAG_BIO_RELEASE, bm[c]);
+    const JPG_LONG r = call_hook(bmh, f, false, c, JPGFLAG_BIO_RELEASE, bm[c]);
     if (r < 0 && !hookerr) hookerr = r;
   }
   if (rc) return p->fail_from_decoder(rc);
+  if (arc) {
+    const char *m = nullptr;
+    mijpeg_last_error(adec, &m);
+    return p->fail(arc, m ? m : "the alpha channel does not reconstruct");
+  }
   if (hookerr) return p->fail(hookerr, "BitMapHook signalled an error");
   return JPG_TRUE;
 }

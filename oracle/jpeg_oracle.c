@@ -167,6 +167,7 @@ typedef struct {
   int nboxes;
   int walk_all;    /* the caller wants the boxes: walk all scans even without planes */
   int xt_legacy;   /* the legacy codestream of a JPEG XT decode: the caller follows the merging specification itself */
+  int in_memory;   /* the codestream lives in a box (the alpha channel's): a memory stream like a nested one's, an image of its own otherwise */
   int nested;      /* this is the residual codestream of a RESI box */
   int legacy_eoi_gone; /* nested: the residual codestream ran dry in front of a scan header and the search for one took the legacy
                         * stream's EOI (see rs_run) */
@@ -1425,7 +1426,8 @@ static int spec_without_residual(const oj_box *spec, const oj_box *boxes, int nb
    * (colortransformerfactory.cpp:379-383) */
   if (ltrafo != 255 && ltrafo >= 5 && !have_mtx[ltrafo]) return RS_OBJECT_DOESNT_EXIST;
   if (tables || hidden || (ctrafo != 255 && ctrafo != 1) || (ltrafo != 255 && ltrafo >= 5)) return 1;
-  if (ocon >= 0 && ((ocon >> 4) != 0 || (ocon & 0x0d) || !(ocon & 0x02))) return 1; /* more bits, lossless, float, lookup, or wrap-around */
+  /* (the lossless flag changes the residual's side only; the lookup indices are read and never used: xt_decode_common) */
+  if (ocon >= 0 && ((ocon >> 4) != 0 || (ocon & 0x04) || !(ocon & 0x02))) return 1; /* more bits, float, or wrap-around */
   if (ltrafo == 2 && f->ncomp != 3) return 1;
   if (ltrafo == 2) f->ycbcr = 1;
   else if (ltrafo == 1) f->ycbcr = 0;
@@ -1445,7 +1447,7 @@ static int walk(oj_parser *ps, int32_t *const planes[OJ_MAX_COMP])
     ps->boxes = own; ps->nboxes = 0;
   }
   bs_open(&io, ps->data, ps->len);
-  io.in_memory = ps->nested;
+  io.in_memory = ps->nested || ps->in_memory;
   if (setjmp(ps->jb) == 0) rs_run(ps, &io);
   else thrown = 1;
   if (!thrown) {
@@ -2664,7 +2666,7 @@ static void xt_ctx_free(struct oj_xt_ctx *ctx)
  * (Tables::ColorTrafoOf, codestream/tables.cpp:1517-1555).  -> 0, or the error with the reference's code in *ref_error;
  * *eoi_image: the legacy codestream came to its EOI, i.e. there is a residual frame for the transformer to merge. */
 static int xt_codestreams_verdict(const uint8_t *data, size_t len, const oj_info *info, const oj_box *boxes, int nboxes,
-                                  const oj_box *resi, int hidden_l, int hidden_r, int *ref_error, int *eoi_image)
+                                  const oj_box *resi, int hidden_l, int hidden_r, int *ref_error, int *eoi_image, int in_memory)
 {
   oj_parser ls, rs;
   oj_info ltmp, rtmp, rinfo;
@@ -2672,7 +2674,7 @@ static int xt_codestreams_verdict(const uint8_t *data, size_t len, const oj_info
   int c, rc;
   memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
   *ref_error = 0; *eoi_image = 0;
-  ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1;
+  ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1; ls.in_memory = in_memory;
   for (c = 0; c < info->ncomp; c++) {
     planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
     if (!planes[c]) { rc = OJ_ERR_NOMEM; goto done; }
@@ -2707,8 +2709,10 @@ done:
  * picture through the L chain alone */
 #define XT_DISABLE_TO_RGB 1
 #define XT_IGNORE_RESIDUAL 2
+/* given / ngiven: the codestream is an alpha channel's (the payload of the ALFA box): its boxes are these -- the file's, the
+ * alpha kinds under the names of their image counterparts (oj_decode_alpha) -- instead of what the walk over it collects */
 static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, oj_requester **rq_out, int flags,
-                            int32_t **lplanes_out)
+                            int32_t **lplanes_out, const oj_box *given, int ngiven)
 {
   const int disable_to_rgb = flags & XT_DISABLE_TO_RGB;
   int retry_lonly = 0;
@@ -2732,9 +2736,21 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   if (pixels) *pixels = NULL;
   if (rq_out) *rq_out = NULL;
   memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(nlt, 0, sizeof(nlt)); memset(&xt, 0, sizeof(xt)); memset(&rinfo, 0, sizeof(rinfo));
-  ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes; ps.walk_all = 1;
+  ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes; ps.walk_all = 1; ps.in_memory = given != NULL; ps.xt_legacy = given != NULL;
   rc = walk(&ps, NULL);
   if (rc) { free_boxes(boxes, ps.nboxes); return rc; }
+  if (given) {
+    free_boxes(boxes, ps.nboxes);
+    memset(boxes, 0, sizeof(boxes));
+    for (b = 0; b < ngiven && b < OJ_MAX_BOXES; b++) {
+      boxes[b] = given[b];
+      boxes[b].data = (uint8_t *)malloc(given[b].len ? given[b].len : 1);
+      if (!boxes[b].data) { free_boxes(boxes, b); return OJ_ERR_NOMEM; }
+      memcpy(boxes[b].data, given[b].data, given[b].len);
+      boxes[b].cap = given[b].len;
+    }
+    ps.nboxes = b;
+  }
   for (b = 0; b < ps.nboxes; b++) {
     if (!boxes[b].complete) continue; /* (tables.cpp:1191-1225: the tables learn of a box when its last byte was announced) */
     if (boxes[b].type == BOXID('S', 'P', 'E', 'C')) spec = &boxes[b];
@@ -2749,7 +2765,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
      * INVALID_PARAMETER "The combination of L and R transformation is non-standard and not supported".  Without an EOI behind
      * the legacy codestream the residual frame never comes to be (image.cpp:1416-1431): a plain picture, not this function's. */
     int verr = 0, eoi = 0;
-    rc = xt_codestreams_verdict(data, len, info, boxes, ps.nboxes, resi, 0, 0, &verr, &eoi);
+    rc = xt_codestreams_verdict(data, len, info, boxes, ps.nboxes, resi, 0, 0, &verr, &eoi, given != NULL);
     if (rc) { info->ref_error = verr; goto out; }
     if (!eoi) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     info->ref_error = RS_INVALID_PARAMETER;
@@ -2831,7 +2847,10 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   /* the lossless flag only changes the residual's side (codestream/tables.cpp:1643, 1687; marker/frame.cpp:595), the output
    * lookup indices are read and never used by the decoder: without a residual neither matters */
   if (lonly) ocon &= ~0x09;
-  if (ocon < 0 || (ocon & 0x08) || (ocon & 0x01)) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* lossless / output lookup */
+  /* (the output lookup flag and its table indices are read -- boxes/outputconversionbox.cpp:91-127 -- and never used by the
+   * decoder: MergingSpecBox::OutputConversionLookupOf has no caller; the encoder sets them for alpha channels with a residual) */
+  if (ocon >= 0) ocon &= ~0x01;
+  if (ocon < 0 || (ocon & 0x08)) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* lossless */
   xt.outmax = ((int64_t)1 << (8 + (ocon >> 4))) - 1;
   xt.outshift = (xt.outmax + 1) >> 1;
   xt.is_float = (ocon & 0x04) ? 1 : 0;
@@ -2860,7 +2879,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     oj_parser ls;
     oj_info ltmp;
     memset(&ls, 0, sizeof(ls)); memset(&ltmp, 0, sizeof(ltmp));
-    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1;
+    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1; ls.in_memory = given != NULL;
     for (c = 0; c < nc; c++) {
       planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
       if (!planes[c]) { rc = OJ_ERR_NOMEM; goto out; }
@@ -2916,7 +2935,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     oj_parser ls, rs;
     oj_info ltmp, rtmp;
     memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
-    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1;
+    ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1; ls.in_memory = given != NULL;
     if (!lonly) { rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r; rs.nested = 1; }
     for (c = 0; c < nc; c++) {
       memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
@@ -2994,7 +3013,7 @@ late:
   {
     const int lrc = rc, lerr = info->ref_error;
     int verr = 0, eoi = 0;
-    rc = xt_codestreams_verdict(data, len, info, boxes, ps.nboxes, resi, hidden_l, hidden_r, &verr, &eoi);
+    rc = xt_codestreams_verdict(data, len, info, boxes, ps.nboxes, resi, hidden_l, hidden_r, &verr, &eoi, given != NULL);
     if (rc) info->ref_error = verr;
     else if (!eoi && late_residual_only) { retry_lonly = 1; info->ref_error = 0; }
     else { rc = lrc; info->ref_error = lerr; }
@@ -3004,13 +3023,13 @@ out:
   for (c = 0; c < 16; c++) free(nlt[c].lut);
   for (c = 0; c < 9; c++) free(owned[c]);
   free_boxes(boxes, ps.nboxes);
-  if (retry_lonly && !(flags & XT_IGNORE_RESIDUAL)) return xt_decode_common(data, len, info, pixels, is_float, rq_out, flags | XT_IGNORE_RESIDUAL, lplanes_out);
+  if (retry_lonly && !(flags & XT_IGNORE_RESIDUAL)) return xt_decode_common(data, len, info, pixels, is_float, rq_out, flags | XT_IGNORE_RESIDUAL, lplanes_out, given, ngiven);
   return rc;
 }
 
 int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float)
 {
-  return xt_decode_common(data, len, info, pixels, is_float, NULL, 0, NULL);
+  return xt_decode_common(data, len, info, pixels, is_float, NULL, 0, NULL, NULL, 0);
 }
 
 /* The legacy frame's coefficient planes as the JPEG XT merge sees them -- visible scans moved up by the hidden bits, hidden
@@ -3018,20 +3037,20 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
  * hidden bits.  For the tests of the product's host decoder. */
 int oj_decode_xt_planes(const uint8_t *data, size_t len, oj_info *info, int32_t **planes)
 {
-  return xt_decode_common(data, len, info, NULL, NULL, NULL, 0, planes);
+  return xt_decode_common(data, len, info, NULL, NULL, NULL, 0, planes, NULL, 0);
 }
 
 /* ... as the reference's command line decodes it with -c (no colour transformation) */
 int oj_decode_xt_ex(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, int disable_to_rgb)
 {
-  return xt_decode_common(data, len, info, pixels, is_float, NULL, disable_to_rgb ? XT_DISABLE_TO_RGB : 0, NULL);
+  return xt_decode_common(data, len, info, pixels, is_float, NULL, disable_to_rgb ? XT_DISABLE_TO_RGB : 0, NULL, NULL, 0);
 }
 
 /* A requester (oj_requester_display / _cursor / _free) on a JPEG XT stream: both codestreams decoded, the residual image's
  * cursors and upsamplers beside the legacy image's.  *out_max = 2^(8 + extra range bits) - 1: samples of 2 bytes above 255. */
 int oj_xt_requester_new(const uint8_t *data, size_t len, oj_info *info, oj_requester **rq, int *is_float, int *out_max)
 {
-  const int rc = xt_decode_common(data, len, info, NULL, is_float, rq, 0, NULL);
+  const int rc = xt_decode_common(data, len, info, NULL, is_float, rq, 0, NULL, NULL, 0);
   if (!rc && out_max) *out_max = (int)(*rq)->xt->outmax;
   return rc;
 }
@@ -3065,6 +3084,112 @@ int oj_decode(const uint8_t *data, size_t len, oj_info *info, uint8_t **pixels)
   if (rc) { free(*pixels); *pixels = NULL; }
 out:
   for (c = 0; c < OJ_MAX_COMP; c++) free(planes[c]);
+  return rc;
+}
+
+/* The alpha channel of a JPEG XT file (part 9 of the standard as the reference implements it): a one-component image of its own
+ * in the ALFA box -- SOI, tables, frame, scans (Image::ParseAlphaChannel, codestream/image.cpp:1337-1404, entered from the legacy
+ * image's trailer, :1430-1460) -- with the alpha merging specification ASPC in the role of SPEC (Tables::ResidualSpecsOf,
+ * codestream/tables.hpp:451-460), the boxes ARES / AFIN / ARRF in the roles of RESI / FINE / RFIN (boxes/databox.hpp:90-96,
+ * codestream/tables.cpp:752-775, 850-903) and the file's TONE / CURV / MTRX boxes behind the specification's own
+ * (Tables::AlphaNamespace, codestream/tables.cpp:109, 2115-2125).  The decoder hands the plane out beside the picture, it does
+ * not composite; mode and matte colour of the AMUL box (boxes/alphabox.cpp:60-90) are what JPEG::GetInformation reports
+ * (interface/jpeg.cpp:919-945).
+ * -> 16-bit codes, one per pixel (*out_max = 2^bits - 1; half-float codes when *is_float); *mode: AMUL's compositing method, -1
+ * without that box.  OJ_ERR_UNSUPPORTED: the file has no (complete) ALFA box. */
+int oj_decode_alpha(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, int *out_max, int *mode, uint32_t matte[3])
+{
+  oj_box boxes[OJ_MAX_BOXES], given[OJ_MAX_BOXES];
+  oj_parser ps;
+  oj_info main_info;
+  const oj_box *alfa = NULL, *aspc = NULL;
+  int b, n = 0, rc, isf = 0;
+  *pixels = NULL;
+  if (mode) *mode = -1;
+  if (matte) matte[0] = matte[1] = matte[2] = 0;
+  memset(&ps, 0, sizeof(ps)); memset(&main_info, 0, sizeof(main_info));
+  ps.data = data; ps.len = len; ps.info = &main_info; ps.boxes = boxes; ps.walk_all = 1;
+  rc = walk(&ps, NULL);
+  if (rc) { free_boxes(boxes, ps.nboxes); return rc; }
+  for (b = 0; b < ps.nboxes; b++) {
+    const oj_box *bx = &boxes[b];
+    uint32_t t = bx->type;
+    if (!bx->complete) continue;
+    if (t == BOXID('A', 'L', 'F', 'A')) { alfa = bx; continue; }
+    if (t == BOXID('A', 'S', 'P', 'C')) { aspc = bx; t = BOXID('S', 'P', 'E', 'C'); }
+    else if (t == BOXID('A', 'R', 'E', 'S')) t = BOXID('R', 'E', 'S', 'I');
+    else if (t == BOXID('A', 'F', 'I', 'N')) t = BOXID('F', 'I', 'N', 'E');
+    else if (t == BOXID('A', 'R', 'R', 'F')) t = BOXID('R', 'F', 'I', 'N');
+    else if (t != BOXID('T', 'O', 'N', 'E') && t != BOXID('C', 'U', 'R', 'V') && t != BOXID('M', 'T', 'R', 'X')) continue;
+    given[n] = *bx;
+    given[n].type = t;
+    n++;
+  }
+  if (!alfa) { free_boxes(boxes, ps.nboxes); return OJ_ERR_UNSUPPORTED; }
+  if (aspc) { /* AMUL inside the alpha merging specification */
+    size_t j;
+    for (j = 0; j + 8 <= aspc->len;) {
+      const uint32_t l = ((uint32_t)rd16(aspc->data + j) << 16) | (uint32_t)rd16(aspc->data + j + 2);
+      const uint32_t t = ((uint32_t)rd16(aspc->data + j + 4) << 16) | (uint32_t)rd16(aspc->data + j + 6);
+      if (l < 8 || j + l > aspc->len) break;
+      if (t == BOXID('A', 'M', 'U', 'L') && l == 8 + 10) {
+        const uint8_t *pl = aspc->data + j + 8;
+        if (mode) *mode = pl[0] >> 4;
+        if (matte) { matte[0] = rd16(pl + 2); matte[1] = rd16(pl + 4); matte[2] = rd16(pl + 6); }
+      }
+      j += l;
+    }
+  }
+  rc = xt_decode_common(alfa->data, alfa->len, info, pixels, &isf, NULL, 0, NULL, given, n);
+  if (!rc) {
+    /* (the depth of the output: the OCON box of the specification) */
+    int bits = 8;
+    size_t j;
+    for (j = 0; aspc && j + 8 <= aspc->len;) {
+      const uint32_t l = ((uint32_t)rd16(aspc->data + j) << 16) | (uint32_t)rd16(aspc->data + j + 2);
+      const uint32_t t = ((uint32_t)rd16(aspc->data + j + 4) << 16) | (uint32_t)rd16(aspc->data + j + 6);
+      if (l < 8 || j + l > aspc->len) break;
+      if (t == BOXID('O', 'C', 'O', 'N') && l >= 9) bits = 8 + (aspc->data[j + 8] >> 4);
+      j += l;
+    }
+    if (out_max) *out_max = (1 << bits) - 1;
+  } else if (rc == OJ_ERR_UNSUPPORTED && !aspc) {
+    /* no alpha merging specification: a plain one-component picture of 8 or 12 bits */
+    int32_t *planes[OJ_MAX_COMP] = {0, 0, 0, 0};
+    int c;
+    rc = oj_read_info(alfa->data, alfa->len, info);
+    for (c = 0; !rc && c < info->ncomp; c++) {
+      planes[c] = (int32_t *)malloc((size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
+      if (!planes[c]) rc = OJ_ERR_NOMEM;
+    }
+    if (!rc) rc = oj_decode_coefficients(alfa->data, alfa->len, info, planes);
+    if (!rc) {
+      *pixels = (uint16_t *)malloc((size_t)info->width * info->height * info->ncomp * sizeof(uint16_t));
+      if (!*pixels) rc = OJ_ERR_NOMEM;
+    }
+    if (!rc) {
+      if (info->precision > 8) rc = oj_reconstruct16(info, planes, *pixels, -1);
+      else {
+        uint8_t *p8 = (uint8_t *)malloc((size_t)info->width * info->height * info->ncomp);
+        size_t i, cnt = (size_t)info->width * info->height * info->ncomp;
+        if (!p8) rc = OJ_ERR_NOMEM;
+        else {
+          rc = oj_reconstruct(info, planes, p8, -1);
+          for (i = 0; !rc && i < cnt; i++) (*pixels)[i] = p8[i];
+          free(p8);
+        }
+      }
+      if (rc) { free(*pixels); *pixels = NULL; }
+    }
+    for (c = 0; c < OJ_MAX_COMP; c++) free(planes[c]);
+    if (out_max) *out_max = (1 << info->precision) - 1;
+    isf = 0;
+  }
+  if (!rc && (info->width != main_info.width || info->height != main_info.height || info->ncomp != 1)) {
+    info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; free(*pixels); *pixels = NULL; /* codestream/image.cpp:1370-1380 */
+  }
+  if (is_float) *is_float = isf;
+  free_boxes(boxes, ps.nboxes);
   return rc;
 }
 

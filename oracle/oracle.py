@@ -61,6 +61,8 @@ def lib():
         L.oj_decode_xt.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.oj_decode_xt_ex.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
         L.oj_decode_xt_planes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
+        L.oj_decode_alpha.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         L.oj_free.argtypes = [C.c_void_p]
         L.oj_forward.argtypes = [C.POINTER(OjInfo), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.oj_fdct_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -188,6 +190,22 @@ def decode_xt_planes(data: bytes):
         planes.append(np.ctypeslib.as_array((C.c_int32 * n).from_address(ptrs[c])).reshape(info.bh[c], info.bw[c], 64).copy())
         lib().oj_free(ptrs[c])
     return info, planes
+
+
+def decode_alpha(data: bytes):
+    """The alpha channel of a JPEG XT file -> (codes (H, W) uint16 or None, is_float, out_max, mode, matte (r, g, b), ref_error):
+    ref_error 0 with a plane, None where the file has no alpha channel or the restatement does not follow, else the reference's code."""
+    info = OjInfo()
+    px = C.c_void_p()
+    isf, omax, mode = C.c_int(0), C.c_int(0), C.c_int(-1)
+    matte = (C.c_uint32 * 3)()
+    rc = lib().oj_decode_alpha(data, len(data), C.byref(info), C.byref(px), C.byref(isf), C.byref(omax), C.byref(mode), matte)
+    if rc:
+        return None, False, 0, mode.value, tuple(matte), (info.ref_error if (rc != -2 and info.ref_error) else None)
+    n = info.width * info.height
+    out = np.ctypeslib.as_array((C.c_uint16 * n).from_address(px.value)).reshape(info.height, info.width).copy()
+    lib().oj_free(px)
+    return out, bool(isf.value), omax.value, mode.value, tuple(matte), 0
 
 
 def decode_xt_status(data: bytes, no_color_transform: bool = False):
