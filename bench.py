@@ -45,6 +45,23 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PIXEL_420 = 6.0  # int16 coefficients in (3 B/px) + interleaved RGB out (3 B/px)
 
 
+def verify_against_oracle(frames):
+    """The checker, AFTER a timed region: frames = [(device tensor of one frame's pixels, its JPEG stream)] -> True when every frame
+    the timed launches wrote equals oracle.decode() of its stream, byte for byte (the oracle is never on the measured path)."""
+    from oracle import oracle as O
+
+    cache = {}
+    ok = True
+    for px, data in frames:
+        key = id(data)
+        if key not in cache:
+            cache[key] = O.decode(data)
+        exp = cache[key]
+        got = px.cpu().numpy().reshape(-1)
+        ok = ok and got.size == exp.size and bool(np.array_equal(got, exp.reshape(-1)))
+    return ok
+
+
 def cpu_baseline(jpeg_bytes, width, height):
     """Reference CPU path timed on this box's host cores (rank 0, N=1 only).  Uses oracle/_ref/jpeg (the
     real reference binary, kind 'reference') if it was built, else the oracle's C restatement ('port')."""
@@ -385,6 +402,11 @@ def xt_profile_c(local_rank, stream, with_cpu, frames=8, steps=10):
         bpp = 3 + (12 if wide else 6) + 6
         ach = W * H * F * bpp / (ms * 1e-3) / 1e9
         kname = api.kernel_name(info, xt=xt)
+        try:  # what the timed launches wrote (every frame is a copy of the same picture) against the oracle's half-float codes
+            codes, _ = O.decode_xt(data)
+            verified = all(bool(np.array_equal(out[i].cpu().numpy().view(np.uint16).reshape(codes.shape), codes)) for i in sorted({0, F // 2, F - 1}))
+        except Exception as e:  # noqa: BLE001
+            verified = repr(e)
         del coef, ws
         # bytes -> half codes left in HBM, bytes -> float32 in host memory
         dev_out = out[0]
@@ -407,6 +429,7 @@ def xt_profile_c(local_rank, stream, with_cpu, frames=8, steps=10):
         del out, host_f32
         ent = {"variant": "jpeg " + " ".join(XT_ARGS + extra), "stream_bytes": len(data), "reference_encode_s": round(enc_s, 1),
                "kernel": kname, "frames": F, "kernel_ms": round(ms, 4), "value": round(W * H * F / ms / 1e3, 1), "unit": "Mpixels/s",
+               "verified": verified,
                "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                             "bytes_per_pixel": bpp, "residual_coefficients": "int32" if wide else "int16"},
                "residual_hidden_bits": int(xt.residual_hidden_bits), "legacy_hidden_bits": int(xt.hidden_bits),
@@ -542,6 +565,12 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
         if best is None or r["seconds"] < best["seconds"]:
             best = r
     last_shard = r.pop("shard")
+    verified = None
+    try:  # three frames of what the last timed batch left in HBM, against the oracle
+        o = last_shard.out
+        verified = verify_against_oracle([(o[i], streams[mine[i]]) for i in sorted({0, 1, len(mine) - 1})])
+    except Exception as e:  # noqa: BLE001
+        verified = repr(e)
     W, H = cfg["width"], cfg["height"]
     ms = best["seconds"] * 1e3 / steps
     rank_ms = [best["rank_ms"]]
@@ -553,6 +582,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
     res = {"metric": "decoded Mpixels/s, 256 x 4K 4:2:0 Q85 DRI=8 streams in host memory -> pixels in HBM (BASELINE configs[3])",
            "value": round(best["total_pixels"] / best["seconds"] / 1e6, 1), "unit": "Mpixels/s", "scaling": "strong", "n_gpus": world,
            "frames": frames_total, "frames_per_rank": len(mine), "ms_per_batch": round(ms, 2), "ms_per_frame": round(ms / frames_total, 4),
+           "verified": verified,
            "per_rank_ms": [round(x, 2) for x in rank_ms], "steps": steps, "chunk_frames": best["chunk"], "decoder_objects": best["depth"],
            "ramped_schedule": best["ramp"],
            "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(),
@@ -730,6 +760,13 @@ def main():
         kernel_ms = float(t[0])
     assert total_pixels == W * H * F * args.steps * world
 
+    # what the timed launches wrote, against the oracle (rank 0's frames; after the timed region, never part of it)
+    verified = None
+    if rank == 0:
+        try:
+            verified = verify_against_oracle([(out[i], jpegs[i % 2]) for i in sorted({0, 1, F - 1})])
+        except Exception as e:  # noqa: BLE001 -- reported, never hidden
+            verified = repr(e)
     pixels_per_step = W * H * F * world
     ms_per_step = wall * 1e3 / args.steps
     value = pixels_per_step / (ms_per_step * 1e-3) / 1e6
@@ -745,11 +782,15 @@ def main():
         "config": {"workload": f"{F} x {W}x{H} {args.subsampling[0]}:{args.subsampling[1]}:{args.subsampling[2]} Q85 DRI=8 baseline frames per GPU per step (BASELINE configs[2] frame shape, "
                                f"device-resident coefficient planes; 2 distinct pictures per rank repeated over the {F} frames: {F * n * 2 >> 20} MiB in + "
                                f"{F * H * row >> 20} MiB out per launch, far beyond the 256 MiB Infinity Cache)", "frames_per_gpu": F, "kernel": api.kernel_name(info), "settle_launches": settle_launches,
-                   "fast_arith": int(info.fast_arith), "parallelism": f"image-sharded x{world}, no data-path collective"},
+                   "fast_arith": int(info.fast_arith), "parallelism": f"image-sharded x{world}, no data-path collective",
+                   "verified": verified},
+        "verified": verified,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)},
+                     "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "verified": verified},
     }
+    result["verified_note"] = ("frames 0, 1 and F-1 of the output the timed launches wrote, downloaded after the timed region and compared byte for byte "
+                               "with oracle.decode() of their streams (oracle/: the checker, never on the measured path)")
 
     if rank == 0 and world == 1 and not args.no_traffic:
         tb, tnote = measure_traffic(info, host_planes, api.kernel_name(info), F)
@@ -985,6 +1026,27 @@ def main():
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     dec.close()
     if rank == 0:
+        # the side measurements in a few scalars: inside `config` (the driver's record keeps the scalars of the contract's keys) and once
+        # more as the LAST key of the line (what a tail of the output still shows)
+        def pick(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+
+        summary = {"verified": result.get("verified"), "kernel_frac": pick(result, "roofline", "frac"),
+                   "batch4k_ms": pick(result, "batch4k", "ms_per_batch"), "batch4k_mpix": pick(result, "batch4k", "value"),
+                   "batch4k_verified": pick(result, "batch4k", "verified"),
+                   "xt_r12_kernel_ms": pick(result, "xt_profile_c", "r12", "kernel_ms"), "xt_r12_frac": pick(result, "xt_profile_c", "r12", "roofline", "frac"),
+                   "xt_r12_verified": pick(result, "xt_profile_c", "r12", "verified"),
+                   "xt_rR4_kernel_ms": pick(result, "xt_profile_c", "r12_rR4", "kernel_ms"), "xt_rR4_frac": pick(result, "xt_profile_c", "r12_rR4", "roofline", "frac"),
+                   "xt_rR4_bytes_to_codes_ms": pick(result, "xt_profile_c", "r12_rR4", "bytes_to_half_codes_in_hbm", "ms"),
+                   "xt_rR4_verified": pick(result, "xt_profile_c", "r12_rR4", "verified"),
+                   "e2e_ms": pick(result, "end_to_end", "ms"), "e2e_device_entropy_ms": pick(result, "end_to_end", "device_entropy", "ms"),
+                   "dense_frac": pick(result, "roofline_dense", "frac"), "reference_encoded_frac": pick(result, "roofline_reference_encoded", "frac")}
+        for k, v in summary.items():
+            if k != "verified":
+                result["config"]["side_" + k] = v
+        result["summary"] = summary
         print(json.dumps(result))
     if dist:
         dist.barrier()

@@ -267,7 +267,7 @@ def test_gpu_alpha_stripes_through_display_rect(oracle, dec):
     dec.read(stream(name))
     a = dec.alpha_channel()
     h, w = a.info.height, a.info.width
-    canvas = np.zeros((h, w, 1), np.uint8)
+    canvas = np.zeros((1, h, w), np.uint8)  # (planar: one plane per component)
     for y in range(0, h, 8):
         a.display_rect(canvas, 0, y, w - 1, min(h, y + 8) - 1, bm_height=8 + y)
     assert np.array_equal(canvas.reshape(h, w), alpha_plane(name))
