@@ -351,7 +351,8 @@ def xt_profile_c(local_rank, stream, with_cpu, frames=8, steps=10):
     res = {"input": f"{W}x{H} HDR, seed 99 (libjpeg_amd/synth.py synth_hdr = SURVEY 8d recipe), reference encoder `jpeg {' '.join(XT_ARGS)}` [+ -rR 4]"}
     hip = C.CDLL("libamdhip64.so")
     dec = api.Decoder(local_rank)
-    for name, extra in (("r12", []), ("r12_rR4", ["-rR", "4"])):
+    # (-z 8: with restart intervals every hidden refinement scan decodes interval-parallel on the host instead of as one chain)
+    for name, extra in (("r12", []), ("r12_rR4", ["-rR", "4"]), ("r12_rR4_z8", ["-rR", "4", "-z", "8"])):
         t = time.perf_counter()
         data = O.reference_encode_hdr(hdr, XT_ARGS + extra)
         enc_s = time.perf_counter() - t
@@ -553,7 +554,9 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
     # the pipeline two stages deep)
     # (chunk frames, decoder objects, ramped schedule: small chunks at both ends of the batch -- libjpeg_amd/batch.py)
     settings = (((24, 4, False), (28, 4, True), (32, 4, True), (24, 4, True), (32, 4, False)) if len(mine) >= 128 else
-                ((8, 4, True), (8, 4, False), (16, 4, False), (16, 2, False), (4, 8, False), (max(1, len(mine)), 1, False)))
+                # (no setting with two objects: the upload engine then idles whenever the host's one wait per chunk returns late, and on
+                # most boxes that is the case for the first hundred chunks of a shard -- profiles/r05/batch4k_stall.txt)
+                ((8, 4, True), (8, 4, False), (11, 3, False), (16, 3, False), (4, 8, False), (max(1, len(mine)), 1, False)))
     for ci, (chunk, depth, ramp) in enumerate(settings):
         r = batch.run_sharded(streams, frames_total, rank, world, local_rank, dist, steps=steps, warmup=10 if ci == 0 else 2, chunk=chunk, depth=depth,
                               ramp=ramp)
@@ -561,8 +564,13 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
             r["shard"].close()
             r.pop("shard")
         r.update(chunk=chunk, depth=depth, ramp=ramp)
-        tried.append({"chunk_frames": chunk, "decoder_objects": depth, "ramp": ramp, "ms_per_batch": round(r["seconds"] * 1e3 / steps, 2)})
-        if best is None or r["seconds"] < best["seconds"]:
+        sm = sorted(r["step_ms"])
+        r["median_ms"] = sm[len(sm) // 2]
+        tried.append({"chunk_frames": chunk, "decoder_objects": depth, "ramp": ramp, "ms_per_batch": round(r["seconds"] * 1e3 / steps, 2),
+                      "median_ms": round(r["median_ms"], 2), "step_ms": [round(x, 2) for x in r["step_ms"]]})
+        # (the setting is chosen by its median step: one pass in twenty takes 6-8 ms longer on some boxes -- same device work, host
+        # side, profiles/r05/batch4k_stall.txt -- and with five steps a mean would pick the setting that happened not to meet one)
+        if best is None or r["median_ms"] < best["median_ms"]:
             best = r
     last_shard = r.pop("shard")
     verified = None
@@ -582,6 +590,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
     res = {"metric": "decoded Mpixels/s, 256 x 4K 4:2:0 Q85 DRI=8 streams in host memory -> pixels in HBM (BASELINE configs[3])",
            "value": round(best["total_pixels"] / best["seconds"] / 1e6, 1), "unit": "Mpixels/s", "scaling": "strong", "n_gpus": world,
            "frames": frames_total, "frames_per_rank": len(mine), "ms_per_batch": round(ms, 2), "ms_per_frame": round(ms / frames_total, 4),
+           "median_ms_per_batch": round(best["median_ms"], 2), "step_ms": [round(x, 2) for x in best["step_ms"]],
            "verified": verified,
            "per_rank_ms": [round(x, 2) for x in rank_ms], "steps": steps, "chunk_frames": best["chunk"], "decoder_objects": best["depth"],
            "ramped_schedule": best["ramp"],
@@ -1034,15 +1043,18 @@ def main():
             return d
 
         summary = {"verified": result.get("verified"), "kernel_frac": pick(result, "roofline", "frac"),
-                   "batch4k_ms": pick(result, "batch4k", "ms_per_batch"), "batch4k_mpix": pick(result, "batch4k", "value"),
+                   "batch4k_ms": pick(result, "batch4k", "ms_per_batch"), "batch4k_median_ms": pick(result, "batch4k", "median_ms_per_batch"),
+                   "batch4k_mpix": pick(result, "batch4k", "value"),
                    "batch4k_verified": pick(result, "batch4k", "verified"),
                    "xt_r12_kernel_ms": pick(result, "xt_profile_c", "r12", "kernel_ms"), "xt_r12_frac": pick(result, "xt_profile_c", "r12", "roofline", "frac"),
                    "xt_r12_verified": pick(result, "xt_profile_c", "r12", "verified"),
                    "xt_rR4_kernel_ms": pick(result, "xt_profile_c", "r12_rR4", "kernel_ms"), "xt_rR4_frac": pick(result, "xt_profile_c", "r12_rR4", "roofline", "frac"),
                    "xt_rR4_bytes_to_codes_ms": pick(result, "xt_profile_c", "r12_rR4", "bytes_to_half_codes_in_hbm", "ms"),
                    "xt_rR4_verified": pick(result, "xt_profile_c", "r12_rR4", "verified"),
+                   "xt_rR4_z8_bytes_to_codes_ms": pick(result, "xt_profile_c", "r12_rR4_z8", "bytes_to_half_codes_in_hbm", "ms"),
+                   "xt_rR4_z8_verified": pick(result, "xt_profile_c", "r12_rR4_z8", "verified"),
                    "e2e_ms": pick(result, "end_to_end", "ms"), "e2e_device_entropy_ms": pick(result, "end_to_end", "device_entropy", "ms"),
-                   "dense_frac": pick(result, "roofline_dense", "frac"), "reference_encoded_frac": pick(result, "roofline_reference_encoded", "frac")}
+                   "dense_frac": pick(result, "roofline_dense", "dense", "frac"), "reference_encoded_frac": pick(result, "roofline_reference_encoded", "frac")}
         for k, v in summary.items():
             if k != "verified":
                 result["config"]["side_" + k] = v

@@ -59,6 +59,8 @@ extern "C" {
 #define MIJPEG_FLAG_FORCE_SAFE 4u         /* use the 32/64-bit "safe" arithmetic flavour even if the range check passed */
 #define MIJPEG_FLAG_NO_UPSAMPLING 16u      /* mijpeg_reconstruct_rect: JPGTAG_DECODER_UPSAMPLE = false -- one component on its own sample grid */
 #define MIJPEG_FLAG_DEVICE_OUTPUT 8u      /* mijpeg_reconstruct_rect: dst[] are DEVICE pointers; nothing crosses PCIe */
+#define MIJPEG_FLAG_SPECULATIVE 32u       /* mijpeg_reconstruct_batch_device with sync = 0 on a SUBMITTED batch: launch the reconstruction
+                                             behind the Huffman kernel without waiting for that kernel's report (see there) */
 
 typedef struct mijpeg_decoder mijpeg_decoder;
 
@@ -204,6 +206,17 @@ int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams,
  * mijpeg_decode_batch_device, which looks at the walk between its rounds, decodes such a batch. */
 int mijpeg_submit_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals);
 int mijpeg_finish_batch_device(mijpeg_decoder *d);
+/* Pipelines that never block on the device: mijpeg_reconstruct_batch_device(.., flags | MIJPEG_FLAG_SPECULATIVE, sync = 0) on a batch
+ * that was only SUBMITTED launches the reconstruction right behind the Huffman kernel, on the range check (the kernel selection's
+ * input, which the Huffman kernel reports) of the last finished batch of the same frame shape and tables, rounded up to the next
+ * gate of the selection -- instead of waiting for this batch's.  mijpeg_finish_batch_device then VALIDATES: it waits, evaluates what
+ * the Huffman kernel reported (damaged streams: the usual MIJPEG_ERR_NOT_AVAILABLE) and, should the real range check lie beyond the
+ * assumed one, runs the reconstruction again with the kernel it selects (synchronously, into the same destination).  Until it has
+ * returned MIJPEG_OK the destination's pixels do not count; mijpeg_synchronize and the next mijpeg_submit_batch_device validate as
+ * well (and report the batch's error).  Without a finished batch of this shape to go by, with per-image tables, or for streams
+ * without restart markers the call behaves as without the flag.  mijpeg_batch_speculation: diagnostics -- returns 1 when the last
+ * validation had to reconstruct again; *launched / *redone count the object's speculative launches and the ones redone. */
+int mijpeg_batch_speculation(mijpeg_decoder *d, int64_t *launched, int64_t *redone);
 /* Capacity planning / diagnostics: the HOST half of mijpeg_submit_batch_device alone -- header parse, restart marker search
  * and the copy of the entropy coded data without its byte stuffing into the staging area, one stream per pool worker -- with
  * no device involved (works on host-only objects).  This is what a rank's cores do per chunk of a batch; `bench.py

@@ -23,6 +23,7 @@ FLAG_FORCE_GENERIC = 2
 FLAG_FORCE_SAFE = 4
 FLAG_DEVICE_OUTPUT = 8
 FLAG_NO_UPSAMPLING = 16
+FLAG_SPECULATIVE = 32
 
 ERR_DEVICE = -8191
 ERR_NOT_AVAILABLE = -1029
@@ -120,6 +121,7 @@ def lib():
         L.mijpeg_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]
         L.mijpeg_submit_batch_device.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]
         L.mijpeg_finish_batch_device.argtypes = [C.c_void_p]
+        L.mijpeg_batch_speculation.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mijpeg_reconstruct_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_int]
         L.mijpeg_device_walk_rounds.argtypes = [C.c_void_p]
         L.mijpeg_device_walk_rounds.restype = C.c_int
@@ -432,6 +434,12 @@ class Decoder:
         self._check(lib().mijpeg_get_info(self._h, C.byref(info)))
         self.info = info
         return info
+
+    def batch_speculation(self):
+        """-> (last validation had to reconstruct again, speculative launches of this object, of them redone): MIJPEG_FLAG_SPECULATIVE"""
+        launched, redone = C.c_int64(0), C.c_int64(0)
+        again = lib().mijpeg_batch_speculation(self._h, C.byref(launched), C.byref(redone))
+        return bool(again == 1), launched.value, redone.value
 
     def reconstruct_batch_device(self, dst_ptr: int, frame_stride: int, row_stride: int, flags: int = 0, sync: bool = True,
                                  wait_foreign: bool = True):

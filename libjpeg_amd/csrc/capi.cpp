@@ -105,6 +105,16 @@ struct mijpeg_decoder {
   size_t batch_quant_cap = 0;
   bool batch_own_tables = false;
   std::vector<uint16_t> batch_quant_host;
+  // MIJPEG_FLAG_SPECULATIVE: the reconstruction of a submitted batch was launched on an ASSUMED range check (spec_assumed:
+  // what the last batch of this shape reported, rounded up to the kernel selection's next gate) behind the Huffman kernel,
+  // without the host waiting for what that kernel reports; finish_batch validates and launches again where the assumption
+  // did not hold (settle_speculation)
+  bool spec_active = false, spec_redone = false;
+  void *spec_dst = nullptr;
+  int64_t spec_frame_stride = 0, spec_row_stride = 0;
+  uint32_t spec_flags = 0;
+  int32_t spec_assumed[MIJPEG_MAX_COMPONENTS] = {0, 0, 0, 0};
+  int64_t spec_launched = 0, spec_redone_count = 0; // diagnostics (mijpeg_batch_speculation)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t chain_ev = nullptr; // mijpeg_stream_wait
@@ -1343,6 +1353,43 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
 // Aggregation over the images of a decoded batch: what one reconstruction launch for all of them needs to know.
 static int finish_batch(mijpeg_decoder *d);
 
+// What the last finished batch of shared tables reported, for the speculative launch of the next one (MIJPEG_FLAG_SPECULATIVE):
+// frame geometry, tables, and the range check that selected its kernel.  Process-wide: the decoder objects of a pipeline work
+// on chunks of the same material.
+namespace {
+struct SpecHint {
+  std::mutex m;
+  bool valid = false;
+  mijpeg_info info{};
+};
+SpecHint *spec_hint()
+{
+  static SpecHint *h = new SpecHint;
+  return h;
+}
+// the gates of the kernel selection (use_* above): an assumed range just below the next gate selects the kernel the hint's
+// batch ran on and holds for every batch that stays below that gate
+int32_t next_gate_below(int32_t range)
+{
+  static const int32_t gates[] = {2047, 7600, 8190, 16384, 45056, 49152, 65536};
+  for (int32_t g : gates)
+    if (range < g) return g - 1;
+  return -1;
+}
+bool same_shape_and_tables(const mijpeg_info &a, const mijpeg_info &b)
+{
+  if (a.width != b.width || a.height != b.height || a.components != b.components || a.precision != b.precision || a.ycbcr != b.ycbcr || a.xt != b.xt ||
+      a.dnl != b.dnl || a.coef_count != b.coef_count)
+    return false;
+  for (int c = 0; c < a.components; c++) {
+    if (a.hsamp[c] != b.hsamp[c] || a.vsamp[c] != b.vsamp[c]) return false;
+    if (memcmp(a.quant[a.quant_index[c]], b.quant[b.quant_index[c]], sizeof(a.quant[0]))) return false;
+  }
+  return true;
+}
+} // namespace
+static int settle_speculation(mijpeg_decoder *d);
+
 static int submit_batch(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals, bool defer)
 {
   if (!d || !streams || !sizes || n < 1) return MIJPEG_ERR_INVALID_PARAMETER;
@@ -1350,6 +1397,10 @@ static int submit_batch(mijpeg_decoder *d, const uint8_t *const *streams, const 
   HIP_TRY(d, hipSetDevice(d->device));
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
+  if (d->spec_active) { // a speculative reconstruction nobody validated (mijpeg_finish_batch_device): its verdict comes first
+    const int src = settle_speculation(d);
+    if (src) return src;
+  }
   if (const int prc = settle_pending(d)) return prc; // a submitted batch nobody waited for: its staging buffers are about to be reused
   d->batch_frames = 0;
   if (d->batch_hosts.size() < (size_t)n) d->batch_hosts.resize((size_t)n); // never shrinks: a pipeline's chunks differ in size, and
@@ -1420,6 +1471,21 @@ static int finish_batch(mijpeg_decoder *d)
   if (d->pend_n) { // wait for the upload and the Huffman kernel of the submitted batch, then look at what it reported
     const int pn = d->pend_n;
     d->pend_n = 0;
+    // The pipeline's one wait on the device.  hipStreamSynchronize blocks on an interrupt after a short spin, and how long the wake-up
+    // takes is the host's business (idle states of the core that takes the interrupt): on some boxes 0.3 ms per wait for seconds
+    // on end -- sixteen chunks of a batch, five milliseconds (profiles/r05/batch4k_stall.txt).  A submitted batch is a
+    // millisecond from done when somebody asks for it: poll the stream for that long, block only beyond.
+    {
+      static const bool no_spin = getenv("MIJPEG_NO_SPIN_WAIT") != nullptr; // A-B measurements
+      const auto t_spin = std::chrono::steady_clock::now();
+      while (!no_spin && hipStreamQuery(d->stream) == hipErrorNotReady) {
+        if (std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(4)) break;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+    }
     HIP_TRY(d, hipStreamSynchronize(d->stream));
     d->phase_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - d->pend_t0).count();
     if (d->pend_walk_round > 0) { // streams without restart markers: did the walk settle within the rounds it was given?
@@ -1473,7 +1539,33 @@ static int finish_batch(mijpeg_decoder *d)
     for (int c = 0; c < f.components; c++) d->batch_info.range_max[c] = std::max(d->batch_info.range_max[c], f.range_max[c]);
   }
   d->batch_frames = n;
+  if (!own_tables && !d->batch_info.xt) { // the next batch of this shape may launch its reconstruction on this range check
+    SpecHint &h = *spec_hint();
+    std::lock_guard<std::mutex> lock(h.m);
+    h.info = d->batch_info;
+    h.valid = true;
+  }
   return MIJPEG_OK;
+}
+
+// A speculative launch is validated: the batch is finished the ordinary way (wait, errors, range check), and where the range
+// check is not the one the launch assumed the reconstruction runs again with the kernel the real one selects.
+static int settle_speculation(mijpeg_decoder *d)
+{
+  if (!d->spec_active) return MIJPEG_OK;
+  d->spec_active = false;
+  d->spec_redone = false;
+  if (d->batch_frames == 0) return MIJPEG_OK; // (the batch was abandoned: another stream was set on the object)
+  if (d->batch_frames < 0) {
+    const int rc = finish_batch(d);
+    if (rc) return rc; // (the stream is damaged, the walk had not settled ...: nothing of the speculative pixels counts)
+  }
+  bool holds = d->batch_info.fast_arith != 0;
+  for (int c = 0; c < d->batch_info.components; c++) holds = holds && d->batch_info.range_max[c] <= d->spec_assumed[c];
+  if (holds) return MIJPEG_OK;
+  d->spec_redone = true;
+  d->spec_redone_count++;
+  return mijpeg_reconstruct_batch_device(d, d->spec_dst, d->spec_frame_stride, d->spec_row_stride, d->spec_flags & ~MIJPEG_FLAG_SPECULATIVE, 1);
 }
 
 int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)
@@ -1524,6 +1616,7 @@ int mijpeg_synchronize(mijpeg_decoder *d)
   if (d->device < 0 || !d->stream) return MIJPEG_OK;
   HIP_TRY(d, hipSetDevice(d->device));
   HIP_TRY(d, hipStreamSynchronize(d->stream));
+  if (d->spec_active) return settle_speculation(d); // (pixels of a speculative launch count once it is validated)
   return MIJPEG_OK;
 }
 
@@ -1542,29 +1635,57 @@ int mijpeg_finish_batch_device(mijpeg_decoder *d)
 {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
+  if (d->spec_active) return settle_speculation(d);
   return finish_batch(d);
+}
+
+int mijpeg_batch_speculation(mijpeg_decoder *d, int64_t *launched, int64_t *redone)
+{
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  if (launched) *launched = d->spec_launched;
+  if (redone) *redone = d->spec_redone_count;
+  return d->spec_redone ? 1 : 0;
 }
 
 int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags, int sync)
 {
   if (!d || !dst_device) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
-  if (d->batch_frames < 0) { // submitted with mijpeg_submit_batch_device: wait for it now
-    const int rc = finish_batch(d);
+  bool speculate = false;
+  mijpeg_info assumed;
+  if (d->batch_frames < 0 && (flags & MIJPEG_FLAG_SPECULATIVE) && !sync && d->pend_n && !d->pend_walk_round && !d->batch_own_tables && !d->spec_active) {
+    // A submitted batch whose Huffman kernel may still be running: launch the reconstruction behind it on the range check the
+    // last batch of this shape and these tables reported (rounded up to the selection's next gate) instead of waiting for this
+    // one's.  The pipeline's host thread never blocks on the device; mijpeg_finish_batch_device validates.
+    const mijpeg_info &f0 = d->batch_hosts[0]->info;
+    SpecHint &h = *spec_hint();
+    std::lock_guard<std::mutex> lock(h.m);
+    if (h.valid && h.info.fast_arith && same_shape_and_tables(h.info, f0)) {
+      assumed = f0;
+      assumed.fast_arith = 1;
+      speculate = true;
+      for (int c = 0; c < f0.components; c++) {
+        assumed.range_max[c] = next_gate_below(h.info.range_max[c]);
+        if (assumed.range_max[c] < 0) speculate = false;
+      }
+    }
+  }
+  if (d->batch_frames < 0 && !speculate) { // submitted with mijpeg_submit_batch_device: wait for it now
+    const int rc = d->spec_active ? settle_speculation(d) : finish_batch(d);
     if (rc) return rc;
   }
-  if (d->batch_frames < 1) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded batch: call mijpeg_decode_batch_device first");
+  if (d->batch_frames < 1 && !speculate) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded batch: call mijpeg_decode_batch_device first");
   mijpeg_batch b;
   memset(&b, 0, sizeof(b));
-  b.info = d->batch_info;
+  b.info = speculate ? assumed : d->batch_info;
   b.coef_dev = d->coef_dev;
   b.coef_frame_stride = b.info.coef_count;
   b.out_dev = (uint8_t *)dst_device;
   b.out_row_stride = row_stride;
   b.out_frame_stride = frame_stride;
-  b.frames = d->batch_frames;
+  b.frames = speculate ? -d->batch_frames : d->batch_frames;
   b.quant_dev = d->batch_own_tables ? d->batch_quant_dev : nullptr;
-  b.flags = flags & ~(MIJPEG_FLAG_DEVICE_OUTPUT | MIJPEG_FLAG_NO_UPSAMPLING);
+  b.flags = flags & ~(MIJPEG_FLAG_DEVICE_OUTPUT | MIJPEG_FLAG_NO_UPSAMPLING | MIJPEG_FLAG_SPECULATIVE);
   const size_t ws = mijpeg_workspace_bytes(&b);
   if (ws) {
     const int rc = ensure_dev(d, (void **)&d->ws_dev, &d->ws_cap, ws);
@@ -1575,6 +1696,17 @@ int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t
   const int rc = mijpeg_launch_reconstruct(&b, d->stream);
   if (rc) return set_error(d, rc, rc == MIJPEG_ERR_DEVICE ? std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError())
                                                            : std::string("reconstruction not available for this batch"));
+  if (speculate) {
+    d->spec_active = true;
+    d->spec_redone = false;
+    d->spec_dst = dst_device;
+    d->spec_frame_stride = frame_stride;
+    d->spec_row_stride = row_stride;
+    d->spec_flags = flags;
+    for (int c = 0; c < MIJPEG_MAX_COMPONENTS; c++) d->spec_assumed[c] = assumed.range_max[c];
+    d->spec_launched++;
+    return MIJPEG_OK;
+  }
   if (sync) HIP_TRY(d, hipStreamSynchronize(d->stream));
   return MIJPEG_OK;
 }

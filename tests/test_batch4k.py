@@ -125,3 +125,90 @@ def test_full_duplex_download_delivers_every_frame(oracle):
             exp = oracle.decode(streams[i])
             assert np.array_equal(host[i].numpy().reshape(exp.shape), exp), i
     shard.close()
+
+
+@pytest.mark.gpu
+def test_speculative_reconstruction_is_validated(oracle):
+    """MIJPEG_FLAG_SPECULATIVE: the reconstruction of a submitted batch is launched behind its Huffman kernel on the range check
+    of the last finished batch of that shape and those tables; mijpeg_finish_batch_device validates.  (1) the assumption holds:
+    nothing is redone; (2) a batch whose chroma leaves the assumed gate: the validation reconstructs again -- the pixels are the
+    oracle's either way; (3) a damaged member: the validation reports NOT_AVAILABLE like an ordinary finish; (4) the
+    pipeline of libjpeg_amd/batch.py on top of it, second pass speculative, with the full-duplex download."""
+    import torch
+    from PIL import Image
+    import io
+
+    from libjpeg_amd import api, synth
+
+    w, h = 416, 240
+    row = w * 3
+
+    def encode(img):
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=85, subsampling=2, restart_marker_blocks=2)
+        return buf.getvalue()
+
+    rng = np.random.default_rng(4)
+    calm = [encode(np.clip(128 + 40 * np.sin(np.arange(w)[None, :, None] / (9.0 + i)) + rng.normal(0, 3, (h, w, 3)), 0, 255).astype(np.uint8)) for i in range(4)]
+    wild = [encode(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)) for i in range(4)]  # noise in every channel: chroma far beyond the packed kernel's gate
+    out = torch.zeros((4, h, row), dtype=torch.uint8, device="cuda")
+    d = api.Decoder(0)
+
+    def pixels(i):
+        return out[i].cpu().numpy().reshape(h, w, 3)
+
+    # the hint: one ordinary batch of the calm material
+    d.submit_batch_device(calm, 1)
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row)
+    # (1) holds
+    d.submit_batch_device(calm, 1)
+    out.zero_()
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row, flags=api.FLAG_SPECULATIVE, sync=False)
+    d.finish_batch_device()
+    again, launched, redone = d.batch_speculation()
+    assert launched == 1 and redone == 0 and not again
+    for i in range(4):
+        assert np.array_equal(pixels(i), oracle.decode(calm[i])), i
+    # (2) the wild batch on the calm hint: redone
+    d.submit_batch_device(wild, 1)
+    out.zero_()
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row, flags=api.FLAG_SPECULATIVE, sync=False)
+    info = d.finish_batch_device()
+    again, launched, redone = d.batch_speculation()
+    assert launched == 2 and redone == 1 and again, (launched, redone, list(info.range_max))
+    for i in range(4):
+        assert np.array_equal(pixels(i), oracle.decode(wild[i])), i
+    # ... mijpeg_synchronize validates as well
+    d.submit_batch_device(calm, 1)  # (hint is the wild one now: calm lies below it, nothing to redo)
+    out.zero_()
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row, flags=api.FLAG_SPECULATIVE, sync=False)
+    d.synchronize()
+    assert d.batch_speculation()[1:] == (3, 1)
+    for i in range(4):
+        assert np.array_equal(pixels(i), oracle.decode(calm[i])), i
+    # (3) a damaged member
+    bad = bytearray(calm[1])
+    pos = bad.find(b"\xff\xda") + 200
+    while any(x == 0xFF for x in bad[pos - 1:pos + 14]):
+        pos += 1
+    bad[pos:pos + 12] = b"\xff\x00" * 6
+    d.submit_batch_device([calm[0], bytes(bad), calm[2]], 1)
+    d.reconstruct_batch_device(out.data_ptr(), h * row, row, flags=api.FLAG_SPECULATIVE, sync=False)
+    with pytest.raises(api.MijpegError) as e:
+        d.finish_batch_device()
+    assert e.value.code == api.ERR_NOT_AVAILABLE
+    d.close()
+    # (4) the pipeline
+    cfg = dict(batch.CONFIG4, width=640, height=368, frames=24)
+    streams = batch.make_streams(range(24), cfg)
+    shard = batch.BatchShard([streams[i] for i in range(24)], 0, chunk=5, depth=3)
+    shard.speculate = True  # (opt-in: MIJPEG_BATCH_SPECULATION)
+    host = torch.zeros(tuple(shard.out.shape), dtype=torch.uint8).pin_memory()
+    for p in range(3):
+        host.zero_()
+        shard.run(download_to=host)
+        for i in range(24):
+            exp = oracle.decode(streams[i])
+            assert np.array_equal(host[i].numpy().reshape(exp.shape), exp), (p, i)
+    assert sum(dec.batch_speculation()[1] for dec in shard.decoders) >= 8 and shard.redone == 0
+    shard.close()
