@@ -139,7 +139,7 @@ typedef struct {
 } oj_box;
 
 #define OJ_MAX_BOXES 64
-enum { FT_BASELINE = 0, FT_SEQUENTIAL = 1, FT_PROGRESSIVE = 2 };
+enum { FT_BASELINE = 0, FT_SEQUENTIAL = 1, FT_PROGRESSIVE = 2, FT_RESIDUAL = 3 /* SOF 0xffb1: the residual scan type of part 8 (lossless / near-lossless coding) */ };
 
 typedef struct {
   jmp_buf jb;
@@ -167,6 +167,7 @@ typedef struct {
   int nboxes;
   int walk_all;    /* the caller wants the boxes: walk all scans even without planes */
   int xt_legacy;   /* the legacy codestream of a JPEG XT decode: the caller follows the merging specification itself */
+  int residual_ok; /* the header of a RESI box's codestream is being read: SOF 0xffb1 is a frame type here */
   int in_memory;   /* the codestream lives in a box (the alpha channel's): a memory stream like a nested one's, an image of its own otherwise */
   int nested;      /* this is the residual codestream of a RESI box */
   int legacy_eoi_gone; /* nested: the residual codestream ran dry in front of a scan header and the search for one took the legacy
@@ -723,19 +724,23 @@ static void rs_parse_frame_header(oj_parser *ps, oj_bs *io)
   case 0xffc0: type = FT_BASELINE; break;
   case 0xffc1: type = FT_SEQUENTIAL; break;
   case 0xffc2: type = FT_PROGRESSIVE; break;
+  case 0xffb1: if (ps->nested || ps->residual_ok) type = FT_RESIDUAL; break; /* residual sequential: what `-ro` / `-Q 100` put into the RESI box */
   case 0xffc3: case 0xffc5: case 0xffc6: case 0xffc7: case 0xffc9: case 0xffca: case 0xffcb: case 0xffcd: case 0xffce:
-  case 0xffcf: case 0xffb1: case 0xffb2: case 0xffb3: case 0xffb9: case 0xffba: case 0xffbb: case 0xfff7: case 0xffde:
-    break; /* lossless, arithmetic, hierarchical, residual-only, JPEG LS: other coding processes */
+  case 0xffcf: case 0xffb2: case 0xffb3: case 0xffb9: case 0xffba: case 0xffbb: case 0xfff7: case 0xffde:
+    break; /* lossless, arithmetic, hierarchical, the other residual types, JPEG LS: other coding processes */
   default: rs_throw(ps, RS_MALFORMED_STREAM); /* "unexpected marker while parsing the image, decoder out of sync" */
   }
   if (ps->have_frame) rs_throw(ps, RS_MALFORMED_STREAM); /* "found a double frame header" */
   if (type < 0) rs_unsupported(ps);
   ps->frame_type = type;
   ps->progressive = ps->frame_type == FT_PROGRESSIVE;
+  f->residual_type = type == FT_RESIDUAL;
   len = bs_getword(io);
   if (len < 8) rs_throw(ps, RS_MALFORMED_STREAM);
   f->precision = (int)(bs_get(io) & 0xff);
-  if (ps->frame_type == FT_BASELINE ? f->precision != 8 : (f->precision != 8 && f->precision != 12)) rs_throw(ps, RS_MALFORMED_STREAM);
+  /* marker/frame.cpp:121-149: residual types 2..17 bits, baseline 8, the rest 8 or 12 */
+  if (ps->frame_type == FT_RESIDUAL ? (f->precision < 2 || f->precision > 17)
+                                    : ps->frame_type == FT_BASELINE ? f->precision != 8 : (f->precision != 8 && f->precision != 12)) rs_throw(ps, RS_MALFORMED_STREAM);
   data = bs_getword(io);
   if (data == BS_EOF) rs_throw(ps, RS_MALFORMED_STREAM);
   f->height = (int)data;
@@ -892,6 +897,7 @@ typedef struct {
   int ss, se, lowbit;
   int refinement;      /* RefinementScan instead of SequentialScan */
   int progressive_run; /* m_bProgressive: EOB runs are legal (sequentialscan.cpp:84-87) */
+  int residual;        /* m_bResidual: no DC coding, the band starts at position 0, symbol 0x10 = -0x8000 (sequentialscan.cpp:682, 709, 727-736) */
   int32_t pred[OJ_MAX_COMP];
   int skip[OJ_MAX_COMP];
   uint32_t ri, togo;
@@ -900,11 +906,12 @@ typedef struct {
   int scan_for_dnl, dnl_found; /* m_bScanForDNL, m_bDNLFound (codestream/entropyparser.cpp:79-80) */
 } oj_scan;
 
-/* SequentialScan::DecodeBlock, codestream/sequentialscan.cpp:678-773 (not residual, not large range, not differential) */
+/* SequentialScan::DecodeBlock, codestream/sequentialscan.cpp:678-773 (not large range, not differential; the residual flavour
+ * of `SequentialScan(.., true, true)`, marker/scan.cpp:483-489: no DC part, the AC part from position 0 on, symbol 0x10) */
 static void decode_block(oj_scan *sc, int32_t *block, const oj_huff *dc, const oj_huff *ac, int32_t *prevdc, int *skip)
 {
   oj_bits *b = &sc->bits;
-  if (sc->ss == 0) {
+  if (sc->ss == 0 && !sc->residual) {
     int32_t diff = 0;
     const int value = huff_get(b, dc);
     if (value > 0) {
@@ -920,7 +927,7 @@ static void decode_block(oj_scan *sc, int32_t *block, const oj_huff *dc, const o
     if (*skip > 0) {
       (*skip)--;
     } else {
-      int k = sc->ss ? sc->ss : 1;
+      int k = sc->ss ? sc->ss : (sc->residual ? 0 : 1);
       do {
         const int rs = huff_get(b, ac);
         int r = rs >> 4;
@@ -933,6 +940,14 @@ static void decode_block(oj_scan *sc, int32_t *block, const oj_huff *dc, const o
             if (r) *skip |= (int)bits_get(b, r);
             *skip = (*skip - 1) & 0xffff; /* UWORD */
             break;
+          }
+          if (sc->residual && rs == 0x10) { /* the value -0x8000, which has no magnitude category: four bits of run follow */
+            r = (int)bits_get(b, 4);
+            k += r;
+            if (k >= 64) rs_throw(sc->ps, RS_MALFORMED_STREAM);
+            block[g_scan_order[k]] = (int32_t)((uint32_t)(-0x8000) << sc->lowbit);
+            k++;
+            continue;
           }
           rs_throw(sc->ps, RS_MALFORMED_STREAM);
         }
@@ -1127,6 +1142,11 @@ static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
     if (sc.se < sc.ss) rs_throw(ps, RS_MALFORMED_STREAM);
     if (sc.ss == 0 && sc.se != 0) rs_throw(ps, RS_MALFORMED_STREAM);
     if (sc.ss && sc.ns != 1) rs_throw(ps, RS_MALFORMED_STREAM);
+  } else if (type == FT_RESIDUAL) { /* marker/scan.cpp:262-272 */
+    if (ah && ah != al + 1) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (sc.se < sc.ss) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (ah) rs_unsupported(ps); /* (no successive approximation here: the encoder writes none without -rR) */
+    sc.residual = 1;
   } else {
     if (sc.se != 63 || sc.ss != 0) rs_throw(ps, RS_MALFORMED_STREAM);
     if (ah != 0) rs_throw(ps, RS_MALFORMED_STREAM);
@@ -1154,7 +1174,7 @@ static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
   f->restart_interval = (int)ps->restart_interval;
   /* Huffman decoders: Tables::FindDC/ACHuffmanTable (tables.cpp:1423-1452) */
   for (i = 0; i < sc.ns; i++) {
-    if (sc.ss == 0 && !sc.refinement) {
+    if (sc.ss == 0 && !sc.refinement && !sc.residual) {
       oj_huff *h = &ps->huff[td[i]];
       if (!ps->have_huff) rs_throw(ps, RS_OBJECT_DOESNT_EXIST);
       if (!h->defined) huff_default(ps, h, 0, td[i] != 0);
@@ -1491,6 +1511,16 @@ int oj_read_info(const uint8_t *data, size_t len, oj_info *info)
   memset(&ps, 0, sizeof(ps));
   memset(info, 0, sizeof(*info));
   ps.data = data; ps.len = len; ps.info = info;
+  return walk(&ps, NULL);
+}
+
+/* ... of the codestream in a RESI box (its frame may be of the residual type) */
+static int read_residual_info(const uint8_t *data, size_t len, oj_info *info)
+{
+  oj_parser ps;
+  memset(&ps, 0, sizeof(ps));
+  memset(info, 0, sizeof(*info));
+  ps.data = data; ps.len = len; ps.info = info; ps.residual_ok = 1;
   return walk(&ps, NULL);
 }
 
@@ -1859,6 +1889,9 @@ typedef struct {
   const int32_t *qlut[3];           /* Q tables, 2^(Pr + 4) entries, NULL = the identity (a shift) */
   const int32_t *r2lut[3];          /* R2 tables, 2^(16 + 4) entries, NULL = the identity (x + 8) >> 4 */
   int rbypass, rnoise;              /* RDCT box: residual DCT bypassed (control/residualblockhelper.cpp:203-231), noise shaping */
+  int rct;                          /* R transformation = RCT (lossless / near-lossless coding: colortrafo/ycbcrtrafo.cpp:752-766) */
+  int rbits;                        /* fractional bits of the residual path: 4, 1 (RCT: a precision bit really) or 0 (identity,
+                                       lossless): Tables::FractionalColorBitsOf, codestream/tables.cpp:1621-1660 */
   int64_t outmax, outshift;         /* 2^(8 + extra bits) - 1 and its half */
   int is_float, clamp;              /* OCON: cast to float (half codes), clamping */
   int nc;                           /* components: 3, or 1 (grey scale; every transformation is the identity then) */
@@ -1895,12 +1928,29 @@ static void xt_merge_pixel(const oj_xt *xt, int64_t maxval, const int64_t vin[3]
 {
   const oj_info *r = xt->rinfo; /* (NULL where nothing is merged) */
   const int64_t rmax16 = r ? ((((int64_t)1 << r->precision)) << 4) - 1 : 0; /* ((m_lRMax + 1) << COLOR_BITS) - 1 */
+  const int64_t rmax = r ? ((int64_t)1 << r->precision) - 1 : 0;            /* m_lRMax */
   const int64_t omax16 = ((xt->outmax + 1) << 4) - 1;
   int64_t rr[3], q3[3], lv[3], v[3];
   int c;
   const int nc = xt->nc == 1 ? 1 : 3;
   rr[0] = rr[1] = rr[2] = 0; q3[1] = q3[2] = 0; lv[1] = lv[2] = 0;
   if (xt->no_residual) { rr[0] = rr[1] = rr[2] = xt->outshift; goto merge; }
+  if (xt->rct) {
+    /* colortrafo/ycbcrtrafo.cpp:752-766: the Q tables on the samples as they are (one extra bit, no fractional ones), then the
+     * reversible transformation with wrap-around (all LONG) */
+    int64_t y = xt->qlut[0][clampmax(rk[0], rmax)], cb = xt->qlut[1][clampmax(rk[1], rmax)], cr = xt->qlut[2][clampmax(rk[2], rmax)];
+    y = W32(y) >> 1;
+    cb = W32(cb - (xt->outshift << 1));
+    cr = W32(cr - (xt->outshift << 1));
+    rr[1] = W32(y - (W32(cb + cr) >> 2)) & xt->outmax;
+    rr[0] = W32(cr + rr[1]) & xt->outmax;
+    rr[2] = W32(cb + rr[1]) & xt->outmax;
+    goto merge;
+  }
+  if (!xt->rtrafo_ycbcr && !xt->clamp) { /* identity without clamping (:797-801, :820-822): the Q table alone, no fractional bits */
+    for (c = 0; c < nc; c++) rr[c] = xt->qlut[c][clampmax(rk[c], rmax)];
+    goto merge;
+  }
   /* Q tables (APPLY_LUT: index clamped to the table); the identity, 2^(Pr + 4) -> 2^(16 + 4), scales by 2^(16 - Pr)
    * (parametrictonemappingbox.cpp:387-430) */
   for (c = 0; c < nc; c++) {
@@ -1935,8 +1985,12 @@ merge:
       int64_t t = v[c] > pinf ? pinf : (v[c] < minf ? minf : v[c]);
       out[c] = (uint16_t)invert_negs((int16_t)t);
     }
-  } else {
+  } else if (xt->clamp) {
     for (c = 0; c < nc; c++) out[c] = (uint16_t)clampmax(v[c], xt->outmax);
+  } else if (xt->is_float) { /* :940-955: complement -> sign-magnitude, nothing else */
+    for (c = 0; c < nc; c++) out[c] = (uint16_t)invert_negs((int16_t)(uint16_t)v[c]);
+  } else { /* :957-972: WRAP */
+    for (c = 0; c < nc; c++) out[c] = (uint16_t)(v[c] & xt->outmax);
   }
 }
 
@@ -1972,7 +2026,8 @@ static int reconstruct_ex(const oj_info *f, int32_t *const planes[OJ_MAX_COMP], 
       if (xt->rbypass) {
         /* only the highest-frequency delta is used, times 2^COLOR_BITS; the level shift is NOT scaled (:196, :225) */
         const uint16_t *rq = r->scan_state_valid ? r->cquant[c] : r->quant[r->tq[c]];
-        const int32_t quant = ((int32_t)rq[63] << 4) & 0xffff /* UWORD m_usQuantization <<= rbits, residualblockhelper.cpp:351-364 */, dcs = (int32_t)(1 << r->precision) >> 1;
+        /* UWORD m_usQuantization, shifted by the fractional bits where there is more than one (residualblockhelper.cpp:351-364) */
+        const int32_t quant = xt->rbits > 1 ? ((int32_t)rq[63] << xt->rbits) & 0xffff : (int32_t)rq[63], dcs = (int32_t)(1 << r->precision) >> 1;
         int bx, by, i;
         for (by = 0; by < r->bh[c]; by++)
           for (bx = 0; bx < r->bw[c]; bx++) {
@@ -2684,7 +2739,7 @@ static int xt_codestreams_verdict(const uint8_t *data, size_t len, const oj_info
   if (ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) { *ref_error = ls.err; goto done; } }
   *eoi_image = ls.eoi_image;
   if (!ls.eoi_image || !resi) goto done;
-  rc = oj_read_info(resi->data, resi->len, &rinfo);
+  rc = read_residual_info(resi->data, resi->len, &rinfo);
   if (!rc && (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp)) { rinfo.ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; }
   if (rc) { *ref_error = rinfo.ref_error; goto done; }
   rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r; rs.nested = 1;
@@ -2838,7 +2893,8 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   /* (what the colour transformer finds: behind both codestreams' verdicts, see `late`) */
   if (ltrafo == 0 || ltrafo == 3 || ltrafo == 4) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto late; } /* "the base transformation ... is invalid" */
   if (rtrafo == 3) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; }
-  if (rtrafo == 4 || rtrafo == 0) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* RCT (lossless coding, part 8), zero */
+  if (rtrafo == 0) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* zero */
+  if (rtrafo == 4 && nc != 3) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   if (ctrafo != 255 && ctrafo != 1 && ctrafo < 5) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto late; }
   /* OBJECT_DOESNT_EXIST "the base / color / residual transformation specified in the codestream does not exist" (colortransformerfactory.cpp:355-400, 528-566) */
   if ((ltrafo >= 5 && !have_mtx[ltrafo]) || (ctrafo != 255 && ctrafo >= 5 && !have_mtx[ctrafo])) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; goto late; }
@@ -2850,7 +2906,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   /* (the output lookup flag and its table indices are read -- boxes/outputconversionbox.cpp:91-127 -- and never used by the
    * decoder: MergingSpecBox::OutputConversionLookupOf has no caller; the encoder sets them for alpha channels with a residual) */
   if (ocon >= 0) ocon &= ~0x01;
-  if (ocon < 0 || (ocon & 0x08)) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* lossless */
+  if (ocon < 0) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   xt.outmax = ((int64_t)1 << (8 + (ocon >> 4))) - 1;
   xt.outshift = (xt.outmax + 1) >> 1;
   xt.is_float = (ocon & 0x04) ? 1 : 0;
@@ -2858,17 +2914,26 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   /* without a residual only the clamping flavours of the transformer exist (colortransformerfactory.cpp:698-725, 850-885):
    * INVALID_PARAMETER "The combination of L and R transformation is non-standard and not supported" */
   if (!xt.clamp && lonly) { info->ref_error = RS_INVALID_PARAMETER; rc = OJ_ERR_MALFORMED; goto late; }
-  if (!xt.clamp) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* (wrap-around output: not followed) */
+  /* Which transformers exist beside a residual (colortransformerfactory.cpp:681-757, 793-995): R = YCbCr / free-form needs the
+   * clamping flavours, R = RCT the ones without, R = identity has all four; anything else: INVALID_PARAMETER "The combination of L
+   * and R transformation is non-standard and not supported" */
+  if (!lonly && ((rtrafo == 4 && xt.clamp) || (rtrafo != 4 && rtrafo != 1 && !xt.clamp))) { info->ref_error = RS_INVALID_PARAMETER; rc = OJ_ERR_MALFORMED; goto late; }
+  /* fractional bits of the residual path (Tables::FractionalColorBitsOf, tables.cpp:1621-1660): RCT one, the identity none when
+   * the lossless flag is set, four otherwise */
+  xt.rct = rtrafo == 4;
+  xt.rbits = rtrafo == 4 ? 1 : (rtrafo == 1 && (ocon & 0x08)) ? 0 : 4;
+  if (!lonly && xt.rbits == 0 && xt.clamp) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* (the reference indexes a table of 2^Pr entries with 2^(Pr+4): not followed) */
   if (xt.is_float && xt.outmax != 65535) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   /* free-form matrices run through the YCbCr branches of the transformer (colortransformerfactory.cpp:1036-1058) */
-  xt.ltrafo_ycbcr = ltrafo != 1; xt.rtrafo_ycbcr = rtrafo != 1;
+  xt.ltrafo_ycbcr = ltrafo != 1; xt.rtrafo_ycbcr = rtrafo != 1 && rtrafo != 4;
   if (disable_to_rgb && ltrafo == 2) xt.ltrafo_ycbcr = 0; /* MergingSpecBox::YCbCr only: a free-form matrix stays */
   memcpy(xt.lmat, ltrafo >= 5 ? mtx[ltrafo] : ltrafo == 2 ? std_ycc : std_id, sizeof(xt.lmat));
-  memcpy(xt.rmat, rtrafo >= 5 ? mtx[rtrafo] : rtrafo == 2 ? std_ycc : std_id, sizeof(xt.rmat));
+  memcpy(xt.rmat, rtrafo >= 5 ? mtx[rtrafo] : (rtrafo == 2 || rtrafo == 4) ? std_ycc : std_id, sizeof(xt.rmat));
   memcpy(xt.cmat, (ctrafo != 255 && ctrafo >= 5) ? mtx[ctrafo] : std_id, sizeof(xt.cmat));
   xt.rbypass = (rdct >> 4) == 3; xt.rnoise = rdct & 1;
+  if (!lonly && xt.rbits != 4 && !xt.rbypass) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* (a DCT with other preshifts: IDCT<1> / IDCT<0>, not restated) */
   /* the residual codestream is needed for the table dimensions */
-  rc = lonly ? OJ_OK : oj_read_info(resi->data, resi->len, &rinfo);
+  rc = lonly ? OJ_OK : read_residual_info(resi->data, resi->len, &rinfo);
   /* Image::ParseResidualStream (codestream/image.cpp:1289-1299) compares right behind the residual frame header, where a
    * residual codestream with a DNL marker still has zero lines: "residual image dimensions do not match ..." */
   if (!rc && !lonly && (rinfo.dnl || rinfo.width != info->width || rinfo.height != info->height)) { rinfo.ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; }
@@ -2908,12 +2973,14 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     if (!owned[c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; if (info->ref_error) goto late; goto out; }
     xt.ltable[c] = owned[c];
     if (lonly) continue; /* (Q and R2 tables are looked up beside a residual frame only, colortransformerfactory.cpp:452, 496) */
-    if (pr > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+    if (pr - (xt.rbits == 1) > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     t = qidx[c] == 255 ? &id0 : &nlt[qidx[c]];
     if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; }
-    owned[3 + c] = scaled_table(t, pr, outbits, 4, 4, &rc);
+    /* (the RCT's extra bit is a precision bit, not a fractional one: colortransformerfactory.cpp:441-446) */
+    owned[3 + c] = scaled_table(t, pr - (xt.rbits == 1), outbits, xt.rbits, xt.rbits, &rc);
     if (!owned[3 + c]) { info->ref_error = rc; rc = rc ? OJ_ERR_MALFORMED : OJ_ERR_NOMEM; late_residual_only = 1; if (info->ref_error) goto late; goto out; }
     xt.qlut[c] = owned[3 + c];
+    if (!xt.clamp) continue; /* (R2 tables exist with clipping only, colortransformerfactory.cpp:481) */
     t = r2idx[c] == 255 ? &id0 : &nlt[r2idx[c]];
     if (!t->kind) { info->ref_error = -1031; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; }
     owned[6 + c] = scaled_table(t, outbits, outbits, 4, 0, &rc);
@@ -2922,7 +2989,8 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   }
   /* the residual codestream is an ordinary codestream of its own (codestream/image.cpp:1264-1300) */
   if (!lonly && (rinfo.width != info->width || rinfo.height != info->height || rinfo.ncomp != info->ncomp)) { rc = OJ_ERR_MALFORMED; goto out; }
-  if (rinfo.precision + hidden_r > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  if (rinfo.precision + hidden_r - (xt.rbits == 1) > 16) { rc = OJ_ERR_UNSUPPORTED; goto out; }
+  if (rinfo.residual_type && hidden_r) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* (refinement scans of the residual kind: not restated) */
   info->ycbcr = xt.ltrafo_ycbcr;
   for (c = 0; c < nc; c++) {
     planes[c] = (int32_t *)malloc((size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));

@@ -76,6 +76,7 @@ typedef struct {
    * row that was not created reads as NULL and transforms to sample value 0 (dct/idct.cpp:336-338). */
   int dnl;
   int rows[OJ_MAX_COMP];
+  int residual_type;         /* the frame header is SOF 0xffb1: the residual scan type of part 8 (a RESI box's codestream) */
 } oj_info;
 
 /* Parse the headers only.  Returns OJ_OK or a negative error. */

@@ -27,7 +27,7 @@ class OjInfo(C.Structure):
         ("quant_defined", C.c_int * 4),
         ("scan_state_valid", C.c_int), ("cquant", (C.c_uint16 * 64) * 4), ("comp_seen", C.c_int * 4),
         ("ref_error", C.c_int), ("warnings", C.c_int),
-        ("dnl", C.c_int), ("rows", C.c_int * 4),
+        ("dnl", C.c_int), ("rows", C.c_int * 4), ("residual_type", C.c_int),
     ]
 
 
