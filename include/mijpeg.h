@@ -149,6 +149,11 @@ typedef struct mijpeg_xt_params {
   int32_t ltrafo_standard;   /* 1: the L transformation is the STANDARD YCbCr one (not a free-form matrix): the one a request without
                                 colour transformation (MIJPEG_FLAG_NO_COLOR_TRANSFORM, the command line's -c) replaces by the
                                 identity -- and nothing else of the merge (colortrafo/colortransformerfactory.cpp:231-232)          */
+  /* Lossless / near-lossless coding (part 8: the reference encoder's -ro and -Q 100): the residual codestream is of the residual scan
+   * type (SOF 0xffb1, no DCT: rdct_bypass), merged through the reversible colour transformation and without clamping */
+  int32_t rct;               /* R transformation = RCT (colortrafo/ycbcrtrafo.cpp:752-766); rtrafo_ycbcr is 0 then                     */
+  int32_t rbits;             /* fractional bits of the residual path: 4; 1 with the RCT (a precision bit: Q tables of 2^Pr entries); 0 for
+                                the identity under the lossless flag (Tables::FractionalColorBitsOf, codestream/tables.cpp:1621-1660)  */
 } mijpeg_xt_params;
 
 /* ---- decoder object (one image at a time; one object = one host thread at a time) ---------- */

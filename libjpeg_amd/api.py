@@ -49,7 +49,7 @@ class MijpegXtParams(C.Structure):
         ("out_max", C.c_int32), ("out_shift", C.c_int32), ("is_float", C.c_int32), ("clamp", C.c_int32),
         ("general", C.c_int32), ("lmat", C.c_int32 * 9), ("rmat", C.c_int32 * 9), ("cmat", C.c_int32 * 9),
         ("rdct_bypass", C.c_int32), ("noise_shaping", C.c_int32), ("qtable_entries", C.c_int32),
-        ("qtable", C.c_void_p * 3), ("r2table", C.c_void_p * 3), ("no_residual", C.c_int32), ("ltrafo_standard", C.c_int32),
+        ("qtable", C.c_void_p * 3), ("r2table", C.c_void_p * 3), ("no_residual", C.c_int32), ("ltrafo_standard", C.c_int32), ("rct", C.c_int32), ("rbits", C.c_int32),
     ]
 
 

@@ -2186,8 +2186,11 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     if (f.xt) {
       const mijpeg_xt_params &x = *b->xt;
       const int rprec = x.residual.precision + x.residual_hidden_bits;
-      if (x.hidden_bits < 0 || x.hidden_bits > 4 || x.residual_hidden_bits < 0 || x.residual_hidden_bits > 4 || rprec > 16 ||
-          x.ltable_entries != (256 << x.hidden_bits) || (x.residual_wide != 0) != (x.residual_hidden_bits > 0))
+      // (a parameter block filled in before the lossless flavours existed has zeros there: with clamping that means four bits)
+      const int xrbits = (x.rbits == 0 && x.clamp) ? 4 : x.rbits;
+      if (x.hidden_bits < 0 || x.hidden_bits > 4 || x.residual_hidden_bits < 0 || x.residual_hidden_bits > 4 || rprec - (x.rct ? 1 : 0) > 16 ||
+          x.ltable_entries != (256 << x.hidden_bits) || (x.residual_wide != 0) != (x.residual_hidden_bits > 0 || x.residual.precision > 12) ||
+          (xrbits != 4 && !(x.general && x.rdct_bypass)) || (x.rct && (x.clamp || xrbits != 1)) || (!x.clamp && !x.general))
         return MIJPEG_ERR_INVALID_PARAMETER;
       for (int c = 0; c < x.residual.components && c < 3; c++) plane(3 + c, x.residual, c, rprec); // (one component: planes 4, 5 stay empty)
       if (!x.residual.components) // (no residual frame at all -- a specification without a residual codestream: the merge reads nothing there)
@@ -2203,6 +2206,9 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       a.is_float = x.is_float;
       a.rprecision = rprec;
       a.xt_no_residual = x.no_residual;
+      a.xt_rct = x.rct;
+      a.xt_noclamp = x.clamp ? 0 : 1;
+      a.xt_rbits = x.residual.components ? xrbits : 4;
       a.legacy32 = lprec == 8 && f.range_max[0] < 16384 && f.range_max[1] < 16384 && f.range_max[2] < 16384 &&
                    !(b->flags & MIJPEG_FLAG_FORCE_SAFE);
       a.ltable = (const int32_t *)b->workspace;
@@ -2211,7 +2217,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
                            hipMemcpyHostToDevice, s) != hipSuccess)
           return MIJPEG_ERR_DEVICE;
       if (x.general) {
-        if (x.residual.components && x.qtable_entries != (1 << (rprec + 4))) return MIJPEG_ERR_INVALID_PARAMETER; // (no residual frame: no Q tables)
+        if (x.residual.components && x.qtable_entries != (1 << (rprec - (xrbits == 1) + xrbits))) return MIJPEG_ERR_INVALID_PARAMETER; // (no residual frame: no Q tables)
         a.xt_general = 1;
         a.rbypass = x.rdct_bypass;
         a.rnoise = x.noise_shaping;
@@ -2222,7 +2228,8 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
         char *tp = (char *)b->workspace + (mijpeg_workspace_bytes(b) - xt_table_bytes(b));
         for (int c = 0; c < 3; c++) {
           // only the highest-frequency delta is used, with the colour bits folded in (residualblockhelper.cpp:351-364)
-          a.rquant63[c] = ((int32_t)x.residual.quant[x.residual.quant_index[c]][63] << 4) & 0xffff; // m_usQuantization is a UWORD: deltas >= 4096 wrap
+          // (m_usQuantization is a UWORD: deltas >= 4096 wrap; shifted where the path has more than one fractional bit)
+          a.rquant63[c] = xrbits > 1 ? ((int32_t)x.residual.quant[x.residual.quant_index[c]][63] << xrbits) & 0xffff : (int32_t)x.residual.quant[x.residual.quant_index[c]][63];
           // (components that share a table share its copy)
           for (int j = 0; j < c; j++) {
             if (x.qtable[c] && x.qtable[j] == x.qtable[c]) a.qlut[c] = a.qlut[j];

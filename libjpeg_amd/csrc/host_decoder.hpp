@@ -73,6 +73,7 @@ struct Scan {
   // what the reference's parser for this scan is (marker/scan.cpp:355-470, codestream/sequentialscan.cpp:72-94)
   bool refinement = false;      // RefinementScan instead of SequentialScan
   bool progressive_run = false; // EOB runs are legal (m_bProgressive)
+  bool residual = false;        // the residual scan type of part 8 (SequentialScan(.., true, true), marker/scan.cpp:483-489)
   int lowbit = 0;               // point transform incl. hidden bits
 };
 

@@ -3340,13 +3340,33 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
   const int minf = -pinf - 1;
   for (int x = 0; x < npx; x++) {
     // residual chain: Q table, R transformation (FIX_COLOR_TO_INTCOLOR), R2 table
-    long long q3[3];
+    long long q3[3] = {0, 0, 0};
+    if (!a.xt_rct && !(a.xt_noclamp && !a.rtrafo_ycbcr)) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const int idx = min(max(rs[c][x], 0), rmax16);
-      q3[c] = a.qlut[c] ? (long long)a.qlut[c][idx] : (long long)idx << qshift;
+      for (int c = 0; c < 3; c++) {
+        const int idx = min(max(rs[c][x], 0), rmax16);
+        q3[c] = a.qlut[c] ? (long long)a.qlut[c][idx] : (long long)idx << qshift;
+      }
     }
     long long rr[3];
+    if (a.xt_rct) {
+      // lossless coding (colortrafo/ycbcrtrafo.cpp:752-766): the Q tables on the samples as they are -- the RCT's extra bit is a
+      // precision bit, no fractional ones -- then the reversible transformation with wrap-around, all in LONGs
+      const int rmax = (1 << a.rprecision) - 1;
+      int y = a.qlut[0][min(max(rs[0][x], 0), rmax)], cb = a.qlut[1][min(max(rs[1][x], 0), rmax)], cr = a.qlut[2][min(max(rs[2][x], 0), rmax)];
+      y >>= 1;
+      cb = (int)((unsigned)cb - ((unsigned)a.out_shift << 1));
+      cr = (int)((unsigned)cr - ((unsigned)a.out_shift << 1));
+      const int rg = (int)((unsigned)y - (unsigned)((int)((unsigned)cb + (unsigned)cr) >> 2)) & a.out_max;
+      rr[0] = (int)((unsigned)cr + (unsigned)rg) & a.out_max;
+      rr[1] = rg;
+      rr[2] = (int)((unsigned)cb + (unsigned)rg) & a.out_max;
+    } else if (a.xt_noclamp && !a.rtrafo_ycbcr) {
+      // identity without clamping (:797-801): the Q table alone, no fractional bits, no R2 table
+      const int rmax = (1 << a.rprecision) - 1;
+#pragma unroll
+      for (int c = 0; c < 3; c++) rr[c] = a.qlut[c][min(max(rs[c][x], 0), rmax)];
+    } else {
     if (a.rtrafo_ycbcr) {
       // (LONG variables around QUAD products in the reference: a table entry beyond the range -- curves with parameters no
       // encoder writes -- wraps where it narrows, colortrafo/ycbcrtrafo.cpp:776-789)
@@ -3360,6 +3380,7 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
     for (int c = 0; c < 3; c++) {
       const int idx = (int)min(max(rr[c], 0ll), (long long)omax16);
       rr[c] = a.r2lut[c] ? (long long)a.r2lut[c][idx] : (long long)((idx + 8) >> 4);
+    }
     }
     if (a.xt_no_residual) rr[0] = rr[1] = rr[2] = a.out_shift; // nothing to merge (colortrafo/ycbcrtrafo.cpp:744-746)
     // legacy chain: L transformation (FIX_COLOR_TO_INT), L table, C transformation (FIX_TO_INT)
@@ -3378,7 +3399,12 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       long long m = (int)(((lv[0] * a.cmat[3 * c] + lv[1] * a.cmat[3 * c + 1] + lv[2] * a.cmat[3 * c + 2] + 4096) >> 13) + rr[c] - a.out_shift); // (:868-879)
-      if (a.is_float) {
+      if (a.xt_noclamp) { // :940-972: the sign conversion of half float codes alone, or wrap-around
+        const short w = (short)m;
+        const unsigned v = a.is_float ? (unsigned)(uint16_t)(short)(((w >> 15) & 0x7fff) ^ w) : (unsigned)m & (unsigned)a.out_max;
+        if (a.sample_bytes == 1) reinterpret_cast<uint8_t *>(a.out + (int64_t)frame * a.out_frame_stride + (int64_t)Y * a.row_stride)[3 * (X0 + x) + c] = (uint8_t)v;
+        else dst[3 * x + c] = (uint16_t)v;
+      } else if (a.is_float) {
         m = min(max(m, (long long)minf), (long long)pinf);
         const short w = (short)m;
         dst[3 * x + c] = (uint16_t)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS
@@ -3419,15 +3445,25 @@ __global__ __launch_bounds__(256) void xt_merge1_kernel(const GenericArgs a)
   const int pinf = (a.out_max >> 1) - (a.out_max >> 6) - 1;
   const int minf = -pinf - 1;
   for (int x = 0; x < npx; x++) {
-    const int idx = min(max(rs[x], 0), rmax16);
-    const long long q = a.qlut[0] ? (long long)a.qlut[0][idx] : (long long)idx << qshift;
-    const int idx2 = (int)min(max(q, 0ll), (long long)omax16);
-    long long rr = a.r2lut[0] ? (long long)a.r2lut[0][idx2] : (long long)((idx2 + 8) >> 4);
+    long long rr;
+    if (a.xt_noclamp) { // identity without clamping (colortrafo/ycbcrtrafo.cpp:820-822): the Q table alone, no fractional bits
+      rr = a.qlut[0] ? (long long)a.qlut[0][min(max(rs[x], 0), (1 << a.rprecision) - 1)] : (long long)rs[x];
+    } else {
+      const int idx = min(max(rs[x], 0), rmax16);
+      const long long q = a.qlut[0] ? (long long)a.qlut[0][idx] : (long long)idx << qshift;
+      const int idx2 = (int)min(max(q, 0ll), (long long)omax16);
+      rr = a.r2lut[0] ? (long long)a.r2lut[0][idx2] : (long long)((idx2 + 8) >> 4);
+    }
     if (a.xt_no_residual) rr = a.out_shift; // nothing to merge (colortrafo/ycbcrtrafo.cpp:744-746)
     const long long v = ((long long)s[x] + 8) >> 4;
     const long long lv = a.ltable[(int)min(max(v, 0ll), (long long)a.maxval)];
     long long m = (int)(lv + rr - a.out_shift); // (a LONG: colortrafo/ycbcrtrafo.cpp:886-890)
-    if (a.is_float) {
+    if (a.xt_noclamp) {
+      const short w = (short)m;
+      const unsigned v = a.is_float ? (unsigned)(uint16_t)(short)(((w >> 15) & 0x7fff) ^ w) : (unsigned)m & (unsigned)a.out_max;
+      if (a.sample_bytes == 1) line[X0 + x] = (uint8_t)v;
+      else reinterpret_cast<uint16_t *>(line)[X0 + x] = (uint16_t)v;
+    } else if (a.is_float) {
       m = min(max(m, (long long)minf), (long long)pinf);
       const short w = (short)m;
       reinterpret_cast<uint16_t *>(line)[X0 + x] = (uint16_t)(short)(((w >> 15) & 0x7fff) ^ w); // INVERT_NEGS

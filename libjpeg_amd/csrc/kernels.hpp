@@ -80,6 +80,9 @@ struct GenericArgs {
   // JPEG XT profile C merge (colortrafo/ycbcrtrafo.cpp:750-955)
   int32_t xt, rtrafo_ycbcr, out_shift, out_max, is_float, rprecision;
   int32_t xt_no_residual;      // mijpeg_xt_params::no_residual: the residual chain's result is the output shift
+  int32_t xt_rct;              // R transformation = RCT (lossless coding): Q tables, reversible transformation with wrap-around
+  int32_t xt_noclamp;          // output without clamping: wrap-around (integers) or sign conversion alone (half float codes)
+  int32_t xt_rbits;            // fractional bits of the residual path (4, 1 with the RCT, 0 identity + lossless)
   int32_t legacy32;            // legacy colour stage may run in 32 bits (8-bit frame that passed the range check)
   int32_t ltable_entries;      // entries per L table: 256 << hidden bits of the legacy frame
   int32_t wide_first, wide_count; // planes [wide_first, wide_first + wide_count) hold int32 coefficients at coef_off (in

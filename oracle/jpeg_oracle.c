@@ -1515,6 +1515,7 @@ int oj_read_info(const uint8_t *data, size_t len, oj_info *info)
 }
 
 /* ... of the codestream in a RESI box (its frame may be of the residual type) */
+int oj_read_info_residual(const uint8_t *data, size_t len, oj_info *info);
 static int read_residual_info(const uint8_t *data, size_t len, oj_info *info)
 {
   oj_parser ps;
@@ -1564,6 +1565,8 @@ static int decode_coefficients_as(const uint8_t *data, size_t len, const oj_info
   if (!rc) out->ycbcr = tmp.ycbcr; /* the full walk has seen every box */
   return rc;
 }
+
+int oj_read_info_residual(const uint8_t *data, size_t len, oj_info *info) { return read_residual_info(data, len, info); }
 
 int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
                            int32_t *const planes[OJ_MAX_COMP])

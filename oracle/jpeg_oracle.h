@@ -87,6 +87,8 @@ int oj_read_info(const uint8_t *data, size_t len, oj_info *info);
  * they are zero-initialised here (coding/blockrow.cpp:77-87).  Reports info->rows[] (and the scan state) back. */
 int oj_decode_coefficients(const uint8_t *data, size_t len, const oj_info *info,
                            int32_t *const planes[OJ_MAX_COMP]);
+/* headers of the payload of a JPEG XT RESI box: its frame may be of the residual scan type (SOF 0xffb1, info->residual_type) */
+int oj_read_info_residual(const uint8_t *data, size_t len, oj_info *info);
 /* the same for the payload of a JPEG XT RESI box: the residual codestream, walked as the legacy image's trailer walks it */
 int oj_decode_coefficients_residual(const uint8_t *data, size_t len, const oj_info *info,
                                     int32_t *const planes[OJ_MAX_COMP]);

@@ -126,7 +126,12 @@ def xt_box_payload(data: bytes, box_type: bytes) -> bytes | None:
 def decode_residual_coefficients(data: bytes):
     """JPEG XT: -> (info, planes) of the residual codestream in the file's RESI box, walked as the reference walks it."""
     resi = xt_box_payload(data, b"RESI")
-    info = read_info(resi)
+    info = OjInfo()
+    L = lib()
+    L.oj_read_info_residual.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo)]
+    rc = L.oj_read_info_residual(resi, len(resi), C.byref(info))
+    if rc:
+        raise ValueError(f"oracle: oj_read_info_residual failed rc={rc}")
     planes = [np.zeros((info.bh[c], info.bw[c], 64), np.int32) for c in range(info.ncomp)]
     ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes] + [None] * (4 - info.ncomp))
     rc = lib().oj_decode_coefficients_residual(resi, len(resi), C.byref(info), ptrs)
