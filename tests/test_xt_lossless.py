@@ -56,6 +56,9 @@ def test_host_side(oracle, name):
     assert rinfo.residual_type == 1
     for c in range(info.components):
         assert np.array_equal(d.residual_coefficients(c).astype(np.int32), planes[c]), (name, c)
+        # every component's quantiser table is the one in force at ITS scan (one DQT per scan in these streams): what the bypass
+        # multiplies with is entry 63 of that one (control/residualblockhelper.cpp:351-364)
+        assert list(x.residual.quant[x.residual.quant_index[c]]) == list(rinfo.cquant[c]), (name, c)
     d.close()
 
 
