@@ -72,6 +72,8 @@ struct mijpeg_decoder {
   // (mijpeg_alpha_channel); its codestream is copied here because every parse of the file rebuilds the boxes
   mijpeg_decoder *alpha = nullptr;
   bool alpha_ready = false;
+  int alpha_refusal = 0;          // the alpha image reads, its transformer would not build (or this path declines it): the code
+  std::string alpha_refusal_msg;
   std::vector<uint8_t> alpha_data;
   uint8_t *enc_dev = nullptr; // encoder direction: pixels + coefficients of one picture
   size_t enc_cap = 0;
@@ -412,6 +414,7 @@ static int ensure_coef_store(mijpeg_decoder *d, size_t count, bool need_host = t
 static int decode_alpha_channel(mijpeg_decoder *d, int threads)
 {
   d->alpha_ready = false;
+  d->alpha_refusal = 0;
   if (!d->host.has_alpha()) return MIJPEG_OK;
   const uint8_t *p = nullptr;
   size_t n = 0;
@@ -430,9 +433,18 @@ static int decode_alpha_channel(mijpeg_decoder *d, int threads)
     else if (a.components != 1)
       rc = set_error(d->alpha, MIJPEG_ERR_MALFORMED_STREAM, "Malformed stream - the alpha channel may only consist of a single component");
   }
+  d->alpha_refusal = 0;
   if (rc) {
     const char *m = nullptr;
     mijpeg_last_error(d->alpha, &m);
+    // What the alpha image's colour transformer would refuse (a table that does not exist ...) the reference only finds when
+    // alpha pixels are asked for (Tables::ColorTrafoOf at the first request); what this path declines (-1034) is no reason to
+    // withhold the picture either: the file reads, mijpeg_alpha_channel reports why there is no alpha.
+    if (rc == MIJPEG_ERR_OPERATION_UNIMPLEMENTED || d->alpha->host.transformer_refused()) {
+      d->alpha_refusal = rc;
+      d->alpha_refusal_msg = m ? m : "";
+      return MIJPEG_OK;
+    }
     d->decoded = false; // the read has failed: no picture either (JPEG::Read returns false)
     return set_error(d, rc, m ? m : "the alpha channel does not decode");
   }
@@ -1723,6 +1735,10 @@ int mijpeg_last_error(mijpeg_decoder *d, const char **message)
 mijpeg_decoder *mijpeg_alpha_channel(mijpeg_decoder *d)
 {
   if (!d) return nullptr;
+  if (d->decoded && !d->alpha_ready && d->alpha_refusal) { // (what the reference reports at the first request for alpha pixels)
+    set_error(d, d->alpha_refusal, d->alpha_refusal_msg);
+    return nullptr;
+  }
   if (!d->decoded || !d->alpha_ready) {
     set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "the decoded stream has no alpha channel");
     return nullptr;

@@ -175,6 +175,9 @@ public:
   void preset_boxes(std::vector<XtBox> boxes) { preset_boxes_ = std::move(boxes); alpha_child_ = true; }
   // the last decode() stopped at a coefficient beyond the 16-bit store: decode_wide() is the next step (plain JPEG), or a refusal
   bool left_16bit_store() const { return left_16bit_store_; }
+  // the last parse failed with what the colour transformer refuses (a table or transformation that does not exist or does not fit):
+  // the reference reads such a file without complaint and fails at the first request for pixels
+  bool transformer_refused() const { return transformer_refused_; }
   mijpeg_xt_params xt{};
   std::vector<Scan> scans;
   StreamError error;
@@ -235,6 +238,7 @@ private:
   uint32_t alpha_matte_[3] = {0, 0, 0};
   std::vector<XtBox> preset_boxes_;
   bool ignore_residual_ = false; // late_verdict parses again: the legacy codestream has no EOI, the residual codestream is never looked at
+  bool transformer_refused_ = false;
   bool left_16bit_store_ = false; // the last decode stopped at a coefficient beyond the 16-bit store (OVERFLOW_PARAMETER): int32 planes next
   bool nested_ = false; // this object decodes a residual codestream
   int hidden_ = 0;      // JPEG XT: low bits of every coefficient that arrive in hidden refinement scans

@@ -339,14 +339,15 @@ static void rs_parse_dht(oj_parser *ps, oj_bs *io)
  * parametrictonemappingbox.cpp:85-149, lineartransformationbox.cpp:62-99).  announced: the box length; have: the bytes that
  * arrived (fewer when the file ends inside the box: reads beyond them find EOF). */
 #define SPEC_ID(a, b, c, d) (((uint32_t)(a) << 24) | ((uint32_t)(b) << 16) | ((uint32_t)(c) << 8) | (uint32_t)(d))
-static void rs_check_merging_spec(oj_parser *ps, const uint8_t *d, size_t have, uint64_t announced)
+/* is_alpha: the box is the ALPHA merging specification (ASPC), where the compositing box AMUL belongs (boxes/alphabox.cpp:60-90) */
+static void rs_check_merging_spec(oj_parser *ps, const uint8_t *d, size_t have, uint64_t announced, int is_alpha)
 {
   static const uint32_t once[16] = {
     SPEC_ID('R', 'S', 'P', 'C'), SPEC_ID('O', 'C', 'O', 'N'), SPEC_ID('L', 'D', 'C', 'T'), SPEC_ID('R', 'D', 'C', 'T'),
     SPEC_ID('L', 'T', 'R', 'F'), SPEC_ID('C', 'T', 'R', 'F'), SPEC_ID('R', 'T', 'R', 'F'), SPEC_ID('D', 'T', 'R', 'F'),
     SPEC_ID('S', 'T', 'R', 'F'), SPEC_ID('L', 'P', 'T', 'S'), SPEC_ID('Q', 'P', 'T', 'S'), SPEC_ID('C', 'P', 'T', 'S'),
     SPEC_ID('R', 'P', 'T', 'S'), SPEC_ID('S', 'P', 'T', 'S'), SPEC_ID('P', 'P', 'T', 'S'), SPEC_ID('D', 'P', 'T', 'S')};
-  int seen[16] = {0}, curve[16] = {0}, matrix[16] = {0};
+  int seen[16] = {0}, curve[16] = {0}, matrix[16] = {0}, amul = 0;
   uint64_t j = 0;
   while (j < announced) {
     const uint64_t left = announced - j;
@@ -409,7 +410,11 @@ static void rs_check_merging_spec(oj_parser *ps, const uint8_t *d, size_t have, 
       if (b < 0 || (b >> 4) < 5 || (b & 15) != 13 || j + overhead + len > have) rs_throw(ps, RS_MALFORMED_STREAM);
       if (matrix[b >> 4]) rs_throw(ps, RS_MALFORMED_STREAM); /* "found an double linear transformation for the same index" */
       matrix[b >> 4] = 1;
-    } else if (tbox == SPEC_ID('A', 'M', 'U', 'L')) rs_throw(ps, RS_MALFORMED_STREAM); /* alpha composition outside the alpha specification */
+    } else if (tbox == SPEC_ID('A', 'M', 'U', 'L')) {
+      if (!is_alpha || amul) rs_throw(ps, RS_MALFORMED_STREAM); /* outside the alpha specification, or twice */
+      amul = 1;
+      if (len != 10 || (SPEC_BYTE(0) >> 4) > 3 || (SPEC_BYTE(0) & 15) || SPEC_BYTE(1) != 0) rs_throw(ps, RS_MALFORMED_STREAM);
+    }
 #undef SPEC_BYTE
     j += xl;
   }
@@ -484,7 +489,8 @@ static void rs_parse_box_marker(oj_parser *ps, oj_bs *io, long length)
   if (ps->boxes[b].parsed == ps->boxes[b].boxsize) {
     const oj_box *bx = &ps->boxes[b];
     ps->boxes[b].complete = 1;
-    if (tbox == 0x53504543u) rs_check_merging_spec(ps, bx->data, bx->len, bx->boxsize);
+    if (tbox == 0x53504543u) rs_check_merging_spec(ps, bx->data, bx->len, bx->boxsize, 0);
+    if (tbox == 0x41535043u) rs_check_merging_spec(ps, bx->data, bx->len, bx->boxsize, 1); /* ASPC */
     /* tables and matrices of the file's own list parse where they complete (inversetonemappingbox.cpp:72-118,
      * parametrictonemappingbox.cpp:85-149, lineartransformationbox.cpp:62-99); a table index / matrix id may be taken once
      * (codestream/tables.cpp:1247-1266; NameSpace::isUniqueNonlinearity counts TONE, FTON and CURV boxes) */
@@ -2888,7 +2894,8 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     ltrafo = 1;
     if (!lonly) rtrafo = 1;
   }
-  if (ltrafo == 255) ltrafo = 2;
+  /* undefined: the rule of plain JPEG -- three components and no Adobe marker that says "none" (Tables::LTrafoTypeOf, tables.cpp:2021-2030) */
+  if (ltrafo == 255) ltrafo = (nc == 3 && info->adobe_transform != 0) ? 2 : 1;
   /* Tables::RTrafoTypeOf (codestream/tables.cpp:2040-2075) is asked whether there is a residual or not: "Found an invalid
    * residual transformation" for zero and JPEG_LS; any other value is never used without one */
   if (lonly && (rtrafo == 0 || rtrafo == 3)) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto late; }
@@ -3020,8 +3027,12 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
       rc = walk(&rs, rplanes);
       if (rc) info->ref_error = rtmp.ref_error;
       if (!rc && rs.eoi_frame) { rc = decode_hidden_scans(&rs, boxes, ps.nboxes, BOXID('R', 'F', 'I', 'N'), rplanes); if (rc) info->ref_error = rs.err; }
-    } else if (!rc)
+    } else if (!rc) {
       xt.no_residual = 1;
+      /* ... and the transformer is built without a residual frame: only the clamping flavours exist then
+       * (colortransformerfactory.cpp:262-283 with R transformation "zero", :698-725, 850-885) */
+      if (!xt.clamp) { info->ref_error = RS_INVALID_PARAMETER; rc = OJ_ERR_MALFORMED; }
+    }
     if (rc) goto out; /* (the reference's error code travels in info->ref_error) */
     memcpy(info->cquant, ltmp.cquant, sizeof(ltmp.cquant)); memcpy(info->comp_seen, ltmp.comp_seen, sizeof(ltmp.comp_seen));
     if (!lonly) { memcpy(rinfo.cquant, rtmp.cquant, sizeof(rtmp.cquant)); memcpy(rinfo.comp_seen, rtmp.comp_seen, sizeof(rtmp.comp_seen)); }
@@ -3196,7 +3207,9 @@ int oj_decode_alpha(const uint8_t *data, size_t len, oj_info *info, uint16_t **p
     given[n].type = t;
     n++;
   }
-  if (!alfa) { free_boxes(boxes, ps.nboxes); return OJ_ERR_UNSUPPORTED; }
+  /* (the reference turns to the ALFA box behind the legacy codestream's EOI, codestream/image.cpp:1430-1460: without one the file
+   * has no alpha channel) */
+  if (!alfa || !ps.eoi_image) { free_boxes(boxes, ps.nboxes); return OJ_ERR_UNSUPPORTED; }
   if (aspc) { /* AMUL inside the alpha merging specification */
     size_t j;
     for (j = 0; j + 8 <= aspc->len;) {

@@ -133,3 +133,32 @@ def test_gpu_pixels_of_box_variants(oracle, name):
         assert np.array_equal(d.reconstruct(), exp), name
     finally:
         d.close()
+
+
+def test_an_undefined_l_transformation_follows_the_adobe_marker(oracle):
+    """A merging specification WITHOUT an LTRF box leaves the L transformation to the rule of plain JPEG (Tables::LTrafoTypeOf,
+    codestream/tables.cpp:2021-2030): three components and no Adobe marker that says "none" -> YCbCr, else the identity -- with or
+    without a residual codestream.  (Rounds 1-4 took YCbCr for granted beside a residual; found by a byte inserted into the box's
+    type, tools/box_campaign.py.)"""
+    import os
+
+    import xt_craft
+    from conftest import GOLDEN_DIR
+
+    with open(os.path.join(GOLDEN_DIR, "xt_int8", "enc_444.jpg"), "rb") as f:
+        base = f.read()
+    no_ltrf = xt_craft.edit_spec(base, drop=(b"LTRF",))
+    adobe_none = b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00"
+    with_adobe = no_ltrf[:2] + adobe_none + no_ltrf[2:]
+    for blob, ycc in ((no_ltrf, 1), (with_adobe, 0)):
+        codes, _, err = oracle.decode_xt_status(blob)
+        assert err == 0
+        if oracle.have_reference():
+            rpx, rerr = oracle.reference_decode_status(blob)
+            assert rerr == 0 and np.array_equal(rpx.astype(np.uint16), codes.reshape(rpx.shape))
+        d = api.Decoder(None)
+        f = d.read(blob)
+        assert f.xt == 1 and d.xt_params().ltrafo_ycbcr == ycc and f.ycbcr == ycc
+        d.close()
+    a, b = oracle.decode_xt_status(no_ltrf)[0], oracle.decode_xt_status(with_adobe)[0]
+    assert not np.array_equal(a, b)
