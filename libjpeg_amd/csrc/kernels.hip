@@ -2328,6 +2328,96 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
   }
 }
 
+// 12-bit flavour (SOF1, P = 12; 16-bit samples out, 6 B in + 6 B out per pixel): the same decomposition with the chroma blocks kept as
+// 32-bit values (64 + 64 VGPRs: a 12-bit chroma sample times 16 does not fit 16 bits), two waves per SIMD.  The colour stage is
+// fused420_kernel<.., 12>'s: (y' + 32776 + (c L >> 13)) >> 4 clamped to [0, 4095], exact under the host's range gates
+// (use_fused444_12: the 12-bit 4:2:0 kernel's bounds; there is no filter between transform and colour stage here).
+template <bool QDEV>
+__global__ __launch_bounds__(F420_THREADS, 2) void fused444_12_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const TilePos tp = tile_position(blockIdx.x, a);
+  if (tp.frame < 0) return;
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+  const int x0 = gbx0 + (lane >> 3);
+  auto fetch = [&](u32x4 (&rows)[8], int64_t plane_off) {
+    const char *pbase = reinterpret_cast<const char *>(coef + plane_off) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  };
+
+  int cb[64], cr[64], yv[64];
+  {
+    u32x4 rows[8];
+    fetch(rows, a.off_cb);
+    dequant_idct_sparse<false>(rows, frame_deltas<QDEV>(a, frame, 1), cb);
+    __builtin_amdgcn_sched_barrier(0); // (register pressure: one component at a time)
+    fetch(rows, a.off_cr);
+    dequant_idct_sparse<false>(rows, frame_deltas<QDEV>(a, frame, 2), cr);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(rows, a.off_y);
+  
+    if (gbx * 8 >= a.width || gby * 8 >= a.height) return;
+    dequant_idct_sparse<false>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 6u;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = npx == 8;
+  static_assert(L_CB_B % 4 == 0, "the blue product is taken at a quarter of the constant");
+  auto c12 = [](int v) { return (unsigned)min(max(v, 0), 4095); };
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    if (l < nln) {
+      int rr[8], gg[8], bb[8];
+#pragma unroll
+      for (int x = 0; x < 8; x++) {
+        const int yk = yv[l * 8 + x] + (32768 + 8);
+        const int b = cb[l * 8 + x], r = cr[l * 8 + x];
+        rr[x] = (yk + (__mul24(r, L_CR_R) >> 13)) >> 4;
+        gg[x] = (yk + (mad24(r, -L_CR_G, __mul24(b, -L_CB_G)) >> 13)) >> 4;
+        bb[x] = (yk + (__mul24(b, L_CB_B / 4) >> 11)) >> 4;
+      }
+      uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+      if (fast_store) {
+        unsigned w[12]; // 48 bytes r0 g0 b0 r1 ... b7, 16-bit samples
+#pragma unroll
+        for (int x = 0; x < 8; x += 2) {
+          w[3 * (x / 2) + 0] = c12(rr[x]) | (c12(gg[x]) << 16);
+          w[3 * (x / 2) + 1] = c12(bb[x]) | (c12(rr[x + 1]) << 16);
+          w[3 * (x / 2) + 2] = c12(gg[x + 1]) | (c12(bb[x + 1]) << 16);
+        }
+        u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
+        __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
+        __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
+        __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+        __builtin_amdgcn_sched_barrier(0); // one line at a time
+      } else {
+        uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+          if (x < npx) {
+            d16[3 * x] = (uint16_t)c12(rr[x]); d16[3 * x + 1] = (uint16_t)c12(gg[x]); d16[3 * x + 2] = (uint16_t)c12(bb[x]);
+          }
+      }
+    }
+  }
+}
+
 // ==============================================================================================
 // single-component kernel (grey scale frames, and one component of any frame reconstructed without upsampling):
 // ReconstructUnsampled with the identity transformation, control/blockbitmaprequester.cpp:1013-1074
@@ -3761,6 +3851,16 @@ int launch_fused444(const Fused420Args &a0, hipStream_t stream)
   // 168 VGPRs -> three waves per SIMD: 5 % faster than the unconstrained 171-register build
   if (a.qdev) hipLaunchKernelGGL((fused444_kernel<2, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused444_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused444_12(const Fused420Args &a0, hipStream_t stream)
+{
+  const Fused420Args a = with_tile_magic(a0);
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
+  if (total == 0) return 0;
+  if (a.qdev) hipLaunchKernelGGL((fused444_12_kernel<true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused444_12_kernel<false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

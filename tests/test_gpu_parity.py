@@ -1499,15 +1499,19 @@ def test_rectangle_service_band_waits(dec, oracle):
 # ------------------------------------------------------------------------------------------------------
 # 12-bit 4:2:0 frames on the fused kernel (fused420_kernel<12>)
 # ------------------------------------------------------------------------------------------------------
+KERNEL_12 = {"420": "fused420_kernel<12>", "444": "fused444_12_kernel"}
+
+
+@pytest.mark.parametrize("sub", ["420", "444"])
 @pytest.mark.parametrize("w,h,dri,scale", [(200, 120, 8, 16), (272, 144, 0, 16), (129, 71, 3, 9), (640, 368, 4, 16), (1, 1, 0, 16), (17, 250, 1, 5)])
-def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale):
-    """12-bit extended sequential 4:2:0 frames (synth.to_12bit: the 8-bit stream's entropy coded data with deltas times
-    `scale`): the 12-bit flavour of the fused kernel against the oracle (which the CPU tests pin against the reference binary
+def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale, sub):
+    """12-bit extended sequential 4:2:0 and 4:4:4 frames (synth.to_12bit: the 8-bit stream's entropy coded data with deltas times
+    `scale`): the 12-bit flavours of the fused kernels against the oracle (which the CPU tests pin against the reference binary
     on the same kind of stream), against the unfused kernels, and through the stripe service."""
-    data = synth.to_12bit(synth.synth_jpeg(w, h, 11 + w, 85, "420", dri), scale)
+    data = synth.to_12bit(synth.synth_jpeg(w, h, 11 + w, 85, sub, dri), scale)
     f = dec.read(data)
     assert f.precision == 12 and f.sample_bytes == 2
-    assert api.kernel_name(f) == "fused420_kernel<12>", list(f.range_max)
+    assert api.kernel_name(f) == KERNEL_12[sub], list(f.range_max)
     exp = oracle.decode16(data)
     out = dec.reconstruct()
     assert out.dtype == np.uint16 and np.array_equal(out, exp)
@@ -1521,15 +1525,16 @@ def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale):
         assert rerr == 0 and np.array_equal(np.asarray(rpx).reshape(exp.shape), exp)
 
 
+@pytest.mark.parametrize("sub", ["420", "444"])
 @pytest.mark.parametrize("luma_budget,chroma_budget,fused", [(49151, 45055, True), (49151, 45056, False), (49152, 1000, False), (30000, 45055, True), (45055, 32767, True)])
-def test_extreme_coefficients_at_the_12bit_gates(oracle, luma_budget, chroma_budget, fused):
-    """fused420_kernel<12> is admitted by sum |c| q < 49152 (the 32-bit butterflies) and < 45056 for the chroma planes (the
+def test_extreme_coefficients_at_the_12bit_gates(oracle, luma_budget, chroma_budget, fused, sub):
+    """fused420_kernel<12> (and fused444_12_kernel, same bounds) is admitted by sum |c| q < 49152 (the 32-bit butterflies) and < 45056 for the chroma planes (the
     32-bit colour products).  Blocks right at those bounds with every sign pattern (DC-only, one AC coefficient, dense) must still come
     out like the reference's 64-bit arithmetic; one step beyond, the unfused kernels take the frame (and agree as well)."""
     torch = _torch()
     W, H = 272, 144
     d = api.Decoder(0)
-    data = synth.to_12bit(synth.synth_jpeg(W, H, 5, 85, "420", 0))
+    data = synth.to_12bit(synth.synth_jpeg(W, H, 5, 85, sub, 0))
     f = d.read(data)
     d.close()
     rng = np.random.default_rng(luma_budget + chroma_budget)
@@ -1569,7 +1574,7 @@ def test_extreme_coefficients_at_the_12bit_gates(oracle, luma_budget, chroma_bud
         f.range_max[c] = int((np.abs(planes[c]).astype(np.int64) * q).sum(axis=2).max())
     assert f.range_max[0] <= luma_budget and f.range_max[1] <= chroma_budget and f.range_max[2] <= chroma_budget
     assert f.range_max[0] == luma_budget and f.range_max[1] == chroma_budget, list(f.range_max)
-    assert (api.kernel_name(f) == "fused420_kernel<12>") == fused, (api.kernel_name(f), list(f.range_max))
+    assert (api.kernel_name(f) == KERNEL_12[sub]) == fused, (api.kernel_name(f), list(f.range_max))
     exp = oracle.reconstruct16(info, planes)
     coef = torch.from_numpy(np.concatenate([p.astype(np.int16).reshape(-1) for p in planes])).cuda()
     row = W * 6
