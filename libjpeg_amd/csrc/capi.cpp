@@ -1898,6 +1898,21 @@ static bool use_fused444_12(const mijpeg_batch *b)
   return true;
 }
 
+// 12-bit 4:2:2 frames: the same bounds again (the horizontal filter weighs samples below 2^18 with 4 in total)
+static bool use_fused422_12(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  static const bool off = getenv("MIJPEG_NO_F422_12") != nullptr; // A-B comparisons
+  if (off || !is_422(f) || !f.ycbcr || f.xt || f.precision != 12 ||
+      (b->flags & (MIJPEG_FLAG_FORCE_GENERIC | MIJPEG_FLAG_NO_COLOR_TRANSFORM | MIJPEG_FLAG_FORCE_SAFE)) || !fits32(b))
+    return false;
+  if (f.range_max[0] <= 0 || f.range_max[0] >= 49152 || f.range_max[1] >= 45056 || f.range_max[2] >= 45056) return false;
+  for (int c = 0; c < 3; c++)
+    for (int i = 0; i < 64; i++)
+      if (f.quant[f.quant_index[c]][i] > 2047) return false;
+  return true;
+}
+
 // 12-bit single-component frames: the butterflies' bound alone
 static bool use_fused1_12(const mijpeg_batch *b)
 {
@@ -2042,6 +2057,7 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (use_fused420_12(b)) return "fused420_kernel<12>";
   if (use_fused1_12(b)) return "fused1_kernel<12>";
   if (use_fused444_12(b)) return "fused444_12_kernel";
+  if (use_fused422_12(b)) return "fused422_12_kernel";
   if (b->info.coef_wide) return "idct_planes_long_kernel+upsample_color_kernel";
   if (use_fused420(b)) return "fused420_kernel";
   if (use_fused444(b)) return "fused444_kernel";
@@ -2072,7 +2088,7 @@ static size_t expanded_tables_bytes(const mijpeg_batch *b) { return b->quant_dev
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
 {
   if (!b) return 0;
-  if (use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused411(b) || use_fused1(b) || use_fused420_12(b) || use_fused1_12(b) || use_fused444_12(b)) return expanded_tables_bytes(b);
+  if (use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused411(b) || use_fused1(b) || use_fused420_12(b) || use_fused1_12(b) || use_fused444_12(b) || use_fused422_12(b)) return expanded_tables_bytes(b);
   if (use_fusedxt(b)) return LUT_BYTES;
   // [LUT_BYTES: L lookup tables (JPEG XT, up to 3 x 4096 entries)] [per frame: int32 sample planes, one sample per
   // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients] [expanded per-frame tables]
@@ -2104,7 +2120,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
   hipStream_t s = (hipStream_t)stream;
   int rc;
   const bool f444 = use_fused444(b), fxt = use_fusedxt(b), f422 = use_fused422(b), f440 = use_fused440(b), f411 = use_fused411(b), f1 = use_fused1(b);
-  const bool f420_12 = use_fused420_12(b), f1_12 = use_fused1_12(b), f444_12 = use_fused444_12(b);
+  const bool f420_12 = use_fused420_12(b), f1_12 = use_fused1_12(b), f444_12 = use_fused444_12(b), f422_12 = use_fused422_12(b);
   if (fxt && (!b->workspace || b->workspace_bytes < LUT_BYTES)) return MIJPEG_ERR_MISSING_PARAMETER;
   const int32_t *qdev = nullptr;
   if (b->quant_dev) {
@@ -2114,7 +2130,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     if (launch_expand_deltas(b->quant_dev, dst, b->frames, s)) return MIJPEG_ERR_DEVICE;
     qdev = dst;
   }
-  if (use_fused420(b) || f444 || fxt || f422 || f440 || f411 || f1 || f420_12 || f1_12 || f444_12) {
+  if (use_fused420(b) || f444 || fxt || f422 || f440 || f411 || f1 || f420_12 || f1_12 || f444_12 || f422_12) {
     FusedXtArgs xa;
     memset(&xa, 0, sizeof(xa));
     Fused420Args &a = xa.base;
@@ -2133,11 +2149,11 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
     a.bw_c = f.blocks_w[1];
     a.bh_c = f.blocks_h[1];
     a.cw = f440 ? f.width : f411 ? (f.width + 3) / 4 : (f.width + 1) / 2;
-    a.ch = (f422 || f411) ? f.height : (f.height + 1) / 2;
+    a.ch = (f422 || f411 || f422_12) ? f.height : (f.height + 1) / 2;
     // DNL frames: the reference's upsamplers never learnt the height (upsampling/upsamplerbase.cpp:61-75), their line buffers
     // have no bottom edge: below the last chroma line comes what the block rows hold (the padding of the last one, then the
     // MCU row the first scan created behind the picture: the store has it, include/mijpeg.h) instead of that line again
-    if (f.dnl && !(f422 || f411) && f.components > 1) a.ch = a.bh_c * 8;
+    if (f.dnl && !(f422 || f411 || f422_12) && f.components > 1) a.ch = a.bh_c * 8;
     a.tiles_x = (f.width + 127) / 128;
     a.tiles_y = (f.height + 127) / 128;
     a.frames = b->frames;
@@ -2163,7 +2179,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       xa.ext.rprecision = r.precision + x.residual_hidden_bits;
       rc = launch_fusedxt420(xa, s);
     } else
-      rc = f420_12 ? launch_fused420_12(a, s) : f444_12 ? launch_fused444_12(a, s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
+      rc = f420_12 ? launch_fused420_12(a, s) : f444_12 ? launch_fused444_12(a, s) : f422_12 ? launch_fused422_12(a, s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

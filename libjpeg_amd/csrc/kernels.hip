@@ -1459,6 +1459,161 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
   }
 }
 
+// 12-bit flavour of the 4:2:2 kernel (SOF1, P = 12; 16-bit samples out, 4 B in + 6 B out per pixel): the same tile, the chroma
+// samples as 32-bit values in two LDS planes (a 12-bit chroma sample times 16 does not fit 16 bits: 72 KB + the fetch staging
+// = half a CU's LDS, two workgroups per CU), fused420_kernel<.., 12>'s colour stage behind the horizontal filter.  Gates:
+// use_fused422_12 (capi.cpp), the 12-bit 4:2:0 kernel's.
+template <bool QDEV>
+__global__ __launch_bounds__(F420_THREADS, 2) void fused422_12_kernel(const Fused420Args a)
+{
+  __shared__ __attribute__((aligned(16))) int cplane[2][F422_CROWS * F420_CPITCH];
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 *stage = stage_all[wave];
+
+  const TilePos tp = tile_position(blockIdx.x, a);
+  if (tp.frame < 0) return;
+  const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
+  const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
+
+  // ------------------------------------------------------------------ phase A: chroma -> LDS (see fused422_kernel)
+  {
+    const int comp = wave >> 1;
+    const int16_t *__restrict__ plane = coef + (comp ? a.off_cr : a.off_cb);
+    const int gx0 = tx * 8, gy0 = ty * 16 + (wave & 1) * 8;
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    int *cp = cplane[comp];
+    u32x4 rows[8];
+    {
+      const int xx = min(gx0 + (lane >> 3), a.bw_c - 1);
+      fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int yy = min(gy0 + m, a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
+      });
+      const int cbx = lane & 7, cby = lane >> 3;
+      if (gx0 + cbx < a.bw_c && gy0 + cby < a.bh_c) {
+        int v[64];
+        dequant_idct_sparse<false>(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          i32x4 *dst = reinterpret_cast<i32x4 *>(cp + (8 * ((wave & 1) * 8 + cby) + r) * F420_CPITCH + 8 * cbx + 4);
+          dst[0] = i32x4{v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3]};
+          dst[1] = i32x4{v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]};
+        }
+      }
+    }
+    {
+      fetch_blocks16(rows, stage, lane, [&](int m) -> const u32x4 * {
+        const int n = (lane >> 3) + 8 * m;
+        const int xx = min(max((n & 1) ? gx0 + 8 : gx0 - 1, 0), a.bw_c - 1), yy = min(gy0 + (n >> 1), a.bh_c - 1);
+        return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_c + xx) * 128));
+      });
+      const int side = lane & 1, cby = lane >> 1, gx = side ? gx0 + 8 : gx0 - 1;
+      if (lane < 16 && gx >= 0 && gx < a.bw_c && gy0 + cby < a.bh_c) {
+        int col[8];
+        dequant_idct_column(rows, frame_deltas<QDEV>(a, frame, 1 + comp), side == 0, col);
+#pragma unroll
+        for (int r = 0; r < 8; r++) cp[(8 * ((wave & 1) * 8 + cby) + r) * F420_CPITCH + (side ? 68 : 3)] = col[r];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int last_col = a.cw - 1 - tx * 64; // last valid chroma column, tile-relative
+    if ((tx == 0) | (last_col < 64)) {
+      if (tid < 2 * F422_CROWS) { // one thread per stored line and component
+        int *p = cplane[tid >> 7] + (tid & (F422_CROWS - 1)) * F420_CPITCH;
+        if (tx == 0) p[3] = p[4];
+        if (last_col < 64) {
+          const int v = p[last_col + 4];
+          for (int pc = last_col + 5; pc <= 68; pc++) p[pc] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ phase B: luma, upsampling, colour
+  const int bx = lane & 15, by = wave * 4 + (lane >> 4);
+  const int gbx = tx * F420_TILE_BLOCKS + bx, gby = ty * F420_TILE_BLOCKS + by;
+  u32x4 rows[8];
+  {
+    const int16_t *__restrict__ plane = coef + a.off_y;
+    const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int x = min(x0 + 8 * (m & 1), a.bw_y - 1), y = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((y * a.bw_y + x) * 128));
+    });
+  }
+  const int X0 = gbx * 8, Y0 = gby * 8;
+  if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
+  int yv[64];
+  dequant_idct_sparse<false>(rows, frame_deltas<QDEV>(a, frame, 0), yv);
+
+  uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
+  const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 6u;
+  const int npx = min(8, a.width - X0);
+  const int nln = min(8, a.height - Y0);
+  const bool fast_store = npx == 8;
+  const int *cb_base = cplane[0] + (8 * by) * F420_CPITCH + 4 * bx;
+  const int *cr_base = cplane[1] + (8 * by) * F420_CPITCH + 4 * bx;
+  auto load6 = [](const int *p, int (&d)[6]) { // p is 16-byte aligned; wanted: p[3..8]
+    const i32x4 mid = *reinterpret_cast<const i32x4 *>(p + 4);
+    d[0] = p[3]; d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w; d[5] = p[8];
+  };
+  static_assert(L_CB_B % 4 == 0, "the blue product is taken at a quarter of the constant");
+  auto c12 = [](int v) { return (unsigned)min(max(v, 0), 4095); };
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    int vb[6], vr[6], ub[8], ur[8];
+    load6(cb_base + l * F420_CPITCH, vb);
+    load6(cr_base + l * F420_CPITCH, vr);
+    // horizontal filter in place (upsampler.cpp:291-303); src[k] = v[k + 1]
+#define MIJ_HFILTER(o, s)                                                                                        \
+    o[7] = tap13(s[5], s[4], 1); o[6] = tap13(s[3], s[4], 2); o[5] = tap13(s[4], s[3], 1); o[4] = tap13(s[2], s[3], 2); \
+    o[3] = tap13(s[3], s[2], 1); o[2] = tap13(s[1], s[2], 2); o[1] = tap13(o[2], s[1], 1); o[0] = tap13(s[0], s[1], 2);
+    MIJ_HFILTER(ub, vb)
+    MIJ_HFILTER(ur, vr)
+#undef MIJ_HFILTER
+    if (l < nln) {
+      int rr[8], gg[8], bb[8];
+#pragma unroll
+      for (int x = 0; x < 8; x++) { // (fused420_kernel<.., 12> has the derivation)
+        const int yk = yv[l * 8 + x] + (32768 + 8);
+        rr[x] = (yk + (__mul24(ur[x], L_CR_R) >> 13)) >> 4;
+        gg[x] = (yk + (mad24(ur[x], -L_CR_G, __mul24(ub[x], -L_CB_G)) >> 13)) >> 4;
+        bb[x] = (yk + (__mul24(ub[x], L_CB_B / 4) >> 11)) >> 4;
+      }
+      uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
+      if (fast_store) {
+        unsigned w[12];
+#pragma unroll
+        for (int x = 0; x < 8; x += 2) {
+          w[3 * (x / 2) + 0] = c12(rr[x]) | (c12(gg[x]) << 16);
+          w[3 * (x / 2) + 1] = c12(bb[x]) | (c12(rr[x + 1]) << 16);
+          w[3 * (x / 2) + 2] = c12(gg[x + 1]) | (c12(bb[x + 1]) << 16);
+        }
+        u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
+        __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
+        __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
+        __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+      } else {
+        uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+          if (x < npx) {
+            d16[3 * x] = (uint16_t)c12(rr[x]); d16[3 * x + 1] = (uint16_t)c12(gg[x]); d16[3 * x + 2] = (uint16_t)c12(bb[x]);
+          }
+      }
+    }
+  }
+}
+
 // ==============================================================================================
 // fused 4:1:1 kernel (Y 1x1, Cb/Cr subsampled 4x1: DV-style sampling, `jpeg -s 1x1,4x1,4x1`)
 // ==============================================================================================
@@ -3851,6 +4006,16 @@ int launch_fused444(const Fused420Args &a0, hipStream_t stream)
   // 168 VGPRs -> three waves per SIMD: 5 % faster than the unconstrained 171-register build
   if (a.qdev) hipLaunchKernelGGL((fused444_kernel<2, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused444_kernel<3, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused422_12(const Fused420Args &a0, hipStream_t stream)
+{
+  const Fused420Args a = with_tile_magic(a0);
+  const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
+  if (total == 0) return 0;
+  if (a.qdev) hipLaunchKernelGGL((fused422_12_kernel<true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused422_12_kernel<false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -121,6 +121,7 @@ int launch_fused1_12(const Fused420Args &a, hipStream_t stream);   // 12-bit sin
 int launch_fused420_12(const Fused420Args &a, hipStream_t stream); // 12-bit frames inside the range gates, 16-bit samples out
 int launch_fused420p(const Fused420Args &a, hipStream_t stream); // FAST only, chroma samples within int16 filter range
 int launch_fused444(const Fused420Args &a, hipStream_t stream); // same argument block; all planes bw_y x bh_y
+int launch_fused422_12(const Fused420Args &a, hipStream_t stream); // 12-bit 4:2:2 frames inside the range gates
 int launch_fused444_12(const Fused420Args &a, hipStream_t stream); // 12-bit 4:4:4 frames inside the range gates, 16-bit samples out
 int launch_fused1(const Fused420Args &a, hipStream_t stream);   // single component: plane off_y, bw_y x bh_y blocks, one byte per pixel
 int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream);

@@ -1499,13 +1499,13 @@ def test_rectangle_service_band_waits(dec, oracle):
 # ------------------------------------------------------------------------------------------------------
 # 12-bit 4:2:0 frames on the fused kernel (fused420_kernel<12>)
 # ------------------------------------------------------------------------------------------------------
-KERNEL_12 = {"420": "fused420_kernel<12>", "444": "fused444_12_kernel"}
+KERNEL_12 = {"420": "fused420_kernel<12>", "444": "fused444_12_kernel", "422": "fused422_12_kernel"}
 
 
-@pytest.mark.parametrize("sub", ["420", "444"])
+@pytest.mark.parametrize("sub", ["420", "444", "422"])
 @pytest.mark.parametrize("w,h,dri,scale", [(200, 120, 8, 16), (272, 144, 0, 16), (129, 71, 3, 9), (640, 368, 4, 16), (1, 1, 0, 16), (17, 250, 1, 5)])
 def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale, sub):
-    """12-bit extended sequential 4:2:0 and 4:4:4 frames (synth.to_12bit: the 8-bit stream's entropy coded data with deltas times
+    """12-bit extended sequential 4:2:0, 4:4:4 and 4:2:2 frames (synth.to_12bit: the 8-bit stream's entropy coded data with deltas times
     `scale`): the 12-bit flavours of the fused kernels against the oracle (which the CPU tests pin against the reference binary
     on the same kind of stream), against the unfused kernels, and through the stripe service."""
     data = synth.to_12bit(synth.synth_jpeg(w, h, 11 + w, 85, sub, dri), scale)
@@ -1525,10 +1525,10 @@ def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale, sub):
         assert rerr == 0 and np.array_equal(np.asarray(rpx).reshape(exp.shape), exp)
 
 
-@pytest.mark.parametrize("sub", ["420", "444"])
+@pytest.mark.parametrize("sub", ["420", "444", "422"])
 @pytest.mark.parametrize("luma_budget,chroma_budget,fused", [(49151, 45055, True), (49151, 45056, False), (49152, 1000, False), (30000, 45055, True), (45055, 32767, True)])
 def test_extreme_coefficients_at_the_12bit_gates(oracle, luma_budget, chroma_budget, fused, sub):
-    """fused420_kernel<12> (and fused444_12_kernel, same bounds) is admitted by sum |c| q < 49152 (the 32-bit butterflies) and < 45056 for the chroma planes (the
+    """fused420_kernel<12> (and fused444_12_kernel, fused422_12_kernel: same bounds) is admitted by sum |c| q < 49152 (the 32-bit butterflies) and < 45056 for the chroma planes (the
     32-bit colour products).  Blocks right at those bounds with every sign pattern (DC-only, one AC coefficient, dense) must still come
     out like the reference's 64-bit arithmetic; one step beyond, the unfused kernels take the frame (and agree as well)."""
     torch = _torch()
