@@ -191,7 +191,7 @@ private:
   uint16_t quant_[4][64];
   bool quant_defined_[4] = {false, false, false, false};
   bool have_quant_ = false, have_huff_ = false; // a DQT / DHT marker was seen at all
-  int frame_type_ = 0;                          // 0 baseline (SOF0), 1 extended sequential (SOF1), 2 progressive (SOF2)
+  int frame_type_ = 0;                          // 0 baseline (SOF0), 1 extended sequential (SOF1), 2 progressive (SOF2), 3 / 4 residual sequential / progressive (FFB1 / FFB2, inside a RESI box)
   // the transform of a component uses the quantiser table that was in force when the component first appeared in a
   // scan; a component that appears in no scan reconstructs as sample value 0 (control/blockbuffer.cpp:177-208,
   // control/blockbitmaprequester.cpp:1047-1054)

@@ -144,6 +144,7 @@ int oj_decode_xt(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixe
 int oj_decode_xt_ex(const uint8_t *data, size_t len, oj_info *info, uint16_t **pixels, int *is_float, int disable_to_rgb);
 /* the legacy frame's coefficient planes as that merge sees them (hidden refinement scans applied); planes[c]: oj_free */
 int oj_decode_xt_planes(const uint8_t *data, size_t len, oj_info *info, int32_t **planes);
+int oj_decode_xt_planes2(const uint8_t *data, size_t len, oj_info *info, int32_t **planes, oj_info *rinfo, int32_t **rplanes);
 /* The alpha channel of a JPEG XT file (ALFA box: a one-component image of its own under the alpha merging specification ASPC,
  * residual and refinement boxes ARES / AFIN / ARRF): 16-bit codes, one per pixel, *out_max = 2^bits - 1; *mode / matte: the AMUL
  * box (compositing method, -1 without one).  OJ_ERR_UNSUPPORTED: no alpha channel in the file. */

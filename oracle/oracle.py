@@ -61,6 +61,7 @@ def lib():
         L.oj_decode_xt.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.oj_decode_xt_ex.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
         L.oj_decode_xt_planes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
+        L.oj_decode_xt_planes2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(OjInfo), C.POINTER(C.c_void_p)]
         L.oj_decode_alpha.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OjInfo), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         L.oj_free.argtypes = [C.c_void_p]
@@ -195,6 +196,22 @@ def decode_xt_planes(data: bytes):
         planes.append(np.ctypeslib.as_array((C.c_int32 * n).from_address(ptrs[c])).reshape(info.bh[c], info.bw[c], 64).copy())
         lib().oj_free(ptrs[c])
     return info, planes
+
+
+def decode_xt_residual_planes(data: bytes):
+    """JPEG XT: -> (rinfo, planes) of the RESIDUAL frame as the merge sees it (hidden bits of the RFIN boxes included)."""
+    info, rinfo = OjInfo(), OjInfo()
+    ptrs, rptrs = (C.c_void_p * 4)(), (C.c_void_p * 4)()
+    rc = lib().oj_decode_xt_planes2(data, len(data), C.byref(info), ptrs, C.byref(rinfo), rptrs)
+    if rc:
+        raise ValueError(f"oracle: oj_decode_xt_planes2 failed rc={rc}")
+    planes = []
+    for c in range(info.ncomp):
+        lib().oj_free(ptrs[c])
+        n = rinfo.bw[c] * rinfo.bh[c] * 64
+        planes.append(np.ctypeslib.as_array((C.c_int32 * n).from_address(rptrs[c])).reshape(rinfo.bh[c], rinfo.bw[c], 64).copy())
+        lib().oj_free(rptrs[c])
+    return rinfo, planes
 
 
 def decode_alpha(data: bytes):

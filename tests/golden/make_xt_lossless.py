@@ -54,6 +54,11 @@ def main():
             "rgb8_ro_dri4": ("rgb8.ppm", ro + ["-z", "4"]), "rgb8_ro_prog": ("rgb8.ppm", ro + ["-v"]),
             "grey8_ro": ("grey8.pgm", ro), "rgb16_ro": ("rgb16.ppm", ro), "grey16_ro": ("grey16.pgm", ro),
             "hdr_ro": ("hdr.pfm", ro + ["-profile", "c"]), "ghdr_ro": ("ghdr.pfm", ro + ["-profile", "c"]),
+            # round 5, second half: the progressive residual type (SOF 0xffb2, -rv) and hidden refinement scans of the residual kind (-rR n)
+            "rgb8_ro_rv": ("rgb8.ppm", ro + ["-rv"]), "rgb8_ro_rR2": ("rgb8.ppm", ro + ["-rR", "2"]),
+            "rgb8_q100_rv_rR3": ("rgb8.ppm", ["-r", "-q", "85", "-Q", "100", "-h", "-rv", "-rR", "3"]),
+            "rgb8_ro_rv_rR2_420_dri4": ("rgb8.ppm", ro + ["-rv", "-rR", "2", "-s", "1x1,2x2,2x2", "-z", "4"]),
+            "grey16_ro_rv": ("grey16.pgm", ro + ["-rv"]), "rgb16_ro_rR4": ("rgb16.ppm", ro + ["-rR", "4"]), "hdr_ro_rv_rR1": ("hdr.pfm", ro + ["-profile", "c", "-rv", "-rR", "1"]),
         }
         for name, (src, args) in cases.items():
             r = subprocess.run([O.REF_BIN, *args, p(src), p("o.jpg")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)

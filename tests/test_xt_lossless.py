@@ -3,8 +3,11 @@ refused all of them, 16 / 16 in the judge's sweep).  The RESI box holds a codest
 symbol 0x10 for -0x8000; marker/scan.cpp:483-489, codestream/sequentialscan.cpp:678-773) of up to 16 + 1 bits, the DCT is bypassed
 (control/residualblockhelper.cpp:203-231), the R transformation is the RCT (three components) or the identity, and the output leaves
 without clamping -- wrap-around or, for half float codes, the sign conversion alone (colortrafo/ycbcrtrafo.cpp:752-766, 797-801, 820-822,
-940-972; the transformers of colortrafo/colortransformerfactory.cpp:726-757, 826-849, 963-990).  tests/golden/xt_lossless/: 13
-reference-written files with the reference decoder's output.  CPU: the oracle against them and against the live binary, the product's host
+940-972; the transformers of colortrafo/colortransformerfactory.cpp:726-757, 826-849, 963-990).  With `-rv` the residual frame is of
+the progressive residual type (SOF 0xffb2: bands from position 0, successive approximation, EOB runs; marker/scan.cpp:411-424), with
+`-rR n` its low bits travel in RFIN boxes as refinement scans of the residual kind (marker/scan.cpp:941-953,
+codestream/refinementscan.cpp:584-700 with m_bResidual).  tests/golden/xt_lossless/: 20 reference-written files with the reference
+decoder's output.  CPU: the oracle against them and against the live binary, the product's host
 side (parameters, residual coefficients); -m gpu: pixels through the C ABI and the command line."""
 import json
 import os
@@ -49,10 +52,14 @@ def test_host_side(oracle, name):
     three = ent["channels"] == 3
     assert info.xt == 1 and x.clamp == 0 and x.rdct_bypass == 1 and x.general == 1 and x.noise_shaping == (1 if name.endswith("noise") else 0)
     assert x.rct == (1 if three and not name.endswith("noct") else 0) and x.rbits == (1 if x.rct else 0)
-    assert x.residual.precision == (8 if ent["dtype"] == "|u1" else 16) + x.rct and x.residual_wide == (1 if x.residual.precision > 12 else 0)
+    hidden = int(name.split("_rR")[1][0]) if "_rR" in name else 0
+    assert x.residual_hidden_bits == hidden and x.residual.progressive == 0
+    assert x.residual.precision + hidden == (8 if ent["dtype"] == "|u1" else 16) + x.rct
+    assert x.residual_wide == (1 if x.residual.precision > 12 or hidden else 0)
     assert info.sample_bytes == (1 if ent["dtype"] == "|u1" else 2) and bool(info.is_float) == ent["is_float"]
     # the residual codestream's coefficients (samples, really: the DCT is bypassed) as the oracle's walk decodes them
-    rinfo, planes = oracle.decode_residual_coefficients(stream(name))
+    # (hidden bits: the visible scans moved up, the RFIN boxes' refinement scans applied)
+    rinfo, planes = oracle.decode_xt_residual_planes(stream(name)) if hidden else oracle.decode_residual_coefficients(stream(name))
     assert rinfo.residual_type == 1
     for c in range(info.components):
         assert np.array_equal(d.residual_coefficients(c).astype(np.int32), planes[c]), (name, c)
@@ -63,18 +70,18 @@ def test_host_side(oracle, name):
 
 
 def test_what_stays_outside(oracle):
-    """Refinement scans of the residual kind (-rR with -ro) and the progressive residual type (-rv: SOF 0xffb2) are declined, by the oracle
-    and by the product alike, never decoded wrongly; a clamping output beside the RCT has no transformer (INVALID_PARAMETER)."""
-    if not oracle.have_reference():
-        pytest.skip("needs the reference encoder (build container)")
+    """The integer (lifting) DCT in the residual domain (`-rl`: part 8's lossless DCT, SURVEY section 2 "out of scope") is declined by
+    the oracle and by the product alike, never decoded wrongly; a clamping output beside the RCT has no transformer
+    (INVALID_PARAMETER)."""
     from libjpeg_amd import synth
 
-    with tempfile.TemporaryDirectory(dir=TMP) as d:
-        oracle.write_ppm(os.path.join(d, "in.ppm"), synth.synth_image(40, 24, 3))
-        for extra in (["-rR", "2"], ["-rv"]):
-            subprocess.run([oracle.REF_BIN, "-r", "-q", "85", "-Q", "90", "-ro", "-h", *extra, os.path.join(d, "in.ppm"), os.path.join(d, "o.jpg")],
+    if oracle.have_reference():
+        with tempfile.TemporaryDirectory(dir=TMP) as d:
+            oracle.write_ppm(os.path.join(d, "in.ppm"), synth.synth_image(40, 24, 3))
+            subprocess.run([oracle.REF_BIN, "-r", "-q", "85", "-Q", "90", "-rl", "-h", os.path.join(d, "in.ppm"), os.path.join(d, "o.jpg")],
                            check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             blob = open(os.path.join(d, "o.jpg"), "rb").read()
+            assert oracle.reference_decode_status(blob)[1] == 0
             assert oracle.decode_xt_status(blob)[2] is None
             dec = api.Decoder(None)
             with pytest.raises(api.MijpegError) as e:
@@ -127,6 +134,10 @@ def _live_cases(oracle, count, seed):
                 args += ["-N"]
             if rng.integers(0, 3) == 0:
                 args += ["-z", str(int(rng.integers(1, 9)))]
+            if rng.integers(0, 3) == 0:
+                args += ["-rv"]
+            if rng.integers(0, 3) == 0:
+                args += ["-rR", str(int(rng.integers(1, 5)))]
             if ch == 3 and kind == 0 and rng.integers(0, 4) == 0:
                 args += ["-c"]
             r = subprocess.run([oracle.REF_BIN, *args, p(src), p("o.jpg")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -173,7 +184,7 @@ def test_gpu_pixels_equal_the_reference(oracle, dec, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["rgb8_ro", "grey8_ro", "rgb16_ro", "hdr_ro", "ghdr_ro", "rgb8_ro_420"])
+@pytest.mark.parametrize("name", ["rgb8_ro", "grey8_ro", "rgb16_ro", "hdr_ro", "ghdr_ro", "rgb8_ro_420", "rgb8_ro_rv", "rgb16_ro_rR4", "hdr_ro_rv_rR1"])
 def test_gpu_cli_writes_the_references_file(oracle, tmp_path, name):
     ent = CASES[name]
     src, dst = tmp_path / "in.jpg", tmp_path / "out.bin"
