@@ -3020,6 +3020,10 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     oj_info ltmp, rtmp;
     memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
     ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1; ls.in_memory = given != NULL;
+    /* (a legacy frame whose height arrives in a DNL marker -- no residual codestream beside it, the reference refuses those: the
+     * header pass has decoded the first scan for the height and the block rows, as for a plain frame) */
+    ls.known_height = info->dnl ? info->height : 0;
+    for (c = 0; c < OJ_MAX_COMP; c++) ls.known_bh[c] = info->bh[c];
     if (!lonly) { rs.data = resi->data; rs.len = resi->len; rs.info = &rtmp; rs.hidden = hidden_r; rs.nested = 1; }
     for (c = 0; c < nc; c++) {
       memset(planes[c], 0, (size_t)info->bw[c] * info->bh[c] * 64 * sizeof(int32_t));
@@ -3027,6 +3031,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     }
     rc = walk(&ls, planes);
     if (rc) info->ref_error = ltmp.ref_error;
+    if (ltmp.dnl) memcpy(info->rows, ltmp.rows, sizeof(ltmp.rows));
     /* (hidden scans and residual only behind an EOI, see eoi_frame / eoi_image) */
     if (!rc && ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) info->ref_error = ls.err; }
     if (!rc && ls.eoi_image && !lonly) {

@@ -57,7 +57,7 @@ def decode(data, ext):
         return O.read_pnm_any(dst).astype("<u2")
 
 
-def sources():
+def sources(W=W, H=H):
     hdr = synth.synth_hdr(W, H, 5).astype("<f4")
     i16 = (np.clip(hdr / hdr.max(), 0, 1) ** 0.45 * 65535).astype(np.uint16)
     return {
@@ -91,6 +91,24 @@ def main():
                 manifest[name] = dict(jpeg_sha256=hashlib.sha256(blob).hexdigest(), width=W, height=H, channels=ch,
                                       is_float=ext == "pfm", hidden=hidden, pixels_sha256=hashlib.sha256(px.tobytes()).hexdigest())
                 print(f"{name:18s} {len(blob):6d} bytes")
+    # Frames whose height arrives in a DNL marker (`-n`) -- legal here, where no residual codestream's frame header would disagree
+    # with the legacy one's: the reference's rows behind the picture and upsamplers without a bottom edge under the L
+    # chain.  Heights on and off the block grid.
+    for h in (29, 32):
+        for sname, (header, raw, ext, ch) in sources(W, h).items():
+            for mname, margs in (("dnl", ["-n"]), ("dnl420", ["-n", "-s", "1x1,2x2,2x2"]), ("dnlprog", ["-n", "-v"])):
+                if mname == "dnl420" and ch == 1:
+                    continue
+                name = f"{sname}_R2_{mname}_h{h}"
+                blob = encode(header, raw, ext, ["-q", "85", "-R", "2", "-h", *margs])
+                assert b"RESI" not in blob and b"SPEC" in blob and b"\xff\xdc\x00\x04" in blob, name
+                px = decode(blob, "pfm" if ext == "pfm" else ext).reshape(h, W, ch)
+                with open(os.path.join(OUT, name + ".jpg"), "wb") as f:
+                    f.write(blob)
+                px.tofile(os.path.join(OUT, name + ".bin"))
+                manifest[name] = dict(jpeg_sha256=hashlib.sha256(blob).hexdigest(), width=W, height=h, channels=ch,
+                                      is_float=ext == "pfm", hidden=2, pixels_sha256=hashlib.sha256(px.tobytes()).hexdigest())
+                print(f"{name:24s} {len(blob):6d} bytes")
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Every switch of the reference ENCODER's command line that leaves a Huffman-coded DCT stream, alone and in pairs, on five kinds of
+input (8-bit RGB / grey, 16-bit RGB / grey, float RGB): does the oracle decode the file to the reference decoder's samples, and does the
+product's host side accept what the oracle accepts?  (CPU only: the pixels of the product are the GPU suite's business.)  Build
+container only (needs oracle/_ref/jpeg).   python tools/encoder_sweep.py [seed]
+
+Classes reported: ok (oracle = reference, product reads it), declined (oracle "outside the restatement" and product -1034: coding
+processes outside SURVEY section 8 -- arithmetic coding, the predictive lossless and JPEG-LS processes, hierarchical frames, the
+integer DCT), MISMATCH (anything else)."""
+import itertools
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from libjpeg_amd import api, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+W, H = 45, 29
+BASES = {
+    "plain": ["-q", "85"],
+    "plain_R2": ["-q", "85", "-R", "2"],
+    "xt": ["-r", "-q", "85", "-Q", "90"],
+    "xt12": ["-r", "-q", "85", "-Q", "90", "-r12"],
+    "xt_ro": ["-r", "-q", "85", "-Q", "90", "-ro"],
+    "xt_q100": ["-r", "-q", "85", "-Q", "100"],
+    "xt_rl": ["-r", "-q", "85", "-Q", "100", "-rl"],
+    "profc": ["-r", "-q", "85", "-Q", "90", "-profile", "c"],
+}
+MODS = {
+    "h": ["-h"], "v": ["-v"], "qv": ["-qv"], "bl": ["-bl"], "c": ["-c"], "z3": ["-z", "3"], "n": ["-n"], "N": ["-N"], "U": [],
+    "s420": ["-s", "1x1,2x2,2x2"], "s422": ["-s", "1x1,2x1,2x1"], "sr420": ["-sr", "1x1,2x2,2x2"], "rs": ["-rs"], "rv": ["-rv"],
+    "R1": ["-R", "1"], "rR2": ["-rR", "2"], "rR4": ["-rR", "4"], "ol": ["-ol"], "dz": ["-dz"], "oz": ["-oz"], "dr": ["-dr"], "qt3": ["-qt", "3"],
+    "rqt1": ["-rqt", "1"], "sp": ["-sp"], "md": ["-md"], "ct": ["-ct"], "sm2": ["-sm", "2"], "ncl": ["-ncl"], "g24": ["-g", "2.4"], "g0": ["-g", "0"],
+    "xyz": ["-xyz"], "cxyz": ["-cxyz"], "a": ["-a"], "ra": ["-ra"], "l": ["-l"], "p": ["-p"], "y1": ["-y", "1"], "ls0": ["-ls", "0"],
+}
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    rng = np.random.default_rng(seed)
+    tmp = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    p = lambda n: os.path.join(tmp, n)  # noqa: E731
+    img = synth.synth_image(W, H, 3 + seed)
+    hdr = synth.synth_hdr(W, H, 5 + seed).astype("<f4")
+    i16 = (np.clip(hdr / hdr.max(), 0, 1) ** 0.45 * 65535).astype(np.uint16)
+    O.write_ppm(p("rgb8.ppm"), img)
+    O.write_ppm(p("grey8.pgm"), img[:, :, 1])
+    O.write_pfm(p("hdr.pfm"), hdr)
+    open(p("rgb16.ppm"), "wb").write(b"P6\n%d %d\n65535\n" % (W, H) + i16.astype(">u2").tobytes())
+    open(p("grey16.pgm"), "wb").write(b"P5\n%d %d\n65535\n" % (W, H) + i16[:, :, 2].astype(">u2").tobytes())
+    inputs = ["rgb8.ppm", "grey8.pgm", "rgb16.ppm", "grey16.pgm", "hdr.pfm"]
+    names = sorted(MODS)
+    combos = [()] + [(m,) for m in names] + [tuple(c) for c in itertools.combinations(names, 2)]
+    rng.shuffle(combos[1 + len(names):])
+    budget = int(os.environ.get("SWEEP_CASES", "900"))
+    count = dict(ok=0, declined=0, encode_failed=0, ref_fails=0, mismatch=0)
+    declined_by, bad = {}, []
+    done = 0
+    for combo in combos:
+        for bname, base in BASES.items():
+            src = inputs[int(rng.integers(0, len(inputs)))] if combo else None
+            for s in ([src] if src else inputs):
+                if done >= budget:
+                    break
+                if s == "hdr.pfm" and bname in ("plain",):
+                    continue
+                args = list(base) + sum((MODS[m] for m in combo), [])
+                if s == "hdr.pfm" and "-profile" not in args and bname.startswith("xt"):
+                    args += ["-profile", "c"]
+                if os.path.exists(p("o.jpg")):
+                    os.remove(p("o.jpg"))
+                r = subprocess.run([O.REF_BIN, *args, p(s), p("o.jpg")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=60)
+                if r.returncode or b"failed" in r.stderr or not os.path.exists(p("o.jpg")):
+                    count["encode_failed"] += 1
+                    continue
+                done += 1
+                blob = open(p("o.jpg"), "rb").read()
+                rpx, rerr = O.reference_decode_status(blob)
+                if rerr != 0:
+                    count["ref_fails"] += 1
+                    continue
+                try:
+                    if b"JP" in blob and (b"SPEC" in blob or b"RESI" in blob):
+                        codes, _, oerr = O.decode_xt_status(blob)
+                    else:
+                        codes, oerr, _ = O.decode_status(blob)
+                except Exception as e:  # noqa: BLE001
+                    codes, oerr = None, repr(e)
+                d = api.Decoder(None)
+                try:
+                    d.read(blob)
+                    perr = 0
+                except api.MijpegError as e:
+                    perr = e.code
+                d.close()
+                what = (bname, combo, s)
+                if oerr is None and perr == -1034:
+                    count["declined"] += 1
+                    key = "+".join(sorted(set(combo) & {"a", "ra", "l", "p", "y1", "ls0"})) or bname
+                    declined_by[key] = declined_by.get(key, 0) + 1
+                elif oerr == 0 and perr == 0 and codes is not None and np.array_equal(np.asarray(rpx).astype(np.uint16).reshape(-1), np.asarray(codes).astype(np.uint16).reshape(-1)):
+                    count["ok"] += 1
+                else:
+                    count["mismatch"] += 1
+                    bad.append((what, oerr, perr))
+    print(f"seed {seed}: {count}")
+    print("declined by:", dict(sorted(declined_by.items(), key=lambda kv: -kv[1])))
+    for b in bad[:40]:
+        print("MISMATCH", b)
+
+
+if __name__ == "__main__":
+    main()
