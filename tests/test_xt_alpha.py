@@ -168,6 +168,12 @@ def _live_cases(oracle, count, seed):
                     aargs += ["-aq", str(int(rng.integers(30, 95))), "-aQ", str(int(rng.integers(50, 98))), str(rng.choice(["-ar", "-ar12"]))]
                     if rng.integers(0, 3) == 0:
                         aargs += ["-arR", str(int(rng.integers(1, 4)))]
+                    if rng.integers(0, 3) == 0:  # lossless / near-lossless alpha: the residual scan type in the ARES box (-h: its tables)
+                        aargs += [str(rng.choice(["-alo", "-aQ"])), "-h"]
+                        if aargs[-2] == "-aQ":
+                            aargs.insert(-1, "100")
+                elif rng.integers(0, 3) == 0:
+                    aargs += ["-aR", str(int(rng.integers(1, 4)))]
             elif kind == 1:
                 with open(p("a.pgm"), "wb") as f:
                     f.write(b"P5\n%d %d\n65535\n" % (w, h) + (a8.astype(np.uint16) * 257).astype(">u2").tobytes())
