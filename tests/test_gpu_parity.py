@@ -1088,12 +1088,15 @@ def test_batch_whose_images_bring_their_own_quantisation_tables(oracle, w, h, su
     d.close()
 
 
-def test_stateless_launch_with_per_frame_tables(oracle):
-    """mijpeg_launch_reconstruct with quant_dev: coefficient stores of two images side by side, their deltas as u16
-    [frames][4][64] in device memory, info.quant = the element-wise maximum."""
+@pytest.mark.parametrize("sub,p12,kernel", [("420", False, None), ("420", True, "fused420_kernel<12>"), ("444", True, "fused444_12_kernel"), ("422", True, "fused422_12_kernel")])
+def test_stateless_launch_with_per_frame_tables(oracle, sub, p12, kernel):
+    """mijpeg_launch_reconstruct with quant_dev: coefficient stores of three images side by side, their deltas as u16
+    [frames][4][64] in device memory, info.quant = the element-wise maximum.  8-bit 4:2:0 and the 12-bit kernels' QDEV builds."""
     torch = _torch()
     w, h = 384, 256
-    streams = [synth.synth_jpeg(w, h, 50 + i, q, "420", 4) for i, q in enumerate((90, 35, 75))]
+    streams = [synth.synth_jpeg(w, h, 50 + i, q, sub, 4) for i, q in enumerate((90, 35, 75))]
+    if p12:
+        streams = [synth.to_12bit(st, sc) for st, sc in zip(streams, (16, 11, 16))]
     n = len(streams)
     d = api.Decoder(0)
     infos, coefs = [], []
@@ -1120,8 +1123,10 @@ def test_stateless_launch_with_per_frame_tables(oracle):
         info.range_max[c] = max(int(f.range_max[c]) for f in infos)
     coef = torch.from_numpy(np.stack(coefs)).cuda()
     qd = torch.from_numpy(tabs.view(np.int16)).cuda()
-    row = w * 3
+    row = w * (6 if p12 else 3)
     out = torch.zeros((n, h, row), dtype=torch.uint8, device="cuda")
+    if kernel:
+        assert api.kernel_name(info) == kernel, (api.kernel_name(info), list(info.range_max))
     for flags in (0, api.FLAG_FORCE_GENERIC):
         out.zero_()
         wsb = api.workspace_bytes(info, n, flags, own_tables=True)
@@ -1132,9 +1137,9 @@ def test_stateless_launch_with_per_frame_tables(oracle):
         api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), n, row, h * row, flags=flags, workspace=ws.data_ptr(), workspace_bytes=wsb,
                                quant_dev=qd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        res = out.cpu().numpy().reshape(n, h, w, 3)
+        res = out.cpu().numpy().view(np.uint16).reshape(n, h, w, 3) if p12 else out.cpu().numpy().reshape(n, h, w, 3)
         for i in range(n):
-            assert np.array_equal(res[i], oracle.decode(streams[i])), (flags, i)
+            assert np.array_equal(res[i], oracle.decode16(streams[i]) if p12 else oracle.decode(streams[i])), (flags, i)
     d.close()
 
 
