@@ -3277,6 +3277,7 @@ __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const Generi
   // the (component, 64 blocks) chunks of the tile go to the four waves in turn: every wave transforms a quarter of the
   // tile's blocks whatever the components' sizes are.  One copy of the code for all components (the component is a uniform
   // run-time value here: phase A alone would otherwise be four times three transforms long).
+#ifndef TILE_SKIP_A // (A-B measurements: phase B alone)
   for (int chunk = wave; chunk < chunks; chunk += 4) {
     int c = 0, k = chunk;
 #pragma unroll
@@ -3316,6 +3317,7 @@ __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const Generi
       }
     }
   }
+#endif
   __syncthreads();
   if (edge) { // (uniform) tiles on the left / right image edge: the replicated columns of the horizontally subsampled planes
 #pragma unroll
@@ -3335,6 +3337,10 @@ __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const Generi
     __syncthreads();
   }
   // ------------------------------------------------------------------ phase B: lines of 8-pixel groups
+#ifdef TILE_SKIP_B // (A-B measurements: phase A alone)
+  if (tid == 0) a.out[(int64_t)frame * a.out_frame_stride + (int64_t)py0 * a.row_stride + px0] = (uint8_t)planes[base[0]];
+  return;
+#endif
   const int groups = (px1 - px0 + 8) >> 3, lines = py1 - py0 + 1;
   const int sb = a.sample_bytes;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;

@@ -43,6 +43,23 @@ int main(int argc, char **argv)
         std::vector<int16_t> c((size_t)h.info.coef_count + 64);
         rc = h.decode(c.data(), 2, nullptr);
       }
+      // the alpha channel of a JPEG XT file: a child decoder on the ALFA box's codestream with the boxes translated (what
+      // capi.cpp's decode_alpha_channel does)
+      if (!rc && h.has_alpha()) {
+        const uint8_t *ap = nullptr;
+        size_t an = 0;
+        if (h.alpha_stream(&ap, &an) && an) {
+          std::vector<uint8_t> adata(ap, ap + an);
+          mij::HostDecoder child;
+          child.preset_boxes(h.alpha_boxes());
+          int arc = child.parse(adata.data(), adata.size(), false);
+          if (!arc) {
+            std::vector<int16_t> c((size_t)child.info.coef_count + 64);
+            arc = child.decode(c.data(), 2, nullptr);
+          }
+          (void)arc;
+        }
+      }
       (rc ? bad : ok)++;
     }
   }
