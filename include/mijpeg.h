@@ -59,6 +59,7 @@ extern "C" {
 #define MIJPEG_FLAG_FORCE_SAFE 4u         /* use the 32/64-bit "safe" arithmetic flavour even if the range check passed */
 #define MIJPEG_FLAG_NO_UPSAMPLING 16u      /* mijpeg_reconstruct_rect: JPGTAG_DECODER_UPSAMPLE = false -- one component on its own sample grid */
 #define MIJPEG_FLAG_DEVICE_OUTPUT 8u      /* mijpeg_reconstruct_rect: dst[] are DEVICE pointers; nothing crosses PCIe */
+#define MIJPEG_FLAG_FORCE_DOT2 64u        /* (testing) the 16-bit second pass of the packed 4:2:0 kernel whatever the range check says */
 #define MIJPEG_FLAG_SPECULATIVE 32u       /* mijpeg_reconstruct_batch_device with sync = 0 on a SUBMITTED batch: launch the reconstruction
                                              behind the Huffman kernel without waiting for that kernel's report (see there) */
 

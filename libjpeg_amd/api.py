@@ -24,6 +24,7 @@ FLAG_FORCE_SAFE = 4
 FLAG_DEVICE_OUTPUT = 8
 FLAG_NO_UPSAMPLING = 16
 FLAG_SPECULATIVE = 32
+FLAG_FORCE_DOT2 = 64  # (testing) the packed 4:2:0 kernel's 16-bit second pass whatever the range check says
 
 ERR_DEVICE = -8191
 ERR_NOT_AVAILABLE = -1029

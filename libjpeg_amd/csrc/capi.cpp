@@ -1950,6 +1950,17 @@ static bool use_fused420p(const mijpeg_batch *b)
   return !off && use_fused420(b) && fast_ok(b) && f.range_max[1] < 2047 && f.range_max[2] < 2047;
 }
 
+// ... and where the first-pass results of every transform fit 16 bits the second pass runs on v_dot2 as well (idct_columns_dot2 in
+// kernels.hip has the bound: sum |c| q <= 1476 per block).  MIJPEG_FLAG_FORCE_DOT2 (testing): whatever the range check says.
+static bool use_dot2_pass(const mijpeg_batch *b)
+{
+  const mijpeg_info &f = b->info;
+  static const bool off = getenv("MIJPEG_NO_DOT2") != nullptr; // A-B comparisons
+  if (off || b->quant_dev) return false;
+  if (b->flags & MIJPEG_FLAG_FORCE_DOT2) return true;
+  return f.range_max[0] <= 1476 && f.range_max[1] <= 1476 && f.range_max[2] <= 1476;
+}
+
 // JPEG XT profile C in the shape the fused kernel covers: 8-bit 4:2:0 legacy frame and 12-bit 4:4:4 residual frame without
 // hidden bits, L transformation on, both frames within the range the fast transforms are exact for
 // JPEG XT: the L transformation in force for this launch.  A request without colour transformation (the command line's -c)
@@ -2179,7 +2190,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       xa.ext.rprecision = r.precision + x.residual_hidden_bits;
       rc = launch_fusedxt420(xa, s);
     } else
-      rc = f420_12 ? launch_fused420_12(a, s) : f444_12 ? launch_fused444_12(a, s) : f422_12 ? launch_fused422_12(a, s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, s) : launch_fused420(a, fast, s);
+      rc = f420_12 ? launch_fused420_12(a, s) : f444_12 ? launch_fused444_12(a, s) : f422_12 ? launch_fused422_12(a, s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, use_dot2_pass(b), s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

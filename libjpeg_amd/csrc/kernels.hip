@@ -320,7 +320,8 @@ constexpr int LUMA_FOLD_R = 2048 + ((2048 + 8) << 12);
 // ... and with the second pass doubled (idct_1d X2) the outputs are 2 * (sum + LUMA_FOLD_R): luma13() of one is the y << 13 above
 constexpr int LUMA_FOLD_R2 = 2 * LUMA_FOLD_R;
 __device__ __forceinline__ int luma13(int doubled_sum) { return doubled_sum & (int)0xffffe000; }
-template <bool FAST, int NR = 8, int NC = 8, bool X2 = false>
+template <int NR, bool X2> __device__ __forceinline__ void idct_columns_dot2(int (&v)[64], const int R);
+template <bool FAST, int NR = 8, int NC = 8, bool X2 = false, bool D2 = false>
 __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff, const int colr = 2048)
 {
 #pragma unroll
@@ -342,6 +343,7 @@ __device__ __forceinline__ void dequant_idct(const u32x4 (&rows)[8], const int *
   for (int r = 0; r < NR; r++)
     idct_1d<FAST, 9, NC>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5],
                          v[r * 8 + 6], v[r * 8 + 7]);
+  if constexpr (D2) { idct_columns_dot2<NR, X2>(v, colr); return; }
 #pragma unroll
   for (int c = 0; c < 8; c++)
     idct_1d<FAST, 12, NR, X2>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], colr);
@@ -374,7 +376,56 @@ __device__ __forceinline__ int sdot2(unsigned pk, int k, int c)
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pk), __builtin_bit_cast(s16x2, k), c, false);
 }
-template <int NR, int NC, bool X2 = false>
+// The SECOND pass as v_dot2_i32_i16 inner products (D2 flavours; 8-bit FAST frames whose first-pass results fit 16 bits: the host
+// admits them by sum |c| q <= 1476 per block -- a first-pass output is (sum_x s_x M_xj + 16) >> 5 with |M_xj| <= 710, the largest
+// entry of the butterfly's integer matrix, and (710 * 1476 + 16) >> 5 = 32749; the level shift is not in it, dcoff = 0).  The pass
+// is the same product of its eight inputs with that matrix as the first one (dequant_idct16 has the derivation): the rows of a
+// column are paired (0,4) (2,6) (1,5) (3,7) by v_perm_b32 -- (0,2) (1,3) when rows 4..7 are zero -- and every butterfly term is
+// one dot product that takes the previous one as its accumulator; 22 issue slots per column where the mad24 butterfly takes 36
+// (X2) / 44, plus four packings.  Exact: the ring Z / 2^32 is distributive, the operands are the same integers.
+// R, X2 as in idct_1d (the doubled pass: every constant twice, no final shift).
+template <int NR, bool X2>
+__device__ __forceinline__ void idct_columns_dot2(int (&v)[64], const int R)
+{
+  constexpr int M = X2 ? 2 : 1, OSH = X2 ? 0 : 12;
+  constexpr int C0541 = M * FIX9(0.541196100), C0765 = M * FIX9(0.765366865), C1847 = M * FIX9(1.847759065), C1175 = M * FIX9(1.175875602),
+                C1961 = M * FIX9(1.961570560), C0390 = M * FIX9(0.390180644), C0899 = M * FIX9(0.899976223), C0298 = M * FIX9(0.298631336),
+                C2562 = M * FIX9(2.562915447), C2053 = M * FIX9(2.053119869), C3072 = M * FIX9(3.072711026), C1501 = M * FIX9(1.501321110),
+                ONE = M * 512;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    int t10, t11, t12, t13, o0, o1, o2, o3;
+    if (NR == 8) {
+      const unsigned s04 = pack_lo16_now(v[32 + c], v[c]), s15 = pack_lo16_now(v[40 + c], v[8 + c]);
+      const unsigned s26 = pack_lo16_now(v[48 + c], v[16 + c]), s37 = pack_lo16_now(v[56 + c], v[24 + c]);
+      const int A = sdot2(s04, PK16(ONE, ONE), R), B = sdot2(s04, PK16(ONE, -ONE), R);
+      t10 = sdot2(s26, PK16(C0541 + C0765, C0541), A);
+      t13 = sdot2(s26, PK16(-(C0541 + C0765), -C0541), A);
+      t11 = sdot2(s26, PK16(C0541, C0541 - C1847), B);
+      t12 = sdot2(s26, PK16(-C0541, C1847 - C0541), B);
+      o0 = sdot2(s37, PK16(C1175 - C1961, -C0899 + C0298 + C1175 - C1961), sdot2(s15, PK16(-C0899 + C1175, C1175), 0));
+      o1 = sdot2(s37, PK16(-C2562 + C1175, C1175), sdot2(s15, PK16(C1175 - C0390, -C2562 + C2053 + C1175 - C0390), 0));
+      o2 = sdot2(s37, PK16(-C2562 + C3072 + C1175 - C1961, C1175 - C1961), sdot2(s15, PK16(C1175, -C2562 + C1175), 0));
+      o3 = sdot2(s37, PK16(C1175, -C0899 + C1175), sdot2(s15, PK16(-C0899 + C1501 + C1175 - C0390, C1175 - C0390), 0));
+    } else {
+      const unsigned s02 = pack_lo16_now(v[16 + c], v[c]), s13 = pack_lo16_now(v[24 + c], v[8 + c]);
+      t10 = sdot2(s02, PK16(ONE, C0541 + C0765), R);
+      t13 = sdot2(s02, PK16(ONE, -(C0541 + C0765)), R);
+      t11 = sdot2(s02, PK16(ONE, C0541), R);
+      t12 = sdot2(s02, PK16(ONE, -C0541), R);
+      o0 = sdot2(s13, PK16(-C0899 + C1175, C1175 - C1961), 0);
+      o1 = sdot2(s13, PK16(C1175 - C0390, -C2562 + C1175), 0);
+      o2 = sdot2(s13, PK16(C1175, -C2562 + C3072 + C1175 - C1961), 0);
+      o3 = sdot2(s13, PK16(-C0899 + C1501 + C1175 - C0390, C1175), 0);
+    }
+    v[c] = (t10 + o3) >> OSH; v[56 + c] = (t10 - o3) >> OSH;
+    v[8 + c] = (t11 + o2) >> OSH; v[48 + c] = (t11 - o2) >> OSH;
+    v[16 + c] = (t12 + o1) >> OSH; v[40 + c] = (t12 - o1) >> OSH;
+    v[24 + c] = (t13 + o0) >> OSH; v[32 + c] = (t13 - o0) >> OSH;
+  }
+}
+
+template <int NR, int NC, bool X2 = false, bool D2 = false>
 __device__ __forceinline__ void dequant_idct16(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff, const int colr = 2048)
 {
   constexpr int C0541 = FIX9(0.541196100), C0765 = FIX9(0.765366865), C1847 = FIX9(1.847759065), C1175 = FIX9(1.175875602),
@@ -420,6 +471,7 @@ __device__ __forceinline__ void dequant_idct16(const u32x4 (&rows)[8], const int
     v[k * 8 + 2] = (t12 + o1) >> 5; v[k * 8 + 5] = (t12 - o1) >> 5;
     v[k * 8 + 3] = (t13 + o0) >> 5; v[k * 8 + 4] = (t13 - o0) >> 5;
   }
+  if (D2) { idct_columns_dot2<NR, X2>(v, colr); return; }
 #pragma unroll
   for (int c = 0; c < 8; c++)
     idct_1d<true, 12, NR, X2>(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], colr);
@@ -446,14 +498,16 @@ __device__ __forceinline__ bool cols_4_to_7_zero(const u32x4 (&rows)[8])
 
 // dequant_idct<true> with the pruned paths where the data allow it.  PK16ROW: q is a row of the kernel's argument block (the
 // packed deltas follow the 64) and the frame has 8-bit samples -- the first pass runs in 16 bits (dequant_idct16).
-template <bool PK16ROW = false, bool X2 = false>
+// D2 (with PK16ROW): the second pass on v_dot2 as well (idct_columns_dot2: the host's gate, dcoff = 0).
+template <bool PK16ROW = false, bool X2 = false, bool D2 = false>
 __device__ __forceinline__ void dequant_idct_sparse(const u32x4 (&rows)[8], const int *__restrict__ q, int (&v)[64], int dcoff = 0, const int colr = 2048)
 {
+  static_assert(!D2 || PK16ROW, "the 16-bit second pass belongs to the 8-bit FAST flavours");
   if (PK16ROW) {
     if (rows_4_to_7_zero(rows)) {
-      if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4, X2>(rows, q, v, dcoff, colr); // (the pruned butterfly is as short as the products)
-      else dequant_idct16<4, 8, X2>(rows, q, v, dcoff, colr);
-    } else dequant_idct16<8, 8, X2>(rows, q, v, dcoff, colr);
+      if (cols_4_to_7_zero(rows)) dequant_idct<true, 4, 4, X2, D2>(rows, q, v, dcoff, colr); // (the pruned butterfly is as short as the products)
+      else dequant_idct16<4, 8, X2, D2>(rows, q, v, dcoff, colr);
+    } else dequant_idct16<8, 8, X2, D2>(rows, q, v, dcoff, colr);
     return;
   }
   if (rows_4_to_7_zero(rows)) {
@@ -1060,7 +1114,9 @@ __device__ __forceinline__ unsigned tap_sum_pk(unsigned a, unsigned w)
   return __builtin_bit_cast(unsigned, t);
 }
 
-template <int MINW, bool QDEV>
+// D2: the second pass of every transform on v_dot2 (idct_columns_dot2; admitted by the host where sum |c| q <= 1476 in all three
+// components: use_dot2_pass in capi.cpp)
+template <int MINW, bool QDEV, bool D2 = false>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) unsigned cpair[F420_CROWS * F420_CPITCH];
@@ -1123,7 +1179,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
 #endif
     if (idx < F420_CGRID * F420_CGRID && gx >= 0 && gy >= 0 && gx < a.bw_c && gy < a.bh_c) {
       int v[64];
-      dequant_idct_sparse<!QDEV>(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
+      dequant_idct_sparse<!QDEV, false, D2>(rows, frame_deltas<QDEV>(a, frame, 1 + comp), v);
       short *cp = reinterpret_cast<short *>(cpair) + comp; // this component's half of every dword
 #pragma unroll
       for (int r = 0; r < 8; r++) {
@@ -1193,7 +1249,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   const int X0 = gbx * 8, Y0 = gby * 8;
   if (X0 >= a.width || Y0 >= a.height) return; // no barrier below this point
   int yv[64];
-  dequant_idct_sparse<!QDEV, true>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R2);
+  dequant_idct_sparse<!QDEV, true, D2>(rows, frame_deltas<QDEV>(a, frame, 0), yv, 0, LUMA_FOLD_R2);
 
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
   const unsigned out_off = (unsigned)Y0 * (unsigned)a.row_stride + (unsigned)X0 * 3u;
@@ -3928,13 +3984,14 @@ int launch_fused420_12(const Fused420Args &a0, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused420p(const Fused420Args &a0, hipStream_t stream)
+int launch_fused420p(const Fused420Args &a0, bool dot2, hipStream_t stream)
 {
   const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
   // four workgroups per CU (127 VGPRs with the luma prefetch, 27 KB LDS); the per-frame-table build three (133 VGPRs)
   if (a.qdev) hipLaunchKernelGGL((fused420p_kernel<3, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else if (dot2) hipLaunchKernelGGL((fused420p_kernel<F420P_MINW, false, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   else hipLaunchKernelGGL((fused420p_kernel<F420P_MINW, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }

@@ -119,7 +119,7 @@ struct GenericArgs {
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
 int launch_fused1_12(const Fused420Args &a, hipStream_t stream);   // 12-bit single component frames inside the range gate
 int launch_fused420_12(const Fused420Args &a, hipStream_t stream); // 12-bit frames inside the range gates, 16-bit samples out
-int launch_fused420p(const Fused420Args &a, hipStream_t stream); // FAST only, chroma samples within int16 filter range
+int launch_fused420p(const Fused420Args &a, bool dot2, hipStream_t stream); // FAST only, chroma samples within int16 filter range; dot2: the second pass in 16 bits too (range_max <= 1476)
 int launch_fused444(const Fused420Args &a, hipStream_t stream); // same argument block; all planes bw_y x bh_y
 int launch_fused422_12(const Fused420Args &a, hipStream_t stream); // 12-bit 4:2:2 frames inside the range gates
 int launch_fused444_12(const Fused420Args &a, hipStream_t stream); // 12-bit 4:4:4 frames inside the range gates, 16-bit samples out
