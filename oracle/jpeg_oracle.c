@@ -2744,6 +2744,8 @@ static int xt_codestreams_verdict(const uint8_t *data, size_t len, const oj_info
   memset(&ls, 0, sizeof(ls)); memset(&rs, 0, sizeof(rs)); memset(&ltmp, 0, sizeof(ltmp)); memset(&rtmp, 0, sizeof(rtmp));
   *ref_error = 0; *eoi_image = 0;
   ls.data = data; ls.len = len; ls.info = &ltmp; ls.hidden = hidden_l; ls.xt_legacy = 1; ls.in_memory = in_memory;
+  ls.known_height = info->dnl ? info->height : 0; /* (a DNL legacy frame: the header pass's height and rows, as in xt_decode_common) */
+  for (c = 0; c < OJ_MAX_COMP; c++) ls.known_bh[c] = info->bh[c];
   for (c = 0; c < info->ncomp; c++) {
     planes[c] = (int32_t *)calloc((size_t)info->bw[c] * info->bh[c] * 64, sizeof(int32_t));
     if (!planes[c]) { rc = OJ_ERR_NOMEM; goto done; }
@@ -2840,6 +2842,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     if (rc) { info->ref_error = verr; goto out; }
     if (!eoi) { rc = OJ_ERR_UNSUPPORTED; goto out; }
     info->ref_error = RS_INVALID_PARAMETER;
+    info->transformer_refused = 1;
     rc = OJ_ERR_MALFORMED;
     goto out;
   }
@@ -3042,7 +3045,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
       xt.no_residual = 1;
       /* ... and the transformer is built without a residual frame: only the clamping flavours exist then
        * (colortransformerfactory.cpp:262-283 with R transformation "zero", :698-725, 850-885) */
-      if (!xt.clamp) { info->ref_error = RS_INVALID_PARAMETER; rc = OJ_ERR_MALFORMED; }
+      if (!xt.clamp) { info->ref_error = RS_INVALID_PARAMETER; info->transformer_refused = 1; rc = OJ_ERR_MALFORMED; }
     }
     if (rc) goto out; /* (the reference's error code travels in info->ref_error) */
     memcpy(info->cquant, ltmp.cquant, sizeof(ltmp.cquant)); memcpy(info->comp_seen, ltmp.comp_seen, sizeof(ltmp.comp_seen));
@@ -3113,7 +3116,7 @@ late:
     rc = xt_codestreams_verdict(data, len, info, boxes, ps.nboxes, resi, hidden_l, hidden_r, &verr, &eoi, given != NULL);
     if (rc) info->ref_error = verr;
     else if (!eoi && late_residual_only) { retry_lonly = 1; info->ref_error = 0; }
-    else { rc = lrc; info->ref_error = lerr; }
+    else { rc = lrc; info->ref_error = lerr; info->transformer_refused = 1; }
   }
 out:
   for (c = 0; c < OJ_MAX_COMP; c++) { free(planes[c]); free(rplanes[c]); }

@@ -76,7 +76,9 @@ typedef struct {
    * row that was not created reads as NULL and transforms to sample value 0 (dct/idct.cpp:336-338). */
   int dnl;
   int rows[OJ_MAX_COMP];
-  int residual_type;         /* the frame header is SOF 0xffb1: the residual scan type of part 8 (a RESI box's codestream) */
+  int residual_type;         /* the frame header is SOF 0xffb1 / 0xffb2: the residual scan types of part 8 (a RESI box's codestream) */
+  int transformer_refused;   /* JPEG XT: ref_error is what the colour transformer refuses at the FIRST REQUEST for pixels -- both codestreams
+                              * read without complaint (JPEG::Read succeeds; an alpha channel nobody asks for does not fail anything) */
 } oj_info;
 
 /* Parse the headers only.  Returns OJ_OK or a negative error. */

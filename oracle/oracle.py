@@ -27,7 +27,7 @@ class OjInfo(C.Structure):
         ("quant_defined", C.c_int * 4),
         ("scan_state_valid", C.c_int), ("cquant", (C.c_uint16 * 64) * 4), ("comp_seen", C.c_int * 4),
         ("ref_error", C.c_int), ("warnings", C.c_int),
-        ("dnl", C.c_int), ("rows", C.c_int * 4), ("residual_type", C.c_int),
+        ("dnl", C.c_int), ("rows", C.c_int * 4), ("residual_type", C.c_int), ("transformer_refused", C.c_int),
     ]
 
 
@@ -214,9 +214,28 @@ def decode_xt_residual_planes(data: bytes):
     return rinfo, planes
 
 
+def alpha_read_error(data: bytes):
+    """What the alpha channel does to JPEG::Read: the reference's code where the alpha image's codestreams (or the form of its boxes)
+    stop the read, 0 where they do not -- a refusal of the alpha image's colour transformer is NOT a read error: it arrives with the
+    first request for alpha pixels, and a client that never asks (the command line without -al, or any client of a file whose alpha
+    merging specification names no compositing method) never sees it.  None: no alpha channel / outside the restatement."""
+    info = OjInfo()
+    px = C.c_void_p()
+    isf, omax, mode = C.c_int(0), C.c_int(0), C.c_int(-1)
+    matte = (C.c_uint32 * 3)()
+    rc = lib().oj_decode_alpha(data, len(data), C.byref(info), C.byref(px), C.byref(isf), C.byref(omax), C.byref(mode), matte)
+    if rc == 0:
+        lib().oj_free(px)
+        return 0
+    if rc == -2 or not info.ref_error:
+        return None
+    return 0 if info.transformer_refused else info.ref_error
+
+
 def decode_alpha(data: bytes):
     """The alpha channel of a JPEG XT file -> (codes (H, W) uint16 or None, is_float, out_max, mode, matte (r, g, b), ref_error):
-    ref_error 0 with a plane, None where the file has no alpha channel or the restatement does not follow, else the reference's code."""
+    ref_error 0 with a plane, None where the file has no alpha channel or the restatement does not follow, else the reference's code
+    (of the read, or of the first request for alpha pixels: alpha_read_error tells them apart)."""
     info = OjInfo()
     px = C.c_void_p()
     isf, omax, mode = C.c_int(0), C.c_int(0), C.c_int(-1)
@@ -247,8 +266,13 @@ def decode_xt_status(data: bytes, no_color_transform: bool = False):
 
 
 def half_codes_to_float(codes: np.ndarray) -> np.ndarray:
-    """cmd/iohelpers.hpp:60-77 (HalfToDouble) for finite codes: exact, so numpy's float16 view does the same."""
-    return codes.view(np.float16).astype(np.float32)
+    """cmd/iohelpers.hpp:60-77 (HalfToDouble): exact for finite codes, so numpy's float16 view does the same; every code with
+    exponent 31 -- the NaN patterns an unclamped merge of a damaged stream can produce included -- is HUGE_VAL with the code's sign."""
+    codes = np.ascontiguousarray(codes, np.uint16)
+    f = codes.view(np.float16).astype(np.float32)
+    top = (codes & 0x7C00) == 0x7C00
+    f[top] = np.where(codes[top] & 0x8000, -np.inf, np.inf).astype(np.float32)
+    return f
 
 
 def decode(data: bytes, use_ycbcr: int = -1) -> np.ndarray:

@@ -119,6 +119,11 @@ def damaged_alpha(name):
     b[off + 12:off + 16] = lbox.to_bytes(4, "big")
     out["lbox"] = bytes(b)
     out["no_eoi"] = data[:-2]  # the reference never gets to the alpha channel
+    # the alpha merging specification gone (its segment's first byte swallowed by the one in front of it, tools/box_campaign.py): no
+    # compositing method -> JPEG::GetInformation reports no alpha channel and nobody asks for one; with an ARES box left behind the
+    # alpha image's transformer would refuse (R transformation "zero" beside a residual, -1024) -- at a request that never comes
+    (aoff, aln), = _segments(data, b"ASPC")
+    out["no_aspc"] = data[:aoff] + data[aoff + 2 + aln:]
     return out
 
 
@@ -128,7 +133,8 @@ def test_damaged_alpha_channels(oracle, name):
         d = api.Decoder(None)
         try:
             d.read(blob)
-            perr, has = 0, d.alpha_channel() is not None
+            # (what the command line goes by: an alpha channel whose specification names a compositing method other than "opaque")
+            perr, has = 0, d.alpha_channel() is not None and d.alpha_info()[0] >= 1
         except api.MijpegError as e:
             perr, has = e.code, False
         d.close()
@@ -142,8 +148,10 @@ def test_damaged_alpha_channels(oracle, name):
                 rerr, rhas = (int(m.group(1)) if m else 0), os.path.exists(adst) and os.path.getsize(adst) > 20
             assert perr == rerr, (name, kind, perr, rerr, r.stderr[-200:])
             assert has == rhas, (name, kind)
-        if kind in ("lbox", "no_eoi"):
+        if kind in ("lbox", "no_eoi", "no_aspc"):
             assert perr == 0 and not has, (name, kind)
+            if kind == "no_aspc":
+                assert oracle.alpha_read_error(blob) == 0
         else:
             assert perr == -1038, (name, kind, perr)
 

@@ -215,3 +215,23 @@ def test_gpu_lonly_at_4k(oracle, dec):
     dec.read(data)
     out = dec.reconstruct()
     assert np.array_equal(out, codes)
+
+
+def test_an_eob_run_above_hidden_bits_is_out_of_sync(oracle):
+    """The visible scans of a sequential frame with hidden bits sit above them (Al + hidden), but the reference's parser for them is
+    not a progressive one (m_bProgressive needs lowbit > hidden, sequentialscan.cpp:84-87): an EOB-run symbol there -- a DHT value
+    turned into 0x40 -- is "AC coefficient decoding out of sync" (-1038, :722-750), not a run of empty blocks (tools/box_campaign.py
+    r5: the scan pipeline of the host decoder took it for one)."""
+    data = bytearray(stream("i16_R1_z2"))
+    dht = data.rindex(b"\xff\xc4")
+    i = data.index(b"\x82", dht + 40)
+    data[i] = 0x40
+    data = bytes(data)
+    if oracle.have_reference():
+        assert oracle.reference_decode_status(data)[1] == -1038
+    assert oracle.decode_xt_status(data)[2] == -1038
+    d = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        d.read(data)
+    assert e.value.code == -1038
+    d.close()

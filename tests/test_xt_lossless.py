@@ -101,6 +101,33 @@ def test_what_stays_outside(oracle):
     dec.close()
 
 
+@pytest.mark.parametrize("name", ["rgb8_ro", "hdr_ro", "rgb8_ro_rv_rR2_420_dri4", "rgb8_ro_noise"])
+def test_a_file_cut_short_inside_its_residual_box(oracle, name):
+    """The reference's encoder writes the RESI box between frame header and first scan: a lossless file that ends inside it has
+    a frame, no scan and no EOI.  Where the residual codestream's own verdict does not come first, the reference reads such a file
+    to its end and the first request builds the transformer without a residual frame -- of which only the clamping flavours
+    exist: -1024 (colortransformerfactory.cpp:262-283, 698-725), not the legacy picture through the L chain (tools/box_campaign.py
+    r5: the product read these files without complaint)."""
+    data = stream(name)
+    i = data.index(b"RESI") + 4
+    seen = set()
+    for k in range(1, 12):
+        cut = data[:i + (len(data) - i) * k // 12]
+        oerr = oracle.decode_xt_status(cut)[2]
+        if oracle.have_reference():
+            assert oracle.reference_decode_status(cut)[1] == oerr, (name, k)
+        d = api.Decoder(None)
+        try:
+            d.read(cut)
+            perr = 0
+        except api.MijpegError as e:
+            perr = e.code
+        d.close()
+        assert perr == oerr, (name, k, perr, oerr)
+        seen.add(oerr)
+    assert -1024 in seen and 0 not in seen, (name, seen)
+
+
 def _live_cases(oracle, count, seed):
     from libjpeg_amd import synth
 

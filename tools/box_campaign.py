@@ -136,8 +136,9 @@ def one(item):
     codes, is_float, oerr = O.decode_xt_status(blob)
     if oerr == 0 or (codes is None and oerr is None):
         # an alpha channel is read inside JPEG::Read behind the picture's codestreams: what is wrong with it fails the read
-        acodes, _, _, _, _, aerr = O.decode_alpha(blob)
-        if acodes is None and aerr not in (None, 0) and (oerr == 0 or plain_oracle(blob)[1] == 0):
+        # (... unless it is the alpha image's colour transformer that refuses: that waits for the first request for alpha pixels)
+        aerr = O.alpha_read_error(blob)
+        if aerr not in (None, 0) and (oerr == 0 or plain_oracle(blob)[1] == 0):
             codes, oerr = None, aerr
     if perr in DECLINED and rerr in (0, perr) or (perr in DECLINED and codes is None and oerr is None):
         return ("declined", name, kind, rerr, perr)  # (an XT file outside the accelerated subset: nothing to compare)
