@@ -1399,13 +1399,13 @@ static void rs_run(oj_parser *ps, oj_bs *io)
         /* The residual codestream: Image::ParseResidualStream (codestream/image.cpp:1318-1331) hands the SAME frame back when
          * its image trailer finds a marker (the parent's m_pCurrent, m_bReceivedFrameHeader set): no frame header is read,
          * the frame goes on looking for scans. */
-        if (ps->nested) continue;
+        if (ps->nested || ps->in_memory) continue; /* (... and Image::ParseAlphaChannel, image.cpp:1386-1397, does the same for the alpha codestream) */
         break; /* next frame: a second frame header throws */
       } else {
         /* no scan: end of frame (interface/jpeg.cpp:305-317) */
         if (rs_frame_trailer(ps, io)) continue;
         if (!rs_image_trailer(ps, io)) return;
-        if (ps->nested) continue;
+        if (ps->nested || ps->in_memory) continue; /* (... and Image::ParseAlphaChannel, image.cpp:1386-1397, does the same for the alpha codestream) */
         rs_throw(ps, RS_INVALID_PARAMETER); /* the reference dereferences a NULL frame here */
       }
     }
@@ -2789,6 +2789,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
 {
   const int disable_to_rgb = flags & XT_DISABLE_TO_RGB;
   int retry_lonly = 0;
+  int header_error_rc = 0, header_error = 0; /* what the header walk over all scans met behind the first scan header (see below) */
   oj_box boxes[OJ_MAX_BOXES];
   oj_parser ps;
   oj_info rinfo;
@@ -2811,7 +2812,20 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info)); memset(nlt, 0, sizeof(nlt)); memset(&xt, 0, sizeof(xt)); memset(&rinfo, 0, sizeof(rinfo));
   ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes; ps.walk_all = 1; ps.in_memory = given != NULL; ps.xt_legacy = given != NULL;
   rc = walk(&ps, NULL);
-  if (rc) { free_boxes(boxes, ps.nboxes); return rc; }
+  if (rc) {
+    /* The header walk over ALL scans (it is after the boxes) met an error.  Behind the first scan header that need not be the
+     * reference's verdict: it reads the stream in order, and the entropy coded data of an earlier scan may stop it first (a DHT
+     * value changed into a symbol that runs into the next marker, -1025, in front of a scan header whose length is wrong, -1038:
+     * tools/box_campaign.py r5).  Walk again up to the first scan header: an error there stands; otherwise go on with the boxes
+     * in front of it (where every encoder puts them) and let the decoding walks below meet the errors in stream order. */
+    const int first_rc = rc, first_err = info->ref_error;
+    free_boxes(boxes, ps.nboxes);
+    memset(&ps, 0, sizeof(ps)); memset(info, 0, sizeof(*info));
+    ps.data = data; ps.len = len; ps.info = info; ps.boxes = boxes; ps.in_memory = given != NULL; ps.xt_legacy = given != NULL;
+    rc = walk(&ps, NULL);
+    if (rc) { free_boxes(boxes, ps.nboxes); info->ref_error = first_err; return first_rc; }
+    header_error_rc = first_rc; header_error = first_err;
+  }
   if (given) {
     free_boxes(boxes, ps.nboxes);
     memset(boxes, 0, sizeof(boxes));
@@ -2895,6 +2909,13 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     rc = register_box(boxes[b].type, boxes[b].data, boxes[b].len, nlt, mtx, have_mtx);
     if (rc) goto out;
   }
+  /* A TONE box that never completes stays in the reference's list as an object that was constructed and never parsed: no entries,
+   * and a table index nobody initialised (boxes/tonemapperbox.hpp:64-76) -- in practice the zero of fresh heap memory.  A
+   * specification that names table 0 finds it (namespace.cpp:60-91) and its ScaledTableOf refuses, -1024
+   * (inversetonemappingbox.cpp:192-212) -- not "does not exist", -1031.  Restated as the table with no entries. */
+  if (!nlt[0].kind)
+    for (b = 0; b < ps.nboxes; b++)
+      if (!boxes[b].complete && boxes[b].type == BOXID('T', 'O', 'N', 'E')) { nlt[0].kind = 1; nlt[0].entries = 0; nlt[0].resbits = 0; }
   /* codestream/tables.cpp:1994-2031 and the R analogue: undefined -> YCbCr for three components */
   if (nc == 1) {
     /* one component: the L and C transformation boxes must not exist (tables.cpp:2003-2005, 2079-2081), everything is the identity;
@@ -3048,6 +3069,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
       if (!xt.clamp) { info->ref_error = RS_INVALID_PARAMETER; info->transformer_refused = 1; rc = OJ_ERR_MALFORMED; }
     }
     if (rc) goto out; /* (the reference's error code travels in info->ref_error) */
+    if (header_error_rc) { rc = header_error_rc; info->ref_error = header_error; goto out; } /* (nothing came first: the header walk's error stands) */
     memcpy(info->cquant, ltmp.cquant, sizeof(ltmp.cquant)); memcpy(info->comp_seen, ltmp.comp_seen, sizeof(ltmp.comp_seen));
     if (!lonly) { memcpy(rinfo.cquant, rtmp.cquant, sizeof(rtmp.cquant)); memcpy(rinfo.comp_seen, rtmp.comp_seen, sizeof(rtmp.comp_seen)); }
     info->scan_state_valid = ltmp.scan_state_valid; rinfo.scan_state_valid = rtmp.scan_state_valid;

@@ -274,6 +274,45 @@ def test_gpu_clients_write_the_references_files(oracle, tmp_path, name, client):
         assert np.array_equal(samples(adst).reshape(want.shape), want), name
 
 
+def marker_in_the_alpha_scan(name="a8_matte"):
+    """three bytes of the alpha codestream's entropy coded data become FF FF FF in front of a byte that makes a marker of them"""
+    data = bytearray(stream(name))
+    (off, ln), = _segments(bytes(data), b"ALFA")
+    seg = bytes(data[off:off + 2 + ln])
+    sos = seg.find(b"\xff\xda")
+    data[off + sos + 40:off + sos + 43] = b"\xff\xff\xff"
+    data[off + sos + 43] = 0xB1
+    return bytes(data)
+
+
+def test_a_marker_behind_the_alpha_scan_is_no_second_frame(oracle):
+    """Image::ParseAlphaChannel hands the SAME frame back when the alpha image's trailer finds a marker (codestream/image.cpp:1386-1397,
+    like ParseResidualStream for the residual codestream): FF B1 in the alpha scan's data ends the scan, is no "double frame header", and
+    the picture and the alpha plane -- the rest of the scan zero bits -- come out (tools/box_campaign.py r5: oracle and product said -1038)."""
+    blob = marker_in_the_alpha_scan()
+    codes, is_float, out_max, mode, matte, err = oracle.decode_alpha(blob)
+    assert err == 0 and codes is not None and mode == 3
+    if oracle.have_reference():
+        with tempfile.TemporaryDirectory(dir=TMP) as t:
+            src, dst, adst = os.path.join(t, "i.jpg"), os.path.join(t, "o.ppm"), os.path.join(t, "a.pgm")
+            open(src, "wb").write(blob)
+            r = subprocess.run([oracle.REF_BIN, "-al", adst, src, dst], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            assert r.returncode == 0 and b"failed" not in r.stderr
+            assert np.array_equal(oracle.read_pnm_any(adst).reshape(codes.shape), codes)
+    d = api.Decoder(None)
+    d.read(blob)
+    assert d.alpha_channel() is not None and d.alpha_info()[0] == 3
+    d.close()
+
+
+@pytest.mark.gpu
+def test_gpu_alpha_plane_behind_a_marker_in_its_scan(oracle, dec):
+    blob = marker_in_the_alpha_scan()
+    dec.read(blob)
+    a = dec.alpha_channel()
+    assert np.array_equal(a.reconstruct().reshape(a.info.height, a.info.width), oracle.decode_alpha(blob)[0])
+
+
 @pytest.mark.gpu
 def test_gpu_alpha_stripes_through_display_rect(oracle, dec):
     """The alpha image has row cursors of its own: eight-line stripes through mijpeg_display_rect like the command line asks."""

@@ -235,3 +235,46 @@ def test_an_eob_run_above_hidden_bits_is_out_of_sync(oracle):
         d.read(data)
     assert e.value.code == -1038
     d.close()
+
+
+def test_a_tone_box_that_never_completes_is_an_empty_table_zero(oracle):
+    """A TONE box whose announced length never fills up stays in the reference's list as an object nobody parsed: no entries and a
+    table index nobody initialised (boxes/tonemapperbox.hpp:64-76) -- in practice the zero of fresh heap memory.  A specification
+    that names table 0 finds it and its ScaledTableOf refuses: INVALID_PARAMETER, not OBJECT_DOESNT_EXIST
+    (inversetonemappingbox.cpp:192-212; the most frequent mismatch of tools/box_campaign.py r5 until it was restated)."""
+    for name in ("i16_R3_prog", "hdr_R2_seq", "g16_R1_seq"):
+        data = bytearray(stream(name))
+        i = data.index(b"TONE") - 4  # LBox in front of TBox
+        data[i] ^= 0x40
+        data = bytes(data)
+        if oracle.have_reference():
+            assert oracle.reference_decode_status(data)[1] == -1024, name
+        assert oracle.decode_xt_status(data)[2] == -1024, name
+        d = api.Decoder(None)
+        with pytest.raises(api.MijpegError) as e:
+            d.read(data)
+        assert e.value.code == -1024, name
+        d.close()
+
+
+def test_errors_come_in_stream_order(oracle):
+    """A DHT value turned into a symbol that runs the scan into the next marker (-1025 from the bit reader) in front of a scan header
+    whose length is wrong (-1038): the reference reads in order and reports the first; the oracle's header walk over all scans (it
+    collects the boxes) used to report the second."""
+    data = bytearray(stream("hdr_R1_prog"))
+    sos = [i for i in range(len(data) - 1) if data[i] == 0xFF and data[i + 1] == 0xDA]
+    a, b = 2034, 2146  # two of the visible scans' headers
+    assert a in sos and b in sos and data[a - 1] == 0x31
+    data[a - 1] = 0xCC  # the last value of the DHT segment in front of scan a
+    one = bytes(data)
+    data[b + 2] = 0x83  # ... and the length field of scan header b
+    both = bytes(data)
+    for blob in (one, both):
+        if oracle.have_reference():
+            assert oracle.reference_decode_status(blob)[1] == -1025
+        assert oracle.decode_xt_status(blob)[2] == -1025
+        d = api.Decoder(None)
+        with pytest.raises(api.MijpegError) as e:
+            d.read(blob)
+        assert e.value.code == -1025
+        d.close()
