@@ -152,6 +152,7 @@ typedef struct {
   oj_info *info;
   /* tables (codestream/tables.hpp) */
   int have_quant, have_huff;
+  int late_quant_missing; /* nested: a component's quantiser table does not exist -- found out at the first request, see rs_scan */
   oj_huff huff[8]; /* 0..3 DC, 4..7 AC (marker/huffmantable.cpp:153) */
   uint32_t restart_interval;
   /* frame */
@@ -1205,6 +1206,16 @@ static void rs_scan(oj_parser *ps, oj_bs *io, int hidden_scan)
   for (i = 0; i < sc.ns; i++) {
     c = sc.ci[i];
     if (!f->comp_seen[c]) {
+      if ((ps->nested || ps->residual_ok) && (!ps->have_quant || !f->quant_defined[f->tq[c]])) {
+        /* The RESIDUAL image's transforms are not built at the start of a scan: ResidualBlockHelper::AllocateBuffers builds them
+         * (and looks the quantiser tables up, codestream/tables.cpp:1481-1494, 1750) when the first block is dequantised, i.e. at
+         * the first request for pixels -- whatever stops either codestream, and what the colour transformer refuses, comes first
+         * (a residual codestream whose DQT marker is gone AND whose entropy coded data is damaged: -1038, not -1031). */
+        ps->late_quant_missing = 1;
+        memset(f->cquant[c], 0, sizeof(f->cquant[c]));
+        f->comp_seen[c] = 1;
+        continue;
+      }
       if (!ps->have_quant) rs_throw(ps, RS_OBJECT_DOESNT_EXIST);
       if (!f->quant_defined[f->tq[c]]) rs_throw(ps, RS_OBJECT_DOESNT_EXIST);
       memcpy(f->cquant[c], f->quant[f->tq[c]], sizeof(f->cquant[c]));
@@ -3070,6 +3081,9 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     }
     if (rc) goto out; /* (the reference's error code travels in info->ref_error) */
     if (header_error_rc) { rc = header_error_rc; info->ref_error = header_error; goto out; } /* (nothing came first: the header walk's error stands) */
+    if (!lonly && !xt.no_residual && rs.late_quant_missing) { /* (see rs_scan: the first request finds the residual's quantiser table missing) */
+      info->ref_error = RS_OBJECT_DOESNT_EXIST; info->transformer_refused = 1; rc = OJ_ERR_MALFORMED; goto out;
+    }
     memcpy(info->cquant, ltmp.cquant, sizeof(ltmp.cquant)); memcpy(info->comp_seen, ltmp.comp_seen, sizeof(ltmp.comp_seen));
     if (!lonly) { memcpy(rinfo.cquant, rtmp.cquant, sizeof(rtmp.cquant)); memcpy(rinfo.comp_seen, rtmp.comp_seen, sizeof(rtmp.comp_seen)); }
     info->scan_state_valid = ltmp.scan_state_valid; rinfo.scan_state_valid = rtmp.scan_state_valid;

@@ -158,3 +158,32 @@ def test_gpu_damaged_xt_pixels(oracle):
     print(stats)
     assert not bad, bad[:10]
     assert stats["ok"] >= 150 and stats["declined"] <= 10
+
+
+def test_the_residual_images_quantiser_tables_are_looked_up_at_the_first_request(oracle):
+    """The RESIDUAL image's transforms are built when its first block is dequantised (ResidualBlockHelper::AllocateBuffers ->
+    Tables::BuildDCT -> FindQuantizationTable, codestream/tables.cpp:1481-1494, 1750), not at the start of its first scan like the
+    legacy image's: a residual codestream without its DQT marker is -1031 -- but whatever stops its entropy coded data comes first
+    (tools/box_campaign.py r5: a DQT marker turned into garbage AND a damaged scan, -1038 in the reference)."""
+    data = golden_jpeg("xt_129x71_420")
+    i = data.index(b"RESI") + 4
+    assert data[i:i + 4] == b"\xff\xd8\xff\xdb"
+    no_dqt = data[:i + 2] + b"\x5e" + data[i + 3:]  # FF DB -> 5E DB: the parser skips to the next marker, the table never arrives
+    rsos = no_dqt.index(b"\xff\xda", i)
+    both = bytearray(no_dqt)
+    both[rsos + 14 + 60:rsos + 14 + 62] = b"\xff\xc4"  # a DHT marker in the residual scan's data
+    both = bytes(both)
+    for blob, want in ((no_dqt, -1031), (both, None)):
+        oerr = oracle.decode_xt_status(blob)[2]
+        if oracle.have_reference():
+            rerr = reference_status(oracle, blob)[1]
+            assert rerr == oerr, (rerr, oerr)
+        if want is not None:
+            assert oerr == want
+        else:
+            assert oerr not in (0, -1031)
+        d = api.Decoder(None)
+        with pytest.raises(api.MijpegError) as e:
+            d.read(blob)
+        assert e.value.code == oerr
+        d.close()
