@@ -425,6 +425,17 @@ static int decode_alpha_channel(mijpeg_decoder *d, int threads)
   d->alpha->host.preset_boxes(d->host.alpha_boxes());
   int rc = n ? mijpeg_set_input(d->alpha, d->alpha_data.data(), n)
              : set_error(d->alpha, MIJPEG_ERR_MALFORMED_STREAM, "Alpha channel codestream is invalid, SOI marker missing.");
+  if (!rc) {
+    // Image::ParseAlphaChannel compares the dimensions right behind the alpha FRAME HEADER (codestream/image.cpp:1366-1380), before
+    // any of its scans is looked at (a frame header whose width byte is damaged: -1038, whatever its entropy coded data would do
+    // to a frame of that size).  A height that arrives in a DNL marker still says 0 there.
+    d->alpha->host.parse(d->alpha_data.data(), n, true); // (headers only; what it returns is the decode's to report)
+    const mijpeg_info &a = d->alpha->host.info, &f = d->host.info;
+    if (a.width > 0 && (a.width != f.width || a.height != f.height || a.dnl))
+      rc = set_error(d->alpha, MIJPEG_ERR_MALFORMED_STREAM, "Malformed stream - residual image dimensions do not match the dimensions of the legacy image");
+    else if (a.width > 0 && a.components != 1)
+      rc = set_error(d->alpha, MIJPEG_ERR_MALFORMED_STREAM, "Malformed stream - the alpha channel may only consist of a single component");
+  }
   if (!rc) rc = mijpeg_decode_coefficients(d->alpha, threads);
   if (!rc) {
     const mijpeg_info &a = d->alpha->host.info, &f = d->host.info;

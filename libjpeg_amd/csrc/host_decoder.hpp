@@ -239,6 +239,7 @@ private:
   std::vector<XtBox> preset_boxes_;
   bool ignore_residual_ = false; // late_verdict parses again: the legacy codestream has no EOI, the residual codestream is never looked at
   bool transformer_refused_ = false;
+  int verdict_hidden_l_ = 0, verdict_hidden_r_ = 0; // RSPC's counts as finish_xt read them: for late_verdict's decoders
   const char *late_quant_missing_ = nullptr; // nested: a quantiser table of the residual image does not exist -- the first request's finding (RefWalker::scan)
   bool left_16bit_store_ = false; // the last decode stopped at a coefficient beyond the 16-bit store (OVERFLOW_PARAMETER): int32 planes next
   bool nested_ = false; // this object decodes a residual codestream

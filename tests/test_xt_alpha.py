@@ -274,6 +274,33 @@ def test_gpu_clients_write_the_references_files(oracle, tmp_path, name, client):
         assert np.array_equal(samples(adst).reshape(want.shape), want), name
 
 
+def test_the_alpha_frame_header_is_judged_before_its_scans(oracle):
+    """Image::ParseAlphaChannel compares the alpha image's dimensions right behind its frame header (codestream/image.cpp:1366-1380): a
+    damaged width is -1038 at the read, whatever the scan's data would do to a frame of that size; and a byte that turns the SOF
+    marker into one of a coding process outside this library in front of a header that no longer fits is the reference's "frame
+    header marker size is invalid" (-1038), not a refusal that waits for the request (tools/box_campaign.py r5)."""
+    data = stream("a16_residual")
+    (off, ln), = _segments(data, b"ALFA")
+    seg = data[off:off + 2 + ln]
+    sof = seg.find(b"\xff\xc1")
+    wide = bytearray(data)
+    wide[off + sof + 7] = 0x1A  # the high byte of the alpha frame's width
+    other = bytearray(stream("a8_420"))
+    (off2, ln2), = _segments(bytes(other), b"ALFA")
+    sof2 = bytes(other[off2:off2 + 2 + ln2]).find(b"\xff\xc1")
+    assert sof2 > 0
+    shifted = bytes(other[:off2 + sof2 + 1]) + b"\xb3" + bytes(other[off2 + sof2 + 1:off2 + 2 + ln2 - 1]) + bytes(other[off2 + 2 + ln2:])  # FF B3 C0 ..: the box keeps its size
+    for blob in (bytes(wide), shifted):
+        assert oracle.alpha_read_error(blob) == -1038
+        if oracle.have_reference():
+            assert oracle.reference_decode_status(blob)[1] == -1038
+        d = api.Decoder(None)
+        with pytest.raises(api.MijpegError) as e:
+            d.read(blob)
+        assert e.value.code == -1038
+        d.close()
+
+
 def marker_in_the_alpha_scan(name="a8_matte"):
     """three bytes of the alpha codestream's entropy coded data become FF FF FF in front of a byte that makes a marker of them"""
     data = bytearray(stream(name))

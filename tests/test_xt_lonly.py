@@ -278,3 +278,38 @@ def test_errors_come_in_stream_order(oracle):
             d.read(blob)
         assert e.value.code == -1025
         d.close()
+
+
+def _three_way(oracle, blob, want):
+    if oracle.have_reference():
+        assert oracle.reference_decode_status(blob)[1] == want
+    assert oracle.decode_xt_status(blob)[2] == want
+    d = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        d.read(blob)
+    assert e.value.code == want
+    d.close()
+
+
+def test_a_box_segment_the_file_ends_in_is_filled_with_zeros(oracle):
+    """DecoderStream::Append (io/decoderstream.cpp:136-158) gives a box every byte its segment announced: what the file no longer
+    had is zeros.  A merging specification cut short is therefore "found a box size of zero within a superbox" (-1038), not an EOF
+    inside a box header (-1025, what rounds 4-5 answered; tools/box_campaign.py r5)."""
+    data = stream("g16_R1_seq")
+    i = data.index(b"SPEC")
+    _three_way(oracle, data[:i + 4 + 15], -1038)
+
+
+def test_hidden_scans_give_their_verdict_before_the_transformer_refuses(oracle):
+    """What the colour transformer refuses arrives with the first request; the reference has read the whole file by then, the hidden
+    refinement scans of the FINE boxes included (marker/frame.cpp:1063-1070).  A TONE box that never completes (-1024 at the request)
+    AND a damaged refinement scan: the scan's -1038 comes first."""
+    data = bytearray(stream("i16_R3_prog"))
+    t = data.index(b"TONE")
+    seg = t - 16  # FF EB of the TONE box's segment
+    assert data[seg:seg + 2] == b"\xff\xeb"
+    data[seg + 3] -= 5  # the segment is five bytes shorter than the box needs: the box never completes
+    only_tone = bytes(data)
+    _three_way(oracle, only_tone, -1024)
+    data[5145] = 0xC3  # inside the refinement scan of the FINE box with En = 5
+    _three_way(oracle, bytes(data), -1038)
