@@ -445,6 +445,12 @@ static int decode_alpha_channel(mijpeg_decoder *d, int threads)
       rc = set_error(d->alpha, MIJPEG_ERR_MALFORMED_STREAM, "Malformed stream - the alpha channel may only consist of a single component");
   }
   d->alpha_refusal = 0;
+  if (rc == MIJPEG_ERR_OPERATION_UNIMPLEMENTED) {
+    // (what this path declines does not fail the read -- but what stops the alpha image's codestreams does, and the reference has
+    // read them whatever their specification says)
+    const int v = d->alpha->host.declined_verdict();
+    if (v && v != MIJPEG_ERR_OPERATION_UNIMPLEMENTED) rc = set_error(d->alpha, v, d->alpha->host.error.message.c_str());
+  }
   if (rc) {
     const char *m = nullptr;
     mijpeg_last_error(d->alpha, &m);

@@ -178,6 +178,7 @@ public:
   // the last parse failed with what the colour transformer refuses (a table or transformation that does not exist or does not fit):
   // the reference reads such a file without complaint and fails at the first request for pixels
   bool transformer_refused() const { return transformer_refused_; }
+  int declined_verdict(); // after a parse / decode that ended with -1034: the codestreams' own verdict, else -1034 again
   mijpeg_xt_params xt{};
   std::vector<Scan> scans;
   StreamError error;

@@ -2779,6 +2779,9 @@ static int xt_codestreams_verdict(const uint8_t *data, size_t len, const oj_info
   rc = walk(&ls, planes);
   if (rc) { *ref_error = ltmp.ref_error; goto done; }
   if (ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) { *ref_error = ls.err; goto done; } }
+  /* (the ALPHA image's residual codestream is read whichever way its own codestream ended: the outer image's trailer turns to it
+   * when Image::ParseAlphaChannel has no more scans to give, codestream/image.cpp:1440-1462 -- EOI, end of the box or anything else) */
+  if (in_memory) ls.eoi_image = 1;
   *eoi_image = ls.eoi_image;
   if (!ls.eoi_image || !resi) goto done;
   rc = read_residual_info(resi->data, resi->len, &rinfo);
@@ -3020,7 +3023,7 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     if (rc) info->ref_error = ltmp.ref_error;
     if (!rc && ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) info->ref_error = ls.err; }
     if (!rc) {
-      if (ls.eoi_image) { rc = rrc; info->ref_error = rerr; }
+      if (ls.eoi_image || given) { rc = rrc; info->ref_error = rerr; } /* (the alpha image's residual: always reached) */
       else retry_lonly = 1; /* the residual codestream that does not parse is never looked at */
     }
     goto out;
@@ -3082,7 +3085,8 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
     rc = walk(&ls, planes);
     if (rc) info->ref_error = ltmp.ref_error;
     if (ltmp.dnl) memcpy(info->rows, ltmp.rows, sizeof(ltmp.rows));
-    /* (hidden scans and residual only behind an EOI, see eoi_frame / eoi_image) */
+    /* (hidden scans and residual only behind an EOI, see eoi_frame / eoi_image -- the alpha image's residual always: xt_codestreams_verdict) */
+    if (given) ls.eoi_image = 1;
     if (!rc && ls.eoi_frame) { rc = decode_hidden_scans(&ls, boxes, ps.nboxes, BOXID('F', 'I', 'N', 'E'), planes); if (rc) info->ref_error = ls.err; }
     if (!rc && ls.eoi_image && !lonly) {
       rc = walk(&rs, rplanes);
@@ -3309,6 +3313,19 @@ int oj_decode_alpha(const uint8_t *data, size_t len, oj_info *info, uint16_t **p
     }
   }
   rc = xt_decode_common(alfa->data, alfa->len, info, pixels, &isf, NULL, 0, NULL, given, n);
+  if (rc == OJ_ERR_UNSUPPORTED && aspc) {
+    /* a specification outside this restatement: the reference has read the alpha image's codestreams all the same, and what stops
+     * one of them fails the read (the rest waits for a request for alpha pixels: not followed) */
+    oj_info ai;
+    const oj_box *ares = NULL;
+    int verr = 0, eoi = 0;
+    for (b = 0; b < n; b++)
+      if (given[b].type == BOXID('R', 'E', 'S', 'I') && given[b].complete) ares = &given[b];
+    if (oj_read_info(alfa->data, alfa->len, &ai) == OJ_OK) {
+      const int vrc = xt_codestreams_verdict(alfa->data, alfa->len, &ai, given, n, ares, 0, 0, &verr, &eoi, 1);
+      if (vrc && vrc != OJ_ERR_UNSUPPORTED && verr) { info->ref_error = verr; info->transformer_refused = 0; rc = OJ_ERR_MALFORMED; }
+    }
+  }
   if (!rc) {
     /* (the depth of the output: the OCON box of the specification) */
     int bits = 8;

@@ -301,6 +301,65 @@ def test_the_alpha_frame_header_is_judged_before_its_scans(oracle):
         d.close()
 
 
+def _alpha_with_reference(oracle, blob):
+    """-> (the reference's code, its alpha plane or None) through `jpeg -al`"""
+    import re
+    with tempfile.TemporaryDirectory(dir=TMP) as t:
+        src, dst, adst = os.path.join(t, "i.jpg"), os.path.join(t, "o.ppm"), os.path.join(t, "a.pgm")
+        open(src, "wb").write(blob)
+        r = subprocess.run([oracle.REF_BIN, "-al", adst, src, dst], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        m = re.search(rb"failed - error (-?\d+)", r.stderr)
+        plane = oracle.read_pnm_any(adst) if (not m and os.path.exists(adst) and os.path.getsize(adst) > 20) else None
+        return (int(m.group(1)) if m else 0), plane
+
+
+def test_the_alpha_residual_is_read_however_the_alpha_codestream_ends(oracle):
+    """The main image's residual codestream is reached at the legacy EOI only; the ALPHA image's is turned to by the outer image's
+    trailer when Image::ParseAlphaChannel has no more scans to give -- EOI, end of the box, a marker, anything
+    (codestream/image.cpp:1440-1462).  An alpha codestream whose EOI is gone still merges its residual (tools/box_campaign.py r5:
+    2044 of 2183 alpha samples differed); and a residual codestream that does not parse fails the read whatever the alpha merging
+    specification says -- one this library declines included."""
+    data = bytearray(stream("a8_residual_hidden"))
+    (off, ln), = _segments(bytes(data), b"ALFA")
+    assert data[off + ln:off + ln + 2] == b"\xff\xd9"
+    data[off + ln + 1] = 0x44
+    no_eoi = bytes(data)
+    codes, is_float, out_max, mode, matte, err = oracle.decode_alpha(no_eoi)
+    assert err == 0
+    if oracle.have_reference():
+        rerr, plane = _alpha_with_reference(oracle, no_eoi)
+        assert rerr == 0 and np.array_equal(plane.reshape(codes.shape), codes)
+    d = api.Decoder(None)
+    d.read(no_eoi)
+    a = d.alpha_channel()
+    assert a is not None and d.alpha_info()[0] == 1
+    d.close()
+    # a specification outside the accelerated path (the integer DCT in the residual domain) beside an ARES codestream whose DHT is damaged
+    data = bytearray(stream("a8_openloop"))
+    (soff, sln), = _segments(bytes(data), b"ASPC")
+    i = bytes(data).index(b"RDCT", soff)
+    assert data[i + 4] == 0x00
+    data[i + 4] = 0x20
+    declined = bytes(data)
+    if oracle.have_reference():
+        assert oracle.reference_decode_status(declined)[1] == 0
+    d = api.Decoder(None)
+    d.read(declined)
+    assert d.alpha_channel() is None  # (declined: the picture reads, the alpha request is refused)
+    d.close()
+    (roff, rln), = _segments(declined, b"ARES")
+    j = declined.index(b"\xff\xc4", roff)
+    broken = declined[:j + 4] + b"\x7f" + declined[j + 5:]  # table class / index byte of the ARES codestream's first DHT
+    if oracle.have_reference():
+        assert oracle.reference_decode_status(broken)[1] == -1038
+    assert oracle.alpha_read_error(broken) == -1038
+    d = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        d.read(broken)
+    assert e.value.code == -1038
+    d.close()
+
+
 def marker_in_the_alpha_scan(name="a8_matte"):
     """three bytes of the alpha codestream's entropy coded data become FF FF FF in front of a byte that makes a marker of them"""
     data = bytearray(stream(name))
