@@ -313,17 +313,21 @@ def _alpha_with_reference(oracle, blob):
         return (int(m.group(1)) if m else 0), plane
 
 
+def alpha_codestream_without_eoi(name="a8_residual_hidden"):
+    data = bytearray(stream(name))
+    (off, ln), = _segments(bytes(data), b"ALFA")
+    assert data[off + ln:off + ln + 2] == b"\xff\xd9"
+    data[off + ln + 1] = 0x44
+    return bytes(data)
+
+
 def test_the_alpha_residual_is_read_however_the_alpha_codestream_ends(oracle):
     """The main image's residual codestream is reached at the legacy EOI only; the ALPHA image's is turned to by the outer image's
     trailer when Image::ParseAlphaChannel has no more scans to give -- EOI, end of the box, a marker, anything
     (codestream/image.cpp:1440-1462).  An alpha codestream whose EOI is gone still merges its residual (tools/box_campaign.py r5:
     2044 of 2183 alpha samples differed); and a residual codestream that does not parse fails the read whatever the alpha merging
     specification says -- one this library declines included."""
-    data = bytearray(stream("a8_residual_hidden"))
-    (off, ln), = _segments(bytes(data), b"ALFA")
-    assert data[off + ln:off + ln + 2] == b"\xff\xd9"
-    data[off + ln + 1] = 0x44
-    no_eoi = bytes(data)
+    no_eoi = alpha_codestream_without_eoi()
     codes, is_float, out_max, mode, matte, err = oracle.decode_alpha(no_eoi)
     assert err == 0
     if oracle.have_reference():
@@ -392,8 +396,9 @@ def test_a_marker_behind_the_alpha_scan_is_no_second_frame(oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_alpha_plane_behind_a_marker_in_its_scan(oracle, dec):
-    blob = marker_in_the_alpha_scan()
+@pytest.mark.parametrize("make", [marker_in_the_alpha_scan, alpha_codestream_without_eoi])
+def test_gpu_alpha_plane_of_damaged_alpha_codestreams(oracle, dec, make):
+    blob = make()
     dec.read(blob)
     a = dec.alpha_channel()
     assert np.array_equal(a.reconstruct().reshape(a.info.height, a.info.width), oracle.decode_alpha(blob)[0])
