@@ -514,6 +514,9 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
     if (rc) return rc;
     rc = d->host.decode_wide((int32_t *)d->coef_host, threads);
     d->timing[0] += d->host.huffman_seconds;
+    // (a frame with hidden refinement scans has no 32-bit planes on this path: declined, not the stream's fault)
+    if (rc == MIJPEG_ERR_OVERFLOW_PARAMETER && d->host.left_16bit_store())
+      return set_error(d, MIJPEG_ERR_OPERATION_UNIMPLEMENTED, "frame with hidden refinement scans and coefficients beyond the 16-bit store (a damaged scan) is not on the accelerated path");
     if (rc) return set_error(d, rc, d->host.error.message);
     if (d->device >= 0 && copy_err == hipSuccess)
       copy_err = hipMemcpyAsync(d->coef_dev, d->coef_host, (size_t)f.coef_count * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);

@@ -174,7 +174,7 @@ public:
   // this object decodes an alpha channel's codestream: `boxes` are the file's, translated (alpha_boxes of the file's decoder)
   void preset_boxes(std::vector<XtBox> boxes) { preset_boxes_ = std::move(boxes); alpha_child_ = true; }
   // the last decode() stopped at a coefficient beyond the 16-bit store: decode_wide() is the next step (plain JPEG), or a refusal
-  bool left_16bit_store() const { return left_16bit_store_; }
+  bool left_16bit_store() const { return left_16bit_store_ || (residual_ && residual_->left_16bit_store_); } // (either codestream's walk)
   // the last parse failed with what the colour transformer refuses (a table or transformation that does not exist or does not fit):
   // the reference reads such a file without complaint and fails at the first request for pixels
   bool transformer_refused() const { return transformer_refused_; }

@@ -1559,6 +1559,7 @@ static int read_residual_info(const uint8_t *data, size_t len, oj_info *info)
   memset(&ps, 0, sizeof(ps));
   memset(info, 0, sizeof(*info));
   ps.data = data; ps.len = len; ps.info = info; ps.residual_ok = 1;
+  ps.in_memory = 1; /* (the payload of a box: a memory stream, whose skips beyond the end throw -- see rs_run) */
   return walk(&ps, NULL);
 }
 
