@@ -109,9 +109,12 @@ typedef struct mijpeg_info {
  * installs into YCbCrTrafo<UWORD,3,Residual|Extended|ClampFlag|Float,...>.  Supported: explicit (TONE box), parametric
  * (CURV box) or identity L tables, parametric or identity Q and R2 tables, standard or free-form (MTRX box) L, R and C
  * transformations, residual codestream = Huffman sequential / progressive 8..12 bit with the fixpoint DCT or the DCT
- * bypass, hidden refinement scans (-R / -rR of the reference encoder: FINE / RFIN boxes, up to four bits each).
- * Not supported (JPGERR_NOT_IMPLEMENTED): lossless coding (part 8: integer DCT, RCT, residual scan types), profiles A / B
- * (float tables, pre/post scaling), alpha channels. */
+ * bypass, hidden refinement scans (-R / -rR of the reference encoder: FINE / RFIN boxes, up to four bits each); merging
+ * specifications WITHOUT a residual codestream (the L chain alone: no_residual); the lossless / near-lossless files of part 8 that
+ * need no integer DCT (-ro, -Q 100: residual scan types FFB1 / FFB2, RCT, no clamping; rct, rbits, clamp below); alpha channels
+ * (mijpeg_alpha_channel).
+ * Not supported (JPGERR_NOT_IMPLEMENTED): the integer (lifting) DCT of part 8 (-l, -rl), profiles A / B (float tables, pre/post
+ * scaling), arithmetic coding. */
 typedef struct mijpeg_xt_params {
   mijpeg_info residual;      /* residual codestream: geometry and quantiser tables; its coef_offset[] are offsets
                                 into the SAME per-frame coefficient buffer, behind the legacy planes            */
