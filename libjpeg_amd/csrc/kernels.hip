@@ -878,6 +878,52 @@ __device__ __forceinline__ void f420_chroma_edges(const Fused420Args &a, int (*c
 
 // P = 12 (FAST only): 12-bit frames (SOF1, P = 12) -- the same transforms and filters on samples sixteen times as large, the
 // colour stage rearranged so that it stays inside 32 bits (see there), 16-bit samples out (clamp 4095).
+// 24-byte line pieces as three 8-byte stores (the kernels that do not use store24_nt's 16 + 8): A-B macros for the hint
+#ifndef F444_TEMPORAL
+#define F444_TEMPORAL 0
+#endif
+#ifndef F420U_TEMPORAL
+#define F420U_TEMPORAL 0
+#endif
+template <bool TEMPORAL>
+__device__ __forceinline__ void store24_3x8(uint8_t *dst, const unsigned (&w)[6])
+{
+  u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
+  if (TEMPORAL) {
+    d2[0] = u32x2{w[0], w[1]}; d2[1] = u32x2{w[2], w[3]}; d2[2] = u32x2{w[4], w[5]};
+  } else {
+    __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
+    __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
+    __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+  }
+}
+
+// The 48-byte line pieces of the 12-bit kernels (8 pixels x 3 x 16 bit) leave as three 16-byte stores per lane, i.e. every store
+// instruction writes 16 bytes out of every 48: with the non-temporal hint the write counter showed 1.17 x the bytes written
+// (profiles/r05/summary_12bit_r05.txt: partial lines leave the cache before their neighbours arrive), without it the lines are
+// completed in L2 -- 12-bit 4:4:4 369 -> 429 Gpixel/s, 4:2:2 425 -> 477 (profiles/r05/f12_stores.txt).  0 = the hint, for A-B builds.
+#ifndef F12_TEMPORAL
+#define F12_TEMPORAL 1
+#endif
+#ifndef F420_12_TEMPORAL
+#define F420_12_TEMPORAL 1 // the 12-bit 4:2:0 kernel: 418-438 -> 491 Gpixel/s
+#endif
+#ifndef FXT_TEMPORAL
+#define FXT_TEMPORAL 0 // fusedxt420_kernel / fusedxtw420_kernel (config 5: 8 pixels x 3 half-float codes per line piece)
+#endif
+template <bool TEMPORAL = F12_TEMPORAL != 0>
+__device__ __forceinline__ void store48(uint8_t *dst, const unsigned (&w)[12])
+{
+  u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
+  if (TEMPORAL) {
+    d4[0] = u32x4{w[0], w[1], w[2], w[3]}; d4[1] = u32x4{w[4], w[5], w[6], w[7]}; d4[2] = u32x4{w[8], w[9], w[10], w[11]};
+  } else {
+    __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
+    __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
+    __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+  }
+}
+
 template <bool FAST, int MINW, bool QDEV, int P = 8>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fused420Args a)
 {
@@ -1008,10 +1054,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
               w[3 * (x / 2) + 1] = c12(bb[x]) | (c12(rr[x + 1]) << 16);
               w[3 * (x / 2) + 2] = c12(gg[x + 1]) | (c12(bb[x + 1]) << 16);
             }
-            u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
-            __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
-            __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
-            __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+            store48<F420_12_TEMPORAL != 0>(dst, w);
           } else {
             uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
 #pragma unroll
@@ -1036,10 +1079,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
             // 24 bytes r0 g0 b0 r1 ... b7: clamp + pack two samples per instruction pair
             unsigned w[6];
             rgb_shift17_sat_pack(rr, gg, bb, w);
-            u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
-            __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
-            __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
-            __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+            store24_3x8<F420U_TEMPORAL != 0>(dst, w);
           } else {
 #pragma unroll
             for (int x = 0; x < 8; x++)
@@ -1059,10 +1099,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
             unsigned w[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) w[i] = px[4 * i] | (px[4 * i + 1] << 8) | (px[4 * i + 2] << 16) | (px[4 * i + 3] << 24);
-            u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
-            __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
-            __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
-            __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+            store24_3x8<F420U_TEMPORAL != 0>(dst, w);
           } else {
 #pragma unroll
             for (int x = 0; x < 8; x++)
@@ -1654,10 +1691,7 @@ __global__ __launch_bounds__(F420_THREADS, 2) void fused422_12_kernel(const Fuse
           w[3 * (x / 2) + 1] = c12(bb[x]) | (c12(rr[x + 1]) << 16);
           w[3 * (x / 2) + 2] = c12(gg[x + 1]) | (c12(bb[x + 1]) << 16);
         }
-        u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
-        __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
-        __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
-        __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+        store48(dst, w);
       } else {
         uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
 #pragma unroll
@@ -2196,10 +2230,7 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
       if (l < nln) {
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         if (fast_store) {
-          u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
-          __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
-          __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
-          __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+          store48<FXT_TEMPORAL != 0>(dst, w);
         } else {
           unsigned short *d16 = reinterpret_cast<unsigned short *>(dst);
 #pragma unroll
@@ -2417,10 +2448,7 @@ __global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fuse
       if (l < nln) {
         uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
         if (fast_store) {
-          u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
-          __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
-          __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
-          __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+          store48<FXT_TEMPORAL != 0>(dst, w);
         } else {
           unsigned short *d16 = reinterpret_cast<unsigned short *>(dst);
 #pragma unroll
@@ -2523,10 +2551,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
       if (fast_store) {
         unsigned w[6];
         rgb_shift17_sat_pack(rr, gg, bb, w);
-        u32x2_any *d2 = reinterpret_cast<u32x2_any *>(dst);
-        __builtin_nontemporal_store(u32x2{w[0], w[1]}, d2);
-        __builtin_nontemporal_store(u32x2{w[2], w[3]}, d2 + 1);
-        __builtin_nontemporal_store(u32x2{w[4], w[5]}, d2 + 2);
+        store24_3x8<F444_TEMPORAL != 0>(dst, w);
         __builtin_amdgcn_sched_barrier(0); // one line at a time: do not interleave the lines' temporaries
       } else {
 #pragma unroll
@@ -2612,10 +2637,7 @@ __global__ __launch_bounds__(F420_THREADS, 2) void fused444_12_kernel(const Fuse
           w[3 * (x / 2) + 1] = c12(bb[x]) | (c12(rr[x + 1]) << 16);
           w[3 * (x / 2) + 2] = c12(gg[x + 1]) | (c12(bb[x + 1]) << 16);
         }
-        u32x4_any *d4 = reinterpret_cast<u32x4_any *>(dst);
-        __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, d4);
-        __builtin_nontemporal_store(u32x4{w[4], w[5], w[6], w[7]}, d4 + 1);
-        __builtin_nontemporal_store(u32x4{w[8], w[9], w[10], w[11]}, d4 + 2);
+        store48(dst, w);
         __builtin_amdgcn_sched_barrier(0); // one line at a time
       } else {
         uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);

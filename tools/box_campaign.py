@@ -104,7 +104,7 @@ def work_list(mode, seed):
             sorted(glob.glob(os.path.join(g, "xt_int16", "*.jpg"))) + sorted(glob.glob(os.path.join(g, "xt_*x*.jpg")))
     elif mode == "r5":  # the stream classes of round 5: specifications without residual, alpha channels, lossless coding
         g = os.path.join(ROOT, "tests", "golden")
-        files = sorted(glob.glob(os.path.join(g, "xt_lonly", "*.jpg")))[::3] + sorted(glob.glob(os.path.join(g, "xt_alpha", "*.jpg"))) + \
+        files = sorted(glob.glob(os.path.join(g, "xt_lonly", "*.jpg")))[seed % 3::3] + sorted(glob.glob(os.path.join(g, "xt_alpha", "*.jpg"))) + \
             sorted(glob.glob(os.path.join(g, "xt_lossless", "*.jpg")))
     if mode in ("xt", "r5"):
         streams = [(os.path.basename(f)[:-4], open(f, "rb").read()) for f in files]
