@@ -174,6 +174,11 @@ typedef struct {
   int nested;      /* this is the residual codestream of a RESI box */
   int legacy_eoi_gone; /* nested: the residual codestream ran dry in front of a scan header and the search for one took the legacy
                         * stream's EOI (see rs_run) */
+  int dri_seen, dri_extended; /* the first DRI marker stood in the header part: lengths 5 and 6 are legal from then on */
+  int header_part;   /* the tables in front of the frame header of the file itself are being read: an LSE marker may stand there */
+  int ls_trafo_seen; /* ... and one held a JPEG LS colour transformation: Tables::LTrafoTypeOf (codestream/tables.cpp:2024-2028)
+                      * makes that the transformation of a three component frame without a merging specification --
+                      * outside the accelerated subset (declined) */
   int32_t *const *planes; /* NULL: headers only */
 } oj_parser;
 
@@ -564,13 +569,19 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
     }
     break;
   }
-  case 0xffdd: { /* RestartIntervalMarker::ParseMarker, marker/restartintervalmarker.cpp:80-102 (not the JPEG LS flavour) */
-    long len;
+  case 0xffdd: { /* RestartIntervalMarker::ParseMarker, marker/restartintervalmarker.cpp:80-102.  The marker object is made where the
+                  * first DRI stands (codestream/tables.cpp:1045-1047), with the JPEG LS lengths (5 and 6 bytes: 24 and 32 bit
+                  * intervals) when that is the header part of the file: see the LSE marker below */
+    long len, upper = 0;
     bs_getword(io);
+    if (!ps->dri_seen) { ps->dri_seen = 1; ps->dri_extended = ps->header_part; }
     len = bs_getword(io);
-    if (len < 4 || len > 4) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (len < 4 || len > (ps->dri_extended ? 6 : 4)) rs_throw(ps, RS_MALFORMED_STREAM);
+    if (len == 6) upper = bs_getword(io);
+    else if (len == 5) upper = bs_get(io);
     len = bs_getword(io);
     if (len == BS_EOF) rs_throw(ps, RS_UNEXPECTED_EOF);
+    if (upper != 0) rs_unsupported(ps); /* intervals beyond 16 bits: outside the accelerated subset (declined) */
     ps->restart_interval = (uint32_t)(len & 0xffff);
     break;
   }
@@ -583,7 +594,48 @@ static int rs_tables_incremental(oj_parser *ps, oj_bs *io)
     { if (bs_skip(io, size - 2)) rs_throw(ps, RS_UNEXPECTED_EOF); }
     break;
   }
-  case 0xfff8: rs_throw(ps, RS_MALFORMED_STREAM); break; /* LSE outside JPEG LS */
+  case 0xfff8: { /* LSE, codestream/tables.cpp:1073-1110: read in the header part of the file itself -- Decoder::ParseHeaderIncremental,
+                  * codestream/decoder.cpp:85, passes isls = true as the frame type is not known yet --, "outside of a JPEG LS
+                  * stream" behind the frame header (marker/frame.cpp:812-822) and in the codestreams of boxes (image.cpp:1285, 1362) */
+    long len;
+    if (!ps->header_part) rs_throw(ps, RS_MALFORMED_STREAM);
+    bs_getword(io);
+    len = bs_getword(io);
+    if (len > 3) {
+      const int id = (int)(bs_get(io) & 0xff);
+      if (id == 1) { /* Thresholds::ParseMarker, marker/thresholds.cpp:84-94 */
+        int k;
+        if (len != 13) rs_throw(ps, RS_MALFORMED_STREAM);
+        for (k = 0; k < 5; k++) bs_getword(io);
+        break;
+      } else if (id == 2 || id == 3 || id == 4) {
+        rs_throw(ps, RS_NOT_IMPLEMENTED); /* the reference's own refusal: mapping tables, size extensions */
+      } else if (id == 0x0d) { /* LSColorTrafo::ParseMarker, marker/lscolortrafo.cpp:120-169 */
+        int depth, k, j;
+        if (ps->ls_trafo_seen) rs_throw(ps, RS_MALFORMED_STREAM);
+        ps->ls_trafo_seen = 1;
+        if (len < 6) rs_throw(ps, RS_MALFORMED_STREAM);
+        bs_getword(io);
+        depth = (int)(bs_get(io) & 0xff);
+        len -= 6;
+        if (len != 2 * depth * depth) rs_throw(ps, RS_MALFORMED_STREAM);
+        if (depth == 0) rs_throw(ps, RS_MALFORMED_STREAM);
+        for (k = 0; k < depth; k++) bs_get(io);
+        for (k = 0; k < depth; k++) {
+          const int v = (int)(bs_get(io) & 0xff);
+          if ((v & 0x7f) > 32) rs_throw(ps, RS_OVERFLOW_PARAMETER);
+          for (j = 0; j + 1 < depth; j++) bs_getword(io);
+        }
+        break;
+      } else {
+        RS_WARN(ps);
+        len--;
+      }
+    }
+    if (len <= 2) rs_throw(ps, RS_MALFORMED_STREAM);
+    bs_skip(io, len - 2);
+    break;
+  }
   case 0xffe0: { /* APP0: JFIF is parsed (marker/jfifmarker.cpp:103-129), anything else skipped */
     long len;
     bs_getword(io);
@@ -776,6 +828,7 @@ static void rs_parse_frame_header(oj_parser *ps, oj_bs *io)
   len -= 8;
   if (len != 3 * data) rs_throw(ps, RS_MALFORMED_STREAM);
   if (other_process) rs_unsupported(ps);
+  if (ps->ls_trafo_seen && data == 3) rs_unsupported(ps); /* the JPEG LS colour transformation on a DCT frame: declined */
   if (data > OJ_MAX_COMP) rs_unsupported(ps); /* more than four components: not on the accelerated path */
   f->ncomp = (int)data;
   f->hmax = f->vmax = 0;
@@ -1408,7 +1461,9 @@ static void rs_run(oj_parser *ps, oj_bs *io)
   f->adobe_transform = -1;
   /* Decoder::ParseHeaderIncremental, codestream/decoder.cpp:77-108 */
   if (bs_getword(io) != 0xffd8) rs_throw(ps, RS_MALFORMED_STREAM);
+  ps->header_part = !ps->nested && !ps->in_memory;
   while (rs_tables_incremental(ps, io)) {}
+  ps->header_part = 0;
   for (;;) { /* frames */
     rs_parse_frame_header(ps, io);
     for (;;) { /* scans: Frame::StartParseScan, marker/frame.cpp:796-861 */
@@ -2967,9 +3022,6 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
   if (rtrafo == 0) { rc = OJ_ERR_UNSUPPORTED; goto out; } /* zero */
   if (rtrafo == 4 && nc != 3) { rc = OJ_ERR_UNSUPPORTED; goto out; }
   if (ctrafo != 255 && ctrafo != 1 && ctrafo < 5) { info->ref_error = RS_MALFORMED_STREAM; rc = OJ_ERR_MALFORMED; goto late; }
-  /* OBJECT_DOESNT_EXIST "the base / color / residual transformation specified in the codestream does not exist" (colortransformerfactory.cpp:355-400, 528-566) */
-  if ((ltrafo >= 5 && !have_mtx[ltrafo]) || (ctrafo != 255 && ctrafo >= 5 && !have_mtx[ctrafo])) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; goto late; }
-  if (rtrafo >= 5 && !have_mtx[rtrafo]) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; } /* (looked up beside a residual frame only) */
   if (ocon < 0 && lonly) ocon = 0x02; /* no output conversion box: no extra bits, clipping (boxes/mergingspecbox.cpp:323-331, 648-656) */
   /* the lossless flag only changes the residual's side (codestream/tables.cpp:1643, 1687; marker/frame.cpp:595), the output
    * lookup indices are read and never used by the decoder: without a residual neither matters */
@@ -2989,6 +3041,10 @@ static int xt_decode_common(const uint8_t *data, size_t len, oj_info *info, uint
    * clamping flavours, R = RCT the ones without, R = identity has all four; anything else: INVALID_PARAMETER "The combination of L
    * and R transformation is non-standard and not supported" */
   if (!lonly && ((rtrafo == 4 && xt.clamp) || (rtrafo != 4 && rtrafo != 1 && !xt.clamp))) { info->ref_error = RS_INVALID_PARAMETER; rc = OJ_ERR_MALFORMED; goto late; }
+  /* ... and only a transformer that exists gets its parameters (InstallIntegerParameters, colortransformerfactory.cpp:283-286): */
+  /* OBJECT_DOESNT_EXIST "the base / color / residual transformation specified in the codestream does not exist" (colortransformerfactory.cpp:355-400, 528-566) */
+  if ((ltrafo >= 5 && !have_mtx[ltrafo]) || (ctrafo != 255 && ctrafo >= 5 && !have_mtx[ctrafo])) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; goto late; }
+  if (rtrafo >= 5 && !have_mtx[rtrafo]) { info->ref_error = RS_OBJECT_DOESNT_EXIST; rc = OJ_ERR_MALFORMED; late_residual_only = 1; goto late; } /* (looked up beside a residual frame only) */
   /* fractional bits of the residual path (Tables::FractionalColorBitsOf, tables.cpp:1621-1660): RCT one, the identity none when
    * the lossless flag is set, four otherwise */
   xt.rct = rtrafo == 4;

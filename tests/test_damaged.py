@@ -15,6 +15,7 @@ codestream/sequentialscan.cpp:416-420), the bit reader feeds zero bits at marker
 """
 import json
 import os
+import struct
 
 import numpy as np
 import pytest
@@ -305,3 +306,74 @@ def test_gpu_runaway_dc_pixels_equal_the_reference(oracle, dec):
     f = dec.read(good, entropy="host")
     assert f.coef_wide == 0
     assert np.array_equal(dec.reconstruct(), oracle.decode(good))
+
+
+# ------------------------------------------------------------------------------------------------ JPEG LS markers in a DCT file
+def _segment(marker, payload):
+    return bytes([0xff, marker]) + struct.pack(">H", len(payload) + 2) + payload
+
+
+def _ls_marker_cases(data):
+    """LSE (0xfff8) and the long DRI flavours of JPEG LS around a DCT frame: name -> (stream, the reference's verdict; None =
+    outside the accelerated subset).  The header part of a file is read before its frame type is known
+    (codestream/decoder.cpp:85 passes isls = true): the markers are legal there and nowhere else."""
+    i = 2
+    while data[i + 1] != 0xda:
+        i += 2 + ((data[i + 2] << 8) | data[i + 3])
+    sos = i
+    three = data[[k for k in range(2, sos) if data[k] == 0xff and data[k + 1] in (0xc0, 0xc1, 0xc2)][0] + 9] == 3
+    put = lambda at, s: data[:at] + s + data[at:]  # noqa: E731
+    thresholds = _segment(0xf8, b"\x01" + struct.pack(">5H", 255, 3, 7, 21, 64))
+    trafo = lambda depth, flags=0: _segment(0xf8, b"\x0d" + struct.pack(">H", 255) + bytes([depth]) + bytes(range(1, depth + 1)) +  # noqa: E731
+                                            (bytes([flags]) + b"\x00\x00" * (depth - 1)) * depth)
+    own = [k for k in range(2, sos) if data[k] == 0xff and data[k + 1] == 0xdd and data[k + 2:k + 4] == b"\x00\x04"]
+    long_dri = bytes([0xff, 0xdd, 0, 6, 0, 0]) + (data[own[-1] + 4:own[-1] + 6] if own else b"\x00\x00")  # (the file's own interval)
+    return {
+        "thresholds": (put(2, thresholds), 0),
+        "unknown_id": (put(2, _segment(0xf8, b"\x07abcdef")), 0),
+        "length_2": (put(2, _segment(0xf8, b"")), -1038),
+        "length_3": (put(2, _segment(0xf8, b"\x07")), 0),
+        "length_4": (put(2, _segment(0xf8, b"\x07\x00")), 0),
+        "thresholds_short": (put(2, _segment(0xf8, b"\x01" + struct.pack(">4H", 255, 3, 7, 21))), -1038),
+        "mapping_table": (put(2, _segment(0xf8, b"\x02\x01\x01\x00\x00")), -1034),
+        "size_extension": (put(2, _segment(0xf8, b"\x04\x04\x00\x00\x00\x10")), -1034),
+        "trafo_for_one": (put(2, trafo(1)), None if three else 0),
+        "trafo_for_three": (put(2, trafo(3)), None if three else 0),
+        "trafo_twice": (put(2, trafo(1) + trafo(1)), -1038),
+        "trafo_shift_33": (put(2, trafo(1, 0x21)), -1028),
+        "trafo_of_nothing": (put(2, _segment(0xf8, b"\x0d" + struct.pack(">H", 255) + b"\x00")), -1038),
+        "behind_the_frame_header": (put(sos, thresholds), -1038),
+        "dri_6_bytes": (put(2, long_dri), 0),
+        "dri_5_bytes": (put(2, long_dri[:3] + b"\x05" + long_dri[5:]), 0),
+        "dri_6_bytes_beyond_16_bits": (put(2, long_dri[:5] + b"\x01" + long_dri[6:]), None),
+        "dri_6_bytes_behind_the_frame_header": (put(sos, long_dri), -1038),
+        "dri_6_bytes_behind_one_in_the_header_part": (put(2, bytes([0xff, 0xdd, 0, 4, 0, 9]))[:sos + 6] + long_dri + data[sos:], 0),
+    }
+
+
+@pytest.mark.parametrize("base", ["ref_80x48_420", "pil_70x40_gray", "refprog_97x61_420"])
+def test_jpeg_ls_markers_in_the_header_part(oracle, base):
+    clean = oracle.decode(golden_jpeg(base))
+    for name, (blob, want) in _ls_marker_cases(golden_jpeg(base)).items():
+        px, oerr, _ = oracle.decode_status(blob)
+        d = api.Decoder(None)
+        try:
+            d.read(blob, entropy="host")
+            perr = 0
+        except api.MijpegError as e:
+            perr = e.code
+        finally:
+            d.close()
+        if want is None:  # declined by both: the LS colour transformation on a DCT frame, 32 bit restart intervals
+            assert perr == -1034 and oerr in (None, -1034), (name, oerr, perr)
+            continue
+        assert (oerr, perr) == (want, want), (name, oerr, perr)
+        if want == 0:
+            assert np.array_equal(px, clean), name
+            verdict, detail = damage.product_vs_oracle(blob)
+            assert verdict == "ok", (name, verdict, detail)
+        if oracle.have_reference():
+            rpx, rerr = oracle.reference_decode_status(blob)
+            assert rerr == want, (name, rerr)
+            if want == 0:
+                assert np.array_equal(rpx, px), name

@@ -99,6 +99,19 @@ def test_what_stays_outside(oracle):
         dec.read(clamped)
     assert e.value.code == -1024
     dec.close()
+    # ... and a transformer that does not exist is never given its matrices: a free-form R transformation whose MTRX box is
+    # missing, without clamping, is "non-standard" (-1024), not "does not exist" (-1031; colortransformerfactory.cpp:277-291)
+    blob = stream("rgb8_ro_prog")
+    i = blob.index(b"RTRF") + 4
+    freeform = blob[:i] + b"\xc0" + blob[i + 1:]
+    if oracle.have_reference():
+        assert oracle.reference_decode_status(freeform)[1] == -1024
+    assert oracle.decode_xt_status(freeform)[2] == -1024
+    dec = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        dec.read(freeform)
+    assert e.value.code == -1024
+    dec.close()
 
 
 @pytest.mark.parametrize("name", ["rgb8_ro", "hdr_ro", "rgb8_ro_rv_rR2_420_dri4", "rgb8_ro_noise"])
