@@ -794,8 +794,13 @@ static void rs_parse_frame_header(oj_parser *ps, oj_bs *io)
   case 0xffc2: type = FT_PROGRESSIVE; break;
   case 0xffb1: if (ps->nested || ps->residual_ok) type = FT_RESIDUAL; break; /* residual sequential: what `-ro` / `-Q 100` put into the RESI box */
   case 0xffb2: if (ps->nested || ps->residual_ok) type = FT_RESIDUAL_PROGRESSIVE; break; /* ... with `-rv` */
-  case 0xffc3: case 0xffc5: case 0xffc6: case 0xffc7: case 0xffc9: case 0xffca: case 0xffcb: case 0xffcd: case 0xffce:
-  case 0xffcf: case 0xffb3: case 0xffb9: case 0xffba: case 0xffbb: case 0xfff7: case 0xffde:
+  case 0xffc5: case 0xffc6: case 0xffc7: case 0xffcd: case 0xffce: case 0xffcf:
+    /* Image::CreateFrameBuffer, codestream/image.cpp:487-500: "found a differential frame outside a hierarchical image process"
+     * -- in front of everything else, the header is not even read (a DHP marker, the only way into such a process, is declined) */
+    rs_throw(ps, RS_MALFORMED_STREAM);
+    break;
+  case 0xffc3: case 0xffc9: case 0xffca: case 0xffcb:
+  case 0xffb3: case 0xffb9: case 0xffba: case 0xffbb: case 0xfff7: case 0xffde:
     break; /* lossless, arithmetic, hierarchical, the other residual types, JPEG LS: other coding processes */
   default: rs_throw(ps, RS_MALFORMED_STREAM); /* "unexpected marker while parsing the image, decoder out of sync" */
   }

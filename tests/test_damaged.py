@@ -377,3 +377,21 @@ def test_jpeg_ls_markers_in_the_header_part(oracle, base):
             assert rerr == want, (name, rerr)
             if want == 0:
                 assert np.array_equal(rpx, px), name
+
+
+@pytest.mark.parametrize("base", ["ref_80x48_420", "refprog_97x61_420"])
+def test_differential_frame_types_are_malformed_not_declined(oracle, base):
+    """SOF5-7 / SOF13-15 without a DHP marker in front: "found a differential frame outside a hierarchical image process"
+    (codestream/image.cpp:487-500) before the header is read -- the reference's verdict, not a coding process to decline."""
+    data = golden_jpeg(base)
+    at = [k for k in range(2, len(data)) if data[k] == 0xff and data[k + 1] in (0xc0, 0xc1, 0xc2)][0]
+    for marker in (0xc5, 0xc6, 0xc7, 0xcd, 0xce, 0xcf):
+        blob = data[:at + 1] + bytes([marker]) + data[at + 2:]
+        assert oracle.decode_status(blob)[1] == -1038, hex(marker)
+        d = api.Decoder(None)
+        with pytest.raises(api.MijpegError) as e:
+            d.read(blob)
+        d.close()
+        assert e.value.code == -1038, hex(marker)
+        if oracle.have_reference():
+            assert oracle.reference_decode_status(blob)[1] == -1038, hex(marker)
