@@ -476,12 +476,16 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
   if (const int prc = settle_pending(d)) return prc;
   d->batch_frames = 0;
+  static const bool trace = getenv("MIJPEG_READ_TIMES") != nullptr; // diagnostics: where a read spends its time
+  const auto t_begin = std::chrono::steady_clock::now();
   int rc = d->host.parse(d->data, d->size, false);
   if (rc) return set_error(d, rc, d->host.error.message);
   d->parsed = true;
   const mijpeg_info &f = d->host.info;
+  const auto t_parsed = std::chrono::steady_clock::now();
   rc = ensure_coef_store(d, (size_t)f.coef_count);
   if (rc) return rc;
+  const auto t_store = std::chrono::steady_clock::now();
   d->img_valid = d->model_valid = false;
   d->uploaded = false;
   d->host_planes_stale = false;
@@ -503,6 +507,11 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   }
   rc = d->host.decode(d->coef_host, threads, cb);
   d->timing[0] = d->host.huffman_seconds;
+  if (trace) {
+    const auto ms = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+    fprintf(stderr, "read: parse %.2f ms, coefficient store %.2f ms, decode %.2f ms (entropy decoders %.2f)\n", ms(t_begin, t_parsed), ms(t_parsed, t_store),
+            ms(t_store, std::chrono::steady_clock::now()), d->host.huffman_seconds * 1e3);
+  }
   if (rc == MIJPEG_ERR_OVERFLOW_PARAMETER && !d->host.is_xt()) {
     // A coefficient beyond the 16-bit store -- only damaged streams get there: a DC prediction that runs away, a point
     // transform on garbage.  The reference keeps LONG coefficients and reconstructs what they hold; so does this frame,

@@ -23,6 +23,7 @@
 #include <atomic>
 #include <functional>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/mijpeg.h"
@@ -230,6 +231,16 @@ private:
   std::vector<uint8_t> rst_code_;
   std::vector<std::vector<size_t>> scan_interval_end_;
   std::vector<std::vector<uint8_t>> scan_rst_code_;
+  // the mask planes of deferred AC refinement scans (decode_t; kept between reads, never initialised)
+  std::unique_ptr<uint64_t[]> refine_scratch_;
+  size_t refine_scratch_cap_ = 0;
+  // ... and the residual decoder's, which is a new object with every parse, while there is none
+  std::unique_ptr<uint64_t[]> spare_scratch_;
+  size_t spare_scratch_cap_ = 0;
+  void drop_residual();
+  // the byte stores of the last parse's big boxes (the residual codestream, refinement scans): the next file's boxes take them
+  // over instead of growing fresh vectors segment by segment
+  std::vector<std::vector<uint8_t>> box_spares_;
   std::vector<XtBox> boxes_;
   std::vector<int32_t> xt_q_[3], xt_r2_[3]; // Q / R2 tables of a JPEG XT stream when they are not the identities (xt.qtable / r2table point here)
   HostDecoder *residual_ = nullptr;

@@ -524,7 +524,7 @@ out = []
 for fi, n in enumerate(names):
     blobs = [golden_jpeg(n)] + [b for _, b in damage.cases(golden_jpeg(n), 6, 7000 + fi, "entropy")]
     for blob in blobs:
-        for th in (1, 5):
+        for th in (1, 5, 16):  # (16: the refinement chains of a component run in one window, on bit masks passed along)
             try:
                 f = d.read(blob, threads=th)
                 h = hashlib.sha256(b"".join(d.coefficients(c).tobytes() for c in range(f.components)))

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Round 5: the host side of config 5 with hidden bits on the GPU box's cores (no kernel runs)
+ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
+cd "$ROOT"; mkdir -p gpurun_out/r5y
+nproc > gpurun_out/r5y/host_refine_times.txt; lscpu | grep -E "Model name|Socket|Core|Thread|L2|L3|NUMA node\(s\)" >> gpurun_out/r5y/host_refine_times.txt
+timeout 600 python tools/host_refine_times.py >> gpurun_out/r5y/host_refine_times.txt 2>&1
+tail -60 gpurun_out/r5y/host_refine_times.txt
