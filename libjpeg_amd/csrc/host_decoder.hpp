@@ -213,7 +213,7 @@ private:
   void publish_tables(bool header_only);
   template <class T> int decode_sequential(T *coef, int threads);
   template <class T> void fill_unseen_components(T *coef);
-  template <class T> void range_pass(const T *coef, int threads, std::atomic<uint32_t> (&qmax_all)[MIJPEG_MAX_COMPONENTS]);
+  template <class T> void range_pass(const T *coef, int threads, std::atomic<uint32_t> (&qmax_all)[MIJPEG_MAX_COMPONENTS], unsigned done = 0);
   int restart_interval_ = 0;
   int adobe_transform_ = -1;
   bool have_frame_ = false;

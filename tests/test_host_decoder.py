@@ -464,7 +464,8 @@ for path in sys.argv[1:]:
         f = d.read(data, thr)
         base = L.mijpeg_coefficients(d._h, 0) - int(f.coef_offset[0]) * 2
         n = int(f.coef_count) * (4 if f.coef_wide else 2)
-        print(path, thr, hashlib.sha256(bytes((C.c_uint8 * n).from_address(base))).hexdigest(), list(f.range_max)[:f.components])
+        rr = list(d.xt_params().residual.range_max)[:3] if f.xt else []  # (the residual frame's: its last window takes it on the way)
+        print(path, thr, hashlib.sha256(bytes((C.c_uint8 * n).from_address(base))).hexdigest(), list(f.range_max)[:f.components], rr)
         d.close()
 """ % ROOT
     outs = []
