@@ -505,7 +505,22 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
       }
     };
   }
+  // ... and the residual planes of a JPEG XT frame with hidden bits as the last refinement window finishes them (a worker thread
+  // calls: its own device binding, its own error slot)
+  std::atomic<int> rcopy_err{(int)hipSuccess};
+  if (d->device >= 0 && d->host.residual()) {
+    d->host.set_residual_rows_callback([&, d](int c, int y0, int y1) {
+      (void)hipSetDevice(d->device);
+      const mijpeg_xt_params &x = d->host.xt;
+      const size_t row = (size_t)x.residual.blocks_w[c] * 64 * (x.residual_wide ? 2 : 1); // int16 units per block row
+      const size_t off = (size_t)x.residual.coef_offset[c] + row * (size_t)y0;
+      const hipError_t e = hipMemcpyAsync(d->coef_dev + off, d->coef_host + off, row * (size_t)(y1 - y0) * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
+      if (e != hipSuccess) rcopy_err.store((int)e);
+    });
+  }
   rc = d->host.decode(d->coef_host, threads, cb);
+  d->host.set_residual_rows_callback(nullptr);
+  if (rcopy_err.load() != (int)hipSuccess && copy_err == hipSuccess) copy_err = (hipError_t)rcopy_err.load();
   d->timing[0] = d->host.huffman_seconds;
   if (trace) {
     const auto ms = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
@@ -537,8 +552,20 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   if (rc) return set_error(d, rc, d->host.error.message);
   if (d->device >= 0 && d->host.residual() && copy_err == hipSuccess) {
     // the residual codestream's planes sit behind the legacy planes in the same buffer
-    const size_t off = (size_t)d->host.xt.residual.coef_offset[0], cnt = (size_t)f.coef_count - off;
-    copy_err = hipMemcpyAsync(d->coef_dev + off, d->coef_host + off, cnt * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
+    const mijpeg_xt_params &x = d->host.xt;
+    bool some = false;
+    for (int c = 0; c < x.residual.components; c++) some |= d->host.residual_rows_reported(c) > 0;
+    if (!some) {
+      const size_t off = (size_t)x.residual.coef_offset[0], cnt = (size_t)f.coef_count - off;
+      copy_err = hipMemcpyAsync(d->coef_dev + off, d->coef_host + off, cnt * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
+    } else // (rows the decode has sent on their way already: the rest of each plane)
+      for (int c = 0; c < x.residual.components && copy_err == hipSuccess; c++) {
+        const int y0 = d->host.residual_rows_reported(c), y1 = x.residual.blocks_h[c];
+        if (y0 >= y1) continue;
+        const size_t row = (size_t)x.residual.blocks_w[c] * 64 * (x.residual_wide ? 2 : 1);
+        const size_t off = (size_t)x.residual.coef_offset[c] + row * (size_t)y0;
+        copy_err = hipMemcpyAsync(d->coef_dev + off, d->coef_host + off, row * (size_t)(y1 - y0) * sizeof(int16_t), hipMemcpyHostToDevice, d->stream);
+      }
   }
   if (copy_err != hipSuccess) return hip_fail(d, copy_err, "hipMemcpyAsync(coefficients)");
   d->decoded = true;

@@ -151,6 +151,12 @@ public:
   const uint8_t *stream_base() const { return data_; } // the parsed input
   size_t stream_size() const { return size_; }
   HostDecoder *residual() const { return residual_; } // JPEG XT: decoder of the residual codestream
+  // JPEG XT, for one decode(): block rows [y0, y1) of residual component c hold their final coefficients -- called from a
+  // worker thread while the decode goes on (the last refinement window's appliers, decode_t), so that the owner can send them
+  // on their way; residual_rows_reported(c) = rows it has been told about when decode() returns (0: none, or told and taken
+  // back -- a decode that fell back to the sequential walk)
+  void set_residual_rows_callback(std::function<void(int, int, int)> cb) { final_rows_cb_ = std::move(cb); }
+  int residual_rows_reported(int c) const { return residual_ ? residual_->rows_reported_[c].load() : 0; }
   int hidden_bits() const { return hidden_; }
   // hidden refinement scans follow the visible ones (with a merging specification that never arrived they refine zero hidden bits)
   bool has_hidden_scans() const { return hidden_ > 0 || !hidden_src_.empty(); }
@@ -238,6 +244,8 @@ private:
   std::unique_ptr<uint64_t[]> spare_scratch_;
   size_t spare_scratch_cap_ = 0;
   void drop_residual();
+  std::function<void(int, int, int)> final_rows_cb_;
+  std::atomic<int> rows_reported_[MIJPEG_MAX_COMPONENTS] = {};
   // the byte stores of the last parse's big boxes (the residual codestream, refinement scans): the next file's boxes take them
   // over instead of growing fresh vectors segment by segment
   std::vector<std::vector<uint8_t>> box_spares_;
