@@ -32,6 +32,8 @@ struct mijpeg_decoder {
   const uint8_t *data = nullptr;
   size_t size = 0;
   bool parsed = false, decoded = false, uploaded = false;
+  bool parse_fresh = false; // host holds a full parse of (data, size) that nothing has touched since: mijpeg_decode_coefficients_device
+                            // found the stream not to qualify, the host decode that follows need not parse again
   // coefficient store: pinned when a device is attached
   int16_t *coef_host = nullptr;
   size_t coef_host_cap = 0; // int16 units
@@ -354,6 +356,7 @@ int mijpeg_set_input(mijpeg_decoder *d, const uint8_t *data, size_t size)
   d->data = data;
   d->size = size;
   d->parsed = d->decoded = d->uploaded = d->img_valid = d->model_valid = false;
+  d->parse_fresh = false;
   return MIJPEG_OK;
 }
 
@@ -361,6 +364,7 @@ int mijpeg_read_header(mijpeg_decoder *d, mijpeg_info *info)
 {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
+  d->parse_fresh = false;
   const int rc = d->host.parse(d->data, d->size, true);
   if (rc) return set_error(d, rc, d->host.error.message);
   if (info) *info = d->host.info;
@@ -478,7 +482,9 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
   d->batch_frames = 0;
   static const bool trace = getenv("MIJPEG_READ_TIMES") != nullptr; // diagnostics: where a read spends its time
   const auto t_begin = std::chrono::steady_clock::now();
-  int rc = d->host.parse(d->data, d->size, false);
+  const bool parsed_already = d->parse_fresh; // (by mijpeg_decode_coefficients_device a moment ago)
+  d->parse_fresh = false;
+  int rc = parsed_already ? 0 : d->host.parse(d->data, d->size, false);
   if (rc) return set_error(d, rc, d->host.error.message);
   d->parsed = true;
   const mijpeg_info &f = d->host.info;
@@ -532,6 +538,7 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
     // transform on garbage.  The reference keeps LONG coefficients and reconstructs what they hold; so does this frame,
     // in int32 planes (info.coef_wide) that the unfused kernels transform with the reference's 32-bit arithmetic.
     if (d->device >= 0) HIP_TRY(d, hipStreamSynchronize(d->stream)); // band uploads of the first attempt read coef_host
+    d->parse_fresh = false;
     rc = d->host.parse(d->data, d->size, false);
     if (rc) return set_error(d, rc, d->host.error.message);
     rc = ensure_coef_store(d, (size_t)f.coef_count * 2);
@@ -585,6 +592,7 @@ int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, 
   if (piece_bytes == 1 && dst) { // the other producer: the marker search writes the copy itself (what a batch's workers do)
     if (capacity < d->size + 64) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "the sink needs the stream's size (+ 64 bytes of slack)");
     d->host.set_unstuff_sink(dst, d->size);
+    d->parse_fresh = false;
     const int rc = d->host.parse(d->data, d->size, false);
     if (rc) return set_error(d, rc, d->host.error.message);
     if (d->host.scans.empty() || d->host.scans[0].unstuffed_at != dst) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "the marker search did not write the copy");
@@ -1361,17 +1369,21 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
   if (const int prc = settle_pending(d)) return prc;
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
+  d->parse_fresh = false;
   int rc = d->host.parse(d->data, d->size, false);
   if (rc) return set_error(d, rc, d->host.error.message);
   d->parsed = true;
   d->batch_frames = 0;
   const auto t_parsed = clk::now();
   HostDecoder *h = &d->host, *res = d->host.residual();
+  // (a stream that does not qualify: the parse is as good as the one mijpeg_decode_coefficients would make next)
+  d->parse_fresh = true;
   if (const char *why = device_entropy_obstacle(d->host, d->size, res != nullptr)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
   if (res) {
     if (const char *why = device_entropy_obstacle(*res, res->stream_size(), true)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
     if (d->host.xt.residual_wide) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "32-bit residual coefficients are decoded on the host");
   }
+  d->parse_fresh = false;
   rc = ensure_coef_store(d, (size_t)d->host.info.coef_count, false);
   if (rc) return rc;
   d->img_valid = d->model_valid = false;
