@@ -249,6 +249,7 @@ private:
   // the byte stores of the last parse's big boxes (the residual codestream, refinement scans): the next file's boxes take them
   // over instead of growing fresh vectors segment by segment
   std::vector<std::vector<uint8_t>> box_spares_;
+  size_t box_bytes_promised_ = 0; // what the boxes of this parse reserved up front: bounded by the length of the file
   std::vector<XtBox> boxes_;
   std::vector<int32_t> xt_q_[3], xt_r2_[3]; // Q / R2 tables of a JPEG XT stream when they are not the identities (xt.qtable / r2table point here)
   HostDecoder *residual_ = nullptr;
