@@ -2,6 +2,7 @@
 //   g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined tools/fuzz_host.cpp libjpeg_amd/csrc/host_decoder.cpp libjpeg_amd/csrc/encoder.cpp -o /tmp/fuzz_host
 //   /tmp/fuzz_host tests/golden/*.jpg
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -12,6 +13,8 @@ static uint64_t rng_state = 88172645463325252ull;
 static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 int main(int argc, char **argv)
 {
+  // FUZZ_THREADS=24: windows of many scans -- the refinement chains on bit masks, their appliers; 2 otherwise
+  const int fuzz_threads = getenv("FUZZ_THREADS") ? atoi(getenv("FUZZ_THREADS")) : 2;
   long ok = 0, bad = 0;
   for (int a = 1; a < argc; a++) {
     std::ifstream f(argv[a], std::ios::binary);
@@ -41,7 +44,7 @@ int main(int argc, char **argv)
       }
       if (!rc) {
         std::vector<int16_t> c((size_t)h.info.coef_count + 64);
-        rc = h.decode(c.data(), 2, nullptr);
+        rc = h.decode(c.data(), fuzz_threads, nullptr);
       }
       // the alpha channel of a JPEG XT file: a child decoder on the ALFA box's codestream with the boxes translated (what
       // capi.cpp's decode_alpha_channel does)
@@ -55,7 +58,7 @@ int main(int argc, char **argv)
           int arc = child.parse(adata.data(), adata.size(), false);
           if (!arc) {
             std::vector<int16_t> c((size_t)child.info.coef_count + 64);
-            arc = child.decode(c.data(), 2, nullptr);
+            arc = child.decode(c.data(), fuzz_threads, nullptr);
           }
           (void)arc;
         }

@@ -50,6 +50,34 @@ int main(int argc, char **argv)
       }
     });
   for (auto &t : ts) t.join();
-  printf("single: decoded %ld rejected %ld mismatched %ld; concurrent: %ld %ld %ld %ld decoded\n", decoded, rejected, mismatched, ok[0], ok[1], ok[2], ok[3]);
-  return mismatched ? 1 : 0;
+  // 3. JPEG XT frames with hidden residual bits at 24 threads: the refinement chains on bit masks, the planes updated by the
+  // window's spare threads, and the rows of the residual planes handed out while the decode goes on (what the C-ABI layer
+  // uploads early): every row once, in order, and FINAL when it is handed out -- the callback copies it right then, from
+  // another thread than those still writing the rest (a row that was not final is a data race here, and a mismatch below)
+  long early_rows = 0, early_bad = 0;
+  for (const auto &d : files) {
+    mij::HostDecoder a;
+    if (a.parse(d.data(), d.size(), false) || !a.residual() || !a.xt.residual_wide) continue;
+    std::vector<int16_t> ca((size_t)a.info.coef_count + 64);
+    const mijpeg_info &r = a.xt.residual;
+    std::vector<std::vector<int16_t>> snap((size_t)r.components);
+    std::vector<int> next((size_t)r.components, 0);
+    a.set_residual_rows_callback([&](int c, int y0, int y1) {
+      const size_t row = (size_t)r.blocks_w[c] * 64 * 2;
+      if (y0 != next[(size_t)c] || y1 <= y0 || y1 > r.blocks_h[c]) early_bad++;
+      next[(size_t)c] = y1;
+      const int16_t *src = ca.data() + (size_t)r.coef_offset[c] + row * (size_t)y0;
+      snap[(size_t)c].insert(snap[(size_t)c].end(), src, src + row * (size_t)(y1 - y0));
+      early_rows += y1 - y0;
+    });
+    if (a.decode(ca.data(), 24, nullptr)) continue;
+    a.set_residual_rows_callback(nullptr);
+    for (int c = 0; c < r.components; c++) {
+      if (a.residual_rows_reported(c) != next[(size_t)c]) early_bad++;
+      if (memcmp(snap[(size_t)c].data(), ca.data() + (size_t)r.coef_offset[c], snap[(size_t)c].size() * 2)) early_bad++;
+    }
+  }
+  printf("single: decoded %ld rejected %ld mismatched %ld; concurrent: %ld %ld %ld %ld decoded; residual rows handed out early %ld, wrong %ld\n", decoded, rejected,
+         mismatched, ok[0], ok[1], ok[2], ok[3], early_rows, early_bad);
+  return mismatched || early_bad ? 1 : 0;
 }
