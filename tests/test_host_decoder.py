@@ -469,12 +469,13 @@ for path in sys.argv[1:]:
         d.close()
 """ % ROOT
     outs = []
-    for extra in ({}, {"MIJPEG_NO_SCAN_PIPELINE": "1", "MIJPEG_NO_FRAME_OVERLAP": "1"}):
+    # (third child: the pipeline with the blocks themselves as the medium between the scans of a refinement chain, not bit masks)
+    for extra in ({}, {"MIJPEG_NO_SCAN_PIPELINE": "1", "MIJPEG_NO_FRAME_OVERLAP": "1"}, {"MIJPEG_NO_DEFERRED_REFINE": "1"}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code] + files, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.splitlines())
-    assert len(outs[0]) == 3 * len(files) and outs[0] == outs[1]
+    assert len(outs[0]) == 3 * len(files) and outs[0] == outs[1] == outs[2]
     # ... and the thread count changes nothing either
     for i in range(0, len(outs[0]), 3):
         assert len({" ".join(ln.split()[2:]) for ln in outs[0][i:i + 3]}) == 1, outs[0][i:i + 3]
@@ -540,7 +541,7 @@ for fi, n in enumerate(names):
 print(len(names), hashlib.sha256(" ".join(out).encode()).hexdigest())
 ''' % (ROOT, os.path.join(ROOT, "tests"))
     res = []
-    for env in ({}, {"MIJPEG_NO_REFINE_MASKS": "1", "MIJPEG_NO_SPEC_FIRST_PASS": "1"}):
+    for env in ({}, {"MIJPEG_NO_REFINE_MASKS": "1", "MIJPEG_NO_SPEC_FIRST_PASS": "1"}, {"MIJPEG_NO_DEFERRED_REFINE": "1"}, {"MIJPEG_NO_TRAILING_APPLY": "1"}):
         r = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True, env=dict(os.environ, **env))
         res.append(r.stdout.split())
-    assert res[0] == res[1] and int(res[0][0]) >= 12, res
+    assert res[0] == res[1] == res[2] == res[3] and int(res[0][0]) >= 12, res
