@@ -16,8 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CHILD = r"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, %r)
+if os.environ.get("BIND_NODE"):  # this process and the library's worker pool on one socket
+    spec = open("/sys/devices/system/node/node%%s/cpulist" %% os.environ["BIND_NODE"]).read().strip()
+    cpus = set()
+    for part in spec.split(","):
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    os.sched_setaffinity(0, cpus & os.sched_getaffinity(0))
 from libjpeg_amd import api
 data = open(sys.argv[1], "rb").read()
 d = api.Decoder(None)
@@ -66,6 +73,14 @@ def main():
             for label, env in (("masks ", {}), ("blocks", {"MIJPEG_NO_DEFERRED_REFINE": "1"}), ("blocks, first pass in order", {"MIJPEG_NO_DEFERRED_REFINE": "1", "MIJPEG_NO_SPEC_FIRST_PASS": "1"})):
                 print(label, run("r12_rR4", env, a.reads)[0], flush=True)
         print("r12 (no hidden bits)", run("r12", {}, a.reads)[0])
+        # the slow reads (+25-30 ms, in whatever step they hit): a process that is not bound to a socket?
+        try:
+            print("--- /proc/sys/kernel/numa_balancing =", open("/proc/sys/kernel/numa_balancing").read().strip(), "; masks, %d reads, bound to node 0 / not bound" % (2 * a.reads))
+        except OSError:
+            pass
+        for _ in range(2):
+            print("bound    ", run("r12_rR4", {"BIND_NODE": "0"}, 2 * a.reads)[0], flush=True)
+            print("not bound", run("r12_rR4", {}, 2 * a.reads)[0], flush=True)
 
 
 if __name__ == "__main__":
