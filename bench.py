@@ -157,9 +157,26 @@ def cpu_baseline_all_cores(streams, width, height):
                 best = dt if best is None else min(best, dt)
         finally:
             os.sched_setaffinity(0, bound)
-    return dict(value=round(nproc * width * height / best / 1e6, 1), unit="Mpixels/s", cores=nproc, kind="reference",
+    quota = cpu_quota_cpus()
+    return dict(value=round(nproc * width * height / best / 1e6, 1), unit="Mpixels/s", cores=nproc, kind="reference", cpu_quota_cpus=quota,
                 sample=f"{nproc} concurrent whole-process decodes of {min(nproc, len(streams))} distinct {width}x{height} 4:2:0 Q85 DRI=8 frames by "
-                       f"oracle/_ref/jpeg (files in /dev/shm -> /dev/null), best of 2 rounds: {best * 1e3:.0f} ms; host has {os.cpu_count()} logical cores")
+                       f"oracle/_ref/jpeg (files in /dev/shm -> /dev/null), best of 2 rounds: {best * 1e3:.0f} ms; host has {os.cpu_count()} logical cores"
+                       + (f", but the container's CPU quota (cgroup cpu.max) is {quota:g} CPUs' worth of time: that, not the core count, bounds this figure" if quota else ""))
+
+
+def cpu_quota_cpus():
+    """CPUs' worth of time per period the container may spend (cgroup v2 cpu.max, v1 cfs quota), None when unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
 
 
 # ---- HBM traffic of the headline launch, measured where it is reported ------------------------------------------------
@@ -594,7 +611,7 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
            "verified": verified,
            "per_rank_ms": [round(x, 2) for x in rank_ms], "steps": steps, "chunk_frames": best["chunk"], "decoder_objects": best["depth"],
            "ramped_schedule": best["ramp"],
-           "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(),
+           "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(), "cpu_quota_cpus": cpu_quota_cpus(),
            "stream_bytes_total": int(sum(len(v) for v in streams.values())) if world == 1 else None,
            "generation_s": round(gen_s, 1), "settings_tried": tried, "numa_binding": NUMA_BINDING,
            "note": "per rank: `decoder_objects` decoder objects driven round-robin by one thread, `chunk_frames` frames each: parallel header parse + "
@@ -854,7 +871,7 @@ def main():
         tm = dec.timing()
         best = min(ts)
         result["end_to_end"] = {"value": round(W * H / best / 1e6, 1), "unit": "Mpixels/s", "ms": round(best * 1e3, 2),
-                                "host_threads": api.default_threads(), "host_cores": os.cpu_count(),
+                                "host_threads": api.default_threads(), "host_cores": os.cpu_count(), "cpu_quota_cpus": cpu_quota_cpus(),
                                 "phases_ms": {k: round(v * 1e3, 2) for k, v in tm.items()},
                                 "note": "one frame, PCIe and host inclusive: bytes -> host Huffman (restart-interval parallel) -> "
                                         "pinned H2D (streamed) -> kernel -> D2H -> copy into the caller's interleaved bitmap"}
