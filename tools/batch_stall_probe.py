@@ -28,6 +28,16 @@ def gpu_clock():
     return None
 
 
+def throttled():
+    """(periods in which the container's CPU quota ran out, microseconds its threads stood still) so far -- cgroup v2 cpu.stat;
+    (None, None) where there is none"""
+    try:
+        d = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except (OSError, ValueError):
+        return None, None
+
+
 def main():
     if not os.environ.get("MIJPEG_BENCH_NO_NUMA"):
         print("NUMA binding:", sharding.bind_to_gpu_node(0))
@@ -47,16 +57,23 @@ def main():
             if idle:
                 time.sleep(idle)
             sclk = gpu_clock()
+            th0 = throttled()
             t = time.perf_counter()
             shard.run()
             torch.cuda.synchronize()
-            rows.append(((time.perf_counter() - t) * 1e3, list(shard.chunk_ms), list(shard.chunk_phases_ms), sclk, gpu_clock()))
+            dt = (time.perf_counter() - t) * 1e3
+            th1 = throttled()
+            rows.append((dt, list(shard.chunk_ms), list(shard.chunk_phases_ms), sclk, gpu_clock(),
+                         None if th0[0] is None else (th1[0] - th0[0], (th1[1] - th0[1]) / 1e3)))
         ms = sorted(r[0] for r in rows)
         print(f"chunk {chunk:3d} x {depth}{' ramp' if ramp else ''}: steps ms {' '.join('%.2f' % r[0] for r in rows)}   median {ms[len(ms) // 2]:.2f} min {ms[0]:.2f} max {ms[-1]:.2f}")
         best = ms[0]
         if rows[0][3] is not None:
             print('   shader clock MHz before/after each step:', ' '.join(f'{r[3]}/{r[4]}' for r in rows))
-        for si, (tot, cms, ph, _, _) in enumerate(rows):
+        if rows[0][5] is not None:  # the container's CPU quota (cgroup cpu.max) ran out inside a step?
+            print("   quota periods that ran out inside each step / ms its threads stood still (summed over the threads):",
+                  " ".join(f"{r[5][0]}/{r[5][1]:.0f}" for r in rows))
+        for si, (tot, cms, ph, _, _, _) in enumerate(rows):
             if tot > 1.25 * best:
                 worst = max(range(len(cms)), key=lambda i: cms[i])
                 print(f"   step {si}: {tot:.2f} ms; submit ms per chunk {' '.join('%.2f' % x for x in cms)}")
