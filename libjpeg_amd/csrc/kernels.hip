@@ -2273,7 +2273,10 @@ __device__ __forceinline__ void idct_column_quadwrap(int &s0, int &s1, int &s2, 
   s1 -= f1; s6 -= f1; s2 -= f1; s5 -= f1;
 }
 
-__global__ __launch_bounds__(F420_THREADS, 1) void fusedxtw420_kernel(const Fused420Args a, const FusedXtExtra x)
+#ifndef XTW_MIN_BLOCKS
+#define XTW_MIN_BLOCKS 1 // (A-B: 2 asks the compiler for 256 registers -- see profiles/r05/xt_kernels.txt)
+#endif
+__global__ __launch_bounds__(F420_THREADS, XTW_MIN_BLOCKS) void fusedxtw420_kernel(const Fused420Args a, const FusedXtExtra x)
 {
   __shared__ __attribute__((aligned(16))) int cplane[2][F420_CROWS * F420_CPITCH];
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
