@@ -354,6 +354,9 @@ int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_b
  * mijpeg_alpha_info: *mode = the compositing method of the AMUL box (0 opaque, 1 regular, 2 premultiplied, 3 matte removal;
  * -1: the alpha merging specification has no such box and JPEG::GetInformation reports no alpha channel), matte = its colour. */
 mijpeg_decoder *mijpeg_alpha_channel(mijpeg_decoder *d);
+/* 1 when mijpeg_alpha_channel(d) would hand out a decoder, 0 otherwise; never records an error (JPEG::GetInformation asks on every file,
+ * interface/jpeg.cpp:919-951, and must not leave "no alpha channel" behind as the object's last error). */
+int mijpeg_has_alpha(mijpeg_decoder *d);
 int mijpeg_alpha_info(mijpeg_decoder *d, int32_t *mode, int32_t matte[3]);
 
 /* Error of the last failing call on this object (JPEG::LastError). Returns the code, 0 if none. */

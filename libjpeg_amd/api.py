@@ -12,6 +12,7 @@ import ctypes as C
 import os
 import subprocess
 import sys
+import weakref
 
 import numpy as np
 
@@ -147,6 +148,7 @@ def lib():
         L.mijpeg_last_error.argtypes = [C.c_void_p, P(C.c_char_p)]
         L.mijpeg_alpha_channel.argtypes = [C.c_void_p]
         L.mijpeg_alpha_channel.restype = C.c_void_p
+        L.mijpeg_has_alpha.argtypes = [C.c_void_p]
         L.mijpeg_alpha_info.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_int32)]
         L.mijpeg_last_timing.argtypes = [C.c_void_p, P(C.c_double)]
         L.mijpeg_launch_reconstruct.argtypes = [P(MijpegBatch), C.c_void_p]
@@ -179,6 +181,12 @@ class Decoder:
         self.info: MijpegInfo | None = None
 
     def close(self):
+        # the alpha decoders handed out are owned by this object's handle: they die with it
+        for ref in getattr(self, "_children", ()):
+            child = ref()
+            if child is not None:
+                child._h = C.c_void_p()
+        self._children = []
         if self._h:
             if not getattr(self, "_borrowed", False):
                 lib().mijpeg_destroy(self._h)
@@ -195,6 +203,9 @@ class Decoder:
         a._borrowed = True
         a._data = None
         a._owner = self  # keep the owning object alive
+        if not hasattr(self, "_children"):
+            self._children = []
+        self._children.append(weakref.ref(a))
         a.info = MijpegInfo()
         a._check(lib().mijpeg_get_info(a._h, C.byref(a.info)))
         return a
@@ -214,6 +225,8 @@ class Decoder:
 
     def _check(self, rc: int):
         if rc:
+            if not self._h:
+                raise MijpegError(rc, "the decoder object is closed")
             msg = C.c_char_p()
             lib().mijpeg_last_error(self._h, C.byref(msg))
             raise MijpegError(rc, (msg.value or b"").decode())

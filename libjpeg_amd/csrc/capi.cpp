@@ -1451,7 +1451,7 @@ SpecHint *spec_hint()
 // batch ran on and holds for every batch that stays below that gate
 int32_t next_gate_below(int32_t range)
 {
-  static const int32_t gates[] = {2047, 7600, 8190, 16384, 45056, 49152, 65536};
+  static const int32_t gates[] = {1477, 2047, 7600, 8190, 16384, 45056, 49152, 65536}; // (1477: use_dot2_pass's range_max <= 1476)
   for (int32_t g : gates)
     if (range < g) return g - 1;
   return -1;
@@ -1558,13 +1558,17 @@ static int finish_batch(mijpeg_decoder *d)
     {
       static const bool no_spin = getenv("MIJPEG_NO_SPIN_WAIT") != nullptr; // A-B measurements
       const auto t_spin = std::chrono::steady_clock::now();
-      while (!no_spin && hipStreamQuery(d->stream) == hipErrorNotReady) {
+      hipError_t q = hipSuccess;
+      while (!no_spin && (q = hipStreamQuery(d->stream)) == hipErrorNotReady) {
         if (std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(4)) break;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
       }
-      (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+      // hipErrorNotReady is not an error: drop it -- and only it; anything else the query saw (a failed launch of the work it waits
+      // for) is the batch's verdict
+      if (q == hipErrorNotReady) (void)hipGetLastError();
+      else if (q != hipSuccess) HIP_TRY(d, q);
     }
     HIP_TRY(d, hipStreamSynchronize(d->stream));
     d->phase_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - d->pend_t0).count();
@@ -1812,6 +1816,11 @@ mijpeg_decoder *mijpeg_alpha_channel(mijpeg_decoder *d)
     return nullptr;
   }
   return d->alpha;
+}
+
+int mijpeg_has_alpha(mijpeg_decoder *d)
+{
+  return d && d->decoded && d->alpha_ready ? 1 : 0; // (a query: leaves the object's last error alone)
 }
 
 int mijpeg_alpha_info(mijpeg_decoder *d, int32_t *mode, int32_t matte[3])
@@ -2319,6 +2328,10 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
           x.ltable_entries != (256 << x.hidden_bits) || (x.residual_wide != 0) != (x.residual_hidden_bits > 0 || x.residual.precision > 12) ||
           (xrbits != 4 && !(x.general && x.rdct_bypass)) || (x.rct && (x.clamp || xrbits != 1)) || (!x.clamp && !x.general))
         return MIJPEG_ERR_INVALID_PARAMETER;
+      // the flavours without clamping (RCT, lossless identity) index their Q tables directly: a caller-made block without them is refused
+      if ((x.rct || !x.clamp) && !x.no_residual)
+        for (int c = 0; c < x.residual.components && c < 3; c++)
+          if (!x.qtable[c]) return MIJPEG_ERR_INVALID_PARAMETER;
       for (int c = 0; c < x.residual.components && c < 3; c++) plane(3 + c, x.residual, c, rprec); // (one component: planes 4, 5 stay empty)
       if (!x.residual.components) // (no residual frame at all -- a specification without a residual codestream: the merge reads nothing there)
         for (int pn = 3; pn < 6; pn++) a.subx[pn] = a.suby[pn] = 1;

@@ -385,7 +385,7 @@ JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
   // output conversion of the alpha image; without, the reference neutralises the two tags
   struct JPG_TagItem *alphatag = tags->FindTagItem(JPGTAG_ALPHA_MODE), *alphalist = tags->FindTagItem(JPGTAG_ALPHA_TAGLIST);
   int32_t mode = -1, matte[3] = {0, 0, 0};
-  mijpeg_decoder *adec = mijpeg_alpha_channel(p->dec);
+  mijpeg_decoder *adec = mijpeg_has_alpha(p->dec) ? mijpeg_alpha_channel(p->dec) : nullptr;
   mijpeg_info a;
   if (adec && mijpeg_alpha_info(p->dec, &mode, matte) == MIJPEG_OK && mode >= 0 && mijpeg_get_info(adec, &a) == MIJPEG_OK) {
     if (alphatag) alphatag->ti_Data.ti_lData = mode;

@@ -3685,7 +3685,10 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
       // lossless coding (colortrafo/ycbcrtrafo.cpp:752-766): the Q tables on the samples as they are -- the RCT's extra bit is a
       // precision bit, no fractional ones -- then the reversible transformation with wrap-around, all in LONGs
       const int rmax = (1 << a.rprecision) - 1;
-      int y = a.qlut[0][min(max(rs[0][x], 0), rmax)], cb = a.qlut[1][min(max(rs[1][x], 0), rmax)], cr = a.qlut[2][min(max(rs[2][x], 0), rmax)];
+      // (a missing table is APPLY_LUT's pass-through, :59; the host materialises them for these flavours and the launch refuses otherwise)
+      int y = a.qlut[0] ? a.qlut[0][min(max(rs[0][x], 0), rmax)] : rs[0][x];
+      int cb = a.qlut[1] ? a.qlut[1][min(max(rs[1][x], 0), rmax)] : rs[1][x];
+      int cr = a.qlut[2] ? a.qlut[2][min(max(rs[2][x], 0), rmax)] : rs[2][x];
       y >>= 1;
       cb = (int)((unsigned)cb - ((unsigned)a.out_shift << 1));
       cr = (int)((unsigned)cr - ((unsigned)a.out_shift << 1));
@@ -3697,7 +3700,7 @@ __global__ __launch_bounds__(256) void xt_merge_general_kernel(const GenericArgs
       // identity without clamping (:797-801): the Q table alone, no fractional bits, no R2 table
       const int rmax = (1 << a.rprecision) - 1;
 #pragma unroll
-      for (int c = 0; c < 3; c++) rr[c] = a.qlut[c][min(max(rs[c][x], 0), rmax)];
+      for (int c = 0; c < 3; c++) rr[c] = a.qlut[c] ? a.qlut[c][min(max(rs[c][x], 0), rmax)] : rs[c][x];
     } else {
     if (a.rtrafo_ycbcr) {
       // (LONG variables around QUAD products in the reference: a table entry beyond the range -- curves with parameters no

@@ -86,6 +86,30 @@ def test_a_file_without_alpha_has_no_alpha_channel():
     d.close()
 
 
+def test_asking_for_alpha_leaves_no_error_behind_and_children_die_with_their_owner():
+    """mijpeg_has_alpha is a query (JPEG::GetInformation asks on every file): the object's last error stays what it was.  The
+    alpha decoder a parent handed out is the parent's: closing the parent invalidates the binding's child object."""
+    import ctypes as C
+
+    L = api.lib()
+    d = api.Decoder(None)
+    with open(os.path.join(GOLDEN_DIR, "xt_int8", "enc_444.jpg"), "rb") as f:
+        d.read(f.read())
+    assert L.mijpeg_has_alpha(d._h) == 0
+    msg = C.c_char_p()
+    assert L.mijpeg_last_error(d._h, C.byref(msg)) == 0 and msg.value is None
+    d.close()
+    d = api.Decoder(None)
+    d.read(stream("a8_matte"))
+    assert L.mijpeg_has_alpha(d._h) == 1
+    a = d.alpha_channel()
+    assert a is not None and a._h
+    d.close()
+    assert not a._h  # no dangling handle: a call on it fails in the binding, not in freed memory
+    with pytest.raises(api.MijpegError):
+        a._check(-1024)
+
+
 def _segments(data, box_type):
     out, i = [], 2
     while i + 4 <= len(data) and data[i] == 0xFF and data[i + 1] != 0xDA:

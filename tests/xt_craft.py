@@ -75,5 +75,8 @@ def variants(data: bytes) -> dict[str, bytes]:
     v["bypass_noise"] = edit_spec(data, subbox(b"RDCT", b"\x31"))
     v["q_table_missing"] = edit_spec(data, pts(b"QPTS", 15))
     v["q_is_tone_box"] = edit_spec(data, pts(b"QPTS", 0))  # an explicit table where fractional bits are needed: INVALID_PARAMETER
+    # R = identity WITHOUT clamping and without the lossless flag, half float output: the Q table is indexed with the samples as they
+    # are (colortrafo/ycbcrtrafo.cpp:797-801) -- the default table must exist as a real table there
+    v["r_identity_noclamp"] = edit_spec(data, subbox(b"RTRF", b"\x10") + subbox(b"OCON", b"\x84\x00\x00"), drop=(b"RTRF", b"OCON", b"RDCT"))
     v["r2_linear_negative_slope"] = edit_spec(data, pts(b"RPTS", 9), new_boxes=app11(b"CURV", curv(9, "linear", 0, (0.9, 0.1, 0, 0))))
     return v
