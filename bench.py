@@ -7,8 +7,12 @@ resident in HBM; pixels are written to HBM.  value = decoded Mpixels/s over all 
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--size 8k|4k] [--workload both|headline|batch4k]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL barrier only: frames
-are independent, nothing is exchanged).  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU, RCCL barriers and scalar reductions only (frames are independent, nothing is exchanged).  Started
+either by the driver through torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or plainly as
+`python bench.py --gpus N`: without WORLD_SIZE the script starts its N ranks itself through
+`torch.distributed.run --standalone` (`--launcher always` does that for N = 1 too: world 1 over RCCL).  More ranks asked
+for than devices visible, or a WORLD_SIZE that contradicts --gpus, is an error -- never a silent run on fewer GPUs.
+Rank 0 prints ONE JSON line.
 
 Beside the headline the same line carries
   "batch4k"        BASELINE config 4 as written: 256 distinct 4K 4:2:0 Q85 DRI=8 streams in host memory, image-sharded
@@ -599,11 +603,22 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
     W, H = cfg["width"], cfg["height"]
     ms = best["seconds"] * 1e3 / steps
     rank_ms = [best["rank_ms"]]
+    rank_threads = [api.default_threads()]
+    rank_verified = [verified is True]
     if dist is not None:
-        tt = torch.zeros(world, dtype=torch.float64, device="cuda")
-        tt[rank] = best["rank_ms"]
+        # per rank: its milliseconds, the size of its host pool, and whether ITS frames equal the oracle's (a rank that decoded
+        # something else fails the whole line)
+        tt = torch.zeros((3, world), dtype=torch.float64, device="cuda")
+        tt[0, rank] = best["rank_ms"]
+        tt[1, rank] = api.default_threads()
+        tt[2, rank] = 1.0 if verified is True else 0.0
         dist.all_reduce(tt)
-        rank_ms = [float(x) for x in tt]
+        rank_ms = [float(x) for x in tt[0]]
+        rank_threads = [int(x) for x in tt[1]]
+        rank_verified = [bool(x > 0.5) for x in tt[2]]
+        if verified is True and not all(rank_verified):
+            verified = f"frames differ from the oracle on rank(s) {[r for r, ok in enumerate(rank_verified) if not ok]}"
+    quota = cpu_quota_cpus()
     res = {"metric": "decoded Mpixels/s, 256 x 4K 4:2:0 Q85 DRI=8 streams in host memory -> pixels in HBM (BASELINE configs[3])",
            "value": round(best["total_pixels"] / best["seconds"] / 1e6, 1), "unit": "Mpixels/s", "scaling": "strong", "n_gpus": world,
            "frames": frames_total, "frames_per_rank": len(mine), "ms_per_batch": round(ms, 2), "ms_per_frame": round(ms / frames_total, 4),
@@ -611,7 +626,9 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
            "verified": verified,
            "per_rank_ms": [round(x, 2) for x in rank_ms], "steps": steps, "chunk_frames": best["chunk"], "decoder_objects": best["depth"],
            "ramped_schedule": best["ramp"],
-           "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(), "cpu_quota_cpus": cpu_quota_cpus(),
+           "per_rank_verified": rank_verified, "per_rank_host_threads": rank_threads,
+           "host_threads_per_rank": api.default_threads(), "host_cores": os.cpu_count(), "cpu_quota_cpus": quota,
+           "cpu_quota_cpus_per_rank": None if quota is None else round(quota / world, 2),
            "stream_bytes_total": int(sum(len(v) for v in streams.values())) if world == 1 else None,
            "generation_s": round(gen_s, 1), "settings_tried": tried, "numa_binding": NUMA_BINDING,
            "note": "per rank: `decoder_objects` decoder objects driven round-robin by one thread, `chunk_frames` frames each: parallel header parse + "
@@ -679,6 +696,20 @@ def batch4k(rank, world, local_rank, dist, steps, frames_total, with_cpu, emulat
     return res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: become one.  N ranks of this very command line through
+    torch.distributed.run --standalone on 127.0.0.1 (the container's hostname may not resolve); returns its exit code."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} but {have} device(s) visible: not running on fewer GPUs than asked for")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on these hosts)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -705,7 +736,20 @@ def main():
                          "other cores) and report the PROJECTED aggregate; 0 disables")
     ap.add_argument("--emulate-world-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--emulate-dir", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--launcher", default="auto", choices=["auto", "always", "never"],
+                    help="auto: with --gpus N > 1 and no WORLD_SIZE in the environment, start the N ranks through torch.distributed.run "
+                         "--standalone; always: also for N = 1 (one rank over RCCL); never: run as the single process this is")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not launched and not args.traffic_child and not args.emulate_world_child and \
+            (args.launcher == "always" or (args.launcher == "auto" and args.gpus > 1)):
+        sys.exit(launch_ranks(args.gpus))
+    if launched and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if not launched and args.gpus > 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} with --launcher never and no WORLD_SIZE: refusing to report {args.gpus} GPUs from one process")
     if args.traffic_child:
         traffic_child(args.traffic_child)
         return
@@ -722,8 +766,10 @@ def main():
     # one process per GPU, on the socket its GPU hangs off (before the library creates its worker pool); MIJPEG_BENCH_NO_NUMA=1: as is
     global NUMA_BINDING
     NUMA_BINDING = None if os.environ.get("MIJPEG_BENCH_NO_NUMA") else sharding.bind_to_gpu_node(local_rank)
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, {torch.cuda.device_count()} visible")
     dist = None
-    if world > 1:
+    if world > 1 or launched:  # (a launched world of one still runs its barriers and reductions over RCCL)
         import torch.distributed as dist_
 
         dist = dist_
@@ -815,6 +861,8 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "verified": verified},
     }
+    result["launch"] = {"launched_by": "torch.distributed.run" if launched else "single process", "world": world,
+                        "collectives": dist.get_backend() if dist else None, "visible_devices": torch.cuda.device_count()}
     result["verified_note"] = ("frames 0, 1 and F-1 of the output the timed launches wrote, downloaded after the timed region and compared byte for byte "
                                "with oracle.decode() of their streams (oracle/: the checker, never on the measured path)")
 

@@ -12,6 +12,8 @@
 #include <new>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 
@@ -137,6 +139,39 @@ static int set_error(mijpeg_decoder *d, int code, const std::string &msg)
 static int hip_fail(mijpeg_decoder *d, hipError_t e, const char *what)
 {
   return set_error(d, MIJPEG_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// The boundary lets no C++ exception through (the reference turns everything into an error code at JPEG::Read /
+// DisplayRectangle, interface/jpeg.cpp:205-220, tools/environment.hpp:752-784): every extern "C" body is a function-try-block
+// whose handler lands here.  Out of memory is the reference's JPGERR_OUT_OF_MEMORY; anything else is a defect of this library
+// and reported as such, not as a verdict on the stream.
+static int boundary_catch(mijpeg_decoder *d, const char *where) noexcept
+{
+  int code = MIJPEG_ERR_PHASE_ERROR;
+  const char *what = "unexpected exception";
+  char buf[160];
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    code = MIJPEG_ERR_OUT_OF_MEMORY;
+    what = "out of memory";
+  } catch (const std::length_error &) { // (a container asked for more than max_size: memory all the same)
+    code = MIJPEG_ERR_OUT_OF_MEMORY;
+    what = "out of memory (container size)";
+  } catch (const std::exception &e) {
+    snprintf(buf, sizeof(buf), "%s", e.what());
+    what = buf;
+  } catch (...) {
+  }
+  if (d) {
+    d->err_code = code;
+    try {
+      d->err_msg = std::string(where) + ": " + what;
+    } catch (...) {
+      d->err_msg.clear(); // (no memory for the message either: the code stands)
+    }
+  }
+  return code;
 }
 
 #define HIP_TRY(d, call)                                  \
@@ -281,10 +316,13 @@ const char *mijpeg_version(void) { return "libjpeg_amd/mijpeg 0.1 (gfx950)"; }
 
 int mijpeg_default_threads(void) { return default_threads(); }
 
-size_t mijpeg_trim_cache(void) { return buffer_cache().trim(); }
+size_t mijpeg_trim_cache(void)
+try {
+  return buffer_cache().trim();
+} catch (...) { (void)boundary_catch(nullptr, "mijpeg_trim_cache"); return 0; }
 
 int mijpeg_create(mijpeg_decoder **out, int device)
-{
+try {
   if (!out) return MIJPEG_ERR_INVALID_PARAMETER;
   *out = nullptr;
   mijpeg_decoder *d = new (std::nothrow) mijpeg_decoder();
@@ -302,10 +340,10 @@ int mijpeg_create(mijpeg_decoder **out, int device)
   }
   *out = d;
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(nullptr, "mijpeg_create"); }
 
 void mijpeg_destroy(mijpeg_decoder *d)
-{
+try {
   if (!d) return;
   if (d->device >= 0) {
     (void)hipSetDevice(d->device);
@@ -345,10 +383,10 @@ void mijpeg_destroy(mijpeg_decoder *d)
   }
   if (d->alpha) mijpeg_destroy(d->alpha);
   delete d;
-}
+} catch (...) { (void)boundary_catch(d, "mijpeg_destroy"); }
 
 int mijpeg_set_input(mijpeg_decoder *d, const uint8_t *data, size_t size)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!data) return set_error(d, MIJPEG_ERR_STREAM_EMPTY, "empty input stream");
   // a stream of no bytes: the reference's first GetWord meets the end of file, which is its SOI error (codestream/decoder.cpp:92-96)
@@ -358,10 +396,10 @@ int mijpeg_set_input(mijpeg_decoder *d, const uint8_t *data, size_t size)
   d->parsed = d->decoded = d->uploaded = d->img_valid = d->model_valid = false;
   d->parse_fresh = false;
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_set_input"); }
 
 int mijpeg_read_header(mijpeg_decoder *d, mijpeg_info *info)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
   d->parse_fresh = false;
@@ -369,7 +407,7 @@ int mijpeg_read_header(mijpeg_decoder *d, mijpeg_info *info)
   if (rc) return set_error(d, rc, d->host.error.message);
   if (info) *info = d->host.info;
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_read_header"); }
 
 static int ensure_dev(mijpeg_decoder *d, void **ptr, size_t *cap, size_t bytes);
 
@@ -474,7 +512,7 @@ static int decode_alpha_channel(mijpeg_decoder *d, int threads)
 }
 
 int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
   if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
@@ -581,7 +619,7 @@ int mijpeg_decode_coefficients(mijpeg_decoder *d, int threads)
     d->uploaded = true;
   }
   return decode_alpha_channel(d, threads);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_decode_coefficients"); }
 
 int64_t mijpeg_unstuffed_scan(mijpeg_decoder *d, uint8_t *dst, size_t capacity, uint32_t *begin, size_t n_begin, size_t piece_bytes,
                               int32_t *n_intervals)
@@ -621,7 +659,7 @@ int64_t mijpeg_speculative_scans(int64_t *pieces)
 int mijpeg_device_walk_rounds(mijpeg_decoder *d) { return d ? d->walk_rounds : 0; }
 
 int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info)
-{
+try {
   if (!d || !info) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->batch_frames < 0) { // a submitted batch: the range check is known once its Huffman kernel is through
     const int rc = mijpeg_finish_batch_device(d);
@@ -634,15 +672,15 @@ int mijpeg_get_info(mijpeg_decoder *d, mijpeg_info *info)
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
   *info = d->host.info;
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_get_info"); }
 
 int mijpeg_get_xt_params(mijpeg_decoder *d, mijpeg_xt_params *xt)
-{
+try {
   if (!d || !xt) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->data || !d->host.is_xt()) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "the loaded stream is not a JPEG XT stream");
   *xt = d->host.xt;
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_get_xt_params"); }
 
 const int32_t *mijpeg_coefficients32(mijpeg_decoder *d, int component)
 {
@@ -1361,7 +1399,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
 }
 
 int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->data) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no input stream has been set");
   if (d->device < 0) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "decoder was created without a device");
@@ -1402,9 +1440,17 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
     const size_t rsize = res->stream_size();
     int rc2 = MIJPEG_OK;
     std::thread helper([&]() {
-      if (hipSetDevice(d->device) != hipSuccess) { rc2 = MIJPEG_ERR_DEVICE; return; }
-      rc2 = device_entropy_batch(d->xt_helper, &res, &rdata, &rsize, 1, min_intervals, d->coef_dev + own_count, res->info.coef_count, true);
+      try {
+        if (hipSetDevice(d->device) != hipSuccess) { rc2 = MIJPEG_ERR_DEVICE; return; }
+        rc2 = device_entropy_batch(d->xt_helper, &res, &rdata, &rsize, 1, min_intervals, d->coef_dev + own_count, res->info.coef_count, true);
+      } catch (...) { // (nothing may leave a thread's function)
+        rc2 = boundary_catch(d->xt_helper, "residual codestream, device entropy decoding");
+      }
     });
+    struct Joiner { // (an exception on this thread must not meet a joinable thread object)
+      std::thread &t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{helper};
     rc = device_entropy_batch(d, &h, &d->data, &d->size, 1, min_intervals, d->coef_dev, own_count, true);
     helper.join();
     if (!rc && rc2) {
@@ -1425,7 +1471,7 @@ int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
   d->uploaded = true;
   d->host_planes_stale = true;
   return decode_alpha_channel(d, 0);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_decode_coefficients_device"); }
 
 // ------------------------------------------------------------------------------------------------
 // batches: n streams of one geometry -> n coefficient stores -> n frames, two kernel launches in all
@@ -1653,12 +1699,12 @@ static int settle_speculation(mijpeg_decoder *d)
 }
 
 int mijpeg_decode_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)
-{
+try {
   return submit_batch(d, streams, sizes, n, min_intervals, false);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_decode_batch_device"); }
 
 int mijpeg_prepare_batch_host(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n)
-{
+try {
   if (!d || !streams || !sizes || n < 1) return MIJPEG_ERR_INVALID_PARAMETER;
   if (const int prc = settle_pending(d)) return prc;
   d->batch_frames = 0;
@@ -1687,25 +1733,25 @@ int mijpeg_prepare_batch_host(mijpeg_decoder *d, const uint8_t *const *streams, 
   for (int i = 0; i < n; i++)
     if (rcs[(size_t)i]) return set_error(d, rcs[(size_t)i], d->batch_hosts[(size_t)i]->error.message);
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_prepare_batch_host"); }
 
 int mijpeg_submit_batch_device(mijpeg_decoder *d, const uint8_t *const *streams, const size_t *sizes, int n, int min_intervals)
-{
+try {
   return submit_batch(d, streams, sizes, n, min_intervals, true);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_submit_batch_device"); }
 
 int mijpeg_synchronize(mijpeg_decoder *d)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0 || !d->stream) return MIJPEG_OK;
   HIP_TRY(d, hipSetDevice(d->device));
   HIP_TRY(d, hipStreamSynchronize(d->stream));
   if (d->spec_active) return settle_speculation(d); // (pixels of a speculative launch count once it is validated)
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_synchronize"); }
 
 int mijpeg_stream_wait(mijpeg_decoder *d, void *client_stream)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0 || !d->stream) return MIJPEG_OK;
   HIP_TRY(d, hipSetDevice(d->device));
@@ -1713,26 +1759,26 @@ int mijpeg_stream_wait(mijpeg_decoder *d, void *client_stream)
   HIP_TRY(d, hipEventRecord(d->chain_ev, d->stream));
   HIP_TRY(d, hipStreamWaitEvent((hipStream_t)client_stream, d->chain_ev, 0));
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_stream_wait"); }
 
 int mijpeg_finish_batch_device(mijpeg_decoder *d)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
   if (d->spec_active) return settle_speculation(d);
   return finish_batch(d);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_finish_batch_device"); }
 
 int mijpeg_batch_speculation(mijpeg_decoder *d, int64_t *launched, int64_t *redone)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (launched) *launched = d->spec_launched;
   if (redone) *redone = d->spec_redone_count;
   return d->spec_redone ? 1 : 0;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_batch_speculation"); }
 
 int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t frame_stride, int64_t row_stride, uint32_t flags, int sync)
-{
+try {
   if (!d || !dst_device) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device >= 0) HIP_TRY(d, hipSetDevice(d->device));
   bool speculate = false;
@@ -1793,19 +1839,19 @@ int mijpeg_reconstruct_batch_device(mijpeg_decoder *d, void *dst_device, int64_t
   }
   if (sync) HIP_TRY(d, hipStreamSynchronize(d->stream));
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_reconstruct_batch_device"); }
 
 const int16_t *mijpeg_device_coefficients(mijpeg_decoder *d) { return (d && d->uploaded) ? d->coef_dev : nullptr; }
 
 int mijpeg_last_error(mijpeg_decoder *d, const char **message)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (message) *message = d->err_code ? d->err_msg.c_str() : nullptr;
   return d->err_code;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_last_error"); }
 
 mijpeg_decoder *mijpeg_alpha_channel(mijpeg_decoder *d)
-{
+try {
   if (!d) return nullptr;
   if (d->decoded && !d->alpha_ready && d->alpha_refusal) { // (what the reference reports at the first request for alpha pixels)
     set_error(d, d->alpha_refusal, d->alpha_refusal_msg);
@@ -1816,35 +1862,35 @@ mijpeg_decoder *mijpeg_alpha_channel(mijpeg_decoder *d)
     return nullptr;
   }
   return d->alpha;
-}
+} catch (...) { (void)boundary_catch(d, "mijpeg_alpha_channel"); return nullptr; }
 
 int mijpeg_has_alpha(mijpeg_decoder *d)
-{
+try {
   return d && d->decoded && d->alpha_ready ? 1 : 0; // (a query: leaves the object's last error alone)
-}
+} catch (...) { return boundary_catch(d, "mijpeg_has_alpha"); }
 
 int mijpeg_alpha_info(mijpeg_decoder *d, int32_t *mode, int32_t matte[3])
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (!d->decoded || !d->alpha_ready) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "the decoded stream has no alpha channel");
   if (mode) *mode = d->host.alpha_mode();
   for (int k = 0; k < 3 && matte; k++) matte[k] = (int32_t)d->host.alpha_matte()[k];
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_alpha_info"); }
 
 int mijpeg_last_warning(mijpeg_decoder *d, const char **message)
-{
+try {
   if (message) *message = nullptr;
   if (!d || !d->data) return 0;
   return d->host.last_warning(message);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_last_warning"); }
 
 int mijpeg_last_timing(mijpeg_decoder *d, double out_seconds[4])
-{
+try {
   if (!d || !out_seconds) return MIJPEG_ERR_INVALID_PARAMETER;
   for (int i = 0; i < 4; i++) out_seconds[i] = d->timing[i];
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_last_timing"); }
 
 // ------------------------------------------------------------------------------------------------
 // stateless batch launch
@@ -2134,7 +2180,7 @@ static bool use_fused_flat(const mijpeg_batch *b)
 }
 
 const char *mijpeg_kernel_name(const mijpeg_batch *b)
-{
+try {
   if (!b) return "";
   if (use_fusedxt(b)) return b->xt->residual_hidden_bits ? "fusedxtw420_kernel" : "fusedxt420_kernel";
   if (use_fused420p(b)) return "fused420p_kernel";
@@ -2154,7 +2200,7 @@ const char *mijpeg_kernel_name(const mijpeg_batch *b)
   if (use_fused_flat(b)) return "fused_flat_kernel";
   if (b->quant_dev || (b->flags & MIJPEG_FLAG_FORCE_GENERIC) || getenv("MIJPEG_NO_FUSED_TILE") || dnl_row_missing(b->info)) return "idct_planes_kernel+upsample_color_kernel";
   return "fused_tile_kernel";
-}
+} catch (...) { (void)boundary_catch(nullptr, "mijpeg_kernel_name"); return nullptr; }
 
 static const size_t LUT_BYTES = 3 * 4096 * sizeof(int32_t);
 
@@ -2174,14 +2220,14 @@ static size_t xt_table_bytes(const mijpeg_batch *b)
 static size_t expanded_tables_bytes(const mijpeg_batch *b) { return b->quant_dev ? (size_t)b->frames * 4 * 64 * sizeof(int32_t) : 0; }
 
 size_t mijpeg_workspace_bytes(const mijpeg_batch *b)
-{
+try {
   if (!b) return 0;
   if (use_fused420(b) || use_fused444(b) || use_fused422(b) || use_fused440(b) || use_fused411(b) || use_fused1(b) || use_fused420_12(b) || use_fused1_12(b) || use_fused444_12(b) || use_fused422_12(b)) return expanded_tables_bytes(b);
   if (use_fusedxt(b)) return LUT_BYTES;
   // [LUT_BYTES: L lookup tables (JPEG XT, up to 3 x 4096 entries)] [per frame: int32 sample planes, one sample per
   // coefficient: coef_count of them, fewer when the residual planes hold 32-bit coefficients] [expanded per-frame tables]
   return LUT_BYTES + (size_t)b->info.coef_count * sizeof(int32_t) * (size_t)b->frames + expanded_tables_bytes(b) + xt_table_bytes(b);
-}
+} catch (...) { (void)boundary_catch(nullptr, "mijpeg_workspace_bytes"); return 0; }
 
 // What a rectangle request that does not show the plain picture adds to a launch (request_model.hpp; GenericArgs::rowmap ...)
 struct RequestExtra {
@@ -2193,7 +2239,10 @@ struct RequestExtra {
 };
 static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const RequestExtra *rx);
 
-int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream) { return launch_reconstruct_ex(b, stream, nullptr); }
+int mijpeg_launch_reconstruct(const mijpeg_batch *b, void *stream)
+try {
+  return launch_reconstruct_ex(b, stream, nullptr);
+} catch (...) { return boundary_catch(nullptr, "mijpeg_launch_reconstruct"); }
 
 static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const RequestExtra *rx)
 {
@@ -2419,7 +2468,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
 // encoder direction of the block pipeline
 // ------------------------------------------------------------------------------------------------
 int mijpeg_frame_layout(mijpeg_info *f)
-{
+try {
   if (!f || f->width < 1 || f->height < 1 || f->width > 65535 || f->height > 65535 || f->components < 1 || f->components > MIJPEG_MAX_COMPONENTS)
     return MIJPEG_ERR_INVALID_PARAMETER;
   int hmax = 1, vmax = 1;
@@ -2444,10 +2493,10 @@ int mijpeg_frame_layout(mijpeg_info *f)
   f->coef_count = off;
   f->sample_bytes = 1;
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(nullptr, "mijpeg_frame_layout"); }
 
 int mijpeg_launch_forward(const mijpeg_forward_batch *b, void *stream)
-{
+try {
   if (!b || !b->pixels_dev || !b->coef_dev || b->frames < 1) return MIJPEG_ERR_INVALID_PARAMETER;
   const mijpeg_info &f = b->info;
   if (f.precision != 8 || (f.components != 1 && f.components != 3) || f.xt) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
@@ -2497,10 +2546,10 @@ int mijpeg_launch_forward(const mijpeg_forward_batch *b, void *stream)
     for (int c = 1; c < 3; c++) { a.tile_nbx[c] = tx * 8; a.tile_nby[c] = ty * 8; }
   }
   return launch_forward(a, (hipStream_t)stream) ? MIJPEG_ERR_DEVICE : MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(nullptr, "mijpeg_launch_forward"); }
 
 void mijpeg_quality_tables(int quality, uint16_t luma[64], uint16_t chroma[64])
-{
+try {
   // ISO/IEC 10918-1 Annex K.1 / K.2 matrices, natural order
   static const uint8_t K1[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,  69,  56,
                                  14, 17, 22, 29, 51,  87,  80,  62,  18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
@@ -2513,7 +2562,7 @@ void mijpeg_quality_tables(int quality, uint16_t luma[64], uint16_t chroma[64])
     luma[j] = (uint16_t)std::min(255, std::max(1, (K1[j] * scale + 50) / 100)); // :411, :443-466
     chroma[j] = (uint16_t)std::min(255, std::max(1, (K2[j] * scale + 50) / 100));
   }
-}
+} catch (...) { (void)boundary_catch(nullptr, "mijpeg_quality_tables"); }
 
 // Entropy coding of one frame's coefficient planes on the device (hencode.hip) and download of the finished stream, as a
 // job of three stages with a host synchronisation in front of the second and the third (the byte counts the next stage
@@ -2695,7 +2744,7 @@ static int device_entropy_code(mijpeg_decoder *d, const mijpeg_info &f, const in
 }
 
 int mijpeg_encode_batch_device(mijpeg_decoder *d, const mijpeg_forward_batch *b, int restart_interval, int optimize, uint8_t **streams, size_t *sizes)
-{
+try {
   if (!d || !b || !streams || !sizes || b->frames < 1 || restart_interval < 0 || restart_interval > 65535) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "decoder was created without a device");
   HIP_TRY(d, hipSetDevice(d->device));
@@ -2726,18 +2775,18 @@ int mijpeg_encode_batch_device(mijpeg_decoder *d, const mijpeg_forward_batch *b,
   d->timing[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); // mijpeg_last_timing: the whole call
   d->timing[1] = d->timing[2] = d->timing[3] = 0;
   return rc;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_encode_batch_device"); }
 
 int mijpeg_encode_image(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
                         int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint8_t **stream, size_t *size)
-{
+try {
   return mijpeg_encode_image_ex(d, pixels, width, height, components, row_stride, quality, hsamp, vsamp, restart_interval, optimize, 0, stream, size);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_encode_image"); }
 
 int mijpeg_encode_image_ex(mijpeg_decoder *d, const uint8_t *pixels, int32_t width, int32_t height, int32_t components, int64_t row_stride,
                            int quality, const int32_t *hsamp, const int32_t *vsamp, int restart_interval, int optimize, uint32_t flags,
                            uint8_t **stream, size_t *size)
-{
+try {
   using clk = std::chrono::steady_clock;
   const auto t_begin = clk::now();
   if (!d || !pixels || !stream || !size || (components != 1 && components != 3) || row_stride < (int64_t)width * components)
@@ -2824,7 +2873,7 @@ int mijpeg_encode_image_ex(mijpeg_decoder *d, const uint8_t *pixels, int32_t wid
   d->timing[3] = std::chrono::duration<double>(clk::now() - t_down).count();
   if (rc) return set_error(d, rc, "entropy coding failed");
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_encode_image_ex"); }
 
 // ------------------------------------------------------------------------------------------------
 // decoder-object reconstruction
@@ -2900,27 +2949,27 @@ static int reconstruct_view(mijpeg_decoder *d, int comp, void *dst_device, int64
 }
 
 int mijpeg_reconstruct_device(mijpeg_decoder *d, void *dst_device, int64_t row_stride, uint32_t flags, int sync)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
   if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
   if (!dst_device) return set_error(d, MIJPEG_ERR_INVALID_PARAMETER, "destination pointer is NULL");
   return reconstruct_view(d, -1, dst_device, row_stride, flags & ~(MIJPEG_FLAG_DEVICE_OUTPUT | MIJPEG_FLAG_NO_UPSAMPLING), sync);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_reconstruct_device"); }
 
 void *mijpeg_host_alloc(size_t bytes)
-{
+try {
   void *p = nullptr;
   return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
-}
+} catch (...) { (void)boundary_catch(nullptr, "mijpeg_host_alloc"); return nullptr; }
 
 void mijpeg_host_free(void *p)
-{
+try {
   if (p) (void)hipHostFree(p);
-}
+} catch (...) { (void)boundary_catch(nullptr, "mijpeg_host_free"); }
 
 int mijpeg_reconstruct_host(mijpeg_decoder *d, void *dst_host, int64_t row_stride, uint32_t flags)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
   if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
@@ -2946,7 +2995,7 @@ int mijpeg_reconstruct_host(mijpeg_decoder *d, void *dst_host, int64_t row_strid
   d->timing[3] = std::chrono::duration<double>(clk::now() - t0).count(); // upload tail + kernel + D2H
   d->img_valid = false;
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_reconstruct_host"); }
 
 static int serve_rect(mijpeg_decoder *d, int view, uint32_t flags, bool to_device, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y,
                       int32_t min_comp, int32_t max_comp, void *const dst[MIJPEG_MAX_COMPONENTS],
@@ -2956,7 +3005,7 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
                             int32_t max_comp, uint32_t flags, void *const dst[MIJPEG_MAX_COMPONENTS],
                             const int32_t bytes_per_pixel[MIJPEG_MAX_COMPONENTS],
                             const int32_t bytes_per_row[MIJPEG_MAX_COMPONENTS])
-{
+try {
   if (!d || !dst || !bytes_per_pixel || !bytes_per_row) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
   if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
@@ -2991,7 +3040,7 @@ int mijpeg_reconstruct_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int
     min_comp = max_comp = 0;
   }
   return serve_rect(d, view, flags, to_device, min_x, min_y, max_x, max_y, min_comp, max_comp, vdst, vbpp, vbpr);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_reconstruct_rect"); }
 
 // The rectangle [min_x, max_x] x [min_y, max_y] (on the grid of `view`: the canvas, or a component's own samples) of the
 // plain picture, components [min_comp, max_comp] of the view, into the bitmaps.
@@ -3250,7 +3299,7 @@ static int hand_out_request(mijpeg_decoder *d, int min_x, int min_y, int y_count
 
 int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
                         uint32_t flags, const mijpeg_bitmap bitmaps[MIJPEG_MAX_COMPONENTS])
-{
+try {
   if (!d || !bitmaps) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->device < 0) return set_error(d, MIJPEG_ERR_DEVICE, "decoder was created without a device: no reconstruction path");
   if (!d->uploaded) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no decoded coefficients: call mijpeg_decode_coefficients first");
@@ -3498,10 +3547,10 @@ int mijpeg_display_rect(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
                                                              : std::string("reconstruction not available for this request"));
   }
   return hand_out_request(d, p.min_x, p.min_y, y_count, cx1, cy1, min_comp, max_comp, nc, sb, row, padded, vc, all_on_view, to_device, dst, bpp, bpr);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_display_rect"); }
 
 int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_byte, int capacity)
-{
+try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
   // scans of the codestream itself first; then -- JPEG XT -- the scans that live in boxes (hidden refinement scans of the legacy
   // frame, the residual codestream and its refinement scans): the reference parses them from memory streams while its
@@ -3524,11 +3573,11 @@ int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_b
       if (end_byte) end_byte[n] = 0;
     }
   return n;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_scan_offsets"); }
 
 int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
                         uint32_t flags, const uint32_t bm_height[MIJPEG_MAX_COMPONENTS], int32_t out[8 + 6 * MIJPEG_MAX_COMPONENTS])
-{
+try {
   if (!d || !bm_height || !out) return MIJPEG_ERR_INVALID_PARAMETER;
   if (d->host.info.components < 1 || d->host.info.width < 1) return set_error(d, MIJPEG_ERR_OBJECT_DOESNT_EXIST, "no parsed stream: call mijpeg_read_header first");
   const mijpeg_info &f = d->host.info;
@@ -3549,12 +3598,12 @@ int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t
     o[5] = zeros;
   }
   return MIJPEG_OK;
-}
+} catch (...) { return boundary_catch(d, "mijpeg_display_plan"); }
 
 int mijpeg_display_cursor(mijpeg_decoder *d, int component)
-{
+try {
   if (!d || component < 0 || component >= 2 * MIJPEG_MAX_COMPONENTS || !d->model_valid) return 0;
   return component >= MIJPEG_MAX_COMPONENTS ? d->rmodel.cursor(component - MIJPEG_MAX_COMPONENTS) : d->model.cursor(component);
-}
+} catch (...) { return boundary_catch(d, "mijpeg_display_cursor"); }
 
 } // extern "C"

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <atomic>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 #include "encoder.hpp"
@@ -286,7 +288,7 @@ extern "C" void mijpeg_free(void *p) { free(p); }
 
 extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t *coef, int restart_interval, int optimize, int threads,
                                           uint8_t **stream, size_t *size)
-{
+try {
   if (!info || !coef || !stream || !size || restart_interval < 0 || restart_interval > 65535) return MIJPEG_ERR_INVALID_PARAMETER;
   const mijpeg_info &f = *info;
   if (f.precision != 8 || (f.components != 1 && f.components != 3)) return MIJPEG_ERR_OPERATION_UNIMPLEMENTED;
@@ -491,4 +493,8 @@ extern "C" int mijpeg_encode_coefficients(const mijpeg_info *info, const int16_t
   *stream = p;
   *size = total_size;
   return MIJPEG_OK;
+} catch (const std::bad_alloc &) {
+  return MIJPEG_ERR_OUT_OF_MEMORY; // (nothing crosses the C boundary as an exception)
+} catch (...) {
+  return MIJPEG_ERR_PHASE_ERROR;
 }

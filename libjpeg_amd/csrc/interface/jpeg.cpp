@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -94,6 +96,25 @@ struct JPEG::Impl {
     errmsg = msg ? msg : "";
     return JPG_FALSE;
   }
+  // Nothing is thrown across the boundary (the reference: JPG_TRY / JPG_CATCH around every call, interface/jpeg.cpp:205-220): what
+  // the methods' function-try-blocks catch is out of memory in the vectors this object keeps, or a defect.
+  void caught(const char *where) noexcept
+  {
+    try {
+      throw;
+    } catch (const std::bad_alloc &) {
+      err = JPGERR_OUT_OF_MEMORY;
+    } catch (const std::length_error &) {
+      err = JPGERR_OUT_OF_MEMORY;
+    } catch (...) {
+      err = JPGERR_PHASE_ERROR;
+    }
+    try {
+      errmsg = std::string(where) + (err == JPGERR_OUT_OF_MEMORY ? ": out of memory" : ": unexpected exception");
+    } catch (...) {
+      errmsg.clear();
+    }
+  }
   int fail_from_decoder(int code)
   {
     const char *m = nullptr;
@@ -136,7 +157,7 @@ void JPEG::Destruct(class JPEG *o)
 }
 
 JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
-{
+try {
   Impl *p = m_pImpl;
   p->err = 0;
   if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::Read requires a tag list with an I/O hook");
@@ -342,10 +363,10 @@ JPG_LONG JPEG::Read(struct JPG_TagItem *tags)
     default: return JPG_TRUE;
     }
   }
-}
+} catch (...) { m_pImpl->caught("JPEG::Read"); return JPG_FALSE; }
 
 JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
-{
+try {
   Impl *p = m_pImpl;
   if (!p->loaded) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no image loaded to request information from");
   if (!tags) return JPG_TRUE;
@@ -404,10 +425,10 @@ JPG_LONG JPEG::GetInformation(struct JPG_TagItem *tags)
     if (alphalist) alphalist->ti_Tag = JPGTAG_TAG_IGNORE;
   }
   return JPG_TRUE;
-}
+} catch (...) { m_pImpl->caught("JPEG::GetInformation"); return JPG_FALSE; }
 
 JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
-{
+try {
   Impl *p = m_pImpl;
   p->err = 0;
   if (!p->loaded) return p->fail(JPGERR_OBJECT_DOESNT_EXIST, "no image loaded that could be reconstructed");
@@ -550,7 +571,7 @@ JPG_LONG JPEG::DisplayRectangle(struct JPG_TagItem *tags)
   }
   if (hookerr) return p->fail(hookerr, "BitMapHook signalled an error");
   return JPG_TRUE;
-}
+} catch (...) { m_pImpl->caught("JPEG::DisplayRectangle"); return JPG_FALSE; }
 
 JPG_LONG JPEG::LastError(const char *&error)
 {
@@ -567,7 +588,7 @@ JPG_LONG JPEG::LastWarning(const char *&warning)
 }
 
 JPG_LONG JPEG::ProvideImage(struct JPG_TagItem *tags)
-{
+try {
   Impl *p = m_pImpl;
   p->err = 0;
   if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::ProvideImage requires a tag list");
@@ -651,10 +672,10 @@ JPG_LONG JPEG::ProvideImage(struct JPG_TagItem *tags)
   } while (loop);
   tags->SetTagData(JPGTAG_ENCODER_IMAGE_COMPLETE, p->enc_lines >= h);
   return JPG_TRUE;
-}
+} catch (...) { m_pImpl->caught("JPEG::ProvideImage"); return JPG_FALSE; }
 
 JPG_LONG JPEG::Write(struct JPG_TagItem *tags)
-{
+try {
   Impl *p = m_pImpl;
   p->err = 0;
   if (!tags) return p->fail(JPGERR_MISSING_PARAMETER, "JPEG::Write requires a tag list with an I/O hook");
@@ -686,7 +707,7 @@ JPG_LONG JPEG::Write(struct JPG_TagItem *tags)
   }
   mijpeg_free(stream);
   return JPG_TRUE;
-}
+} catch (...) { m_pImpl->caught("JPEG::Write"); return JPG_FALSE; }
 
 // interface/jpeg.cpp:505-575: the 16 bits at the position reading stopped at, 0 for the markers that can only be handled by
 // the library (frame and scan headers, EOI, DHP), -1 at the end of the data or when no decoding is in progress.
@@ -706,7 +727,7 @@ JPG_LONG JPEG::PeekMarker(struct JPG_TagItem *)
 
 // interface/jpeg.cpp:577-611: the client takes bytes out of the stream itself; the library never sees them.
 JPG_LONG JPEG::ReadMarker(void *buffer, JPG_LONG bufsize, struct JPG_TagItem *)
-{
+try {
   Impl *p = m_pImpl;
   if (!p->pulled) { p->fail(JPGERR_OBJECT_DOESNT_EXIST, "decoding not in progress"); return -1; }
   if (p->phase == Impl::P_DONE || bufsize < 0 || !buffer) return bufsize == 0 ? 0 : -1;
@@ -715,11 +736,11 @@ JPG_LONG JPEG::ReadMarker(void *buffer, JPG_LONG bufsize, struct JPG_TagItem *)
   memcpy(buffer, p->stream.data() + p->cursor, n);
   p->take(n);
   return (JPG_LONG)n;
-}
+} catch (...) { m_pImpl->caught("JPEG::ReadMarker"); return -1; }
 
 // interface/jpeg.cpp:613-645
 JPG_LONG JPEG::SkipMarker(JPG_LONG bytes, struct JPG_TagItem *)
-{
+try {
   Impl *p = m_pImpl;
   if (!p->pulled) { p->fail(JPGERR_OBJECT_DOESNT_EXIST, "decoding not in progress"); return -1; }
   if (p->phase == Impl::P_DONE) return 0;
@@ -728,5 +749,5 @@ JPG_LONG JPEG::SkipMarker(JPG_LONG bytes, struct JPG_TagItem *)
     p->take((size_t)bytes < left ? (size_t)bytes : left);
   }
   return 0;
-}
+} catch (...) { m_pImpl->caught("JPEG::SkipMarker"); return -1; }
 JPG_LONG JPEG::WriteMarker(void *, JPG_LONG, struct JPG_TagItem *) { m_pImpl->fail(JPGERR_NOT_IMPLEMENTED, "the encoder is not part of the accelerated path"); return -1; }

@@ -8,6 +8,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 from conftest import ROOT
 
 WORKER = textwrap.dedent("""
@@ -146,3 +148,41 @@ def test_batch_schedule_covers_every_frame_once():
     sizes = [b - a for a, b in r]
     assert sizes[0] < sizes[1] < sizes[2] and sizes[-1] < sizes[-2] < sizes[-3] and sizes[:2] == sizes[-2:][::-1]
     assert BatchShard.schedule(32, 24, True) == BatchShard.schedule(32, 24, False)
+
+
+def _bench(*args, env=None, timeout=900):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout,
+                          env=dict(os.environ, **(env or {})))
+
+
+def test_bench_never_reports_more_gpus_than_it_runs_on():
+    """`bench.py --gpus N` starts its ranks itself; what it cannot start is an error, not a run on fewer devices."""
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 64:
+        pytest.skip("a box with 64 devices")
+    r = _bench("--gpus", "64", "--steps", "1")
+    assert r.returncode != 0 and "--gpus 64" in r.stderr and "visible" in r.stderr, r.stderr[-400:]
+    r = _bench("--gpus", "4", "--steps", "1", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr, r.stderr[-400:]
+    r = _bench("--gpus", "2", "--launcher", "never", "--steps", "1")
+    assert r.returncode != 0 and "refusing" in r.stderr, r.stderr[-400:]
+
+
+@pytest.mark.gpu
+def test_bench_through_its_own_launcher_over_rccl():
+    """One rank, started the way N ranks are (`--launcher always`): init_process_group("nccl"), the barriers around both timed regions
+    and the reductions run on the device over RCCL; the line says so, and every rank's frames are checked against the oracle."""
+    import json
+
+    r = _bench("--gpus", "1", "--launcher", "always", "--workload", "batch4k", "--batch-frames", "32", "--batch-steps", "2", "--frames", "8",
+               "--steps", "2", "--warmup", "1", "--settle-ms", "0", "--no-traffic", "--no-dense", "--no-xt", "--no-end-to-end", "--no-cpu-baseline",
+               "--emulate-world", "0", env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-600:], r.stderr[-1200:])
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["verified"] is True
+    assert res["launch"] == {"launched_by": "torch.distributed.run", "world": 1, "collectives": "nccl", "visible_devices": res["launch"]["visible_devices"]}
+    b = res["batch4k"]
+    assert b["verified"] is True and b["per_rank_verified"] == [True] and b["n_gpus"] == 1 and b["frames"] == 32
+    assert len(b["per_rank_ms"]) == 1 and b["per_rank_host_threads"] == [b["host_threads_per_rank"]]
