@@ -967,7 +967,7 @@ static int evaluate_entropy_status(mijpeg_decoder *d, HostDecoder *const *hosts,
 // ten bits, in a 64-entry table indexed by the six bits that follow (entries as in the direct table: huff_dev_entry).  Codes
 // whose prefix finds no table left keep the direct entry HUFF_DEV_SUB | HUFF_DEV_NO_SUB: the kernels walk the canonical arrays
 // for those.
-static void fill_second_level(HuffDevTable &dst, const HuffTable &h, bool ac)
+static void fill_second_level(HuffDevTable &dst, const HuffTable &h, int ac)
 {
   int prefix_of[HUFF_DEV_SUBTABLES], used = 0;
   int code = 0, k = 0;
@@ -989,6 +989,23 @@ static void fill_second_level(HuffDevTable &dst, const HuffTable &h, bool ac)
     }
     code <<= 1;
   }
+}
+
+// The host's decoder table in the device's form (huffman_dev.hpp): direct entries, second-level tables, the canonical arrays.
+// mode: 0 DC, 1 AC of a sequential scan, 2 AC of a progressive / refinement scan (huff_dev_entry).
+static void build_dev_table(HuffDevTable &dst, const HuffTable &src, int mode)
+{
+  memset(&dst, 0, sizeof(dst));
+  // the host's direct table ((length << 8) | symbol, 0 = a longer code or none) in the device's entry format
+  for (int x = 0; x < (1 << HUFF_DEV_LOOKAHEAD); x++) {
+    const uint16_t he = src.fast[x];
+    dst.fast[x] = he ? (uint16_t)huff_dev_entry(he >> 8, he & 0xffu, mode) : (uint16_t)(HUFF_DEV_SUB | HUFF_DEV_NO_SUB);
+  }
+  static const bool no_sub = getenv("MIJPEG_HUFF_NO_SUBTABLES") != nullptr; // A-B measurements: long codes walk the canonical arrays
+  if (!no_sub) fill_second_level(dst, src, mode);
+  memcpy(dst.maxcode, src.maxcode, sizeof(dst.maxcode));
+  memcpy(dst.valoff, src.valoff, sizeof(dst.valoff));
+  memcpy(dst.values, src.values, sizeof(dst.values));
 }
 
 // Entropy-decode n parsed images of identical frame geometry on the device, image i into coef_dev + i * frame_stride.
@@ -1203,18 +1220,7 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
     for (int k = 0; k < s.ncomp && !same_tables; k++) {
       const HuffTable *src[2] = {&s.dc[k], &s.ac[k]};
       for (int t = 0; t < 2; t++) {
-        HuffDevTable &dst = tabs[tab_slot[k][t]];
-        memset(&dst, 0, sizeof(dst));
-        // the host's direct table ((length << 8) | symbol, 0 = a longer code or none) in the device's entry format
-        for (int x = 0; x < (1 << HUFF_DEV_LOOKAHEAD); x++) {
-          const uint16_t he = src[t]->fast[x];
-          dst.fast[x] = he ? (uint16_t)huff_dev_entry(he >> 8, he & 0xffu, t == 1) : (uint16_t)(HUFF_DEV_SUB | HUFF_DEV_NO_SUB);
-        }
-        static const bool no_sub = getenv("MIJPEG_HUFF_NO_SUBTABLES") != nullptr; // A-B measurements: long codes walk the canonical arrays
-        if (!no_sub) fill_second_level(dst, *src[t], t == 1);
-        memcpy(dst.maxcode, src[t]->maxcode, sizeof(dst.maxcode));
-        memcpy(dst.valoff, src[t]->valoff, sizeof(dst.valoff));
-        memcpy(dst.values, src[t]->values, sizeof(dst.values));
+        build_dev_table(tabs[tab_slot[k][t]], *src[t], t);
       }
       const int c = s.sc[k].comp;
       const uint16_t *delta = f.quant[f.quant_index[c]];
@@ -1398,6 +1404,281 @@ static int device_entropy_batch(mijpeg_decoder *d, HostDecoder *const *hosts, co
   return evaluate_entropy_status(d, hosts, n, status_host);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Progressive frames and frames with hidden refinement scans on the device (huffman_prog_kernel)
+// ------------------------------------------------------------------------------------------------
+// One frame of a file: its decoder, the element type of its planes, where they start in the object's coefficient store.
+struct MultiScanFrame {
+  HostDecoder *h;
+  bool wide;        // int32 coefficients (JPEG XT residual frames with hidden bits)
+  int64_t base16;   // offset of the frame's planes in coef_dev, in int16 units
+};
+
+// nullptr: every scan of the frame can be decoded one restart interval per lane.
+static const char *multiscan_obstacle(const HostDecoder &h, bool xt_part, bool residual_frame)
+{
+  const mijpeg_info &f = h.info;
+  if (h.needs_sequential())
+    return "on-device entropy decoding: the stream is damaged; the host decoder walks it with the reference's resynchronisation (entropyparser.cpp:117-201)";
+  if (f.xt && !xt_part) return "on-device entropy decoding: not for this JPEG XT stream";
+  if (!h.residual_merged()) return "on-device entropy decoding: the legacy codestream has no EOI marker (the host decoder decides what is merged)";
+  if (h.verdict_pending()) return "on-device entropy decoding: the file's verdict is the host decoder's (residual codestream header / tables looked up at the first request)";
+  if (f.dnl) return "on-device entropy decoding: frames whose height arrives in a DNL marker are decoded on the host";
+  if (f.precision != 8 && !(xt_part && residual_frame && f.precision >= 8 && f.precision <= 12))
+    return "on-device entropy decoding: 8-bit frames (8..12-bit residual frames of JPEG XT) only";
+  if (h.scans.empty() || h.scans.size() > 4096) return "on-device entropy decoding: no scans, or more than the device path plans for";
+  if (!h.every_component_seen()) return "on-device entropy decoding: a component appears in no scan (the host decoder supplies its stand-in)";
+  for (int c = 0; c < f.components; c++)
+    if (f.hsamp[c] > 4 || f.vsamp[c] > 4) return "on-device entropy decoding: MCUs of more than 4 x 4 blocks of a component are decoded on the host";
+  for (size_t si = 0; si < h.scans.size(); si++) {
+    const Scan &s = h.scans[si];
+    if (s.residual) return "on-device entropy decoding: the residual scan types of part 8 are decoded on the host";
+    if (s.ncomp < 1 || (s.se > 0 && s.ss > 0 && s.ncomp != 1)) return "on-device entropy decoding: scan layout";
+    if (s.ah > 0 && !s.refinement) return "on-device entropy decoding: scan layout";
+    if (s.unstuffed_size >= ((size_t)1 << 28)) return "on-device entropy decoding: entropy coded segment too large for the device decoder's bit addresses";
+    const int64_t total_mcus = (int64_t)s.mcus_x * s.mcus_y;
+    if (total_mcus < 1 || total_mcus > 0x7fffffff) return "on-device entropy decoding: scan layout";
+    if (s.restart_interval > 0) {
+      const int64_t nint = (total_mcus + s.restart_interval - 1) / s.restart_interval;
+      if ((int64_t)s.interval_begin.size() < nint || (int64_t)s.interval_ubegin.size() < nint)
+        return "restart markers missing: the host decoder resynchronises like the reference (entropyparser.cpp:117-201)";
+      const std::vector<uint8_t> &rst = h.restart_codes(si);
+      if ((int64_t)rst.size() + 1 < nint) return "restart markers missing: the host decoder resynchronises like the reference (entropyparser.cpp:117-201)";
+      for (int64_t k = 0; k + 1 < nint; k++)
+        if (rst[(size_t)k] != 0xd0 + (k & 7))
+          return "restart markers out of sequence: the host decoder resynchronises like the reference (entropyparser.cpp:117-201)";
+    } else {
+      // One interval: one lane decodes the whole scan.  First passes could be cut into pieces that fall into step with the real
+      // decoder; an AC refinement scan cannot -- the bits a block takes depend on which block it is -- so scans
+      // without restart markers are left to the host's pipeline of scans unless they are small
+      if (s.interval_ubegin.empty()) return "on-device entropy decoding: scan without data";
+      if (s.unstuffed_size > ((size_t)24 << 10))
+        return "on-device entropy decoding: progressive / refinement scans without restart markers are serial by construction (refinementscan.cpp:584-700): host";
+    }
+    for (int k = 0; k < s.ncomp; k++) {
+      if (s.ss == 0 && s.ah == 0 && !s.dc[k].built) return "on-device entropy decoding: a Huffman table the scan names does not exist";
+      if (s.se > 0 && !s.ac[k].built) return "on-device entropy decoding: a Huffman table the scan names does not exist";
+    }
+  }
+  return nullptr;
+}
+
+// All scans of the given frames (one file: a progressive picture, or the two frames of a JPEG XT file): upload of the entropy
+// coded data without its stuffing, planes cleared, the scans launched level by level (scans that share a component one after
+// the other, the rest side by side), range pass.  MIJPEG_ERR_NOT_AVAILABLE: the host decoder's.
+static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *frames, int nframes, int min_intervals)
+{
+  struct Item { int frame; size_t scan; int level; int64_t nint; size_t stream_off; size_t table_off; int ntab; int dc_tab[4], ac_tab[4]; int64_t first; };
+  std::vector<Item> items;
+  auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  size_t stream_bytes = 0, table_bytes = 0;
+  int64_t total_intervals = 0;
+  int max_tables = 1;
+  std::vector<int> frame_levels((size_t)nframes, 0);
+  for (int fi = 0; fi < nframes; fi++) {
+    const HostDecoder &h = *frames[fi].h;
+    std::vector<int> level(h.scans.size(), 0);
+    for (size_t j = 0; j < h.scans.size(); j++) {
+      const Scan &b = h.scans[j];
+      // (a scan of the AC kind writes whole blocks back: two scans that share a component never run side by side)
+      for (size_t i = 0; i < j; i++) {
+        const Scan &a = h.scans[i];
+        bool common = false;
+        for (int ka = 0; ka < a.ncomp; ka++)
+          for (int kb = 0; kb < b.ncomp; kb++) common |= a.sc[ka].comp == b.sc[kb].comp;
+        if (common) level[j] = std::max(level[j], level[i] + 1);
+      }
+      Item it;
+      memset(&it, 0, sizeof(it));
+      it.frame = fi;
+      it.scan = j;
+      it.level = level[j];
+      const int64_t total_mcus = (int64_t)b.mcus_x * b.mcus_y;
+      it.nint = b.restart_interval > 0 ? (total_mcus + b.restart_interval - 1) / b.restart_interval : 1;
+      it.stream_off = stream_bytes;
+      stream_bytes += align16(b.unstuffed_size) + HUFF_STREAM_PAD;
+      it.table_off = table_bytes;
+      for (int k = 0; k < b.ncomp; k++) {
+        it.dc_tab[k] = it.ac_tab[k] = 0;
+        if (b.ss == 0 && b.ah == 0) it.dc_tab[k] = it.ntab++;
+        if (b.se > 0) it.ac_tab[k] = it.ntab++;
+      }
+      table_bytes += (size_t)it.ntab * sizeof(HuffDevTable);
+      max_tables = std::max(max_tables, it.ntab);
+      it.first = total_intervals;
+      total_intervals += it.nint;
+      frame_levels[(size_t)fi] = std::max(frame_levels[(size_t)fi], level[j] + 1);
+      items.push_back(it);
+    }
+  }
+  if (stream_bytes > 0xfffffff0ull || total_intervals > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "file too large for one device decode");
+  // the largest launch decides whether the device is worth the trip ("auto") and how many lanes of a wave decode
+  int64_t widest = 0;
+  for (int fi = 0; fi < nframes; fi++)
+    for (int lv = 0; lv < frame_levels[(size_t)fi]; lv++) {
+      int64_t n = 0;
+      for (const Item &it : items)
+        if (it.frame == fi && it.level == lv) n += it.nint;
+      widest = std::max(widest, n);
+    }
+  if (min_intervals <= 0) min_intervals = 2048;
+  if (widest < min_intervals) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too few restart intervals to occupy the device");
+  int lanes = 64;
+  while (lanes > 1 && widest / lanes < 768) lanes >>= 1;
+  if (const char *e = getenv("MIJPEG_HUFF_LANES")) { // tuning
+    const int l = atoi(e);
+    if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) lanes = l;
+  }
+  const int waves = 4, per_group = lanes * waves;
+  int64_t n_groups = 0;
+  for (const Item &it : items) n_groups += (it.nint + per_group - 1) / per_group;
+  // device buffer: [streams][ibegin][iend][tables][scans][groups][status: 8 dwords per frame]
+  const size_t off_ib = stream_bytes, off_ie = off_ib + (size_t)total_intervals * 4, off_tab = align16(off_ie + (size_t)total_intervals * 4);
+  const size_t off_scan = align16(off_tab + table_bytes), off_grp = align16(off_scan + items.size() * sizeof(ProgScanDev));
+  const size_t off_status = align16(off_grp + (size_t)n_groups * sizeof(ProgGroup)), status_bytes = (size_t)nframes * 32, total = off_status + status_bytes;
+  int rc = ensure_dev(d, (void **)&d->ent_dev, &d->ent_cap, total);
+  if (rc) return rc;
+  const size_t host_part = off_status - stream_bytes;
+  if (d->ent_host_cap < host_part + status_bytes) {
+    if (d->ent_host) (void)hipHostFree(d->ent_host);
+    d->ent_host = nullptr;
+    d->ent_host_cap = 0;
+    HIP_TRY(d, hipHostMalloc((void **)&d->ent_host, host_part + status_bytes, hipHostMallocDefault));
+    d->ent_host_cap = host_part + status_bytes;
+  }
+  rc = ensure_stage(d, stream_bytes);
+  if (rc) return rc;
+  uint8_t *hp = d->ent_host - stream_bytes; // hp + device offset = staging address
+  uint32_t *ib = (uint32_t *)(hp + off_ib), *ie = (uint32_t *)(hp + off_ie);
+  ProgScanDev *sd = (ProgScanDev *)(hp + off_scan);
+  ProgGroup *groups = (ProgGroup *)(hp + off_grp);
+  // groups in launch order: frame, level, scan
+  std::vector<std::pair<int64_t, int64_t>> launches; // [first group, groups) of every (frame, level)
+  std::vector<int> launch_frame;
+  int64_t g = 0;
+  for (int fi = 0; fi < nframes; fi++)
+    for (int lv = 0; lv < frame_levels[(size_t)fi]; lv++) {
+      const int64_t g0 = g;
+      for (size_t ii = 0; ii < items.size(); ii++) {
+        const Item &it = items[ii];
+        if (it.frame != fi || it.level != lv) continue;
+        for (int64_t k = 0; k < it.nint; k += per_group) {
+          groups[g].scan = (uint32_t)ii;
+          groups[g].first_interval = (uint32_t)k;
+          g++;
+        }
+      }
+      if (g > g0) { launches.push_back(std::make_pair(g0, g - g0)); launch_frame.push_back(fi); }
+    }
+  for (size_t ii = 0; ii < items.size(); ii++) {
+    const Item &it = items[ii];
+    const HostDecoder &h = *frames[it.frame].h;
+    const mijpeg_info &f = h.info;
+    const Scan &s = h.scans[it.scan];
+    ProgScanDev &o = sd[ii];
+    memset(&o, 0, sizeof(o));
+    o.stream_off = (uint32_t)it.stream_off;
+    o.first_interval = (uint32_t)it.first;
+    o.n_intervals = (int32_t)it.nint;
+    o.total_mcus = s.mcus_x * s.mcus_y;
+    o.restart_interval = s.restart_interval > 0 ? s.restart_interval : o.total_mcus;
+    o.mcus_x = s.mcus_x;
+    o.ncomp = s.ncomp;
+    o.ntables = it.ntab;
+    o.table_off = (uint32_t)it.table_off;
+    o.ss = s.ss; o.se = s.se; o.ah = s.ah; o.al = s.al;
+    o.runs_legal = s.progressive_run ? 1 : 0;
+    HuffDevTable *tabs = (HuffDevTable *)(hp + off_tab + it.table_off);
+    for (int k = 0; k < s.ncomp; k++) {
+      const int c = s.sc[k].comp;
+      o.comp[k] = c;
+      o.hs[k] = s.ncomp > 1 ? f.hsamp[c] : 1;
+      o.vs[k] = s.ncomp > 1 ? f.vsamp[c] : 1;
+      o.bw[k] = f.blocks_w[c];
+      o.coef_off[k] = f.coef_offset[c] / (f.coef_wide ? 2 : 1);
+      o.dc_tab[k] = it.dc_tab[k];
+      o.ac_tab[k] = it.ac_tab[k];
+      if (s.ss == 0 && s.ah == 0) build_dev_table(tabs[it.dc_tab[k]], s.dc[k], 0);
+      if (s.se > 0) build_dev_table(tabs[it.ac_tab[k]], s.ac[k], 2);
+    }
+    for (int64_t k = 0; k < it.nint; k++) {
+      ib[it.first + k] = s.interval_ubegin[(size_t)k];
+      ie[it.first + k] = s.interval_uend[(size_t)k];
+    }
+  }
+  // the entropy coded data of every scan without its stuffing, gathered by the pool
+  {
+    struct Job { size_t item; HostDecoder::UnstuffPiece piece; };
+    std::vector<Job> jobs;
+    std::vector<HostDecoder::UnstuffPiece> ps;
+    for (size_t ii = 0; ii < items.size(); ii++) {
+      ps.clear();
+      frames[items[ii].frame].h->unstuff_pieces(items[ii].scan, (size_t)256 << 10, ps);
+      for (const auto &pc : ps) jobs.push_back(Job{ii, pc});
+    }
+    const int workers = std::max(1, std::min<int>((int)jobs.size(), std::min(default_threads(), 32)));
+    parallel_for(workers, [&](int w) {
+      for (size_t k = (size_t)w; k < jobs.size(); k += (size_t)workers) {
+        const Item &it = items[jobs[k].item];
+        frames[it.frame].h->unstuff_piece(it.scan, jobs[k].piece, d->stage_host + it.stream_off);
+      }
+    });
+  }
+  HIP_TRY(d, hipMemcpyAsync(d->ent_dev, d->stage_host, stream_bytes, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
+  // coefficients accumulate over the scans: the planes start out as zeros (coding/blockrow.cpp:77-87)
+  for (int fi = 0; fi < nframes; fi++) {
+    const mijpeg_info &f = frames[fi].h->info;
+    int64_t count = 0;
+    for (int c = 0; c < f.components; c++) count += (int64_t)f.blocks_w[c] * f.blocks_h[c] * 64;
+    HIP_TRY(d, hipMemsetAsync(d->coef_dev + frames[fi].base16, 0, (size_t)count * (frames[fi].wide ? 4 : 2), d->stream));
+  }
+  ProgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.data = d->ent_dev;
+  a.ibegin = (const uint32_t *)(d->ent_dev + off_ib);
+  a.iend = (const uint32_t *)(d->ent_dev + off_ie);
+  a.scans = (const ProgScanDev *)(d->ent_dev + off_scan);
+  a.lanes = lanes;
+  a.waves_per_group = waves;
+  a.max_tables = max_tables;
+  a.tables = d->ent_dev + off_tab;
+  for (size_t li = 0; li < launches.size(); li++) {
+    const int fi = launch_frame[li];
+    a.groups = (const ProgGroup *)(d->ent_dev + off_grp) + launches[li].first;
+    a.n_groups = (int32_t)launches[li].second;
+    a.wide = frames[fi].wide ? 1 : 0;
+    a.coef = (void *)(d->coef_dev + frames[fi].base16);
+    a.status = (uint32_t *)(d->ent_dev + off_status) + 8 * fi;
+    if (launch_huffman_prog(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_prog_kernel launch");
+  }
+  for (int fi = 0; fi < nframes; fi++) {
+    const mijpeg_info &f = frames[fi].h->info;
+    CoefRangeArgs r;
+    memset(&r, 0, sizeof(r));
+    r.coef = (const void *)(d->coef_dev + frames[fi].base16);
+    r.wide = frames[fi].wide ? 1 : 0;
+    r.ncomp = f.components;
+    for (int c = 0; c < f.components; c++) {
+      r.coef_off[c] = f.coef_offset[c] / (f.coef_wide ? 2 : 1);
+      r.nblocks[c] = (int64_t)f.blocks_w[c] * f.blocks_h[c];
+      memcpy(r.q[c], f.quant[f.quant_index[c]], sizeof(r.q[c]));
+    }
+    r.status = (uint32_t *)(d->ent_dev + off_status) + 8 * fi;
+    if (launch_coef_range(r, d->stream)) return hip_fail(d, hipGetLastError(), "coef_range_kernel launch");
+  }
+  uint32_t *status_host = (uint32_t *)(d->ent_host + host_part);
+  HIP_TRY(d, hipMemcpyAsync(status_host, d->ent_dev + off_status, status_bytes, hipMemcpyDeviceToHost, d->stream));
+  if (!d->ent_free) HIP_TRY(d, hipEventCreateWithFlags(&d->ent_free, hipEventDisableTiming));
+  HIP_TRY(d, hipEventRecord(d->ent_free, d->stream));
+  d->ent_free_valid = true;
+  HIP_TRY(d, hipStreamSynchronize(d->stream));
+  std::vector<HostDecoder *> hosts((size_t)nframes);
+  for (int fi = 0; fi < nframes; fi++) hosts[(size_t)fi] = frames[fi].h;
+  return evaluate_entropy_status(d, hosts.data(), nframes, status_host);
+}
+
 int mijpeg_decode_coefficients_device(mijpeg_decoder *d, int min_intervals)
 try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
@@ -1416,10 +1697,20 @@ try {
   HostDecoder *h = &d->host, *res = d->host.residual();
   // (a stream that does not qualify: the parse is as good as the one mijpeg_decode_coefficients would make next)
   d->parse_fresh = true;
-  if (const char *why = device_entropy_obstacle(d->host, d->size, res != nullptr)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
-  if (res) {
-    if (const char *why = device_entropy_obstacle(*res, res->stream_size(), true)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
-    if (d->host.xt.residual_wide) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "32-bit residual coefficients are decoded on the host");
+  // progressive frames and frames with hidden refinement scans: every scan one restart interval per lane (huffman_prog_kernel)
+  auto many_scans = [](const HostDecoder &x) { return x.info.progressive != 0 || x.has_hidden_scans() || x.scans.size() != 1; };
+  static const bool no_multiscan = getenv("MIJPEG_NO_DEVICE_MULTISCAN") != nullptr; // A-B comparisons
+  const bool multiscan = !no_multiscan && (many_scans(d->host) || (res && many_scans(*res)));
+  if (multiscan) {
+    if (const char *why = multiscan_obstacle(d->host, res != nullptr, false)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+    if (res)
+      if (const char *why = multiscan_obstacle(*res, true, true)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+  } else {
+    if (const char *why = device_entropy_obstacle(d->host, d->size, res != nullptr)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+    if (res) {
+      if (const char *why = device_entropy_obstacle(*res, res->stream_size(), true)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
+      if (d->host.xt.residual_wide) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "32-bit residual coefficients are decoded on the host");
+    }
   }
   d->parse_fresh = false;
   rc = ensure_coef_store(d, (size_t)d->host.info.coef_count, false);
@@ -1430,7 +1721,14 @@ try {
   // JPEG XT: the planes of the residual frame follow those of the legacy frame in the same store
   int64_t own_count = 0;
   for (int c = 0; c < d->host.info.components; c++) own_count += (int64_t)d->host.info.blocks_w[c] * d->host.info.blocks_h[c] * 64;
-  if (!res) {
+  if (multiscan) {
+    MultiScanFrame fr[2] = {{h, false, 0}, {res, res && d->host.xt.residual_wide != 0, own_count}};
+    rc = device_entropy_multiscan(d, fr, res ? 2 : 1, min_intervals);
+    if (!rc && res) {
+      for (int c = 0; c < MIJPEG_MAX_COMPONENTS; c++) d->host.xt.residual.range_max[c] = res->info.range_max[c];
+      d->host.info.fast_arith = 0; // as HostDecoder::decode has it: the fast flavours are chosen per kernel for XT
+    }
+  } else if (!res) {
     rc = device_entropy_batch(d, &h, &d->data, &d->size, 1, min_intervals, d->coef_dev, own_count, false);
   } else {
     // JPEG XT: the two codestreams are independent, so the residual one is decoded at the same time by a helper object

@@ -162,6 +162,16 @@ public:
   bool has_hidden_scans() const { return hidden_ > 0 || !hidden_src_.empty(); }
   // JPEG XT: the legacy codestream came to its EOI, i.e. the reference merges the residual codestream (else nothing: see decode_t)
   bool residual_merged() const { return eoi_image_; }
+  // what decode() would still have to say about this file beside decoding it: a residual codestream whose header is refused, a
+  // quantiser table of the residual image that is looked up at the first request (the device decoders leave such files to it)
+  bool verdict_pending() const { return residual_error_.code != 0 || late_error_.code != 0 || (residual_ && residual_->late_quant_missing_ != nullptr); }
+  // a component that appears in no scan reconstructs from a stand-in block (fill_unseen_components): the host decoder's business
+  bool every_component_seen() const
+  {
+    for (int c = 0; c < info.components; c++)
+      if (!comp_seen_[c]) return false;
+    return true;
+  }
 
   mijpeg_info info{};
   // restart-interval byte ranges of scan i (valid after parse(..., false)): [interval_begin[k], interval_ends(i)[k])

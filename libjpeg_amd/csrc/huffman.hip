@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t add_sat_u32(uint32_t a, uint32_t b)
   return d;
 }
 
-template <bool AC> __device__ __forceinline__ uint32_t dev_lookup(uint32_t win, const HuffDevTable *h)
+template <int AC> __device__ __forceinline__ uint32_t dev_lookup(uint32_t win, const HuffDevTable *h)
 {
   uint32_t e = h->fast[win >> (32 - HUFF_DEV_LOOKAHEAD)];
   if (__builtin_expect((e & HUFF_DEV_SUB) != 0, 0)) { // a code of 11..16 bits (or none at all): ONE rarely taken branch per symbol
@@ -182,7 +182,7 @@ __device__ __forceinline__ int dev_block(DevBits &br, const HuffDevTable *dc, co
 {
   br.refill();
   uint32_t win = br.window();
-  uint32_t e = dev_lookup<false>(win, dc);
+  uint32_t e = dev_lookup<0>(win, dc);
   int s = (int)(e & 0xff), tot = (int)((e >> 8) & 31u);
   if (e & HUFF_DEV_INVALID) return HUFF_ERR_MALFORMED; // ":686 DC coefficient decoding out of sync"
   pred += dev_value(win, tot, s);
@@ -190,7 +190,7 @@ __device__ __forceinline__ int dev_block(DevBits &br, const HuffDevTable *dc, co
   if (pred != (int16_t)pred) return HUFF_ERR_OVERFLOW;
   br.refill();
   win = br.window();
-  e = dev_lookup<true>(win, ac);
+  e = dev_lookup<1>(win, ac);
   *reinterpret_cast<int16_t *>(slot + swz16) = (int16_t)pred;
   // range check sum |c| q: both factors fit 16 bits (24-bit multiply), the sum saturates -- the host cuts at 2^31 - 1 like its
   // own decoder does (evaluate_entropy_status), and anything beyond that has saturated or is beyond it for good
@@ -211,7 +211,7 @@ __device__ __forceinline__ int dev_block(DevBits &br, const HuffDevTable *dc, co
     br.refill();
     win = br.window();
     const uint32_t z = zqm1[kk]; // position <= 63 + 15, the table is padded; in flight together with the lookup below
-    e = dev_lookup<true>(win, ac);
+    e = dev_lookup<1>(win, ac);
     *reinterpret_cast<int16_t *>(slot + ((z & 0xffffu) ^ (uint32_t)swz16)) = (int16_t)val;
     qsum = add_sat_u32(qsum, __umul24((uint32_t)abs(val), z >> 16));
     if (last) break;
@@ -364,7 +364,7 @@ __device__ __forceinline__ int dev_walk_block(DevBits &br, const HuffDevTable *d
 {
   br.refill();
   uint32_t win = br.window();
-  uint32_t e = dev_lookup<false>(win, dc);
+  uint32_t e = dev_lookup<0>(win, dc);
   int s = (int)(e & 0xff), tot = (int)((e >> 8) & 31u);
   if (e & HUFF_DEV_INVALID) return 1;
   dcdiff = dev_value(win, tot, s);
@@ -374,7 +374,7 @@ __device__ __forceinline__ int dev_walk_block(DevBits &br, const HuffDevTable *d
   for (;;) {
     br.refill();
     win = br.window();
-    e = dev_lookup<true>(win, ac);
+    e = dev_lookup<1>(win, ac);
     const int rs = (int)(e & 0xff);
     s = rs & 15;
     tot = (int)((e >> 8) & 31u);
@@ -605,6 +605,313 @@ __global__ __launch_bounds__(WALK_TILE) void huffman_walk_prefix_kernel(const Hu
     if (live && run.v[c] != (long long)(short)run.v[c]) bad |= 2;
   *reinterpret_cast<int4 *>(a.first_pred + (size_t)(s0 + i) * 4) = fp;
   if (bad) atomicOr(&a.walk_status[img_i], bad);
+}
+
+
+// ==============================================================================================
+// Progressive frames (SOF2) and hidden refinement scans (JPEG XT) with restart markers: one lane per restart interval
+// ==============================================================================================
+// A progressive frame is a sequence of scans over the same coefficient store: DC first passes (interleaved), AC first passes
+// over a spectral band of one component with EOB runs (codestream/sequentialscan.cpp:678-773 with m_bProgressive), and
+// successive approximation refinement scans (codestream/refinementscan.cpp:584-700; T.81 G.1.2.3).  The hidden refinement
+// scans of a JPEG XT frame (marker/scan.cpp:899-980) are refinement scans below a sequential frame's visible scan, which then
+// carries a point transform.  Restart intervals are independent here as well: predictors, the bit reader AND the EOB run are
+// reset at every RSTn (sequentialscan.cpp:266-274, refinementscan.cpp:223-232).
+//
+// What is NOT parallel in this coding: an AC refinement scan without restart markers.  How many bits a block takes there
+// depends on the block's own non-zero pattern (one correction bit per coefficient the earlier scans left non-zero), so a
+// decoder that starts somewhere in the middle of the data cannot know which block it is in and does not fall into step with
+// the real one the way the decoders of first passes do: such scans stay on the host.
+//
+// Blocks of AC scans travel through a slot in LDS per lane: the wave loads its L blocks as full lines, every lane decodes
+// into / refines its slot, the wave writes them back.  DC scans (band 0..0) touch one coefficient per block and go straight
+// to memory.  Natural-order position of scan position k (padded like HuffDevAux::zq: a corrupt run may point behind 63).
+__device__ const uint8_t prog_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
+                                            6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
+                                            39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+
+template <class T> struct ProgStore {
+  uint8_t *slot;  // this lane's block in LDS, natural order, 16-byte chunks XOR-swizzled by the lane
+  uint32_t swz;
+  __device__ __forceinline__ T *at(int pos) const { return reinterpret_cast<T *>(slot + (((uint32_t)pos * (uint32_t)sizeof(T)) ^ swz)); }
+  __device__ __forceinline__ int get(int pos) const { return (int)*at(pos); }
+  __device__ __forceinline__ void put(int pos, int v) const { *at(pos) = (T)v; }
+};
+
+// First pass of a block (sequentialscan.cpp:678-773): DC difference when the band starts at 0, then run / size pairs with EOB
+// runs over [max(ss, 1), se], everything shifted up by al.  Returns 0 or HUFF_ERR_*.
+template <class T>
+__device__ __forceinline__ int prog_block_first(DevBits &br, const HuffDevTable *dc, const HuffDevTable *ac, const uint8_t *zz, const ProgStore<T> &st,
+                                                int &pred, int &skip, int ss, int se, int al, bool runs_legal)
+{
+  if (ss == 0) {
+    br.refill();
+    const uint32_t win = br.window();
+    const uint32_t e = dev_lookup<0>(win, dc);
+    if (e & HUFF_DEV_INVALID) return HUFF_ERR_MALFORMED;
+    const int s = (int)(e & 0xff), tot = (int)((e >> 8) & 31u);
+    pred += dev_value(win, tot, s);
+    br.skip(tot);
+    const int v = (int)((uint32_t)pred << al);
+    if (v != (int)(T)v) return HUFF_ERR_OVERFLOW;
+    st.put(0, v);
+  }
+  if (se) {
+    if (skip > 0) { skip--; return 0; }
+    int k = ss ? ss : 1;
+    do {
+      br.refill();
+      const uint32_t win = br.window();
+      const uint32_t e = dev_lookup<2>(win, ac);
+      if (e >= (uint32_t)HUFF_DEV_INVALID) return HUFF_ERR_MALFORMED;
+      const int rs = (int)(e & 0xff), r = rs >> 4, s = rs & 15, tot = (int)((e >> 8) & 31u);
+      br.skip(tot);
+      if (s == 0) {
+        if (r == 15) { k += 16; continue; }
+        skip = (int)((1u << r) | __builtin_amdgcn_ubfe(win, (uint32_t)(32 - tot), (uint32_t)r)) - 1;
+        // an EOB run where the reference's parser is not a progressive one (sequentialscan.cpp:84-87, 722-750): its walk decides
+        if (skip > 0 && !runs_legal) return HUFF_ERR_MALFORMED;
+        break;
+      }
+      k += r;
+      const int v = (int)((uint32_t)dev_value(win, tot, s) << al);
+      if (k >= 64) return HUFF_ERR_MALFORMED;
+      if (v != (int)(T)v) return HUFF_ERR_OVERFLOW;
+      st.put(zz[k], v);
+      k++;
+    } while (k <= se);
+  }
+  return 0;
+}
+
+// Refinement pass of a block, the statements of the host's decode_block_refine (refinementscan.cpp:584-700).
+template <class T>
+__device__ __forceinline__ int prog_block_refine(DevBits &br, const HuffDevTable *ac, const uint8_t *zz, const ProgStore<T> &st, int &skip, int ss, int se,
+                                                 int al)
+{
+  if (ss == 0) {
+    br.refill();
+    const int bit = (int)(br.window() >> 31);
+    br.skip(1);
+    st.put(0, st.get(0) | (bit << al));
+  }
+  if (se) {
+    int k = ss, run = 0, s = 0;
+    bool at_start = false, overflow = false;
+    if (skip > 0) { run = se - ss + 1; skip--; }
+    else { k--; at_start = true; }
+    do {
+      if (!at_start) {
+        const int pos = zz[k];
+        const int data = st.get(pos);
+        if (data) { // a correction bit: one step away from zero, or nothing
+          br.refill();
+          const int bit = (int)(br.window() >> 31);
+          br.skip(1);
+          const int nv = data + ((int)((uint32_t)((data >> 31) | 1) << al) & -bit);
+          overflow |= nv != (int)(T)nv;
+          st.put(pos, nv);
+          continue;
+        }
+        if (run) { run--; continue; }
+        st.put(pos, (int)((uint32_t)s << al));
+        if (k == se) break;
+      }
+      at_start = false;
+      br.refill();
+      const uint32_t win = br.window();
+      const uint32_t e = dev_lookup<2>(win, ac);
+      if (e >= (uint32_t)HUFF_DEV_INVALID) return HUFF_ERR_MALFORMED;
+      const int rs = (int)(e & 0xff), r = rs >> 4, tot = (int)((e >> 8) & 31u);
+      s = rs & 15;
+      br.skip(tot);
+      if (s == 0) {
+        if (r == 15) run = 15;
+        else {
+          skip = (int)((1u << r) | __builtin_amdgcn_ubfe(win, (uint32_t)(32 - tot), (uint32_t)r)) - 1;
+          run = se - k + 1;
+        }
+      } else {
+        if (s != 1) return HUFF_ERR_MALFORMED; // (the reference warns and decodes on: its walk on the host)
+        if (!__builtin_amdgcn_ubfe(win, (uint32_t)(32 - tot), 1u)) s = -1; // the sign bit behind the code
+        run = r;
+      }
+    } while (++k <= se);
+    if (overflow) return HUFF_ERR_OVERFLOW;
+  }
+  return 0;
+}
+
+// LDS: [max_tables tables][per wave: L block slots | L rings | L block numbers]
+template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(const ProgArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  constexpr int SLOT = 64 * (int)sizeof(T), CH = SLOT / 16;
+  constexpr int LANE_BYTES = SLOT + RING_PITCH + 16;
+  const int table_bytes = a.max_tables * (int)sizeof(HuffDevTable);
+  const HuffDevTable *tabs = reinterpret_cast<const HuffDevTable *>(lds_raw);
+  const int L = a.lanes, nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const ProgGroup grp = a.groups[blockIdx.x];
+  const ProgScanDev sc = a.scans[grp.scan]; // uniform
+  uint8_t *stage = lds_raw + table_bytes + wv * (L * LANE_BYTES);
+  uint8_t *rings = stage + L * SLOT;
+  uint32_t *blkno = reinterpret_cast<uint32_t *>(stage + L * (SLOT + RING_PITCH));
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables + sc.table_off);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
+    const int words = sc.ntables * (int)sizeof(HuffDevTable) / 4, first = table_bytes / 4, rest = nwaves * L * LANE_BYTES / 4;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < rest; i += blockDim.x) dst[first + i] = 0;
+  }
+  __syncthreads();
+  const int interval = (int)grp.first_interval + wv * L + lane;
+  const bool decoding = lane < L && interval < sc.n_intervals;
+  const int ln = lane & (L - 1);
+  const uint8_t *stream = a.data + sc.stream_off;
+  T *coef = reinterpret_cast<T *>(a.coef);
+  DevBits br;
+  br.base = stream;
+  br.ring = rings + ln * RING_PITCH;
+  br.idle();
+  if (decoding) {
+    const uint32_t idx = sc.first_interval + (uint32_t)interval;
+    br.open(stream, rings + ln * RING_PITCH, a.ibegin[idx], a.iend[idx]);
+  }
+  uint32_t pend_at = br.fill;
+  u32x4 pend0 = br.fetch(pend_at), pend1 = br.fetch(pend_at + 16);
+  int pred[4] = {0, 0, 0, 0}, skip[4] = {0, 0, 0, 0};
+  int err = 0;
+  const int m0 = interval * sc.restart_interval;
+  ProgStore<T> st;
+  st.slot = stage + ln * SLOT;
+  st.swz = (uint32_t)(lane & (CH - 1)) << 4;
+  const bool dc_only = sc.se == 0;
+  for (int mi = 0; mi < sc.restart_interval; mi++) {
+    const int m = m0 + mi;
+    const bool live = decoding && m < sc.total_mcus;
+    if (__ballot(live && !err) == 0) break;
+    const int my = m / sc.mcus_x, mx = m - my * sc.mcus_x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (k >= sc.ncomp) break;
+      const HuffDevTable *dc = tabs + sc.dc_tab[k], *ac = tabs + sc.ac_tab[k];
+      const int h = sc.hs[k], v = sc.vs[k];
+      const uint32_t comp_base = (uint32_t)(sc.coef_off[k] >> 6);
+      for (int by = 0; by < v; by++)
+        for (int bx = 0; bx < h; bx++) {
+          const uint32_t bidx = comp_base + (uint32_t)(my * v + by) * (uint32_t)sc.bw[k] + (uint32_t)(mx * h + bx);
+          if (dc_only) {
+            // one coefficient per block: straight to memory (DC first pass: prediction, point transform; DC refinement: one raw bit)
+            if (live && !err) {
+              T *p = coef + ((size_t)bidx << 6);
+              br.refill();
+              const uint32_t win = br.window();
+              if (sc.ah == 0) {
+                const uint32_t e = dev_lookup<0>(win, dc);
+                if (e & HUFF_DEV_INVALID) err = HUFF_ERR_MALFORMED;
+                else {
+                  const int s = (int)(e & 0xff), tot = (int)((e >> 8) & 31u);
+                  pred[k] += dev_value(win, tot, s);
+                  br.skip(tot);
+                  const int val = (int)((uint32_t)pred[k] << sc.al);
+                  if (val != (int)(T)val) err = HUFF_ERR_OVERFLOW;
+                  else *p = (T)val;
+                }
+              } else {
+                br.skip(1);
+                *p = (T)((int)*p | ((int)(win >> 31) << sc.al));
+              }
+            }
+            if (decoding && pend_at == br.fill && br.room()) br.commit(pend0);
+            if (decoding && pend_at + 16 == br.fill && br.room()) br.commit(pend1);
+            pend_at = br.fill;
+            pend0 = br.fetch(pend_at);
+            pend1 = br.fetch(pend_at + 16);
+            continue;
+          }
+          const bool work = live && !err;
+          if (lane < L) blkno[lane] = work ? bidx + 1u : 0u;
+          wave_lds_sync();
+          for (int c = lane; c < L * CH; c += 64) { // the wave fetches its L blocks as whole lines
+            const int sl = c / CH, ch = c % CH;
+            const uint32_t b = blkno[sl];
+            if (b) *reinterpret_cast<u32x4 *>(stage + sl * SLOT + ((ch ^ (sl & (CH - 1))) << 4)) =
+                     *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint8_t *>(coef + ((size_t)(b - 1) << 6)) + ch * 16);
+          }
+          wave_lds_sync();
+          if (work)
+            err = sc.ah == 0 ? prog_block_first<T>(br, dc, ac, prog_zigzag, st, pred[k], skip[k], sc.ss, sc.se, sc.al, sc.runs_legal != 0)
+                             : prog_block_refine<T>(br, ac, prog_zigzag, st, skip[k], sc.ss, sc.se, sc.al);
+          if (decoding && pend_at == br.fill && br.room()) br.commit(pend0);
+          if (decoding && pend_at + 16 == br.fill && br.room()) br.commit(pend1);
+          wave_lds_sync();
+          for (int c = lane; c < L * CH; c += 64) { // ... and writes them back (a block whose lane failed keeps what it held)
+            const int sl = c / CH, ch = c % CH;
+            const uint32_t b = blkno[sl];
+            if (b) *reinterpret_cast<u32x4 *>(reinterpret_cast<uint8_t *>(coef + ((size_t)(b - 1) << 6)) + ch * 16) =
+                     *reinterpret_cast<const u32x4 *>(stage + sl * SLOT + ((ch ^ (sl & (CH - 1))) << 4));
+          }
+          wave_lds_sync();
+          pend_at = br.fill;
+          pend0 = br.fetch(pend_at);
+          pend1 = br.fetch(pend_at + 16);
+        }
+    }
+  }
+  // (as in huffman_scan_kernel: an interval that only decoded by reading the zero bits behind its data is a damaged one)
+  if (decoding && !err && br.bp > br.endbit) err = HUFF_ERR_DESYNC;
+  if (err) atomicMax(&a.status[0], (uint32_t)err);
+}
+
+int launch_huffman_prog(const ProgArgs &a, hipStream_t stream)
+{
+  if (a.n_groups <= 0) return 0;
+  const size_t slot = a.wide ? 256 : 128;
+  const size_t lds = (size_t)a.max_tables * sizeof(HuffDevTable) + (size_t)a.waves_per_group * a.lanes * (slot + RING_PITCH + 16);
+  if (a.wide) hipLaunchKernelGGL(huffman_prog_kernel<int32_t>, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
+  else hipLaunchKernelGGL(huffman_prog_kernel<int16_t>, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+// max over the blocks of a component of sum |c| q (saturating at 2^31 - 1) of finished planes: what selects the arithmetic of
+// the reconstruction (the host decoder's range_pass).  grid (blocks / 256, components)
+template <class T> __global__ __launch_bounds__(256) void coef_range_kernel(const CoefRangeArgs a)
+{
+  const int c = blockIdx.y;
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t m = 0;
+  if (b < a.nblocks[c]) {
+    const T *p = reinterpret_cast<const T *>(a.coef) + a.coef_off[c] + b * 64;
+    uint64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 64; k += 16 / (int)sizeof(T)) {
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(p + k);
+#pragma unroll
+      for (int j = 0; j < 16 / (int)sizeof(T); j++) {
+        int x;
+        if (sizeof(T) == 2) x = (int)(int16_t)(v[j >> 1] >> ((j & 1) * 16));
+        else x = (int)v[j];
+        const int64_t ax = x < 0 ? -(int64_t)x : (int64_t)x;
+        sum += (uint64_t)ax * a.q[c][k + j];
+      }
+    }
+    m = (uint32_t)(sum < 0x7fffffffull ? sum : 0x7fffffffull);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(&a.status[1 + c], m);
+}
+
+int launch_coef_range(const CoefRangeArgs &a, hipStream_t stream)
+{
+  int64_t most = 0;
+  for (int c = 0; c < a.ncomp; c++) most = a.nblocks[c] > most ? a.nblocks[c] : most;
+  if (most <= 0 || a.ncomp <= 0) return 0;
+  const dim3 grid((unsigned)((most + 255) / 256), (unsigned)a.ncomp);
+  if (a.wide) hipLaunchKernelGGL(coef_range_kernel<int32_t>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(coef_range_kernel<int16_t>, grid, dim3(256), 0, stream, a);
+  return (int)hipGetLastError();
 }
 
 int launch_huffman_walk_scan(const HuffWalkArgs &a, int n_images, hipStream_t stream)

@@ -26,8 +26,17 @@ constexpr int HUFF_DEV_NO_SUB = 15;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline uint32_t huff_dev_entry(int length, uint32_t symbol, bool ac)
+inline uint32_t huff_dev_entry(int length, uint32_t symbol, int ac)
 {
+  // ac: 0 = DC table, 1 = AC table of a sequential scan, 2 = AC table of a progressive / refinement scan (huffman_prog_kernel):
+  // every run / size pair is legal there and the bits behind a code are the value bits of a coefficient (s of them), the low
+  // bits of an EOB run (r of them for EOBr, r < 15; sequentialscan.cpp:722-750) or the one sign bit of a refinement scan's
+  // new coefficient (s = 1; refinementscan.cpp:640-660): 16 + 15 = 31 bits at most, like everywhere
+  if (ac == 2) {
+    const uint32_t r = (symbol >> 4) & 15u, sz = symbol & 15u;
+    const uint32_t extra = sz ? sz : (r < 15u ? r : 0u);
+    return ((uint32_t)(length + (int)extra) << 8) | (symbol & 0xffu);
+  }
   const uint32_t s = ac ? (symbol & 15u) : symbol;
   if (s > 15u) return (uint32_t)HUFF_DEV_INVALID;
   uint32_t e = ((uint32_t)(length + (int)s) << 8) | symbol;
@@ -130,6 +139,51 @@ struct HuffWalkArgs {
   uint32_t sub_bytes;
 };
 
+// ---- progressive frames and hidden refinement scans (huffman_prog_kernel) -------------------------------------------------
+// One scan of a launch (device memory).  A launch holds scans that do not depend on one another (different components, or
+// disjoint spectral bands of one); scans that refine what earlier ones wrote go into later launches on the same stream.
+struct ProgScanDev {
+  uint32_t stream_off;      // the scan's entropy coded data (no stuffing, no markers) in `data`, 16-byte aligned
+  uint32_t first_interval;  // its first entry in ibegin / iend (offsets relative to stream_off)
+  int32_t n_intervals, restart_interval, total_mcus, mcus_x; // (a scan without restart markers: one interval of total_mcus MCUs)
+  int32_t ncomp, ntables;
+  int32_t comp[4], hs[4], vs[4], bw[4];
+  int64_t coef_off[4];      // plane offsets inside the frame's coefficient store, in coefficients
+  int32_t dc_tab[4], ac_tab[4];
+  uint32_t table_off;       // byte offset (from `tables`) of its ntables HuffDevTable
+  int32_t ss, se, ah, al;   // spectral selection, successive approximation (al includes the hidden bits below a visible scan)
+  int32_t runs_legal;       // EOB runs are legal (the reference's parser is a progressive one, sequentialscan.cpp:84-87)
+  int32_t reserved;
+};
+struct ProgGroup {
+  uint32_t scan, first_interval;
+};
+struct ProgArgs {
+  const uint8_t *data;
+  const uint32_t *ibegin, *iend;
+  const ProgScanDev *scans;
+  const ProgGroup *groups;  // one per workgroup (already offset to this launch's)
+  int32_t n_groups;
+  int32_t lanes, waves_per_group;
+  int32_t max_tables;       // LDS is sized for this many tables
+  int32_t wide;             // 1: int32 coefficients (JPEG XT residual frames with hidden bits)
+  int32_t reserved;
+  const uint8_t *tables;
+  void *coef;               // the frame's coefficient store
+  uint32_t *status;         // [0] error (0 = ok)
+};
+// max over a component's blocks of sum |c| q, saturating at 2^31 - 1, of finished planes -> status[1 + c] (atomicMax)
+struct CoefRangeArgs {
+  const void *coef;
+  int32_t wide, ncomp;
+  int64_t coef_off[4];
+  int64_t nblocks[4];
+  uint16_t q[4][64];
+  uint32_t *status;
+};
+
+int launch_huffman_prog(const ProgArgs &a, hipStream_t stream);
+int launch_coef_range(const CoefRangeArgs &a, hipStream_t stream);
 int launch_huffman_scan(const HuffScanArgs &a, hipStream_t stream);
 int launch_huffman_walk(const HuffWalkArgs &a, bool emit, hipStream_t stream);
 int launch_huffman_walk_scan(const HuffWalkArgs &a, int n_images, hipStream_t stream);
