@@ -124,6 +124,7 @@ struct mijpeg_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t chain_ev = nullptr; // mijpeg_stream_wait
+  hipEvent_t ms_ready = nullptr, ms_done = nullptr; // device_entropy_multiscan: the second frame's stream
   int err_code = 0;
   std::string err_msg;
   double timing[4] = {0, 0, 0, 0};
@@ -377,6 +378,8 @@ try {
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     if (d->chain_ev) (void)hipEventDestroy(d->chain_ev);
+    if (d->ms_ready) (void)hipEventDestroy(d->ms_ready);
+    if (d->ms_done) (void)hipEventDestroy(d->ms_done);
     if (d->stream) (void)hipStreamDestroy(d->stream);
   } else {
     free(d->coef_host);
@@ -1470,6 +1473,11 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
 {
   struct Item { int frame; size_t scan; int level; int64_t nint; size_t stream_off; size_t table_off; int ntab; int dc_tab[4], ac_tab[4]; int64_t first; };
   std::vector<Item> items;
+  const auto tm0 = std::chrono::steady_clock::now();
+  static const bool trace_phases = getenv("MIJPEG_TRACE_SUBMIT") != nullptr; // diagnostics: host time of the steps below, on stderr
+  auto mark = [&](const char *what) {
+    if (trace_phases) fprintf(stderr, "[mijpeg multiscan] %-28s %8.3f ms\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count() * 1e3);
+  };
   auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
   size_t stream_bytes = 0, table_bytes = 0;
   int64_t total_intervals = 0;
@@ -1606,6 +1614,7 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
       ie[it.first + k] = s.interval_uend[(size_t)k];
     }
   }
+  mark("tables + intervals");
   // the entropy coded data of every scan without its stuffing, gathered by the pool
   {
     struct Job { size_t item; HostDecoder::UnstuffPiece piece; };
@@ -1624,6 +1633,7 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
       }
     });
   }
+  mark("streams gathered");
   HIP_TRY(d, hipMemcpyAsync(d->ent_dev, d->stage_host, stream_bytes, hipMemcpyHostToDevice, d->stream));
   HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part, hipMemcpyHostToDevice, d->stream));
   HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
@@ -1644,6 +1654,17 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
   a.waves_per_group = waves;
   a.max_tables = max_tables;
   a.tables = d->ent_dev + off_tab;
+  // the two frames of a JPEG XT file share nothing: the second one's launches go to a stream of their own, behind the uploads
+  // and the clearing of the planes, and the object's stream waits for them before the range pass
+  hipStream_t second = d->stream;
+  if (nframes > 1) {
+    if (!d->copy_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    if (!d->ms_ready) HIP_TRY(d, hipEventCreateWithFlags(&d->ms_ready, hipEventDisableTiming));
+    if (!d->ms_done) HIP_TRY(d, hipEventCreateWithFlags(&d->ms_done, hipEventDisableTiming));
+    second = d->copy_stream;
+    HIP_TRY(d, hipEventRecord(d->ms_ready, d->stream));
+    HIP_TRY(d, hipStreamWaitEvent(second, d->ms_ready, 0));
+  }
   for (size_t li = 0; li < launches.size(); li++) {
     const int fi = launch_frame[li];
     a.groups = (const ProgGroup *)(d->ent_dev + off_grp) + launches[li].first;
@@ -1651,7 +1672,11 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
     a.wide = frames[fi].wide ? 1 : 0;
     a.coef = (void *)(d->coef_dev + frames[fi].base16);
     a.status = (uint32_t *)(d->ent_dev + off_status) + 8 * fi;
-    if (launch_huffman_prog(a, d->stream)) return hip_fail(d, hipGetLastError(), "huffman_prog_kernel launch");
+    if (launch_huffman_prog(a, fi == 0 ? d->stream : second)) return hip_fail(d, hipGetLastError(), "huffman_prog_kernel launch");
+  }
+  if (second != d->stream) {
+    HIP_TRY(d, hipEventRecord(d->ms_done, second));
+    HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ms_done, 0));
   }
   for (int fi = 0; fi < nframes; fi++) {
     const mijpeg_info &f = frames[fi].h->info;
@@ -1673,7 +1698,9 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
   if (!d->ent_free) HIP_TRY(d, hipEventCreateWithFlags(&d->ent_free, hipEventDisableTiming));
   HIP_TRY(d, hipEventRecord(d->ent_free, d->stream));
   d->ent_free_valid = true;
+  mark("launches enqueued");
   HIP_TRY(d, hipStreamSynchronize(d->stream));
+  mark("device done");
   std::vector<HostDecoder *> hosts((size_t)nframes);
   for (int fi = 0; fi < nframes; fi++) hosts[(size_t)fi] = frames[fi].h;
   return evaluate_entropy_status(d, hosts.data(), nframes, status_host);
@@ -1721,6 +1748,10 @@ try {
   // JPEG XT: the planes of the residual frame follow those of the legacy frame in the same store
   int64_t own_count = 0;
   for (int c = 0; c < d->host.info.components; c++) own_count += (int64_t)d->host.info.blocks_w[c] * d->host.info.blocks_h[c] * 64;
+  static const bool trace_read = getenv("MIJPEG_TRACE_SUBMIT") != nullptr; // diagnostics
+  if (trace_read)
+    fprintf(stderr, "[mijpeg device read] parse %.3f ms, checks + coefficient store %.3f ms\n", std::chrono::duration<double>(t_parsed - t0).count() * 1e3,
+            std::chrono::duration<double>(clk::now() - t_parsed).count() * 1e3);
   if (multiscan) {
     MultiScanFrame fr[2] = {{h, false, 0}, {res, res && d->host.xt.residual_wide != 0, own_count}};
     rc = device_entropy_multiscan(d, fr, res ? 2 : 1, min_intervals);
@@ -1764,6 +1795,7 @@ try {
   d->timing[0] = std::chrono::duration<double>(clk::now() - t0).count();
   d->timing[1] = std::chrono::duration<double>(t_parsed - t0).count(); // header parse + restart marker search
   d->timing[2] = d->timing[3] = 0;
+  if (trace_read) fprintf(stderr, "[mijpeg device read] whole call %.3f ms\n", d->timing[0] * 1e3);
   if (rc) return rc;
   d->decoded = true;
   d->uploaded = true;

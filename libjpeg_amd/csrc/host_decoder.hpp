@@ -298,6 +298,10 @@ private:
   int fail(int code, const char *msg);
   int frame_geometry();
   void find_intervals(Scan &s);
+  void find_intervals_in(Scan &s, const uint8_t *data, size_t size, std::vector<size_t> &interval_end, std::vector<uint8_t> &rst_code, bool may_sink);
+  // the marker searches of a frame's hidden refinement scans, put off until all their boxes have been walked (add_hidden_scans)
+  struct DeferredSearch { size_t scan; const uint8_t *data; size_t size; int type; bool hidden; };
+  std::vector<DeferredSearch> *deferred_hidden_ = nullptr;
 };
 
 int default_threads();

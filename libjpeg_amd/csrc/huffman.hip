@@ -626,7 +626,7 @@ __global__ __launch_bounds__(WALK_TILE) void huffman_walk_prefix_kernel(const Hu
 // Blocks of AC scans travel through a slot in LDS per lane: the wave loads its L blocks as full lines, every lane decodes
 // into / refines its slot, the wave writes them back.  DC scans (band 0..0) touch one coefficient per block and go straight
 // to memory.  Natural-order position of scan position k (padded like HuffDevAux::zq: a corrupt run may point behind 63).
-__device__ const uint8_t prog_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
+__device__ const uint8_t __attribute__((aligned(16))) prog_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
                                             6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
                                             39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
 
@@ -700,13 +700,23 @@ __device__ __forceinline__ int prog_block_refine(DevBits &br, const HuffDevTable
     bool at_start = false, overflow = false;
     if (skip > 0) { run = se - ss + 1; skip--; }
     else { k--; at_start = true; }
+    // correction bits come one at a time, up to 63 per block: they are taken from a copy of the reader's window (32 bits that
+    // are valid from the reader's position on), which is fetched again when it runs dry or a symbol is due
+    uint32_t cw = 0;
+    int chave = 0;
     do {
       if (!at_start) {
         const int pos = zz[k];
         const int data = st.get(pos);
         if (data) { // a correction bit: one step away from zero, or nothing
-          br.refill();
-          const int bit = (int)(br.window() >> 31);
+          if (chave == 0) {
+            br.refill();
+            cw = br.window();
+            chave = 32;
+          }
+          const int bit = (int)(cw >> 31);
+          cw <<= 1;
+          chave--;
           br.skip(1);
           const int nv = data + ((int)((uint32_t)((data >> 31) | 1) << al) & -bit);
           overflow |= nv != (int)(T)nv;
@@ -719,6 +729,7 @@ __device__ __forceinline__ int prog_block_refine(DevBits &br, const HuffDevTable
       }
       at_start = false;
       br.refill();
+      chave = 0;
       const uint32_t win = br.window();
       const uint32_t e = dev_lookup<2>(win, ac);
       if (e >= (uint32_t)HUFF_DEV_INVALID) return HUFF_ERR_MALFORMED;
@@ -742,13 +753,15 @@ __device__ __forceinline__ int prog_block_refine(DevBits &br, const HuffDevTable
   return 0;
 }
 
-// LDS: [max_tables tables][per wave: L block slots | L rings | L block numbers]
+// LDS: [max_tables tables | zigzag order][per wave: L block slots | L rings | L block numbers]
+constexpr int PROG_ZZ_BYTES = 80;
 template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(const ProgArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   constexpr int SLOT = 64 * (int)sizeof(T), CH = SLOT / 16;
   constexpr int LANE_BYTES = SLOT + RING_PITCH + 16;
-  const int table_bytes = a.max_tables * (int)sizeof(HuffDevTable);
+  const int table_bytes = a.max_tables * (int)sizeof(HuffDevTable) + PROG_ZZ_BYTES;
+  const uint8_t *zz = lds_raw + table_bytes - PROG_ZZ_BYTES; // (a look-up per coefficient, at a position that differs from lane to lane: LDS, not memory)
   const HuffDevTable *tabs = reinterpret_cast<const HuffDevTable *>(lds_raw);
   const int L = a.lanes, nwaves = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -763,6 +776,7 @@ template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(co
     const int words = sc.ntables * (int)sizeof(HuffDevTable) / 4, first = table_bytes / 4, rest = nwaves * L * LANE_BYTES / 4;
     for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     for (int i = threadIdx.x; i < rest; i += blockDim.x) dst[first + i] = 0;
+    if (threadIdx.x < PROG_ZZ_BYTES / 4) dst[first - PROG_ZZ_BYTES / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(prog_zigzag)[threadIdx.x];
   }
   __syncthreads();
   const int interval = (int)grp.first_interval + wv * L + lane;
@@ -841,8 +855,8 @@ template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(co
           }
           wave_lds_sync();
           if (work)
-            err = sc.ah == 0 ? prog_block_first<T>(br, dc, ac, prog_zigzag, st, pred[k], skip[k], sc.ss, sc.se, sc.al, sc.runs_legal != 0)
-                             : prog_block_refine<T>(br, ac, prog_zigzag, st, skip[k], sc.ss, sc.se, sc.al);
+            err = sc.ah == 0 ? prog_block_first<T>(br, dc, ac, zz, st, pred[k], skip[k], sc.ss, sc.se, sc.al, sc.runs_legal != 0)
+                             : prog_block_refine<T>(br, ac, zz, st, skip[k], sc.ss, sc.se, sc.al);
           if (decoding && pend_at == br.fill && br.room()) br.commit(pend0);
           if (decoding && pend_at + 16 == br.fill && br.room()) br.commit(pend1);
           wave_lds_sync();
@@ -868,7 +882,7 @@ int launch_huffman_prog(const ProgArgs &a, hipStream_t stream)
 {
   if (a.n_groups <= 0) return 0;
   const size_t slot = a.wide ? 256 : 128;
-  const size_t lds = (size_t)a.max_tables * sizeof(HuffDevTable) + (size_t)a.waves_per_group * a.lanes * (slot + RING_PITCH + 16);
+  const size_t lds = (size_t)a.max_tables * sizeof(HuffDevTable) + PROG_ZZ_BYTES + (size_t)a.waves_per_group * a.lanes * (slot + RING_PITCH + 16);
   if (a.wide) hipLaunchKernelGGL(huffman_prog_kernel<int32_t>, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
   else hipLaunchKernelGGL(huffman_prog_kernel<int16_t>, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
   return (int)hipGetLastError();
