@@ -2644,6 +2644,8 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       xa.ext.out_max = x.out_max;
       xa.ext.out_shift = x.out_shift;
       xa.ext.rprecision = r.precision + x.residual_hidden_bits;
+      // (the two-wave flavour of the hidden-bit kernel keeps the luma block as int16: sample * 16 + 2056 with |sample * 16| <= 4 sum |c| q)
+      xa.luma_fits16 = f.range_max[0] < 7600 ? 1 : 0;
       rc = launch_fusedxt420(xa, s);
     } else
       rc = f420_12 ? launch_fused420_12(a, s) : f444_12 ? launch_fused444_12(a, s) : f422_12 ? launch_fused422_12(a, s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, use_dot2_pass(b), s) : launch_fused420(a, fast, s);

@@ -2273,14 +2273,23 @@ __device__ __forceinline__ void idct_column_quadwrap(int &s0, int &s1, int &s2, 
   s1 -= f1; s6 -= f1; s2 -= f1; s5 -= f1;
 }
 
-#ifndef XTW_MIN_BLOCKS
-#define XTW_MIN_BLOCKS 1 // (A-B: 2 asks the compiler for 256 registers -- see profiles/r05/xt_kernels.txt)
+// Round 6: two waves per SIMD.  The block's legacy luma samples wait in LDS for the merge (eight int16 per line and lane:
+// (sample * 16 + 2056) fits sixteen bits on the 16384 gate) instead of in 64 registers beside the 128 of packed residual samples,
+// and the L tables shrink to int16 (entries minus the output shift lie in [-2^15, 2^15)): 80 512 bytes per workgroup, two of
+// them per CU, and a register budget of 256 (profiles/r05/xt_kernels.txt has round 5's counters; profiles/r06/xt_kernels.txt these).
+// LUMA_LDS = false is round 5's kernel (one wave per SIMD, the luma block in registers): legacy frames whose luma leaves the
+// int16 line (sum |c| q >= 7600 -- 4 * that + 2056 must stay below 2^15: no photograph, but nothing forbids it) keep it.
+#ifndef XTW_HALF_BARRIER
+#define XTW_HALF_BARRIER 1
 #endif
-__global__ __launch_bounds__(F420_THREADS, XTW_MIN_BLOCKS) void fusedxtw420_kernel(const Fused420Args a, const FusedXtExtra x)
+template <bool LUMA_LDS>
+__global__ __launch_bounds__(F420_THREADS, LUMA_LDS ? 2 : 1) void fusedxtw420_kernel(const Fused420Args a, const FusedXtExtra x)
 {
   __shared__ __attribute__((aligned(16))) int cplane[2][F420_CROWS * F420_CPITCH];
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
-  __shared__ int ltab[3 * 256];
+  typedef typename std::conditional<LUMA_LDS, short, int>::type ltab_t;
+  __shared__ ltab_t ltab[3 * 256];
+  __shared__ __attribute__((aligned(16))) u32x4 luma_lines[LUMA_LDS ? 8 * F420_THREADS : 1]; // [line][thread]: 8 x int16, no two lanes on one bank
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -2292,7 +2301,7 @@ __global__ __launch_bounds__(F420_THREADS, XTW_MIN_BLOCKS) void fusedxtw420_kern
   const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
-  for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift;
+  for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = (ltab_t)(x.ltable[i] - x.out_shift);
   f420_chroma_to_lds<true, false, true>(a, coef, cplane, stage, lane, wave, tx, ty); // (the legacy frame passed the 16384 range check: use_fusedxt)
   __syncthreads();
   f420_chroma_edges(a, cplane, tid, tx, ty);
@@ -2302,12 +2311,46 @@ __global__ __launch_bounds__(F420_THREADS, XTW_MIN_BLOCKS) void fusedxtw420_kern
   const int X0 = (gbx0 + bx) * 8, Y0 = (ty * F420_TILE_BLOCKS + by) * 8;
   u32x4 rows[8];
 
+  // ------------------------------------------------------------------ legacy luma
+  {
+    const int x0 = gbx0 + (lane >> 3);
+    const char *pbase = reinterpret_cast<const char *>(coef + a.off_y) + (lane & 7) * 16;
+    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+      const int xx = min(x0 + 8 * (m & 1), a.bw_y - 1), yy = min(gby0 + (m >> 1), a.bh_y - 1);
+      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_y + xx) * 128));
+    });
+  }
+  int yv[LUMA_LDS ? 1 : 64];
+  if constexpr (LUMA_LDS) {
+    int yw[64];
+    dequant_idct_sparse<true, true>(rows, a.q[0], yw, 0, LUMA_FOLD_R2);
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+      u32x4 w;
+      w.x = pack_lo16_now(yw[l * 8 + 1] >> 13, yw[l * 8 + 0] >> 13);
+      w.y = pack_lo16_now(yw[l * 8 + 3] >> 13, yw[l * 8 + 2] >> 13);
+      w.z = pack_lo16_now(yw[l * 8 + 5] >> 13, yw[l * 8 + 4] >> 13);
+      w.w = pack_lo16_now(yw[l * 8 + 7] >> 13, yw[l * 8 + 6] >> 13);
+      luma_lines[l * F420_THREADS + tid] = w;
+    }
+  } else {
+    int yw[64];
+    dequant_idct_sparse<true, true>(rows, a.q[0], yw, 0, LUMA_FOLD_R2);
+#pragma unroll
+    for (int i = 0; i < 64; i++) yv[LUMA_LDS ? 0 : i] = yw[i];
+  }
+
+  __builtin_amdgcn_sched_barrier(0); // (the residual blocks' fetches stay behind the luma block's transform: register pressure)
   // ------------------------------------------------------------------ residual blocks -> 20-bit samples minus 2^19, packed
   const int rprec = x.rprecision;                 // 13..16
   const int level7 = 1 << (rprec + 6);            // (2^(P-1)) << 7: the level shift as the column pass sees it in row 0
   const int level_out = 1 << (rprec + 3);         // ... and as it leaves the transform
   const int rmax = (1 << (rprec + 4)) - 1, qshift = 16 - rprec;
-  unsigned rA[64], rB[64];
+  // two registers per pixel: rA = Y sample (20 bits) | low 12 bits of the Cb sample, rB = Cr sample (20 bits) | high 8 bits of
+  // the Cb sample.  Those eight bits wait in hB, four to a register, while the Cr block is transformed: 80 registers of samples
+  // beside that transform instead of 128 (two waves per SIMD leave 256 in all)
+  unsigned rA[64], rB[LUMA_LDS ? 32 : 64], hB[16];
+  const int omax16 = ((x.out_max + 1) << 4) - 1;
   auto residual_block = [&](int64_t off, const int *__restrict__ q, int which) {
     const char *plane = reinterpret_cast<const char *>(coef + off);
     int v[64];
@@ -2327,40 +2370,63 @@ __global__ __launch_bounds__(F420_THREADS, XTW_MIN_BLOCKS) void fusedxtw420_kern
         v[base + 2] = __mul24((int)rows[k].z, q[base + 2]);
         v[base + 3] = __mul24((int)rows[k].w, q[base + 3]);
       }
+      if (LUMA_LDS && XTW_HALF_BARRIER) __builtin_amdgcn_sched_barrier(0); // (the second half's rows are not asked for before the first half's are spent)
     }
 #pragma unroll
     for (int r = 0; r < 8; r++)
       idct_1d<true, 9>(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+    // column by column: transform, then clamp / scale / pack the column's eight samples at once -- the transform's 64 registers
+    // drain into the packed ones as the pass goes (what is live beside it decides whether two waves fit a SIMD)
 #pragma unroll
-    for (int c = 0; c < 8; c++)
+    for (int c = 0; c < 8; c++) {
       idct_column_quadwrap(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], level7);
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
-      // Q table of the subset: clamp to [0, 2^(P+4)), scale to 2^20; kept minus 2^19
-      const int d = (min(max(v[i] + level_out, 0), rmax) << qshift) - (1 << 19);
-      if (which == 0) rA[i] = (unsigned)d & 0xfffffu;
-      else if (which == 1) rB[i] = (unsigned)d & 0xfffffu;
-      else {
-        rA[i] |= ((unsigned)d & 0xfffu) << 20;
-        rB[i] |= (unsigned)(d >> 12) << 20; // twelve bits with the sign: what the arithmetic shift of the unpacking wants
+      for (int r = 0; r < 8; r++) {
+        const int i = r * 8 + c;
+        // Q table of the subset: clamp to [0, 2^(P+4)), scale to 2^20; kept minus 2^19
+        const int d = (min(max(v[i] + level_out, 0), rmax) << qshift) - (1 << 19);
+        if (which == 0) rA[i] = (unsigned)d & 0xfffffu;
+        else if (which == 1) {
+          rA[i] |= ((unsigned)d & 0xfffu) << 20;
+          const unsigned top = ((unsigned)(d >> 12) & 0xffu) << (8 * (i & 3)); // eight bits with the sign
+          if ((i & 3) == 0) hB[i >> 2] = top;
+          else hB[i >> 2] |= top;
+        } else if constexpr (!LUMA_LDS) {
+          rB[i] = ((unsigned)d & 0xfffffu) | (((hB[i >> 2] >> (8 * (i & 3))) & 0xffu) << 20);
+        } else {
+          // The two-wave flavour (half-float output) finishes the residual chain HERE -- R transformation and the R2 table of the
+          // subset, (clamp(rr, 0, 2^20 - 1) + 8) >> 4 (colortrafo/ycbcrtrafo.cpp:776-800) -- and keeps three 16-bit results per
+          // pixel, 96 registers for the block instead of 128.  A result of 65536 (rr at the very top) is kept as 65535: with
+          // an L table entry of at least -32768 the sum is then 32767 or more either way, beyond the largest half-float code
+          // the clamp below lets through (31743) -- the integer flavour of the output would see the difference and keeps the
+          // other kernel.
+          const int d0 = ((int)(rA[i] << 12)) >> 12;
+          const int d1 = (((int)(hB[i >> 2] << (24 - 8 * (i & 3))) >> 24) << 12) | (int)(rA[i] >> 20);
+          int rr0, rr1, rr2;
+          if (x.rtrafo_ycbcr) {
+            const int qy = d0 + (1 << 19);
+            rr0 = qy + (int)(((long long)d * L_CR_R + 4096) >> 13);
+            rr1 = qy + (int)(((long long)d1 * -L_CB_G + (long long)d * -L_CR_G + 4096) >> 13);
+            rr2 = qy + (int)(((long long)d1 * L_CB_B + 4096) >> 13);
+          } else {
+            rr0 = d0 + (1 << 19); rr1 = d1 + (1 << 19); rr2 = d + (1 << 19);
+          }
+          const unsigned v0 = (unsigned)min((min(max(rr0, 0), omax16) + 8) >> 4, 65535), v1 = (unsigned)min((min(max(rr1, 0), omax16) + 8) >> 4, 65535),
+                         v2 = (unsigned)min((min(max(rr2, 0), omax16) + 8) >> 4, 65535);
+          rA[i] = v0 | (v1 << 16);
+          if ((i & 1) == 0) rB[i >> 1] = v2;
+          else rB[i >> 1] |= v2 << 16;
+        }
       }
+      if (LUMA_LDS) __builtin_amdgcn_sched_barrier(0);
     }
   };
   residual_block(x.off_r[0], x.rq[0], 0);
+  __builtin_amdgcn_sched_barrier(0);
   residual_block(x.off_r[1], x.rq[1], 1);
+  __builtin_amdgcn_sched_barrier(0);
   residual_block(x.off_r[2], x.rq[2], 2);
-
-  // ------------------------------------------------------------------ legacy luma
-  {
-    const int x0 = gbx0 + (lane >> 3);
-    const char *pbase = reinterpret_cast<const char *>(coef + a.off_y) + (lane & 7) * 16;
-    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
-      const int xx = min(x0 + 8 * (m & 1), a.bw_y - 1), yy = min(gby0 + (m >> 1), a.bh_y - 1);
-      return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * a.bw_y + xx) * 128));
-    });
-  }
-  int yv[64];
-  dequant_idct_sparse<true, true>(rows, a.q[0], yv, 0, LUMA_FOLD_R2);
+  __builtin_amdgcn_sched_barrier(0);
 
   const bool active = X0 < a.width && Y0 < a.height;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
@@ -2377,7 +2443,6 @@ __global__ __launch_bounds__(F420_THREADS, XTW_MIN_BLOCKS) void fusedxtw420_kern
   };
   const int pinf = (x.out_max >> 1) - (x.out_max >> 6) - 1, minf = -pinf - 1;
   const unsigned pinf2 = (unsigned)pinf * 0x10001u, minf2 = ((unsigned)minf & 0xffffu) * 0x10001u;
-  const int omax16 = ((x.out_max + 1) << 4) - 1;
 
   int cbT[6], cbC[6], cbB[6], crT[6], crC[6], crB[6];
   load6(cb_base, cbT); load6(cb_base + F420_CPITCH, cbC);
@@ -2410,17 +2475,31 @@ __global__ __launch_bounds__(F420_THREADS, XTW_MIN_BLOCKS) void fusedxtw420_kern
       hfilt(vb, ub);
       hfilt(vr, ur);
       int mm[24];
+      u32x4 yl = u32x4{0, 0, 0, 0};
+      if constexpr (LUMA_LDS) yl = luma_lines[l * F420_THREADS + tid]; // (written by this lane: no barrier)
 #pragma unroll
       for (int xx = 0; xx < 8; xx++) {
-        const int yk = luma13(yv[l * 8 + xx]); // (level shift and rounding are inside: LUMA_FOLD_R2)
+        int yk;
+        if constexpr (LUMA_LDS) {
+          const unsigned ypair = xx < 2 ? yl.x : xx < 4 ? yl.y : xx < 6 ? yl.z : yl.w;
+          yk = (int)((xx & 1) ? (ypair & 0xffff0000u) : (ypair << 16)) >> 3; // (sample * 16 + 2056) << 13, sign included
+        } else
+          yk = luma13(yv[LUMA_LDS ? 0 : l * 8 + xx]); // (level shift and rounding are inside: LUMA_FOLD_R2)
         const int lr = clamp255(mad24(ur[xx], L_CR_R, yk) >> 17);
         const int lg = clamp255(mad24(ur[xx], -L_CR_G, mad24(ub[xx], -L_CB_G, yk)) >> 17);
         const int lb = clamp255(mad24(ub[xx], L_CB_B, yk) >> 17);
         const int lv[3] = {ltab[lr], ltab[256 + lg], ltab[512 + lb]};
         // residual chain (colortrafo/ycbcrtrafo.cpp:750-829): the three 20-bit samples minus 2^19
         const int i = l * 8 + xx;
-        const int d0 = ((int)(rA[i] << 12)) >> 12, d1 = ((int)(rB[i] << 12)) >> 12;
-        const int d2 = (((int)rB[i] >> 20) << 12) | (int)(rA[i] >> 20);
+        if constexpr (LUMA_LDS) { // (done where the samples were packed: three 16-bit results)
+          const unsigned p2 = rB[LUMA_LDS ? i >> 1 : 0];
+          mm[3 * xx + 0] = lv[0] + (int)(rA[i] & 0xffffu);
+          mm[3 * xx + 1] = lv[1] + (int)(rA[i] >> 16);
+          mm[3 * xx + 2] = lv[2] + (int)((i & 1) ? p2 >> 16 : p2 & 0xffffu);
+          continue;
+        }
+        const int d0 = ((int)(rA[i] << 12)) >> 12, d2 = ((int)(rB[LUMA_LDS ? 0 : i] << 12)) >> 12;
+        const int d1 = (((int)(rB[LUMA_LDS ? 0 : i] << 4) >> 24) << 12) | (int)(rA[i] >> 20);
         int rr[3];
         if (x.rtrafo_ycbcr) {
           // (ry 8192 + rcb Lb + rcr Lr + 4096) >> 13 with ry = d0 + 2^19 a whole number of 8192ths: ry + ((d L + 4096) >> 13)
@@ -4029,7 +4108,11 @@ int launch_fusedxt420(const FusedXtArgs &x0, hipStream_t stream)
   FusedXtArgs x = x0;
   x.base = with_tile_magic(x0.base);
   const unsigned total = workgroups_for_tiles<XT_TILE_ORDER>((unsigned)x.base.tiles_x, (unsigned)x.base.tiles_y * (unsigned)x.base.frames);
-  if (x.ext.rprecision > 12) hipLaunchKernelGGL(fusedxtw420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
+  if (x.ext.rprecision > 12) {
+    static const bool one_wave = getenv("MIJPEG_XTW_ONE_WAVE") != nullptr; // A-B comparisons
+    if (x.luma_fits16 && x.ext.is_float && !one_wave) hipLaunchKernelGGL(fusedxtw420_kernel<true>, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
+    else hipLaunchKernelGGL(fusedxtw420_kernel<false>, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
+  }
   else hipLaunchKernelGGL(fusedxt420_kernel, dim3(total), dim3(F420_THREADS), 0, stream, x.base, x.ext);
   return (int)hipGetLastError();
 }

@@ -54,6 +54,7 @@ struct FusedXtExtra {
 struct FusedXtArgs {
   Fused420Args base;          // legacy frame, geometry; out = 16-bit samples, strides in bytes
   FusedXtExtra ext;
+  int luma_fits16;            // host: the legacy luma plane's range check admits int16 samples (fusedxtw420_kernel<true>)
 };
 
 // generic path: any sampling / component count / precision, two kernels with int32 sample planes in between.

@@ -1749,3 +1749,91 @@ def test_fused_tile_kernel_on_big_frames(oracle):
         if k == 1:
             assert np.array_equal(a, oracle.decode(data))
     dec.close()
+
+
+@pytest.mark.parametrize("luma_budget", [7599, 7600, 16383])  # below / at the int16 luma line of the two-wave flavour, at the kernel's gate
+@pytest.mark.parametrize("is_float", [1, 0])
+def test_hidden_bit_kernel_on_adversarial_coefficients(oracle, luma_budget, is_float):
+    """fusedxtw420_kernel in both flavours -- round 6's two waves per SIMD (legacy luma through LDS as int16, the residual chain
+    finished where the samples are packed, results kept in sixteen bits with 65536 as 65535) and round 5's -- on synthetic
+    coefficient planes that drive the residual samples to both ends of their range (DC coefficients that saturate the Q clamp,
+    dense blocks at the 65535 gate, sums that make the reference's IDCT<4,QUAD> wrap) and the legacy luma plane to its budget:
+    bit for bit the unfused kernels' output (idct_planes + xt_merge: the literal chain in 64-bit sums, pinned by the oracle
+    in test_xt_hidden_residual_bits_1080p_vs_oracle)."""
+    if not oracle.have_reference():
+        pytest.skip("needs oracle/_ref/jpeg to encode the HDR stream the layout comes from")
+    import ctypes as C
+
+    torch = _torch()
+    W, H = 264, 136
+    data = oracle.reference_encode_hdr(synth.synth_hdr(W, H, 3), ["-r", "-q", "85", "-Q", "90", "-h", "-profile", "c", "-r12", "-rR", "4", "-s", "1x1,2x2,2x2"])
+    d = api.Decoder(0)
+    f = d.read(data)
+    xt = d.xt_params()
+    assert api.kernel_name(f, xt=xt) == "fusedxtw420_kernel" and xt.residual_wide
+    rng = np.random.default_rng(luma_budget * 2 + is_float)
+    n16 = int(f.coef_count)
+    buf = np.zeros(n16, np.int16)
+    # legacy planes (int16): random sparse blocks scaled to the budget; component 0 spends it exactly somewhere
+    for c in range(3):
+        bw, bh = f.blocks_w[c], f.blocks_h[c]
+        q = np.array(f.quant[f.quant_index[c]], np.int64)
+        p = np.zeros((bh, bw, 64), np.int64)
+        budget = luma_budget if c == 0 else 2000
+        for by in range(bh):
+            for bx in range(bw):
+                k = rng.integers(0, 64, size=3)
+                s = rng.choice([-1, 1], size=3)
+                share = budget // 3
+                for kk, ss in zip(k, s):
+                    p[by, bx, kk] += ss * (share // q[kk])
+        p[0, 0] = 0
+        p[0, 0, 0] = budget // q[0]
+        p[0, 0, 1] = -((budget - (budget // q[0]) * q[0]) // q[1])
+        rm = int((np.abs(p) * q).sum(axis=2).max())
+        assert rm <= budget
+        f.range_max[c] = rm if c else budget  # (the host's range check: what selects the flavour)
+        off = int(f.coef_offset[c])
+        buf[off:off + p.size] = p.reshape(-1).astype(np.int16)
+    # residual planes (int32, two int16 slots each): DC at both ends, dense noise, sums near the 65535 gate
+    r = xt.residual
+    wide = np.zeros((n16 - int(r.coef_offset[0])) // 2, np.int32)
+    for c in range(3):
+        bw, bh = r.blocks_w[c], r.blocks_h[c]
+        q = np.array(r.quant[r.quant_index[c]], np.int64)
+        p = np.zeros((bh, bw, 64), np.int64)
+        kind = rng.integers(0, 4, size=(bh, bw))
+        for by in range(bh):
+            for bx in range(bw):
+                if kind[by, bx] == 0:
+                    p[by, bx, 0] = rng.choice([-1, 1]) * (65000 // q[0])  # saturates the Q table's clamp one way or the other
+                elif kind[by, bx] == 1:
+                    v = rng.integers(-30, 31, size=64)
+                    tot = int((np.abs(v) * q).sum())
+                    p[by, bx] = v * max(1, 60000 // max(tot, 1))
+                else:
+                    k = rng.integers(0, 64)
+                    p[by, bx, k] = rng.choice([-1, 1]) * (64000 // q[k])
+        rm = int((np.abs(p) * q).sum(axis=2).max())
+        assert rm < 65536
+        xt.residual.range_max[c] = rm
+        off = (int(r.coef_offset[c]) - int(r.coef_offset[0])) // 2
+        wide[off:off + p.size] = p.reshape(-1).astype(np.int32)
+    buf[int(r.coef_offset[0]):] = wide.view(np.int16)
+    xt.is_float = is_float
+    f.is_float = is_float
+    coef = torch.from_numpy(buf).cuda()
+    row = W * 6
+    outs = []
+    for flags in (0, api.FLAG_FORCE_GENERIC):
+        out = torch.zeros((H, row), dtype=torch.uint8, device="cuda")
+        wsb = api.workspace_bytes(f, 1, flags=flags, xt=xt)
+        ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device="cuda")
+        api.launch_reconstruct(f, coef.data_ptr(), out.data_ptr(), 1, row, H * row, n16, flags=flags, workspace=ws.data_ptr(), workspace_bytes=wsb,
+                               stream=torch.cuda.current_stream().cuda_stream, xt=xt)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy().view(np.uint16).reshape(H, W, 3))
+    d.close()
+    bad = int((outs[0] != outs[1]).sum())
+    assert bad == 0, f"{bad} differing samples, first at {np.argwhere(outs[0] != outs[1])[:4].tolist()}"
+    assert len(np.unique(outs[0])) > 50  # (not a constant picture: both ends of the range and what lies between)

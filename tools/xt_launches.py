@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--hidden", action="store_true")
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--time", action="store_true")
     a = ap.parse_args()
     W, H = bench.SIZES["4k"]
     data = O.reference_encode_hdr(synth.synth_hdr(W, H, 99), bench.XT_ARGS + (["-rR", "4"] if a.hidden else []))
@@ -40,10 +41,24 @@ def main():
     wsb = api.workspace_bytes(info, F, xt=xt)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
     s = torch.cuda.Stream()
-    for _ in range(a.launches):
+
+    def launch():
         api.launch_reconstruct(info, coef.data_ptr(), out.data_ptr(), F, row, H * row, n, workspace=ws.data_ptr(), workspace_bytes=wsb, stream=s.cuda_stream, xt=xt)
+
+    if a.time:  # settle the clocks, then HIP events around the launches (on the launch stream)
+        import time
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.2:
+            launch()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+    for _ in range(a.launches):
+        launch()
+    if a.time:
+        e1.record(s)
     torch.cuda.synchronize()
-    print(api.kernel_name(info, xt=xt), "launches", a.launches, "frames", F)
+    print(api.kernel_name(info, xt=xt), "launches", a.launches, "frames", F, ("ms per launch %.4f" % (e0.elapsed_time(e1) / a.launches)) if a.time else "")
 
 
 if __name__ == "__main__":
