@@ -2385,12 +2385,17 @@ __global__ __launch_bounds__(F420_THREADS, LUMA_LDS ? 2 : 1) void fusedxtw420_ke
         const int i = r * 8 + c;
         // Q table of the subset: clamp to [0, 2^(P+4)), scale to 2^20; kept minus 2^19
         const int d = (min(max(v[i] + level_out, 0), rmax) << qshift) - (1 << 19);
-        if (which == 0) rA[i] = (unsigned)d & 0xfffffu;
-        else if (which == 1) {
+        // (LUMA_LDS: the empty asm statements make the packed word exist HERE -- left to itself the compiler keeps the raw sample
+        // of every block and packs where the words are used, a hundred registers later; profiles/r06/xt_kernels.txt)
+        if (which == 0) {
+          rA[i] = (unsigned)d & 0xfffffu;
+          if (LUMA_LDS) asm volatile("" : "+v"(rA[i]));
+        } else if (which == 1) {
           rA[i] |= ((unsigned)d & 0xfffu) << 20;
           const unsigned top = ((unsigned)(d >> 12) & 0xffu) << (8 * (i & 3)); // eight bits with the sign
           if ((i & 3) == 0) hB[i >> 2] = top;
           else hB[i >> 2] |= top;
+          if (LUMA_LDS) asm volatile("" : "+v"(rA[i]), "+v"(hB[i >> 2]));
         } else if constexpr (!LUMA_LDS) {
           rB[i] = ((unsigned)d & 0xfffffu) | (((hB[i >> 2] >> (8 * (i & 3))) & 0xffu) << 20);
         } else {
@@ -2416,6 +2421,7 @@ __global__ __launch_bounds__(F420_THREADS, LUMA_LDS ? 2 : 1) void fusedxtw420_ke
           rA[i] = v0 | (v1 << 16);
           if ((i & 1) == 0) rB[i >> 1] = v2;
           else rB[i >> 1] |= v2 << 16;
+          asm volatile("" : "+v"(rA[i]), "+v"(rB[i >> 1]));
         }
       }
       if (LUMA_LDS) __builtin_amdgcn_sched_barrier(0);

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round 5: rocprofv3 over config 5's two fused kernels (kernel trace + stats, SQ counters, HBM bytes in separate passes)
+# rocprofv3 over config 5's two fused kernels (kernel trace + stats, SQ counters, HBM bytes in separate passes)
+TAG="${1:-r06}"
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
-OUT="$ROOT/gpurun_out/prof_xt_r05"; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
-for v in "" "--hidden"; do
+OUT="$ROOT/gpurun_out/prof_xt_${TAG:-r06}"; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
+for v in ${VARIANTS:-"" "--hidden"}; do
   tag=r12; [ -n "$v" ] && tag=rR4
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$tag" -o t -- python $ROOT/tools/xt_launches.py $v > "$OUT/trace_$tag.log" 2>&1; echo "trace $tag exit $?"
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_sq_$tag" -o t -- python $ROOT/tools/xt_launches.py $v > "$OUT/pmc_sq_$tag.log" 2>&1; echo "pmc_sq $tag exit $?"
@@ -10,9 +11,10 @@ for v in "" "--hidden"; do
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$tag" -o t -- python $ROOT/tools/xt_launches.py $v > "$OUT/pmc_write_$tag.log" 2>&1; echo "write $tag exit $?"
 done
 cd "$ROOT"
-python - <<'PY'
+TAG=$TAG python - <<'PY'
 import csv, glob, os, collections
-out = "gpurun_out/prof_xt_r05"
+import os as _os
+out = "gpurun_out/prof_xt_" + _os.environ.get("TAG", "r06")
 with open(os.path.join(out, "summary.txt"), "w") as fo:
     for tag in ("r12", "rR4"):
         for f in glob.glob(f"{out}/trace_{tag}/**/*kernel_stats.csv", recursive=True):
