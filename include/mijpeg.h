@@ -339,6 +339,10 @@ int mijpeg_display_cursor(mijpeg_decoder *d, int component);
  * parses them from memory), end_byte = 0.  Either array may be NULL.  Returns the number of scans (also when capacity is
  * smaller) or a negative error. */
 int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_byte, int capacity);
+/* ... and their MCU grids, same order: mcus_y[k] rows of mcus_x[k] MCUs (a single-component scan walks its component's own blocks,
+ * codestream/sequentialscan.cpp:396-397).  What JPEG::Read with JPGFLAG_DECODER_STOP_ROW / _MCU counts its returns by: one at the
+ * start of every MCU row, one behind every MCU of a row but the last (interface/jpeg.cpp:326-350).  Returns the number of scans. */
+int mijpeg_scan_grids(mijpeg_decoder *d, int32_t *mcus_x, int32_t *mcus_y, int capacity);
 
 /* JPEG XT alpha channel (the reference: Image::ParseAlphaChannel, codestream/image.cpp:1337-1404; JPEG::GetInformation's
  * JPGTAG_ALPHA_MODE / JPGTAG_ALPHA_TAGLIST / JPGTAG_ALPHA_MATTE, interface/jpeg.cpp:870-945; JPEG::DisplayRectangle with

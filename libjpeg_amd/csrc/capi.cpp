@@ -3907,6 +3907,26 @@ try {
   return n;
 } catch (...) { return boundary_catch(d, "mijpeg_scan_offsets"); }
 
+int mijpeg_scan_grids(mijpeg_decoder *d, int32_t *mcus_x, int32_t *mcus_y, int capacity)
+try {
+  if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  int n = 0;
+  auto put = [&](const Scan &sc) {
+    if (n < capacity) {
+      if (mcus_x) mcus_x[n] = sc.mcus_x;
+      if (mcus_y) mcus_y[n] = sc.mcus_y;
+    }
+    n++;
+  };
+  for (const Scan &sc : d->host.scans)
+    if (!sc.base) put(sc);
+  for (const Scan &sc : d->host.scans)
+    if (sc.base) put(sc);
+  if (HostDecoder *res = d->host.residual())
+    for (const Scan &sc : res->scans) put(sc);
+  return n;
+} catch (...) { return boundary_catch(d, "mijpeg_scan_grids"); }
+
 int mijpeg_display_plan(mijpeg_decoder *d, int32_t min_x, int32_t min_y, int32_t max_x, int32_t max_y, int32_t min_comp, int32_t max_comp,
                         uint32_t flags, const uint32_t bm_height[MIJPEG_MAX_COMPONENTS], int32_t out[8 + 6 * MIJPEG_MAX_COMPONENTS])
 try {

@@ -36,6 +36,12 @@ struct JPEG::Impl {
   // JPGFLAG_DECODER_STOP_SCAN: where the reference stands when it returns with a scan header parsed (the first entropy coded
   // byte of every scan), in the order of the scans; the scans are decoded -- in parallel -- by the call that meets the first one
   std::vector<size_t> scan_stops, scan_ends; // first entropy coded byte / first byte behind the data of every scan of the codestream
+  // JPGFLAG_DECODER_STOP_ROW / _MCU (interface/jpeg.cpp:326-350): behind a scan header the reference returns at the start of every
+  // MCU row and behind every MCU of a row but its last.  The scans are decoded already; what is walked is the grid of each.
+  std::vector<int32_t> grid_x, grid_y; // per scan, the boxed ones behind the codestream's (mijpeg_scan_grids)
+  bool in_scan = false, in_row = false;
+  int32_t row = 0, mcu = 0;
+  size_t walking = 0; // the scan whose grid is being walked
   size_t boxed_stops = 0;                   // JPEG XT: further scans that live in boxes
   size_t next_stop = 0;
   bool between = false;                     // walking the marker segments between two scans
@@ -310,6 +316,10 @@ try {
             if (r.first <= pos) pos += r.second - r.first;
           return pos < p->stream.size() ? pos : p->stream.size();
         };
+        p->grid_x.assign((size_t)std::max(ns, 1), 1);
+        p->grid_y.assign((size_t)std::max(ns, 1), 0);
+        mijpeg_scan_grids(p->dec, p->grid_x.data(), p->grid_y.data(), ns);
+        p->in_scan = p->in_row = false;
         p->boxed_stops = 0;
         for (int k = 0; k < ns; k++) {
           if (end[(size_t)k] == 0) { p->boxed_stops++; continue; }
@@ -325,7 +335,35 @@ try {
       // a scan's data Frame::StartParseScan takes the marker segments in front of the next scan header one per call (each a
       // return under JPGFLAG_DECODER_STOP_FRAME), then parses the header (a return under JPGFLAG_DECODER_STOP_SCAN, with the
       // stream at the scan's entropy coded data).  The scans themselves are decoded already.
+      if (p->in_scan) { // the rows and MCUs of the scan whose header was the last stop
+        const int32_t rows = p->walking < p->grid_y.size() ? p->grid_y[p->walking] : 0, across = p->walking < p->grid_x.size() ? p->grid_x[p->walking] : 1;
+        if (!p->in_row) {
+          if (p->row < rows) { // StartMCURow: another row
+            p->in_row = true;
+            p->mcu = 0;
+            if (stopflags & JPGFLAG_DECODER_STOP_ROW) return JPG_TRUE;
+          } else {
+            p->in_scan = false;
+            break;
+          }
+        }
+        // ParseMCU says "more in this row" behind every MCU but the last
+        if (!(stopflags & JPGFLAG_DECODER_STOP_MCU)) p->mcu = across > 0 ? across - 1 : 0;
+        if (p->mcu + 1 < across) {
+          p->mcu++;
+          return JPG_TRUE;
+        }
+        p->in_row = false;
+        p->row++;
+        break;
+      }
       const size_t k = p->next_stop;
+      auto enter_scan = [&](size_t which) {
+        p->in_scan = true;
+        p->in_row = false;
+        p->row = p->mcu = 0;
+        p->walking = which;
+      };
       if (k < p->scan_stops.size()) {
         if (k > 0) {
           if (!p->between) {
@@ -340,6 +378,7 @@ try {
         p->between = false;
         p->cursor = p->scan_stops[k];
         p->next_stop++;
+        enter_scan(k);
         if (stopflags & JPGFLAG_DECODER_STOP_SCAN) return JPG_TRUE;
         break;
       }
@@ -353,6 +392,7 @@ try {
           if (stopflags & JPGFLAG_DECODER_STOP_FRAME) return JPG_TRUE;
         }
         p->next_stop++;
+        enter_scan(k);
         if (stopflags & JPGFLAG_DECODER_STOP_SCAN) return JPG_TRUE;
         break;
       }

@@ -32,8 +32,13 @@ int main(int argc, char **argv)
   if (argc < 3) return 2;
   FILE *in = fopen(argv[1], "rb");
   if (!in) return 2;
-  const bool scans = !strcmp(argv[2], "scan"); // JPGFLAG_DECODER_STOP_SCAN: one Read per scan header, until the data ends
-  const JPG_LONG stop = !strcmp(argv[2], "image") ? JPGFLAG_DECODER_STOP_IMAGE : scans ? JPGFLAG_DECODER_STOP_SCAN : JPGFLAG_DECODER_STOP_FRAME;
+  // row / mcu / scanrow: JPGFLAG_DECODER_STOP_ROW, _MCU, _SCAN | _ROW until the data ends.  Inside a scan the stream stands wherever
+  // the bit reader's buffer got to, so what is compared there is the NUMBER of returns ("reads N"), not what a peek shows
+  const bool rows = !strcmp(argv[2], "row") || !strcmp(argv[2], "mcu") || !strcmp(argv[2], "scanrow");
+  const bool scans = !strcmp(argv[2], "scan") || rows; // JPGFLAG_DECODER_STOP_SCAN: one Read per scan header, until the data ends
+  const JPG_LONG stop = !strcmp(argv[2], "image") ? JPGFLAG_DECODER_STOP_IMAGE : !strcmp(argv[2], "row") ? JPGFLAG_DECODER_STOP_ROW :
+                        !strcmp(argv[2], "mcu") ? JPGFLAG_DECODER_STOP_MCU : !strcmp(argv[2], "scanrow") ? (JPGFLAG_DECODER_STOP_SCAN | JPGFLAG_DECODER_STOP_ROW) :
+                        scans ? JPGFLAG_DECODER_STOP_SCAN : JPGFLAG_DECODER_STOP_FRAME;
   const long extra = argc > 3 ? atol(argv[3]) : 0; // raw bytes behind every APP9 segment that the client removes as well
   struct JPG_Hook filehook(FileHook, in);
   class JPEG *jpeg = JPEG::Construct(NULL);
@@ -47,7 +52,8 @@ int main(int argc, char **argv)
   do {
     ok = jpeg->Read(tags);
     marker = jpeg->PeekMarker(NULL);
-    printf("peek %lx\n", (unsigned long)(marker & 0xffffffffUL));
+    if (!rows) printf("peek %lx\n", (unsigned long)(marker & 0xffffffffUL));
+    if (rows && marker == 0xffe9) marker = 1; // (entropy coded bytes that look like a marker are no marker)
     if (marker == 0xffe9) {
       unsigned char buffer[4];
       ok = jpeg->ReadMarker(buffer, sizeof(buffer), NULL) == (JPG_LONG)sizeof(buffer);
@@ -57,7 +63,8 @@ int main(int argc, char **argv)
         printf("took %ld\n", (long)(2 + size + extra));
       }
     }
-  } while ((scans ? marker != -1L : (marker && marker != -1L)) && ok && ++guard < 1000);
+  } while ((scans ? marker != -1L : (marker && marker != -1L)) && ok && ++guard < (rows ? 50000000 : 1000));
+  if (rows) printf("reads %d\n", guard + 1);
   tags->SetTagData(JPGTAG_DECODER_STOP, 0);
   if (!ok || !jpeg->Read(tags)) {
     const char *msg = NULL;

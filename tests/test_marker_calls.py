@@ -4,6 +4,7 @@ cmd/reconstruct.cpp:80-119 -- is compiled against libjpeg_amd's interface header
 Where the reference's objects are present (oracle/_ref/obj, build container) the SAME source is also linked against the
 real reference library and the traces are compared line by line."""
 import glob
+import json
 import os
 import subprocess
 
@@ -131,3 +132,23 @@ def test_stop_scan_returns_at_every_scan_header(clients, name):
     if ref:
         rrc, exp = run(ref, src, "scan")
         assert rrc == 0 and exp == lines, (lines, exp)
+
+
+with open(os.path.join(GOLDEN_DIR, "stop_counts.json")) as _f:
+    STOP_COUNTS = json.load(_f)
+
+
+@pytest.mark.parametrize("mode", ["row", "mcu", "scanrow"])
+@pytest.mark.parametrize("name", sorted(STOP_COUNTS))
+def test_stop_row_and_stop_mcu_return_as_often_as_the_reference(clients, name, mode):
+    """JPGFLAG_DECODER_STOP_ROW / _MCU (interface/jpeg.cpp:326-350): behind every scan header one return at the start of every MCU
+    row, one behind every MCU of a row but its last -- walked over the grids of the scans this library has decoded by then
+    (mijpeg_scan_grids).  What happens inside a scan cannot be told from the stream (the reference's input stands wherever its
+    bit reader's buffer got to), so the trace is the NUMBER of returns: tests/golden/stop_counts.json holds the real library's
+    (make_stop_counts.py), and where its objects are present the same client is run against it live."""
+    ours, ref = clients
+    rc, lines = run(ours, os.path.join(GOLDEN_DIR, name + ".jpg"), mode)
+    assert rc == 0 and lines == STOP_COUNTS[name][mode], (lines, STOP_COUNTS[name][mode])
+    if ref:
+        rrc, exp = run(ref, os.path.join(GOLDEN_DIR, name + ".jpg"), mode)
+        assert rrc == 0 and exp == lines
