@@ -226,6 +226,29 @@ int mijpeg_finish_batch_device(mijpeg_decoder *d);
  * without restart markers the call behaves as without the flag.  mijpeg_batch_speculation: diagnostics -- returns 1 when the last
  * validation had to reconstruct again; *launched / *redone count the object's speculative launches and the ones redone. */
 int mijpeg_batch_speculation(mijpeg_decoder *d, int64_t *launched, int64_t *redone);
+/* BASELINE config 4 as ONE call (round 6; libjpeg_amd/csrc/batch_pipeline.cpp -- until then a Python loop): `decoder_objects`
+ * decoder objects on `device`, driven round-robin by the calling thread over chunks of `chunk_frames` streams (ramp != 0:
+ * smaller chunks at both ends of the batch): submit of chunk i + 1 (host: parse, marker search, gather) while chunk i's upload,
+ * Huffman kernel and fused kernel run.  run: n streams of one shape, bytes in host memory -> frame i at dst_device + i *
+ * frame_stride (device memory, `row_stride` bytes per line); returns when every frame is there.  download_host != NULL: the
+ * frames also travel to that (pinned) host buffer, same strides, each chunk as soon as its reconstruction is through, on a
+ * stream of the pipeline's own; run returns when the last one has arrived.  A chunk the device path declines
+ * (MIJPEG_ERR_NOT_AVAILABLE) is decoded by mijpeg_decode_batch_device, failing that stream by stream on the host; any other
+ * error ends the run with its code (mijpeg_batch_pipeline_last_error).  stats: chunks of the last run, how many fell back, host
+ * milliseconds of every submit.  schedule: the chunk boundaries run would use.  decoder: object k (diagnostics: mijpeg_get_info,
+ * mijpeg_last_timing of its last chunk). */
+typedef struct mijpeg_batch_pipeline mijpeg_batch_pipeline;
+int mijpeg_batch_pipeline_create(mijpeg_batch_pipeline **out, int device, int chunk_frames, int decoder_objects, int ramp);
+void mijpeg_batch_pipeline_destroy(mijpeg_batch_pipeline *p);
+int mijpeg_batch_pipeline_run(mijpeg_batch_pipeline *p, const uint8_t *const *streams, const size_t *sizes, int n, void *dst_device,
+                              int64_t frame_stride, int64_t row_stride, void *download_host);
+int mijpeg_batch_pipeline_schedule(int n, int chunk_frames, int ramp, int32_t *first, int32_t *end, int capacity);
+int mijpeg_batch_pipeline_stats(mijpeg_batch_pipeline *p, int32_t *chunks, int32_t *fallbacks, float *submit_ms, int capacity);
+int mijpeg_batch_pipeline_last_error(mijpeg_batch_pipeline *p, const char **message);
+/* on = 1 / 0: launch the reconstructions speculatively (MIJPEG_FLAG_SPECULATIVE above; off by default), on < 0: leave as is.
+ * Returns how many chunks of the last run were reconstructed again by their validation. */
+int mijpeg_batch_pipeline_speculation(mijpeg_batch_pipeline *p, int on);
+mijpeg_decoder *mijpeg_batch_pipeline_decoder(mijpeg_batch_pipeline *p, int k);
 /* Capacity planning / diagnostics: the HOST half of mijpeg_submit_batch_device alone -- header parse, restart marker search
  * and the copy of the entropy coded data without its byte stuffing into the staging area, one stream per pool worker -- with
  * no device involved (works on host-only objects).  This is what a rank's cores do per chunk of a batch; `bench.py

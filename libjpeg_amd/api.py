@@ -149,6 +149,16 @@ def lib():
         L.mijpeg_alpha_channel.argtypes = [C.c_void_p]
         L.mijpeg_alpha_channel.restype = C.c_void_p
         L.mijpeg_has_alpha.argtypes = [C.c_void_p]
+        L.mijpeg_batch_pipeline_create.argtypes = [P(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.mijpeg_batch_pipeline_destroy.argtypes = [C.c_void_p]
+        L.mijpeg_batch_pipeline_destroy.restype = None
+        L.mijpeg_batch_pipeline_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.mijpeg_batch_pipeline_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.mijpeg_batch_pipeline_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.mijpeg_batch_pipeline_last_error.argtypes = [C.c_void_p, P(C.c_char_p)]
+        L.mijpeg_batch_pipeline_speculation.argtypes = [C.c_void_p, C.c_int]
+        L.mijpeg_batch_pipeline_decoder.argtypes = [C.c_void_p, C.c_int]
+        L.mijpeg_batch_pipeline_decoder.restype = C.c_void_p
         L.mijpeg_alpha_info.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_int32)]
         L.mijpeg_last_timing.argtypes = [C.c_void_p, P(C.c_double)]
         L.mijpeg_launch_reconstruct.argtypes = [P(MijpegBatch), C.c_void_p]

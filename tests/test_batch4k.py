@@ -1,11 +1,13 @@
 """BASELINE config 4 at its stated shape: 256 independent 3840x2160 4:2:0 Q85 DRI=8 frames (seeds 1000...1255), compressed
 streams in host memory -> pixels in HBM through the batch entry points of the C ABI, every frame against the oracle."""
 import hashlib
+import os
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
 
+from conftest import ROOT
 from libjpeg_amd import batch
 
 
@@ -212,3 +214,48 @@ def test_speculative_reconstruction_is_validated(oracle):
             assert np.array_equal(host[i].numpy().reshape(exp.shape), exp), (p, i)
     assert sum(dec.batch_speculation()[1] for dec in shard.decoders) >= 8 and shard.redone == 0
     shard.close()
+
+
+@pytest.mark.gpu
+def test_cxx_client_of_the_batch_pipeline(oracle, tmp_path):
+    """Config 4's driver is behind the C ABI (mijpeg_batch_pipeline_create / _run / _destroy): tests/cxx/batch_client.cpp, built
+    against include/mijpeg.h alone, sends 24 streams -- one of them damaged in its entropy coded data, one without restart markers
+    -- through the pipeline, pixels into HBM and full duplex into pinned host memory; every frame's hash equals the oracle's
+    decode, the chunk with the damaged stream fell back (blocking batch call, then stream by stream on the host), nothing else did."""
+    import subprocess
+
+    from libjpeg_amd import synth
+
+    cfg = dict(batch.CONFIG4, width=640, height=368, frames=24)
+    streams = batch.make_streams(range(24), cfg)
+    blobs = [streams[i] for i in range(24)]
+    bad = bytearray(blobs[7])
+    pos = bad.find(b"\xff\xd3", bad.find(b"\xff\xda"))
+    del bad[pos:pos + 2]  # a restart marker gone: the reference resynchronises at the next one (entropyparser.cpp:117-201) -- the host walk's business
+    blobs[7] = bytes(bad)
+    assert oracle.decode(blobs[7]).shape == (368, 640, 3)
+    blobs[20] = synth.synth_jpeg(640, 368, 77, 85, "420", 0)  # no restart markers: virtual restart intervals from the device walk
+    paths = []
+    for i, b in enumerate(blobs):
+        p = tmp_path / f"{i}.jpg"
+        p.write_bytes(b)
+        paths.append(str(p))
+    exe = str(tmp_path / "batch_client")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.run(["g++", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"), "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cxx", "batch_client.cpp"), "-o", exe, "-L", os.path.join(ROOT, "libjpeg_amd"), "-lmijpeg",
+                    "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "libjpeg_amd")], check=True)
+    r = subprocess.run([exe, "5", "3", "0", "2"] + paths, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1].startswith("summary frames 24 640x368 chunks 5 fallbacks "), lines[-1]
+    assert int(lines[-1].split("fallbacks ")[1].split()[0]) == 1  # the chunk of frame 7 (frame 20's takes the device walk)
+
+    def fnv(a):
+        h = 1469598103934665603
+        for byte in a.tobytes():
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    for i in (0, 6, 7, 8, 19, 20, 23):
+        assert int(lines[i].split()[2], 16) == fnv(oracle.decode(blobs[i])), i

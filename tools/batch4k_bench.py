@@ -43,7 +43,7 @@ def main():
         ms = r["seconds"] * 1e3 / int(os.environ.get("STEPS", "3"))
         px = cfg["width"] * cfg["height"] * n
         print(f"chunk {chunk:4d} depth {depth}{' ramp' if ramp else '     '}: {ms:8.2f} ms per batch, {ms / n:.4f} ms per frame, {px / ms / 1e6:8.1f} Gpixel/s   chunk ms {['%.1f' % x for x in r['shard'].chunk_ms[:6]]}")
-        ph = [p for p in r["shard"].chunk_phases_ms if p]
+        ph = [p for p in getattr(r["shard"], "chunk_phases_ms", []) if p]
         if ph:
             print("      decode call / parse / prepare / upload+huffman+status ms, mean over chunks:", ["%.2f" % (sum(p[k] for p in ph) / len(ph)) for k in range(4)])
         r["shard"].close()

@@ -63,7 +63,7 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t) * 1e3
             th1 = throttled()
-            rows.append((dt, list(shard.chunk_ms), list(shard.chunk_phases_ms), sclk, gpu_clock(),
+            rows.append((dt, list(shard.chunk_ms), list(getattr(shard, "chunk_phases_ms", [])), sclk, gpu_clock(),
                          None if th0[0] is None else (th1[0] - th0[0], (th1[1] - th0[1]) / 1e3)))
         ms = sorted(r[0] for r in rows)
         print(f"chunk {chunk:3d} x {depth}{' ramp' if ramp else ''}: steps ms {' '.join('%.2f' % r[0] for r in rows)}   median {ms[len(ms) // 2]:.2f} min {ms[0]:.2f} max {ms[-1]:.2f}")
