@@ -3393,6 +3393,9 @@ __device__ __forceinline__ void tile_plane_line(const T *planes, const TileComp 
   }
 }
 
+#ifndef TILE_STRIP
+#define TILE_STRIP 1
+#endif
 template <bool FAST, bool NARROW>
 __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const GenericArgs a)
 {
@@ -3527,9 +3530,16 @@ __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const Generi
   // one instance per component count: the loops over components and the sample packing have static shapes
   auto phase_b = [&](auto NCc) {
     constexpr int NC = decltype(NCc)::value;
-    for (int it = tid; it < groups * lines; it += 256) {
-      const int ly = div_recip(it, rgroups), g = mad24(ly, -groups, it);
-      const int X0 = px0 + 8 * g, Y = py0 + ly;
+    // A lane owns TILE_STRIP consecutive lines of one 8-pixel group: what depends on the column alone (the group's place in every
+    // plane, the horizontal phase) is worked out once per strip.  (Measured in round 6, profiles/r06/tile_strips.txt.)
+    const int strips = (lines + TILE_STRIP - 1) / TILE_STRIP;
+    for (int it = tid; it < groups * strips; it += 256) {
+      const int st = div_recip(it, rgroups), g = mad24(st, -groups, it);
+      const int X0 = px0 + 8 * g;
+#pragma unroll
+     for (int sub = 0; sub < TILE_STRIP; sub++) {
+      const int ly = st * TILE_STRIP + sub, Y = py0 + ly;
+      if (TILE_STRIP > 1 && ly >= lines) break;
       int s[NC][8];
 #pragma unroll
       for (int c = 0; c < NC; c++) tile_plane_line<FAST, T>(planes, comp[c], X0, Y, s[c]);
@@ -3621,6 +3631,7 @@ __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const Generi
           }
         }
       }
+     }
     }
   };
   if (a.ncomp == 1) phase_b(std::integral_constant<int, 1>{});
