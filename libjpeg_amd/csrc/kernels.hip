@@ -4011,7 +4011,10 @@ __global__ __launch_bounds__(F420_THREADS, NC == 4 ? FLAT4_MINW : 3) void fused_
     // level shift inside, + 8 of COLOR_TO_INT in the second pass's rounding constant: v = sample * 16 + 8
     dequant_idct_sparse<true>(rows, a.q[c], v, a.dcoff[c], 2048 + (8 << 12));
 #pragma unroll
-    for (int k = 0; k < 16; k++) pk[c][k] = ashr_sat_pack4<4>(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    for (int k = 0; k < 16; k++) {
+      pk[c][k] = ashr_sat_pack4<4>(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+      asm volatile("" : "+v"(pk[c][k])); // (the packed word exists from here on: see fusedxtw420_kernel, profiles/r06/xt_kernels.txt)
+    }
     __builtin_amdgcn_sched_barrier(0); // keep the next component's loads from being hoisted above this transform (register pressure)
   }
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;

@@ -874,14 +874,22 @@ def test_device_entropy_decoder_grey_and_optimized_tables(dec, oracle):
 
 
 def test_device_entropy_decoder_eligibility_and_errors(dec):
-    # tiny without restart markers (the walk wants 256 MCUs), progressive: not available on the device ("auto" falls
-    # back to the host silently)
-    for data in (synth.synth_jpeg(160, 120), synth.synth_jpeg(320, 240, restart_mcus=4, progressive=True)):
+    # tiny without restart markers (the walk wants 256 MCUs), a progressive picture whose scans have no restart markers and are
+    # beyond a lane's reach (AC refinement is serial by construction): not available on the device ("auto" falls back
+    # to the host silently)
+    for data in (synth.synth_jpeg(160, 120), synth.synth_jpeg(1600, 1200, quality=92, progressive=True)):
         with pytest.raises(api.MijpegError) as e:
             dec.read(data, entropy="gpu")
         assert e.value.code == api.ERR_NOT_AVAILABLE
         dec.read(data, entropy="auto")
         assert dec.entropy_used == "host"
+    # ... with restart markers a progressive picture is the device's since round 6 (tests/test_device_multiscan.py); "auto" keeps a
+    # small one on the host, like a small sequential one
+    data = synth.synth_jpeg(320, 240, restart_mcus=4, progressive=True)
+    dec.read(data, entropy="gpu")
+    assert dec.entropy_used == "gpu"
+    dec.read(data, entropy="auto")
+    assert dec.entropy_used == "host"
     # few intervals: "auto" keeps it on the host, "gpu" forces it
     data = synth.synth_jpeg(320, 240, restart_mcus=4)
     dec.read(data, entropy="auto")
