@@ -704,10 +704,14 @@ __device__ __forceinline__ int prog_block_refine(DevBits &br, const HuffDevTable
     // are valid from the reader's position on), which is fetched again when it runs dry or a symbol is due
     uint32_t cw = 0;
     int chave = 0;
+    // the coefficient of the NEXT position is asked for one step ahead (a step only writes its own position): the two dependent
+    // LDS reads -- scan order, then the coefficient -- are off the step-to-step chain
+    int pos_c = zz[ss], data_c = st.get(pos_c);
     do {
       if (!at_start) {
-        const int pos = zz[k];
-        const int data = st.get(pos);
+        const int pos = pos_c, data = data_c;
+        pos_c = zz[k + 1];
+        data_c = st.get(pos_c);
         if (data) { // a correction bit: one step away from zero, or nothing
           if (chave == 0) {
             br.refill();
