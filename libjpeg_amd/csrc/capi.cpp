@@ -962,6 +962,7 @@ static int evaluate_entropy_status(mijpeg_decoder *d, HostDecoder *const *hosts,
       f.range_max[c] = (int32_t)std::min<uint32_t>(st[1 + c], 0x7fffffffu);
       if (f.range_max[c] >= 16384) f.fast_arith = 0;
     }
+    if (f.precision != 8) f.fast_arith = 0; // (as HostDecoder::decode has it: the fast flavour is derived for 8-bit frames; 12-bit kernels gate on range_max)
   }
   return MIJPEG_OK;
 }
@@ -1427,8 +1428,9 @@ static const char *multiscan_obstacle(const HostDecoder &h, bool xt_part, bool r
   if (!h.residual_merged()) return "on-device entropy decoding: the legacy codestream has no EOI marker (the host decoder decides what is merged)";
   if (h.verdict_pending()) return "on-device entropy decoding: the file's verdict is the host decoder's (residual codestream header / tables looked up at the first request)";
   if (f.dnl) return "on-device entropy decoding: frames whose height arrives in a DNL marker are decoded on the host";
-  if (f.precision != 8 && !(xt_part && residual_frame && f.precision >= 8 && f.precision <= 12))
-    return "on-device entropy decoding: 8-bit frames (8..12-bit residual frames of JPEG XT) only";
+  // (12-bit frames: the same int16 store as the host decoder's, a coefficient beyond it sends the frame there like everywhere)
+  if (f.precision < 8 || f.precision > 12 || (xt_part && !residual_frame && f.precision != 8))
+    return "on-device entropy decoding: frames of 8 to 12 bits (JPEG XT: an 8-bit legacy frame)";
   if (h.scans.empty() || h.scans.size() > 4096) return "on-device entropy decoding: no scans, or more than the device path plans for";
   if (!h.every_component_seen()) return "on-device entropy decoding: a component appears in no scan (the host decoder supplies its stand-in)";
   for (int c = 0; c < f.components; c++)
@@ -1727,7 +1729,8 @@ try {
   // progressive frames and frames with hidden refinement scans: every scan one restart interval per lane (huffman_prog_kernel)
   auto many_scans = [](const HostDecoder &x) { return x.info.progressive != 0 || x.has_hidden_scans() || x.scans.size() != 1; };
   static const bool no_multiscan = getenv("MIJPEG_NO_DEVICE_MULTISCAN") != nullptr; // A-B comparisons
-  const bool multiscan = !no_multiscan && (many_scans(d->host) || (res && many_scans(*res)));
+  // (... and 12-bit frames, whose single scan the sequential kernel's path declines: round 6)
+  const bool multiscan = !no_multiscan && (many_scans(d->host) || (res && many_scans(*res)) || (!res && d->host.info.precision != 8));
   if (multiscan) {
     if (const char *why = multiscan_obstacle(d->host, res != nullptr, false)) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, why);
     if (res)

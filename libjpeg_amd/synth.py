@@ -90,10 +90,12 @@ def to_12bit(jpeg8: bytes, scale: int = 16) -> bytes:
             out += bytes((0xFF, 0xDB, (len(body) + 2) >> 8, (len(body) + 2) & 255)) + body
         elif m == 0xC0 or m == 0xC1:  # SOF0 / SOF1, P = 8 -> SOF1, P = 12
             out += bytes((0xFF, 0xC1)) + jpeg8[p + 2:p + 4] + bytes((12,)) + seg[1:]
+        elif m == 0xC2:  # a progressive frame stays one: SOF2, P = 12 (its later scans carry DHT segments of their own: copied as they are)
+            out += bytes((0xFF, 0xC2)) + jpeg8[p + 2:p + 4] + bytes((12,)) + seg[1:]
         else:
             out += jpeg8[p:p + 2 + ln]
         p += 2 + ln
         if m == 0xDA:
-            out += jpeg8[p:]
+            out += jpeg8[p:]  # (everything behind the first scan header as it is: later scans' tables are Huffman tables, not DQT)
             break
     return bytes(out)

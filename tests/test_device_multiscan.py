@@ -152,3 +152,17 @@ def test_damaged_progressive_streams_leave_the_device_path(oracle, dec, hostdec)
             for c in range(dec.info.components):
                 assert np.array_equal(dec.coefficients(c), hostdec.coefficients(c)), (kind, c)
     assert n >= 10
+
+
+@pytest.mark.parametrize("sub,dri,prog", [("444", 2, False), ("420", 3, False), ("420", 4, True), ("422", 1, True)])
+def test_12bit_frames_on_the_device(oracle, dec, hostdec, sub, dri, prog):
+    """SOF1 / SOF2 frames of twelve bits (round 6: the device decoders took 8-bit frames only): same coefficient planes as the host
+    decoder's, the 16-bit samples the oracle's; the goldens written by the reference with them."""
+    data = synth.to_12bit(synth.synth_jpeg(328, 200, 31 + dri, 88, sub, dri, progressive=prog))
+    info = same_coefficients(dec, hostdec, data)
+    assert info.precision == 12 and bool(info.progressive) == prog
+    assert np.array_equal(dec.reconstruct(), oracle.decode16(data))
+    for name in ("p12_64x48_444", "p12_120x90_420_dri3"):
+        data = golden(name)
+        same_coefficients(dec, hostdec, data)
+        assert np.array_equal(dec.reconstruct(), oracle.decode16(data))
