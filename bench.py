@@ -1039,6 +1039,30 @@ def main():
             "note": "bytes -> header parse + restart marker search on the host -> H2D of the compressed stream -> "
                     "huffman_scan_kernel (one lane per restart interval) -> fused kernel -> D2H of the pixels"}
     if rank == 0 and world == 1 and not args.no_end_to_end:
+        # progressive frames with restart markers: every scan on the device since round 6 (huffman_prog_kernel), host decoder beside it
+        try:
+            pdata = synth.synth_jpeg(W, H, seed=1234 + 17 * rank, quality=85, subsampling=args.subsampling, restart_mcus=8, progressive=True)
+            pr = {}
+            for mode in ("host", "prefer-gpu"):
+                ts = []
+                for _ in range(4):
+                    t = time.perf_counter()
+                    dec.read(pdata, entropy=mode)
+                    ts.append(time.perf_counter() - t)
+                pr[mode] = (min(ts), dec.entropy_used)
+            dec.read(pdata, entropy="prefer-gpu")
+            dev_px = torch.empty((H, row), dtype=torch.uint8, device="cuda")
+            dec.reconstruct_device(dev_px.data_ptr(), row)
+            ok = verify_against_oracle([(dev_px, pdata)])
+            del dev_px
+            result["end_to_end"]["progressive"] = {
+                "stream_bytes": len(pdata), "read_ms_host": round(pr["host"][0] * 1e3, 2), "read_ms_prefer_gpu": round(pr["prefer-gpu"][0] * 1e3, 2),
+                "prefer_gpu_ran_on": pr["prefer-gpu"][1], "verified": ok,
+                "note": "one 8K 4:2:0 Q85 progressive frame (Pillow's scan script, DRI = 8): bytes -> coefficients in HBM; device = header parse + "
+                        "marker search on the host, every scan one restart interval per lane (DC / AC first passes with EOB runs, refinement passes)"}
+        except Exception as e:  # noqa: BLE001 -- a side measurement never costs the headline number
+            result["end_to_end"]["progressive"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_end_to_end:
         # encoder direction of the block pipeline: forward kernels on frames resident in HBM, and one picture
         # from host memory to a baseline stream (upload, kernels, download of the coefficients, entropy coder on the host)
         try:
@@ -1119,6 +1143,8 @@ def main():
                    "xt_rR4_z8_bytes_to_codes_ms": pick(result, "xt_profile_c", "r12_rR4_z8", "bytes_to_half_codes_in_hbm", "ms"),
                    "xt_rR4_z8_verified": pick(result, "xt_profile_c", "r12_rR4_z8", "verified"),
                    "e2e_ms": pick(result, "end_to_end", "ms"), "e2e_device_entropy_ms": pick(result, "end_to_end", "device_entropy", "ms"),
+                   "progressive_read_ms_host": pick(result, "end_to_end", "progressive", "read_ms_host"),
+                   "progressive_read_ms_device": pick(result, "end_to_end", "progressive", "read_ms_prefer_gpu"),
                    "dense_frac": pick(result, "roofline_dense", "dense", "frac"), "reference_encoded_frac": pick(result, "roofline_reference_encoded", "frac")}
         for k, v in summary.items():
             if k != "verified":
