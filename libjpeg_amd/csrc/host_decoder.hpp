@@ -302,6 +302,9 @@ private:
   // the marker searches of a frame's hidden refinement scans, put off until all their boxes have been walked (add_hidden_scans)
   struct DeferredSearch { size_t scan; const uint8_t *data; size_t size; int type; bool hidden; };
   std::vector<DeferredSearch> *deferred_hidden_ = nullptr;
+  std::vector<DeferredSearch> deferred_scans_; // ... and of a progressive frame's scans: run when parse()'s walk is through
+  void run_deferred_searches(std::vector<DeferredSearch> &searches);
+  static bool defer_progressive_scans(); // (MIJPEG_NO_DEFERRED_SEARCH: A-B)
 };
 
 int default_threads();
