@@ -3530,8 +3530,10 @@ __global__ __launch_bounds__(256, TILE_MINW) void fused_tile_kernel(const Generi
   // one instance per component count: the loops over components and the sample packing have static shapes
   auto phase_b = [&](auto NCc) {
     constexpr int NC = decltype(NCc)::value;
-    // A lane owns TILE_STRIP consecutive lines of one 8-pixel group: what depends on the column alone (the group's place in every
-    // plane, the horizontal phase) is worked out once per strip.  (Measured in round 6, profiles/r06/tile_strips.txt.)
+    // A lane owns TILE_STRIP consecutive lines of one 8-pixel group (what depends on the column alone -- the group's place in every
+    // plane, the horizontal phase -- is then worked out once per strip).  The product is 1: strips of 2 and 4 lines measured 2-6 %
+    // SLOWER on every layout in round 6 (the stores of a wave spread over more lines; profiles/r06/tile_strips.txt); the switch
+    // stays for A-B builds.
     const int strips = (lines + TILE_STRIP - 1) / TILE_STRIP;
     for (int it = tid; it < groups * strips; it += 256) {
       const int st = div_recip(it, rgroups), g = mad24(st, -groups, it);
