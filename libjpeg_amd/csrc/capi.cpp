@@ -125,6 +125,7 @@ struct mijpeg_decoder {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t chain_ev = nullptr; // mijpeg_stream_wait
   hipEvent_t ms_ready = nullptr, ms_done = nullptr; // device_entropy_multiscan: the second frame's stream
+  hipStream_t ms_stream = nullptr;
   int err_code = 0;
   std::string err_msg;
   double timing[4] = {0, 0, 0, 0};
@@ -295,6 +296,7 @@ static void quiesce(mijpeg_decoder *d)
   if (d->device < 0) return;
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->copy_stream) (void)hipStreamSynchronize(d->copy_stream);
+  if (d->ms_stream) (void)hipStreamSynchronize(d->ms_stream);
 }
 
 // A batch that was submitted (mijpeg_submit_batch_device) and not waited for still reads the pinned staging buffers
@@ -350,6 +352,7 @@ try {
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     if (d->copy_stream) (void)hipStreamSynchronize(d->copy_stream); // (the buffers below may go to another object)
+    if (d->ms_stream) (void)hipStreamSynchronize(d->ms_stream);
     release_big(d->device, true, d->coef_host, d->coef_host_cap * sizeof(int16_t));
     release_big(d->device, true, d->img_host, d->img_host_cap);
     release_big(d->device, false, d->coef_dev, d->coef_dev_cap * sizeof(int16_t));
@@ -380,6 +383,7 @@ try {
     if (d->chain_ev) (void)hipEventDestroy(d->chain_ev);
     if (d->ms_ready) (void)hipEventDestroy(d->ms_ready);
     if (d->ms_done) (void)hipEventDestroy(d->ms_done);
+    if (d->ms_stream) (void)hipStreamDestroy(d->ms_stream);
     if (d->stream) (void)hipStreamDestroy(d->stream);
   } else {
     free(d->coef_host);
@@ -1505,8 +1509,6 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
       it.level = level[j];
       const int64_t total_mcus = (int64_t)b.mcus_x * b.mcus_y;
       it.nint = b.restart_interval > 0 ? (total_mcus + b.restart_interval - 1) / b.restart_interval : 1;
-      it.stream_off = stream_bytes;
-      stream_bytes += align16(b.unstuffed_size) + HUFF_STREAM_PAD;
       it.table_off = table_bytes;
       for (int k = 0; k < b.ncomp; k++) {
         it.dc_tab[k] = it.ac_tab[k] = 0;
@@ -1520,6 +1522,19 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
       frame_levels[(size_t)fi] = std::max(frame_levels[(size_t)fi], level[j] + 1);
       items.push_back(it);
     }
+  }
+  // The entropy coded data lies in the upload level by level: what the first launches read goes up first, and the rest is
+  // gathered and uploaded while they run (level_end[l]: end of level l's bytes).
+  int n_levels = 0;
+  for (int fi = 0; fi < nframes; fi++) n_levels = std::max(n_levels, frame_levels[(size_t)fi]);
+  std::vector<size_t> level_end((size_t)n_levels, 0);
+  for (int lv = 0; lv < n_levels; lv++) {
+    for (Item &it : items)
+      if (it.level == lv) {
+        it.stream_off = stream_bytes;
+        stream_bytes += align16(frames[it.frame].h->scans[it.scan].unstuffed_size) + HUFF_STREAM_PAD;
+      }
+    level_end[(size_t)lv] = stream_bytes;
   }
   if (stream_bytes > 0xfffffff0ull || total_intervals > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "file too large for one device decode");
   // the largest launch decides whether the device is worth the trip ("auto") and how many lanes of a wave decode
@@ -1564,7 +1579,7 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
   ProgGroup *groups = (ProgGroup *)(hp + off_grp);
   // groups in launch order: frame, level, scan
   std::vector<std::pair<int64_t, int64_t>> launches; // [first group, groups) of every (frame, level)
-  std::vector<int> launch_frame;
+  std::vector<int> launch_frame, launch_level;
   int64_t g = 0;
   for (int fi = 0; fi < nframes; fi++)
     for (int lv = 0; lv < frame_levels[(size_t)fi]; lv++) {
@@ -1578,7 +1593,7 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
           g++;
         }
       }
-      if (g > g0) { launches.push_back(std::make_pair(g0, g - g0)); launch_frame.push_back(fi); }
+      if (g > g0) { launches.push_back(std::make_pair(g0, g - g0)); launch_frame.push_back(fi); launch_level.push_back(lv); }
     }
   for (size_t ii = 0; ii < items.size(); ii++) {
     const Item &it = items[ii];
@@ -1617,16 +1632,20 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
     }
   }
   mark("tables + intervals");
-  // the entropy coded data of every scan without its stuffing, gathered by the pool
-  {
+  // The entropy coded data of every scan without its stuffing, gathered by the pool in two goes: what the first launches read
+  // (level 0 of every frame), then the rest -- while the copy engine brings up the first part and the first launches run.
+  // Uploads on the copy stream, one event per level; the frames' launches wait for their level's event.
+  auto gather = [&](int lv0, int lv1) {
     struct Job { size_t item; HostDecoder::UnstuffPiece piece; };
     std::vector<Job> jobs;
     std::vector<HostDecoder::UnstuffPiece> ps;
     for (size_t ii = 0; ii < items.size(); ii++) {
+      if (items[ii].level < lv0 || items[ii].level >= lv1) continue;
       ps.clear();
       frames[items[ii].frame].h->unstuff_pieces(items[ii].scan, (size_t)256 << 10, ps);
       for (const auto &pc : ps) jobs.push_back(Job{ii, pc});
     }
+    if (jobs.empty()) return;
     const int workers = std::max(1, std::min<int>((int)jobs.size(), std::min(default_threads(), 32)));
     parallel_for(workers, [&](int w) {
       for (size_t k = (size_t)w; k < jobs.size(); k += (size_t)workers) {
@@ -1634,18 +1653,23 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
         frames[it.frame].h->unstuff_piece(it.scan, jobs[k].piece, d->stage_host + it.stream_off);
       }
     });
+  };
+  if (!d->copy_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+  while (d->copy_events.size() < (size_t)n_levels) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(d, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    d->copy_events.push_back(e);
   }
-  mark("streams gathered");
-  HIP_TRY(d, hipMemcpyAsync(d->ent_dev, d->stage_host, stream_bytes, hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part, hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
-  // coefficients accumulate over the scans: the planes start out as zeros (coding/blockrow.cpp:77-87)
-  for (int fi = 0; fi < nframes; fi++) {
-    const mijpeg_info &f = frames[fi].h->info;
-    int64_t count = 0;
-    for (int c = 0; c < f.components; c++) count += (int64_t)f.blocks_w[c] * f.blocks_h[c] * 64;
-    HIP_TRY(d, hipMemsetAsync(d->coef_dev + frames[fi].base16, 0, (size_t)count * (frames[fi].wide ? 4 : 2), d->stream));
-  }
+  if (d->ent_free_valid) HIP_TRY(d, hipStreamWaitEvent(d->copy_stream, d->ent_free, 0));
+  auto upload_levels = [&](int lv0, int lv1) -> int {
+    for (int lv = lv0; lv < lv1; lv++) {
+      const size_t b0 = lv ? level_end[(size_t)lv - 1] : 0, b1 = level_end[(size_t)lv];
+      if (lv == 0) HIP_TRY(d, hipMemcpyAsync(d->ent_dev + stream_bytes, d->ent_host, host_part, hipMemcpyHostToDevice, d->copy_stream));
+      if (b1 > b0) HIP_TRY(d, hipMemcpyAsync(d->ent_dev + b0, d->stage_host + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
+      HIP_TRY(d, hipEventRecord(d->copy_events[(size_t)lv], d->copy_stream));
+    }
+    return 0;
+  };
   ProgArgs a;
   memset(&a, 0, sizeof(a));
   a.data = d->ent_dev;
@@ -1656,25 +1680,57 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
   a.waves_per_group = waves;
   a.max_tables = max_tables;
   a.tables = d->ent_dev + off_tab;
-  // the two frames of a JPEG XT file share nothing: the second one's launches go to a stream of their own, behind the uploads
-  // and the clearing of the planes, and the object's stream waits for them before the range pass
+  // the two frames of a JPEG XT file share nothing: the second one's launches go to a stream of their own
   hipStream_t second = d->stream;
   if (nframes > 1) {
-    if (!d->copy_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    if (!d->ms_stream) HIP_TRY(d, hipStreamCreateWithFlags(&d->ms_stream, hipStreamNonBlocking));
     if (!d->ms_ready) HIP_TRY(d, hipEventCreateWithFlags(&d->ms_ready, hipEventDisableTiming));
     if (!d->ms_done) HIP_TRY(d, hipEventCreateWithFlags(&d->ms_done, hipEventDisableTiming));
-    second = d->copy_stream;
+    second = d->ms_stream;
+  }
+  auto launch_levels = [&](int lv0, int lv1) -> int {
+    for (size_t li = 0; li < launches.size(); li++) {
+      const int fi = launch_frame[li], lv = launch_level[li];
+      if (lv < lv0 || lv >= lv1) continue;
+      hipStream_t st = fi == 0 ? d->stream : second;
+      HIP_TRY(d, hipStreamWaitEvent(st, d->copy_events[(size_t)lv], 0));
+      a.groups = (const ProgGroup *)(d->ent_dev + off_grp) + launches[li].first;
+      a.n_groups = (int32_t)launches[li].second;
+      a.wide = frames[fi].wide ? 1 : 0;
+      a.coef = (void *)(d->coef_dev + frames[fi].base16);
+      a.status = (uint32_t *)(d->ent_dev + off_status) + 8 * fi;
+      if (launch_huffman_prog(a, st)) return hip_fail(d, hipGetLastError(), "huffman_prog_kernel launch");
+    }
+    return 0;
+  };
+  // where to cut: behind the first level that brings a quarter of the bytes (a progressive frame's DC scan alone is over before
+  // anything could hide behind it); no cut when that is the last level
+  int cut = n_levels;
+  for (int lv = 0; lv + 1 < n_levels; lv++)
+    if (level_end[(size_t)lv] * 4 >= stream_bytes) { cut = lv + 1; break; }
+  const char *split_env = getenv("MIJPEG_MS_SPLIT"); // A-B: 0 = one gather, then everything enqueued
+  if (split_env && atoi(split_env) == 0) cut = n_levels;
+  gather(0, cut);
+  mark("first levels gathered");
+  if ((rc = upload_levels(0, cut))) return rc;
+  HIP_TRY(d, hipMemsetAsync(d->ent_dev + off_status, 0, status_bytes, d->stream));
+  if (nframes > 1) { // (behind whatever the object's stream still does with the planes, and the cleared status words)
     HIP_TRY(d, hipEventRecord(d->ms_ready, d->stream));
     HIP_TRY(d, hipStreamWaitEvent(second, d->ms_ready, 0));
   }
-  for (size_t li = 0; li < launches.size(); li++) {
-    const int fi = launch_frame[li];
-    a.groups = (const ProgGroup *)(d->ent_dev + off_grp) + launches[li].first;
-    a.n_groups = (int32_t)launches[li].second;
-    a.wide = frames[fi].wide ? 1 : 0;
-    a.coef = (void *)(d->coef_dev + frames[fi].base16);
-    a.status = (uint32_t *)(d->ent_dev + off_status) + 8 * fi;
-    if (launch_huffman_prog(a, fi == 0 ? d->stream : second)) return hip_fail(d, hipGetLastError(), "huffman_prog_kernel launch");
+  // coefficients accumulate over the scans: the planes start out as zeros (coding/blockrow.cpp:77-87)
+  for (int fi = 0; fi < nframes; fi++) {
+    const mijpeg_info &f = frames[fi].h->info;
+    int64_t count = 0;
+    for (int c = 0; c < f.components; c++) count += (int64_t)f.blocks_w[c] * f.blocks_h[c] * 64;
+    HIP_TRY(d, hipMemsetAsync(d->coef_dev + frames[fi].base16, 0, (size_t)count * (frames[fi].wide ? 4 : 2), fi == 0 ? d->stream : second));
+  }
+  if ((rc = launch_levels(0, cut))) return rc;
+  if (cut < n_levels) {
+    gather(cut, n_levels);
+    mark("other levels gathered");
+    if ((rc = upload_levels(cut, n_levels))) return rc;
+    if ((rc = launch_levels(cut, n_levels))) return rc;
   }
   if (second != d->stream) {
     HIP_TRY(d, hipEventRecord(d->ms_done, second));
