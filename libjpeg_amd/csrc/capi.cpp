@@ -1537,26 +1537,31 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
     level_end[(size_t)lv] = stream_bytes;
   }
   if (stream_bytes > 0xfffffff0ull || total_intervals > 0x7fffffff) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "file too large for one device decode");
-  // the largest launch decides whether the device is worth the trip ("auto") and how many lanes of a wave decode
-  int64_t widest = 0;
+  // the largest launch decides whether the device is worth the trip ("auto"); every launch -- the scans of one level of one
+  // frame -- picks how many lanes of a wave decode by its own number of intervals: fewer lanes = more waves, less divergence
+  int lanes_env = 0;
+  if (const char *e = getenv("MIJPEG_HUFF_LANES")) { // tuning
+    const int l = atoi(e);
+    if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) lanes_env = l;
+  }
+  const int waves = 4;
+  int64_t widest = 0, n_groups = 0;
+  std::vector<std::vector<int>> level_lanes((size_t)nframes);
   for (int fi = 0; fi < nframes; fi++)
     for (int lv = 0; lv < frame_levels[(size_t)fi]; lv++) {
       int64_t n = 0;
       for (const Item &it : items)
         if (it.frame == fi && it.level == lv) n += it.nint;
       widest = std::max(widest, n);
+      int lanes = 64;
+      while (lanes > 1 && n / lanes < 768) lanes >>= 1;
+      if (lanes_env) lanes = lanes_env;
+      level_lanes[(size_t)fi].push_back(lanes);
+      for (const Item &it : items)
+        if (it.frame == fi && it.level == lv) n_groups += (it.nint + lanes * waves - 1) / (lanes * waves);
     }
   if (min_intervals <= 0) min_intervals = 2048;
   if (widest < min_intervals) return set_error(d, MIJPEG_ERR_NOT_AVAILABLE, "too few restart intervals to occupy the device");
-  int lanes = 64;
-  while (lanes > 1 && widest / lanes < 768) lanes >>= 1;
-  if (const char *e = getenv("MIJPEG_HUFF_LANES")) { // tuning
-    const int l = atoi(e);
-    if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) lanes = l;
-  }
-  const int waves = 4, per_group = lanes * waves;
-  int64_t n_groups = 0;
-  for (const Item &it : items) n_groups += (it.nint + per_group - 1) / per_group;
   // device buffer: [streams][ibegin][iend][tables][scans][groups][status: 8 dwords per frame]
   const size_t off_ib = stream_bytes, off_ie = off_ib + (size_t)total_intervals * 4, off_tab = align16(off_ie + (size_t)total_intervals * 4);
   const size_t off_scan = align16(off_tab + table_bytes), off_grp = align16(off_scan + items.size() * sizeof(ProgScanDev));
@@ -1584,6 +1589,7 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
   for (int fi = 0; fi < nframes; fi++)
     for (int lv = 0; lv < frame_levels[(size_t)fi]; lv++) {
       const int64_t g0 = g;
+      const int per_group = level_lanes[(size_t)fi][(size_t)lv] * waves;
       for (size_t ii = 0; ii < items.size(); ii++) {
         const Item &it = items[ii];
         if (it.frame != fi || it.level != lv) continue;
@@ -1676,7 +1682,6 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
   a.ibegin = (const uint32_t *)(d->ent_dev + off_ib);
   a.iend = (const uint32_t *)(d->ent_dev + off_ie);
   a.scans = (const ProgScanDev *)(d->ent_dev + off_scan);
-  a.lanes = lanes;
   a.waves_per_group = waves;
   a.max_tables = max_tables;
   a.tables = d->ent_dev + off_tab;
@@ -1696,6 +1701,7 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
       HIP_TRY(d, hipStreamWaitEvent(st, d->copy_events[(size_t)lv], 0));
       a.groups = (const ProgGroup *)(d->ent_dev + off_grp) + launches[li].first;
       a.n_groups = (int32_t)launches[li].second;
+      a.lanes = level_lanes[(size_t)fi][(size_t)lv];
       a.wide = frames[fi].wide ? 1 : 0;
       a.coef = (void *)(d->coef_dev + frames[fi].base16);
       a.status = (uint32_t *)(d->ent_dev + off_status) + 8 * fi;

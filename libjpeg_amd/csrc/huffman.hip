@@ -128,6 +128,28 @@ struct DevBits {
   }
   __device__ __forceinline__ uint32_t window() const { return win; }
   __device__ __forceinline__ void skip(int k) { bp += (uint32_t)k; }
+  // refill() for a reader that may have moved on by more than one dword since the last one (refill() follows the window over
+  // one at most; slow() takes the three registers from the ring again)
+  __device__ __forceinline__ void refill_far()
+  {
+    const uint32_t nd = bp >> 5;
+    if (__builtin_expect(bp + 32u > lim || nd - d > 1u, 0)) { slow(); return; }
+    const bool adv = nd != d;
+    B0 = adv ? B1 : B0;
+    B1 = adv ? __builtin_bswap32(R2) : B1;
+    R2 = ld_raw(nd + 2);
+    d = nd;
+    win = (uint32_t)(((((uint64_t)B0) << 32 | B1) << (bp & 31u)) >> 32);
+  }
+  // up to 64 bits from bit address `at` on, left-aligned, straight from the ring (which is topped up as far as they reach)
+  __device__ __forceinline__ uint64_t peek64(uint32_t at, int n)
+  {
+    while (8u * fill < at + (uint32_t)n) commit(fetch(fill));
+    const uint32_t i = at >> 5, sh = at & 31u;
+    const uint32_t d0 = ld(i), d1 = ld(i + 1), d2 = ld(i + 2);
+    const uint32_t hi = (uint32_t)(((((uint64_t)d0) << 32 | d1) << sh) >> 32), lo = (uint32_t)(((((uint64_t)d1) << 32 | d2) << sh) >> 32);
+    return ((uint64_t)hi << 32) | lo;
+  }
 };
 
 // Huffman code at the top of the 32-bit window -> (tot << 8) | symbol, tot = code length + value bits that follow (what the
@@ -684,86 +706,140 @@ __device__ __forceinline__ int prog_block_first(DevBits &br, const HuffDevTable 
   return 0;
 }
 
-// Refinement pass of a block, the statements of the host's decode_block_refine (refinementscan.cpp:584-700).
+// scan position k[p] of natural position p and natural position zz[k] of scan position k, for straight-line code
+struct ProgUnzz {
+  uint8_t k[64], zz[64];
+  constexpr ProgUnzz() : k{}, zz{}
+  {
+    constexpr uint8_t order[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    for (int i = 0; i < 64; i++) {
+      zz[i] = order[i];
+      k[order[i]] = (uint8_t)i;
+    }
+  }
+};
+constexpr ProgUnzz PROG_UNZZ;
+
+// Refinement pass of a block (refinementscan.cpp:584-700; T.81 G.1.2.3), in three steps so that what is serial -- one
+// Huffman symbol after the other, each of which says how far to go -- is a short loop per SYMBOL and everything per
+// coefficient is the same straight code in every lane:
+//   1. the block's non-zero pattern H in scan order (bit k = scan position k), from the slot, sixteen bytes at a time, and
+//      the list of the band's FREE positions (scan position and natural position, two bytes each) in the lane's LDS;
+//   2. per symbol: its target is the free position r entries on in that list; the history positions passed on the way
+//      take one correction bit each -- target - cursor - r of them, and they follow the symbol in the data in position
+//      order, so they are taken in one piece (from the reader's window when they fit) and appended to the block's string of
+//      correction bits CC; a new coefficient goes straight into the slot;
+//   3. every coefficient once: a history coefficient takes the bit of CC its rank in H names.
+// Same statements as the host's decode_block_refine, same verdicts.
+constexpr int PROG_ZLIST_PITCH = 132; // 64 entries of two bytes + a bank's worth, so that lanes at the same entry do not collide
 template <class T>
-__device__ __forceinline__ int prog_block_refine(DevBits &br, const HuffDevTable *ac, const uint8_t *zz, const ProgStore<T> &st, int &skip, int ss, int se,
-                                                 int al)
+__device__ __forceinline__ int prog_block_refine(DevBits &br, const HuffDevTable *ac, const ProgStore<T> &st, uint16_t *zl, int &skip, int ss, int se, int al)
 {
   if (ss == 0) {
-    br.refill();
+    br.refill_far(); // (the block before this one may have left the reader several dwords on)
     const int bit = (int)(br.window() >> 31);
     br.skip(1);
     st.put(0, st.get(0) | (bit << al));
   }
-  if (se) {
-    int k = ss, run = 0, s = 0;
-    bool at_start = false, overflow = false;
-    if (skip > 0) { run = se - ss + 1; skip--; }
-    else { k--; at_start = true; }
-    // correction bits come one at a time, up to 63 per block: they are taken from a copy of the reader's window (32 bits that
-    // are valid from the reader's position on), which is fetched again when it runs dry or a symbol is due
-    uint32_t cw = 0;
-    int chave = 0;
-    // the coefficient of the NEXT position is asked for one step ahead (a step only writes its own position): the two dependent
-    // LDS reads -- scan order, then the coefficient -- are off the step-to-step chain
-    int pos_c = zz[ss], data_c = st.get(pos_c);
-    do {
-      if (!at_start) {
-        const int pos = pos_c, data = data_c;
-        pos_c = zz[k + 1];
-        data_c = st.get(pos_c);
-        if (data) { // a correction bit: one step away from zero, or nothing
-          if (chave == 0) {
-            br.refill();
-            cw = br.window();
-            chave = 32;
-          }
-          const int bit = (int)(cw >> 31);
-          cw <<= 1;
-          chave--;
-          br.skip(1);
-          const int nv = data + ((int)((uint32_t)((data >> 31) | 1) << al) & -bit);
-          overflow |= nv != (int)(T)nv;
-          st.put(pos, nv);
-          continue;
-        }
-        if (run) { run--; continue; }
-        st.put(pos, (int)((uint32_t)s << al));
-        if (k == se) break;
-      }
-      at_start = false;
-      br.refill();
-      chave = 0;
-      const uint32_t win = br.window();
-      const uint32_t e = dev_lookup<2>(win, ac);
-      if (e >= (uint32_t)HUFF_DEV_INVALID) return HUFF_ERR_MALFORMED;
-      const int rs = (int)(e & 0xff), r = rs >> 4, tot = (int)((e >> 8) & 31u);
-      s = rs & 15;
-      br.skip(tot);
-      if (s == 0) {
-        if (r == 15) run = 15;
-        else {
-          skip = (int)((1u << r) | __builtin_amdgcn_ubfe(win, (uint32_t)(32 - tot), (uint32_t)r)) - 1;
-          run = se - k + 1;
-        }
-      } else {
-        if (s != 1) return HUFF_ERR_MALFORMED; // (the reference warns and decodes on: its walk on the host)
-        if (!__builtin_amdgcn_ubfe(win, (uint32_t)(32 - tot), 1u)) s = -1; // the sign bit behind the code
-        run = r;
-      }
-    } while (++k <= se);
-    if (overflow) return HUFF_ERR_OVERFLOW;
+  if (!se) return 0;
+  constexpr int PER = 16 / (int)sizeof(T), CHUNKS = 64 / PER;
+  uint32_t hlo = 0, hhi = 0;
+#pragma unroll
+  for (int ch = 0; ch < CHUNKS; ch++) {
+    const u32x4 w = *reinterpret_cast<const u32x4 *>(st.slot + (((uint32_t)ch << 4) ^ st.swz));
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      const int k = PROG_UNZZ.k[ch * PER + e];
+      const int v = sizeof(T) == 4 ? (int)w[e] : (int)(short)(w[e >> 1] >> ((e & 1) * 16));
+      if (k < 32) hlo |= v ? 1u << k : 0u;
+      else hhi |= v ? 1u << (k - 32) : 0u;
+    }
   }
-  return 0;
+  const uint64_t band = (~0ull << ss) & (~0ull >> (63 - se));
+  const uint32_t Hlo = hlo & (uint32_t)band, Hhi = hhi & (uint32_t)(band >> 32);
+  const uint32_t zlo = ~hlo & (uint32_t)band, zhi = ~hhi & (uint32_t)(band >> 32);
+  int nz = 0;
+#pragma unroll
+  for (int k = 0; k < 64; k++) { // (written at every step, kept where the position is free)
+    zl[nz] = (uint16_t)(k | (PROG_UNZZ.zz[k] << 8));
+    nz += (int)((k < 32 ? zlo >> k : zhi >> (k - 32)) & 1u);
+  }
+  const int nHlo = __popc(Hlo), nH = nHlo + __popc(Hhi);
+  const int one = (int)(1u << al);
+  uint64_t CC = 0;
+  int count = 0, passed = 0, zi = 0, k = ss;
+  bool eob = false, bad = false;
+  if (skip > 0) { skip--; eob = true; } // inside an EOB run: corrections only
+  while (!eob && k <= se) {
+    br.refill_far();
+    const uint32_t win = br.window();
+    const uint32_t e = dev_lookup<2>(win, ac);
+    const int rs = (int)(e & 0xff), r = rs >> 4, s = rs & 15, tot = (int)((e >> 8) & 31u);
+    if (e >= (uint32_t)HUFF_DEV_INVALID || s > 1) { // (a size beyond one: the reference warns and decodes on -- its walk on the host)
+      bad = true;
+      break;
+    }
+    if (s == 0 && r < 15) { // EOBr: the rest of the band, in this block and the next `skip`, only takes its corrections
+      skip = (int)((1u << r) | __builtin_amdgcn_ubfe(win, (uint32_t)(32 - tot), (uint32_t)r)) - 1;
+      br.skip(tot);
+      eob = true;
+      break;
+    }
+    const int j = zi + r; // (ZRL: the sixteenth free position from here, which stays zero)
+    zi = j + 1;
+    const bool found = j < nz;
+    const uint32_t ent = found ? (uint32_t)zl[j] : 64u;
+    const int target = (int)(ent & 0xffu);
+    const int ncorr = found ? target - k - r : nH - passed; // the history positions between the cursor and the target
+    if (ncorr) {
+      uint64_t chunk;
+      if (tot + ncorr <= 32) chunk = (uint64_t)((win << tot) & (~0u << (32 - ncorr))) << 32;
+      else chunk = br.peek64(br.bp + (uint32_t)tot, ncorr) & (~0ull << (64 - ncorr));
+      CC |= chunk >> count;
+      count += ncorr;
+      passed += ncorr;
+    }
+    br.bp += (uint32_t)(tot + ncorr);
+    if (s && found) st.put((int)(ent >> 8), __builtin_amdgcn_ubfe(win, (uint32_t)(32 - tot), 1u) ? one : -one); // the sign bit behind the code
+    k = target + 1;
+  }
+  if (eob && nH > passed) { // the history coefficients behind the last symbol
+    const int ncorr = nH - passed;
+    CC |= (br.peek64(br.bp, ncorr) & (~0ull << (64 - ncorr))) >> count;
+    br.bp += (uint32_t)ncorr;
+  }
+  // every coefficient once
+  bool overflow = false;
+#pragma unroll
+  for (int ch = 0; ch < CHUNKS; ch++) {
+    u32x4 *slot = reinterpret_cast<u32x4 *>(st.slot + (((uint32_t)ch << 4) ^ st.swz));
+    const u32x4 w = *slot;
+    u32x4 o = w;
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      const int kp = PROG_UNZZ.k[ch * PER + e];
+      const int v = sizeof(T) == 4 ? (int)w[e] : (int)(short)(w[e >> 1] >> ((e & 1) * 16));
+      const bool hk = kp < 32 ? (Hlo >> kp) & 1u : (Hhi >> (kp - 32)) & 1u;
+      const int rank = kp < 32 ? __popc(Hlo & ((1u << kp) - 1u)) : nHlo + __popc(Hhi & ((1u << (kp - 32)) - 1u));
+      const bool cbit = (uint32_t)((CC << rank) >> 63) != 0;
+      const int nv = v + (hk && cbit ? (v < 0 ? -one : one) : 0);
+      overflow |= nv != (int)(T)nv;
+      if (sizeof(T) == 4) o[e] = (uint32_t)nv;
+      else o[e >> 1] = (e & 1) ? (o[e >> 1] & 0xffffu) | ((uint32_t)nv << 16) : (o[e >> 1] & 0xffff0000u) | ((uint32_t)nv & 0xffffu);
+    }
+    *slot = o;
+  }
+  return bad ? HUFF_ERR_MALFORMED : overflow ? HUFF_ERR_OVERFLOW : 0;
 }
 
-// LDS: [max_tables tables | zigzag order][per wave: L block slots | L rings | L block numbers]
+// LDS: [max_tables tables | zigzag order][per wave: L block slots | L rings | L block numbers | L lists of free positions]
 constexpr int PROG_ZZ_BYTES = 80;
 template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(const ProgArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   constexpr int SLOT = 64 * (int)sizeof(T), CH = SLOT / 16;
-  constexpr int LANE_BYTES = SLOT + RING_PITCH + 16;
+  constexpr int LANE_BYTES = SLOT + RING_PITCH + 16 + PROG_ZLIST_PITCH;
   const int table_bytes = a.max_tables * (int)sizeof(HuffDevTable) + PROG_ZZ_BYTES;
   const uint8_t *zz = lds_raw + table_bytes - PROG_ZZ_BYTES; // (a look-up per coefficient, at a position that differs from lane to lane: LDS, not memory)
   const HuffDevTable *tabs = reinterpret_cast<const HuffDevTable *>(lds_raw);
@@ -774,6 +850,7 @@ template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(co
   uint8_t *stage = lds_raw + table_bytes + wv * (L * LANE_BYTES);
   uint8_t *rings = stage + L * SLOT;
   uint32_t *blkno = reinterpret_cast<uint32_t *>(stage + L * (SLOT + RING_PITCH));
+  uint16_t *zlist = reinterpret_cast<uint16_t *>(stage + L * (SLOT + RING_PITCH + 16) + (lane & (L - 1)) * PROG_ZLIST_PITCH);
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(a.tables + sc.table_off);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
@@ -805,6 +882,7 @@ template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(co
   st.slot = stage + ln * SLOT;
   st.swz = (uint32_t)(lane & (CH - 1)) << 4;
   const bool dc_only = sc.se == 0;
+  const bool fresh = sc.ah == 0 && sc.ss == 0 && sc.se == 63;
   for (int mi = 0; mi < sc.restart_interval; mi++) {
     const int m = m0 + mi;
     const bool live = decoding && m < sc.total_mcus;
@@ -854,13 +932,14 @@ template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(co
           for (int c = lane; c < L * CH; c += 64) { // the wave fetches its L blocks as whole lines
             const int sl = c / CH, ch = c % CH;
             const uint32_t b = blkno[sl];
+            // (a first pass over the whole band meets the zeros the planes were cleared to: nothing to fetch)
             if (b) *reinterpret_cast<u32x4 *>(stage + sl * SLOT + ((ch ^ (sl & (CH - 1))) << 4)) =
-                     *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint8_t *>(coef + ((size_t)(b - 1) << 6)) + ch * 16);
+                     fresh ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint8_t *>(coef + ((size_t)(b - 1) << 6)) + ch * 16);
           }
           wave_lds_sync();
           if (work)
             err = sc.ah == 0 ? prog_block_first<T>(br, dc, ac, zz, st, pred[k], skip[k], sc.ss, sc.se, sc.al, sc.runs_legal != 0)
-                             : prog_block_refine<T>(br, ac, zz, st, skip[k], sc.ss, sc.se, sc.al);
+                             : prog_block_refine<T>(br, ac, st, zlist, skip[k], sc.ss, sc.se, sc.al);
           if (decoding && pend_at == br.fill && br.room()) br.commit(pend0);
           if (decoding && pend_at + 16 == br.fill && br.room()) br.commit(pend1);
           wave_lds_sync();
@@ -886,7 +965,7 @@ int launch_huffman_prog(const ProgArgs &a, hipStream_t stream)
 {
   if (a.n_groups <= 0) return 0;
   const size_t slot = a.wide ? 256 : 128;
-  const size_t lds = (size_t)a.max_tables * sizeof(HuffDevTable) + PROG_ZZ_BYTES + (size_t)a.waves_per_group * a.lanes * (slot + RING_PITCH + 16);
+  const size_t lds = (size_t)a.max_tables * sizeof(HuffDevTable) + PROG_ZZ_BYTES + (size_t)a.waves_per_group * a.lanes * (slot + RING_PITCH + 16 + PROG_ZLIST_PITCH);
   if (a.wide) hipLaunchKernelGGL(huffman_prog_kernel<int32_t>, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
   else hipLaunchKernelGGL(huffman_prog_kernel<int16_t>, dim3(a.n_groups), dim3(64 * a.waves_per_group), lds, stream, a);
   return (int)hipGetLastError();
