@@ -91,6 +91,13 @@ struct XtBox {
   uint64_t boxsize = 0;  // payload bytes the box header announces
   uint64_t parsed = 0;   // payload bytes its segments announced so far (m_uqParsedBytes: counted even where the file ends inside one)
   bool complete = false; // all of them announced: only then the reference's tables know the box (codestream/tables.cpp:1191-1283)
+  // A codestream box of many segments (RESI, FINE, RFIN, the alpha kinds) is not copied segment by segment while the walk goes
+  // over the file: the walk notes where its pieces lie, and HostDecoder::materialize_boxes copies them -- all boxes' pieces, on
+  // the pool -- when the walk is through.  Nothing reads such a box before that.
+  struct Piece { const uint8_t *src; size_t len, pad; }; // (pad: bytes the file no longer had: zeros, io/decoderstream.cpp:136-158)
+  std::vector<Piece> pieces;
+  size_t pending = 0; // bytes of the pieces, padding included
+  bool deferred = false;
 };
 
 // "Virtual restart intervals" of a scan without restart markers: exact restart points (byte, bits to skip, DC
@@ -195,6 +202,7 @@ public:
   // the last parse failed with what the colour transformer refuses (a table or transformation that does not exist or does not fit):
   // the reference reads such a file without complaint and fails at the first request for pixels
   bool transformer_refused() const { return transformer_refused_; }
+  void materialize_boxes();
   int declined_verdict(); // after a parse / decode that ended with -1034: the codestreams' own verdict, else -1034 again
   mijpeg_xt_params xt{};
   std::vector<Scan> scans;
