@@ -973,31 +973,47 @@ int launch_huffman_prog(const ProgArgs &a, hipStream_t stream)
 
 // max over the blocks of a component of sum |c| q (saturating at 2^31 - 1) of finished planes: what selects the arithmetic of
 // the reconstruction (the host decoder's range_pass).  grid (blocks / 256, components)
+// (a lane takes sixteen bytes of a block, the lanes of a block add up what they found: the planes are read in whole lines)
+constexpr int RANGE_ROUNDS = 8; // blocks per lane group and workgroup
 template <class T> __global__ __launch_bounds__(256) void coef_range_kernel(const CoefRangeArgs a)
 {
+  constexpr int PER = 16 / (int)sizeof(T), LPB = 64 / PER, BPG = 256 / LPB; // coefficients per lane, lanes per block, blocks per round
+  __shared__ uint16_t q[64];
   const int c = blockIdx.y;
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < 64) q[threadIdx.x] = a.q[c][threadIdx.x];
+  __syncthreads();
+  const int j = threadIdx.x % LPB;
+  uint32_t qs[PER];
+#pragma unroll
+  for (int e = 0; e < PER; e++) qs[e] = q[j * PER + e];
+  const T *plane = reinterpret_cast<const T *>(a.coef) + a.coef_off[c];
   uint32_t m = 0;
-  if (b < a.nblocks[c]) {
-    const T *p = reinterpret_cast<const T *>(a.coef) + a.coef_off[c] + b * 64;
+#pragma unroll
+  for (int r = 0; r < RANGE_ROUNDS; r++) {
+    const int64_t b = ((int64_t)blockIdx.x * RANGE_ROUNDS + r) * BPG + threadIdx.x / LPB;
     uint64_t sum = 0;
+    if (b < a.nblocks[c]) {
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(plane + b * 64 + j * PER);
 #pragma unroll
-    for (int k = 0; k < 64; k += 16 / (int)sizeof(T)) {
-      const u32x4 v = *reinterpret_cast<const u32x4 *>(p + k);
-#pragma unroll
-      for (int j = 0; j < 16 / (int)sizeof(T); j++) {
+      for (int e = 0; e < PER; e++) {
         int x;
-        if (sizeof(T) == 2) x = (int)(int16_t)(v[j >> 1] >> ((j & 1) * 16));
-        else x = (int)v[j];
+        if (sizeof(T) == 2) x = (int)(int16_t)(v[e >> 1] >> ((e & 1) * 16));
+        else x = (int)v[e];
         const int64_t ax = x < 0 ? -(int64_t)x : (int64_t)x;
-        sum += (uint64_t)ax * a.q[c][k + j];
+        sum += (uint64_t)ax * qs[e];
       }
     }
-    m = (uint32_t)(sum < 0x7fffffffull ? sum : 0x7fffffffull);
+#pragma unroll
+    for (int o = LPB / 2; o > 0; o >>= 1) {
+      const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)sum, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(sum >> 32), o);
+      sum += ((uint64_t)hi << 32) | lo;
+    }
+    m = max(m, (uint32_t)(sum < 0x7fffffffull ? sum : 0x7fffffffull));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(&a.status[1 + c], m);
+  // (one word per component takes every group's maximum: asked only by groups that would raise it)
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&a.status[1 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.status[1 + c], m);
 }
 
 int launch_coef_range(const CoefRangeArgs &a, hipStream_t stream)
@@ -1005,7 +1021,8 @@ int launch_coef_range(const CoefRangeArgs &a, hipStream_t stream)
   int64_t most = 0;
   for (int c = 0; c < a.ncomp; c++) most = a.nblocks[c] > most ? a.nblocks[c] : most;
   if (most <= 0 || a.ncomp <= 0) return 0;
-  const dim3 grid((unsigned)((most + 255) / 256), (unsigned)a.ncomp);
+  const int64_t per_group = (int64_t)RANGE_ROUNDS * (a.wide ? 16 : 32);
+  const dim3 grid((unsigned)((most + per_group - 1) / per_group), (unsigned)a.ncomp);
   if (a.wide) hipLaunchKernelGGL(coef_range_kernel<int32_t>, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(coef_range_kernel<int16_t>, grid, dim3(256), 0, stream, a);
   return (int)hipGetLastError();
