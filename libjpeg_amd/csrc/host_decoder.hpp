@@ -203,6 +203,10 @@ public:
   // the reference reads such a file without complaint and fails at the first request for pixels
   bool transformer_refused() const { return transformer_refused_; }
   void materialize_boxes();
+  size_t segment_end(const uint8_t *base, size_t size, size_t from);
+  const uint8_t *term_base_ = nullptr; // segment_end's list of segment-ending markers: of which bytes, from where on
+  size_t term_size_ = 0, term_from_ = 0;
+  std::vector<size_t> term_pos_;
   int declined_verdict(); // after a parse / decode that ended with -1034: the codestreams' own verdict, else -1034 again
   mijpeg_xt_params xt{};
   std::vector<Scan> scans;

@@ -90,6 +90,20 @@ def test_parallel_marker_search_on_a_stream_of_several_chunks(oracle, dri, progr
     d.close()
 
 
+@pytest.mark.parametrize("dri", [8, 0])
+def test_segment_ends_of_a_large_progressive_file_come_from_one_pass_of_the_pool(oracle, dri):
+    """Beyond 2 MiB the planning walk over a progressive frame asks HostDecoder::segment_end, which has the pool note every
+    segment-ending marker of the file once and answers every scan from that list."""
+    data = synth.encode_jpeg(synth.synth_image(3200, 2000, 11), 97, "444", restart_mcus=dri, progressive=True)
+    assert len(data) > (5 << 19)
+    d = api.Decoder(None)
+    f = d.read(data, 4)
+    _, planes = oracle.decode_coefficients(data)
+    for c in range(f.components):
+        assert np.array_equal(d.coefficients(c), planes[c].astype(np.int16))
+    d.close()
+
+
 @pytest.mark.parametrize("w,h,sub,q", [(2560, 1440, "444", 95), (3840, 2160, "420", 85), (1600, 1200, "422", 90), (2048, 2048, "gray", 92)])
 def test_streams_without_restart_markers_decode_in_parallel(oracle, w, h, sub, q):
     """No DRI: the entropy coded segment is cut into ranges that are decoded speculatively and stitched where they
