@@ -1653,11 +1653,7 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
     }
     if (jobs.empty()) return;
     const int workers = std::max(1, std::min<int>((int)jobs.size(), std::min(default_threads(), 32)));
-    if (trace_phases) {
-      size_t bytes = 0, largest = 0;
-      for (const Job &jb : jobs) { bytes += jb.piece.src1 - jb.piece.src0; largest = std::max(largest, jb.piece.src1 - jb.piece.src0); }
-      fprintf(stderr, "[mijpeg multiscan]   gather of levels %d..%d: %zu pieces, %zu bytes, largest %zu, %d workers\n", lv0, lv1 - 1, jobs.size(), bytes, largest, workers);
-    }
+    if (trace_phases) fprintf(stderr, "[mijpeg multiscan]   gather of levels %d..%d: %zu pieces on %d workers\n", lv0, lv1 - 1, jobs.size(), workers);
     parallel_for(workers, [&](int w) {
       for (size_t k = (size_t)w; k < jobs.size(); k += (size_t)workers) {
         const Item &it = items[jobs[k].item];
