@@ -406,6 +406,45 @@ print("checked", n)
         assert "checked 9" in r.stdout
 
 
+def test_progressive_scans_searched_in_tiny_chunks_give_the_same_coefficients(oracle):
+    """The restart marker searches of a progressive frame's scans run as one list of chunk tasks (run_deferred_searches); with
+    MIJPEG_MARKER_CHUNK the chunks are a few bytes long and every seam -- a marker, a stuffed pair, a fill byte astride two
+    chunks -- is met: same coefficient planes as with the default chunks, which are the oracle's."""
+    import subprocess
+    import sys
+    code = """
+import sys, os, hashlib, numpy as np
+sys.path.insert(0, %r)
+from libjpeg_amd import api, synth
+rng = np.random.default_rng(5)
+for dri in (1, 3, 8):
+    for img in (rng.integers(0, 256, (72, 104, 3)).astype(np.uint8), synth.synth_image(200, 120, 5 + dri)):
+        data = synth.encode_jpeg(img, 95, "420", restart_mcus=dri, progressive=True)
+        d = api.Decoder(None)
+        f = d.read(data, 4)
+        print(hashlib.sha256(b"".join(d.coefficients(c).tobytes() for c in range(f.components))).hexdigest())
+        d.close()
+""" % (ROOT,)
+    outs = []
+    for chunk in ("0", "16", "61"):
+        env = dict(os.environ)
+        if chunk != "0":
+            env["MIJPEG_MARKER_CHUNK"] = chunk
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split())
+    assert len(outs[0]) == 6 and outs[0] == outs[1] == outs[2]
+    # ... and the default chunks' planes are the oracle's
+    rng = np.random.default_rng(5)
+    data = synth.encode_jpeg(rng.integers(0, 256, (72, 104, 3)).astype(np.uint8), 95, "420", restart_mcus=1, progressive=True)
+    d = api.Decoder(None)
+    f = d.read(data, 4)
+    _, planes = oracle.decode_coefficients(data)
+    for c in range(f.components):
+        assert np.array_equal(d.coefficients(c), planes[c].astype(np.int16))
+    d.close()
+
+
 def test_scan_offsets_are_where_the_scan_headers_end():
     """mijpeg_scan_offsets (what JPGFLAG_DECODER_STOP_SCAN returns at): every SOS of the codestream, first entropy coded byte
     behind its header, and the marker that follows the scan's data; JPEG XT scans from boxes come last with end 0."""
