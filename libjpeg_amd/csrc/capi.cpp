@@ -727,6 +727,9 @@ static const char *device_entropy_obstacle(const HostDecoder &h, size_t size, bo
   if (f.progressive) return "on-device entropy decoding: progressive frames are decoded on the host";
   if (f.xt && !xt_part) return "on-device entropy decoding: not for this JPEG XT stream";
   if (!h.residual_merged()) return "on-device entropy decoding: the legacy codestream has no EOI marker (the host decoder decides what is merged)";
+  // (a RESI box without a merging specification, a residual codestream header that does not match, tables looked up at the first
+  // request: what the reference reports behind the legacy frame's decode -- HostDecoder::decode reports it, this path would not)
+  if (h.verdict_pending()) return "on-device entropy decoding: the file's verdict is the host decoder's (residual codestream header / tables looked up at the first request)";
   if (f.precision != 8 && !(xt_part && f.precision == 12)) return "on-device entropy decoding: 8-bit frames (12-bit residual frames of JPEG XT) only";
   if (h.scans.size() != 1 || h.hidden_bits()) return "on-device entropy decoding: the frame has more than one scan";
   const Scan &s = h.scans[0];

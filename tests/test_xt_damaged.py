@@ -187,3 +187,86 @@ def test_the_residual_images_quantiser_tables_are_looked_up_at_the_first_request
             d.read(blob)
         assert e.value.code == oerr
         d.close()
+
+
+def _residual_without_its_visible_scan():
+    """tests/golden/xt_grey/ghdr_R1_rR3 with the SOS marker of its residual codestream turned into a reserved marker (FF DA -> FF 58):
+    the residual frame's component is named by no visible scan and appears in the hidden refinement scans of the RFIN boxes first
+    (found by tools/xt_gpu_damage_campaign.py, seed 72)."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xt_grey", "ghdr_R1_rR3.jpg"), "rb") as f:
+        data = f.read()
+    i = data.index(b"RESI")
+    sos = data.index(b"\xff\xda", i)
+    assert sos < data.index(b"FINE", i)  # (still inside the RESI box)
+    return data, data[:sos + 1] + b"\x58" + data[sos + 2:]
+
+
+def test_a_component_that_first_appears_in_a_hidden_scan_takes_the_table_in_force_there(oracle):
+    """The transform of a component is built, with the quantiser table in force then, when the component first appears in a scan
+    (control/blockbuffer.cpp:177-208) -- for a residual frame whose scan header is gone that is the first hidden refinement scan;
+    the product published the stand-in of a component that appears nowhere (a table of ones) before it had looked at the boxes."""
+    good, blob = _residual_without_its_visible_scan()
+    codes, _, oerr = oracle.decode_xt_status(blob)
+    assert oerr == 0
+    if oracle.have_reference():
+        ref = oracle.reference_decode_hdr(blob)
+        assert np.array_equal(ref.reshape(-1), oracle.half_codes_to_float(np.asarray(codes)).reshape(-1).astype(np.float32))
+    tables = []
+    for data in (good, blob):
+        d = api.Decoder(None)
+        d.read(data)
+        r = d.xt_params().residual
+        tables.append(np.ctypeslib.as_array(r.quant).reshape(4, 64)[list(r.quant_index)[0]].copy())
+        d.close()
+    assert np.array_equal(tables[0], tables[1]) and tables[0].max() > 1
+
+
+@pytest.mark.gpu
+def test_gpu_residual_frame_without_its_visible_scan(oracle):
+    _, blob = _residual_without_its_visible_scan()
+    codes, _, oerr = oracle.decode_xt_status(blob)
+    assert oerr == 0
+    dec = api.Decoder(0)
+    dec.read(blob)
+    out = dec.reconstruct()
+    dec.close()
+    assert out.shape == codes.shape and np.array_equal(out, codes)
+
+
+def _residual_without_a_specification():
+    """A RESI box and no merging specification (the SPEC box's type damaged): the reference reads the legacy frame like a plain
+    JPEG's and refuses at the first request -- -1024, "The combination of L and R transformation is non-standard"."""
+    data = golden_jpeg("xt_129x71_420_rR1_dri2")
+    i = data.index(b"SPEC")
+    return data[:i] + b"SPEX" + data[i + 4:]
+
+
+def test_a_residual_codestream_without_a_specification_is_refused_behind_the_legacy_frame(oracle):
+    blob = _residual_without_a_specification()
+    assert oracle.decode_xt_status(blob)[2] == -1024
+    if oracle.have_reference():
+        assert reference_status(oracle, blob)[1] == -1024
+    d = api.Decoder(None)
+    with pytest.raises(api.MijpegError) as e:
+        d.read(blob)
+    assert e.value.code == -1024
+    d.close()
+
+
+@pytest.mark.gpu
+def test_gpu_the_device_entropy_decoder_leaves_pending_verdicts_to_the_host(oracle):
+    """The legacy frame of such a file is one sequential scan with restart markers -- what the device entropy decoder takes; the
+    verdict that waits behind the frame (HostDecoder::verdict_pending) is the host decoder's to report, in every entropy mode
+    (tools/multiscan_campaign.py DAMAGE=1, seed 74: two files read without complaint through "prefer-gpu")."""
+    blob = _residual_without_a_specification()
+    for mode in ("host", "auto", "prefer-gpu"):
+        d = api.Decoder(0)
+        with pytest.raises(api.MijpegError) as e:
+            d.read(blob, entropy=mode)
+        assert e.value.code == -1024, mode
+        d.close()
+    d = api.Decoder(0)
+    with pytest.raises(api.MijpegError) as e:
+        d.read(blob, entropy="gpu")
+    assert e.value.code == api.ERR_NOT_AVAILABLE
+    d.close()

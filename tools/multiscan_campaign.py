@@ -3,7 +3,8 @@
 subsampling, qualities, restart intervals, scan scripts -v / -qv, hidden bits -R n / -rR n, progressive residuals -rv, 12-bit
 input) -- the device decoder of progressive frames / hidden refinement scans (huffman_prog_kernel) against the host decoder,
 coefficient plane by coefficient plane, and every eighth file's pixels against the oracle.
-    N=300 SEED=1 [DAMAGE=1] python tools/multiscan_campaign.py      (DAMAGE: every file corrupted, verdicts and coefficients compared)"""
+    N=300 SEED=1 [DAMAGE=1] [DUMP=dir] python tools/multiscan_campaign.py      (DAMAGE: every file corrupted, verdicts and coefficients
+    compared; DUMP: streams whose verdicts differ are written there)"""
 import os
 import sys
 
@@ -69,6 +70,10 @@ for i in range(N):
     if dv != hv:
         stats["verdict_mismatch"] += 1
         print("verdict", i, args, hv, dv, flush=True)
+        if os.environ.get("DUMP"):  # the stream, for a closer look
+            os.makedirs(os.environ["DUMP"], exist_ok=True)
+            with open(os.path.join(os.environ["DUMP"], "verdict_%d_%d.jpg" % (SEED, i)), "wb") as f:
+                f.write(data)
         continue
     if dv:
         continue
