@@ -599,3 +599,79 @@ def test_refusal_beside_a_residual_scan_only_the_sequential_walk_rejects(oracle)
         d.read(blob)
     d.close()
     assert e.value.code == -1038 and "out of sync" in str(e.value)
+
+
+def _resegment(data, types=(b"RESI", b"RFIN", b"FINE"), piece=3000):
+    """The boxes of `types` cut into APP11 segments of `piece` payload bytes (same instance number, sequence numbers 1, 2, ...:
+    Box::ParseBoxMarker, boxes/box.cpp:93-200, puts them together again) -- what the reference's encoder does from 64 KiB on."""
+    import struct
+    out = bytearray(data[:2])
+    p = 2
+    while p < len(data) - 4 and data[p] == 0xFF:
+        m = data[p + 1]
+        ln = struct.unpack(">H", data[p + 2:p + 4])[0]
+        seg = data[p:p + 2 + ln]
+        if m == 0xEB and seg[4:6] == b"JP" and seg[16:20] in types and ln - 18 > piece:
+            en, lbox, tbox, payload = seg[6:8], seg[12:16], seg[16:20], seg[20:]
+            assert struct.unpack(">I", seg[8:12])[0] == 1
+            for k, a in enumerate(range(0, len(payload), piece)):
+                part = payload[a:a + piece]
+                out += b"\xff\xeb" + struct.pack(">H", 18 + len(part)) + b"JP" + en + struct.pack(">I", k + 1) + lbox + tbox + part
+        else:
+            out += seg
+        if m == 0xDA:
+            out += data[p + 2 + ln:]
+            break
+        p += 2 + ln
+    return bytes(out)
+
+
+def test_codestream_boxes_of_many_segments(oracle):
+    """A codestream box of many APP11 segments is not copied segment by segment: the walk notes its pieces and the pool copies them
+    when it is through (XtBox::pieces, HostDecoder::materialize_boxes), into a store a box of the last parse left behind where
+    one fits.  Same planes as the file with one segment per box, same verdicts where the file ends inside a segment (the reference
+    fills up with zeros, io/decoderstream.cpp:136-158), and nothing of one read shows in the next on the same object."""
+    data = golden_jpeg("xt_200x120_420_R3_rR4")
+    multi = _resegment(data, piece=700)
+    assert multi != data and multi.count(b"RESI") > 3
+    want = oracle.decode_xt_status(data)
+    got = oracle.decode_xt_status(multi)
+    assert want[2] == 0 and got[2] == 0 and np.array_equal(want[0], got[0])
+    if oracle.have_reference():
+        assert np.array_equal(oracle.reference_decode_hdr(data), oracle.reference_decode_hdr(multi))
+    one = api.Decoder(None)
+    f = one.read(data)
+    planes = [one.coefficients(c).copy() for c in range(f.components)] + [one.residual_coefficients(c).copy() for c in range(f.components)]
+    one.close()
+    # cuts inside the second segment of the residual codestream's box, inside a refinement box, and right behind a segment header
+    r = [m.start() for m in re.finditer(b"RESI", multi)]
+    cuts = [multi[:r[1] + 700], multi[:r[2] + 4], multi[:multi.index(b"RFIN") + 1500], multi[:r[-1] + 10]]
+    verdicts = []
+    for blob in cuts:
+        oerr = oracle.decode_xt_status(blob)[2]
+        if oracle.have_reference():
+            assert _reference_error(oracle, blob) == oerr
+        verdicts.append(oerr)
+    d = api.Decoder(None)  # ONE object through all of them, the whole file in between
+    for rep in range(2):
+        for blob, oerr in zip(cuts, verdicts):
+            f = d.read(multi)
+            now = [d.coefficients(c) for c in range(f.components)] + [d.residual_coefficients(c) for c in range(f.components)]
+            assert all(np.array_equal(a, b) for a, b in zip(planes, now))
+            if oerr == 0:
+                d.read(blob)
+            else:
+                with pytest.raises(api.MijpegError) as e:
+                    d.read(blob)
+                assert e.value.code == oerr
+    d.close()
+
+
+def _reference_error(oracle, blob):
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as t:
+        src, dst = os.path.join(t, "in.jpg"), os.path.join(t, "out.pfm")
+        with open(src, "wb") as f:
+            f.write(blob)
+        r = subprocess.run([oracle.REF_BIN, src, dst], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=20)
+        m = re.search(rb"failed - error (-?\d+)", r.stderr)
+        return int(m.group(1)) if m else 0
