@@ -886,6 +886,10 @@ template <class T> __global__ __launch_bounds__(256) void huffman_prog_kernel(co
   for (int mi = 0; mi < sc.restart_interval; mi++) {
     const int m = m0 + mi;
     const bool live = decoding && m < sc.total_mcus;
+    // An interval that has read past its data is a damaged one (the check behind the loop): it stops HERE.  A scan without
+    // restart markers is one interval of any number of blocks -- an EOB run covers 32 767 of them in three bytes -- and what a
+    // lane reads behind its data is whatever lies there, a hundred bytes a block: it must not walk out of the buffer.
+    if (live && !err && br.bp > br.endbit) err = HUFF_ERR_DESYNC;
     if (__ballot(live && !err) == 0) break;
     const int my = m / sc.mcus_x, mx = m - my * sc.mcus_x;
 #pragma unroll
