@@ -1635,10 +1635,8 @@ static int device_entropy_multiscan(mijpeg_decoder *d, const MultiScanFrame *fra
       if (s.ss == 0 && s.ah == 0) build_dev_table(tabs[it.dc_tab[k]], s.dc[k], 0);
       if (s.se > 0) build_dev_table(tabs[it.ac_tab[k]], s.ac[k], 2);
     }
-    for (int64_t k = 0; k < it.nint; k++) {
-      ib[it.first + k] = s.interval_ubegin[(size_t)k];
-      ie[it.first + k] = s.interval_uend[(size_t)k];
-    }
+    memcpy(ib + it.first, s.interval_ubegin.data(), (size_t)it.nint * sizeof(uint32_t)); // (multiscan_obstacle: both lists hold nint entries at least)
+    memcpy(ie + it.first, s.interval_uend.data(), (size_t)it.nint * sizeof(uint32_t));
   }
   mark("tables + intervals");
   // The entropy coded data of every scan without its stuffing, gathered by the pool in two goes: what the first launches read
