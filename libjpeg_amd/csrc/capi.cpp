@@ -2783,7 +2783,11 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       for (int c = 0; c < x.residual.components && c < 3; c++) plane(3 + c, x.residual, c, rprec); // (one component: planes 4, 5 stay empty)
       if (!x.residual.components) // (no residual frame at all -- a specification without a residual codestream: the merge reads nothing there)
         for (int pn = 3; pn < 6; pn++) a.subx[pn] = a.suby[pn] = 1;
-      if (x.residual_wide) { a.wide_first = 3; a.wide_count = 3; }
+      // int32 planes: beyond 12 bits (hidden bits included) the reference transforms with IDCT<4,QUAD>, up to 12 with the LONG
+      // flavour like every other frame (codestream/tables.cpp:1876-1891) -- the same numbers until a damaged scan leaves a
+      // coefficient that overflows 32 bits on the way (an 8-bit alpha residual with one hidden bit and 52 241 in a block:
+      // tools/xt_gpu_damage_campaign.py, seed 2002)
+      if (x.residual_wide) { a.wide_first = 3; a.wide_count = 3; a.wide_long = rprec <= 12 ? 1 : 0; }
       a.ltable_entries = x.ltable_entries;
       a.nplanes = 6;
       a.xt = 1;

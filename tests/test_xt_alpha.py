@@ -472,3 +472,37 @@ def test_gpu_alpha_at_4k(oracle, dec):
     assert np.array_equal(dec.reconstruct(), oracle.decode(data))
     plane = dec.alpha_channel().reconstruct()
     assert np.array_equal(plane.reshape(h, w), codes.astype(plane.dtype))
+
+
+def _alpha_residual_with_a_runaway_coefficient():
+    """a8_residual_hidden with one byte of the alpha residual codestream's entropy coded data changed: its decode leaves 52 241 in
+    one block of a 9-bit frame (8 bits + one hidden bit) -- found by tools/xt_gpu_damage_campaign.py, seed 2002."""
+    data = bytearray(stream("a8_residual_hidden"))
+    assert data[1036] == 0xF0
+    data[1036] = 0x7F
+    return bytes(data)
+
+
+def test_oracle_wraps_like_the_reference_where_a_residual_coefficient_runs_away(oracle):
+    blob = _alpha_residual_with_a_runaway_coefficient()
+    acodes, _, _, _, _, ae = oracle.decode_alpha(blob)
+    assert ae == 0
+    if oracle.have_reference():
+        rc, plane = _alpha_with_reference(oracle, blob)
+        assert rc == 0 and np.array_equal(np.asarray(plane).reshape(acodes.shape).astype(np.uint16), acodes)
+
+
+@pytest.mark.gpu
+def test_gpu_int32_residual_planes_of_up_to_12_bits_take_the_long_transform(oracle):
+    """A residual frame with hidden bits keeps int32 coefficients; the reference transforms it with IDCT<.., QUAD> only beyond 12 bits
+    (hidden bits included), with the LONG flavour otherwise (codestream/tables.cpp:1876-1891) -- the same numbers until a
+    coefficient overflows 32 bits on the way, which the 64-bit flavour then does not reproduce."""
+    blob = _alpha_residual_with_a_runaway_coefficient()
+    acodes = oracle.decode_alpha(blob)[0]
+    codes = oracle.decode_xt_status(blob)[0]
+    d = api.Decoder(0)
+    d.read(blob)
+    assert np.array_equal(np.asarray(d.reconstruct()).reshape(-1).astype(np.uint16), np.asarray(codes).reshape(-1).astype(np.uint16))
+    a = d.alpha_channel()
+    assert a is not None and np.array_equal(np.asarray(a.reconstruct()).reshape(-1).astype(np.uint16), acodes.reshape(-1))
+    d.close()

@@ -270,3 +270,41 @@ def test_gpu_the_device_entropy_decoder_leaves_pending_verdicts_to_the_host(orac
         d.read(blob, entropy="gpu")
     assert e.value.code == api.ERR_NOT_AVAILABLE
     d.close()
+
+
+def _rebuild_resi(data, edit):
+    """The RESI box's payload (one APP11 segment in this fixture) replaced by edit(payload), lengths adjusted."""
+    import struct
+    p = data.index(b"RESI") - 16
+    assert data[p:p + 2] == b"\xff\xeb"
+    ln = struct.unpack(">H", data[p + 2:p + 4])[0]
+    seg = data[p:p + 2 + ln]
+    payload = edit(seg[20:])
+    new = b"\xff\xeb" + struct.pack(">H", 18 + len(payload)) + seg[4:12] + struct.pack(">I", 8 + len(payload)) + seg[16:20] + payload
+    return data[:p] + new + data[p + 2 + ln:]
+
+
+@pytest.mark.parametrize("which", ["no_eoi", "insert_and_no_eoi", "insert_with_eoi", "insert_and_nothing_of_the_eoi"])
+def test_a_residual_codestream_that_simply_ends(oracle, which):
+    """A residual frame whose data simply ends stands at "its" EOI -- the legacy stream's, which Image::InputStreamOf hands out
+    then (codestream/image.cpp:978-996) -- and its hidden refinement scans are read; but only if the scan's decoder stopped at the
+    very end of the data: one whose data went wrong (a byte too many) is through with its blocks a byte in front of it, the
+    trailer finds garbage, and the RFIN boxes are never looked at (tools/xt_gpu_damage_campaign.py, seed 2001: the planned
+    decode applied them).  Residual planes against the oracle's, the oracle's picture against the reference's."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xt_grey", "ghdr_R1_rR3.jpg"), "rb") as f:
+        data = f.read()
+    edit = {"no_eoi": lambda p: p[:-1], "insert_and_no_eoi": lambda p: p[:700] + b"\x3f" + p[700:-1],
+            "insert_with_eoi": lambda p: p[:700] + b"\x3f" + p[700:], "insert_and_nothing_of_the_eoi": lambda p: p[:700] + b"\x3f" + p[700:-2]}[which]
+    blob = _rebuild_resi(data, edit)
+    codes, _, oerr = oracle.decode_xt_status(blob)
+    assert oerr == 0
+    if oracle.have_reference():
+        assert np.array_equal(oracle.reference_decode_hdr(blob).reshape(-1), oracle.half_codes_to_float(np.asarray(codes)).reshape(-1).astype(np.float32))
+    _, rp = oracle.decode_xt_residual_planes(blob)
+    refined = bool((np.asarray(rp[0]) % 8 != 0).any())  # three hidden bits: without the RFIN scans every coefficient is a multiple of 8
+    assert refined == (which in ("no_eoi", "insert_with_eoi"))
+    for threads in (1, 4):
+        d = api.Decoder(None)
+        d.read(blob, threads)
+        assert np.array_equal(d.residual_coefficients(0).reshape(-1).astype(np.int64), np.asarray(rp[0]).reshape(-1).astype(np.int64)), threads
+        d.close()
