@@ -105,7 +105,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             want, oerr = None, repr(e)
         try:
-            info = dec.read(blob, entropy="auto" if rng.integers(0, 2) else "host")
+            info = dec.read(blob, entropy=os.environ.get("ENTROPY", "auto") if rng.integers(0, 2) else "host")  # (ENTROPY=prefer-gpu: the device entropy decoders however small the file)
             got = dec.reconstruct()
             perr = 0
         except api.MijpegError as e:
