@@ -3360,6 +3360,19 @@ int oj_decode_alpha(const uint8_t *data, size_t len, oj_info *info, uint16_t **p
   /* (the reference turns to the ALFA box behind the legacy codestream's EOI, codestream/image.cpp:1430-1460: without one the file
    * has no alpha channel) */
   if (!alfa || !ps.eoi_image) { free_boxes(boxes, ps.nboxes); return OJ_ERR_UNSUPPORTED; }
+  {
+    /* Image::ParseAlphaChannel, codestream/image.cpp:1366-1380: right behind the alpha image's frame header -- whatever its scans
+     * would do to a frame of that size -- its dimensions are compared with the image's ("residual image dimensions do not match
+     * the dimensions of the legacy image", the residual's message), and it may have one component only.  What stops the SOI, the
+     * tables or the frame header itself comes first: the walk below reports it. */
+    oj_info ai;
+    if (oj_read_info(alfa->data, alfa->len, &ai) == OJ_OK && (ai.width != main_info.width || ai.height != main_info.height || ai.ncomp != 1)) {
+      memset(info, 0, sizeof(*info));
+      info->ref_error = RS_MALFORMED_STREAM;
+      free_boxes(boxes, ps.nboxes);
+      return OJ_ERR_MALFORMED;
+    }
+  }
   if (aspc) { /* AMUL inside the alpha merging specification */
     size_t j;
     for (j = 0; j + 8 <= aspc->len;) {

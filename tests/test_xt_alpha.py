@@ -309,12 +309,14 @@ def test_the_alpha_frame_header_is_judged_before_its_scans(oracle):
     sof = seg.find(b"\xff\xc1")
     wide = bytearray(data)
     wide[off + sof + 7] = 0x1A  # the high byte of the alpha frame's width
+    tall = bytearray(data)
+    tall[off + sof + 5] = 0x0A  # ... of its height (a frame its scan's data could never fill: -1025 if the scan were looked at first)
     other = bytearray(stream("a8_420"))
     (off2, ln2), = _segments(bytes(other), b"ALFA")
     sof2 = bytes(other[off2:off2 + 2 + ln2]).find(b"\xff\xc1")
     assert sof2 > 0
     shifted = bytes(other[:off2 + sof2 + 1]) + b"\xb3" + bytes(other[off2 + sof2 + 1:off2 + 2 + ln2 - 1]) + bytes(other[off2 + 2 + ln2:])  # FF B3 C0 ..: the box keeps its size
-    for blob in (bytes(wide), shifted):
+    for blob in (bytes(wide), bytes(tall), shifted):
         assert oracle.alpha_read_error(blob) == -1038
         if oracle.have_reference():
             assert oracle.reference_decode_status(blob)[1] == -1038

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: the stream classes of round 5 (tests/golden/xt_lonly, xt_alpha, xt_lossless) under the seeded corruptions of tests/damage.py and
 random bytes in front of the first scan -- where oracle and product both decode, the product's picture (and alpha plane) on the device must
-be the oracle's.  (Return codes three-way with the reference binary: tools/box_campaign.py, CPU.)   SEED=1 PER_FILE=12 [ENTROPY=prefer-gpu] [FILES=all] python tools/xt_gpu_damage_campaign.py"""
+be the oracle's.  (Return codes three-way with the reference binary: tools/box_campaign.py, CPU.)   SEED=1 PER_FILE=12 [ENTROPY=prefer-gpu] [FILES=all|every] python tools/xt_gpu_damage_campaign.py"""
 import collections
 import glob
 import os
@@ -24,6 +24,8 @@ def cases():
     g = os.path.join(ROOT, "tests", "golden")
     files = sorted(glob.glob(os.path.join(g, "xt_lonly", "*.jpg")))[::2] + sorted(glob.glob(os.path.join(g, "xt_alpha", "*.jpg"))) + \
         sorted(glob.glob(os.path.join(g, "xt_lossless", "*.jpg"))) + sorted(glob.glob(os.path.join(g, "xt_grey", "*.jpg"))) + sorted(glob.glob(os.path.join(g, "xt_int8", "*.jpg")))[:10]
+    if os.environ.get("FILES") == "every":  # every class of tests/golden/xt_*/ (general transformations, integer output, boxes, ...) and the files beside them
+        files = sorted(glob.glob(os.path.join(g, "xt_*.jpg"))) + sorted(glob.glob(os.path.join(g, "xt_*", "*.jpg")))
     if os.environ.get("FILES") == "all":  # every JPEG XT golden, the ones with restart markers included (what the device entropy decoders take)
         files = sorted(glob.glob(os.path.join(g, "xt_*.jpg"))) + files
     if os.environ.get("CLASSES") == "refinement":
