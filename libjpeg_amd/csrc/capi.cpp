@@ -3970,6 +3970,12 @@ try {
     n++;
   }
   if (HostDecoder *res = d->host.residual()) boxed += (int)res->scans.size();
+  // ... and behind them the alpha channel's: its own codestream (ALFA box), that one's refinement boxes, its residual codestream
+  // (Image::ParseAlphaChannel / ParseResidualStream of the alpha image, codestream/image.cpp:1337-1404, 1440-1462)
+  if (d->alpha && d->alpha_ready) {
+    boxed += (int)d->alpha->host.scans.size();
+    if (HostDecoder *ares = d->alpha->host.residual()) boxed += (int)ares->scans.size();
+  }
   for (int k = 0; k < boxed; k++, n++)
     if (n < capacity) {
       if (first_byte) first_byte[n] = behind;
@@ -3995,6 +4001,14 @@ try {
     if (sc.base) put(sc);
   if (HostDecoder *res = d->host.residual())
     for (const Scan &sc : res->scans) put(sc);
+  if (d->alpha && d->alpha_ready) { // (the alpha channel's codestreams, in the same order: mijpeg_scan_offsets)
+    for (const Scan &sc : d->alpha->host.scans)
+      if (!sc.base) put(sc);
+    for (const Scan &sc : d->alpha->host.scans)
+      if (sc.base) put(sc);
+    if (HostDecoder *ares = d->alpha->host.residual())
+      for (const Scan &sc : ares->scans) put(sc);
+  }
   return n;
 } catch (...) { return boundary_catch(d, "mijpeg_scan_grids"); }
 

@@ -13,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 REF = os.environ.get("LIBJPEG_REFERENCE", "/root/reference")
 CASES = ["pil_200x120_420_dri8", "ref_75x45_420_dri2", "pil_70x40_gray", "pilprog_75x45_420", "refprog_64x64_444_dri5", "xt_64x48_444", "p12_64x48_444",
          "ref_97x61_3x3", "pilprog_200x130_422", "xt_200x120_420_R3_rR4", "xt_129x71_420_R2_rR3_dri3", "xt_64x48_444_R4", "pil_90x60_cmyk",
-         "ref_23x50_lumasub", "ref_97x61_mixed", "ref_97x61_411", "refc_83x47_440"]
+         "ref_23x50_lumasub", "ref_97x61_mixed", "ref_97x61_411", "refc_83x47_440",
+         # alpha channels: the scans of the alpha image's codestreams count behind the image's own (round 6)
+         "xt_alpha/a8_beside_hdr", "xt_alpha/a16_residual", "xt_alpha/a8_residual_hidden", "xt_alpha/af_beside_hdr", "xt_alpha/a8_420"]
 
 
 def main():

@@ -39,9 +39,10 @@ def main():
     rng = np.random.default_rng(SEED)
     count = collections.Counter()
     bad = []
-    # (JPEG XT: the profile C goldens whose scans this library plans.  Files it walks sequentially -- the residual scan types of `-ro`,
-    # DNL frames -- and the codestreams of alpha channels have no stops of their own here: INTEGRATION.md, "Deviations")
-    xt = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "xt_*.jpg")) + glob.glob(os.path.join(ROOT, "tests", "golden", "xt_grey", "g*_r12.jpg")))
+    # (JPEG XT: the profile C goldens whose scans this library plans, alpha channels included.  Files it walks sequentially -- the
+    # residual scan types of `-ro`, DNL frames -- have no stops of their own here: INTEGRATION.md, "Deviations")
+    xt = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "xt_*.jpg")) + glob.glob(os.path.join(ROOT, "tests", "golden", "xt_grey", "g*_r12.jpg")) +
+                glob.glob(os.path.join(ROOT, "tests", "golden", "xt_alpha", "*.jpg")))
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
         ours, ref = build(d)
         for i in range(N):
