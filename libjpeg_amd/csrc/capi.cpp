@@ -3952,63 +3952,79 @@ try {
   return hand_out_request(d, p.min_x, p.min_y, y_count, cx1, cy1, min_comp, max_comp, nc, sb, row, padded, vc, all_on_view, to_device, dst, bpp, bpr);
 } catch (...) { return boundary_catch(d, "mijpeg_display_rect"); }
 
+// The scans of one codestream in the order the reference meets them: the codestream's own, then the ones that live in its
+// refinement boxes.  A frame whose decode went through the sequential walk (damaged streams, DNL frames, the residual scan types of
+// part 8) planned no scans: the walk's own record stands in (HostDecoder::walked_scans).
+struct ScanStop { uint64_t begin, end; int32_t mcus_x, mcus_y; bool boxed; };
+static void scans_of(const HostDecoder &h, bool all_boxed, std::vector<ScanStop> &out)
+{
+  if (h.walked()) {
+    for (const auto &w : h.walked_scans()) out.push_back(ScanStop{(uint64_t)w.begin, (uint64_t)w.end, w.mcus_x, w.mcus_y, all_boxed || w.boxed});
+    return;
+  }
+  for (const Scan &sc : h.scans)
+    if (!sc.base) out.push_back(ScanStop{(uint64_t)sc.ecs_begin, (uint64_t)sc.ecs_end, sc.mcus_x, sc.mcus_y, all_boxed});
+  for (const Scan &sc : h.scans)
+    if (sc.base) out.push_back(ScanStop{0, 0, sc.mcus_x, sc.mcus_y, true});
+}
+static void all_scans(mijpeg_decoder *d, std::vector<ScanStop> &out)
+{
+  // scans of the codestream itself first; then -- JPEG XT -- the scans that live in boxes (hidden refinement scans of the legacy
+  // frame, the residual codestream and its refinement scans): the reference parses them from memory streams while its input
+  // stands at the marker behind the legacy frame's last scan (the EOI); behind them the alpha channel's: its own codestream (ALFA
+  // box), that one's refinement boxes, its residual codestream (Image::ParseAlphaChannel / ParseResidualStream of the alpha image,
+  // codestream/image.cpp:1337-1404, 1440-1462)
+  scans_of(d->host, false, out);
+  if (HostDecoder *res = d->host.residual()) scans_of(*res, true, out);
+  if (d->alpha && d->alpha_ready) {
+    scans_of(d->alpha->host, true, out);
+    if (HostDecoder *ares = d->alpha->host.residual()) scans_of(*ares, true, out);
+  }
+}
+
 int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_byte, int capacity)
 try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
-  // scans of the codestream itself first; then -- JPEG XT -- the scans that live in boxes (hidden refinement scans of the legacy
-  // frame, the residual codestream and its refinement scans): the reference parses them from memory streams while its
-  // input stands at the marker behind the legacy frame's last scan (the EOI)
-  int n = 0, boxed = 0;
+  std::vector<ScanStop> all;
+  all_scans(d, all);
+  // (boxed scans: the input stands behind the last scan of the codestream itself; end 0 marks them)
+  int n = 0;
   uint64_t behind = 0;
-  for (const Scan &sc : d->host.scans) {
-    if (sc.base) { boxed++; continue; }
+  for (const ScanStop &sc : all) {
+    if (sc.boxed) continue;
     if (n < capacity) {
-      if (first_byte) first_byte[n] = (uint64_t)sc.ecs_begin;
-      if (end_byte) end_byte[n] = (uint64_t)sc.ecs_end;
+      if (first_byte) first_byte[n] = sc.begin;
+      if (end_byte) end_byte[n] = sc.end;
     }
-    behind = (uint64_t)sc.ecs_end;
+    behind = sc.end;
     n++;
   }
-  if (HostDecoder *res = d->host.residual()) boxed += (int)res->scans.size();
-  // ... and behind them the alpha channel's: its own codestream (ALFA box), that one's refinement boxes, its residual codestream
-  // (Image::ParseAlphaChannel / ParseResidualStream of the alpha image, codestream/image.cpp:1337-1404, 1440-1462)
-  if (d->alpha && d->alpha_ready) {
-    boxed += (int)d->alpha->host.scans.size();
-    if (HostDecoder *ares = d->alpha->host.residual()) boxed += (int)ares->scans.size();
-  }
-  for (int k = 0; k < boxed; k++, n++)
+  for (const ScanStop &sc : all) {
+    if (!sc.boxed) continue;
     if (n < capacity) {
       if (first_byte) first_byte[n] = behind;
       if (end_byte) end_byte[n] = 0;
     }
+    n++;
+  }
   return n;
 } catch (...) { return boundary_catch(d, "mijpeg_scan_offsets"); }
 
 int mijpeg_scan_grids(mijpeg_decoder *d, int32_t *mcus_x, int32_t *mcus_y, int capacity)
 try {
   if (!d) return MIJPEG_ERR_INVALID_PARAMETER;
+  std::vector<ScanStop> all;
+  all_scans(d, all);
   int n = 0;
-  auto put = [&](const Scan &sc) {
-    if (n < capacity) {
-      if (mcus_x) mcus_x[n] = sc.mcus_x;
-      if (mcus_y) mcus_y[n] = sc.mcus_y;
+  for (int boxed = 0; boxed < 2; boxed++) // (the same order as mijpeg_scan_offsets)
+    for (const ScanStop &sc : all) {
+      if ((int)sc.boxed != boxed) continue;
+      if (n < capacity) {
+        if (mcus_x) mcus_x[n] = sc.mcus_x;
+        if (mcus_y) mcus_y[n] = sc.mcus_y;
+      }
+      n++;
     }
-    n++;
-  };
-  for (const Scan &sc : d->host.scans)
-    if (!sc.base) put(sc);
-  for (const Scan &sc : d->host.scans)
-    if (sc.base) put(sc);
-  if (HostDecoder *res = d->host.residual())
-    for (const Scan &sc : res->scans) put(sc);
-  if (d->alpha && d->alpha_ready) { // (the alpha channel's codestreams, in the same order: mijpeg_scan_offsets)
-    for (const Scan &sc : d->alpha->host.scans)
-      if (!sc.base) put(sc);
-    for (const Scan &sc : d->alpha->host.scans)
-      if (sc.base) put(sc);
-    if (HostDecoder *ares = d->alpha->host.residual())
-      for (const Scan &sc : ares->scans) put(sc);
-  }
   return n;
 } catch (...) { return boundary_catch(d, "mijpeg_scan_grids"); }
 

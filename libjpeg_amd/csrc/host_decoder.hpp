@@ -132,6 +132,12 @@ public:
   // out of sequence or in excess, or a sequential scan with a point transform.  decode() then walks the stream
   // sequentially the way the reference does (resynchronisation, grey intervals; RefWalker in host_decoder.cpp).
   bool needs_sequential() const { return needs_sequential_; }
+  // The scans a frame's SEQUENTIAL walk met (decode_sequential: damaged streams, DNL frames, the residual scan types of part 8):
+  // where their entropy coded data begins and ends and their MCU grid -- what the stop loops of class JPEG walk for frames that
+  // planned no scans.  walked(): the last decode went that way.
+  struct WalkedScan { size_t begin, end; int mcus_x, mcus_y; bool boxed; };
+  bool walked() const { return walked_; }
+  const std::vector<WalkedScan> &walked_scans() const { return walked_scans_; }
   // conditions the reference only warns about that the last parse / decode passed (stray markers, resynchronisation ...)
   int warnings() const { return warnings_; }
   // JPEG::LastWarning: 0, or the code of what the reference warns about at this stream (message in *msg): the LCHK checksum of
@@ -232,6 +238,8 @@ private:
   uint8_t *active_sink_ = nullptr; // ... which takes it over (and forgets it whatever becomes of the parse)
   size_t active_cap_ = 0;
   bool needs_sequential_ = false;
+  bool walked_ = false;
+  std::vector<WalkedScan> walked_scans_;
   bool parsed_ = false;
   int warnings_ = 0;
   bool have_lchk_ = false;

@@ -15,7 +15,9 @@ CASES = ["pil_200x120_420_dri8", "ref_75x45_420_dri2", "pil_70x40_gray", "pilpro
          "ref_97x61_3x3", "pilprog_200x130_422", "xt_200x120_420_R3_rR4", "xt_129x71_420_R2_rR3_dri3", "xt_64x48_444_R4", "pil_90x60_cmyk",
          "ref_23x50_lumasub", "ref_97x61_mixed", "ref_97x61_411", "refc_83x47_440",
          # alpha channels: the scans of the alpha image's codestreams count behind the image's own (round 6)
-         "xt_alpha/a8_beside_hdr", "xt_alpha/a16_residual", "xt_alpha/a8_residual_hidden", "xt_alpha/af_beside_hdr", "xt_alpha/a8_420"]
+         "xt_alpha/a8_beside_hdr", "xt_alpha/a16_residual", "xt_alpha/a8_residual_hidden", "xt_alpha/af_beside_hdr", "xt_alpha/a8_420",
+         # frames the library walks sequentially: a height that arrives in a DNL marker, the residual scan types of part 8
+         "dnl/dnl_1x2_33_prog", "dnl/dnl_420_32_dri2", "dnl/dnl_gray_33", "dnl/dnl_1x2_16_bl", "xt_lossless/rgb8_ro_dri4", "xt_lossless/rgb8_ro_rv", "xt_lossless/ghdr_ro"]
 
 
 def main():
