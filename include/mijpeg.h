@@ -359,12 +359,16 @@ int mijpeg_display_cursor(mijpeg_decoder *d, int component);
  * entropy coded byte of scan k, i.e. where the reference stands when JPEG::Read returns with JPGFLAG_DECODER_STOP_SCAN
  * (interface/jpeg.cpp:310-353), end_byte[k] = offset of the marker that follows the scan's data.  JPEG XT scans that live in
  * boxes come last: first_byte = the marker behind the codestream's last scan (where the reference's input stands while it
- * parses them from memory), end_byte = 0.  Either array may be NULL.  Returns the number of scans (also when capacity is
+ * parses them from memory), end_byte = 0 -- the legacy frame's refinement scans, the residual codestream's scans, then the
+ * alpha channel's codestreams in the same order (Image::ParseAlphaChannel, codestream/image.cpp:1337-1404).  A frame that
+ * was decoded by the sequential walk (a height from a DNL marker, the residual scan types of part 8, damaged streams) is
+ * listed by the scans that walk met.  Either array may be NULL.  Returns the number of scans (also when capacity is
  * smaller) or a negative error. */
 int mijpeg_scan_offsets(mijpeg_decoder *d, uint64_t *first_byte, uint64_t *end_byte, int capacity);
 /* ... and their MCU grids, same order: mcus_y[k] rows of mcus_x[k] MCUs (a single-component scan walks its component's own blocks,
  * codestream/sequentialscan.cpp:396-397).  What JPEG::Read with JPGFLAG_DECODER_STOP_ROW / _MCU counts its returns by: one at the
- * start of every MCU row, one behind every MCU of a row but the last (interface/jpeg.cpp:326-350).  Returns the number of scans. */
+ * start of every MCU row, one behind every MCU of a row but the last (interface/jpeg.cpp:326-350).  (The scan that brings a DNL
+ * marker: as many rows as the reference starts to find it.)  Returns the number of scans. */
 int mijpeg_scan_grids(mijpeg_decoder *d, int32_t *mcus_x, int32_t *mcus_y, int capacity);
 
 /* JPEG XT alpha channel (the reference: Image::ParseAlphaChannel, codestream/image.cpp:1337-1404; JPEG::GetInformation's
