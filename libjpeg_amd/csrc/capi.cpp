@@ -2403,6 +2403,21 @@ static bool use_fused420_12(const mijpeg_batch *b)
   return true;
 }
 
+// The 12-bit kernels' colour stage in one 32-bit sum per channel (colour12<true>, kernels.hip): the luma sample times 16 is at most
+// 4.02 * range_max[0] + 2 in magnitude, a chroma sample behind the upsampling filters 4.02 * range_max[c] + 4 (the bounds of
+// use_fused420_12; the filters are convex combinations plus a rounding), so (|y'| + 32776) * 8192 + 14516 |c| -- 14516 is the largest
+// weight a channel puts on chroma, 2819 + 5850 the green one's -- stays below 2^31 where this holds.  Monotone in every range: a
+// speculative launch that assumed larger ranges and selected the flavour holds for the smaller ones.  MIJPEG_NO_NARROW12: A-B runs.
+static bool narrow12_colour(const mijpeg_info &f)
+{
+  static const bool off = getenv("MIJPEG_NO_NARROW12") != nullptr;
+  if (off || f.precision != 12 || f.components != 3) return false;
+  const int64_t ry = f.range_max[0], rc = std::max(f.range_max[1], f.range_max[2]);
+  if (ry <= 0 || rc < 0) return false;
+  const int64_t sum = ((402 * ry + 99) / 100 + 2 + 32776) * 8192 + 14516 * ((402 * rc + 99) / 100 + 4);
+  return sum < ((int64_t)1 << 31);
+}
+
 // 12-bit 4:4:4 frames: the same bounds (no filter between the transforms and the colour stage)
 static bool use_fused444_12(const mijpeg_batch *b)
 {
@@ -2585,10 +2600,10 @@ try {
   if (use_fused440(b)) return chroma_packed(b->info) ? "fused440_kernel" : "fused440_kernel<wide>";
   if (use_fused411(b)) return "fused411_kernel";
   if (use_fused1(b)) return "fused1_kernel";
-  if (use_fused420_12(b)) return "fused420_kernel<12>";
+  if (use_fused420_12(b)) return narrow12_colour(b->info) ? "fused420_kernel<12>/narrow" : "fused420_kernel<12>";
   if (use_fused1_12(b)) return "fused1_kernel<12>";
-  if (use_fused444_12(b)) return "fused444_12_kernel";
-  if (use_fused422_12(b)) return "fused422_12_kernel";
+  if (use_fused444_12(b)) return narrow12_colour(b->info) ? "fused444_12_kernel/narrow" : "fused444_12_kernel";
+  if (use_fused422_12(b)) return narrow12_colour(b->info) ? "fused422_12_kernel/narrow" : "fused422_12_kernel";
   if (b->info.coef_wide) return "idct_planes_long_kernel+upsample_color_kernel";
   if (use_fused420(b)) return "fused420_kernel";
   if (use_fused444(b)) return "fused444_kernel";
@@ -2715,7 +2730,7 @@ static int launch_reconstruct_ex(const mijpeg_batch *b, void *stream, const Requ
       xa.luma_fits16 = f.range_max[0] < 7600 ? 1 : 0;
       rc = launch_fusedxt420(xa, s);
     } else
-      rc = f420_12 ? launch_fused420_12(a, s) : f444_12 ? launch_fused444_12(a, s) : f422_12 ? launch_fused422_12(a, s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, use_dot2_pass(b), s) : launch_fused420(a, fast, s);
+      rc = f420_12 ? launch_fused420_12(a, narrow12_colour(f), s) : f444_12 ? launch_fused444_12(a, narrow12_colour(f), s) : f422_12 ? launch_fused422_12(a, narrow12_colour(f), s) : f1_12 ? launch_fused1_12(a, s) : f1 ? launch_fused1(a, s) : f444 ? launch_fused444(a, s) : f422 ? launch_fused422(a, !chroma_packed(f), s) : f440 ? launch_fused440(a, !chroma_packed(f), s) : f411 ? launch_fused411(a, s) : use_fused420p(b) ? launch_fused420p(a, use_dot2_pass(b), s) : launch_fused420(a, fast, s);
   } else {
     if (!b->workspace || b->workspace_bytes < mijpeg_workspace_bytes(b)) return MIJPEG_ERR_MISSING_PARAMETER;
     GenericArgs a;

@@ -745,6 +745,30 @@ __device__ __forceinline__ int color_to_int(int x)
 // (a + 3 b + r) >> 2 in wrapping 32-bit arithmetic (the reference's LONG), upsampler.cpp filter taps
 __device__ __forceinline__ int tap13(int a, int b, int r) { return (int)((unsigned)a + 3u * (unsigned)b + (unsigned)r) >> 2; }
 
+// The colour stage of the 12-bit kernels, one pixel: (y * 8192 + cb' * Lb + cr' * Lr + 65536) >> 17 per channel (ycbcrtrafo.cpp:842-856,
+// :921-936; 64-bit sums in the reference), y = y' + 32768 * 16 / 16, samples times 16 without the level shift.
+//   NARROW: the whole sum in 32 bits -- one multiply-add per product and one shift per channel.  Exact where
+//           (|y'| + 32776) * 8192 + 14516 |c| < 2^31; the host admits it by the range check (narrow12_colour, capi.cpp).  Partial
+//           sums of the green channel may wrap, the complete one does not.
+//   else:   c L = q 2^13 + r, 0 <= r < 2^13, gives ((y' + 32776 + q) 2^13 + r) >> 17 = (y' + 32776 + q) >> 4: products alone must fit
+//           32 bits (fused420_kernel<.., 12> has the derivation and the bounds).
+template <bool NARROW>
+__device__ __forceinline__ void colour12(int y, int cb, int cr, int &r, int &g, int &b)
+{
+  static_assert(L_CB_B % 4 == 0, "the blue product is taken at a quarter of the constant");
+  if (NARROW) {
+    const int yk = shlw(y, 13) + ((32768 + 8) << 13);
+    r = mad24(cr, L_CR_R, yk) >> 17;
+    g = mad24(cr, -L_CR_G, mad24(cb, -L_CB_G, yk)) >> 17;
+    b = mad24(cb, L_CB_B, yk) >> 17;
+  } else {
+    const int yk = y + (32768 + 8);
+    r = (yk + (__mul24(cr, L_CR_R) >> 13)) >> 4;
+    g = (yk + (mad24(cr, -L_CR_G, __mul24(cb, -L_CB_G)) >> 13)) >> 4;
+    b = (yk + (__mul24(cb, L_CB_B / 4) >> 11)) >> 4;
+  }
+}
+
 // ==============================================================================================
 // fused 4:2:0 kernel
 // ==============================================================================================
@@ -924,7 +948,7 @@ __device__ __forceinline__ void store48(uint8_t *dst, const unsigned (&w)[12])
   }
 }
 
-template <bool FAST, int MINW, bool QDEV, int P = 8>
+template <bool FAST, int MINW, bool QDEV, int P = 8, bool N12 = false>
 __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fused420Args a)
 {
   static_assert(P == 8 || (P == 12 && FAST), "12-bit frames: FAST flavour only (the host checks the ranges)");
@@ -1035,16 +1059,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
           // exactly.  The products must fit 32 bits: |c| <= 4.02 * 45056 + 2 < 181 200 by the host's range check (an IDCT
           // output times 16 is at most 4 sum |c_k| q_k; the 9-bit constants and the two roundings add < 0.5 %), times 11485
           // < 2^31; Lb = 14516 = 4 * 3629 is applied as (c * 3629) >> 11, which is the same number.
-          static_assert(L_CB_B % 4 == 0, "the blue product is taken at a quarter of the constant");
-          const int KY = 32768 + 8;
           int rr[8], gg[8], bb[8];
 #pragma unroll
-          for (int x = 0; x < 8; x++) {
-            const int yk = yv[l * 8 + x] + KY;
-            rr[x] = (yk + (__mul24(ur[x], L_CR_R) >> 13)) >> 4;
-            gg[x] = (yk + (mad24(ur[x], -L_CR_G, __mul24(ub[x], -L_CB_G)) >> 13)) >> 4;
-            bb[x] = (yk + (__mul24(ub[x], L_CB_B / 4) >> 11)) >> 4;
-          }
+          for (int x = 0; x < 8; x++) colour12<N12>(yv[l * 8 + x], ub[x], ur[x], rr[x], gg[x], bb[x]);
           auto c12 = [](int v) { return (unsigned)min(max(v, 0), 4095); };
           if (fast_store) {
             unsigned w[12]; // 48 bytes r0 g0 b0 r1 ... b7, 16-bit samples
@@ -1556,7 +1573,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused422_kernel(const Fuse
 // samples as 32-bit values in two LDS planes (a 12-bit chroma sample times 16 does not fit 16 bits: 72 KB + the fetch staging
 // = half a CU's LDS, two workgroups per CU), fused420_kernel<.., 12>'s colour stage behind the horizontal filter.  Gates:
 // use_fused422_12 (capi.cpp), the 12-bit 4:2:0 kernel's.
-template <bool QDEV>
+template <bool QDEV, bool N12>
 __global__ __launch_bounds__(F420_THREADS, 2) void fused422_12_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) int cplane[2][F422_CROWS * F420_CPITCH];
@@ -1676,12 +1693,7 @@ __global__ __launch_bounds__(F420_THREADS, 2) void fused422_12_kernel(const Fuse
     if (l < nln) {
       int rr[8], gg[8], bb[8];
 #pragma unroll
-      for (int x = 0; x < 8; x++) { // (fused420_kernel<.., 12> has the derivation)
-        const int yk = yv[l * 8 + x] + (32768 + 8);
-        rr[x] = (yk + (__mul24(ur[x], L_CR_R) >> 13)) >> 4;
-        gg[x] = (yk + (mad24(ur[x], -L_CR_G, __mul24(ub[x], -L_CB_G)) >> 13)) >> 4;
-        bb[x] = (yk + (__mul24(ub[x], L_CB_B / 4) >> 11)) >> 4;
-      }
+      for (int x = 0; x < 8; x++) colour12<N12>(yv[l * 8 + x], ub[x], ur[x], rr[x], gg[x], bb[x]);
       uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
       if (fast_store) {
         unsigned w[12];
@@ -2656,7 +2668,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused444_kernel(const Fuse
 // 32-bit values (64 + 64 VGPRs: a 12-bit chroma sample times 16 does not fit 16 bits), two waves per SIMD.  The colour stage is
 // fused420_kernel<.., 12>'s: (y' + 32776 + (c L >> 13)) >> 4 clamped to [0, 4095], exact under the host's range gates
 // (use_fused444_12: the 12-bit 4:2:0 kernel's bounds; there is no filter between transform and colour stage here).
-template <bool QDEV>
+template <bool QDEV, bool N12>
 __global__ __launch_bounds__(F420_THREADS, 2) void fused444_12_kernel(const Fused420Args a)
 {
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4][128];
@@ -2709,13 +2721,7 @@ __global__ __launch_bounds__(F420_THREADS, 2) void fused444_12_kernel(const Fuse
     if (l < nln) {
       int rr[8], gg[8], bb[8];
 #pragma unroll
-      for (int x = 0; x < 8; x++) {
-        const int yk = yv[l * 8 + x] + (32768 + 8);
-        const int b = cb[l * 8 + x], r = cr[l * 8 + x];
-        rr[x] = (yk + (__mul24(r, L_CR_R) >> 13)) >> 4;
-        gg[x] = (yk + (mad24(r, -L_CR_G, __mul24(b, -L_CB_G)) >> 13)) >> 4;
-        bb[x] = (yk + (__mul24(b, L_CB_B / 4) >> 11)) >> 4;
-      }
+      for (int x = 0; x < 8; x++) colour12<N12>(yv[l * 8 + x], cb[l * 8 + x], cr[l * 8 + x], rr[x], gg[x], bb[x]);
       uint8_t *dst = out_frame + (out_off + (unsigned)l * (unsigned)a.row_stride);
       if (fast_store) {
         unsigned w[12]; // 48 bytes r0 g0 b0 r1 ... b7, 16-bit samples
@@ -4103,13 +4109,16 @@ int launch_fused420(const Fused420Args &a0, bool fast, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused420_12(const Fused420Args &a0, hipStream_t stream)
+int launch_fused420_12(const Fused420Args &a0, bool narrow, hipStream_t stream)
 {
   const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles<1>((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
-  if (a.qdev) hipLaunchKernelGGL((fused420_kernel<true, F420_12_MINW, true, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused420_kernel<true, F420_12_MINW, false, 12>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) {
+    if (narrow) hipLaunchKernelGGL((fused420_kernel<true, F420_12_MINW, true, 12, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused420_kernel<true, F420_12_MINW, true, 12, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  } else if (narrow) hipLaunchKernelGGL((fused420_kernel<true, F420_12_MINW, false, 12, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused420_kernel<true, F420_12_MINW, false, 12, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -4205,23 +4214,29 @@ int launch_fused444(const Fused420Args &a0, hipStream_t stream)
   return (int)hipGetLastError();
 }
 
-int launch_fused422_12(const Fused420Args &a0, hipStream_t stream)
+int launch_fused422_12(const Fused420Args &a0, bool narrow, hipStream_t stream)
 {
   const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
-  if (a.qdev) hipLaunchKernelGGL((fused422_12_kernel<true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused422_12_kernel<false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) {
+    if (narrow) hipLaunchKernelGGL((fused422_12_kernel<true, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused422_12_kernel<true, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  } else if (narrow) hipLaunchKernelGGL((fused422_12_kernel<false, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused422_12_kernel<false, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 
-int launch_fused444_12(const Fused420Args &a0, hipStream_t stream)
+int launch_fused444_12(const Fused420Args &a0, bool narrow, hipStream_t stream)
 {
   const Fused420Args a = with_tile_magic(a0);
   const unsigned total = workgroups_for_tiles((unsigned)a.tiles_x, (unsigned)a.tiles_y * (unsigned)a.frames);
   if (total == 0) return 0;
-  if (a.qdev) hipLaunchKernelGGL((fused444_12_kernel<true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL((fused444_12_kernel<false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  if (a.qdev) {
+    if (narrow) hipLaunchKernelGGL((fused444_12_kernel<true, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((fused444_12_kernel<true, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  } else if (narrow) hipLaunchKernelGGL((fused444_12_kernel<false, true>), dim3(total), dim3(F420_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((fused444_12_kernel<false, false>), dim3(total), dim3(F420_THREADS), 0, stream, a);
   return (int)hipGetLastError();
 }
 

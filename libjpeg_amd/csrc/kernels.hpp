@@ -119,11 +119,11 @@ struct GenericArgs {
 
 int launch_fused420(const Fused420Args &a, bool fast, hipStream_t stream);
 int launch_fused1_12(const Fused420Args &a, hipStream_t stream);   // 12-bit single component frames inside the range gate
-int launch_fused420_12(const Fused420Args &a, hipStream_t stream); // 12-bit frames inside the range gates, 16-bit samples out
+int launch_fused420_12(const Fused420Args &a, bool narrow, hipStream_t stream); // 12-bit frames inside the range gates, 16-bit samples out; narrow: the colour sums fit 32 bits (colour12)
 int launch_fused420p(const Fused420Args &a, bool dot2, hipStream_t stream); // FAST only, chroma samples within int16 filter range; dot2: the second pass in 16 bits too (range_max <= 1476)
 int launch_fused444(const Fused420Args &a, hipStream_t stream); // same argument block; all planes bw_y x bh_y
-int launch_fused422_12(const Fused420Args &a, hipStream_t stream); // 12-bit 4:2:2 frames inside the range gates
-int launch_fused444_12(const Fused420Args &a, hipStream_t stream); // 12-bit 4:4:4 frames inside the range gates, 16-bit samples out
+int launch_fused422_12(const Fused420Args &a, bool narrow, hipStream_t stream); // 12-bit 4:2:2 frames inside the range gates
+int launch_fused444_12(const Fused420Args &a, bool narrow, hipStream_t stream); // 12-bit 4:4:4 frames inside the range gates, 16-bit samples out
 int launch_fused1(const Fused420Args &a, hipStream_t stream);   // single component: plane off_y, bw_y x bh_y blocks, one byte per pixel
 int launch_fused440(const Fused420Args &a, bool wide, hipStream_t stream);
 int launch_fused411(const Fused420Args &a, hipStream_t stream); // same argument block; chroma planes bw_c x bh_y, cw = ceil(W/4), ch = H // same argument block; chroma planes bw_y x bh_c, cw = W, ch = ceil(H/2)

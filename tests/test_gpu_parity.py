@@ -1147,7 +1147,7 @@ def test_stateless_launch_with_per_frame_tables(oracle, sub, p12, kernel):
     row = w * (6 if p12 else 3)
     out = torch.zeros((n, h, row), dtype=torch.uint8, device="cuda")
     if kernel:
-        assert api.kernel_name(info) == kernel, (api.kernel_name(info), list(info.range_max))
+        assert api.kernel_name(info).split("/")[0] == kernel, (api.kernel_name(info), list(info.range_max))
     for flags in (0, api.FLAG_FORCE_GENERIC):
         out.zero_()
         wsb = api.workspace_bytes(info, n, flags, own_tables=True)
@@ -1528,6 +1528,24 @@ def test_rectangle_service_band_waits(dec, oracle):
 KERNEL_12 = {"420": "fused420_kernel<12>", "444": "fused444_12_kernel", "422": "fused422_12_kernel"}
 
 
+def _k12(name):
+    """The 12-bit kernels come in two flavours of the colour stage ("/narrow": every channel's sum in 32 bits, narrow12_colour in
+    capi.cpp); the kernel is the part in front."""
+    return name.split("/")[0]
+
+
+def _narrow12_admits(ry, rc):
+    """capi.cpp narrow12_colour, restated: (|y'| + 32776) * 8192 + 14516 |c| < 2^31 with |y'| <= 4.02 ry + 2, |c| <= 4.02 rc + 4"""
+    return ((402 * ry + 99) // 100 + 2 + 32776) * 8192 + 14516 * ((402 * rc + 99) // 100 + 4) < 2 ** 31
+
+
+def _narrow12_chroma_limit(ry):
+    rc = 0
+    while _narrow12_admits(ry, rc + 1):
+        rc += 1
+    return rc
+
+
 @pytest.mark.parametrize("sub", ["420", "444", "422"])
 @pytest.mark.parametrize("w,h,dri,scale", [(200, 120, 8, 16), (272, 144, 0, 16), (129, 71, 3, 9), (640, 368, 4, 16), (1, 1, 0, 16), (17, 250, 1, 5)])
 def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale, sub):
@@ -1537,7 +1555,8 @@ def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale, sub):
     data = synth.to_12bit(synth.synth_jpeg(w, h, 11 + w, 85, sub, dri), scale)
     f = dec.read(data)
     assert f.precision == 12 and f.sample_bytes == 2
-    assert api.kernel_name(f) == KERNEL_12[sub], list(f.range_max)
+    assert _k12(api.kernel_name(f)) == KERNEL_12[sub], list(f.range_max)
+    assert api.kernel_name(f).endswith("/narrow") == _narrow12_admits(f.range_max[0], max(f.range_max[1], f.range_max[2]))
     exp = oracle.decode16(data)
     out = dec.reconstruct()
     assert out.dtype == np.uint16 and np.array_equal(out, exp)
@@ -1552,7 +1571,12 @@ def test_fused420_12bit_vs_oracle(dec, oracle, w, h, dri, scale, sub):
 
 
 @pytest.mark.parametrize("sub", ["420", "444", "422"])
-@pytest.mark.parametrize("luma_budget,chroma_budget,fused", [(49151, 45055, True), (49151, 45056, False), (49152, 1000, False), (30000, 45055, True), (45055, 32767, True)])
+@pytest.mark.parametrize("luma_budget,chroma_budget,fused", [(49151, 45055, True), (49151, 45056, False), (49152, 1000, False), (30000, 45055, True), (45055, 32767, True),
+                                                             # the colour stage's 32-bit flavour at its bound and one step beyond, along the bound's curve
+                                                             (16000, _narrow12_chroma_limit(16000), True), (16000, _narrow12_chroma_limit(16000) + 1, True),
+                                                             (4000, _narrow12_chroma_limit(4000), True), (4000, _narrow12_chroma_limit(4000) + 1, True),
+                                                             (32000, _narrow12_chroma_limit(32000), True), (32000, _narrow12_chroma_limit(32000) + 1, True),
+                                                             (49151, _narrow12_chroma_limit(49151), True), (49151, _narrow12_chroma_limit(49151) + 1, True)])
 def test_extreme_coefficients_at_the_12bit_gates(oracle, luma_budget, chroma_budget, fused, sub):
     """fused420_kernel<12> (and fused444_12_kernel, fused422_12_kernel: same bounds) is admitted by sum |c| q < 49152 (the 32-bit butterflies) and < 45056 for the chroma planes (the
     32-bit colour products).  Blocks right at those bounds with every sign pattern (DC-only, one AC coefficient, dense) must still come
@@ -1600,7 +1624,8 @@ def test_extreme_coefficients_at_the_12bit_gates(oracle, luma_budget, chroma_bud
         f.range_max[c] = int((np.abs(planes[c]).astype(np.int64) * q).sum(axis=2).max())
     assert f.range_max[0] <= luma_budget and f.range_max[1] <= chroma_budget and f.range_max[2] <= chroma_budget
     assert f.range_max[0] == luma_budget and f.range_max[1] == chroma_budget, list(f.range_max)
-    assert (api.kernel_name(f) == KERNEL_12[sub]) == fused, (api.kernel_name(f), list(f.range_max))
+    assert (_k12(api.kernel_name(f)) == KERNEL_12[sub]) == fused, (api.kernel_name(f), list(f.range_max))
+    assert api.kernel_name(f).endswith("/narrow") == (fused and _narrow12_admits(luma_budget, chroma_budget)), (api.kernel_name(f), list(f.range_max))
     exp = oracle.reconstruct16(info, planes)
     coef = torch.from_numpy(np.concatenate([p.astype(np.int16).reshape(-1) for p in planes])).cuda()
     row = W * 6
@@ -1619,7 +1644,7 @@ def test_fused420_12bit_large_frame_properties(dec):
     """A 4K 12-bit frame: fused and unfused kernels agree band by band; an odd row stride takes the unaligned store path."""
     data = synth.to_12bit(synth.synth_jpeg(3840, 2160, 77, 85, "420", 8))
     f = dec.read(data)
-    assert api.kernel_name(f) == "fused420_kernel<12>", list(f.range_max)
+    assert _k12(api.kernel_name(f)) == "fused420_kernel<12>", list(f.range_max)
     a = dec.reconstruct()
     b = dec.reconstruct(api.FLAG_FORCE_GENERIC)
     assert [_sha(a[y:y + 135]) for y in range(0, 2160, 135)] == [_sha(b[y:y + 135]) for y in range(0, 2160, 135)]
