@@ -805,6 +805,9 @@ __device__ __forceinline__ const int *frame_deltas(const Args &a, int frame, int
 #ifndef F420P_PREFETCH
 #define F420P_PREFETCH 1
 #endif
+#ifndef F420_12_PREFETCH
+#define F420_12_PREFETCH 0 // the same for the 12-bit flavour of fused420_kernel (A-B builds)
+#endif
 #ifndef F420P_TEMPORAL
 #define F420P_TEMPORAL 0 // A-B builds: 1 = the pixel stores of aligned frames without the nt hint as well
 #endif
@@ -981,7 +984,7 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420_kernel(const Fuse
     });
   };
   // (8-bit frames only: the 12-bit flavour measured 30 % slower with it, profiles/r04/headline_variants.txt visit x)
-  constexpr bool PREFETCH = F420P_PREFETCH && P == 8;
+  constexpr bool PREFETCH = F420P_PREFETCH && (P == 8 || F420_12_PREFETCH);
   if (PREFETCH) f420_chroma_to_lds<FAST, QDEV, !QDEV && P == 8>(a, coef, cplane, stage, lane, wave, tx, ty, frame, luma_loads);
   else f420_chroma_to_lds<FAST, QDEV, !QDEV && P == 8>(a, coef, cplane, stage, lane, wave, tx, ty, frame);
   __syncthreads();
