@@ -2084,6 +2084,9 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused440_kernel(const Fuse
 // below 2^31 (|row output| <= 16 M_r 725 / 512 with M_r the row's share of the sum, 725 = largest entry of the scaled
 // transform matrix; the column pass sees 22.7 M in total), so wrapping 32-bit and 24-bit-operand arithmetic agree.
 // The level shift 2^11 << 7 passes through both rounding shifts exactly and comes out as 2^15 (see dequant_idct).
+#ifndef FXT_PREFETCH
+#define FXT_PREFETCH 0
+#endif
 constexpr int FXT_MINW = 2;
 __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(const Fused420Args a, const FusedXtExtra x)
 {
@@ -2101,30 +2104,35 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
   const int frame = tp.frame, ty = tp.ty, tx = tp.tx;
   const int16_t *__restrict__ coef = a.coef + (int64_t)frame * a.coef_frame_stride;
 
-  for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift; // the merge subtracts it anyway
-  f420_chroma_to_lds<true, false, true>(a, coef, cplane, stage, lane, wave, tx, ty); // (the legacy frame passed the 16384 range check: use_fusedxt)
-  __syncthreads();
-  f420_chroma_edges(a, cplane, tid, tx, ty);
-
   const int bx = lane & 15, by = wave * 4 + (lane >> 4);
   const int gbx0 = tx * F420_TILE_BLOCKS, gby0 = ty * F420_TILE_BLOCKS + wave * 4;
   const int X0 = (gbx0 + bx) * 8, Y0 = (ty * F420_TILE_BLOCKS + by) * 8;
   u32x4 rows[8];
   // the wave's 16 x 4 blocks of a plane of bw x bh blocks: local block n = (lane >> 3) + 8 m sits at column
   // (lane >> 3) + 8 (m & 1), row m >> 1; blocks outside the plane are redirected to a valid one and never used
-  auto fetch_plane = [&](const int16_t *__restrict__ plane, int bw, int bh) {
+  auto load_plane = [&](u32x4 (&raw)[8], const int16_t *__restrict__ plane, int bw, int bh) {
     const int x0 = gbx0 + (lane >> 3);
     const char *pbase = reinterpret_cast<const char *>(plane) + (lane & 7) * 16;
-    fetch_blocks(rows, stage, lane, [&](int m) -> const u32x4 * {
+    load_blocks(raw, [&](int m) -> const u32x4 * {
       const int xx = min(x0 + 8 * (m & 1), bw - 1), yy = min(gby0 + (m >> 1), bh - 1);
       return reinterpret_cast<const u32x4 *>(pbase + (unsigned)((yy * bw + xx) * 128));
     });
   };
+  // FXT_PREFETCH (A-B builds): a plane's blocks are requested while the plane before them is transformed (two waves per SIMD hide
+  // little of a fetch by themselves), the first residual plane's in front of phase A
+#if FXT_PREFETCH
+  u32x4 rawA[8], rawB[8];
+  load_plane(rawA, coef + x.off_r[0], x.bw_r, x.bh_r);
+#endif
+
+  for (int i = tid; i < 3 * 256; i += F420_THREADS) ltab[i] = x.ltable[i] - x.out_shift; // the merge subtracts it anyway
+  f420_chroma_to_lds<true, false, true>(a, coef, cplane, stage, lane, wave, tx, ty); // (the legacy frame passed the 16384 range check: use_fusedxt)
+  __syncthreads();
+  f420_chroma_edges(a, cplane, tid, tx, ty);
 
   // ------------------------------------------------------------------ residual blocks -> packed, clamped samples
   unsigned rp0[32], rp1[32], rp2[32];
-  auto residual_block = [&](int64_t off, const int *__restrict__ q, unsigned (&rp)[32]) {
-    fetch_plane(coef + off, x.bw_r, x.bh_r);
+  auto residual_rows = [&](const int *__restrict__ q, unsigned (&rp)[32]) {
     int v[64];
     dequant_idct_sparse(rows, q, v);
 #pragma unroll
@@ -2135,14 +2143,39 @@ __global__ __launch_bounds__(F420_THREADS, FXT_MINW) void fusedxt420_kernel(cons
       rp[i] = d;
     }
   };
-  residual_block(x.off_r[0], x.rq[0], rp0);
-  residual_block(x.off_r[1], x.rq[1], rp1);
-  residual_block(x.off_r[2], x.rq[2], rp2);
-
+  int yv[64];
+#if FXT_PREFETCH
+  load_plane(rawB, coef + x.off_r[1], x.bw_r, x.bh_r);
+  __builtin_amdgcn_sched_barrier(0);
+  transpose_blocks(rows, stage, lane, rawA);
+  residual_rows(x.rq[0], rp0);
+  load_plane(rawA, coef + x.off_r[2], x.bw_r, x.bh_r);
+  __builtin_amdgcn_sched_barrier(0);
+  transpose_blocks(rows, stage, lane, rawB);
+  residual_rows(x.rq[1], rp1);
+  load_plane(rawB, coef + a.off_y, a.bw_y, a.bh_y);
+  __builtin_amdgcn_sched_barrier(0);
+  transpose_blocks(rows, stage, lane, rawA);
+  residual_rows(x.rq[2], rp2);
+  // ------------------------------------------------------------------ legacy luma
+  transpose_blocks(rows, stage, lane, rawB);
+  dequant_idct_sparse<true, true>(rows, a.q[0], yv, 0, LUMA_FOLD_R2);
+#else
+  auto fetch_plane = [&](const int16_t *__restrict__ plane, int bw, int bh) {
+    u32x4 raw[8];
+    load_plane(raw, plane, bw, bh);
+    transpose_blocks(rows, stage, lane, raw);
+  };
+  fetch_plane(coef + x.off_r[0], x.bw_r, x.bh_r);
+  residual_rows(x.rq[0], rp0);
+  fetch_plane(coef + x.off_r[1], x.bw_r, x.bh_r);
+  residual_rows(x.rq[1], rp1);
+  fetch_plane(coef + x.off_r[2], x.bw_r, x.bh_r);
+  residual_rows(x.rq[2], rp2);
   // ------------------------------------------------------------------ legacy luma
   fetch_plane(coef + a.off_y, a.bw_y, a.bh_y);
-  int yv[64];
   dequant_idct_sparse<true, true>(rows, a.q[0], yv, 0, LUMA_FOLD_R2);
+#endif
 
   const bool active = X0 < a.width && Y0 < a.height;
   uint8_t *__restrict__ out_frame = a.out + (int64_t)frame * a.out_frame_stride;
