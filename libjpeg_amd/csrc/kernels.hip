@@ -163,6 +163,12 @@ __device__ __forceinline__ void store32_nt(uint8_t *__restrict__ base, unsigned 
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx4 %0, %3, %2 offset:16 nt\n\ts_nop 0" : : "v"(off), "v"(lo), "s"(base), "v"(hi) : "memory");
 }
 
+// 16 bytes at base + off, non-temporal (one asm statement with its wait state, as above)
+__device__ __forceinline__ void store16_nt(uint8_t *__restrict__ base, unsigned off, const u32x4 v)
+{
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+
 // The same 24 bytes when the line's address is NOT a multiple of four (m = address & 3: a packed frame whose width is not a
 // multiple of four pixels has such lines): gfx950 stores dwords at any address, but at a third more time per launch
 // (`profiles/r03/layouts.txt`, W = 7678).  The sixteen lanes of a row own 384 consecutive bytes; each lane takes the last m bytes
@@ -808,6 +814,13 @@ __device__ __forceinline__ const int *frame_deltas(const Args &a, int frame, int
 #ifndef F420_12_PREFETCH
 #define F420_12_PREFETCH 0 // the same for the 12-bit flavour of fused420_kernel (A-B builds)
 #endif
+// F420P_STAGED: whole waves of whole blocks send a line's pixels through the wave's (idle) fetch staging buffer -- sixteen 24-byte
+// pieces per block row in, 96 chunks of 16 contiguous bytes out -- so that every store instruction writes whole aligned runs of the
+// four 384-byte line segments instead of 16 and then 8 bytes of every lane's 24: tools/microbench/stream_ceiling --staged puts the
+// kernel's access pattern at 0.742 of 8 TB/s with such stores, 0.707 with the pieces (profiles/r06/staged_stores.txt).
+#ifndef F420P_STAGED
+#define F420P_STAGED 1 // (0: the 24-byte pieces everywhere, for A-B builds)
+#endif
 #ifndef F420P_TEMPORAL
 #define F420P_TEMPORAL 0 // A-B builds: 1 = the pixel stores of aligned frames without the nt hint as well
 #endif
@@ -1324,8 +1337,16 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
   // copy of the loop without the per-line exec masks (wave-uniform choice: one ballot)
   // (a third copy, FULL with every lane active, for frames whose lines do not all start on a dword: store24_nt_shifted)
   const unsigned base_lo = (unsigned)(uintptr_t)out_frame;
-  auto lines = [&](auto full_tag, auto shift_tag) {
-    constexpr bool FULL = decltype(full_tag)::value, SHIFTED = decltype(shift_tag)::value;
+  auto lines = [&](auto full_tag, auto shift_tag, auto staged_tag) {
+    constexpr bool FULL = decltype(full_tag)::value, SHIFTED = decltype(shift_tag)::value, STAGED = decltype(staged_tag)::value;
+    // STAGED: chunk c of the wave's 96 per line is bytes 16 (c % 24) .. of block row c / 24's segment; lanes 0..31 own a second one
+    unsigned so0 = 0, so1 = 0;
+    if (STAGED) {
+      const unsigned wave_off = (unsigned)((ty * F420_TILE_BLOCKS + wave * 4) * 8) * (unsigned)a.row_stride + (unsigned)(tx * F420_TILE_BLOCKS * 8) * 3u;
+      const unsigned c1 = 64u + (unsigned)lane;
+      so0 = wave_off + ((unsigned)lane / 24u) * 8u * (unsigned)a.row_stride + ((unsigned)lane % 24u) * 16u;
+      so1 = wave_off + (c1 / 24u) * 8u * (unsigned)a.row_stride + (c1 % 24u) * 16u;
+    }
     unsigned cT[6], cC[6], cB[6];
     load6(c_base, cT);
     load6(c_base + F420_CPITCH, cC);
@@ -1367,7 +1388,18 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
             rgb_shift17_sat_pack(rr, gg, bb, w);
             const unsigned off = out_off + (unsigned)l * (unsigned)a.row_stride;
             const int m = SHIFTED ? (int)__builtin_amdgcn_readfirstlane((base_lo + (unsigned)l * (unsigned)a.row_stride) & 3u) : 0;
-            if (SHIFTED && m) store24_nt_shifted(out_frame, off, w, bx, m);
+            if (STAGED) {
+              unsigned *sw = reinterpret_cast<unsigned *>(stage);
+              u32x2 *pw = reinterpret_cast<u32x2 *>(sw + lane * 6);
+              pw[0] = u32x2{w[0], w[1]}; pw[1] = u32x2{w[2], w[3]}; pw[2] = u32x2{w[4], w[5]};
+              __builtin_amdgcn_wave_barrier();
+              const u32x4 v0 = *reinterpret_cast<const u32x4 *>(sw + lane * 4);
+              const u32x4 v1 = *reinterpret_cast<const u32x4 *>(sw + ((lane & 31) + 64) * 4);
+              __builtin_amdgcn_wave_barrier();
+              store16_nt(out_frame, so0 + (unsigned)l * (unsigned)a.row_stride, v0);
+              if (lane < 32) store16_nt(out_frame, so1 + (unsigned)l * (unsigned)a.row_stride, v1);
+            }
+            else if (SHIFTED && m) store24_nt_shifted(out_frame, off, w, bx, m);
             else if (SHIFTED) store24_nt<false>(out_frame, off, w);
             else store24_nt<!F420P_TEMPORAL>(out_frame, off, w);
           } else {
@@ -1386,9 +1418,12 @@ __global__ __launch_bounds__(F420_THREADS, MINW) void fused420p_kernel(const Fus
     }
   };
   const bool whole = __builtin_amdgcn_ballot_w64(npx != 8 || nln != 8) == 0;
-  if (whole && ((base_lo | (unsigned)a.row_stride) & 3u) && __builtin_amdgcn_ballot_w64(true) == ~0ull) lines(std::true_type{}, std::true_type{});
-  else if (whole) lines(std::true_type{}, std::false_type{});
-  else lines(std::false_type{}, std::false_type{});
+  if (whole && ((base_lo | (unsigned)a.row_stride) & 3u) && __builtin_amdgcn_ballot_w64(true) == ~0ull) lines(std::true_type{}, std::true_type{}, std::false_type{});
+#if F420P_STAGED
+  else if (whole && __builtin_amdgcn_ballot_w64(true) == ~0ull) lines(std::true_type{}, std::false_type{}, std::true_type{});
+#endif
+  else if (whole) lines(std::true_type{}, std::false_type{}, std::false_type{});
+  else lines(std::false_type{}, std::false_type{}, std::false_type{});
 }
 
 // ==============================================================================================

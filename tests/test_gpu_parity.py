@@ -483,6 +483,31 @@ def test_unaligned_output_stride_whole_tiles(oracle):
             assert (res[:, line:] == 0xAB).all() and (flat[:base] == 0xAB).all() and (flat[base + h * row:] == 0xAB).all()
 
 
+def test_staged_stores_at_every_dword_aligned_address(oracle):
+    """Whole waves of whole blocks of the packed 4:2:0 kernel send their pixels through LDS and store 16 contiguous bytes per lane
+    (F420P_STAGED, round 6): lines at every dword-aligned address -- base + 0, 4, 8, 12, strides 0, 4, 8, 12 mod 16 -- where those
+    stores are not 16-byte aligned; widths with and without a partial last tile column; nothing outside the picture is written."""
+    torch = _torch()
+    for w, h in ((400, 300), (512, 272), (1024, 136)):
+        d = api.Decoder(0)
+        data = synth.synth_jpeg(w, h, 31 + w, 85, "420", 0)
+        f = d.read(data)
+        assert api.kernel_name(f) == "fused420p_kernel"
+        coef = torch.from_numpy(np.concatenate([d.coefficients(c).reshape(-1) for c in range(3)])).cuda()
+        d.close()
+        line = w * 3
+        exp = oracle.decode(data).reshape(h, line)
+        for row, base in ((line, 0), (line, 4), (line + 4, 8), (line + 8, 12), (line + 12, 0), (line + 16, 4), (line + 20, 12)):
+            buf = torch.full((h * row + 32,), 0xAB, dtype=torch.uint8, device="cuda")
+            assert buf.data_ptr() % 16 == 0
+            api.launch_reconstruct(f, coef.data_ptr(), buf.data_ptr() + base, 1, row, h * row, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            flat = buf.cpu().numpy()
+            res = flat[base:base + h * row].reshape(h, row)
+            assert np.array_equal(res[:, :line], exp), f"{w}x{h}: row stride {row}, base + {base}: {np.count_nonzero(res[:, :line] != exp)} bytes differ"
+            assert (res[:, line:] == 0xAB).all() and (flat[:base] == 0xAB).all() and (flat[base + h * row:] == 0xAB).all()
+
+
 @pytest.mark.parametrize("generic", [False, True])
 def test_adversarial_coefficients_safe_flavour(oracle, generic):
     """Coefficients no encoder would produce (|c| up to 32767, q up to 255): intermediates wrap around 2^32.

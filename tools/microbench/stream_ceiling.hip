@@ -135,6 +135,38 @@ __global__ __launch_bounds__(256, 4) void shape_kernel(const int16_t *__restrict
   }
   const int bx = tid % TBX, by = tid / TBX;
   const int X0 = (tx * TBX + bx) * 8, Y0 = (ty * TBY + by) * 8;
+  if (MODE == 3) {
+    // staged stores (TBX = 16): a wave's four block rows of sixteen 24-byte pieces are four 384-byte line segments per line number;
+    // they go through 1.5 KB of LDS and leave as 96 chunks of 16 contiguous bytes -- every store instruction writes whole
+    // 16-byte-aligned runs (lanes 0..23 the first segment, 24..47 the second, ...), none of them a piece of a lane's 24 bytes
+    static_assert(MODE != 3 || TBX == 16, "staged stores: sixteen blocks per row");
+    __shared__ __attribute__((aligned(16))) uint32_t stg[4][384];
+    uint32_t *sw = stg[wave];
+    const int c0 = lane, c1 = 64 + lane;
+    const int Yw = (ty * TBY + wave * 4) * 8, Xw = tx * TBX * 8;
+    uint8_t *wbase = out_all + frame * OUT_FRAME + (int64_t)Yw * (W * 3) + Xw * 3;
+    const unsigned o0 = (unsigned)(c0 / 24) * 8u * (W * 3) + (unsigned)(c0 % 24) * 16u, o1 = (unsigned)(c1 / 24) * 8u * (W * 3) + (unsigned)(c1 % 24) * 16u;
+    const bool ok0 = Yw + (c0 / 24) * 8 < H, ok1 = lane < 32 && Yw + (c1 / 24) * 8 < H;
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+      const u32x4 a = acc + (uint32_t)l;
+      const u32x2 b = {acc.x ^ (uint32_t)l, acc.w + (uint32_t)l};
+      u32x2 *pw = reinterpret_cast<u32x2 *>(sw + lane * 6);
+      pw[0] = u32x2{a.x, a.y}; pw[1] = u32x2{a.z, a.w}; pw[2] = b;
+      __builtin_amdgcn_wave_barrier();
+      const u32x4 v0 = *reinterpret_cast<const u32x4 *>(sw + c0 * 4);
+      const u32x4 v1 = *reinterpret_cast<const u32x4 *>(sw + (lane < 32 ? c1 : c0) * 4);
+      __builtin_amdgcn_wave_barrier();
+      if (NT) {
+        if (ok0) __builtin_nontemporal_store(v0, reinterpret_cast<u32x4 *>(wbase + o0 + (unsigned)l * (W * 3)));
+        if (ok1) __builtin_nontemporal_store(v1, reinterpret_cast<u32x4 *>(wbase + o1 + (unsigned)l * (W * 3)));
+      } else {
+        if (ok0) *reinterpret_cast<u32x4 *>(wbase + o0 + (unsigned)l * (W * 3)) = v0;
+        if (ok1) *reinterpret_cast<u32x4 *>(wbase + o1 + (unsigned)l * (W * 3)) = v1;
+      }
+    }
+    return;
+  }
   if (Y0 >= H) return;
   uint8_t *dst = out_all + frame * OUT_FRAME + (int64_t)Y0 * (W * 3) + X0 * 3;
   if (MODE == 1) {
@@ -196,6 +228,18 @@ int main(int argc, char **argv)
   const double gb = (double)(coef_bytes + out_bytes) * 1e-9;
   const int tiles = TX * TY * FRAMES;
   const int LDS = 40 * 1024; // dynamic LDS nobody touches: four workgroups per CU, the fused kernel's occupancy
+  if (argc > 1 && !strcmp(argv[1], "--staged")) { // the fused kernel's pattern against the same with LDS-staged, fully coalesced stores
+    const int order = TX, n = (tiles + 8 * order - 1) / (8 * order) * (8 * order);
+    for (int round = 0; round < 3; round++) {
+      const float p = time_ms([&] { hipLaunchKernelGGL((shape_kernel<16, 16, 0, true>), dim3(n), dim3(256), LDS, 0, coef, out, order); }, 100);
+      const float sn = time_ms([&] { hipLaunchKernelGGL((shape_kernel<16, 16, 3, true>), dim3(n), dim3(256), LDS - 6144, 0, coef, out, order); }, 100);
+      const float st = time_ms([&] { hipLaunchKernelGGL((shape_kernel<16, 16, 3, false>), dim3(n), dim3(256), LDS - 6144, 0, coef, out, order); }, 100);
+      const float pt = time_ms([&] { hipLaunchKernelGGL((shape_kernel<16, 16, 0, false>), dim3(n), dim3(256), LDS, 0, coef, out, order); }, 100);
+      printf("round %d: 24-byte pieces nt %.4f ms (%.3f of 8)  temporal %.4f (%.3f) | staged 16-byte chunks nt %.4f ms (%.3f)  temporal %.4f (%.3f)\n", round, p, gb / p / 8.0, pt,
+             gb / pt / 8.0, sn, gb / sn / 8.0, st, gb / st / 8.0);
+    }
+    return hipDeviceSynchronize() != hipSuccess;
+  }
   if (brief) {
     float copy_ms = 1e9f;
     for (int blocks : {32768, 131072, 388800}) {
