@@ -880,9 +880,10 @@ def main():
             t = json.loads(subprocess.run([mb, "--brief"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
             result["roofline"]["traffic_only"] = {
                 "pattern_ms_per_8_frames": t["pattern_ms"], "pattern_frac": t["pattern_frac"], "copy_ms_per_8_frames": t["copy_ms"], "copy_frac": t["copy_frac"],
-                "kernel_ms_per_8_frames": round(kernel_ms * 8 / F, 4),
+                "kernel_ms_per_8_frames": round(kernel_ms * 8 / F, 4), "pieces_frac": t.get("pieces_frac"),
                 "note": "tools/microbench/stream_ceiling --brief on the same GPU right after the timed steps: 'pattern' = the fused kernel's loads and stores (tile shape, "
-                        "tile order, halo re-reads, 24-byte non-temporal line pieces) with no arithmetic between them, 'copy' = the best of three grid sizes of a plain "
+                        "tile order, halo re-reads, a line's pixels through LDS and out as 16 contiguous non-temporal bytes per lane) with no arithmetic between them; "
+                        "'pieces' = the same with the 24-byte line pieces the kernel stored until the end of round 6; 'copy' = the best of three grid sizes of a plain "
                         "16-byte-per-lane copy of the same 3 + 3 bytes per pixel; fractions of the same 8 TB/s"}
         except Exception as e:  # noqa: BLE001
             result["roofline"]["traffic_only"] = {"error": repr(e)}

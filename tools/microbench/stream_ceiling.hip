@@ -248,10 +248,12 @@ int main(int argc, char **argv)
     }
     const int order = TX; // the fused kernels' tile order: runs of one tile row per XCD
     const int n = (tiles + 8 * order - 1) / (8 * order) * (8 * order);
-    const float pat_ms = time_ms([&] { hipLaunchKernelGGL((shape_kernel<16, 16, 0, true>), dim3(n), dim3(256), LDS, 0, coef, out, order); }, 100);
+    // (the kernel's stores since round 6's end: 16 contiguous bytes per lane through LDS, MODE 3; "pieces" = the 24-byte pieces before that)
+    const float pieces_ms = time_ms([&] { hipLaunchKernelGGL((shape_kernel<16, 16, 0, true>), dim3(n), dim3(256), LDS, 0, coef, out, order); }, 100);
+    const float pat_ms = time_ms([&] { hipLaunchKernelGGL((shape_kernel<16, 16, 3, true>), dim3(n), dim3(256), LDS - 6144, 0, coef, out, order); }, 100);
     if (hipDeviceSynchronize() != hipSuccess) { printf("{\"error\": \"device\"}\n"); return 1; }
-    printf("{\"frames\": %d, \"bytes_per_launch\": %lld, \"copy_ms\": %.4f, \"copy_frac\": %.4f, \"pattern_ms\": %.4f, \"pattern_frac\": %.4f}\n", FRAMES,
-           (long long)(coef_bytes + out_bytes), copy_ms, gb / copy_ms / 8.0, pat_ms, gb / pat_ms / 8.0);
+    printf("{\"frames\": %d, \"bytes_per_launch\": %lld, \"copy_ms\": %.4f, \"copy_frac\": %.4f, \"pattern_ms\": %.4f, \"pattern_frac\": %.4f, \"pieces_ms\": %.4f, \"pieces_frac\": %.4f}\n",
+           FRAMES, (long long)(coef_bytes + out_bytes), copy_ms, gb / copy_ms / 8.0, pat_ms, gb / pat_ms / 8.0, pieces_ms, gb / pieces_ms / 8.0);
     return 0;
   }
   printf("8 x 8K 4:2:0 frames: %.1f MB in + %.1f MB out per launch\n", coef_bytes * 1e-6, out_bytes * 1e-6);
