@@ -752,7 +752,8 @@ __device__ __forceinline__ int color_to_int(int x)
 __device__ __forceinline__ int tap13(int a, int b, int r) { return (int)((unsigned)a + 3u * (unsigned)b + (unsigned)r) >> 2; }
 
 // The colour stage of the 12-bit kernels, one pixel: (y * 8192 + cb' * Lb + cr' * Lr + 65536) >> 17 per channel (ycbcrtrafo.cpp:842-856,
-// :921-936; 64-bit sums in the reference), y = y' + 32768 * 16 / 16, samples times 16 without the level shift.
+// :921-936; 64-bit sums in the reference) with y = y' + 32768 (the level shift 2048, times 16) and cb' = cb - 32768: the transforms leave
+// the level shift out, so y', cb', cr' are what arrives here -- samples times 16.
 //   NARROW: the whole sum in 32 bits -- one multiply-add per product and one shift per channel.  Exact where
 //           (|y'| + 32776) * 8192 + 14516 |c| < 2^31; the host admits it by the range check (narrow12_colour, capi.cpp).  Partial
 //           sums of the green channel may wrap, the complete one does not.
@@ -817,7 +818,7 @@ __device__ __forceinline__ const int *frame_deltas(const Args &a, int frame, int
 // F420P_STAGED: whole waves of whole blocks send a line's pixels through the wave's (idle) fetch staging buffer -- sixteen 24-byte
 // pieces per block row in, 96 chunks of 16 contiguous bytes out -- so that every store instruction writes whole aligned runs of the
 // four 384-byte line segments instead of 16 and then 8 bytes of every lane's 24: tools/microbench/stream_ceiling --staged puts the
-// kernel's access pattern at 0.742 of 8 TB/s with such stores, 0.707 with the pieces (profiles/r06/staged_stores.txt).
+// kernel's access pattern at 0.74-0.755 of 8 TB/s with such stores, 0.71-0.72 with the pieces (profiles/r06/staged_stores.txt).
 #ifndef F420P_STAGED
 #define F420P_STAGED 1 // (0: the 24-byte pieces everywhere, for A-B builds)
 #endif
